@@ -1,0 +1,943 @@
+/* oracle.c -- TEST INFRASTRUCTURE ONLY.  Never linked into, imported by or
+ * called from the product path (raytracing_amd/); only tests/, bench.py's
+ * cpu_baseline leg and __graft_entry__.smoke() use it, as the checker.
+ *
+ * A plain-C, single-threaded restatement of the reference's wavefront path
+ * tracing loop, one function per reference kernel, each citing the file:line
+ * it follows (paths relative to /root/reference).  Arithmetic is restated
+ * operation for operation (evaluation order, fp32/fp64 mix, IEEE NaN paths);
+ * the OpenCL builtins are the project-normative definitions of
+ * oracle/ref_shim/cl_builtins.cpp + raytracing_amd/csrc/rt_detmath.h.
+ *
+ * PINNING: tests/test_ref_pin.py checks this file BIT FOR BIT, stage by stage
+ * and end to end, against oracle/_ref/libref.so = the reference's own
+ * unmodified .cl kernels compiled for x86-64 (the reference ships no golden
+ * vectors or tests of its own), and against the golden
+ * fixtures under tests/golden/ that were generated from that build.
+ *
+ * Queue order: appends are sequential in work-item order, which is exactly the
+ * order the single-threaded reference build produces with its atomic_add
+ * appends (hit_surface.cl:138,173), so intermediate buffers compare directly.
+ *
+ * Extra (not in the reference): traversal counters n_nodes / n_tris per ray
+ * class -- the "algorithmic bytes" inputs of SURVEY.md section 8(d).
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include "rt_types.h"
+#include "rt_detmath.h"
+
+typedef struct { float x, y, z; } v3;
+typedef struct { float x, y; } v2;
+
+/* ---- normative OpenCL builtins (cl_builtins.cpp) ------------------------ */
+static inline float f_min(float x, float y) { return y < x ? y : x; }
+static inline float f_max(float x, float y) { return x < y ? y : x; }
+static inline v3 V3(float x, float y, float z) { v3 r = {x, y, z}; return r; }
+static inline v3 v_add(v3 a, v3 b) { return V3(a.x + b.x, a.y + b.y, a.z + b.z); }
+static inline v3 v_sub(v3 a, v3 b) { return V3(a.x - b.x, a.y - b.y, a.z - b.z); }
+static inline v3 v_mul(v3 a, v3 b) { return V3(a.x * b.x, a.y * b.y, a.z * b.z); }
+static inline v3 v_scale(v3 a, float s) { return V3(a.x * s, a.y * s, a.z * s); }
+static inline v3 v_divs(v3 a, float s) { return V3(a.x / s, a.y / s, a.z / s); }
+static inline v3 v_neg(v3 a) { return V3(-a.x, -a.y, -a.z); }
+static inline float v_dot(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+static inline v3 v_cross(v3 a, v3 b)
+{
+    return V3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+static inline float v_length(v3 a) { return __builtin_sqrtf(a.x * a.x + a.y * a.y + a.z * a.z); }
+static inline v3 v_normalize(v3 a)
+{
+    float l = __builtin_sqrtf(a.x * a.x + a.y * a.y + a.z * a.z);
+    return V3(a.x / l, a.y / l, a.z / l);
+}
+static inline v3 v_mix(v3 x, v3 y, float a)
+{
+    return V3(x.x + (y.x - x.x) * a, x.y + (y.y - x.y) * a, x.z + (y.z - x.z) * a);
+}
+static inline v3 f3(rt_float3 a) { return V3(a.x, a.y, a.z); }
+static inline int i_clamp(int x, int lo, int hi) { int m = x < lo ? lo : x; return hi < m ? hi : m; }
+
+/* ---- state -------------------------------------------------------------- */
+typedef struct orc
+{
+    uint32_t width, height;
+    int furnace;
+    uint32_t max_bounces;
+    int request_reset;
+    rt_camera camera;
+    rt_scene_info scene_info;
+
+    rt_float4* radiance;
+    rt_ray* rays[2];
+    uint32_t* pixel_indices[2];
+    uint32_t ray_counter[2];
+    rt_ray* shadow_rays;
+    uint32_t* shadow_pixel_indices;
+    uint32_t shadow_ray_counter;
+    rt_hit* hits;
+    uint32_t* shadow_hits;
+    rt_float3* throughputs;
+    uint32_t sample_counter;
+    rt_float4* direct_light_samples;
+    rt_float4* resolved;
+
+    rt_triangle* triangles; uint32_t n_triangles;
+    rt_bvh_node* nodes; uint32_t n_nodes;
+    rt_packed_material* materials; uint32_t n_materials;
+    rt_texture* textures; uint32_t n_textures;
+    uint32_t* texture_data; uint32_t n_texture_data;
+    rt_light* lights; uint32_t n_lights;
+    float* env; uint32_t env_w, env_h;
+
+    /* statistics */
+    uint64_t total_closest, total_shadow;
+    uint64_t closest_nodes, closest_tris, shadow_nodes, shadow_tris;
+    uint64_t n_escaped, n_hits, n_emissive, n_texels, n_unoccluded, n_outgoing;
+    uint32_t last_active[64], last_shadow[64];
+} orc;
+
+/* ---- RNG / hashing ------------------------------------------------------ */
+/* utils.h:113-121 */
+static uint32_t WangHash(uint32_t x)
+{
+    x = (x ^ 61u) ^ (x >> 16);
+    x = x + (x << 3);
+    x = x ^ (x >> 4);
+    x = x * 0x27d4eb2du;
+    x = x ^ (x >> 15);
+    return x;
+}
+
+/* raygeneration.cl:28-38 */
+static float GetRandomFloat(uint32_t* seed)
+{
+    uint32_t s = *seed;
+    s = (s ^ 61u) ^ (s >> 16);
+    s = s + (s << 3);
+    s = s ^ (s >> 4);
+    s = s * 0x27d4eb2du;
+    s = s ^ (s >> 15);
+    s = 1103515245u * s + 12345u;
+    *seed = s;
+    return (float)s * 2.3283064365386963e-10f;
+}
+
+/* sampling.h:64-82 (kRandom branch) */
+static float SampleRandom(uint32_t px, uint32_t py, uint32_t sample_index, uint32_t bounce, uint32_t type)
+{
+    uint32_t dim = bounce * 5u + type;
+    uint32_t seed = WangHash(px);
+    seed = WangHash(seed + WangHash(py));
+    seed = WangHash(seed + WangHash(sample_index));
+    seed = WangHash(seed + WangHash(dim));
+    return (float)seed * 2.3283064365386963e-10f;
+}
+
+/* ---- RayGeneration, raygeneration.cl:65-139 ----------------------------- */
+static void RayGeneration(orc* o, uint32_t ray_idx)
+{
+    uint32_t width = o->width, height = o->height;
+    if (ray_idx >= width * height) return;
+    const rt_camera* cam = &o->camera;
+    uint32_t pixel_idx = ray_idx;
+    uint32_t pixel_x = pixel_idx % width;
+    uint32_t pixel_y = pixel_idx / width;
+    float inv_width = 1.0f / (float)width;
+    float inv_height = 1.0f / (float)height;
+    uint32_t sample_idx = o->sample_counter;
+    uint32_t seed = pixel_idx + (1103515245u * sample_idx + 12345u);      /* :61,98 */
+
+    float x = ((float)pixel_x + GetRandomFloat(&seed)) * inv_width;        /* :101 */
+    float y = ((float)pixel_y + GetRandomFloat(&seed)) * inv_height;       /* :102 */
+
+    float angle = rt_tanf(0.5f * cam->fov);                                /* :108 */
+    x = (x * 2.0f - 1.0f) * angle * cam->aspect_ratio;
+    y = (y * 2.0f - 1.0f) * angle;
+
+    v3 front = f3(cam->front), up = f3(cam->up), pos = f3(cam->position);
+    v3 right = v_cross(front, up);
+    v3 dir = v_normalize(v_add(v_add(v_scale(right, x), v_scale(up, y)), front));   /* :112 */
+
+    v3 point_aimed = v_add(pos, v_scale(dir, cam->focus_distance));       /* :115 */
+    /* PointInHexagon :40-49 */
+    static const float hx[4] = {-1.0f, 0.5f, 0.5f, 0.0f};
+    static const float hy[4] = {0.0f, 0.866f, -0.866f, 0.0f};
+    int hidx = (int)__builtin_floorf(GetRandomFloat(&seed) * 3.0f);
+    /* the reference indexes hexPoints[3] (out of bounds, UB) when the draw is
+       exactly 1.0f (p ~ 3e-8); this restatement defines that entry as (0,0) */
+    int h1 = hidx > 3 ? 3 : hidx;
+    int h2 = (hidx + 1) % 3;
+    float p1 = GetRandomFloat(&seed);
+    float p2 = GetRandomFloat(&seed);
+    float dofx = p1 * hx[h1] + p2 * hx[h2];
+    float dofy = p1 * hy[h1] + p2 * hy[h2];
+    float r = cam->aperture;
+    v3 new_pos = v_add(v_add(pos, v_scale(right, dofx * r)), v_scale(up, dofy * r));  /* :118 */
+
+    rt_ray ray;
+    ray.origin.x = new_pos.x; ray.origin.y = new_pos.y; ray.origin.z = new_pos.z; ray.origin.w = 0.0f;
+    v3 d = v_normalize(v_sub(point_aimed, new_pos));
+    ray.direction.x = d.x; ray.direction.y = d.y; ray.direction.z = d.z;
+    ray.direction.w = RT_MAX_RENDER_DIST;
+
+    o->rays[0][ray_idx] = ray;
+    o->pixel_indices[0][ray_idx] = pixel_idx;
+    o->throughputs[pixel_idx].x = 1.0f;
+    o->throughputs[pixel_idx].y = 1.0f;
+    o->throughputs[pixel_idx].z = 1.0f;
+    if (ray_idx == 0) o->ray_counter[0] = width * height;
+}
+
+/* ---- TraceBvh, trace_bvh.cl:28-211 -------------------------------------- */
+/* RayTriangle :28-73 */
+static int RayTriangle(v3 org, v3 dir, float t_min, float t_max, const rt_triangle* tri, float* bu, float* bv,
+    float* out_t)
+{
+    v3 p1 = f3(tri->v1.position), p2 = f3(tri->v2.position), p3 = f3(tri->v3.position);
+    v3 e1 = v_sub(p2, p1);
+    v3 e2 = v_sub(p3, p1);
+    v3 pvec = v_cross(dir, e2);
+    float det = v_dot(e1, pvec);
+    if (det < 1e-8f || -det > 1e-8f) return 0;
+    float inv_det = 1.0f / det;
+    v3 tvec = v_sub(org, p1);
+    float u = v_dot(tvec, pvec) * inv_det;
+    if (u < 0.0f || u > 1.0f) return 0;
+    v3 qvec = v_cross(tvec, e1);
+    float v = v_dot(dir, qvec) * inv_det;
+    if (v < 0.0f || u + v > 1.0f) return 0;
+    float t = v_dot(e2, qvec) * inv_det;
+    if (t < t_min || t > t_max) return 0;
+    *bu = u; *bv = v; *out_t = t;
+    return 1;
+}
+
+/* RayBounds :85-97 */
+static int RayBounds(const rt_bvh_node* n, v3 org, v3 inv, float t_min, float t_max)
+{
+    v3 t0 = v_mul(v_sub(f3(n->bounds_min), org), inv);
+    v3 t1 = v_mul(v_sub(f3(n->bounds_max), org), inv);
+    v3 lo = V3(f_min(t0.x, t1.x), f_min(t0.y, t1.y), f_min(t0.z, t1.z));
+    v3 hi = V3(f_max(t0.x, t1.x), f_max(t0.y, t1.y), f_max(t0.z, t1.z));
+    float tmin = f_max(f_max(f_max(lo.x, lo.y), lo.z), t_min);
+    float tmax = f_min(f_min(f_min(hi.x, hi.y), hi.z), t_max);
+    return tmax >= tmin;
+}
+
+/* kernel body :99-211; shadow != 0 is the -D SHADOW_RAYS variant */
+static void TraceOne(orc* o, const rt_ray* rays, uint32_t ray_idx, int shadow, rt_hit* hit_out, uint32_t* shadow_out)
+{
+    rt_ray ray = rays[ray_idx];
+    v3 org = V3(ray.origin.x, ray.origin.y, ray.origin.z);
+    v3 dir = V3(ray.direction.x, ray.direction.y, ray.direction.z);
+    float t_min = ray.origin.w;
+    float t_max = ray.direction.w;
+    v3 inv = V3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);               /* :125 */
+    int ray_sign[3];
+    ray_sign[0] = inv.x < 0; ray_sign[1] = inv.y < 0; ray_sign[2] = inv.z < 0;
+
+    uint32_t shadow_hit = RT_INVALID_ID;
+    rt_hit hit;
+    memset(&hit, 0, sizeof(hit));   /* reference leaves bc/t uninitialised on a miss */
+    hit.primitive_id = RT_INVALID_ID;
+
+    int toVisitOffset = 0, currentNodeIndex = 0;
+    int nodesToVisit[64];
+    uint64_t n_nodes = 0, n_tris = 0;
+
+    for (;;)
+    {
+        const rt_bvh_node* node = &o->nodes[currentNodeIndex];
+        ++n_nodes;
+        if (RayBounds(node, org, inv, t_min, t_max))
+        {
+            int num_primitives = (int)(node->num_primitives_axis >> 16);
+            if (num_primitives > 0)
+            {
+                for (int i = 0; i < num_primitives; ++i)
+                {
+                    ++n_tris;
+                    float u, v, t;
+                    if (RayTriangle(org, dir, t_min, t_max, &o->triangles[node->offset + i], &u, &v, &t))
+                    {
+                        hit.bc.x = u; hit.bc.y = v; hit.t = t;
+                        hit.primitive_id = node->offset + i;
+                        t_max = t;                                       /* :162 */
+                        if (shadow) { shadow_hit = 0; goto endtrace; }   /* :164-167 */
+                    }
+                }
+                if (toVisitOffset == 0) break;
+                currentNodeIndex = nodesToVisit[--toVisitOffset];
+            }
+            else
+            {
+                if (ray_sign[node->num_primitives_axis & 0xFFFF])        /* :181-190 */
+                {
+                    nodesToVisit[toVisitOffset++] = currentNodeIndex + 1;
+                    currentNodeIndex = (int)node->offset;
+                }
+                else
+                {
+                    nodesToVisit[toVisitOffset++] = (int)node->offset;
+                    currentNodeIndex = currentNodeIndex + 1;
+                }
+            }
+        }
+        else
+        {
+            if (toVisitOffset == 0) break;
+            currentNodeIndex = nodesToVisit[--toVisitOffset];
+        }
+    }
+endtrace:
+    if (shadow)
+    {
+        *shadow_out = shadow_hit;
+        o->shadow_nodes += n_nodes; o->shadow_tris += n_tris;
+    }
+    else
+    {
+        *hit_out = hit;
+        o->closest_nodes += n_nodes; o->closest_tris += n_tris;
+    }
+}
+
+/* ---- Miss, miss.cl:28-77 ------------------------------------------------ */
+/* read_imagef with CLK_NORMALIZED_COORDS_TRUE | CLK_ADDRESS_REPEAT |
+   CLK_FILTER_LINEAR (miss.cl:30): OpenCL 1.2 spec 8.2, evaluation order of
+   cl_builtins.cpp shim_read_imagef */
+static v3 ReadImageLinearRepeat(const orc* o, float cx, float cy)
+{
+    int w = (int)o->env_w, h = (int)o->env_h;
+    float u = (cx - __builtin_floorf(cx)) * (float)w;
+    float v = (cy - __builtin_floorf(cy)) * (float)h;
+    float fu = __builtin_floorf(u - 0.5f);
+    float fv = __builtin_floorf(v - 0.5f);
+    int i0 = (int)fu, j0 = (int)fv;
+    int i1 = i0 + 1, j1 = j0 + 1;
+    if (i0 < 0) i0 = w + i0;
+    if (i1 > w - 1) i1 = i1 - w;
+    if (j0 < 0) j0 = h + j0;
+    if (j1 > h - 1) j1 = j1 - h;
+    float a = (u - 0.5f) - fu;
+    float b = (v - 0.5f) - fv;
+    float wa0 = 1.0f - a, wb0 = 1.0f - b;
+    const float* t00 = o->env + 4 * ((size_t)j0 * w + i0);
+    const float* t10 = o->env + 4 * ((size_t)j0 * w + i1);
+    const float* t01 = o->env + 4 * ((size_t)j1 * w + i0);
+    const float* t11 = o->env + 4 * ((size_t)j1 * w + i1);
+    float w00 = wa0 * wb0, w10 = a * wb0, w01 = wa0 * b, w11 = a * b;
+    return V3(w00 * t00[0] + w10 * t10[0] + w01 * t01[0] + w11 * t11[0],
+              w00 * t00[1] + w10 * t10[1] + w01 * t01[1] + w11 * t11[1],
+              w00 * t00[2] + w10 * t10[2] + w01 * t01[2] + w11 * t11[2]);
+}
+
+/* SampleSky :28-39 */
+static v3 SampleSky(const orc* o, v3 dir)
+{
+    float cx = rt_atan2f(dir.x, dir.y) + RT_PI;
+    float cy = rt_acosf(dir.z);
+    cx = cx < 0.0f ? cx + RT_TWO_PI : cx;
+    cx *= RT_INV_TWO_PI;
+    cy *= RT_INV_PI;
+    return ReadImageLinearRepeat(o, cx, cy);
+}
+
+static void Miss(orc* o, uint32_t bounce, uint32_t ray_idx)
+{
+    uint32_t in = bounce & 1;
+    if (ray_idx >= o->ray_counter[in]) return;
+    rt_ray ray = o->rays[in][ray_idx];
+    rt_hit hit = o->hits[ray_idx];
+    if (hit.primitive_id == RT_INVALID_ID)
+    {
+        uint32_t pixel_idx = o->pixel_indices[in][ray_idx];
+        v3 thr = f3(o->throughputs[pixel_idx]);
+        v3 sky = o->furnace ? V3(0.5f, 0.5f, 0.5f)                        /* :70-71 */
+                            : SampleSky(o, V3(ray.direction.x, ray.direction.y, ray.direction.z));
+        v3 add = v_mul(sky, thr);
+        o->radiance[pixel_idx].x += add.x;
+        o->radiance[pixel_idx].y += add.y;
+        o->radiance[pixel_idx].z += add.z;
+        o->n_escaped++;
+    }
+}
+
+/* ---- material library --------------------------------------------------- */
+typedef struct
+{
+    v3 diffuse_albedo; float roughness;
+    v3 specular_albedo; float metalness;
+    v3 emission; float ior; float transparency;
+} Material;                                                               /* material.h:35-49 */
+
+/* utils.h:123-131, material.h:251-264 */
+static v3 SampleTexture(orc* o, rt_texture tex, v2 uv)
+{
+    uv.x -= __builtin_floorf(uv.x);
+    uv.y -= __builtin_floorf(uv.y);
+    uv.y = 1.f - uv.y;
+    int texel_x = i_clamp((int)(uv.x * (float)tex.width), 0, tex.width - 1);
+    int texel_y = i_clamp((int)(uv.y * (float)tex.height), 0, tex.height - 1);
+    int texel_addr = tex.data_start + texel_y * tex.width + texel_x;
+    uint32_t data = o->texture_data[texel_addr];
+    o->n_texels++;
+    float r = (float)(data & 0xFF) / 255.0f;
+    float g = (float)((data >> 8) & 0xFF) / 255.0f;
+    float b = (float)((data >> 16) & 0xFF) / 255.0f;
+    return V3(f_min(f_max(r, 0.0f), 1.0f), f_min(f_max(g, 0.0f), 1.0f), f_min(f_max(b, 0.0f), 1.0f));
+}
+
+static v3 pow3(v3 a, float e) { return V3(rt_powf(a.x, e), rt_powf(a.y, e), rt_powf(a.z, e)); }
+
+/* utils.h:133-147 */
+static v3 UnpackRGBTex(uint32_t data, uint32_t* idx)
+{
+    float r = (float)(data & 0xFF), g = (float)((data >> 8) & 0xFF), b = (float)((data >> 16) & 0xFF);
+    *idx = (data >> 24) & 0xFF;
+    return V3(r / 255.0f, g / 255.0f, b / 255.0f);
+}
+
+/* utils.h:149-158 */
+static v3 UnpackRGBE(uint32_t rgbe)
+{
+    int r = (int)((rgbe >> 0) & 0xFF), g = (int)((rgbe >> 8) & 0xFF), b = (int)((rgbe >> 16) & 0xFF);
+    int e = (int)(rgbe >> 24);
+    float f = rt_ldexpf(1.0f, e - (128 + 8));
+    return V3((float)r * f, (float)g * f, (float)b * f);
+}
+
+/* material.h:319-369 */
+static void ApplyTextures(orc* o, rt_packed_material in, Material* out, v2 uv)
+{
+    uint32_t idx;
+    out->diffuse_albedo = UnpackRGBTex(in.diffuse_albedo, &idx);
+    if (idx != RT_INVALID_TEXTURE_IDX) out->diffuse_albedo = pow3(SampleTexture(o, o->textures[idx], uv), 2.2f);
+    out->specular_albedo = UnpackRGBTex(in.specular_albedo, &idx);
+    if (idx != RT_INVALID_TEXTURE_IDX) out->specular_albedo = pow3(SampleTexture(o, o->textures[idx], uv), 2.2f);
+    out->emission = UnpackRGBE(in.emission);
+
+    uint32_t d = in.roughness_metalness;                                  /* utils.h:160-174 */
+    out->roughness = (float)((d >> 0) & 0xFF) / 255.0f;
+    uint32_t roughness_idx = (d >> 8) & 0xFF;
+    out->metalness = (float)((d >> 16) & 0xFF) / 255.0f;
+    uint32_t metalness_idx = (d >> 24) & 0xFF;
+    if (roughness_idx != RT_INVALID_TEXTURE_IDX) out->roughness = SampleTexture(o, o->textures[roughness_idx], uv).x;
+    if (metalness_idx != RT_INVALID_TEXTURE_IDX) out->metalness = SampleTexture(o, o->textures[metalness_idx], uv).x;
+
+    d = in.ior_emission_idx_transparency;                                 /* utils.h:176-190 */
+    out->ior = (float)((d >> 0) & 0xFF) / 25.5f;
+    uint32_t emission_idx = (d >> 8) & 0xFF;
+    out->transparency = (float)((d >> 16) & 0xFF) / 255.0f;
+    uint32_t transparency_idx = (d >> 24) & 0xFF;
+    if (emission_idx != RT_INVALID_TEXTURE_IDX)
+        out->emission = v_mul(out->emission, pow3(SampleTexture(o, o->textures[emission_idx], uv), 2.2f));
+    if (transparency_idx != RT_INVALID_TEXTURE_IDX)
+        out->transparency *= SampleTexture(o, o->textures[transparency_idx], uv).x;
+}
+
+/* bxdf.h:57-61 */
+static float IorToF0(float ior_incident, float ior_transmitted)
+{
+    float result = (ior_transmitted - ior_incident) / (ior_transmitted + ior_incident);
+    return result * result;
+}
+
+/* bxdf.h:71-74 */
+static v3 FresnelSchlick(v3 f0, float h_dot_o)
+{
+    float p = rt_powf(1.0f - h_dot_o, 5.0f);
+    return V3(f0.x + (1.0f - f0.x) * p, f0.y + (1.0f - f0.y) * p, f0.z + (1.0f - f0.z) * p);
+}
+
+/* bxdf.h:90-95 */
+static float GGX_D(float alpha, float n_dot_h)
+{
+    float alpha2 = alpha * alpha;
+    float denom = n_dot_h * n_dot_h * (alpha2 - 1.0f) + 1.0f;
+    return alpha2 * RT_INV_PI / (denom * denom);
+}
+
+/* bxdf.h:104-119 */
+static float V_SmithGGXCorrelated(float n_dot_i, float n_dot_o, float alphaG)
+{
+    float alphaG2 = alphaG * alphaG;
+    float Lambda_GGXV = n_dot_o * __builtin_sqrtf((-n_dot_i * alphaG2 + n_dot_i) * n_dot_i + alphaG2);
+    float Lambda_GGXL = n_dot_i * __builtin_sqrtf((-n_dot_o * alphaG2 + n_dot_o) * n_dot_o + alphaG2);
+    return 0.5f / (Lambda_GGXV + Lambda_GGXL);
+}
+
+static float Luma(v3 rgb) { return rgb.x * 0.299f + rgb.y * 0.587f + rgb.z * 0.114f; }   /* utils.h:108-111 */
+
+/* utils.h:99-106 */
+static v3 TangentToWorld(v3 dir, v3 n)
+{
+    v3 axis = __builtin_fabsf(n.x) > 0.001f ? V3(0.0f, 1.0f, 0.0f) : V3(1.0f, 0.0f, 0.0f);
+    v3 t = v_normalize(v_cross(axis, n));
+    v3 b = v_cross(n, t);
+    return v_normalize(v_add(v_add(v_scale(b, dir.x), v_scale(t, dir.y)), v_scale(n, dir.z)));
+}
+
+static v3 reflect(v3 v, v3 n) { return v_sub(v, v_scale(n, 2.0f * v_dot(v, n))); }      /* utils.h:83-86 */
+
+/* bxdf.h:157-168 */
+static v3 GGX_Sample(v2 s, v3 n, float alpha)
+{
+    float phi = RT_TWO_PI * s.x;
+    /* double-precision literals in the reference: 1.0 + (float)/(1.0 - s.y) -> fp64 sqrt, fp64 divide */
+    float cos_theta = (float)(1.0 / __builtin_sqrt(1.0 + (double)(alpha * alpha * s.y) / (1.0 - (double)s.y)));
+    float sin_theta = __builtin_sqrtf(f_max(0.0f, 1.0f - cos_theta * cos_theta));
+    v3 axis = __builtin_fabsf(n.x) > 0.001f ? V3(0.0f, 1.0f, 0.0f) : V3(1.0f, 0.0f, 0.0f);
+    v3 t = v_normalize(v_cross(axis, n));
+    v3 b = v_cross(n, t);
+    float cp = rt_cosf(phi), sp = rt_sinf(phi);
+    v3 r = v_add(v_add(v_scale(v_scale(b, cp), sin_theta), v_scale(v_scale(t, sp), sin_theta)), v_scale(n, cos_theta));
+    return v_normalize(r);
+}
+
+/* material.h:132-169 */
+static v3 EvaluateMaterial(const Material* m, v3 normal, v3 incoming, v3 outgoing)
+{
+    if ((double)m->transparency < 0.5) return V3(0.0f, 0.0f, 0.0f);
+    v3 half_vec = v_normalize(v_add(incoming, outgoing));
+    float n_dot_i = f_max(v_dot(normal, incoming), RT_EPS);
+    float n_dot_o = f_max(v_dot(normal, outgoing), RT_EPS);
+    float n_dot_h = f_max(v_dot(normal, half_vec), RT_EPS);
+    float h_dot_o = f_max(v_dot(half_vec, outgoing), RT_EPS);
+    float alpha = m->roughness * m->roughness;
+    float f0_dielectric = IorToF0(1.0f, m->ior);
+    v3 f0 = v_mix(V3(f0_dielectric, f0_dielectric, f0_dielectric), m->specular_albedo, m->metalness);
+    v3 diffuse_color = v_scale(m->diffuse_albedo, 1.0f - m->metalness);
+    v3 fresnel = FresnelSchlick(f0, h_dot_o);
+    float specular = GGX_D(alpha, n_dot_h) * V_SmithGGXCorrelated(n_dot_i, n_dot_o, alpha);   /* :119-125 */
+    v3 diffuse = v_scale(diffuse_color, RT_INV_PI);
+    return V3(fresnel.x * specular + (1.0f - fresnel.x) * diffuse.x,
+              fresnel.y * specular + (1.0f - fresnel.y) * diffuse.y,
+              fresnel.z * specular + (1.0f - fresnel.z) * diffuse.z);
+}
+
+/* material.h:171-241 (with SampleSpecular :66-103, SampleDiffuse :51-64, SampleTransparency :105-117) */
+static v3 SampleBxdf(const orc* o, float s1, v2 s, Material material, v3 normal, v3 incoming, v3* outgoing,
+    float* pdf, float* offset)
+{
+    if (o->furnace)
+    {
+        material.diffuse_albedo = V3(1.0f, 1.0f, 1.0f);
+        material.specular_albedo = V3(1.0f, 1.0f, 1.0f);
+    }
+    float alpha = material.roughness * material.roughness;
+    float f0_dielectric = IorToF0(1.0f, material.ior);
+    v3 f0 = v_mix(V3(f0_dielectric, f0_dielectric, f0_dielectric), material.specular_albedo, material.metalness);
+    v3 diffuse_albedo = v_scale(material.diffuse_albedo, 1.0f - material.metalness);
+    v3 specular_albedo = v_mix(material.specular_albedo, V3(1.0f, 1.0f, 1.0f), material.metalness);
+    v3 fresnel = v_mul(FresnelSchlick(f0, v_dot(normal, incoming)), specular_albedo);
+    float specular_weight = Luma(v_mul(specular_albedo, fresnel));
+    float diffuse_weight = Luma(v_mul(diffuse_albedo, V3(1.0f - fresnel.x, 1.0f - fresnel.y, 1.0f - fresnel.z)));
+    float weight_sum = diffuse_weight + specular_weight;
+    float specular_sampling_pdf = specular_weight / weight_sum;
+    float diffuse_sampling_pdf = diffuse_weight / weight_sum;
+
+    *offset = 1.0f;
+    if ((double)material.transparency < 0.5)
+    {
+        *pdf = 1.0f;
+        *outgoing = v_neg(incoming);
+        *offset = -1.0f;
+        return V3(1.0f, 1.0f, 1.0f);
+    }
+
+    v3 bxdf;
+    if (s1 <= specular_sampling_pdf)
+    {
+        float spec;
+        if (alpha <= 1e-4f)
+        {
+            *outgoing = reflect(v_neg(incoming), normal);
+            *pdf = 1.0f;
+            float n_dot_o = v_dot(*outgoing, normal);
+            spec = 1.0f / n_dot_o;
+        }
+        else
+        {
+            v3 wh = GGX_Sample(s, normal, alpha);
+            *outgoing = reflect(v_neg(incoming), wh);
+            float n_dot_o = v_dot(normal, *outgoing);
+            float n_dot_h = v_dot(normal, wh);
+            float n_dot_i = v_dot(normal, incoming);
+            float D = GGX_D(alpha, n_dot_h);
+            float G = V_SmithGGXCorrelated(n_dot_i, n_dot_o, alpha);
+            *pdf = D * n_dot_h / (4.0f * v_dot(wh, *outgoing));
+            spec = D * G;
+        }
+        float m = f_max(v_dot(*outgoing, normal), 0.0f);
+        bxdf = V3(fresnel.x * spec * m, fresnel.y * spec * m, fresnel.z * spec * m);
+        *pdf *= specular_sampling_pdf;
+    }
+    else
+    {
+        /* SampleHemisphereCosine bxdf.h:33-54 */
+        float phi = RT_TWO_PI * s.x;
+        float sin_theta = __builtin_sqrtf(s.y);
+        float cos_theta = __builtin_sqrtf(1.0f - s.y);
+        *pdf = cos_theta * RT_INV_PI;
+        v3 tbn = V3(rt_cosf(phi) * sin_theta, rt_sinf(phi) * sin_theta, cos_theta);
+        *outgoing = TangentToWorld(tbn, normal);
+        v3 d = v_scale(diffuse_albedo, RT_INV_PI);
+        float m = f_max(v_dot(*outgoing, normal), 0.0f);
+        bxdf = V3((1.0f - fresnel.x) * d.x * m, (1.0f - fresnel.y) * d.y * m, (1.0f - fresnel.z) * d.z * m);
+        *pdf *= diffuse_sampling_pdf;
+    }
+    return bxdf;
+}
+
+/* light.h:30-65 */
+static v3 Light_Sample(const orc* o, v3 position, float s, v3* outgoing, float* pdf)
+{
+    uint32_t count = o->scene_info.analytic_light_count;
+    int light_idx = i_clamp((int)(s * (float)count), 0, (int)count - 1);
+    rt_light light = o->lights[light_idx];
+    *pdf = 1.0f / (float)count;
+    v3 light_radiance = f3(light.radiance);
+    if (light.type == RT_LIGHT_TYPE_POINT)
+    {
+        v3 to_light = v_sub(f3(light.origin), position);
+        float sq_length = v_dot(to_light, to_light);
+        light_radiance = v_divs(light_radiance, sq_length);
+        *outgoing = to_light;
+    }
+    else
+    {
+        *outgoing = v_scale(f3(light.origin), RT_MAX_RENDER_DIST);
+    }
+    return light_radiance;
+}
+
+/* ---- HitSurface, hit_surface.cl:30-186 ---------------------------------- */
+static void HitSurface(orc* o, uint32_t bounce, uint32_t ray_idx)
+{
+    uint32_t in = bounce & 1, out = (bounce + 1) & 1;
+    if (ray_idx >= o->ray_counter[in]) return;
+    rt_hit hit = o->hits[ray_idx];
+    if (hit.primitive_id == RT_INVALID_ID) return;
+    o->n_hits++;
+
+    rt_ray incoming_ray = o->rays[in][ray_idx];
+    v3 incoming = V3(-incoming_ray.direction.x, -incoming_ray.direction.y, -incoming_ray.direction.z);
+    uint32_t pixel_idx = o->pixel_indices[in][ray_idx];
+    uint32_t sample_idx = o->sample_counter;
+    int x = (int)(pixel_idx % o->width);
+    int y = (int)(pixel_idx / o->width);
+
+    const rt_triangle* tri = &o->triangles[hit.primitive_id];
+    float bu = hit.bc.x, bv = hit.bc.y;
+    float w0 = 1.0f - bu - bv;
+    v3 p1 = f3(tri->v1.position), p2 = f3(tri->v2.position), p3 = f3(tri->v3.position);
+    v3 position = v_add(v_add(v_scale(p1, w0), v_scale(p2, bu)), v_scale(p3, bv));     /* utils.h:94-97 */
+    v3 geometry_normal = v_normalize(v_cross(v_sub(p2, p1), v_sub(p3, p1)));
+    v2 texcoord;
+    texcoord.x = tri->v1.texcoord.x * w0 + tri->v2.texcoord.x * bu + tri->v3.texcoord.x * bv;
+    texcoord.y = tri->v1.texcoord.y * w0 + tri->v2.texcoord.y * bu + tri->v3.texcoord.y * bv;
+    v3 normal = v_normalize(v_add(v_add(v_scale(f3(tri->v1.normal), w0), v_scale(f3(tri->v2.normal), bu)),
+        v_scale(f3(tri->v3.normal), bv)));
+
+    Material material;
+    ApplyTextures(o, o->materials[tri->mtl_index], &material, texcoord);
+    v3 hit_throughput = f3(o->throughputs[pixel_idx]);
+
+    if (!o->furnace)                                                      /* :107-112 */
+    {
+        if (material.emission.x * 1.0f + material.emission.y * 1.0f + material.emission.z * 1.0f > 0.0f)
+        {
+            v3 e = v_mul(hit_throughput, material.emission);
+            o->radiance[pixel_idx].x += e.x;
+            o->radiance[pixel_idx].y += e.y;
+            o->radiance[pixel_idx].z += e.z;
+            o->n_emissive++;
+        }
+    }
+
+    /* Direct lighting :115-145 */
+    {
+        float s_light = SampleRandom((uint32_t)x, (uint32_t)y, sample_idx, bounce, 4);
+        v3 outgoing;
+        float pdf;
+        v3 light_radiance = Light_Sample(o, position, s_light, &outgoing, &pdf);
+        float distance_to_light = v_length(outgoing);
+        outgoing = v_normalize(outgoing);
+        v3 brdf = EvaluateMaterial(&material, normal, incoming, outgoing);
+        float m = f_max(v_dot(outgoing, normal), 0.0f);
+        v3 ls = v_scale(v_divs(v_mul(v_mul(light_radiance, hit_throughput), brdf), pdf), m);
+        int spawn_shadow_ray = (pdf > 0.0f) && (v_dot(ls, ls) > 0.0f);
+        if (spawn_shadow_ray)
+        {
+            uint32_t idx = o->shadow_ray_counter++;
+            rt_ray sr;
+            v3 so = v_add(position, v_scale(normal, RT_EPS));
+            sr.origin.x = so.x; sr.origin.y = so.y; sr.origin.z = so.z; sr.origin.w = 0.0f;
+            sr.direction.x = outgoing.x; sr.direction.y = outgoing.y; sr.direction.z = outgoing.z;
+            sr.direction.w = distance_to_light;
+            o->shadow_rays[idx] = sr;
+            o->shadow_pixel_indices[idx] = pixel_idx;
+            o->direct_light_samples[idx].x = ls.x;
+            o->direct_light_samples[idx].y = ls.y;
+            o->direct_light_samples[idx].z = ls.z;
+        }
+    }
+
+    /* Indirect lighting :148-184 */
+    {
+        v2 s;
+        s.x = SampleRandom((uint32_t)x, (uint32_t)y, sample_idx, bounce, 2);
+        s.y = SampleRandom((uint32_t)x, (uint32_t)y, sample_idx, bounce, 3);
+        float s1 = SampleRandom((uint32_t)x, (uint32_t)y, sample_idx, bounce, 1);
+        float pdf = 0.0f;
+        v3 throughput = V3(0.0f, 0.0f, 0.0f);
+        v3 outgoing;
+        float offset;
+        v3 bxdf = SampleBxdf(o, s1, s, material, normal, incoming, &outgoing, &pdf, &offset);
+        if ((double)pdf > 0.0) throughput = v_divs(bxdf, pdf);
+        o->throughputs[pixel_idx].x *= throughput.x;
+        o->throughputs[pixel_idx].y *= throughput.y;
+        o->throughputs[pixel_idx].z *= throughput.z;
+        if ((double)pdf > 0.0)
+        {
+            uint32_t idx = o->ray_counter[out]++;
+            v3 oo = v_add(position, v_scale(v_scale(geometry_normal, RT_EPS), offset));
+            rt_ray r;
+            r.origin.x = oo.x; r.origin.y = oo.y; r.origin.z = oo.z; r.origin.w = 0.0f;
+            r.direction.x = outgoing.x; r.direction.y = outgoing.y; r.direction.z = outgoing.z;
+            r.direction.w = RT_MAX_RENDER_DIST;
+            o->rays[out][idx] = r;
+            o->pixel_indices[out][idx] = pixel_idx;
+            o->n_outgoing++;
+        }
+    }
+}
+
+/* ---- AccumulateDirectSamples, accumulate_direct_samples.cl:27-53 -------- */
+static void AccumulateDirectSamples(orc* o, uint32_t ray_idx)
+{
+    if (ray_idx >= o->shadow_ray_counter) return;
+    if (o->shadow_hits[ray_idx] == RT_INVALID_ID)
+    {
+        uint32_t pixel_idx = o->shadow_pixel_indices[ray_idx];
+        o->radiance[pixel_idx].x += o->direct_light_samples[ray_idx].x;
+        o->radiance[pixel_idx].y += o->direct_light_samples[ray_idx].y;
+        o->radiance[pixel_idx].z += o->direct_light_samples[ray_idx].z;
+        o->n_unoccluded++;
+    }
+}
+
+/* ---- host schedule ------------------------------------------------------ */
+#define ORC_EXPORT __attribute__((visibility("default")))
+
+ORC_EXPORT void* orc_create(uint32_t width, uint32_t height, int white_furnace)
+{
+    orc* o = (orc*)calloc(1, sizeof(orc));
+    size_t n = (size_t)width * height;
+    o->width = width; o->height = height; o->furnace = white_furnace;
+    o->max_bounces = 3;                                                   /* integrator.hpp:91 */
+    o->radiance = (rt_float4*)calloc(n, sizeof(rt_float4));
+    for (int i = 0; i < 2; ++i)
+    {
+        o->rays[i] = (rt_ray*)calloc(n, sizeof(rt_ray));
+        o->pixel_indices[i] = (uint32_t*)calloc(n, 4);
+    }
+    o->shadow_rays = (rt_ray*)calloc(n, sizeof(rt_ray));
+    o->shadow_pixel_indices = (uint32_t*)calloc(n, 4);
+    o->hits = (rt_hit*)calloc(n, sizeof(rt_hit));
+    o->shadow_hits = (uint32_t*)calloc(n, 4);
+    o->throughputs = (rt_float3*)calloc(n, sizeof(rt_float3));
+    o->direct_light_samples = (rt_float4*)calloc(n, sizeof(rt_float4));
+    o->resolved = (rt_float4*)calloc(n, sizeof(rt_float4));
+    return o;
+}
+
+ORC_EXPORT void orc_destroy(void* h)
+{
+    orc* o = (orc*)h;
+    free(o->radiance);
+    for (int i = 0; i < 2; ++i) { free(o->rays[i]); free(o->pixel_indices[i]); }
+    free(o->shadow_rays); free(o->shadow_pixel_indices); free(o->hits); free(o->shadow_hits);
+    free(o->throughputs); free(o->direct_light_samples); free(o->resolved);
+    free(o->triangles); free(o->nodes); free(o->materials); free(o->textures); free(o->texture_data);
+    free(o->lights); free(o->env);
+    free(o);
+}
+
+static void* dup_mem(const void* p, size_t bytes)
+{
+    void* q = malloc(bytes ? bytes : 1);
+    if (bytes) memcpy(q, p, bytes);
+    return q;
+}
+
+/* CLPathTraceIntegrator::UploadGPUData, cl_pt_integrator.cpp:373-456 */
+ORC_EXPORT void orc_upload(void* h, const rt_triangle* tris, uint32_t ntris, const rt_bvh_node* nodes, uint32_t nnodes,
+    const rt_packed_material* mats, uint32_t nmats, const rt_texture* tex, uint32_t ntex,
+    const uint32_t* texdata, uint32_t ntexdata, const rt_light* lights, uint32_t nlights,
+    const uint32_t* emissive, uint32_t nemissive, const float* env_rgba, uint32_t env_w, uint32_t env_h)
+{
+    orc* o = (orc*)h;
+    (void)emissive;   /* emissive_indices is bound but never read by the kernels (hit_surface.cl:39) */
+    o->triangles = (rt_triangle*)dup_mem(tris, (size_t)ntris * sizeof(rt_triangle)); o->n_triangles = ntris;
+    o->nodes = (rt_bvh_node*)dup_mem(nodes, (size_t)nnodes * sizeof(rt_bvh_node)); o->n_nodes = nnodes;
+    o->materials = (rt_packed_material*)dup_mem(mats, (size_t)nmats * sizeof(rt_packed_material)); o->n_materials = nmats;
+    o->textures = (rt_texture*)dup_mem(tex, (size_t)ntex * sizeof(rt_texture)); o->n_textures = ntex;
+    o->texture_data = (uint32_t*)dup_mem(texdata, (size_t)ntexdata * 4); o->n_texture_data = ntexdata;
+    o->lights = (rt_light*)dup_mem(lights, (size_t)nlights * sizeof(rt_light)); o->n_lights = nlights;
+    o->env = (float*)dup_mem(env_rgba, (size_t)env_w * env_h * 16); o->env_w = env_w; o->env_h = env_h;
+    o->scene_info.analytic_light_count = nlights;
+    o->scene_info.emissive_count = nemissive;
+}
+
+ORC_EXPORT void orc_set_camera(void* h, const rt_camera* cam) { ((orc*)h)->camera = *cam; }
+ORC_EXPORT void orc_set_max_bounces(void* h, uint32_t b) { ((orc*)h)->max_bounces = b; ((orc*)h)->request_reset = 1; }
+ORC_EXPORT void orc_request_reset(void* h) { ((orc*)h)->request_reset = 1; }
+
+/* stages == the protected virtuals of Integrator (integrator.hpp:65-79) */
+ORC_EXPORT void orc_stage_reset(void* h)                                  /* cl_pt_integrator.cpp:497-508 */
+{
+    orc* o = (orc*)h;
+    o->sample_counter = 0;
+    memset(o->radiance, 0, (size_t)o->width * o->height * sizeof(rt_float4));
+}
+ORC_EXPORT void orc_stage_generate_rays(void* h)
+{
+    orc* o = (orc*)h;
+    uint32_t n = o->width * o->height;
+    for (uint32_t i = 0; i < n; ++i) RayGeneration(o, i);
+}
+ORC_EXPORT void orc_stage_intersect(void* h, uint32_t bounce)
+{
+    orc* o = (orc*)h;
+    uint32_t in = bounce & 1, n = o->ray_counter[in];
+    for (uint32_t i = 0; i < n; ++i) TraceOne(o, o->rays[in], i, 0, &o->hits[i], NULL);
+}
+ORC_EXPORT void orc_stage_shade_miss(void* h, uint32_t bounce)
+{
+    orc* o = (orc*)h;
+    uint32_t n = o->width * o->height;
+    for (uint32_t i = 0; i < n; ++i) Miss(o, bounce, i);
+}
+ORC_EXPORT void orc_stage_clear_counters(void* h, uint32_t bounce)
+{
+    orc* o = (orc*)h;
+    o->ray_counter[(bounce + 1) & 1] = 0;
+    o->shadow_ray_counter = 0;
+}
+ORC_EXPORT void orc_stage_shade_hits(void* h, uint32_t bounce)
+{
+    orc* o = (orc*)h;
+    uint32_t n = o->width * o->height;
+    for (uint32_t i = 0; i < n; ++i) HitSurface(o, bounce, i);
+}
+ORC_EXPORT void orc_stage_intersect_shadow(void* h)
+{
+    orc* o = (orc*)h;
+    uint32_t n = o->shadow_ray_counter;
+    for (uint32_t i = 0; i < n; ++i) TraceOne(o, o->shadow_rays, i, 1, NULL, &o->shadow_hits[i]);
+}
+ORC_EXPORT void orc_stage_accumulate(void* h)
+{
+    orc* o = (orc*)h;
+    uint32_t n = o->width * o->height;
+    for (uint32_t i = 0; i < n; ++i) AccumulateDirectSamples(o, i);
+}
+ORC_EXPORT void orc_stage_advance(void* h) { ((orc*)h)->sample_counter++; }
+
+/* Integrator::Integrate(), integrator.cpp:27-59 */
+ORC_EXPORT void orc_integrate(void* h)
+{
+    orc* o = (orc*)h;
+    if (o->request_reset) { orc_stage_reset(h); o->request_reset = 0; }
+    orc_stage_generate_rays(h);
+    for (uint32_t bounce = 0; bounce <= o->max_bounces; ++bounce)
+    {
+        orc_stage_intersect(h, bounce);
+        orc_stage_shade_miss(h, bounce);
+        orc_stage_clear_counters(h, bounce);
+        orc_stage_shade_hits(h, bounce);
+        orc_stage_intersect_shadow(h);
+        orc_stage_accumulate(h);
+        uint32_t active = o->ray_counter[bounce & 1];
+        o->total_closest += active;
+        o->total_shadow += o->shadow_ray_counter;
+        if (bounce < 64) { o->last_active[bounce] = active; o->last_shadow[bounce] = o->shadow_ray_counter; }
+    }
+    orc_stage_advance(h);
+}
+
+/* ResolveRadiance, resolve_radiance.cl:76-85 (shaded colour, no denoiser) */
+ORC_EXPORT const float* orc_resolve(void* h)
+{
+    orc* o = (orc*)h;
+    size_t n = (size_t)o->width * o->height;
+    float spp = (float)o->sample_counter;
+    for (size_t i = 0; i < n; ++i)
+    {
+        float hx = o->radiance[i].x / spp, hy = o->radiance[i].y / spp, hz = o->radiance[i].z / spp;
+        o->resolved[i].x = hx / (hx + 1.0f);
+        o->resolved[i].y = hy / (hy + 1.0f);
+        o->resolved[i].z = hz / (hz + 1.0f);
+        o->resolved[i].w = 1.0f;
+    }
+    return (const float*)o->resolved;
+}
+
+ORC_EXPORT const float* orc_radiance(void* h) { return (const float*)((orc*)h)->radiance; }
+ORC_EXPORT uint32_t orc_sample_count(void* h) { return ((orc*)h)->sample_counter; }
+ORC_EXPORT void orc_ray_totals(void* h, uint64_t* closest, uint64_t* shadow)
+{
+    *closest = ((orc*)h)->total_closest; *shadow = ((orc*)h)->total_shadow;
+}
+ORC_EXPORT void orc_last_counts(void* h, uint32_t* active, uint32_t* shadow, uint32_t n)
+{
+    orc* o = (orc*)h;
+    for (uint32_t i = 0; i < n && i < 64; ++i) { active[i] = o->last_active[i]; shadow[i] = o->last_shadow[i]; }
+}
+/* stats[0..9] = closest_nodes, closest_tris, shadow_nodes, shadow_tris, escaped, hits, emissive, texels,
+   unoccluded, outgoing (cumulative since creation) */
+ORC_EXPORT void orc_stats(void* h, uint64_t* stats)
+{
+    orc* o = (orc*)h;
+    stats[0] = o->closest_nodes; stats[1] = o->closest_tris; stats[2] = o->shadow_nodes; stats[3] = o->shadow_tris;
+    stats[4] = o->n_escaped; stats[5] = o->n_hits; stats[6] = o->n_emissive; stats[7] = o->n_texels;
+    stats[8] = o->n_unoccluded; stats[9] = o->n_outgoing;
+}
+
+ORC_EXPORT void* orc_buffer(void* h, const char* name)
+{
+    orc* o = (orc*)h;
+    if (!strcmp(name, "rays0")) return o->rays[0];
+    if (!strcmp(name, "rays1")) return o->rays[1];
+    if (!strcmp(name, "pixel_indices0")) return o->pixel_indices[0];
+    if (!strcmp(name, "pixel_indices1")) return o->pixel_indices[1];
+    if (!strcmp(name, "ray_counter0")) return &o->ray_counter[0];
+    if (!strcmp(name, "ray_counter1")) return &o->ray_counter[1];
+    if (!strcmp(name, "shadow_rays")) return o->shadow_rays;
+    if (!strcmp(name, "shadow_pixel_indices")) return o->shadow_pixel_indices;
+    if (!strcmp(name, "shadow_ray_counter")) return &o->shadow_ray_counter;
+    if (!strcmp(name, "hits")) return o->hits;
+    if (!strcmp(name, "shadow_hits")) return o->shadow_hits;
+    if (!strcmp(name, "throughputs")) return o->throughputs;
+    if (!strcmp(name, "direct_light_samples")) return o->direct_light_samples;
+    if (!strcmp(name, "radiance")) return o->radiance;
+    if (!strcmp(name, "sample_counter")) return &o->sample_counter;
+    return NULL;
+}
+
+/* known-answer access to the leaf functions (tests/test_oracle_kat.py) */
+ORC_EXPORT uint32_t orc_wang_hash(uint32_t x) { return WangHash(x); }
+ORC_EXPORT float orc_sample_random(uint32_t x, uint32_t y, uint32_t s, uint32_t b, uint32_t t)
+{
+    return SampleRandom(x, y, s, b, t);
+}
+ORC_EXPORT float orc_tanf(float x) { return rt_tanf(x); }
+ORC_EXPORT float orc_sinf(float x) { return rt_sinf(x); }
+ORC_EXPORT float orc_cosf(float x) { return rt_cosf(x); }
+ORC_EXPORT float orc_powf(float x, float y) { return rt_powf(x, y); }
+ORC_EXPORT float orc_atan2f(float y, float x) { return rt_atan2f(y, x); }
+ORC_EXPORT float orc_acosf(float x) { return rt_acosf(x); }

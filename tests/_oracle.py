@@ -1,0 +1,122 @@
+"""ctypes binding of oracle/liboracle.so (oracle/oracle.c, the plain-C
+restatement).  TEST INFRASTRUCTURE: imported only by tests/, bench.py's
+cpu_baseline leg and __graft_entry__.smoke()."""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "oracle", "liboracle.so")
+_lib = None
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "oracle"])
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    src = os.path.join(ROOT, "oracle", "oracle.c")
+    if not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(src):
+        build()
+    lib = C.CDLL(LIB)
+    vp, u32, f32, cp = C.c_void_p, C.c_uint32, C.c_float, C.c_char_p
+    sig = {
+        "orc_create": (vp, [u32, u32, C.c_int]), "orc_destroy": (None, [vp]),
+        "orc_upload": (None, [vp, vp, u32, vp, u32, vp, u32, vp, u32, vp, u32, vp, u32, vp, u32, vp, u32, u32]),
+        "orc_set_camera": (None, [vp, vp]), "orc_set_max_bounces": (None, [vp, u32]),
+        "orc_request_reset": (None, [vp]), "orc_integrate": (None, [vp]),
+        "orc_resolve": (vp, [vp]), "orc_radiance": (vp, [vp]), "orc_sample_count": (u32, [vp]),
+        "orc_ray_totals": (None, [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+        "orc_last_counts": (None, [vp, vp, vp, u32]), "orc_buffer": (vp, [vp, cp]), "orc_stats": (None, [vp, vp]),
+        "orc_stage_reset": (None, [vp]), "orc_stage_generate_rays": (None, [vp]),
+        "orc_stage_intersect": (None, [vp, u32]), "orc_stage_shade_miss": (None, [vp, u32]),
+        "orc_stage_clear_counters": (None, [vp, u32]), "orc_stage_shade_hits": (None, [vp, u32]),
+        "orc_stage_intersect_shadow": (None, [vp]), "orc_stage_accumulate": (None, [vp]),
+        "orc_stage_advance": (None, [vp]),
+        "orc_wang_hash": (u32, [u32]), "orc_sample_random": (f32, [u32] * 5),
+        "orc_tanf": (f32, [f32]), "orc_sinf": (f32, [f32]), "orc_cosf": (f32, [f32]),
+        "orc_powf": (f32, [f32, f32]), "orc_atan2f": (f32, [f32, f32]), "orc_acosf": (f32, [f32]),
+    }
+    for k, (res, args) in sig.items():
+        f = getattr(lib, k)
+        f.restype, f.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def _arr(ptr, n, dtype):
+    if n == 0 or not ptr:
+        return np.zeros(0, dtype=dtype)
+    buf = (C.c_char * (n * np.dtype(dtype).itemsize)).from_address(ptr)
+    return np.frombuffer(buf, dtype=dtype, count=n).copy()
+
+
+STAT_NAMES = ("closest_nodes", "closest_tris", "shadow_nodes", "shadow_tris", "escaped", "hits", "emissive",
+              "texels", "unoccluded", "outgoing")
+
+
+class Oracle:
+    """Same surface as tests/_ref.RefIntegrator."""
+
+    def __init__(self, width, height, scene, furnace=False):
+        self.lib = load()
+        self.w, self.h = width, height
+        self.handle = self.lib.orc_create(width, height, int(furnace))
+        s = {k: np.ascontiguousarray(v) for k, v in scene.items()}
+        p = lambda a: a.ctypes.data if a.size else None
+        env = s["env"]
+        self.lib.orc_upload(self.handle, p(s["triangles"]), len(s["triangles"]), p(s["nodes"]), len(s["nodes"]),
+                            p(s["materials"]), len(s["materials"]), p(s["textures"]), len(s["textures"]),
+                            p(s["texture_data"]), len(s["texture_data"]), p(s["lights"]), len(s["lights"]),
+                            p(s["emissive"]), len(s["emissive"]), p(env), env.shape[1], env.shape[0])
+
+    def set_camera(self, cam):
+        self._cam = np.ascontiguousarray(cam)
+        self.lib.orc_set_camera(self.handle, self._cam.ctypes.data)
+
+    def set_max_bounces(self, b):
+        self.lib.orc_set_max_bounces(self.handle, b)
+
+    def integrate(self, n=1):
+        for _ in range(n):
+            self.lib.orc_integrate(self.handle)
+
+    def radiance(self):
+        return _arr(self.lib.orc_radiance(self.handle), self.w * self.h * 4, np.float32).reshape(self.h, self.w, 4)
+
+    def resolve(self):
+        return _arr(self.lib.orc_resolve(self.handle), self.w * self.h * 4, np.float32).reshape(self.h, self.w, 4)
+
+    def sample_count(self):
+        return self.lib.orc_sample_count(self.handle)
+
+    def ray_totals(self):
+        a, b = C.c_uint64(), C.c_uint64()
+        self.lib.orc_ray_totals(self.handle, C.byref(a), C.byref(b))
+        return a.value, b.value
+
+    def last_counts(self, n):
+        a = np.zeros(n, np.uint32); b = np.zeros(n, np.uint32)
+        self.lib.orc_last_counts(self.handle, a.ctypes.data, b.ctypes.data, n)
+        return a, b
+
+    def stats(self):
+        st = np.zeros(10, np.uint64)
+        self.lib.orc_stats(self.handle, st.ctypes.data)
+        return dict(zip(STAT_NAMES, (int(x) for x in st)))
+
+    def buffer(self, name, dtype, count):
+        return _arr(self.lib.orc_buffer(self.handle, name.encode()), count, dtype)
+
+    def stage(self, name, *args):
+        getattr(self.lib, "orc_stage_" + name)(self.handle, *args)
+
+    def __del__(self):
+        try:
+            self.lib.orc_destroy(self.handle)
+        except Exception:
+            pass

@@ -165,3 +165,10 @@ class RefIntegrator:
             self.lib.ref_destroy(self.handle)
         except Exception:
             pass
+
+
+def _stage(self, name, *args):
+    getattr(self.lib, "ref_stage_" + name)(self.handle, *args)
+
+
+RefIntegrator.stage = _stage
