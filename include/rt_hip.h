@@ -1,0 +1,167 @@
+/* rt_hip.h -- C-ABI of the MI355X (gfx950) wavefront path-tracing backend.
+ *
+ * This library is the drop-in replacement for the reference's OpenCL wrapper
+ * layer src/gpu_wrappers/cl_context.{hpp,cpp} (CLContext / CLKernel) together
+ * with the device half of src/integrator/cl_pt_integrator.{hpp,cpp} (the
+ * buffers it owns and the 11 kernels it launches).  A reference-side
+ * `HIPPathTraceIntegrator : Integrator` binds these entry points one to one
+ * (this repo ships that class in raytracing_amd/host/).
+ *
+ * Conventions: every function returns 0 on success, non-zero on failure; the
+ * message is available from rt_last_error() (replaces the thrown CLException,
+ * src/utils/cl_exception.hpp:109-123 -- the C++ host shim rethrows).  Plain
+ * pointers and sizes only; records are the PODs of rt_types.h.  One HIP stream
+ * per context with in-order semantics, like the reference's single in-order
+ * command queue (cl_context.cpp:89).  No call synchronises with the host
+ * except rt_finish, rt_buffer_read, rt_frame_read_* and rt_frame_get_stats.
+ */
+#ifndef RT_HIP_H
+#define RT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include "rt_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_OK 0
+#define RT_ERROR 1
+#define RT_MAX_BOUNCES_LIMIT 62u
+
+typedef struct rt_ctx rt_ctx;        /* CLContext, cl_context.hpp:37-65 */
+typedef struct rt_buffer rt_buffer;  /* cl::Buffer */
+typedef struct rt_frame rt_frame;    /* per-integrator device state, cl_pt_integrator.hpp:80-120 */
+
+/* ---- context: CLContext::CLContext / Finish (cl_context.cpp:47-94, hpp:49) */
+int rt_ctx_create(int device_ordinal, rt_ctx** out);
+int rt_ctx_destroy(rt_ctx* ctx);
+int rt_finish(rt_ctx* ctx);
+/* last error message of `ctx`, or of the calling thread when ctx == NULL */
+const char* rt_last_error(rt_ctx* ctx);
+/* device name / CU count (the device info dump of cl_context.cpp:70-83) */
+int rt_ctx_device_info(rt_ctx* ctx, char* name, size_t name_len, int* compute_units, size_t* hbm_bytes);
+/* the hipStream_t of this context (for interop with other HIP libraries) */
+void* rt_ctx_stream(rt_ctx* ctx);
+
+/* ---- buffers: cl::Buffer(ctx, flags, size, host_ptr) (cl_pt_integrator.cpp:178-186)
+ *      WriteBuffer / ReadBuffer / CopyBuffer (cl_context.cpp:96-113).
+ *      rt_buffer_read is BLOCKING (the reference's ReadBuffer is non-blocking
+ *      and never waited on, a latent race this ABI does not reproduce). */
+int rt_buffer_create(rt_ctx* ctx, size_t bytes, const void* init_or_null, rt_buffer** out);
+int rt_buffer_destroy(rt_buffer* buf);
+int rt_buffer_write(rt_buffer* buf, size_t offset, const void* src, size_t bytes);
+int rt_buffer_read(rt_buffer* buf, size_t offset, void* dst, size_t bytes);
+int rt_buffer_copy(rt_buffer* src, rt_buffer* dst, size_t src_offset, size_t dst_offset, size_t bytes);
+void* rt_buffer_device_ptr(rt_buffer* buf);
+size_t rt_buffer_size(rt_buffer* buf);
+
+/* ---- scene: CLPathTraceIntegrator::UploadGPUData (cl_pt_integrator.cpp:373-456)
+ * Host arrays in the reference's layouts; the device re-layout (child-pair BVH
+ * nodes, pre-differenced trace triangles, 128-byte shading records) happens
+ * behind this call.  Arrays are copied; the caller keeps ownership. */
+typedef struct rt_scene_desc
+{
+    const rt_triangle* triangles;         uint32_t num_triangles;   /* Scene::GetTriangles(), BVH order */
+    const rt_bvh_node* nodes;             uint32_t num_nodes;       /* AccelerationStructure::GetNodes() */
+    const rt_packed_material* materials;  uint32_t num_materials;
+    const rt_texture* textures;           uint32_t num_textures;
+    const uint32_t* texture_data;         uint32_t num_texture_data;
+    const rt_light* lights;               uint32_t num_lights;
+    const uint32_t* emissive_indices;     uint32_t num_emissive;    /* uploaded, unused (hit_surface.cl:39) */
+    const float* env_rgba;                uint32_t env_width, env_height;  /* Scene::GetEnvImage(), float RGBA */
+} rt_scene_desc;
+
+int rt_scene_upload(rt_ctx* ctx, const rt_scene_desc* scene);
+
+/* ---- frame: the per-pixel state CLPathTraceIntegrator allocates in its ctor
+ * (cl_pt_integrator.cpp:188-259).  A frame renders a TILE of the full image:
+ * the rows whose band index (row / band_height) is congruent to tile_rank
+ * modulo tile_count.  tile_count == 1 is the whole image.  Random numbers are
+ * keyed by GLOBAL pixel coordinates, so any tiling yields identical pixels. */
+typedef struct rt_frame_desc
+{
+    uint32_t width, height;      /* full image */
+    uint32_t tile_rank;          /* 0 .. tile_count-1 */
+    uint32_t tile_count;         /* >= 1 */
+    uint32_t band_height;        /* rows per interleaved band (>= 1) */
+} rt_frame_desc;
+
+int rt_frame_create(rt_ctx* ctx, const rt_frame_desc* desc, rt_frame** out);
+int rt_frame_destroy(rt_frame* frame);
+/* number of rows / pixels this tile owns, and the global row of local row r */
+uint32_t rt_frame_local_rows(rt_frame* frame);
+uint32_t rt_frame_global_row(rt_frame* frame, uint32_t local_row);
+
+/* ---- integrator state (Integrator public API, integrator.hpp:52-62) */
+enum rt_option
+{
+    RT_OPT_MAX_BOUNCES = 0,    /* Integrator::SetMaxBounces, default 3 (integrator.hpp:91) */
+    RT_OPT_WHITE_FURNACE = 1,  /* Integrator::EnableWhiteFurnace (-D ENABLE_WHITE_FURNACE) */
+    RT_OPT_SAMPLER = 2,        /* Integrator::SetSamplerType: 0 = kRandom (only one implemented) */
+    RT_OPT_AOV = 3,            /* Integrator::SetAOV: 0 = kShadedColor (only one implemented) */
+    RT_OPT_DENOISER = 4,       /* Integrator::EnableDenoiser: 0 (only value implemented) */
+    RT_OPT_TRACE_DROP_LAST_BOUNCE_RAYS = 5  /* 1 (default): do not emit the never-traced rays of the last bounce */
+};
+int rt_set_option(rt_frame* frame, int option, uint32_t value);
+int rt_set_camera(rt_frame* frame, const rt_camera* camera);       /* SetCameraData, cl_pt_integrator.cpp:365-371 */
+
+/* ---- stages: the protected virtuals Integrator::Integrate() schedules
+ * (integrator.hpp:65-79, integrator.cpp:27-59).  The HIP backend fuses
+ *   Miss + ClearCounter x2 + HitSurface          -> rt_shade
+ *   TraceBvh(SHADOW_RAYS) + AccumulateDirectSamples -> rt_intersect_shadow
+ * so rt_shade_miss / rt_clear_* / rt_accumulate_direct are accepted no-ops
+ * kept for schedule compatibility. */
+int rt_reset(rt_frame* frame);                          /* Reset */
+int rt_generate_rays(rt_frame* frame);                  /* GenerateRays */
+int rt_intersect(rt_frame* frame, uint32_t bounce);     /* IntersectRays */
+int rt_shade_miss(rt_frame* frame, uint32_t bounce);    /* ShadeMissedRays (fused into rt_shade) */
+int rt_clear_outgoing_counter(rt_frame* frame, uint32_t bounce);   /* ClearOutgoingRayCounter (no-op) */
+int rt_clear_shadow_counter(rt_frame* frame);           /* ClearShadowRayCounter (no-op) */
+int rt_shade(rt_frame* frame, uint32_t bounce);         /* ShadeSurfaceHits (+ miss) */
+int rt_intersect_shadow(rt_frame* frame, uint32_t bounce);  /* IntersectShadowRays (+ accumulate) */
+int rt_accumulate_direct(rt_frame* frame);              /* AccumulateDirectSamples (fused, no-op) */
+int rt_advance_sample(rt_frame* frame);                 /* AdvanceSampleCount */
+/* fast path: n_samples x Integrate() enqueued without returning to the caller */
+int rt_integrate(rt_frame* frame, uint32_t n_samples);
+
+/* ---- output.  ResolveRadiance (resolve_radiance.cl:31-86) headless: RGBA32F,
+ * local_rows x width, row-major.  rt_frame_read_radiance returns the running
+ * SUM over samples (radiance_buffer_), rt_frame_resolve the tonemapped image. */
+int rt_frame_resolve(rt_frame* frame, float* host_rgba);
+int rt_frame_read_radiance(rt_frame* frame, float* host_rgba);
+/* device pointer of the running-sum radiance (float4[local_rows*width]) for
+ * device-side gathers (RCCL) without a host bounce */
+void* rt_frame_radiance_device_ptr(rt_frame* frame);
+uint32_t rt_frame_sample_count(rt_frame* frame);
+
+/* ---- statistics: the queue counters the reference keeps in
+ * ray_counter_buffer_[2] / shadow_ray_counter_buffer_ (cl_pt_integrator.hpp:85-86),
+ * sampled per bounce and accumulated on the device. */
+typedef struct rt_stats
+{
+    uint64_t closest_rays;        /* sum over samples and bounces of rays traced closest-hit */
+    uint64_t shadow_rays;         /* ... of shadow rays traced */
+    uint64_t samples;             /* Integrate() calls since the last reset */
+    uint32_t last_active[64];     /* per-bounce counts of the most recent sample */
+    uint32_t last_shadow[64];
+} rt_stats;
+int rt_frame_get_stats(rt_frame* frame, rt_stats* out);
+
+/* ---- debug / parity access: copy a ray queue back in the reference's layouts.
+ * which: 0 = incoming queue of `bounce` (rays_buffer_[bounce&1]), 1 = shadow queue.
+ * Returns the element count through *count; arrays may be NULL. */
+int rt_frame_debug_read_queue(rt_frame* frame, int which, uint32_t bounce, rt_ray* rays, uint32_t* pixel_indices,
+    rt_float4* payload /* throughput (which=0) or direct light sample (which=1) */, uint32_t* count);
+int rt_frame_debug_read_hits(rt_frame* frame, rt_hit* hits, uint32_t count);
+
+/* ---- kernel self-test hooks (known-answer tests of the device math):
+ * evaluates fn over n inputs on the device.  fn: 0 sin, 1 cos, 2 tan, 3 pow(a,b),
+ * 4 atan2(a,b), 5 acos, 6 sqrt, 7 a/b, 8 SampleRandom(bits of a.. as uints) */
+int rt_debug_eval(rt_ctx* ctx, int fn, const float* a, const float* b, float* out, uint32_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_HIP_H */

@@ -1,0 +1,250 @@
+"""ctypes binding of the C-ABI in include/rt_hip.h (raytracing_amd/librt_hip.so).
+
+Python here is plumbing for tests and bench.py; the product is the shared
+library.  There is NO fallback: if the library is missing or no GPU is present
+the constructors raise."""
+import ctypes as C
+import os
+import numpy as np
+from . import types as T
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librt_hip.so")
+_lib = None
+
+
+class RtError(RuntimeError):
+    """Mirrors the reference's CLException (src/utils/cl_exception.hpp:109-123)."""
+
+
+class rt_stats(C.Structure):
+    _fields_ = [("closest_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("samples", C.c_uint64),
+                ("last_active", C.c_uint32 * 64), ("last_shadow", C.c_uint32 * 64)]
+
+
+class rt_scene_desc(C.Structure):
+    _fields_ = [("triangles", C.c_void_p), ("num_triangles", C.c_uint32),
+                ("nodes", C.c_void_p), ("num_nodes", C.c_uint32),
+                ("materials", C.c_void_p), ("num_materials", C.c_uint32),
+                ("textures", C.c_void_p), ("num_textures", C.c_uint32),
+                ("texture_data", C.c_void_p), ("num_texture_data", C.c_uint32),
+                ("lights", C.c_void_p), ("num_lights", C.c_uint32),
+                ("emissive_indices", C.c_void_p), ("num_emissive", C.c_uint32),
+                ("env_rgba", C.c_void_p), ("env_width", C.c_uint32), ("env_height", C.c_uint32)]
+
+
+class rt_frame_desc(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("tile_rank", C.c_uint32),
+                ("tile_count", C.c_uint32), ("band_height", C.c_uint32)]
+
+
+EXPORTS = [
+    "rt_ctx_create", "rt_ctx_destroy", "rt_finish", "rt_last_error", "rt_ctx_device_info", "rt_ctx_stream",
+    "rt_buffer_create", "rt_buffer_destroy", "rt_buffer_write", "rt_buffer_read", "rt_buffer_copy",
+    "rt_buffer_device_ptr", "rt_buffer_size", "rt_scene_upload", "rt_frame_create", "rt_frame_destroy",
+    "rt_frame_local_rows", "rt_frame_global_row", "rt_set_option", "rt_set_camera", "rt_reset",
+    "rt_generate_rays", "rt_intersect", "rt_shade_miss", "rt_clear_outgoing_counter", "rt_clear_shadow_counter",
+    "rt_shade", "rt_intersect_shadow", "rt_accumulate_direct", "rt_advance_sample", "rt_integrate",
+    "rt_frame_resolve", "rt_frame_read_radiance", "rt_frame_radiance_device_ptr", "rt_frame_sample_count",
+    "rt_frame_get_stats", "rt_frame_debug_read_queue", "rt_frame_debug_read_hits", "rt_debug_eval",
+]
+
+OPT_MAX_BOUNCES, OPT_WHITE_FURNACE, OPT_SAMPLER, OPT_AOV, OPT_DENOISER, OPT_DROP_LAST = range(6)
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RtError("librt_hip.so is not built (run `python -c 'import __graft_entry__ as g; g.build()'`)")
+    lib = C.CDLL(LIB_PATH)
+    vp, u32, i32, sz = C.c_void_p, C.c_uint32, C.c_int, C.c_size_t
+    sig = {
+        "rt_ctx_create": (i32, [i32, C.POINTER(vp)]), "rt_ctx_destroy": (i32, [vp]), "rt_finish": (i32, [vp]),
+        "rt_last_error": (C.c_char_p, [vp]),
+        "rt_ctx_device_info": (i32, [vp, C.c_char_p, sz, C.POINTER(i32), C.POINTER(sz)]),
+        "rt_ctx_stream": (vp, [vp]),
+        "rt_buffer_create": (i32, [vp, sz, vp, C.POINTER(vp)]), "rt_buffer_destroy": (i32, [vp]),
+        "rt_buffer_write": (i32, [vp, sz, vp, sz]), "rt_buffer_read": (i32, [vp, sz, vp, sz]),
+        "rt_buffer_copy": (i32, [vp, vp, sz, sz, sz]), "rt_buffer_device_ptr": (vp, [vp]),
+        "rt_buffer_size": (sz, [vp]),
+        "rt_scene_upload": (i32, [vp, C.POINTER(rt_scene_desc)]),
+        "rt_frame_create": (i32, [vp, C.POINTER(rt_frame_desc), C.POINTER(vp)]), "rt_frame_destroy": (i32, [vp]),
+        "rt_frame_local_rows": (u32, [vp]), "rt_frame_global_row": (u32, [vp, u32]),
+        "rt_set_option": (i32, [vp, i32, u32]), "rt_set_camera": (i32, [vp, vp]),
+        "rt_reset": (i32, [vp]), "rt_generate_rays": (i32, [vp]), "rt_intersect": (i32, [vp, u32]),
+        "rt_shade_miss": (i32, [vp, u32]), "rt_clear_outgoing_counter": (i32, [vp, u32]),
+        "rt_clear_shadow_counter": (i32, [vp]), "rt_shade": (i32, [vp, u32]),
+        "rt_intersect_shadow": (i32, [vp, u32]), "rt_accumulate_direct": (i32, [vp]),
+        "rt_advance_sample": (i32, [vp]), "rt_integrate": (i32, [vp, u32]),
+        "rt_frame_resolve": (i32, [vp, vp]), "rt_frame_read_radiance": (i32, [vp, vp]),
+        "rt_frame_radiance_device_ptr": (vp, [vp]), "rt_frame_sample_count": (u32, [vp]),
+        "rt_frame_get_stats": (i32, [vp, C.POINTER(rt_stats)]),
+        "rt_frame_debug_read_queue": (i32, [vp, i32, u32, vp, vp, vp, C.POINTER(u32)]),
+        "rt_frame_debug_read_hits": (i32, [vp, vp, u32]),
+        "rt_debug_eval": (i32, [vp, i32, vp, vp, vp, u32]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def _check(lib, ctx, rc):
+    if rc != 0:
+        msg = lib.rt_last_error(ctx)
+        raise RtError(msg.decode() if msg else "unknown error")
+
+
+class Context:
+    """CLContext replacement (src/gpu_wrappers/cl_context.hpp:37-65)."""
+
+    def __init__(self, device=0):
+        self.lib = load()
+        h = C.c_void_p()
+        _check(self.lib, None, self.lib.rt_ctx_create(device, C.byref(h)))
+        self.handle = h
+        self._scene_keep = None
+
+    def device_info(self):
+        name = C.create_string_buffer(256)
+        cu = C.c_int()
+        mem = C.c_size_t()
+        _check(self.lib, self.handle, self.lib.rt_ctx_device_info(self.handle, name, 256, C.byref(cu), C.byref(mem)))
+        return name.value.decode(), cu.value, mem.value
+
+    def stream(self):
+        return self.lib.rt_ctx_stream(self.handle)
+
+    def finish(self):
+        _check(self.lib, self.handle, self.lib.rt_finish(self.handle))
+
+    def upload_scene(self, scene):
+        """scene: dict with triangles (BVH order), nodes, materials, textures,
+        texture_data, lights, emissive, env (H x W x 4 float32)."""
+        s = {k: np.ascontiguousarray(v) for k, v in scene.items() if k != "scene_info"}
+        for key, dt in (("triangles", T.triangle), ("nodes", T.bvh_node), ("materials", T.packed_material),
+                        ("textures", T.texture), ("lights", T.light)):
+            if s[key].dtype != dt:
+                raise RtError("scene['%s'] has the wrong dtype" % key)
+        env = s["env"].astype(np.float32, copy=False)
+        p = lambda a: a.ctypes.data if a.size else None
+        d = rt_scene_desc(p(s["triangles"]), len(s["triangles"]), p(s["nodes"]), len(s["nodes"]),
+                          p(s["materials"]), len(s["materials"]), p(s["textures"]), len(s["textures"]),
+                          p(s["texture_data"]), len(s["texture_data"]), p(s["lights"]), len(s["lights"]),
+                          p(s["emissive"]), len(s["emissive"]), p(env), env.shape[1], env.shape[0])
+        _check(self.lib, self.handle, self.lib.rt_scene_upload(self.handle, C.byref(d)))
+
+    def debug_eval(self, fn, a, b=None):
+        a = np.ascontiguousarray(a, np.float32)
+        out = np.zeros_like(a)
+        bp = None
+        if b is not None:
+            b = np.ascontiguousarray(b, np.float32)
+            bp = b.ctypes.data
+        _check(self.lib, self.handle, self.lib.rt_debug_eval(self.handle, fn, a.ctypes.data, bp, out.ctypes.data,
+                                                             a.size))
+        return out
+
+    def close(self):
+        if self.handle:
+            self.lib.rt_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Frame:
+    """Device half of CLPathTraceIntegrator for one tile of the image."""
+
+    def __init__(self, ctx, width, height, tile_rank=0, tile_count=1, band_height=8):
+        self.ctx, self.lib = ctx, ctx.lib
+        self.width, self.height = width, height
+        d = rt_frame_desc(width, height, tile_rank, tile_count, band_height)
+        h = C.c_void_p()
+        _check(self.lib, ctx.handle, self.lib.rt_frame_create(ctx.handle, C.byref(d), C.byref(h)))
+        self.handle = h
+        self.local_rows = self.lib.rt_frame_local_rows(h)
+
+    def _c(self, rc):
+        _check(self.lib, self.ctx.handle, rc)
+
+    def global_rows(self):
+        return np.array([self.lib.rt_frame_global_row(self.handle, r) for r in range(self.local_rows)], np.int64)
+
+    def set_camera(self, cam):
+        cam = np.ascontiguousarray(cam)
+        self._c(self.lib.rt_set_camera(self.handle, cam.ctypes.data))
+
+    def set_option(self, opt, value):
+        self._c(self.lib.rt_set_option(self.handle, opt, value))
+
+    def set_max_bounces(self, b):
+        self.set_option(OPT_MAX_BOUNCES, b)
+
+    def reset(self):
+        self._c(self.lib.rt_reset(self.handle))
+
+    def integrate(self, n=1):
+        self._c(self.lib.rt_integrate(self.handle, n))
+
+    # stage API
+    def generate_rays(self): self._c(self.lib.rt_generate_rays(self.handle))
+    def intersect(self, b): self._c(self.lib.rt_intersect(self.handle, b))
+    def shade(self, b): self._c(self.lib.rt_shade(self.handle, b))
+    def intersect_shadow(self, b): self._c(self.lib.rt_intersect_shadow(self.handle, b))
+    def advance_sample(self): self._c(self.lib.rt_advance_sample(self.handle))
+
+    def radiance(self):
+        out = np.zeros((self.local_rows, self.width, 4), np.float32)
+        self._c(self.lib.rt_frame_read_radiance(self.handle, out.ctypes.data))
+        return out
+
+    def resolve(self):
+        out = np.zeros((self.local_rows, self.width, 4), np.float32)
+        self._c(self.lib.rt_frame_resolve(self.handle, out.ctypes.data))
+        return out
+
+    def radiance_device_ptr(self):
+        return self.lib.rt_frame_radiance_device_ptr(self.handle)
+
+    def sample_count(self):
+        return self.lib.rt_frame_sample_count(self.handle)
+
+    def stats(self):
+        st = rt_stats()
+        self._c(self.lib.rt_frame_get_stats(self.handle, C.byref(st)))
+        return st
+
+    def read_queue(self, which, bounce):
+        n_max = self.local_rows * self.width
+        rays = np.zeros(n_max, T.ray)
+        pix = np.zeros(n_max, np.uint32)
+        payload = np.zeros(n_max, T.float4)
+        cnt = C.c_uint32()
+        self._c(self.lib.rt_frame_debug_read_queue(self.handle, which, bounce, rays.ctypes.data, pix.ctypes.data,
+                                                   payload.ctypes.data, C.byref(cnt)))
+        n = cnt.value
+        return rays[:n], pix[:n], payload[:n]
+
+    def read_hits(self, count):
+        hits = np.zeros(count, T.hit)
+        self._c(self.lib.rt_frame_debug_read_hits(self.handle, hits.ctypes.data, count))
+        return hits
+
+    def close(self):
+        if self.handle:
+            self.lib.rt_frame_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

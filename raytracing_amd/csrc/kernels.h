@@ -1,0 +1,795 @@
+// kernels.h -- the wavefront path-tracing kernels, hand-written for gfx950.
+//
+// Reference kernels replaced (src/kernels/cl/):
+//   raygeneration.cl:65-139                        -> k_raygen
+//   trace_bvh.cl:99-211                            -> k_trace<false>
+//   trace_bvh.cl (-D SHADOW_RAYS) + accumulate_direct_samples.cl:27-53
+//                                                  -> k_trace<true>
+//   miss.cl:41-77 + hit_surface.cl:30-186 + clear_counter.cl (x2)
+//                                                  -> k_shade
+//   resolve_radiance.cl:31-86                      -> k_resolve
+//   reset_radiance.cl / increment_counter.cl       -> hipMemsetAsync / host scalar
+//
+// Device data layout (HBM), chosen for coalesced 16-byte accesses:
+//   ray queues   SoA: o4[i] = (origin.xyz, t_max), d4[i] = (dir.xyz, pixel bits),
+//                thr[i] = (throughput.xyz, -) ; shadow queue adds ls[i] = light sample
+//   BVH          one 64-byte "child-pair" record per INTERIOR node of the
+//                reference BVH2: both children's boxes + refs in one line, so
+//                one dependent fetch serves two box tests (the reference needs
+//                one 48-byte fetch per box).  Topology, near/far rule and
+//                cull decisions are exactly the reference's (see k_trace).
+//   trace tris   48 B: (p1, last-in-leaf flag), e1 = p2-p1, e2 = p3-p1
+//   shade tris   128 B, line aligned: p1..p3, n1..n3, uv1..uv3, material
+#pragma once
+#include "device_math.h"
+#include "rt_types.h"
+
+#define RT_LEAF_BIT 0x80000000u
+#define RT_EMPTY_REF 0xFFFFFFFFu
+#define RT_TRACE_STACK_LDS 24     // per-lane stack entries kept in LDS
+#define RT_TRACE_STACK_MAX 64     // the reference's nodesToVisit[64] (trace_bvh.cl:142)
+
+struct DScene
+{
+    const float4* nodes;          // 4 x float4 per interior node
+    const float4* tris_rt;        // 3 x float4 per triangle
+    const float4* tris_sh;        // 8 x float4 per triangle
+    const rt_packed_material* materials;
+    const rt_texture* textures;
+    const uint32_t* texture_data;
+    const float4* lights;         // 3 x float4 per light: origin, radiance, (type bits,0,0,0)
+    const float4* env;
+    int env_w, env_h;
+    uint32_t light_count;
+    uint32_t root_ref;            // RT_LEAF_BIT | first triangle, or interior node 0
+    float root_min[3];
+    float root_max[3];
+};
+
+struct DTile                      // which pixels of the full image this frame owns
+{
+    uint32_t width, height;       // full image
+    uint32_t band_h, rank, nranks;
+    uint32_t local_rows;
+};
+
+RT_DEV uint32_t tile_global_row(const DTile& t, uint32_t ly)
+{
+    uint32_t band = ly / t.band_h;
+    return (band * t.nranks + t.rank) * t.band_h + (ly - band * t.band_h);
+}
+
+struct DCounters                  // one per frame, device memory
+{
+    uint32_t queue[64];           // queue[b]  = rays in the incoming queue of bounce b
+    uint32_t shadow[64];          // shadow[b] = shadow rays emitted at bounce b
+    unsigned long long total_closest, total_shadow, samples;
+    uint32_t last_queue[64], last_shadow[64];
+};
+
+// ---------------------------------------------------------------------------
+// sample begin + ray generation (raygeneration.cl:65-139)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_raygen(DTile tile, rt_camera cam, uint32_t sample_idx, float tan_half_fov,
+    uint32_t prev_bounces, float4* __restrict__ o4, float4* __restrict__ d4, float4* __restrict__ thr,
+    DCounters* __restrict__ counters)
+{
+    uint32_t n_local = tile.local_rows * tile.width;
+    uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i == 0)
+    {
+        // fold the previous sample's per-bounce counters into the totals, then
+        // clear them (replaces the ClearCounter launches, cl_pt_integrator.cpp:651-663)
+        unsigned long long c = 0, s = 0;
+        for (uint32_t b = 0; b <= prev_bounces && b < 64; ++b)
+        {
+            c += counters->queue[b];
+            s += counters->shadow[b];
+            counters->last_queue[b] = counters->queue[b];
+            counters->last_shadow[b] = counters->shadow[b];
+        }
+        counters->total_closest += c;
+        counters->total_shadow += s;
+        for (uint32_t b = 0; b < 64; ++b) { counters->queue[b] = 0; counters->shadow[b] = 0; }
+        counters->queue[0] = n_local;                                    // raygeneration.cl:135-138
+    }
+    if (i >= n_local) return;
+
+    uint32_t ly = i / tile.width;
+    uint32_t pixel_x = i - ly * tile.width;
+    uint32_t pixel_y = tile_global_row(tile, ly);
+    uint32_t pixel_idx = pixel_y * tile.width + pixel_x;                 // GLOBAL pixel index
+
+    float inv_width = 1.0f / (float)tile.width;
+    float inv_height = 1.0f / (float)tile.height;
+    uint32_t seed = pixel_idx + (1103515245u * sample_idx + 12345u);     // :61,98
+
+    float x = ((float)pixel_x + GetRandomFloat(seed)) * inv_width;
+    float y = ((float)pixel_y + GetRandomFloat(seed)) * inv_height;
+
+    float angle = tan_half_fov;                                          // rt_tanf(0.5f * fov), host-evaluated
+    x = (x * 2.0f - 1.0f) * angle * cam.aspect_ratio;
+    y = (y * 2.0f - 1.0f) * angle;
+
+    f3 front = F3(cam.front.x, cam.front.y, cam.front.z);
+    f3 up = F3(cam.up.x, cam.up.y, cam.up.z);
+    f3 pos = F3(cam.position.x, cam.position.y, cam.position.z);
+    f3 right = cross3(front, up);
+    f3 dir = normalize3(right * x + up * y + front);
+
+    f3 point_aimed = pos + dir * cam.focus_distance;
+    // PointInHexagon :40-49 (index 3 = the reference's out-of-bounds read, defined as (0,0))
+    int hidx = (int)__builtin_floorf(GetRandomFloat(seed) * 3.0f);
+    int h1 = hidx > 3 ? 3 : hidx;
+    int h2 = (hidx + 1) % 3;
+    float hx1 = h1 == 0 ? -1.0f : (h1 == 3 ? 0.0f : 0.5f);
+    float hy1 = h1 == 1 ? 0.866f : (h1 == 2 ? -0.866f : 0.0f);
+    float hx2 = h2 == 0 ? -1.0f : 0.5f;
+    float hy2 = h2 == 1 ? 0.866f : (h2 == 2 ? -0.866f : 0.0f);
+    float p1 = GetRandomFloat(seed);
+    float p2 = GetRandomFloat(seed);
+    float dofx = p1 * hx1 + p2 * hx2;
+    float dofy = p1 * hy1 + p2 * hy2;
+    float r = cam.aperture;
+    f3 new_pos = pos + right * (dofx * r) + up * (dofy * r);
+    f3 d = normalize3(point_aimed - new_pos);
+
+    o4[i] = make_float4(new_pos.x, new_pos.y, new_pos.z, RT_MAX_RENDER_DIST);
+    d4[i] = make_float4(d.x, d.y, d.z, __uint_as_float(i));              // LOCAL pixel slot
+    thr[i] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+}
+
+// ---------------------------------------------------------------------------
+// BVH traversal (trace_bvh.cl:28-211)
+// ---------------------------------------------------------------------------
+// Exactness argument (DESIGN.md "traversal equivalence"): the reference pops a
+// node, box-tests it against the CURRENT t_max, and descends near-first.  Here
+// both children are box-tested when their parent is visited; the near child
+// is visited next with the same t_max the reference would use; the far child is
+// pushed with its entry distance A = max(max3(min(t0,t1)), t_min) and re-tested
+// at pop time by `t_max >= A`, which (for the box test's min/max select forms
+// and a non-increasing t_max) is equivalent to re-running the full box test.
+// Leaves are visited in the reference's order and triangles are tested in
+// array order with the same accept rule, so the closest hit (including ties,
+// "later triangle replaces", trace_bvh.cl:157-162) is identical.
+
+RT_DEV bool box_test(float bminx, float bminy, float bminz, float bmaxx, float bmaxy, float bmaxz, f3 org, f3 inv,
+    float t_min, float t_max, float& entry)
+{
+    // RayBounds, trace_bvh.cl:85-97
+    float t0x = (bminx - org.x) * inv.x, t0y = (bminy - org.y) * inv.y, t0z = (bminz - org.z) * inv.z;
+    float t1x = (bmaxx - org.x) * inv.x, t1y = (bmaxy - org.y) * inv.y, t1z = (bmaxz - org.z) * inv.z;
+    float lox = cl_min(t0x, t1x), loy = cl_min(t0y, t1y), loz = cl_min(t0z, t1z);
+    float hix = cl_max(t0x, t1x), hiy = cl_max(t0y, t1y), hiz = cl_max(t0z, t1z);
+    float tmin = cl_max(cl_max(cl_max(lox, loy), loz), t_min);
+    float tmax = cl_min(cl_min(cl_min(hix, hiy), hiz), t_max);
+    entry = tmin;
+    return tmax >= tmin;
+}
+
+template <bool SHADOW>
+__global__ __launch_bounds__(64) void k_trace(DScene sc, const float4* __restrict__ o4, const float4* __restrict__ d4,
+    const uint32_t* __restrict__ count_ptr, float4* __restrict__ hits, const float4* __restrict__ ls,
+    float4* __restrict__ radiance, uint2* __restrict__ spill)
+{
+    __shared__ uint2 stack[RT_TRACE_STACK_LDS][64];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t count = *count_ptr;
+    const uint32_t nchunks = (count + 63u) >> 6;
+    // XCD-aware persistent schedule: block b runs on XCD b % 8 (observed
+    // dispatch order); give each XCD one contiguous eighth of the queue so
+    // that its private L2 sees one screen/queue region.
+    const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
+    const uint32_t cpx = (nchunks + 7u) >> 3;
+    uint2* my_spill = spill + (size_t)(blockIdx.x * 64u + lane) * (RT_TRACE_STACK_MAX - RT_TRACE_STACK_LDS);
+
+    for (uint32_t c = slot; c < cpx; c += per_xcd)
+    {
+        uint32_t chunk = xcd * cpx + c;
+        uint32_t i = chunk * 64u + lane;
+        if (i >= count) continue;
+
+        float4 ro = o4[i], rd = d4[i];
+        f3 org = F3(ro.x, ro.y, ro.z), dir = F3(rd.x, rd.y, rd.z);
+        const float t_min = 0.0f;                                        // origin.w is 0 for every ray the path emits
+        float t_max = ro.w;
+        f3 inv = F3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);           // trace_bvh.cl:125
+        uint32_t sign_bits = (inv.x < 0.0f ? 1u : 0u) | (inv.y < 0.0f ? 2u : 0u) | (inv.z < 0.0f ? 4u : 0u);
+
+        uint32_t hit_prim = RT_INVALID_ID;
+        float hit_u = 0.0f, hit_v = 0.0f, hit_t = 0.0f;
+        bool occluded = false;
+
+        int sp = 0;
+        uint32_t ref = sc.root_ref;
+        float entry;
+        bool alive = box_test(sc.root_min[0], sc.root_min[1], sc.root_min[2], sc.root_max[0], sc.root_max[1],
+            sc.root_max[2], org, inv, t_min, t_max, entry);
+
+        while (alive)
+        {
+            bool need_pop;
+            if (ref & RT_LEAF_BIT)
+            {
+                // leaf: test its triangles in array order (trace_bvh.cl:155-169)
+                uint32_t prim = ref & ~RT_LEAF_BIT;
+                bool last;
+                do
+                {
+                    const float4* tp = sc.tris_rt + (size_t)prim * 3;
+                    float4 a = tp[0], b = tp[1], cc = tp[2];
+                    last = a.w != 0.0f;
+                    f3 p1 = F3(a.x, a.y, a.z), e1 = F3(b.x, b.y, b.z), e2 = F3(cc.x, cc.y, cc.z);
+                    // RayTriangle, trace_bvh.cl:28-73
+                    f3 pvec = cross3(dir, e2);
+                    float det = dot3(e1, pvec);
+                    if (!(det < 1e-8f || -det > 1e-8f))
+                    {
+                        float inv_det = 1.0f / det;
+                        f3 tvec = org - p1;
+                        float u = dot3(tvec, pvec) * inv_det;
+                        if (!(u < 0.0f || u > 1.0f))
+                        {
+                            f3 qvec = cross3(tvec, e1);
+                            float v = dot3(dir, qvec) * inv_det;
+                            if (!(v < 0.0f || u + v > 1.0f))
+                            {
+                                float t = dot3(e2, qvec) * inv_det;
+                                if (!(t < t_min || t > t_max))
+                                {
+                                    hit_u = u; hit_v = v; hit_t = t; hit_prim = prim;
+                                    t_max = t;                           // :162
+                                    if (SHADOW) { occluded = true; }
+                                }
+                            }
+                        }
+                    }
+                    ++prim;
+                } while (!last && !(SHADOW && occluded));
+                if (SHADOW && occluded) break;                           // goto endtrace, :164-167
+                need_pop = true;
+            }
+            else
+            {
+                const float4* np = sc.nodes + (size_t)ref * 4;
+                float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+                uint32_t c0 = __float_as_uint(n3.x), c1 = __float_as_uint(n3.y), axis = __float_as_uint(n3.z);
+                float a0, a1;
+                bool h0 = box_test(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, org, inv, t_min, t_max, a0);
+                bool h1 = box_test(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, org, inv, t_min, t_max, a1);
+                h1 = h1 && (c1 != RT_EMPTY_REF);
+                // near child: first child unless the ray is negative along the split axis (:181-190)
+                bool swap = (sign_bits >> axis) & 1u;
+                uint32_t near_ref = swap ? c1 : c0, far_ref = swap ? c0 : c1;
+                bool near_hit = swap ? h1 : h0, far_hit = swap ? h0 : h1;
+                float far_entry = swap ? a0 : a1;
+                if (near_hit)
+                {
+                    if (far_hit)
+                    {
+                        uint2 e = make_uint2(far_ref, __float_as_uint(far_entry));
+                        if (sp < RT_TRACE_STACK_LDS) stack[sp][lane] = e;
+                        else my_spill[sp - RT_TRACE_STACK_LDS] = e;
+                        ++sp;
+                    }
+                    ref = near_ref;
+                    need_pop = false;
+                }
+                else if (far_hit)
+                {
+                    ref = far_ref;
+                    need_pop = false;
+                }
+                else
+                {
+                    need_pop = true;
+                }
+            }
+            if (need_pop)
+            {
+                alive = false;
+                while (sp > 0)
+                {
+                    --sp;
+                    uint2 e = (sp < RT_TRACE_STACK_LDS) ? stack[sp][lane] : my_spill[sp - RT_TRACE_STACK_LDS];
+                    if (t_max >= __uint_as_float(e.y))                   // box re-test at pop time
+                    {
+                        ref = e.x;
+                        alive = true;
+                        break;
+                    }
+                }
+            }
+        }
+
+        if (SHADOW)
+        {
+            // AccumulateDirectSamples (accumulate_direct_samples.cl:46-52) fused:
+            // each pixel owns at most one shadow ray per bounce -> plain RMW
+            if (!occluded)
+            {
+                uint32_t pix = __float_as_uint(rd.w);
+                float4 s = ls[i];
+                float4 r = radiance[pix];
+                r.x += s.x; r.y += s.y; r.z += s.z;
+                radiance[pix] = r;
+            }
+        }
+        else
+        {
+            hits[i] = make_float4(hit_u, hit_v, __uint_as_float(hit_prim), hit_t);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// shading (miss.cl + hit_surface.cl + material.h + bxdf.h + light.h)
+// ---------------------------------------------------------------------------
+struct Material
+{
+    f3 diffuse_albedo; float roughness;
+    f3 specular_albedo; float metalness;
+    f3 emission; float ior; float transparency;
+};
+
+// material.h:251-264 + utils.h:123-131
+RT_DEV f3 SampleTexture(const DScene& sc, uint32_t tex_idx, f2 uv)
+{
+    rt_texture tex = sc.textures[tex_idx];
+    uv.x -= __builtin_floorf(uv.x);
+    uv.y -= __builtin_floorf(uv.y);
+    uv.y = 1.f - uv.y;
+    int texel_x = cl_clampi((int)(uv.x * (float)tex.width), 0, tex.width - 1);
+    int texel_y = cl_clampi((int)(uv.y * (float)tex.height), 0, tex.height - 1);
+    int texel_addr = tex.data_start + texel_y * tex.width + texel_x;
+    uint32_t data = sc.texture_data[texel_addr];
+    float r = (float)(data & 0xFF) / 255.0f;
+    float g = (float)((data >> 8) & 0xFF) / 255.0f;
+    float b = (float)((data >> 16) & 0xFF) / 255.0f;
+    return F3(cl_min(cl_max(r, 0.0f), 1.0f), cl_min(cl_max(g, 0.0f), 1.0f), cl_min(cl_max(b, 0.0f), 1.0f));
+}
+
+RT_DEV f3 pow3(f3 a, float e) { return F3(rt_powf(a.x, e), rt_powf(a.y, e), rt_powf(a.z, e)); }
+
+RT_DEV f3 UnpackRGBTex(uint32_t data, uint32_t& idx)                    // utils.h:133-147
+{
+    float r = (float)(data & 0xFF), g = (float)((data >> 8) & 0xFF), b = (float)((data >> 16) & 0xFF);
+    idx = (data >> 24) & 0xFF;
+    return F3(r / 255.0f, g / 255.0f, b / 255.0f);
+}
+
+RT_DEV void ApplyTextures(const DScene& sc, rt_packed_material in, Material& out, f2 uv)   // material.h:319-369
+{
+    uint32_t idx;
+    out.diffuse_albedo = UnpackRGBTex(in.diffuse_albedo, idx);
+    if (idx != RT_INVALID_TEXTURE_IDX) out.diffuse_albedo = pow3(SampleTexture(sc, idx, uv), 2.2f);
+    out.specular_albedo = UnpackRGBTex(in.specular_albedo, idx);
+    if (idx != RT_INVALID_TEXTURE_IDX) out.specular_albedo = pow3(SampleTexture(sc, idx, uv), 2.2f);
+    {
+        uint32_t rgbe = in.emission;                                     // utils.h:149-158
+        int r = (int)(rgbe & 0xFF), g = (int)((rgbe >> 8) & 0xFF), b = (int)((rgbe >> 16) & 0xFF);
+        int e = (int)(rgbe >> 24);
+        float f = rt_ldexpf(1.0f, e - (128 + 8));
+        out.emission = F3((float)r * f, (float)g * f, (float)b * f);
+    }
+    uint32_t d = in.roughness_metalness;                                 // utils.h:160-174
+    out.roughness = (float)(d & 0xFF) / 255.0f;
+    uint32_t roughness_idx = (d >> 8) & 0xFF;
+    out.metalness = (float)((d >> 16) & 0xFF) / 255.0f;
+    uint32_t metalness_idx = (d >> 24) & 0xFF;
+    if (roughness_idx != RT_INVALID_TEXTURE_IDX) out.roughness = SampleTexture(sc, roughness_idx, uv).x;
+    if (metalness_idx != RT_INVALID_TEXTURE_IDX) out.metalness = SampleTexture(sc, metalness_idx, uv).x;
+    d = in.ior_emission_idx_transparency;                                // utils.h:176-190
+    out.ior = (float)(d & 0xFF) / 25.5f;
+    uint32_t emission_idx = (d >> 8) & 0xFF;
+    out.transparency = (float)((d >> 16) & 0xFF) / 255.0f;
+    uint32_t transparency_idx = (d >> 24) & 0xFF;
+    if (emission_idx != RT_INVALID_TEXTURE_IDX)
+        out.emission = out.emission * pow3(SampleTexture(sc, emission_idx, uv), 2.2f);
+    if (transparency_idx != RT_INVALID_TEXTURE_IDX)
+        out.transparency *= SampleTexture(sc, transparency_idx, uv).x;
+}
+
+RT_DEV float IorToF0(float ior_incident, float ior_transmitted)          // bxdf.h:57-61
+{
+    float result = (ior_transmitted - ior_incident) / (ior_transmitted + ior_incident);
+    return result * result;
+}
+
+RT_DEV f3 FresnelSchlick(f3 f0, float h_dot_o)                           // bxdf.h:71-74
+{
+    float p = rt_powf(1.0f - h_dot_o, 5.0f);
+    return F3(f0.x + (1.0f - f0.x) * p, f0.y + (1.0f - f0.y) * p, f0.z + (1.0f - f0.z) * p);
+}
+
+RT_DEV float GGX_D(float alpha, float n_dot_h)                           // bxdf.h:90-95
+{
+    float alpha2 = alpha * alpha;
+    float denom = n_dot_h * n_dot_h * (alpha2 - 1.0f) + 1.0f;
+    return alpha2 * RT_INV_PI / (denom * denom);
+}
+
+RT_DEV float V_SmithGGXCorrelated(float n_dot_i, float n_dot_o, float alphaG)   // bxdf.h:104-119
+{
+    float alphaG2 = alphaG * alphaG;
+    float Lambda_GGXV = n_dot_o * __builtin_sqrtf((-n_dot_i * alphaG2 + n_dot_i) * n_dot_i + alphaG2);
+    float Lambda_GGXL = n_dot_i * __builtin_sqrtf((-n_dot_o * alphaG2 + n_dot_o) * n_dot_o + alphaG2);
+    return 0.5f / (Lambda_GGXV + Lambda_GGXL);
+}
+
+RT_DEV float Luma(f3 rgb) { return rgb.x * 0.299f + rgb.y * 0.587f + rgb.z * 0.114f; }   // utils.h:108-111
+
+RT_DEV void tangent_frame(f3 n, f3& t, f3& b)                            // utils.h:101-103, bxdf.h:163-165
+{
+    f3 axis = __builtin_fabsf(n.x) > 0.001f ? F3(0.0f, 1.0f, 0.0f) : F3(1.0f, 0.0f, 0.0f);
+    t = normalize3(cross3(axis, n));
+    b = cross3(n, t);
+}
+
+RT_DEV f3 reflect3(f3 v, f3 n) { return v - n * (2.0f * dot3(v, n)); }   // utils.h:83-86
+
+RT_DEV f3 EvaluateMaterial(const Material& m, f3 normal, f3 incoming, f3 outgoing)   // material.h:132-169
+{
+    if ((double)m.transparency < 0.5) return F3s(0.0f);
+    f3 half_vec = normalize3(incoming + outgoing);
+    float n_dot_i = cl_max(dot3(normal, incoming), RT_EPS);
+    float n_dot_o = cl_max(dot3(normal, outgoing), RT_EPS);
+    float n_dot_h = cl_max(dot3(normal, half_vec), RT_EPS);
+    float h_dot_o = cl_max(dot3(half_vec, outgoing), RT_EPS);
+    float alpha = m.roughness * m.roughness;
+    float f0_dielectric = IorToF0(1.0f, m.ior);
+    f3 f0 = mix3(F3s(f0_dielectric), m.specular_albedo, m.metalness);
+    f3 diffuse_color = m.diffuse_albedo * (1.0f - m.metalness);
+    f3 fresnel = FresnelSchlick(f0, h_dot_o);
+    float specular = GGX_D(alpha, n_dot_h) * V_SmithGGXCorrelated(n_dot_i, n_dot_o, alpha);
+    f3 diffuse = diffuse_color * RT_INV_PI;
+    return F3(fresnel.x * specular + (1.0f - fresnel.x) * diffuse.x,
+              fresnel.y * specular + (1.0f - fresnel.y) * diffuse.y,
+              fresnel.z * specular + (1.0f - fresnel.z) * diffuse.z);
+}
+
+// material.h:171-241 with SampleSpecular :66-103, SampleDiffuse :51-64, SampleTransparency :105-117
+template <bool FURNACE>
+RT_DEV f3 SampleBxdf(float s1, f2 s, Material material, f3 normal, f3 incoming, f3& outgoing, float& pdf,
+    float& offset)
+{
+    if (FURNACE)
+    {
+        material.diffuse_albedo = F3s(1.0f);
+        material.specular_albedo = F3s(1.0f);
+    }
+    float alpha = material.roughness * material.roughness;
+    float f0_dielectric = IorToF0(1.0f, material.ior);
+    f3 f0 = mix3(F3s(f0_dielectric), material.specular_albedo, material.metalness);
+    f3 diffuse_albedo = material.diffuse_albedo * (1.0f - material.metalness);
+    f3 specular_albedo = mix3(material.specular_albedo, F3s(1.0f), material.metalness);
+    f3 fresnel = FresnelSchlick(f0, dot3(normal, incoming)) * specular_albedo;
+    float specular_weight = Luma(specular_albedo * fresnel);
+    float diffuse_weight = Luma(diffuse_albedo * F3(1.0f - fresnel.x, 1.0f - fresnel.y, 1.0f - fresnel.z));
+    float weight_sum = diffuse_weight + specular_weight;
+    float specular_sampling_pdf = specular_weight / weight_sum;
+    float diffuse_sampling_pdf = diffuse_weight / weight_sum;
+
+    offset = 1.0f;
+    if ((double)material.transparency < 0.5)
+    {
+        pdf = 1.0f;
+        outgoing = -incoming;
+        offset = -1.0f;
+        return F3s(1.0f);
+    }
+
+    f3 bxdf;
+    if (s1 <= specular_sampling_pdf)
+    {
+        float spec;
+        if (alpha <= 1e-4f)
+        {
+            outgoing = reflect3(-incoming, normal);
+            pdf = 1.0f;
+            float n_dot_o = dot3(outgoing, normal);
+            spec = 1.0f / n_dot_o;
+        }
+        else
+        {
+            // GGX_Sample bxdf.h:157-168 (fp64 literals in the reference -> fp64 divide + sqrt)
+            float phi = RT_TWO_PI * s.x;
+            float cos_theta = (float)(1.0 / __builtin_sqrt(1.0 + (double)(alpha * alpha * s.y) / (1.0 - (double)s.y)));
+            float sin_theta = __builtin_sqrtf(cl_max(0.0f, 1.0f - cos_theta * cos_theta));
+            f3 t, b;
+            tangent_frame(normal, t, b);
+            double sd, cd;
+            rtd_sincos((double)phi, &sd, &cd);
+            float cp = (float)cd, sn = (float)sd;
+            f3 wh = normalize3(b * cp * sin_theta + t * sn * sin_theta + normal * cos_theta);
+            outgoing = reflect3(-incoming, wh);
+            float n_dot_o = dot3(normal, outgoing);
+            float n_dot_h = dot3(normal, wh);
+            float n_dot_i = dot3(normal, incoming);
+            float D = GGX_D(alpha, n_dot_h);
+            float G = V_SmithGGXCorrelated(n_dot_i, n_dot_o, alpha);
+            pdf = D * n_dot_h / (4.0f * dot3(wh, outgoing));
+            spec = D * G;
+        }
+        float m = cl_max(dot3(outgoing, normal), 0.0f);
+        bxdf = F3(fresnel.x * spec * m, fresnel.y * spec * m, fresnel.z * spec * m);
+        pdf *= specular_sampling_pdf;
+    }
+    else
+    {
+        // SampleHemisphereCosine bxdf.h:33-54 + TangentToWorld utils.h:99-106
+        float phi = RT_TWO_PI * s.x;
+        float sin_theta = __builtin_sqrtf(s.y);
+        float cos_theta = __builtin_sqrtf(1.0f - s.y);
+        pdf = cos_theta * RT_INV_PI;
+        double sd, cd;
+        rtd_sincos((double)phi, &sd, &cd);
+        f3 tbn = F3((float)cd * sin_theta, (float)sd * sin_theta, cos_theta);
+        f3 t, b;
+        tangent_frame(normal, t, b);
+        outgoing = normalize3(b * tbn.x + t * tbn.y + normal * tbn.z);
+        f3 d = diffuse_albedo * RT_INV_PI;
+        float m = cl_max(dot3(outgoing, normal), 0.0f);
+        bxdf = F3((1.0f - fresnel.x) * d.x * m, (1.0f - fresnel.y) * d.y * m, (1.0f - fresnel.z) * d.z * m);
+        pdf *= diffuse_sampling_pdf;
+    }
+    return bxdf;
+}
+
+// miss.cl:28-39 with the OpenCL 1.2 (8.2) linear / repeat / normalized sampler
+RT_DEV f3 SampleSky(const DScene& sc, f3 dir)
+{
+    float cx = rt_atan2f(dir.x, dir.y) + RT_PI;
+    float cy = rt_acosf(dir.z);
+    cx = cx < 0.0f ? cx + RT_TWO_PI : cx;
+    cx *= RT_INV_TWO_PI;
+    cy *= RT_INV_PI;
+    int w = sc.env_w, h = sc.env_h;
+    float u = (cx - __builtin_floorf(cx)) * (float)w;
+    float v = (cy - __builtin_floorf(cy)) * (float)h;
+    float fu = __builtin_floorf(u - 0.5f);
+    float fv = __builtin_floorf(v - 0.5f);
+    int i0 = (int)fu, j0 = (int)fv;
+    int i1 = i0 + 1, j1 = j0 + 1;
+    if (i0 < 0) i0 = w + i0;
+    if (i1 > w - 1) i1 = i1 - w;
+    if (j0 < 0) j0 = h + j0;
+    if (j1 > h - 1) j1 = j1 - h;
+    float a = (u - 0.5f) - fu;
+    float b = (v - 0.5f) - fv;
+    float wa0 = 1.0f - a, wb0 = 1.0f - b;
+    float4 t00 = sc.env[(size_t)j0 * w + i0];
+    float4 t10 = sc.env[(size_t)j0 * w + i1];
+    float4 t01 = sc.env[(size_t)j1 * w + i0];
+    float4 t11 = sc.env[(size_t)j1 * w + i1];
+    float w00 = wa0 * wb0, w10 = a * wb0, w01 = wa0 * b, w11 = a * b;
+    return F3(w00 * t00.x + w10 * t10.x + w01 * t01.x + w11 * t11.x,
+              w00 * t00.y + w10 * t10.y + w01 * t01.y + w11 * t11.y,
+              w00 * t00.z + w10 * t10.z + w01 * t01.z + w11 * t11.z);
+}
+
+// wave64 stream compaction: one global atomic per wave per queue instead of
+// the reference's one per ray (hit_surface.cl:138,173)
+RT_DEV uint32_t wave_append(bool want, uint32_t* counter)
+{
+    unsigned long long mask = __ballot(want);
+    uint32_t total = (uint32_t)__popcll(mask);
+    uint32_t lane = threadIdx.x & 63u;
+    uint32_t before = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+    uint32_t base = 0;
+    if (total != 0)
+    {
+        int leader = __ffsll((long long)mask) - 1;
+        if ((int)lane == leader) base = atomicAdd(counter, total);
+        base = __shfl(base, leader, 64);
+    }
+    return base + before;
+}
+
+struct ShadeArgs
+{
+    const float4* in_o4; const float4* in_d4; const float4* in_thr; const float4* hits;
+    float4* out_o4; float4* out_d4; float4* out_thr;
+    float4* sh_o4; float4* sh_d4; float4* sh_ls;
+    float4* radiance;
+    DCounters* counters;
+    uint32_t bounce, sample_idx, emit_outgoing;
+};
+
+template <bool FURNACE>
+__global__ __launch_bounds__(256) void k_shade(DScene sc, DTile tile, ShadeArgs a)
+{
+    const uint32_t count = a.counters->queue[a.bounce];
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (blockIdx.x * 256u >= count) return;                              // whole block idle (uniform)
+    const bool active = i < count;
+
+    bool want_shadow = false, want_next = false;
+    float4 sh_o = make_float4(0, 0, 0, 0), sh_d = sh_o, sh_l = sh_o, nx_o = sh_o, nx_d = sh_o, nx_t = sh_o;
+
+    if (active)
+    {
+        float4 hit = a.hits[i];
+        float4 rd = a.in_d4[i];
+        uint32_t prim = __float_as_uint(hit.z);
+        uint32_t pix = __float_as_uint(rd.w);
+        float4 thr4 = a.in_thr[i];
+        f3 hit_throughput = F3(thr4.x, thr4.y, thr4.z);
+
+        if (prim == RT_INVALID_ID)
+        {
+            // Miss, miss.cl:65-76
+            f3 sky = FURNACE ? F3s(0.5f) : SampleSky(sc, F3(rd.x, rd.y, rd.z));
+            f3 add = sky * hit_throughput;
+            float4 r = a.radiance[pix];
+            r.x += add.x; r.y += add.y; r.z += add.z;
+            a.radiance[pix] = r;
+        }
+        else
+        {
+            // HitSurface, hit_surface.cl:79-184
+            f3 incoming = F3(-rd.x, -rd.y, -rd.z);
+            uint32_t ly = pix / tile.width;
+            uint32_t px = pix - ly * tile.width;
+            uint32_t py = tile_global_row(tile, ly);
+
+            const float4* tp = sc.tris_sh + (size_t)prim * 8;
+            float4 q0 = tp[0], q1 = tp[1], q2 = tp[2], q3 = tp[3], q4 = tp[4], q5 = tp[5], q6 = tp[6];
+            f3 p1 = xyz(q0), p2 = xyz(q1), p3 = xyz(q2);
+            f3 n1 = xyz(q3), n2 = xyz(q4), n3 = xyz(q5);
+            float bu = hit.x, bv = hit.y;
+            float w0 = 1.0f - bu - bv;
+            f3 position = p1 * w0 + p2 * bu + p3 * bv;
+            f3 geometry_normal = normalize3(cross3(p2 - p1, p3 - p1));
+            f2 texcoord;
+            texcoord.x = q0.w * w0 + q2.w * bu + q4.w * bv;                // uv1.x, uv2.x, uv3.x
+            texcoord.y = q1.w * w0 + q3.w * bu + q5.w * bv;                // uv1.y, uv2.y, uv3.y
+            f3 normal = normalize3(n1 * w0 + n2 * bu + n3 * bv);
+
+            Material material;
+            ApplyTextures(sc, sc.materials[__float_as_uint(q6.x)], material, texcoord);
+
+            if (!FURNACE)
+            {
+                if (material.emission.x * 1.0f + material.emission.y * 1.0f + material.emission.z * 1.0f > 0.0f)
+                {
+                    f3 e = hit_throughput * material.emission;
+                    float4 r = a.radiance[pix];
+                    r.x += e.x; r.y += e.y; r.z += e.z;
+                    a.radiance[pix] = r;
+                }
+            }
+
+            uint32_t sample_seed = SampleRandomSampleSeed(SampleRandomPixelSeed(px, py), a.sample_idx);
+
+            // Direct lighting :115-145 (Light_Sample light.h:30-65)
+            {
+                float s_light = SampleRandomDim(sample_seed, a.bounce, 4);
+                int light_idx = cl_clampi((int)(s_light * (float)sc.light_count), 0, (int)sc.light_count - 1);
+                float4 lo = sc.lights[light_idx * 3 + 0], lr = sc.lights[light_idx * 3 + 1];
+                uint32_t ltype = __float_as_uint(sc.lights[light_idx * 3 + 2].x);
+                float pdf = 1.0f / (float)sc.light_count;
+                f3 light_radiance = xyz(lr);
+                f3 outgoing;
+                if (ltype == RT_LIGHT_TYPE_POINT)
+                {
+                    f3 to_light = xyz(lo) - position;
+                    float sq_length = dot3(to_light, to_light);
+                    light_radiance = light_radiance / sq_length;
+                    outgoing = to_light;
+                }
+                else
+                {
+                    outgoing = xyz(lo) * RT_MAX_RENDER_DIST;
+                }
+                float distance_to_light = length3(outgoing);
+                outgoing = normalize3(outgoing);
+                f3 brdf = EvaluateMaterial(material, normal, incoming, outgoing);
+                float m = cl_max(dot3(outgoing, normal), 0.0f);
+                f3 lsamp = ((light_radiance * hit_throughput) * brdf / pdf) * m;
+                want_shadow = (pdf > 0.0f) && (dot3(lsamp, lsamp) > 0.0f);
+                f3 so = position + normal * RT_EPS;
+                sh_o = make_float4(so.x, so.y, so.z, distance_to_light);
+                sh_d = make_float4(outgoing.x, outgoing.y, outgoing.z, rd.w);
+                sh_l = make_float4(lsamp.x, lsamp.y, lsamp.z, 0.0f);
+            }
+
+            // Indirect lighting :148-184
+            {
+                f2 s;
+                s.x = SampleRandomDim(sample_seed, a.bounce, 2);
+                s.y = SampleRandomDim(sample_seed, a.bounce, 3);
+                float s1 = SampleRandomDim(sample_seed, a.bounce, 1);
+                float pdf = 0.0f;
+                f3 outgoing;
+                float offset;
+                f3 bxdf = SampleBxdf<FURNACE>(s1, s, material, normal, incoming, outgoing, pdf, offset);
+                f3 throughput = F3s(0.0f);
+                if ((double)pdf > 0.0) throughput = bxdf / pdf;
+                f3 new_thr = hit_throughput * throughput;                 // throughputs[pixel] *= throughput
+                want_next = ((double)pdf > 0.0) && (a.emit_outgoing != 0);
+                f3 oo = position + geometry_normal * RT_EPS * offset;
+                nx_o = make_float4(oo.x, oo.y, oo.z, RT_MAX_RENDER_DIST);
+                nx_d = make_float4(outgoing.x, outgoing.y, outgoing.z, rd.w);
+                nx_t = make_float4(new_thr.x, new_thr.y, new_thr.z, 0.0f);
+            }
+        }
+    }
+
+    uint32_t sidx = wave_append(want_shadow, &a.counters->shadow[a.bounce]);
+    if (want_shadow)
+    {
+        a.sh_o4[sidx] = sh_o;
+        a.sh_d4[sidx] = sh_d;
+        a.sh_ls[sidx] = sh_l;
+    }
+    uint32_t nidx = wave_append(want_next, &a.counters->queue[a.bounce + 1]);
+    if (want_next)
+    {
+        a.out_o4[nidx] = nx_o;
+        a.out_d4[nidx] = nx_d;
+        a.out_thr[nidx] = nx_t;
+    }
+}
+
+// ResolveRadiance, resolve_radiance.cl:76-85 (shaded colour, denoiser off)
+__global__ __launch_bounds__(256) void k_resolve(const float4* __restrict__ radiance, float4* __restrict__ out,
+    uint32_t n, uint32_t sample_count)
+{
+    uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    float4 r = radiance[i];
+    float spp = (float)sample_count;
+    float hx = r.x / spp, hy = r.y / spp, hz = r.z / spp;
+    out[i] = make_float4(hx / (hx + 1.0f), hy / (hy + 1.0f), hz / (hz + 1.0f), 1.0f);
+}
+
+// end-of-run fold of the per-bounce counters (same as the prologue of k_raygen)
+__global__ void k_fold_counters(DCounters* counters, uint32_t bounces)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    unsigned long long c = 0, s = 0;
+    for (uint32_t b = 0; b <= bounces && b < 64; ++b)
+    {
+        c += counters->queue[b];
+        s += counters->shadow[b];
+        counters->last_queue[b] = counters->queue[b];
+        counters->last_shadow[b] = counters->shadow[b];
+        counters->queue[b] = 0;
+        counters->shadow[b] = 0;
+    }
+    counters->total_closest += c;
+    counters->total_shadow += s;
+}
+
+// device-math known-answer hook (rt_debug_eval)
+__global__ void k_debug_eval(int fn, const float* a, const float* b, float* out, uint32_t n)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float x = a[i], y = b ? b[i] : 0.0f, r = 0.0f;
+    switch (fn)
+    {
+    case 0: r = rt_sinf(x); break;
+    case 1: r = rt_cosf(x); break;
+    case 2: r = rt_tanf(x); break;
+    case 3: r = rt_powf(x, y); break;
+    case 4: r = rt_atan2f(x, y); break;
+    case 5: r = rt_acosf(x); break;
+    case 6: r = __builtin_sqrtf(x); break;
+    case 7: r = x / y; break;
+    case 8:
+    {
+        uint32_t px = __float_as_uint(x) & 0xFFFFu, py = __float_as_uint(x) >> 16;
+        uint32_t smp = __float_as_uint(y) & 0xFFFFu, dim = __float_as_uint(y) >> 16;
+        uint32_t ss = SampleRandomSampleSeed(SampleRandomPixelSeed(px, py), smp);
+        r = SampleRandomDim(ss, dim / 5u, dim % 5u);
+        break;
+    }
+    case 9:   // fp64 path of GGX_Sample: x = alpha*alpha*s.y, y = s.y
+        r = (float)(1.0 / __builtin_sqrt(1.0 + (double)x / (1.0 - (double)y)));
+        break;
+    default: break;
+    }
+    out[i] = r;
+}

@@ -1,0 +1,672 @@
+// rt_hip.hip -- implementation of the C-ABI in include/rt_hip.h over HIP for
+// gfx950.  Replaces the reference's src/gpu_wrappers/cl_context.cpp and the
+// device-facing half of src/integrator/cl_pt_integrator.cpp.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include "rt_hip.h"
+#include "kernels.h"
+
+namespace
+{
+thread_local std::string g_thread_error;
+
+struct Scene
+{
+    void* nodes = nullptr; void* tris_rt = nullptr; void* tris_sh = nullptr; void* materials = nullptr;
+    void* textures = nullptr; void* texture_data = nullptr; void* lights = nullptr; void* env = nullptr;
+    void* emissive = nullptr;
+    DScene d = {};
+    bool valid = false;
+};
+} // namespace
+
+struct rt_ctx
+{
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipDeviceProp_t prop;
+    std::string error;
+    Scene scene;
+};
+
+struct rt_buffer
+{
+    rt_ctx* ctx;
+    void* ptr;
+    size_t bytes;
+};
+
+struct rt_frame
+{
+    rt_ctx* ctx;
+    DTile tile;
+    uint32_t n_local;
+    // queues (ping-pong), hits, shadow queue, radiance
+    float4* o4[2]; float4* d4[2]; float4* thr[2];
+    float4* hits;
+    float4* sh_o4; float4* sh_d4; float4* sh_ls;
+    float4* radiance; float4* resolved;
+    DCounters* counters;
+    uint2* spill;
+    uint32_t trace_blocks;
+    // integrator state
+    rt_camera camera;
+    uint32_t max_bounces = 3;
+    uint32_t white_furnace = 0;
+    uint32_t drop_last = 1;
+    uint32_t sample_count = 0;
+    uint32_t prev_bounces = 0;
+};
+
+namespace
+{
+int fail(rt_ctx* ctx, const std::string& msg)
+{
+    if (ctx) ctx->error = msg;
+    g_thread_error = msg;
+    return RT_ERROR;
+}
+
+#define HIPCHK(ctx, expr)                                                                         \
+    do                                                                                            \
+    {                                                                                             \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            return fail(ctx, std::string(#expr) + ": " + hipGetErrorString(e_));                  \
+    } while (0)
+
+int dev_alloc_copy(rt_ctx* ctx, void** out, const void* src, size_t bytes)
+{
+    *out = nullptr;
+    size_t alloc = bytes ? bytes : 16;
+    HIPCHK(ctx, hipMalloc(out, alloc));
+    if (bytes && src) HIPCHK(ctx, hipMemcpyAsync(*out, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return RT_OK;
+}
+
+void free_scene(Scene& s)
+{
+    void* ptrs[] = {s.nodes, s.tris_rt, s.tris_sh, s.materials, s.textures, s.texture_data, s.lights, s.env, s.emissive};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    s = Scene();
+}
+} // namespace
+
+extern "C" {
+
+const char* rt_last_error(rt_ctx* ctx)
+{
+    return ctx ? ctx->error.c_str() : g_thread_error.c_str();
+}
+
+int rt_ctx_create(int device_ordinal, rt_ctx** out)
+{
+    if (!out) return fail(nullptr, "rt_ctx_create: out is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n == 0)
+        return fail(nullptr, std::string("rt_ctx_create: no HIP device (") + hipGetErrorString(e) + ")");
+    if (device_ordinal < 0 || device_ordinal >= n) return fail(nullptr, "rt_ctx_create: bad device ordinal");
+    rt_ctx* ctx = new rt_ctx;
+    ctx->device = device_ordinal;
+    if (hipSetDevice(device_ordinal) != hipSuccess || hipGetDeviceProperties(&ctx->prop, device_ordinal) != hipSuccess ||
+        hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess)
+    {
+        delete ctx;
+        return fail(nullptr, "rt_ctx_create: device initialisation failed");
+    }
+    *out = ctx;
+    return RT_OK;
+}
+
+int rt_ctx_destroy(rt_ctx* ctx)
+{
+    if (!ctx) return RT_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    free_scene(ctx->scene);
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return RT_OK;
+}
+
+int rt_finish(rt_ctx* ctx)
+{
+    if (!ctx) return fail(nullptr, "rt_finish: ctx is NULL");
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+int rt_ctx_device_info(rt_ctx* ctx, char* name, size_t name_len, int* compute_units, size_t* hbm_bytes)
+{
+    if (!ctx) return fail(nullptr, "rt_ctx_device_info: ctx is NULL");
+    if (name && name_len) snprintf(name, name_len, "%s (%s)", ctx->prop.name, ctx->prop.gcnArchName);
+    if (compute_units) *compute_units = ctx->prop.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = ctx->prop.totalGlobalMem;
+    return RT_OK;
+}
+
+void* rt_ctx_stream(rt_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+// ---- buffers ---------------------------------------------------------------
+int rt_buffer_create(rt_ctx* ctx, size_t bytes, const void* init, rt_buffer** out)
+{
+    if (!ctx || !out) return fail(ctx, "rt_buffer_create: NULL argument");
+    *out = nullptr;
+    (void)hipSetDevice(ctx->device);
+    void* p = nullptr;
+    HIPCHK(ctx, hipMalloc(&p, bytes ? bytes : 16));
+    if (init && bytes)
+    {
+        hipError_t e = hipMemcpy(p, init, bytes, hipMemcpyHostToDevice);
+        if (e != hipSuccess) { (void)hipFree(p); return fail(ctx, "rt_buffer_create: upload failed"); }
+    }
+    *out = new rt_buffer{ctx, p, bytes};
+    return RT_OK;
+}
+
+int rt_buffer_destroy(rt_buffer* buf)
+{
+    if (!buf) return RT_OK;
+    (void)hipStreamSynchronize(buf->ctx->stream);
+    (void)hipFree(buf->ptr);
+    delete buf;
+    return RT_OK;
+}
+
+int rt_buffer_write(rt_buffer* buf, size_t offset, const void* src, size_t bytes)
+{
+    if (!buf || !src) return fail(nullptr, "rt_buffer_write: NULL argument");
+    if (offset + bytes > buf->bytes) return fail(buf->ctx, "rt_buffer_write: out of range");
+    HIPCHK(buf->ctx, hipMemcpyAsync((char*)buf->ptr + offset, src, bytes, hipMemcpyHostToDevice, buf->ctx->stream));
+    HIPCHK(buf->ctx, hipStreamSynchronize(buf->ctx->stream));   // blocking, like WriteBuffer (CL_TRUE)
+    return RT_OK;
+}
+
+int rt_buffer_read(rt_buffer* buf, size_t offset, void* dst, size_t bytes)
+{
+    if (!buf || !dst) return fail(nullptr, "rt_buffer_read: NULL argument");
+    if (offset + bytes > buf->bytes) return fail(buf->ctx, "rt_buffer_read: out of range");
+    HIPCHK(buf->ctx, hipMemcpyAsync(dst, (char*)buf->ptr + offset, bytes, hipMemcpyDeviceToHost, buf->ctx->stream));
+    HIPCHK(buf->ctx, hipStreamSynchronize(buf->ctx->stream));
+    return RT_OK;
+}
+
+int rt_buffer_copy(rt_buffer* src, rt_buffer* dst, size_t src_offset, size_t dst_offset, size_t bytes)
+{
+    if (!src || !dst) return fail(nullptr, "rt_buffer_copy: NULL argument");
+    if (src_offset + bytes > src->bytes || dst_offset + bytes > dst->bytes)
+        return fail(src->ctx, "rt_buffer_copy: out of range");
+    HIPCHK(src->ctx, hipMemcpyAsync((char*)dst->ptr + dst_offset, (char*)src->ptr + src_offset, bytes,
+        hipMemcpyDeviceToDevice, src->ctx->stream));
+    return RT_OK;
+}
+
+void* rt_buffer_device_ptr(rt_buffer* buf) { return buf ? buf->ptr : nullptr; }
+size_t rt_buffer_size(rt_buffer* buf) { return buf ? buf->bytes : 0; }
+
+// ---- scene -----------------------------------------------------------------
+int rt_scene_upload(rt_ctx* ctx, const rt_scene_desc* sd)
+{
+    if (!ctx || !sd) return fail(ctx, "rt_scene_upload: NULL argument");
+    if (!sd->triangles || sd->num_triangles == 0) return fail(ctx, "rt_scene_upload: no triangles");
+    if (!sd->nodes || sd->num_nodes == 0) return fail(ctx, "rt_scene_upload: no BVH nodes");
+    if (!sd->materials || sd->num_materials == 0) return fail(ctx, "rt_scene_upload: no materials");
+    if (!sd->env_rgba || sd->env_width == 0 || sd->env_height == 0)
+        return fail(ctx, "rt_scene_upload: no environment image");
+    (void)hipSetDevice(ctx->device);
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    free_scene(ctx->scene);
+    Scene& s = ctx->scene;
+    const uint32_t nt = sd->num_triangles, nn = sd->num_nodes;
+
+    // --- BVH re-layout: LinearBVHNode[] (bvh.cpp:223-245) -> child-pair records
+    std::vector<uint32_t> interior_index(nn, RT_EMPTY_REF);
+    uint32_t n_interior = 0;
+    for (uint32_t i = 0; i < nn; ++i)
+        if ((sd->nodes[i].num_primitives_axis >> 16) == 0) interior_index[i] = n_interior++;
+    std::vector<uint8_t> last_in_leaf(nt, 0);
+    for (uint32_t i = 0; i < nn; ++i)
+    {
+        uint32_t n = sd->nodes[i].num_primitives_axis >> 16;
+        if (n > 0)
+        {
+            uint32_t first = sd->nodes[i].offset;
+            if ((uint64_t)first + n > nt) return fail(ctx, "rt_scene_upload: leaf range outside the triangle array");
+            last_in_leaf[first + n - 1] = 1;
+        }
+    }
+    auto child_ref = [&](uint32_t ref_idx) -> uint32_t
+    {
+        const rt_bvh_node& c = sd->nodes[ref_idx];
+        if ((c.num_primitives_axis >> 16) > 0) return RT_LEAF_BIT | c.offset;
+        return interior_index[ref_idx];
+    };
+    std::vector<float4> nodes2((size_t)(n_interior ? n_interior : 1) * 4);
+    for (uint32_t i = 0; i < nn; ++i)
+    {
+        const rt_bvh_node& nd = sd->nodes[i];
+        if ((nd.num_primitives_axis >> 16) != 0) continue;
+        uint32_t c0 = i + 1, c1 = nd.offset;                    // first child follows, second child at offset
+        if (c0 >= nn || c1 >= nn) return fail(ctx, "rt_scene_upload: child index outside the node array");
+        const rt_bvh_node& a = sd->nodes[c0];
+        const rt_bvh_node& b = sd->nodes[c1];
+        float4* out = &nodes2[(size_t)interior_index[i] * 4];
+        out[0] = make_float4(a.bounds_min.x, a.bounds_min.y, a.bounds_min.z, a.bounds_max.x);
+        out[1] = make_float4(a.bounds_max.y, a.bounds_max.z, b.bounds_min.x, b.bounds_min.y);
+        out[2] = make_float4(b.bounds_min.z, b.bounds_max.x, b.bounds_max.y, b.bounds_max.z);
+        uint32_t r0 = child_ref(c0), r1 = child_ref(c1), axis = nd.num_primitives_axis & 0xFFFF;
+        if (axis > 2) return fail(ctx, "rt_scene_upload: bad split axis");
+        float fr0, fr1, fax;
+        memcpy(&fr0, &r0, 4); memcpy(&fr1, &r1, 4); memcpy(&fax, &axis, 4);
+        out[3] = make_float4(fr0, fr1, fax, 0.0f);
+    }
+    const rt_bvh_node& root = sd->nodes[0];
+    s.d.root_ref = (root.num_primitives_axis >> 16) > 0 ? (RT_LEAF_BIT | root.offset) : 0u;
+    s.d.root_min[0] = root.bounds_min.x; s.d.root_min[1] = root.bounds_min.y; s.d.root_min[2] = root.bounds_min.z;
+    s.d.root_max[0] = root.bounds_max.x; s.d.root_max[1] = root.bounds_max.y; s.d.root_max[2] = root.bounds_max.z;
+
+    // --- triangles: trace record (p1, e1, e2) and 128-byte shading record
+    std::vector<float4> trt((size_t)nt * 3), tsh((size_t)nt * 8);
+    for (uint32_t i = 0; i < nt; ++i)
+    {
+        const rt_triangle& t = sd->triangles[i];
+        const rt_float3 &p1 = t.v1.position, &p2 = t.v2.position, &p3 = t.v3.position;
+        trt[(size_t)i * 3 + 0] = make_float4(p1.x, p1.y, p1.z, last_in_leaf[i] ? 1.0f : 0.0f);
+        trt[(size_t)i * 3 + 1] = make_float4(p2.x - p1.x, p2.y - p1.y, p2.z - p1.z, 0.0f);   // e1, trace_bvh.cl:30
+        trt[(size_t)i * 3 + 2] = make_float4(p3.x - p1.x, p3.y - p1.y, p3.z - p1.z, 0.0f);   // e2, trace_bvh.cl:31
+        float4* q = &tsh[(size_t)i * 8];
+        q[0] = make_float4(p1.x, p1.y, p1.z, t.v1.texcoord.x);
+        q[1] = make_float4(p2.x, p2.y, p2.z, t.v1.texcoord.y);
+        q[2] = make_float4(p3.x, p3.y, p3.z, t.v2.texcoord.x);
+        q[3] = make_float4(t.v1.normal.x, t.v1.normal.y, t.v1.normal.z, t.v2.texcoord.y);
+        q[4] = make_float4(t.v2.normal.x, t.v2.normal.y, t.v2.normal.z, t.v3.texcoord.x);
+        q[5] = make_float4(t.v3.normal.x, t.v3.normal.y, t.v3.normal.z, t.v3.texcoord.y);
+        if (t.mtl_index >= sd->num_materials) return fail(ctx, "rt_scene_upload: material index out of range");
+        float fm; uint32_t mi = t.mtl_index; memcpy(&fm, &mi, 4);
+        q[6] = make_float4(fm, 0.0f, 0.0f, 0.0f);
+        q[7] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+    std::vector<float4> lights((size_t)(sd->num_lights ? sd->num_lights : 1) * 3);
+    for (uint32_t i = 0; i < sd->num_lights; ++i)
+    {
+        const rt_light& l = sd->lights[i];
+        float ft; uint32_t ty = l.type; memcpy(&ft, &ty, 4);
+        lights[(size_t)i * 3 + 0] = make_float4(l.origin.x, l.origin.y, l.origin.z, 0.0f);
+        lights[(size_t)i * 3 + 1] = make_float4(l.radiance.x, l.radiance.y, l.radiance.z, 0.0f);
+        lights[(size_t)i * 3 + 2] = make_float4(ft, 0.0f, 0.0f, 0.0f);
+    }
+    for (uint32_t i = 0; i < sd->num_textures; ++i)
+    {
+        const rt_texture& t = sd->textures[i];
+        if (t.width <= 0 || t.height <= 0 || t.data_start < 0 ||
+            (uint64_t)t.data_start + (uint64_t)t.width * t.height > sd->num_texture_data)
+            return fail(ctx, "rt_scene_upload: texture outside texture_data");
+    }
+
+    int rc = RT_OK;
+    rc |= dev_alloc_copy(ctx, &s.nodes, nodes2.data(), nodes2.size() * sizeof(float4));
+    rc |= dev_alloc_copy(ctx, &s.tris_rt, trt.data(), trt.size() * sizeof(float4));
+    rc |= dev_alloc_copy(ctx, &s.tris_sh, tsh.data(), tsh.size() * sizeof(float4));
+    rc |= dev_alloc_copy(ctx, &s.materials, sd->materials, (size_t)sd->num_materials * sizeof(rt_packed_material));
+    rc |= dev_alloc_copy(ctx, &s.textures, sd->textures, (size_t)sd->num_textures * sizeof(rt_texture));
+    rc |= dev_alloc_copy(ctx, &s.texture_data, sd->texture_data, (size_t)sd->num_texture_data * 4);
+    rc |= dev_alloc_copy(ctx, &s.lights, lights.data(), lights.size() * sizeof(float4));
+    rc |= dev_alloc_copy(ctx, &s.env, sd->env_rgba, (size_t)sd->env_width * sd->env_height * 16);
+    rc |= dev_alloc_copy(ctx, &s.emissive, sd->emissive_indices, (size_t)sd->num_emissive * 4);
+    if (rc != RT_OK) { free_scene(s); return RT_ERROR; }
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // host staging vectors die here
+
+    s.d.nodes = (const float4*)s.nodes;
+    s.d.tris_rt = (const float4*)s.tris_rt;
+    s.d.tris_sh = (const float4*)s.tris_sh;
+    s.d.materials = (const rt_packed_material*)s.materials;
+    s.d.textures = (const rt_texture*)s.textures;
+    s.d.texture_data = (const uint32_t*)s.texture_data;
+    s.d.lights = (const float4*)s.lights;
+    s.d.env = (const float4*)s.env;
+    s.d.env_w = (int)sd->env_width;
+    s.d.env_h = (int)sd->env_height;
+    s.d.light_count = sd->num_lights;
+    s.valid = true;
+    return RT_OK;
+}
+
+// ---- frame -----------------------------------------------------------------
+int rt_frame_create(rt_ctx* ctx, const rt_frame_desc* fd, rt_frame** out)
+{
+    if (!ctx || !fd || !out) return fail(ctx, "rt_frame_create: NULL argument");
+    *out = nullptr;
+    if (fd->width == 0 || fd->height == 0) return fail(ctx, "rt_frame_create: empty image");
+    if (fd->tile_count == 0 || fd->tile_rank >= fd->tile_count || fd->band_height == 0)
+        return fail(ctx, "rt_frame_create: bad tile description");
+    (void)hipSetDevice(ctx->device);
+    rt_frame* f = new rt_frame();
+    f->ctx = ctx;
+    f->tile.width = fd->width; f->tile.height = fd->height;
+    f->tile.band_h = fd->band_height; f->tile.rank = fd->tile_rank; f->tile.nranks = fd->tile_count;
+    uint32_t rows = 0;
+    for (uint32_t band = fd->tile_rank; (uint64_t)band * fd->band_height < fd->height; band += fd->tile_count)
+    {
+        uint32_t start = band * fd->band_height;
+        uint32_t h = fd->height - start < fd->band_height ? fd->height - start : fd->band_height;
+        rows += h;
+    }
+    f->tile.local_rows = rows;
+    if ((uint64_t)rows * fd->width > 0x7FFFFFFFull) { delete f; return fail(ctx, "rt_frame_create: tile too large"); }
+    f->n_local = rows * fd->width;
+    size_t n = f->n_local ? f->n_local : 1;
+    f->trace_blocks = (uint32_t)ctx->prop.multiProcessorCount * 12u;
+    f->trace_blocks = (f->trace_blocks + 7u) & ~7u;
+    size_t q = n * sizeof(float4);
+    void** ptrs[] = {(void**)&f->o4[0], (void**)&f->o4[1], (void**)&f->d4[0], (void**)&f->d4[1], (void**)&f->thr[0],
+        (void**)&f->thr[1], (void**)&f->hits, (void**)&f->sh_o4, (void**)&f->sh_d4, (void**)&f->sh_ls,
+        (void**)&f->radiance, (void**)&f->resolved};
+    for (void** p : ptrs) *p = nullptr;
+    f->counters = nullptr; f->spill = nullptr;
+    bool ok = true;
+    for (void** p : ptrs) ok = ok && hipMalloc(p, q) == hipSuccess;
+    ok = ok && hipMalloc((void**)&f->counters, sizeof(DCounters)) == hipSuccess;
+    size_t spill_bytes = (size_t)f->trace_blocks * 64 * (RT_TRACE_STACK_MAX - RT_TRACE_STACK_LDS) * sizeof(uint2);
+    ok = ok && hipMalloc((void**)&f->spill, spill_bytes) == hipSuccess;
+    if (!ok)
+    {
+        rt_frame_destroy(f);
+        return fail(ctx, "rt_frame_create: out of device memory");
+    }
+    memset(&f->camera, 0, sizeof(f->camera));
+    *out = f;
+    return rt_reset(f);                                  // the reference ctor ends with Reset(), cl_pt_integrator.cpp:258
+}
+
+int rt_frame_destroy(rt_frame* f)
+{
+    if (!f) return RT_OK;
+    (void)hipSetDevice(f->ctx->device);
+    (void)hipStreamSynchronize(f->ctx->stream);
+    void* ptrs[] = {f->o4[0], f->o4[1], f->d4[0], f->d4[1], f->thr[0], f->thr[1], f->hits, f->sh_o4, f->sh_d4, f->sh_ls,
+        f->radiance, f->resolved, f->counters, f->spill};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    delete f;
+    return RT_OK;
+}
+
+uint32_t rt_frame_local_rows(rt_frame* f) { return f ? f->tile.local_rows : 0; }
+
+uint32_t rt_frame_global_row(rt_frame* f, uint32_t ly)
+{
+    if (!f) return 0;
+    uint32_t band = ly / f->tile.band_h;
+    return (band * f->tile.nranks + f->tile.rank) * f->tile.band_h + (ly - band * f->tile.band_h);
+}
+
+int rt_set_option(rt_frame* f, int option, uint32_t value)
+{
+    if (!f) return fail(nullptr, "rt_set_option: frame is NULL");
+    switch (option)
+    {
+    case RT_OPT_MAX_BOUNCES:
+        if (value > RT_MAX_BOUNCES_LIMIT) return fail(f->ctx, "rt_set_option: max_bounces above RT_MAX_BOUNCES_LIMIT");
+        f->max_bounces = value;
+        return RT_OK;
+    case RT_OPT_WHITE_FURNACE: f->white_furnace = value ? 1 : 0; return RT_OK;
+    case RT_OPT_SAMPLER:
+        if (value != 0) return fail(f->ctx, "rt_set_option: only SamplerType::kRandom is implemented");
+        return RT_OK;
+    case RT_OPT_AOV:
+        if (value != 0) return fail(f->ctx, "rt_set_option: only AOV::kShadedColor is implemented");
+        return RT_OK;
+    case RT_OPT_DENOISER:
+        if (value != 0) return fail(f->ctx, "rt_set_option: the temporal denoiser is not implemented");
+        return RT_OK;
+    case RT_OPT_TRACE_DROP_LAST_BOUNCE_RAYS: f->drop_last = value ? 1 : 0; return RT_OK;
+    default: return fail(f->ctx, "rt_set_option: unknown option");
+    }
+}
+
+int rt_set_camera(rt_frame* f, const rt_camera* camera)
+{
+    if (!f || !camera) return fail(nullptr, "rt_set_camera: NULL argument");
+    f->camera = *camera;
+    return RT_OK;
+}
+
+// ---- stages ----------------------------------------------------------------
+#define FRAME_PROLOGUE(f, name)                                                         \
+    if (!(f)) return fail(nullptr, name ": frame is NULL");                             \
+    rt_ctx* ctx = (f)->ctx;                                                             \
+    if (!ctx->scene.valid) return fail(ctx, name ": no scene uploaded");                \
+    (void)hipSetDevice(ctx->device)
+
+int rt_reset(rt_frame* f)                               // CLPathTraceIntegrator::Reset, cl_pt_integrator.cpp:497-508
+{
+    if (!f) return fail(nullptr, "rt_reset: frame is NULL");
+    rt_ctx* ctx = f->ctx;
+    (void)hipSetDevice(ctx->device);
+    f->sample_count = 0;
+    f->prev_bounces = 0;
+    HIPCHK(ctx, hipMemsetAsync(f->radiance, 0, (size_t)(f->n_local ? f->n_local : 1) * sizeof(float4), ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(f->counters, 0, sizeof(DCounters), ctx->stream));
+    return RT_OK;
+}
+
+int rt_generate_rays(rt_frame* f)                       // GenerateRays, :516-520
+{
+    FRAME_PROLOGUE(f, "rt_generate_rays");
+    float tan_half_fov = rt_tanf(0.5f * f->camera.fov);  // raygeneration.cl:108, uniform -> host
+    uint32_t blocks = (f->n_local + 255u) / 256u;
+    if (blocks == 0) blocks = 1;
+    hipLaunchKernelGGL(k_raygen, dim3(blocks), dim3(256), 0, ctx->stream, f->tile, f->camera, f->sample_count,
+        tan_half_fov, f->prev_bounces, f->o4[0], f->d4[0], f->thr[0], f->counters);
+    f->prev_bounces = f->max_bounces;
+    HIPCHK(ctx, hipGetLastError());
+    return RT_OK;
+}
+
+int rt_intersect(rt_frame* f, uint32_t bounce)          // IntersectRays, :522-539
+{
+    FRAME_PROLOGUE(f, "rt_intersect");
+    if (bounce > RT_MAX_BOUNCES_LIMIT) return fail(ctx, "rt_intersect: bounce out of range");
+    uint32_t in = bounce & 1u;
+    hipLaunchKernelGGL(k_trace<false>, dim3(f->trace_blocks), dim3(64), 0, ctx->stream, ctx->scene.d, f->o4[in],
+        f->d4[in], &f->counters->queue[bounce], f->hits, (const float4*)nullptr, (float4*)nullptr, f->spill);
+    HIPCHK(ctx, hipGetLastError());
+    return RT_OK;
+}
+
+int rt_shade_miss(rt_frame* f, uint32_t) { return f ? RT_OK : fail(nullptr, "rt_shade_miss: frame is NULL"); }
+int rt_clear_outgoing_counter(rt_frame* f, uint32_t) { return f ? RT_OK : fail(nullptr, "rt_clear_outgoing_counter: frame is NULL"); }
+int rt_clear_shadow_counter(rt_frame* f) { return f ? RT_OK : fail(nullptr, "rt_clear_shadow_counter: frame is NULL"); }
+int rt_accumulate_direct(rt_frame* f) { return f ? RT_OK : fail(nullptr, "rt_accumulate_direct: frame is NULL"); }
+
+int rt_shade(rt_frame* f, uint32_t bounce)              // ShadeMissedRays + ShadeSurfaceHits, :582-643
+{
+    FRAME_PROLOGUE(f, "rt_shade");
+    if (bounce > RT_MAX_BOUNCES_LIMIT) return fail(ctx, "rt_shade: bounce out of range");
+    uint32_t in = bounce & 1u, out = (bounce + 1u) & 1u;
+    ShadeArgs a;
+    a.in_o4 = f->o4[in]; a.in_d4 = f->d4[in]; a.in_thr = f->thr[in]; a.hits = f->hits;
+    a.out_o4 = f->o4[out]; a.out_d4 = f->d4[out]; a.out_thr = f->thr[out];
+    a.sh_o4 = f->sh_o4; a.sh_d4 = f->sh_d4; a.sh_ls = f->sh_ls;
+    a.radiance = f->radiance; a.counters = f->counters;
+    a.bounce = bounce; a.sample_idx = f->sample_count;
+    a.emit_outgoing = (f->drop_last && bounce >= f->max_bounces) ? 0u : 1u;
+    uint32_t blocks = (f->n_local + 255u) / 256u;
+    if (blocks == 0) blocks = 1;
+    if (f->white_furnace)
+        hipLaunchKernelGGL(k_shade<true>, dim3(blocks), dim3(256), 0, ctx->stream, ctx->scene.d, f->tile, a);
+    else
+        hipLaunchKernelGGL(k_shade<false>, dim3(blocks), dim3(256), 0, ctx->stream, ctx->scene.d, f->tile, a);
+    HIPCHK(ctx, hipGetLastError());
+    return RT_OK;
+}
+
+int rt_intersect_shadow(rt_frame* f, uint32_t bounce)   // IntersectShadowRays + AccumulateDirectSamples, :564-580,645-649
+{
+    FRAME_PROLOGUE(f, "rt_intersect_shadow");
+    if (bounce > RT_MAX_BOUNCES_LIMIT) return fail(ctx, "rt_intersect_shadow: bounce out of range");
+    hipLaunchKernelGGL(k_trace<true>, dim3(f->trace_blocks), dim3(64), 0, ctx->stream, ctx->scene.d, f->sh_o4,
+        f->sh_d4, &f->counters->shadow[bounce], (float4*)nullptr, f->sh_ls, f->radiance, f->spill);
+    HIPCHK(ctx, hipGetLastError());
+    return RT_OK;
+}
+
+int rt_advance_sample(rt_frame* f)                      // AdvanceSampleCount, :510-514
+{
+    if (!f) return fail(nullptr, "rt_advance_sample: frame is NULL");
+    f->sample_count++;
+    return RT_OK;
+}
+
+int rt_integrate(rt_frame* f, uint32_t n_samples)       // n x Integrator::Integrate(), integrator.cpp:27-59
+{
+    FRAME_PROLOGUE(f, "rt_integrate");
+    for (uint32_t s = 0; s < n_samples; ++s)
+    {
+        if (rt_generate_rays(f) != RT_OK) return RT_ERROR;
+        for (uint32_t bounce = 0; bounce <= f->max_bounces; ++bounce)
+        {
+            if (rt_intersect(f, bounce) != RT_OK) return RT_ERROR;
+            if (rt_shade(f, bounce) != RT_OK) return RT_ERROR;
+            if (rt_intersect_shadow(f, bounce) != RT_OK) return RT_ERROR;
+        }
+        f->sample_count++;
+    }
+    return RT_OK;
+}
+
+// ---- output ----------------------------------------------------------------
+int rt_frame_resolve(rt_frame* f, float* host_rgba)     // ResolveRadiance, :677-684
+{
+    if (!f || !host_rgba) return fail(nullptr, "rt_frame_resolve: NULL argument");
+    rt_ctx* ctx = f->ctx;
+    (void)hipSetDevice(ctx->device);
+    if (f->n_local == 0) return RT_OK;
+    uint32_t blocks = (f->n_local + 255u) / 256u;
+    hipLaunchKernelGGL(k_resolve, dim3(blocks), dim3(256), 0, ctx->stream, f->radiance, f->resolved, f->n_local,
+        f->sample_count);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(host_rgba, f->resolved, (size_t)f->n_local * sizeof(float4), hipMemcpyDeviceToHost,
+        ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));      // the frame's only host sync, like Finish() at :682
+    return RT_OK;
+}
+
+int rt_frame_read_radiance(rt_frame* f, float* host_rgba)
+{
+    if (!f || !host_rgba) return fail(nullptr, "rt_frame_read_radiance: NULL argument");
+    rt_ctx* ctx = f->ctx;
+    (void)hipSetDevice(ctx->device);
+    if (f->n_local == 0) return RT_OK;
+    HIPCHK(ctx, hipMemcpyAsync(host_rgba, f->radiance, (size_t)f->n_local * sizeof(float4), hipMemcpyDeviceToHost,
+        ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+void* rt_frame_radiance_device_ptr(rt_frame* f) { return f ? (void*)f->radiance : nullptr; }
+uint32_t rt_frame_sample_count(rt_frame* f) { return f ? f->sample_count : 0; }
+
+int rt_frame_get_stats(rt_frame* f, rt_stats* out)
+{
+    if (!f || !out) return fail(nullptr, "rt_frame_get_stats: NULL argument");
+    rt_ctx* ctx = f->ctx;
+    (void)hipSetDevice(ctx->device);
+    hipLaunchKernelGGL(k_fold_counters, dim3(1), dim3(64), 0, ctx->stream, f->counters, f->prev_bounces);
+    DCounters h;
+    HIPCHK(ctx, hipMemcpyAsync(&h, f->counters, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    out->closest_rays = h.total_closest;
+    out->shadow_rays = h.total_shadow;
+    out->samples = f->sample_count;
+    for (int i = 0; i < 64; ++i) { out->last_active[i] = h.last_queue[i]; out->last_shadow[i] = h.last_shadow[i]; }
+    return RT_OK;
+}
+
+// ---- debug / parity --------------------------------------------------------
+int rt_frame_debug_read_queue(rt_frame* f, int which, uint32_t bounce, rt_ray* rays, uint32_t* pixel_indices,
+    rt_float4* payload, uint32_t* count)
+{
+    if (!f || !count) return fail(nullptr, "rt_frame_debug_read_queue: NULL argument");
+    rt_ctx* ctx = f->ctx;
+    (void)hipSetDevice(ctx->device);
+    if (bounce > RT_MAX_BOUNCES_LIMIT + 1) return fail(ctx, "rt_frame_debug_read_queue: bounce out of range");
+    DCounters h;
+    HIPCHK(ctx, hipMemcpyAsync(&h, f->counters, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    uint32_t n = which == 0 ? h.queue[bounce] : h.shadow[bounce];
+    if (n > f->n_local) return fail(ctx, "rt_frame_debug_read_queue: corrupt counter");
+    *count = n;
+    if (n == 0) return RT_OK;
+    const float4* so = which == 0 ? f->o4[bounce & 1u] : f->sh_o4;
+    const float4* sdir = which == 0 ? f->d4[bounce & 1u] : f->sh_d4;
+    const float4* sp = which == 0 ? f->thr[bounce & 1u] : f->sh_ls;
+    std::vector<float4> o(n), d(n), p(n);
+    HIPCHK(ctx, hipMemcpy(o.data(), so, (size_t)n * 16, hipMemcpyDeviceToHost));
+    HIPCHK(ctx, hipMemcpy(d.data(), sdir, (size_t)n * 16, hipMemcpyDeviceToHost));
+    HIPCHK(ctx, hipMemcpy(p.data(), sp, (size_t)n * 16, hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < n; ++i)
+    {
+        uint32_t local_pix;
+        memcpy(&local_pix, &d[i].w, 4);
+        if (rays)
+        {
+            rays[i].origin.x = o[i].x; rays[i].origin.y = o[i].y; rays[i].origin.z = o[i].z; rays[i].origin.w = 0.0f;
+            rays[i].direction.x = d[i].x; rays[i].direction.y = d[i].y; rays[i].direction.z = d[i].z;
+            rays[i].direction.w = o[i].w;
+        }
+        if (pixel_indices)
+        {
+            uint32_t ly = local_pix / f->tile.width, px = local_pix - ly * f->tile.width;
+            pixel_indices[i] = rt_frame_global_row(f, ly) * f->tile.width + px;   // GLOBAL pixel index
+        }
+        if (payload) { payload[i].x = p[i].x; payload[i].y = p[i].y; payload[i].z = p[i].z; payload[i].w = 0.0f; }
+    }
+    return RT_OK;
+}
+
+int rt_frame_debug_read_hits(rt_frame* f, rt_hit* hits, uint32_t count)
+{
+    if (!f || !hits) return fail(nullptr, "rt_frame_debug_read_hits: NULL argument");
+    rt_ctx* ctx = f->ctx;
+    (void)hipSetDevice(ctx->device);
+    if (count > f->n_local) return fail(ctx, "rt_frame_debug_read_hits: count too large");
+    std::vector<float4> h(count ? count : 1);
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipMemcpy(h.data(), f->hits, (size_t)count * 16, hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < count; ++i)
+    {
+        hits[i].bc.x = h[i].x; hits[i].bc.y = h[i].y;
+        memcpy(&hits[i].primitive_id, &h[i].z, 4);
+        hits[i].t = h[i].w;
+    }
+    return RT_OK;
+}
+
+int rt_debug_eval(rt_ctx* ctx, int fn, const float* a, const float* b, float* out, uint32_t n)
+{
+    if (!ctx || !a || !out) return fail(ctx, "rt_debug_eval: NULL argument");
+    (void)hipSetDevice(ctx->device);
+    float *da = nullptr, *db = nullptr, *dout = nullptr;
+    HIPCHK(ctx, hipMalloc((void**)&da, (size_t)n * 4 + 16));
+    HIPCHK(ctx, hipMalloc((void**)&dout, (size_t)n * 4 + 16));
+    HIPCHK(ctx, hipMemcpy(da, a, (size_t)n * 4, hipMemcpyHostToDevice));
+    if (b)
+    {
+        HIPCHK(ctx, hipMalloc((void**)&db, (size_t)n * 4 + 16));
+        HIPCHK(ctx, hipMemcpy(db, b, (size_t)n * 4, hipMemcpyHostToDevice));
+    }
+    hipLaunchKernelGGL(k_debug_eval, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, fn, da, db, dout, n);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipMemcpy(out, dout, (size_t)n * 4, hipMemcpyDeviceToHost));
+    (void)hipFree(da); (void)hipFree(dout);
+    if (db) (void)hipFree(db);
+    return RT_OK;
+}
+
+} // extern "C"
