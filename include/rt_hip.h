@@ -102,7 +102,8 @@ enum rt_option
     RT_OPT_SAMPLER = 2,        /* Integrator::SetSamplerType: 0 = kRandom (only one implemented) */
     RT_OPT_AOV = 3,            /* Integrator::SetAOV: 0 = kShadedColor (only one implemented) */
     RT_OPT_DENOISER = 4,       /* Integrator::EnableDenoiser: 0 (only value implemented) */
-    RT_OPT_TRACE_DROP_LAST_BOUNCE_RAYS = 5  /* 1 (default): do not emit the never-traced rays of the last bounce */
+    RT_OPT_TRACE_DROP_LAST_BOUNCE_RAYS = 5, /* 1 (default): do not emit the never-traced rays of the last bounce */
+    RT_OPT_PROFILE_KERNELS = 6  /* 1: bracket every kernel launch with HIP events on the context stream */
 };
 int rt_set_option(rt_frame* frame, int option, uint32_t value);
 int rt_set_camera(rt_frame* frame, const rt_camera* camera);       /* SetCameraData, cl_pt_integrator.cpp:365-371 */
@@ -148,6 +149,21 @@ typedef struct rt_stats
     uint32_t last_shadow[64];
 } rt_stats;
 int rt_frame_get_stats(rt_frame* frame, rt_stats* out);
+
+/* ---- per-kernel timing (RT_OPT_PROFILE_KERNELS): HIP-event durations of the
+ * launches since the option was switched on / since the last call, summed per
+ * kernel class.  Synchronises the stream. */
+typedef struct rt_profile
+{
+    double ms_raygen, ms_trace_closest, ms_shade, ms_trace_shadow;
+    uint32_t n_raygen, n_trace_closest, n_shade, n_trace_shadow;
+} rt_profile;
+int rt_frame_get_profile(rt_frame* frame, rt_profile* out);
+
+/* D2D copy of the running-sum radiance (float4[local_rows*width]) into a caller
+ * buffer on the same device (e.g. a tensor handed to an RCCL gather); ordered
+ * on the context stream and completed on return. */
+int rt_frame_copy_radiance(rt_frame* frame, void* device_dst);
 
 /* ---- debug / parity access: copy a ray queue back in the reference's layouts.
  * which: 0 = incoming queue of `bounce` (rays_buffer_[bounce&1]), 1 = shadow queue.

@@ -22,6 +22,12 @@ class rt_stats(C.Structure):
                 ("last_active", C.c_uint32 * 64), ("last_shadow", C.c_uint32 * 64)]
 
 
+class rt_profile(C.Structure):
+    _fields_ = [("ms_raygen", C.c_double), ("ms_trace_closest", C.c_double), ("ms_shade", C.c_double),
+                ("ms_trace_shadow", C.c_double), ("n_raygen", C.c_uint32), ("n_trace_closest", C.c_uint32),
+                ("n_shade", C.c_uint32), ("n_trace_shadow", C.c_uint32)]
+
+
 class rt_scene_desc(C.Structure):
     _fields_ = [("triangles", C.c_void_p), ("num_triangles", C.c_uint32),
                 ("nodes", C.c_void_p), ("num_nodes", C.c_uint32),
@@ -46,10 +52,10 @@ EXPORTS = [
     "rt_generate_rays", "rt_intersect", "rt_shade_miss", "rt_clear_outgoing_counter", "rt_clear_shadow_counter",
     "rt_shade", "rt_intersect_shadow", "rt_accumulate_direct", "rt_advance_sample", "rt_integrate",
     "rt_frame_resolve", "rt_frame_read_radiance", "rt_frame_radiance_device_ptr", "rt_frame_sample_count",
-    "rt_frame_get_stats", "rt_frame_debug_read_queue", "rt_frame_debug_read_hits", "rt_debug_eval",
+    "rt_frame_get_stats", "rt_frame_get_profile", "rt_frame_copy_radiance", "rt_frame_debug_read_queue", "rt_frame_debug_read_hits", "rt_debug_eval",
 ]
 
-OPT_MAX_BOUNCES, OPT_WHITE_FURNACE, OPT_SAMPLER, OPT_AOV, OPT_DENOISER, OPT_DROP_LAST = range(6)
+OPT_MAX_BOUNCES, OPT_WHITE_FURNACE, OPT_SAMPLER, OPT_AOV, OPT_DENOISER, OPT_DROP_LAST, OPT_PROFILE = range(7)
 
 
 def load():
@@ -81,6 +87,8 @@ def load():
         "rt_frame_resolve": (i32, [vp, vp]), "rt_frame_read_radiance": (i32, [vp, vp]),
         "rt_frame_radiance_device_ptr": (vp, [vp]), "rt_frame_sample_count": (u32, [vp]),
         "rt_frame_get_stats": (i32, [vp, C.POINTER(rt_stats)]),
+        "rt_frame_get_profile": (i32, [vp, C.POINTER(rt_profile)]),
+        "rt_frame_copy_radiance": (i32, [vp, vp]),
         "rt_frame_debug_read_queue": (i32, [vp, i32, u32, vp, vp, vp, C.POINTER(u32)]),
         "rt_frame_debug_read_hits": (i32, [vp, vp, u32]),
         "rt_debug_eval": (i32, [vp, i32, vp, vp, vp, u32]),
@@ -221,6 +229,14 @@ class Frame:
         st = rt_stats()
         self._c(self.lib.rt_frame_get_stats(self.handle, C.byref(st)))
         return st
+
+    def profile(self):
+        p = rt_profile()
+        self._c(self.lib.rt_frame_get_profile(self.handle, C.byref(p)))
+        return p
+
+    def copy_radiance_to(self, device_ptr):
+        self._c(self.lib.rt_frame_copy_radiance(self.handle, device_ptr))
 
     def read_queue(self, which, bounce):
         n_max = self.local_rows * self.width

@@ -11,7 +11,7 @@
  *   (1) the HIP kernels (raytracing_amd/csrc/kernels.hip),
  *   (2) the C restatement oracle (oracle/oracle.c),
  *   (3) the builtin shim under the reference's own unmodified .cl kernels
- *       (oracle/ref_shim/cl_builtins.cpp -> oracle/_ref/libref.so).
+ *       (oracle/ref_shim/cl_builtins.cpp, the reference-kernel build).
  * Because binary64 + - * / sqrt are correctly rounded on x86-64 and on gfx950
  * (and every translation unit is built with -ffp-contract=off and no
  * fast-math), the three agree BIT FOR BIT, which turns the radiance parity gate

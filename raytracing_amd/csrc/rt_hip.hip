@@ -59,6 +59,11 @@ struct rt_frame
     uint32_t drop_last = 1;
     uint32_t sample_count = 0;
     uint32_t prev_bounces = 0;
+    // RT_OPT_PROFILE_KERNELS
+    uint32_t profile = 0;
+    struct Span { hipEvent_t a, b; int cls; };
+    std::vector<Span> spans;
+    std::vector<hipEvent_t> event_pool;
 };
 
 namespace
@@ -391,6 +396,8 @@ int rt_frame_destroy(rt_frame* f)
     void* ptrs[] = {f->o4[0], f->o4[1], f->d4[0], f->d4[1], f->thr[0], f->thr[1], f->hits, f->sh_o4, f->sh_d4, f->sh_ls,
         f->radiance, f->resolved, f->counters, f->spill};
     for (void* p : ptrs) if (p) (void)hipFree(p);
+    for (auto& s : f->spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
+    for (auto e : f->event_pool) (void)hipEventDestroy(e);
     delete f;
     return RT_OK;
 }
@@ -424,6 +431,7 @@ int rt_set_option(rt_frame* f, int option, uint32_t value)
         if (value != 0) return fail(f->ctx, "rt_set_option: the temporal denoiser is not implemented");
         return RT_OK;
     case RT_OPT_TRACE_DROP_LAST_BOUNCE_RAYS: f->drop_last = value ? 1 : 0; return RT_OK;
+    case RT_OPT_PROFILE_KERNELS: f->profile = value ? 1 : 0; return RT_OK;
     default: return fail(f->ctx, "rt_set_option: unknown option");
     }
 }
@@ -436,6 +444,28 @@ int rt_set_camera(rt_frame* f, const rt_camera* camera)
 }
 
 // ---- stages ----------------------------------------------------------------
+namespace
+{
+// RAII bracket: records a start event now and a stop event at scope exit
+struct KernelSpan
+{
+    rt_frame* f; int cls; hipEvent_t a = nullptr, b = nullptr;
+    KernelSpan(rt_frame* f_, int cls_) : f(f_), cls(cls_)
+    {
+        if (!f->profile) return;
+        auto get = [&]() { hipEvent_t e = nullptr; if (!f->event_pool.empty()) { e = f->event_pool.back(); f->event_pool.pop_back(); } else (void)hipEventCreate(&e); return e; };
+        a = get(); b = get();
+        (void)hipEventRecord(a, f->ctx->stream);
+    }
+    ~KernelSpan()
+    {
+        if (!a) return;
+        (void)hipEventRecord(b, f->ctx->stream);
+        f->spans.push_back({a, b, cls});
+    }
+};
+} // namespace
+
 #define FRAME_PROLOGUE(f, name)                                                         \
     if (!(f)) return fail(nullptr, name ": frame is NULL");                             \
     rt_ctx* ctx = (f)->ctx;                                                             \
@@ -460,6 +490,7 @@ int rt_generate_rays(rt_frame* f)                       // GenerateRays, :516-52
     float tan_half_fov = rt_tanf(0.5f * f->camera.fov);  // raygeneration.cl:108, uniform -> host
     uint32_t blocks = (f->n_local + 255u) / 256u;
     if (blocks == 0) blocks = 1;
+    KernelSpan span(f, 0);
     hipLaunchKernelGGL(k_raygen, dim3(blocks), dim3(256), 0, ctx->stream, f->tile, f->camera, f->sample_count,
         tan_half_fov, f->prev_bounces, f->o4[0], f->d4[0], f->thr[0], f->counters);
     f->prev_bounces = f->max_bounces;
@@ -472,6 +503,7 @@ int rt_intersect(rt_frame* f, uint32_t bounce)          // IntersectRays, :522-5
     FRAME_PROLOGUE(f, "rt_intersect");
     if (bounce > RT_MAX_BOUNCES_LIMIT) return fail(ctx, "rt_intersect: bounce out of range");
     uint32_t in = bounce & 1u;
+    KernelSpan span(f, 1);
     hipLaunchKernelGGL(k_trace<false>, dim3(f->trace_blocks), dim3(64), 0, ctx->stream, ctx->scene.d, f->o4[in],
         f->d4[in], &f->counters->queue[bounce], f->hits, (const float4*)nullptr, (float4*)nullptr, f->spill);
     HIPCHK(ctx, hipGetLastError());
@@ -497,6 +529,7 @@ int rt_shade(rt_frame* f, uint32_t bounce)              // ShadeMissedRays + Sha
     a.emit_outgoing = (f->drop_last && bounce >= f->max_bounces) ? 0u : 1u;
     uint32_t blocks = (f->n_local + 255u) / 256u;
     if (blocks == 0) blocks = 1;
+    KernelSpan span(f, 2);
     if (f->white_furnace)
         hipLaunchKernelGGL(k_shade<true>, dim3(blocks), dim3(256), 0, ctx->stream, ctx->scene.d, f->tile, a);
     else
@@ -509,6 +542,7 @@ int rt_intersect_shadow(rt_frame* f, uint32_t bounce)   // IntersectShadowRays +
 {
     FRAME_PROLOGUE(f, "rt_intersect_shadow");
     if (bounce > RT_MAX_BOUNCES_LIMIT) return fail(ctx, "rt_intersect_shadow: bounce out of range");
+    KernelSpan span(f, 3);
     hipLaunchKernelGGL(k_trace<true>, dim3(f->trace_blocks), dim3(64), 0, ctx->stream, ctx->scene.d, f->sh_o4,
         f->sh_d4, &f->counters->shadow[bounce], (float4*)nullptr, f->sh_ls, f->radiance, f->spill);
     HIPCHK(ctx, hipGetLastError());
@@ -584,6 +618,38 @@ int rt_frame_get_stats(rt_frame* f, rt_stats* out)
     out->shadow_rays = h.total_shadow;
     out->samples = f->sample_count;
     for (int i = 0; i < 64; ++i) { out->last_active[i] = h.last_queue[i]; out->last_shadow[i] = h.last_shadow[i]; }
+    return RT_OK;
+}
+
+int rt_frame_get_profile(rt_frame* f, rt_profile* out)
+{
+    if (!f || !out) return fail(nullptr, "rt_frame_get_profile: NULL argument");
+    rt_ctx* ctx = f->ctx;
+    (void)hipSetDevice(ctx->device);
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    memset(out, 0, sizeof(*out));
+    double* ms[4] = {&out->ms_raygen, &out->ms_trace_closest, &out->ms_shade, &out->ms_trace_shadow};
+    uint32_t* cnt[4] = {&out->n_raygen, &out->n_trace_closest, &out->n_shade, &out->n_trace_shadow};
+    for (auto& s : f->spans)
+    {
+        float t = 0.0f;
+        if (hipEventElapsedTime(&t, s.a, s.b) == hipSuccess) { *ms[s.cls] += t; (*cnt[s.cls])++; }
+        f->event_pool.push_back(s.a);
+        f->event_pool.push_back(s.b);
+    }
+    f->spans.clear();
+    return RT_OK;
+}
+
+int rt_frame_copy_radiance(rt_frame* f, void* device_dst)
+{
+    if (!f || !device_dst) return fail(nullptr, "rt_frame_copy_radiance: NULL argument");
+    rt_ctx* ctx = f->ctx;
+    (void)hipSetDevice(ctx->device);
+    if (f->n_local == 0) return RT_OK;
+    HIPCHK(ctx, hipMemcpyAsync(device_dst, f->radiance, (size_t)f->n_local * sizeof(float4), hipMemcpyDeviceToDevice,
+        ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return RT_OK;
 }
 

@@ -1,0 +1,19 @@
+// bvh.hpp -- binned-SAH BVH2 builder producing the reference's LinearBVHNode[]
+// (reference: src/bvh.hpp, src/bvh.cpp:36-245).
+#pragma once
+#include "acceleration_structure.hpp"
+
+namespace rt
+{
+class Bvh : public AccelerationStructure
+{
+public:
+    void BuildCPU(std::vector<Triangle>& triangles) override;
+    std::vector<LinearBVHNode> const& GetNodes() const override { return nodes_; }
+    // verbose = print the two progress lines the reference prints (bvh.cpp:38,55-58)
+    bool verbose = false;
+
+private:
+    std::vector<LinearBVHNode> nodes_;
+};
+} // namespace rt

@@ -1,0 +1,81 @@
+// main.cpp -- headless command line front end with the reference's flags
+// (src/main.cpp:34-58: -w -h --scene --scale --flip_yz) plus the knobs the GUI
+// exposed (--bounces, --furnace, aperture/focus) and --spp / --out for batch use.
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <string>
+#include "render.hpp"
+
+static void WritePFM(const char* path, const std::vector<float>& rgba, unsigned w, unsigned h)
+{
+    FILE* f = fopen(path, "wb");
+    if (!f) return;
+    fprintf(f, "PF\n%u %u\n-1.0\n", w, h);
+    for (unsigned y = 0; y < h; ++y)
+        for (unsigned x = 0; x < w; ++x) fwrite(&rgba[((size_t)y * w + x) * 4], sizeof(float), 3, f);
+    fclose(f);
+}
+
+int main(int argc, char** argv)
+{
+    try
+    {
+        unsigned width = 1280, height = 720, spp = 16, bounces = 3;
+        std::string scene_path = "assets/ShaderBalls.obj", out;
+        float scale = 1.0f, aperture = 0.0f, focus = 10.0f;
+        bool flip_yz = false, furnace = false;
+        for (int i = 1; i < argc; ++i)
+        {
+            auto next = [&]() -> const char* { if (i + 1 >= argc) { std::cerr << "missing value for " << argv[i] << "\n"; exit(2); } return argv[++i]; };
+            if (!strcmp(argv[i], "-w")) width = (unsigned)atoi(next());
+            else if (!strcmp(argv[i], "-h")) height = (unsigned)atoi(next());
+            else if (!strcmp(argv[i], "--scene")) scene_path = next();
+            else if (!strcmp(argv[i], "--scale")) scale = (float)atof(next());
+            else if (!strcmp(argv[i], "--flip_yz")) flip_yz = atoi(next()) != 0;
+            else if (!strcmp(argv[i], "--spp")) spp = (unsigned)atoi(next());
+            else if (!strcmp(argv[i], "--bounces")) bounces = (unsigned)atoi(next());
+            else if (!strcmp(argv[i], "--furnace")) furnace = atoi(next()) != 0;
+            else if (!strcmp(argv[i], "--aperture")) aperture = (float)atof(next());
+            else if (!strcmp(argv[i], "--focus")) focus = (float)atof(next());
+            else if (!strcmp(argv[i], "--out")) out = next();
+            else if (!strcmp(argv[i], "--help"))
+            {
+                std::cout << "rt_render -w W -h H --scene file.obj [--scale s] [--flip_yz 0|1] [--spp n] [--bounces b]"
+                             " [--furnace 0|1] [--aperture a] [--focus d] [--out image.pfm]\n";
+                return 0;
+            }
+        }
+        rt::Scene scene(scene_path.c_str(), scale, flip_yz);
+        scene.AddDirectionalLight({-0.6f, -1.5f, 3.5f}, {15.0f, 10.0f, 5.0f});   // main.cpp:58
+        rt::Render render(width, height, scene);
+        std::cout << "device: " << render.GetContext().DeviceName() << std::endl;
+        rt::Camera cam = rt::DefaultCamera(width, height);
+        cam.aperture = aperture;
+        cam.focus_distance = focus;
+        render.SetCamera(cam);
+        render.GetIntegrator().SetMaxBounces(bounces);
+        render.GetIntegrator().EnableWhiteFurnace(furnace);
+        auto t0 = std::chrono::steady_clock::now();
+        render.RenderSamples(spp);
+        render.GetContext().Finish();
+        double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        rt_stats st = render.GetIntegrator().GetStats();
+        double rays = (double)st.closest_rays + (double)st.shadow_rays;
+        std::cout << spp << " spp in " << dt << " s, " << rays / dt / 1e6 << " Mrays/s" << std::endl;
+        if (!out.empty())
+        {
+            std::vector<float> sum = render.GetIntegrator().ReadRadianceSum();
+            for (float& v : sum) v /= (float)spp;
+            WritePFM(out.c_str(), sum, width, height);
+        }
+    }
+    catch (std::exception& ex)
+    {
+        std::cerr << "Caught exception: " << ex.what() << std::endl;   // main.cpp:74-77
+        return 1;
+    }
+    return 0;
+}

@@ -1,0 +1,60 @@
+// scene.hpp -- the scene-loader surface the integrator consumes
+// (reference: src/scene/scene.hpp:34-67 -- same constructor, getters, Finalize,
+// AddPointLight, AddDirectionalLight).
+#pragma once
+#include <string>
+#include <unordered_map>
+#include <vector>
+#include "structures.hpp"
+
+namespace rt
+{
+bool LoadHDR(const char* filename, Image& result);   // Radiance RGBE (reference: src/loaders/hdr_loader.cpp:29-100)
+bool LoadTGA(const char* filename, Image& result);   // 8-bit TGA -> packed RGBA8 (reference path: LoadSTB, image_loader.cpp:30-63)
+
+class Scene
+{
+public:
+    // Loads an OBJ + MTL pair (main.cpp:56).  Throws std::runtime_error on failure.
+    Scene(const char* filename, float scale, bool flip_yz);
+    // Adopts caller-built arrays (procedural scenes / binary caches); no file IO.
+    Scene(std::vector<Triangle> triangles, std::vector<PackedMaterial> materials, std::vector<Texture> textures,
+        std::vector<std::uint32_t> texture_data);
+
+    std::vector<Triangle>& GetTriangles() { return triangles_; }
+    std::vector<Triangle> const& GetTriangles() const { return triangles_; }
+    std::vector<std::uint32_t> const& GetEmissiveIndices() const { return emissive_indices_; }
+    std::vector<PackedMaterial> const& GetMaterials() const { return materials_; }
+    std::vector<Texture> const& GetTextures() const { return textures_; }
+    std::vector<std::uint32_t> const& GetTextureData() const { return texture_data_; }
+    std::vector<Light> const& GetLights() const { return lights_; }
+    SceneInfo const& GetSceneInfo() const { return scene_info_; }
+    Image const& GetEnvImage() const { return env_image_; }
+
+    // Collects emissive triangles (after the BVH reorder), counts lights and loads
+    // the environment map -- by default the path the reference hard-codes,
+    // "assets/ibl/CGSkies_0036_free.hdr" relative to the CWD (scene.cpp:353-361).
+    void Finalize();
+    void SetEnvironmentPath(std::string path) { env_path_ = std::move(path); }
+    void SetEnvironmentImage(Image image) { env_image_ = std::move(image); env_preset_ = true; }
+    void AddPointLight(float3 origin, float3 radiance);
+    void AddDirectionalLight(float3 direction, float3 radiance);
+
+private:
+    void Load(const char* filename, float scale, bool flip_yz);
+    std::size_t LoadTexture(const std::string& filename);
+    void CollectEmissiveTriangles();
+
+    std::vector<Triangle> triangles_;
+    std::vector<std::uint32_t> emissive_indices_;
+    std::vector<PackedMaterial> materials_;
+    std::vector<Light> lights_;
+    std::vector<Texture> textures_;
+    std::vector<std::uint32_t> texture_data_;
+    std::unordered_map<std::string, std::size_t> loaded_textures_;
+    SceneInfo scene_info_ = {};
+    Image env_image_;
+    std::string env_path_ = "assets/ibl/CGSkies_0036_free.hdr";
+    bool env_preset_ = false;
+};
+} // namespace rt

@@ -62,3 +62,33 @@ def default_camera(width, height):
     cam["aperture"] = 0.0
     cam["focus_distance"] = 10.0
     return cam
+
+
+def _strip(a):
+    """Field-wise view of a structured array without padding members (the
+    reference leaves float3 padding uninitialised, mathlib.hpp:74-76)."""
+    import numpy.lib.recfunctions as rfn
+    out = []
+
+    def walk(arr, dt):
+        for name in dt.names:
+            sub = dt.fields[name][0]
+            if name in ("w", "padding", "pad"):
+                continue
+            if sub.names:
+                walk(arr[name], sub)
+            else:
+                out.append(np.ascontiguousarray(arr[name]).reshape(len(arr), -1).view(np.uint32))
+    walk(a, a.dtype)
+    return np.concatenate(out, axis=1) if out else np.zeros((len(a), 0), np.uint32)
+
+
+def records_equal(a, b):
+    """Bitwise equality of two record arrays over their payload fields."""
+    if a.dtype != b.dtype or a.shape != b.shape:
+        return False
+    if a.size == 0:
+        return True
+    if a.dtype.names is None:
+        return np.array_equal(a.view(np.uint8), b.view(np.uint8))
+    return np.array_equal(_strip(a), _strip(b))

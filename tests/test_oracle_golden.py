@@ -1,0 +1,79 @@
+"""The CPU oracle (oracle/oracle.c) against the golden vectors generated from the
+reference's own kernels (tests/golden/make_golden.py).  Bit-exact."""
+import numpy as np
+import pytest
+from tests.conftest import GOLDEN_CASES
+from tests import _oracle
+
+
+@pytest.mark.parametrize("case", GOLDEN_CASES, ids=[c[0] for c in GOLDEN_CASES])
+def test_oracle_reproduces_reference_radiance(case, golden_scenes, golden_radiance):
+    name, key, w, h, b, spp, furnace = case
+    g = golden_radiance
+    orc = _oracle.Oracle(w, h, golden_scenes[key], furnace=furnace)
+    orc.set_camera(g[name + "/camera"])
+    orc.set_max_bounces(b)
+    orc.integrate(spp)
+    assert np.array_equal(orc.radiance()[..., :3], g[name + "/radiance"])
+    assert np.array_equal(orc.resolve()[..., :3], g[name + "/resolved"])
+    assert tuple(int(x) for x in g[name + "/totals"]) == orc.ray_totals()
+    a, s = orc.last_counts(b + 1)
+    assert np.array_equal(a, g[name + "/last_active"]) and np.array_equal(s, g[name + "/last_shadow"])
+    assert orc.sample_count() == spp
+
+
+def test_oracle_reset_and_accumulation(golden_scenes, golden_radiance):
+    """Radiance is a running sum; a reset restarts the sample sequence (integrator.cpp:29-33)."""
+    g = golden_radiance
+    name = "cornell_64_b4_s2"
+    orc = _oracle.Oracle(64, 64, golden_scenes["cornell"])
+    orc.set_camera(g[name + "/camera"])
+    orc.set_max_bounces(4)
+    orc.integrate(1)
+    one = orc.radiance().copy()
+    orc.integrate(1)
+    two = orc.radiance()
+    assert np.array_equal(two[..., :3], g[name + "/radiance"])
+    assert (two[..., :3] >= one[..., :3]).all()
+    orc.set_max_bounces(4)      # SetMaxBounces requests a reset
+    orc.integrate(2)
+    assert np.array_equal(orc.radiance()[..., :3], g[name + "/radiance"])
+
+
+def test_wang_hash_and_sample_random_known_answers():
+    lib = _oracle.load()
+    # WangHash (utils.h:113-121) evaluated by hand-expanded integer arithmetic
+    def wang(x):
+        x &= 0xFFFFFFFF
+        x = ((x ^ 61) ^ (x >> 16)) & 0xFFFFFFFF
+        x = (x + (x << 3)) & 0xFFFFFFFF
+        x = x ^ (x >> 4)
+        x = (x * 0x27d4eb2d) & 0xFFFFFFFF
+        return x ^ (x >> 15)
+    for x in (0, 1, 61, 12345, 0xFFFFFFFF, 0x80000000, 921599):
+        assert lib.orc_wang_hash(x) == wang(x)
+    for (px, py, s, b, t) in ((0, 0, 0, 0, 0), (17, 5, 3, 2, 4), (1279, 719, 63, 8, 1)):
+        seed = wang(px)
+        seed = wang((seed + wang(py)) & 0xFFFFFFFF)
+        seed = wang((seed + wang(s)) & 0xFFFFFFFF)
+        seed = wang((seed + wang(b * 5 + t)) & 0xFFFFFFFF)
+        want = np.float32(np.float32(seed) * np.float32(2.3283064365386963e-10))
+        assert np.float32(lib.orc_sample_random(px, py, s, b, t)) == want
+
+
+def test_detmath_matches_correctly_rounded_double():
+    """rt_detmath.h returns the binary64 result rounded once to binary32."""
+    import math
+    lib = _oracle.load()
+    rng = np.random.RandomState(7)
+    bad = 0
+    for x in (rng.rand(2000) * 6.2831855).astype(np.float32):
+        bad += np.float32(lib.orc_sinf(float(x))) != np.float32(math.sin(float(x)))
+        bad += np.float32(lib.orc_cosf(float(x))) != np.float32(math.cos(float(x)))
+    for u in rng.rand(2000).astype(np.float32):
+        bad += np.float32(lib.orc_powf(float(u), 2.200000047683716)) != np.float32(math.pow(float(u), 2.200000047683716))
+        bad += np.float32(lib.orc_acosf(float(u))) != np.float32(math.acos(float(u)))
+    assert bad <= 2     # <= 1 ulp in ~1e-7 of cases (double rounding)
+    assert lib.orc_powf(0.0, 2.2) == 0.0 and lib.orc_powf(-2.0, 5.0) == -32.0
+    assert math.isnan(lib.orc_powf(-2.0, 0.5))
+    assert np.float32(lib.orc_acosf(-1.0)) == np.float32(math.pi)
