@@ -1,0 +1,253 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark of the wavefront path-tracing hot path.
+
+  python bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one batch: one Integrator::Integrate()
+= one sample per pixel of the full frame (raygen, then per bounce: closest-hit
+trace, miss+shade, shadow trace+accumulate).  Workload at N = 1: BASELINE.json
+configs[1], "CornellBox_Dragon.obj 1280x720 64spp 8-bounce on 1 MI355X" -- the
+mesh is stripped from the reference checkout (.MISSING_LARGE_BLOBS), so the
+deterministic stand-in of SURVEY.md section 8d is generated: the Cornell shell +
+an 871 200-triangle displaced blob with the `dragon` material + a 20 000-triangle
+sphere with the `teapot` material (raytracing_amd/scenes.py); default K = 64
+steps = the 64 spp of the config.  Metric = BASELINE.json's: Mrays/s, all
+bounces + shadow rays, counted by the device queue counters the reference itself
+keeps (ray_counter_buffer_, shadow_ray_counter_buffer_).
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): the frame is split
+into interleaved 8-row bands, the scene is replicated, there is no communication
+while rendering and ONE gather (RCCL) of the accumulated radiance to rank 0
+inside the timed region -> "scaling": "strong" (total work fixed).
+
+Extra objects on the JSON line:
+  roofline     dominant kernel = k_trace<closest>; achieved = algorithmic bytes
+               (48 + 32 n_nodes + 36 n_tris per ray, n_* measured by
+               the instrumented CPU oracle on the reference BVH2) x rays per
+               launch / HIP-event duration of those launches, measured live here.
+  cpu_baseline the reference's own OpenCL kernels compiled for x86-64
+               (oracle/_ref, kind "reference") or the C restatement (kind
+               "port"), timed on this box's host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+LIGHT = ((-0.6, -1.5, 3.5), (15.0, 10.0, 5.0))   # reference main.cpp:58
+
+
+def build_scene(args, host, S):
+    tris, mats = S.cornell_blob(args.blob_tris, args.ball_tris)
+    scene = host.Scene(arrays=dict(triangles=tris, materials=mats))
+    scene.add_directional_light(*LIGHT)
+    scene.set_env_path(os.path.join(ROOT, "assets", "ibl", "CGSkies_0036_free.hdr"))
+    return scene, len(tris)
+
+
+def cpu_legs(args, scene_arrays, cam_small, small_w, small_h):
+    """(a) instrumented oracle pass -> nodes/tris per ray; (b) timed CPU baseline."""
+    from tests import _oracle, _ref
+    orc = _oracle.Oracle(small_w, small_h, scene_arrays)
+    orc.set_camera(cam_small)
+    orc.set_max_bounces(args.bounces)
+    t0 = time.time()
+    orc.integrate(1)
+    t_orc = time.time() - t0
+    c, s = orc.ray_totals()
+    st = orc.stats()
+    per_ray = dict(closest_nodes=st["closest_nodes"] / max(c, 1), closest_tris=st["closest_tris"] / max(c, 1),
+                   shadow_nodes=st["shadow_nodes"] / max(s, 1), shadow_tris=st["shadow_tris"] / max(s, 1))
+    baseline = None
+    if not args.no_cpu_baseline:
+        cores = os.cpu_count() or 1
+        if _ref.available():
+            ri = _ref.RefIntegrator(small_w, small_h, scene_arrays, threads=cores)
+            ri.set_camera(cam_small)
+            ri.set_max_bounces(args.bounces)
+            ri.integrate(1)                                   # warm-up (page in, thread start)
+            r0 = sum(ri.ray_totals())
+            t0 = time.time()
+            n = 0
+            while True:
+                ri.integrate(1)
+                n += 1
+                if time.time() - t0 >= args.cpu_seconds or n >= 64:
+                    break
+            dt = time.time() - t0
+            rays = sum(ri.ray_totals()) - r0
+            baseline = dict(value=rays / dt / 1e6, unit="Mrays/s", cores=cores, kind="reference",
+                            sample="%d spp of the same scene at %dx%d, %d bounces (%.1f s; the reference's unmodified "
+                                   ".cl kernels compiled for x86-64, NDRange = %d-thread parallel-for)"
+                                   % (n, small_w, small_h, args.bounces, dt, cores))
+        else:
+            baseline = dict(value=(c + s) / t_orc / 1e6, unit="Mrays/s", cores=1, kind="port",
+                            sample="1 spp of the same scene at %dx%d, %d bounces (%.1f s, oracle/oracle.c, scalar)"
+                                   % (small_w, small_h, args.bounces, t_orc))
+    return per_ray, baseline
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--width", type=int, default=1280)
+    ap.add_argument("--height", type=int, default=720)
+    ap.add_argument("--bounces", type=int, default=8)
+    ap.add_argument("--blob-tris", type=int, default=871_200)
+    ap.add_argument("--ball-tris", type=int, default=20_000)
+    ap.add_argument("--band-height", type=int, default=8)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
+        args.gpus = world
+
+    import torch
+    import torch.distributed as dist
+    from raytracing_amd import capi, host, scenes as S, distributed as D
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)   # "nccl" is RCCL on ROCm
+
+    # ---- setup (untimed): scene, BVH, upload -------------------------------
+    scene, n_tris = build_scene(args, host, S)
+    t0 = time.time()
+    render = host.Render(args.width, args.height, scene, device=local_rank, tile_rank=rank, tile_count=world,
+                         band_height=args.band_height)      # builds the BVH, finalises, uploads
+    t_setup = time.time() - t0
+    cam = host.default_camera(args.width, args.height)
+    render.set_camera(cam)
+    render.set_max_bounces(args.bounces)
+    render.set_resolve_every_frame(False)
+    frame = host.load().rth_render_frame_handle(render.handle)
+    lib = capi.load()
+
+    def sync():
+        render.finish()
+        torch.cuda.synchronize()
+
+    local_rows = render.local_rows
+    tile = torch.zeros((max(local_rows, 1), args.width, 4), dtype=torch.float32, device="cuda")
+
+    # ---- warm-up ------------------------------------------------------------
+    render.render_samples(args.warmup) if args.warmup > 0 else None
+    sync()
+    st0 = render.stats()
+    lib.rt_set_option(frame, capi.OPT_PROFILE, 1)
+    prof = capi.rt_profile()
+    lib.rt_frame_get_profile(frame, prof)                  # drain
+    if world > 1:
+        dist.barrier()
+    sync()
+
+    # ---- timed region: exactly K steps + the one gather ----------------------
+    t0 = time.perf_counter()
+    render.render_samples(args.steps)
+    if local_rows:
+        lib.rt_frame_copy_radiance(frame, tile.data_ptr())
+    full = D.gather_image(tile[:local_rows], args.height, args.width, rank, world, args.band_height)
+    sync()
+    if world > 1:
+        dist.barrier()
+    sync()
+    dt = time.perf_counter() - t0
+
+    st1 = render.stats()
+    lib.rt_frame_get_profile(frame, prof)
+    closest = st1.closest_rays - st0.closest_rays
+    shadow = st1.shadow_rays - st0.shadow_rays
+    agg = torch.tensor([float(closest), float(shadow), prof.ms_trace_closest, prof.ms_trace_shadow, prof.ms_shade,
+                        prof.ms_raygen], dtype=torch.float64, device="cuda")
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(agg, op=dist.ReduceOp.SUM)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    agg = agg.cpu().numpy()
+    dt_max = float(tmax.item())
+
+    if rank == 0:
+        assert full is not None
+        # NaN pixels are legal in the reference arithmetic (inf * 0 in the mirror branch) but must be rare
+        nan_px = int((~torch.isfinite(full[..., :3]).all(-1)).sum().item())
+        assert nan_px <= 1e-4 * args.width * args.height, "too many non-finite pixels: %d" % nan_px
+        total_rays = agg[0] + agg[1]
+        value = total_rays / dt_max / 1e6
+        # CPU legs on a reduced frame of the same scene (bounded, see docstring)
+        small_w, small_h = 320, 180
+        arrays = render.scene_arrays()
+        per_ray, baseline = cpu_legs(args, arrays, host.default_camera(small_w, small_h), small_w, small_h)
+        bytes_closest = 48.0 + 32.0 * per_ray["closest_nodes"] + 36.0 * per_ray["closest_tris"]
+        # per launch: average rays per closest-hit launch x bytes per ray / average launch duration
+        n_launch = max(prof.n_trace_closest, 1) * world
+        ms_sum = agg[2]
+        ach = (agg[0] * bytes_closest) / (ms_sum * 1e-3) / 1e9 if ms_sum > 0 else 0.0
+        roofline = dict(bound="hbm", achieved=round(ach, 2), peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=round(ach / HBM_PEAK_GBS, 5), traffic=None,
+                        kernel="k_trace<closest>",
+                        algorithmic_bytes_per_ray=round(bytes_closest, 1),
+                        nodes_per_ray=round(per_ray["closest_nodes"], 2), tris_per_ray=round(per_ray["closest_tris"], 2),
+                        rays_per_launch=round(agg[0] / n_launch, 1),
+                        avg_launch_ms=round(ms_sum / n_launch, 5),
+                        kernel_ms_per_step=dict(trace_closest=round(agg[2] / world / args.steps, 4),
+                                                trace_shadow=round(agg[3] / world / args.steps, 4),
+                                                shade=round(agg[4] / world / args.steps, 4),
+                                                raygen=round(agg[5] / world / args.steps, 4)))
+        traffic_file = os.path.join(ROOT, "profiles", "trace_closest_hbm_traffic.json")
+        if os.path.exists(traffic_file):
+            try:
+                roofline["traffic"] = json.load(open(traffic_file)).get("bytes_per_launch")
+            except Exception:
+                pass
+        name, cus, mem = render_ctx_info(capi, host, render)
+        line = dict(metric="Mrays/s (all bounces+shadow)", value=round(value, 2), unit="Mrays/s", n_gpus=world,
+                    steps=args.steps, warmup=args.warmup, ms_per_step=round(dt_max * 1e3 / args.steps, 4),
+                    higher_is_better=True, scaling="strong", vs_baseline=None, dtype="f32", data="synthetic",
+                    config=dict(workload="BASELINE configs[1] stand-in: Cornell shell + %d-tri displaced blob (dragon "
+                                         "mtl) + %d-tri sphere (teapot mtl), %dx%d, %d-bounce, 1 spp per step, default "
+                                         "camera, directional light + CGSkies env map"
+                                         % (args.blob_tris, args.ball_tris, args.width, args.height, args.bounces),
+                                triangles=int(n_tris), width=args.width, height=args.height,
+                                max_bounces=args.bounces, spp=args.steps,
+                                tiling="%d interleaved %d-row bands per GPU, 1 RCCL gather" % (world, args.band_height)
+                                if world > 1 else "single tile",
+                                rays_per_step=round(total_rays / args.steps, 1), non_finite_pixels=nan_px,
+                                setup_s=round(t_setup, 2), device=name),
+                    roofline=roofline, cpu_baseline=baseline)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def render_ctx_info(capi, host, render):
+    import ctypes as C
+    lib = capi.load()
+    ctx = host.load().rth_render_ctx_handle(render.handle)
+    name = C.create_string_buffer(256)
+    cu = C.c_int()
+    mem = C.c_size_t()
+    lib.rt_ctx_device_info(ctx, name, 256, C.byref(cu), C.byref(mem))
+    return name.value.decode(), cu.value, mem.value
+
+
+if __name__ == "__main__":
+    main()

@@ -88,6 +88,7 @@ typedef struct rt_frame_desc
     uint32_t band_height;        /* rows per interleaved band (>= 1) */
 } rt_frame_desc;
 
+/* A frame borrows its context: destroy every frame before rt_ctx_destroy. */
 int rt_frame_create(rt_ctx* ctx, const rt_frame_desc* desc, rt_frame** out);
 int rt_frame_destroy(rt_frame* frame);
 /* number of rows / pixels this tile owns, and the global row of local row r */

@@ -114,7 +114,7 @@ class Context:
         h = C.c_void_p()
         _check(self.lib, None, self.lib.rt_ctx_create(device, C.byref(h)))
         self.handle = h
-        self._scene_keep = None
+        self._frames = []          # weakrefs: frames must be destroyed before their context
 
     def device_info(self):
         name = C.create_string_buffer(256)
@@ -158,6 +158,11 @@ class Context:
 
     def close(self):
         if self.handle:
+            for ref in self._frames:
+                fr = ref()
+                if fr is not None:
+                    fr.close()
+            self._frames = []
             self.lib.rt_ctx_destroy(self.handle)
             self.handle = None
 
@@ -179,6 +184,8 @@ class Frame:
         _check(self.lib, ctx.handle, self.lib.rt_frame_create(ctx.handle, C.byref(d), C.byref(h)))
         self.handle = h
         self.local_rows = self.lib.rt_frame_local_rows(h)
+        import weakref
+        ctx._frames.append(weakref.ref(self))
 
     def _c(self, rc):
         _check(self.lib, self.ctx.handle, rc)

@@ -20,7 +20,7 @@ EXPORTS = [
     "rth_render_enable_denoiser", "rth_render_set_resolve_every_frame", "rth_render_frame", "rth_render_samples",
     "rth_render_finish", "rth_render_local_rows", "rth_render_global_row", "rth_render_sample_count",
     "rth_render_read_radiance", "rth_render_read_resolved", "rth_render_stats", "rth_render_frame_handle",
-    "rth_render_ctx_handle",
+    "rth_render_ctx_handle", "rth_render_num_nodes", "rth_render_nodes",
 ]
 
 
@@ -55,6 +55,7 @@ def load():
         "rth_render_sample_count": (u32, [vp]), "rth_render_read_radiance": (i32, [vp, vp]),
         "rth_render_read_resolved": (i32, [vp, vp]), "rth_render_stats": (i32, [vp, C.POINTER(rt_stats)]),
         "rth_render_frame_handle": (vp, [vp]), "rth_render_ctx_handle": (vp, [vp]),
+        "rth_render_num_nodes": (u32, [vp]), "rth_render_nodes": (vp, [vp]),
     }
     for name in ("triangles", "materials", "textures", "texture_data", "lights", "emissive"):
         sig["rth_scene_num_" + name] = (u32, [vp])
@@ -222,6 +223,13 @@ class Render:
         st = rt_stats()
         self._c(self.lib.rth_render_stats(self.handle, C.byref(st)))
         return st
+
+    def scene_arrays(self):
+        """Scene + BVH arrays exactly as uploaded (triangles in BVH order)."""
+        out = self.scene.arrays()
+        out["nodes"] = _arr(self.lib.rth_render_nodes(self.handle), self.lib.rth_render_num_nodes(self.handle),
+                            T.bvh_node)
+        return out
 
     def radiance_device_ptr(self):
         from . import capi

@@ -158,6 +158,8 @@ int rth_render_read_resolved(void* r, float* out)
     return 0;
 }
 int rth_render_stats(void* r, rt_stats* out) { return guard([&]() { *out = ((rt::Render*)r)->GetIntegrator().GetStats(); return 0; }, 1); }
+uint32_t rth_render_num_nodes(void* r) { return (uint32_t)((rt::Render*)r)->GetAccelerationStructure().GetNodes().size(); }
+const void* rth_render_nodes(void* r) { return ((rt::Render*)r)->GetAccelerationStructure().GetNodes().data(); }
 void* rth_render_frame_handle(void* r) { return ((rt::Render*)r)->GetIntegrator().GetFrame(); }
 void* rth_render_ctx_handle(void* r) { return ((rt::Render*)r)->GetContext().Get(); }
 

@@ -23,6 +23,7 @@ public:
     void SetCamera(Camera const& camera);
     HIPPathTraceIntegrator& GetIntegrator() { return *integrator_; }
     HIPContext& GetContext() { return *context_; }
+    AccelerationStructure const& GetAccelerationStructure() const { return *acc_structure_; }
     std::uint32_t GetWidth() const { return width_; }
     std::uint32_t GetHeight() const { return height_; }
 

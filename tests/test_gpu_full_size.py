@@ -1,0 +1,79 @@
+"""-m gpu: BASELINE.json's configs at FULL size, through size-independent
+properties (the oracle needs ~20 s per 720p sample, so exact comparison is done
+on crops/tiles): determinism, tile invariance, furnace bound, ray accounting."""
+import numpy as np
+import pytest
+from tests import _oracle
+from raytracing_amd import capi, host, scenes as S, types as T
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def blob_scene(env_map):
+    """Stand-in for config 2 (CornellBox_Dragon.obj 1280x720 8-bounce) at a size
+    whose BVH builds in seconds."""
+    tris, mats = S.cornell_blob(200_000, 20_000)
+    s = host.Scene(arrays=dict(triangles=tris, materials=mats))
+    s.add_directional_light((-0.6, -1.5, 3.5), (15.0, 10.0, 5.0))
+    nodes = s.build_bvh()
+    s.set_env_image(env_map)
+    s.finalize()
+    return s.arrays()
+
+
+def test_config2_720p_8_bounce_properties(blob_scene):
+    w, h, b = 1280, 720, 8
+    ctx = capi.Context(0)
+    ctx.upload_scene(blob_scene)
+    cam = T.default_camera(w, h)
+    def run(spp, **tile):
+        fr = capi.Frame(ctx, w, h, **tile)
+        fr.set_camera(cam); fr.set_max_bounces(b); fr.integrate(spp)
+        return fr
+    a = run(2)
+    img = a.radiance()
+    # the reference arithmetic can produce NaN (e.g. the mirror branch's 1/n.o * max(n.o,0)
+    # = inf * 0, material.h:79-81 + :230); such pixels must be rare and identical run to run
+    bad = ~np.isfinite(img[..., :3]).all(-1)
+    assert bad.mean() < 1e-4 and (img[..., :3][~bad] >= 0).all()
+    st = a.stats()
+    n = w * h
+    assert st.last_active[0] == n and all(st.last_active[i] >= st.last_active[i + 1] for i in range(1, b))
+    assert all(st.last_shadow[i] <= st.last_active[i] for i in range(b + 1))
+    assert st.closest_rays <= 2 * (b + 1) * n
+    # determinism: same seed (sample indices 0,1) -> same bits, independent of atomics order
+    assert np.array_equal(run(2).radiance(), img, equal_nan=True)
+    # tile invariance at full resolution: 8 GPUs' worth of tiles reassemble the frame
+    out = np.zeros_like(img)
+    for r in range(8):
+        t = run(2, tile_rank=r, tile_count=8, band_height=8)
+        out[t.global_rows()] = t.radiance()
+    assert np.array_equal(out, img, equal_nan=True)
+    # exact check of a window against the oracle rendering the SAME full-frame pixels:
+    # the oracle renders the full frame only at low resolution, so compare a low-res frame
+    lo = capi.Frame(ctx, 160, 90); lo.set_camera(T.default_camera(160, 90)); lo.set_max_bounces(b); lo.integrate(1)
+    orc = _oracle.Oracle(160, 90, blob_scene)
+    orc.set_camera(T.default_camera(160, 90)); orc.set_max_bounces(b); orc.integrate(1)
+    assert np.array_equal(lo.radiance()[..., :3], orc.radiance()[..., :3], equal_nan=True)
+    assert (lo.stats().closest_rays, lo.stats().shadow_rays) == orc.ray_totals()
+    ctx.close()
+
+
+def test_1080p_and_4k_frames_allocate_and_render(blob_scene):
+    """Configs 3-5 sizes (1920x1080, 3840x2160, 16 bounces): the per-pixel state
+    fits and the schedule runs; linearity in spp of the running sum."""
+    ctx = capi.Context(0)
+    ctx.upload_scene(blob_scene)
+    for (w, h, b) in ((1920, 1080, 8), (3840, 2160, 16)):
+        fr = capi.Frame(ctx, w, h)
+        fr.set_camera(T.default_camera(w, h)); fr.set_max_bounces(b)
+        fr.integrate(1)
+        one = fr.radiance()[::8, ::8, :3].copy()
+        fr.integrate(1)
+        two = fr.radiance()[::8, ::8, :3]
+        ok = np.isfinite(two).all(-1) & np.isfinite(one).all(-1)
+        assert ok.mean() > 0.9999 and (two[ok] >= one[ok]).all()
+        assert fr.stats().last_active[0] == w * h
+        fr.close()
+    ctx.close()

@@ -1,0 +1,261 @@
+"""-m gpu: the HIP path (through the C-ABI) against the CPU oracle and the
+golden fixtures of the reference build.  Integer/index results and -- because
+of the shared arithmetic contract -- fp32 radiance are compared BIT FOR BIT;
+the north-star tolerance (rel-L2 < 1e-4) is asserted as well so that the test
+states the contract it would fall back to."""
+import os
+import numpy as np
+import pytest
+from tests.conftest import GOLDEN_CASES
+from tests import _oracle, _ref
+from raytracing_amd import capi, host, scenes as S, types as T
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TOL = 1e-4   # BASELINE.json north_star: radiance rel-L2 < 1e-4 in fp32
+
+
+def rel_l2(a, b):
+    a = a.astype(np.float64)
+    b = b.astype(np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = capi.Context(0)
+    name, cus, mem = c.device_info()
+    assert "gfx950" in name and cus == 256, name
+    yield c
+    c.close()
+
+
+def render(ctx, scene, w, h, cam, bounces, spp, furnace=False, **tile):
+    ctx.upload_scene(scene)
+    fr = capi.Frame(ctx, w, h, **tile)
+    fr.set_camera(cam)
+    fr.set_max_bounces(bounces)
+    fr.set_option(capi.OPT_WHITE_FURNACE, int(furnace))
+    fr.integrate(spp)
+    return fr
+
+
+@pytest.mark.parametrize("case", GOLDEN_CASES, ids=[c[0] for c in GOLDEN_CASES])
+def test_radiance_matches_reference_golden_vectors(ctx, case, golden_scenes, golden_radiance):
+    name, key, w, h, b, spp, furnace = case
+    g = golden_radiance
+    fr = render(ctx, golden_scenes[key], w, h, g[name + "/camera"], b, spp, furnace)
+    got = fr.radiance()[..., :3]
+    assert rel_l2(got, g[name + "/radiance"]) < TOL
+    assert np.array_equal(got, g[name + "/radiance"])
+    assert np.array_equal(fr.resolve()[..., :3], g[name + "/resolved"])
+    st = fr.stats()
+    assert (st.closest_rays, st.shadow_rays) == tuple(int(x) for x in g[name + "/totals"])
+    assert list(st.last_active[: b + 1]) == list(g[name + "/last_active"])
+    assert list(st.last_shadow[: b + 1]) == list(g[name + "/last_shadow"])
+    assert fr.sample_count() == spp
+
+
+def test_device_math_known_answers(ctx):
+    """Leaf arithmetic on the device vs the oracle's C functions, bit for bit."""
+    lib = _oracle.load()
+    rng = np.random.RandomState(11)
+    x = (rng.rand(4000) * 6.2831855).astype(np.float32)
+    u = rng.rand(4000).astype(np.float32)
+    a1 = (rng.rand(4000) * 2 - 1).astype(np.float32)
+    a2 = (rng.rand(4000) * 2 - 1).astype(np.float32)
+    def cpu(fn, *cols):
+        return np.array([fn(*[float(v) for v in row]) for row in zip(*cols)], np.float32)
+    bits = lambda v: np.asarray(v, np.float32).view(np.uint32)
+    assert np.array_equal(bits(ctx.debug_eval(0, x)), bits(cpu(lib.orc_sinf, x)))
+    assert np.array_equal(bits(ctx.debug_eval(1, x)), bits(cpu(lib.orc_cosf, x)))
+    assert np.array_equal(bits(ctx.debug_eval(2, u)), bits(cpu(lib.orc_tanf, u)))
+    assert np.array_equal(bits(ctx.debug_eval(3, u, np.full_like(u, 2.2))), bits(cpu(lambda v: lib.orc_powf(v, 2.2), u)))
+    assert np.array_equal(bits(ctx.debug_eval(3, a1 * 1.5, np.full_like(u, 5.0))),
+                          bits(cpu(lambda v: lib.orc_powf(v, 5.0), a1 * 1.5)))
+    assert np.array_equal(bits(ctx.debug_eval(4, a1, a2)), bits(cpu(lib.orc_atan2f, a1, a2)))
+    assert np.array_equal(bits(ctx.debug_eval(5, a1)), bits(cpu(lib.orc_acosf, a1)))
+    assert np.array_equal(bits(ctx.debug_eval(6, u)), bits(np.sqrt(u)))            # IEEE sqrt
+    assert np.array_equal(bits(ctx.debug_eval(7, a1, a2)), bits(a1 / a2))          # IEEE divide
+    y = (rng.rand(4000) * 0.999).astype(np.float32)
+    want = (1.0 / np.sqrt(1.0 + u.astype(np.float64) / (1.0 - y.astype(np.float64)))).astype(np.float32)
+    assert np.array_equal(bits(ctx.debug_eval(9, u, y)), bits(want))               # fp64 path of GGX_Sample
+    # SampleRandom: (px | py<<16), (sample | dim<<16)
+    px, py, smp, dim = rng.randint(0, 1920, 500), rng.randint(0, 1080, 500), rng.randint(0, 256, 500), rng.randint(0, 45, 500)
+    a = (px | (py << 16)).astype(np.uint32).view(np.float32)
+    b = (smp | (dim << 16)).astype(np.uint32).view(np.float32)
+    want = np.array([lib.orc_sample_random(int(p), int(q), int(s), int(d) // 5, int(d) % 5)
+                     for p, q, s, d in zip(px, py, smp, dim)], np.float32)
+    assert np.array_equal(bits(ctx.debug_eval(8, a, b)), bits(want))
+
+
+def test_stage_level_parity_rekeyed_by_pixel(ctx, golden_scenes):
+    """Per-kernel buffers vs the oracle's.  Queue ORDER is free on the GPU
+    (wave-ballot compaction), so queues are compared after sorting by pixel."""
+    w, h, bounces = 56, 40, 3
+    sc = golden_scenes["coverage"]
+    cam = T.default_camera(w, h)
+    ctx.upload_scene(sc)
+    fr = capi.Frame(ctx, w, h)
+    fr.set_camera(cam)
+    fr.set_max_bounces(bounces)
+    orc = _oracle.Oracle(w, h, sc)
+    orc.set_camera(cam)
+    orc.stage("reset")
+    n = w * h
+    fr.generate_rays()
+    orc.stage("generate_rays")
+    for bounce in range(bounces + 1):
+        k = int(orc.buffer("ray_counter%d" % (bounce & 1), np.uint32, 1)[0])
+        rays, pix, thr = fr.read_queue(0, bounce)
+        assert len(rays) == k
+        o_rays = orc.buffer("rays%d" % (bounce & 1), T.ray, n)[:k]
+        o_pix = orc.buffer("pixel_indices%d" % (bounce & 1), np.uint32, n)[:k]
+        gi, oi = np.argsort(pix), np.argsort(o_pix)
+        assert np.array_equal(pix[gi], o_pix[oi])
+        assert T.records_equal(rays[gi], o_rays[oi])
+        o_thr = orc.buffer("throughputs", T.float3, n)[o_pix[oi]]
+        assert T.records_equal(thr[gi], o_thr)
+        fr.intersect(bounce)
+        orc.stage("intersect", bounce)
+        hits = fr.read_hits(k)[gi]
+        o_hits = orc.buffer("hits", T.hit, n)[:k][oi]
+        assert np.array_equal(hits["primitive_id"], o_hits["primitive_id"])
+        m = hits["primitive_id"] != 0xFFFFFFFF
+        assert np.array_equal(hits[m].tobytes(), o_hits[m].tobytes())
+        fr.shade(bounce)
+        for st in ("shade_miss", "clear_counters", "shade_hits"):
+            orc.stage(st, bounce)
+        ks = int(orc.buffer("shadow_ray_counter", np.uint32, 1)[0])
+        srays, spix, sls = fr.read_queue(1, bounce)
+        assert len(srays) == ks
+        gs, os_ = np.argsort(spix), np.argsort(orc.buffer("shadow_pixel_indices", np.uint32, n)[:ks])
+        assert T.records_equal(srays[gs], orc.buffer("shadow_rays", T.ray, n)[:ks][os_])
+        o_ls = orc.buffer("direct_light_samples", T.float4, n)[:ks][os_]
+        assert T.records_equal(sls[gs], o_ls)
+        fr.intersect_shadow(bounce)
+        orc.stage("intersect_shadow")
+        orc.stage("accumulate")
+        assert np.array_equal(fr.radiance()[..., :3].reshape(n, 3),
+                              orc.buffer("radiance", np.float32, n * 4).reshape(n, 4)[:, :3])
+
+
+@pytest.mark.parametrize("world,band", [(2, 8), (3, 4), (8, 8)])
+def test_tiling_is_bit_invariant(ctx, golden_scenes, world, band):
+    """Image-space sharding (the multi-GPU partition) cannot change a pixel."""
+    w, h = 72, 60
+    sc = golden_scenes["coverage"]
+    cam = T.default_camera(w, h)
+    full = render(ctx, sc, w, h, cam, 4, 2).radiance()
+    img = np.zeros_like(full)
+    seen = np.zeros(h, bool)
+    rays = 0
+    for r in range(world):
+        t = render(ctx, sc, w, h, cam, 4, 2, tile_rank=r, tile_count=world, band_height=band)
+        rows = t.global_rows()
+        assert not seen[rows].any()
+        seen[rows] = True
+        img[rows] = t.radiance()
+        rays += t.stats().closest_rays
+    assert seen.all() and np.array_equal(img, full)
+    assert rays == render(ctx, sc, w, h, cam, 4, 2).stats().closest_rays
+
+
+def test_cpp_host_layer_end_to_end(ctx, golden_scenes, golden_radiance):
+    """Scene(OBJ) -> Bvh -> Render -> HIPPathTraceIntegrator::Integrate(), i.e. the
+    reference's own call sequence (main.cpp:56-72, render.cpp:38-83,172-204)."""
+    name = "cornell_64_b4_s2"
+    g = golden_radiance
+    scene = host.Scene(os.path.join(ROOT, "assets", "CornellBox.obj"))
+    scene.add_directional_light((-0.6, -1.5, 3.5), (15.0, 10.0, 5.0))
+    r = host.Render(64, 64, scene)
+    r.set_max_bounces(4)
+    r.set_camera(g[name + "/camera"])
+    r.render_frame()                # staged path: the 15 virtuals, one Integrate()
+    r.render_frame()
+    assert np.array_equal(r.radiance()[..., :3], g[name + "/radiance"])
+    assert np.array_equal(r.resolved()[..., :3], g[name + "/resolved"])   # ResolveRadiance ran inside Integrate()
+    assert r.sample_count() == 2
+    r.set_max_bounces(4)            # SetMaxBounces -> RequestReset
+    r.render_samples(2)             # fused fast path
+    assert np.array_equal(r.radiance()[..., :3], g[name + "/radiance"])
+    r.enable_white_furnace(True)
+    r.render_samples(1)
+    assert r.sample_count() == 1    # furnace toggle requested a reset
+    with pytest.raises(host.RtError, match="kRandom"):
+        r.set_blue_noise(True)      # not implemented -> loud, not silent
+    with pytest.raises(host.RtError, match="denoiser"):
+        r.enable_denoiser(True)
+
+
+def test_furnace_energy_bound(ctx, golden_scenes):
+    """White furnace (the reference's built-in check, render.cpp:157-160): with
+    the analytic light switched off, albedo 1 and sky 0.5, no pixel can exceed
+    0.5 by more than the BSDF's known energy gain... it must stay finite and the
+    diffuse-only Cornell box must converge to <= 0.5."""
+    sc = dict(golden_scenes["cornell"])
+    lights = sc["lights"].copy()
+    lights["radiance"]["x"] = 0; lights["radiance"]["y"] = 0; lights["radiance"]["z"] = 0
+    sc["lights"] = lights
+    fr = render(ctx, sc, 64, 64, T.default_camera(64, 64), 8, 16, furnace=True)
+    img = fr.radiance()[..., :3] / 16.0
+    assert np.isfinite(img).all() and img.min() >= 0.0
+    assert img.mean() <= 0.5 + 1e-3
+
+
+def test_errors_are_reported_not_swallowed(golden_scenes):
+    c = capi.Context(0)
+    fr = capi.Frame(c, 16, 16)
+    with pytest.raises(capi.RtError, match="no scene uploaded"):
+        fr.integrate(1)
+    with pytest.raises(capi.RtError, match="max_bounces"):
+        fr.set_max_bounces(1000)
+    with pytest.raises(capi.RtError, match="bad device ordinal"):
+        capi.Context(99)
+    bad = dict(golden_scenes["cornell"])
+    tris = bad["triangles"].copy()
+    tris["mtl_index"][0] = 1000
+    bad["triangles"] = tris
+    with pytest.raises(capi.RtError, match="material index"):
+        c.upload_scene(bad)
+    fr.close()
+    c.close()
+
+
+def test_empty_tile_and_single_pixel(ctx, golden_scenes):
+    sc = golden_scenes["cornell"]
+    cam = T.default_camera(8, 4)
+    t = render(ctx, sc, 8, 4, cam, 2, 1, tile_rank=3, tile_count=4, band_height=8)   # owns no rows
+    assert t.local_rows == 0 and t.radiance().shape == (0, 8, 4)
+    assert t.stats().closest_rays == 0
+    one = render(ctx, sc, 1, 1, T.default_camera(1, 1), 3, 2)
+    orc = _oracle.Oracle(1, 1, sc)
+    orc.set_camera(T.default_camera(1, 1)); orc.set_max_bounces(3); orc.integrate(2)
+    assert np.array_equal(one.radiance()[..., :3], orc.radiance()[..., :3])
+
+
+def test_deep_bounce_limit(ctx, golden_scenes):
+    sc = golden_scenes["coverage"]
+    cam = T.default_camera(40, 32)
+    fr = render(ctx, sc, 40, 32, cam, 16, 1)          # San-Miguel config depth
+    orc = _oracle.Oracle(40, 32, sc)
+    orc.set_camera(cam); orc.set_max_bounces(16); orc.integrate(1)
+    assert np.array_equal(fr.radiance()[..., :3], orc.radiance()[..., :3])
+    assert fr.stats().closest_rays == orc.ray_totals()[0]
+
+
+@pytest.mark.skipif(not _ref.available(), reason="oracle/_ref/libref.so not shipped")
+def test_directly_against_the_reference_kernels(ctx, golden_scenes):
+    """The reference's own OpenCL kernels (x86 build) run next to the GPU."""
+    w, h = 96, 64
+    sc = golden_scenes["coverage"]
+    cam = T.default_camera(w, h)
+    cam["aperture"] = 0.02
+    cam["focus_distance"] = 1.8
+    ri = _ref.RefIntegrator(w, h, sc, threads=4)
+    ri.set_camera(cam); ri.set_max_bounces(8); ri.integrate(3)
+    fr = render(ctx, sc, w, h, cam, 8, 3)
+    assert rel_l2(fr.radiance()[..., :3], ri.radiance()[..., :3]) < TOL
+    assert np.array_equal(fr.radiance()[..., :3], ri.radiance()[..., :3])
+    st = fr.stats()
+    assert (st.closest_rays, st.shadow_rays) == ri.ray_totals()
