@@ -104,7 +104,13 @@ enum rt_option
     RT_OPT_AOV = 3,            /* Integrator::SetAOV: 0 = kShadedColor (only one implemented) */
     RT_OPT_DENOISER = 4,       /* Integrator::EnableDenoiser: 0 (only value implemented) */
     RT_OPT_TRACE_DROP_LAST_BOUNCE_RAYS = 5, /* 1 (default): do not emit the never-traced rays of the last bounce */
-    RT_OPT_PROFILE_KERNELS = 6  /* 1: bracket every kernel launch with HIP events on the context stream */
+    RT_OPT_PROFILE_KERNELS = 6, /* 1: bracket every kernel launch with HIP events on the context stream */
+    RT_OPT_TRACE_VARIANT = 7    /* traversal kernel: 0 = v1 per-ray loop; 1 (default) .. 4 = one-fetch-per-iteration
+                                   state machine with a 16 / 24 / 12 / 8 entry LDS stack.  Results are identical. */
+    , RT_OPT_TRACE_WAVES_PER_CU = 8 /* persistent-grid size of the trace kernels in waves per CU (0 = as many as fit) */
+    , RT_OPT_SAMPLES_IN_FLIGHT = 9  /* rt_integrate traces this many consecutive samples per pixel concurrently
+                                       (1..64, default 1; tile pixels x samples <= 2^25).  Results are bit-identical
+                                       for every value: contributions are logged per path and replayed in order. */
 };
 int rt_set_option(rt_frame* frame, int option, uint32_t value);
 int rt_set_camera(rt_frame* frame, const rt_camera* camera);       /* SetCameraData, cl_pt_integrator.cpp:365-371 */

@@ -55,7 +55,7 @@ EXPORTS = [
     "rt_frame_get_stats", "rt_frame_get_profile", "rt_frame_copy_radiance", "rt_frame_debug_read_queue", "rt_frame_debug_read_hits", "rt_debug_eval",
 ]
 
-OPT_MAX_BOUNCES, OPT_WHITE_FURNACE, OPT_SAMPLER, OPT_AOV, OPT_DENOISER, OPT_DROP_LAST, OPT_PROFILE = range(7)
+OPT_MAX_BOUNCES, OPT_WHITE_FURNACE, OPT_SAMPLER, OPT_AOV, OPT_DENOISER, OPT_DROP_LAST, OPT_PROFILE, OPT_TRACE_VARIANT, OPT_TRACE_WAVES, OPT_SAMPLES_IN_FLIGHT = range(10)
 
 
 def load():

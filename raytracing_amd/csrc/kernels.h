@@ -11,14 +11,21 @@
 //   reset_radiance.cl / increment_counter.cl       -> hipMemsetAsync / host scalar
 //
 // Device data layout (HBM), chosen for coalesced 16-byte accesses:
-//   ray queues   SoA: o4[i] = (origin.xyz, t_max), d4[i] = (dir.xyz, pixel bits),
-//                thr[i] = (throughput.xyz, -) ; shadow queue adds ls[i] = light sample
+//   ray queues   SoA: o4[i] = (origin.xyz, t_max), d4[i] = (dir.xyz, path id bits),
+//                thr[i] = (throughput.xyz, -).  path id = slot * n_pixels + pixel, where
+//                `slot` numbers the samples in flight (RT_OPT_SAMPLES_IN_FLIGHT); shadow
+//                rays carry (log entry << 25 | path id)
+//   radiance log per path: cnt[id] + log[k][id] (float4) = the path's radiance
+//                contributions in the order the reference adds them (miss or emission,
+//                then direct light, per bounce).  k_flush replays them pixel by pixel,
+//                sample by sample, so the fp32 sum is associated exactly as in the
+//                reference although several samples are traced concurrently.
 //   BVH          one 64-byte "child-pair" record per INTERIOR node of the
 //                reference BVH2: both children's boxes + refs in one line, so
 //                one dependent fetch serves two box tests (the reference needs
 //                one 48-byte fetch per box).  Topology, near/far rule and
 //                cull decisions are exactly the reference's (see k_trace).
-//   trace tris   48 B: (p1, last-in-leaf flag), e1 = p2-p1, e2 = p3-p1
+//   trace tris   64 B, line aligned: (p1, last-in-leaf flag), e1 = p2-p1, e2 = p3-p1, spare
 //   shade tris   128 B, line aligned: p1..p3, n1..n3, uv1..uv3, material
 #pragma once
 #include "device_math.h"
@@ -28,11 +35,13 @@
 #define RT_EMPTY_REF 0xFFFFFFFFu
 #define RT_TRACE_STACK_LDS 24     // per-lane stack entries kept in LDS
 #define RT_TRACE_STACK_MAX 64     // the reference's nodesToVisit[64] (trace_bvh.cl:142)
+#define RT_ID_BITS 25u            // path id bits in a shadow ray's payload; the rest = log entry
+#define RT_ID_MASK ((1u << RT_ID_BITS) - 1u)
 
 struct DScene
 {
     const float4* nodes;          // 4 x float4 per interior node
-    const float4* tris_rt;        // 3 x float4 per triangle
+    const float4* tris_rt;        // 4 x float4 per triangle
     const float4* tris_sh;        // 8 x float4 per triangle
     const rt_packed_material* materials;
     const rt_texture* textures;
@@ -65,16 +74,20 @@ struct DCounters                  // one per frame, device memory
     uint32_t shadow[64];          // shadow[b] = shadow rays emitted at bounce b
     unsigned long long total_closest, total_shadow, samples;
     uint32_t last_queue[64], last_shadow[64];
+    // work-distribution heads of the persistent trace kernels: one per XCD and per
+    // kernel flavour (0 = closest, 1 = shadow), offsets inside the XCD's region
+    uint32_t head[2][8];
 };
 
 // ---------------------------------------------------------------------------
 // sample begin + ray generation (raygeneration.cl:65-139)
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_raygen(DTile tile, rt_camera cam, uint32_t sample_idx, float tan_half_fov,
-    uint32_t prev_bounces, float4* __restrict__ o4, float4* __restrict__ d4, float4* __restrict__ thr,
-    DCounters* __restrict__ counters)
+__global__ __launch_bounds__(256) void k_raygen(DTile tile, rt_camera cam, uint32_t sample_base, uint32_t n_slots,
+    float tan_half_fov, uint32_t prev_bounces, float4* __restrict__ o4, float4* __restrict__ d4,
+    float4* __restrict__ thr, DCounters* __restrict__ counters)
 {
     uint32_t n_local = tile.local_rows * tile.width;
+    uint32_t n_total = n_local * n_slots;                                // n_slots samples in flight
     uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i == 0)
     {
@@ -91,12 +104,16 @@ __global__ __launch_bounds__(256) void k_raygen(DTile tile, rt_camera cam, uint3
         counters->total_closest += c;
         counters->total_shadow += s;
         for (uint32_t b = 0; b < 64; ++b) { counters->queue[b] = 0; counters->shadow[b] = 0; }
-        counters->queue[0] = n_local;                                    // raygeneration.cl:135-138
+        counters->queue[0] = n_total;                                    // raygeneration.cl:135-138
     }
-    if (i >= n_local) return;
+    if (i < 16) counters->head[i >> 3][i & 7] = 0;                       // the next trace launches start from 0
+    if (i >= n_total) return;
 
-    uint32_t ly = i / tile.width;
-    uint32_t pixel_x = i - ly * tile.width;
+    uint32_t slot = i / n_local;
+    uint32_t lp = i - slot * n_local;                                    // local pixel of this tile
+    uint32_t sample_idx = sample_base + slot;
+    uint32_t ly = lp / tile.width;
+    uint32_t pixel_x = lp - ly * tile.width;
     uint32_t pixel_y = tile_global_row(tile, ly);
     uint32_t pixel_idx = pixel_y * tile.width + pixel_x;                 // GLOBAL pixel index
 
@@ -135,7 +152,7 @@ __global__ __launch_bounds__(256) void k_raygen(DTile tile, rt_camera cam, uint3
     f3 d = normalize3(point_aimed - new_pos);
 
     o4[i] = make_float4(new_pos.x, new_pos.y, new_pos.z, RT_MAX_RENDER_DIST);
-    d4[i] = make_float4(d.x, d.y, d.z, __uint_as_float(i));              // LOCAL pixel slot
+    d4[i] = make_float4(d.x, d.y, d.z, __uint_as_float(i));              // path id = slot * n_local + local pixel
     thr[i] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
 }
 
@@ -168,9 +185,9 @@ RT_DEV bool box_test(float bminx, float bminy, float bminz, float bmaxx, float b
 }
 
 template <bool SHADOW>
-__global__ __launch_bounds__(64) void k_trace(DScene sc, const float4* __restrict__ o4, const float4* __restrict__ d4,
-    const uint32_t* __restrict__ count_ptr, float4* __restrict__ hits, const float4* __restrict__ ls,
-    float4* __restrict__ radiance, uint2* __restrict__ spill)
+__global__ __launch_bounds__(64) void k_trace_v1(DScene sc, const float4* __restrict__ o4, const float4* __restrict__ d4,
+    const uint32_t* __restrict__ count_ptr, float4* __restrict__ hits, float4* __restrict__ rlog,
+    uint32_t log_stride, uint2* __restrict__ spill)
 {
     __shared__ uint2 stack[RT_TRACE_STACK_LDS][64];
     const uint32_t lane = threadIdx.x;
@@ -216,7 +233,7 @@ __global__ __launch_bounds__(64) void k_trace(DScene sc, const float4* __restric
                 bool last;
                 do
                 {
-                    const float4* tp = sc.tris_rt + (size_t)prim * 3;
+                    const float4* tp = sc.tris_rt + (size_t)prim * 4;
                     float4 a = tp[0], b = tp[1], cc = tp[2];
                     last = a.w != 0.0f;
                     f3 p1 = F3(a.x, a.y, a.z), e1 = F3(b.x, b.y, b.z), e2 = F3(cc.x, cc.y, cc.z);
@@ -304,20 +321,240 @@ __global__ __launch_bounds__(64) void k_trace(DScene sc, const float4* __restric
 
         if (SHADOW)
         {
-            // AccumulateDirectSamples (accumulate_direct_samples.cl:46-52) fused:
-            // each pixel owns at most one shadow ray per bounce -> plain RMW
-            if (!occluded)
+            // AccumulateDirectSamples (accumulate_direct_samples.cl:46-52) fused: k_shade
+            // logged the direct sample tentatively; an occluded ray retracts it
+            if (occluded)
             {
-                uint32_t pix = __float_as_uint(rd.w);
-                float4 s = ls[i];
-                float4 r = radiance[pix];
-                r.x += s.x; r.y += s.y; r.z += s.z;
-                radiance[pix] = r;
+                uint32_t payload = __float_as_uint(rd.w);
+                rlog[(size_t)(payload >> RT_ID_BITS) * log_stride + (payload & RT_ID_MASK)] = make_float4(0, 0, 0, 0);
             }
         }
         else
         {
             hits[i] = make_float4(hit_u, hit_v, __uint_as_float(hit_prim), hit_t);
+        }
+    }
+}
+
+
+// ---------------------------------------------------------------------------
+// k_trace: persistent "one fetch per iteration" traversal (the production kernel)
+// ---------------------------------------------------------------------------
+// What bounds this kernel is the chain of dependent HBM/L2 round trips per ray
+// (~46 box tests + ~2.5 triangle tests per ray on the 890 k-triangle stand-in),
+// not arithmetic.  v1 above pays (a) one round trip for the node branch PLUS one
+// for the leaf branch whenever a wave has lanes in both, and (b) idles lanes
+// whose ray finished until the slowest ray of the wave is done.  Here every lane
+// is a small state machine and every loop iteration issues exactly ONE 64-byte
+// record fetch per lane -- the next ray (o4/d4), a child-pair node, or a
+// triangle -- through the same four load instructions, so the wave pays one
+// memory round trip per iteration whatever mix of states it holds, and a lane
+// that finishes pulls a new ray in the very next iteration (wave-level pool of
+// ray indices, refilled RT_TRACE_BATCH at a time from a per-XCD queue head with
+// one atomic; exhausted XCD regions steal from the next region).
+// The arithmetic per record is unchanged from v1 (bit-identical results).
+#define RT_TRACE_BATCH 128u
+enum { ST_NEED = 0, ST_RAY = 1, ST_TRAV = 2, ST_DONE = 3 };
+
+template <bool SHADOW, int STACK>
+__global__ __launch_bounds__(64) void k_trace(DScene sc, const float4* __restrict__ o4, const float4* __restrict__ d4,
+    const uint32_t* __restrict__ count_ptr, uint32_t* __restrict__ heads, float4* __restrict__ hits,
+    float4* __restrict__ rlog, uint32_t log_stride, uint2* __restrict__ spill)
+{
+    __shared__ uint2 stack[STACK][64];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t count = *count_ptr;
+    if (count == 0) return;
+    const uint32_t xcd = blockIdx.x & 7u;
+    // eight contiguous regions of the queue, 64-ray aligned, one per XCD (L2 affinity)
+    const uint32_t per = (((count + 7u) >> 3) + 63u) & ~63u;
+    uint2* my_spill = spill + (size_t)(blockIdx.x * 64u + lane) * (RT_TRACE_STACK_MAX - STACK);
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+
+    uint32_t pool_next = 0, pool_end = 0, regions_tried = 0;   // wave-uniform
+    uint32_t state = ST_NEED;
+    uint32_t ray_i = 0, ref = 0, sign_bits = 0, hit_prim = RT_INVALID_ID;
+    int sp = 0;
+    f3 org = F3s(0.0f), dir = F3s(0.0f), inv = F3s(0.0f);
+    float t_max = 0.0f, hit_u = 0.0f, hit_v = 0.0f;
+    uint32_t payload = 0;                                                    // SHADOW: log entry << 25 | path id
+    const float t_min = 0.0f;
+
+    for (;;)
+    {
+        // ---- hand new ray indices to the lanes that need one --------------------
+        unsigned long long need = __ballot(state == ST_NEED);
+        while (need)
+        {
+            if (pool_next >= pool_end)
+            {
+                bool got = false;
+                while (regions_tried < 8u)
+                {
+                    uint32_t x = (xcd + regions_tried) & 7u;
+                    uint32_t rb = x * per < count ? x * per : count;
+                    uint32_t re = (x + 1u) * per < count ? (x + 1u) * per : count;
+                    uint32_t b = 0;
+                    if (lane == 0 && rb < re) b = atomicAdd(&heads[x], RT_TRACE_BATCH);
+                    b = __shfl(b, 0, 64);
+                    if (rb < re && b < re - rb)
+                    {
+                        pool_next = rb + b;
+                        pool_end = (b + RT_TRACE_BATCH < re - rb) ? rb + b + RT_TRACE_BATCH : re;
+                        got = true;
+                        break;
+                    }
+                    ++regions_tried;
+                }
+                if (!got)
+                {
+                    if (state == ST_NEED) state = ST_DONE;
+                    break;
+                }
+            }
+            uint32_t avail = pool_end - pool_next;
+            uint32_t rank = (uint32_t)__popcll(need & lt_mask);
+            uint32_t n = (uint32_t)__popcll(need);
+            if (state == ST_NEED && rank < avail)
+            {
+                ray_i = pool_next + rank;
+                state = ST_RAY;
+            }
+            pool_next += n < avail ? n : avail;
+            need = __ballot(state == ST_NEED);
+        }
+        if (__ballot(state != ST_DONE) == 0ull) break;
+
+        // ---- ONE 64-byte record per lane: ray | node | triangle -----------------
+        const float4* pa;
+        const float4* pb;
+        if (state == ST_RAY) { pa = o4 + ray_i; pb = d4 + ray_i; }
+        else
+        {
+            const float4* base = (ref & RT_LEAF_BIT) ? sc.tris_rt + (size_t)(ref & ~RT_LEAF_BIT) * 4
+                                                     : sc.nodes + (size_t)ref * 4;
+            pa = base;
+            pb = base + 1;
+        }
+        float4 q0 = make_float4(0, 0, 0, 0), q1 = q0, q2 = q0, q3 = q0;
+        if (state != ST_DONE)
+        {
+            q0 = pa[0]; q1 = pb[0]; q2 = pa[2]; q3 = pb[2];
+        }
+        if (SHADOW && state == ST_RAY) payload = __float_as_uint(q1.w);
+
+        bool finished = false, need_pop = false;
+        if (state == ST_RAY)
+        {
+            org = F3(q0.x, q0.y, q0.z);
+            dir = F3(q1.x, q1.y, q1.z);
+            t_max = q0.w;
+            inv = F3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);             // trace_bvh.cl:125
+            sign_bits = (inv.x < 0.0f ? 1u : 0u) | (inv.y < 0.0f ? 2u : 0u) | (inv.z < 0.0f ? 4u : 0u);
+            hit_prim = RT_INVALID_ID;
+            hit_u = 0.0f; hit_v = 0.0f;
+            sp = 0;
+            ref = sc.root_ref;
+            float entry;
+            bool alive = box_test(sc.root_min[0], sc.root_min[1], sc.root_min[2], sc.root_max[0], sc.root_max[1],
+                sc.root_max[2], org, inv, t_min, t_max, entry);
+            state = ST_TRAV;
+            finished = !alive;
+        }
+        else if (state == ST_TRAV)
+        {
+            if (ref & RT_LEAF_BIT)
+            {
+                // one triangle of a leaf (trace_bvh.cl:28-73,155-169)
+                uint32_t prim = ref & ~RT_LEAF_BIT;
+                bool last = q0.w != 0.0f;
+                f3 p1 = F3(q0.x, q0.y, q0.z), e1 = F3(q1.x, q1.y, q1.z), e2 = F3(q2.x, q2.y, q2.z);
+                f3 pvec = cross3(dir, e2);
+                float det = dot3(e1, pvec);
+                if (!(det < 1e-8f || -det > 1e-8f))
+                {
+                    float inv_det = 1.0f / det;
+                    f3 tvec = org - p1;
+                    float u = dot3(tvec, pvec) * inv_det;
+                    if (!(u < 0.0f || u > 1.0f))
+                    {
+                        f3 qvec = cross3(tvec, e1);
+                        float v = dot3(dir, qvec) * inv_det;
+                        if (!(v < 0.0f || u + v > 1.0f))
+                        {
+                            float t = dot3(e2, qvec) * inv_det;
+                            if (!(t < t_min || t > t_max))
+                            {
+                                hit_u = u; hit_v = v; hit_prim = prim;
+                                t_max = t;                                   // :162
+                                if (SHADOW) finished = true;                 // goto endtrace, :164-167
+                            }
+                        }
+                    }
+                }
+                if (!finished)
+                {
+                    if (last) need_pop = true;
+                    else ref = ref + 1u;
+                }
+            }
+            else
+            {
+                uint32_t c0 = __float_as_uint(q3.x), c1 = __float_as_uint(q3.y), axis = __float_as_uint(q3.z);
+                float a0, a1;
+                bool h0 = box_test(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, org, inv, t_min, t_max, a0);
+                bool h1 = box_test(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, org, inv, t_min, t_max, a1);
+                h1 = h1 && (c1 != RT_EMPTY_REF);
+                bool swap = (sign_bits >> axis) & 1u;                        // :181-190
+                uint32_t near_ref = swap ? c1 : c0, far_ref = swap ? c0 : c1;
+                bool near_hit = swap ? h1 : h0, far_hit = swap ? h0 : h1;
+                float far_entry = swap ? a0 : a1;
+                if (near_hit)
+                {
+                    if (far_hit)
+                    {
+                        uint2 e = make_uint2(far_ref, __float_as_uint(far_entry));
+                        if (sp < STACK) stack[sp][lane] = e;
+                        else my_spill[sp - STACK] = e;
+                        ++sp;
+                    }
+                    ref = near_ref;
+                }
+                else if (far_hit) ref = far_ref;
+                else need_pop = true;
+            }
+            if (need_pop)
+            {
+                finished = true;
+                while (sp > 0)
+                {
+                    --sp;
+                    uint2 e = (sp < STACK) ? stack[sp][lane] : my_spill[sp - STACK];
+                    if (t_max >= __uint_as_float(e.y))                       // box re-test at pop time
+                    {
+                        ref = e.x;
+                        finished = false;
+                        break;
+                    }
+                }
+            }
+        }
+
+        if (finished)
+        {
+            if (SHADOW)
+            {
+                // AccumulateDirectSamples fused (accumulate_direct_samples.cl:46-52): k_shade
+                // logged the direct sample tentatively; an occluded ray (it stopped on its
+                // first accepted triangle, hit_prim set) retracts it.  Store only, no wait.
+                if (hit_prim != RT_INVALID_ID)
+                    rlog[(size_t)(payload >> RT_ID_BITS) * log_stride + (payload & RT_ID_MASK)] = make_float4(0, 0, 0, 0);
+            }
+            else
+            {
+                hits[ray_i] = make_float4(hit_u, hit_v, __uint_as_float(hit_prim), t_max);
+            }
+            state = ST_NEED;
         }
     }
 }
@@ -590,10 +827,10 @@ struct ShadeArgs
 {
     const float4* in_o4; const float4* in_d4; const float4* in_thr; const float4* hits;
     float4* out_o4; float4* out_d4; float4* out_thr;
-    float4* sh_o4; float4* sh_d4; float4* sh_ls;
-    float4* radiance;
+    float4* sh_o4; float4* sh_d4;
+    float4* rlog; uint32_t* cnt;      // radiance log (see file header)
     DCounters* counters;
-    uint32_t bounce, sample_idx, emit_outgoing;
+    uint32_t bounce, sample_base, emit_outgoing, n_local, log_stride;
 };
 
 template <bool FURNACE>
@@ -601,18 +838,26 @@ __global__ __launch_bounds__(256) void k_shade(DScene sc, DTile tile, ShadeArgs 
 {
     const uint32_t count = a.counters->queue[a.bounce];
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    // the closest-hit trace of this bounce has completed (stream order): rewind the
+    // work heads for the shadow trace of this bounce and the closest trace of the next
+    if (i < 16) a.counters->head[i >> 3][i & 7] = 0;
     if (blockIdx.x * 256u >= count) return;                              // whole block idle (uniform)
     const bool active = i < count;
 
     bool want_shadow = false, want_next = false;
-    float4 sh_o = make_float4(0, 0, 0, 0), sh_d = sh_o, sh_l = sh_o, nx_o = sh_o, nx_d = sh_o, nx_t = sh_o;
+    float4 sh_o = make_float4(0, 0, 0, 0), sh_d = sh_o, nx_o = sh_o, nx_d = sh_o, nx_t = sh_o;
 
     if (active)
     {
         float4 hit = a.hits[i];
         float4 rd = a.in_d4[i];
         uint32_t prim = __float_as_uint(hit.z);
-        uint32_t pix = __float_as_uint(rd.w);
+        uint32_t id = __float_as_uint(rd.w);                               // slot * n_local + local pixel
+        uint32_t slot = id / a.n_local;
+        uint32_t pix = id - slot * a.n_local;
+        uint32_t sample_idx = a.sample_base + slot;
+        uint32_t nlog = a.cnt[id];                                         // contributions logged so far
+        float4* mylog = a.rlog + id;
         float4 thr4 = a.in_thr[i];
         f3 hit_throughput = F3(thr4.x, thr4.y, thr4.z);
 
@@ -621,9 +866,8 @@ __global__ __launch_bounds__(256) void k_shade(DScene sc, DTile tile, ShadeArgs 
             // Miss, miss.cl:65-76
             f3 sky = FURNACE ? F3s(0.5f) : SampleSky(sc, F3(rd.x, rd.y, rd.z));
             f3 add = sky * hit_throughput;
-            float4 r = a.radiance[pix];
-            r.x += add.x; r.y += add.y; r.z += add.z;
-            a.radiance[pix] = r;
+            mylog[(size_t)nlog * a.log_stride] = make_float4(add.x, add.y, add.z, 0.0f);   // radiance[pix] += ...
+            ++nlog;
         }
         else
         {
@@ -654,13 +898,12 @@ __global__ __launch_bounds__(256) void k_shade(DScene sc, DTile tile, ShadeArgs 
                 if (material.emission.x * 1.0f + material.emission.y * 1.0f + material.emission.z * 1.0f > 0.0f)
                 {
                     f3 e = hit_throughput * material.emission;
-                    float4 r = a.radiance[pix];
-                    r.x += e.x; r.y += e.y; r.z += e.z;
-                    a.radiance[pix] = r;
+                    mylog[(size_t)nlog * a.log_stride] = make_float4(e.x, e.y, e.z, 0.0f);         // radiance[pix] += ...
+                    ++nlog;
                 }
             }
 
-            uint32_t sample_seed = SampleRandomSampleSeed(SampleRandomPixelSeed(px, py), a.sample_idx);
+            uint32_t sample_seed = SampleRandomSampleSeed(SampleRandomPixelSeed(px, py), sample_idx);
 
             // Direct lighting :115-145 (Light_Sample light.h:30-65)
             {
@@ -690,8 +933,14 @@ __global__ __launch_bounds__(256) void k_shade(DScene sc, DTile tile, ShadeArgs 
                 want_shadow = (pdf > 0.0f) && (dot3(lsamp, lsamp) > 0.0f);
                 f3 so = position + normal * RT_EPS;
                 sh_o = make_float4(so.x, so.y, so.z, distance_to_light);
-                sh_d = make_float4(outgoing.x, outgoing.y, outgoing.z, rd.w);
-                sh_l = make_float4(lsamp.x, lsamp.y, lsamp.z, 0.0f);
+                sh_d = make_float4(outgoing.x, outgoing.y, outgoing.z, __uint_as_float(id | (nlog << RT_ID_BITS)));
+                if (want_shadow)
+                {
+                    // deferred direct sample (direct_light_samples_buffer_): logged now, retracted
+                    // by the shadow trace if the light turns out to be occluded
+                    mylog[(size_t)nlog * a.log_stride] = make_float4(lsamp.x, lsamp.y, lsamp.z, 0.0f);
+                    ++nlog;
+                }
             }
 
             // Indirect lighting :148-184
@@ -714,6 +963,7 @@ __global__ __launch_bounds__(256) void k_shade(DScene sc, DTile tile, ShadeArgs 
                 nx_t = make_float4(new_thr.x, new_thr.y, new_thr.z, 0.0f);
             }
         }
+        a.cnt[id] = nlog;
     }
 
     uint32_t sidx = wave_append(want_shadow, &a.counters->shadow[a.bounce]);
@@ -721,7 +971,6 @@ __global__ __launch_bounds__(256) void k_shade(DScene sc, DTile tile, ShadeArgs 
     {
         a.sh_o4[sidx] = sh_o;
         a.sh_d4[sidx] = sh_d;
-        a.sh_ls[sidx] = sh_l;
     }
     uint32_t nidx = wave_append(want_next, &a.counters->queue[a.bounce + 1]);
     if (want_next)
@@ -730,6 +979,29 @@ __global__ __launch_bounds__(256) void k_shade(DScene sc, DTile tile, ShadeArgs 
         a.out_d4[nidx] = nx_d;
         a.out_thr[nidx] = nx_t;
     }
+}
+
+// Replays the radiance log: for every pixel, sample slot by sample slot, contribution
+// by contribution -- the exact order in which the reference's kernels executed
+// `radiance[pixel] += ...` (miss.cl:75, hit_surface.cl:110, accumulate_direct_samples.cl:51).
+__global__ __launch_bounds__(256) void k_flush(float4* __restrict__ radiance, const float4* __restrict__ rlog,
+    uint32_t* __restrict__ cnt, uint32_t n_local, uint32_t n_slots, uint32_t log_stride)
+{
+    uint32_t p = blockIdx.x * 256u + threadIdx.x;
+    if (p >= n_local) return;
+    float4 r = radiance[p];
+    for (uint32_t slot = 0; slot < n_slots; ++slot)
+    {
+        uint32_t id = slot * n_local + p;
+        uint32_t c = cnt[id];
+        for (uint32_t k = 0; k < c; ++k)
+        {
+            float4 v = rlog[(size_t)k * log_stride + id];
+            r.x += v.x; r.y += v.y; r.z += v.z;
+        }
+        if (c) cnt[id] = 0;
+    }
+    radiance[p] = r;
 }
 
 // ResolveRadiance, resolve_radiance.cl:76-85 (shaded colour, denoiser off)

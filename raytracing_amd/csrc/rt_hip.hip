@@ -47,11 +47,20 @@ struct rt_frame
     // queues (ping-pong), hits, shadow queue, radiance
     float4* o4[2]; float4* d4[2]; float4* thr[2];
     float4* hits;
-    float4* sh_o4; float4* sh_d4; float4* sh_ls;
+    float4* sh_o4; float4* sh_d4;
     float4* radiance; float4* resolved;
+    // radiance log (kernels.h header): cnt[id], rlog[entry][id]; id < slots * n_local
+    float4* rlog = nullptr; uint32_t* cnt = nullptr;
+    uint32_t slots = 1;            // RT_OPT_SAMPLES_IN_FLIGHT: samples traced concurrently
+    uint32_t cur_slots = 0;        // slots used by the batch in flight (0 = nothing pending)
+    uint32_t log_stride = 0;       // elements per log entry row = slots * n_local
+    uint32_t log_entries = 0;      // rows allocated (>= 2 * (max_bounces + 1))
+    bool shadow_pending = false;   // rt_shade issued, rt_intersect_shadow not yet
     DCounters* counters;
     uint2* spill;
-    uint32_t trace_blocks;
+    uint32_t trace_blocks;       // v1 grid
+    uint32_t trace_variant = 1;  // RT_OPT_TRACE_VARIANT
+    uint32_t trace_waves_per_cu = 0;   // RT_OPT_TRACE_WAVES_PER_CU (0 = LDS-limited residency)
     // integrator state
     rt_camera camera;
     uint32_t max_bounces = 3;
@@ -276,14 +285,15 @@ int rt_scene_upload(rt_ctx* ctx, const rt_scene_desc* sd)
     s.d.root_max[0] = root.bounds_max.x; s.d.root_max[1] = root.bounds_max.y; s.d.root_max[2] = root.bounds_max.z;
 
     // --- triangles: trace record (p1, e1, e2) and 128-byte shading record
-    std::vector<float4> trt((size_t)nt * 3), tsh((size_t)nt * 8);
+    std::vector<float4> trt((size_t)nt * 4), tsh((size_t)nt * 8);
     for (uint32_t i = 0; i < nt; ++i)
     {
         const rt_triangle& t = sd->triangles[i];
         const rt_float3 &p1 = t.v1.position, &p2 = t.v2.position, &p3 = t.v3.position;
-        trt[(size_t)i * 3 + 0] = make_float4(p1.x, p1.y, p1.z, last_in_leaf[i] ? 1.0f : 0.0f);
-        trt[(size_t)i * 3 + 1] = make_float4(p2.x - p1.x, p2.y - p1.y, p2.z - p1.z, 0.0f);   // e1, trace_bvh.cl:30
-        trt[(size_t)i * 3 + 2] = make_float4(p3.x - p1.x, p3.y - p1.y, p3.z - p1.z, 0.0f);   // e2, trace_bvh.cl:31
+        trt[(size_t)i * 4 + 0] = make_float4(p1.x, p1.y, p1.z, last_in_leaf[i] ? 1.0f : 0.0f);
+        trt[(size_t)i * 4 + 1] = make_float4(p2.x - p1.x, p2.y - p1.y, p2.z - p1.z, 0.0f);   // e1, trace_bvh.cl:30
+        trt[(size_t)i * 4 + 2] = make_float4(p3.x - p1.x, p3.y - p1.y, p3.z - p1.z, 0.0f);   // e2, trace_bvh.cl:31
+        trt[(size_t)i * 4 + 3] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);                        // pad to one 64-byte line
         float4* q = &tsh[(size_t)i * 8];
         q[0] = make_float4(p1.x, p1.y, p1.z, t.v1.texcoord.x);
         q[1] = make_float4(p2.x, p2.y, p2.z, t.v1.texcoord.y);
@@ -342,6 +352,72 @@ int rt_scene_upload(rt_ctx* ctx, const rt_scene_desc* sd)
 }
 
 // ---- frame -----------------------------------------------------------------
+} // extern "C"
+
+namespace
+{
+void free_path_buffers(rt_frame* f)
+{
+    void* ptrs[] = {f->o4[0], f->o4[1], f->d4[0], f->d4[1], f->thr[0], f->thr[1], f->hits, f->sh_o4, f->sh_d4, f->rlog,
+        f->cnt};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    for (int i = 0; i < 2; ++i) { f->o4[i] = nullptr; f->d4[i] = nullptr; f->thr[i] = nullptr; }
+    f->hits = nullptr; f->sh_o4 = nullptr; f->sh_d4 = nullptr; f->rlog = nullptr; f->cnt = nullptr;
+}
+
+// Per-path state: ray queues for `slots` samples in flight and the radiance log
+// with 2 * (max_bounces + 1) entries per path.  (Re)allocated when either changes.
+int alloc_path_buffers(rt_frame* f)
+{
+    rt_ctx* ctx = f->ctx;
+    free_path_buffers(f);
+    uint64_t paths = (uint64_t)(f->n_local ? f->n_local : 1) * f->slots;
+    if (paths > (uint64_t)RT_ID_MASK) return fail(ctx, "samples in flight x tile pixels exceeds 2^25 paths");
+    f->log_stride = (uint32_t)paths;
+    f->log_entries = 2u * (f->max_bounces + 1u);
+    size_t q = (size_t)(paths + 4) * sizeof(float4);   // +4: the unified 64-byte fetch of k_trace reads o4[i+2] / d4[i+2]
+    void** ptrs[] = {(void**)&f->o4[0], (void**)&f->o4[1], (void**)&f->d4[0], (void**)&f->d4[1], (void**)&f->thr[0],
+        (void**)&f->thr[1], (void**)&f->hits, (void**)&f->sh_o4, (void**)&f->sh_d4};
+    bool ok = true;
+    for (void** p : ptrs) ok = ok && hipMalloc(p, q) == hipSuccess;
+    ok = ok && hipMalloc((void**)&f->rlog, (size_t)f->log_entries * paths * sizeof(float4)) == hipSuccess;
+    ok = ok && hipMalloc((void**)&f->cnt, (size_t)paths * sizeof(uint32_t)) == hipSuccess;
+    if (!ok) { free_path_buffers(f); return fail(ctx, "out of device memory for the per-path buffers"); }
+    if (hipMemsetAsync(f->cnt, 0, (size_t)paths * sizeof(uint32_t), ctx->stream) != hipSuccess)
+        return fail(ctx, "hipMemsetAsync failed");
+    f->cur_slots = 0;
+    f->shadow_pending = false;
+    return RT_OK;
+}
+
+// Adds the logged contributions of the batch in flight to the running sum.
+int flush_log(rt_frame* f)
+{
+    rt_ctx* ctx = f->ctx;
+    if (f->cur_slots == 0 || f->n_local == 0) { f->cur_slots = 0; return RT_OK; }
+    if (f->shadow_pending)
+        return fail(ctx, "radiance requested between rt_shade and rt_intersect_shadow (direct samples still tentative)");
+    uint32_t blocks = (f->n_local + 255u) / 256u;
+    hipLaunchKernelGGL(k_flush, dim3(blocks), dim3(256), 0, ctx->stream, f->radiance, (const float4*)f->rlog, f->cnt,
+        f->n_local, f->cur_slots, f->log_stride);
+    if (hipGetLastError() != hipSuccess) return fail(ctx, "k_flush launch failed");
+    f->cur_slots = 0;
+    return RT_OK;
+}
+
+// Mid-sample read (stage API / debugging): apply what has been logged so far but
+// keep the sample open -- later contributions append again from entry 0.
+int flush_log_keep(rt_frame* f)
+{
+    uint32_t keep = f->cur_slots;
+    int rc = flush_log(f);
+    f->cur_slots = keep;
+    return rc;
+}
+} // namespace
+
+extern "C" {
+
 int rt_frame_create(rt_ctx* ctx, const rt_frame_desc* fd, rt_frame** out)
 {
     if (!ctx || !fd || !out) return fail(ctx, "rt_frame_create: NULL argument");
@@ -367,16 +443,16 @@ int rt_frame_create(rt_ctx* ctx, const rt_frame_desc* fd, rt_frame** out)
     size_t n = f->n_local ? f->n_local : 1;
     f->trace_blocks = (uint32_t)ctx->prop.multiProcessorCount * 12u;
     f->trace_blocks = (f->trace_blocks + 7u) & ~7u;
-    size_t q = n * sizeof(float4);
-    void** ptrs[] = {(void**)&f->o4[0], (void**)&f->o4[1], (void**)&f->d4[0], (void**)&f->d4[1], (void**)&f->thr[0],
-        (void**)&f->thr[1], (void**)&f->hits, (void**)&f->sh_o4, (void**)&f->sh_d4, (void**)&f->sh_ls,
-        (void**)&f->radiance, (void**)&f->resolved};
-    for (void** p : ptrs) *p = nullptr;
+    for (int i = 0; i < 2; ++i) { f->o4[i] = nullptr; f->d4[i] = nullptr; f->thr[i] = nullptr; }
+    f->hits = nullptr; f->sh_o4 = nullptr; f->sh_d4 = nullptr; f->radiance = nullptr; f->resolved = nullptr;
     f->counters = nullptr; f->spill = nullptr;
     bool ok = true;
-    for (void** p : ptrs) ok = ok && hipMalloc(p, q) == hipSuccess;
+    ok = ok && hipMalloc((void**)&f->radiance, n * sizeof(float4)) == hipSuccess;
+    ok = ok && hipMalloc((void**)&f->resolved, n * sizeof(float4)) == hipSuccess;
+    ok = ok && alloc_path_buffers(f) == RT_OK;
     ok = ok && hipMalloc((void**)&f->counters, sizeof(DCounters)) == hipSuccess;
-    size_t spill_bytes = (size_t)f->trace_blocks * 64 * (RT_TRACE_STACK_MAX - RT_TRACE_STACK_LDS) * sizeof(uint2);
+    // worst case over the kernel variants: 32 one-wave blocks per CU, 8-entry LDS stack
+    size_t spill_bytes = (size_t)ctx->prop.multiProcessorCount * 32 * 64 * (RT_TRACE_STACK_MAX - 8) * sizeof(uint2);
     ok = ok && hipMalloc((void**)&f->spill, spill_bytes) == hipSuccess;
     if (!ok)
     {
@@ -393,8 +469,8 @@ int rt_frame_destroy(rt_frame* f)
     if (!f) return RT_OK;
     (void)hipSetDevice(f->ctx->device);
     (void)hipStreamSynchronize(f->ctx->stream);
-    void* ptrs[] = {f->o4[0], f->o4[1], f->d4[0], f->d4[1], f->thr[0], f->thr[1], f->hits, f->sh_o4, f->sh_d4, f->sh_ls,
-        f->radiance, f->resolved, f->counters, f->spill};
+    free_path_buffers(f);
+    void* ptrs[] = {f->radiance, f->resolved, f->counters, f->spill};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& s : f->spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
     for (auto e : f->event_pool) (void)hipEventDestroy(e);
@@ -418,7 +494,24 @@ int rt_set_option(rt_frame* f, int option, uint32_t value)
     {
     case RT_OPT_MAX_BOUNCES:
         if (value > RT_MAX_BOUNCES_LIMIT) return fail(f->ctx, "rt_set_option: max_bounces above RT_MAX_BOUNCES_LIMIT");
-        f->max_bounces = value;
+        if (value != f->max_bounces)
+        {
+            if (flush_log(f) != RT_OK) return RT_ERROR;
+            HIPCHK(f->ctx, hipStreamSynchronize(f->ctx->stream));
+            f->max_bounces = value;
+            if (2u * (value + 1u) > f->log_entries) return alloc_path_buffers(f);
+        }
+        return RT_OK;
+    case RT_OPT_SAMPLES_IN_FLIGHT:
+        if (value == 0 || value > 64) return fail(f->ctx, "rt_set_option: samples in flight must be 1..64");
+        if (value != f->slots)
+        {
+            if (flush_log(f) != RT_OK) return RT_ERROR;
+            HIPCHK(f->ctx, hipStreamSynchronize(f->ctx->stream));
+            uint32_t old = f->slots;
+            f->slots = value;
+            if (alloc_path_buffers(f) != RT_OK) { f->slots = old; (void)alloc_path_buffers(f); return RT_ERROR; }
+        }
         return RT_OK;
     case RT_OPT_WHITE_FURNACE: f->white_furnace = value ? 1 : 0; return RT_OK;
     case RT_OPT_SAMPLER:
@@ -432,6 +525,11 @@ int rt_set_option(rt_frame* f, int option, uint32_t value)
         return RT_OK;
     case RT_OPT_TRACE_DROP_LAST_BOUNCE_RAYS: f->drop_last = value ? 1 : 0; return RT_OK;
     case RT_OPT_PROFILE_KERNELS: f->profile = value ? 1 : 0; return RT_OK;
+    case RT_OPT_TRACE_WAVES_PER_CU: f->trace_waves_per_cu = value; return RT_OK;
+    case RT_OPT_TRACE_VARIANT:
+        if (value > 4) return fail(f->ctx, "rt_set_option: unknown trace kernel variant");
+        f->trace_variant = value;
+        return RT_OK;
     default: return fail(f->ctx, "rt_set_option: unknown option");
     }
 }
@@ -472,6 +570,48 @@ struct KernelSpan
     if (!ctx->scene.valid) return fail(ctx, name ": no scene uploaded");                \
     (void)hipSetDevice(ctx->device)
 
+} // extern "C"
+
+namespace
+{
+// Trace kernel variants (RT_OPT_TRACE_VARIANT): 0 = v1 (per-ray loop, 24-entry LDS
+// stack); 1..4 = the one-fetch-per-iteration state machine with a 16 / 24 / 12 / 8
+// entry LDS stack (deeper entries spill to HBM).  One-wave blocks; the persistent
+// grid is sized to the LDS-limited residency: 160 KiB / (entries * 512 B) per CU.
+template <bool SHADOW, int STACK>
+void launch_trace_sm(rt_frame* f, const float4* o4, const float4* d4, const uint32_t* count)
+{
+    rt_ctx* ctx = f->ctx;
+    uint32_t per_cu = (160u * 1024u) / (STACK * 512u);
+    if (per_cu > 32u) per_cu = 32u;
+    if (f->trace_waves_per_cu && f->trace_waves_per_cu < per_cu) per_cu = f->trace_waves_per_cu;
+    uint32_t blocks = ((uint32_t)ctx->prop.multiProcessorCount * per_cu + 7u) & ~7u;
+    hipLaunchKernelGGL((k_trace<SHADOW, STACK>), dim3(blocks), dim3(64), 0, ctx->stream, ctx->scene.d, o4, d4, count,
+        &f->counters->head[SHADOW ? 1 : 0][0], SHADOW ? (float4*)nullptr : f->hits,
+        SHADOW ? f->rlog : (float4*)nullptr, f->log_stride, f->spill);
+}
+
+template <bool SHADOW>
+void launch_trace(rt_frame* f, const float4* o4, const float4* d4, const uint32_t* count)
+{
+    rt_ctx* ctx = f->ctx;
+    switch (f->trace_variant)
+    {
+    case 0:
+        hipLaunchKernelGGL(k_trace_v1<SHADOW>, dim3(f->trace_waves_per_cu ? (((uint32_t)ctx->prop.multiProcessorCount *
+            (f->trace_waves_per_cu < 13u ? f->trace_waves_per_cu : 13u) + 7u) & ~7u) : f->trace_blocks), dim3(64), 0, ctx->stream, ctx->scene.d, o4, d4,
+            count, SHADOW ? (float4*)nullptr : f->hits, SHADOW ? f->rlog : (float4*)nullptr, f->log_stride, f->spill);
+        break;
+    case 2: launch_trace_sm<SHADOW, 24>(f, o4, d4, count); break;
+    case 3: launch_trace_sm<SHADOW, 12>(f, o4, d4, count); break;
+    case 4: launch_trace_sm<SHADOW, 8>(f, o4, d4, count); break;
+    default: launch_trace_sm<SHADOW, 16>(f, o4, d4, count); break;
+    }
+}
+} // namespace
+
+extern "C" {
+
 int rt_reset(rt_frame* f)                               // CLPathTraceIntegrator::Reset, cl_pt_integrator.cpp:497-508
 {
     if (!f) return fail(nullptr, "rt_reset: frame is NULL");
@@ -479,23 +619,44 @@ int rt_reset(rt_frame* f)                               // CLPathTraceIntegrator
     (void)hipSetDevice(ctx->device);
     f->sample_count = 0;
     f->prev_bounces = 0;
+    f->cur_slots = 0;
+    f->shadow_pending = false;
+    HIPCHK(ctx, hipMemsetAsync(f->cnt, 0, (size_t)f->log_stride * sizeof(uint32_t), ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(f->radiance, 0, (size_t)(f->n_local ? f->n_local : 1) * sizeof(float4), ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(f->counters, 0, sizeof(DCounters), ctx->stream));
     return RT_OK;
 }
 
+} // extern "C"
+
+namespace
+{
+// Primary rays for `n_slots` consecutive samples (sample indices sample_count ..
+// sample_count + n_slots - 1) in one launch; they then travel through the same queues.
+int generate_rays(rt_frame* f, uint32_t n_slots)
+{
+    rt_ctx* ctx = f->ctx;
+    if (f->cur_slots != 0) return fail(ctx, "rt_generate_rays: the previous sample was not advanced (rt_advance_sample)");
+    if (2u * (f->max_bounces + 1u) > f->log_entries && alloc_path_buffers(f) != RT_OK) return RT_ERROR;
+    float tan_half_fov = rt_tanf(0.5f * f->camera.fov);  // raygeneration.cl:108, uniform -> host
+    uint32_t blocks = (f->n_local * n_slots + 255u) / 256u;
+    if (blocks == 0) blocks = 1;
+    KernelSpan span(f, 0);
+    hipLaunchKernelGGL(k_raygen, dim3(blocks), dim3(256), 0, ctx->stream, f->tile, f->camera, f->sample_count, n_slots,
+        tan_half_fov, f->prev_bounces, f->o4[0], f->d4[0], f->thr[0], f->counters);
+    f->prev_bounces = f->max_bounces;
+    f->cur_slots = n_slots;
+    HIPCHK(ctx, hipGetLastError());
+    return RT_OK;
+}
+} // namespace
+
+extern "C" {
+
 int rt_generate_rays(rt_frame* f)                       // GenerateRays, :516-520
 {
     FRAME_PROLOGUE(f, "rt_generate_rays");
-    float tan_half_fov = rt_tanf(0.5f * f->camera.fov);  // raygeneration.cl:108, uniform -> host
-    uint32_t blocks = (f->n_local + 255u) / 256u;
-    if (blocks == 0) blocks = 1;
-    KernelSpan span(f, 0);
-    hipLaunchKernelGGL(k_raygen, dim3(blocks), dim3(256), 0, ctx->stream, f->tile, f->camera, f->sample_count,
-        tan_half_fov, f->prev_bounces, f->o4[0], f->d4[0], f->thr[0], f->counters);
-    f->prev_bounces = f->max_bounces;
-    HIPCHK(ctx, hipGetLastError());
-    return RT_OK;
+    return generate_rays(f, 1);
 }
 
 int rt_intersect(rt_frame* f, uint32_t bounce)          // IntersectRays, :522-539
@@ -504,8 +665,7 @@ int rt_intersect(rt_frame* f, uint32_t bounce)          // IntersectRays, :522-5
     if (bounce > RT_MAX_BOUNCES_LIMIT) return fail(ctx, "rt_intersect: bounce out of range");
     uint32_t in = bounce & 1u;
     KernelSpan span(f, 1);
-    hipLaunchKernelGGL(k_trace<false>, dim3(f->trace_blocks), dim3(64), 0, ctx->stream, ctx->scene.d, f->o4[in],
-        f->d4[in], &f->counters->queue[bounce], f->hits, (const float4*)nullptr, (float4*)nullptr, f->spill);
+    launch_trace<false>(f, f->o4[in], f->d4[in], &f->counters->queue[bounce]);
     HIPCHK(ctx, hipGetLastError());
     return RT_OK;
 }
@@ -523,12 +683,15 @@ int rt_shade(rt_frame* f, uint32_t bounce)              // ShadeMissedRays + Sha
     ShadeArgs a;
     a.in_o4 = f->o4[in]; a.in_d4 = f->d4[in]; a.in_thr = f->thr[in]; a.hits = f->hits;
     a.out_o4 = f->o4[out]; a.out_d4 = f->d4[out]; a.out_thr = f->thr[out];
-    a.sh_o4 = f->sh_o4; a.sh_d4 = f->sh_d4; a.sh_ls = f->sh_ls;
-    a.radiance = f->radiance; a.counters = f->counters;
-    a.bounce = bounce; a.sample_idx = f->sample_count;
+    a.sh_o4 = f->sh_o4; a.sh_d4 = f->sh_d4;
+    a.rlog = f->rlog; a.cnt = f->cnt; a.counters = f->counters;
+    a.bounce = bounce; a.sample_base = f->sample_count;
     a.emit_outgoing = (f->drop_last && bounce >= f->max_bounces) ? 0u : 1u;
-    uint32_t blocks = (f->n_local + 255u) / 256u;
+    a.n_local = f->n_local ? f->n_local : 1; a.log_stride = f->log_stride;
+    if (2u * (bounce + 1u) > f->log_entries) return fail(ctx, "rt_shade: bounce beyond the configured max_bounces");
+    uint32_t blocks = (f->n_local * (f->cur_slots ? f->cur_slots : 1u) + 255u) / 256u;
     if (blocks == 0) blocks = 1;
+    f->shadow_pending = true;
     KernelSpan span(f, 2);
     if (f->white_furnace)
         hipLaunchKernelGGL(k_shade<true>, dim3(blocks), dim3(256), 0, ctx->stream, ctx->scene.d, f->tile, a);
@@ -543,8 +706,8 @@ int rt_intersect_shadow(rt_frame* f, uint32_t bounce)   // IntersectShadowRays +
     FRAME_PROLOGUE(f, "rt_intersect_shadow");
     if (bounce > RT_MAX_BOUNCES_LIMIT) return fail(ctx, "rt_intersect_shadow: bounce out of range");
     KernelSpan span(f, 3);
-    hipLaunchKernelGGL(k_trace<true>, dim3(f->trace_blocks), dim3(64), 0, ctx->stream, ctx->scene.d, f->sh_o4,
-        f->sh_d4, &f->counters->shadow[bounce], (float4*)nullptr, f->sh_ls, f->radiance, f->spill);
+    launch_trace<true>(f, f->sh_o4, f->sh_d4, &f->counters->shadow[bounce]);
+    f->shadow_pending = false;
     HIPCHK(ctx, hipGetLastError());
     return RT_OK;
 }
@@ -552,23 +715,31 @@ int rt_intersect_shadow(rt_frame* f, uint32_t bounce)   // IntersectShadowRays +
 int rt_advance_sample(rt_frame* f)                      // AdvanceSampleCount, :510-514
 {
     if (!f) return fail(nullptr, "rt_advance_sample: frame is NULL");
-    f->sample_count++;
+    (void)hipSetDevice(f->ctx->device);
+    uint32_t n = f->cur_slots ? f->cur_slots : 1u;
+    if (flush_log(f) != RT_OK) return RT_ERROR;          // radiance_buffer_ += this sample's contributions
+    f->sample_count += n;
     return RT_OK;
 }
 
 int rt_integrate(rt_frame* f, uint32_t n_samples)       // n x Integrator::Integrate(), integrator.cpp:27-59
 {
     FRAME_PROLOGUE(f, "rt_integrate");
-    for (uint32_t s = 0; s < n_samples; ++s)
+    // `slots` samples travel through the wavefront together (more rays per launch ->
+    // fuller machine, shorter relative tails); the radiance log keeps the sum exact.
+    uint32_t done = 0;
+    while (done < n_samples)
     {
-        if (rt_generate_rays(f) != RT_OK) return RT_ERROR;
+        uint32_t batch = n_samples - done < f->slots ? n_samples - done : f->slots;
+        if (generate_rays(f, batch) != RT_OK) return RT_ERROR;
         for (uint32_t bounce = 0; bounce <= f->max_bounces; ++bounce)
         {
             if (rt_intersect(f, bounce) != RT_OK) return RT_ERROR;
             if (rt_shade(f, bounce) != RT_OK) return RT_ERROR;
             if (rt_intersect_shadow(f, bounce) != RT_OK) return RT_ERROR;
         }
-        f->sample_count++;
+        if (rt_advance_sample(f) != RT_OK) return RT_ERROR;
+        done += batch;
     }
     return RT_OK;
 }
@@ -580,6 +751,7 @@ int rt_frame_resolve(rt_frame* f, float* host_rgba)     // ResolveRadiance, :677
     rt_ctx* ctx = f->ctx;
     (void)hipSetDevice(ctx->device);
     if (f->n_local == 0) return RT_OK;
+    if (flush_log(f) != RT_OK) return RT_ERROR;
     uint32_t blocks = (f->n_local + 255u) / 256u;
     hipLaunchKernelGGL(k_resolve, dim3(blocks), dim3(256), 0, ctx->stream, f->radiance, f->resolved, f->n_local,
         f->sample_count);
@@ -596,6 +768,7 @@ int rt_frame_read_radiance(rt_frame* f, float* host_rgba)
     rt_ctx* ctx = f->ctx;
     (void)hipSetDevice(ctx->device);
     if (f->n_local == 0) return RT_OK;
+    if (flush_log_keep(f) != RT_OK) return RT_ERROR;
     HIPCHK(ctx, hipMemcpyAsync(host_rgba, f->radiance, (size_t)f->n_local * sizeof(float4), hipMemcpyDeviceToHost,
         ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -647,6 +820,7 @@ int rt_frame_copy_radiance(rt_frame* f, void* device_dst)
     rt_ctx* ctx = f->ctx;
     (void)hipSetDevice(ctx->device);
     if (f->n_local == 0) return RT_OK;
+    if (flush_log_keep(f) != RT_OK) return RT_ERROR;
     HIPCHK(ctx, hipMemcpyAsync(device_dst, f->radiance, (size_t)f->n_local * sizeof(float4), hipMemcpyDeviceToDevice,
         ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -665,20 +839,24 @@ int rt_frame_debug_read_queue(rt_frame* f, int which, uint32_t bounce, rt_ray* r
     HIPCHK(ctx, hipMemcpyAsync(&h, f->counters, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     uint32_t n = which == 0 ? h.queue[bounce] : h.shadow[bounce];
-    if (n > f->n_local) return fail(ctx, "rt_frame_debug_read_queue: corrupt counter");
+    if (n > f->log_stride) return fail(ctx, "rt_frame_debug_read_queue: corrupt counter");
     *count = n;
     if (n == 0) return RT_OK;
     const float4* so = which == 0 ? f->o4[bounce & 1u] : f->sh_o4;
     const float4* sdir = which == 0 ? f->d4[bounce & 1u] : f->sh_d4;
-    const float4* sp = which == 0 ? f->thr[bounce & 1u] : f->sh_ls;
     std::vector<float4> o(n), d(n), p(n);
     HIPCHK(ctx, hipMemcpy(o.data(), so, (size_t)n * 16, hipMemcpyDeviceToHost));
     HIPCHK(ctx, hipMemcpy(d.data(), sdir, (size_t)n * 16, hipMemcpyDeviceToHost));
-    HIPCHK(ctx, hipMemcpy(p.data(), sp, (size_t)n * 16, hipMemcpyDeviceToHost));
+    if (which == 0) HIPCHK(ctx, hipMemcpy(p.data(), f->thr[bounce & 1u], (size_t)n * 16, hipMemcpyDeviceToHost));
     for (uint32_t i = 0; i < n; ++i)
     {
-        uint32_t local_pix;
-        memcpy(&local_pix, &d[i].w, 4);
+        uint32_t pl;
+        memcpy(&pl, &d[i].w, 4);
+        uint32_t id = which == 0 ? pl : (pl & RT_ID_MASK);
+        uint32_t local_pix = id % (f->n_local ? f->n_local : 1);
+        if (which == 1)   // the deferred direct-light sample lives in the radiance log
+            HIPCHK(ctx, hipMemcpy(&p[i], f->rlog + (size_t)(pl >> RT_ID_BITS) * f->log_stride + id, 16,
+                hipMemcpyDeviceToHost));
         if (rays)
         {
             rays[i].origin.x = o[i].x; rays[i].origin.y = o[i].y; rays[i].origin.z = o[i].z; rays[i].origin.w = 0.0f;
@@ -700,7 +878,7 @@ int rt_frame_debug_read_hits(rt_frame* f, rt_hit* hits, uint32_t count)
     if (!f || !hits) return fail(nullptr, "rt_frame_debug_read_hits: NULL argument");
     rt_ctx* ctx = f->ctx;
     (void)hipSetDevice(ctx->device);
-    if (count > f->n_local) return fail(ctx, "rt_frame_debug_read_hits: count too large");
+    if (count > f->log_stride) return fail(ctx, "rt_frame_debug_read_hits: count too large");
     std::vector<float4> h(count ? count : 1);
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     HIPCHK(ctx, hipMemcpy(h.data(), f->hits, (size_t)count * 16, hipMemcpyDeviceToHost));
