@@ -150,7 +150,13 @@ def main():
 
     # ---- warm-up ------------------------------------------------------------
     render.render_samples(args.warmup) if args.warmup > 0 else None
+    if args.warmup > 0:     # the gather path too (first use loads torch / RCCL kernels)
+        if local_rows:
+            lib.rt_frame_copy_radiance(frame, tile.data_ptr())
+        D.gather_image(tile[:local_rows], args.height, args.width, rank, world, args.band_height)
     sync()
+    # the timed region starts from a reset accumulation (sample indices 0..K-1, counters at 0)
+    assert lib.rt_reset(frame) == 0
     st0 = render.stats()
     lib.rt_set_option(frame, capi.OPT_PROFILE, 1)
     prof = capi.rt_profile()
@@ -162,14 +168,19 @@ def main():
     # ---- timed region: exactly K steps + the one gather ----------------------
     t0 = time.perf_counter()
     render.render_samples(args.steps)
+    t_enq = time.perf_counter() - t0
     if local_rows:
         lib.rt_frame_copy_radiance(frame, tile.data_ptr())
+    t_render = time.perf_counter() - t0
     full = D.gather_image(tile[:local_rows], args.height, args.width, rank, world, args.band_height)
     sync()
     if world > 1:
         dist.barrier()
     sync()
     dt = time.perf_counter() - t0
+    if os.environ.get("RT_BENCH_DEBUG"):
+        print("rank %d: enqueue %.1f ms, render+copy %.1f ms, total %.1f ms" % (rank, t_enq * 1e3, t_render * 1e3, dt * 1e3),
+              file=sys.stderr, flush=True)
 
     st1 = render.stats()
     lib.rt_frame_get_profile(frame, prof)

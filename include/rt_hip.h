@@ -105,12 +105,13 @@ enum rt_option
     RT_OPT_DENOISER = 4,       /* Integrator::EnableDenoiser: 0 (only value implemented) */
     RT_OPT_TRACE_DROP_LAST_BOUNCE_RAYS = 5, /* 1 (default): do not emit the never-traced rays of the last bounce */
     RT_OPT_PROFILE_KERNELS = 6, /* 1: bracket every kernel launch with HIP events on the context stream */
-    RT_OPT_TRACE_VARIANT = 7    /* traversal kernel: 0 = v1 per-ray loop; 1 (default) .. 4 = one-fetch-per-iteration
-                                   state machine with a 16 / 24 / 12 / 8 entry LDS stack.  Results are identical. */
+    RT_OPT_TRACE_VARIANT = 7    /* traversal kernel: 0 = v1 per-ray loop; 1 .. 4 = one-fetch-per-iteration state
+                                   machine with a 16 / 24 / 12 (default, 3) / 8 entry LDS stack.  Results are identical. */
     , RT_OPT_TRACE_WAVES_PER_CU = 8 /* persistent-grid size of the trace kernels in waves per CU (0 = as many as fit) */
     , RT_OPT_SAMPLES_IN_FLIGHT = 9  /* rt_integrate traces this many consecutive samples per pixel concurrently
-                                       (1..64, default 1; tile pixels x samples <= 2^25).  Results are bit-identical
-                                       for every value: contributions are logged per path and replayed in order. */
+                                       (1..64; 0 = auto, the default: largest power of two <= 32 with tile pixels x
+                                       samples < 2^25).  Results are bit-identical for every value: contributions
+                                       are logged per path and replayed in the reference's order. */
 };
 int rt_set_option(rt_frame* frame, int option, uint32_t value);
 int rt_set_camera(rt_frame* frame, const rt_camera* camera);       /* SetCameraData, cl_pt_integrator.cpp:365-371 */
@@ -152,7 +153,7 @@ typedef struct rt_stats
     uint64_t closest_rays;        /* sum over samples and bounces of rays traced closest-hit */
     uint64_t shadow_rays;         /* ... of shadow rays traced */
     uint64_t samples;             /* Integrate() calls since the last reset */
-    uint32_t last_active[64];     /* per-bounce counts of the most recent sample */
+    uint32_t last_active[64];     /* per-bounce counts of the most recent batch of samples in flight */
     uint32_t last_shadow[64];
 } rt_stats;
 int rt_frame_get_stats(rt_frame* frame, rt_stats* out);

@@ -805,22 +805,38 @@ RT_DEV f3 SampleSky(const DScene& sc, f3 dir)
               w00 * t00.z + w10 * t10.z + w01 * t01.z + w11 * t11.z);
 }
 
-// wave64 stream compaction: one global atomic per wave per queue instead of
-// the reference's one per ray (hit_surface.cl:138,173)
-RT_DEV uint32_t wave_append(bool want, uint32_t* counter)
+// Stream compaction for the two output queues: wave64 ballot + prefix inside a
+// wave, LDS prefix across the waves of a block, ONE global atomic per block per
+// queue -- instead of the reference's one same-address atomic per ray
+// (hit_surface.cl:138,173).  Same-address L2 atomics retire at ~10 ns each on
+// MI355X, so at ~20 M rays per launch even one atomic per wave (600 k of them) was
+// the shade kernel's bottleneck; per 512-thread block it is 8x fewer.
+#define RT_SHADE_BLOCK 512
+RT_DEV void block_append2(bool want_a, bool want_b, uint32_t* counter_a, uint32_t* counter_b, uint32_t& idx_a,
+    uint32_t& idx_b)
 {
-    unsigned long long mask = __ballot(want);
-    uint32_t total = (uint32_t)__popcll(mask);
-    uint32_t lane = threadIdx.x & 63u;
-    uint32_t before = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-    uint32_t base = 0;
-    if (total != 0)
+    __shared__ uint32_t s_cnt[2][RT_SHADE_BLOCK / 64];
+    __shared__ uint32_t s_base[2];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    unsigned long long ma = __ballot(want_a), mb = __ballot(want_b);
+    if (lane == 0)
     {
-        int leader = __ffsll((long long)mask) - 1;
-        if ((int)lane == leader) base = atomicAdd(counter, total);
-        base = __shfl(base, leader, 64);
+        s_cnt[0][wave] = (uint32_t)__popcll(ma);
+        s_cnt[1][wave] = (uint32_t)__popcll(mb);
     }
-    return base + before;
+    __syncthreads();
+    if (threadIdx.x < 2)
+    {
+        uint32_t total = 0;
+        for (uint32_t w = 0; w < RT_SHADE_BLOCK / 64; ++w) total += s_cnt[threadIdx.x][w];
+        s_base[threadIdx.x] = total ? atomicAdd(threadIdx.x == 0 ? counter_a : counter_b, total) : 0u;
+    }
+    __syncthreads();
+    uint32_t pa = s_base[0], pb = s_base[1];
+    for (uint32_t w = 0; w < wave; ++w) { pa += s_cnt[0][w]; pb += s_cnt[1][w]; }
+    idx_a = pa + (uint32_t)__popcll(ma & lt);
+    idx_b = pb + (uint32_t)__popcll(mb & lt);
 }
 
 struct ShadeArgs
@@ -834,14 +850,14 @@ struct ShadeArgs
 };
 
 template <bool FURNACE>
-__global__ __launch_bounds__(256) void k_shade(DScene sc, DTile tile, ShadeArgs a)
+__global__ __launch_bounds__(RT_SHADE_BLOCK) void k_shade(DScene sc, DTile tile, ShadeArgs a)
 {
     const uint32_t count = a.counters->queue[a.bounce];
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t i = blockIdx.x * RT_SHADE_BLOCK + threadIdx.x;
     // the closest-hit trace of this bounce has completed (stream order): rewind the
     // work heads for the shadow trace of this bounce and the closest trace of the next
     if (i < 16) a.counters->head[i >> 3][i & 7] = 0;
-    if (blockIdx.x * 256u >= count) return;                              // whole block idle (uniform)
+    if (blockIdx.x * RT_SHADE_BLOCK >= count) return;                    // whole block idle (uniform)
     const bool active = i < count;
 
     bool want_shadow = false, want_next = false;
@@ -966,13 +982,13 @@ __global__ __launch_bounds__(256) void k_shade(DScene sc, DTile tile, ShadeArgs 
         a.cnt[id] = nlog;
     }
 
-    uint32_t sidx = wave_append(want_shadow, &a.counters->shadow[a.bounce]);
+    uint32_t sidx, nidx;
+    block_append2(want_shadow, want_next, &a.counters->shadow[a.bounce], &a.counters->queue[a.bounce + 1], sidx, nidx);
     if (want_shadow)
     {
         a.sh_o4[sidx] = sh_o;
         a.sh_d4[sidx] = sh_d;
     }
-    uint32_t nidx = wave_append(want_next, &a.counters->queue[a.bounce + 1]);
     if (want_next)
     {
         a.out_o4[nidx] = nx_o;

@@ -51,7 +51,8 @@ struct rt_frame
     float4* radiance; float4* resolved;
     // radiance log (kernels.h header): cnt[id], rlog[entry][id]; id < slots * n_local
     float4* rlog = nullptr; uint32_t* cnt = nullptr;
-    uint32_t slots = 1;            // RT_OPT_SAMPLES_IN_FLIGHT: samples traced concurrently
+    uint32_t slots = 1;            // samples traced concurrently (resolved from slots_opt)
+    uint32_t slots_opt = 0;        // RT_OPT_SAMPLES_IN_FLIGHT as set by the caller (0 = auto)
     uint32_t cur_slots = 0;        // slots used by the batch in flight (0 = nothing pending)
     uint32_t log_stride = 0;       // elements per log entry row = slots * n_local
     uint32_t log_entries = 0;      // rows allocated (>= 2 * (max_bounces + 1))
@@ -59,7 +60,7 @@ struct rt_frame
     DCounters* counters;
     uint2* spill;
     uint32_t trace_blocks;       // v1 grid
-    uint32_t trace_variant = 1;  // RT_OPT_TRACE_VARIANT
+    uint32_t trace_variant = 3;  // RT_OPT_TRACE_VARIANT
     uint32_t trace_waves_per_cu = 0;   // RT_OPT_TRACE_WAVES_PER_CU (0 = LDS-limited residency)
     // integrator state
     rt_camera camera;
@@ -367,10 +368,19 @@ void free_path_buffers(rt_frame* f)
 
 // Per-path state: ray queues for `slots` samples in flight and the radiance log
 // with 2 * (max_bounces + 1) entries per path.  (Re)allocated when either changes.
+// auto: the largest power of two <= 32 that keeps tile pixels x samples within the 2^25 path ids
+uint32_t auto_slots(uint32_t n_local)
+{
+    uint32_t s = 32;
+    while (s > 1 && (uint64_t)s * (n_local ? n_local : 1) > (uint64_t)RT_ID_MASK) s >>= 1;
+    return s;
+}
+
 int alloc_path_buffers(rt_frame* f)
 {
     rt_ctx* ctx = f->ctx;
     free_path_buffers(f);
+    f->slots = f->slots_opt ? f->slots_opt : auto_slots(f->n_local);
     uint64_t paths = (uint64_t)(f->n_local ? f->n_local : 1) * f->slots;
     if (paths > (uint64_t)RT_ID_MASK) return fail(ctx, "samples in flight x tile pixels exceeds 2^25 paths");
     f->log_stride = (uint32_t)paths;
@@ -503,14 +513,14 @@ int rt_set_option(rt_frame* f, int option, uint32_t value)
         }
         return RT_OK;
     case RT_OPT_SAMPLES_IN_FLIGHT:
-        if (value == 0 || value > 64) return fail(f->ctx, "rt_set_option: samples in flight must be 1..64");
-        if (value != f->slots)
+        if (value > 64) return fail(f->ctx, "rt_set_option: samples in flight must be 0 (auto) or 1..64");
+        if (value != f->slots_opt)
         {
             if (flush_log(f) != RT_OK) return RT_ERROR;
             HIPCHK(f->ctx, hipStreamSynchronize(f->ctx->stream));
-            uint32_t old = f->slots;
-            f->slots = value;
-            if (alloc_path_buffers(f) != RT_OK) { f->slots = old; (void)alloc_path_buffers(f); return RT_ERROR; }
+            uint32_t old = f->slots_opt;
+            f->slots_opt = value;
+            if (alloc_path_buffers(f) != RT_OK) { f->slots_opt = old; (void)alloc_path_buffers(f); return RT_ERROR; }
         }
         return RT_OK;
     case RT_OPT_WHITE_FURNACE: f->white_furnace = value ? 1 : 0; return RT_OK;
@@ -602,10 +612,10 @@ void launch_trace(rt_frame* f, const float4* o4, const float4* d4, const uint32_
             (f->trace_waves_per_cu < 13u ? f->trace_waves_per_cu : 13u) + 7u) & ~7u) : f->trace_blocks), dim3(64), 0, ctx->stream, ctx->scene.d, o4, d4,
             count, SHADOW ? (float4*)nullptr : f->hits, SHADOW ? f->rlog : (float4*)nullptr, f->log_stride, f->spill);
         break;
+    case 1: launch_trace_sm<SHADOW, 16>(f, o4, d4, count); break;
     case 2: launch_trace_sm<SHADOW, 24>(f, o4, d4, count); break;
-    case 3: launch_trace_sm<SHADOW, 12>(f, o4, d4, count); break;
     case 4: launch_trace_sm<SHADOW, 8>(f, o4, d4, count); break;
-    default: launch_trace_sm<SHADOW, 16>(f, o4, d4, count); break;
+    default: launch_trace_sm<SHADOW, 12>(f, o4, d4, count); break;
     }
 }
 } // namespace
@@ -689,14 +699,14 @@ int rt_shade(rt_frame* f, uint32_t bounce)              // ShadeMissedRays + Sha
     a.emit_outgoing = (f->drop_last && bounce >= f->max_bounces) ? 0u : 1u;
     a.n_local = f->n_local ? f->n_local : 1; a.log_stride = f->log_stride;
     if (2u * (bounce + 1u) > f->log_entries) return fail(ctx, "rt_shade: bounce beyond the configured max_bounces");
-    uint32_t blocks = (f->n_local * (f->cur_slots ? f->cur_slots : 1u) + 255u) / 256u;
+    uint32_t blocks = (f->n_local * (f->cur_slots ? f->cur_slots : 1u) + RT_SHADE_BLOCK - 1u) / RT_SHADE_BLOCK;
     if (blocks == 0) blocks = 1;
     f->shadow_pending = true;
     KernelSpan span(f, 2);
     if (f->white_furnace)
-        hipLaunchKernelGGL(k_shade<true>, dim3(blocks), dim3(256), 0, ctx->stream, ctx->scene.d, f->tile, a);
+        hipLaunchKernelGGL(k_shade<true>, dim3(blocks), dim3(RT_SHADE_BLOCK), 0, ctx->stream, ctx->scene.d, f->tile, a);
     else
-        hipLaunchKernelGGL(k_shade<false>, dim3(blocks), dim3(256), 0, ctx->stream, ctx->scene.d, f->tile, a);
+        hipLaunchKernelGGL(k_shade<false>, dim3(blocks), dim3(RT_SHADE_BLOCK), 0, ctx->stream, ctx->scene.d, f->tile, a);
     HIPCHK(ctx, hipGetLastError());
     return RT_OK;
 }

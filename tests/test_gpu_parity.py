@@ -30,12 +30,14 @@ def ctx():
     c.close()
 
 
-def render(ctx, scene, w, h, cam, bounces, spp, furnace=False, **tile):
+def render(ctx, scene, w, h, cam, bounces, spp, furnace=False, slots=None, **tile):
     ctx.upload_scene(scene)
     fr = capi.Frame(ctx, w, h, **tile)
     fr.set_camera(cam)
     fr.set_max_bounces(bounces)
     fr.set_option(capi.OPT_WHITE_FURNACE, int(furnace))
+    if slots is not None:
+        fr.set_option(capi.OPT_SAMPLES_IN_FLIGHT, slots)     # default 0 = auto (several samples per batch)
     fr.integrate(spp)
     return fr
 
@@ -44,8 +46,10 @@ def render(ctx, scene, w, h, cam, bounces, spp, furnace=False, **tile):
 def test_radiance_matches_reference_golden_vectors(ctx, case, golden_scenes, golden_radiance):
     name, key, w, h, b, spp, furnace = case
     g = golden_radiance
-    fr = render(ctx, golden_scenes[key], w, h, g[name + "/camera"], b, spp, furnace)
+    fr = render(ctx, golden_scenes[key], w, h, g[name + "/camera"], b, spp, furnace, slots=1)
     got = fr.radiance()[..., :3]
+    auto = render(ctx, golden_scenes[key], w, h, g[name + "/camera"], b, spp, furnace)   # default batching
+    assert np.array_equal(auto.radiance()[..., :3], g[name + "/radiance"])
     assert rel_l2(got, g[name + "/radiance"]) < TOL
     assert np.array_equal(got, g[name + "/radiance"])
     assert np.array_equal(fr.resolve()[..., :3], g[name + "/resolved"])
@@ -271,7 +275,7 @@ def test_samples_in_flight_and_kernel_variants_are_bit_invariant(ctx, golden_sce
     w, h, b, spp = 64, 48, 6, 7          # 7 is not a multiple of any slots value: partial last batch
     sc = golden_scenes["coverage"]
     cam = T.default_camera(w, h)
-    base = render(ctx, sc, w, h, cam, b, spp)
+    base = render(ctx, sc, w, h, cam, b, spp, slots=1)
     ctx.upload_scene(sc)
     fr = capi.Frame(ctx, w, h)
     fr.set_camera(cam)
