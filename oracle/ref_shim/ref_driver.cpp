@@ -16,6 +16,10 @@
 #include <vector>
 #include <thread>
 #include <functional>
+#include <atomic>
+#include <condition_variable>
+#include <memory>
+#include <mutex>
 #include "rt_types.h"
 
 typedef float float2 __attribute__((ext_vector_type(2)));
@@ -56,6 +60,7 @@ void ResolveRadiance(uint, uint, uint, float4*, float3*, float*, float3*, float2
 namespace
 {
 struct RTTri { rt_float3 p1, p2, p3; };   // RTTriangle, shared_structures.h:143-153
+class Pool;
 
 struct RefIntegrator
 {
@@ -100,36 +105,99 @@ struct RefIntegrator
     // statistics (ray counters sampled per bounce)
     uint64_t total_closest = 0, total_shadow = 0;
     uint last_active[64] = {0}, last_shadow[64] = {0};
+    std::shared_ptr<Pool> pool;
 };
 
 // single work-item launches (ExecuteKernel(kernel, 1), cl_pt_integrator.cpp:503,513,656,662)
 void Clear(uint* counter) { ref_global_id = 0; ClearCounter(counter); }
 void Increment(uint* counter) { ref_global_id = 0; IncrementCounter(counter); }
 
+// Persistent worker pool: an NDRange is split into 256-item chunks handed out
+// through an atomic counter (dynamic schedule -- path lengths vary a lot).
+class Pool
+{
+public:
+    explicit Pool(int n) : n_(n > 1 ? n : 1)
+    {
+        for (int t = 1; t < n_; ++t) workers_.emplace_back([this]() { Loop(); });
+    }
+    ~Pool()
+    {
+        {
+            std::unique_lock<std::mutex> lk(m_);
+            stop_ = true;
+            ++epoch_;
+        }
+        cv_.notify_all();
+        for (auto& w : workers_) w.join();
+    }
+    void Run(size_t work_size, const std::function<void()>& body)
+    {
+        if (n_ == 1 || work_size < 4096)
+        {
+            for (size_t i = 0; i < work_size; ++i) { ref_global_id = i; body(); }
+            return;
+        }
+        {
+            std::unique_lock<std::mutex> lk(m_);
+            body_ = &body;
+            work_ = work_size;
+            next_.store(0);
+            pending_ = n_ - 1;
+            ++epoch_;
+        }
+        cv_.notify_all();
+        Work();
+        std::unique_lock<std::mutex> lk(m_);
+        done_.wait(lk, [this]() { return pending_ == 0; });
+    }
+
+private:
+    void Work()
+    {
+        const size_t chunk = 256;
+        for (;;)
+        {
+            size_t b = next_.fetch_add(chunk);
+            if (b >= work_) break;
+            size_t e = b + chunk < work_ ? b + chunk : work_;
+            for (size_t i = b; i < e; ++i) { ref_global_id = i; (*body_)(); }
+        }
+    }
+    void Loop()
+    {
+        uint64_t seen = 0;
+        for (;;)
+        {
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [&]() { return epoch_ != seen; });
+                seen = epoch_;
+                if (stop_) return;
+            }
+            Work();
+            std::unique_lock<std::mutex> lk(m_);
+            if (--pending_ == 0) done_.notify_one();
+        }
+    }
+    int n_;
+    std::vector<std::thread> workers_;
+    std::mutex m_;
+    std::condition_variable cv_, done_;
+    const std::function<void()>* body_ = nullptr;
+    size_t work_ = 0;
+    std::atomic<size_t> next_{0};
+    int pending_ = 0;
+    uint64_t epoch_ = 0;
+    bool stop_ = false;
+};
+
 template <class F>
 void NDRange(RefIntegrator& r, size_t work_size, F&& body)
 {
-    const size_t chunk = 64;
-    int nthreads = r.threads;
-    if (nthreads <= 1 || work_size < 4096)
-    {
-        for (size_t i = 0; i < work_size; ++i) { ref_global_id = i; body(); }
-        return;
-    }
-    size_t nchunks = (work_size + chunk - 1) / chunk;
-    std::vector<std::thread> pool;
-    for (int t = 0; t < nthreads; ++t)
-    {
-        pool.emplace_back([&, t]()
-        {
-            for (size_t c = t; c < nchunks; c += nthreads)
-            {
-                size_t end = (c + 1) * chunk < work_size ? (c + 1) * chunk : work_size;
-                for (size_t i = c * chunk; i < end; ++i) { ref_global_id = i; body(); }
-            }
-        });
-    }
-    for (auto& th : pool) th.join();
+    if (!r.pool) r.pool = std::make_shared<Pool>(r.threads);
+    std::function<void()> fn = body;
+    r.pool->Run(work_size, fn);
 }
 
 void Reset(RefIntegrator& r)                       // cl_pt_integrator.cpp:497-508
