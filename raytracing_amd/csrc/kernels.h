@@ -12,7 +12,9 @@
 //
 // Device data layout (HBM), chosen for coalesced 16-byte accesses:
 //   ray queues   SoA: o4[i] = (origin.xyz, t_max), d4[i] = (dir.xyz, path id bits),
-//                thr[i] = (throughput.xyz, -).  path id = slot * n_pixels + pixel, where
+//                iv4[i] = (1/dir.xyz, sign bits) computed by the PRODUCER of the ray (all 64
+//                lanes busy) instead of by the traversal kernel (where ~2 lanes of a wave
+//                start a ray in any given iteration), thr[i] = (throughput.xyz, -).  path id = slot * n_pixels + pixel, where
 //                `slot` numbers the samples in flight (RT_OPT_SAMPLES_IN_FLIGHT); shadow
 //                rays carry (log entry << 25 | path id)
 //   radiance log per path: cnt[id] + log[k][id] (float4) = the path's radiance
@@ -51,6 +53,7 @@ struct DScene
     int env_w, env_h;
     uint32_t light_count;
     uint32_t root_ref;            // RT_LEAF_BIT | first triangle, or interior node 0
+    uint32_t entry_ref;           // "super-root" record: child 0 = (root box, root_ref), child 1 empty
     float root_min[3];
     float root_max[3];
 };
@@ -79,12 +82,20 @@ struct DCounters                  // one per frame, device memory
     uint32_t head[2][8];
 };
 
+// ray_inv_dir and ray_sign of TraceBvh (trace_bvh.cl:125-129), packed as (inv.xyz, sign bits)
+RT_DEV float4 ray_inverse(f3 dir)
+{
+    f3 inv = F3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
+    uint32_t sign_bits = (inv.x < 0.0f ? 1u : 0u) | (inv.y < 0.0f ? 2u : 0u) | (inv.z < 0.0f ? 4u : 0u);
+    return make_float4(inv.x, inv.y, inv.z, __uint_as_float(sign_bits));
+}
+
 // ---------------------------------------------------------------------------
 // sample begin + ray generation (raygeneration.cl:65-139)
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_raygen(DTile tile, rt_camera cam, uint32_t sample_base, uint32_t n_slots,
     float tan_half_fov, uint32_t prev_bounces, float4* __restrict__ o4, float4* __restrict__ d4,
-    float4* __restrict__ thr, DCounters* __restrict__ counters)
+    float4* __restrict__ iv4, float4* __restrict__ thr, DCounters* __restrict__ counters)
 {
     uint32_t n_local = tile.local_rows * tile.width;
     uint32_t n_total = n_local * n_slots;                                // n_slots samples in flight
@@ -153,6 +164,7 @@ __global__ __launch_bounds__(256) void k_raygen(DTile tile, rt_camera cam, uint3
 
     o4[i] = make_float4(new_pos.x, new_pos.y, new_pos.z, RT_MAX_RENDER_DIST);
     d4[i] = make_float4(d.x, d.y, d.z, __uint_as_float(i));              // path id = slot * n_local + local pixel
+    iv4[i] = ray_inverse(d);
     thr[i] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
 }
 
@@ -358,7 +370,8 @@ enum { ST_NEED = 0, ST_RAY = 1, ST_TRAV = 2, ST_DONE = 3 };
 
 template <bool SHADOW, int STACK>
 __global__ __launch_bounds__(64) void k_trace(DScene sc, const float4* __restrict__ o4, const float4* __restrict__ d4,
-    const uint32_t* __restrict__ count_ptr, uint32_t* __restrict__ heads, float4* __restrict__ hits,
+    const float4* __restrict__ iv4, const uint32_t* __restrict__ count_ptr, uint32_t* __restrict__ heads,
+    float4* __restrict__ hits,
     float4* __restrict__ rlog, uint32_t log_stride, uint2* __restrict__ spill)
 {
     __shared__ uint2 stack[STACK][64];
@@ -426,40 +439,37 @@ __global__ __launch_bounds__(64) void k_trace(DScene sc, const float4* __restric
         if (__ballot(state != ST_DONE) == 0ull) break;
 
         // ---- ONE 64-byte record per lane: ray | node | triangle -----------------
-        const float4* pa;
-        const float4* pb;
-        if (state == ST_RAY) { pa = o4 + ray_i; pb = d4 + ray_i; }
+        const float4 *p0, *p1, *p2, *p3;
+        if (state == ST_RAY) { p0 = o4 + ray_i; p1 = d4 + ray_i; p2 = iv4 + ray_i; p3 = p2; }
         else
         {
             const float4* base = (ref & RT_LEAF_BIT) ? sc.tris_rt + (size_t)(ref & ~RT_LEAF_BIT) * 4
                                                      : sc.nodes + (size_t)ref * 4;
-            pa = base;
-            pb = base + 1;
+            p0 = base; p1 = base + 1; p2 = base + 2; p3 = base + 3;
         }
         float4 q0 = make_float4(0, 0, 0, 0), q1 = q0, q2 = q0, q3 = q0;
         if (state != ST_DONE)
         {
-            q0 = pa[0]; q1 = pb[0]; q2 = pa[2]; q3 = pb[2];
+            q0 = *p0; q1 = *p1; q2 = *p2; q3 = *p3;
         }
         if (SHADOW && state == ST_RAY) payload = __float_as_uint(q1.w);
 
         bool finished = false, need_pop = false;
         if (state == ST_RAY)
         {
+            // ray start: registers only.  1/dir and the sign bits come from the producer
+            // (ray_inverse); the root box test (trace_bvh.cl:146-148, first iteration) is the
+            // ordinary node test of the "super-root" record entry_ref in the next iteration.
             org = F3(q0.x, q0.y, q0.z);
             dir = F3(q1.x, q1.y, q1.z);
             t_max = q0.w;
-            inv = F3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);             // trace_bvh.cl:125
-            sign_bits = (inv.x < 0.0f ? 1u : 0u) | (inv.y < 0.0f ? 2u : 0u) | (inv.z < 0.0f ? 4u : 0u);
+            inv = F3(q2.x, q2.y, q2.z);
+            sign_bits = __float_as_uint(q2.w);
             hit_prim = RT_INVALID_ID;
             hit_u = 0.0f; hit_v = 0.0f;
             sp = 0;
-            ref = sc.root_ref;
-            float entry;
-            bool alive = box_test(sc.root_min[0], sc.root_min[1], sc.root_min[2], sc.root_max[0], sc.root_max[1],
-                sc.root_max[2], org, inv, t_min, t_max, entry);
+            ref = sc.entry_ref;
             state = ST_TRAV;
-            finished = !alive;
         }
         else if (state == ST_TRAV)
         {
@@ -842,8 +852,8 @@ RT_DEV void block_append2(bool want_a, bool want_b, uint32_t* counter_a, uint32_
 struct ShadeArgs
 {
     const float4* in_o4; const float4* in_d4; const float4* in_thr; const float4* hits;
-    float4* out_o4; float4* out_d4; float4* out_thr;
-    float4* sh_o4; float4* sh_d4;
+    float4* out_o4; float4* out_d4; float4* out_iv4; float4* out_thr;
+    float4* sh_o4; float4* sh_d4; float4* sh_iv4;
     float4* rlog; uint32_t* cnt;      // radiance log (see file header)
     DCounters* counters;
     uint32_t bounce, sample_base, emit_outgoing, n_local, log_stride;
@@ -988,11 +998,13 @@ __global__ __launch_bounds__(RT_SHADE_BLOCK) void k_shade(DScene sc, DTile tile,
     {
         a.sh_o4[sidx] = sh_o;
         a.sh_d4[sidx] = sh_d;
+        a.sh_iv4[sidx] = ray_inverse(F3(sh_d.x, sh_d.y, sh_d.z));
     }
     if (want_next)
     {
         a.out_o4[nidx] = nx_o;
         a.out_d4[nidx] = nx_d;
+        a.out_iv4[nidx] = ray_inverse(F3(nx_d.x, nx_d.y, nx_d.z));
         a.out_thr[nidx] = nx_t;
     }
 }

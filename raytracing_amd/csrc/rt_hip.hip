@@ -45,9 +45,9 @@ struct rt_frame
     DTile tile;
     uint32_t n_local;
     // queues (ping-pong), hits, shadow queue, radiance
-    float4* o4[2]; float4* d4[2]; float4* thr[2];
+    float4* o4[2]; float4* d4[2]; float4* iv4[2]; float4* thr[2];
     float4* hits;
-    float4* sh_o4; float4* sh_d4;
+    float4* sh_o4; float4* sh_d4; float4* sh_iv4;
     float4* radiance; float4* resolved;
     // radiance log (kernels.h header): cnt[id], rlog[entry][id]; id < slots * n_local
     float4* rlog = nullptr; uint32_t* cnt = nullptr;
@@ -261,7 +261,7 @@ int rt_scene_upload(rt_ctx* ctx, const rt_scene_desc* sd)
         if ((c.num_primitives_axis >> 16) > 0) return RT_LEAF_BIT | c.offset;
         return interior_index[ref_idx];
     };
-    std::vector<float4> nodes2((size_t)(n_interior ? n_interior : 1) * 4);
+    std::vector<float4> nodes2((size_t)(n_interior + 1) * 4);   // + the super-root record
     for (uint32_t i = 0; i < nn; ++i)
     {
         const rt_bvh_node& nd = sd->nodes[i];
@@ -282,6 +282,19 @@ int rt_scene_upload(rt_ctx* ctx, const rt_scene_desc* sd)
     }
     const rt_bvh_node& root = sd->nodes[0];
     s.d.root_ref = (root.num_primitives_axis >> 16) > 0 ? (RT_LEAF_BIT | root.offset) : 0u;
+    {
+        // super-root: child 0 = (root box, root ref), child 1 = empty.  Visiting it IS the
+        // reference's first loop iteration (box test of node 0, trace_bvh.cl:146-148).
+        s.d.entry_ref = n_interior;
+        float4* out = &nodes2[(size_t)n_interior * 4];
+        out[0] = make_float4(root.bounds_min.x, root.bounds_min.y, root.bounds_min.z, root.bounds_max.x);
+        out[1] = make_float4(root.bounds_max.y, root.bounds_max.z, 0.0f, 0.0f);
+        out[2] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        uint32_t r0 = s.d.root_ref, r1 = RT_EMPTY_REF, axis = 0;
+        float fr0, fr1, fax;
+        memcpy(&fr0, &r0, 4); memcpy(&fr1, &r1, 4); memcpy(&fax, &axis, 4);
+        out[3] = make_float4(fr0, fr1, fax, 0.0f);
+    }
     s.d.root_min[0] = root.bounds_min.x; s.d.root_min[1] = root.bounds_min.y; s.d.root_min[2] = root.bounds_min.z;
     s.d.root_max[0] = root.bounds_max.x; s.d.root_max[1] = root.bounds_max.y; s.d.root_max[2] = root.bounds_max.z;
 
@@ -359,11 +372,11 @@ namespace
 {
 void free_path_buffers(rt_frame* f)
 {
-    void* ptrs[] = {f->o4[0], f->o4[1], f->d4[0], f->d4[1], f->thr[0], f->thr[1], f->hits, f->sh_o4, f->sh_d4, f->rlog,
-        f->cnt};
+    void* ptrs[] = {f->o4[0], f->o4[1], f->d4[0], f->d4[1], f->iv4[0], f->iv4[1], f->thr[0], f->thr[1], f->hits,
+        f->sh_o4, f->sh_d4, f->sh_iv4, f->rlog, f->cnt};
     for (void* p : ptrs) if (p) (void)hipFree(p);
-    for (int i = 0; i < 2; ++i) { f->o4[i] = nullptr; f->d4[i] = nullptr; f->thr[i] = nullptr; }
-    f->hits = nullptr; f->sh_o4 = nullptr; f->sh_d4 = nullptr; f->rlog = nullptr; f->cnt = nullptr;
+    for (int i = 0; i < 2; ++i) { f->o4[i] = nullptr; f->d4[i] = nullptr; f->iv4[i] = nullptr; f->thr[i] = nullptr; }
+    f->hits = nullptr; f->sh_o4 = nullptr; f->sh_d4 = nullptr; f->sh_iv4 = nullptr; f->rlog = nullptr; f->cnt = nullptr;
 }
 
 // Per-path state: ray queues for `slots` samples in flight and the radiance log
@@ -386,8 +399,9 @@ int alloc_path_buffers(rt_frame* f)
     f->log_stride = (uint32_t)paths;
     f->log_entries = 2u * (f->max_bounces + 1u);
     size_t q = (size_t)(paths + 4) * sizeof(float4);   // +4: the unified 64-byte fetch of k_trace reads o4[i+2] / d4[i+2]
-    void** ptrs[] = {(void**)&f->o4[0], (void**)&f->o4[1], (void**)&f->d4[0], (void**)&f->d4[1], (void**)&f->thr[0],
-        (void**)&f->thr[1], (void**)&f->hits, (void**)&f->sh_o4, (void**)&f->sh_d4};
+    void** ptrs[] = {(void**)&f->o4[0], (void**)&f->o4[1], (void**)&f->d4[0], (void**)&f->d4[1], (void**)&f->iv4[0],
+        (void**)&f->iv4[1], (void**)&f->thr[0], (void**)&f->thr[1], (void**)&f->hits, (void**)&f->sh_o4,
+        (void**)&f->sh_d4, (void**)&f->sh_iv4};
     bool ok = true;
     for (void** p : ptrs) ok = ok && hipMalloc(p, q) == hipSuccess;
     ok = ok && hipMalloc((void**)&f->rlog, (size_t)f->log_entries * paths * sizeof(float4)) == hipSuccess;
@@ -453,8 +467,9 @@ int rt_frame_create(rt_ctx* ctx, const rt_frame_desc* fd, rt_frame** out)
     size_t n = f->n_local ? f->n_local : 1;
     f->trace_blocks = (uint32_t)ctx->prop.multiProcessorCount * 12u;
     f->trace_blocks = (f->trace_blocks + 7u) & ~7u;
-    for (int i = 0; i < 2; ++i) { f->o4[i] = nullptr; f->d4[i] = nullptr; f->thr[i] = nullptr; }
-    f->hits = nullptr; f->sh_o4 = nullptr; f->sh_d4 = nullptr; f->radiance = nullptr; f->resolved = nullptr;
+    for (int i = 0; i < 2; ++i) { f->o4[i] = nullptr; f->d4[i] = nullptr; f->iv4[i] = nullptr; f->thr[i] = nullptr; }
+    f->hits = nullptr; f->sh_o4 = nullptr; f->sh_d4 = nullptr; f->sh_iv4 = nullptr; f->radiance = nullptr;
+    f->resolved = nullptr;
     f->counters = nullptr; f->spill = nullptr;
     bool ok = true;
     ok = ok && hipMalloc((void**)&f->radiance, n * sizeof(float4)) == hipSuccess;
@@ -589,20 +604,20 @@ namespace
 // entry LDS stack (deeper entries spill to HBM).  One-wave blocks; the persistent
 // grid is sized to the LDS-limited residency: 160 KiB / (entries * 512 B) per CU.
 template <bool SHADOW, int STACK>
-void launch_trace_sm(rt_frame* f, const float4* o4, const float4* d4, const uint32_t* count)
+void launch_trace_sm(rt_frame* f, const float4* o4, const float4* d4, const float4* iv4, const uint32_t* count)
 {
     rt_ctx* ctx = f->ctx;
     uint32_t per_cu = (160u * 1024u) / (STACK * 512u);
     if (per_cu > 32u) per_cu = 32u;
     if (f->trace_waves_per_cu && f->trace_waves_per_cu < per_cu) per_cu = f->trace_waves_per_cu;
     uint32_t blocks = ((uint32_t)ctx->prop.multiProcessorCount * per_cu + 7u) & ~7u;
-    hipLaunchKernelGGL((k_trace<SHADOW, STACK>), dim3(blocks), dim3(64), 0, ctx->stream, ctx->scene.d, o4, d4, count,
+    hipLaunchKernelGGL((k_trace<SHADOW, STACK>), dim3(blocks), dim3(64), 0, ctx->stream, ctx->scene.d, o4, d4, iv4, count,
         &f->counters->head[SHADOW ? 1 : 0][0], SHADOW ? (float4*)nullptr : f->hits,
         SHADOW ? f->rlog : (float4*)nullptr, f->log_stride, f->spill);
 }
 
 template <bool SHADOW>
-void launch_trace(rt_frame* f, const float4* o4, const float4* d4, const uint32_t* count)
+void launch_trace(rt_frame* f, const float4* o4, const float4* d4, const float4* iv4, const uint32_t* count)
 {
     rt_ctx* ctx = f->ctx;
     switch (f->trace_variant)
@@ -612,10 +627,10 @@ void launch_trace(rt_frame* f, const float4* o4, const float4* d4, const uint32_
             (f->trace_waves_per_cu < 13u ? f->trace_waves_per_cu : 13u) + 7u) & ~7u) : f->trace_blocks), dim3(64), 0, ctx->stream, ctx->scene.d, o4, d4,
             count, SHADOW ? (float4*)nullptr : f->hits, SHADOW ? f->rlog : (float4*)nullptr, f->log_stride, f->spill);
         break;
-    case 1: launch_trace_sm<SHADOW, 16>(f, o4, d4, count); break;
-    case 2: launch_trace_sm<SHADOW, 24>(f, o4, d4, count); break;
-    case 4: launch_trace_sm<SHADOW, 8>(f, o4, d4, count); break;
-    default: launch_trace_sm<SHADOW, 12>(f, o4, d4, count); break;
+    case 1: launch_trace_sm<SHADOW, 16>(f, o4, d4, iv4, count); break;
+    case 2: launch_trace_sm<SHADOW, 24>(f, o4, d4, iv4, count); break;
+    case 4: launch_trace_sm<SHADOW, 8>(f, o4, d4, iv4, count); break;
+    default: launch_trace_sm<SHADOW, 12>(f, o4, d4, iv4, count); break;
     }
 }
 } // namespace
@@ -653,7 +668,7 @@ int generate_rays(rt_frame* f, uint32_t n_slots)
     if (blocks == 0) blocks = 1;
     KernelSpan span(f, 0);
     hipLaunchKernelGGL(k_raygen, dim3(blocks), dim3(256), 0, ctx->stream, f->tile, f->camera, f->sample_count, n_slots,
-        tan_half_fov, f->prev_bounces, f->o4[0], f->d4[0], f->thr[0], f->counters);
+        tan_half_fov, f->prev_bounces, f->o4[0], f->d4[0], f->iv4[0], f->thr[0], f->counters);
     f->prev_bounces = f->max_bounces;
     f->cur_slots = n_slots;
     HIPCHK(ctx, hipGetLastError());
@@ -675,7 +690,7 @@ int rt_intersect(rt_frame* f, uint32_t bounce)          // IntersectRays, :522-5
     if (bounce > RT_MAX_BOUNCES_LIMIT) return fail(ctx, "rt_intersect: bounce out of range");
     uint32_t in = bounce & 1u;
     KernelSpan span(f, 1);
-    launch_trace<false>(f, f->o4[in], f->d4[in], &f->counters->queue[bounce]);
+    launch_trace<false>(f, f->o4[in], f->d4[in], f->iv4[in], &f->counters->queue[bounce]);
     HIPCHK(ctx, hipGetLastError());
     return RT_OK;
 }
@@ -692,8 +707,8 @@ int rt_shade(rt_frame* f, uint32_t bounce)              // ShadeMissedRays + Sha
     uint32_t in = bounce & 1u, out = (bounce + 1u) & 1u;
     ShadeArgs a;
     a.in_o4 = f->o4[in]; a.in_d4 = f->d4[in]; a.in_thr = f->thr[in]; a.hits = f->hits;
-    a.out_o4 = f->o4[out]; a.out_d4 = f->d4[out]; a.out_thr = f->thr[out];
-    a.sh_o4 = f->sh_o4; a.sh_d4 = f->sh_d4;
+    a.out_o4 = f->o4[out]; a.out_d4 = f->d4[out]; a.out_iv4 = f->iv4[out]; a.out_thr = f->thr[out];
+    a.sh_o4 = f->sh_o4; a.sh_d4 = f->sh_d4; a.sh_iv4 = f->sh_iv4;
     a.rlog = f->rlog; a.cnt = f->cnt; a.counters = f->counters;
     a.bounce = bounce; a.sample_base = f->sample_count;
     a.emit_outgoing = (f->drop_last && bounce >= f->max_bounces) ? 0u : 1u;
@@ -716,7 +731,7 @@ int rt_intersect_shadow(rt_frame* f, uint32_t bounce)   // IntersectShadowRays +
     FRAME_PROLOGUE(f, "rt_intersect_shadow");
     if (bounce > RT_MAX_BOUNCES_LIMIT) return fail(ctx, "rt_intersect_shadow: bounce out of range");
     KernelSpan span(f, 3);
-    launch_trace<true>(f, f->sh_o4, f->sh_d4, &f->counters->shadow[bounce]);
+    launch_trace<true>(f, f->sh_o4, f->sh_d4, f->sh_iv4, &f->counters->shadow[bounce]);
     f->shadow_pending = false;
     HIPCHK(ctx, hipGetLastError());
     return RT_OK;

@@ -4,7 +4,7 @@
 OUT=$1; VAR=$2; shift 2
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-run() { name=$1; shift; rocprofv3 --pmc "$@" --output-format csv -d $R/gpurun_out/$OUT -o $name -- python $R/tools/trace_variants.py --variants $VAR --spp 2 $EXTRA > $R/gpurun_out/$OUT/$name.log 2>&1; }
+run() { name=$1; shift; rocprofv3 --pmc "$@" --output-format csv -d $R/gpurun_out/$OUT -o $name -- python $R/tools/trace_variants.py --variants $VAR $EXTRA > $R/gpurun_out/$OUT/$name.log 2>&1; }
 mkdir -p $R/gpurun_out/$OUT
 EXTRA="$*"
 run fetch FETCH_SIZE TCC_HIT_sum
