@@ -76,14 +76,20 @@ struct RefIntegrator
     std::vector<rt_float4> radiance;
     std::vector<rt_ray> rays[2];
     std::vector<uint> pixel_indices[2];
-    uint ray_counter[2] = {0, 0};
+    // every counter is its own cl::Buffer in the reference (cl_pt_integrator.cpp:206-219):
+    // keep them on separate cache lines so that the atomic appends of HitSurface do not
+    // false-share with the read-only counters
+    alignas(64) uint ray_counter_a = 0;
+    alignas(64) uint ray_counter_b = 0;
+    uint& rc(uint i) { return i ? ray_counter_b : ray_counter_a; }
     std::vector<rt_ray> shadow_rays;
     std::vector<uint> shadow_pixel_indices;
-    uint shadow_ray_counter = 0;
+    alignas(64) uint shadow_ray_counter = 0;
     std::vector<rt_hit> hits;
     std::vector<uint> shadow_hits;
     std::vector<rt_float3> throughputs;
-    uint sample_counter = 0;
+    alignas(64) uint sample_counter = 0;
+    alignas(64) char pad_after_counters[64] = {0};
     std::vector<rt_float4> direct_light_samples;
     std::vector<rt_float3> diffuse_albedo, normal;
     std::vector<float> depth;
@@ -210,7 +216,7 @@ void GenerateRays(RefIntegrator& r)                // :516-520
 {
     NDRange(r, r.width * r.height, [&]()
     {
-        RayGeneration(r.width, r.height, r.camera, &r.sample_counter, r.rays[0].data(), &r.ray_counter[0],
+        RayGeneration(r.width, r.height, r.camera, &r.sample_counter, r.rays[0].data(), &r.rc(0),
             r.pixel_indices[0].data(), (float3*)r.throughputs.data(), (float3*)r.diffuse_albedo.data(),
             r.depth.data(), (float3*)r.normal.data(), (float2*)r.velocity.data());
     });
@@ -221,7 +227,7 @@ void IntersectRays(RefIntegrator& r, uint bounce)  // :522-539
     uint in = bounce & 1;
     NDRange(r, r.width * r.height, [&]()
     {
-        TraceBvh(r.rays[in].data(), &r.ray_counter[in], r.rt_triangles.data(), r.nodes.data(), r.hits.data());
+        TraceBvh(r.rays[in].data(), &r.rc(in), r.rt_triangles.data(), r.nodes.data(), r.hits.data());
     });
 }
 
@@ -231,10 +237,10 @@ void ShadeMissedRays(RefIntegrator& r, uint bounce) // :582-592
     NDRange(r, r.width * r.height, [&]()
     {
         if (r.furnace)
-            MissFurnace(r.rays[in].data(), &r.ray_counter[in], r.hits.data(), r.pixel_indices[in].data(),
+            MissFurnace(r.rays[in].data(), &r.rc(in), r.hits.data(), r.pixel_indices[in].data(),
                 (float3*)r.throughputs.data(), &r.env_image, (float3*)r.radiance.data());
         else
-            Miss(r.rays[in].data(), &r.ray_counter[in], r.hits.data(), r.pixel_indices[in].data(),
+            Miss(r.rays[in].data(), &r.rc(in), r.hits.data(), r.pixel_indices[in].data(),
                 (float3*)r.throughputs.data(), &r.env_image, (float3*)r.radiance.data());
     });
 }
@@ -245,11 +251,11 @@ void ShadeSurfaceHits(RefIntegrator& r, uint bounce) // :594-643
     auto fn = r.furnace ? HitSurfaceFurnace : HitSurface;
     NDRange(r, r.width * r.height, [&]()
     {
-        fn(r.rays[in].data(), &r.ray_counter[in], r.pixel_indices[in].data(), r.hits.data(),
+        fn(r.rays[in].data(), &r.rc(in), r.pixel_indices[in].data(), r.hits.data(),
             r.triangles.data(), r.lights.data(), r.emissive.data(), r.materials.data(),
             r.textures.data(), r.texture_data.data(), bounce, r.width, r.height, &r.sample_counter,
             r.scene_info, nullptr, nullptr, nullptr, (float3*)r.throughputs.data(),
-            r.rays[out].data(), &r.ray_counter[out], r.pixel_indices[out].data(),
+            r.rays[out].data(), &r.rc(out), r.pixel_indices[out].data(),
             r.shadow_rays.data(), &r.shadow_ray_counter, r.shadow_pixel_indices.data(),
             (float3*)r.direct_light_samples.data(), (float4*)r.radiance.data());
     });
@@ -341,7 +347,7 @@ void ref_stage_shade_miss(void* h, uint32_t b) { ShadeMissedRays(*(RefIntegrator
 void ref_stage_clear_counters(void* h, uint32_t b)
 {
     auto& r = *(RefIntegrator*)h;
-    Clear(&r.ray_counter[(b + 1) & 1]);     // :651-657
+    Clear(&r.rc((b + 1) & 1));     // :651-657
     Clear(&r.shadow_ray_counter);           // :659-663
 }
 void ref_stage_shade_hits(void* h, uint32_t b) { ShadeSurfaceHits(*(RefIntegrator*)h, b); }
@@ -359,12 +365,12 @@ void ref_integrate(void* h)
     {
         IntersectRays(r, bounce);
         ShadeMissedRays(r, bounce);
-        Clear(&r.ray_counter[(bounce + 1) & 1]);
+        Clear(&r.rc((bounce + 1) & 1));
         Clear(&r.shadow_ray_counter);
         ShadeSurfaceHits(r, bounce);
         IntersectShadowRays(r);
         AccumulateDirect(r);
-        uint active = r.ray_counter[bounce & 1];
+        uint active = r.rc(bounce & 1);
         r.total_closest += active;
         r.total_shadow += r.shadow_ray_counter;
         if (bounce < 64) { r.last_active[bounce] = active; r.last_shadow[bounce] = r.shadow_ray_counter; }
@@ -405,8 +411,8 @@ void* ref_buffer(void* h, const char* name)
     if (!strcmp(name, "rays1")) return r.rays[1].data();
     if (!strcmp(name, "pixel_indices0")) return r.pixel_indices[0].data();
     if (!strcmp(name, "pixel_indices1")) return r.pixel_indices[1].data();
-    if (!strcmp(name, "ray_counter0")) return &r.ray_counter[0];
-    if (!strcmp(name, "ray_counter1")) return &r.ray_counter[1];
+    if (!strcmp(name, "ray_counter0")) return &r.rc(0);
+    if (!strcmp(name, "ray_counter1")) return &r.rc(1);
     if (!strcmp(name, "shadow_rays")) return r.shadow_rays.data();
     if (!strcmp(name, "shadow_pixel_indices")) return r.shadow_pixel_indices.data();
     if (!strcmp(name, "shadow_ray_counter")) return &r.shadow_ray_counter;

@@ -296,3 +296,45 @@ def test_samples_in_flight_and_kernel_variants_are_bit_invariant(ctx, golden_sce
     fr.integrate(2)
     orc.set_max_bounces(b + 3); orc.integrate(2)
     assert np.array_equal(fr.radiance()[..., :3], orc.radiance()[..., :3])
+
+
+def test_generic_buffers_mirror_clcontext_semantics(ctx):
+    """rt_buffer_* = cl::Buffer + CLContext::WriteBuffer/ReadBuffer/CopyBuffer (cl_context.cpp:96-113)."""
+    import ctypes as C
+    lib = ctx.lib
+    data = np.arange(1024, dtype=np.uint32)
+    a, b = C.c_void_p(), C.c_void_p()
+    assert lib.rt_buffer_create(ctx.handle, data.nbytes, data.ctypes.data, C.byref(a)) == 0     # CL_MEM_COPY_HOST_PTR
+    assert lib.rt_buffer_create(ctx.handle, data.nbytes, None, C.byref(b)) == 0
+    assert lib.rt_buffer_size(a) == data.nbytes and lib.rt_buffer_device_ptr(a)
+    assert lib.rt_buffer_copy(a, b, 256 * 4, 0, 512 * 4) == 0
+    out = np.zeros(512, np.uint32)
+    assert lib.rt_buffer_read(b, 0, out.ctypes.data, out.nbytes) == 0                             # blocking read
+    assert np.array_equal(out, data[256:768])
+    patch = np.full(16, 7, np.uint32)
+    assert lib.rt_buffer_write(b, 64, patch.ctypes.data, patch.nbytes) == 0
+    assert lib.rt_buffer_read(b, 0, out.ctypes.data, out.nbytes) == 0
+    assert (out[16:32] == 7).all() and out[15] == data[256 + 15] and out[32] == data[256 + 32]
+    assert lib.rt_buffer_read(b, data.nbytes, out.ctypes.data, 4) != 0                            # out of range -> error
+    assert b"out of range" in lib.rt_last_error(ctx.handle)
+    assert lib.rt_buffer_destroy(a) == 0 and lib.rt_buffer_destroy(b) == 0
+    assert lib.rt_finish(ctx.handle) == 0
+
+
+def test_kernel_profile_and_stats_accounting(ctx, golden_scenes):
+    """RT_OPT_PROFILE_KERNELS brackets every launch with HIP events; counts add up."""
+    sc = golden_scenes["coverage"]
+    ctx.upload_scene(sc)
+    fr = capi.Frame(ctx, 64, 64)
+    fr.set_camera(T.default_camera(64, 64)); fr.set_max_bounces(5)
+    fr.set_option(capi.OPT_SAMPLES_IN_FLIGHT, 4)
+    fr.set_option(capi.OPT_PROFILE, 1)
+    fr.integrate(8)                       # two batches of 4
+    p = fr.profile()
+    assert p.n_raygen == 2 and p.n_trace_closest == 12 and p.n_shade == 12 and p.n_trace_shadow == 12
+    assert p.ms_trace_closest > 0 and p.ms_shade > 0
+    st = fr.stats()
+    assert st.samples == 8 and st.last_active[0] == 4 * 64 * 64
+    orc = _oracle.Oracle(64, 64, sc)
+    orc.set_camera(T.default_camera(64, 64)); orc.set_max_bounces(5); orc.integrate(8)
+    assert (st.closest_rays, st.shadow_rays) == orc.ray_totals()
