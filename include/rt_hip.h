@@ -101,8 +101,9 @@ enum rt_option
     RT_OPT_MAX_BOUNCES = 0,    /* Integrator::SetMaxBounces, default 3 (integrator.hpp:91) */
     RT_OPT_WHITE_FURNACE = 1,  /* Integrator::EnableWhiteFurnace (-D ENABLE_WHITE_FURNACE) */
     RT_OPT_SAMPLER = 2,        /* Integrator::SetSamplerType: 0 = kRandom (only one implemented) */
-    RT_OPT_AOV = 3,            /* Integrator::SetAOV: 0 = kShadedColor (only one implemented) */
-    RT_OPT_DENOISER = 4,       /* Integrator::EnableDenoiser: 0 (only value implemented) */
+    RT_OPT_AOV = 3,            /* Integrator::SetAOV: 0 shaded colour, 1 diffuse albedo, 2 depth, 3 normal, 4 motion vectors
+                                  (resolve_radiance.cl:25-29); non-zero needs tile_count == 1 */
+    RT_OPT_DENOISER = 4,       /* Integrator::EnableDenoiser: temporal reprojection (denoiser.cl); needs tile_count == 1 */
     RT_OPT_TRACE_DROP_LAST_BOUNCE_RAYS = 5, /* 1 (default): do not emit the never-traced rays of the last bounce */
     RT_OPT_PROFILE_KERNELS = 6, /* 1: bracket every kernel launch with HIP events on the context stream */
     RT_OPT_TRACE_VARIANT = 7    /* traversal kernel: 0 = v1 per-ray loop; 1 .. 4 = one-fetch-per-iteration state
@@ -131,7 +132,10 @@ int rt_clear_shadow_counter(rt_frame* frame);           /* ClearShadowRayCounter
 int rt_shade(rt_frame* frame, uint32_t bounce);         /* ShadeSurfaceHits (+ miss) */
 int rt_intersect_shadow(rt_frame* frame, uint32_t bounce);  /* IntersectShadowRays (+ accumulate) */
 int rt_accumulate_direct(rt_frame* frame);              /* AccumulateDirectSamples (fused, no-op) */
+int rt_compute_aovs(rt_frame* frame);                   /* ComputeAOVs (after rt_intersect(frame, 0)); no-op unless an AOV or the denoiser is on */
 int rt_advance_sample(rt_frame* frame);                 /* AdvanceSampleCount */
+int rt_denoise(rt_frame* frame);                        /* Denoise (TemporalAccumulation); no-op unless RT_OPT_DENOISER */
+int rt_copy_history(rt_frame* frame);                   /* CopyHistoryBuffers */
 /* fast path: n_samples x Integrate() enqueued without returning to the caller */
 int rt_integrate(rt_frame* frame, uint32_t n_samples);
 

@@ -67,7 +67,13 @@ typedef struct orc
     uint32_t max_bounces;
     int request_reset;
     rt_camera camera;
+    rt_camera prev_camera;       /* Integrator::prev_camera_ */
+    rt_camera aov_prev_camera;   /* kPrevCamera bound by the last SetCameraData (cl_pt_integrator.cpp:365-371) */
+    int denoiser;
+    uint32_t aov;
     rt_scene_info scene_info;
+    rt_float3* diffuse_albedo; float* depth; rt_float3* normal; rt_float2* velocity;
+    rt_float4* prev_radiance; float* prev_depth;
 
     rt_float4* radiance;
     rt_ray* rays[2];
@@ -187,6 +193,10 @@ static void RayGeneration(orc* o, uint32_t ray_idx)
     o->throughputs[pixel_idx].x = 1.0f;
     o->throughputs[pixel_idx].y = 1.0f;
     o->throughputs[pixel_idx].z = 1.0f;
+    o->diffuse_albedo[pixel_idx].x = 0.0f; o->diffuse_albedo[pixel_idx].y = 0.0f; o->diffuse_albedo[pixel_idx].z = 0.0f;
+    o->depth[pixel_idx] = RT_MAX_RENDER_DIST;                             /* :129-132 */
+    o->normal[pixel_idx].x = 0.0f; o->normal[pixel_idx].y = 0.0f; o->normal[pixel_idx].z = 0.0f;
+    o->velocity[pixel_idx].x = 0.0f; o->velocity[pixel_idx].y = 0.0f;
     if (ray_idx == 0) o->ray_counter[0] = width * height;
 }
 
@@ -716,6 +726,76 @@ static void HitSurface(orc* o, uint32_t bounce, uint32_t ray_idx)
     }
 }
 
+/* ---- GenerateAOV, aov.cl:30-110 ----------------------------------------- */
+static v2 ProjectScreen(v3 position, const rt_camera* cam)              /* aov.cl:30-42 */
+{
+    v3 d = v_normalize(v_sub(position, f3(cam->position)));
+    v3 ipd = v_divs(d, v_dot(f3(cam->front), d));
+    float angle = rt_tanf(0.5f * cam->fov);
+    v3 right = v_cross(f3(cam->front), f3(cam->up));
+    float u = v_dot(right, ipd) / (angle * cam->aspect_ratio);
+    float v = v_dot(f3(cam->up), ipd) / (angle);
+    v2 r;
+    r.x = u * 0.5f + 0.5f;
+    r.y = v * 0.5f + 0.5f;
+    return r;
+}
+
+static void GenerateAOV(orc* o, uint32_t ray_idx)
+{
+    if (ray_idx >= o->ray_counter[0]) return;
+    rt_hit hit = o->hits[ray_idx];
+    if (hit.primitive_id == RT_INVALID_ID) return;
+    rt_ray ray = o->rays[0][ray_idx];
+    uint32_t pixel_idx = o->pixel_indices[0][ray_idx];
+    const rt_triangle* tri = &o->triangles[hit.primitive_id];
+    float bu = hit.bc.x, bv = hit.bc.y;
+    float w0 = 1.0f - bu - bv;
+    v3 p1 = f3(tri->v1.position), p2 = f3(tri->v2.position), p3 = f3(tri->v3.position);
+    v3 position = v_add(v_add(v_scale(p1, w0), v_scale(p2, bu)), v_scale(p3, bv));
+    v2 texcoord;
+    texcoord.x = tri->v1.texcoord.x * w0 + tri->v2.texcoord.x * bu + tri->v3.texcoord.x * bv;
+    texcoord.y = tri->v1.texcoord.y * w0 + tri->v2.texcoord.y * bu + tri->v3.texcoord.y * bv;
+    v3 normal = v_normalize(v_add(v_add(v_scale(f3(tri->v1.normal), w0), v_scale(f3(tri->v2.normal), bu)),
+        v_scale(f3(tri->v3.normal), bv)));
+    Material material;
+    ApplyTextures(o, o->materials[tri->mtl_index], &material, texcoord);
+    o->diffuse_albedo[pixel_idx].x = material.diffuse_albedo.x;
+    o->diffuse_albedo[pixel_idx].y = material.diffuse_albedo.y;
+    o->diffuse_albedo[pixel_idx].z = material.diffuse_albedo.z;
+    o->depth[pixel_idx] = v_length(v_sub(V3(ray.origin.x, ray.origin.y, ray.origin.z), position));
+    o->normal[pixel_idx].x = normal.x; o->normal[pixel_idx].y = normal.y; o->normal[pixel_idx].z = normal.z;
+    v2 a = ProjectScreen(position, &o->camera), b = ProjectScreen(position, &o->aov_prev_camera);
+    o->velocity[pixel_idx].x = a.x - b.x;
+    o->velocity[pixel_idx].y = a.y - b.y;
+}
+
+/* ---- TemporalAccumulation, denoiser.cl:27-79 ---------------------------- */
+static void TemporalAccumulation(orc* o, uint32_t pixel_idx)
+{
+    uint32_t width = o->width, height = o->height;
+    int x = (int)(pixel_idx % width);
+    int y = (int)(pixel_idx / width);
+    if ((uint32_t)x >= width || (uint32_t)y >= height) return;
+    float depth_value = o->depth[pixel_idx];
+    if (depth_value == RT_MAX_RENDER_DIST) return;
+    float mx = o->velocity[pixel_idx].x, my = o->velocity[pixel_idx].y;
+    float prev_u = ((float)x + 0.5f) / (float)width - mx;
+    float prev_v = ((float)y + 0.5f) / (float)height - my;
+    int prev_x = (int)(prev_u * (float)width);
+    int prev_y = (int)(prev_v * (float)height);
+    /* the comparisons against the unsigned width/height promote prev_x to unsigned (C rules), so a
+       negative prev_x fails the `>= width` test as well -- same outcome as written */
+    if (prev_x < 0 || (uint32_t)prev_x >= width || prev_y < 0 || (uint32_t)prev_y >= height) return;
+    int prev_idx = prev_y * (int)width + prev_x;
+    float prev_depth_value = o->prev_depth[prev_idx];
+    if (__builtin_fabsf(depth_value - prev_depth_value) / depth_value > 0.1f) return;
+    v3 cur = V3(o->radiance[pixel_idx].x, o->radiance[pixel_idx].y, o->radiance[pixel_idx].z);
+    v3 prev = V3(o->prev_radiance[prev_idx].x, o->prev_radiance[prev_idx].y, o->prev_radiance[prev_idx].z);
+    v3 m = v_mix(cur, prev, 0.9f);
+    o->radiance[pixel_idx].x = m.x; o->radiance[pixel_idx].y = m.y; o->radiance[pixel_idx].z = m.z;
+}
+
 /* ---- AccumulateDirectSamples, accumulate_direct_samples.cl:27-53 -------- */
 static void AccumulateDirectSamples(orc* o, uint32_t ray_idx)
 {
@@ -752,6 +832,12 @@ ORC_EXPORT void* orc_create(uint32_t width, uint32_t height, int white_furnace)
     o->throughputs = (rt_float3*)calloc(n, sizeof(rt_float3));
     o->direct_light_samples = (rt_float4*)calloc(n, sizeof(rt_float4));
     o->resolved = (rt_float4*)calloc(n, sizeof(rt_float4));
+    o->diffuse_albedo = (rt_float3*)calloc(n, sizeof(rt_float3));
+    o->depth = (float*)calloc(n, sizeof(float));
+    o->normal = (rt_float3*)calloc(n, sizeof(rt_float3));
+    o->velocity = (rt_float2*)calloc(n, sizeof(rt_float2));
+    o->prev_radiance = (rt_float4*)calloc(n, sizeof(rt_float4));
+    o->prev_depth = (float*)calloc(n, sizeof(float));
     return o;
 }
 
@@ -762,6 +848,7 @@ ORC_EXPORT void orc_destroy(void* h)
     for (int i = 0; i < 2; ++i) { free(o->rays[i]); free(o->pixel_indices[i]); }
     free(o->shadow_rays); free(o->shadow_pixel_indices); free(o->hits); free(o->shadow_hits);
     free(o->throughputs); free(o->direct_light_samples); free(o->resolved);
+    free(o->diffuse_albedo); free(o->depth); free(o->normal); free(o->velocity); free(o->prev_radiance); free(o->prev_depth);
     free(o->triangles); free(o->nodes); free(o->materials); free(o->textures); free(o->texture_data);
     free(o->lights); free(o->env);
     free(o);
@@ -793,7 +880,27 @@ ORC_EXPORT void orc_upload(void* h, const rt_triangle* tris, uint32_t ntris, con
     o->scene_info.emissive_count = nemissive;
 }
 
-ORC_EXPORT void orc_set_camera(void* h, const rt_camera* cam) { ((orc*)h)->camera = *cam; }
+ORC_EXPORT void orc_set_camera(void* h, const rt_camera* cam)           /* cl_pt_integrator.cpp:365-371 */
+{
+    orc* o = (orc*)h;
+    o->camera = *cam;
+    o->aov_prev_camera = o->prev_camera;
+    o->prev_camera = *cam;
+}
+ORC_EXPORT void orc_enable_denoiser(void* h, int enable)                /* :485-495 */
+{
+    orc* o = (orc*)h;
+    if ((enable != 0) == (o->denoiser != 0)) return;
+    o->denoiser = enable != 0;
+    o->request_reset = 1;
+}
+ORC_EXPORT void orc_set_aov(void* h, uint32_t aov)                      /* :470-483 */
+{
+    orc* o = (orc*)h;
+    if (aov == o->aov) return;
+    o->aov = aov;
+    o->request_reset = 1;
+}
 ORC_EXPORT void orc_set_max_bounces(void* h, uint32_t b) { ((orc*)h)->max_bounces = b; ((orc*)h)->request_reset = 1; }
 ORC_EXPORT void orc_request_reset(void* h) { ((orc*)h)->request_reset = 1; }
 
@@ -801,7 +908,7 @@ ORC_EXPORT void orc_request_reset(void* h) { ((orc*)h)->request_reset = 1; }
 ORC_EXPORT void orc_stage_reset(void* h)                                  /* cl_pt_integrator.cpp:497-508 */
 {
     orc* o = (orc*)h;
-    o->sample_counter = 0;
+    if (!o->denoiser) o->sample_counter = 0;
     memset(o->radiance, 0, (size_t)o->width * o->height * sizeof(rt_float4));
 }
 ORC_EXPORT void orc_stage_generate_rays(void* h)
@@ -847,16 +954,36 @@ ORC_EXPORT void orc_stage_accumulate(void* h)
     for (uint32_t i = 0; i < n; ++i) AccumulateDirectSamples(o, i);
 }
 ORC_EXPORT void orc_stage_advance(void* h) { ((orc*)h)->sample_counter++; }
+ORC_EXPORT void orc_stage_compute_aovs(void* h)
+{
+    orc* o = (orc*)h;
+    uint32_t n = o->width * o->height;
+    for (uint32_t i = 0; i < n; ++i) GenerateAOV(o, i);
+}
+ORC_EXPORT void orc_stage_denoise(void* h)
+{
+    orc* o = (orc*)h;
+    uint32_t n = o->width * o->height;
+    for (uint32_t i = 0; i < n; ++i) TemporalAccumulation(o, i);
+}
+ORC_EXPORT void orc_stage_copy_history(void* h)                         /* cl_pt_integrator.cpp:670-675 */
+{
+    orc* o = (orc*)h;
+    size_t n = (size_t)o->width * o->height;
+    memcpy(o->prev_radiance, o->radiance, n * sizeof(rt_float4));
+    memcpy(o->prev_depth, o->depth, n * sizeof(float));
+}
 
 /* Integrator::Integrate(), integrator.cpp:27-59 */
 ORC_EXPORT void orc_integrate(void* h)
 {
     orc* o = (orc*)h;
-    if (o->request_reset) { orc_stage_reset(h); o->request_reset = 0; }
+    if (o->request_reset || o->denoiser) { orc_stage_reset(h); o->request_reset = 0; }
     orc_stage_generate_rays(h);
     for (uint32_t bounce = 0; bounce <= o->max_bounces; ++bounce)
     {
         orc_stage_intersect(h, bounce);
+        if (bounce == 0) orc_stage_compute_aovs(h);
         orc_stage_shade_miss(h, bounce);
         orc_stage_clear_counters(h, bounce);
         orc_stage_shade_hits(h, bounce);
@@ -868,9 +995,14 @@ ORC_EXPORT void orc_integrate(void* h)
         if (bounce < 64) { o->last_active[bounce] = active; o->last_shadow[bounce] = o->shadow_ray_counter; }
     }
     orc_stage_advance(h);
+    if (o->denoiser)
+    {
+        orc_stage_denoise(h);
+        orc_stage_copy_history(h);
+    }
 }
 
-/* ResolveRadiance, resolve_radiance.cl:76-85 (shaded colour, no denoiser) */
+/* ResolveRadiance, resolve_radiance.cl:31-86 */
 ORC_EXPORT const float* orc_resolve(void* h)
 {
     orc* o = (orc*)h;
@@ -878,11 +1010,31 @@ ORC_EXPORT const float* orc_resolve(void* h)
     float spp = (float)o->sample_counter;
     for (size_t i = 0; i < n; ++i)
     {
-        float hx = o->radiance[i].x / spp, hy = o->radiance[i].y / spp, hz = o->radiance[i].z / spp;
-        o->resolved[i].x = hx / (hx + 1.0f);
-        o->resolved[i].y = hy / (hy + 1.0f);
-        o->resolved[i].z = hz / (hz + 1.0f);
-        o->resolved[i].w = 1.0f;
+        rt_float4* out = &o->resolved[i];
+        out->w = 1.0f;
+        if (o->aov == 1)        /* DIFFUSE_INDEX :52-56 */
+        {
+            out->x = o->diffuse_albedo[i].x; out->y = o->diffuse_albedo[i].y; out->z = o->diffuse_albedo[i].z;
+        }
+        else if (o->aov == 2)   /* DEPTH_INDEX :57-62 */
+        {
+            float d = o->depth[i] * 0.1f;
+            out->x = d; out->y = d; out->z = d;
+        }
+        else if (o->aov == 3)   /* NORMAL_INDEX :63-68 */
+        {
+            out->x = o->normal[i].x * 0.5f + 0.5f; out->y = o->normal[i].y * 0.5f + 0.5f; out->z = o->normal[i].z * 0.5f + 0.5f;
+        }
+        else if (o->aov == 4)   /* MOTION_VECTORS_INDEX :69-73 */
+        {
+            out->x = o->velocity[i].x; out->y = o->velocity[i].y; out->z = 0.0f;
+        }
+        else                    /* shaded colour :76-85 */
+        {
+            float hx = o->radiance[i].x, hy = o->radiance[i].y, hz = o->radiance[i].z;
+            if (!o->denoiser) { hx = hx / spp; hy = hy / spp; hz = hz / spp; }
+            out->x = hx / (hx + 1.0f); out->y = hy / (hy + 1.0f); out->z = hz / (hz + 1.0f);
+        }
     }
     return (const float*)o->resolved;
 }

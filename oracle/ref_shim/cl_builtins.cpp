@@ -151,6 +151,16 @@ float3 shim_mix(float3 x, float3 y, float3 a)
     return r;
 }
 
+float3 shim_mix_s(float3 x, float3 y, float a) __asm__("_Z3mixDv3_fS_f");
+float3 shim_mix_s(float3 x, float3 y, float a)
+{
+    float3 r;
+    r.x = x.x + (y.x - x.x) * a;
+    r.y = x.y + (y.y - x.y) * a;
+    r.z = x.z + (y.z - x.z) * a;
+    return r;
+}
+
 float3 shim_pow3(float3 x, float3 y) __asm__("_Z3powDv3_fS_");
 float3 shim_pow3(float3 x, float3 y)
 {

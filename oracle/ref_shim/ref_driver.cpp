@@ -55,6 +55,10 @@ void HitSurface(HIT_SURFACE_ARGS);
 void HitSurfaceFurnace(HIT_SURFACE_ARGS);
 void AccumulateDirectSamples(uint*, uint*, uint*, float3*, float4*);
 void ResolveRadiance(uint, uint, uint, float4*, float3*, float*, float3*, float2*, uint*, ShimImage*);
+void ResolveRadianceDenoiser(uint, uint, uint, float4*, float3*, float*, float3*, float2*, uint*, ShimImage*);
+void GenerateAOV(rt_ray*, uint*, uint*, rt_hit*, rt_triangle*, rt_packed_material*, rt_texture*, uint*, uint, uint, CamCL, CamCL,
+    float3*, float*, float3*, float2*);
+void TemporalAccumulation(uint, uint, float4*, float4*, float*, float*, float2*);
 }
 
 namespace
@@ -70,7 +74,13 @@ struct RefIntegrator
     uint max_bounces = 3;       // integrator.hpp:91
     bool request_reset = false;
     CamCL camera = {};
+    CamCL prev_camera = {};        // Integrator::prev_camera_ (integrator.hpp:89)
+    CamCL aov_prev_camera = {};    // the kPrevCamera argument bound by the last SetCameraData
+    int denoiser = 0;
+    uint aov = 0;
     SceneInfoCL scene_info = {};
+    std::vector<rt_float4> prev_radiance;
+    std::vector<float> prev_depth;
 
     // per-pixel buffers (cl_pt_integrator.cpp:199-249)
     std::vector<rt_float4> radiance;
@@ -208,7 +218,7 @@ void NDRange(RefIntegrator& r, size_t work_size, F&& body)
 
 void Reset(RefIntegrator& r)                       // cl_pt_integrator.cpp:497-508
 {
-    Clear(&r.sample_counter);
+    if (!r.denoiser) Clear(&r.sample_counter);
     NDRange(r, r.width * r.height, [&]() { ResetRadiance(r.width, r.height, (float4*)r.radiance.data()); });
 }
 
@@ -270,6 +280,31 @@ void IntersectShadowRays(RefIntegrator& r)         // :564-580
     });
 }
 
+void ComputeAOVs(RefIntegrator& r)                 // :541-562
+{
+    NDRange(r, r.width * r.height, [&]()
+    {
+        GenerateAOV(r.rays[0].data(), &r.rc(0), r.pixel_indices[0].data(), r.hits.data(), r.triangles.data(),
+            r.materials.data(), r.textures.data(), r.texture_data.data(), r.width, r.height, r.camera, r.aov_prev_camera,
+            (float3*)r.diffuse_albedo.data(), r.depth.data(), (float3*)r.normal.data(), (float2*)r.velocity.data());
+    });
+}
+
+void Denoise(RefIntegrator& r)                     // :665-668
+{
+    NDRange(r, r.width * r.height, [&]()
+    {
+        TemporalAccumulation(r.width, r.height, (float4*)r.radiance.data(), (float4*)r.prev_radiance.data(),
+            r.depth.data(), r.prev_depth.data(), (float2*)r.velocity.data());
+    });
+}
+
+void CopyHistory(RefIntegrator& r)                 // :670-675
+{
+    r.prev_radiance = r.radiance;
+    r.prev_depth = r.depth;
+}
+
 void AccumulateDirect(RefIntegrator& r)            // :645-649
 {
     NDRange(r, r.width * r.height, [&]()
@@ -295,6 +330,7 @@ void* ref_create(uint32_t width, uint32_t height, int white_furnace, int threads
     r->direct_light_samples.resize(n);
     r->diffuse_albedo.resize(n); r->normal.resize(n); r->depth.resize(n); r->velocity.resize(n);
     r->resolved.resize(n);
+    r->prev_radiance.resize(n); r->prev_depth.resize(n);
     Reset(*r);                                     // ctor ends with Reset(), :258
     return r;
 }
@@ -328,8 +364,27 @@ void ref_upload(void* h, const rt_triangle* tris, uint32_t ntris, const rt_bvh_n
 
 void ref_set_camera(void* h, const rt_camera* cam)
 {
+    // CLPathTraceIntegrator::SetCameraData, cl_pt_integrator.cpp:365-371
     auto& r = *(RefIntegrator*)h;
     memcpy(&r.camera, cam, sizeof(CamCL));
+    r.aov_prev_camera = r.prev_camera;
+    r.prev_camera = r.camera;
+}
+
+void ref_enable_denoiser(void* h, int enable)      // :485-495
+{
+    auto& r = *(RefIntegrator*)h;
+    if ((enable != 0) == (r.denoiser != 0)) return;
+    r.denoiser = enable != 0;
+    r.request_reset = true;
+}
+
+void ref_set_aov(void* h, uint32_t aov)            // :470-483
+{
+    auto& r = *(RefIntegrator*)h;
+    if (aov == r.aov) return;
+    r.aov = aov;
+    r.request_reset = true;
 }
 
 void ref_set_max_bounces(void* h, uint32_t b)      // integrator.cpp:61-65
@@ -359,11 +414,12 @@ void ref_stage_advance(void* h) { Increment(&((RefIntegrator*)h)->sample_counter
 void ref_integrate(void* h)
 {
     auto& r = *(RefIntegrator*)h;
-    if (r.request_reset) { Reset(r); r.request_reset = false; }
+    if (r.request_reset || r.denoiser) { Reset(r); r.request_reset = false; }
     GenerateRays(r);
     for (uint bounce = 0; bounce <= r.max_bounces; ++bounce)
     {
         IntersectRays(r, bounce);
+        if (bounce == 0) ComputeAOVs(r);
         ShadeMissedRays(r, bounce);
         Clear(&r.rc((bounce + 1) & 1));
         Clear(&r.shadow_ray_counter);
@@ -376,17 +432,23 @@ void ref_integrate(void* h)
         if (bounce < 64) { r.last_active[bounce] = active; r.last_shadow[bounce] = r.shadow_ray_counter; }
     }
     Increment(&r.sample_counter);
+    if (r.denoiser)
+    {
+        Denoise(r);
+        CopyHistory(r);
+    }
 }
 
-// ResolveRadiance (resolve_radiance.cl:31-86), aov 0, headless image
+// ResolveRadiance (resolve_radiance.cl:31-86), headless image
 const float* ref_resolve(void* h)
 {
     auto& r = *(RefIntegrator*)h;
     ShimImage out{(int)r.width, (int)r.height, (float*)r.resolved.data()};
     NDRange(r, r.width * r.height, [&]()
     {
-        ResolveRadiance(r.width, r.height, 0, (float4*)r.radiance.data(), (float3*)r.diffuse_albedo.data(),
-            r.depth.data(), (float3*)r.normal.data(), (float2*)r.velocity.data(), &r.sample_counter, &out);
+        (r.denoiser ? ResolveRadianceDenoiser : ResolveRadiance)(r.width, r.height, r.aov, (float4*)r.radiance.data(),
+            (float3*)r.diffuse_albedo.data(), r.depth.data(), (float3*)r.normal.data(), (float2*)r.velocity.data(),
+            &r.sample_counter, &out);
     });
     return (const float*)r.resolved.data();
 }

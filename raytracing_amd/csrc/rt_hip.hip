@@ -64,6 +64,12 @@ struct rt_frame
     uint32_t trace_waves_per_cu = 0;   // RT_OPT_TRACE_WAVES_PER_CU (0 = LDS-limited residency)
     // integrator state
     rt_camera camera;
+    rt_camera camera_last;        // Integrator::prev_camera_ (integrator.hpp:89)
+    rt_camera prev_camera;        // the kPrevCamera argument bound by the last rt_set_camera
+    uint32_t aov = 0;             // RT_OPT_AOV
+    uint32_t denoiser = 0;        // RT_OPT_DENOISER
+    DAov aov_buf = {nullptr, nullptr, nullptr, nullptr};
+    float4* prev_radiance = nullptr; float* prev_depth = nullptr;
     uint32_t max_bounces = 3;
     uint32_t white_furnace = 0;
     uint32_t drop_last = 1;
@@ -474,6 +480,21 @@ int rt_frame_create(rt_ctx* ctx, const rt_frame_desc* fd, rt_frame** out)
     bool ok = true;
     ok = ok && hipMalloc((void**)&f->radiance, n * sizeof(float4)) == hipSuccess;
     ok = ok && hipMalloc((void**)&f->resolved, n * sizeof(float4)) == hipSuccess;
+    ok = ok && hipMalloc((void**)&f->aov_buf.diffuse_albedo, n * sizeof(float4)) == hipSuccess;
+    ok = ok && hipMalloc((void**)&f->aov_buf.depth, n * sizeof(float)) == hipSuccess;
+    ok = ok && hipMalloc((void**)&f->aov_buf.normal, n * sizeof(float4)) == hipSuccess;
+    ok = ok && hipMalloc((void**)&f->aov_buf.velocity, n * sizeof(float2)) == hipSuccess;
+    ok = ok && hipMalloc((void**)&f->prev_radiance, n * sizeof(float4)) == hipSuccess;
+    ok = ok && hipMalloc((void**)&f->prev_depth, n * sizeof(float)) == hipSuccess;
+    if (ok)
+    {
+        (void)hipMemsetAsync(f->aov_buf.diffuse_albedo, 0, n * sizeof(float4), ctx->stream);
+        (void)hipMemsetAsync(f->aov_buf.depth, 0, n * sizeof(float), ctx->stream);
+        (void)hipMemsetAsync(f->aov_buf.normal, 0, n * sizeof(float4), ctx->stream);
+        (void)hipMemsetAsync(f->aov_buf.velocity, 0, n * sizeof(float2), ctx->stream);
+        (void)hipMemsetAsync(f->prev_radiance, 0, n * sizeof(float4), ctx->stream);
+        (void)hipMemsetAsync(f->prev_depth, 0, n * sizeof(float), ctx->stream);
+    }
     ok = ok && alloc_path_buffers(f) == RT_OK;
     ok = ok && hipMalloc((void**)&f->counters, sizeof(DCounters)) == hipSuccess;
     // worst case over the kernel variants: 32 one-wave blocks per CU, 8-entry LDS stack
@@ -485,6 +506,8 @@ int rt_frame_create(rt_ctx* ctx, const rt_frame_desc* fd, rt_frame** out)
         return fail(ctx, "rt_frame_create: out of device memory");
     }
     memset(&f->camera, 0, sizeof(f->camera));
+    memset(&f->camera_last, 0, sizeof(f->camera_last));
+    memset(&f->prev_camera, 0, sizeof(f->prev_camera));
     *out = f;
     return rt_reset(f);                                  // the reference ctor ends with Reset(), cl_pt_integrator.cpp:258
 }
@@ -495,7 +518,8 @@ int rt_frame_destroy(rt_frame* f)
     (void)hipSetDevice(f->ctx->device);
     (void)hipStreamSynchronize(f->ctx->stream);
     free_path_buffers(f);
-    void* ptrs[] = {f->radiance, f->resolved, f->counters, f->spill};
+    void* ptrs[] = {f->radiance, f->resolved, f->counters, f->spill, f->aov_buf.diffuse_albedo, f->aov_buf.depth,
+        f->aov_buf.normal, f->aov_buf.velocity, f->prev_radiance, f->prev_depth};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& s : f->spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
     for (auto e : f->event_pool) (void)hipEventDestroy(e);
@@ -543,10 +567,15 @@ int rt_set_option(rt_frame* f, int option, uint32_t value)
         if (value != 0) return fail(f->ctx, "rt_set_option: only SamplerType::kRandom is implemented");
         return RT_OK;
     case RT_OPT_AOV:
-        if (value != 0) return fail(f->ctx, "rt_set_option: only AOV::kShadedColor is implemented");
+        if (value > 4) return fail(f->ctx, "rt_set_option: AOV index must be 0..4");
+        if (value != 0 && f->tile.nranks != 1) return fail(f->ctx, "rt_set_option: AOVs need the whole image on one GPU");
+        f->aov = value;
         return RT_OK;
     case RT_OPT_DENOISER:
-        if (value != 0) return fail(f->ctx, "rt_set_option: the temporal denoiser is not implemented");
+        if (value != 0 && f->tile.nranks != 1)
+            return fail(f->ctx, "rt_set_option: the temporal denoiser reprojects across rows and needs the whole image "
+                                "on one GPU (tile_count == 1)");
+        f->denoiser = value ? 1 : 0;
         return RT_OK;
     case RT_OPT_TRACE_DROP_LAST_BOUNCE_RAYS: f->drop_last = value ? 1 : 0; return RT_OK;
     case RT_OPT_PROFILE_KERNELS: f->profile = value ? 1 : 0; return RT_OK;
@@ -563,6 +592,8 @@ int rt_set_camera(rt_frame* f, const rt_camera* camera)
 {
     if (!f || !camera) return fail(nullptr, "rt_set_camera: NULL argument");
     f->camera = *camera;
+    f->prev_camera = f->camera_last;     // what GenerateAOV sees as prev_camera this frame
+    f->camera_last = *camera;
     return RT_OK;
 }
 
@@ -642,7 +673,7 @@ int rt_reset(rt_frame* f)                               // CLPathTraceIntegrator
     if (!f) return fail(nullptr, "rt_reset: frame is NULL");
     rt_ctx* ctx = f->ctx;
     (void)hipSetDevice(ctx->device);
-    f->sample_count = 0;
+    if (!f->denoiser) f->sample_count = 0;   // Reset() keeps the frame index while denoising (:499-504)
     f->prev_bounces = 0;
     f->cur_slots = 0;
     f->shadow_pending = false;
@@ -737,6 +768,45 @@ int rt_intersect_shadow(rt_frame* f, uint32_t bounce)   // IntersectShadowRays +
     return RT_OK;
 }
 
+int rt_compute_aovs(rt_frame* f)                        // ComputeAOVs, :541-562 (after rt_intersect(frame, 0))
+{
+    FRAME_PROLOGUE(f, "rt_compute_aovs");
+    if (f->aov == 0 && !f->denoiser) return RT_OK;      // outputs unobservable: skip the work
+    if (f->cur_slots != 1) return fail(ctx, "rt_compute_aovs: AOVs need one sample in flight (use the stage API or rt_integrate with the denoiser/AOV option set)");
+    if (f->n_local == 0) return RT_OK;
+    uint32_t blocks = (f->n_local + 255u) / 256u;
+    hipLaunchKernelGGL(k_aov_clear, dim3(blocks), dim3(256), 0, ctx->stream, f->aov_buf, f->n_local);
+    hipLaunchKernelGGL(k_aov, dim3(blocks), dim3(256), 0, ctx->stream, ctx->scene.d, (const float4*)f->o4[0],
+        (const float4*)f->d4[0], (const float4*)f->hits, (const uint32_t*)&f->counters->queue[0], f->camera, f->prev_camera,
+        rt_tanf(0.5f * f->camera.fov), rt_tanf(0.5f * f->prev_camera.fov), f->aov_buf);
+    HIPCHK(ctx, hipGetLastError());
+    return RT_OK;
+}
+
+int rt_denoise(rt_frame* f)                             // Denoise, :665-668
+{
+    FRAME_PROLOGUE(f, "rt_denoise");
+    if (!f->denoiser || f->n_local == 0) return RT_OK;
+    if (flush_log(f) != RT_OK) return RT_ERROR;
+    uint32_t blocks = (f->n_local + 255u) / 256u;
+    hipLaunchKernelGGL(k_denoise, dim3(blocks), dim3(256), 0, ctx->stream, f->tile.width, f->tile.height, f->radiance,
+        (const float4*)f->prev_radiance, (const float*)f->aov_buf.depth, (const float*)f->prev_depth,
+        (const float2*)f->aov_buf.velocity);
+    HIPCHK(ctx, hipGetLastError());
+    return RT_OK;
+}
+
+int rt_copy_history(rt_frame* f)                        // CopyHistoryBuffers, :670-675
+{
+    FRAME_PROLOGUE(f, "rt_copy_history");
+    if (!f->denoiser || f->n_local == 0) return RT_OK;
+    HIPCHK(ctx, hipMemcpyAsync(f->prev_radiance, f->radiance, (size_t)f->n_local * sizeof(float4), hipMemcpyDeviceToDevice,
+        ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(f->prev_depth, f->aov_buf.depth, (size_t)f->n_local * sizeof(float), hipMemcpyDeviceToDevice,
+        ctx->stream));
+    return RT_OK;
+}
+
 int rt_advance_sample(rt_frame* f)                      // AdvanceSampleCount, :510-514
 {
     if (!f) return fail(nullptr, "rt_advance_sample: frame is NULL");
@@ -753,17 +823,22 @@ int rt_integrate(rt_frame* f, uint32_t n_samples)       // n x Integrator::Integ
     // `slots` samples travel through the wavefront together (more rays per launch ->
     // fuller machine, shorter relative tails); the radiance log keeps the sum exact.
     uint32_t done = 0;
+    const bool per_frame = f->denoiser || f->aov != 0;  // interactive features: one sample per Integrate()
     while (done < n_samples)
     {
         uint32_t batch = n_samples - done < f->slots ? n_samples - done : f->slots;
+        if (per_frame) batch = 1;
+        if (f->denoiser && rt_reset(f) != RT_OK) return RT_ERROR;   // integrator.cpp:29: Reset() every frame
         if (generate_rays(f, batch) != RT_OK) return RT_ERROR;
         for (uint32_t bounce = 0; bounce <= f->max_bounces; ++bounce)
         {
             if (rt_intersect(f, bounce) != RT_OK) return RT_ERROR;
+            if (bounce == 0 && per_frame && rt_compute_aovs(f) != RT_OK) return RT_ERROR;
             if (rt_shade(f, bounce) != RT_OK) return RT_ERROR;
             if (rt_intersect_shadow(f, bounce) != RT_OK) return RT_ERROR;
         }
         if (rt_advance_sample(f) != RT_OK) return RT_ERROR;
+        if (f->denoiser && (rt_denoise(f) != RT_OK || rt_copy_history(f) != RT_OK)) return RT_ERROR;
         done += batch;
     }
     return RT_OK;
@@ -778,8 +853,8 @@ int rt_frame_resolve(rt_frame* f, float* host_rgba)     // ResolveRadiance, :677
     if (f->n_local == 0) return RT_OK;
     if (flush_log(f) != RT_OK) return RT_ERROR;
     uint32_t blocks = (f->n_local + 255u) / 256u;
-    hipLaunchKernelGGL(k_resolve, dim3(blocks), dim3(256), 0, ctx->stream, f->radiance, f->resolved, f->n_local,
-        f->sample_count);
+    hipLaunchKernelGGL(k_resolve, dim3(blocks), dim3(256), 0, ctx->stream, (const float4*)f->radiance, f->aov_buf,
+        f->resolved, f->n_local, f->sample_count, f->aov, f->denoiser);
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipMemcpyAsync(host_rgba, f->resolved, (size_t)f->n_local * sizeof(float4), hipMemcpyDeviceToHost,
         ctx->stream));

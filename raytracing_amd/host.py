@@ -20,7 +20,7 @@ EXPORTS = [
     "rth_render_enable_denoiser", "rth_render_set_resolve_every_frame", "rth_render_frame", "rth_render_samples",
     "rth_render_finish", "rth_render_local_rows", "rth_render_global_row", "rth_render_sample_count",
     "rth_render_read_radiance", "rth_render_read_resolved", "rth_render_stats", "rth_render_frame_handle",
-    "rth_render_ctx_handle", "rth_render_num_nodes", "rth_render_nodes",
+    "rth_render_ctx_handle", "rth_render_num_nodes", "rth_render_nodes", "rth_render_set_aov", "rth_render_resolve",
 ]
 
 
@@ -56,6 +56,7 @@ def load():
         "rth_render_read_resolved": (i32, [vp, vp]), "rth_render_stats": (i32, [vp, C.POINTER(rt_stats)]),
         "rth_render_frame_handle": (vp, [vp]), "rth_render_ctx_handle": (vp, [vp]),
         "rth_render_num_nodes": (u32, [vp]), "rth_render_nodes": (vp, [vp]),
+        "rth_render_set_aov": (i32, [vp, i32]), "rth_render_resolve": (i32, [vp, vp]),
     }
     for name in ("triangles", "materials", "textures", "texture_data", "lights", "emissive"):
         sig["rth_scene_num_" + name] = (u32, [vp])
@@ -200,6 +201,12 @@ class Render:
     def enable_white_furnace(self, e): self._c(self.lib.rth_render_enable_white_furnace(self.handle, int(e)))
     def set_blue_noise(self, e): self._c(self.lib.rth_render_set_sampler(self.handle, int(e)))
     def enable_denoiser(self, e): self._c(self.lib.rth_render_enable_denoiser(self.handle, int(e)))
+    def set_aov(self, aov): self._c(self.lib.rth_render_set_aov(self.handle, int(aov)))
+
+    def resolve_now(self):
+        out = np.zeros((self.local_rows, self.width, 4), np.float32)
+        self._c(self.lib.rth_render_resolve(self.handle, out.ctypes.data))
+        return out
     def set_resolve_every_frame(self, e): self._c(self.lib.rth_render_set_resolve_every_frame(self.handle, int(e)))
     def render_frame(self): self._c(self.lib.rth_render_frame(self.handle))
     def render_samples(self, n): self._c(self.lib.rth_render_samples(self.handle, n))

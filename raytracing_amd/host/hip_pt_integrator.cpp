@@ -13,6 +13,8 @@
 //   IntersectShadowRays :564-580       -> rt_intersect_shadow (+ accumulate)
 //   AccumulateDirectSamples :645-649   -> rt_accumulate_direct (no-op: fused)
 //   AdvanceSampleCount :510-514        -> rt_advance_sample
+//   ComputeAOVs :541-562               -> rt_compute_aovs
+//   Denoise / CopyHistoryBuffers :665-675 -> rt_denoise / rt_copy_history
 //   ResolveRadiance :677-684           -> rt_frame_resolve (the frame's only host sync)
 #include "hip_pt_integrator.hpp"
 #include "acceleration_structure.hpp"
@@ -129,15 +131,15 @@ void HIPPathTraceIntegrator::Reset() { SyncOptions(); Check(rt_reset(frame_)); }
 void HIPPathTraceIntegrator::AdvanceSampleCount() { Check(rt_advance_sample(frame_)); }
 void HIPPathTraceIntegrator::GenerateRays() { SyncOptions(); Check(rt_generate_rays(frame_)); }
 void HIPPathTraceIntegrator::IntersectRays(std::uint32_t bounce) { Check(rt_intersect(frame_, bounce)); }
-void HIPPathTraceIntegrator::ComputeAOVs() {}   // AOV viewer: not on the hot path
+void HIPPathTraceIntegrator::ComputeAOVs() { Check(rt_compute_aovs(frame_)); }
 void HIPPathTraceIntegrator::ShadeMissedRays(std::uint32_t bounce) { Check(rt_shade_miss(frame_, bounce)); }
 void HIPPathTraceIntegrator::ShadeSurfaceHits(std::uint32_t bounce) { Check(rt_shade(frame_, bounce)); }
 void HIPPathTraceIntegrator::IntersectShadowRays() { Check(rt_intersect_shadow(frame_, current_bounce_)); }
 void HIPPathTraceIntegrator::AccumulateDirectSamples() { Check(rt_accumulate_direct(frame_)); }
 void HIPPathTraceIntegrator::ClearOutgoingRayCounter(std::uint32_t bounce) { Check(rt_clear_outgoing_counter(frame_, bounce)); }
 void HIPPathTraceIntegrator::ClearShadowRayCounter() { Check(rt_clear_shadow_counter(frame_)); }
-void HIPPathTraceIntegrator::Denoise() {}
-void HIPPathTraceIntegrator::CopyHistoryBuffers() {}
+void HIPPathTraceIntegrator::Denoise() { Check(rt_denoise(frame_)); }
+void HIPPathTraceIntegrator::CopyHistoryBuffers() { Check(rt_copy_history(frame_)); }
 
 void HIPPathTraceIntegrator::ResolveRadiance()
 {
@@ -146,7 +148,7 @@ void HIPPathTraceIntegrator::ResolveRadiance()
 
 void HIPPathTraceIntegrator::IntegrateSamples(std::uint32_t n_samples)
 {
-    if (request_reset_) { Reset(); request_reset_ = false; }
+    if (request_reset_ || enable_denoiser_) { Reset(); request_reset_ = false; }
     SyncOptions();
     Check(rt_integrate(frame_, n_samples));
 }
@@ -156,6 +158,12 @@ std::vector<float> HIPPathTraceIntegrator::ReadRadianceSum() const
     std::vector<float> out((size_t)rt_frame_local_rows(frame_) * width_ * 4);
     Check(rt_frame_read_radiance(frame_, out.data()));
     return out;
+}
+
+std::vector<float> const& HIPPathTraceIntegrator::ResolveNow()
+{
+    Check(rt_frame_resolve(frame_, resolved_.data()));
+    return resolved_;
 }
 
 std::uint32_t HIPPathTraceIntegrator::GetSampleCount() const { return rt_frame_sample_count(frame_); }

@@ -57,6 +57,7 @@ public:
     // Headless outputs (the reference writes a GL-shared image in ResolveRadiance).
     std::vector<float> const& GetResolvedImage() const { return resolved_; }   // local_rows x width x RGBA
     std::vector<float> ReadRadianceSum() const;
+    std::vector<float> const& ResolveNow();      // runs the resolve stage and returns the image
     std::uint32_t GetSampleCount() const;
     std::uint32_t GetLocalRows() const;
     std::uint32_t GetGlobalRow(std::uint32_t local_row) const;

@@ -135,6 +135,16 @@ int rth_render_set_sampler(void* r, int blue_noise)
     return guard([&]() { ((rt::Render*)r)->GetIntegrator().SetSamplerType(blue_noise ? rt::Integrator::SamplerType::kBlueNoise : rt::Integrator::SamplerType::kRandom); return 0; }, 1);
 }
 int rth_render_enable_denoiser(void* r, int e) { return guard([&]() { ((rt::Render*)r)->GetIntegrator().EnableDenoiser(e != 0); return 0; }, 1); }
+int rth_render_set_aov(void* r, int aov) { return guard([&]() { ((rt::Render*)r)->GetIntegrator().SetAOV((rt::Integrator::AOV)aov); return 0; }, 1); }
+int rth_render_resolve(void* r, float* out)
+{
+    return guard([&]()
+    {
+        auto const& v = ((rt::Render*)r)->GetIntegrator().ResolveNow();
+        memcpy(out, v.data(), v.size() * sizeof(float));
+        return 0;
+    }, 1);
+}
 int rth_render_set_resolve_every_frame(void* r, int e) { ((rt::Render*)r)->GetIntegrator().SetResolveEveryFrame(e != 0); return 0; }
 int rth_render_frame(void* r) { return guard([&]() { ((rt::Render*)r)->RenderFrame(); return 0; }, 1); }
 int rth_render_samples(void* r, uint32_t n) { return guard([&]() { ((rt::Render*)r)->RenderSamples(n); return 0; }, 1); }

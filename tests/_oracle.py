@@ -37,6 +37,7 @@ def load():
         "orc_stage_clear_counters": (None, [vp, u32]), "orc_stage_shade_hits": (None, [vp, u32]),
         "orc_stage_intersect_shadow": (None, [vp]), "orc_stage_accumulate": (None, [vp]),
         "orc_stage_advance": (None, [vp]),
+        "orc_enable_denoiser": (None, [vp, C.c_int]), "orc_set_aov": (None, [vp, u32]),
         "orc_wang_hash": (u32, [u32]), "orc_sample_random": (f32, [u32] * 5),
         "orc_tanf": (f32, [f32]), "orc_sinf": (f32, [f32]), "orc_cosf": (f32, [f32]),
         "orc_powf": (f32, [f32, f32]), "orc_atan2f": (f32, [f32, f32]), "orc_acosf": (f32, [f32]),
@@ -80,6 +81,12 @@ class Oracle:
 
     def set_max_bounces(self, b):
         self.lib.orc_set_max_bounces(self.handle, b)
+
+    def enable_denoiser(self, e):
+        self.lib.orc_enable_denoiser(self.handle, int(e))
+
+    def set_aov(self, aov):
+        self.lib.orc_set_aov(self.handle, aov)
 
     def integrate(self, n=1):
         for _ in range(n):

@@ -43,6 +43,7 @@ def load(libm=False):
         "ref_stage_clear_counters": (None, [vp, u32]), "ref_stage_shade_hits": (None, [vp, u32]),
         "ref_stage_intersect_shadow": (None, [vp]), "ref_stage_accumulate": (None, [vp]),
         "ref_stage_advance": (None, [vp]),
+        "ref_enable_denoiser": (None, [vp, C.c_int]), "ref_set_aov": (None, [vp, u32]),
     }
     for name in ("triangles", "nodes", "materials", "textures", "texture_data", "lights", "emissive"):
         sig["refh_num_" + name] = (u32, [vp])
@@ -131,6 +132,12 @@ class RefIntegrator:
 
     def set_max_bounces(self, b):
         self.lib.ref_set_max_bounces(self.handle, b)
+
+    def enable_denoiser(self, e):
+        self.lib.ref_enable_denoiser(self.handle, int(e))
+
+    def set_aov(self, aov):
+        self.lib.ref_set_aov(self.handle, aov)
 
     def integrate(self, n=1):
         for _ in range(n):

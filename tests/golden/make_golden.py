@@ -86,6 +86,27 @@ def main():
         out[name + "/last_shadow"] = sh
         out[name + "/camera"] = cam
         print(name, "mean", out[name + "/radiance"].mean(), "rays", c, s)
+    # AOV viewer + temporal denoiser (aov.cl, denoiser.cl, resolve_radiance.cl AOV switch): a 5-frame
+    # sequence with a moving camera, resolved image of every frame
+    w, h = 64, 48
+    ri = _ref.RefIntegrator(w, h, scenes["coverage"], threads=1)
+    ri.set_max_bounces(3)
+    cam = T.default_camera(w, h)
+    for aov in (1, 2, 3, 4):
+        ri.set_aov(aov)
+        ri.set_camera(cam)
+        ri.integrate(1)
+        out["aov%d/resolved" % aov] = ri.resolve()[..., :3].copy()
+    ri.set_aov(0)
+    ri.enable_denoiser(True)
+    for f in range(5):
+        c = cam.copy()
+        c["position"]["x"] = 0.02 * f
+        ri.set_camera(c)
+        ri.integrate(1)
+        out["denoise%d/resolved" % f] = ri.resolve()[..., :3].copy()
+        out["denoise%d/radiance" % f] = ri.radiance()[..., :3].copy()
+    out["aov_denoise/camera"] = cam
     np.savez_compressed(os.path.join(HERE, "radiance.npz"), **out)
 
     host = {

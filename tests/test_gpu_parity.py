@@ -188,8 +188,6 @@ def test_cpp_host_layer_end_to_end(ctx, golden_scenes, golden_radiance):
     assert r.sample_count() == 1    # furnace toggle requested a reset
     with pytest.raises(host.RtError, match="kRandom"):
         r.set_blue_noise(True)      # not implemented -> loud, not silent
-    with pytest.raises(host.RtError, match="denoiser"):
-        r.enable_denoiser(True)
 
 
 def test_furnace_energy_bound(ctx, golden_scenes):
@@ -338,3 +336,62 @@ def test_kernel_profile_and_stats_accounting(ctx, golden_scenes):
     orc = _oracle.Oracle(64, 64, sc)
     orc.set_camera(T.default_camera(64, 64)); orc.set_max_bounces(5); orc.integrate(8)
     assert (st.closest_rays, st.shadow_rays) == orc.ray_totals()
+
+
+class _FrameAdapter:
+    """Gives capi.Frame / host.Render the surface of the sequence helper."""
+    def __init__(self, obj, kind):
+        self.o, self.kind, self.request_reset = obj, kind, False
+    def set_max_bounces(self, b): self.o.set_max_bounces(b)
+    def set_camera(self, c): self.o.set_camera(c)
+    def set_aov(self, a):
+        if self.kind == "capi":
+            self.o.set_option(capi.OPT_AOV, a); self.request_reset = True      # SetAOV -> RequestReset (:470-483)
+        else:
+            self.o.set_aov(a)
+    def enable_denoiser(self, e):
+        if self.kind == "capi":
+            self.o.set_option(capi.OPT_DENOISER, int(e)); self.request_reset = True
+        else:
+            self.o.enable_denoiser(e)
+    def integrate(self, n):
+        if self.kind == "capi":
+            if self.request_reset:          # Integrate(): Reset() happens lazily, with the options of that moment
+                self.o.reset(); self.request_reset = False
+            self.o.integrate(n)
+        elif self.kind == "frames":
+            for _ in range(n): self.o.render_frame()                # Integrator::Integrate(), all 15 hooks
+        else: self.o.render_samples(n)
+    def resolve(self): return self.o.resolve() if self.kind == "capi" else self.o.resolve_now()
+    def radiance(self): return self.o.radiance()
+
+
+@pytest.mark.parametrize("kind", ["capi", "frames", "samples"])
+def test_aov_viewer_and_temporal_denoiser(ctx, golden_scenes, golden_radiance, kind):
+    """GenerateAOV + TemporalAccumulation + the AOV switch of ResolveRadiance: through the C-ABI
+    against the golden sequence of the reference kernels, and through Integrator::Integrate()
+    (all 15 hooks) / the fused IntegrateSamples path of the C++ host layer against the oracle."""
+    from tests.test_oracle_golden import _aov_denoise_sequence
+    g = golden_radiance
+    cam = g["aov_denoise/camera"]
+    if kind == "capi":
+        ctx.upload_scene(golden_scenes["coverage"])
+        got = _aov_denoise_sequence(_FrameAdapter(capi.Frame(ctx, 64, 48), "capi"), cam)
+        want = g
+    else:
+        scene = host.Scene(os.path.join(ROOT, "assets", "CornellBox.obj"))
+        scene.add_directional_light((-0.6, -1.5, 3.5), (15.0, 10.0, 5.0))
+        r = host.Render(64, 48, scene)
+        got = _aov_denoise_sequence(_FrameAdapter(r, kind), cam)
+        want = _aov_denoise_sequence(_oracle.Oracle(64, 48, r.scene_arrays()), cam)
+    for k, v in got.items():
+        assert np.array_equal(v, want[k], equal_nan=True), k
+
+
+def test_denoiser_needs_the_whole_image(ctx, golden_scenes):
+    ctx.upload_scene(golden_scenes["cornell"])
+    t = capi.Frame(ctx, 32, 32, tile_rank=0, tile_count=2)
+    with pytest.raises(capi.RtError, match="whole image"):
+        t.set_option(capi.OPT_DENOISER, 1)
+    with pytest.raises(capi.RtError, match="whole image"):
+        t.set_option(capi.OPT_AOV, 2)

@@ -77,3 +77,31 @@ def test_detmath_matches_correctly_rounded_double():
     assert lib.orc_powf(0.0, 2.2) == 0.0 and lib.orc_powf(-2.0, 5.0) == -32.0
     assert math.isnan(lib.orc_powf(-2.0, 0.5))
     assert np.float32(lib.orc_acosf(-1.0)) == np.float32(math.pi)
+
+
+def _aov_denoise_sequence(obj, cam):
+    """The sequence tests/golden/make_golden.py recorded from the reference kernels."""
+    out = {}
+    obj.set_max_bounces(3)
+    for aov in (1, 2, 3, 4):
+        obj.set_aov(aov)
+        obj.set_camera(cam)
+        obj.integrate(1)
+        out["aov%d/resolved" % aov] = obj.resolve()[..., :3].copy()
+    obj.set_aov(0)
+    obj.enable_denoiser(True)
+    for f in range(5):
+        c = cam.copy()
+        c["position"]["x"] = 0.02 * f
+        obj.set_camera(c)
+        obj.integrate(1)
+        out["denoise%d/resolved" % f] = obj.resolve()[..., :3].copy()
+        out["denoise%d/radiance" % f] = obj.radiance()[..., :3].copy()
+    return out
+
+
+def test_oracle_aov_and_denoiser_sequence(golden_scenes, golden_radiance):
+    g = golden_radiance
+    got = _aov_denoise_sequence(_oracle.Oracle(64, 48, golden_scenes["coverage"]), g["aov_denoise/camera"])
+    for k, v in got.items():
+        assert np.array_equal(v, g[k], equal_nan=True), k
