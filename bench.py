@@ -44,12 +44,34 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MI
 LIGHT = ((-0.6, -1.5, 3.5), (15.0, 10.0, 5.0))   # reference main.cpp:58
 
 
+# BASELINE.json configs (index = position in "configs"); config 1 is the CPU plumbing case.
+CONFIGS = {
+    2: dict(width=1280, height=720, bounces=8, name="BASELINE configs[1] stand-in: Cornell shell + %(blob)d-tri displaced "
+            "blob (dragon mtl) + %(ball)d-tri sphere (teapot mtl)"),
+    3: dict(width=1920, height=1080, bounces=3, name="BASELINE configs[2] stand-in: ShaderBalls.mtl 3x3 material grid on "
+            "tessellated spheres + floor + 3 emissive quads, loaded from a generated OBJ (GGX+Lambert heavy)"),
+    4: dict(width=1920, height=1080, bounces=8, name="BASELINE configs[3] stand-in: procedural 'city block' (boxes, props, "
+            "displaced foliage, 120 materials, textured) ~2.8 M triangles in place of Bistro exterior"),
+    5: dict(width=3840, height=2160, bounces=16, name="BASELINE configs[4] stand-in: procedural dense foliage courtyard "
+            "~10 M triangles in place of San Miguel (deep BVH, high divergence)"),
+}
+
+
 def build_scene(args, host, S):
-    tris, mats = S.cornell_blob(args.blob_tris, args.ball_tris)
-    scene = host.Scene(arrays=dict(triangles=tris, materials=mats))
+    if args.config == 3:
+        import tempfile
+        path = S.shader_balls_obj(tempfile.mkdtemp(prefix="rt_bench_"), 100_000)
+        scene = host.Scene(path)
+    elif args.config == 4:
+        scene = host.Scene(arrays=S.city_block(2_800_000))
+    elif args.config == 5:
+        scene = host.Scene(arrays=S.dense_foliage(10_000_000))
+    else:
+        tris, mats = S.cornell_blob(args.blob_tris, args.ball_tris)
+        scene = host.Scene(arrays=dict(triangles=tris, materials=mats))
     scene.add_directional_light(*LIGHT)
     scene.set_env_path(os.path.join(ROOT, "assets", "ibl", "CGSkies_0036_free.hdr"))
-    return scene, len(tris)
+    return scene, scene.lib.rth_scene_num_triangles(scene.handle)
 
 
 def cpu_legs(args, scene_arrays, cam_small, small_w, small_h, cam_full):
@@ -116,15 +138,23 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--warmup", type=int, default=4)
-    ap.add_argument("--width", type=int, default=1280)
-    ap.add_argument("--height", type=int, default=720)
-    ap.add_argument("--bounces", type=int, default=8)
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS),
+                    help="BASELINE.json config (1-based index into 'configs'); default 2 = the metric's single-GPU config")
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--bounces", type=int, default=None)
     ap.add_argument("--blob-tris", type=int, default=871_200)
     ap.add_argument("--ball-tris", type=int, default=20_000)
     ap.add_argument("--band-height", type=int, default=8)
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--debug-shared-gpu", action="store_true",
+                    help="plumbing test only: all ranks share GPU 0 and gather over gloo (RCCL refuses two ranks per device)")
     args = ap.parse_args()
+    cfg = CONFIGS[args.config]
+    args.width = args.width or cfg["width"]
+    args.height = args.height or cfg["height"]
+    args.bounces = cfg["bounces"] if args.bounces is None else args.bounces
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -140,10 +170,14 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    if args.debug_shared_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)   # "nccl" is RCCL on ROCm
+        # "nccl" is RCCL on ROCm; one rank per GPU, xGMI underneath
+        dist.init_process_group("gloo" if args.debug_shared_gpu else "nccl", rank=rank, world_size=world)
+    coll_dev = "cpu" if (args.debug_shared_gpu and world > 1) else "cuda"
 
     # ---- setup (untimed): scene, BVH, upload -------------------------------
     scene, n_tris = build_scene(args, host, S)
@@ -170,7 +204,7 @@ def main():
     if args.warmup > 0:     # the gather path too (first use loads torch / RCCL kernels)
         if local_rows:
             lib.rt_frame_copy_radiance(frame, tile.data_ptr())
-        D.gather_image(tile[:local_rows], args.height, args.width, rank, world, args.band_height)
+        D.gather_image(tile[:local_rows].to(coll_dev), args.height, args.width, rank, world, args.band_height)
     sync()
     # the timed region starts from a reset accumulation (sample indices 0..K-1, counters at 0)
     assert lib.rt_reset(frame) == 0
@@ -189,7 +223,7 @@ def main():
     if local_rows:
         lib.rt_frame_copy_radiance(frame, tile.data_ptr())
     t_render = time.perf_counter() - t0
-    full = D.gather_image(tile[:local_rows], args.height, args.width, rank, world, args.band_height)
+    full = D.gather_image(tile[:local_rows].to(coll_dev), args.height, args.width, rank, world, args.band_height)
     sync()
     if world > 1:
         dist.barrier()
@@ -204,8 +238,8 @@ def main():
     closest = st1.closest_rays - st0.closest_rays
     shadow = st1.shadow_rays - st0.shadow_rays
     agg = torch.tensor([float(closest), float(shadow), prof.ms_trace_closest, prof.ms_trace_shadow, prof.ms_shade,
-                        prof.ms_raygen], dtype=torch.float64, device="cuda")
-    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+                        prof.ms_raygen], dtype=torch.float64, device=coll_dev)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
     if world > 1:
         dist.all_reduce(agg, op=dist.ReduceOp.SUM)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -240,7 +274,7 @@ def main():
                                                 shade=round(agg[4] / world / args.steps, 4),
                                                 raygen=round(agg[5] / world / args.steps, 4)))
         traffic_file = os.path.join(ROOT, "profiles", "trace_closest_hbm_traffic.json")
-        if os.path.exists(traffic_file):
+        if world == 1 and os.path.exists(traffic_file):   # measured at the single-GPU launch size
             try:
                 roofline["traffic"] = json.load(open(traffic_file)).get("bytes_per_launch")
             except Exception:
@@ -249,10 +283,9 @@ def main():
         line = dict(metric="Mrays/s (all bounces+shadow)", value=round(value, 2), unit="Mrays/s", n_gpus=world,
                     steps=args.steps, warmup=args.warmup, ms_per_step=round(dt_max * 1e3 / args.steps, 4),
                     higher_is_better=True, scaling="strong", vs_baseline=None, dtype="f32", data="synthetic",
-                    config=dict(workload="BASELINE configs[1] stand-in: Cornell shell + %d-tri displaced blob (dragon "
-                                         "mtl) + %d-tri sphere (teapot mtl), %dx%d, %d-bounce, 1 spp per step, default "
-                                         "camera, directional light + CGSkies env map"
-                                         % (args.blob_tris, args.ball_tris, args.width, args.height, args.bounces),
+                    config=dict(workload=(cfg["name"] % dict(blob=args.blob_tris, ball=args.ball_tris)) +
+                                         ", %dx%d, %d-bounce, 1 spp per step, default camera, directional light + "
+                                         "CGSkies env map" % (args.width, args.height, args.bounces),
                                 triangles=int(n_tris), width=args.width, height=args.height,
                                 max_bounces=args.bounces, spp=args.steps,
                                 tiling="%d interleaved %d-row bands per GPU, 1 RCCL gather" % (world, args.band_height)

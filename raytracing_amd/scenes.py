@@ -324,3 +324,171 @@ def write_obj(path_obj, meshes, material_names, mtl_text):
                 a = base + 3 * t
                 f.write("f %d/%d/%d %d/%d/%d %d/%d/%d\n" % (a, a, a, a + 1, a + 1, a + 1, a + 2, a + 2, a + 2))
             base += 3 * n
+
+
+# --------------------------------------------------------------------------
+# stand-ins for BASELINE configs 3-5
+# --------------------------------------------------------------------------
+def _instances(unit, centers, scales, rng, mtl_ids):
+    """Vectorised instancing of a unit mesh: scale, rotate about z, translate."""
+    P0, N0, U0 = unit
+    k, m = len(centers), len(P0)
+    ang = rng.uniform(0, 2 * np.pi, k)
+    c, s = np.cos(ang), np.sin(ang)
+    R = np.zeros((k, 3, 3))
+    R[:, 0, 0], R[:, 0, 1], R[:, 1, 0], R[:, 1, 1], R[:, 2, 2] = c, -s, s, c, 1.0
+    P = np.einsum("kij,mvj->kmvi", R, P0.astype(np.float64)) * scales[:, None, None, None] + centers[:, None, None, :]
+    N = np.einsum("kij,mvj->kmvi", R, N0.astype(np.float64))
+    U = np.broadcast_to(U0, (k,) + U0.shape)
+    mt = np.repeat(mtl_ids, m)
+    return (P.reshape(k * m, 3, 3).astype(np.float32), N.reshape(k * m, 3, 3).astype(np.float32),
+            U.reshape(k * m, 3, 2).astype(np.float32), mt.astype(np.uint32))
+
+
+def _triangles_with_ids(P, N, U, mt):
+    tris = np.zeros(len(P), dtype=T.triangle)
+    for vi, vn in enumerate(("v1", "v2", "v3")):
+        for ci, c in enumerate("xyz"):
+            tris[vn]["position"][c] = P[:, vi, ci]
+            tris[vn]["normal"][c] = N[:, vi, ci]
+        tris[vn]["texcoord"]["x"] = U[:, vi, 0]
+        tris[vn]["texcoord"]["y"] = U[:, vi, 1]
+    tris["mtl_index"] = mt
+    return tris
+
+
+def random_materials(n, rng, n_textures=0):
+    mats = []
+    for i in range(n):
+        kind = i % 4
+        kd = tuple(rng.uniform(0.05, 0.9, 3))
+        if kind == 0:
+            m = dict(kd=kd)
+        elif kind == 1:
+            m = dict(kd=kd, ks=tuple(rng.uniform(0.5, 1.0, 3)), roughness=float(rng.uniform(0.05, 0.6)), metalness=1.0)
+        elif kind == 2:
+            m = dict(kd=kd, ks=(1, 1, 1), roughness=float(rng.uniform(0.0, 0.4)), metalness=0.0, ior=1.5)
+        else:
+            m = dict(kd=kd, ks=tuple(rng.uniform(0.2, 0.8, 3)), roughness=float(rng.uniform(0.2, 0.8)),
+                     metalness=float(rng.uniform(0, 1)))
+        if n_textures and i % 5 == 0:
+            m["kd_tex"] = int(rng.randint(0, n_textures))
+        mats.append(make_material(**m))
+    return np.array(mats, dtype=T.packed_material)
+
+
+def city_block(n_tris=2_800_000, seed=7, n_materials=120):
+    """Stand-in for BASELINE config 4 (Amazon Lumberyard Bistro exterior, ~2.8 M triangles,
+    100+ materials, some textured): a street grid of box 'buildings', tessellated 'props' and
+    displaced 'foliage' blobs in front of the default camera."""
+    rng = np.random.RandomState(seed)
+    tex = [checker_texture(64, 8), checker_texture(64, 16, c0=(200, 180, 150), c1=(90, 60, 40)),
+           checker_texture(32, 4, c0=(240, 240, 240), c1=(120, 160, 120))]
+    textures = np.zeros(3, dtype=T.texture)
+    off = 0
+    for i, t in enumerate(tex):
+        side = int(np.sqrt(len(t)))
+        textures[i] = (off, side, side, 0)
+        off += len(t)
+    texture_data = np.concatenate(tex).astype(np.uint32)
+    mats = random_materials(n_materials, rng, n_textures=3)
+    parts = []
+    # ground (two triangles, textured)
+    g = quad((-30, -2, 0), (30, -2, 0), (30, 60, 0), (-30, 60, 0), uv_scale=40.0)
+    parts.append((g[0], g[1], g[2], np.zeros(2, np.uint32)))
+    # buildings: boxes on a jittered grid, 12 triangles each
+    n_boxes = 3000
+    bx = rng.uniform(-28, 28, n_boxes)
+    by = rng.uniform(3, 58, n_boxes)
+    keep = np.abs(bx) > 1.5                       # leave a street in front of the camera
+    bx, by = bx[keep], by[keep]
+    unit_box = box((-0.5, -0.5, 0.0), (0.5, 0.5, 1.0))
+    for i in range(len(bx)):
+        w, d, hgt = rng.uniform(0.6, 2.5), rng.uniform(0.6, 2.5), rng.uniform(1.0, 9.0)
+        P = unit_box[0] * np.array([w, d, hgt], np.float32) + np.array([bx[i], by[i], 0], np.float32)
+        parts.append((P, unit_box[1], unit_box[2] * 4.0, np.full(12, 1 + rng.randint(n_materials - 1), np.uint32)))
+    used = sum(len(p[0]) for p in parts)
+    # props: tessellated spheres (smooth) -- 40 % of the budget; foliage: displaced blobs -- the rest
+    per_prop = 5000
+    n_props = max(1, int(0.4 * (n_tris - used) / per_prop))
+    lat = max(6, int(round(math.sqrt(per_prop / 4.0))))
+    unit_s = uv_sphere((0, 0, 0), 1.0, lat, 2 * lat)
+    centers = np.stack([rng.uniform(-25, 25, n_props), rng.uniform(1.5, 55, n_props), rng.uniform(0.2, 3.0, n_props)], 1)
+    parts.append(_instances(unit_s, centers, rng.uniform(0.15, 0.6, n_props), rng, 1 + rng.randint(0, n_materials - 1, n_props)))
+    used = sum(len(p[0]) for p in parts)
+    per_blob = len(unit_s[0])
+    unit_b = uv_sphere((0, 0, 0), 1.0, lat, 2 * lat, bump=0.5, seed=seed)
+    n_blobs = max(1, (n_tris - used) // len(unit_b[0]))
+    centers = np.stack([rng.uniform(-25, 25, n_blobs), rng.uniform(1.5, 55, n_blobs), rng.uniform(0.5, 6.0, n_blobs)], 1)
+    parts.append(_instances(unit_b, centers, rng.uniform(0.3, 1.2, n_blobs), rng, 1 + rng.randint(0, n_materials - 1, n_blobs)))
+    P = np.concatenate([p[0] for p in parts]); N = np.concatenate([p[1] for p in parts])
+    U = np.concatenate([p[2] for p in parts]); mt = np.concatenate([p[3] for p in parts])
+    tris = _triangles_with_ids(P, N, U, mt)
+    return dict(triangles=tris, materials=mats, textures=textures, texture_data=texture_data)
+
+
+def dense_foliage(n_tris=10_000_000, seed=11, n_materials=64):
+    """Stand-in for BASELINE config 5 (San Miguel, ~10 M triangles, deep BVH, high depth
+    complexity): thousands of overlapping displaced blobs inside a courtyard of walls."""
+    rng = np.random.RandomState(seed)
+    mats = random_materials(n_materials, rng)
+    parts = []
+    g = quad((-12, -2, 0), (12, -2, 0), (12, 30, 0), (-12, 30, 0))
+    parts.append((g[0], g[1], g[2], np.zeros(2, np.uint32)))
+    for wall in (quad((-12, 30, 0), (12, 30, 0), (12, 30, 8), (-12, 30, 8)),
+                 quad((12, -2, 0), (12, -2, 8), (12, 30, 8), (12, 30, 0)),
+                 quad((-12, -2, 0), (-12, 30, 0), (-12, 30, 8), (-12, -2, 8))):
+        parts.append((wall[0], wall[1], wall[2], np.full(2, 1, np.uint32)))
+    per = 4000
+    lat = max(6, int(round(math.sqrt(per / 4.0))))
+    unit_b = uv_sphere((0, 0, 0), 1.0, lat, 2 * lat, bump=0.6, seed=seed)
+    n_blobs = max(1, n_tris // len(unit_b[0]))
+    # nested clusters: blob centres drawn around ~200 cluster centres -> heavy overlap
+    cl = np.stack([rng.uniform(-10, 10, 200), rng.uniform(1.0, 28, 200), rng.uniform(0.3, 5.0, 200)], 1)
+    centers = cl[rng.randint(0, 200, n_blobs)] + rng.normal(0, 0.6, (n_blobs, 3))
+    centers[:, 2] = np.abs(centers[:, 2]) + 0.1
+    chunk = 250
+    for a in range(0, n_blobs, chunk):
+        b = min(n_blobs, a + chunk)
+        parts.append(_instances(unit_b, centers[a:b], rng.uniform(0.08, 0.45, b - a), rng,
+                                2 + rng.randint(0, n_materials - 2, b - a)))
+    P = np.concatenate([p[0] for p in parts]); N = np.concatenate([p[1] for p in parts])
+    U = np.concatenate([p[2] for p in parts]); mt = np.concatenate([p[3] for p in parts])
+    return dict(triangles=_triangles_with_ids(P, N, U, mt), materials=mats,
+                textures=np.zeros(0, T.texture), texture_data=np.zeros(0, np.uint32))
+
+
+def shader_balls_obj(directory, tris_per_ball=20_000):
+    """Stand-in for BASELINE config 3 (ShaderBalls.obj): writes ShaderBallsStandIn.obj next to a
+    copy of the reference's ShaderBalls.mtl -- a 3x3 grid of tessellated spheres using mat00..mat22,
+    the floor and the three emissive quads -- and returns the OBJ path (loaded through Scene)."""
+    import os
+    import shutil
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    shutil.copy(os.path.join(here, "assets", "ShaderBalls.mtl"), os.path.join(directory, "ShaderBalls.mtl"))
+    lat = max(6, int(round(math.sqrt(tris_per_ball / 4.0))))
+    names = ["mat%d%d" % (r, c) for r in range(3) for c in range(3)] + ["floor", "light", "light_red", "light_blue"]
+    meshes = []
+    for r in range(3):
+        for c in range(3):
+            meshes.append(uv_sphere((-1.3 + 1.3 * c, 1.2 + 1.3 * r, 0.5), 0.5, lat, 2 * lat) + (3 * r + c,))
+    meshes.append(quad((-6, -2, 0), (6, -2, 0), (6, 8, 0), (-6, 8, 0)) + (9,))
+    meshes.append(quad((-1, 1.5, 3.0), (1, 1.5, 3.0), (1, 3.0, 3.0), (-1, 3.0, 3.0), normal=(0, 0, -1)) + (10,))
+    meshes.append(quad((-3.5, 1.0, 0.2), (-3.5, 2.0, 0.2), (-3.5, 2.0, 1.5), (-3.5, 1.0, 1.5), normal=(1, 0, 0)) + (11,))
+    meshes.append(quad((3.5, 2.0, 0.2), (3.5, 1.0, 0.2), (3.5, 1.0, 1.5), (3.5, 2.0, 1.5), normal=(-1, 0, 0)) + (12,))
+    path = os.path.join(directory, "ShaderBallsStandIn.obj")
+    mtl_name = "ShaderBalls.mtl"
+    with open(path, "w") as f:
+        f.write("mtllib %s\n" % mtl_name)
+        base = 1
+        for P, N, U, mtl in meshes:
+            f.write("o mesh%d\nusemtl %s\n" % (base, names[mtl]))
+            n = len(P)
+            np.savetxt(f, P.reshape(-1, 3), fmt="v %.7g %.7g %.7g")
+            np.savetxt(f, U.reshape(-1, 2), fmt="vt %.7g %.7g")
+            np.savetxt(f, N.reshape(-1, 3), fmt="vn %.7g %.7g %.7g")
+            idx = base + 3 * np.arange(n)[:, None] + np.arange(3)[None, :]
+            np.savetxt(f, np.repeat(idx, 3, axis=1).reshape(n, 9)[:, [0, 1, 2, 3, 4, 5, 6, 7, 8]],
+                       fmt="f %d/%d/%d %d/%d/%d %d/%d/%d")
+            base += 3 * n
+    return path
