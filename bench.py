@@ -274,7 +274,7 @@ def main():
                                                 shade=round(agg[4] / world / args.steps, 4),
                                                 raygen=round(agg[5] / world / args.steps, 4)))
         traffic_file = os.path.join(ROOT, "profiles", "trace_closest_hbm_traffic.json")
-        if world == 1 and os.path.exists(traffic_file):   # measured at the single-GPU launch size
+        if world == 1 and args.config == 2 and os.path.exists(traffic_file):   # measured on this workload, N = 1
             try:
                 roofline["traffic"] = json.load(open(traffic_file)).get("bytes_per_launch")
             except Exception:

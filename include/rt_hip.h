@@ -44,6 +44,13 @@ const char* rt_last_error(rt_ctx* ctx);
 int rt_ctx_device_info(rt_ctx* ctx, char* name, size_t name_len, int* compute_units, size_t* hbm_bytes);
 /* the hipStream_t of this context (for interop with other HIP libraries) */
 void* rt_ctx_stream(rt_ctx* ctx);
+/* context options, effective at the next rt_scene_upload */
+enum rt_ctx_option
+{
+    RT_CTX_OPT_TREELET_NODES = 0   /* BVH record layout: interior nodes per contiguous breadth-first cluster
+                                      (default 7; 1 = the reference's depth-first order).  Layout only. */
+};
+int rt_ctx_set_option(rt_ctx* ctx, int option, uint32_t value);
 
 /* ---- buffers: cl::Buffer(ctx, flags, size, host_ptr) (cl_pt_integrator.cpp:178-186)
  *      WriteBuffer / ReadBuffer / CopyBuffer (cl_context.cpp:96-113).
@@ -107,7 +114,8 @@ enum rt_option
     RT_OPT_TRACE_DROP_LAST_BOUNCE_RAYS = 5, /* 1 (default): do not emit the never-traced rays of the last bounce */
     RT_OPT_PROFILE_KERNELS = 6, /* 1: bracket every kernel launch with HIP events on the context stream */
     RT_OPT_TRACE_VARIANT = 7    /* traversal kernel: 0 = v1 per-ray loop; 1 .. 4 = one-fetch-per-iteration state
-                                   machine with a 16 / 24 / 12 (default, 3) / 8 entry LDS stack.  Results are identical. */
+                                   machine with a 16 / 24 / 12 / 8 entry LDS stack; 5 (default) = auto: 0 below
+                                   2 M paths per launch, 3 above.  Results are identical for every value. */
     , RT_OPT_TRACE_WAVES_PER_CU = 8 /* persistent-grid size of the trace kernels in waves per CU (0 = as many as fit) */
     , RT_OPT_SAMPLES_IN_FLIGHT = 9  /* rt_integrate traces this many consecutive samples per pixel concurrently
                                        (1..64; 0 = auto, the default: largest power of two <= 32 with tile pixels x

@@ -120,8 +120,14 @@ __global__ __launch_bounds__(256) void k_raygen(DTile tile, rt_camera cam, uint3
     if (i < 16) counters->head[i >> 3][i & 7] = 0;                       // the next trace launches start from 0
     if (i >= n_total) return;
 
-    uint32_t slot = i / n_local;
-    uint32_t lp = i - slot * n_local;                                    // local pixel of this tile
+    // queue order is PIXEL-major: the n_slots samples of a pixel sit next to each other, so
+    // a wave holds a few pixels x all their samples -- nearly identical primary rays, and
+    // secondary/shadow rays that start from the same small surface patch (shadow rays towards
+    // a directional light are then almost parallel AND co-located).  Fewer distinct BVH
+    // records per load instruction is what the L1 data path rewards.  The path id keeps the
+    // slot-major form (slot * n_local + pixel) the radiance log is laid out by.
+    uint32_t lp = i / n_slots;                                           // local pixel of this tile
+    uint32_t slot = i - lp * n_slots;
     uint32_t sample_idx = sample_base + slot;
     uint32_t ly = lp / tile.width;
     uint32_t pixel_x = lp - ly * tile.width;
@@ -163,7 +169,7 @@ __global__ __launch_bounds__(256) void k_raygen(DTile tile, rt_camera cam, uint3
     f3 d = normalize3(point_aimed - new_pos);
 
     o4[i] = make_float4(new_pos.x, new_pos.y, new_pos.z, RT_MAX_RENDER_DIST);
-    d4[i] = make_float4(d.x, d.y, d.z, __uint_as_float(i));              // path id = slot * n_local + local pixel
+    d4[i] = make_float4(d.x, d.y, d.z, __uint_as_float(slot * n_local + lp));   // path id
     iv4[i] = ray_inverse(d);
     thr[i] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
 }

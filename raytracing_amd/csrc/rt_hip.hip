@@ -30,6 +30,7 @@ struct rt_ctx
     hipDeviceProp_t prop;
     std::string error;
     Scene scene;
+    uint32_t treelet_nodes = 7;   // RT_CTX_OPT_TREELET_NODES
 };
 
 struct rt_buffer
@@ -60,7 +61,7 @@ struct rt_frame
     DCounters* counters;
     uint2* spill;
     uint32_t trace_blocks;       // v1 grid
-    uint32_t trace_variant = 3;  // RT_OPT_TRACE_VARIANT
+    uint32_t trace_variant = 5;  // RT_OPT_TRACE_VARIANT (5 = auto)
     uint32_t trace_waves_per_cu = 0;   // RT_OPT_TRACE_WAVES_PER_CU (0 = LDS-limited residency)
     // integrator state
     rt_camera camera;
@@ -173,6 +174,18 @@ int rt_ctx_device_info(rt_ctx* ctx, char* name, size_t name_len, int* compute_un
 
 void* rt_ctx_stream(rt_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 
+int rt_ctx_set_option(rt_ctx* ctx, int option, uint32_t value)
+{
+    if (!ctx) return fail(nullptr, "rt_ctx_set_option: ctx is NULL");
+    if (option == RT_CTX_OPT_TREELET_NODES)
+    {
+        if (value == 0 || value > 4096) return fail(ctx, "rt_ctx_set_option: treelet size must be 1..4096");
+        ctx->treelet_nodes = value;
+        return RT_OK;
+    }
+    return fail(ctx, "rt_ctx_set_option: unknown option");
+}
+
 // ---- buffers ---------------------------------------------------------------
 int rt_buffer_create(rt_ctx* ctx, size_t bytes, const void* init, rt_buffer** out)
 {
@@ -246,10 +259,41 @@ int rt_scene_upload(rt_ctx* ctx, const rt_scene_desc* sd)
     const uint32_t nt = sd->num_triangles, nn = sd->num_nodes;
 
     // --- BVH re-layout: LinearBVHNode[] (bvh.cpp:223-245) -> child-pair records
+    // Record order = cache-friendly "treelet" layout: a breadth-first cluster of up to
+    // RT_TREELET_NODES interior nodes is stored contiguously (7 records = 448 B, i.e. the
+    // next three levels below a node share a few cache lines), then the clusters hanging
+    // off it, depth first.  This is a pure permutation of records: traversal decisions and
+    // results do not depend on it.  (RT_TREELET_NODES = 1 gives the reference's DFS order.)
     std::vector<uint32_t> interior_index(nn, RT_EMPTY_REF);
     uint32_t n_interior = 0;
-    for (uint32_t i = 0; i < nn; ++i)
-        if ((sd->nodes[i].num_primitives_axis >> 16) == 0) interior_index[i] = n_interior++;
+    {
+        auto is_interior = [&](uint32_t i) { return (sd->nodes[i].num_primitives_axis >> 16) == 0; };
+        const uint32_t kTreelet = ctx->treelet_nodes ? ctx->treelet_nodes : 1u;
+        std::vector<uint32_t> roots, cluster, frontier;
+        if (is_interior(0)) roots.push_back(0);
+        while (!roots.empty())
+        {
+            uint32_t r = roots.back();
+            roots.pop_back();
+            cluster.clear();
+            frontier.clear();
+            cluster.push_back(r);
+            for (size_t head = 0; head < cluster.size(); ++head)       // BFS inside the treelet
+            {
+                uint32_t n = cluster[head];
+                uint32_t kids[2] = {n + 1, sd->nodes[n].offset};
+                for (uint32_t c : kids)
+                {
+                    if (c >= nn) return fail(ctx, "rt_scene_upload: child index outside the node array");
+                    if (!is_interior(c)) continue;
+                    if (cluster.size() < kTreelet) cluster.push_back(c);
+                    else frontier.push_back(c);
+                }
+            }
+            for (uint32_t n : cluster) interior_index[n] = n_interior++;
+            for (size_t k = frontier.size(); k-- > 0;) roots.push_back(frontier[k]);   // first child's cluster next
+        }
+    }
     std::vector<uint8_t> last_in_leaf(nt, 0);
     for (uint32_t i = 0; i < nn; ++i)
     {
@@ -581,7 +625,7 @@ int rt_set_option(rt_frame* f, int option, uint32_t value)
     case RT_OPT_PROFILE_KERNELS: f->profile = value ? 1 : 0; return RT_OK;
     case RT_OPT_TRACE_WAVES_PER_CU: f->trace_waves_per_cu = value; return RT_OK;
     case RT_OPT_TRACE_VARIANT:
-        if (value > 4) return fail(f->ctx, "rt_set_option: unknown trace kernel variant");
+        if (value > 5) return fail(f->ctx, "rt_set_option: unknown trace kernel variant");
         f->trace_variant = value;
         return RT_OK;
     default: return fail(f->ctx, "rt_set_option: unknown option");
@@ -651,7 +695,17 @@ template <bool SHADOW>
 void launch_trace(rt_frame* f, const float4* o4, const float4* d4, const float4* iv4, const uint32_t* count)
 {
     rt_ctx* ctx = f->ctx;
-    switch (f->trace_variant)
+    uint32_t variant = f->trace_variant;
+    if (variant == 5)
+    {
+        // auto: with few rays per launch (one or two samples of a 720p frame in flight, the
+        // interactive RenderFrame() case) every lane gets only ~3 rays and the per-ray loop of
+        // v1 wins (measured 770 vs 600 Mrays/s); from ~2 M paths up the state machine wins
+        // (profiles/r01_variants_3_samples_in_flight.log)
+        uint64_t paths = (uint64_t)f->n_local * (f->cur_slots ? f->cur_slots : 1u);
+        variant = paths >= 2000000ull ? 3u : 0u;
+    }
+    switch (variant)
     {
     case 0:
         hipLaunchKernelGGL(k_trace_v1<SHADOW>, dim3(f->trace_waves_per_cu ? (((uint32_t)ctx->prop.multiProcessorCount *
