@@ -114,6 +114,14 @@ int refh_load_hdr(const char* path, uint32_t* w, uint32_t* h)
     *w = g_img.width; *h = g_img.height;
     return 1;
 }
+// LoadSTB (image_loader.cpp:30-63): stb_image decode -> packed RGBA8
+int refh_load_stb(const char* path, uint32_t* w, uint32_t* h)
+{
+    g_img = Image();
+    if (!LoadSTB(path, g_img)) return 0;
+    *w = g_img.width; *h = g_img.height;
+    return 1;
+}
 const void* refh_loaded_image_data() { return g_img.data.data(); }
 
 } // extern "C"

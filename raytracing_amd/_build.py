@@ -52,13 +52,13 @@ def build_hip(force=False):
 
 def build_host(force=False):
     out = os.path.join(HERE, "librt_host.so")
-    cpps = [os.path.join(HOST, f) for f in ("bvh.cpp", "scene.cpp", "integrator.cpp", "hip_pt_integrator.cpp",
-                                            "render.cpp", "host_capi.cpp")]
+    cpps = [os.path.join(HOST, f) for f in ("bvh.cpp", "scene.cpp", "png_loader.cpp", "integrator.cpp",
+                                            "hip_pt_integrator.cpp", "render.cpp", "host_capi.cpp")]
     deps = cpps + [os.path.join(HOST, f) for f in os.listdir(HOST) if f.endswith(".hpp")]
     deps += [os.path.join(ROOT, "include", f) for f in ("rt_hip.h", "rt_types.h")]
     hip = os.path.join(HERE, "librt_hip.so")
     if force or _newer(out, deps + [hip]):
-        _run(["g++"] + CXX_FLAGS + ["-shared"] + INC + cpps + ["-o", out, "-L" + HERE, "-lrt_hip", "-Wl,-rpath,$ORIGIN"])
+        _run(["g++"] + CXX_FLAGS + ["-shared"] + INC + cpps + ["-o", out, "-L" + HERE, "-lrt_hip", "-lz", "-Wl,-rpath,$ORIGIN"])
     exe = os.path.join(HERE, "rt_render")
     main = os.path.join(HOST, "main.cpp")
     if force or _newer(exe, [main, out]):

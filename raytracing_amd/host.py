@@ -14,7 +14,7 @@ EXPORTS = [
     "rth_last_error", "rth_scene_load", "rth_scene_from_arrays", "rth_scene_destroy",
     "rth_scene_add_directional_light", "rth_scene_add_point_light", "rth_scene_set_env_path",
     "rth_scene_set_env_image", "rth_scene_finalize", "rth_bvh_build", "rth_bvh_destroy", "rth_bvh_num_nodes",
-    "rth_bvh_nodes", "rth_load_hdr", "rth_load_tga", "rth_loaded_image_data", "rth_default_camera",
+    "rth_bvh_nodes", "rth_load_hdr", "rth_load_tga", "rth_load_png", "rth_loaded_image_data", "rth_default_camera",
     "rth_make_camera", "rth_render_create", "rth_render_destroy", "rth_render_set_camera",
     "rth_render_set_max_bounces", "rth_render_enable_white_furnace", "rth_render_set_sampler",
     "rth_render_enable_denoiser", "rth_render_set_resolve_every_frame", "rth_render_frame", "rth_render_samples",
@@ -45,6 +45,7 @@ def load():
         "rth_bvh_nodes": (vp, [vp]),
         "rth_load_hdr": (i32, [cp, C.POINTER(u32), C.POINTER(u32)]),
         "rth_load_tga": (i32, [cp, C.POINTER(u32), C.POINTER(u32)]), "rth_loaded_image_data": (vp, []),
+        "rth_load_png": (i32, [cp, C.POINTER(u32), C.POINTER(u32)]),
         "rth_default_camera": (None, [u32, u32, vp]), "rth_make_camera": (None, [f32] * 9 + [vp]),
         "rth_render_create": (vp, [u32, u32, vp, i32, u32, u32, u32]), "rth_render_destroy": (None, [vp]),
         "rth_render_set_camera": (i32, [vp, vp]), "rth_render_set_max_bounces": (i32, [vp, u32]),
@@ -101,6 +102,14 @@ def load_tga(path):
     w, h = C.c_uint32(), C.c_uint32()
     if lib.rth_load_tga(path.encode(), C.byref(w), C.byref(h)):
         raise RtError("LoadTGA failed: " + path)
+    return _arr(lib.rth_loaded_image_data(), w.value * h.value, np.uint32).reshape(h.value, w.value)
+
+
+def load_png(path):
+    lib = load()
+    w, h = C.c_uint32(), C.c_uint32()
+    if lib.rth_load_png(path.encode(), C.byref(w), C.byref(h)):
+        raise RtError("LoadPNG failed: " + path)
     return _arr(lib.rth_loaded_image_data(), w.value * h.value, np.uint32).reshape(h.value, w.value)
 
 

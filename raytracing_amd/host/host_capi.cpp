@@ -108,6 +108,13 @@ int rth_load_tga(const char* path, uint32_t* w, uint32_t* h)
     *w = g_img.width; *h = g_img.height;
     return 0;
 }
+int rth_load_png(const char* path, uint32_t* w, uint32_t* h)
+{
+    g_img = rt::Image();
+    if (!rt::LoadPNG(path, g_img)) return 1;
+    *w = g_img.width; *h = g_img.height;
+    return 0;
+}
 const void* rth_loaded_image_data() { return g_img.data.data(); }
 void rth_default_camera(uint32_t w, uint32_t h, rt_camera* out) { *out = rt::DefaultCamera(w, h); }
 void rth_make_camera(float px, float py, float pz, float yaw, float pitch, float fov, float aspect, float aperture,

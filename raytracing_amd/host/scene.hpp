@@ -10,7 +10,8 @@
 namespace rt
 {
 bool LoadHDR(const char* filename, Image& result);   // Radiance RGBE (reference: src/loaders/hdr_loader.cpp:29-100)
-bool LoadTGA(const char* filename, Image& result);   // 8-bit TGA -> packed RGBA8 (reference path: LoadSTB, image_loader.cpp:30-63)
+bool LoadTGA(const char* filename, Image& result);
+bool LoadPNG(const char* filename, Image& result);   // png_loader.cpp   // 8-bit TGA -> packed RGBA8 (reference path: LoadSTB, image_loader.cpp:30-63)
 
 class Scene
 {

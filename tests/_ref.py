@@ -31,6 +31,7 @@ def load(libm=False):
         "refh_scene_info": (None, [vp, vp]),
         "refh_bvh_build": (u32, [vp, u32]), "refh_bvh_nodes": (None, [vp]),
         "refh_load_hdr": (C.c_int, [cp, C.POINTER(u32), C.POINTER(u32)]), "refh_loaded_image_data": (vp, []),
+        "refh_load_stb": (C.c_int, [cp, C.POINTER(u32), C.POINTER(u32)]),
         "ref_create": (vp, [u32, u32, C.c_int, C.c_int]), "ref_destroy": (None, [vp]),
         "ref_upload": (None, [vp, vp, u32, vp, u32, vp, u32, vp, u32, vp, u32, vp, u32, vp, u32, vp, u32, u32]),
         "ref_set_camera": (None, [vp, vp]), "ref_set_max_bounces": (None, [vp, u32]),
@@ -110,6 +111,15 @@ def load_hdr(path, libm=False):
     if not lib.refh_load_hdr(path.encode(), C.byref(w), C.byref(h)):
         raise RuntimeError("LoadHDR failed")
     return _arr(lib.refh_loaded_image_data(), w.value * h.value * 4, np.float32).reshape(h.value, w.value, 4)
+
+
+def load_stb(path, libm=False):
+    """The reference's LoadSTB (stb_image) -> packed RGBA8 texels."""
+    lib = load(libm)
+    w, h = C.c_uint32(), C.c_uint32()
+    if not lib.refh_load_stb(path.encode(), C.byref(w), C.byref(h)):
+        raise RuntimeError("LoadSTB failed")
+    return _arr(lib.refh_loaded_image_data(), w.value * h.value, np.uint32).reshape(h.value, w.value)
 
 
 class RefIntegrator:

@@ -195,3 +195,129 @@ class TestAgainstReferenceHost:
     def test_hdr_loader_identical_to_reference(self, env_map):
         ref = _ref.load_hdr(os.path.join(ROOT, "assets", "ibl", "CGSkies_0036_free.hdr"))
         assert np.array_equal(ref.view(np.uint32), env_map.view(np.uint32))
+
+
+# ---------------------------------------------------------------------------
+# PNG textures (png_loader.cpp) -- what LoadSTB/stb_image would hand to the path
+# ---------------------------------------------------------------------------
+def _write_png(path, pixels, color, depth=8, palette=None, trns=None, filters=None):
+    """Minimal PNG writer for tests: pixels = uint array [h, w, samples]."""
+    import struct
+    import zlib
+    h, w, s = pixels.shape
+    def chunk(tag, data):
+        c = struct.pack(">I", len(data)) + tag + data
+        return c + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
+    rows = []
+    prev = None
+    for y in range(h):
+        if depth == 8:
+            raw = pixels[y].astype(np.uint8).tobytes()
+        elif depth == 16:
+            raw = pixels[y].astype(">u2").tobytes()
+        else:
+            bits = "".join(format(int(v), "0%db" % depth) for v in pixels[y].ravel())
+            bits += "0" * (-len(bits) % 8)
+            raw = bytes(int(bits[i:i + 8], 2) for i in range(0, len(bits), 8))
+        raw = np.frombuffer(raw, np.uint8).astype(np.int32)
+        ft = filters[y % len(filters)] if filters else 0
+        bpp = max(1, s * depth // 8)
+        a = np.concatenate([np.zeros(bpp, np.int32), raw[:-bpp]]) if len(raw) > bpp else np.zeros_like(raw)
+        b = prev if prev is not None else np.zeros_like(raw)
+        c = np.concatenate([np.zeros(bpp, np.int32), b[:-bpp]]) if len(raw) > bpp else np.zeros_like(raw)
+        if ft == 0: enc = raw
+        elif ft == 1: enc = raw - a
+        elif ft == 2: enc = raw - b
+        elif ft == 3: enc = raw - ((a + b) >> 1)
+        else:
+            p = a + b - c
+            pa, pb, pc = np.abs(p - a), np.abs(p - b), np.abs(p - c)
+            pred = np.where((pa <= pb) & (pa <= pc), a, np.where(pb <= pc, b, c))
+            enc = raw - pred
+        rows.append(bytes([ft]) + (enc & 0xFF).astype(np.uint8).tobytes())
+        prev = raw
+    data = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, color, 0, 0, 0))
+    if palette is not None:
+        data += chunk(b"PLTE", bytes(palette))
+    if trns is not None:
+        data += chunk(b"tRNS", bytes(trns))
+    comp = zlib.compress(b"".join(rows))
+    data += chunk(b"IDAT", comp[: len(comp) // 2]) + chunk(b"IDAT", comp[len(comp) // 2:]) + chunk(b"IEND", b"")
+    open(path, "wb").write(data)
+
+
+def _png_cases(rng):
+    return [
+        ("rgb8", rng.randint(0, 256, (5, 7, 3)), 2, 8, None, None),
+        ("rgba8", rng.randint(0, 256, (4, 6, 4)), 6, 8, None, None),
+        ("grey8", rng.randint(0, 256, (6, 5, 1)), 0, 8, None, None),
+        ("greya8", rng.randint(0, 256, (3, 9, 2)), 4, 8, None, None),
+        ("rgb16", rng.randint(0, 65536, (4, 5, 3)), 2, 16, None, None),
+        ("pal8", rng.randint(0, 4, (5, 5, 1)), 3, 8, [255, 0, 0, 0, 255, 0, 0, 0, 255, 9, 8, 7], None),
+        ("pal4t", rng.randint(0, 4, (5, 6, 1)), 3, 4, [255, 0, 0, 0, 255, 0, 0, 0, 255, 9, 8, 7], [0, 128]),
+        ("grey2", rng.randint(0, 4, (4, 7, 1)), 0, 2, None, None),
+        ("rgb8key", np.tile(np.array([[[1, 2, 3], [9, 9, 9]]]), (3, 2, 1)), 2, 8, None, [0, 1, 0, 2, 0, 3]),
+    ]
+
+
+def test_png_loader_expected_texels(tmp_path):
+    rng = np.random.RandomState(5)
+    for name, px, color, depth, pal, trns in _png_cases(rng):
+        p = str(tmp_path / (name + ".png"))
+        _write_png(p, px, color, depth, pal, trns, filters=[0, 1, 2, 3, 4])
+        got = host.load_png(p)
+        h, w, s = px.shape
+        v = px.astype(np.uint32)
+        if depth == 16:
+            v = v >> 8
+        elif depth < 8 and color == 0:
+            v = v * {1: 255, 2: 85, 4: 17}[depth]
+        if color == 3:
+            palarr = np.array(pal, np.uint32).reshape(-1, 3)
+            ch = [palarr[px[..., 0], k] for k in range(3)]
+            if trns is not None:
+                ta = np.array(list(trns) + [255] * (len(palarr) - len(trns)), np.uint32)
+                ch.append(ta[px[..., 0]])
+        else:
+            ch = [v[..., k] for k in range(s)]
+            if trns is not None:
+                key = np.array([(trns[2 * k] << 8) | trns[2 * k + 1] for k in range(s)])
+                ch.append(np.where((px == key).all(-1), 0, 255).astype(np.uint32))
+        want = np.zeros((h, w), np.uint32)
+        for k, c in enumerate(ch[:4]):
+            want |= c.astype(np.uint32) << (8 * k)
+        assert np.array_equal(got, want), name
+    with pytest.raises(host.RtError):
+        host.load_png(str(tmp_path / "missing.png"))
+
+
+def test_scene_loads_png_and_tga_textures_and_rejects_jpg(tmp_path):
+    rng = np.random.RandomState(6)
+    _write_png(str(tmp_path / "kd.png"), rng.randint(0, 256, (8, 8, 3)), 2, filters=[4])
+    (tmp_path / "t.obj").write_text("mtllib t.mtl\nv 0 0 0\nv 1 0 0\nv 0 1 0\nvn 0 0 1\nvt 0 0\nvt 1 0\nvt 0 1\n"
+                                    "usemtl m\nf 1/1/1 2/2/1 3/3/1\n")
+    (tmp_path / "t.mtl").write_text("newmtl m\nKd 1 1 1\nTf 1 1 1\nmap_Kd kd.png\nmap_Pr -bm 1 kd.png\n")
+    a = host.Scene(str(tmp_path / "t.obj")).arrays()
+    assert len(a["textures"]) == 1 and int(a["textures"][0]["width"]) == 8      # cached: one texture, two uses
+    assert len(a["texture_data"]) == 64
+    m = a["materials"][0]
+    assert (int(m["diffuse_albedo"]) >> 24) == 0 and ((int(m["roughness_metalness"]) >> 8) & 0xFF) == 0
+    (tmp_path / "j.mtl").write_text("newmtl m\nKd 1 1 1\nmap_Kd photo.jpg\n")
+    (tmp_path / "j.obj").write_text("mtllib j.mtl\nv 0 0 0\nv 1 0 0\nv 0 1 0\nvn 0 0 1\nusemtl m\nf 1//1 2//1 3//1\n")
+    with pytest.raises(host.RtError, match="JPEG"):
+        host.Scene(str(tmp_path / "j.obj"))
+
+
+@pytest.mark.skipif(not _ref.available(), reason="oracle/_ref/libref.so not built")
+def test_png_and_tga_texels_identical_to_stb_image(tmp_path):
+    """The reference decodes with stb_image (LoadSTB); same files, same texels."""
+    rng = np.random.RandomState(7)
+    for name, px, color, depth, pal, trns in _png_cases(rng):
+        p = str(tmp_path / (name + ".png"))
+        _write_png(p, px, color, depth, pal, trns, filters=[4, 3, 2, 1, 0])
+        assert np.array_equal(host.load_png(p), _ref.load_stb(p)), name
+    w, h = 6, 4
+    rgb = rng.randint(0, 256, size=(h, w, 4)).astype(np.uint8)
+    hdr = bytes([0, 0, 2, 0, 0, 0, 0, 0, 0, 0, 0, 0, w, 0, h, 0, 32, 8])
+    (tmp_path / "a.tga").write_bytes(hdr + rgb[::-1, :, [2, 1, 0, 3]].tobytes())
+    assert np.array_equal(host.load_tga(str(tmp_path / "a.tga")), _ref.load_stb(str(tmp_path / "a.tga")))
