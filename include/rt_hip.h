@@ -51,6 +51,11 @@ enum rt_ctx_option
                                       (default 7; 1 = the reference's depth-first order).  Layout only. */
 };
 int rt_ctx_set_option(rt_ctx* ctx, int option, uint32_t value);
+/* The blue-noise sampler tables (src/utils/blue_noise_sampler.hpp: sobol_256spp_256d[256*256],
+ * scramblingTile[128*128*8], rankingTile[128*128*8], values 0..255) that CLPathTraceIntegrator
+ * uploads in its ctor (cl_pt_integrator.cpp:222-235).  Required before RT_OPT_SAMPLER = 1. */
+int rt_upload_blue_noise_tables(rt_ctx* ctx, const int* sobol_256spp_256d, const int* scramblingTile,
+    const int* rankingTile);
 
 /* ---- buffers: cl::Buffer(ctx, flags, size, host_ptr) (cl_pt_integrator.cpp:178-186)
  *      WriteBuffer / ReadBuffer / CopyBuffer (cl_context.cpp:96-113).
@@ -107,7 +112,7 @@ enum rt_option
 {
     RT_OPT_MAX_BOUNCES = 0,    /* Integrator::SetMaxBounces, default 3 (integrator.hpp:91) */
     RT_OPT_WHITE_FURNACE = 1,  /* Integrator::EnableWhiteFurnace (-D ENABLE_WHITE_FURNACE) */
-    RT_OPT_SAMPLER = 2,        /* Integrator::SetSamplerType: 0 = kRandom (only one implemented) */
+    RT_OPT_SAMPLER = 2,        /* Integrator::SetSamplerType: 0 = kRandom, 1 = kBlueNoise (-D BLUE_NOISE_SAMPLER) */
     RT_OPT_AOV = 3,            /* Integrator::SetAOV: 0 shaded colour, 1 diffuse albedo, 2 depth, 3 normal, 4 motion vectors
                                   (resolve_radiance.cl:25-29); non-zero needs tile_count == 1 */
     RT_OPT_DENOISER = 4,       /* Integrator::EnableDenoiser: temporal reprojection (denoiser.cl); needs tile_count == 1 */

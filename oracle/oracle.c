@@ -70,6 +70,7 @@ typedef struct orc
     rt_camera prev_camera;       /* Integrator::prev_camera_ */
     rt_camera aov_prev_camera;   /* kPrevCamera bound by the last SetCameraData (cl_pt_integrator.cpp:365-371) */
     int denoiser;
+    int blue_noise;              /* Integrator::sampler_type_ == kBlueNoise */
     uint32_t aov;
     rt_scene_info scene_info;
     rt_float3* diffuse_albedo; float* depth; rt_float3* normal; rt_float2* velocity;
@@ -130,10 +131,29 @@ static float GetRandomFloat(uint32_t* seed)
     return (float)s * 2.3283064365386963e-10f;
 }
 
-/* sampling.h:64-82 (kRandom branch) */
+/* SampleBlueNoise, sampling.h:40-61.  bn = sobol_256spp_256d[65536] | scramblingTile[131072] |
+   rankingTile[131072 + 256 zero padding]: the reference indexes rankingTile with the un-wrapped
+   dimension (:50), which runs past the table for the last pixels; the padding reads as 0. */
+static const int* g_bn_sobol; static const int* g_bn_scramble; static const int* g_bn_rank;
+static float SampleBlueNoise(int pixel_i, int pixel_j, int sampleIndex, int sampleDimension)
+{
+    pixel_i = pixel_i & 127;
+    pixel_j = pixel_j & 127;
+    sampleIndex = sampleIndex & 255;
+    sampleDimension = sampleDimension & 255;
+    int rankedSampleIndex = sampleIndex ^ g_bn_rank[sampleDimension + (pixel_i + pixel_j * 128) * 8];
+    int value = g_bn_sobol[sampleDimension + rankedSampleIndex * 256];
+    value = value ^ g_bn_scramble[(sampleDimension % 8) + (pixel_i + pixel_j * 128) * 8];
+    float v = (0.5f + value) / 256.0f;
+    return v;
+}
+
+/* sampling.h:64-82 */
+static int g_blue_noise;
 static float SampleRandom(uint32_t px, uint32_t py, uint32_t sample_index, uint32_t bounce, uint32_t type)
 {
     uint32_t dim = bounce * 5u + type;
+    if (g_blue_noise) return SampleBlueNoise((int)px, (int)py, (int)sample_index, (int)dim);
     uint32_t seed = WangHash(px);
     seed = WangHash(seed + WangHash(py));
     seed = WangHash(seed + WangHash(sample_index));
@@ -894,6 +914,24 @@ ORC_EXPORT void orc_enable_denoiser(void* h, int enable)                /* :485-
     o->denoiser = enable != 0;
     o->request_reset = 1;
 }
+/* Integrator::SetSamplerType (cl_pt_integrator.cpp:458-468).  Process-wide in this oracle. */
+static int* g_bn_storage;
+ORC_EXPORT void orc_set_blue_noise_tables(const int* sobol, const int* scrambling, const int* ranking)
+{
+    free(g_bn_storage);
+    g_bn_storage = (int*)calloc(65536 + 131072 + 131072 + 256, sizeof(int));
+    memcpy(g_bn_storage, sobol, 65536 * sizeof(int));
+    memcpy(g_bn_storage + 65536, scrambling, 131072 * sizeof(int));
+    memcpy(g_bn_storage + 65536 + 131072, ranking, 131072 * sizeof(int));
+    g_bn_sobol = g_bn_storage; g_bn_scramble = g_bn_storage + 65536; g_bn_rank = g_bn_storage + 65536 + 131072;
+}
+ORC_EXPORT void orc_set_sampler(void* h, int blue_noise)
+{
+    orc* o = (orc*)h;
+    if ((blue_noise != 0) == (o->blue_noise != 0)) return;
+    o->blue_noise = blue_noise != 0;
+    o->request_reset = 1;
+}
 ORC_EXPORT void orc_set_aov(void* h, uint32_t aov)                      /* :470-483 */
 {
     orc* o = (orc*)h;
@@ -938,6 +976,7 @@ ORC_EXPORT void orc_stage_clear_counters(void* h, uint32_t bounce)
 ORC_EXPORT void orc_stage_shade_hits(void* h, uint32_t bounce)
 {
     orc* o = (orc*)h;
+    g_blue_noise = o->blue_noise;   /* kernel variant -D BLUE_NOISE_SAMPLER (cl_pt_integrator.cpp:273-276) */
     uint32_t n = o->width * o->height;
     for (uint32_t i = 0; i < n; ++i) HitSurface(o, bounce, i);
 }

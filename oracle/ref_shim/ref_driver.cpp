@@ -53,6 +53,8 @@ void MissFurnace(rt_ray*, uint*, rt_hit*, uint*, float3*, ShimImage*, float3*);
     float3*, float4*
 void HitSurface(HIT_SURFACE_ARGS);
 void HitSurfaceFurnace(HIT_SURFACE_ARGS);
+void HitSurfaceBlue(HIT_SURFACE_ARGS);
+void HitSurfaceFurnaceBlue(HIT_SURFACE_ARGS);
 void AccumulateDirectSamples(uint*, uint*, uint*, float3*, float4*);
 void ResolveRadiance(uint, uint, uint, float4*, float3*, float*, float3*, float2*, uint*, ShimImage*);
 void ResolveRadianceDenoiser(uint, uint, uint, float4*, float3*, float*, float3*, float2*, uint*, ShimImage*);
@@ -77,6 +79,8 @@ struct RefIntegrator
     CamCL prev_camera = {};        // Integrator::prev_camera_ (integrator.hpp:89)
     CamCL aov_prev_camera = {};    // the kPrevCamera argument bound by the last SetCameraData
     int denoiser = 0;
+    int blue_noise = 0;
+    std::vector<int> bn_sobol, bn_scramble, bn_rank;   // rank padded with 256 zeros (sampling.h:50 overrun)
     uint aov = 0;
     SceneInfoCL scene_info = {};
     std::vector<rt_float4> prev_radiance;
@@ -258,13 +262,14 @@ void ShadeMissedRays(RefIntegrator& r, uint bounce) // :582-592
 void ShadeSurfaceHits(RefIntegrator& r, uint bounce) // :594-643
 {
     uint in = bounce & 1, out = (bounce + 1) & 1;
-    auto fn = r.furnace ? HitSurfaceFurnace : HitSurface;
+    auto fn = r.blue_noise ? (r.furnace ? HitSurfaceFurnaceBlue : HitSurfaceBlue)
+                           : (r.furnace ? HitSurfaceFurnace : HitSurface);
     NDRange(r, r.width * r.height, [&]()
     {
         fn(r.rays[in].data(), &r.rc(in), r.pixel_indices[in].data(), r.hits.data(),
             r.triangles.data(), r.lights.data(), r.emissive.data(), r.materials.data(),
             r.textures.data(), r.texture_data.data(), bounce, r.width, r.height, &r.sample_counter,
-            r.scene_info, nullptr, nullptr, nullptr, (float3*)r.throughputs.data(),
+            r.scene_info, r.bn_sobol.data(), r.bn_scramble.data(), r.bn_rank.data(), (float3*)r.throughputs.data(),
             r.rays[out].data(), &r.rc(out), r.pixel_indices[out].data(),
             r.shadow_rays.data(), &r.shadow_ray_counter, r.shadow_pixel_indices.data(),
             (float3*)r.direct_light_samples.data(), (float4*)r.radiance.data());
@@ -376,6 +381,23 @@ void ref_enable_denoiser(void* h, int enable)      // :485-495
     auto& r = *(RefIntegrator*)h;
     if ((enable != 0) == (r.denoiser != 0)) return;
     r.denoiser = enable != 0;
+    r.request_reset = true;
+}
+
+void ref_set_blue_noise_tables(void* h, const int* sobol, const int* scrambling, const int* ranking)   // :222-235
+{
+    auto& r = *(RefIntegrator*)h;
+    r.bn_sobol.assign(sobol, sobol + 65536);
+    r.bn_scramble.assign(scrambling, scrambling + 131072);
+    r.bn_rank.assign(ranking, ranking + 131072);
+    r.bn_rank.resize(131072 + 256, 0);
+}
+
+void ref_set_sampler(void* h, int blue_noise)      // SetSamplerType, :458-468
+{
+    auto& r = *(RefIntegrator*)h;
+    if ((blue_noise != 0) == (r.blue_noise != 0)) return;
+    r.blue_noise = blue_noise != 0;
     r.request_reset = true;
 }
 

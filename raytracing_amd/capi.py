@@ -46,7 +46,7 @@ class rt_frame_desc(C.Structure):
 
 EXPORTS = [
     "rt_ctx_create", "rt_ctx_destroy", "rt_finish", "rt_last_error", "rt_ctx_device_info", "rt_ctx_stream",
-    "rt_ctx_set_option",
+    "rt_ctx_set_option", "rt_upload_blue_noise_tables",
     "rt_buffer_create", "rt_buffer_destroy", "rt_buffer_write", "rt_buffer_read", "rt_buffer_copy",
     "rt_buffer_device_ptr", "rt_buffer_size", "rt_scene_upload", "rt_frame_create", "rt_frame_destroy",
     "rt_frame_local_rows", "rt_frame_global_row", "rt_set_option", "rt_set_camera", "rt_reset",
@@ -73,6 +73,7 @@ def load():
         "rt_last_error": (C.c_char_p, [vp]),
         "rt_ctx_device_info": (i32, [vp, C.c_char_p, sz, C.POINTER(i32), C.POINTER(sz)]),
         "rt_ctx_stream": (vp, [vp]), "rt_ctx_set_option": (i32, [vp, i32, u32]),
+        "rt_upload_blue_noise_tables": (i32, [vp, vp, vp, vp]),
         "rt_buffer_create": (i32, [vp, sz, vp, C.POINTER(vp)]), "rt_buffer_destroy": (i32, [vp]),
         "rt_buffer_write": (i32, [vp, sz, vp, sz]), "rt_buffer_read": (i32, [vp, sz, vp, sz]),
         "rt_buffer_copy": (i32, [vp, vp, sz, sz, sz]), "rt_buffer_device_ptr": (vp, [vp]),
@@ -128,6 +129,10 @@ class Context:
 
     def stream(self):
         return self.lib.rt_ctx_stream(self.handle)
+
+    def upload_blue_noise_tables(self, sobol, scrambling, ranking):
+        t = [np.ascontiguousarray(x, np.int32) for x in (sobol, scrambling, ranking)]
+        _check(self.lib, self.handle, self.lib.rt_upload_blue_noise_tables(self.handle, *[x.ctypes.data for x in t]))
 
     def set_treelet_nodes(self, n):
         _check(self.lib, self.handle, self.lib.rt_ctx_set_option(self.handle, 0, n))

@@ -861,11 +861,28 @@ struct ShadeArgs
     float4* out_o4; float4* out_d4; float4* out_iv4; float4* out_thr;
     float4* sh_o4; float4* sh_d4; float4* sh_iv4;
     float4* rlog; uint32_t* cnt;      // radiance log (see file header)
+    const uint8_t* bn_sobol; const uint8_t* bn_scramble; const uint8_t* bn_rank;   // SamplerType::kBlueNoise tables
     DCounters* counters;
     uint32_t bounce, sample_base, emit_outgoing, n_local, log_stride;
 };
 
-template <bool FURNACE>
+// SampleBlueNoise, sampling.h:40-61 (Heitz et al. 2019 tables, values 0..255).  The reference
+// indexes rankingTile with the un-wrapped dimension (sampling.h:50, no `% 8`), which runs past
+// the end of the table for the last pixels of a tile row; entries past the end read as 0 here
+// (oracle and reference-kernel build pad the table the same way).
+RT_DEV float SampleBlueNoise(const ShadeArgs& a, uint32_t px, uint32_t py, uint32_t sample_index, uint32_t dim)
+{
+    int pixel_i = (int)px & 127, pixel_j = (int)py & 127;
+    int sampleIndex = (int)sample_index & 255, sampleDimension = (int)dim & 255;
+    int ridx = sampleDimension + (pixel_i + pixel_j * 128) * 8;
+    int rank = ridx < 128 * 128 * 8 ? (int)a.bn_rank[ridx] : 0;
+    int rankedSampleIndex = sampleIndex ^ rank;
+    int value = (int)a.bn_sobol[sampleDimension + rankedSampleIndex * 256];
+    value = value ^ (int)a.bn_scramble[(sampleDimension % 8) + (pixel_i + pixel_j * 128) * 8];
+    return (0.5f + (float)value) / 256.0f;
+}
+
+template <bool FURNACE, bool BLUE>
 __global__ __launch_bounds__(RT_SHADE_BLOCK) void k_shade(DScene sc, DTile tile, ShadeArgs a)
 {
     const uint32_t count = a.counters->queue[a.bounce];
@@ -935,11 +952,17 @@ __global__ __launch_bounds__(RT_SHADE_BLOCK) void k_shade(DScene sc, DTile tile,
                 }
             }
 
-            uint32_t sample_seed = SampleRandomSampleSeed(SampleRandomPixelSeed(px, py), sample_idx);
+            uint32_t sample_seed = BLUE ? 0u : SampleRandomSampleSeed(SampleRandomPixelSeed(px, py), sample_idx);
+            // SampleRandom(x, y, sample, bounce, type), sampling.h:64-82
+            auto draw = [&](uint32_t type) -> float
+            {
+                return BLUE ? SampleBlueNoise(a, px, py, sample_idx, a.bounce * 5u + type)
+                            : SampleRandomDim(sample_seed, a.bounce, type);
+            };
 
             // Direct lighting :115-145 (Light_Sample light.h:30-65)
             {
-                float s_light = SampleRandomDim(sample_seed, a.bounce, 4);
+                float s_light = draw(4);
                 int light_idx = cl_clampi((int)(s_light * (float)sc.light_count), 0, (int)sc.light_count - 1);
                 float4 lo = sc.lights[light_idx * 3 + 0], lr = sc.lights[light_idx * 3 + 1];
                 uint32_t ltype = __float_as_uint(sc.lights[light_idx * 3 + 2].x);
@@ -978,9 +1001,9 @@ __global__ __launch_bounds__(RT_SHADE_BLOCK) void k_shade(DScene sc, DTile tile,
             // Indirect lighting :148-184
             {
                 f2 s;
-                s.x = SampleRandomDim(sample_seed, a.bounce, 2);
-                s.y = SampleRandomDim(sample_seed, a.bounce, 3);
-                float s1 = SampleRandomDim(sample_seed, a.bounce, 1);
+                s.x = draw(2);
+                s.y = draw(3);
+                float s1 = draw(1);
                 float pdf = 0.0f;
                 f3 outgoing;
                 float offset;

@@ -31,6 +31,7 @@ struct rt_ctx
     std::string error;
     Scene scene;
     uint32_t treelet_nodes = 7;   // RT_CTX_OPT_TREELET_NODES
+    uint8_t* blue_noise = nullptr;   // sobol[65536] | scramblingTile[131072] | rankingTile[131072]
 };
 
 struct rt_buffer
@@ -67,6 +68,7 @@ struct rt_frame
     rt_camera camera;
     rt_camera camera_last;        // Integrator::prev_camera_ (integrator.hpp:89)
     rt_camera prev_camera;        // the kPrevCamera argument bound by the last rt_set_camera
+    uint32_t sampler = 0;         // RT_OPT_SAMPLER: 0 kRandom, 1 kBlueNoise
     uint32_t aov = 0;             // RT_OPT_AOV
     uint32_t denoiser = 0;        // RT_OPT_DENOISER
     DAov aov_buf = {nullptr, nullptr, nullptr, nullptr};
@@ -151,6 +153,7 @@ int rt_ctx_destroy(rt_ctx* ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     free_scene(ctx->scene);
+    if (ctx->blue_noise) (void)hipFree(ctx->blue_noise);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return RT_OK;
@@ -173,6 +176,27 @@ int rt_ctx_device_info(rt_ctx* ctx, char* name, size_t name_len, int* compute_un
 }
 
 void* rt_ctx_stream(rt_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+// The sampler tables CLPathTraceIntegrator uploads in its ctor (cl_pt_integrator.cpp:222-235)
+int rt_upload_blue_noise_tables(rt_ctx* ctx, const int* sobol_256spp_256d, const int* scramblingTile, const int* rankingTile)
+{
+    if (!ctx || !sobol_256spp_256d || !scramblingTile || !rankingTile)
+        return fail(ctx, "rt_upload_blue_noise_tables: NULL argument");
+    (void)hipSetDevice(ctx->device);
+    std::vector<uint8_t> packed(65536 + 131072 + 131072);
+    const int* src[3] = {sobol_256spp_256d, scramblingTile, rankingTile};
+    const size_t n[3] = {65536, 131072, 131072};
+    size_t o = 0;
+    for (int t = 0; t < 3; ++t)
+        for (size_t i = 0; i < n[t]; ++i)
+        {
+            if (src[t][i] < 0 || src[t][i] > 255) return fail(ctx, "rt_upload_blue_noise_tables: table value outside 0..255");
+            packed[o++] = (uint8_t)src[t][i];
+        }
+    if (!ctx->blue_noise) HIPCHK(ctx, hipMalloc((void**)&ctx->blue_noise, packed.size()));
+    HIPCHK(ctx, hipMemcpy(ctx->blue_noise, packed.data(), packed.size(), hipMemcpyHostToDevice));
+    return RT_OK;
+}
 
 int rt_ctx_set_option(rt_ctx* ctx, int option, uint32_t value)
 {
@@ -608,7 +632,10 @@ int rt_set_option(rt_frame* f, int option, uint32_t value)
         return RT_OK;
     case RT_OPT_WHITE_FURNACE: f->white_furnace = value ? 1 : 0; return RT_OK;
     case RT_OPT_SAMPLER:
-        if (value != 0) return fail(f->ctx, "rt_set_option: only SamplerType::kRandom is implemented");
+        if (value > 1) return fail(f->ctx, "rt_set_option: sampler must be 0 (kRandom) or 1 (kBlueNoise)");
+        if (value == 1 && !f->ctx->blue_noise)
+            return fail(f->ctx, "rt_set_option: SamplerType::kBlueNoise needs rt_upload_blue_noise_tables first");
+        f->sampler = value;
         return RT_OK;
     case RT_OPT_AOV:
         if (value > 4) return fail(f->ctx, "rt_set_option: AOV index must be 0..4");
@@ -795,6 +822,8 @@ int rt_shade(rt_frame* f, uint32_t bounce)              // ShadeMissedRays + Sha
     a.out_o4 = f->o4[out]; a.out_d4 = f->d4[out]; a.out_iv4 = f->iv4[out]; a.out_thr = f->thr[out];
     a.sh_o4 = f->sh_o4; a.sh_d4 = f->sh_d4; a.sh_iv4 = f->sh_iv4;
     a.rlog = f->rlog; a.cnt = f->cnt; a.counters = f->counters;
+    a.bn_sobol = ctx->blue_noise; a.bn_scramble = ctx->blue_noise ? ctx->blue_noise + 65536 : nullptr;
+    a.bn_rank = ctx->blue_noise ? ctx->blue_noise + 65536 + 131072 : nullptr;
     a.bounce = bounce; a.sample_base = f->sample_count;
     a.emit_outgoing = (f->drop_last && bounce >= f->max_bounces) ? 0u : 1u;
     a.n_local = f->n_local ? f->n_local : 1; a.log_stride = f->log_stride;
@@ -803,10 +832,15 @@ int rt_shade(rt_frame* f, uint32_t bounce)              // ShadeMissedRays + Sha
     if (blocks == 0) blocks = 1;
     f->shadow_pending = true;
     KernelSpan span(f, 2);
-    if (f->white_furnace)
-        hipLaunchKernelGGL(k_shade<true>, dim3(blocks), dim3(RT_SHADE_BLOCK), 0, ctx->stream, ctx->scene.d, f->tile, a);
+    const bool blue = f->sampler == 1;   // kernel variants are AOT (the reference rebuilds with -D..., :267-285)
+    if (f->white_furnace && blue)
+        hipLaunchKernelGGL((k_shade<true, true>), dim3(blocks), dim3(RT_SHADE_BLOCK), 0, ctx->stream, ctx->scene.d, f->tile, a);
+    else if (f->white_furnace)
+        hipLaunchKernelGGL((k_shade<true, false>), dim3(blocks), dim3(RT_SHADE_BLOCK), 0, ctx->stream, ctx->scene.d, f->tile, a);
+    else if (blue)
+        hipLaunchKernelGGL((k_shade<false, true>), dim3(blocks), dim3(RT_SHADE_BLOCK), 0, ctx->stream, ctx->scene.d, f->tile, a);
     else
-        hipLaunchKernelGGL(k_shade<false>, dim3(blocks), dim3(RT_SHADE_BLOCK), 0, ctx->stream, ctx->scene.d, f->tile, a);
+        hipLaunchKernelGGL((k_shade<false, false>), dim3(blocks), dim3(RT_SHADE_BLOCK), 0, ctx->stream, ctx->scene.d, f->tile, a);
     HIPCHK(ctx, hipGetLastError());
     return RT_OK;
 }

@@ -21,6 +21,7 @@ EXPORTS = [
     "rth_render_finish", "rth_render_local_rows", "rth_render_global_row", "rth_render_sample_count",
     "rth_render_read_radiance", "rth_render_read_resolved", "rth_render_stats", "rth_render_frame_handle",
     "rth_render_ctx_handle", "rth_render_num_nodes", "rth_render_nodes", "rth_render_set_aov", "rth_render_resolve",
+    "rth_render_set_blue_noise_path",
 ]
 
 
@@ -58,6 +59,7 @@ def load():
         "rth_render_frame_handle": (vp, [vp]), "rth_render_ctx_handle": (vp, [vp]),
         "rth_render_num_nodes": (u32, [vp]), "rth_render_nodes": (vp, [vp]),
         "rth_render_set_aov": (i32, [vp, i32]), "rth_render_resolve": (i32, [vp, vp]),
+        "rth_render_set_blue_noise_path": (i32, [vp, cp]),
     }
     for name in ("triangles", "materials", "textures", "texture_data", "lights", "emissive"):
         sig["rth_scene_num_" + name] = (u32, [vp])
@@ -208,7 +210,10 @@ class Render:
 
     def set_max_bounces(self, b): self._c(self.lib.rth_render_set_max_bounces(self.handle, b))
     def enable_white_furnace(self, e): self._c(self.lib.rth_render_enable_white_furnace(self.handle, int(e)))
-    def set_blue_noise(self, e): self._c(self.lib.rth_render_set_sampler(self.handle, int(e)))
+    def set_blue_noise(self, e, table_path=None):
+        path = table_path or os.path.join(os.path.dirname(_HERE), "assets", "blue_noise", "heitz2019_256spp_256d.bin")
+        self.lib.rth_render_set_blue_noise_path(self.handle, path.encode())
+        self._c(self.lib.rth_render_set_sampler(self.handle, int(e)))
     def enable_denoiser(self, e): self._c(self.lib.rth_render_enable_denoiser(self.handle, int(e)))
     def set_aov(self, aov): self._c(self.lib.rth_render_set_aov(self.handle, int(aov)))
 

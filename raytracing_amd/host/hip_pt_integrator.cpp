@@ -17,6 +17,7 @@
 //   Denoise / CopyHistoryBuffers :665-675 -> rt_denoise / rt_copy_history
 //   ResolveRadiance :677-684           -> rt_frame_resolve (the frame's only host sync)
 #include "hip_pt_integrator.hpp"
+#include <cstdio>
 #include "acceleration_structure.hpp"
 #include "scene.hpp"
 
@@ -33,6 +34,23 @@ HIPContext::~HIPContext() { rt_ctx_destroy(ctx_); }
 void HIPContext::Finish() const
 {
     if (rt_finish(ctx_) != RT_OK) throw HIPException(rt_last_error(ctx_));
+}
+
+void HIPContext::LoadBlueNoiseTables(const std::string& path)
+{
+    const size_t n[3] = {65536, 131072, 131072};
+    std::vector<unsigned char> raw(n[0] + n[1] + n[2]);
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f || fread(raw.data(), 1, raw.size(), f) != raw.size())
+    {
+        if (f) fclose(f);
+        throw HIPException("Failed to load the blue-noise sampler tables " + path);
+    }
+    fclose(f);
+    std::vector<int> t(raw.begin(), raw.end());
+    if (rt_upload_blue_noise_tables(ctx_, t.data(), t.data() + n[0], t.data() + n[0] + n[1]) != RT_OK)
+        throw HIPException(rt_last_error(ctx_));
+    has_blue_noise_ = true;
 }
 
 std::string HIPContext::DeviceName() const
@@ -96,6 +114,8 @@ void HIPPathTraceIntegrator::SetCameraData(Camera const& camera)
 void HIPPathTraceIntegrator::SetSamplerType(SamplerType sampler_type)
 {
     if (sampler_type == sampler_type_) return;
+    if (sampler_type == SamplerType::kBlueNoise && !context_.HasBlueNoiseTables())
+        context_.LoadBlueNoiseTables(blue_noise_path_);
     Check(rt_set_option(frame_, RT_OPT_SAMPLER, sampler_type == SamplerType::kBlueNoise ? 1u : 0u));
     sampler_type_ = sampler_type;
     RequestReset();

@@ -29,9 +29,14 @@ public:
     rt_ctx* Get() const { return ctx_; }
     void Finish() const;
     std::string DeviceName() const;
+    // Loads the blue-noise sampler tables (the data the reference compiles in through
+    // src/utils/blue_noise_sampler.hpp) from a packed asset file and uploads them.
+    void LoadBlueNoiseTables(const std::string& path);
+    bool HasBlueNoiseTables() const { return has_blue_noise_; }
 
 private:
     rt_ctx* ctx_ = nullptr;
+    bool has_blue_noise_ = false;
 };
 
 struct TileDesc   // which interleaved row bands of the image this integrator renders
@@ -63,6 +68,8 @@ public:
     std::uint32_t GetGlobalRow(std::uint32_t local_row) const;
     rt_stats GetStats() const;
     void SetResolveEveryFrame(bool enable) { resolve_every_frame_ = enable; }
+    // packed uint8 tables, see tools/make_blue_noise_asset.py (default: relative to the CWD like the env map)
+    void SetBlueNoiseTablePath(std::string path) { blue_noise_path_ = std::move(path); }
     rt_frame* GetFrame() const { return frame_; }
 
 protected:
@@ -90,5 +97,6 @@ private:
     rt_frame* frame_ = nullptr;
     std::vector<float> resolved_;
     bool resolve_every_frame_ = true;
+    std::string blue_noise_path_ = "assets/blue_noise/heitz2019_256spp_256d.bin";
 };
 } // namespace rt

@@ -141,6 +141,7 @@ int rth_render_set_sampler(void* r, int blue_noise)
 {
     return guard([&]() { ((rt::Render*)r)->GetIntegrator().SetSamplerType(blue_noise ? rt::Integrator::SamplerType::kBlueNoise : rt::Integrator::SamplerType::kRandom); return 0; }, 1);
 }
+int rth_render_set_blue_noise_path(void* r, const char* path) { ((rt::Render*)r)->GetIntegrator().SetBlueNoiseTablePath(path); return 0; }
 int rth_render_enable_denoiser(void* r, int e) { return guard([&]() { ((rt::Render*)r)->GetIntegrator().EnableDenoiser(e != 0); return 0; }, 1); }
 int rth_render_set_aov(void* r, int aov) { return guard([&]() { ((rt::Render*)r)->GetIntegrator().SetAOV((rt::Integrator::AOV)aov); return 0; }, 1); }
 int rth_render_resolve(void* r, float* out)

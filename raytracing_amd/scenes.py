@@ -492,3 +492,14 @@ def shader_balls_obj(directory, tris_per_ball=20_000):
                        fmt="f %d/%d/%d %d/%d/%d %d/%d/%d")
             base += 3 * n
     return path
+
+
+def blue_noise_tables(path=None):
+    """(sobol_256spp_256d, scramblingTile, rankingTile) as int32 arrays from the packed asset
+    (tools/make_blue_noise_asset.py)."""
+    import os
+    path = path or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "assets", "blue_noise",
+                                "heitz2019_256spp_256d.bin")
+    raw = np.fromfile(path, dtype=np.uint8)
+    assert len(raw) == 65536 + 131072 + 131072
+    return raw[:65536].astype(np.int32), raw[65536:65536 + 131072].astype(np.int32), raw[65536 + 131072:].astype(np.int32)

@@ -37,6 +37,7 @@ def load():
         "orc_stage_clear_counters": (None, [vp, u32]), "orc_stage_shade_hits": (None, [vp, u32]),
         "orc_stage_intersect_shadow": (None, [vp]), "orc_stage_accumulate": (None, [vp]),
         "orc_stage_advance": (None, [vp]),
+        "orc_set_blue_noise_tables": (None, [vp, vp, vp]), "orc_set_sampler": (None, [vp, C.c_int]),
         "orc_enable_denoiser": (None, [vp, C.c_int]), "orc_set_aov": (None, [vp, u32]),
         "orc_wang_hash": (u32, [u32]), "orc_sample_random": (f32, [u32] * 5),
         "orc_tanf": (f32, [f32]), "orc_sinf": (f32, [f32]), "orc_cosf": (f32, [f32]),
@@ -81,6 +82,12 @@ class Oracle:
 
     def set_max_bounces(self, b):
         self.lib.orc_set_max_bounces(self.handle, b)
+
+    def set_blue_noise(self, enable, tables=None):
+        if tables is not None:
+            self._bn = [np.ascontiguousarray(t, np.int32) for t in tables]
+            self.lib.orc_set_blue_noise_tables(*[t.ctypes.data for t in self._bn])
+        self.lib.orc_set_sampler(self.handle, int(enable))
 
     def enable_denoiser(self, e):
         self.lib.orc_enable_denoiser(self.handle, int(e))

@@ -44,6 +44,7 @@ def load(libm=False):
         "ref_stage_clear_counters": (None, [vp, u32]), "ref_stage_shade_hits": (None, [vp, u32]),
         "ref_stage_intersect_shadow": (None, [vp]), "ref_stage_accumulate": (None, [vp]),
         "ref_stage_advance": (None, [vp]),
+        "ref_set_blue_noise_tables": (None, [vp, vp, vp, vp]), "ref_set_sampler": (None, [vp, C.c_int]),
         "ref_enable_denoiser": (None, [vp, C.c_int]), "ref_set_aov": (None, [vp, u32]),
     }
     for name in ("triangles", "nodes", "materials", "textures", "texture_data", "lights", "emissive"):
@@ -142,6 +143,12 @@ class RefIntegrator:
 
     def set_max_bounces(self, b):
         self.lib.ref_set_max_bounces(self.handle, b)
+
+    def set_blue_noise(self, enable, tables=None):
+        if tables is not None:
+            self._bn = [np.ascontiguousarray(t, np.int32) for t in tables]
+            self.lib.ref_set_blue_noise_tables(self.handle, *[t.ctypes.data for t in self._bn])
+        self.lib.ref_set_sampler(self.handle, int(enable))
 
     def enable_denoiser(self, e):
         self.lib.ref_enable_denoiser(self.handle, int(e))

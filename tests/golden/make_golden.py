@@ -107,6 +107,17 @@ def main():
         out["denoise%d/resolved" % f] = ri.resolve()[..., :3].copy()
         out["denoise%d/radiance" % f] = ri.radiance()[..., :3].copy()
     out["aov_denoise/camera"] = cam
+    # blue-noise sampler (hit_surface.cl -D BLUE_NOISE_SAMPLER), frame larger than the 128x128 tile
+    bw, bh = 160, 136
+    bcam = T.default_camera(bw, bh)
+    for furnace in (False, True):
+        ri = _ref.RefIntegrator(bw, bh, scenes["coverage"], furnace=furnace, threads=1)
+        ri.set_camera(bcam)
+        ri.set_max_bounces(9)
+        ri.set_blue_noise(True, S.blue_noise_tables())
+        ri.integrate(3)
+        out["blue_noise/radiance_furnace%d" % furnace] = ri.radiance()[..., :3].copy()
+    out["blue_noise/camera"] = bcam
     np.savez_compressed(os.path.join(HERE, "radiance.npz"), **out)
 
     host = {

@@ -186,8 +186,8 @@ def test_cpp_host_layer_end_to_end(ctx, golden_scenes, golden_radiance):
     r.enable_white_furnace(True)
     r.render_samples(1)
     assert r.sample_count() == 1    # furnace toggle requested a reset
-    with pytest.raises(host.RtError, match="kRandom"):
-        r.set_blue_noise(True)      # not implemented -> loud, not silent
+    with pytest.raises(host.RtError, match="blue-noise sampler tables"):
+        r.set_blue_noise(True, table_path="/nonexistent/tables.bin")     # missing asset -> loud
 
 
 def test_furnace_energy_bound(ctx, golden_scenes):
@@ -395,3 +395,42 @@ def test_denoiser_needs_the_whole_image(ctx, golden_scenes):
         t.set_option(capi.OPT_DENOISER, 1)
     with pytest.raises(capi.RtError, match="whole image"):
         t.set_option(capi.OPT_AOV, 2)
+
+
+@pytest.mark.parametrize("furnace", [False, True])
+def test_blue_noise_sampler(ctx, golden_scenes, golden_radiance, furnace):
+    """Integrator::SetSamplerType(kBlueNoise): C-ABI path against the reference-kernel golden
+    vectors; C++ host path (asset file -> HIPContext::LoadBlueNoiseTables) against the oracle."""
+    g = golden_radiance
+    sc = golden_scenes["coverage"]
+    ctx.upload_scene(sc)
+    fr = capi.Frame(ctx, 160, 136)
+    with pytest.raises(capi.RtError, match="rt_upload_blue_noise_tables") if not getattr(ctx, "_bn", False) else _nullcontext():
+        fr.set_option(capi.OPT_SAMPLER, 1)
+    ctx.upload_blue_noise_tables(*S.blue_noise_tables())
+    ctx._bn = True
+    fr.set_option(capi.OPT_SAMPLER, 1)
+    fr.set_option(capi.OPT_WHITE_FURNACE, int(furnace))
+    fr.set_camera(g["blue_noise/camera"]); fr.set_max_bounces(9)
+    fr.integrate(3)
+    assert np.array_equal(fr.radiance()[..., :3], g["blue_noise/radiance_furnace%d" % furnace], equal_nan=True)
+    if not furnace:
+        scene = host.Scene(os.path.join(ROOT, "assets", "CornellBox.obj"))
+        scene.add_directional_light((-0.6, -1.5, 3.5), (15.0, 10.0, 5.0))
+        r = host.Render(140, 130, scene)
+        r.set_max_bounces(4)
+        r.set_blue_noise(True)
+        r.set_camera(T.default_camera(140, 130))
+        r.render_frame(); r.render_frame()
+        orc = _oracle.Oracle(140, 130, r.scene_arrays())
+        orc.set_camera(T.default_camera(140, 130)); orc.set_max_bounces(4)
+        orc.set_blue_noise(True, S.blue_noise_tables()); orc.integrate(2)
+        assert np.array_equal(r.radiance()[..., :3], orc.radiance()[..., :3], equal_nan=True)
+        r.set_blue_noise(False)
+        r.render_frame()
+        assert r.sample_count() == 1          # sampler change requested a reset
+
+
+class _nullcontext:
+    def __enter__(self): return None
+    def __exit__(self, *a): return False

@@ -105,3 +105,20 @@ def test_oracle_aov_and_denoiser_sequence(golden_scenes, golden_radiance):
     got = _aov_denoise_sequence(_oracle.Oracle(64, 48, golden_scenes["coverage"]), g["aov_denoise/camera"])
     for k, v in got.items():
         assert np.array_equal(v, g[k], equal_nan=True), k
+
+
+def test_oracle_blue_noise_sampler_golden(golden_scenes, golden_radiance):
+    """SamplerType::kBlueNoise (sampling.h:40-61): golden radiance from the reference kernels built
+    with -D BLUE_NOISE_SAMPLER, at a frame larger than the 128x128 tile (wrap + table overrun)."""
+    from raytracing_amd import scenes as S
+    g = golden_radiance
+    for furnace in (False, True):
+        orc = _oracle.Oracle(160, 136, golden_scenes["coverage"], furnace=furnace)
+        orc.set_camera(g["blue_noise/camera"])
+        orc.set_max_bounces(9)
+        orc.set_blue_noise(True, S.blue_noise_tables())
+        orc.integrate(3)
+        assert np.array_equal(orc.radiance()[..., :3], g["blue_noise/radiance_furnace%d" % furnace], equal_nan=True)
+        orc.set_blue_noise(False)       # SetSamplerType back -> reset, white-noise sequence again
+        orc.integrate(1)
+        assert orc.sample_count() == 1
