@@ -16,43 +16,47 @@ bool LoadPNG(const char* filename, Image& result);   // png_loader.cpp   // 8-bi
 class Scene
 {
 public:
-    // Loads an OBJ + MTL pair (main.cpp:56).  Throws std::runtime_error on failure.
+    // ---- construction -----------------------------------------------------------
+    // OBJ + MTL from disk (main.cpp:56); throws std::runtime_error on failure.
     Scene(const char* filename, float scale, bool flip_yz);
-    // Adopts caller-built arrays (procedural scenes / binary caches); no file IO.
+    // Caller-built arrays (procedural scenes / binary caches); no file IO.
     Scene(std::vector<Triangle> triangles, std::vector<PackedMaterial> materials, std::vector<Texture> textures,
         std::vector<std::uint32_t> texture_data);
 
-    std::vector<Triangle>& GetTriangles() { return triangles_; }
+    // ---- lights (OBJ has none; main.cpp:58 adds one directional light) -----------
+    void AddPointLight(float3 origin, float3 radiance);
+    void AddDirectionalLight(float3 direction, float3 radiance);   // stored as the unit vector TOWARDS the light
+
+    // ---- finalisation: emissive list (after the BVH reorder), light count, env map.
+    // The env map defaults to the path the reference hard-codes relative to the CWD
+    // (scene.cpp:353-361); both setters are extensions for headless/batch use.
+    void Finalize();
+    void SetEnvironmentPath(std::string path) { env_path_ = std::move(path); }
+    void SetEnvironmentImage(Image image) { env_image_ = std::move(image); env_preset_ = true; }
+
+    // ---- what the integrator uploads (scene.hpp:39-47) -----------------------------
+    std::vector<Triangle>& GetTriangles() { return triangles_; }   // mutable: Bvh::BuildCPU reorders them
     std::vector<Triangle> const& GetTriangles() const { return triangles_; }
-    std::vector<std::uint32_t> const& GetEmissiveIndices() const { return emissive_indices_; }
     std::vector<PackedMaterial> const& GetMaterials() const { return materials_; }
     std::vector<Texture> const& GetTextures() const { return textures_; }
     std::vector<std::uint32_t> const& GetTextureData() const { return texture_data_; }
     std::vector<Light> const& GetLights() const { return lights_; }
+    std::vector<std::uint32_t> const& GetEmissiveIndices() const { return emissive_indices_; }
     SceneInfo const& GetSceneInfo() const { return scene_info_; }
     Image const& GetEnvImage() const { return env_image_; }
 
-    // Collects emissive triangles (after the BVH reorder), counts lights and loads
-    // the environment map -- by default the path the reference hard-codes,
-    // "assets/ibl/CGSkies_0036_free.hdr" relative to the CWD (scene.cpp:353-361).
-    void Finalize();
-    void SetEnvironmentPath(std::string path) { env_path_ = std::move(path); }
-    void SetEnvironmentImage(Image image) { env_image_ = std::move(image); env_preset_ = true; }
-    void AddPointLight(float3 origin, float3 radiance);
-    void AddDirectionalLight(float3 direction, float3 radiance);
-
 private:
     void Load(const char* filename, float scale, bool flip_yz);
-    std::size_t LoadTexture(const std::string& filename);
+    std::size_t LoadTexture(const std::string& filename);   // cached by file name, returns the texture index
     void CollectEmissiveTriangles();
 
     std::vector<Triangle> triangles_;
-    std::vector<std::uint32_t> emissive_indices_;
     std::vector<PackedMaterial> materials_;
-    std::vector<Light> lights_;
     std::vector<Texture> textures_;
-    std::vector<std::uint32_t> texture_data_;
+    std::vector<std::uint32_t> texture_data_;               // RGBA8 atlas, all textures back to back
     std::unordered_map<std::string, std::size_t> loaded_textures_;
+    std::vector<Light> lights_;
+    std::vector<std::uint32_t> emissive_indices_;
     SceneInfo scene_info_ = {};
     Image env_image_;
     std::string env_path_ = "assets/ibl/CGSkies_0036_free.hdr";
