@@ -434,3 +434,72 @@ def test_blue_noise_sampler(ctx, golden_scenes, golden_radiance, furnace):
 class _nullcontext:
     def __enter__(self): return None
     def __exit__(self, *a): return False
+
+
+def _tiny_scene(env, tris_spec):
+    """tris_spec: list of 3x3 vertex arrays; one diffuse + one emissive material."""
+    n = len(tris_spec)
+    P = np.array(tris_spec, np.float32).reshape(n, 3, 3)
+    e1, e2 = P[:, 1] - P[:, 0], P[:, 2] - P[:, 0]
+    nrm = np.cross(e1, e2); nrm /= np.maximum(np.linalg.norm(nrm, axis=1, keepdims=True), 1e-20)
+    N = np.repeat(nrm[:, None, :], 3, axis=1).astype(np.float32)
+    U = np.zeros((n, 3, 2), np.float32)
+    tris = S.to_triangles([(P, N, U, 0)])
+    mats = np.array([S.make_material(kd=(0.8, 0.6, 0.3), ks=(0.4, 0.4, 0.4), roughness=0.3)], dtype=T.packed_material)
+    s = host.Scene(arrays=dict(triangles=tris, materials=mats))
+    s.add_directional_light((-0.6, -1.5, 3.5), (15.0, 10.0, 5.0))
+    s.add_point_light((0.0, 0.0, 3.0), (4.0, 4.0, 4.0))
+    s.build_bvh()
+    s.set_env_image(env)
+    s.finalize()
+    return s.arrays()
+
+
+@pytest.mark.parametrize("variant", [0, 3, 4])
+def test_degenerate_bvhs(ctx, env_map, variant):
+    """Root-is-a-leaf trees (1 triangle), 2-triangle trees, a leaf with many coincident-centroid
+    triangles (the reference's 'all centroids equal' leaf, bvh.cpp:112-123), and a long chain of
+    nested triangles that makes a deep, one-sided tree."""
+    big = [[(-1, 1, 0), (1, 1, 0), (0, 1, 2)]]
+    cases = {
+        "one": big,
+        "two": big + [[(-1, 2, 0), (1, 2, 0), (0, 2, 2)]],
+        # 9 coincident triangles (same centroid) + 1 apart -> one 9-primitive leaf
+        "coincident": [[(-1 + 0.0, 1.5, 0), (1, 1.5, 0), (0, 1.5, 2)]] * 9 + big,
+        # 70 slabs stacked in depth: every ray pierces many boxes
+        "stack": [[(-2, 1 + 0.05 * k, -1), (2, 1 + 0.05 * k, -1), (0, 1 + 0.05 * k, 3)] for k in range(70)],
+    }
+    for name, spec in cases.items():
+        sc = _tiny_scene(env_map, spec)
+        cam = T.default_camera(48, 40)
+        ctx.upload_scene(sc)
+        fr = capi.Frame(ctx, 48, 40)
+        fr.set_camera(cam); fr.set_max_bounces(3); fr.set_option(capi.OPT_TRACE_VARIANT, variant)
+        fr.integrate(3)
+        orc = _oracle.Oracle(48, 40, sc)
+        orc.set_camera(cam); orc.set_max_bounces(3); orc.integrate(3)
+        assert np.array_equal(fr.radiance()[..., :3], orc.radiance()[..., :3], equal_nan=True), (name, variant)
+        st = fr.stats()
+        assert (st.closest_rays, st.shadow_rays) == orc.ray_totals(), name
+
+
+def test_rt_render_cli(tmp_path):
+    """The headless CLI with the reference's flags (main.cpp:42-53) renders the Cornell box."""
+    import subprocess
+    exe = os.path.join(ROOT, "raytracing_amd", "rt_render")
+    out = tmp_path / "img.pfm"
+    r = subprocess.run([exe, "-w", "64", "-h", "48", "--scene", "assets/CornellBox.obj", "--spp", "4", "--bounces", "4",
+                        "--out", str(out)], cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert "Mrays/s" in r.stdout and "gfx950" in r.stdout
+    raw = open(out, "rb").read()
+    assert raw.startswith(b"PF\n64 48\n-1.0\n")
+    img = np.frombuffer(raw[len(b"PF\n64 48\n-1.0\n"):], np.float32).reshape(48, 64, 3)
+    scene = host.Scene(os.path.join(ROOT, "assets", "CornellBox.obj"))
+    scene.add_directional_light((-0.6, -1.5, 3.5), (15.0, 10.0, 5.0))
+    scene.build_bvh(); scene.finalize()
+    orc = _oracle.Oracle(64, 48, scene.arrays())
+    orc.set_camera(T.default_camera(64, 48)); orc.set_max_bounces(4); orc.integrate(4)
+    assert np.array_equal(img, orc.radiance()[..., :3] / np.float32(4.0))
+    bad = subprocess.run([exe, "--scene", "assets/does_not_exist.obj"], cwd=ROOT, capture_output=True, text=True, timeout=60)
+    assert bad.returncode == 1 and "Caught exception: Failed to load the scene!" in bad.stderr
