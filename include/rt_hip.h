@@ -123,8 +123,8 @@ enum rt_option
                                    2 M paths per launch, 3 above.  Results are identical for every value. */
     , RT_OPT_TRACE_WAVES_PER_CU = 8 /* persistent-grid size of the trace kernels in waves per CU (0 = as many as fit) */
     , RT_OPT_SAMPLES_IN_FLIGHT = 9  /* rt_integrate traces this many consecutive samples per pixel concurrently
-                                       (1..64; 0 = auto, the default: largest power of two <= 32 with tile pixels x
-                                       samples < 2^25).  Results are bit-identical for every value: contributions
+                                       (1..256; 0 = auto, the default: largest power of two <= 64 whose paths fit
+                                       the path-id range and ~96 GB of per-path buffers).  Results are bit-identical for every value: contributions
                                        are logged per path and replayed in the reference's order. */
 };
 int rt_set_option(rt_frame* frame, int option, uint32_t value);

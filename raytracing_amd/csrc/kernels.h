@@ -37,8 +37,8 @@
 #define RT_EMPTY_REF 0xFFFFFFFFu
 #define RT_TRACE_STACK_LDS 24     // per-lane stack entries kept in LDS
 #define RT_TRACE_STACK_MAX 64     // the reference's nodesToVisit[64] (trace_bvh.cl:142)
-#define RT_ID_BITS 25u            // path id bits in a shadow ray's payload; the rest = log entry
-#define RT_ID_MASK ((1u << RT_ID_BITS) - 1u)
+// A shadow ray's payload = log entry << id_bits | path id.  id_bits is chosen per frame:
+// 32 - bits(2 * (max_bounces + 1)), e.g. 27 bits (134 M paths) for 8 bounces.
 
 struct DScene
 {
@@ -205,7 +205,7 @@ RT_DEV bool box_test(float bminx, float bminy, float bminz, float bmaxx, float b
 template <bool SHADOW>
 __global__ __launch_bounds__(64) void k_trace_v1(DScene sc, const float4* __restrict__ o4, const float4* __restrict__ d4,
     const uint32_t* __restrict__ count_ptr, float4* __restrict__ hits, float4* __restrict__ rlog,
-    uint32_t log_stride, uint2* __restrict__ spill)
+    uint32_t log_stride, uint32_t id_bits, uint2* __restrict__ spill)
 {
     __shared__ uint2 stack[RT_TRACE_STACK_LDS][64];
     const uint32_t lane = threadIdx.x;
@@ -344,7 +344,7 @@ __global__ __launch_bounds__(64) void k_trace_v1(DScene sc, const float4* __rest
             if (occluded)
             {
                 uint32_t payload = __float_as_uint(rd.w);
-                rlog[(size_t)(payload >> RT_ID_BITS) * log_stride + (payload & RT_ID_MASK)] = make_float4(0, 0, 0, 0);
+                rlog[(size_t)(payload >> id_bits) * log_stride + (payload & ((1u << id_bits) - 1u))] = make_float4(0, 0, 0, 0);
             }
         }
         else
@@ -378,7 +378,7 @@ template <bool SHADOW, int STACK>
 __global__ __launch_bounds__(64) void k_trace(DScene sc, const float4* __restrict__ o4, const float4* __restrict__ d4,
     const float4* __restrict__ iv4, const uint32_t* __restrict__ count_ptr, uint32_t* __restrict__ heads,
     float4* __restrict__ hits,
-    float4* __restrict__ rlog, uint32_t log_stride, uint2* __restrict__ spill)
+    float4* __restrict__ rlog, uint32_t log_stride, uint32_t id_bits, uint2* __restrict__ spill)
 {
     __shared__ uint2 stack[STACK][64];
     const uint32_t lane = threadIdx.x;
@@ -564,7 +564,7 @@ __global__ __launch_bounds__(64) void k_trace(DScene sc, const float4* __restric
                 // logged the direct sample tentatively; an occluded ray (it stopped on its
                 // first accepted triangle, hit_prim set) retracts it.  Store only, no wait.
                 if (hit_prim != RT_INVALID_ID)
-                    rlog[(size_t)(payload >> RT_ID_BITS) * log_stride + (payload & RT_ID_MASK)] = make_float4(0, 0, 0, 0);
+                    rlog[(size_t)(payload >> id_bits) * log_stride + (payload & ((1u << id_bits) - 1u))] = make_float4(0, 0, 0, 0);
             }
             else
             {
@@ -863,7 +863,7 @@ struct ShadeArgs
     float4* rlog; uint32_t* cnt;      // radiance log (see file header)
     const uint8_t* bn_sobol; const uint8_t* bn_scramble; const uint8_t* bn_rank;   // SamplerType::kBlueNoise tables
     DCounters* counters;
-    uint32_t bounce, sample_base, emit_outgoing, n_local, log_stride;
+    uint32_t bounce, sample_base, emit_outgoing, n_local, log_stride, id_bits;
 };
 
 // SampleBlueNoise, sampling.h:40-61 (Heitz et al. 2019 tables, values 0..255).  The reference
@@ -988,7 +988,7 @@ __global__ __launch_bounds__(RT_SHADE_BLOCK) void k_shade(DScene sc, DTile tile,
                 want_shadow = (pdf > 0.0f) && (dot3(lsamp, lsamp) > 0.0f);
                 f3 so = position + normal * RT_EPS;
                 sh_o = make_float4(so.x, so.y, so.z, distance_to_light);
-                sh_d = make_float4(outgoing.x, outgoing.y, outgoing.z, __uint_as_float(id | (nlog << RT_ID_BITS)));
+                sh_d = make_float4(outgoing.x, outgoing.y, outgoing.z, __uint_as_float(id | (nlog << a.id_bits)));
                 if (want_shadow)
                 {
                     // deferred direct sample (direct_light_samples_buffer_): logged now, retracted

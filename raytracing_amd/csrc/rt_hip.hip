@@ -58,6 +58,7 @@ struct rt_frame
     uint32_t cur_slots = 0;        // slots used by the batch in flight (0 = nothing pending)
     uint32_t log_stride = 0;       // elements per log entry row = slots * n_local
     uint32_t log_entries = 0;      // rows allocated (>= 2 * (max_bounces + 1))
+    uint32_t id_bits = 27;         // path-id bits of a shadow ray's payload (the rest: log entry)
     bool shadow_pending = false;   // rt_shade issued, rt_intersect_shadow not yet
     DCounters* counters;
     uint2* spill;
@@ -455,11 +456,24 @@ void free_path_buffers(rt_frame* f)
 
 // Per-path state: ray queues for `slots` samples in flight and the radiance log
 // with 2 * (max_bounces + 1) entries per path.  (Re)allocated when either changes.
-// auto: the largest power of two <= 32 that keeps tile pixels x samples within the 2^25 path ids
-uint32_t auto_slots(uint32_t n_local)
+// bits left for the path id once the log-entry index (< 2 * (max_bounces + 1)) is packed above it
+uint32_t id_bits_for(uint32_t max_bounces)
 {
-    uint32_t s = 32;
-    while (s > 1 && (uint64_t)s * (n_local ? n_local : 1) > (uint64_t)RT_ID_MASK) s >>= 1;
+    uint32_t entries = 2u * (max_bounces + 1u), eb = 1;
+    while ((1u << eb) < entries) ++eb;
+    return 32u - eb;
+}
+
+size_t bytes_per_path(uint32_t max_bounces) { return 12u * 16u + 4u + 32u * (max_bounces + 1u); }
+
+// auto: the largest power of two <= 64 that keeps tile pixels x samples inside the path-id
+// range and the per-path buffers under ~96 GB (a third of the 288 GB of HBM)
+uint32_t auto_slots(uint32_t n_local, uint32_t max_bounces)
+{
+    const uint64_t n = n_local ? n_local : 1;
+    const uint64_t max_paths = (1ull << id_bits_for(max_bounces)) - 1ull;
+    uint32_t s = 64;
+    while (s > 1 && (s * n > max_paths || s * n * bytes_per_path(max_bounces) > (96ull << 30))) s >>= 1;
     return s;
 }
 
@@ -467,9 +481,10 @@ int alloc_path_buffers(rt_frame* f)
 {
     rt_ctx* ctx = f->ctx;
     free_path_buffers(f);
-    f->slots = f->slots_opt ? f->slots_opt : auto_slots(f->n_local);
+    f->slots = f->slots_opt ? f->slots_opt : auto_slots(f->n_local, f->max_bounces);
+    f->id_bits = id_bits_for(f->max_bounces);
     uint64_t paths = (uint64_t)(f->n_local ? f->n_local : 1) * f->slots;
-    if (paths > (uint64_t)RT_ID_MASK) return fail(ctx, "samples in flight x tile pixels exceeds 2^25 paths");
+    if (paths >= (1ull << f->id_bits)) return fail(ctx, "samples in flight x tile pixels exceeds the path-id range");
     f->log_stride = (uint32_t)paths;
     f->log_entries = 2u * (f->max_bounces + 1u);
     size_t q = (size_t)(paths + 4) * sizeof(float4);   // +4: the unified 64-byte fetch of k_trace reads o4[i+2] / d4[i+2]
@@ -616,11 +631,13 @@ int rt_set_option(rt_frame* f, int option, uint32_t value)
             if (flush_log(f) != RT_OK) return RT_ERROR;
             HIPCHK(f->ctx, hipStreamSynchronize(f->ctx->stream));
             f->max_bounces = value;
-            if (2u * (value + 1u) > f->log_entries) return alloc_path_buffers(f);
+            if (2u * (value + 1u) > f->log_entries || id_bits_for(value) != f->id_bits ||
+                (!f->slots_opt && auto_slots(f->n_local, value) != f->slots))
+                return alloc_path_buffers(f);
         }
         return RT_OK;
     case RT_OPT_SAMPLES_IN_FLIGHT:
-        if (value > 64) return fail(f->ctx, "rt_set_option: samples in flight must be 0 (auto) or 1..64");
+        if (value > 256) return fail(f->ctx, "rt_set_option: samples in flight must be 0 (auto) or 1..256");
         if (value != f->slots_opt)
         {
             if (flush_log(f) != RT_OK) return RT_ERROR;
@@ -715,7 +732,7 @@ void launch_trace_sm(rt_frame* f, const float4* o4, const float4* d4, const floa
     uint32_t blocks = ((uint32_t)ctx->prop.multiProcessorCount * per_cu + 7u) & ~7u;
     hipLaunchKernelGGL((k_trace<SHADOW, STACK>), dim3(blocks), dim3(64), 0, ctx->stream, ctx->scene.d, o4, d4, iv4, count,
         &f->counters->head[SHADOW ? 1 : 0][0], SHADOW ? (float4*)nullptr : f->hits,
-        SHADOW ? f->rlog : (float4*)nullptr, f->log_stride, f->spill);
+        SHADOW ? f->rlog : (float4*)nullptr, f->log_stride, f->id_bits, f->spill);
 }
 
 template <bool SHADOW>
@@ -737,7 +754,7 @@ void launch_trace(rt_frame* f, const float4* o4, const float4* d4, const float4*
     case 0:
         hipLaunchKernelGGL(k_trace_v1<SHADOW>, dim3(f->trace_waves_per_cu ? (((uint32_t)ctx->prop.multiProcessorCount *
             (f->trace_waves_per_cu < 13u ? f->trace_waves_per_cu : 13u) + 7u) & ~7u) : f->trace_blocks), dim3(64), 0, ctx->stream, ctx->scene.d, o4, d4,
-            count, SHADOW ? (float4*)nullptr : f->hits, SHADOW ? f->rlog : (float4*)nullptr, f->log_stride, f->spill);
+            count, SHADOW ? (float4*)nullptr : f->hits, SHADOW ? f->rlog : (float4*)nullptr, f->log_stride, f->id_bits, f->spill);
         break;
     case 1: launch_trace_sm<SHADOW, 16>(f, o4, d4, iv4, count); break;
     case 2: launch_trace_sm<SHADOW, 24>(f, o4, d4, iv4, count); break;
@@ -826,7 +843,7 @@ int rt_shade(rt_frame* f, uint32_t bounce)              // ShadeMissedRays + Sha
     a.bn_rank = ctx->blue_noise ? ctx->blue_noise + 65536 + 131072 : nullptr;
     a.bounce = bounce; a.sample_base = f->sample_count;
     a.emit_outgoing = (f->drop_last && bounce >= f->max_bounces) ? 0u : 1u;
-    a.n_local = f->n_local ? f->n_local : 1; a.log_stride = f->log_stride;
+    a.n_local = f->n_local ? f->n_local : 1; a.log_stride = f->log_stride; a.id_bits = f->id_bits;
     if (2u * (bounce + 1u) > f->log_entries) return fail(ctx, "rt_shade: bounce beyond the configured max_bounces");
     uint32_t blocks = (f->n_local * (f->cur_slots ? f->cur_slots : 1u) + RT_SHADE_BLOCK - 1u) / RT_SHADE_BLOCK;
     if (blocks == 0) blocks = 1;
@@ -1040,10 +1057,10 @@ int rt_frame_debug_read_queue(rt_frame* f, int which, uint32_t bounce, rt_ray* r
     {
         uint32_t pl;
         memcpy(&pl, &d[i].w, 4);
-        uint32_t id = which == 0 ? pl : (pl & RT_ID_MASK);
+        uint32_t id = which == 0 ? pl : (pl & ((1u << f->id_bits) - 1u));
         uint32_t local_pix = id % (f->n_local ? f->n_local : 1);
         if (which == 1)   // the deferred direct-light sample lives in the radiance log
-            HIPCHK(ctx, hipMemcpy(&p[i], f->rlog + (size_t)(pl >> RT_ID_BITS) * f->log_stride + id, 16,
+            HIPCHK(ctx, hipMemcpy(&p[i], f->rlog + (size_t)(pl >> f->id_bits) * f->log_stride + id, 16,
                 hipMemcpyDeviceToHost));
         if (rays)
         {
