@@ -5,15 +5,16 @@
 
 A "step" is one pass of the hot path over one batch: one Integrator::Integrate()
 = one sample per pixel of the full frame (raygen, then per bounce: closest-hit
-trace, miss+shade, shadow trace+accumulate).  Workload at N = 1: BASELINE.json
-configs[1], "CornellBox_Dragon.obj 1280x720 64spp 8-bounce on 1 MI355X" -- the
-mesh is stripped from the reference checkout (.MISSING_LARGE_BLOBS), so the
-deterministic stand-in of SURVEY.md section 8d is generated: the Cornell shell +
-an 871 200-triangle displaced blob with the `dragon` material + a 20 000-triangle
-sphere with the `teapot` material (raytracing_amd/scenes.py); default K = 64
-steps = the 64 spp of the config.  Metric = BASELINE.json's: Mrays/s, all
-bounces + shadow rays, counted by the device queue counters the reference itself
-keeps (ray_counter_buffer_, shadow_ray_counter_buffer_).
+trace, miss+shade, shadow trace+accumulate).  Workload: the configuration
+BASELINE.json's metric is quoted on, configs[3] "Amazon Lumberyard Bistro
+1920x1080 256spp 8-bounce" -- it fits one GPU, so N = 1 runs it whole and N > 1
+tiles it.  The Bistro asset is a download the reference does not ship
+(assets/download_bistro.bat), so the deterministic stand-in of SURVEY.md section
+8d is generated (raytracing_amd/scenes.py: city_block, ~2.8 M triangles, 120
+materials, textured); default K = 256 steps = the config's 256 spp.  --config 2 / 3 / 5 select the other BASELINE
+configs' stand-ins.  Metric = BASELINE.json's: Mrays/s, all bounces + shadow
+rays, counted by the device queue counters the reference itself keeps
+(ray_counter_buffer_, shadow_ray_counter_buffer_).
 
 N > 1 (launched by torch.distributed.run, one rank per GPU): the frame is split
 into interleaved 8-row bands, the scene is replicated, there is no communication
@@ -136,10 +137,11 @@ def cpu_legs(args, scene_arrays, cam_small, small_w, small_h, cam_full):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--steps", type=int, default=256)
     ap.add_argument("--warmup", type=int, default=4)
-    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS),
-                    help="BASELINE.json config (1-based index into 'configs'); default 2 = the metric's single-GPU config")
+    ap.add_argument("--config", type=int, default=4, choices=sorted(CONFIGS),
+                    help="BASELINE.json config (1-based index into 'configs'); default 4 = the one the metric is quoted on "
+                         "(Bistro 1080p 8-bounce stand-in)")
     ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--bounces", type=int, default=None)
@@ -198,6 +200,10 @@ def main():
 
     local_rows = render.local_rows
     tile = torch.zeros((max(local_rows, 1), args.width, 4), dtype=torch.float32, device="cuda")
+
+    # per-path buffers sized for the K-sample job before anything is timed (they would
+    # otherwise grow inside the first rt_integrate that asks for a larger batch)
+    in_flight = render.reserve_samples(args.steps)
 
     # ---- warm-up ------------------------------------------------------------
     render.render_samples(args.warmup) if args.warmup > 0 else None
@@ -274,9 +280,9 @@ def main():
                                                 shade=round(agg[4] / world / args.steps, 4),
                                                 raygen=round(agg[5] / world / args.steps, 4)))
         traffic_file = os.path.join(ROOT, "profiles", "trace_closest_hbm_traffic.json")
-        if world == 1 and args.config == 2 and os.path.exists(traffic_file):   # measured on this workload, N = 1
+        if world == 1 and os.path.exists(traffic_file):   # rocprofv3 --pmc passes of this workload at N = 1
             try:
-                roofline["traffic"] = json.load(open(traffic_file)).get("bytes_per_launch")
+                roofline["traffic"] = json.load(open(traffic_file))["config_%d" % args.config]["bytes_per_launch"]
             except Exception:
                 pass
         name, cus, mem = render_ctx_info(capi, host, render)
@@ -287,7 +293,7 @@ def main():
                                          ", %dx%d, %d-bounce, 1 spp per step, default camera, directional light + "
                                          "CGSkies env map" % (args.width, args.height, args.bounces),
                                 triangles=int(n_tris), width=args.width, height=args.height,
-                                max_bounces=args.bounces, spp=args.steps,
+                                max_bounces=args.bounces, spp=args.steps, samples_in_flight=in_flight,
                                 tiling="%d interleaved %d-row bands per GPU, 1 RCCL gather" % (world, args.band_height)
                                 if world > 1 else "single tile",
                                 rays_per_step=round(total_rays / args.steps, 1), non_finite_pixels=nan_px,

@@ -123,9 +123,14 @@ enum rt_option
                                    2 M paths per launch, 3 above.  Results are identical for every value. */
     , RT_OPT_TRACE_WAVES_PER_CU = 8 /* persistent-grid size of the trace kernels in waves per CU (0 = as many as fit) */
     , RT_OPT_SAMPLES_IN_FLIGHT = 9  /* rt_integrate traces this many consecutive samples per pixel concurrently
-                                       (1..256; 0 = auto, the default: largest power of two <= 64 whose paths fit
-                                       the path-id range and ~96 GB of per-path buffers).  Results are bit-identical for every value: contributions
+                                       (1..256, allocated at once; 0 = auto, the default: up to the largest power
+                                       of two <= 256 whose paths fit the path-id range and ~96 GB of per-path
+                                       buffers, allocated as batches ask for them).  Results are bit-identical for every value: contributions
                                        are logged per path and replayed in the reference's order. */
+    , RT_OPT_TRACE_SELECT_FORM_BOX = 10 /* validation: 1 = every ray uses the reference's compare+select min/max in the
+                                       slab test (trace_bvh.cl:85-97); by default only rays whose 1/dir has a
+                                       non-finite component do (the only ones for which v_min/v_max_f32 could
+                                       differ).  Results are identical for both values. */
 };
 int rt_set_option(rt_frame* frame, int option, uint32_t value);
 int rt_set_camera(rt_frame* frame, const rt_camera* camera);       /* SetCameraData, cl_pt_integrator.cpp:365-371 */
@@ -151,6 +156,12 @@ int rt_denoise(rt_frame* frame);                        /* Denoise (TemporalAccu
 int rt_copy_history(rt_frame* frame);                   /* CopyHistoryBuffers */
 /* fast path: n_samples x Integrate() enqueued without returning to the caller */
 int rt_integrate(rt_frame* frame, uint32_t n_samples);
+/* The per-path buffers (ray queues + radiance log) are sized by the largest batch of samples
+ * requested so far and grow inside rt_integrate when a larger one arrives.  This call sizes
+ * them ahead of time for rt_integrate(n_samples) -- clamped to RT_OPT_SAMPLES_IN_FLIGHT --
+ * and returns the samples the frame can now keep in flight (like vector::reserve; no
+ * reference counterpart: the reference allocates per-pixel state once, cl_pt_integrator.cpp:204-257). */
+int rt_frame_reserve_samples(rt_frame* frame, uint32_t n_samples, uint32_t* reserved);
 
 /* ---- output.  ResolveRadiance (resolve_radiance.cl:31-86) headless: RGBA32F,
  * local_rows x width, row-major.  rt_frame_read_radiance returns the running

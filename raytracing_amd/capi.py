@@ -52,12 +52,13 @@ EXPORTS = [
     "rt_frame_local_rows", "rt_frame_global_row", "rt_set_option", "rt_set_camera", "rt_reset",
     "rt_generate_rays", "rt_intersect", "rt_shade_miss", "rt_clear_outgoing_counter", "rt_clear_shadow_counter",
     "rt_shade", "rt_intersect_shadow", "rt_accumulate_direct", "rt_advance_sample", "rt_integrate",
+    "rt_frame_reserve_samples",
     "rt_compute_aovs", "rt_denoise", "rt_copy_history",
     "rt_frame_resolve", "rt_frame_read_radiance", "rt_frame_radiance_device_ptr", "rt_frame_sample_count",
     "rt_frame_get_stats", "rt_frame_get_profile", "rt_frame_copy_radiance", "rt_frame_debug_read_queue", "rt_frame_debug_read_hits", "rt_debug_eval",
 ]
 
-OPT_MAX_BOUNCES, OPT_WHITE_FURNACE, OPT_SAMPLER, OPT_AOV, OPT_DENOISER, OPT_DROP_LAST, OPT_PROFILE, OPT_TRACE_VARIANT, OPT_TRACE_WAVES, OPT_SAMPLES_IN_FLIGHT = range(10)
+OPT_MAX_BOUNCES, OPT_WHITE_FURNACE, OPT_SAMPLER, OPT_AOV, OPT_DENOISER, OPT_DROP_LAST, OPT_PROFILE, OPT_TRACE_VARIANT, OPT_TRACE_WAVES, OPT_SAMPLES_IN_FLIGHT, OPT_SELECT_FORM_BOX = range(11)
 
 
 def load():
@@ -87,6 +88,7 @@ def load():
         "rt_clear_shadow_counter": (i32, [vp]), "rt_shade": (i32, [vp, u32]),
         "rt_intersect_shadow": (i32, [vp, u32]), "rt_accumulate_direct": (i32, [vp]),
         "rt_advance_sample": (i32, [vp]), "rt_integrate": (i32, [vp, u32]),
+        "rt_frame_reserve_samples": (i32, [vp, u32, C.POINTER(C.c_uint32)]),
         "rt_compute_aovs": (i32, [vp]), "rt_denoise": (i32, [vp]), "rt_copy_history": (i32, [vp]),
         "rt_frame_resolve": (i32, [vp, vp]), "rt_frame_read_radiance": (i32, [vp, vp]),
         "rt_frame_radiance_device_ptr": (vp, [vp]), "rt_frame_sample_count": (u32, [vp]),
@@ -219,6 +221,11 @@ class Frame:
 
     def integrate(self, n=1):
         self._c(self.lib.rt_integrate(self.handle, n))
+
+    def reserve_samples(self, n):
+        got = C.c_uint32(0)
+        self._c(self.lib.rt_frame_reserve_samples(self.handle, n, C.byref(got)))
+        return got.value
 
     # stage API
     def generate_rays(self): self._c(self.lib.rt_generate_rays(self.handle))

@@ -83,10 +83,16 @@ struct DCounters                  // one per frame, device memory
 };
 
 // ray_inv_dir and ray_sign of TraceBvh (trace_bvh.cl:125-129), packed as (inv.xyz, sign bits)
+#define RT_SIGN_SLOW 8u
 RT_DEV float4 ray_inverse(f3 dir)
 {
     f3 inv = F3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
     uint32_t sign_bits = (inv.x < 0.0f ? 1u : 0u) | (inv.y < 0.0f ? 2u : 0u) | (inv.z < 0.0f ? 4u : 0u);
+    // a non-finite component (dir component 0, denormal or NaN) can make the slab test produce
+    // 0 * inf = NaN: such rays keep the select-form min/max of the reference (box_test)
+    const float inf = __builtin_inff();
+    if (!(__builtin_fabsf(inv.x) < inf && __builtin_fabsf(inv.y) < inf && __builtin_fabsf(inv.z) < inf))
+        sign_bits |= RT_SIGN_SLOW;
     return make_float4(inv.x, inv.y, inv.z, __uint_as_float(sign_bits));
 }
 
@@ -202,10 +208,28 @@ RT_DEV bool box_test(float bminx, float bminy, float bminz, float bmaxx, float b
     return tmax >= tmin;
 }
 
+// The same test on v_min_f32 / v_max_f32 (v_min3 / v_max3): 20 VALU per child pair instead
+// of 48 compare+select.  minNum/maxNum differ from the select forms above only (a) in the
+// sign of a zero result -- every value here feeds comparisons only -- and (b) when an
+// operand is NaN, which needs 0 * inf, i.e. a non-finite 1/dir component: rays with one are
+// flagged by the producer (RT_SIGN_SLOW) and take box_test.
+RT_DEV bool box_test_fast(float bminx, float bminy, float bminz, float bmaxx, float bmaxy, float bmaxz, f3 org, f3 inv,
+    float t_min, float t_max, float& entry)
+{
+    float t0x = (bminx - org.x) * inv.x, t0y = (bminy - org.y) * inv.y, t0z = (bminz - org.z) * inv.z;
+    float t1x = (bmaxx - org.x) * inv.x, t1y = (bmaxy - org.y) * inv.y, t1z = (bmaxz - org.z) * inv.z;
+    float lox = __builtin_fminf(t0x, t1x), loy = __builtin_fminf(t0y, t1y), loz = __builtin_fminf(t0z, t1z);
+    float hix = __builtin_fmaxf(t0x, t1x), hiy = __builtin_fmaxf(t0y, t1y), hiz = __builtin_fmaxf(t0z, t1z);
+    float tmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(lox, loy), loz), t_min);
+    float tmax = __builtin_fminf(__builtin_fminf(__builtin_fminf(hix, hiy), hiz), t_max);
+    entry = tmin;
+    return tmax >= tmin;
+}
+
 template <bool SHADOW>
 __global__ __launch_bounds__(64) void k_trace_v1(DScene sc, const float4* __restrict__ o4, const float4* __restrict__ d4,
     const uint32_t* __restrict__ count_ptr, float4* __restrict__ hits, float4* __restrict__ rlog,
-    uint32_t log_stride, uint32_t id_bits, uint2* __restrict__ spill)
+    uint32_t log_stride, uint32_t id_bits, uint32_t /*force_sign_bits: v1 always uses box_test*/, uint2* __restrict__ spill)
 {
     __shared__ uint2 stack[RT_TRACE_STACK_LDS][64];
     const uint32_t lane = threadIdx.x;
@@ -378,7 +402,7 @@ template <bool SHADOW, int STACK>
 __global__ __launch_bounds__(64) void k_trace(DScene sc, const float4* __restrict__ o4, const float4* __restrict__ d4,
     const float4* __restrict__ iv4, const uint32_t* __restrict__ count_ptr, uint32_t* __restrict__ heads,
     float4* __restrict__ hits,
-    float4* __restrict__ rlog, uint32_t log_stride, uint32_t id_bits, uint2* __restrict__ spill)
+    float4* __restrict__ rlog, uint32_t log_stride, uint32_t id_bits, uint32_t force_sign_bits, uint2* __restrict__ spill)
 {
     __shared__ uint2 stack[STACK][64];
     const uint32_t lane = threadIdx.x;
@@ -470,7 +494,7 @@ __global__ __launch_bounds__(64) void k_trace(DScene sc, const float4* __restric
             dir = F3(q1.x, q1.y, q1.z);
             t_max = q0.w;
             inv = F3(q2.x, q2.y, q2.z);
-            sign_bits = __float_as_uint(q2.w);
+            sign_bits = __float_as_uint(q2.w) | force_sign_bits;
             hit_prim = RT_INVALID_ID;
             hit_u = 0.0f; hit_v = 0.0f;
             sp = 0;
@@ -518,8 +542,17 @@ __global__ __launch_bounds__(64) void k_trace(DScene sc, const float4* __restric
             {
                 uint32_t c0 = __float_as_uint(q3.x), c1 = __float_as_uint(q3.y), axis = __float_as_uint(q3.z);
                 float a0, a1;
-                bool h0 = box_test(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, org, inv, t_min, t_max, a0);
-                bool h1 = box_test(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, org, inv, t_min, t_max, a1);
+                bool h0, h1;
+                if (sign_bits & RT_SIGN_SLOW)
+                {
+                    h0 = box_test(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, org, inv, t_min, t_max, a0);
+                    h1 = box_test(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, org, inv, t_min, t_max, a1);
+                }
+                else
+                {
+                    h0 = box_test_fast(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, org, inv, t_min, t_max, a0);
+                    h1 = box_test_fast(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, org, inv, t_min, t_max, a1);
+                }
                 h1 = h1 && (c1 != RT_EMPTY_REF);
                 bool swap = (sign_bits >> axis) & 1u;                        // :181-190
                 uint32_t near_ref = swap ? c1 : c0, far_ref = swap ? c0 : c1;

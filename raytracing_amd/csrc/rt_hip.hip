@@ -65,6 +65,7 @@ struct rt_frame
     uint32_t trace_blocks;       // v1 grid
     uint32_t trace_variant = 5;  // RT_OPT_TRACE_VARIANT (5 = auto)
     uint32_t trace_waves_per_cu = 0;   // RT_OPT_TRACE_WAVES_PER_CU (0 = LDS-limited residency)
+    uint32_t select_form_box = 0;      // RT_OPT_TRACE_SELECT_FORM_BOX: every ray takes the select-form slab test
     // integrator state
     rt_camera camera;
     rt_camera camera_last;        // Integrator::prev_camera_ (integrator.hpp:89)
@@ -466,22 +467,25 @@ uint32_t id_bits_for(uint32_t max_bounces)
 
 size_t bytes_per_path(uint32_t max_bounces) { return 12u * 16u + 4u + 32u * (max_bounces + 1u); }
 
-// auto: the largest power of two <= 64 that keeps tile pixels x samples inside the path-id
+// auto: the largest power of two <= 256 that keeps tile pixels x samples inside the path-id
 // range and the per-path buffers under ~96 GB (a third of the 288 GB of HBM)
 uint32_t auto_slots(uint32_t n_local, uint32_t max_bounces)
 {
     const uint64_t n = n_local ? n_local : 1;
     const uint64_t max_paths = (1ull << id_bits_for(max_bounces)) - 1ull;
-    uint32_t s = 64;
+    uint32_t s = 256;
     while (s > 1 && (s * n > max_paths || s * n * bytes_per_path(max_bounces) > (96ull << 30))) s >>= 1;
     return s;
 }
 
-int alloc_path_buffers(rt_frame* f)
+// the most samples rt_integrate will trace together
+uint32_t slot_cap(const rt_frame* f) { return f->slots_opt ? f->slots_opt : auto_slots(f->n_local, f->max_bounces); }
+
+int alloc_path_buffers(rt_frame* f, uint32_t slots)
 {
     rt_ctx* ctx = f->ctx;
     free_path_buffers(f);
-    f->slots = f->slots_opt ? f->slots_opt : auto_slots(f->n_local, f->max_bounces);
+    f->slots = slots ? slots : 1u;
     f->id_bits = id_bits_for(f->max_bounces);
     uint64_t paths = (uint64_t)(f->n_local ? f->n_local : 1) * f->slots;
     if (paths >= (1ull << f->id_bits)) return fail(ctx, "samples in flight x tile pixels exceeds the path-id range");
@@ -501,6 +505,22 @@ int alloc_path_buffers(rt_frame* f)
     f->cur_slots = 0;
     f->shadow_pending = false;
     return RT_OK;
+}
+
+int flush_log(rt_frame* f);
+
+// Grows the per-path buffers to hold `want` samples in flight (clamped to slot_cap); they
+// are sized by the largest batch actually requested, not by the cap.
+int ensure_slots(rt_frame* f, uint32_t want)
+{
+    uint32_t cap = slot_cap(f);
+    if (want > cap) want = cap;
+    if (want <= f->slots && 2u * (f->max_bounces + 1u) <= f->log_entries && id_bits_for(f->max_bounces) == f->id_bits)
+        return RT_OK;
+    if (flush_log(f) != RT_OK) return RT_ERROR;
+    HIPCHK(f->ctx, hipStreamSynchronize(f->ctx->stream));
+    uint32_t keep = f->slots < cap ? f->slots : cap;
+    return alloc_path_buffers(f, want > keep ? want : keep);
 }
 
 // Adds the logged contributions of the batch in flight to the running sum.
@@ -578,7 +598,7 @@ int rt_frame_create(rt_ctx* ctx, const rt_frame_desc* fd, rt_frame** out)
         (void)hipMemsetAsync(f->prev_radiance, 0, n * sizeof(float4), ctx->stream);
         (void)hipMemsetAsync(f->prev_depth, 0, n * sizeof(float), ctx->stream);
     }
-    ok = ok && alloc_path_buffers(f) == RT_OK;
+    ok = ok && alloc_path_buffers(f, 1) == RT_OK;     // grows on demand (ensure_slots)
     ok = ok && hipMalloc((void**)&f->counters, sizeof(DCounters)) == hipSuccess;
     // worst case over the kernel variants: 32 one-wave blocks per CU, 8-entry LDS stack
     size_t spill_bytes = (size_t)ctx->prop.multiProcessorCount * 32 * 64 * (RT_TRACE_STACK_MAX - 8) * sizeof(uint2);
@@ -631,9 +651,7 @@ int rt_set_option(rt_frame* f, int option, uint32_t value)
             if (flush_log(f) != RT_OK) return RT_ERROR;
             HIPCHK(f->ctx, hipStreamSynchronize(f->ctx->stream));
             f->max_bounces = value;
-            if (2u * (value + 1u) > f->log_entries || id_bits_for(value) != f->id_bits ||
-                (!f->slots_opt && auto_slots(f->n_local, value) != f->slots))
-                return alloc_path_buffers(f);
+            return ensure_slots(f, 1);                // log rows / payload split follow max_bounces
         }
         return RT_OK;
     case RT_OPT_SAMPLES_IN_FLIGHT:
@@ -642,9 +660,15 @@ int rt_set_option(rt_frame* f, int option, uint32_t value)
         {
             if (flush_log(f) != RT_OK) return RT_ERROR;
             HIPCHK(f->ctx, hipStreamSynchronize(f->ctx->stream));
-            uint32_t old = f->slots_opt;
+            uint32_t old = f->slots_opt, old_slots = f->slots;
             f->slots_opt = value;
-            if (alloc_path_buffers(f) != RT_OK) { f->slots_opt = old; (void)alloc_path_buffers(f); return RT_ERROR; }
+            // an explicit count is allocated now; auto (0) grows with the batches requested
+            if (alloc_path_buffers(f, value ? value : 1u) != RT_OK)
+            {
+                f->slots_opt = old;
+                (void)alloc_path_buffers(f, old_slots);
+                return RT_ERROR;
+            }
         }
         return RT_OK;
     case RT_OPT_WHITE_FURNACE: f->white_furnace = value ? 1 : 0; return RT_OK;
@@ -668,6 +692,7 @@ int rt_set_option(rt_frame* f, int option, uint32_t value)
     case RT_OPT_TRACE_DROP_LAST_BOUNCE_RAYS: f->drop_last = value ? 1 : 0; return RT_OK;
     case RT_OPT_PROFILE_KERNELS: f->profile = value ? 1 : 0; return RT_OK;
     case RT_OPT_TRACE_WAVES_PER_CU: f->trace_waves_per_cu = value; return RT_OK;
+    case RT_OPT_TRACE_SELECT_FORM_BOX: f->select_form_box = value ? RT_SIGN_SLOW : 0u; return RT_OK;
     case RT_OPT_TRACE_VARIANT:
         if (value > 5) return fail(f->ctx, "rt_set_option: unknown trace kernel variant");
         f->trace_variant = value;
@@ -732,7 +757,7 @@ void launch_trace_sm(rt_frame* f, const float4* o4, const float4* d4, const floa
     uint32_t blocks = ((uint32_t)ctx->prop.multiProcessorCount * per_cu + 7u) & ~7u;
     hipLaunchKernelGGL((k_trace<SHADOW, STACK>), dim3(blocks), dim3(64), 0, ctx->stream, ctx->scene.d, o4, d4, iv4, count,
         &f->counters->head[SHADOW ? 1 : 0][0], SHADOW ? (float4*)nullptr : f->hits,
-        SHADOW ? f->rlog : (float4*)nullptr, f->log_stride, f->id_bits, f->spill);
+        SHADOW ? f->rlog : (float4*)nullptr, f->log_stride, f->id_bits, f->select_form_box, f->spill);
 }
 
 template <bool SHADOW>
@@ -754,7 +779,7 @@ void launch_trace(rt_frame* f, const float4* o4, const float4* d4, const float4*
     case 0:
         hipLaunchKernelGGL(k_trace_v1<SHADOW>, dim3(f->trace_waves_per_cu ? (((uint32_t)ctx->prop.multiProcessorCount *
             (f->trace_waves_per_cu < 13u ? f->trace_waves_per_cu : 13u) + 7u) & ~7u) : f->trace_blocks), dim3(64), 0, ctx->stream, ctx->scene.d, o4, d4,
-            count, SHADOW ? (float4*)nullptr : f->hits, SHADOW ? f->rlog : (float4*)nullptr, f->log_stride, f->id_bits, f->spill);
+            count, SHADOW ? (float4*)nullptr : f->hits, SHADOW ? f->rlog : (float4*)nullptr, f->log_stride, f->id_bits, f->select_form_box, f->spill);
         break;
     case 1: launch_trace_sm<SHADOW, 16>(f, o4, d4, iv4, count); break;
     case 2: launch_trace_sm<SHADOW, 24>(f, o4, d4, iv4, count); break;
@@ -791,7 +816,8 @@ int generate_rays(rt_frame* f, uint32_t n_slots)
 {
     rt_ctx* ctx = f->ctx;
     if (f->cur_slots != 0) return fail(ctx, "rt_generate_rays: the previous sample was not advanced (rt_advance_sample)");
-    if (2u * (f->max_bounces + 1u) > f->log_entries && alloc_path_buffers(f) != RT_OK) return RT_ERROR;
+    if (ensure_slots(f, n_slots) != RT_OK) return RT_ERROR;
+    if (n_slots > f->slots) return fail(ctx, "rt_generate_rays: more samples than the frame can keep in flight");
     float tan_half_fov = rt_tanf(0.5f * f->camera.fov);  // raygeneration.cl:108, uniform -> host
     uint32_t blocks = (f->n_local * n_slots + 255u) / 256u;
     if (blocks == 0) blocks = 1;
@@ -922,6 +948,14 @@ int rt_advance_sample(rt_frame* f)                      // AdvanceSampleCount, :
     return RT_OK;
 }
 
+int rt_frame_reserve_samples(rt_frame* f, uint32_t n_samples, uint32_t* reserved)
+{
+    FRAME_PROLOGUE(f, "rt_frame_reserve_samples");
+    if (ensure_slots(f, n_samples ? n_samples : 1u) != RT_OK) return RT_ERROR;
+    if (reserved) *reserved = f->slots;
+    return RT_OK;
+}
+
 int rt_integrate(rt_frame* f, uint32_t n_samples)       // n x Integrator::Integrate(), integrator.cpp:27-59
 {
     FRAME_PROLOGUE(f, "rt_integrate");
@@ -929,9 +963,11 @@ int rt_integrate(rt_frame* f, uint32_t n_samples)       // n x Integrator::Integ
     // fuller machine, shorter relative tails); the radiance log keeps the sum exact.
     uint32_t done = 0;
     const bool per_frame = f->denoiser || f->aov != 0;  // interactive features: one sample per Integrate()
+    const uint32_t cap = per_frame ? 1u : slot_cap(f);
+    if (ensure_slots(f, n_samples < cap ? n_samples : cap) != RT_OK) return RT_ERROR;
     while (done < n_samples)
     {
-        uint32_t batch = n_samples - done < f->slots ? n_samples - done : f->slots;
+        uint32_t batch = n_samples - done < cap ? n_samples - done : cap;
         if (per_frame) batch = 1;
         if (f->denoiser && rt_reset(f) != RT_OK) return RT_ERROR;   // integrator.cpp:29: Reset() every frame
         if (generate_rays(f, batch) != RT_OK) return RT_ERROR;

@@ -21,7 +21,7 @@ EXPORTS = [
     "rth_render_finish", "rth_render_local_rows", "rth_render_global_row", "rth_render_sample_count",
     "rth_render_read_radiance", "rth_render_read_resolved", "rth_render_stats", "rth_render_frame_handle",
     "rth_render_ctx_handle", "rth_render_num_nodes", "rth_render_nodes", "rth_render_set_aov", "rth_render_resolve",
-    "rth_render_set_blue_noise_path",
+    "rth_render_set_blue_noise_path", "rth_render_reserve_samples",
 ]
 
 
@@ -52,7 +52,7 @@ def load():
         "rth_render_set_camera": (i32, [vp, vp]), "rth_render_set_max_bounces": (i32, [vp, u32]),
         "rth_render_enable_white_furnace": (i32, [vp, i32]), "rth_render_set_sampler": (i32, [vp, i32]),
         "rth_render_enable_denoiser": (i32, [vp, i32]), "rth_render_set_resolve_every_frame": (i32, [vp, i32]),
-        "rth_render_frame": (i32, [vp]), "rth_render_samples": (i32, [vp, u32]), "rth_render_finish": (i32, [vp]),
+        "rth_render_frame": (i32, [vp]), "rth_render_samples": (i32, [vp, u32]), "rth_render_reserve_samples": (i32, [vp, u32]), "rth_render_finish": (i32, [vp]),
         "rth_render_local_rows": (u32, [vp]), "rth_render_global_row": (u32, [vp, u32]),
         "rth_render_sample_count": (u32, [vp]), "rth_render_read_radiance": (i32, [vp, vp]),
         "rth_render_read_resolved": (i32, [vp, vp]), "rth_render_stats": (i32, [vp, C.POINTER(rt_stats)]),
@@ -224,6 +224,13 @@ class Render:
     def set_resolve_every_frame(self, e): self._c(self.lib.rth_render_set_resolve_every_frame(self.handle, int(e)))
     def render_frame(self): self._c(self.lib.rth_render_frame(self.handle))
     def render_samples(self, n): self._c(self.lib.rth_render_samples(self.handle, n))
+
+    def reserve_samples(self, n):
+        """Size the device's per-path buffers for render_samples(n); returns the samples traced together."""
+        r = self.lib.rth_render_reserve_samples(self.handle, n)
+        if r < 0:
+            self._c(1)
+        return r
     def finish(self): self._c(self.lib.rth_render_finish(self.handle))
     def sample_count(self): return self.lib.rth_render_sample_count(self.handle)
 

@@ -173,6 +173,14 @@ void HIPPathTraceIntegrator::IntegrateSamples(std::uint32_t n_samples)
     Check(rt_integrate(frame_, n_samples));
 }
 
+std::uint32_t HIPPathTraceIntegrator::ReserveSamples(std::uint32_t n_samples)
+{
+    SyncOptions();
+    std::uint32_t reserved = 0;
+    Check(rt_frame_reserve_samples(frame_, n_samples, &reserved));
+    return reserved;
+}
+
 std::vector<float> HIPPathTraceIntegrator::ReadRadianceSum() const
 {
     std::vector<float> out((size_t)rt_frame_local_rows(frame_) * width_ * 4);

@@ -59,6 +59,9 @@ public:
 
     // Fast path: n x Integrate() without leaving the native side between stages.
     void IntegrateSamples(std::uint32_t n_samples);
+    // Sizes the per-path device buffers for IntegrateSamples(n_samples) ahead of time; returns the
+    // number of samples the device will trace together.
+    std::uint32_t ReserveSamples(std::uint32_t n_samples);
     // Headless outputs (the reference writes a GL-shared image in ResolveRadiance).
     std::vector<float> const& GetResolvedImage() const { return resolved_; }   // local_rows x width x RGBA
     std::vector<float> ReadRadianceSum() const;

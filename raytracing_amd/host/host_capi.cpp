@@ -156,6 +156,10 @@ int rth_render_resolve(void* r, float* out)
 int rth_render_set_resolve_every_frame(void* r, int e) { ((rt::Render*)r)->GetIntegrator().SetResolveEveryFrame(e != 0); return 0; }
 int rth_render_frame(void* r) { return guard([&]() { ((rt::Render*)r)->RenderFrame(); return 0; }, 1); }
 int rth_render_samples(void* r, uint32_t n) { return guard([&]() { ((rt::Render*)r)->RenderSamples(n); return 0; }, 1); }
+int rth_render_reserve_samples(void* r, uint32_t n)
+{
+    return guard([&]() { return (int)((rt::Render*)r)->GetIntegrator().ReserveSamples(n); }, -1);
+}
 int rth_render_finish(void* r) { return guard([&]() { ((rt::Render*)r)->GetContext().Finish(); return 0; }, 1); }
 uint32_t rth_render_local_rows(void* r) { return ((rt::Render*)r)->GetIntegrator().GetLocalRows(); }
 uint32_t rth_render_global_row(void* r, uint32_t row) { return ((rt::Render*)r)->GetIntegrator().GetGlobalRow(row); }

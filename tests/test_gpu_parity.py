@@ -483,6 +483,66 @@ def test_degenerate_bvhs(ctx, env_map, variant):
         assert (st.closest_rays, st.shadow_rays) == orc.ray_totals(), name
 
 
+def test_axis_aligned_rays_and_select_form_slab_test(ctx, env_map, golden_scenes):
+    """k_trace runs the slab test on v_min/v_max_f32 except for rays whose 1/dir has a
+    non-finite component (0 * inf = NaN is where minNum/maxNum and the reference's
+    compare+select forms differ) -- those keep the select forms.  An overhead light along
+    +z makes EVERY shadow ray such a ray (dir = (0, 0, 1), 1/dir = (inf, inf, 1)), over
+    axis-aligned geometry whose box planes the ray origins sit on; RT_OPT_TRACE_SELECT_FORM_BOX
+    forces the select forms for all rays and must not change a bit."""
+    quads = []
+    for z, half in ((0.0, 3.0), (0.5, 0.5), (1.0, 0.25)):           # stacked axis-aligned plates
+        a, b, c, d = (-half, 1 - half, z), (half, 1 - half, z), (half, 1 + half, z), (-half, 1 + half, z)
+        quads += [[a, b, c], [a, c, d]]
+    n = len(quads)
+    P = np.array(quads, np.float32).reshape(n, 3, 3)
+    N = np.tile(np.array([0, 0, 1], np.float32), (n, 3, 1))
+    tris = S.to_triangles([(P, N, np.zeros((n, 3, 2), np.float32), 0)])
+    mats = np.array([S.make_material(kd=(0.7, 0.7, 0.7), ks=(0.3, 0.3, 0.3), roughness=0.4)], dtype=T.packed_material)
+    s = host.Scene(arrays=dict(triangles=tris, materials=mats))
+    s.add_directional_light((0.0, 0.0, 1.0), (6.0, 6.0, 6.0))
+    s.build_bvh(); s.set_env_image(env_map); s.finalize()
+    w, h = 64, 48
+    cam = T.default_camera(w, h)
+    for sc, bounces in ((s.arrays(), 4), (golden_scenes["coverage"], 6)):
+        imgs = []
+        for select in (0, 1):
+            ctx.upload_scene(sc)
+            fr = capi.Frame(ctx, w, h)
+            fr.set_camera(cam); fr.set_max_bounces(bounces)
+            fr.set_option(capi.OPT_SELECT_FORM_BOX, select)
+            fr.integrate(4)
+            imgs.append(fr.radiance()[..., :3].copy())
+            st = fr.stats()
+        orc = _oracle.Oracle(w, h, sc)
+        orc.set_camera(cam); orc.set_max_bounces(bounces); orc.integrate(4)
+        assert np.array_equal(imgs[0], imgs[1], equal_nan=True)
+        assert np.array_equal(imgs[0], orc.radiance()[..., :3], equal_nan=True)
+        assert (st.closest_rays, st.shadow_rays) == orc.ray_totals()
+
+
+def test_reserve_samples_and_lazy_path_buffers(ctx, golden_scenes):
+    """Per-path buffers follow the largest batch requested (rt_frame_reserve_samples or
+    rt_integrate) instead of the cap; growing them between batches keeps the sum exact."""
+    w, h, b = 64, 48, 5
+    sc = golden_scenes["coverage"]
+    cam = T.default_camera(w, h)
+    base = render(ctx, sc, w, h, cam, b, 9, slots=1)
+    ctx.upload_scene(sc)
+    fr = capi.Frame(ctx, w, h)
+    fr.set_camera(cam); fr.set_max_bounces(b)
+    assert fr.reserve_samples(4) == 4
+    fr.integrate(2)                      # fits the reservation
+    assert fr.reserve_samples(1) == 4    # never shrinks
+    fr.integrate(7)                      # grows to 7 in flight with 2 samples already accumulated
+    assert fr.reserve_samples(0) == 7
+    assert fr.sample_count() == 9
+    assert np.array_equal(fr.radiance(), base.radiance(), equal_nan=True)
+    assert fr.reserve_samples(100000) == 256          # clamped to the auto cap at this tile size
+    fr.set_option(capi.OPT_SAMPLES_IN_FLIGHT, 3)      # explicit: allocated at once, and the new cap
+    assert fr.reserve_samples(50) == 3
+
+
 def test_rt_render_cli(tmp_path):
     """The headless CLI with the reference's flags (main.cpp:42-53) renders the Cornell box."""
     import subprocess
