@@ -469,18 +469,22 @@ __global__ __launch_bounds__(64) void k_trace(DScene sc, const float4* __restric
         if (__ballot(state != ST_DONE) == 0ull) break;
 
         // ---- ONE 64-byte record per lane: ray | node | triangle -----------------
-        const float4 *p0, *p1, *p2, *p3;
-        if (state == ST_RAY) { p0 = o4 + ray_i; p1 = d4 + ray_i; p2 = iv4 + ray_i; p3 = p2; }
+        // (the L1 sees one access per lane per load instruction: only child-pair nodes use
+        // the fourth 16 bytes, so triangle and ray lanes skip that load)
+        const float4 *p0, *p1, *p2;
+        const bool is_node = state == ST_TRAV && !(ref & RT_LEAF_BIT);
+        if (state == ST_RAY) { p0 = o4 + ray_i; p1 = d4 + ray_i; p2 = iv4 + ray_i; }
         else
         {
             const float4* base = (ref & RT_LEAF_BIT) ? sc.tris_rt + (size_t)(ref & ~RT_LEAF_BIT) * 4
                                                      : sc.nodes + (size_t)ref * 4;
-            p0 = base; p1 = base + 1; p2 = base + 2; p3 = base + 3;
+            p0 = base; p1 = base + 1; p2 = base + 2;
         }
-        float4 q0 = make_float4(0, 0, 0, 0), q1 = q0, q2 = q0, q3 = q0;
+        float4 q0, q1, q2, q3;
         if (state != ST_DONE)
         {
-            q0 = *p0; q1 = *p1; q2 = *p2; q3 = *p3;
+            q0 = *p0; q1 = *p1; q2 = *p2;
+            if (is_node) q3 = p2[1];
         }
         if (SHADOW && state == ST_RAY) payload = __float_as_uint(q1.w);
 
