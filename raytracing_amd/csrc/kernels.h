@@ -213,15 +213,23 @@ RT_DEV bool box_test(float bminx, float bminy, float bminz, float bmaxx, float b
 // sign of a zero result -- every value here feeds comparisons only -- and (b) when an
 // operand is NaN, which needs 0 * inf, i.e. a non-finite 1/dir component: rays with one are
 // flagged by the producer (RT_SIGN_SLOW) and take box_test.
+// (v_min/v_max are issued directly: through fminf/fmaxf the compiler first quiets every
+// operand with a v_max_f32 x, x, eight extra instructions per child pair that only matter for
+// signalling NaNs, which cannot occur here.)
+RT_DEV float hw_min(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+RT_DEV float hw_max(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+RT_DEV float hw_min3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+RT_DEV float hw_max3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+
 RT_DEV bool box_test_fast(float bminx, float bminy, float bminz, float bmaxx, float bmaxy, float bmaxz, f3 org, f3 inv,
     float t_min, float t_max, float& entry)
 {
     float t0x = (bminx - org.x) * inv.x, t0y = (bminy - org.y) * inv.y, t0z = (bminz - org.z) * inv.z;
     float t1x = (bmaxx - org.x) * inv.x, t1y = (bmaxy - org.y) * inv.y, t1z = (bmaxz - org.z) * inv.z;
-    float lox = __builtin_fminf(t0x, t1x), loy = __builtin_fminf(t0y, t1y), loz = __builtin_fminf(t0z, t1z);
-    float hix = __builtin_fmaxf(t0x, t1x), hiy = __builtin_fmaxf(t0y, t1y), hiz = __builtin_fmaxf(t0z, t1z);
-    float tmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(lox, loy), loz), t_min);
-    float tmax = __builtin_fminf(__builtin_fminf(__builtin_fminf(hix, hiy), hiz), t_max);
+    float lox = hw_min(t0x, t1x), loy = hw_min(t0y, t1y), loz = hw_min(t0z, t1z);
+    float hix = hw_max(t0x, t1x), hiy = hw_max(t0y, t1y), hiz = hw_max(t0z, t1z);
+    float tmin = hw_max(hw_max3(lox, loy, loz), t_min);
+    float tmax = hw_min(hw_min3(hix, hiy, hiz), t_max);
     entry = tmin;
     return tmax >= tmin;
 }
