@@ -138,7 +138,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=256)
-    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=64)
     ap.add_argument("--config", type=int, default=4, choices=sorted(CONFIGS),
                     help="BASELINE.json config (1-based index into 'configs'); default 4 = the one the metric is quoted on "
                          "(Bistro 1080p 8-bounce stand-in)")
@@ -282,7 +282,14 @@ def main():
         traffic_file = os.path.join(ROOT, "profiles", "trace_closest_hbm_traffic.json")
         if world == 1 and os.path.exists(traffic_file):   # rocprofv3 --pmc passes of this workload at N = 1
             try:
-                roofline["traffic"] = json.load(open(traffic_file))["config_%d" % args.config]["bytes_per_launch"]
+                pmc = json.load(open(traffic_file))["config_%d" % args.config]
+                roofline["traffic"] = pmc["bytes_per_launch"]
+                # what actually binds the kernel (rocprofv3 --pmc, profiles/): HBM moves only
+                # `traffic` bytes per launch -- nodes and triangles are re-read from L1/L2 -- while
+                # the vector ALU issue slots and the L1's one-access-per-clock rate are saturated
+                roofline["hbm_rate_GBs"] = round(pmc["bytes_per_launch"] / (ms_sum / n_launch * 1e-3) / 1e9, 1)
+                roofline["pmc"] = {k: round(pmc[k], 4) for k in ("valu_issue_utilisation", "l1_accesses_per_clk_per_cu",
+                                                                 "l1_hit_rate", "l2_hit_rate")}
             except Exception:
                 pass
         name, cus, mem = render_ctx_info(capi, host, render)

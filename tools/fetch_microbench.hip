@@ -62,7 +62,7 @@ int main(int argc, char** argv)
     for (size_t i = 0; i < h.size(); ++i)
     {
         s = s * 1664525u + 1013904223u;
-        unsigned v = s % n_recs;
+        unsigned v = (s >> 5) % n_recs;              // high LCG bits: the low ones cycle quickly
         float f; memcpy(&f, &v, 4);
         h[i] = make_float4(f, (float)(i & 255), 1.0f, 2.0f);
     }

@@ -16,7 +16,7 @@ run tcc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum
 run sq SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES GRBM_GUI_ACTIVE
 run tcp TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_PENDING_STALL_CYCLES_sum
 # calibration of FETCH_SIZE on this kernel's access pattern: random 64-byte records out of a
-# 4 GiB table (beyond the 256 MiB Infinity Cache), known byte count = records x 64
+# 3.8 GB table (beyond the 256 MiB Infinity Cache), known byte count = records x 64
 hipcc --offload-arch=gfx950 -O3 $R/tools/fetch_microbench.hip -o /tmp/fetch_mb 2> $D/calib_build.log
-rocprofv3 --pmc FETCH_SIZE TCC_EA0_RDREQ_sum --output-format csv -d $D -o calib -- /tmp/fetch_mb 67108864 > $D/calib.log 2>&1
+rocprofv3 --pmc FETCH_SIZE TCC_EA0_RDREQ_sum --output-format csv -d $D -o calib -- /tmp/fetch_mb 60000001 > $D/calib.log 2>&1
 ls $D
