@@ -118,9 +118,10 @@ enum rt_option
     RT_OPT_DENOISER = 4,       /* Integrator::EnableDenoiser: temporal reprojection (denoiser.cl); needs tile_count == 1 */
     RT_OPT_TRACE_DROP_LAST_BOUNCE_RAYS = 5, /* 1 (default): do not emit the never-traced rays of the last bounce */
     RT_OPT_PROFILE_KERNELS = 6, /* 1: bracket every kernel launch with HIP events on the context stream */
-    RT_OPT_TRACE_VARIANT = 7    /* traversal kernel: 0 = v1 per-ray loop; 1 .. 4 = one-fetch-per-iteration state
-                                   machine with a 16 / 24 / 12 / 8 entry LDS stack; 5 (default) = auto: 0 below
-                                   2 M paths per launch, 3 above.  Results are identical for every value. */
+    RT_OPT_TRACE_VARIANT = 7    /* traversal kernel: 0 = v1 per-ray loop; 1 .. 4, 6, 7 = one-fetch-per-iteration
+                                   state machine with a 16 / 24 / 12 / 8, 10 / 11 entry LDS stack; 5 (default) =
+                                   auto: 0 below 2 M paths per launch, 3 above.  Results are identical for every
+                                   value. */
     , RT_OPT_TRACE_WAVES_PER_CU = 8 /* persistent-grid size of the trace kernels in waves per CU (0 = as many as fit) */
     , RT_OPT_SAMPLES_IN_FLIGHT = 9  /* rt_integrate traces this many consecutive samples per pixel concurrently
                                        (1..256, allocated at once; 0 = auto, the default: up to the largest power

@@ -407,7 +407,7 @@ __global__ __launch_bounds__(64) void k_trace_v1(DScene sc, const float4* __rest
 enum { ST_NEED = 0, ST_RAY = 1, ST_TRAV = 2, ST_DONE = 3 };
 
 template <bool SHADOW, int STACK>
-__global__ __launch_bounds__(64) void k_trace(DScene sc, const float4* __restrict__ o4, const float4* __restrict__ d4,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(STACK <= 10 ? 8 : 6, 8))) void k_trace(DScene sc, const float4* __restrict__ o4, const float4* __restrict__ d4,
     const float4* __restrict__ iv4, const uint32_t* __restrict__ count_ptr, uint32_t* __restrict__ heads,
     float4* __restrict__ hits,
     float4* __restrict__ rlog, uint32_t log_stride, uint32_t id_bits, uint32_t force_sign_bits, uint2* __restrict__ spill)

@@ -694,7 +694,7 @@ int rt_set_option(rt_frame* f, int option, uint32_t value)
     case RT_OPT_TRACE_WAVES_PER_CU: f->trace_waves_per_cu = value; return RT_OK;
     case RT_OPT_TRACE_SELECT_FORM_BOX: f->select_form_box = value ? RT_SIGN_SLOW : 0u; return RT_OK;
     case RT_OPT_TRACE_VARIANT:
-        if (value > 5) return fail(f->ctx, "rt_set_option: unknown trace kernel variant");
+        if (value > 7) return fail(f->ctx, "rt_set_option: unknown trace kernel variant");
         f->trace_variant = value;
         return RT_OK;
     default: return fail(f->ctx, "rt_set_option: unknown option");
@@ -784,6 +784,8 @@ void launch_trace(rt_frame* f, const float4* o4, const float4* d4, const float4*
     case 1: launch_trace_sm<SHADOW, 16>(f, o4, d4, iv4, count); break;
     case 2: launch_trace_sm<SHADOW, 24>(f, o4, d4, iv4, count); break;
     case 4: launch_trace_sm<SHADOW, 8>(f, o4, d4, iv4, count); break;
+    case 6: launch_trace_sm<SHADOW, 10>(f, o4, d4, iv4, count); break;
+    case 7: launch_trace_sm<SHADOW, 11>(f, o4, d4, iv4, count); break;
     default: launch_trace_sm<SHADOW, 12>(f, o4, d4, iv4, count); break;
     }
 }

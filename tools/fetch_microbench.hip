@@ -6,6 +6,10 @@
 //           global_load_lds_dwordx4 (16 contiguous-64B requests per instruction),
 //           4 instructions cover the wave, data lands in LDS and every lane reads
 //           its own record back with 4 x ds_read_b128
+//   mode 2: as mode 1, but (a) the record indices travel through LDS as one ds_write_b32 +
+//           4 broadcast ds_read_b32 instead of 8 bpermutes, and (b) the piece each loader lane
+//           fetches is rotated by (record >> 2) so that the readback at a 64-byte lane stride
+//           is bank-conflict free
 // Build: hipcc --offload-arch=gfx950 -O3 tools/fetch_microbench.hip -o /tmp/fetch_mb
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -18,6 +22,7 @@ __global__ __launch_bounds__(64) void k_fetch(const float4* __restrict__ recs, u
     unsigned coherence, float4* __restrict__ out)
 {
     __shared__ float4 stage[4][64];
+    __shared__ unsigned idxs[64];
     const unsigned lane = threadIdx.x;
     unsigned idx = (blockIdx.x * 64u + lane) * 2654435761u;
     if (coherence) idx = (blockIdx.x * 2654435761u) + lane / coherence;   // groups of lanes share records
@@ -30,6 +35,24 @@ __global__ __launch_bounds__(64) void k_fetch(const float4* __restrict__ recs, u
         if (MODE == 0)
         {
             q0 = base[0]; q1 = base[1]; q2 = base[2]; q3 = base[3];
+        }
+        else if (MODE == 2)
+        {
+            idxs[lane] = idx;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const unsigned piece = ((lane & 3u) - (lane >> 4)) & 3u;
+            for (int k = 0; k < 4; ++k)
+            {
+                unsigned us = idxs[16 * k + (lane >> 2)];
+                const float4* p = recs + (size_t)us * 4 + piece;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
+                    (__attribute__((address_space(3))) void*)&stage[k][0], 16, 0, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const float4* mine = &stage[0][0] + lane * 4;
+            const unsigned rot = lane >> 2;
+            q0 = mine[(0 + rot) & 3]; q1 = mine[(1 + rot) & 3]; q2 = mine[(2 + rot) & 3]; q3 = mine[(3 + rot) & 3];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
         else
         {
@@ -72,12 +95,13 @@ int main(int argc, char** argv)
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
     std::vector<float4> r0((size_t)blocks * 64), r1((size_t)blocks * 64);
     for (unsigned coh : {0u, 4u, 16u})
-        for (int mode = 0; mode < 2; ++mode)
+        for (int mode = 0; mode < 3; ++mode)
         {
             for (int rep = 0; rep < 2; ++rep)
             {
                 hipEventRecord(a);
                 if (mode == 0) hipLaunchKernelGGL(k_fetch<0>, dim3(blocks), dim3(64), 0, 0, d, n_recs, iters, coh, out);
+                else if (mode == 2) hipLaunchKernelGGL(k_fetch<2>, dim3(blocks), dim3(64), 0, 0, d, n_recs, iters, coh, out);
                 else hipLaunchKernelGGL(k_fetch<1>, dim3(blocks), dim3(64), 0, 0, d, n_recs, iters, coh, out);
                 hipEventRecord(b); hipEventSynchronize(b);
             }
@@ -86,7 +110,7 @@ int main(int argc, char** argv)
             double fetches = (double)blocks * 64 * iters;
             printf("coherence %2u mode %d: %.3f ms, %.2f G records/s, %.2f TB/s of 64-byte records\n", coh, mode, ms,
                 fetches / ms / 1e6, fetches * 64 / ms / 1e9);
-            if (mode == 1) printf("   results identical: %s\n", memcmp(r0.data(), r1.data(), r0.size() * 16) == 0 ? "yes" : "NO");
+            if (mode >= 1) printf("   results identical: %s\n", memcmp(r0.data(), r1.data(), r0.size() * 16) == 0 ? "yes" : "NO");
         }
     return 0;
 }

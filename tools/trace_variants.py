@@ -15,12 +15,19 @@ ap.add_argument("--bounces", type=int, default=8)
 ap.add_argument("--waves", default="0")
 ap.add_argument("--slots", default="1")
 ap.add_argument("--select", default="0", help="RT_OPT_TRACE_SELECT_FORM_BOX values to sweep")
+ap.add_argument("--config", type=int, default=0, help="bench.py config (scene, frame, bounces) instead of --tris/--width/--height/--bounces")
 args = ap.parse_args()
 
-tris, mats = S.cornell_blob(args.tris, 20000)
-scene = host.Scene(arrays=dict(triangles=tris, materials=mats))
-scene.add_directional_light((-0.6, -1.5, 3.5), (15., 10., 5.))
-scene.set_env_path(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "assets", "ibl", "CGSkies_0036_free.hdr"))
+if args.config:
+    import bench
+    cfg = bench.CONFIGS[args.config]
+    args.width, args.height, args.bounces = cfg["width"], cfg["height"], cfg["bounces"]
+    scene, _ = bench.build_scene(argparse.Namespace(config=args.config, blob_tris=871200, ball_tris=20000), host, S)
+else:
+    tris, mats = S.cornell_blob(args.tris, 20000)
+    scene = host.Scene(arrays=dict(triangles=tris, materials=mats))
+    scene.add_directional_light((-0.6, -1.5, 3.5), (15., 10., 5.))
+    scene.set_env_path(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "assets", "ibl", "CGSkies_0036_free.hdr"))
 render = host.Render(args.width, args.height, scene)
 render.set_camera(host.default_camera(args.width, args.height))
 render.set_max_bounces(args.bounces)
