@@ -37,8 +37,8 @@
 #define RT_EMPTY_REF 0xFFFFFFFFu
 #define RT_TRACE_STACK_LDS 24     // per-lane stack entries kept in LDS
 #define RT_TRACE_STACK_MAX 64     // the reference's nodesToVisit[64] (trace_bvh.cl:142)
-// A shadow ray's payload = log entry << id_bits | path id.  id_bits is chosen per frame:
-// 32 - bits(2 * (max_bounces + 1)), e.g. 27 bits (134 M paths) for 8 bounces.
+// A shadow ray carries its path id in direction.w and, in the w of its 1/direction record,
+// sign bits | RT_SIGN_SLOW | (radiance-log entry of its deferred direct sample << 8).
 
 struct DScene
 {
@@ -236,8 +236,9 @@ RT_DEV bool box_test_fast(float bminx, float bminy, float bminz, float bmaxx, fl
 
 template <bool SHADOW>
 __global__ __launch_bounds__(64) void k_trace_v1(DScene sc, const float4* __restrict__ o4, const float4* __restrict__ d4,
-    const uint32_t* __restrict__ count_ptr, float4* __restrict__ hits, float4* __restrict__ rlog,
-    uint32_t log_stride, uint32_t id_bits, uint32_t /*force_sign_bits: v1 always uses box_test*/, uint2* __restrict__ spill)
+    const float4* __restrict__ iv4, const uint32_t* __restrict__ count_ptr, float4* __restrict__ hits,
+    float4* __restrict__ rlog, uint32_t log_stride, uint32_t /*force_sign_bits: v1 always uses box_test*/,
+    uint2* __restrict__ spill)
 {
     __shared__ uint2 stack[RT_TRACE_STACK_LDS][64];
     const uint32_t lane = threadIdx.x;
@@ -375,8 +376,8 @@ __global__ __launch_bounds__(64) void k_trace_v1(DScene sc, const float4* __rest
             // logged the direct sample tentatively; an occluded ray retracts it
             if (occluded)
             {
-                uint32_t payload = __float_as_uint(rd.w);
-                rlog[(size_t)(payload >> id_bits) * log_stride + (payload & ((1u << id_bits) - 1u))] = make_float4(0, 0, 0, 0);
+                uint32_t entry = __float_as_uint(iv4[i].w) >> 8;
+                rlog[(size_t)entry * log_stride + __float_as_uint(rd.w)] = make_float4(0, 0, 0, 0);
             }
         }
         else
@@ -410,7 +411,7 @@ template <bool SHADOW, int STACK>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(STACK <= 10 ? 8 : 6, 8))) void k_trace(DScene sc, const float4* __restrict__ o4, const float4* __restrict__ d4,
     const float4* __restrict__ iv4, const uint32_t* __restrict__ count_ptr, uint32_t* __restrict__ heads,
     float4* __restrict__ hits,
-    float4* __restrict__ rlog, uint32_t log_stride, uint32_t id_bits, uint32_t force_sign_bits, uint2* __restrict__ spill)
+    float4* __restrict__ rlog, uint32_t log_stride, uint32_t force_sign_bits, uint2* __restrict__ spill)
 {
     __shared__ uint2 stack[STACK][64];
     const uint32_t lane = threadIdx.x;
@@ -428,7 +429,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(STACK <= 10 
     int sp = 0;
     f3 org = F3s(0.0f), dir = F3s(0.0f), inv = F3s(0.0f);
     float t_max = 0.0f, hit_u = 0.0f, hit_v = 0.0f;
-    uint32_t payload = 0;                                                    // SHADOW: log entry << 25 | path id
+    uint32_t payload = 0, log_entry = 0;                                     // SHADOW: path id, radiance-log entry
     const float t_min = 0.0f;
 
     for (;;)
@@ -494,7 +495,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(STACK <= 10 
             q0 = *p0; q1 = *p1; q2 = *p2;
             if (is_node) q3 = p2[1];
         }
-        if (SHADOW && state == ST_RAY) payload = __float_as_uint(q1.w);
+        if (SHADOW && state == ST_RAY) { payload = __float_as_uint(q1.w); log_entry = __float_as_uint(q2.w) >> 8; }
 
         bool finished = false, need_pop = false;
         if (state == ST_RAY)
@@ -506,7 +507,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(STACK <= 10 
             dir = F3(q1.x, q1.y, q1.z);
             t_max = q0.w;
             inv = F3(q2.x, q2.y, q2.z);
-            sign_bits = __float_as_uint(q2.w) | force_sign_bits;
+            sign_bits = (__float_as_uint(q2.w) & 0xFFu) | force_sign_bits;
             hit_prim = RT_INVALID_ID;
             hit_u = 0.0f; hit_v = 0.0f;
             sp = 0;
@@ -609,7 +610,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(STACK <= 10 
                 // logged the direct sample tentatively; an occluded ray (it stopped on its
                 // first accepted triangle, hit_prim set) retracts it.  Store only, no wait.
                 if (hit_prim != RT_INVALID_ID)
-                    rlog[(size_t)(payload >> id_bits) * log_stride + (payload & ((1u << id_bits) - 1u))] = make_float4(0, 0, 0, 0);
+                    rlog[(size_t)log_entry * log_stride + payload] = make_float4(0, 0, 0, 0);
             }
             else
             {
@@ -908,7 +909,7 @@ struct ShadeArgs
     float4* rlog; uint32_t* cnt;      // radiance log (see file header)
     const uint8_t* bn_sobol; const uint8_t* bn_scramble; const uint8_t* bn_rank;   // SamplerType::kBlueNoise tables
     DCounters* counters;
-    uint32_t bounce, sample_base, emit_outgoing, n_local, log_stride, id_bits;
+    uint32_t bounce, sample_base, emit_outgoing, n_local, log_stride;
 };
 
 // SampleBlueNoise, sampling.h:40-61 (Heitz et al. 2019 tables, values 0..255).  The reference
@@ -940,6 +941,7 @@ __global__ __launch_bounds__(RT_SHADE_BLOCK) void k_shade(DScene sc, DTile tile,
 
     bool want_shadow = false, want_next = false;
     float4 sh_o = make_float4(0, 0, 0, 0), sh_d = sh_o, nx_o = sh_o, nx_d = sh_o, nx_t = sh_o;
+    uint32_t sh_entry = 0;
 
     if (active)
     {
@@ -1033,7 +1035,8 @@ __global__ __launch_bounds__(RT_SHADE_BLOCK) void k_shade(DScene sc, DTile tile,
                 want_shadow = (pdf > 0.0f) && (dot3(lsamp, lsamp) > 0.0f);
                 f3 so = position + normal * RT_EPS;
                 sh_o = make_float4(so.x, so.y, so.z, distance_to_light);
-                sh_d = make_float4(outgoing.x, outgoing.y, outgoing.z, __uint_as_float(id | (nlog << a.id_bits)));
+                sh_d = make_float4(outgoing.x, outgoing.y, outgoing.z, __uint_as_float(id));
+                sh_entry = nlog;
                 if (want_shadow)
                 {
                     // deferred direct sample (direct_light_samples_buffer_): logged now, retracted
@@ -1072,7 +1075,9 @@ __global__ __launch_bounds__(RT_SHADE_BLOCK) void k_shade(DScene sc, DTile tile,
     {
         a.sh_o4[sidx] = sh_o;
         a.sh_d4[sidx] = sh_d;
-        a.sh_iv4[sidx] = ray_inverse(F3(sh_d.x, sh_d.y, sh_d.z));
+        float4 siv = ray_inverse(F3(sh_d.x, sh_d.y, sh_d.z));
+        siv.w = __uint_as_float(__float_as_uint(siv.w) | (sh_entry << 8));
+        a.sh_iv4[sidx] = siv;
     }
     if (want_next)
     {

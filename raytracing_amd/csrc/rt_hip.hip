@@ -58,7 +58,6 @@ struct rt_frame
     uint32_t cur_slots = 0;        // slots used by the batch in flight (0 = nothing pending)
     uint32_t log_stride = 0;       // elements per log entry row = slots * n_local
     uint32_t log_entries = 0;      // rows allocated (>= 2 * (max_bounces + 1))
-    uint32_t id_bits = 27;         // path-id bits of a shadow ray's payload (the rest: log entry)
     bool shadow_pending = false;   // rt_shade issued, rt_intersect_shadow not yet
     DCounters* counters;
     uint2* spill;
@@ -457,24 +456,16 @@ void free_path_buffers(rt_frame* f)
 
 // Per-path state: ray queues for `slots` samples in flight and the radiance log
 // with 2 * (max_bounces + 1) entries per path.  (Re)allocated when either changes.
-// bits left for the path id once the log-entry index (< 2 * (max_bounces + 1)) is packed above it
-uint32_t id_bits_for(uint32_t max_bounces)
-{
-    uint32_t entries = 2u * (max_bounces + 1u), eb = 1;
-    while ((1u << eb) < entries) ++eb;
-    return 32u - eb;
-}
-
 size_t bytes_per_path(uint32_t max_bounces) { return 12u * 16u + 4u + 32u * (max_bounces + 1u); }
 
-// auto: the largest power of two <= 256 that keeps tile pixels x samples inside the path-id
-// range and the per-path buffers under ~96 GB (a third of the 288 GB of HBM)
+// auto: the largest power of two <= 256 that keeps tile pixels x samples inside 32-bit path
+// ids and the per-path buffers under ~144 GB (half of the 288 GB of HBM)
 uint32_t auto_slots(uint32_t n_local, uint32_t max_bounces)
 {
     const uint64_t n = n_local ? n_local : 1;
-    const uint64_t max_paths = (1ull << id_bits_for(max_bounces)) - 1ull;
+    const uint64_t max_paths = 0xFFFFFFF0ull;
     uint32_t s = 256;
-    while (s > 1 && (s * n > max_paths || s * n * bytes_per_path(max_bounces) > (96ull << 30))) s >>= 1;
+    while (s > 1 && (s * n > max_paths || s * n * bytes_per_path(max_bounces) > (144ull << 30))) s >>= 1;
     return s;
 }
 
@@ -486,9 +477,8 @@ int alloc_path_buffers(rt_frame* f, uint32_t slots)
     rt_ctx* ctx = f->ctx;
     free_path_buffers(f);
     f->slots = slots ? slots : 1u;
-    f->id_bits = id_bits_for(f->max_bounces);
     uint64_t paths = (uint64_t)(f->n_local ? f->n_local : 1) * f->slots;
-    if (paths >= (1ull << f->id_bits)) return fail(ctx, "samples in flight x tile pixels exceeds the path-id range");
+    if (paths > 0xFFFFFFF0ull) return fail(ctx, "samples in flight x tile pixels exceeds the 32-bit path-id range");
     f->log_stride = (uint32_t)paths;
     f->log_entries = 2u * (f->max_bounces + 1u);
     size_t q = (size_t)(paths + 4) * sizeof(float4);   // +4: the unified 64-byte fetch of k_trace reads o4[i+2] / d4[i+2]
@@ -515,7 +505,7 @@ int ensure_slots(rt_frame* f, uint32_t want)
 {
     uint32_t cap = slot_cap(f);
     if (want > cap) want = cap;
-    if (want <= f->slots && 2u * (f->max_bounces + 1u) <= f->log_entries && id_bits_for(f->max_bounces) == f->id_bits)
+    if (want <= f->slots && 2u * (f->max_bounces + 1u) <= f->log_entries)
         return RT_OK;
     if (flush_log(f) != RT_OK) return RT_ERROR;
     HIPCHK(f->ctx, hipStreamSynchronize(f->ctx->stream));
@@ -757,7 +747,7 @@ void launch_trace_sm(rt_frame* f, const float4* o4, const float4* d4, const floa
     uint32_t blocks = ((uint32_t)ctx->prop.multiProcessorCount * per_cu + 7u) & ~7u;
     hipLaunchKernelGGL((k_trace<SHADOW, STACK>), dim3(blocks), dim3(64), 0, ctx->stream, ctx->scene.d, o4, d4, iv4, count,
         &f->counters->head[SHADOW ? 1 : 0][0], SHADOW ? (float4*)nullptr : f->hits,
-        SHADOW ? f->rlog : (float4*)nullptr, f->log_stride, f->id_bits, f->select_form_box, f->spill);
+        SHADOW ? f->rlog : (float4*)nullptr, f->log_stride, f->select_form_box, f->spill);
 }
 
 template <bool SHADOW>
@@ -779,7 +769,7 @@ void launch_trace(rt_frame* f, const float4* o4, const float4* d4, const float4*
     case 0:
         hipLaunchKernelGGL(k_trace_v1<SHADOW>, dim3(f->trace_waves_per_cu ? (((uint32_t)ctx->prop.multiProcessorCount *
             (f->trace_waves_per_cu < 13u ? f->trace_waves_per_cu : 13u) + 7u) & ~7u) : f->trace_blocks), dim3(64), 0, ctx->stream, ctx->scene.d, o4, d4,
-            count, SHADOW ? (float4*)nullptr : f->hits, SHADOW ? f->rlog : (float4*)nullptr, f->log_stride, f->id_bits, f->select_form_box, f->spill);
+            iv4, count, SHADOW ? (float4*)nullptr : f->hits, SHADOW ? f->rlog : (float4*)nullptr, f->log_stride, f->select_form_box, f->spill);
         break;
     case 1: launch_trace_sm<SHADOW, 16>(f, o4, d4, iv4, count); break;
     case 2: launch_trace_sm<SHADOW, 24>(f, o4, d4, iv4, count); break;
@@ -871,7 +861,7 @@ int rt_shade(rt_frame* f, uint32_t bounce)              // ShadeMissedRays + Sha
     a.bn_rank = ctx->blue_noise ? ctx->blue_noise + 65536 + 131072 : nullptr;
     a.bounce = bounce; a.sample_base = f->sample_count;
     a.emit_outgoing = (f->drop_last && bounce >= f->max_bounces) ? 0u : 1u;
-    a.n_local = f->n_local ? f->n_local : 1; a.log_stride = f->log_stride; a.id_bits = f->id_bits;
+    a.n_local = f->n_local ? f->n_local : 1; a.log_stride = f->log_stride;
     if (2u * (bounce + 1u) > f->log_entries) return fail(ctx, "rt_shade: bounce beyond the configured max_bounces");
     uint32_t blocks = (f->n_local * (f->cur_slots ? f->cur_slots : 1u) + RT_SHADE_BLOCK - 1u) / RT_SHADE_BLOCK;
     if (blocks == 0) blocks = 1;
@@ -1095,11 +1085,16 @@ int rt_frame_debug_read_queue(rt_frame* f, int which, uint32_t bounce, rt_ray* r
     {
         uint32_t pl;
         memcpy(&pl, &d[i].w, 4);
-        uint32_t id = which == 0 ? pl : (pl & ((1u << f->id_bits) - 1u));
+        uint32_t id = pl;
         uint32_t local_pix = id % (f->n_local ? f->n_local : 1);
         if (which == 1)   // the deferred direct-light sample lives in the radiance log
-            HIPCHK(ctx, hipMemcpy(&p[i], f->rlog + (size_t)(pl >> f->id_bits) * f->log_stride + id, 16,
-                hipMemcpyDeviceToHost));
+        {
+            float4 iv;
+            HIPCHK(ctx, hipMemcpy(&iv, f->sh_iv4 + i, 16, hipMemcpyDeviceToHost));
+            uint32_t entry;
+            memcpy(&entry, &iv.w, 4);
+            HIPCHK(ctx, hipMemcpy(&p[i], f->rlog + (size_t)(entry >> 8) * f->log_stride + id, 16, hipMemcpyDeviceToHost));
+        }
         if (rays)
         {
             rays[i].origin.x = o[i].x; rays[i].origin.y = o[i].y; rays[i].origin.z = o[i].z; rays[i].origin.w = 0.0f;
