@@ -132,6 +132,12 @@ enum rt_option
                                        slab test (trace_bvh.cl:85-97); by default only rays whose 1/dir has a
                                        non-finite component do (the only ones for which v_min/v_max_f32 could
                                        differ).  Results are identical for both values. */
+    , RT_OPT_TRACE_PACKET_BOUNCES = 11 /* closest-hit bounces below (value & 255) and shadow-ray bounces below
+                                       (value >> 8 & 255) are traced by the packet kernel: the 64
+                                       consecutive queue entries of a wave walk the tree together and node /
+                                       triangle records are fetched once per wave by the scalar unit.  Default 0
+                                       (off): it pays only for coherent rays over geometry coarser than a pixel.
+                                       Results are identical for every value. */
 };
 int rt_set_option(rt_frame* frame, int option, uint32_t value);
 int rt_set_camera(rt_frame* frame, const rt_camera* camera);       /* SetCameraData, cl_pt_integrator.cpp:365-371 */

@@ -622,6 +622,226 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(STACK <= 10 
 }
 
 // ---------------------------------------------------------------------------
+// Packet traversal for COHERENT ray batches (primary rays and the shadow rays of the first
+// hit): the 64 consecutive queue entries of a wave -- samples of one pixel, or neighbouring
+// pixels -- walk the tree TOGETHER.  The current node is wave-uniform, so its 64-byte record
+// is fetched once per wave by the scalar unit (s_load_dwordx16 through the scalar cache: no
+// vector-memory instruction, no L1 access, no per-lane address arithmetic) and the box /
+// triangle tests read it from SGPRs; the stack holds wave-uniform entries.
+//
+// Exactness: lanes are grouped by their three direction sign bits, so every lane of a group
+// orders children exactly as the reference does for its ray (trace_bvh.cl:181-190).  A lane
+// takes part in a node visit iff its OWN box test of that node passes with its OWN current
+// t_max -- the reference's pop-time test (trace_bvh.cl:146-148): for the near child that is
+// the test made while the parent is visited (nothing happens to the ray in between); a far
+// child is pushed as (parent, child index, lanes that hit the parent) when any lane hits it
+// now (a lane that misses it now misses it later, t_max only shrinks), and when it is popped
+// the parent record is fetched again and those lanes re-run the full box test with their
+// current t_max.  Each lane therefore sees exactly its reference sequence of nodes and
+// triangles -- a subsequence of the packet's -- and produces the same hit.
+RT_DEV uint32_t uniform_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
+struct Rec64 { float4 a, b, c, d; };
+typedef float rt_v4f __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(4))) rt_v4f* const_v4f_ptr;     // constant address space -> s_load
+RT_DEV Rec64 scalar_fetch(const float4* base, uint32_t uniform_index)
+{
+    const_v4f_ptr p = (const_v4f_ptr)(uintptr_t)(base + (size_t)uniform_u32(uniform_index) * 4);
+    rt_v4f a = p[0], b = p[1], c = p[2], d = p[3];
+    Rec64 r;
+    r.a = make_float4(a.x, a.y, a.z, a.w); r.b = make_float4(b.x, b.y, b.z, b.w);
+    r.c = make_float4(c.x, c.y, c.z, c.w); r.d = make_float4(d.x, d.y, d.z, d.w);
+    return r;
+}
+
+RT_DEV bool packet_box(bool slow, float bminx, float bminy, float bminz, float bmaxx, float bmaxy, float bmaxz, f3 org, f3 inv,
+    float t_max)
+{
+    float entry;
+    return slow ? box_test(bminx, bminy, bminz, bmaxx, bmaxy, bmaxz, org, inv, 0.0f, t_max, entry)
+                : box_test_fast(bminx, bminy, bminz, bmaxx, bmaxy, bmaxz, org, inv, 0.0f, t_max, entry);
+}
+
+template <bool SHADOW>
+__global__ __launch_bounds__(64) void k_trace_packet(DScene sc, const float4* __restrict__ o4, const float4* __restrict__ d4,
+    const float4* __restrict__ iv4, const uint32_t* __restrict__ count_ptr, uint32_t* __restrict__ heads,
+    float4* __restrict__ hits, float4* __restrict__ rlog, uint32_t log_stride, uint32_t force_sign_bits)
+{
+    __shared__ uint4 pstack[RT_TRACE_STACK_MAX + 1];                         // wave-uniform entries
+    const uint32_t lane = threadIdx.x;
+    const uint32_t count = *count_ptr;
+    if (count == 0) return;
+    const uint32_t xcd = blockIdx.x & 7u;
+    const uint32_t per = (((count + 7u) >> 3) + 63u) & ~63u;                 // the XCD regions of k_trace
+    const unsigned long long lane_bit = 1ull << lane;
+    uint32_t regions_tried = 0;
+
+    for (;;)
+    {
+        // ---- next packet: 64 consecutive queue entries of this XCD's region (then steal) ----
+        uint32_t base = 0, end = 0;
+        bool got = false;
+        while (regions_tried < 8u)
+        {
+            uint32_t x = (xcd + regions_tried) & 7u;
+            uint32_t rb = x * per < count ? x * per : count;
+            uint32_t re = (x + 1u) * per < count ? (x + 1u) * per : count;
+            uint32_t b = 0;
+            if (lane == 0 && rb < re) b = atomicAdd(&heads[x], 64u);
+            b = uniform_u32(b);
+            if (rb < re && b < re - rb) { base = rb + b; end = re; got = true; break; }
+            ++regions_tried;
+        }
+        if (!got) break;
+
+        const uint32_t i = base + lane;
+        const bool valid = i < end;
+        f3 org = F3s(0.0f), dir = F3s(0.0f), inv = F3s(0.0f);
+        float t_max = 0.0f, hit_u = 0.0f, hit_v = 0.0f;
+        uint32_t sign_bits = 0, hit_prim = RT_INVALID_ID, payload = 0, log_entry = 0;
+        if (valid)
+        {
+            float4 q0 = o4[i], q1 = d4[i], q2 = iv4[i];
+            org = F3(q0.x, q0.y, q0.z); t_max = q0.w;
+            dir = F3(q1.x, q1.y, q1.z); payload = __float_as_uint(q1.w);
+            inv = F3(q2.x, q2.y, q2.z);
+            sign_bits = (__float_as_uint(q2.w) & 0xFFu) | force_sign_bits;
+            log_entry = __float_as_uint(q2.w) >> 8;
+        }
+
+        unsigned long long todo = __ballot(valid);
+        while (todo)
+        {
+            // one group = the lanes that share the first pending lane's direction signs
+            const uint32_t first = (uint32_t)__ffsll((long long)todo) - 1u;
+            const uint32_t sgn = uniform_u32((uint32_t)__shfl((int)(sign_bits & 7u), (int)first, 64));
+            const unsigned long long group = __ballot(valid && (sign_bits & 7u) == sgn) & todo;
+            todo &= ~group;
+            const bool slow = __ballot((group & lane_bit) && (sign_bits & RT_SIGN_SLOW)) != 0ull;   // wave-uniform
+
+            unsigned long long alive = group;          // SHADOW: lanes leave on their first accepted hit
+            unsigned long long mask = group;           // lanes taking part in the current visit
+            uint32_t ref = sc.entry_ref;
+            int sp = 0;
+            for (;;)
+            {
+                bool need_pop = false;
+                if (ref & RT_LEAF_BIT)
+                {
+                    uint32_t prim = ref & ~RT_LEAF_BIT;
+                    for (;;)
+                    {
+                        const Rec64 t = scalar_fetch(sc.tris_rt, prim);
+                        const bool last = t.a.w != 0.0f;
+                        bool accepted = false;
+                        if (mask & alive & lane_bit)
+                        {
+                            // RayTriangle, trace_bvh.cl:28-73,155-169
+                            f3 p1 = F3(t.a.x, t.a.y, t.a.z), e1 = F3(t.b.x, t.b.y, t.b.z), e2 = F3(t.c.x, t.c.y, t.c.z);
+                            f3 pvec = cross3(dir, e2);
+                            float det = dot3(e1, pvec);
+                            if (!(det < 1e-8f || -det > 1e-8f))
+                            {
+                                float inv_det = 1.0f / det;
+                                f3 tvec = org - p1;
+                                float u = dot3(tvec, pvec) * inv_det;
+                                if (!(u < 0.0f || u > 1.0f))
+                                {
+                                    f3 qvec = cross3(tvec, e1);
+                                    float v = dot3(dir, qvec) * inv_det;
+                                    if (!(v < 0.0f || u + v > 1.0f))
+                                    {
+                                        float tt = dot3(e2, qvec) * inv_det;
+                                        if (!(tt < 0.0f || tt > t_max))
+                                        {
+                                            hit_u = u; hit_v = v; hit_prim = prim;
+                                            t_max = tt;
+                                            accepted = true;
+                                        }
+                                    }
+                                }
+                            }
+                        }
+                        if (SHADOW) alive &= ~__ballot(accepted);            // goto endtrace, :164-167
+                        if (last || (mask & alive) == 0ull) break;
+                        ++prim;
+                    }
+                    need_pop = true;
+                }
+                else
+                {
+                    const Rec64 n = scalar_fetch(sc.nodes, ref);
+                    const uint32_t c0 = __float_as_uint(n.d.x), c1 = __float_as_uint(n.d.y), axis = __float_as_uint(n.d.z);
+                    bool h0 = false, h1 = false;
+                    if (mask & alive & lane_bit)
+                    {
+                        h0 = packet_box(slow, n.a.x, n.a.y, n.a.z, n.a.w, n.b.x, n.b.y, org, inv, t_max);
+                        h1 = packet_box(slow, n.b.z, n.b.w, n.c.x, n.c.y, n.c.z, n.c.w, org, inv, t_max);
+                    }
+                    const unsigned long long m0 = __ballot(h0);
+                    const unsigned long long m1 = c1 != RT_EMPTY_REF ? __ballot(h1) : 0ull;
+                    const bool swap = (sgn >> axis) & 1u;                    // :181-190, the same for the whole group
+                    const unsigned long long m_near = swap ? m1 : m0, m_far = swap ? m0 : m1;
+                    const uint32_t near_ref = swap ? c1 : c0, far_ref = swap ? c0 : c1;
+                    if (m_near)
+                    {
+                        if (m_far)
+                        {
+                            const unsigned long long pm = mask & alive;
+                            if (lane == 0) pstack[sp] = make_uint4(ref, swap ? 0u : 1u, (uint32_t)pm, (uint32_t)(pm >> 32));
+                            ++sp;
+                        }
+                        ref = near_ref; mask = m_near;
+                    }
+                    else if (m_far) { ref = far_ref; mask = m_far; }
+                    else need_pop = true;
+                }
+                if (need_pop)
+                {
+                    bool found = false;
+                    while (sp > 0 && alive)
+                    {
+                        --sp;
+                        const uint4 e = pstack[sp];
+                        const uint32_t pref = uniform_u32(e.x), cidx = uniform_u32(e.y);
+                        const unsigned long long pm =
+                            (((unsigned long long)uniform_u32(e.w) << 32) | uniform_u32(e.z)) & alive;
+                        if (pm == 0ull) continue;
+                        const Rec64 n = scalar_fetch(sc.nodes, pref);
+                        bool h = false;
+                        if (pm & lane_bit)
+                            h = cidx ? packet_box(slow, n.b.z, n.b.w, n.c.x, n.c.y, n.c.z, n.c.w, org, inv, t_max)
+                                     : packet_box(slow, n.a.x, n.a.y, n.a.z, n.a.w, n.b.x, n.b.y, org, inv, t_max);
+                        const unsigned long long m = __ballot(h);
+                        if (m)
+                        {
+                            ref = cidx ? __float_as_uint(n.d.y) : __float_as_uint(n.d.x);
+                            mask = m;
+                            found = true;
+                            break;
+                        }
+                    }
+                    if (!found) break;
+                }
+            }
+        }
+
+        if (valid)
+        {
+            if (SHADOW)
+            {
+                if (hit_prim != RT_INVALID_ID)
+                    rlog[(size_t)log_entry * log_stride + payload] = make_float4(0, 0, 0, 0);
+            }
+            else
+            {
+                hits[i] = make_float4(hit_u, hit_v, __uint_as_float(hit_prim), t_max);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // shading (miss.cl + hit_surface.cl + material.h + bxdf.h + light.h)
 // ---------------------------------------------------------------------------
 struct Material

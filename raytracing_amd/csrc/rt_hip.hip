@@ -64,6 +64,7 @@ struct rt_frame
     uint32_t trace_blocks;       // v1 grid
     uint32_t trace_variant = 5;  // RT_OPT_TRACE_VARIANT (5 = auto)
     uint32_t trace_waves_per_cu = 0;   // RT_OPT_TRACE_WAVES_PER_CU (0 = LDS-limited residency)
+    uint32_t packet_bounces = 0;       // RT_OPT_TRACE_PACKET_BOUNCES: closest | shadow << 8 bounce counts for k_trace_packet
     uint32_t select_form_box = 0;      // RT_OPT_TRACE_SELECT_FORM_BOX: every ray takes the select-form slab test
     // integrator state
     rt_camera camera;
@@ -682,6 +683,7 @@ int rt_set_option(rt_frame* f, int option, uint32_t value)
     case RT_OPT_TRACE_DROP_LAST_BOUNCE_RAYS: f->drop_last = value ? 1 : 0; return RT_OK;
     case RT_OPT_PROFILE_KERNELS: f->profile = value ? 1 : 0; return RT_OK;
     case RT_OPT_TRACE_WAVES_PER_CU: f->trace_waves_per_cu = value; return RT_OK;
+    case RT_OPT_TRACE_PACKET_BOUNCES: f->packet_bounces = value; return RT_OK;
     case RT_OPT_TRACE_SELECT_FORM_BOX: f->select_form_box = value ? RT_SIGN_SLOW : 0u; return RT_OK;
     case RT_OPT_TRACE_VARIANT:
         if (value > 7) return fail(f->ctx, "rt_set_option: unknown trace kernel variant");
@@ -750,10 +752,28 @@ void launch_trace_sm(rt_frame* f, const float4* o4, const float4* d4, const floa
         SHADOW ? f->rlog : (float4*)nullptr, f->log_stride, f->select_form_box, f->spill);
 }
 
+// Coherent launches (primary rays): packet traversal, node records through the scalar cache.
+// Measured (profiles/r01_packet_kernel_experiment.log): 1.19x on the primary rays of the
+// city-block scene, but slower where triangles are smaller than a pixel's footprint (the 64
+// samples of a pixel part ways in the bottom levels) -- hence opt-in.  One-wave blocks, 1 KiB of LDS each: residency is register-bound.
 template <bool SHADOW>
-void launch_trace(rt_frame* f, const float4* o4, const float4* d4, const float4* iv4, const uint32_t* count)
+void launch_trace_packet(rt_frame* f, const float4* o4, const float4* d4, const float4* iv4, const uint32_t* count)
 {
     rt_ctx* ctx = f->ctx;
+    uint32_t per_cu = f->trace_waves_per_cu ? f->trace_waves_per_cu : 32u;
+    if (per_cu > 32u) per_cu = 32u;
+    uint32_t blocks = ((uint32_t)ctx->prop.multiProcessorCount * per_cu + 7u) & ~7u;
+    hipLaunchKernelGGL((k_trace_packet<SHADOW>), dim3(blocks), dim3(64), 0, ctx->stream, ctx->scene.d, o4, d4, iv4, count,
+        &f->counters->head[SHADOW ? 1 : 0][0], SHADOW ? (float4*)nullptr : f->hits,
+        SHADOW ? f->rlog : (float4*)nullptr, f->log_stride, f->select_form_box);
+}
+
+template <bool SHADOW>
+void launch_trace(rt_frame* f, const float4* o4, const float4* d4, const float4* iv4, const uint32_t* count,
+    uint32_t bounce)
+{
+    rt_ctx* ctx = f->ctx;
+    if (bounce < ((f->packet_bounces >> (SHADOW ? 8 : 0)) & 0xFFu)) { launch_trace_packet<SHADOW>(f, o4, d4, iv4, count); return; }
     uint32_t variant = f->trace_variant;
     if (variant == 5)
     {
@@ -837,7 +857,7 @@ int rt_intersect(rt_frame* f, uint32_t bounce)          // IntersectRays, :522-5
     if (bounce > RT_MAX_BOUNCES_LIMIT) return fail(ctx, "rt_intersect: bounce out of range");
     uint32_t in = bounce & 1u;
     KernelSpan span(f, 1);
-    launch_trace<false>(f, f->o4[in], f->d4[in], f->iv4[in], &f->counters->queue[bounce]);
+    launch_trace<false>(f, f->o4[in], f->d4[in], f->iv4[in], &f->counters->queue[bounce], bounce);
     HIPCHK(ctx, hipGetLastError());
     return RT_OK;
 }
@@ -885,7 +905,7 @@ int rt_intersect_shadow(rt_frame* f, uint32_t bounce)   // IntersectShadowRays +
     FRAME_PROLOGUE(f, "rt_intersect_shadow");
     if (bounce > RT_MAX_BOUNCES_LIMIT) return fail(ctx, "rt_intersect_shadow: bounce out of range");
     KernelSpan span(f, 3);
-    launch_trace<true>(f, f->sh_o4, f->sh_d4, f->sh_iv4, &f->counters->shadow[bounce]);
+    launch_trace<true>(f, f->sh_o4, f->sh_d4, f->sh_iv4, &f->counters->shadow[bounce], bounce);
     f->shadow_pending = false;
     HIPCHK(ctx, hipGetLastError());
     return RT_OK;

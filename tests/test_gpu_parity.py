@@ -264,7 +264,7 @@ def test_directly_against_the_reference_kernels(ctx, golden_scenes):
 
 
 @pytest.mark.parametrize("slots", [2, 3, 8])
-@pytest.mark.parametrize("variant", [0, 1, 3, 5])
+@pytest.mark.parametrize("variant", [0, 1, 3, 5, 6, 103])
 def test_samples_in_flight_and_kernel_variants_are_bit_invariant(ctx, golden_scenes, slots, variant):
     """RT_OPT_SAMPLES_IN_FLIGHT traces several samples of a pixel concurrently; the
     radiance log replays their contributions in the reference's order, so the sum
@@ -279,7 +279,8 @@ def test_samples_in_flight_and_kernel_variants_are_bit_invariant(ctx, golden_sce
     fr.set_camera(cam)
     fr.set_max_bounces(b)
     fr.set_option(capi.OPT_SAMPLES_IN_FLIGHT, slots)
-    fr.set_option(capi.OPT_TRACE_VARIANT, variant)
+    fr.set_option(capi.OPT_TRACE_VARIANT, variant % 100)
+    fr.set_option(capi.OPT_PACKET_BOUNCES, (3 | 2 << 8) if variant >= 100 else 0)   # 103: packet kernel, closest bounces 0..2, shadow 0..1
     fr.integrate(spp)
     assert fr.sample_count() == spp
     assert np.array_equal(fr.radiance(), base.radiance(), equal_nan=True)
