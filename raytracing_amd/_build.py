@@ -58,7 +58,7 @@ def build_host(force=False):
     deps += [os.path.join(ROOT, "include", f) for f in ("rt_hip.h", "rt_types.h")]
     hip = os.path.join(HERE, "librt_hip.so")
     if force or _newer(out, deps + [hip]):
-        _run(["g++"] + CXX_FLAGS + ["-shared"] + INC + cpps + ["-o", out, "-L" + HERE, "-lrt_hip", "-lz", "-Wl,-rpath,$ORIGIN"])
+        _run(["g++"] + CXX_FLAGS + ["-shared"] + INC + cpps + ["-o", out, "-L" + HERE, "-lrt_hip", "-lz", "-pthread", "-Wl,-rpath,$ORIGIN"])
     exe = os.path.join(HERE, "rt_render")
     main = os.path.join(HOST, "main.cpp")
     if force or _newer(exe, [main, out]):

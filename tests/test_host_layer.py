@@ -179,6 +179,26 @@ class TestAgainstReferenceHost:
             assert T.records_equal(rn, mn)
             assert T.records_equal(rt, s.arrays()["triangles"])
 
+    @pytest.mark.parametrize("grain,threads", [(8, 8), (100, 3), (4096, 5)])
+    def test_parallel_bvh_build_is_identical_to_reference_builder(self, grain, threads, monkeypatch):
+        """Nodes over more than RT_BVH_GRAIN primitives take the all-threads path (chunked folds,
+        reproduced std::partition), the rest are per-subtree tasks; node and triangle arrays must
+        equal the reference's single-threaded build byte for byte -- incl. a soup with thousands
+        of coincident triangles (equal centroids -> big leaves, ties in every fold)."""
+        monkeypatch.setenv("RT_BVH_GRAIN", str(grain))
+        monkeypatch.setenv("RT_BVH_THREADS", str(threads))
+        rng = np.random.default_rng(5)
+        n = 30000
+        P = rng.uniform(-1, 1, (n, 3, 3)).astype(np.float32) * 0.05 + rng.integers(-3, 4, (n, 1, 3)).astype(np.float32)
+        P[:3000] = P[0]
+        soup = S.to_triangles([(P, np.tile(np.array([0, 0, 1], np.float32), (n, 3, 1)), np.zeros((n, 3, 2), np.float32), 0)])
+        for tris in (soup, S.cornell_blob(60000, 3000)[0], S.coverage_scene()["triangles"]):
+            rt, rn = _ref.bvh_build(tris)
+            s = host.Scene(arrays=dict(triangles=tris, materials=np.zeros(1, T.packed_material)))
+            mn = s.build_bvh()
+            assert T.records_equal(rn, mn)
+            assert T.records_equal(rt, s.arrays()["triangles"])
+
     def test_obj_loader_identical_to_reference_scene(self, tmp_path):
         meshes = [S.quad((-1, -1, 0), (1, -1, 0), (1, 1, 0), (-1, 1, 0)) + (0,),
                   S.uv_sphere((0.1, 0.2, 0.5), 0.4, 7, 13, bump=0.2) + (1,)]
