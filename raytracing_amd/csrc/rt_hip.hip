@@ -320,49 +320,15 @@ int rt_scene_upload(rt_ctx* ctx, const rt_scene_desc* sd)
             for (size_t k = frontier.size(); k-- > 0;) roots.push_back(frontier[k]);   // first child's cluster next
         }
     }
-    std::vector<uint8_t> last_in_leaf(nt, 0);
-    for (uint32_t i = 0; i < nn; ++i)
-    {
-        uint32_t n = sd->nodes[i].num_primitives_axis >> 16;
-        if (n > 0)
-        {
-            uint32_t first = sd->nodes[i].offset;
-            if ((uint64_t)first + n > nt) return fail(ctx, "rt_scene_upload: leaf range outside the triangle array");
-            last_in_leaf[first + n - 1] = 1;
-        }
-    }
-    auto child_ref = [&](uint32_t ref_idx) -> uint32_t
-    {
-        const rt_bvh_node& c = sd->nodes[ref_idx];
-        if ((c.num_primitives_axis >> 16) > 0) return RT_LEAF_BIT | c.offset;
-        return interior_index[ref_idx];
-    };
-    std::vector<float4> nodes2((size_t)(n_interior + 1) * 4);   // + the super-root record
-    for (uint32_t i = 0; i < nn; ++i)
-    {
-        const rt_bvh_node& nd = sd->nodes[i];
-        if ((nd.num_primitives_axis >> 16) != 0) continue;
-        uint32_t c0 = i + 1, c1 = nd.offset;                    // first child follows, second child at offset
-        if (c0 >= nn || c1 >= nn) return fail(ctx, "rt_scene_upload: child index outside the node array");
-        const rt_bvh_node& a = sd->nodes[c0];
-        const rt_bvh_node& b = sd->nodes[c1];
-        float4* out = &nodes2[(size_t)interior_index[i] * 4];
-        out[0] = make_float4(a.bounds_min.x, a.bounds_min.y, a.bounds_min.z, a.bounds_max.x);
-        out[1] = make_float4(a.bounds_max.y, a.bounds_max.z, b.bounds_min.x, b.bounds_min.y);
-        out[2] = make_float4(b.bounds_min.z, b.bounds_max.x, b.bounds_max.y, b.bounds_max.z);
-        uint32_t r0 = child_ref(c0), r1 = child_ref(c1), axis = nd.num_primitives_axis & 0xFFFF;
-        if (axis > 2) return fail(ctx, "rt_scene_upload: bad split axis");
-        float fr0, fr1, fax;
-        memcpy(&fr0, &r0, 4); memcpy(&fr1, &r1, 4); memcpy(&fax, &axis, 4);
-        out[3] = make_float4(fr0, fr1, fax, 0.0f);
-    }
+    // the records themselves are written on the device (k_relayout_*), below
+    std::vector<float4> super_root(4);
     const rt_bvh_node& root = sd->nodes[0];
     s.d.root_ref = (root.num_primitives_axis >> 16) > 0 ? (RT_LEAF_BIT | root.offset) : 0u;
     {
         // super-root: child 0 = (root box, root ref), child 1 = empty.  Visiting it IS the
         // reference's first loop iteration (box test of node 0, trace_bvh.cl:146-148).
         s.d.entry_ref = n_interior;
-        float4* out = &nodes2[(size_t)n_interior * 4];
+        float4* out = super_root.data();
         out[0] = make_float4(root.bounds_min.x, root.bounds_min.y, root.bounds_min.z, root.bounds_max.x);
         out[1] = make_float4(root.bounds_max.y, root.bounds_max.z, 0.0f, 0.0f);
         out[2] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -374,28 +340,6 @@ int rt_scene_upload(rt_ctx* ctx, const rt_scene_desc* sd)
     s.d.root_min[0] = root.bounds_min.x; s.d.root_min[1] = root.bounds_min.y; s.d.root_min[2] = root.bounds_min.z;
     s.d.root_max[0] = root.bounds_max.x; s.d.root_max[1] = root.bounds_max.y; s.d.root_max[2] = root.bounds_max.z;
 
-    // --- triangles: trace record (p1, e1, e2) and 128-byte shading record
-    std::vector<float4> trt((size_t)nt * 4), tsh((size_t)nt * 8);
-    for (uint32_t i = 0; i < nt; ++i)
-    {
-        const rt_triangle& t = sd->triangles[i];
-        const rt_float3 &p1 = t.v1.position, &p2 = t.v2.position, &p3 = t.v3.position;
-        trt[(size_t)i * 4 + 0] = make_float4(p1.x, p1.y, p1.z, last_in_leaf[i] ? 1.0f : 0.0f);
-        trt[(size_t)i * 4 + 1] = make_float4(p2.x - p1.x, p2.y - p1.y, p2.z - p1.z, 0.0f);   // e1, trace_bvh.cl:30
-        trt[(size_t)i * 4 + 2] = make_float4(p3.x - p1.x, p3.y - p1.y, p3.z - p1.z, 0.0f);   // e2, trace_bvh.cl:31
-        trt[(size_t)i * 4 + 3] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);                        // pad to one 64-byte line
-        float4* q = &tsh[(size_t)i * 8];
-        q[0] = make_float4(p1.x, p1.y, p1.z, t.v1.texcoord.x);
-        q[1] = make_float4(p2.x, p2.y, p2.z, t.v1.texcoord.y);
-        q[2] = make_float4(p3.x, p3.y, p3.z, t.v2.texcoord.x);
-        q[3] = make_float4(t.v1.normal.x, t.v1.normal.y, t.v1.normal.z, t.v2.texcoord.y);
-        q[4] = make_float4(t.v2.normal.x, t.v2.normal.y, t.v2.normal.z, t.v3.texcoord.x);
-        q[5] = make_float4(t.v3.normal.x, t.v3.normal.y, t.v3.normal.z, t.v3.texcoord.y);
-        if (t.mtl_index >= sd->num_materials) return fail(ctx, "rt_scene_upload: material index out of range");
-        float fm; uint32_t mi = t.mtl_index; memcpy(&fm, &mi, 4);
-        q[6] = make_float4(fm, 0.0f, 0.0f, 0.0f);
-        q[7] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    }
     std::vector<float4> lights((size_t)(sd->num_lights ? sd->num_lights : 1) * 3);
     for (uint32_t i = 0; i < sd->num_lights; ++i)
     {
@@ -413,10 +357,51 @@ int rt_scene_upload(rt_ctx* ctx, const rt_scene_desc* sd)
             return fail(ctx, "rt_scene_upload: texture outside texture_data");
     }
 
+    // --- re-layout on the device: the reference's arrays go to HBM as they are, three streaming
+    // kernels write the child-pair node records and the 64-byte / 128-byte triangle records
     int rc = RT_OK;
-    rc |= dev_alloc_copy(ctx, &s.nodes, nodes2.data(), nodes2.size() * sizeof(float4));
-    rc |= dev_alloc_copy(ctx, &s.tris_rt, trt.data(), trt.size() * sizeof(float4));
-    rc |= dev_alloc_copy(ctx, &s.tris_sh, tsh.data(), tsh.size() * sizeof(float4));
+    void *raw_tris = nullptr, *raw_nodes = nullptr, *d_index = nullptr, *d_last = nullptr, *d_err = nullptr;
+    rc |= dev_alloc_copy(ctx, &raw_tris, sd->triangles, (size_t)nt * sizeof(rt_triangle));
+    rc |= dev_alloc_copy(ctx, &raw_nodes, sd->nodes, (size_t)nn * sizeof(rt_bvh_node));
+    rc |= dev_alloc_copy(ctx, &d_index, interior_index.data(), (size_t)nn * sizeof(uint32_t));
+    rc |= dev_alloc_copy(ctx, &d_last, nullptr, (size_t)nt);
+    rc |= dev_alloc_copy(ctx, &d_err, nullptr, sizeof(int));
+    rc |= dev_alloc_copy(ctx, &s.nodes, nullptr, (size_t)(n_interior + 1) * 64);   // + the super-root record
+    rc |= dev_alloc_copy(ctx, &s.tris_rt, nullptr, (size_t)nt * 64);
+    rc |= dev_alloc_copy(ctx, &s.tris_sh, nullptr, (size_t)nt * 128);
+    auto free_temps = [&]() { for (void* p : {raw_tris, raw_nodes, d_index, d_last, d_err}) if (p) (void)hipFree(p); };
+    if (rc != RT_OK) { free_temps(); free_scene(s); return RT_ERROR; }
+    int relayout_err = RL_OK;
+    bool ok = hipMemsetAsync(d_last, 0, (size_t)nt, ctx->stream) == hipSuccess &&
+              hipMemsetAsync(d_err, 0, sizeof(int), ctx->stream) == hipSuccess;
+    if (ok)
+    {
+        hipLaunchKernelGGL(k_relayout_mark_leaves, dim3((nn + 255u) / 256u), dim3(256), 0, ctx->stream,
+            (const rt_bvh_node*)raw_nodes, nn, nt, (uint8_t*)d_last, (int*)d_err);
+        hipLaunchKernelGGL(k_relayout_nodes, dim3((nn + 255u) / 256u), dim3(256), 0, ctx->stream,
+            (const rt_bvh_node*)raw_nodes, nn, (const uint32_t*)d_index, (float4*)s.nodes, (int*)d_err);
+        hipLaunchKernelGGL(k_relayout_triangles, dim3((nt + 255u) / 256u), dim3(256), 0, ctx->stream,
+            (const rt_triangle*)raw_tris, nt, sd->num_materials, (const uint8_t*)d_last, (float4*)s.tris_rt,
+            (float4*)s.tris_sh, (int*)d_err);
+        ok = hipGetLastError() == hipSuccess &&
+             hipMemcpyAsync((char*)s.nodes + (size_t)n_interior * 64, super_root.data(), 64, hipMemcpyHostToDevice,
+                 ctx->stream) == hipSuccess &&
+             hipMemcpyAsync(&relayout_err, d_err, sizeof(int), hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
+             hipStreamSynchronize(ctx->stream) == hipSuccess;
+    }
+    free_temps();
+    if (!ok) { free_scene(s); return fail(ctx, "rt_scene_upload: device re-layout failed"); }
+    if (relayout_err != RL_OK)
+    {
+        free_scene(s);
+        switch (relayout_err)
+        {
+        case RL_CHILD_RANGE: return fail(ctx, "rt_scene_upload: child index outside the node array");
+        case RL_LEAF_RANGE: return fail(ctx, "rt_scene_upload: leaf range outside the triangle array");
+        case RL_AXIS: return fail(ctx, "rt_scene_upload: bad split axis");
+        default: return fail(ctx, "rt_scene_upload: material index out of range");
+        }
+    }
     rc |= dev_alloc_copy(ctx, &s.materials, sd->materials, (size_t)sd->num_materials * sizeof(rt_packed_material));
     rc |= dev_alloc_copy(ctx, &s.textures, sd->textures, (size_t)sd->num_textures * sizeof(rt_texture));
     rc |= dev_alloc_copy(ctx, &s.texture_data, sd->texture_data, (size_t)sd->num_texture_data * 4);
