@@ -1,0 +1,136 @@
+"""-m gpu: seeded random scenes / cameras / lights / options, HIP path vs the C oracle,
+bit for bit (radiance, ray counters).  Every case is small enough for the single-threaded
+oracle; together they walk combinations the hand-written scenes do not: random triangle
+soups with sliver and coincident triangles, all material parameter ranges incl. textures
+on every slot, point lights inside geometry, axis-aligned cameras and lights (zero
+direction components -> inf / NaN in the slab test), depth of field, 0..9 bounces,
+furnace, both samplers, several samples in flight and kernel variants."""
+import os
+import numpy as np
+import pytest
+from tests import _oracle
+from raytracing_amd import capi, host, scenes as S, types as T
+
+pytestmark = pytest.mark.gpu
+
+
+def random_scene(rng, env):
+    n_tex = int(rng.integers(0, 4))
+    textures = np.zeros(n_tex, dtype=T.texture)
+    data = []
+    start = 0
+    for i in range(n_tex):
+        w, h = int(rng.integers(1, 40)), int(rng.integers(1, 40))
+        textures[i] = (start, w, h, 0)
+        data.append(rng.integers(0, 2 ** 32, w * h, dtype=np.uint64).astype(np.uint32))
+        start += w * h
+    texture_data = np.concatenate(data).astype(np.uint32) if data else np.zeros(0, np.uint32)
+
+    def tex():
+        return int(rng.integers(0, n_tex)) if n_tex and rng.random() < 0.3 else S.INVALID_TEX
+    mats = []
+    for _ in range(int(rng.integers(1, 9))):
+        mats.append(S.make_material(
+            kd=tuple(rng.uniform(0, 1, 3)), ks=tuple(rng.uniform(0, 1, 3)) if rng.random() < 0.7 else (0, 0, 0),
+            ke=tuple(rng.uniform(0, 20, 3)) if rng.random() < 0.2 else (0, 0, 0),
+            roughness=float(rng.choice([0.0, 0.005, 0.01, rng.uniform(0, 1)])), metalness=float(rng.choice([0.0, 1.0, rng.uniform(0, 1)])),
+            ior=float(rng.choice([1.0, 1.5, rng.uniform(0.5, 4)])), transparency=float(rng.choice([1.0, 1.0, 0.0, rng.uniform(0, 1)])),
+            kd_tex=tex(), ks_tex=tex(), r_tex=tex(), m_tex=tex(), e_tex=tex(), t_tex=tex()))
+    materials = np.array(mats, dtype=T.packed_material)
+
+    meshes = []
+    if rng.random() < 0.7:                                   # a floor / some boxes: axis-aligned planes
+        meshes.append(S.quad((-2, -1, 0), (2, -1, 0), (2, 3, 0), (-2, 3, 0), uv_scale=float(rng.uniform(0.5, 4))) + (0,))
+        for _ in range(int(rng.integers(0, 4))):
+            c = rng.uniform([-1, 0, 0], [1, 2, 1]); e = rng.uniform(0.05, 0.5, 3)
+            meshes.append(S.box(c - e, c + e) + (int(rng.integers(0, len(mats))),))
+    for _ in range(int(rng.integers(0, 3))):
+        meshes.append(S.uv_sphere(tuple(rng.uniform([-1, 0, 0.2], [1, 2, 1.5])), float(rng.uniform(0.1, 0.6)),
+                                  int(rng.integers(3, 14)), int(rng.integers(3, 20)), bump=float(rng.uniform(0, 0.4)),
+                                  seed=int(rng.integers(1, 1000))) + (int(rng.integers(0, len(mats))),))
+    n = int(rng.integers(1, 400))                            # soup: random, sliver, coincident triangles
+    P = (rng.uniform(-1, 1, (n, 1, 3)) * [1.5, 1.5, 1.0] + [0, 1, 0.8] + rng.normal(0, 0.25, (n, 3, 3))).astype(np.float32)
+    k = n // 5
+    P[:k, 2] = P[:k, 1] + (P[:k, 1] - P[:k, 0]) * 1e-3      # slivers (det ~ 0)
+    if n > 8:
+        P[k:k + 4] = P[k]                                    # coincident: equal centroids, equal t
+    Nn = rng.normal(0, 1, (n, 3, 3)).astype(np.float32)
+    Nn /= np.maximum(np.linalg.norm(Nn, axis=2, keepdims=True), 1e-6)
+    U = rng.uniform(-3, 3, (n, 3, 2)).astype(np.float32)
+    tris = np.concatenate([S.to_triangles(meshes) if meshes else np.zeros(0, T.triangle),
+                           S.to_triangles([(P, Nn, U, 0)])])
+    tris["mtl_index"][-n:] = rng.integers(0, len(mats), n)
+
+    s = host.Scene(arrays=dict(triangles=tris, materials=materials, textures=textures, texture_data=texture_data))
+    for _ in range(int(rng.integers(0, 3))):
+        d = rng.normal(0, 1, 3)
+        if rng.random() < 0.4:                               # axis-aligned light: zero direction components
+            d = np.eye(3)[rng.integers(0, 3)] * rng.choice([-1.0, 1.0])
+        s.add_directional_light(tuple(d), tuple(rng.uniform(0, 12, 3)))
+    for _ in range(int(rng.integers(0, 3))):
+        s.add_point_light(tuple(rng.uniform([-1.5, -0.5, 0], [1.5, 2.5, 2])), tuple(rng.uniform(0, 6, 3)))
+    s.build_bvh()
+    s.set_env_image(env)
+    s.finalize()
+    return s.arrays()
+
+
+def _set3(cam, field, v):
+    for k, x in zip("xyz", v):
+        cam[field][k] = np.float32(x)
+
+
+def random_camera(rng, w, h):
+    cam = T.default_camera(w, h)
+    if rng.random() < 0.5:
+        _set3(cam, "position", rng.uniform([-1, -2, 0.2], [1, 0, 2]))
+    mode = rng.integers(0, 3)
+    if mode == 1:                                            # exactly along an axis
+        _set3(cam, "front", np.eye(3)[rng.integers(0, 2)] * rng.choice([-1.0, 1.0]))
+        _set3(cam, "up", (0.0, 0.0, 1.0))
+    elif mode == 2:
+        f = rng.normal(0, 1, 3); f[1] = abs(f[1]) + 0.5; f /= np.linalg.norm(f)
+        r = np.cross(f, [0, 0, 1.0]); r /= np.linalg.norm(r)
+        _set3(cam, "front", f)
+        _set3(cam, "up", np.cross(r, f))
+    if rng.random() < 0.3:
+        cam["aperture"] = float(rng.uniform(0, 0.1)); cam["focus_distance"] = float(rng.uniform(0.5, 4))
+    cam["fov"] = np.float32(rng.uniform(0.3, 2.2))
+    return cam
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = capi.Context(0)
+    c.upload_blue_noise_tables(*S.blue_noise_tables())
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("RT_FUZZ_SEEDS", "24"))))   # RT_FUZZ_SEEDS=2000 for a campaign
+def test_random_scene_matches_oracle_bit_for_bit(ctx, env_map, seed):
+    rng = np.random.default_rng(1000 + seed)
+    sc = random_scene(rng, env_map)
+    w, h = int(rng.integers(8, 112)), int(rng.integers(8, 80))
+    cam = random_camera(rng, w, h)
+    bounces = int(rng.integers(0, 10))
+    spp = int(rng.integers(1, 9))
+    furnace = bool(rng.random() < 0.2)
+    blue = bool(rng.random() < 0.3)
+    ctx.upload_scene(sc)
+    fr = capi.Frame(ctx, w, h)
+    fr.set_camera(cam); fr.set_max_bounces(bounces)
+    fr.set_option(capi.OPT_WHITE_FURNACE, int(furnace))
+    fr.set_option(capi.OPT_SAMPLER, int(blue))
+    fr.set_option(capi.OPT_SAMPLES_IN_FLIGHT, int(rng.integers(0, 5)))
+    fr.set_option(capi.OPT_TRACE_VARIANT, int(rng.choice([0, 3, 4, 5, 6])))
+    fr.set_option(capi.OPT_PACKET_BOUNCES, int(rng.choice([0, 0, 1, 2 | 1 << 8])))
+    fr.integrate(spp)
+    orc = _oracle.Oracle(w, h, sc, furnace=furnace)
+    orc.set_camera(cam); orc.set_max_bounces(bounces)
+    orc.set_blue_noise(blue, S.blue_noise_tables())
+    orc.integrate(spp)
+    got, want = fr.radiance()[..., :3], orc.radiance()[..., :3]
+    assert np.array_equal(got, want, equal_nan=True), (seed, np.argwhere(~np.isclose(got, want, equal_nan=True))[:4])
+    st = fr.stats()
+    assert (st.closest_rays, st.shadow_rays) == orc.ray_totals()
