@@ -200,7 +200,7 @@ extern "C" void* __translate_sampler_initializer(int v) { return (void*)(intptr_
 
 // OpenCL 1.2 spec 8.2 (CLK_NORMALIZED_COORDS_TRUE | CLK_ADDRESS_REPEAT |
 // CLK_FILTER_LINEAR), the only sampler the path uses (miss.cl:30).
-// Evaluation order fixed here; mirrored by oracle.c and kernels.hip.
+// Evaluation order fixed here; mirrored by oracle.c and raytracing_amd/csrc/device_math.h.
 float4 shim_read_imagef(ShimImage* img, void* sampler, float2 coord)
     __asm__("_Z11read_imagef14ocl_image2d_ro11ocl_samplerDv2_f");
 float4 shim_read_imagef(ShimImage* img, void* /*sampler*/, float2 coord)

@@ -43,7 +43,7 @@ def hipcc():
 
 def build_hip(force=False):
     out = os.path.join(HERE, "librt_hip.so")
-    srcs = [os.path.join(CSRC, f) for f in ("rt_hip.hip", "kernels.h", "device_math.h", "rt_detmath.h")]
+    srcs = [os.path.join(CSRC, "rt_hip.hip")] + sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h"))
     srcs += [os.path.join(ROOT, "include", f) for f in ("rt_hip.h", "rt_types.h")]
     if force or _newer(out, srcs):
         _run([hipcc()] + HIP_FLAGS + INC + [srcs[0], "-o", out])

@@ -1,0 +1,99 @@
+// kernels_common.h -- device-side records, counters and the ray producer's helpers shared by
+// the wavefront path-tracing kernels (hand-written for gfx950).  The kernels themselves:
+//   raygen_kernels.h  trace_kernels.h  shade_kernels.h  aov_kernels.h  relayout_kernels.h
+//
+// Reference kernels replaced (src/kernels/cl/):
+//   raygeneration.cl:65-139                        -> k_raygen
+//   trace_bvh.cl:99-211                            -> k_trace<false>
+//   trace_bvh.cl (-D SHADOW_RAYS) + accumulate_direct_samples.cl:27-53
+//                                                  -> k_trace<true>
+//   miss.cl:41-77 + hit_surface.cl:30-186 + clear_counter.cl (x2)
+//                                                  -> k_shade
+//   resolve_radiance.cl:31-86                      -> k_resolve
+//   reset_radiance.cl / increment_counter.cl       -> hipMemsetAsync / host scalar
+//
+// Device data layout (HBM), chosen for coalesced 16-byte accesses:
+//   ray queues   SoA: o4[i] = (origin.xyz, t_max), d4[i] = (dir.xyz, path id bits),
+//                iv4[i] = (1/dir.xyz, sign bits) computed by the PRODUCER of the ray (all 64
+//                lanes busy) instead of by the traversal kernel (where ~2 lanes of a wave
+//                start a ray in any given iteration), thr[i] = (throughput.xyz, -).  path id = slot * n_pixels + pixel, where
+//                `slot` numbers the samples in flight (RT_OPT_SAMPLES_IN_FLIGHT); shadow
+//                rays carry (log entry << 25 | path id)
+//   radiance log per path: cnt[id] + log[k][id] (float4) = the path's radiance
+//                contributions in the order the reference adds them (miss or emission,
+//                then direct light, per bounce).  k_flush replays them pixel by pixel,
+//                sample by sample, so the fp32 sum is associated exactly as in the
+//                reference although several samples are traced concurrently.
+//   BVH          one 64-byte "child-pair" record per INTERIOR node of the
+//                reference BVH2: both children's boxes + refs in one line, so
+//                one dependent fetch serves two box tests (the reference needs
+//                one 48-byte fetch per box).  Topology, near/far rule and
+//                cull decisions are exactly the reference's (see k_trace).
+//   trace tris   64 B, line aligned: (p1, last-in-leaf flag), e1 = p2-p1, e2 = p3-p1, spare
+//   shade tris   128 B, line aligned: p1..p3, n1..n3, uv1..uv3, material
+#pragma once
+#include "device_math.h"
+#include "rt_types.h"
+
+#define RT_LEAF_BIT 0x80000000u
+#define RT_EMPTY_REF 0xFFFFFFFFu
+#define RT_TRACE_STACK_LDS 24     // per-lane stack entries kept in LDS
+#define RT_TRACE_STACK_MAX 64     // the reference's nodesToVisit[64] (trace_bvh.cl:142)
+// A shadow ray carries its path id in direction.w and, in the w of its 1/direction record,
+// sign bits | RT_SIGN_SLOW | (radiance-log entry of its deferred direct sample << 8).
+
+struct DScene
+{
+    const float4* nodes;          // 4 x float4 per interior node
+    const float4* tris_rt;        // 4 x float4 per triangle
+    const float4* tris_sh;        // 8 x float4 per triangle
+    const rt_packed_material* materials;
+    const rt_texture* textures;
+    const uint32_t* texture_data;
+    const float4* lights;         // 3 x float4 per light: origin, radiance, (type bits,0,0,0)
+    const float4* env;
+    int env_w, env_h;
+    uint32_t light_count;
+    uint32_t root_ref;            // RT_LEAF_BIT | first triangle, or interior node 0
+    uint32_t entry_ref;           // "super-root" record: child 0 = (root box, root_ref), child 1 empty
+    float root_min[3];
+    float root_max[3];
+};
+
+struct DTile                      // which pixels of the full image this frame owns
+{
+    uint32_t width, height;       // full image
+    uint32_t band_h, rank, nranks;
+    uint32_t local_rows;
+};
+
+RT_DEV uint32_t tile_global_row(const DTile& t, uint32_t ly)
+{
+    uint32_t band = ly / t.band_h;
+    return (band * t.nranks + t.rank) * t.band_h + (ly - band * t.band_h);
+}
+
+struct DCounters                  // one per frame, device memory
+{
+    uint32_t queue[64];           // queue[b]  = rays in the incoming queue of bounce b
+    uint32_t shadow[64];          // shadow[b] = shadow rays emitted at bounce b
+    unsigned long long total_closest, total_shadow, samples;
+    uint32_t last_queue[64], last_shadow[64];
+    // work-distribution heads of the persistent trace kernels: one per XCD and per
+    // kernel flavour (0 = closest, 1 = shadow), offsets inside the XCD's region
+    uint32_t head[2][8];
+};
+
+// ray_inv_dir and ray_sign of TraceBvh (trace_bvh.cl:125-129), packed as (inv.xyz, sign bits)
+#define RT_SIGN_SLOW 8u
+RT_DEV float4 ray_inverse(f3 dir)
+{
+    f3 inv = F3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
+    uint32_t sign_bits = (inv.x < 0.0f ? 1u : 0u) | (inv.y < 0.0f ? 2u : 0u) | (inv.z < 0.0f ? 4u : 0u);
+    // a non-finite component (dir component 0, denormal or NaN) can make the slab test produce
+    // 0 * inf = NaN: such rays keep the select-form min/max of the reference (box_test)
+    const float inf = __builtin_inff();
+    if (!(__builtin_fabsf(inv.x) < inf && __builtin_fabsf(inv.y) < inf && __builtin_fabsf(inv.z) < inf))
+        sign_bits |= RT_SIGN_SLOW;
+    return make_float4(inv.x, inv.y, inv.z, __uint_as_float(sign_bits));
+}

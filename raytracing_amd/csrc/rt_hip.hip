@@ -51,7 +51,7 @@ struct rt_frame
     float4* hits;
     float4* sh_o4; float4* sh_d4; float4* sh_iv4;
     float4* radiance; float4* resolved;
-    // radiance log (kernels.h header): cnt[id], rlog[entry][id]; id < slots * n_local
+    // radiance log (kernels_common.h header): cnt[id], rlog[entry][id]; id < slots * n_local
     float4* rlog = nullptr; uint32_t* cnt = nullptr;
     uint32_t slots = 1;            // samples traced concurrently (resolved from slots_opt)
     uint32_t slots_opt = 0;        // RT_OPT_SAMPLES_IN_FLIGHT as set by the caller (0 = auto)

@@ -1,0 +1,494 @@
+// shade_kernels.h -- miss + surface shading + queue compaction (miss.cl, hit_surface.cl,
+// material.h, bxdf.h, light.h, sampling.h) and the replay of the radiance log (k_flush).
+#pragma once
+#include "kernels_common.h"
+
+// ---------------------------------------------------------------------------
+// shading (miss.cl + hit_surface.cl + material.h + bxdf.h + light.h)
+// ---------------------------------------------------------------------------
+struct Material
+{
+    f3 diffuse_albedo; float roughness;
+    f3 specular_albedo; float metalness;
+    f3 emission; float ior; float transparency;
+};
+
+// material.h:251-264 + utils.h:123-131
+RT_DEV f3 SampleTexture(const DScene& sc, uint32_t tex_idx, f2 uv)
+{
+    rt_texture tex = sc.textures[tex_idx];
+    uv.x -= __builtin_floorf(uv.x);
+    uv.y -= __builtin_floorf(uv.y);
+    uv.y = 1.f - uv.y;
+    int texel_x = cl_clampi((int)(uv.x * (float)tex.width), 0, tex.width - 1);
+    int texel_y = cl_clampi((int)(uv.y * (float)tex.height), 0, tex.height - 1);
+    int texel_addr = tex.data_start + texel_y * tex.width + texel_x;
+    uint32_t data = sc.texture_data[texel_addr];
+    float r = (float)(data & 0xFF) / 255.0f;
+    float g = (float)((data >> 8) & 0xFF) / 255.0f;
+    float b = (float)((data >> 16) & 0xFF) / 255.0f;
+    return F3(cl_min(cl_max(r, 0.0f), 1.0f), cl_min(cl_max(g, 0.0f), 1.0f), cl_min(cl_max(b, 0.0f), 1.0f));
+}
+
+RT_DEV f3 pow3(f3 a, float e) { return F3(rt_powf(a.x, e), rt_powf(a.y, e), rt_powf(a.z, e)); }
+
+RT_DEV f3 UnpackRGBTex(uint32_t data, uint32_t& idx)                    // utils.h:133-147
+{
+    float r = (float)(data & 0xFF), g = (float)((data >> 8) & 0xFF), b = (float)((data >> 16) & 0xFF);
+    idx = (data >> 24) & 0xFF;
+    return F3(r / 255.0f, g / 255.0f, b / 255.0f);
+}
+
+RT_DEV void ApplyTextures(const DScene& sc, rt_packed_material in, Material& out, f2 uv)   // material.h:319-369
+{
+    uint32_t idx;
+    out.diffuse_albedo = UnpackRGBTex(in.diffuse_albedo, idx);
+    if (idx != RT_INVALID_TEXTURE_IDX) out.diffuse_albedo = pow3(SampleTexture(sc, idx, uv), 2.2f);
+    out.specular_albedo = UnpackRGBTex(in.specular_albedo, idx);
+    if (idx != RT_INVALID_TEXTURE_IDX) out.specular_albedo = pow3(SampleTexture(sc, idx, uv), 2.2f);
+    {
+        uint32_t rgbe = in.emission;                                     // utils.h:149-158
+        int r = (int)(rgbe & 0xFF), g = (int)((rgbe >> 8) & 0xFF), b = (int)((rgbe >> 16) & 0xFF);
+        int e = (int)(rgbe >> 24);
+        float f = rt_ldexpf(1.0f, e - (128 + 8));
+        out.emission = F3((float)r * f, (float)g * f, (float)b * f);
+    }
+    uint32_t d = in.roughness_metalness;                                 // utils.h:160-174
+    out.roughness = (float)(d & 0xFF) / 255.0f;
+    uint32_t roughness_idx = (d >> 8) & 0xFF;
+    out.metalness = (float)((d >> 16) & 0xFF) / 255.0f;
+    uint32_t metalness_idx = (d >> 24) & 0xFF;
+    if (roughness_idx != RT_INVALID_TEXTURE_IDX) out.roughness = SampleTexture(sc, roughness_idx, uv).x;
+    if (metalness_idx != RT_INVALID_TEXTURE_IDX) out.metalness = SampleTexture(sc, metalness_idx, uv).x;
+    d = in.ior_emission_idx_transparency;                                // utils.h:176-190
+    out.ior = (float)(d & 0xFF) / 25.5f;
+    uint32_t emission_idx = (d >> 8) & 0xFF;
+    out.transparency = (float)((d >> 16) & 0xFF) / 255.0f;
+    uint32_t transparency_idx = (d >> 24) & 0xFF;
+    if (emission_idx != RT_INVALID_TEXTURE_IDX)
+        out.emission = out.emission * pow3(SampleTexture(sc, emission_idx, uv), 2.2f);
+    if (transparency_idx != RT_INVALID_TEXTURE_IDX)
+        out.transparency *= SampleTexture(sc, transparency_idx, uv).x;
+}
+
+RT_DEV float IorToF0(float ior_incident, float ior_transmitted)          // bxdf.h:57-61
+{
+    float result = (ior_transmitted - ior_incident) / (ior_transmitted + ior_incident);
+    return result * result;
+}
+
+RT_DEV f3 FresnelSchlick(f3 f0, float h_dot_o)                           // bxdf.h:71-74
+{
+    float p = rt_powf(1.0f - h_dot_o, 5.0f);
+    return F3(f0.x + (1.0f - f0.x) * p, f0.y + (1.0f - f0.y) * p, f0.z + (1.0f - f0.z) * p);
+}
+
+RT_DEV float GGX_D(float alpha, float n_dot_h)                           // bxdf.h:90-95
+{
+    float alpha2 = alpha * alpha;
+    float denom = n_dot_h * n_dot_h * (alpha2 - 1.0f) + 1.0f;
+    return alpha2 * RT_INV_PI / (denom * denom);
+}
+
+RT_DEV float V_SmithGGXCorrelated(float n_dot_i, float n_dot_o, float alphaG)   // bxdf.h:104-119
+{
+    float alphaG2 = alphaG * alphaG;
+    float Lambda_GGXV = n_dot_o * __builtin_sqrtf((-n_dot_i * alphaG2 + n_dot_i) * n_dot_i + alphaG2);
+    float Lambda_GGXL = n_dot_i * __builtin_sqrtf((-n_dot_o * alphaG2 + n_dot_o) * n_dot_o + alphaG2);
+    return 0.5f / (Lambda_GGXV + Lambda_GGXL);
+}
+
+RT_DEV float Luma(f3 rgb) { return rgb.x * 0.299f + rgb.y * 0.587f + rgb.z * 0.114f; }   // utils.h:108-111
+
+RT_DEV void tangent_frame(f3 n, f3& t, f3& b)                            // utils.h:101-103, bxdf.h:163-165
+{
+    f3 axis = __builtin_fabsf(n.x) > 0.001f ? F3(0.0f, 1.0f, 0.0f) : F3(1.0f, 0.0f, 0.0f);
+    t = normalize3(cross3(axis, n));
+    b = cross3(n, t);
+}
+
+RT_DEV f3 reflect3(f3 v, f3 n) { return v - n * (2.0f * dot3(v, n)); }   // utils.h:83-86
+
+RT_DEV f3 EvaluateMaterial(const Material& m, f3 normal, f3 incoming, f3 outgoing)   // material.h:132-169
+{
+    if ((double)m.transparency < 0.5) return F3s(0.0f);
+    f3 half_vec = normalize3(incoming + outgoing);
+    float n_dot_i = cl_max(dot3(normal, incoming), RT_EPS);
+    float n_dot_o = cl_max(dot3(normal, outgoing), RT_EPS);
+    float n_dot_h = cl_max(dot3(normal, half_vec), RT_EPS);
+    float h_dot_o = cl_max(dot3(half_vec, outgoing), RT_EPS);
+    float alpha = m.roughness * m.roughness;
+    float f0_dielectric = IorToF0(1.0f, m.ior);
+    f3 f0 = mix3(F3s(f0_dielectric), m.specular_albedo, m.metalness);
+    f3 diffuse_color = m.diffuse_albedo * (1.0f - m.metalness);
+    f3 fresnel = FresnelSchlick(f0, h_dot_o);
+    float specular = GGX_D(alpha, n_dot_h) * V_SmithGGXCorrelated(n_dot_i, n_dot_o, alpha);
+    f3 diffuse = diffuse_color * RT_INV_PI;
+    return F3(fresnel.x * specular + (1.0f - fresnel.x) * diffuse.x,
+              fresnel.y * specular + (1.0f - fresnel.y) * diffuse.y,
+              fresnel.z * specular + (1.0f - fresnel.z) * diffuse.z);
+}
+
+// material.h:171-241 with SampleSpecular :66-103, SampleDiffuse :51-64, SampleTransparency :105-117
+template <bool FURNACE>
+RT_DEV f3 SampleBxdf(float s1, f2 s, Material material, f3 normal, f3 incoming, f3& outgoing, float& pdf,
+    float& offset)
+{
+    if (FURNACE)
+    {
+        material.diffuse_albedo = F3s(1.0f);
+        material.specular_albedo = F3s(1.0f);
+    }
+    float alpha = material.roughness * material.roughness;
+    float f0_dielectric = IorToF0(1.0f, material.ior);
+    f3 f0 = mix3(F3s(f0_dielectric), material.specular_albedo, material.metalness);
+    f3 diffuse_albedo = material.diffuse_albedo * (1.0f - material.metalness);
+    f3 specular_albedo = mix3(material.specular_albedo, F3s(1.0f), material.metalness);
+    f3 fresnel = FresnelSchlick(f0, dot3(normal, incoming)) * specular_albedo;
+    float specular_weight = Luma(specular_albedo * fresnel);
+    float diffuse_weight = Luma(diffuse_albedo * F3(1.0f - fresnel.x, 1.0f - fresnel.y, 1.0f - fresnel.z));
+    float weight_sum = diffuse_weight + specular_weight;
+    float specular_sampling_pdf = specular_weight / weight_sum;
+    float diffuse_sampling_pdf = diffuse_weight / weight_sum;
+
+    offset = 1.0f;
+    if ((double)material.transparency < 0.5)
+    {
+        pdf = 1.0f;
+        outgoing = -incoming;
+        offset = -1.0f;
+        return F3s(1.0f);
+    }
+
+    f3 bxdf;
+    if (s1 <= specular_sampling_pdf)
+    {
+        float spec;
+        if (alpha <= 1e-4f)
+        {
+            outgoing = reflect3(-incoming, normal);
+            pdf = 1.0f;
+            float n_dot_o = dot3(outgoing, normal);
+            spec = 1.0f / n_dot_o;
+        }
+        else
+        {
+            // GGX_Sample bxdf.h:157-168 (fp64 literals in the reference -> fp64 divide + sqrt)
+            float phi = RT_TWO_PI * s.x;
+            float cos_theta = (float)(1.0 / __builtin_sqrt(1.0 + (double)(alpha * alpha * s.y) / (1.0 - (double)s.y)));
+            float sin_theta = __builtin_sqrtf(cl_max(0.0f, 1.0f - cos_theta * cos_theta));
+            f3 t, b;
+            tangent_frame(normal, t, b);
+            double sd, cd;
+            rtd_sincos((double)phi, &sd, &cd);
+            float cp = (float)cd, sn = (float)sd;
+            f3 wh = normalize3(b * cp * sin_theta + t * sn * sin_theta + normal * cos_theta);
+            outgoing = reflect3(-incoming, wh);
+            float n_dot_o = dot3(normal, outgoing);
+            float n_dot_h = dot3(normal, wh);
+            float n_dot_i = dot3(normal, incoming);
+            float D = GGX_D(alpha, n_dot_h);
+            float G = V_SmithGGXCorrelated(n_dot_i, n_dot_o, alpha);
+            pdf = D * n_dot_h / (4.0f * dot3(wh, outgoing));
+            spec = D * G;
+        }
+        float m = cl_max(dot3(outgoing, normal), 0.0f);
+        bxdf = F3(fresnel.x * spec * m, fresnel.y * spec * m, fresnel.z * spec * m);
+        pdf *= specular_sampling_pdf;
+    }
+    else
+    {
+        // SampleHemisphereCosine bxdf.h:33-54 + TangentToWorld utils.h:99-106
+        float phi = RT_TWO_PI * s.x;
+        float sin_theta = __builtin_sqrtf(s.y);
+        float cos_theta = __builtin_sqrtf(1.0f - s.y);
+        pdf = cos_theta * RT_INV_PI;
+        double sd, cd;
+        rtd_sincos((double)phi, &sd, &cd);
+        f3 tbn = F3((float)cd * sin_theta, (float)sd * sin_theta, cos_theta);
+        f3 t, b;
+        tangent_frame(normal, t, b);
+        outgoing = normalize3(b * tbn.x + t * tbn.y + normal * tbn.z);
+        f3 d = diffuse_albedo * RT_INV_PI;
+        float m = cl_max(dot3(outgoing, normal), 0.0f);
+        bxdf = F3((1.0f - fresnel.x) * d.x * m, (1.0f - fresnel.y) * d.y * m, (1.0f - fresnel.z) * d.z * m);
+        pdf *= diffuse_sampling_pdf;
+    }
+    return bxdf;
+}
+
+// miss.cl:28-39 with the OpenCL 1.2 (8.2) linear / repeat / normalized sampler
+RT_DEV f3 SampleSky(const DScene& sc, f3 dir)
+{
+    float cx = rt_atan2f(dir.x, dir.y) + RT_PI;
+    float cy = rt_acosf(dir.z);
+    cx = cx < 0.0f ? cx + RT_TWO_PI : cx;
+    cx *= RT_INV_TWO_PI;
+    cy *= RT_INV_PI;
+    int w = sc.env_w, h = sc.env_h;
+    float u = (cx - __builtin_floorf(cx)) * (float)w;
+    float v = (cy - __builtin_floorf(cy)) * (float)h;
+    float fu = __builtin_floorf(u - 0.5f);
+    float fv = __builtin_floorf(v - 0.5f);
+    int i0 = (int)fu, j0 = (int)fv;
+    int i1 = i0 + 1, j1 = j0 + 1;
+    if (i0 < 0) i0 = w + i0;
+    if (i1 > w - 1) i1 = i1 - w;
+    if (j0 < 0) j0 = h + j0;
+    if (j1 > h - 1) j1 = j1 - h;
+    float a = (u - 0.5f) - fu;
+    float b = (v - 0.5f) - fv;
+    float wa0 = 1.0f - a, wb0 = 1.0f - b;
+    float4 t00 = sc.env[(size_t)j0 * w + i0];
+    float4 t10 = sc.env[(size_t)j0 * w + i1];
+    float4 t01 = sc.env[(size_t)j1 * w + i0];
+    float4 t11 = sc.env[(size_t)j1 * w + i1];
+    float w00 = wa0 * wb0, w10 = a * wb0, w01 = wa0 * b, w11 = a * b;
+    return F3(w00 * t00.x + w10 * t10.x + w01 * t01.x + w11 * t11.x,
+              w00 * t00.y + w10 * t10.y + w01 * t01.y + w11 * t11.y,
+              w00 * t00.z + w10 * t10.z + w01 * t01.z + w11 * t11.z);
+}
+
+// Stream compaction for the two output queues: wave64 ballot + prefix inside a
+// wave, LDS prefix across the waves of a block, ONE global atomic per block per
+// queue -- instead of the reference's one same-address atomic per ray
+// (hit_surface.cl:138,173).  Same-address L2 atomics retire at ~10 ns each on
+// MI355X, so at ~20 M rays per launch even one atomic per wave (600 k of them) was
+// the shade kernel's bottleneck; per 512-thread block it is 8x fewer.
+#define RT_SHADE_BLOCK 512
+RT_DEV void block_append2(bool want_a, bool want_b, uint32_t* counter_a, uint32_t* counter_b, uint32_t& idx_a,
+    uint32_t& idx_b)
+{
+    __shared__ uint32_t s_cnt[2][RT_SHADE_BLOCK / 64];
+    __shared__ uint32_t s_base[2];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    unsigned long long ma = __ballot(want_a), mb = __ballot(want_b);
+    if (lane == 0)
+    {
+        s_cnt[0][wave] = (uint32_t)__popcll(ma);
+        s_cnt[1][wave] = (uint32_t)__popcll(mb);
+    }
+    __syncthreads();
+    if (threadIdx.x < 2)
+    {
+        uint32_t total = 0;
+        for (uint32_t w = 0; w < RT_SHADE_BLOCK / 64; ++w) total += s_cnt[threadIdx.x][w];
+        s_base[threadIdx.x] = total ? atomicAdd(threadIdx.x == 0 ? counter_a : counter_b, total) : 0u;
+    }
+    __syncthreads();
+    uint32_t pa = s_base[0], pb = s_base[1];
+    for (uint32_t w = 0; w < wave; ++w) { pa += s_cnt[0][w]; pb += s_cnt[1][w]; }
+    idx_a = pa + (uint32_t)__popcll(ma & lt);
+    idx_b = pb + (uint32_t)__popcll(mb & lt);
+}
+
+struct ShadeArgs
+{
+    const float4* in_o4; const float4* in_d4; const float4* in_thr; const float4* hits;
+    float4* out_o4; float4* out_d4; float4* out_iv4; float4* out_thr;
+    float4* sh_o4; float4* sh_d4; float4* sh_iv4;
+    float4* rlog; uint32_t* cnt;      // radiance log (see file header)
+    const uint8_t* bn_sobol; const uint8_t* bn_scramble; const uint8_t* bn_rank;   // SamplerType::kBlueNoise tables
+    DCounters* counters;
+    uint32_t bounce, sample_base, emit_outgoing, n_local, log_stride;
+};
+
+// SampleBlueNoise, sampling.h:40-61 (Heitz et al. 2019 tables, values 0..255).  The reference
+// indexes rankingTile with the un-wrapped dimension (sampling.h:50, no `% 8`), which runs past
+// the end of the table for the last pixels of a tile row; entries past the end read as 0 here
+// (oracle and reference-kernel build pad the table the same way).
+RT_DEV float SampleBlueNoise(const ShadeArgs& a, uint32_t px, uint32_t py, uint32_t sample_index, uint32_t dim)
+{
+    int pixel_i = (int)px & 127, pixel_j = (int)py & 127;
+    int sampleIndex = (int)sample_index & 255, sampleDimension = (int)dim & 255;
+    int ridx = sampleDimension + (pixel_i + pixel_j * 128) * 8;
+    int rank = ridx < 128 * 128 * 8 ? (int)a.bn_rank[ridx] : 0;
+    int rankedSampleIndex = sampleIndex ^ rank;
+    int value = (int)a.bn_sobol[sampleDimension + rankedSampleIndex * 256];
+    value = value ^ (int)a.bn_scramble[(sampleDimension % 8) + (pixel_i + pixel_j * 128) * 8];
+    return (0.5f + (float)value) / 256.0f;
+}
+
+template <bool FURNACE, bool BLUE>
+__global__ __launch_bounds__(RT_SHADE_BLOCK) void k_shade(DScene sc, DTile tile, ShadeArgs a)
+{
+    const uint32_t count = a.counters->queue[a.bounce];
+    const uint32_t i = blockIdx.x * RT_SHADE_BLOCK + threadIdx.x;
+    // the closest-hit trace of this bounce has completed (stream order): rewind the
+    // work heads for the shadow trace of this bounce and the closest trace of the next
+    if (i < 16) a.counters->head[i >> 3][i & 7] = 0;
+    if (blockIdx.x * RT_SHADE_BLOCK >= count) return;                    // whole block idle (uniform)
+    const bool active = i < count;
+
+    bool want_shadow = false, want_next = false;
+    float4 sh_o = make_float4(0, 0, 0, 0), sh_d = sh_o, nx_o = sh_o, nx_d = sh_o, nx_t = sh_o;
+    uint32_t sh_entry = 0;
+
+    if (active)
+    {
+        float4 hit = a.hits[i];
+        float4 rd = a.in_d4[i];
+        uint32_t prim = __float_as_uint(hit.z);
+        uint32_t id = __float_as_uint(rd.w);                               // slot * n_local + local pixel
+        uint32_t slot = id / a.n_local;
+        uint32_t pix = id - slot * a.n_local;
+        uint32_t sample_idx = a.sample_base + slot;
+        uint32_t nlog = a.cnt[id];                                         // contributions logged so far
+        float4* mylog = a.rlog + id;
+        float4 thr4 = a.in_thr[i];
+        f3 hit_throughput = F3(thr4.x, thr4.y, thr4.z);
+
+        if (prim == RT_INVALID_ID)
+        {
+            // Miss, miss.cl:65-76
+            f3 sky = FURNACE ? F3s(0.5f) : SampleSky(sc, F3(rd.x, rd.y, rd.z));
+            f3 add = sky * hit_throughput;
+            mylog[(size_t)nlog * a.log_stride] = make_float4(add.x, add.y, add.z, 0.0f);   // radiance[pix] += ...
+            ++nlog;
+        }
+        else
+        {
+            // HitSurface, hit_surface.cl:79-184
+            f3 incoming = F3(-rd.x, -rd.y, -rd.z);
+            uint32_t ly = pix / tile.width;
+            uint32_t px = pix - ly * tile.width;
+            uint32_t py = tile_global_row(tile, ly);
+
+            const float4* tp = sc.tris_sh + (size_t)prim * 8;
+            float4 q0 = tp[0], q1 = tp[1], q2 = tp[2], q3 = tp[3], q4 = tp[4], q5 = tp[5], q6 = tp[6];
+            f3 p1 = xyz(q0), p2 = xyz(q1), p3 = xyz(q2);
+            f3 n1 = xyz(q3), n2 = xyz(q4), n3 = xyz(q5);
+            float bu = hit.x, bv = hit.y;
+            float w0 = 1.0f - bu - bv;
+            f3 position = p1 * w0 + p2 * bu + p3 * bv;
+            f3 geometry_normal = normalize3(cross3(p2 - p1, p3 - p1));
+            f2 texcoord;
+            texcoord.x = q0.w * w0 + q2.w * bu + q4.w * bv;                // uv1.x, uv2.x, uv3.x
+            texcoord.y = q1.w * w0 + q3.w * bu + q5.w * bv;                // uv1.y, uv2.y, uv3.y
+            f3 normal = normalize3(n1 * w0 + n2 * bu + n3 * bv);
+
+            Material material;
+            ApplyTextures(sc, sc.materials[__float_as_uint(q6.x)], material, texcoord);
+
+            if (!FURNACE)
+            {
+                if (material.emission.x * 1.0f + material.emission.y * 1.0f + material.emission.z * 1.0f > 0.0f)
+                {
+                    f3 e = hit_throughput * material.emission;
+                    mylog[(size_t)nlog * a.log_stride] = make_float4(e.x, e.y, e.z, 0.0f);         // radiance[pix] += ...
+                    ++nlog;
+                }
+            }
+
+            uint32_t sample_seed = BLUE ? 0u : SampleRandomSampleSeed(SampleRandomPixelSeed(px, py), sample_idx);
+            // SampleRandom(x, y, sample, bounce, type), sampling.h:64-82
+            auto draw = [&](uint32_t type) -> float
+            {
+                return BLUE ? SampleBlueNoise(a, px, py, sample_idx, a.bounce * 5u + type)
+                            : SampleRandomDim(sample_seed, a.bounce, type);
+            };
+
+            // Direct lighting :115-145 (Light_Sample light.h:30-65)
+            {
+                float s_light = draw(4);
+                int light_idx = cl_clampi((int)(s_light * (float)sc.light_count), 0, (int)sc.light_count - 1);
+                float4 lo = sc.lights[light_idx * 3 + 0], lr = sc.lights[light_idx * 3 + 1];
+                uint32_t ltype = __float_as_uint(sc.lights[light_idx * 3 + 2].x);
+                float pdf = 1.0f / (float)sc.light_count;
+                f3 light_radiance = xyz(lr);
+                f3 outgoing;
+                if (ltype == RT_LIGHT_TYPE_POINT)
+                {
+                    f3 to_light = xyz(lo) - position;
+                    float sq_length = dot3(to_light, to_light);
+                    light_radiance = light_radiance / sq_length;
+                    outgoing = to_light;
+                }
+                else
+                {
+                    outgoing = xyz(lo) * RT_MAX_RENDER_DIST;
+                }
+                float distance_to_light = length3(outgoing);
+                outgoing = normalize3(outgoing);
+                f3 brdf = EvaluateMaterial(material, normal, incoming, outgoing);
+                float m = cl_max(dot3(outgoing, normal), 0.0f);
+                f3 lsamp = ((light_radiance * hit_throughput) * brdf / pdf) * m;
+                want_shadow = (pdf > 0.0f) && (dot3(lsamp, lsamp) > 0.0f);
+                f3 so = position + normal * RT_EPS;
+                sh_o = make_float4(so.x, so.y, so.z, distance_to_light);
+                sh_d = make_float4(outgoing.x, outgoing.y, outgoing.z, __uint_as_float(id));
+                sh_entry = nlog;
+                if (want_shadow)
+                {
+                    // deferred direct sample (direct_light_samples_buffer_): logged now, retracted
+                    // by the shadow trace if the light turns out to be occluded
+                    mylog[(size_t)nlog * a.log_stride] = make_float4(lsamp.x, lsamp.y, lsamp.z, 0.0f);
+                    ++nlog;
+                }
+            }
+
+            // Indirect lighting :148-184
+            {
+                f2 s;
+                s.x = draw(2);
+                s.y = draw(3);
+                float s1 = draw(1);
+                float pdf = 0.0f;
+                f3 outgoing;
+                float offset;
+                f3 bxdf = SampleBxdf<FURNACE>(s1, s, material, normal, incoming, outgoing, pdf, offset);
+                f3 throughput = F3s(0.0f);
+                if ((double)pdf > 0.0) throughput = bxdf / pdf;
+                f3 new_thr = hit_throughput * throughput;                 // throughputs[pixel] *= throughput
+                want_next = ((double)pdf > 0.0) && (a.emit_outgoing != 0);
+                f3 oo = position + geometry_normal * RT_EPS * offset;
+                nx_o = make_float4(oo.x, oo.y, oo.z, RT_MAX_RENDER_DIST);
+                nx_d = make_float4(outgoing.x, outgoing.y, outgoing.z, rd.w);
+                nx_t = make_float4(new_thr.x, new_thr.y, new_thr.z, 0.0f);
+            }
+        }
+        a.cnt[id] = nlog;
+    }
+
+    uint32_t sidx, nidx;
+    block_append2(want_shadow, want_next, &a.counters->shadow[a.bounce], &a.counters->queue[a.bounce + 1], sidx, nidx);
+    if (want_shadow)
+    {
+        a.sh_o4[sidx] = sh_o;
+        a.sh_d4[sidx] = sh_d;
+        float4 siv = ray_inverse(F3(sh_d.x, sh_d.y, sh_d.z));
+        siv.w = __uint_as_float(__float_as_uint(siv.w) | (sh_entry << 8));
+        a.sh_iv4[sidx] = siv;
+    }
+    if (want_next)
+    {
+        a.out_o4[nidx] = nx_o;
+        a.out_d4[nidx] = nx_d;
+        a.out_iv4[nidx] = ray_inverse(F3(nx_d.x, nx_d.y, nx_d.z));
+        a.out_thr[nidx] = nx_t;
+    }
+}
+
+// Replays the radiance log: for every pixel, sample slot by sample slot, contribution
+// by contribution -- the exact order in which the reference's kernels executed
+// `radiance[pixel] += ...` (miss.cl:75, hit_surface.cl:110, accumulate_direct_samples.cl:51).
+__global__ __launch_bounds__(256) void k_flush(float4* __restrict__ radiance, const float4* __restrict__ rlog,
+    uint32_t* __restrict__ cnt, uint32_t n_local, uint32_t n_slots, uint32_t log_stride)
+{
+    uint32_t p = blockIdx.x * 256u + threadIdx.x;
+    if (p >= n_local) return;
+    float4 r = radiance[p];
+    for (uint32_t slot = 0; slot < n_slots; ++slot)
+    {
+        uint32_t id = slot * n_local + p;
+        uint32_t c = cnt[id];
+        for (uint32_t k = 0; k < c; ++k)
+        {
+            float4 v = rlog[(size_t)k * log_stride + id];
+            r.x += v.x; r.y += v.y; r.z += v.z;
+        }
+        if (c) cnt[id] = 0;
+    }
+    radiance[p] = r;
+}

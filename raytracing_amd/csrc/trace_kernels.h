@@ -1,0 +1,666 @@
+// trace_kernels.h -- BVH traversal (trace_bvh.cl, + accumulate_direct_samples.cl for shadow rays):
+// the slab / triangle tests, k_trace_v1 (per-ray loop), k_trace (one 64-byte fetch per lane per
+// iteration, the default) and k_trace_packet (wave-uniform traversal through the scalar cache).
+#pragma once
+#include "kernels_common.h"
+
+// ---------------------------------------------------------------------------
+// BVH traversal (trace_bvh.cl:28-211)
+// ---------------------------------------------------------------------------
+// Exactness argument (DESIGN.md "traversal equivalence"): the reference pops a
+// node, box-tests it against the CURRENT t_max, and descends near-first.  Here
+// both children are box-tested when their parent is visited; the near child
+// is visited next with the same t_max the reference would use; the far child is
+// pushed with its entry distance A = max(max3(min(t0,t1)), t_min) and re-tested
+// at pop time by `t_max >= A`, which (for the box test's min/max select forms
+// and a non-increasing t_max) is equivalent to re-running the full box test.
+// Leaves are visited in the reference's order and triangles are tested in
+// array order with the same accept rule, so the closest hit (including ties,
+// "later triangle replaces", trace_bvh.cl:157-162) is identical.
+
+RT_DEV bool box_test(float bminx, float bminy, float bminz, float bmaxx, float bmaxy, float bmaxz, f3 org, f3 inv,
+    float t_min, float t_max, float& entry)
+{
+    // RayBounds, trace_bvh.cl:85-97
+    float t0x = (bminx - org.x) * inv.x, t0y = (bminy - org.y) * inv.y, t0z = (bminz - org.z) * inv.z;
+    float t1x = (bmaxx - org.x) * inv.x, t1y = (bmaxy - org.y) * inv.y, t1z = (bmaxz - org.z) * inv.z;
+    float lox = cl_min(t0x, t1x), loy = cl_min(t0y, t1y), loz = cl_min(t0z, t1z);
+    float hix = cl_max(t0x, t1x), hiy = cl_max(t0y, t1y), hiz = cl_max(t0z, t1z);
+    float tmin = cl_max(cl_max(cl_max(lox, loy), loz), t_min);
+    float tmax = cl_min(cl_min(cl_min(hix, hiy), hiz), t_max);
+    entry = tmin;
+    return tmax >= tmin;
+}
+
+// The same test on v_min_f32 / v_max_f32 (v_min3 / v_max3): 20 VALU per child pair instead
+// of 48 compare+select.  minNum/maxNum differ from the select forms above only (a) in the
+// sign of a zero result -- every value here feeds comparisons only -- and (b) when an
+// operand is NaN, which needs 0 * inf, i.e. a non-finite 1/dir component: rays with one are
+// flagged by the producer (RT_SIGN_SLOW) and take box_test.
+// (v_min/v_max are issued directly: through fminf/fmaxf the compiler first quiets every
+// operand with a v_max_f32 x, x, eight extra instructions per child pair that only matter for
+// signalling NaNs, which cannot occur here.)
+RT_DEV float hw_min(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+RT_DEV float hw_max(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+RT_DEV float hw_min3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+RT_DEV float hw_max3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+
+RT_DEV bool box_test_fast(float bminx, float bminy, float bminz, float bmaxx, float bmaxy, float bmaxz, f3 org, f3 inv,
+    float t_min, float t_max, float& entry)
+{
+    float t0x = (bminx - org.x) * inv.x, t0y = (bminy - org.y) * inv.y, t0z = (bminz - org.z) * inv.z;
+    float t1x = (bmaxx - org.x) * inv.x, t1y = (bmaxy - org.y) * inv.y, t1z = (bmaxz - org.z) * inv.z;
+    float lox = hw_min(t0x, t1x), loy = hw_min(t0y, t1y), loz = hw_min(t0z, t1z);
+    float hix = hw_max(t0x, t1x), hiy = hw_max(t0y, t1y), hiz = hw_max(t0z, t1z);
+    float tmin = hw_max(hw_max3(lox, loy, loz), t_min);
+    float tmax = hw_min(hw_min3(hix, hiy, hiz), t_max);
+    entry = tmin;
+    return tmax >= tmin;
+}
+
+template <bool SHADOW>
+__global__ __launch_bounds__(64) void k_trace_v1(DScene sc, const float4* __restrict__ o4, const float4* __restrict__ d4,
+    const float4* __restrict__ iv4, const uint32_t* __restrict__ count_ptr, float4* __restrict__ hits,
+    float4* __restrict__ rlog, uint32_t log_stride, uint32_t /*force_sign_bits: v1 always uses box_test*/,
+    uint2* __restrict__ spill)
+{
+    __shared__ uint2 stack[RT_TRACE_STACK_LDS][64];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t count = *count_ptr;
+    const uint32_t nchunks = (count + 63u) >> 6;
+    // XCD-aware persistent schedule: block b runs on XCD b % 8 (observed
+    // dispatch order); give each XCD one contiguous eighth of the queue so
+    // that its private L2 sees one screen/queue region.
+    const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
+    const uint32_t cpx = (nchunks + 7u) >> 3;
+    uint2* my_spill = spill + (size_t)(blockIdx.x * 64u + lane) * (RT_TRACE_STACK_MAX - RT_TRACE_STACK_LDS);
+
+    for (uint32_t c = slot; c < cpx; c += per_xcd)
+    {
+        uint32_t chunk = xcd * cpx + c;
+        uint32_t i = chunk * 64u + lane;
+        if (i >= count) continue;
+
+        float4 ro = o4[i], rd = d4[i];
+        f3 org = F3(ro.x, ro.y, ro.z), dir = F3(rd.x, rd.y, rd.z);
+        const float t_min = 0.0f;                                        // origin.w is 0 for every ray the path emits
+        float t_max = ro.w;
+        f3 inv = F3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);           // trace_bvh.cl:125
+        uint32_t sign_bits = (inv.x < 0.0f ? 1u : 0u) | (inv.y < 0.0f ? 2u : 0u) | (inv.z < 0.0f ? 4u : 0u);
+
+        uint32_t hit_prim = RT_INVALID_ID;
+        float hit_u = 0.0f, hit_v = 0.0f, hit_t = 0.0f;
+        bool occluded = false;
+
+        int sp = 0;
+        uint32_t ref = sc.root_ref;
+        float entry;
+        bool alive = box_test(sc.root_min[0], sc.root_min[1], sc.root_min[2], sc.root_max[0], sc.root_max[1],
+            sc.root_max[2], org, inv, t_min, t_max, entry);
+
+        while (alive)
+        {
+            bool need_pop;
+            if (ref & RT_LEAF_BIT)
+            {
+                // leaf: test its triangles in array order (trace_bvh.cl:155-169)
+                uint32_t prim = ref & ~RT_LEAF_BIT;
+                bool last;
+                do
+                {
+                    const float4* tp = sc.tris_rt + (size_t)prim * 4;
+                    float4 a = tp[0], b = tp[1], cc = tp[2];
+                    last = a.w != 0.0f;
+                    f3 p1 = F3(a.x, a.y, a.z), e1 = F3(b.x, b.y, b.z), e2 = F3(cc.x, cc.y, cc.z);
+                    // RayTriangle, trace_bvh.cl:28-73
+                    f3 pvec = cross3(dir, e2);
+                    float det = dot3(e1, pvec);
+                    if (!(det < 1e-8f || -det > 1e-8f))
+                    {
+                        float inv_det = 1.0f / det;
+                        f3 tvec = org - p1;
+                        float u = dot3(tvec, pvec) * inv_det;
+                        if (!(u < 0.0f || u > 1.0f))
+                        {
+                            f3 qvec = cross3(tvec, e1);
+                            float v = dot3(dir, qvec) * inv_det;
+                            if (!(v < 0.0f || u + v > 1.0f))
+                            {
+                                float t = dot3(e2, qvec) * inv_det;
+                                if (!(t < t_min || t > t_max))
+                                {
+                                    hit_u = u; hit_v = v; hit_t = t; hit_prim = prim;
+                                    t_max = t;                           // :162
+                                    if (SHADOW) { occluded = true; }
+                                }
+                            }
+                        }
+                    }
+                    ++prim;
+                } while (!last && !(SHADOW && occluded));
+                if (SHADOW && occluded) break;                           // goto endtrace, :164-167
+                need_pop = true;
+            }
+            else
+            {
+                const float4* np = sc.nodes + (size_t)ref * 4;
+                float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+                uint32_t c0 = __float_as_uint(n3.x), c1 = __float_as_uint(n3.y), axis = __float_as_uint(n3.z);
+                float a0, a1;
+                bool h0 = box_test(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, org, inv, t_min, t_max, a0);
+                bool h1 = box_test(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, org, inv, t_min, t_max, a1);
+                h1 = h1 && (c1 != RT_EMPTY_REF);
+                // near child: first child unless the ray is negative along the split axis (:181-190)
+                bool swap = (sign_bits >> axis) & 1u;
+                uint32_t near_ref = swap ? c1 : c0, far_ref = swap ? c0 : c1;
+                bool near_hit = swap ? h1 : h0, far_hit = swap ? h0 : h1;
+                float far_entry = swap ? a0 : a1;
+                if (near_hit)
+                {
+                    if (far_hit)
+                    {
+                        uint2 e = make_uint2(far_ref, __float_as_uint(far_entry));
+                        if (sp < RT_TRACE_STACK_LDS) stack[sp][lane] = e;
+                        else my_spill[sp - RT_TRACE_STACK_LDS] = e;
+                        ++sp;
+                    }
+                    ref = near_ref;
+                    need_pop = false;
+                }
+                else if (far_hit)
+                {
+                    ref = far_ref;
+                    need_pop = false;
+                }
+                else
+                {
+                    need_pop = true;
+                }
+            }
+            if (need_pop)
+            {
+                alive = false;
+                while (sp > 0)
+                {
+                    --sp;
+                    uint2 e = (sp < RT_TRACE_STACK_LDS) ? stack[sp][lane] : my_spill[sp - RT_TRACE_STACK_LDS];
+                    if (t_max >= __uint_as_float(e.y))                   // box re-test at pop time
+                    {
+                        ref = e.x;
+                        alive = true;
+                        break;
+                    }
+                }
+            }
+        }
+
+        if (SHADOW)
+        {
+            // AccumulateDirectSamples (accumulate_direct_samples.cl:46-52) fused: k_shade
+            // logged the direct sample tentatively; an occluded ray retracts it
+            if (occluded)
+            {
+                uint32_t entry = __float_as_uint(iv4[i].w) >> 8;
+                rlog[(size_t)entry * log_stride + __float_as_uint(rd.w)] = make_float4(0, 0, 0, 0);
+            }
+        }
+        else
+        {
+            hits[i] = make_float4(hit_u, hit_v, __uint_as_float(hit_prim), hit_t);
+        }
+    }
+}
+
+
+// ---------------------------------------------------------------------------
+// k_trace: persistent "one fetch per iteration" traversal (the production kernel)
+// ---------------------------------------------------------------------------
+// What bounds this kernel is the chain of dependent HBM/L2 round trips per ray
+// (~46 box tests + ~2.5 triangle tests per ray on the 890 k-triangle stand-in),
+// not arithmetic.  v1 above pays (a) one round trip for the node branch PLUS one
+// for the leaf branch whenever a wave has lanes in both, and (b) idles lanes
+// whose ray finished until the slowest ray of the wave is done.  Here every lane
+// is a small state machine and every loop iteration issues exactly ONE 64-byte
+// record fetch per lane -- the next ray (o4/d4), a child-pair node, or a
+// triangle -- through the same four load instructions, so the wave pays one
+// memory round trip per iteration whatever mix of states it holds, and a lane
+// that finishes pulls a new ray in the very next iteration (wave-level pool of
+// ray indices, refilled RT_TRACE_BATCH at a time from a per-XCD queue head with
+// one atomic; exhausted XCD regions steal from the next region).
+// The arithmetic per record is unchanged from v1 (bit-identical results).
+#define RT_TRACE_BATCH 128u
+enum { ST_NEED = 0, ST_RAY = 1, ST_TRAV = 2, ST_DONE = 3 };
+
+template <bool SHADOW, int STACK>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(STACK <= 10 ? 8 : 6, 8))) void k_trace(DScene sc, const float4* __restrict__ o4, const float4* __restrict__ d4,
+    const float4* __restrict__ iv4, const uint32_t* __restrict__ count_ptr, uint32_t* __restrict__ heads,
+    float4* __restrict__ hits,
+    float4* __restrict__ rlog, uint32_t log_stride, uint32_t force_sign_bits, uint2* __restrict__ spill)
+{
+    __shared__ uint2 stack[STACK][64];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t count = *count_ptr;
+    if (count == 0) return;
+    const uint32_t xcd = blockIdx.x & 7u;
+    // eight contiguous regions of the queue, 64-ray aligned, one per XCD (L2 affinity)
+    const uint32_t per = (((count + 7u) >> 3) + 63u) & ~63u;
+    uint2* my_spill = spill + (size_t)(blockIdx.x * 64u + lane) * (RT_TRACE_STACK_MAX - STACK);
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+
+    uint32_t pool_next = 0, pool_end = 0, regions_tried = 0;   // wave-uniform
+    uint32_t state = ST_NEED;
+    uint32_t ray_i = 0, ref = 0, sign_bits = 0, hit_prim = RT_INVALID_ID;
+    int sp = 0;
+    f3 org = F3s(0.0f), dir = F3s(0.0f), inv = F3s(0.0f);
+    float t_max = 0.0f, hit_u = 0.0f, hit_v = 0.0f;
+    uint32_t payload = 0, log_entry = 0;                                     // SHADOW: path id, radiance-log entry
+    const float t_min = 0.0f;
+
+    for (;;)
+    {
+        // ---- hand new ray indices to the lanes that need one --------------------
+        unsigned long long need = __ballot(state == ST_NEED);
+        while (need)
+        {
+            if (pool_next >= pool_end)
+            {
+                bool got = false;
+                while (regions_tried < 8u)
+                {
+                    uint32_t x = (xcd + regions_tried) & 7u;
+                    uint32_t rb = x * per < count ? x * per : count;
+                    uint32_t re = (x + 1u) * per < count ? (x + 1u) * per : count;
+                    uint32_t b = 0;
+                    if (lane == 0 && rb < re) b = atomicAdd(&heads[x], RT_TRACE_BATCH);
+                    b = __shfl(b, 0, 64);
+                    if (rb < re && b < re - rb)
+                    {
+                        pool_next = rb + b;
+                        pool_end = (b + RT_TRACE_BATCH < re - rb) ? rb + b + RT_TRACE_BATCH : re;
+                        got = true;
+                        break;
+                    }
+                    ++regions_tried;
+                }
+                if (!got)
+                {
+                    if (state == ST_NEED) state = ST_DONE;
+                    break;
+                }
+            }
+            uint32_t avail = pool_end - pool_next;
+            uint32_t rank = (uint32_t)__popcll(need & lt_mask);
+            uint32_t n = (uint32_t)__popcll(need);
+            if (state == ST_NEED && rank < avail)
+            {
+                ray_i = pool_next + rank;
+                state = ST_RAY;
+            }
+            pool_next += n < avail ? n : avail;
+            need = __ballot(state == ST_NEED);
+        }
+        if (__ballot(state != ST_DONE) == 0ull) break;
+
+        // ---- ONE 64-byte record per lane: ray | node | triangle -----------------
+        // (the L1 sees one access per lane per load instruction: only child-pair nodes use
+        // the fourth 16 bytes, so triangle and ray lanes skip that load)
+        const float4 *p0, *p1, *p2;
+        const bool is_node = state == ST_TRAV && !(ref & RT_LEAF_BIT);
+        if (state == ST_RAY) { p0 = o4 + ray_i; p1 = d4 + ray_i; p2 = iv4 + ray_i; }
+        else
+        {
+            const float4* base = (ref & RT_LEAF_BIT) ? sc.tris_rt + (size_t)(ref & ~RT_LEAF_BIT) * 4
+                                                     : sc.nodes + (size_t)ref * 4;
+            p0 = base; p1 = base + 1; p2 = base + 2;
+        }
+        float4 q0, q1, q2, q3;
+        if (state != ST_DONE)
+        {
+            q0 = *p0; q1 = *p1; q2 = *p2;
+            if (is_node) q3 = p2[1];
+        }
+        if (SHADOW && state == ST_RAY) { payload = __float_as_uint(q1.w); log_entry = __float_as_uint(q2.w) >> 8; }
+
+        bool finished = false, need_pop = false;
+        if (state == ST_RAY)
+        {
+            // ray start: registers only.  1/dir and the sign bits come from the producer
+            // (ray_inverse); the root box test (trace_bvh.cl:146-148, first iteration) is the
+            // ordinary node test of the "super-root" record entry_ref in the next iteration.
+            org = F3(q0.x, q0.y, q0.z);
+            dir = F3(q1.x, q1.y, q1.z);
+            t_max = q0.w;
+            inv = F3(q2.x, q2.y, q2.z);
+            sign_bits = (__float_as_uint(q2.w) & 0xFFu) | force_sign_bits;
+            hit_prim = RT_INVALID_ID;
+            hit_u = 0.0f; hit_v = 0.0f;
+            sp = 0;
+            ref = sc.entry_ref;
+            state = ST_TRAV;
+        }
+        else if (state == ST_TRAV)
+        {
+            if (ref & RT_LEAF_BIT)
+            {
+                // one triangle of a leaf (trace_bvh.cl:28-73,155-169)
+                uint32_t prim = ref & ~RT_LEAF_BIT;
+                bool last = q0.w != 0.0f;
+                f3 p1 = F3(q0.x, q0.y, q0.z), e1 = F3(q1.x, q1.y, q1.z), e2 = F3(q2.x, q2.y, q2.z);
+                f3 pvec = cross3(dir, e2);
+                float det = dot3(e1, pvec);
+                if (!(det < 1e-8f || -det > 1e-8f))
+                {
+                    float inv_det = 1.0f / det;
+                    f3 tvec = org - p1;
+                    float u = dot3(tvec, pvec) * inv_det;
+                    if (!(u < 0.0f || u > 1.0f))
+                    {
+                        f3 qvec = cross3(tvec, e1);
+                        float v = dot3(dir, qvec) * inv_det;
+                        if (!(v < 0.0f || u + v > 1.0f))
+                        {
+                            float t = dot3(e2, qvec) * inv_det;
+                            if (!(t < t_min || t > t_max))
+                            {
+                                hit_u = u; hit_v = v; hit_prim = prim;
+                                t_max = t;                                   // :162
+                                if (SHADOW) finished = true;                 // goto endtrace, :164-167
+                            }
+                        }
+                    }
+                }
+                if (!finished)
+                {
+                    if (last) need_pop = true;
+                    else ref = ref + 1u;
+                }
+            }
+            else
+            {
+                uint32_t c0 = __float_as_uint(q3.x), c1 = __float_as_uint(q3.y), axis = __float_as_uint(q3.z);
+                float a0, a1;
+                bool h0, h1;
+                if (sign_bits & RT_SIGN_SLOW)
+                {
+                    h0 = box_test(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, org, inv, t_min, t_max, a0);
+                    h1 = box_test(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, org, inv, t_min, t_max, a1);
+                }
+                else
+                {
+                    h0 = box_test_fast(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, org, inv, t_min, t_max, a0);
+                    h1 = box_test_fast(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, org, inv, t_min, t_max, a1);
+                }
+                h1 = h1 && (c1 != RT_EMPTY_REF);
+                bool swap = (sign_bits >> axis) & 1u;                        // :181-190
+                uint32_t near_ref = swap ? c1 : c0, far_ref = swap ? c0 : c1;
+                bool near_hit = swap ? h1 : h0, far_hit = swap ? h0 : h1;
+                float far_entry = swap ? a0 : a1;
+                if (near_hit)
+                {
+                    if (far_hit)
+                    {
+                        uint2 e = make_uint2(far_ref, __float_as_uint(far_entry));
+                        if (sp < STACK) stack[sp][lane] = e;
+                        else my_spill[sp - STACK] = e;
+                        ++sp;
+                    }
+                    ref = near_ref;
+                }
+                else if (far_hit) ref = far_ref;
+                else need_pop = true;
+            }
+            if (need_pop)
+            {
+                finished = true;
+                while (sp > 0)
+                {
+                    --sp;
+                    uint2 e = (sp < STACK) ? stack[sp][lane] : my_spill[sp - STACK];
+                    if (t_max >= __uint_as_float(e.y))                       // box re-test at pop time
+                    {
+                        ref = e.x;
+                        finished = false;
+                        break;
+                    }
+                }
+            }
+        }
+
+        if (finished)
+        {
+            if (SHADOW)
+            {
+                // AccumulateDirectSamples fused (accumulate_direct_samples.cl:46-52): k_shade
+                // logged the direct sample tentatively; an occluded ray (it stopped on its
+                // first accepted triangle, hit_prim set) retracts it.  Store only, no wait.
+                if (hit_prim != RT_INVALID_ID)
+                    rlog[(size_t)log_entry * log_stride + payload] = make_float4(0, 0, 0, 0);
+            }
+            else
+            {
+                hits[ray_i] = make_float4(hit_u, hit_v, __uint_as_float(hit_prim), t_max);
+            }
+            state = ST_NEED;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Packet traversal for COHERENT ray batches (primary rays and the shadow rays of the first
+// hit): the 64 consecutive queue entries of a wave -- samples of one pixel, or neighbouring
+// pixels -- walk the tree TOGETHER.  The current node is wave-uniform, so its 64-byte record
+// is fetched once per wave by the scalar unit (s_load_dwordx16 through the scalar cache: no
+// vector-memory instruction, no L1 access, no per-lane address arithmetic) and the box /
+// triangle tests read it from SGPRs; the stack holds wave-uniform entries.
+//
+// Exactness: lanes are grouped by their three direction sign bits, so every lane of a group
+// orders children exactly as the reference does for its ray (trace_bvh.cl:181-190).  A lane
+// takes part in a node visit iff its OWN box test of that node passes with its OWN current
+// t_max -- the reference's pop-time test (trace_bvh.cl:146-148): for the near child that is
+// the test made while the parent is visited (nothing happens to the ray in between); a far
+// child is pushed as (parent, child index, lanes that hit the parent) when any lane hits it
+// now (a lane that misses it now misses it later, t_max only shrinks), and when it is popped
+// the parent record is fetched again and those lanes re-run the full box test with their
+// current t_max.  Each lane therefore sees exactly its reference sequence of nodes and
+// triangles -- a subsequence of the packet's -- and produces the same hit.
+RT_DEV uint32_t uniform_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
+struct Rec64 { float4 a, b, c, d; };
+typedef float rt_v4f __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(4))) rt_v4f* const_v4f_ptr;     // constant address space -> s_load
+RT_DEV Rec64 scalar_fetch(const float4* base, uint32_t uniform_index)
+{
+    const_v4f_ptr p = (const_v4f_ptr)(uintptr_t)(base + (size_t)uniform_u32(uniform_index) * 4);
+    rt_v4f a = p[0], b = p[1], c = p[2], d = p[3];
+    Rec64 r;
+    r.a = make_float4(a.x, a.y, a.z, a.w); r.b = make_float4(b.x, b.y, b.z, b.w);
+    r.c = make_float4(c.x, c.y, c.z, c.w); r.d = make_float4(d.x, d.y, d.z, d.w);
+    return r;
+}
+
+RT_DEV bool packet_box(bool slow, float bminx, float bminy, float bminz, float bmaxx, float bmaxy, float bmaxz, f3 org, f3 inv,
+    float t_max)
+{
+    float entry;
+    return slow ? box_test(bminx, bminy, bminz, bmaxx, bmaxy, bmaxz, org, inv, 0.0f, t_max, entry)
+                : box_test_fast(bminx, bminy, bminz, bmaxx, bmaxy, bmaxz, org, inv, 0.0f, t_max, entry);
+}
+
+template <bool SHADOW>
+__global__ __launch_bounds__(64) void k_trace_packet(DScene sc, const float4* __restrict__ o4, const float4* __restrict__ d4,
+    const float4* __restrict__ iv4, const uint32_t* __restrict__ count_ptr, uint32_t* __restrict__ heads,
+    float4* __restrict__ hits, float4* __restrict__ rlog, uint32_t log_stride, uint32_t force_sign_bits)
+{
+    __shared__ uint4 pstack[RT_TRACE_STACK_MAX + 1];                         // wave-uniform entries
+    const uint32_t lane = threadIdx.x;
+    const uint32_t count = *count_ptr;
+    if (count == 0) return;
+    const uint32_t xcd = blockIdx.x & 7u;
+    const uint32_t per = (((count + 7u) >> 3) + 63u) & ~63u;                 // the XCD regions of k_trace
+    const unsigned long long lane_bit = 1ull << lane;
+    uint32_t regions_tried = 0;
+
+    for (;;)
+    {
+        // ---- next packet: 64 consecutive queue entries of this XCD's region (then steal) ----
+        uint32_t base = 0, end = 0;
+        bool got = false;
+        while (regions_tried < 8u)
+        {
+            uint32_t x = (xcd + regions_tried) & 7u;
+            uint32_t rb = x * per < count ? x * per : count;
+            uint32_t re = (x + 1u) * per < count ? (x + 1u) * per : count;
+            uint32_t b = 0;
+            if (lane == 0 && rb < re) b = atomicAdd(&heads[x], 64u);
+            b = uniform_u32(b);
+            if (rb < re && b < re - rb) { base = rb + b; end = re; got = true; break; }
+            ++regions_tried;
+        }
+        if (!got) break;
+
+        const uint32_t i = base + lane;
+        const bool valid = i < end;
+        f3 org = F3s(0.0f), dir = F3s(0.0f), inv = F3s(0.0f);
+        float t_max = 0.0f, hit_u = 0.0f, hit_v = 0.0f;
+        uint32_t sign_bits = 0, hit_prim = RT_INVALID_ID, payload = 0, log_entry = 0;
+        if (valid)
+        {
+            float4 q0 = o4[i], q1 = d4[i], q2 = iv4[i];
+            org = F3(q0.x, q0.y, q0.z); t_max = q0.w;
+            dir = F3(q1.x, q1.y, q1.z); payload = __float_as_uint(q1.w);
+            inv = F3(q2.x, q2.y, q2.z);
+            sign_bits = (__float_as_uint(q2.w) & 0xFFu) | force_sign_bits;
+            log_entry = __float_as_uint(q2.w) >> 8;
+        }
+
+        unsigned long long todo = __ballot(valid);
+        while (todo)
+        {
+            // one group = the lanes that share the first pending lane's direction signs
+            const uint32_t first = (uint32_t)__ffsll((long long)todo) - 1u;
+            const uint32_t sgn = uniform_u32((uint32_t)__shfl((int)(sign_bits & 7u), (int)first, 64));
+            const unsigned long long group = __ballot(valid && (sign_bits & 7u) == sgn) & todo;
+            todo &= ~group;
+            const bool slow = __ballot((group & lane_bit) && (sign_bits & RT_SIGN_SLOW)) != 0ull;   // wave-uniform
+
+            unsigned long long alive = group;          // SHADOW: lanes leave on their first accepted hit
+            unsigned long long mask = group;           // lanes taking part in the current visit
+            uint32_t ref = sc.entry_ref;
+            int sp = 0;
+            for (;;)
+            {
+                bool need_pop = false;
+                if (ref & RT_LEAF_BIT)
+                {
+                    uint32_t prim = ref & ~RT_LEAF_BIT;
+                    for (;;)
+                    {
+                        const Rec64 t = scalar_fetch(sc.tris_rt, prim);
+                        const bool last = t.a.w != 0.0f;
+                        bool accepted = false;
+                        if (mask & alive & lane_bit)
+                        {
+                            // RayTriangle, trace_bvh.cl:28-73,155-169
+                            f3 p1 = F3(t.a.x, t.a.y, t.a.z), e1 = F3(t.b.x, t.b.y, t.b.z), e2 = F3(t.c.x, t.c.y, t.c.z);
+                            f3 pvec = cross3(dir, e2);
+                            float det = dot3(e1, pvec);
+                            if (!(det < 1e-8f || -det > 1e-8f))
+                            {
+                                float inv_det = 1.0f / det;
+                                f3 tvec = org - p1;
+                                float u = dot3(tvec, pvec) * inv_det;
+                                if (!(u < 0.0f || u > 1.0f))
+                                {
+                                    f3 qvec = cross3(tvec, e1);
+                                    float v = dot3(dir, qvec) * inv_det;
+                                    if (!(v < 0.0f || u + v > 1.0f))
+                                    {
+                                        float tt = dot3(e2, qvec) * inv_det;
+                                        if (!(tt < 0.0f || tt > t_max))
+                                        {
+                                            hit_u = u; hit_v = v; hit_prim = prim;
+                                            t_max = tt;
+                                            accepted = true;
+                                        }
+                                    }
+                                }
+                            }
+                        }
+                        if (SHADOW) alive &= ~__ballot(accepted);            // goto endtrace, :164-167
+                        if (last || (mask & alive) == 0ull) break;
+                        ++prim;
+                    }
+                    need_pop = true;
+                }
+                else
+                {
+                    const Rec64 n = scalar_fetch(sc.nodes, ref);
+                    const uint32_t c0 = __float_as_uint(n.d.x), c1 = __float_as_uint(n.d.y), axis = __float_as_uint(n.d.z);
+                    bool h0 = false, h1 = false;
+                    if (mask & alive & lane_bit)
+                    {
+                        h0 = packet_box(slow, n.a.x, n.a.y, n.a.z, n.a.w, n.b.x, n.b.y, org, inv, t_max);
+                        h1 = packet_box(slow, n.b.z, n.b.w, n.c.x, n.c.y, n.c.z, n.c.w, org, inv, t_max);
+                    }
+                    const unsigned long long m0 = __ballot(h0);
+                    const unsigned long long m1 = c1 != RT_EMPTY_REF ? __ballot(h1) : 0ull;
+                    const bool swap = (sgn >> axis) & 1u;                    // :181-190, the same for the whole group
+                    const unsigned long long m_near = swap ? m1 : m0, m_far = swap ? m0 : m1;
+                    const uint32_t near_ref = swap ? c1 : c0, far_ref = swap ? c0 : c1;
+                    if (m_near)
+                    {
+                        if (m_far)
+                        {
+                            const unsigned long long pm = mask & alive;
+                            if (lane == 0) pstack[sp] = make_uint4(ref, swap ? 0u : 1u, (uint32_t)pm, (uint32_t)(pm >> 32));
+                            ++sp;
+                        }
+                        ref = near_ref; mask = m_near;
+                    }
+                    else if (m_far) { ref = far_ref; mask = m_far; }
+                    else need_pop = true;
+                }
+                if (need_pop)
+                {
+                    bool found = false;
+                    while (sp > 0 && alive)
+                    {
+                        --sp;
+                        const uint4 e = pstack[sp];
+                        const uint32_t pref = uniform_u32(e.x), cidx = uniform_u32(e.y);
+                        const unsigned long long pm =
+                            (((unsigned long long)uniform_u32(e.w) << 32) | uniform_u32(e.z)) & alive;
+                        if (pm == 0ull) continue;
+                        const Rec64 n = scalar_fetch(sc.nodes, pref);
+                        bool h = false;
+                        if (pm & lane_bit)
+                            h = cidx ? packet_box(slow, n.b.z, n.b.w, n.c.x, n.c.y, n.c.z, n.c.w, org, inv, t_max)
+                                     : packet_box(slow, n.a.x, n.a.y, n.a.z, n.a.w, n.b.x, n.b.y, org, inv, t_max);
+                        const unsigned long long m = __ballot(h);
+                        if (m)
+                        {
+                            ref = cidx ? __float_as_uint(n.d.y) : __float_as_uint(n.d.x);
+                            mask = m;
+                            found = true;
+                            break;
+                        }
+                    }
+                    if (!found) break;
+                }
+            }
+        }
+
+        if (valid)
+        {
+            if (SHADOW)
+            {
+                if (hit_prim != RT_INVALID_ID)
+                    rlog[(size_t)log_entry * log_stride + payload] = make_float4(0, 0, 0, 0);
+            }
+            else
+            {
+                hits[i] = make_float4(hit_u, hit_v, __uint_as_float(hit_prim), t_max);
+            }
+        }
+    }
+}
