@@ -89,7 +89,7 @@ def cpu_legs(args, scene_arrays, cam_small, small_w, small_h, cam_full):
     per_ray = dict(closest_nodes=st["closest_nodes"] / max(c, 1), closest_tris=st["closest_tris"] / max(c, 1),
                    shadow_nodes=st["shadow_nodes"] / max(s, 1), shadow_tris=st["shadow_tris"] / max(s, 1))
     baseline = None
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and args.gpus == 1:          # the CPU baseline is timed at N = 1 only
         cores = os.cpu_count() or 1
         if _ref.available():
             # The reference appends to its ray queues with one same-address atomic per ray
