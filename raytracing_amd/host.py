@@ -21,7 +21,7 @@ EXPORTS = [
     "rth_render_finish", "rth_render_local_rows", "rth_render_global_row", "rth_render_sample_count",
     "rth_render_read_radiance", "rth_render_read_resolved", "rth_render_stats", "rth_render_frame_handle",
     "rth_render_ctx_handle", "rth_render_num_nodes", "rth_render_nodes", "rth_render_set_aov", "rth_render_resolve",
-    "rth_render_set_blue_noise_path", "rth_render_reserve_samples",
+    "rth_render_set_blue_noise_path", "rth_render_reserve_samples", "rth_scene_save_cache",
 ]
 
 
@@ -42,7 +42,7 @@ def load():
         "rth_scene_add_point_light": (None, [vp] + [f32] * 6),
         "rth_scene_set_env_path": (None, [vp, cp]), "rth_scene_set_env_image": (i32, [vp, vp, u32, u32]),
         "rth_scene_finalize": (i32, [vp]),
-        "rth_bvh_build": (vp, [vp]), "rth_bvh_destroy": (None, [vp]), "rth_bvh_num_nodes": (u32, [vp]),
+        "rth_bvh_build": (vp, [vp]), "rth_scene_save_cache": (i32, [vp, vp, C.c_char_p]), "rth_bvh_destroy": (None, [vp]), "rth_bvh_num_nodes": (u32, [vp]),
         "rth_bvh_nodes": (vp, [vp]),
         "rth_load_hdr": (i32, [cp, C.POINTER(u32), C.POINTER(u32)]),
         "rth_load_tga": (i32, [cp, C.POINTER(u32), C.POINTER(u32)]), "rth_loaded_image_data": (vp, []),
@@ -159,6 +159,13 @@ class Scene:
 
     def finalize(self):
         if self.lib.rth_scene_finalize(self.handle):
+            raise _err(self.lib)
+
+    def save_cache(self, path):
+        """Binary scene cache: reordered triangles + BVH nodes + materials + textures; Scene(path) loads it."""
+        if not self.bvh:
+            self.build_bvh()
+        if self.lib.rth_scene_save_cache(self.handle, self.bvh, path.encode()):
             raise _err(self.lib)
 
     def arrays(self):

@@ -84,11 +84,17 @@ void* rth_bvh_build(void* scene)
     return guard([&]() -> void*
     {
         auto* b = new rt::Bvh();
-        b->BuildCPU(((rt::Scene*)scene)->GetTriangles());
+        auto* s = (rt::Scene*)scene;
+        if (s->HasPrebuiltBvh()) b->AdoptNodes(s->GetPrebuiltNodes());
+        else b->BuildCPU(s->GetTriangles());
         return b;
     }, nullptr);
 }
 void rth_bvh_destroy(void* b) { delete (rt::Bvh*)b; }
+int rth_scene_save_cache(void* scene, void* bvh, const char* path)
+{
+    return guard([&]() { ((rt::Scene*)scene)->SaveCache(path, ((rt::Bvh*)bvh)->GetNodes()); return 0; }, 1);
+}
 uint32_t rth_bvh_num_nodes(void* b) { return (uint32_t)((rt::Bvh*)b)->GetNodes().size(); }
 const void* rth_bvh_nodes(void* b) { return ((rt::Bvh*)b)->GetNodes().data(); }
 

@@ -24,7 +24,7 @@ int main(int argc, char** argv)
     try
     {
         unsigned width = 1280, height = 720, spp = 16, bounces = 3;
-        std::string scene_path = "assets/ShaderBalls.obj", out;
+        std::string scene_path = "assets/ShaderBalls.obj", out, save_cache;
         float scale = 1.0f, aperture = 0.0f, focus = 10.0f;
         bool flip_yz = false, furnace = false;
         for (int i = 1; i < argc; ++i)
@@ -41,10 +41,12 @@ int main(int argc, char** argv)
             else if (!strcmp(argv[i], "--aperture")) aperture = (float)atof(next());
             else if (!strcmp(argv[i], "--focus")) focus = (float)atof(next());
             else if (!strcmp(argv[i], "--out")) out = next();
+            else if (!strcmp(argv[i], "--save-cache")) save_cache = next();
             else if (!strcmp(argv[i], "--help"))
             {
                 std::cout << "rt_render -w W -h H --scene file.obj [--scale s] [--flip_yz 0|1] [--spp n] [--bounces b]"
-                             " [--furnace 0|1] [--aperture a] [--focus d] [--out image.pfm]\n";
+                             " [--furnace 0|1] [--aperture a] [--focus d] [--out image.pfm] [--save-cache scene.rtscene]\n"
+                             "  --scene also accepts a file written by --save-cache (parsed scene + BVH)\n";
                 return 0;
             }
         }
@@ -52,6 +54,7 @@ int main(int argc, char** argv)
         scene.AddDirectionalLight({-0.6f, -1.5f, 3.5f}, {15.0f, 10.0f, 5.0f});   // main.cpp:58
         rt::Render render(width, height, scene);
         std::cout << "device: " << render.GetContext().DeviceName() << std::endl;
+        if (!save_cache.empty()) scene.SaveCache(save_cache.c_str(), render.GetAccelerationStructure().GetNodes());
         rt::Camera cam = rt::DefaultCamera(width, height);
         cam.aperture = aperture;
         cam.focus_distance = focus;

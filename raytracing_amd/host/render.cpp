@@ -32,8 +32,10 @@ Render::Render(std::uint32_t width, std::uint32_t height, Scene& scene, int devi
     context_ = std::make_shared<HIPContext>(device_ordinal);
     // Build first, Finalize after: the build reorders the triangles the emissive
     // list indexes (render.cpp:61-67)
-    acc_structure_ = std::make_unique<Bvh>();
-    acc_structure_->BuildCPU(scene_.GetTriangles());
+    auto bvh = std::make_unique<Bvh>();
+    if (scene_.HasPrebuiltBvh()) bvh->AdoptNodes(scene_.GetPrebuiltNodes());   // binary scene cache
+    else bvh->BuildCPU(scene_.GetTriangles());
+    acc_structure_ = std::move(bvh);
     scene_.Finalize();
     integrator_ = std::make_unique<HIPPathTraceIntegrator>(width_, height_, *acc_structure_, *context_, tile);
     integrator_->UploadGPUData(scene_, *acc_structure_);

@@ -306,7 +306,11 @@ void LoadMtl(const std::string& path, std::vector<ObjMaterial>& materials, std::
 // ---------------------------------------------------------------------------
 // Scene
 // ---------------------------------------------------------------------------
-Scene::Scene(const char* filename, float scale, bool flip_yz) { Load(filename, scale, flip_yz); }
+Scene::Scene(const char* filename, float scale, bool flip_yz)
+{
+    if (IsCacheFile(filename)) LoadCache(filename);
+    else Load(filename, scale, flip_yz);
+}
 
 Scene::Scene(std::vector<Triangle> triangles, std::vector<PackedMaterial> materials, std::vector<Texture> textures,
     std::vector<std::uint32_t> texture_data)

@@ -17,7 +17,8 @@ class Scene
 {
 public:
     // ---- construction -----------------------------------------------------------
-    // OBJ + MTL from disk (main.cpp:56); throws std::runtime_error on failure.
+    // OBJ + MTL from disk (main.cpp:56); throws std::runtime_error on failure.  A file written
+    // by SaveCache is recognised by its magic and loaded as is (scale / flip_yz are baked in).
     Scene(const char* filename, float scale, bool flip_yz);
     // Caller-built arrays (procedural scenes / binary caches); no file IO.
     Scene(std::vector<Triangle> triangles, std::vector<PackedMaterial> materials, std::vector<Texture> textures,
@@ -34,6 +35,12 @@ public:
     void SetEnvironmentPath(std::string path) { env_path_ = std::move(path); }
     void SetEnvironmentImage(Image image) { env_image_ = std::move(image); env_preset_ = true; }
 
+    // ---- binary cache (scene_cache.cpp): triangles in BVH order + nodes + materials + textures
+    void SaveCache(const char* path, std::vector<LinearBVHNode> const& nodes) const;
+    static bool IsCacheFile(const char* filename);
+    bool HasPrebuiltBvh() const { return !prebuilt_nodes_.empty(); }
+    std::vector<LinearBVHNode> const& GetPrebuiltNodes() const { return prebuilt_nodes_; }
+
     // ---- what the integrator uploads (scene.hpp:39-47) -----------------------------
     std::vector<Triangle>& GetTriangles() { return triangles_; }   // mutable: Bvh::BuildCPU reorders them
     std::vector<Triangle> const& GetTriangles() const { return triangles_; }
@@ -47,6 +54,7 @@ public:
 
 private:
     void Load(const char* filename, float scale, bool flip_yz);
+    void LoadCache(const char* path);
     std::size_t LoadTexture(const std::string& filename);   // cached by file name, returns the texture index
     void CollectEmissiveTriangles();
 
@@ -57,6 +65,7 @@ private:
     std::unordered_map<std::string, std::size_t> loaded_textures_;
     std::vector<Light> lights_;
     std::vector<std::uint32_t> emissive_indices_;
+    std::vector<LinearBVHNode> prebuilt_nodes_;             // from a cache file: Bvh adopts them instead of building
     SceneInfo scene_info_ = {};
     Image env_image_;
     std::string env_path_ = "assets/ibl/CGSkies_0036_free.hdr";

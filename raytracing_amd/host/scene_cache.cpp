@@ -1,0 +1,129 @@
+// scene_cache.cpp -- binary scene cache: everything Scene::Load and
+// Bvh::BuildCPU produce -- the REORDERED triangles, the LinearBVHNode array, packed
+// materials, texture table and RGBA8 atlas -- in one file, so that a multi-million-triangle
+// scene skips the OBJ/MTL parse, the texture decodes and the BVH build at start-up.
+// Lights and the environment map are not part of it: the reference adds them after loading
+// (main.cpp:58, scene.cpp:353-361) and so does the caller here.
+//
+// Layout (little endian): 64-byte header, then the five arrays back to back.
+//   magic "RTSCENE\1" | u32 version | u32 sizeof(Triangle) | u32 sizeof(LinearBVHNode) |
+//   u32 sizeof(PackedMaterial) | u64 counts[5] (triangles, nodes, materials, textures,
+//   texture words) | u64 checksum of the payload
+#include "scene.hpp"
+#include <cstdio>
+#include <cstring>
+#include <stdexcept>
+
+namespace rt
+{
+namespace
+{
+constexpr char kMagic[8] = {'R', 'T', 'S', 'C', 'E', 'N', 'E', 1};
+constexpr std::uint32_t kVersion = 1;
+
+struct Header
+{
+    char magic[8];
+    std::uint32_t version, triangle_size, node_size, material_size;
+    std::uint64_t counts[5];
+    std::uint64_t checksum;
+};
+static_assert(sizeof(Header) == 72, "cache header layout");
+
+// order-sensitive 64-bit checksum, 8 bytes per step (fast enough to stay IO-bound)
+struct Checksum
+{
+    std::uint64_t h = 0x9E3779B97F4A7C15ull;
+    void Add(const void* data, std::size_t bytes)
+    {
+        const unsigned char* p = static_cast<const unsigned char*>(data);
+        std::size_t words = bytes / 8;
+        for (std::size_t i = 0; i < words; ++i)
+        {
+            std::uint64_t w;
+            std::memcpy(&w, p + i * 8, 8);
+            h = (h ^ w) * 0xD6E8FEB86659FD93ull;
+            h = (h << 31) | (h >> 33);
+        }
+        std::uint64_t tail = 0;
+        std::memcpy(&tail, p + words * 8, bytes - words * 8);
+        h = (h ^ tail ^ (std::uint64_t)bytes) * 0xD6E8FEB86659FD93ull;
+    }
+};
+
+struct File
+{
+    std::FILE* f = nullptr;
+    File(const char* path, const char* mode) : f(std::fopen(path, mode)) {}
+    ~File() { if (f) std::fclose(f); }
+};
+
+template <class T>
+void WriteArray(std::FILE* f, std::vector<T> const& v, Checksum& sum, const char* path)
+{
+    if (!v.empty() && std::fwrite(v.data(), sizeof(T), v.size(), f) != v.size())
+        throw std::runtime_error(std::string("scene cache: short write to ") + path);
+    sum.Add(v.data(), v.size() * sizeof(T));
+}
+
+template <class T>
+void ReadArray(std::FILE* f, std::vector<T>& v, std::uint64_t count, Checksum& sum, const char* path)
+{
+    v.resize((std::size_t)count);
+    if (count && std::fread(v.data(), sizeof(T), (std::size_t)count, f) != count)
+        throw std::runtime_error(std::string("scene cache: truncated file ") + path);
+    sum.Add(v.data(), v.size() * sizeof(T));
+}
+} // namespace
+
+bool Scene::IsCacheFile(const char* filename)
+{
+    File in(filename, "rb");
+    char magic[8];
+    return in.f && std::fread(magic, 1, 8, in.f) == 8 && std::memcmp(magic, kMagic, 8) == 0;
+}
+
+void Scene::SaveCache(const char* path, std::vector<LinearBVHNode> const& nodes) const
+{
+    if (nodes.empty()) throw std::runtime_error("scene cache: no BVH to save (build it first)");
+    File out(path, "wb");
+    if (!out.f) throw std::runtime_error(std::string("scene cache: cannot create ") + path);
+    Header h = {};
+    std::memcpy(h.magic, kMagic, 8);
+    h.version = kVersion;
+    h.triangle_size = sizeof(Triangle); h.node_size = sizeof(LinearBVHNode); h.material_size = sizeof(PackedMaterial);
+    h.counts[0] = triangles_.size(); h.counts[1] = nodes.size(); h.counts[2] = materials_.size();
+    h.counts[3] = textures_.size(); h.counts[4] = texture_data_.size();
+    if (std::fwrite(&h, sizeof(h), 1, out.f) != 1) throw std::runtime_error(std::string("scene cache: short write to ") + path);
+    Checksum sum;
+    WriteArray(out.f, triangles_, sum, path);
+    WriteArray(out.f, nodes, sum, path);
+    WriteArray(out.f, materials_, sum, path);
+    WriteArray(out.f, textures_, sum, path);
+    WriteArray(out.f, texture_data_, sum, path);
+    h.checksum = sum.h;
+    if (std::fseek(out.f, 0, SEEK_SET) != 0 || std::fwrite(&h, sizeof(h), 1, out.f) != 1)
+        throw std::runtime_error(std::string("scene cache: cannot finish ") + path);
+}
+
+void Scene::LoadCache(const char* path)
+{
+    File in(path, "rb");
+    if (!in.f) throw std::runtime_error(std::string("scene cache: cannot open ") + path);
+    Header h;
+    if (std::fread(&h, sizeof(h), 1, in.f) != 1 || std::memcmp(h.magic, kMagic, 8) != 0)
+        throw std::runtime_error(std::string("scene cache: not a scene cache: ") + path);
+    if (h.version != kVersion || h.triangle_size != sizeof(Triangle) || h.node_size != sizeof(LinearBVHNode) ||
+        h.material_size != sizeof(PackedMaterial))
+        throw std::runtime_error(std::string("scene cache: written by an incompatible version: ") + path);
+    if (h.counts[0] == 0 || h.counts[1] == 0 || h.counts[0] > 0xFFFFFFFFull || h.counts[1] > 0xFFFFFFFFull)
+        throw std::runtime_error(std::string("scene cache: implausible counts in ") + path);
+    Checksum sum;
+    ReadArray(in.f, triangles_, h.counts[0], sum, path);
+    ReadArray(in.f, prebuilt_nodes_, h.counts[1], sum, path);
+    ReadArray(in.f, materials_, h.counts[2], sum, path);
+    ReadArray(in.f, textures_, h.counts[3], sum, path);
+    ReadArray(in.f, texture_data_, h.counts[4], sum, path);
+    if (sum.h != h.checksum) throw std::runtime_error(std::string("scene cache: checksum mismatch (corrupt file) ") + path);
+}
+} // namespace rt

@@ -564,3 +564,12 @@ def test_rt_render_cli(tmp_path):
     assert np.array_equal(img, orc.radiance()[..., :3] / np.float32(4.0))
     bad = subprocess.run([exe, "--scene", "assets/does_not_exist.obj"], cwd=ROOT, capture_output=True, text=True, timeout=60)
     assert bad.returncode == 1 and "Caught exception: Failed to load the scene!" in bad.stderr
+    # binary scene cache: written by one run, rendered by the next without parsing or building
+    cache, out2 = tmp_path / "cornell.rtscene", tmp_path / "img2.pfm"
+    w = subprocess.run([exe, "-w", "64", "-h", "48", "--scene", "assets/CornellBox.obj", "--spp", "1", "--bounces", "4",
+                        "--save-cache", str(cache)], cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert w.returncode == 0 and cache.exists(), w.stderr
+    r2 = subprocess.run([exe, "-w", "64", "-h", "48", "--scene", str(cache), "--spp", "4", "--bounces", "4",
+                         "--out", str(out2)], cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert r2.returncode == 0, r2.stderr
+    assert open(out2, "rb").read() == raw

@@ -169,6 +169,33 @@ def test_tga_loader_roundtrip(tmp_path):
     assert img.shape == (1, 4) and (img == (30 | (20 << 8) | (10 << 16) | (40 << 24))).all()
 
 
+def test_binary_scene_cache_round_trip(tmp_path):
+    """Scene.save_cache writes the reordered triangles, the BVH nodes, materials and textures;
+    Scene(path) recognises the file by its magic and yields the same arrays without building;
+    truncation and bit flips are rejected."""
+    cov = S.coverage_scene()
+    s = host.Scene(arrays=cov)
+    nodes = s.build_bvh()
+    path = str(tmp_path / "coverage.rtscene")
+    s.save_cache(path)
+    a = s.arrays()
+    c = host.Scene(path)                      # scale / flip_yz are baked into the cache
+    cn = c.build_bvh()                        # adopts the cached nodes
+    b = c.arrays()
+    assert T.records_equal(nodes, cn)
+    for k in ("triangles", "materials", "textures"):
+        assert T.records_equal(a[k], b[k]), k
+    assert np.array_equal(a["texture_data"], b["texture_data"])
+    raw = bytearray(open(path, "rb").read())
+    open(str(tmp_path / "short.rtscene"), "wb").write(raw[: len(raw) // 2])
+    with pytest.raises(host.RtError, match="truncated"):
+        host.Scene(str(tmp_path / "short.rtscene"))
+    raw[len(raw) // 2] ^= 0x40
+    open(str(tmp_path / "flip.rtscene"), "wb").write(raw)
+    with pytest.raises(host.RtError, match="checksum"):
+        host.Scene(str(tmp_path / "flip.rtscene"))
+
+
 @pytest.mark.skipif(not _ref.available(), reason="oracle/_ref/libref.so not built")
 class TestAgainstReferenceHost:
     def test_bvh_identical_to_reference_builder(self):
