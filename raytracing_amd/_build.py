@@ -52,7 +52,7 @@ def build_hip(force=False):
 
 def build_host(force=False):
     out = os.path.join(HERE, "librt_host.so")
-    cpps = [os.path.join(HOST, f) for f in ("bvh.cpp", "scene.cpp", "scene_cache.cpp", "png_loader.cpp", "integrator.cpp",
+    cpps = [os.path.join(HOST, f) for f in ("bvh.cpp", "scene.cpp", "scene_cache.cpp", "png_loader.cpp", "jpeg_loader.cpp", "integrator.cpp",
                                             "hip_pt_integrator.cpp", "render.cpp", "host_capi.cpp")]
     deps = cpps + [os.path.join(HOST, f) for f in os.listdir(HOST) if f.endswith(".hpp")]
     deps += [os.path.join(ROOT, "include", f) for f in ("rt_hip.h", "rt_types.h")]

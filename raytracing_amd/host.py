@@ -21,7 +21,7 @@ EXPORTS = [
     "rth_render_finish", "rth_render_local_rows", "rth_render_global_row", "rth_render_sample_count",
     "rth_render_read_radiance", "rth_render_read_resolved", "rth_render_stats", "rth_render_frame_handle",
     "rth_render_ctx_handle", "rth_render_num_nodes", "rth_render_nodes", "rth_render_set_aov", "rth_render_resolve",
-    "rth_render_set_blue_noise_path", "rth_render_reserve_samples", "rth_scene_save_cache",
+    "rth_render_set_blue_noise_path", "rth_render_reserve_samples", "rth_scene_save_cache", "rth_load_jpeg",
 ]
 
 
@@ -47,6 +47,7 @@ def load():
         "rth_load_hdr": (i32, [cp, C.POINTER(u32), C.POINTER(u32)]),
         "rth_load_tga": (i32, [cp, C.POINTER(u32), C.POINTER(u32)]), "rth_loaded_image_data": (vp, []),
         "rth_load_png": (i32, [cp, C.POINTER(u32), C.POINTER(u32)]),
+        "rth_load_jpeg": (i32, [cp, C.POINTER(u32), C.POINTER(u32)]),
         "rth_default_camera": (None, [u32, u32, vp]), "rth_make_camera": (None, [f32] * 9 + [vp]),
         "rth_render_create": (vp, [u32, u32, vp, i32, u32, u32, u32]), "rth_render_destroy": (None, [vp]),
         "rth_render_set_camera": (i32, [vp, vp]), "rth_render_set_max_bounces": (i32, [vp, u32]),
@@ -104,6 +105,14 @@ def load_tga(path):
     w, h = C.c_uint32(), C.c_uint32()
     if lib.rth_load_tga(path.encode(), C.byref(w), C.byref(h)):
         raise RtError("LoadTGA failed: " + path)
+    return _arr(lib.rth_loaded_image_data(), w.value * h.value, np.uint32).reshape(h.value, w.value)
+
+
+def load_jpeg(path):
+    lib = load()
+    w, h = C.c_uint32(), C.c_uint32()
+    if lib.rth_load_jpeg(path.encode(), C.byref(w), C.byref(h)):
+        raise RtError("LoadJPEG failed: " + path)
     return _arr(lib.rth_loaded_image_data(), w.value * h.value, np.uint32).reshape(h.value, w.value)
 
 

@@ -107,6 +107,13 @@ int rth_load_hdr(const char* path, uint32_t* w, uint32_t* h)
     *w = g_img.width; *h = g_img.height;
     return 0;
 }
+int rth_load_jpeg(const char* path, uint32_t* w, uint32_t* h)
+{
+    g_img = rt::Image();
+    if (!rt::LoadJPEG(path, g_img)) return 1;
+    *w = g_img.width; *h = g_img.height;
+    return 0;
+}
 int rth_load_tga(const char* path, uint32_t* w, uint32_t* h)
 {
     g_img = rt::Image();

@@ -492,9 +492,7 @@ std::size_t Scene::LoadTexture(const std::string& filename)   // scene.cpp:276-3
     bool ok = false;
     if (ext == ".tga") ok = LoadTGA(filename.c_str(), image);
     else if (ext == ".png") ok = LoadPNG(filename.c_str(), image);
-    else if (ext == ".jpg")
-        throw std::runtime_error("JPEG textures are not supported by the HIP host layer (" + filename +
-                                 "): a lossy decoder cannot reproduce stb_image's texels bit for bit; convert to .png or .tga");
+    else if (ext == ".jpg") ok = LoadJPEG(filename.c_str(), image);
     if (!ok) throw std::runtime_error("Failed to load file " + filename);
     if (textures_.size() >= 255) throw std::runtime_error("More than 255 textures (8-bit texture index, constants.h:35)");
     Texture t;

@@ -11,7 +11,8 @@ namespace rt
 {
 bool LoadHDR(const char* filename, Image& result);   // Radiance RGBE (reference: src/loaders/hdr_loader.cpp:29-100)
 bool LoadTGA(const char* filename, Image& result);
-bool LoadPNG(const char* filename, Image& result);   // png_loader.cpp   // 8-bit TGA -> packed RGBA8 (reference path: LoadSTB, image_loader.cpp:30-63)
+bool LoadPNG(const char* filename, Image& result);   // png_loader.cpp
+bool LoadJPEG(const char* filename, Image& result);  // jpeg_loader.cpp (stb_image's integer pipeline, texel for texel)   // 8-bit TGA -> packed RGBA8 (reference path: LoadSTB, image_loader.cpp:30-63)
 
 class Scene
 {

@@ -169,6 +169,20 @@ def test_tga_loader_roundtrip(tmp_path):
     assert img.shape == (1, 4) and (img == (30 | (20 << 8) | (10 << 16) | (40 << 24))).all()
 
 
+def test_jpeg_loader_matches_stb_image_texels():
+    """LoadJPEG restates stb_image's integer pipeline (IDCT, upsampling, colour conversion); the
+    committed files were decoded by the REFERENCE's stb build (tests/golden/make_jpeg_golden.py):
+    baseline / progressive, 4:4:4 / 4:2:2 / 4:2:0, greyscale, restart intervals, 1x1."""
+    d = os.path.join(ROOT, "tests", "golden", "jpeg")
+    want = np.load(os.path.join(d, "jpeg_texels.npz"))
+    assert len(want.files) >= 7
+    for name in want.files:
+        got = host.load_jpeg(os.path.join(d, name + ".jpg"))
+        assert got.shape == want[name].shape and np.array_equal(got, want[name]), name
+    with pytest.raises(host.RtError):
+        host.load_jpeg(os.path.join(d, "jpeg_texels.npz"))          # not a JPEG
+
+
 def test_binary_scene_cache_round_trip(tmp_path):
     """Scene.save_cache writes the reordered triangles, the BVH nodes, materials and textures;
     Scene(path) recognises the file by its magic and yields the same arrays without building;
@@ -225,6 +239,23 @@ class TestAgainstReferenceHost:
             mn = s.build_bvh()
             assert T.records_equal(rn, mn)
             assert T.records_equal(rt, s.arrays()["triangles"])
+
+    def test_jpeg_loader_against_reference_stb_on_generated_files(self, tmp_path):
+        PI = pytest.importorskip("PIL.Image")
+        from tests.golden.make_jpeg_golden import photo
+        rng = np.random.default_rng(11)
+        n = 0
+        for (w, h) in ((64, 48), (17, 23), (8, 8), (33, 9), (2, 5), (131, 67)):
+            for sub in (0, 1, 2):
+                for prog in (False, True):
+                    for q, restart in ((35, 0), (90, 5)):
+                        p = str(tmp_path / ("t%d.jpg" % n)); n += 1
+                        PI.fromarray(photo(w, h, rng), "RGB").save(p, "JPEG", quality=q, subsampling=sub, progressive=prog,
+                                                                     restart_marker_blocks=restart, optimize=bool(n % 2))
+                        assert np.array_equal(_ref.load_stb(p), host.load_jpeg(p)), (w, h, sub, prog, q, restart)
+        asset = "/root/reference/assets/checker3.jpg"               # the reference's own (progressive 4:2:0) asset
+        if os.path.exists(asset):
+            assert np.array_equal(_ref.load_stb(asset), host.load_jpeg(asset))
 
     def test_obj_loader_identical_to_reference_scene(self, tmp_path):
         meshes = [S.quad((-1, -1, 0), (1, -1, 0), (1, 1, 0), (-1, 1, 0)) + (0,),
@@ -338,7 +369,7 @@ def test_png_loader_expected_texels(tmp_path):
         host.load_png(str(tmp_path / "missing.png"))
 
 
-def test_scene_loads_png_and_tga_textures_and_rejects_jpg(tmp_path):
+def test_scene_loads_png_and_jpeg_textures(tmp_path):
     rng = np.random.RandomState(6)
     _write_png(str(tmp_path / "kd.png"), rng.randint(0, 256, (8, 8, 3)), 2, filters=[4])
     (tmp_path / "t.obj").write_text("mtllib t.mtl\nv 0 0 0\nv 1 0 0\nv 0 1 0\nvn 0 0 1\nvt 0 0\nvt 1 0\nvt 0 1\n"
@@ -349,9 +380,16 @@ def test_scene_loads_png_and_tga_textures_and_rejects_jpg(tmp_path):
     assert len(a["texture_data"]) == 64
     m = a["materials"][0]
     assert (int(m["diffuse_albedo"]) >> 24) == 0 and ((int(m["roughness_metalness"]) >> 8) & 0xFF) == 0
+    import shutil
+    gold = os.path.join(ROOT, "tests", "golden", "jpeg")
+    shutil.copy(os.path.join(gold, "baseline_420_restart.jpg"), tmp_path / "photo.jpg")
     (tmp_path / "j.mtl").write_text("newmtl m\nKd 1 1 1\nmap_Kd photo.jpg\n")
     (tmp_path / "j.obj").write_text("mtllib j.mtl\nv 0 0 0\nv 1 0 0\nv 0 1 0\nvn 0 0 1\nusemtl m\nf 1//1 2//1 3//1\n")
-    with pytest.raises(host.RtError, match="JPEG"):
+    j = host.Scene(str(tmp_path / "j.obj")).arrays()
+    assert (int(j["textures"][0]["width"]), int(j["textures"][0]["height"])) == (57, 35)
+    assert np.array_equal(j["texture_data"], np.load(os.path.join(gold, "jpeg_texels.npz"))["baseline_420_restart"].ravel())
+    (tmp_path / "j.mtl").write_text("newmtl m\nKd 1 1 1\nmap_Kd missing.jpg\n")
+    with pytest.raises(host.RtError, match="Failed to load file"):
         host.Scene(str(tmp_path / "j.obj"))
 
 
