@@ -768,6 +768,10 @@ void launch_trace(rt_frame* f, const float4* o4, const float4* d4, const float4*
         // (profiles/r01_variants_3_samples_in_flight.log)
         uint64_t paths = (uint64_t)f->n_local * (f->cur_slots ? f->cur_slots : 1u);
         variant = paths >= 2000000ull ? 3u : 0u;
+        // closest-hit rays: a 10-entry LDS stack (32 waves per CU instead of 26) wins 2-5 % unless the
+        // tree is deep enough to spill often (10 M triangles: -1.5 %); shadow rays always lose with it
+        // (profiles/r01_variants_7_stack_10_vs_12.log)
+        if (variant == 3u && !SHADOW && ctx->scene.d.entry_ref < 4000000u) variant = 6u;
     }
     switch (variant)
     {
