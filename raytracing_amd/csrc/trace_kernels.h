@@ -246,8 +246,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(STACK <= 10 
     const uint32_t xcd = blockIdx.x & 7u;
     // eight contiguous regions of the queue, 64-ray aligned, one per XCD (L2 affinity)
     const uint32_t per = (((count + 7u) >> 3) + 63u) & ~63u;
-    uint2* my_spill = spill + (size_t)(blockIdx.x * 64u + lane) * (RT_TRACE_STACK_MAX - STACK);
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    // per-lane spill area, addressed on demand (keeps two VGPRs free: 64 registers = 8 waves per SIMD)
+    const uint32_t spill_base = (blockIdx.x * 64u + lane) * (uint32_t)(RT_TRACE_STACK_MAX - STACK);
 
     uint32_t pool_next = 0, pool_end = 0, regions_tried = 0;   // wave-uniform
     uint32_t state = ST_NEED;
@@ -317,7 +317,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(STACK <= 10 
                 }
             }
             uint32_t avail = pool_end - pool_next;
-            uint32_t rank = (uint32_t)__popcll(need & lt_mask);
+            uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
             uint32_t n = (uint32_t)__popcll(need);
             if (state == ST_NEED && rank < avail)
             {
@@ -435,7 +435,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(STACK <= 10 
                     {
                         uint2 e = make_uint2(far_ref, __float_as_uint(far_entry));
                         if (sp < STACK) stack[sp][lane] = e;
-                        else my_spill[sp - STACK] = e;
+                        else spill[(size_t)spill_base + (uint32_t)(sp - STACK)] = e;
                         ++sp;
                     }
                     ref = near_ref;
@@ -449,7 +449,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(STACK <= 10 
                 while (sp > 0)
                 {
                     --sp;
-                    uint2 e = (sp < STACK) ? stack[sp][lane] : my_spill[sp - STACK];
+                    uint2 e = (sp < STACK) ? stack[sp][lane] : spill[(size_t)spill_base + (uint32_t)(sp - STACK)];
                     if (t_max >= __uint_as_float(e.y))                       // box re-test at pop time
                     {
                         ref = e.x;
