@@ -138,7 +138,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=256)
-    ap.add_argument("--warmup", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=-1,
+                    help="untimed warm-up steps; default: one full batch (the samples traced together), so that warm-up "
+                         "and timed launches have the same size")
     ap.add_argument("--config", type=int, default=4, choices=sorted(CONFIGS),
                     help="BASELINE.json config (1-based index into 'configs'); default 4 = the one the metric is quoted on "
                          "(Bistro 1080p 8-bounce stand-in)")
@@ -204,6 +206,8 @@ def main():
     # per-path buffers sized for the K-sample job before anything is timed (they would
     # otherwise grow inside the first rt_integrate that asks for a larger batch)
     in_flight = render.reserve_samples(args.steps)
+    if args.warmup < 0:
+        args.warmup = in_flight
 
     # ---- warm-up ------------------------------------------------------------
     render.render_samples(args.warmup) if args.warmup > 0 else None

@@ -32,7 +32,8 @@ doc["config_%s" % config] = {
     "l1_accesses_per_clk_per_cu": sum(tcp) / 256.0 / (sum(gui) / 8.0) * (len(gui) / len(tcp)),
     "l1_hit_rate": 1.0 - sum(l2r) / sum(tcp),
     "l2_hit_rate": sum(hit) / sum(req),
-    "kernel": "k_trace<false,12>",
+    "kernel": next(r["Kernel_Name"].split("(")[0].replace("void ", "") for r in csv.DictReader(open(d + "/fetch_counter_collection.csv"))
+                   if "k_trace<false" in r["Kernel_Name"]),
     "dispatches": len(fetch),
     "FETCH_SIZE_KB_per_dispatch": sum(fetch) / len(fetch),
     "WRITE_SIZE_KB_per_dispatch": sum(write) / len(write),
