@@ -52,6 +52,7 @@ struct DScene
     const uint32_t* texture_data;
     const float4* lights;         // 3 x float4 per light: origin, radiance, (type bits,0,0,0)
     const float4* env;
+    const float* gamma_lut;       // pow(byte / 255, 2.2f) for the 256 texel values (k_fill_gamma_lut)
     int env_w, env_h;
     uint32_t light_count;
     uint32_t root_ref;            // RT_LEAF_BIT | first triangle, or interior node 0

@@ -32,6 +32,7 @@ struct rt_ctx
     Scene scene;
     uint32_t treelet_nodes = 7;   // RT_CTX_OPT_TREELET_NODES
     uint8_t* blue_noise = nullptr;   // sobol[65536] | scramblingTile[131072] | rankingTile[131072]
+    float* gamma_lut = nullptr;      // pow(byte / 255, 2.2f), 256 entries (k_fill_gamma_lut)
 };
 
 struct rt_buffer
@@ -145,6 +146,12 @@ int rt_ctx_create(int device_ordinal, rt_ctx** out)
         delete ctx;
         return fail(nullptr, "rt_ctx_create: device initialisation failed");
     }
+    if (hipMalloc((void**)&ctx->gamma_lut, 256 * sizeof(float)) != hipSuccess)
+    {
+        delete ctx;
+        return fail(nullptr, "rt_ctx_create: out of device memory");
+    }
+    hipLaunchKernelGGL(k_fill_gamma_lut, dim3(1), dim3(256), 0, ctx->stream, ctx->gamma_lut);
     *out = ctx;
     return RT_OK;
 }
@@ -156,6 +163,7 @@ int rt_ctx_destroy(rt_ctx* ctx)
     (void)hipStreamSynchronize(ctx->stream);
     free_scene(ctx->scene);
     if (ctx->blue_noise) (void)hipFree(ctx->blue_noise);
+    if (ctx->gamma_lut) (void)hipFree(ctx->gamma_lut);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return RT_OK;
@@ -419,6 +427,7 @@ int rt_scene_upload(rt_ctx* ctx, const rt_scene_desc* sd)
     s.d.texture_data = (const uint32_t*)s.texture_data;
     s.d.lights = (const float4*)s.lights;
     s.d.env = (const float4*)s.env;
+    s.d.gamma_lut = ctx->gamma_lut;
     s.d.env_w = (int)sd->env_width;
     s.d.env_h = (int)sd->env_height;
     s.d.light_count = sd->num_lights;

@@ -30,7 +30,27 @@ RT_DEV f3 SampleTexture(const DScene& sc, uint32_t tex_idx, f2 uv)
     return F3(cl_min(cl_max(r, 0.0f), 1.0f), cl_min(cl_max(g, 0.0f), 1.0f), cl_min(cl_max(b, 0.0f), 1.0f));
 }
 
-RT_DEV f3 pow3(f3 a, float e) { return F3(rt_powf(a.x, e), rt_powf(a.y, e), rt_powf(a.z, e)); }
+// pow(SampleTexture(...), 2.2f) (material.h:327,336,361).  A texel channel is one of 256 values,
+// so the three rt_powf evaluations (~200 fp64 operations each, paid by the whole wave as soon as
+// one lane has a textured material) are a table of the very same function, filled on the device
+// by the very same code (k_fill_gamma_lut) -- identical bits by construction.
+RT_DEV f3 SampleTextureGamma(const DScene& sc, uint32_t tex_idx, f2 uv)
+{
+    rt_texture tex = sc.textures[tex_idx];
+    uv.x -= __builtin_floorf(uv.x);
+    uv.y -= __builtin_floorf(uv.y);
+    uv.y = 1.f - uv.y;
+    int texel_x = cl_clampi((int)(uv.x * (float)tex.width), 0, tex.width - 1);
+    int texel_y = cl_clampi((int)(uv.y * (float)tex.height), 0, tex.height - 1);
+    uint32_t data = sc.texture_data[tex.data_start + texel_y * tex.width + texel_x];
+    return F3(sc.gamma_lut[data & 0xFF], sc.gamma_lut[(data >> 8) & 0xFF], sc.gamma_lut[(data >> 16) & 0xFF]);
+}
+
+__global__ void k_fill_gamma_lut(float* __restrict__ lut)
+{
+    float v = (float)threadIdx.x / 255.0f;
+    lut[threadIdx.x] = rt_powf(cl_min(cl_max(v, 0.0f), 1.0f), 2.2f);   // SampleTexture's clamp, then pow
+}
 
 RT_DEV f3 UnpackRGBTex(uint32_t data, uint32_t& idx)                    // utils.h:133-147
 {
@@ -43,9 +63,9 @@ RT_DEV void ApplyTextures(const DScene& sc, rt_packed_material in, Material& out
 {
     uint32_t idx;
     out.diffuse_albedo = UnpackRGBTex(in.diffuse_albedo, idx);
-    if (idx != RT_INVALID_TEXTURE_IDX) out.diffuse_albedo = pow3(SampleTexture(sc, idx, uv), 2.2f);
+    if (idx != RT_INVALID_TEXTURE_IDX) out.diffuse_albedo = SampleTextureGamma(sc, idx, uv);
     out.specular_albedo = UnpackRGBTex(in.specular_albedo, idx);
-    if (idx != RT_INVALID_TEXTURE_IDX) out.specular_albedo = pow3(SampleTexture(sc, idx, uv), 2.2f);
+    if (idx != RT_INVALID_TEXTURE_IDX) out.specular_albedo = SampleTextureGamma(sc, idx, uv);
     {
         uint32_t rgbe = in.emission;                                     // utils.h:149-158
         int r = (int)(rgbe & 0xFF), g = (int)((rgbe >> 8) & 0xFF), b = (int)((rgbe >> 16) & 0xFF);
@@ -66,7 +86,7 @@ RT_DEV void ApplyTextures(const DScene& sc, rt_packed_material in, Material& out
     out.transparency = (float)((d >> 16) & 0xFF) / 255.0f;
     uint32_t transparency_idx = (d >> 24) & 0xFF;
     if (emission_idx != RT_INVALID_TEXTURE_IDX)
-        out.emission = out.emission * pow3(SampleTexture(sc, emission_idx, uv), 2.2f);
+        out.emission = out.emission * SampleTextureGamma(sc, emission_idx, uv);
     if (transparency_idx != RT_INVALID_TEXTURE_IDX)
         out.transparency *= SampleTexture(sc, transparency_idx, uv).x;
 }
