@@ -240,6 +240,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(STACK <= 10 
     float4* __restrict__ rlog, uint32_t log_stride, uint32_t force_sign_bits, uint2* __restrict__ spill)
 {
     __shared__ uint2 stack[STACK][64];
+    uint32_t* const stack32 = reinterpret_cast<uint32_t*>(&stack[0][0]);     // SHADOW: 2 * STACK entries of 4 bytes
+    uint32_t* const spill32 = reinterpret_cast<uint32_t*>(spill);
     const uint32_t lane = threadIdx.x;
     const uint32_t count = *count_ptr;
     if (count == 0) return;
@@ -433,9 +435,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(STACK <= 10 
                 {
                     if (far_hit)
                     {
-                        uint2 e = make_uint2(far_ref, __float_as_uint(far_entry));
-                        if (sp < STACK) stack[sp][lane] = e;
-                        else spill[(size_t)spill_base + (uint32_t)(sp - STACK)] = e;
+                        if (SHADOW)
+                        {
+                            // t_max of a shadow ray never changes (it stops at its first accepted
+                            // triangle), so a child that passes the box test now passes it at pop
+                            // time: the entry is the reference alone and twice as many fit in LDS
+                            if (sp < 2 * STACK) stack32[sp * 64 + lane] = far_ref;
+                            else spill32[(size_t)2 * spill_base + (uint32_t)(sp - 2 * STACK)] = far_ref;
+                        }
+                        else
+                        {
+                            uint2 e = make_uint2(far_ref, __float_as_uint(far_entry));
+                            if (sp < STACK) stack[sp][lane] = e;
+                            else spill[(size_t)spill_base + (uint32_t)(sp - STACK)] = e;
+                        }
                         ++sp;
                     }
                     ref = near_ref;
@@ -446,17 +459,27 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(STACK <= 10 
             if (need_pop)
             {
                 finished = true;
-                while (sp > 0)
+                if (SHADOW)
                 {
-                    --sp;
-                    uint2 e = (sp < STACK) ? stack[sp][lane] : spill[(size_t)spill_base + (uint32_t)(sp - STACK)];
-                    if (t_max >= __uint_as_float(e.y))                       // box re-test at pop time
+                    if (sp > 0)
                     {
-                        ref = e.x;
+                        --sp;
+                        ref = (sp < 2 * STACK) ? stack32[sp * 64 + lane] : spill32[(size_t)2 * spill_base + (uint32_t)(sp - 2 * STACK)];
                         finished = false;
-                        break;
                     }
                 }
+                else
+                    while (sp > 0)
+                    {
+                        --sp;
+                        uint2 e = (sp < STACK) ? stack[sp][lane] : spill[(size_t)spill_base + (uint32_t)(sp - STACK)];
+                        if (t_max >= __uint_as_float(e.y))                   // box re-test at pop time
+                        {
+                            ref = e.x;
+                            finished = false;
+                            break;
+                        }
+                    }
             }
         }
 
