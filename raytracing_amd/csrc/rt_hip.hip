@@ -56,6 +56,7 @@ struct rt_frame
     float4* rlog = nullptr; uint32_t* cnt = nullptr;
     uint32_t slots = 1;            // samples traced concurrently (resolved from slots_opt)
     uint32_t slots_opt = 0;        // RT_OPT_SAMPLES_IN_FLIGHT as set by the caller (0 = auto)
+    uint32_t slots_limit = 0;      // != 0: a larger batch did not fit into device memory
     uint32_t cur_slots = 0;        // slots used by the batch in flight (0 = nothing pending)
     uint32_t log_stride = 0;       // elements per log entry row = slots * n_local
     uint32_t log_entries = 0;      // rows allocated (>= 2 * (max_bounces + 1))
@@ -465,7 +466,11 @@ uint32_t auto_slots(uint32_t n_local, uint32_t max_bounces)
 }
 
 // the most samples rt_integrate will trace together
-uint32_t slot_cap(const rt_frame* f) { return f->slots_opt ? f->slots_opt : auto_slots(f->n_local, f->max_bounces); }
+uint32_t slot_cap(const rt_frame* f)
+{
+    uint32_t cap = f->slots_opt ? f->slots_opt : auto_slots(f->n_local, f->max_bounces);
+    return f->slots_limit && f->slots_limit < cap ? f->slots_limit : cap;    // what the device could actually hold
+}
 
 int alloc_path_buffers(rt_frame* f, uint32_t slots)
 {
@@ -505,7 +510,16 @@ int ensure_slots(rt_frame* f, uint32_t want)
     if (flush_log(f) != RT_OK) return RT_ERROR;
     HIPCHK(f->ctx, hipStreamSynchronize(f->ctx->stream));
     uint32_t keep = f->slots < cap ? f->slots : cap;
-    return alloc_path_buffers(f, want > keep ? want : keep);
+    uint32_t n = want > keep ? want : keep;
+    // HBM shared with other frames / processes: halve the batch until the buffers fit
+    while (alloc_path_buffers(f, n) != RT_OK)
+    {
+        if (n == 1) return RT_ERROR;
+        n = n > 2u * keep && keep > 0 ? n / 2u : (n > keep ? keep : n / 2u);
+        if (n == 0) n = 1;
+        f->slots_limit = n;
+    }
+    return RT_OK;
 }
 
 // Adds the logged contributions of the batch in flight to the running sum.
