@@ -573,3 +573,9 @@ def test_rt_render_cli(tmp_path):
                          "--out", str(out2)], cwd=ROOT, capture_output=True, text=True, timeout=300)
     assert r2.returncode == 0, r2.stderr
     assert open(out2, "rb").read() == raw
+
+
+def test_graft_entry_smoke():
+    """The driver's round-end smoke check: one small invocation of the hot path against the oracle."""
+    import __graft_entry__
+    __graft_entry__.smoke()
