@@ -3,15 +3,20 @@
 
   python bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of the hot path over one batch: one Integrator::Integrate()
-= one sample per pixel of the full frame (raygen, then per bounce: closest-hit
-trace, miss+shade, shadow trace+accumulate).  Workload: the configuration
-BASELINE.json's metric is quoted on, configs[3] "Amazon Lumberyard Bistro
-1920x1080 256spp 8-bounce" -- it fits one GPU, so N = 1 runs it whole and N > 1
-tiles it.  The Bistro asset is a download the reference does not ship
-(assets/download_bistro.bat), so the deterministic stand-in of SURVEY.md section
-8d is generated (raytracing_amd/scenes.py: city_block, ~2.8 M triangles, 120
-materials, textured); default K = 256 steps = the config's 256 spp.  --config 2 / 3 / 5 select the other BASELINE
+A "step" is one pass of the hot path over one batch: the wavefront loop (raygen,
+then per bounce: closest-hit trace, miss+shade, shadow trace+accumulate, then the
+replay of the radiance log) over the batch of samples the path keeps in flight --
+`samples_per_step` samples per pixel of the full frame (128 for the default
+config, fixed per config and independent of N, so K steps are the same work at
+every N).  That is the unit rt_integrate() works in; the reference's Integrate()
+is the same loop over one sample per pixel, and `ms_per_spp` is reported next to
+`ms_per_step`.  Workload: the configuration BASELINE.json's metric is quoted on,
+configs[3] "Amazon Lumberyard Bistro 1920x1080 256spp 8-bounce" -- it fits one
+GPU, so N = 1 runs it whole and N > 1 tiles it.  The Bistro asset is a download
+the reference does not ship (assets/download_bistro.bat), so the deterministic
+stand-in of SURVEY.md section 8d is generated (raytracing_amd/scenes.py:
+city_block, ~2.8 M triangles, 120 materials, textured); default K = 2 steps =
+the config's 256 spp, W = 1.  --config 2 / 3 / 5 select the other BASELINE
 configs' stand-ins.  Metric = BASELINE.json's: Mrays/s, all bounces + shadow
 rays, counted by the device queue counters the reference itself keeps
 (ray_counter_buffer_, shadow_ray_counter_buffer_).
@@ -47,13 +52,13 @@ LIGHT = ((-0.6, -1.5, 3.5), (15.0, 10.0, 5.0))   # reference main.cpp:58
 
 # BASELINE.json configs (index = position in "configs"); config 1 is the CPU plumbing case.
 CONFIGS = {
-    2: dict(width=1280, height=720, bounces=8, name="BASELINE configs[1] stand-in: Cornell shell + %(blob)d-tri displaced "
+    2: dict(width=1280, height=720, bounces=8, samples_per_step=256, name="BASELINE configs[1] stand-in: Cornell shell + %(blob)d-tri displaced "
             "blob (dragon mtl) + %(ball)d-tri sphere (teapot mtl)"),
-    3: dict(width=1920, height=1080, bounces=3, name="BASELINE configs[2] stand-in: ShaderBalls.mtl 3x3 material grid on "
+    3: dict(width=1920, height=1080, bounces=3, samples_per_step=128, name="BASELINE configs[2] stand-in: ShaderBalls.mtl 3x3 material grid on "
             "tessellated spheres + floor + 3 emissive quads, loaded from a generated OBJ (GGX+Lambert heavy)"),
-    4: dict(width=1920, height=1080, bounces=8, name="BASELINE configs[3] stand-in: procedural 'city block' (boxes, props, "
+    4: dict(width=1920, height=1080, bounces=8, samples_per_step=128, name="BASELINE configs[3] stand-in: procedural 'city block' (boxes, props, "
             "displaced foliage, 120 materials, textured) ~2.8 M triangles in place of Bistro exterior"),
-    5: dict(width=3840, height=2160, bounces=16, name="BASELINE configs[4] stand-in: procedural dense foliage courtyard "
+    5: dict(width=3840, height=2160, bounces=16, samples_per_step=16, name="BASELINE configs[4] stand-in: procedural dense foliage courtyard "
             "~10 M triangles in place of San Miguel (deep BVH, high divergence)"),
 }
 
@@ -137,10 +142,10 @@ def cpu_legs(args, scene_arrays, cam_small, small_w, small_h, cam_full):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=256)
-    ap.add_argument("--warmup", type=int, default=-1,
-                    help="untimed warm-up steps; default: one full batch (the samples traced together), so that warm-up "
-                         "and timed launches have the same size")
+    ap.add_argument("--steps", type=int, default=2,
+                    help="timed steps; one step = samples_per_step samples per pixel (see the module docstring)")
+    ap.add_argument("--warmup", type=int, default=1, help="untimed warm-up steps")
+    ap.add_argument("--samples-per-step", type=int, default=None, help="override the config's samples per step")
     ap.add_argument("--config", type=int, default=4, choices=sorted(CONFIGS),
                     help="BASELINE.json config (1-based index into 'configs'); default 4 = the one the metric is quoted on "
                          "(Bistro 1080p 8-bounce stand-in)")
@@ -205,12 +210,12 @@ def main():
 
     # per-path buffers sized for the K-sample job before anything is timed (they would
     # otherwise grow inside the first rt_integrate that asks for a larger batch)
-    in_flight = render.reserve_samples(args.steps)
-    if args.warmup < 0:
-        args.warmup = in_flight
+    sps = args.samples_per_step or cfg["samples_per_step"]
+    spp_timed, spp_warm = args.steps * sps, args.warmup * sps
+    in_flight = render.reserve_samples(max(spp_timed, spp_warm))
 
     # ---- warm-up ------------------------------------------------------------
-    render.render_samples(args.warmup) if args.warmup > 0 else None
+    render.render_samples(spp_warm) if spp_warm > 0 else None
     if args.warmup > 0:     # the gather path too (first use loads torch / RCCL kernels)
         if local_rows:
             lib.rt_frame_copy_radiance(frame, tile.data_ptr())
@@ -228,7 +233,7 @@ def main():
 
     # ---- timed region: exactly K steps + the one gather ----------------------
     t0 = time.perf_counter()
-    render.render_samples(args.steps)
+    render.render_samples(spp_timed)
     t_enq = time.perf_counter() - t0
     if local_rows:
         lib.rt_frame_copy_radiance(frame, tile.data_ptr())
@@ -279,10 +284,10 @@ def main():
                         nodes_per_ray=round(per_ray["closest_nodes"], 2), tris_per_ray=round(per_ray["closest_tris"], 2),
                         rays_per_launch=round(agg[0] / n_launch, 1),
                         avg_launch_ms=round(ms_sum / n_launch, 5),
-                        kernel_ms_per_step=dict(trace_closest=round(agg[2] / world / args.steps, 4),
-                                                trace_shadow=round(agg[3] / world / args.steps, 4),
-                                                shade=round(agg[4] / world / args.steps, 4),
-                                                raygen=round(agg[5] / world / args.steps, 4)))
+                        kernel_ms_per_spp=dict(trace_closest=round(agg[2] / world / spp_timed, 4),
+                                                trace_shadow=round(agg[3] / world / spp_timed, 4),
+                                                shade=round(agg[4] / world / spp_timed, 4),
+                                                raygen=round(agg[5] / world / spp_timed, 4)))
         traffic_file = os.path.join(ROOT, "profiles", "trace_closest_hbm_traffic.json")
         if world == 1 and os.path.exists(traffic_file):   # rocprofv3 --pmc passes of this workload at N = 1
             try:
@@ -299,12 +304,13 @@ def main():
         name, cus, mem = render_ctx_info(capi, host, render)
         line = dict(metric="Mrays/s (all bounces+shadow)", value=round(value, 2), unit="Mrays/s", n_gpus=world,
                     steps=args.steps, warmup=args.warmup, ms_per_step=round(dt_max * 1e3 / args.steps, 4),
+                    ms_per_spp=round(dt_max * 1e3 / spp_timed, 4),
                     higher_is_better=True, scaling="strong", vs_baseline=None, dtype="f32", data="synthetic",
                     config=dict(workload=(cfg["name"] % dict(blob=args.blob_tris, ball=args.ball_tris)) +
-                                         ", %dx%d, %d-bounce, 1 spp per step, default camera, directional light + "
-                                         "CGSkies env map" % (args.width, args.height, args.bounces),
+                                         ", %dx%d, %d-bounce, %d spp per step, default camera, directional light + "
+                                         "CGSkies env map" % (args.width, args.height, args.bounces, sps),
                                 triangles=int(n_tris), width=args.width, height=args.height,
-                                max_bounces=args.bounces, spp=args.steps, samples_in_flight=in_flight,
+                                max_bounces=args.bounces, samples_per_step=sps, spp=spp_timed, samples_in_flight=in_flight,
                                 tiling="%d interleaved %d-row bands per GPU, 1 RCCL gather" % (world, args.band_height)
                                 if world > 1 else "single tile",
                                 rays_per_step=round(total_rays / args.steps, 1), non_finite_pixels=nan_px,
