@@ -15,8 +15,10 @@ configs[3] "Amazon Lumberyard Bistro 1920x1080 256spp 8-bounce" -- it fits one
 GPU, so N = 1 runs it whole and N > 1 tiles it.  The Bistro asset is a download
 the reference does not ship (assets/download_bistro.bat), so the deterministic
 stand-in of SURVEY.md section 8d is generated (raytracing_amd/scenes.py:
-city_block, ~2.8 M triangles, 120 materials, textured); default K = 2 steps =
-the config's 256 spp, W = 1.  --config 2 / 3 / 5 select the other BASELINE
+city_block, ~2.8 M triangles, 120 materials, textured); default K = 8 steps =
+1024 spp (four times the config's 256 spp: the rate does not depend on the
+sample count, and a job of that length lets each of 8 tiles keep as many paths in
+flight as the whole frame does on one GPU), W = 1.  --config 2 / 3 / 5 select the other BASELINE
 configs' stand-ins.  Metric = BASELINE.json's: Mrays/s, all bounces + shadow
 rays, counted by the device queue counters the reference itself keeps
 (ray_counter_buffer_, shadow_ray_counter_buffer_).
@@ -142,7 +144,7 @@ def cpu_legs(args, scene_arrays, cam_small, small_w, small_h, cam_full):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2,
+    ap.add_argument("--steps", type=int, default=8,
                     help="timed steps; one step = samples_per_step samples per pixel (see the module docstring)")
     ap.add_argument("--warmup", type=int, default=1, help="untimed warm-up steps")
     ap.add_argument("--samples-per-step", type=int, default=None, help="override the config's samples per step")

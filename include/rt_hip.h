@@ -124,8 +124,8 @@ enum rt_option
                                    value. */
     , RT_OPT_TRACE_WAVES_PER_CU = 8 /* persistent-grid size of the trace kernels in waves per CU (0 = as many as fit) */
     , RT_OPT_SAMPLES_IN_FLIGHT = 9  /* rt_integrate traces this many consecutive samples per pixel concurrently
-                                       (1..256, allocated at once; 0 = auto, the default: up to the largest power
-                                       of two <= 256 whose per-path buffers stay under ~144 GB, allocated as
+                                       (1..1024, allocated at once; 0 = auto, the default: up to the largest power
+                                       of two <= 1024 whose per-path buffers stay under ~144 GB, allocated as
                                        batches ask for them).  Results are bit-identical for every value: contributions
                                        are logged per path and replayed in the reference's order. */
     , RT_OPT_TRACE_SELECT_FORM_BOX = 10 /* validation: 1 = every ray uses the reference's compare+select min/max in the

@@ -454,13 +454,13 @@ void free_path_buffers(rt_frame* f)
 // with 2 * (max_bounces + 1) entries per path.  (Re)allocated when either changes.
 size_t bytes_per_path(uint32_t max_bounces) { return 12u * 16u + 4u + 32u * (max_bounces + 1u); }
 
-// auto: the largest power of two <= 256 that keeps tile pixels x samples inside 32-bit path
+// auto: the largest power of two <= 1024 that keeps tile pixels x samples inside 32-bit path
 // ids and the per-path buffers under ~144 GB (half of the 288 GB of HBM)
 uint32_t auto_slots(uint32_t n_local, uint32_t max_bounces)
 {
     const uint64_t n = n_local ? n_local : 1;
     const uint64_t max_paths = 0xFFFFFFF0ull;
-    uint32_t s = 256;
+    uint32_t s = 1024;
     while (s > 1 && (s * n > max_paths || s * n * bytes_per_path(max_bounces) > (144ull << 30))) s >>= 1;
     return s;
 }
@@ -654,7 +654,7 @@ int rt_set_option(rt_frame* f, int option, uint32_t value)
         }
         return RT_OK;
     case RT_OPT_SAMPLES_IN_FLIGHT:
-        if (value > 256) return fail(f->ctx, "rt_set_option: samples in flight must be 0 (auto) or 1..256");
+        if (value > 1024) return fail(f->ctx, "rt_set_option: samples in flight must be 0 (auto) or 1..1024");
         if (value != f->slots_opt)
         {
             if (flush_log(f) != RT_OK) return RT_ERROR;

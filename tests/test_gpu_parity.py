@@ -539,7 +539,7 @@ def test_reserve_samples_and_lazy_path_buffers(ctx, golden_scenes):
     assert fr.reserve_samples(0) == 7
     assert fr.sample_count() == 9
     assert np.array_equal(fr.radiance(), base.radiance(), equal_nan=True)
-    assert fr.reserve_samples(100000) == 256          # clamped to the auto cap at this tile size
+    assert fr.reserve_samples(100000) == 1024         # clamped to the auto cap at this tile size
     fr.set_option(capi.OPT_SAMPLES_IN_FLIGHT, 3)      # explicit: allocated at once, and the new cap
     assert fr.reserve_samples(50) == 3
 

@@ -8,7 +8,7 @@ from raytracing_amd import capi, host, scenes as S
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--config", type=int, default=4)
-ap.add_argument("--steps", type=int, default=256)
+ap.add_argument("--steps", type=int, default=1024, help="samples per pixel of the job (bench default: 8 steps x 128)")
 ap.add_argument("--tiles", default="1,2,4,8")
 ap.add_argument("--band-height", type=int, default=8)
 a = ap.parse_args()
