@@ -114,7 +114,7 @@ enum rt_option
     RT_OPT_WHITE_FURNACE = 1,  /* Integrator::EnableWhiteFurnace (-D ENABLE_WHITE_FURNACE) */
     RT_OPT_SAMPLER = 2,        /* Integrator::SetSamplerType: 0 = kRandom, 1 = kBlueNoise (-D BLUE_NOISE_SAMPLER) */
     RT_OPT_AOV = 3,            /* Integrator::SetAOV: 0 shaded colour, 1 diffuse albedo, 2 depth, 3 normal, 4 motion vectors
-                                  (resolve_radiance.cl:25-29); non-zero needs tile_count == 1 */
+                                  (resolve_radiance.cl:25-29); per-pixel, so it works on tiles */
     RT_OPT_DENOISER = 4,       /* Integrator::EnableDenoiser: temporal reprojection (denoiser.cl); needs tile_count == 1 */
     RT_OPT_TRACE_DROP_LAST_BOUNCE_RAYS = 5, /* 1 (default): do not emit the never-traced rays of the last bounce */
     RT_OPT_PROFILE_KERNELS = 6, /* 1: bracket every kernel launch with HIP events on the context stream */

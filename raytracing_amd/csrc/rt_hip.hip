@@ -679,7 +679,6 @@ int rt_set_option(rt_frame* f, int option, uint32_t value)
         return RT_OK;
     case RT_OPT_AOV:
         if (value > 4) return fail(f->ctx, "rt_set_option: AOV index must be 0..4");
-        if (value != 0 && f->tile.nranks != 1) return fail(f->ctx, "rt_set_option: AOVs need the whole image on one GPU");
         f->aov = value;
         return RT_OK;
     case RT_OPT_DENOISER:
