@@ -119,9 +119,10 @@ enum rt_option
     RT_OPT_TRACE_DROP_LAST_BOUNCE_RAYS = 5, /* 1 (default): do not emit the never-traced rays of the last bounce */
     RT_OPT_PROFILE_KERNELS = 6, /* 1: bracket every kernel launch with HIP events on the context stream */
     RT_OPT_TRACE_VARIANT = 7    /* traversal kernel: 0 = v1 per-ray loop; 1 .. 4, 6, 7 = one-fetch-per-iteration
-                                   state machine with a 16 / 24 / 12 / 8, 10 / 11 entry LDS stack; 5 (default) =
-                                   auto: 0 below 2 M paths per launch, 3 above.  Results are identical for every
-                                   value. */
+                                   state machine with a 16 / 24 / 12 / 8, 10 / 11 entry LDS stack; 8 / 9 = k_trace2
+                                   (separate wave-uniform node / triangle / refill loops) with a 10+12 / 12+12 entry
+                                   stack (closest + shadow); 5 (default) = auto: 0 below 2 M paths per launch, 8
+                                   above.  Results are identical for every value. */
     , RT_OPT_TRACE_WAVES_PER_CU = 8 /* persistent-grid size of the trace kernels in waves per CU (0 = as many as fit) */
     , RT_OPT_SAMPLES_IN_FLIGHT = 9  /* rt_integrate traces this many consecutive samples per pixel concurrently
                                        (1..1024, allocated at once; 0 = auto, the default: up to the largest power
@@ -137,6 +138,10 @@ enum rt_option
                                        consecutive queue entries of a wave walk the tree together and node /
                                        triangle records are fetched once per wave by the scalar unit.  Default 0
                                        (off): it pays only for coherent rays over geometry coarser than a pixel.
+                                       Results are identical for every value. */
+    , RT_OPT_TRACE_TUNE = 12       /* k_trace2 (variants 8, 9) loop thresholds: value & 255 = lanes that must hold an
+                                       interior node for a wave to stay in the node loop, value >> 8 & 255 = lanes that
+                                       must wait at a triangle for another pass of the triangle loop.  0 = defaults.
                                        Results are identical for every value. */
 };
 int rt_set_option(rt_frame* frame, int option, uint32_t value);

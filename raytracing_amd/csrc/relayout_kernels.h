@@ -39,9 +39,10 @@ __global__ void k_relayout_nodes(const rt_bvh_node* __restrict__ nodes, uint32_t
     uint32_t r0 = (a.num_primitives_axis >> 16) ? (RT_LEAF_BIT | a.offset) : interior_index[c0];
     uint32_t r1 = (b.num_primitives_axis >> 16) ? (RT_LEAF_BIT | b.offset) : interior_index[c1];
     float4* out = out_nodes + (size_t)interior_index[i] * 4;
-    out[0] = make_float4(a.bounds_min.x, a.bounds_min.y, a.bounds_min.z, a.bounds_max.x);
-    out[1] = make_float4(a.bounds_max.y, a.bounds_max.z, b.bounds_min.x, b.bounds_min.y);
-    out[2] = make_float4(b.bounds_min.z, b.bounds_max.x, b.bounds_max.y, b.bounds_max.z);
+    // pair layout of trace_kernels.h (RT_NODE_C0 / RT_NODE_C1): x,y corners packed, z planes together
+    out[0] = make_float4(a.bounds_min.x, a.bounds_min.y, a.bounds_max.x, a.bounds_max.y);
+    out[1] = make_float4(b.bounds_min.x, b.bounds_min.y, b.bounds_max.x, b.bounds_max.y);
+    out[2] = make_float4(a.bounds_min.z, a.bounds_max.z, b.bounds_min.z, b.bounds_max.z);
     out[3] = make_float4(__uint_as_float(r0), __uint_as_float(r1), __uint_as_float(axis), 0.0f);
 }
 

@@ -20,6 +20,7 @@ struct Scene
     void* emissive = nullptr;
     DScene d = {};
     bool valid = false;
+    bool offsets32 = false;   // node and trace-triangle arrays below 4 GiB: k_trace2 addresses them with 32-bit byte offsets
 };
 } // namespace
 
@@ -68,6 +69,7 @@ struct rt_frame
     uint32_t trace_waves_per_cu = 0;   // RT_OPT_TRACE_WAVES_PER_CU (0 = LDS-limited residency)
     uint32_t packet_bounces = 0;       // RT_OPT_TRACE_PACKET_BOUNCES: closest | shadow << 8 bounce counts for k_trace_packet
     uint32_t select_form_box = 0;      // RT_OPT_TRACE_SELECT_FORM_BOX: every ray takes the select-form slab test
+    uint32_t trace_tune = 0;           // RT_OPT_TRACE_TUNE: k_trace2 loop thresholds (0 = defaults)
     // integrator state
     rt_camera camera;
     rt_camera camera_last;        // Integrator::prev_camera_ (integrator.hpp:89)
@@ -338,9 +340,9 @@ int rt_scene_upload(rt_ctx* ctx, const rt_scene_desc* sd)
         // reference's first loop iteration (box test of node 0, trace_bvh.cl:146-148).
         s.d.entry_ref = n_interior;
         float4* out = super_root.data();
-        out[0] = make_float4(root.bounds_min.x, root.bounds_min.y, root.bounds_min.z, root.bounds_max.x);
-        out[1] = make_float4(root.bounds_max.y, root.bounds_max.z, 0.0f, 0.0f);
-        out[2] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        out[0] = make_float4(root.bounds_min.x, root.bounds_min.y, root.bounds_max.x, root.bounds_max.y);
+        out[1] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        out[2] = make_float4(root.bounds_min.z, root.bounds_max.z, 0.0f, 0.0f);
         uint32_t r0 = s.d.root_ref, r1 = RT_EMPTY_REF, axis = 0;
         float fr0, fr1, fax;
         memcpy(&fr0, &r0, 4); memcpy(&fr1, &r1, 4); memcpy(&fax, &axis, 4);
@@ -432,6 +434,7 @@ int rt_scene_upload(rt_ctx* ctx, const rt_scene_desc* sd)
     s.d.env_w = (int)sd->env_width;
     s.d.env_h = (int)sd->env_height;
     s.d.light_count = sd->num_lights;
+    s.offsets32 = (uint64_t)(n_interior + 1) * 64 <= 0xFFFFFFFFull && (uint64_t)nt * 64 <= 0xFFFFFFFFull;
     s.valid = true;
     return RT_OK;
 }
@@ -692,8 +695,9 @@ int rt_set_option(rt_frame* f, int option, uint32_t value)
     case RT_OPT_TRACE_WAVES_PER_CU: f->trace_waves_per_cu = value; return RT_OK;
     case RT_OPT_TRACE_PACKET_BOUNCES: f->packet_bounces = value; return RT_OK;
     case RT_OPT_TRACE_SELECT_FORM_BOX: f->select_form_box = value ? RT_SIGN_SLOW : 0u; return RT_OK;
+    case RT_OPT_TRACE_TUNE: f->trace_tune = value; return RT_OK;
     case RT_OPT_TRACE_VARIANT:
-        if (value > 7) return fail(f->ctx, "rt_set_option: unknown trace kernel variant");
+        if (value > 9) return fail(f->ctx, "rt_set_option: unknown trace kernel variant");
         f->trace_variant = value;
         return RT_OK;
     default: return fail(f->ctx, "rt_set_option: unknown option");
@@ -759,6 +763,24 @@ void launch_trace_sm(rt_frame* f, const float4* o4, const float4* d4, const floa
         SHADOW ? f->rlog : (float4*)nullptr, f->log_stride, f->select_form_box, f->spill);
 }
 
+// k_trace2: separate wave-uniform loops (trace_kernels.h).  Same grid sizing as launch_trace_sm.
+#define RT_TRACE2_DEFAULT_TUNE (40u | (12u << 8))
+template <bool SHADOW, int STACK>
+void launch_trace2(rt_frame* f, const float4* o4, const float4* d4, const float4* iv4, const uint32_t* count)
+{
+    rt_ctx* ctx = f->ctx;
+    uint32_t per_cu = (160u * 1024u) / (STACK * 512u);
+    if (per_cu > 32u) per_cu = 32u;
+    if (f->trace_waves_per_cu && f->trace_waves_per_cu < per_cu) per_cu = f->trace_waves_per_cu;
+    uint32_t blocks = ((uint32_t)ctx->prop.multiProcessorCount * per_cu + 7u) & ~7u;
+    uint32_t tune = f->trace_tune ? f->trace_tune : RT_TRACE2_DEFAULT_TUNE;
+    if ((tune & 0xFFu) > 64u) tune = (tune & ~0xFFu) | 64u;
+    if ((tune & 0xFFu) == 0u) tune |= 1u;
+    hipLaunchKernelGGL((k_trace2<SHADOW, STACK>), dim3(blocks), dim3(64), 0, ctx->stream, ctx->scene.d, o4, d4, iv4, count,
+        &f->counters->head[SHADOW ? 1 : 0][0], SHADOW ? (float4*)nullptr : f->hits,
+        SHADOW ? f->rlog : (float4*)nullptr, f->log_stride, f->select_form_box, f->spill, tune);
+}
+
 // Coherent launches (primary rays): packet traversal, node records through the scalar cache.
 // Measured (profiles/r01_packet_kernel_experiment.log): 1.19x on the primary rays of the
 // city-block scene, but slower where triangles are smaller than a pixel's footprint (the 64
@@ -795,6 +817,7 @@ void launch_trace(rt_frame* f, const float4* o4, const float4* d4, const float4*
         // (profiles/r01_variants_7_stack_10_vs_12.log)
         if (variant == 3u && !SHADOW && ctx->scene.d.entry_ref < 4000000u) variant = 6u;
     }
+    if ((variant == 8u || variant == 9u) && !ctx->scene.offsets32) variant = 3u;
     switch (variant)
     {
     case 0:
@@ -807,6 +830,11 @@ void launch_trace(rt_frame* f, const float4* o4, const float4* d4, const float4*
     case 4: launch_trace_sm<SHADOW, 8>(f, o4, d4, iv4, count); break;
     case 6: launch_trace_sm<SHADOW, 10>(f, o4, d4, iv4, count); break;
     case 7: launch_trace_sm<SHADOW, 11>(f, o4, d4, iv4, count); break;
+    case 8:
+        if (!SHADOW && ctx->scene.d.entry_ref < 4000000u) launch_trace2<SHADOW, 10>(f, o4, d4, iv4, count);
+        else launch_trace2<SHADOW, 12>(f, o4, d4, iv4, count);
+        break;
+    case 9: launch_trace2<SHADOW, 12>(f, o4, d4, iv4, count); break;
     default: launch_trace_sm<SHADOW, 12>(f, o4, d4, iv4, count); break;
     }
 }

@@ -45,6 +45,14 @@ RT_DEV float hw_max(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=
 RT_DEV float hw_min3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 RT_DEV float hw_max3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 
+// Child-pair record (64 bytes, one per interior node of the reference BVH2), laid out so that the
+// six (bound - origin) * inv_dir products of a child come out of packed-fp32 instructions without
+// register shuffles (x and y of a corner share a 64-bit register pair with the ray's (ox, oy)):
+//   q0 = (c0.min.x, c0.min.y, c0.max.x, c0.max.y)     q1 = (c1.min.x, c1.min.y, c1.max.x, c1.max.y)
+//   q2 = (c0.min.z, c0.max.z, c1.min.z, c1.max.z)     q3 = (ref of child 0, ref of child 1, split axis, -)
+#define RT_NODE_C0(q0, q1, q2) (q0).x, (q0).y, (q2).x, (q0).z, (q0).w, (q2).y
+#define RT_NODE_C1(q0, q1, q2) (q1).x, (q1).y, (q2).z, (q1).z, (q1).w, (q2).w
+
 RT_DEV bool box_test_fast(float bminx, float bminy, float bminz, float bmaxx, float bmaxy, float bmaxz, f3 org, f3 inv,
     float t_min, float t_max, float& entry)
 {
@@ -147,8 +155,8 @@ __global__ __launch_bounds__(64) void k_trace_v1(DScene sc, const float4* __rest
                 float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
                 uint32_t c0 = __float_as_uint(n3.x), c1 = __float_as_uint(n3.y), axis = __float_as_uint(n3.z);
                 float a0, a1;
-                bool h0 = box_test(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, org, inv, t_min, t_max, a0);
-                bool h1 = box_test(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, org, inv, t_min, t_max, a1);
+                bool h0 = box_test(RT_NODE_C0(n0, n1, n2), org, inv, t_min, t_max, a0);
+                bool h1 = box_test(RT_NODE_C1(n0, n1, n2), org, inv, t_min, t_max, a1);
                 h1 = h1 && (c1 != RT_EMPTY_REF);
                 // near child: first child unless the ray is negative along the split axis (:181-190)
                 bool swap = (sign_bits >> axis) & 1u;
@@ -418,13 +426,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(STACK <= 10 
                 bool h0, h1;
                 if (sign_bits & RT_SIGN_SLOW)
                 {
-                    h0 = box_test(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, org, inv, t_min, t_max, a0);
-                    h1 = box_test(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, org, inv, t_min, t_max, a1);
+                    h0 = box_test(RT_NODE_C0(q0, q1, q2), org, inv, t_min, t_max, a0);
+                    h1 = box_test(RT_NODE_C1(q0, q1, q2), org, inv, t_min, t_max, a1);
                 }
                 else
                 {
-                    h0 = box_test_fast(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, org, inv, t_min, t_max, a0);
-                    h1 = box_test_fast(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, org, inv, t_min, t_max, a1);
+                    h0 = box_test_fast(RT_NODE_C0(q0, q1, q2), org, inv, t_min, t_max, a0);
+                    h1 = box_test_fast(RT_NODE_C1(q0, q1, q2), org, inv, t_min, t_max, a1);
                 }
                 h1 = h1 && (c1 != RT_EMPTY_REF);
                 bool swap = (sign_bits >> axis) & 1u;                        // :181-190
@@ -641,8 +649,8 @@ __global__ __launch_bounds__(64) void k_trace_packet(DScene sc, const float4* __
                     bool h0 = false, h1 = false;
                     if (mask & alive & lane_bit)
                     {
-                        h0 = packet_box(slow, n.a.x, n.a.y, n.a.z, n.a.w, n.b.x, n.b.y, org, inv, t_max);
-                        h1 = packet_box(slow, n.b.z, n.b.w, n.c.x, n.c.y, n.c.z, n.c.w, org, inv, t_max);
+                        h0 = packet_box(slow, RT_NODE_C0(n.a, n.b, n.c), org, inv, t_max);
+                        h1 = packet_box(slow, RT_NODE_C1(n.a, n.b, n.c), org, inv, t_max);
                     }
                     const unsigned long long m0 = __ballot(h0);
                     const unsigned long long m1 = c1 != RT_EMPTY_REF ? __ballot(h1) : 0ull;
@@ -676,8 +684,8 @@ __global__ __launch_bounds__(64) void k_trace_packet(DScene sc, const float4* __
                         const Rec64 n = scalar_fetch(sc.nodes, pref);
                         bool h = false;
                         if (pm & lane_bit)
-                            h = cidx ? packet_box(slow, n.b.z, n.b.w, n.c.x, n.c.y, n.c.z, n.c.w, org, inv, t_max)
-                                     : packet_box(slow, n.a.x, n.a.y, n.a.z, n.a.w, n.b.x, n.b.y, org, inv, t_max);
+                            h = cidx ? packet_box(slow, RT_NODE_C1(n.a, n.b, n.c), org, inv, t_max)
+                                     : packet_box(slow, RT_NODE_C0(n.a, n.b, n.c), org, inv, t_max);
                         const unsigned long long m = __ballot(h);
                         if (m)
                         {
@@ -702,6 +710,290 @@ __global__ __launch_bounds__(64) void k_trace_packet(DScene sc, const float4* __
             else
             {
                 hits[i] = make_float4(hit_u, hit_v, __uint_as_float(hit_prim), t_max);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// k_trace2: persistent traversal with SEPARATE wave-uniform loops (round 2)
+// ---------------------------------------------------------------------------
+// rocprofv3 on k_trace (profiles/r01_final_pmc_summary.txt) shows one VALU issued per SIMD
+// every 4.03 cycles -- the vector ALU's issue rate (tools/issue_microbench.hip) -- at ~124
+// wave-instructions per ray, of which the box tests themselves need ~35.  The rest is the price
+// of the single flat loop: every iteration walks through the ray-start, triangle and node code
+// and their merges (exec-mask bookkeeping, phi moves) whenever ONE lane needs them.
+// Here the three activities are three loops with wave-uniform (scalar) trip conditions:
+//
+//   A  retire finished rays + start new ones      (only when the node loop has run dry)
+//   B  one triangle per waiting lane              (while >= leaf_q lanes wait at a leaf)
+//   C  one child-pair node per lane               (while >= node_q lanes have a node)
+//
+// so the hot loop C contains nothing but the node fetch, the two slab tests, the push and
+// the pop.  Lanes that reach a leaf or finish their ray sit out C until fewer than node_q
+// lanes are left in it; then B and A serve everybody who waits, together.  The per-lane
+// sequence of node visits, triangle tests and t_max updates is exactly k_trace's (and the
+// reference's): only the interleaving between lanes changes.
+#define RT_IDLE_REF 0xFFFFFFFFu
+typedef float rt_v2f __attribute__((ext_vector_type(2)));
+
+// Both slab tests of a child-pair record on packed fp32: (bound - origin) * inv_dir for the 24
+// planes in 12 v_pk_add_f32 / v_pk_mul_f32 (each an IEEE subtract / multiply per component, the
+// reference's two roundings), then the v_min / v_max reduction of box_test_fast.
+RT_DEV void pair_test_fast(const float4 q0, const float4 q1, const float4 q2, rt_v2f oxy, float oz, rt_v2f ixy, float iz,
+    float t_min, float t_max, bool& h0, bool& h1, float& a0, float& a1)
+{
+    const rt_v2f ozz = {oz, oz}, izz = {iz, iz};          // one register each: the packed ops broadcast the low half
+    rt_v2f c0a = ((rt_v2f){q0.x, q0.y} - oxy) * ixy;      // child 0: t0.x, t0.y
+    rt_v2f c0b = ((rt_v2f){q0.z, q0.w} - oxy) * ixy;      //          t1.x, t1.y
+    rt_v2f c1a = ((rt_v2f){q1.x, q1.y} - oxy) * ixy;      // child 1
+    rt_v2f c1b = ((rt_v2f){q1.z, q1.w} - oxy) * ixy;
+    rt_v2f c0z = ((rt_v2f){q2.x, q2.y} - ozz) * izz;      // child 0: t0.z, t1.z
+    rt_v2f c1z = ((rt_v2f){q2.z, q2.w} - ozz) * izz;      // child 1
+    float lo0 = hw_max3(hw_min(c0a.x, c0b.x), hw_min(c0a.y, c0b.y), hw_min(c0z.x, c0z.y));
+    float hi0 = hw_min3(hw_max(c0a.x, c0b.x), hw_max(c0a.y, c0b.y), hw_max(c0z.x, c0z.y));
+    float lo1 = hw_max3(hw_min(c1a.x, c1b.x), hw_min(c1a.y, c1b.y), hw_min(c1z.x, c1z.y));
+    float hi1 = hw_min3(hw_max(c1a.x, c1b.x), hw_max(c1a.y, c1b.y), hw_max(c1z.x, c1z.y));
+    a0 = hw_max(lo0, t_min);
+    a1 = hw_max(lo1, t_min);
+    h0 = hw_min(hi0, t_max) >= a0;
+    h1 = hw_min(hi1, t_max) >= a1;
+}
+
+template <bool SHADOW, int STACK>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(STACK <= 10 ? 8 : 6, 8))) void k_trace2(DScene sc, const float4* __restrict__ o4, const float4* __restrict__ d4,
+    const float4* __restrict__ iv4, const uint32_t* __restrict__ count_ptr, uint32_t* __restrict__ heads,
+    float4* __restrict__ hits,
+    float4* __restrict__ rlog, uint32_t log_stride, uint32_t force_sign_bits, uint2* __restrict__ spill, uint32_t tune)
+{
+    __shared__ uint2 stack[STACK][64];
+    uint32_t* const stack32 = reinterpret_cast<uint32_t*>(&stack[0][0]);     // SHADOW: 2 * STACK entries of 4 bytes
+    // the spill area is touched through volatile pointers: it keeps the compiler from folding the
+    // LDS and the HBM side of a push / pop into one flat_load / flat_store on a selected address
+    volatile uint2* const vspill = spill;
+    volatile uint32_t* const vspill32 = reinterpret_cast<volatile uint32_t*>(spill);
+    const uint32_t lane = threadIdx.x;
+    const uint32_t count = *count_ptr;
+    if (count == 0) return;
+    const uint32_t node_q = tune & 0xFFu, leaf_q = (tune >> 8) & 0xFFu;
+    const uint32_t xcd = blockIdx.x & 7u;
+    const uint32_t per = (((count + 7u) >> 3) + 63u) & ~63u;                 // the XCD regions of k_trace
+    const uint32_t spill_base = (blockIdx.x * 64u + lane) * (uint32_t)(RT_TRACE_STACK_MAX - STACK);
+    const char* const node_base = reinterpret_cast<const char*>(sc.nodes);   // 32-bit byte offsets: the arrays
+    const char* const tri_base = reinterpret_cast<const char*>(sc.tris_rt);  // stay below 4 GiB (rt_scene_upload)
+
+    uint32_t pool_next = 0, pool_end = 0, regions_tried = 0;                 // wave-uniform
+    bool exhausted = false;                                                  // wave-uniform: the queue has run dry
+    uint32_t ref = RT_IDLE_REF;                                              // interior node | RT_LEAF_BIT + triangle | idle
+    uint32_t ray_i = RT_INVALID_ID;                                          // != invalid while a result is owed
+    uint32_t sign_bits = 0, hit_prim = RT_INVALID_ID;
+    int sp = 0;
+    rt_v2f oxy = {0.0f, 0.0f}, ixy = oxy;                                    // origin.xy and (1/dir).xy as register pairs
+    float oz = 0.0f, iz = 0.0f;
+    f3 dir = F3s(0.0f);
+    float t_max = 0.0f, hit_u = 0.0f, hit_v = 0.0f;
+    uint32_t payload = 0, log_entry = 0;
+    const float t_min = 0.0f;
+
+    // next entry of this lane's stack that still passes the box test, or idle (ray finished)
+    auto pop = [&]()
+    {
+        ref = RT_IDLE_REF;
+        if (SHADOW)
+        {
+            if (sp > 0)
+            {
+                --sp;
+                if (sp < 2 * STACK) ref = stack32[sp * 64 + lane];
+                else ref = vspill32[(size_t)2 * spill_base + (uint32_t)(sp - 2 * STACK)];
+            }
+        }
+        else
+            while (sp > 0)
+            {
+                --sp;
+                uint32_t ex, ey;
+                if (sp < STACK) { const uint2 e = stack[sp][lane]; ex = e.x; ey = e.y; }
+                else { ex = vspill[(size_t)spill_base + (uint32_t)(sp - STACK)].x; ey = vspill[(size_t)spill_base + (uint32_t)(sp - STACK)].y; }
+                if (t_max >= __uint_as_float(ey)) { ref = ex; break; }       // box re-test at pop time
+            }
+    };
+
+    for (;;)
+    {
+        // ---- A: retire finished rays, start new ones -------------------------------------
+        if (__ballot(ref == RT_IDLE_REF) != 0ull)
+        {
+            if (ref == RT_IDLE_REF && ray_i != RT_INVALID_ID)
+            {
+                if (SHADOW)
+                {
+                    // AccumulateDirectSamples fused: an occluded ray retracts its tentative direct sample
+                    if (hit_prim != RT_INVALID_ID)
+                        rlog[(size_t)log_entry * log_stride + payload] = make_float4(0, 0, 0, 0);
+                }
+                else
+                    hits[ray_i] = make_float4(hit_u, hit_v, __uint_as_float(hit_prim), t_max);
+                ray_i = RT_INVALID_ID;
+            }
+            if (!exhausted)
+            {
+                unsigned long long need = __ballot(ref == RT_IDLE_REF);
+                while (need)
+                {
+                    if (pool_next >= pool_end)
+                    {
+                        bool got = false;
+                        while (regions_tried < 8u)
+                        {
+                            uint32_t x = (xcd + regions_tried) & 7u;
+                            uint32_t rb = x * per < count ? x * per : count;
+                            uint32_t re = (x + 1u) * per < count ? (x + 1u) * per : count;
+                            uint32_t b = 0;
+                            if (lane == 0 && rb < re) b = atomicAdd(&heads[x], RT_TRACE_BATCH);
+                            b = __shfl(b, 0, 64);
+                            if (rb < re && b < re - rb)
+                            {
+                                pool_next = rb + b;
+                                pool_end = (b + RT_TRACE_BATCH < re - rb) ? rb + b + RT_TRACE_BATCH : re;
+                                got = true;
+                                break;
+                            }
+                            ++regions_tried;
+                        }
+                        if (!got) { exhausted = true; break; }
+                    }
+                    uint32_t avail = pool_end - pool_next;
+                    uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
+                    uint32_t n = (uint32_t)__popcll(need);
+                    if (ref == RT_IDLE_REF && ray_i == RT_INVALID_ID && rank < avail) ray_i = pool_next + rank;
+                    pool_next += n < avail ? n : avail;
+                    need = __ballot(ref == RT_IDLE_REF && ray_i == RT_INVALID_ID);
+                }
+                if (ref == RT_IDLE_REF && ray_i != RT_INVALID_ID)
+                {
+                    // ray start: 1/dir and the sign bits come from the producer; the root box test is
+                    // the ordinary node test of the super-root record (see k_trace)
+                    float4 q0 = o4[ray_i], q1 = d4[ray_i], q2 = iv4[ray_i];
+                    oxy = (rt_v2f){q0.x, q0.y}; oz = q0.z;
+                    dir = F3(q1.x, q1.y, q1.z);
+                    t_max = q0.w;
+                    ixy = (rt_v2f){q2.x, q2.y}; iz = q2.z;
+                    sign_bits = (__float_as_uint(q2.w) & 0xFFu) | force_sign_bits;
+                    if (SHADOW) { payload = __float_as_uint(q1.w); log_entry = __float_as_uint(q2.w) >> 8; }
+                    hit_prim = RT_INVALID_ID;
+                    hit_u = 0.0f; hit_v = 0.0f;
+                    sp = 0;
+                    ref = sc.entry_ref;
+                }
+            }
+        }
+        if (__ballot(ref != RT_IDLE_REF) == 0ull) break;                    // queue dry and every ray retired
+
+        // ---- B: triangles (trace_bvh.cl:28-73,155-169), one per waiting lane per pass ----
+        {
+            unsigned long long leaf_m = __ballot((int)ref < -1);
+            const uint32_t n_node = (uint32_t)__popcll(__ballot((int)ref >= 0));
+            if (leaf_m != 0ull && ((uint32_t)__popcll(leaf_m) >= leaf_q || n_node < node_q))
+                do
+                {
+                    if ((int)ref < -1)
+                    {
+                        const uint32_t prim = ref & ~RT_LEAF_BIT;
+                        const float4* tp = reinterpret_cast<const float4*>(tri_base + (size_t)(prim << 6));
+                        const float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
+                        const bool last = q0.w != 0.0f;
+                        bool accepted = false;
+                        const f3 org = F3(oxy.x, oxy.y, oz);
+                        f3 p1 = F3(q0.x, q0.y, q0.z), e1 = F3(q1.x, q1.y, q1.z), e2 = F3(q2.x, q2.y, q2.z);
+                        f3 pvec = cross3(dir, e2);
+                        float det = dot3(e1, pvec);
+                        if (!(det < 1e-8f || -det > 1e-8f))
+                        {
+                            float inv_det = 1.0f / det;
+                            f3 tvec = org - p1;
+                            float u = dot3(tvec, pvec) * inv_det;
+                            if (!(u < 0.0f || u > 1.0f))
+                            {
+                                f3 qvec = cross3(tvec, e1);
+                                float v = dot3(dir, qvec) * inv_det;
+                                if (!(v < 0.0f || u + v > 1.0f))
+                                {
+                                    float t = dot3(e2, qvec) * inv_det;
+                                    if (!(t < t_min || t > t_max))
+                                    {
+                                        hit_u = u; hit_v = v; hit_prim = prim;
+                                        t_max = t;                           // :162
+                                        accepted = true;
+                                    }
+                                }
+                            }
+                        }
+                        if (SHADOW && accepted) ref = RT_IDLE_REF;           // goto endtrace, :164-167
+                        else if (last) pop();
+                        else ref = ref + 1u;
+                    }
+                    leaf_m = __ballot((int)ref < -1);
+                } while ((uint32_t)__popcll(leaf_m) >= leaf_q && leaf_m != 0ull);
+        }
+
+        // ---- C: interior nodes, the hot loop ----------------------------------------------
+        for (;;)
+        {
+            const unsigned long long node_m = __ballot((int)ref >= 0);
+            if (node_m == 0ull) break;
+            if ((uint32_t)__popcll(node_m) < node_q)
+            {
+                // leave when somebody who waits can be served: a lane at a leaf, or a finished lane
+                // while the queue still has rays
+                const unsigned long long waiting = __ballot((int)ref < -1 || (ref == RT_IDLE_REF && !exhausted));
+                if (waiting != 0ull) break;
+            }
+            if ((int)ref >= 0)
+            {
+                const float4* np = reinterpret_cast<const float4*>(node_base + (size_t)(ref << 6));
+                const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
+                const uint32_t c0 = __float_as_uint(q3.x), c1 = __float_as_uint(q3.y), axis = __float_as_uint(q3.z);
+                float a0, a1;
+                bool h0, h1;
+                if (sign_bits & RT_SIGN_SLOW)
+                {
+                    const f3 org = F3(oxy.x, oxy.y, oz), inv = F3(ixy.x, ixy.y, iz);
+                    h0 = box_test(RT_NODE_C0(q0, q1, q2), org, inv, t_min, t_max, a0);
+                    h1 = box_test(RT_NODE_C1(q0, q1, q2), org, inv, t_min, t_max, a1);
+                }
+                else
+                    pair_test_fast(q0, q1, q2, oxy, oz, ixy, iz, t_min, t_max, h0, h1, a0, a1);
+                // near child: first child unless the ray is negative along the split axis (:181-190).
+                // The hit flags are lane masks: they are swapped with scalar mask arithmetic and come
+                // back as branch conditions (inverse ballot), no vector instruction involved.
+                const bool swap = ((sign_bits >> axis) & 1u) != 0u;
+                const unsigned long long m_h0 = __ballot(h0), m_h1 = __ballot(h1 && c1 != RT_EMPTY_REF), m_sw = __ballot(swap);
+                const bool near_hit = __builtin_amdgcn_inverse_ballot_w64((m_sw & m_h1) | (~m_sw & m_h0));
+                const bool far_hit = __builtin_amdgcn_inverse_ballot_w64((m_sw & m_h0) | (~m_sw & m_h1));
+                const uint32_t near_ref = swap ? c1 : c0, far_ref = swap ? c0 : c1;
+                if (near_hit & far_hit)
+                {
+                    if (SHADOW)
+                    {
+                        if (sp < 2 * STACK) stack32[sp * 64 + lane] = far_ref;
+                        else vspill32[(size_t)2 * spill_base + (uint32_t)(sp - 2 * STACK)] = far_ref;
+                    }
+                    else
+                    {
+                        const uint32_t far_entry = __float_as_uint(swap ? a0 : a1);
+                        if (sp < STACK) stack[sp][lane] = make_uint2(far_ref, far_entry);
+                        else
+                        {
+                            vspill[(size_t)spill_base + (uint32_t)(sp - STACK)].x = far_ref;
+                            vspill[(size_t)spill_base + (uint32_t)(sp - STACK)].y = far_entry;
+                        }
+                    }
+                    ++sp;
+                }
+                if (near_hit) ref = near_ref;
+                else if (far_hit) ref = far_ref;
+                else pop();
             }
         }
     }

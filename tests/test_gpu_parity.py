@@ -264,7 +264,7 @@ def test_directly_against_the_reference_kernels(ctx, golden_scenes):
 
 
 @pytest.mark.parametrize("slots", [2, 3, 8])
-@pytest.mark.parametrize("variant", [0, 1, 3, 5, 6, 103])
+@pytest.mark.parametrize("variant", [0, 1, 3, 5, 6, 8, 9, 103, 208, 308])
 def test_samples_in_flight_and_kernel_variants_are_bit_invariant(ctx, golden_scenes, slots, variant):
     """RT_OPT_SAMPLES_IN_FLIGHT traces several samples of a pixel concurrently; the
     radiance log replays their contributions in the reference's order, so the sum
@@ -280,7 +280,9 @@ def test_samples_in_flight_and_kernel_variants_are_bit_invariant(ctx, golden_sce
     fr.set_max_bounces(b)
     fr.set_option(capi.OPT_SAMPLES_IN_FLIGHT, slots)
     fr.set_option(capi.OPT_TRACE_VARIANT, variant % 100)
-    fr.set_option(capi.OPT_PACKET_BOUNCES, (3 | 2 << 8) if variant >= 100 else 0)   # 103: packet kernel, closest bounces 0..2, shadow 0..1
+    fr.set_option(capi.OPT_PACKET_BOUNCES, (3 | 2 << 8) if variant == 103 else 0)   # 103: packet kernel, closest bounces 0..2, shadow 0..1
+    # 208 / 308: k_trace2 with extreme loop thresholds (every lane leaves the node loop at once / nobody until all are done)
+    fr.set_option(capi.OPT_TRACE_TUNE, {208: 64 | (64 << 8), 308: 1 | (1 << 8)}.get(variant, 0))
     fr.integrate(spp)
     assert fr.sample_count() == spp
     assert np.array_equal(fr.radiance(), base.radiance(), equal_nan=True)
@@ -479,7 +481,7 @@ def _tiny_scene(env, tris_spec):
     return s.arrays()
 
 
-@pytest.mark.parametrize("variant", [0, 3, 4])
+@pytest.mark.parametrize("variant", [0, 3, 4, 8, 9])
 def test_degenerate_bvhs(ctx, env_map, variant):
     """Root-is-a-leaf trees (1 triangle), 2-triangle trees, a leaf with many coincident-centroid
     triangles (the reference's 'all centroids equal' leaf, bvh.cpp:112-123), and a long chain of
