@@ -139,6 +139,8 @@ enum rt_option
                                        triangle records are fetched once per wave by the scalar unit.  Default 0
                                        (off): it pays only for coherent rays over geometry coarser than a pixel.
                                        Results are identical for every value. */
+    , RT_OPT_DEBUG_ALLOC_LIMIT = 13 /* test hook: per-path buffer allocations for more than this many samples in flight
+                                       fail as if the device were out of memory (0 = off) */
     , RT_OPT_TRACE_TUNE = 12       /* k_trace2 (variants 8, 9) loop thresholds: value & 255 = lanes that must hold an
                                        interior node for a wave to stay in the node loop, value >> 8 & 255 = lanes that
                                        must wait at a triangle for another pass of the triangle loop.  0 = defaults.
@@ -195,6 +197,9 @@ typedef struct rt_stats
     uint64_t samples;             /* Integrate() calls since the last reset */
     uint32_t last_active[64];     /* per-bounce counts of the most recent batch of samples in flight */
     uint32_t last_shadow[64];
+    uint32_t samples_in_flight;        /* samples the per-path buffers hold at the moment */
+    uint32_t samples_in_flight_limit;  /* != 0: a larger batch did not fit into device memory and was halved to this */
+    uint64_t path_state_bytes;         /* size of the per-path buffers (ray queues + radiance log) */
 } rt_stats;
 int rt_frame_get_stats(rt_frame* frame, rt_stats* out);
 
@@ -217,7 +222,8 @@ int rt_frame_copy_radiance(rt_frame* frame, void* device_dst);
  * which: 0 = incoming queue of `bounce` (rays_buffer_[bounce&1]), 1 = shadow queue.
  * Returns the element count through *count; arrays may be NULL. */
 int rt_frame_debug_read_queue(rt_frame* frame, int which, uint32_t bounce, rt_ray* rays, uint32_t* pixel_indices,
-    rt_float4* payload /* throughput (which=0) or direct light sample (which=1) */, uint32_t* count);
+    rt_float4* payload /* throughput (which=0) or direct light sample (which=1) */,
+    uint32_t capacity /* elements the arrays can hold; all arrays NULL = size query */, uint32_t* count);
 int rt_frame_debug_read_hits(rt_frame* frame, rt_hit* hits, uint32_t count);
 
 /* ---- kernel self-test hooks (known-answer tests of the device math):

@@ -19,7 +19,8 @@ class RtError(RuntimeError):
 
 class rt_stats(C.Structure):
     _fields_ = [("closest_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("samples", C.c_uint64),
-                ("last_active", C.c_uint32 * 64), ("last_shadow", C.c_uint32 * 64)]
+                ("last_active", C.c_uint32 * 64), ("last_shadow", C.c_uint32 * 64),
+                ("samples_in_flight", C.c_uint32), ("samples_in_flight_limit", C.c_uint32), ("path_state_bytes", C.c_uint64)]
 
 
 class rt_profile(C.Structure):
@@ -58,7 +59,7 @@ EXPORTS = [
     "rt_frame_get_stats", "rt_frame_get_profile", "rt_frame_copy_radiance", "rt_frame_debug_read_queue", "rt_frame_debug_read_hits", "rt_debug_eval",
 ]
 
-OPT_MAX_BOUNCES, OPT_WHITE_FURNACE, OPT_SAMPLER, OPT_AOV, OPT_DENOISER, OPT_DROP_LAST, OPT_PROFILE, OPT_TRACE_VARIANT, OPT_TRACE_WAVES, OPT_SAMPLES_IN_FLIGHT, OPT_SELECT_FORM_BOX, OPT_PACKET_BOUNCES, OPT_TRACE_TUNE = range(13)
+OPT_MAX_BOUNCES, OPT_WHITE_FURNACE, OPT_SAMPLER, OPT_AOV, OPT_DENOISER, OPT_DROP_LAST, OPT_PROFILE, OPT_TRACE_VARIANT, OPT_TRACE_WAVES, OPT_SAMPLES_IN_FLIGHT, OPT_SELECT_FORM_BOX, OPT_PACKET_BOUNCES, OPT_TRACE_TUNE, OPT_DEBUG_ALLOC_LIMIT = range(14)
 
 
 def load():
@@ -95,7 +96,7 @@ def load():
         "rt_frame_get_stats": (i32, [vp, C.POINTER(rt_stats)]),
         "rt_frame_get_profile": (i32, [vp, C.POINTER(rt_profile)]),
         "rt_frame_copy_radiance": (i32, [vp, vp]),
-        "rt_frame_debug_read_queue": (i32, [vp, i32, u32, vp, vp, vp, C.POINTER(u32)]),
+        "rt_frame_debug_read_queue": (i32, [vp, i32, u32, vp, vp, vp, u32, C.POINTER(u32)]),
         "rt_frame_debug_read_hits": (i32, [vp, vp, u32]),
         "rt_debug_eval": (i32, [vp, i32, vp, vp, vp, u32]),
     }
@@ -264,14 +265,16 @@ class Frame:
         self._c(self.lib.rt_frame_copy_radiance(self.handle, device_ptr))
 
     def read_queue(self, which, bounce):
-        n_max = self.local_rows * self.width
-        rays = np.zeros(n_max, T.ray)
-        pix = np.zeros(n_max, np.uint32)
-        payload = np.zeros(n_max, T.float4)
         cnt = C.c_uint32()
-        self._c(self.lib.rt_frame_debug_read_queue(self.handle, which, bounce, rays.ctypes.data, pix.ctypes.data,
-                                                   payload.ctypes.data, C.byref(cnt)))
+        # two-call pattern: size query first (the queue holds up to samples-in-flight x tile pixels entries)
+        self._c(self.lib.rt_frame_debug_read_queue(self.handle, which, bounce, None, None, None, 0, C.byref(cnt)))
         n = cnt.value
+        rays = np.zeros(max(n, 1), T.ray)
+        pix = np.zeros(max(n, 1), np.uint32)
+        payload = np.zeros(max(n, 1), T.float4)
+        self._c(self.lib.rt_frame_debug_read_queue(self.handle, which, bounce, rays.ctypes.data, pix.ctypes.data,
+                                                   payload.ctypes.data, n, C.byref(cnt)))
+        assert cnt.value == n
         return rays[:n], pix[:n], payload[:n]
 
     def read_hits(self, count):

@@ -70,6 +70,7 @@ struct rt_frame
     uint32_t packet_bounces = 0;       // RT_OPT_TRACE_PACKET_BOUNCES: closest | shadow << 8 bounce counts for k_trace_packet
     uint32_t select_form_box = 0;      // RT_OPT_TRACE_SELECT_FORM_BOX: every ray takes the select-form slab test
     uint32_t trace_tune = 0;           // RT_OPT_TRACE_TUNE: k_trace2 loop thresholds (0 = defaults)
+    uint32_t debug_alloc_limit = 0;    // RT_OPT_DEBUG_ALLOC_LIMIT: allocations above this many samples in flight fail
     // integrator state
     rt_camera camera;
     rt_camera camera_last;        // Integrator::prev_camera_ (integrator.hpp:89)
@@ -315,13 +316,14 @@ int rt_scene_upload(rt_ctx* ctx, const rt_scene_desc* sd)
             cluster.clear();
             frontier.clear();
             cluster.push_back(r);
+            if (n_interior + cluster.size() > nn) return fail(ctx, "rt_scene_upload: the node array is not a tree (cycle)");
             for (size_t head = 0; head < cluster.size(); ++head)       // BFS inside the treelet
             {
                 uint32_t n = cluster[head];
                 uint32_t kids[2] = {n + 1, sd->nodes[n].offset};
                 for (uint32_t c : kids)
                 {
-                    if (c >= nn) return fail(ctx, "rt_scene_upload: child index outside the node array");
+                    if (c >= nn || c <= n) return fail(ctx, "rt_scene_upload: child index outside the node array");
                     if (!is_interior(c)) continue;
                     if (cluster.size() < kTreelet) cluster.push_back(c);
                     else frontier.push_back(c);
@@ -359,6 +361,16 @@ int rt_scene_upload(rt_ctx* ctx, const rt_scene_desc* sd)
         lights[(size_t)i * 3 + 0] = make_float4(l.origin.x, l.origin.y, l.origin.z, 0.0f);
         lights[(size_t)i * 3 + 1] = make_float4(l.radiance.x, l.radiance.y, l.radiance.z, 0.0f);
         lights[(size_t)i * 3 + 2] = make_float4(ft, 0.0f, 0.0f, 0.0f);
+    }
+    for (uint32_t i = 0; i < sd->num_materials; ++i)
+    {
+        // every 8-bit texture slot of a packed material: 0xFF = none (constants.h:35), else an index into textures
+        const rt_packed_material& m = sd->materials[i];
+        const uint32_t idx[6] = {m.diffuse_albedo >> 24, m.specular_albedo >> 24, (m.roughness_metalness >> 8) & 0xFFu,
+            m.roughness_metalness >> 24, (m.ior_emission_idx_transparency >> 8) & 0xFFu, m.ior_emission_idx_transparency >> 24};
+        for (uint32_t t : idx)
+            if (t != RT_INVALID_TEXTURE_IDX && t >= sd->num_textures)
+                return fail(ctx, "rt_scene_upload: material references a texture that does not exist");
     }
     for (uint32_t i = 0; i < sd->num_textures; ++i)
     {
@@ -479,6 +491,9 @@ int alloc_path_buffers(rt_frame* f, uint32_t slots)
 {
     rt_ctx* ctx = f->ctx;
     free_path_buffers(f);
+    // test hook (tests/test_gpu_parity.py): pretend the device cannot hold more than N samples in flight
+    if (f->debug_alloc_limit && slots > f->debug_alloc_limit)
+        return fail(ctx, "out of device memory for the per-path buffers (RT_OPT_DEBUG_ALLOC_LIMIT)");
     f->slots = slots ? slots : 1u;
     uint64_t paths = (uint64_t)(f->n_local ? f->n_local : 1) * f->slots;
     if (paths > 0xFFFFFFF0ull) return fail(ctx, "samples in flight x tile pixels exceeds the 32-bit path-id range");
@@ -492,7 +507,12 @@ int alloc_path_buffers(rt_frame* f, uint32_t slots)
     for (void** p : ptrs) ok = ok && hipMalloc(p, q) == hipSuccess;
     ok = ok && hipMalloc((void**)&f->rlog, (size_t)f->log_entries * paths * sizeof(float4)) == hipSuccess;
     ok = ok && hipMalloc((void**)&f->cnt, (size_t)paths * sizeof(uint32_t)) == hipSuccess;
-    if (!ok) { free_path_buffers(f); return fail(ctx, "out of device memory for the per-path buffers"); }
+    if (!ok)
+    {
+        free_path_buffers(f);
+        (void)hipGetLastError();      // the failed hipMalloc is handled here: do not let it surface at the next launch check
+        return fail(ctx, "out of device memory for the per-path buffers");
+    }
     if (hipMemsetAsync(f->cnt, 0, (size_t)paths * sizeof(uint32_t), ctx->stream) != hipSuccess)
         return fail(ctx, "hipMemsetAsync failed");
     f->cur_slots = 0;
@@ -591,15 +611,12 @@ int rt_frame_create(rt_ctx* ctx, const rt_frame_desc* fd, rt_frame** out)
     ok = ok && hipMalloc((void**)&f->aov_buf.velocity, n * sizeof(float2)) == hipSuccess;
     ok = ok && hipMalloc((void**)&f->prev_radiance, n * sizeof(float4)) == hipSuccess;
     ok = ok && hipMalloc((void**)&f->prev_depth, n * sizeof(float)) == hipSuccess;
-    if (ok)
-    {
-        (void)hipMemsetAsync(f->aov_buf.diffuse_albedo, 0, n * sizeof(float4), ctx->stream);
-        (void)hipMemsetAsync(f->aov_buf.depth, 0, n * sizeof(float), ctx->stream);
-        (void)hipMemsetAsync(f->aov_buf.normal, 0, n * sizeof(float4), ctx->stream);
-        (void)hipMemsetAsync(f->aov_buf.velocity, 0, n * sizeof(float2), ctx->stream);
-        (void)hipMemsetAsync(f->prev_radiance, 0, n * sizeof(float4), ctx->stream);
-        (void)hipMemsetAsync(f->prev_depth, 0, n * sizeof(float), ctx->stream);
-    }
+    ok = ok && hipMemsetAsync(f->aov_buf.diffuse_albedo, 0, n * sizeof(float4), ctx->stream) == hipSuccess;
+    ok = ok && hipMemsetAsync(f->aov_buf.depth, 0, n * sizeof(float), ctx->stream) == hipSuccess;
+    ok = ok && hipMemsetAsync(f->aov_buf.normal, 0, n * sizeof(float4), ctx->stream) == hipSuccess;
+    ok = ok && hipMemsetAsync(f->aov_buf.velocity, 0, n * sizeof(float2), ctx->stream) == hipSuccess;
+    ok = ok && hipMemsetAsync(f->prev_radiance, 0, n * sizeof(float4), ctx->stream) == hipSuccess;
+    ok = ok && hipMemsetAsync(f->prev_depth, 0, n * sizeof(float), ctx->stream) == hipSuccess;
     ok = ok && alloc_path_buffers(f, 1) == RT_OK;     // grows on demand (ensure_slots)
     ok = ok && hipMalloc((void**)&f->counters, sizeof(DCounters)) == hipSuccess;
     // worst case over the kernel variants: 32 one-wave blocks per CU, 8-entry LDS stack
@@ -608,6 +625,7 @@ int rt_frame_create(rt_ctx* ctx, const rt_frame_desc* fd, rt_frame** out)
     if (!ok)
     {
         rt_frame_destroy(f);
+        (void)hipGetLastError();
         return fail(ctx, "rt_frame_create: out of device memory");
     }
     memset(&f->camera, 0, sizeof(f->camera));
@@ -696,6 +714,7 @@ int rt_set_option(rt_frame* f, int option, uint32_t value)
     case RT_OPT_TRACE_PACKET_BOUNCES: f->packet_bounces = value; return RT_OK;
     case RT_OPT_TRACE_SELECT_FORM_BOX: f->select_form_box = value ? RT_SIGN_SLOW : 0u; return RT_OK;
     case RT_OPT_TRACE_TUNE: f->trace_tune = value; return RT_OK;
+    case RT_OPT_DEBUG_ALLOC_LIMIT: f->debug_alloc_limit = value; return RT_OK;
     case RT_OPT_TRACE_VARIANT:
         if (value > 9) return fail(f->ctx, "rt_set_option: unknown trace kernel variant");
         f->trace_variant = value;
@@ -1014,8 +1033,11 @@ int rt_integrate(rt_frame* f, uint32_t n_samples)       // n x Integrator::Integ
     // fuller machine, shorter relative tails); the radiance log keeps the sum exact.
     uint32_t done = 0;
     const bool per_frame = f->denoiser || f->aov != 0;  // interactive features: one sample per Integrate()
-    const uint32_t cap = per_frame ? 1u : slot_cap(f);
+    uint32_t cap = per_frame ? 1u : slot_cap(f);
     if (ensure_slots(f, n_samples < cap ? n_samples : cap) != RT_OK) return RT_ERROR;
+    // ensure_slots may have halved the batch to fit the device (slots_limit): never ask for more than it got
+    if (!per_frame) cap = slot_cap(f) < f->slots ? slot_cap(f) : f->slots;
+    if (cap == 0) cap = 1;
     while (done < n_samples)
     {
         uint32_t batch = n_samples - done < cap ? n_samples - done : cap;
@@ -1082,6 +1104,9 @@ int rt_frame_get_stats(rt_frame* f, rt_stats* out)
     out->closest_rays = h.total_closest;
     out->shadow_rays = h.total_shadow;
     out->samples = f->sample_count;
+    out->samples_in_flight = f->slots;
+    out->samples_in_flight_limit = f->slots_limit;
+    out->path_state_bytes = (uint64_t)f->log_stride * bytes_per_path(f->max_bounces);
     for (int i = 0; i < 64; ++i) { out->last_active[i] = h.last_queue[i]; out->last_shadow[i] = h.last_shadow[i]; }
     return RT_OK;
 }
@@ -1121,7 +1146,7 @@ int rt_frame_copy_radiance(rt_frame* f, void* device_dst)
 
 // ---- debug / parity --------------------------------------------------------
 int rt_frame_debug_read_queue(rt_frame* f, int which, uint32_t bounce, rt_ray* rays, uint32_t* pixel_indices,
-    rt_float4* payload, uint32_t* count)
+    rt_float4* payload, uint32_t capacity, uint32_t* count)
 {
     if (!f || !count) return fail(nullptr, "rt_frame_debug_read_queue: NULL argument");
     rt_ctx* ctx = f->ctx;
@@ -1134,6 +1159,8 @@ int rt_frame_debug_read_queue(rt_frame* f, int which, uint32_t bounce, rt_ray* r
     if (n > f->log_stride) return fail(ctx, "rt_frame_debug_read_queue: corrupt counter");
     *count = n;
     if (n == 0) return RT_OK;
+    if (!rays && !pixel_indices && !payload) return RT_OK;                 // size query (two-call pattern)
+    if (n > capacity) return fail(ctx, "rt_frame_debug_read_queue: the queue holds more entries than the caller's arrays");
     const float4* so = which == 0 ? f->o4[bounce & 1u] : f->sh_o4;
     const float4* sdir = which == 0 ? f->d4[bounce & 1u] : f->sh_d4;
     std::vector<float4> o(n), d(n), p(n);
@@ -1193,6 +1220,7 @@ int rt_debug_eval(rt_ctx* ctx, int fn, const float* a, const float* b, float* ou
     if (!ctx || !a || !out) return fail(ctx, "rt_debug_eval: NULL argument");
     (void)hipSetDevice(ctx->device);
     float *da = nullptr, *db = nullptr, *dout = nullptr;
+    struct Free { float*& a; float*& b; float*& c; ~Free() { for (float* p : {a, b, c}) if (p) (void)hipFree(p); } } guard{da, db, dout};
     HIPCHK(ctx, hipMalloc((void**)&da, (size_t)n * 4 + 16));
     HIPCHK(ctx, hipMalloc((void**)&dout, (size_t)n * 4 + 16));
     HIPCHK(ctx, hipMemcpy(da, a, (size_t)n * 4, hipMemcpyHostToDevice));
@@ -1205,8 +1233,6 @@ int rt_debug_eval(rt_ctx* ctx, int fn, const float* a, const float* b, float* ou
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     HIPCHK(ctx, hipMemcpy(out, dout, (size_t)n * 4, hipMemcpyDeviceToHost));
-    (void)hipFree(da); (void)hipFree(dout);
-    if (db) (void)hipFree(db);
     return RT_OK;
 }
 
