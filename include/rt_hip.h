@@ -49,6 +49,8 @@ enum rt_ctx_option
 {
     RT_CTX_OPT_TREELET_NODES = 0   /* BVH record layout: interior nodes per contiguous breadth-first cluster
                                       (default 7; 1 = the reference's depth-first order).  Layout only. */
+    , RT_CTX_OPT_WIDE_BVH = 1      /* 1 (default): also build the 4-wide quantized tree of k_trace_w4 (two BVH2 levels
+                                      per 64-byte record); 0: BVH2 records only */
 };
 int rt_ctx_set_option(rt_ctx* ctx, int option, uint32_t value);
 /* The blue-noise sampler tables (src/utils/blue_noise_sampler.hpp: sobol_256spp_256d[256*256],
@@ -121,7 +123,8 @@ enum rt_option
     RT_OPT_TRACE_VARIANT = 7    /* traversal kernel: 0 = v1 per-ray loop; 1 .. 4, 6, 7 = one-fetch-per-iteration
                                    state machine with a 16 / 24 / 12 / 8, 10 / 11 entry LDS stack; 8 / 9 = k_trace2
                                    (separate wave-uniform node / triangle / refill loops) with a 10+12 / 12+12 entry
-                                   stack (closest + shadow); 5 (default) = auto: 0 below 2 M paths per launch, 8
+                                   stack (closest + shadow); 10 = k_trace_w4 (4-wide quantized tree, exact leaf
+                                   re-test; rays it cannot take -- non-finite 1/dir -- go to k_trace2); 5 (default) = auto: 0 below 2 M paths per launch, 8
                                    above.  Results are identical for every value. */
     , RT_OPT_TRACE_WAVES_PER_CU = 8 /* persistent-grid size of the trace kernels in waves per CU (0 = as many as fit) */
     , RT_OPT_SAMPLES_IN_FLIGHT = 9  /* rt_integrate traces this many consecutive samples per pixel concurrently
@@ -225,6 +228,12 @@ int rt_frame_debug_read_queue(rt_frame* frame, int which, uint32_t bounce, rt_ra
     rt_float4* payload /* throughput (which=0) or direct light sample (which=1) */,
     uint32_t capacity /* elements the arrays can hold; all arrays NULL = size query */, uint32_t* count);
 int rt_frame_debug_read_hits(rt_frame* frame, rt_hit* hits, uint32_t count);
+
+/* The 4-wide quantized tree rt_scene_upload builds for k_trace_w4 from the reference's LinearBVHNode[]
+ * (host only, no device needed): 64-byte records {origin.xyz, meta, lo[3], hi[3], ref[4], pad[2]} --
+ * see build_wide_bvh in rt_hip.hip.  records may be NULL (count query).  Fails when the tree does not qualify. */
+int rt_debug_wide_bvh(const rt_bvh_node* nodes, uint32_t num_nodes, void* records, uint32_t capacity, uint32_t* num_records,
+    uint32_t* entry_ref);
 
 /* ---- kernel self-test hooks (known-answer tests of the device math):
  * evaluates fn over n inputs on the device.  fn: 0 sin, 1 cos, 2 tan, 3 pow(a,b),

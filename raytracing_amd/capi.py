@@ -57,6 +57,7 @@ EXPORTS = [
     "rt_compute_aovs", "rt_denoise", "rt_copy_history",
     "rt_frame_resolve", "rt_frame_read_radiance", "rt_frame_radiance_device_ptr", "rt_frame_sample_count",
     "rt_frame_get_stats", "rt_frame_get_profile", "rt_frame_copy_radiance", "rt_frame_debug_read_queue", "rt_frame_debug_read_hits", "rt_debug_eval",
+    "rt_debug_wide_bvh",
 ]
 
 OPT_MAX_BOUNCES, OPT_WHITE_FURNACE, OPT_SAMPLER, OPT_AOV, OPT_DENOISER, OPT_DROP_LAST, OPT_PROFILE, OPT_TRACE_VARIANT, OPT_TRACE_WAVES, OPT_SAMPLES_IN_FLIGHT, OPT_SELECT_FORM_BOX, OPT_PACKET_BOUNCES, OPT_TRACE_TUNE, OPT_DEBUG_ALLOC_LIMIT = range(14)
@@ -99,6 +100,7 @@ def load():
         "rt_frame_debug_read_queue": (i32, [vp, i32, u32, vp, vp, vp, u32, C.POINTER(u32)]),
         "rt_frame_debug_read_hits": (i32, [vp, vp, u32]),
         "rt_debug_eval": (i32, [vp, i32, vp, vp, vp, u32]),
+        "rt_debug_wide_bvh": (i32, [vp, u32, vp, u32, C.POINTER(u32), C.POINTER(u32)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

@@ -58,6 +58,8 @@ struct DScene
     uint32_t light_count;
     uint32_t root_ref;            // RT_LEAF_BIT | first triangle, or interior node 0
     uint32_t entry_ref;           // "super-root" record: child 0 = (root box, root_ref), child 1 empty
+    const float4* wnodes;         // 4-wide quantized nodes (k_trace_w4), 4 x float4 each; nullptr = not built
+    uint32_t w_entry_ref;         // wide node 0, or RT_LEAF_BIT | first triangle when the root is a leaf
     float root_min[3];
     float root_max[3];
 };
@@ -84,6 +86,9 @@ struct DCounters                  // one per frame, device memory
     // work-distribution heads of the persistent trace kernels: one per XCD and per
     // kernel flavour (0 = closest, 1 = shadow), offsets inside the XCD's region
     uint32_t head[2][8];
+    // rays k_trace_w4 hands to the BVH2 kernel (non-finite 1/dir): list length and that launch's work heads
+    uint32_t slow_count[2];
+    uint32_t slow_head[2][8];
 };
 
 // ray_inv_dir and ray_sign of TraceBvh (trace_bvh.cl:125-129), packed as (inv.xyz, sign bits)

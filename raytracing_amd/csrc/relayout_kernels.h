@@ -70,3 +70,24 @@ __global__ void k_relayout_triangles(const rt_triangle* __restrict__ tris, uint3
     q[6] = make_float4(__uint_as_float(t.mtl_index), 0.0f, 0.0f, 0.0f);
     q[7] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 }
+
+// one thread per LinearBVHNode, after k_relayout_triangles: a leaf writes its exact bounds into the spare
+// floats of its triangles' trace records (k_trace_w4 re-tests a leaf's box with them when it reaches it):
+//   r[1].w = min.x, r[2].w = min.y, r[3] = (min.z, max.x, max.y, max.z)
+__global__ void k_relayout_leaf_bounds(const rt_bvh_node* __restrict__ nodes, uint32_t nn, uint32_t nt, float4* __restrict__ trt)
+{
+    uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= nn) return;
+    const rt_bvh_node nd = nodes[i];
+    uint32_t n = nd.num_primitives_axis >> 16;
+    if (n == 0) return;
+    uint32_t first = nd.offset;
+    if ((unsigned long long)first + n > nt) return;          // reported by k_relayout_mark_leaves
+    for (uint32_t k = 0; k < n; ++k)
+    {
+        float* r = reinterpret_cast<float*>(trt + (size_t)(first + k) * 4);
+        r[7] = nd.bounds_min.x;
+        r[11] = nd.bounds_min.y;
+        r[12] = nd.bounds_min.z; r[13] = nd.bounds_max.x; r[14] = nd.bounds_max.y; r[15] = nd.bounds_max.z;
+    }
+}

@@ -4,6 +4,9 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <string.h>
+#include <math.h>
+#include <cmath>
+#include <algorithm>
 #include <string>
 #include <vector>
 #include "rt_hip.h"
@@ -18,8 +21,11 @@ struct Scene
     void* nodes = nullptr; void* tris_rt = nullptr; void* tris_sh = nullptr; void* materials = nullptr;
     void* textures = nullptr; void* texture_data = nullptr; void* lights = nullptr; void* env = nullptr;
     void* emissive = nullptr;
+    void* wnodes = nullptr;   // 4-wide quantized BVH (build_wide_bvh); nullptr when the tree does not qualify
     DScene d = {};
     bool valid = false;
+    uint32_t n_wide = 0;      // wide nodes (0 with a leaf root)
+    bool wide_ok = false;     // build_wide_bvh succeeded (k_trace_w4 usable)
     bool offsets32 = false;   // node and trace-triangle arrays below 4 GiB: k_trace2 addresses them with 32-bit byte offsets
 };
 } // namespace
@@ -32,6 +38,7 @@ struct rt_ctx
     std::string error;
     Scene scene;
     uint32_t treelet_nodes = 7;   // RT_CTX_OPT_TREELET_NODES
+    uint32_t build_wide = 1;      // RT_CTX_OPT_WIDE_BVH
     uint8_t* blue_noise = nullptr;   // sobol[65536] | scramblingTile[131072] | rankingTile[131072]
     float* gamma_lut = nullptr;      // pow(byte / 255, 2.2f), 256 entries (k_fill_gamma_lut)
 };
@@ -64,6 +71,7 @@ struct rt_frame
     bool shadow_pending = false;   // rt_shade issued, rt_intersect_shadow not yet
     DCounters* counters;
     uint2* spill;
+    uint32_t* slow_list = nullptr;   // queue indices k_trace_w4 leaves to k_trace2 (one per path)
     uint32_t trace_blocks;       // v1 grid
     uint32_t trace_variant = 5;  // RT_OPT_TRACE_VARIANT (5 = auto)
     uint32_t trace_waves_per_cu = 0;   // RT_OPT_TRACE_WAVES_PER_CU (0 = LDS-limited residency)
@@ -120,7 +128,7 @@ int dev_alloc_copy(rt_ctx* ctx, void** out, const void* src, size_t bytes)
 
 void free_scene(Scene& s)
 {
-    void* ptrs[] = {s.nodes, s.tris_rt, s.tris_sh, s.materials, s.textures, s.texture_data, s.lights, s.env, s.emissive};
+    void* ptrs[] = {s.nodes, s.tris_rt, s.tris_sh, s.materials, s.textures, s.texture_data, s.lights, s.env, s.emissive, s.wnodes};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     s = Scene();
 }
@@ -221,6 +229,7 @@ int rt_ctx_set_option(rt_ctx* ctx, int option, uint32_t value)
         ctx->treelet_nodes = value;
         return RT_OK;
     }
+    if (option == RT_CTX_OPT_WIDE_BVH) { ctx->build_wide = value ? 1u : 0u; return RT_OK; }
     return fail(ctx, "rt_ctx_set_option: unknown option");
 }
 
@@ -280,6 +289,151 @@ int rt_buffer_copy(rt_buffer* src, rt_buffer* dst, size_t src_offset, size_t dst
 
 void* rt_buffer_device_ptr(rt_buffer* buf) { return buf ? buf->ptr : nullptr; }
 size_t rt_buffer_size(rt_buffer* buf) { return buf ? buf->bytes : 0; }
+
+} // extern "C"
+
+namespace
+{
+// ---- 4-wide quantized BVH (k_trace_w4) --------------------------------------
+// Two levels of the reference BVH2 (LinearBVHNode[], bvh.cpp:223-245) are folded into one 64-byte
+// record: up to four "slots" = the grandchildren of a BVH2 node (a child that is a leaf fills one
+// slot).  Slot boxes are stored as 8-bit grid coordinates relative to a per-node frame
+// (origin, power-of-two cell size per axis), rounded OUTWARD.
+//
+// Why results stay bit-identical to the reference ("wide traversal"):
+//  * the frame is chosen so that origin + q * cell is exactly representable in binary32 for every
+//    q in 0..255 (origin is a multiple of the cell, |origin| / cell < 2^23), so the kernel
+//    dequantises WITHOUT rounding and evaluates the reference's own expression
+//    fl(fl(b - o) * inv) on a box that contains the true one; that expression is monotone in b,
+//    hence "true box passes  =>  stored box passes": interior culling only ever visits MORE;
+//  * every leaf is box-tested again with its exact fp32 bounds and the ray's current t_max when it
+//    is reached (the bounds travel in the leaf's first triangle record), and leaves are reached in
+//    the reference's depth-first near/far order (slot order = BVH2 order, swapped per level by the
+//    ray's sign along that level's split axis).  Node bounds are exact unions of their children's
+//    (bvh.hpp:73, checked below), so a leaf's box passing implies that all its ancestors' boxes
+//    pass: the reference tests the triangles of a leaf iff that leaf's own box test passes at that
+//    point of the traversal -- which is exactly what the kernel evaluates.
+// Record: q0 = (origin.xyz, meta)   meta = ex | ey << 8 | ez << 16 | axes << 24 (biased exponents of
+//                                          the cell sizes; axes = axis0 | axisA << 2 | axisB << 4)
+//         q1 = (lo.x, lo.y, lo.z, hi.x)    one byte per slot in every dword
+//         q2 = (hi.y, hi.z, ref0, ref1)    ref = wide node index | RT_LEAF_BIT + first triangle | RT_EMPTY_REF
+//         q3 = (ref2, ref3, -, -)
+struct WideNode { float ox, oy, oz; uint32_t meta; uint32_t lo[3]; uint32_t hi[3]; uint32_t ref[4]; uint32_t pad[2]; };
+static_assert(sizeof(WideNode) == 64, "wide node record");
+
+// false: the tree does not qualify (non-finite or non-nested bounds, child order): k_trace2 is used
+bool build_wide_bvh(const rt_bvh_node* nodes, uint32_t nn, std::vector<WideNode>& out, uint32_t& entry_ref)
+{
+    auto is_leaf = [&](uint32_t i) { return (nodes[i].num_primitives_axis >> 16) != 0; };
+    out.clear();
+    if (is_leaf(0)) { entry_ref = RT_LEAF_BIT | nodes[0].offset; return true; }
+    auto finite3 = [](const rt_float3& v) { return std::isfinite(v.x) && std::isfinite(v.y) && std::isfinite(v.z); };
+    // pass 0: bounds finite and exactly nested (child inside parent), children after their parent
+    for (uint32_t i = 0; i < nn; ++i)
+    {
+        const rt_bvh_node& n = nodes[i];
+        if (!finite3(n.bounds_min) || !finite3(n.bounds_max)) return false;
+        if (is_leaf(i)) continue;
+        if (i + 1 >= nn || n.offset >= nn || n.offset <= i + 1 || (n.num_primitives_axis & 0xFFFFu) > 2u) return false;
+        for (uint32_t c : {i + 1, n.offset})
+        {
+            const rt_bvh_node& k = nodes[c];
+            if (k.bounds_min.x < n.bounds_min.x || k.bounds_min.y < n.bounds_min.y || k.bounds_min.z < n.bounds_min.z ||
+                k.bounds_max.x > n.bounds_max.x || k.bounds_max.y > n.bounds_max.y || k.bounds_max.z > n.bounds_max.z)
+                return false;
+        }
+    }
+    // pass 1: wide nodes in depth-first order (slot 0's subtree first), like the reference's flattening
+    std::vector<uint32_t> wide_of(nn, RT_EMPTY_REF), todo, order, depth_of;
+    todo.push_back(0);
+    depth_of.push_back(1);
+    auto slots_of = [&](uint32_t n, uint32_t slot[4], uint32_t axes[3])
+    {
+        const uint32_t c[2] = {n + 1, nodes[n].offset};
+        axes[0] = nodes[n].num_primitives_axis & 0xFFFFu;
+        for (int i = 0; i < 2; ++i)
+        {
+            if (is_leaf(c[i])) { slot[2 * i] = c[i]; slot[2 * i + 1] = RT_EMPTY_REF; axes[1 + i] = 0; }
+            else { slot[2 * i] = c[i] + 1; slot[2 * i + 1] = nodes[c[i]].offset; axes[1 + i] = nodes[c[i]].num_primitives_axis & 0xFFFFu; }
+        }
+    };
+    while (!todo.empty())
+    {
+        uint32_t n = todo.back(), depth = depth_of.back();
+        todo.pop_back();
+        depth_of.pop_back();
+        if (depth > 33u) return false;                                     // <= 3 pending slots per level must fit RT_W4_STACK_MAX
+        wide_of[n] = (uint32_t)order.size();
+        order.push_back(n);
+        uint32_t slot[4], axes[3];
+        slots_of(n, slot, axes);
+        for (int k = 3; k >= 0; --k)
+            if (slot[k] != RT_EMPTY_REF && !is_leaf(slot[k])) { todo.push_back(slot[k]); depth_of.push_back(depth + 1u); }
+    }
+    if (order.size() >= (1u << 26)) return false;                          // 32-bit byte offsets in the kernel
+    // pass 2: records
+    out.resize(order.size());
+    for (size_t w = 0; w < order.size(); ++w)
+    {
+        const uint32_t n = order[w];
+        uint32_t slot[4], axes[3];
+        slots_of(n, slot, axes);
+        WideNode& r = out[w];
+        memset(&r, 0, sizeof(r));
+        const float nmin[3] = {nodes[n].bounds_min.x, nodes[n].bounds_min.y, nodes[n].bounds_min.z};
+        const float nmax[3] = {nodes[n].bounds_max.x, nodes[n].bounds_max.y, nodes[n].bounds_max.z};
+        float origin[3];
+        int exps[3];
+        for (int a = 0; a < 3; ++a)
+        {
+            // cell = 2^e: 254 cells span the node (one spare for the floor of the origin), and the grid
+            // stays exactly representable: |origin| / cell < 2^23 leaves room for + 255 below 2^24
+            const double extent = (double)nmax[a] - (double)nmin[a];
+            const double amax = std::max(std::fabs((double)nmin[a]), std::fabs((double)nmax[a]));
+            int e = -126;
+            if (extent > 0.0) e = std::max(e, (int)std::ceil(std::log2(extent / 254.0)));
+            while (std::ldexp(254.0, e) < extent) ++e;
+            while (amax > 0.0 && amax / std::ldexp(1.0, e) >= 8388608.0 - 256.0) ++e;
+            if (e > 127) return false;
+            const double cell = std::ldexp(1.0, e);
+            const double o = std::floor((double)nmin[a] / cell) * cell;
+            origin[a] = (float)o;
+            if ((double)origin[a] != o) return false;                     // cannot happen by construction
+            exps[a] = e;
+        }
+        r.ox = origin[0]; r.oy = origin[1]; r.oz = origin[2];
+        r.meta = (uint32_t)(exps[0] + 127) | (uint32_t)(exps[1] + 127) << 8 | (uint32_t)(exps[2] + 127) << 16 |
+                 (axes[0] | axes[1] << 2 | axes[2] << 4) << 24;
+        for (int k = 0; k < 4; ++k)
+        {
+            if (slot[k] == RT_EMPTY_REF)
+            {
+                r.ref[k] = RT_EMPTY_REF;
+                for (int a = 0; a < 3; ++a) { r.lo[a] |= 255u << (8 * k); }   // lo 255 > hi 0: never hit
+                continue;
+            }
+            const rt_bvh_node& c = nodes[slot[k]];
+            r.ref[k] = is_leaf(slot[k]) ? (RT_LEAF_BIT | c.offset) : wide_of[slot[k]];
+            const float cmin[3] = {c.bounds_min.x, c.bounds_min.y, c.bounds_min.z};
+            const float cmax[3] = {c.bounds_max.x, c.bounds_max.y, c.bounds_max.z};
+            for (int a = 0; a < 3; ++a)
+            {
+                const double cell = std::ldexp(1.0, exps[a]);
+                double lo = std::floor(((double)cmin[a] - (double)origin[a]) / cell);
+                double hi = std::ceil(((double)cmax[a] - (double)origin[a]) / cell);
+                if (lo < 0.0 || hi > 255.0 || lo > hi) return false;      // cannot happen: the child is inside the node
+                r.lo[a] |= (uint32_t)lo << (8 * k);
+                r.hi[a] |= (uint32_t)hi << (8 * k);
+            }
+        }
+    }
+    entry_ref = 0;
+    return true;
+}
+
+} // namespace
+
+extern "C" {
 
 // ---- scene -----------------------------------------------------------------
 int rt_scene_upload(rt_ctx* ctx, const rt_scene_desc* sd)
@@ -406,6 +560,8 @@ int rt_scene_upload(rt_ctx* ctx, const rt_scene_desc* sd)
         hipLaunchKernelGGL(k_relayout_triangles, dim3((nt + 255u) / 256u), dim3(256), 0, ctx->stream,
             (const rt_triangle*)raw_tris, nt, sd->num_materials, (const uint8_t*)d_last, (float4*)s.tris_rt,
             (float4*)s.tris_sh, (int*)d_err);
+        hipLaunchKernelGGL(k_relayout_leaf_bounds, dim3((nn + 255u) / 256u), dim3(256), 0, ctx->stream,
+            (const rt_bvh_node*)raw_nodes, nn, nt, (float4*)s.tris_rt);
         ok = hipGetLastError() == hipSuccess &&
              hipMemcpyAsync((char*)s.nodes + (size_t)n_interior * 64, super_root.data(), 64, hipMemcpyHostToDevice,
                  ctx->stream) == hipSuccess &&
@@ -431,6 +587,11 @@ int rt_scene_upload(rt_ctx* ctx, const rt_scene_desc* sd)
     rc |= dev_alloc_copy(ctx, &s.lights, lights.data(), lights.size() * sizeof(float4));
     rc |= dev_alloc_copy(ctx, &s.env, sd->env_rgba, (size_t)sd->env_width * sd->env_height * 16);
     rc |= dev_alloc_copy(ctx, &s.emissive, sd->emissive_indices, (size_t)sd->num_emissive * 4);
+    // the 4-wide quantized tree for k_trace_w4 (optional: trees that do not qualify keep the BVH2 kernels)
+    std::vector<WideNode> wide;
+    uint32_t w_entry = 0;
+    const bool have_wide = ctx->build_wide && (uint64_t)nt * 64 <= 0xFFFFFFFFull && build_wide_bvh(sd->nodes, nn, wide, w_entry);
+    if (have_wide) rc |= dev_alloc_copy(ctx, &s.wnodes, wide.data(), wide.size() * sizeof(WideNode));
     if (rc != RT_OK) { free_scene(s); return RT_ERROR; }
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // host staging vectors die here
 
@@ -446,6 +607,10 @@ int rt_scene_upload(rt_ctx* ctx, const rt_scene_desc* sd)
     s.d.env_w = (int)sd->env_width;
     s.d.env_h = (int)sd->env_height;
     s.d.light_count = sd->num_lights;
+    s.d.wnodes = have_wide ? (const float4*)s.wnodes : nullptr;
+    s.d.w_entry_ref = w_entry;
+    s.n_wide = have_wide ? (uint32_t)wide.size() : 0u;
+    s.wide_ok = have_wide;
     s.offsets32 = (uint64_t)(n_interior + 1) * 64 <= 0xFFFFFFFFull && (uint64_t)nt * 64 <= 0xFFFFFFFFull;
     s.valid = true;
     return RT_OK;
@@ -459,15 +624,16 @@ namespace
 void free_path_buffers(rt_frame* f)
 {
     void* ptrs[] = {f->o4[0], f->o4[1], f->d4[0], f->d4[1], f->iv4[0], f->iv4[1], f->thr[0], f->thr[1], f->hits,
-        f->sh_o4, f->sh_d4, f->sh_iv4, f->rlog, f->cnt};
+        f->sh_o4, f->sh_d4, f->sh_iv4, f->rlog, f->cnt, f->slow_list};
     for (void* p : ptrs) if (p) (void)hipFree(p);
+    f->slow_list = nullptr;
     for (int i = 0; i < 2; ++i) { f->o4[i] = nullptr; f->d4[i] = nullptr; f->iv4[i] = nullptr; f->thr[i] = nullptr; }
     f->hits = nullptr; f->sh_o4 = nullptr; f->sh_d4 = nullptr; f->sh_iv4 = nullptr; f->rlog = nullptr; f->cnt = nullptr;
 }
 
 // Per-path state: ray queues for `slots` samples in flight and the radiance log
 // with 2 * (max_bounces + 1) entries per path.  (Re)allocated when either changes.
-size_t bytes_per_path(uint32_t max_bounces) { return 12u * 16u + 4u + 32u * (max_bounces + 1u); }
+size_t bytes_per_path(uint32_t max_bounces) { return 12u * 16u + 4u + 4u + 32u * (max_bounces + 1u); }
 
 // auto: the largest power of two <= 1024 that keeps tile pixels x samples inside 32-bit path
 // ids and the per-path buffers under ~144 GB (half of the 288 GB of HBM)
@@ -507,6 +673,7 @@ int alloc_path_buffers(rt_frame* f, uint32_t slots)
     for (void** p : ptrs) ok = ok && hipMalloc(p, q) == hipSuccess;
     ok = ok && hipMalloc((void**)&f->rlog, (size_t)f->log_entries * paths * sizeof(float4)) == hipSuccess;
     ok = ok && hipMalloc((void**)&f->cnt, (size_t)paths * sizeof(uint32_t)) == hipSuccess;
+    ok = ok && hipMalloc((void**)&f->slow_list, (size_t)(paths + 64) * sizeof(uint32_t)) == hipSuccess;
     if (!ok)
     {
         free_path_buffers(f);
@@ -620,7 +787,7 @@ int rt_frame_create(rt_ctx* ctx, const rt_frame_desc* fd, rt_frame** out)
     ok = ok && alloc_path_buffers(f, 1) == RT_OK;     // grows on demand (ensure_slots)
     ok = ok && hipMalloc((void**)&f->counters, sizeof(DCounters)) == hipSuccess;
     // worst case over the kernel variants: 32 one-wave blocks per CU, 8-entry LDS stack
-    size_t spill_bytes = (size_t)ctx->prop.multiProcessorCount * 32 * 64 * (RT_TRACE_STACK_MAX - 8) * sizeof(uint2);
+    size_t spill_bytes = (size_t)ctx->prop.multiProcessorCount * 32 * 64 * (RT_W4_STACK_MAX - 8) * sizeof(uint2);
     ok = ok && hipMalloc((void**)&f->spill, spill_bytes) == hipSuccess;
     if (!ok)
     {
@@ -716,7 +883,7 @@ int rt_set_option(rt_frame* f, int option, uint32_t value)
     case RT_OPT_TRACE_TUNE: f->trace_tune = value; return RT_OK;
     case RT_OPT_DEBUG_ALLOC_LIMIT: f->debug_alloc_limit = value; return RT_OK;
     case RT_OPT_TRACE_VARIANT:
-        if (value > 9) return fail(f->ctx, "rt_set_option: unknown trace kernel variant");
+        if (value > 11) return fail(f->ctx, "rt_set_option: unknown trace kernel variant");
         f->trace_variant = value;
         return RT_OK;
     default: return fail(f->ctx, "rt_set_option: unknown option");
@@ -797,7 +964,29 @@ void launch_trace2(rt_frame* f, const float4* o4, const float4* d4, const float4
     if ((tune & 0xFFu) == 0u) tune |= 1u;
     hipLaunchKernelGGL((k_trace2<SHADOW, STACK>), dim3(blocks), dim3(64), 0, ctx->stream, ctx->scene.d, o4, d4, iv4, count,
         &f->counters->head[SHADOW ? 1 : 0][0], SHADOW ? (float4*)nullptr : f->hits,
-        SHADOW ? f->rlog : (float4*)nullptr, f->log_stride, f->select_form_box, f->spill, tune);
+        SHADOW ? f->rlog : (float4*)nullptr, f->log_stride, f->select_form_box, f->spill, tune, (const uint32_t*)nullptr);
+}
+
+// k_trace_w4 over the 4-wide quantized tree, then k_trace2 over the (normally empty) list of rays it left out
+template <bool SHADOW, int STACK>
+void launch_trace_w4(rt_frame* f, const float4* o4, const float4* d4, const float4* iv4, const uint32_t* count)
+{
+    rt_ctx* ctx = f->ctx;
+    uint32_t per_cu = (160u * 1024u) / (STACK * 512u);
+    if (per_cu > 32u) per_cu = 32u;
+    if (f->trace_waves_per_cu && f->trace_waves_per_cu < per_cu) per_cu = f->trace_waves_per_cu;
+    uint32_t blocks = ((uint32_t)ctx->prop.multiProcessorCount * per_cu + 7u) & ~7u;
+    uint32_t tune = f->trace_tune ? f->trace_tune : RT_TRACE2_DEFAULT_TUNE;
+    if ((tune & 0xFFu) > 64u) tune = (tune & ~0xFFu) | 64u;
+    if ((tune & 0xFFu) == 0u) tune |= 1u;
+    const int s = SHADOW ? 1 : 0;
+    hipLaunchKernelGGL((k_trace_w4<SHADOW, STACK>), dim3(blocks), dim3(64), 0, ctx->stream, ctx->scene.d, o4, d4, iv4, count,
+        &f->counters->head[s][0], SHADOW ? (float4*)nullptr : f->hits, SHADOW ? f->rlog : (float4*)nullptr, f->log_stride,
+        f->spill, tune, f->slow_list, &f->counters->slow_count[s]);
+    uint32_t blocks2 = ((uint32_t)ctx->prop.multiProcessorCount * 8u + 7u) & ~7u;
+    hipLaunchKernelGGL((k_trace2<SHADOW, 12>), dim3(blocks2), dim3(64), 0, ctx->stream, ctx->scene.d, o4, d4, iv4,
+        (const uint32_t*)&f->counters->slow_count[s], &f->counters->slow_head[s][0], SHADOW ? (float4*)nullptr : f->hits,
+        SHADOW ? f->rlog : (float4*)nullptr, f->log_stride, f->select_form_box, f->spill, tune, (const uint32_t*)f->slow_list);
 }
 
 // Coherent launches (primary rays): packet traversal, node records through the scalar cache.
@@ -836,6 +1025,8 @@ void launch_trace(rt_frame* f, const float4* o4, const float4* d4, const float4*
         // (profiles/r01_variants_7_stack_10_vs_12.log)
         if (variant == 3u && !SHADOW && ctx->scene.d.entry_ref < 4000000u) variant = 6u;
     }
+    if ((variant == 10u || variant == 11u) && (!ctx->scene.d.wnodes && !(ctx->scene.d.w_entry_ref & RT_LEAF_BIT))) variant = 8u;
+    if ((variant == 10u || variant == 11u) && !ctx->scene.wide_ok) variant = 8u;
     if ((variant == 8u || variant == 9u) && !ctx->scene.offsets32) variant = 3u;
     switch (variant)
     {
@@ -854,6 +1045,8 @@ void launch_trace(rt_frame* f, const float4* o4, const float4* d4, const float4*
         else launch_trace2<SHADOW, 12>(f, o4, d4, iv4, count);
         break;
     case 9: launch_trace2<SHADOW, 12>(f, o4, d4, iv4, count); break;
+    case 10: launch_trace_w4<SHADOW, 12>(f, o4, d4, iv4, count); break;
+    case 11: launch_trace_w4<SHADOW, 16>(f, o4, d4, iv4, count); break;
     default: launch_trace_sm<SHADOW, 12>(f, o4, d4, iv4, count); break;
     }
 }
@@ -1211,6 +1404,24 @@ int rt_frame_debug_read_hits(rt_frame* f, rt_hit* hits, uint32_t count)
         hits[i].bc.x = h[i].x; hits[i].bc.y = h[i].y;
         memcpy(&hits[i].primitive_id, &h[i].z, 4);
         hits[i].t = h[i].w;
+    }
+    return RT_OK;
+}
+
+int rt_debug_wide_bvh(const rt_bvh_node* nodes, uint32_t num_nodes, void* records, uint32_t capacity, uint32_t* num_records,
+    uint32_t* entry_ref)
+{
+    if (!nodes || num_nodes == 0 || !num_records || !entry_ref) return fail(nullptr, "rt_debug_wide_bvh: NULL argument");
+    std::vector<WideNode> wide;
+    uint32_t entry = 0;
+    if (!build_wide_bvh(nodes, num_nodes, wide, entry))
+        return fail(nullptr, "rt_debug_wide_bvh: the tree does not qualify for the 4-wide layout (bounds not finite / not nested, or too deep)");
+    *num_records = (uint32_t)wide.size();
+    *entry_ref = entry;
+    if (records)
+    {
+        if (wide.size() > capacity) return fail(nullptr, "rt_debug_wide_bvh: capacity too small");
+        memcpy(records, wide.data(), wide.size() * sizeof(WideNode));
     }
     return RT_OK;
 }

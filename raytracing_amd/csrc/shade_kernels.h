@@ -337,7 +337,8 @@ __global__ __launch_bounds__(RT_SHADE_BLOCK) void k_shade(DScene sc, DTile tile,
     const uint32_t i = blockIdx.x * RT_SHADE_BLOCK + threadIdx.x;
     // the closest-hit trace of this bounce has completed (stream order): rewind the
     // work heads for the shadow trace of this bounce and the closest trace of the next
-    if (i < 16) a.counters->head[i >> 3][i & 7] = 0;
+    if (i < 16) { a.counters->head[i >> 3][i & 7] = 0; a.counters->slow_head[i >> 3][i & 7] = 0; }
+    if (i < 2) a.counters->slow_count[i] = 0;
     if (blockIdx.x * RT_SHADE_BLOCK >= count) return;                    // whole block idle (uniform)
     const bool active = i < count;
 

@@ -760,11 +760,54 @@ RT_DEV void pair_test_fast(const float4 q0, const float4 q1, const float4 q2, rt
     h1 = hw_min(hi1, t_max) >= a1;
 }
 
+// Wave-level pool of ray indices for the persistent kernels: RT_TRACE_BATCH indices at a time from the
+// head of this XCD's region of the queue (one atomic), stealing from the next regions when it runs dry.
+struct RayPool { uint32_t next, end, regions_tried; bool exhausted; };     // wave-uniform
+
+// gives every lane with `wants` (and no ray yet) the next index, until all are served or the queue is dry
+RT_DEV void hand_out_rays(RayPool& p, uint32_t lane, uint32_t xcd, uint32_t per, uint32_t count, uint32_t* __restrict__ heads,
+    bool wants, uint32_t& ray_i)
+{
+    unsigned long long need = __ballot(wants && ray_i == RT_INVALID_ID);
+    while (need)
+    {
+        if (p.next >= p.end)
+        {
+            bool got = false;
+            while (p.regions_tried < 8u)
+            {
+                uint32_t x = (xcd + p.regions_tried) & 7u;
+                uint32_t rb = x * per < count ? x * per : count;
+                uint32_t re = (x + 1u) * per < count ? (x + 1u) * per : count;
+                uint32_t b = 0;
+                if (lane == 0 && rb < re) b = atomicAdd(&heads[x], RT_TRACE_BATCH);
+                b = __shfl(b, 0, 64);
+                if (rb < re && b < re - rb)
+                {
+                    p.next = rb + b;
+                    p.end = (b + RT_TRACE_BATCH < re - rb) ? rb + b + RT_TRACE_BATCH : re;
+                    got = true;
+                    break;
+                }
+                ++p.regions_tried;
+            }
+            if (!got) { p.exhausted = true; break; }
+        }
+        uint32_t avail = p.end - p.next;
+        uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
+        uint32_t n = (uint32_t)__popcll(need);
+        if (wants && ray_i == RT_INVALID_ID && rank < avail) ray_i = p.next + rank;
+        p.next += n < avail ? n : avail;
+        need = __ballot(wants && ray_i == RT_INVALID_ID);
+    }
+}
+
 template <bool SHADOW, int STACK>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(STACK <= 10 ? 8 : 6, 8))) void k_trace2(DScene sc, const float4* __restrict__ o4, const float4* __restrict__ d4,
     const float4* __restrict__ iv4, const uint32_t* __restrict__ count_ptr, uint32_t* __restrict__ heads,
     float4* __restrict__ hits,
-    float4* __restrict__ rlog, uint32_t log_stride, uint32_t force_sign_bits, uint2* __restrict__ spill, uint32_t tune)
+    float4* __restrict__ rlog, uint32_t log_stride, uint32_t force_sign_bits, uint2* __restrict__ spill, uint32_t tune,
+    const uint32_t* __restrict__ index_list /* nullptr: the whole queue; else queue entries to trace, *count_ptr of them */)
 {
     __shared__ uint2 stack[STACK][64];
     uint32_t* const stack32 = reinterpret_cast<uint32_t*>(&stack[0][0]);     // SHADOW: 2 * STACK entries of 4 bytes
@@ -782,8 +825,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(STACK <= 10 
     const char* const node_base = reinterpret_cast<const char*>(sc.nodes);   // 32-bit byte offsets: the arrays
     const char* const tri_base = reinterpret_cast<const char*>(sc.tris_rt);  // stay below 4 GiB (rt_scene_upload)
 
-    uint32_t pool_next = 0, pool_end = 0, regions_tried = 0;                 // wave-uniform
-    bool exhausted = false;                                                  // wave-uniform: the queue has run dry
+    RayPool pool = {0u, 0u, 0u, false};
     uint32_t ref = RT_IDLE_REF;                                              // interior node | RT_LEAF_BIT + triangle | idle
     uint32_t ray_i = RT_INVALID_ID;                                          // != invalid while a result is owed
     uint32_t sign_bits = 0, hit_prim = RT_INVALID_ID;
@@ -836,44 +878,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(STACK <= 10 
                     hits[ray_i] = make_float4(hit_u, hit_v, __uint_as_float(hit_prim), t_max);
                 ray_i = RT_INVALID_ID;
             }
-            if (!exhausted)
+            if (!pool.exhausted)
             {
-                unsigned long long need = __ballot(ref == RT_IDLE_REF);
-                while (need)
-                {
-                    if (pool_next >= pool_end)
-                    {
-                        bool got = false;
-                        while (regions_tried < 8u)
-                        {
-                            uint32_t x = (xcd + regions_tried) & 7u;
-                            uint32_t rb = x * per < count ? x * per : count;
-                            uint32_t re = (x + 1u) * per < count ? (x + 1u) * per : count;
-                            uint32_t b = 0;
-                            if (lane == 0 && rb < re) b = atomicAdd(&heads[x], RT_TRACE_BATCH);
-                            b = __shfl(b, 0, 64);
-                            if (rb < re && b < re - rb)
-                            {
-                                pool_next = rb + b;
-                                pool_end = (b + RT_TRACE_BATCH < re - rb) ? rb + b + RT_TRACE_BATCH : re;
-                                got = true;
-                                break;
-                            }
-                            ++regions_tried;
-                        }
-                        if (!got) { exhausted = true; break; }
-                    }
-                    uint32_t avail = pool_end - pool_next;
-                    uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
-                    uint32_t n = (uint32_t)__popcll(need);
-                    if (ref == RT_IDLE_REF && ray_i == RT_INVALID_ID && rank < avail) ray_i = pool_next + rank;
-                    pool_next += n < avail ? n : avail;
-                    need = __ballot(ref == RT_IDLE_REF && ray_i == RT_INVALID_ID);
-                }
+                hand_out_rays(pool, lane, xcd, per, count, heads, ref == RT_IDLE_REF, ray_i);
                 if (ref == RT_IDLE_REF && ray_i != RT_INVALID_ID)
                 {
                     // ray start: 1/dir and the sign bits come from the producer; the root box test is
                     // the ordinary node test of the super-root record (see k_trace)
+                    if (index_list) ray_i = index_list[ray_i];
                     float4 q0 = o4[ray_i], q1 = d4[ray_i], q2 = iv4[ray_i];
                     oxy = (rt_v2f){q0.x, q0.y}; oz = q0.z;
                     dir = F3(q1.x, q1.y, q1.z);
@@ -946,7 +958,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(STACK <= 10 
             {
                 // leave when somebody who waits can be served: a lane at a leaf, or a finished lane
                 // while the queue still has rays
-                const unsigned long long waiting = __ballot((int)ref < -1 || (ref == RT_IDLE_REF && !exhausted));
+                const unsigned long long waiting = __ballot((int)ref < -1 || (ref == RT_IDLE_REF && !pool.exhausted));
                 if (waiting != 0ull) break;
             }
             if ((int)ref >= 0)
@@ -993,6 +1005,284 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(STACK <= 10 
                 }
                 if (near_hit) ref = near_ref;
                 else if (far_hit) ref = far_ref;
+                else pop();
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// k_trace_w4: traversal of the 4-wide quantized tree (build_wide_bvh, rt_hip.hip)
+// ---------------------------------------------------------------------------
+// k_trace2 moves ~137 sixteen-byte L1 accesses per ray and the CU's L1 retires ~1.05 of them per
+// clock whatever the instruction count (profiles/r02_ktrace2_pmc.txt: VALU -43 %, time -7 %): the
+// kernel is bound by the NUMBER of accesses and of dependent round trips.  The wide tree halves
+// both: one 64-byte record holds the four grandchildren of a BVH2 node as 8-bit boxes, so a ray
+// makes ~half as many node visits and each visit costs the same four accesses.
+//
+// Exactness (see build_wide_bvh): interior boxes contain the reference's boxes and are evaluated
+// with the reference's own expression after an EXACT dequantisation, so culling is conservative;
+// every leaf is re-tested with its exact fp32 bounds and the current t_max when it is reached, in the
+// reference's depth-first near/far order; shadow rays only need the boolean, which no superset can
+// change.  Rays whose 1/dir has a non-finite component (RT_SIGN_SLOW: NaNs break the monotonicity
+// argument) are not traced here: their queue indices go to `slow_list` and k_trace2 runs over
+// that list afterwards.
+//   stack entry: (ref, entry distance) as in k_trace2; up to three pushes per visit.
+#define RT_LEAF_CONT_BIT 0x40000000u      // the leaf's box has been tested: this is its 2nd+ triangle
+#define RT_W4_STACK_MAX 104               // <= 3 pending slots per wide level, <= 33 wide levels + slack
+
+RT_DEV float w4_plane(uint32_t word, int k, float cell, float origin)
+{
+    // exact: origin is a multiple of cell and |origin / cell| + 255 < 2^24 (build_wide_bvh)
+    return __builtin_fmaf((float)((word >> (8 * k)) & 0xFFu), cell, origin);
+}
+
+template <bool SHADOW, int STACK>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_trace_w4(DScene sc, const float4* __restrict__ o4, const float4* __restrict__ d4,
+    const float4* __restrict__ iv4, const uint32_t* __restrict__ count_ptr, uint32_t* __restrict__ heads,
+    float4* __restrict__ hits, float4* __restrict__ rlog, uint32_t log_stride, uint2* __restrict__ spill, uint32_t tune,
+    uint32_t* __restrict__ slow_list, uint32_t* __restrict__ slow_count)
+{
+    __shared__ uint2 stack[STACK][64];
+    uint32_t* const stack32 = reinterpret_cast<uint32_t*>(&stack[0][0]);     // SHADOW: 2 * STACK entries of 4 bytes
+    volatile uint2* const vspill = spill;                                   // see k_trace2
+    volatile uint32_t* const vspill32 = reinterpret_cast<volatile uint32_t*>(spill);
+    const uint32_t lane = threadIdx.x;
+    const uint32_t count = *count_ptr;
+    if (count == 0) return;
+    const uint32_t node_q = tune & 0xFFu, leaf_q = (tune >> 8) & 0xFFu;
+    const uint32_t xcd = blockIdx.x & 7u;
+    const uint32_t per = (((count + 7u) >> 3) + 63u) & ~63u;
+    const uint32_t spill_base = (blockIdx.x * 64u + lane) * (uint32_t)(RT_W4_STACK_MAX - STACK);
+    const char* const node_base = reinterpret_cast<const char*>(sc.wnodes);
+    const char* const tri_base = reinterpret_cast<const char*>(sc.tris_rt);
+
+    RayPool pool = {0u, 0u, 0u, false};
+    uint32_t ref = RT_IDLE_REF;                    // wide node | RT_LEAF_BIT (| RT_LEAF_CONT_BIT) + triangle | idle
+    uint32_t ray_i = RT_INVALID_ID;
+    uint32_t sign_bits = 0, hit_prim = RT_INVALID_ID;
+    int sp = 0;
+    f3 org = F3s(0.0f), dir = F3s(0.0f), inv = F3s(0.0f);
+    float t_max = 0.0f, hit_u = 0.0f, hit_v = 0.0f;
+    uint32_t payload = 0, log_entry = 0;
+    const float t_min = 0.0f;
+    const float INF = __builtin_inff();
+
+    auto push = [&](uint32_t r, float entry)
+    {
+        if (SHADOW)
+        {
+            if (sp < 2 * STACK) stack32[sp * 64 + lane] = r;
+            else vspill32[(size_t)2 * spill_base + (uint32_t)(sp - 2 * STACK)] = r;
+        }
+        else
+        {
+            if (sp < STACK) stack[sp][lane] = make_uint2(r, __float_as_uint(entry));
+            else
+            {
+                vspill[(size_t)spill_base + (uint32_t)(sp - STACK)].x = r;
+                vspill[(size_t)spill_base + (uint32_t)(sp - STACK)].y = __float_as_uint(entry);
+            }
+        }
+        ++sp;
+    };
+    auto pop = [&]()
+    {
+        ref = RT_IDLE_REF;
+        if (SHADOW)
+        {
+            if (sp > 0)
+            {
+                --sp;
+                if (sp < 2 * STACK) ref = stack32[sp * 64 + lane];
+                else ref = vspill32[(size_t)2 * spill_base + (uint32_t)(sp - 2 * STACK)];
+            }
+        }
+        else
+            while (sp > 0)
+            {
+                --sp;
+                uint32_t ex, ey;
+                if (sp < STACK) { const uint2 e = stack[sp][lane]; ex = e.x; ey = e.y; }
+                else { ex = vspill[(size_t)spill_base + (uint32_t)(sp - STACK)].x; ey = vspill[(size_t)spill_base + (uint32_t)(sp - STACK)].y; }
+                if (t_max >= __uint_as_float(ey)) { ref = ex; break; }       // conservative entry distance: pre-cull only
+            }
+    };
+
+    for (;;)
+    {
+        // ---- A: retire finished rays, start new ones -------------------------------------
+        if (__ballot(ref == RT_IDLE_REF) != 0ull)
+        {
+            if (ref == RT_IDLE_REF && ray_i != RT_INVALID_ID)
+            {
+                if (SHADOW)
+                {
+                    if (hit_prim != RT_INVALID_ID)
+                        rlog[(size_t)log_entry * log_stride + payload] = make_float4(0, 0, 0, 0);
+                }
+                else
+                    hits[ray_i] = make_float4(hit_u, hit_v, __uint_as_float(hit_prim), t_max);
+                ray_i = RT_INVALID_ID;
+            }
+            if (!pool.exhausted)
+            {
+                hand_out_rays(pool, lane, xcd, per, count, heads, ref == RT_IDLE_REF, ray_i);
+                bool slow = false;
+                if (ref == RT_IDLE_REF && ray_i != RT_INVALID_ID)
+                {
+                    float4 q0 = o4[ray_i], q1 = d4[ray_i], q2 = iv4[ray_i];
+                    org = F3(q0.x, q0.y, q0.z);
+                    dir = F3(q1.x, q1.y, q1.z);
+                    t_max = q0.w;
+                    inv = F3(q2.x, q2.y, q2.z);
+                    sign_bits = __float_as_uint(q2.w) & 0xFFu;
+                    if (SHADOW) { payload = __float_as_uint(q1.w); log_entry = __float_as_uint(q2.w) >> 8; }
+                    hit_prim = RT_INVALID_ID;
+                    hit_u = 0.0f; hit_v = 0.0f;
+                    sp = 0;
+                    slow = (sign_bits & RT_SIGN_SLOW) != 0u;
+                    if (!slow) ref = sc.w_entry_ref;
+                }
+                // rays this kernel does not take: hand their queue index to the BVH2 kernel's list
+                const unsigned long long slow_m = __ballot(slow);
+                if (slow_m != 0ull)
+                {
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(slow_count, (uint32_t)__popcll(slow_m));
+                    base = __shfl(base, 0, 64);
+                    if (slow)
+                    {
+                        uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(slow_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)slow_m, 0u));
+                        slow_list[base + rank] = ray_i;
+                        ray_i = RT_INVALID_ID;                               // nothing owed: the other kernel writes the result
+                    }
+                }
+            }
+        }
+        if (__ballot(ref != RT_IDLE_REF) == 0ull)
+        {
+            if (pool.exhausted) break;                                       // queue dry and every ray retired
+            continue;                                                        // a whole wave of rays went to the slow list
+        }
+
+        // ---- B: leaves: exact box re-test on arrival, then one triangle per pass ----------
+        {
+            unsigned long long leaf_m = __ballot((int)ref < -1);
+            const uint32_t n_node = (uint32_t)__popcll(__ballot((int)ref >= 0));
+            if (leaf_m != 0ull && ((uint32_t)__popcll(leaf_m) >= leaf_q || n_node < node_q))
+                do
+                {
+                    if ((int)ref < -1)
+                    {
+                        const uint32_t prim = ref & ~(RT_LEAF_BIT | RT_LEAF_CONT_BIT);
+                        const float4* tp = reinterpret_cast<const float4*>(tri_base + (size_t)(prim << 6));
+                        const float4 q0 = tp[0], q1 = tp[1], q2 = tp[2], q3 = tp[3];
+                        bool inside = true;
+                        if (!(ref & RT_LEAF_CONT_BIT))
+                        {
+                            // the reference's RayBounds on the leaf node (trace_bvh.cl:146-148) with the current t_max
+                            float entry;
+                            inside = box_test_fast(q1.w, q2.w, q3.x, q3.y, q3.z, q3.w, org, inv, t_min, t_max, entry);
+                        }
+                        if (!inside) pop();
+                        else
+                        {
+                            const bool last = q0.w != 0.0f;
+                            bool accepted = false;
+                            f3 p1 = F3(q0.x, q0.y, q0.z), e1 = F3(q1.x, q1.y, q1.z), e2 = F3(q2.x, q2.y, q2.z);
+                            f3 pvec = cross3(dir, e2);
+                            float det = dot3(e1, pvec);
+                            if (!(det < 1e-8f || -det > 1e-8f))
+                            {
+                                float inv_det = 1.0f / det;
+                                f3 tvec = org - p1;
+                                float u = dot3(tvec, pvec) * inv_det;
+                                if (!(u < 0.0f || u > 1.0f))
+                                {
+                                    f3 qvec = cross3(tvec, e1);
+                                    float v = dot3(dir, qvec) * inv_det;
+                                    if (!(v < 0.0f || u + v > 1.0f))
+                                    {
+                                        float t = dot3(e2, qvec) * inv_det;
+                                        if (!(t < t_min || t > t_max))
+                                        {
+                                            hit_u = u; hit_v = v; hit_prim = prim;
+                                            t_max = t;                       // :162
+                                            accepted = true;
+                                        }
+                                    }
+                                }
+                            }
+                            if (SHADOW && accepted) ref = RT_IDLE_REF;       // goto endtrace, :164-167
+                            else if (last) pop();
+                            else ref = (RT_LEAF_BIT | RT_LEAF_CONT_BIT) | (prim + 1u);
+                        }
+                    }
+                    leaf_m = __ballot((int)ref < -1);
+                } while ((uint32_t)__popcll(leaf_m) >= leaf_q && leaf_m != 0ull);
+        }
+
+        // ---- C: wide nodes, the hot loop ----------------------------------------------------
+        for (;;)
+        {
+            const unsigned long long node_m = __ballot((int)ref >= 0);
+            if (node_m == 0ull) break;
+            if ((uint32_t)__popcll(node_m) < node_q)
+            {
+                const unsigned long long waiting = __ballot((int)ref < -1 || (ref == RT_IDLE_REF && !pool.exhausted));
+                if (waiting != 0ull) break;
+            }
+            if ((int)ref >= 0)
+            {
+                const float4* np = reinterpret_cast<const float4*>(node_base + (size_t)(ref << 6));
+                const float4 q0 = np[0], q1 = np[1], q2 = np[2];
+                const float2 q3 = *reinterpret_cast<const float2*>(np + 3);
+                const uint32_t meta = __float_as_uint(q0.w);
+                const float cx = __uint_as_float((meta & 0xFFu) << 23), cy = __uint_as_float(((meta >> 8) & 0xFFu) << 23),
+                            cz = __uint_as_float(((meta >> 16) & 0xFFu) << 23);
+                // near / far plane words per axis, chosen by the ray's direction sign (for a finite non-zero
+                // 1/dir this IS min / max of the two products: the expression is monotone in the bound)
+                const bool nx = (sign_bits & 1u) != 0u, ny = (sign_bits & 2u) != 0u, nz = (sign_bits & 4u) != 0u;
+                const uint32_t lox = __float_as_uint(q1.x), loy = __float_as_uint(q1.y), loz = __float_as_uint(q1.z);
+                const uint32_t hix = __float_as_uint(q1.w), hiy = __float_as_uint(q2.x), hiz = __float_as_uint(q2.y);
+                const uint32_t nwx = nx ? hix : lox, fwx = nx ? lox : hix;
+                const uint32_t nwy = ny ? hiy : loy, fwy = ny ? loy : hiy;
+                const uint32_t nwz = nz ? hiz : loz, fwz = nz ? loz : hiz;
+                uint32_t r[4] = {__float_as_uint(q2.z), __float_as_uint(q2.w), __float_as_uint(q3.x), __float_as_uint(q3.y)};
+                float e[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                {
+                    const float tnx = (w4_plane(nwx, k, cx, q0.x) - org.x) * inv.x;
+                    const float tny = (w4_plane(nwy, k, cy, q0.y) - org.y) * inv.y;
+                    const float tnz = (w4_plane(nwz, k, cz, q0.z) - org.z) * inv.z;
+                    const float tfx = (w4_plane(fwx, k, cx, q0.x) - org.x) * inv.x;
+                    const float tfy = (w4_plane(fwy, k, cy, q0.y) - org.y) * inv.y;
+                    const float tfz = (w4_plane(fwz, k, cz, q0.z) - org.z) * inv.z;
+                    const float entry = hw_max(hw_max3(tnx, tny, tnz), t_min);
+                    const float exit = hw_min(hw_min3(tfx, tfy, tfz), t_max);
+                    e[k] = (exit >= entry && r[k] != RT_EMPTY_REF) ? entry : INF;      // INF = slot not visited
+                }
+                if (!SHADOW)
+                {
+                    // the reference's order: near child first at both BVH2 levels (trace_bvh.cl:181-190)
+                    const uint32_t axes = meta >> 24;
+                    const bool sw0 = ((sign_bits >> (axes & 3u)) & 1u) != 0u, swa = ((sign_bits >> ((axes >> 2) & 3u)) & 1u) != 0u,
+                               swb = ((sign_bits >> ((axes >> 4) & 3u)) & 1u) != 0u;
+                    // slot 1 empty <=> child 0 of the BVH2 node is a leaf: nothing to swap inside that pair
+                    const bool pa = swa && r[1] != RT_EMPTY_REF, pb = swb && r[3] != RT_EMPTY_REF;
+                    uint32_t tr; float te;
+                    tr = pa ? r[1] : r[0]; r[1] = pa ? r[0] : r[1]; r[0] = tr;  te = pa ? e[1] : e[0]; e[1] = pa ? e[0] : e[1]; e[0] = te;
+                    tr = pb ? r[3] : r[2]; r[3] = pb ? r[2] : r[3]; r[2] = tr;  te = pb ? e[3] : e[2]; e[3] = pb ? e[2] : e[3]; e[2] = te;
+                    tr = sw0 ? r[2] : r[0]; r[2] = sw0 ? r[0] : r[2]; r[0] = tr;  te = sw0 ? e[2] : e[0]; e[2] = sw0 ? e[0] : e[2]; e[0] = te;
+                    tr = sw0 ? r[3] : r[1]; r[3] = sw0 ? r[1] : r[3]; r[1] = tr;  te = sw0 ? e[3] : e[1]; e[3] = sw0 ? e[1] : e[3]; e[1] = te;
+                }
+                // visit position 0 next, positions 3..1 wait on the stack (deepest first)
+                if (e[3] < INF) push(r[3], e[3]);
+                if (e[2] < INF) push(r[2], e[2]);
+                if (e[1] < INF) push(r[1], e[1]);
+                if (e[0] < INF) ref = r[0];
                 else pop();
             }
         }

@@ -1,0 +1,156 @@
+"""The 4-wide quantized tree of k_trace_w4 (build_wide_bvh in rt_hip.hip), checked on the host:
+the invariants the exactness argument of DESIGN.md rests on.
+
+  * every slot box, dequantised EXACTLY in binary32 the way the kernel does it
+    (fma(q, cell, origin)), contains the reference node's box;
+  * origin + q * cell is exactly representable for q = 0..255 (no rounding in the dequantisation);
+  * slots 0,1 / 2,3 are the children of BVH2 child 0 / 1 in the reference's order, the three
+    split axes are the reference's, and the leaves reachable from the wide tree are exactly the
+    reference's leaves, each once;
+  * trees that do not qualify (bounds not nested / not finite) are refused."""
+import ctypes as C
+import numpy as np
+import pytest
+from raytracing_amd import capi, host, scenes as S, types as T
+
+LEAF, EMPTY = 0x80000000, 0xFFFFFFFF
+WIDE = np.dtype([("origin", "<f4", 3), ("meta", "<u4"), ("lo", "<u4", 3), ("hi", "<u4", 3), ("ref", "<u4", 4), ("pad", "<u4", 2)])
+assert WIDE.itemsize == 64
+
+
+def wide_of(nodes):
+    lib = capi.load()
+    n, entry = C.c_uint32(), C.c_uint32()
+    nodes = np.ascontiguousarray(nodes)
+    rc = lib.rt_debug_wide_bvh(nodes.ctypes.data, len(nodes), None, 0, C.byref(n), C.byref(entry))
+    if rc != 0:
+        raise capi.RtError(lib.rt_last_error(None).decode())
+    out = np.zeros(n.value, WIDE)
+    assert lib.rt_debug_wide_bvh(nodes.ctypes.data, len(nodes), out.ctypes.data, len(out), C.byref(n), C.byref(entry)) == 0
+    return out, entry.value
+
+
+def bvh_of(tris, mats):
+    s = host.Scene(arrays=dict(triangles=tris, materials=mats))
+    s.build_bvh()
+    a = s.arrays()
+    return a["nodes"].copy(), a["triangles"].copy()
+
+
+def check(nodes):
+    wide, entry = wide_of(nodes)
+    is_leaf = (nodes["num_primitives_axis"] >> 16) != 0
+    if is_leaf[0]:
+        assert len(wide) == 0 and entry == (LEAF | int(nodes["offset"][0]))
+        return wide
+    assert entry == 0
+    bmin = np.stack([nodes["bounds_min"][c] for c in "xyz"], 1)
+    bmax = np.stack([nodes["bounds_max"][c] for c in "xyz"], 1)
+    # walk the wide tree together with the BVH2: wide node w <-> BVH2 interior node n
+    seen_leaves, seen_wide = [], set()
+    todo = [(0, 0)]
+    f32 = np.float32
+    while todo:
+        w, n = todo.pop()
+        assert w not in seen_wide
+        seen_wide.add(w)
+        rec = wide[w]
+        meta = int(rec["meta"])
+        cell = [f32(2.0) ** f32(((meta >> (8 * a)) & 0xFF) - 127) for a in range(3)]
+        axes = meta >> 24
+        c = [n + 1, int(nodes["offset"][n])]
+        assert (axes & 3) == (int(nodes["num_primitives_axis"][n]) & 0xFFFF)
+        slots = []
+        for i in range(2):
+            if is_leaf[c[i]]:
+                slots += [c[i], None]
+            else:
+                slots += [c[i] + 1, int(nodes["offset"][c[i]])]
+                assert ((axes >> (2 + 2 * i)) & 3) == (int(nodes["num_primitives_axis"][c[i]]) & 0xFFFF)
+        for k, child in enumerate(slots):
+            ref = int(rec["ref"][k])
+            if child is None:
+                assert ref == EMPTY
+                continue
+            for a in range(3):
+                qlo, qhi = (int(rec["lo"][a]) >> (8 * k)) & 0xFF, (int(rec["hi"][a]) >> (8 * k)) & 0xFF
+                o = f32(rec["origin"][a])
+                # exact representability: the fp32 product and sum carry no rounding error
+                lo32 = f32(f32(qlo) * cell[a]) + o
+                hi32 = f32(f32(qhi) * cell[a]) + o
+                assert float(lo32) == float(o) + qlo * float(cell[a])
+                assert float(hi32) == float(o) + qhi * float(cell[a])
+                assert float(o) / float(cell[a]) == round(float(o) / float(cell[a]))
+                assert abs(float(o) / float(cell[a])) + 255 < 2 ** 24
+                # conservative: the stored box contains the reference's box
+                assert lo32 <= bmin[child, a] and hi32 >= bmax[child, a], (w, k, a)
+                # and is tight to the grid
+                assert float(bmin[child, a]) - float(lo32) < float(cell[a]) and float(hi32) - float(bmax[child, a]) < float(cell[a])
+            if is_leaf[child]:
+                assert ref == (LEAF | int(nodes["offset"][child]))
+                seen_leaves.append(child)
+            else:
+                assert ref < len(wide)
+                todo.append((ref, child))
+    assert sorted(seen_leaves) == sorted(np.nonzero(is_leaf)[0].tolist())
+    assert len(seen_wide) == len(wide)
+    return wide
+
+
+def test_wide_tree_of_the_cornell_box_and_a_dense_mesh():
+    import os
+    s = host.Scene(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "assets", "CornellBox.obj"))
+    s.build_bvh()
+    check(s.arrays()["nodes"].copy())
+    tris, mats = S.cornell_blob(20_000, 2_000)
+    nodes, _ = bvh_of(tris, mats)
+    wide = check(nodes)
+    n_interior = int(((nodes["num_primitives_axis"] >> 16) == 0).sum())
+    assert 0.4 * n_interior < len(wide) < 0.75 * n_interior       # two BVH2 levels per record
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_wide_tree_of_random_soups_with_extreme_coordinates(seed):
+    """Slivers, coincident triangles, huge offsets (coarse fp32 grid) and tiny extents."""
+    rng = np.random.default_rng(seed)
+    n = int(rng.integers(1, 400))
+    scale = float(10.0 ** rng.integers(-6, 7))
+    offset = rng.normal(size=3) * float(10.0 ** rng.integers(-3, 8))
+    P = (rng.normal(size=(n, 1, 3)) * scale + rng.normal(size=(n, 3, 3)) * scale * float(10.0 ** rng.integers(-5, 1)) + offset)
+    P = P.astype(np.float32)
+    if seed % 2:
+        P[: n // 3] = P[0]                                   # coincident triangles
+    N = np.tile(np.array([0, 0, 1], np.float32), (n, 3, 1))
+    tris = S.to_triangles([(P, N, np.zeros((n, 3, 2), np.float32), 0)])
+    mats = np.array([S.make_material(kd=(0.7, 0.7, 0.7))], dtype=T.packed_material)
+    nodes, _ = bvh_of(tris, mats)
+    check(nodes)
+
+
+def test_trees_that_do_not_qualify_are_refused():
+    tris, mats = S.cornell_blob(2_000, 500)
+    nodes, _ = bvh_of(tris, mats)
+    bad = nodes.copy()
+    interior = np.nonzero((bad["num_primitives_axis"] >> 16) == 0)[0]
+    bad["bounds_max"]["x"][interior[3] + 1] += 1000.0          # a child sticking out of its parent
+    with pytest.raises(capi.RtError, match="does not qualify"):
+        wide_of(bad)
+    bad = nodes.copy()
+    bad["bounds_min"]["y"][5] = np.nan
+    with pytest.raises(capi.RtError, match="does not qualify"):
+        wide_of(bad)
+    # a left-deep chain deeper than the kernel's stack bound is refused, a shallow one qualifies
+    def chain(n):
+        # interior k at index k (first child k + 1), second child = a leaf stored behind the chain
+        c = np.zeros(2 * n + 1, T.bvh_node)
+        for k in range(2 * n + 1):
+            leaf = k >= n
+            c["num_primitives_axis"][k] = (1 << 16) if leaf else 0
+            c["offset"][k] = (k - n) if leaf else (2 * n - k)
+            for ax in "xyz":
+                c["bounds_min"][ax][k] = -0.5 if leaf else -1.0
+                c["bounds_max"][ax][k] = 0.5 if leaf else 1.0
+        return c
+    with pytest.raises(capi.RtError, match="does not qualify"):
+        wide_of(chain(80))
+    check(chain(20))
