@@ -950,7 +950,7 @@ void launch_trace_sm(rt_frame* f, const float4* o4, const float4* d4, const floa
 }
 
 // k_trace2: separate wave-uniform loops (trace_kernels.h).  Same grid sizing as launch_trace_sm.
-#define RT_TRACE2_DEFAULT_TUNE (40u | (12u << 8))
+#define RT_TRACE2_DEFAULT_TUNE (32u | (8u << 8))     // profiles/r02_ktrace2_tune_sweep.log, r02_w4_tune_sweep.log
 template <bool SHADOW, int STACK>
 void launch_trace2(rt_frame* f, const float4* o4, const float4* d4, const float4* iv4, const uint32_t* count)
 {
@@ -1016,14 +1016,12 @@ void launch_trace(rt_frame* f, const float4* o4, const float4* d4, const float4*
     {
         // auto: with few rays per launch (one or two samples of a 720p frame in flight, the
         // interactive RenderFrame() case) every lane gets only ~3 rays and the per-ray loop of
-        // v1 wins (measured 770 vs 600 Mrays/s); from ~2 M paths up the state machine wins
-        // (profiles/r01_variants_3_samples_in_flight.log)
+        // v1 wins (measured 770 vs 600 Mrays/s, profiles/r01_variants_3_samples_in_flight.log); from
+        // ~2 M paths up the persistent kernels win, and of those the 4-wide quantized tree:
+        // 4214 (k_trace) / 4400 (k_trace2) / 5042 (k_trace_w4) Mrays/s on the headline workload
+        // (profiles/r02_w4_tune_sweep.log)
         uint64_t paths = (uint64_t)f->n_local * (f->cur_slots ? f->cur_slots : 1u);
-        variant = paths >= 2000000ull ? 3u : 0u;
-        // closest-hit rays: a 10-entry LDS stack (32 waves per CU instead of 26) wins 2-5 % unless the
-        // tree is deep enough to spill often (10 M triangles: -1.5 %); shadow rays always lose with it
-        // (profiles/r01_variants_7_stack_10_vs_12.log)
-        if (variant == 3u && !SHADOW && ctx->scene.d.entry_ref < 4000000u) variant = 6u;
+        variant = paths >= 2000000ull ? 10u : 0u;
     }
     if ((variant == 10u || variant == 11u) && (!ctx->scene.d.wnodes && !(ctx->scene.d.w_entry_ref & RT_LEAF_BIT))) variant = 8u;
     if ((variant == 10u || variant == 11u) && !ctx->scene.wide_ok) variant = 8u;
