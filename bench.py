@@ -13,33 +13,49 @@ is the same loop over one sample per pixel, and `ms_per_spp` is reported next to
 `ms_per_step`.  Workload: the configuration BASELINE.json's metric is quoted on,
 configs[3] "Amazon Lumberyard Bistro 1920x1080 256spp 8-bounce" -- it fits one
 GPU, so N = 1 runs it whole and N > 1 tiles it.  The Bistro asset is a download
-the reference does not ship (assets/download_bistro.bat), so the deterministic
-stand-in of SURVEY.md section 8d is generated (raytracing_amd/scenes.py:
-city_block, ~2.8 M triangles, 120 materials, textured); default K = 8 steps =
-1024 spp (four times the config's 256 spp: the rate does not depend on the
-sample count, and a job of that length lets each of 8 tiles keep as many paths in
-flight as the whole frame does on one GPU), W = 1.  --config 2 / 3 / 5 select the other BASELINE
-configs' stand-ins.  Metric = BASELINE.json's: Mrays/s, all bounces + shadow
-rays, counted by the device queue counters the reference itself keeps
-(ray_counter_buffer_, shadow_ray_counter_buffer_).
+the reference does not ship (assets/download_bistro.bat), so by default the
+deterministic stand-in of SURVEY.md section 8d is generated (raytracing_amd/
+scenes.py: city_block, ~2.8 M triangles, 120 materials, textured); with
+`--scene exterior.obj --flip-yz --scale 0.01` (run_bistro.bat:15) or a cache
+written by `rt_render --save-cache` the real asset is rendered instead and the
+line says `"data": "real"`.  Default K = 8 steps = 1024 spp, W = 1.  --config
+2 / 3 / 5 select the other BASELINE configs' stand-ins.  Metric = BASELINE.json's:
+Mrays/s, all bounces + shadow rays, counted by the device queue counters the
+reference itself keeps (ray_counter_buffer_, shadow_ray_counter_buffer_).
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): the frame is split
-into interleaved 8-row bands, the scene is replicated, there is no communication
-while rendering and ONE gather (RCCL) of the accumulated radiance to rank 0
-inside the timed region -> "scaling": "strong" (total work fixed).
+N > 1: one rank per GPU.  Launched by the driver under torch.distributed.run
+(RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment); `python bench.py
+--gpus N` on its own re-executes itself under torch.distributed.run.  The frame is
+split into interleaved 8-row bands, the scene is replicated, there is no
+communication while rendering and ONE gather of the accumulated radiance to rank 0
+inside the timed region -- rt_group_gather_radiance of the C-ABI, i.e. ncclGather
+of RCCL over xGMI; torch.distributed (gloo) only carries the 128-byte group id,
+the barriers and the timing reductions.  "scaling": "strong" (total work fixed).
+--debug-shared-gpu puts all ranks on GPU 0 (RCCL refuses two ranks per device, so
+the gather then goes through gloo): plumbing check on a one-GPU box.
+--plumbing-only runs launch, rendezvous, gather and the JSON line without a GPU
+(synthetic tiles, no rendering, "value": null).
 
 Extra objects on the JSON line:
-  roofline     dominant kernel = k_trace<closest>; achieved = algorithmic bytes
-               (48 + 32 n_nodes + 36 n_tris per ray, n_* measured by
-               the instrumented CPU oracle on the reference BVH2) x rays per
-               launch / HIP-event duration of those launches, measured live here.
-  cpu_baseline the reference's own OpenCL kernels compiled for x86-64
-               (oracle/_ref, kind "reference") or the C restatement (kind
-               "port"), timed on this box's host cores on a bounded sample.
+  roofline     the dominant kernel (closest-hit traversal) against CALIBRATED ceilings:
+               busy fractions of the vector ALU, the scalar ALU and the L1/texture-address
+               path and the HBM rate from rocprofv3 --pmc passes of this workload
+               (profiles/r02_trace_counters.json, made by tools/make_counters_json.py;
+               ceilings from tools/issue_microbench.hip); `bound` = the unit nearest its
+               ceiling, `frac` <= 1 by construction.  Launch duration and rays per launch
+               are measured live (HIP events on the library's stream).
+  parity       at N = 1: the frame the cpu_baseline leg renders with the reference's own
+               kernels is rendered again on the GPU (same samples, outside the timed
+               region) and compared: bit_identical, rel_l2, non-finite pixels on both sides.
+  cpu_baseline the reference's own OpenCL kernels compiled for x86-64 (oracle/_ref, kind
+               "reference") or the C restatement (kind "port"), timed on this box's host
+               cores on a bounded sample.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -50,6 +66,7 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 LIGHT = ((-0.6, -1.5, 3.5), (15.0, 10.0, 5.0))   # reference main.cpp:58
+COUNTERS_FILE = os.path.join(ROOT, "profiles", "r02_trace_counters.json")
 
 
 # BASELINE.json configs (index = position in "configs"); config 1 is the CPU plumbing case.
@@ -66,7 +83,10 @@ CONFIGS = {
 
 
 def build_scene(args, host, S):
-    if args.config == 3:
+    if getattr(args, "scene", None):
+        # a real asset: OBJ/MTL through the C++ loader, or a binary cache written by rt_render --save-cache
+        scene = host.Scene(args.scene, scale=args.scale, flip_yz=args.flip_yz)
+    elif args.config == 3:
         import tempfile
         path = S.shader_balls_obj(tempfile.mkdtemp(prefix="rt_bench_"), 100_000)
         scene = host.Scene(path)
@@ -83,7 +103,8 @@ def build_scene(args, host, S):
 
 
 def cpu_legs(args, scene_arrays, cam_small, small_w, small_h, cam_full):
-    """(a) instrumented oracle pass -> nodes/tris per ray; (b) timed CPU baseline."""
+    """(a) instrumented oracle pass -> nodes/tris per ray; (b) timed CPU baseline.  Returns
+    (per_ray, baseline, reference image or None, samples in that image)."""
     from tests import _oracle, _ref
     orc = _oracle.Oracle(small_w, small_h, scene_arrays)
     orc.set_camera(cam_small)
@@ -95,7 +116,7 @@ def cpu_legs(args, scene_arrays, cam_small, small_w, small_h, cam_full):
     st = orc.stats()
     per_ray = dict(closest_nodes=st["closest_nodes"] / max(c, 1), closest_tris=st["closest_tris"] / max(c, 1),
                    shadow_nodes=st["shadow_nodes"] / max(s, 1), shadow_tris=st["shadow_tris"] / max(s, 1))
-    baseline = None
+    baseline, ref_img, ref_spp = None, None, 0
     if not args.no_cpu_baseline and args.gpus == 1:          # the CPU baseline is timed at N = 1 only
         cores = os.cpu_count() or 1
         if _ref.available():
@@ -117,7 +138,7 @@ def cpu_legs(args, scene_arrays, cam_small, small_w, small_h, cam_full):
             ri = _ref.RefIntegrator(args.width, args.height, scene_arrays, threads=best_t)
             ri.set_camera(cam_full)
             ri.set_max_bounces(args.bounces)
-            ri.integrate(1)                                   # warm-up (page in, thread start)
+            ri.integrate(1)                                   # warm-up (page in, thread start); sample 0 of the image
             r0 = sum(ri.ray_totals())
             t0 = time.time()
             n = 0
@@ -128,6 +149,7 @@ def cpu_legs(args, scene_arrays, cam_small, small_w, small_h, cam_full):
                     break
             dt = time.time() - t0
             rays = sum(ri.ray_totals()) - r0
+            ref_img, ref_spp = ri.radiance()[..., :3].copy(), n + 1
             baseline = dict(value=round(rays / dt / 1e6, 3), unit="Mrays/s", cores=best_t, kind="reference",
                             sample="%d spp of the same scene at %dx%d, %d bounces (%.1f s; the reference's unmodified "
                                    ".cl kernels compiled for x86-64, NDRange = parallel-for over %d threads -- the best of "
@@ -138,7 +160,102 @@ def cpu_legs(args, scene_arrays, cam_small, small_w, small_h, cam_full):
             baseline = dict(value=(c + s) / t_orc / 1e6, unit="Mrays/s", cores=1, kind="port",
                             sample="1 spp of the same scene at %dx%d, %d bounces (%.1f s, oracle/oracle.c, scalar)"
                                    % (small_w, small_h, args.bounces, t_orc))
-    return per_ray, baseline
+    return per_ray, baseline, ref_img, ref_spp
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: run the same command under torch.distributed.run."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
+
+
+def plumbing_only(args, rank, world):
+    """No GPU, no rendering: launch + rendezvous + per-rank tiles + the gather + the JSON line."""
+    import torch
+    import torch.distributed as dist
+    from raytracing_amd import distributed as D
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    w, h = args.width, args.height
+    rows = D.tile_rows(h, rank, world, args.band_height)
+    # a tile whose pixels say where they belong: (global row, column, rank)
+    tile = torch.zeros((len(rows), w, 4), dtype=torch.float32)
+    tile[..., 0] = torch.as_tensor(rows, dtype=torch.float32)[:, None]
+    tile[..., 1] = torch.arange(w, dtype=torch.float32)[None, :]
+    tile[..., 2] = float(rank)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    full = D.gather_image(tile, h, w, rank, world, args.band_height)
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        ok = bool((full[..., 0] == torch.arange(h, dtype=torch.float32)[:, None]).all()
+                  and (full[..., 1] == torch.arange(w, dtype=torch.float32)[None, :]).all())
+        owner = ((torch.arange(h) // args.band_height) % world).to(torch.float32)
+        ok = ok and bool((full[..., 2] == owner[:, None]).all())
+        print(json.dumps(dict(metric="Mrays/s (all bounces+shadow)", value=None, unit="Mrays/s", n_gpus=world, steps=args.steps,
+                              warmup=args.warmup, higher_is_better=True, scaling="strong", plumbing_only=True,
+                              gather=dict(transport="gloo (plumbing check)", ms=round(float(tmax.item()) * 1e3, 3), image_ok=ok,
+                                          nranks=world),
+                              config=dict(workload="no rendering: launch, rendezvous, tile gather and report only",
+                                          width=w, height=h))), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
+def roofline_object(args, world, agg, prof, per_ray, spp_timed):
+    """The dominant kernel against calibrated ceilings (see the module docstring)."""
+    n_launch = max(prof.n_trace_closest, 1) * world
+    ms_sum = agg[2]
+    avg_ms = ms_sum / n_launch
+    rays_per_launch = agg[0] / n_launch
+    bytes_closest = 48.0 + 32.0 * per_ray["closest_nodes"] + 36.0 * per_ray["closest_tris"]     # SURVEY 8d, per ray
+    live = dict(kernel="closest-hit traversal (k_trace_w4<closest> + its k_trace2 follow-up)",
+                rays_per_launch=round(rays_per_launch, 1), avg_launch_ms=round(avg_ms, 5),
+                mrays_per_s=round(agg[0] / (ms_sum * 1e-3) / 1e6, 1) if ms_sum > 0 else 0.0,
+                kernel_ms_per_spp=dict(trace_closest=round(agg[2] / world / spp_timed, 4), trace_shadow=round(agg[3] / world / spp_timed, 4),
+                                        shade=round(agg[4] / world / spp_timed, 4), raygen=round(agg[5] / world / spp_timed, 4)),
+                algorithmic_bytes_per_ray=round(bytes_closest, 1), nodes_per_ray=round(per_ray["closest_nodes"], 2),
+                tris_per_ray=round(per_ray["closest_tris"], 2))
+    alg_gbs = (agg[0] * bytes_closest) / (ms_sum * 1e-3) / 1e9 if ms_sum > 0 else 0.0
+    out = dict(bound="unknown", achieved=None, peak=None, unit=None, frac=None, traffic=None, live=live,
+               hbm_algorithmic=dict(GBs=round(alg_gbs, 1), peak_GBs=HBM_PEAK_GBS, ratio=round(alg_gbs / HBM_PEAK_GBS, 4),
+                                    note="SURVEY 8d byte model (48 + 32 n_nodes + 36 n_tris per ray on the reference BVH2): a "
+                                         "cache-blind count of LOGICAL bytes, not HBM traffic -- kept for continuity, not a ceiling"))
+    try:
+        pmc = json.load(open(COUNTERS_FILE))["config_%d" % args.config]
+    except Exception:
+        return out
+    k = pmc["closest"]
+    units = {n: k[n] for n in ("valu_busy", "salu_busy", "l1_ta_busy", "hbm_frac") if k.get(n) is not None}
+    bound = max(units, key=units.get)
+    out.update(bound=bound, achieved=round(units[bound], 4), peak=1.0,
+               unit="busy fraction of the unit's calibrated ceiling (1.0 = saturated)", frac=round(units[bound], 4),
+               traffic=k.get("hbm_bytes_per_launch"),
+               units=units, counters=k.get("per_ray"), source="profiles/r02_trace_counters.json (rocprofv3 --pmc passes of this "
+               "workload at N = 1, round 2; ceilings: profiles/r02_issue_microbench.log)",
+               hbm_counter=dict(GBs=k.get("hbm_GBs"), peak_GBs=HBM_PEAK_GBS, frac=k.get("hbm_frac")))
+    return out
 
 
 def main():
@@ -151,6 +268,10 @@ def main():
     ap.add_argument("--config", type=int, default=4, choices=sorted(CONFIGS),
                     help="BASELINE.json config (1-based index into 'configs'); default 4 = the one the metric is quoted on "
                          "(Bistro 1080p 8-bounce stand-in)")
+    ap.add_argument("--scene", default=None, help="render this OBJ (with its MTL/textures) or .rtscene cache instead of the stand-in, "
+                    "e.g. --scene exterior.obj --flip-yz --scale 0.01 for Bistro (run_bistro.bat:15)")
+    ap.add_argument("--scale", type=float, default=1.0)
+    ap.add_argument("--flip-yz", action="store_true")
     ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--bounces", type=int, default=None)
@@ -161,19 +282,21 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--debug-shared-gpu", action="store_true",
                     help="plumbing test only: all ranks share GPU 0 and gather over gloo (RCCL refuses two ranks per device)")
+    ap.add_argument("--plumbing-only", action="store_true", help="no GPU: launch, rendezvous, gather and report only")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
     args.width = args.width or cfg["width"]
     args.height = args.height or cfg["height"]
     args.bounces = cfg["bounces"] if args.bounces is None else args.bounces
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return self_launch(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
-        args.gpus = world
+    args.gpus = world
+    if args.plumbing_only:
+        return plumbing_only(args, rank, world)
 
     import torch
     import torch.distributed as dist
@@ -184,11 +307,16 @@ def main():
     if args.debug_shared_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
+    group = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # "nccl" is RCCL on ROCm; one rank per GPU, xGMI underneath
-        dist.init_process_group("gloo" if args.debug_shared_gpu else "nccl", rank=rank, world_size=world)
-    coll_dev = "cpu" if (args.debug_shared_gpu and world > 1) else "cuda"
+        # control plane only (group id, barriers, timing reductions): gloo.  The data-path collective is RCCL
+        # behind the C-ABI (rt_group_gather_radiance).
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        if not args.debug_shared_gpu:
+            ids = [capi.Group.unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0)
+            group = capi.Group.join(world, rank, ids[0], local_rank)
 
     # ---- setup (untimed): scene, BVH, upload -------------------------------
     scene, n_tris = build_scene(args, host, S)
@@ -210,6 +338,18 @@ def main():
     local_rows = render.local_rows
     tile = torch.zeros((max(local_rows, 1), args.width, 4), dtype=torch.float32, device="cuda")
 
+    def gather(want_host):
+        """The one collective.  Returns the full image on rank 0 (torch CPU tensor) when want_host."""
+        if group is not None:
+            img = group.gather_radiance([frame], 0, args.height, args.width, want_host=want_host)
+            return torch.from_numpy(img) if img is not None else None
+        if local_rows:
+            lib.rt_frame_copy_radiance(frame, tile.data_ptr())
+        if world == 1:
+            return tile[:local_rows].cpu() if want_host else None
+        full = D.gather_image(tile[:local_rows].cpu(), args.height, args.width, rank, world, args.band_height)   # debug: gloo
+        return full
+
     # per-path buffers sized for the K-sample job before anything is timed (they would
     # otherwise grow inside the first rt_integrate that asks for a larger batch)
     sps = args.samples_per_step or cfg["samples_per_step"]
@@ -218,10 +358,8 @@ def main():
 
     # ---- warm-up ------------------------------------------------------------
     render.render_samples(spp_warm) if spp_warm > 0 else None
-    if args.warmup > 0:     # the gather path too (first use loads torch / RCCL kernels)
-        if local_rows:
-            lib.rt_frame_copy_radiance(frame, tile.data_ptr())
-        D.gather_image(tile[:local_rows].to(coll_dev), args.height, args.width, rank, world, args.band_height)
+    if args.warmup > 0:     # the gather path too (first use sets up the RCCL channels)
+        gather(False)
     sync()
     # the timed region starts from a reset accumulation (sample indices 0..K-1, counters at 0)
     assert lib.rt_reset(frame) == 0
@@ -236,92 +374,93 @@ def main():
     # ---- timed region: exactly K steps + the one gather ----------------------
     t0 = time.perf_counter()
     render.render_samples(spp_timed)
-    t_enq = time.perf_counter() - t0
-    if local_rows:
-        lib.rt_frame_copy_radiance(frame, tile.data_ptr())
+    render.finish()
     t_render = time.perf_counter() - t0
-    full = D.gather_image(tile[:local_rows].to(coll_dev), args.height, args.width, rank, world, args.band_height)
+    gather(False)
     sync()
+    t_local = time.perf_counter() - t0
     if world > 1:
         dist.barrier()
     sync()
     dt = time.perf_counter() - t0
-    if os.environ.get("RT_BENCH_DEBUG"):
-        print("rank %d: enqueue %.1f ms, render+copy %.1f ms, total %.1f ms" % (rank, t_enq * 1e3, t_render * 1e3, dt * 1e3),
-              file=sys.stderr, flush=True)
 
     st1 = render.stats()
     lib.rt_frame_get_profile(frame, prof)
+    lib.rt_set_option(frame, capi.OPT_PROFILE, 0)
     closest = st1.closest_rays - st0.closest_rays
     shadow = st1.shadow_rays - st0.shadow_rays
     agg = torch.tensor([float(closest), float(shadow), prof.ms_trace_closest, prof.ms_trace_shadow, prof.ms_shade,
-                        prof.ms_raygen], dtype=torch.float64, device=coll_dev)
-    tmax = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
+                        prof.ms_raygen], dtype=torch.float64)
+    tmax = torch.tensor([dt, t_render, t_local - t_render], dtype=torch.float64)
+    tmin = torch.tensor([t_render], dtype=torch.float64)
     if world > 1:
         dist.all_reduce(agg, op=dist.ReduceOp.SUM)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    agg = agg.cpu().numpy()
-    dt_max = float(tmax.item())
+        dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
+    agg = agg.numpy()
+    dt_max = float(tmax[0].item())
+    full = gather(True)                                      # untimed: the image for the checks below
 
     if rank == 0:
         assert full is not None
-        # NaN pixels are legal in the reference arithmetic (inf * 0 in the mirror branch) but must be rare
-        nan_px = int((~torch.isfinite(full[..., :3]).all(-1)).sum().item())
-        assert nan_px <= 1e-4 * args.width * args.height, "too many non-finite pixels: %d" % nan_px
         total_rays = agg[0] + agg[1]
         value = total_rays / dt_max / 1e6
+        nan_px = int((~torch.isfinite(full[..., :3]).all(-1)).sum().item())
         # CPU legs on a reduced frame of the same scene (bounded, see docstring)
         small_w, small_h = 320, 180          # oracle counters + CPU baseline frame
         arrays = render.scene_arrays()
-        per_ray, baseline = cpu_legs(args, arrays, host.default_camera(small_w, small_h), small_w, small_h, cam)
-        bytes_closest = 48.0 + 32.0 * per_ray["closest_nodes"] + 36.0 * per_ray["closest_tris"]
-        # per launch: average rays per closest-hit launch x bytes per ray / average launch duration
-        n_launch = max(prof.n_trace_closest, 1) * world
-        ms_sum = agg[2]
-        ach = (agg[0] * bytes_closest) / (ms_sum * 1e-3) / 1e9 if ms_sum > 0 else 0.0
-        roofline = dict(bound="hbm", achieved=round(ach, 2), peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=round(ach / HBM_PEAK_GBS, 5), traffic=None,
-                        kernel="k_trace<closest>",
-                        algorithmic_bytes_per_ray=round(bytes_closest, 1),
-                        nodes_per_ray=round(per_ray["closest_nodes"], 2), tris_per_ray=round(per_ray["closest_tris"], 2),
-                        rays_per_launch=round(agg[0] / n_launch, 1),
-                        avg_launch_ms=round(ms_sum / n_launch, 5),
-                        kernel_ms_per_spp=dict(trace_closest=round(agg[2] / world / spp_timed, 4),
-                                                trace_shadow=round(agg[3] / world / spp_timed, 4),
-                                                shade=round(agg[4] / world / spp_timed, 4),
-                                                raygen=round(agg[5] / world / spp_timed, 4)))
-        traffic_file = os.path.join(ROOT, "profiles", "trace_closest_hbm_traffic.json")
-        if world == 1 and os.path.exists(traffic_file):   # rocprofv3 --pmc passes of this workload at N = 1
-            try:
-                pmc = json.load(open(traffic_file))["config_%d" % args.config]
-                roofline["traffic"] = pmc["bytes_per_launch"]
-                # what actually binds the kernel (rocprofv3 --pmc, profiles/): HBM moves only
-                # `traffic` bytes per launch -- nodes and triangles are re-read from L1/L2 -- while
-                # the vector ALU issue slots and the L1's one-access-per-clock rate are saturated
-                roofline["hbm_rate_GBs"] = round(pmc["bytes_per_launch"] / (ms_sum / n_launch * 1e-3) / 1e9, 1)
-                roofline["pmc"] = {k: round(pmc[k], 4) for k in ("valu_issue_utilisation", "l1_accesses_per_clk_per_cu",
-                                                                 "l1_hit_rate", "l2_hit_rate")}
-            except Exception:
-                pass
+        per_ray, baseline, ref_img, ref_spp = cpu_legs(args, arrays, host.default_camera(small_w, small_h), small_w, small_h, cam)
+        parity = None
+        if ref_img is not None and world == 1:
+            # the SAME samples on the GPU (outside the timed region), compared with the reference kernels' image
+            assert lib.rt_reset(frame) == 0
+            render.render_samples(ref_spp)
+            got = render.radiance()[..., :3]
+            fin = np.isfinite(ref_img).all(-1) & np.isfinite(got).all(-1)
+            num = np.linalg.norm((got[fin].astype(np.float64) - ref_img[fin]).ravel())
+            den = np.linalg.norm(ref_img[fin].astype(np.float64).ravel())
+            parity = dict(against="oracle/_ref (the reference's own kernels), %d spp at %dx%d, %d bounces" %
+                          (ref_spp, args.width, args.height, args.bounces),
+                          bit_identical=bool(np.array_equal(got, ref_img, equal_nan=True)), rel_l2=float(num / den) if den > 0 else 0.0,
+                          tolerance=1e-4, nan_pixels_ref=int((~np.isfinite(ref_img).all(-1)).sum()),
+                          nan_pixels_hip=int((~np.isfinite(got).all(-1)).sum()),
+                          differing_pixels=int((~((got == ref_img) | (np.isnan(got) & np.isnan(ref_img))).all(-1)).sum()))
+            assert parity["rel_l2"] < 1e-4, "radiance differs from the reference kernels: %r" % parity
+        else:
+            # NaN pixels are legal in the reference arithmetic (inf * 0 in the mirror branch) but must be rare
+            assert nan_px <= 1e-4 * args.width * args.height, "too many non-finite pixels: %d" % nan_px
+        roofline = roofline_object(args, world, agg, prof, per_ray, spp_timed)
         name, cus, mem = render_ctx_info(capi, host, render)
+        if world == 1:
+            gather_info = dict(transport="none (single tile, device copy)", ms=round(float(tmax[2].item()) * 1e3, 3), nranks=1)
+        else:
+            gather_info = dict(transport="gloo over host memory (--debug-shared-gpu)" if group is None else
+                               "RCCL ncclGather over xGMI (rt_group_gather_radiance)", nranks=world,
+                               ms_max=round(float(tmax[2].item()) * 1e3, 3), bytes_per_rank=int(D.max_tile_rows(args.height, world, args.band_height)) * args.width * 16)
         line = dict(metric="Mrays/s (all bounces+shadow)", value=round(value, 2), unit="Mrays/s", n_gpus=world,
                     steps=args.steps, warmup=args.warmup, ms_per_step=round(dt_max * 1e3 / args.steps, 4),
                     ms_per_spp=round(dt_max * 1e3 / spp_timed, 4),
-                    higher_is_better=True, scaling="strong", vs_baseline=None, dtype="f32", data="synthetic",
-                    config=dict(workload=(cfg["name"] % dict(blob=args.blob_tris, ball=args.ball_tris)) +
+                    higher_is_better=True, scaling="strong", vs_baseline=None, dtype="f32", data="real" if args.scene else "synthetic",
+                    config=dict(workload=(("scene file %s (scale %g, flip_yz %d)" % (os.path.basename(args.scene), args.scale, args.flip_yz))
+                                          if args.scene else (cfg["name"] % dict(blob=args.blob_tris, ball=args.ball_tris))) +
                                          ", %dx%d, %d-bounce, %d spp per step, default camera, directional light + "
                                          "CGSkies env map" % (args.width, args.height, args.bounces, sps),
                                 triangles=int(n_tris), width=args.width, height=args.height,
                                 max_bounces=args.bounces, samples_per_step=sps, spp=spp_timed, samples_in_flight=in_flight,
-                                tiling="%d interleaved %d-row bands per GPU, 1 RCCL gather" % (world, args.band_height)
+                                path_state_GB=round(st1.path_state_bytes * world / 2 ** 30, 2),
+                                tiling="%d interleaved %d-row bands per GPU, 1 gather" % (world, args.band_height)
                                 if world > 1 else "single tile",
                                 rays_per_step=round(total_rays / args.steps, 1), non_finite_pixels=nan_px,
                                 setup_s=round(t_setup, 2), device=name),
-                    roofline=roofline, cpu_baseline=baseline)
+                    ranks=dict(render_ms_min=round(float(tmin[0].item()) * 1e3, 3), render_ms_max=round(float(tmax[1].item()) * 1e3, 3)),
+                    gather=gather_info, roofline=roofline, parity=parity, cpu_baseline=baseline)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if group is not None:
+        group.close()
+    return 0
 
 
 def render_ctx_info(capi, host, render):
@@ -336,4 +475,4 @@ def render_ctx_info(capi, host, render):
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -221,6 +221,32 @@ int rt_frame_get_profile(rt_frame* frame, rt_profile* out);
  * on the context stream and completed on return. */
 int rt_frame_copy_radiance(rt_frame* frame, void* device_dst);
 
+/* ---- device groups: one image tiled over several GPUs, ONE collective.
+ * The reference drives a single device (src/gpu_wrappers/cl_context.cpp:89: one queue on devices_[0]);
+ * this is the multi-GPU extension the integrators' pixel independence allows: every rank renders the
+ * interleaved row bands rt_frame_desc gives it (tile_rank / tile_count / band_height), nothing is exchanged
+ * while rendering, and rt_group_gather_radiance is the one RCCL gather (ncclGather over xGMI) of the
+ * accumulated radiance to the root, which also puts the bands back into image order.
+ *   - rt_group_create: all ranks in THIS process (one host thread may drive them; ncclCommInitAll);
+ *   - rt_group_unique_id + rt_group_join: one process per GPU (torch.distributed.run, mpirun): rank 0
+ *     creates the id, the launcher's own channel carries its RT_GROUP_ID_BYTES to the others, all join.
+ * RCCL is loaded on first use (dlopen librccl.so.1); groups are not needed for single-GPU work. */
+typedef struct rt_group rt_group;
+#define RT_GROUP_ID_BYTES 128
+int rt_group_create(int n, const int* device_ordinals, rt_group** out);
+int rt_group_unique_id(void* id_bytes, size_t capacity);
+int rt_group_join(int nranks, int rank, const void* id_bytes, int device_ordinal, rt_group** out);
+int rt_group_size(rt_group* group);                     /* ranks in the group */
+int rt_group_local_count(rt_group* group);              /* ranks living in this process */
+int rt_group_local_rank(rt_group* group, int i);        /* global rank of local member i */
+/* frames[i] = the frame of local member i (its tile_rank must be that member's rank, tile_count the group
+ * size).  On the process that owns `root`: host_rgba (may be NULL) receives height x width RGBA32F running
+ * sums in image order, *device_rgba (may be NULL) the device copy of the same (valid until the next gather).
+ * Stream-ordered after the frames' pending work; returns when the image is complete. */
+int rt_group_gather_radiance(rt_group* group, rt_frame* const* frames, int root, float* host_rgba, void** device_rgba);
+int rt_group_destroy(rt_group* group);
+const char* rt_group_last_error(rt_group* group);
+
 /* ---- debug / parity access: copy a ray queue back in the reference's layouts.
  * which: 0 = incoming queue of `bounce` (rays_buffer_[bounce&1]), 1 = shadow queue.
  * Returns the element count through *count; arrays may be NULL. */

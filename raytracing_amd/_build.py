@@ -16,7 +16,7 @@ INC = ["-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-I" + HOST]
 # -ffp-contract=off + correctly rounded divide/sqrt + no fast-math: the
 # arithmetic contract that makes GPU results bit-identical to the CPU oracle.
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
-             "-fhip-fp32-correctly-rounded-divide-sqrt", "-fPIC", "-shared"]
+             "-fhip-fp32-correctly-rounded-divide-sqrt", "-fPIC", "-shared", "-ldl"]
 CXX_FLAGS = ["-std=c++17", "-O2", "-ffp-contract=off", "-fPIC"]
 
 

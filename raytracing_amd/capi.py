@@ -58,6 +58,8 @@ EXPORTS = [
     "rt_frame_resolve", "rt_frame_read_radiance", "rt_frame_radiance_device_ptr", "rt_frame_sample_count",
     "rt_frame_get_stats", "rt_frame_get_profile", "rt_frame_copy_radiance", "rt_frame_debug_read_queue", "rt_frame_debug_read_hits", "rt_debug_eval",
     "rt_debug_wide_bvh",
+    "rt_group_create", "rt_group_unique_id", "rt_group_join", "rt_group_size", "rt_group_local_count", "rt_group_local_rank",
+    "rt_group_gather_radiance", "rt_group_destroy", "rt_group_last_error",
 ]
 
 OPT_MAX_BOUNCES, OPT_WHITE_FURNACE, OPT_SAMPLER, OPT_AOV, OPT_DENOISER, OPT_DROP_LAST, OPT_PROFILE, OPT_TRACE_VARIANT, OPT_TRACE_WAVES, OPT_SAMPLES_IN_FLIGHT, OPT_SELECT_FORM_BOX, OPT_PACKET_BOUNCES, OPT_TRACE_TUNE, OPT_DEBUG_ALLOC_LIMIT = range(14)
@@ -101,6 +103,11 @@ def load():
         "rt_frame_debug_read_hits": (i32, [vp, vp, u32]),
         "rt_debug_eval": (i32, [vp, i32, vp, vp, vp, u32]),
         "rt_debug_wide_bvh": (i32, [vp, u32, vp, u32, C.POINTER(u32), C.POINTER(u32)]),
+        "rt_group_create": (i32, [i32, C.POINTER(i32), C.POINTER(vp)]), "rt_group_unique_id": (i32, [vp, sz]),
+        "rt_group_join": (i32, [i32, i32, vp, i32, C.POINTER(vp)]), "rt_group_size": (i32, [vp]),
+        "rt_group_local_count": (i32, [vp]), "rt_group_local_rank": (i32, [vp, i32]),
+        "rt_group_gather_radiance": (i32, [vp, C.POINTER(vp), i32, vp, C.POINTER(vp)]), "rt_group_destroy": (i32, [vp]),
+        "rt_group_last_error": (C.c_char_p, [vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -287,6 +294,77 @@ class Frame:
     def close(self):
         if self.handle:
             self.lib.rt_frame_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Group:
+    """rt_group: ranks of one tiled image and their single RCCL gather (include/rt_hip.h, "device groups").
+
+      Group.create([0, 1, ...])            all ranks in this process (one per device)
+      Group.join(nranks, rank, id, device) one process per GPU; id = Group.unique_id() made by rank 0 and
+                                           carried to the others by the launcher's own channel"""
+
+    ID_BYTES = 128
+
+    def __init__(self, handle):
+        self.lib = load()
+        self.handle = handle
+
+    @classmethod
+    def create(cls, devices):
+        lib = load()
+        arr = (C.c_int * len(devices))(*devices)
+        h = C.c_void_p()
+        if lib.rt_group_create(len(devices), arr, C.byref(h)) != 0:
+            raise RtError(lib.rt_group_last_error(None).decode())
+        return cls(h)
+
+    @staticmethod
+    def unique_id():
+        lib = load()
+        buf = C.create_string_buffer(Group.ID_BYTES)
+        if lib.rt_group_unique_id(buf, Group.ID_BYTES) != 0:
+            raise RtError(lib.rt_group_last_error(None).decode())
+        return buf.raw
+
+    @classmethod
+    def join(cls, nranks, rank, id_bytes, device):
+        lib = load()
+        assert len(id_bytes) == Group.ID_BYTES
+        h = C.c_void_p()
+        if lib.rt_group_join(nranks, rank, id_bytes, device, C.byref(h)) != 0:
+            raise RtError(lib.rt_group_last_error(None).decode())
+        return cls(h)
+
+    def size(self):
+        return self.lib.rt_group_size(self.handle)
+
+    def local_ranks(self):
+        return [self.lib.rt_group_local_rank(self.handle, i) for i in range(self.lib.rt_group_local_count(self.handle))]
+
+    def gather_radiance(self, frame_handles, root, height, width, want_host=True):
+        """frame_handles: rt_frame* of the local members, in member order.  Returns the image (numpy,
+        height x width x 4) on the process that owns `root` when want_host, else None."""
+        n = len(frame_handles)
+        arr = (C.c_void_p * n)(*[h if isinstance(h, int) else h.value for h in frame_handles])
+        owns_root = root in self.local_ranks()
+        out = np.zeros((height, width, 4), np.float32) if (owns_root and want_host) else None
+        dev = C.c_void_p()
+        rc = self.lib.rt_group_gather_radiance(self.handle, arr, root, out.ctypes.data if out is not None else None, C.byref(dev))
+        if rc != 0:
+            raise RtError(self.lib.rt_group_last_error(self.handle).decode())
+        self.device_image = dev.value
+        return out
+
+    def close(self):
+        if self.handle:
+            self.lib.rt_group_destroy(self.handle)
             self.handle = None
 
     def __del__(self):

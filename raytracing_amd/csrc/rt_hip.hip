@@ -1446,3 +1446,5 @@ int rt_debug_eval(rt_ctx* ctx, int fn, const float* a, const float* b, float* ou
 }
 
 } // extern "C"
+
+#include "group_impl.h"

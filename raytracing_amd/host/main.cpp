@@ -14,7 +14,7 @@ static void WritePFM(const char* path, const std::vector<float>& rgba, unsigned 
     FILE* f = fopen(path, "wb");
     if (!f) return;
     fprintf(f, "PF\n%u %u\n-1.0\n", w, h);
-    for (unsigned y = 0; y < h; ++y)
+    for (unsigned y = h; y-- > 0;)            // PFM stores the bottom row first
         for (unsigned x = 0; x < w; ++x) fwrite(&rgba[((size_t)y * w + x) * 4], sizeof(float), 3, f);
     fclose(f);
 }
@@ -23,10 +23,10 @@ int main(int argc, char** argv)
 {
     try
     {
-        unsigned width = 1280, height = 720, spp = 16, bounces = 3;
+        unsigned width = 1280, height = 720, spp = 16, bounces = 3, gpus = 1;
         std::string scene_path = "assets/ShaderBalls.obj", out, save_cache;
         float scale = 1.0f, aperture = 0.0f, focus = 10.0f;
-        bool flip_yz = false, furnace = false;
+        bool flip_yz = false, furnace = false, tiled_path = false;
         for (int i = 1; i < argc; ++i)
         {
             auto next = [&]() -> const char* { if (i + 1 >= argc) { std::cerr << "missing value for " << argv[i] << "\n"; exit(2); } return argv[++i]; };
@@ -42,16 +42,50 @@ int main(int argc, char** argv)
             else if (!strcmp(argv[i], "--focus")) focus = (float)atof(next());
             else if (!strcmp(argv[i], "--out")) out = next();
             else if (!strcmp(argv[i], "--save-cache")) save_cache = next();
+            else if (!strcmp(argv[i], "--gpus")) gpus = (unsigned)atoi(next());
+            else if (!strcmp(argv[i], "--tiled")) tiled_path = atoi(next()) != 0;      // take the TiledRender path even with one GPU
             else if (!strcmp(argv[i], "--help"))
             {
                 std::cout << "rt_render -w W -h H --scene file.obj [--scale s] [--flip_yz 0|1] [--spp n] [--bounces b]"
-                             " [--furnace 0|1] [--aperture a] [--focus d] [--out image.pfm] [--save-cache scene.rtscene]\n"
+                             " [--furnace 0|1] [--aperture a] [--focus d] [--out image.pfm] [--save-cache scene.rtscene] [--gpus n]\n"
+                             "  --gpus n tiles the image over devices 0..n-1 (interleaved 8-row bands, one RCCL gather)\n"
                              "  --scene also accepts a file written by --save-cache (parsed scene + BVH)\n";
                 return 0;
             }
         }
         rt::Scene scene(scene_path.c_str(), scale, flip_yz);
         scene.AddDirectionalLight({-0.6f, -1.5f, 3.5f}, {15.0f, 10.0f, 5.0f});   // main.cpp:58
+        if (gpus > 1 || tiled_path)
+        {
+            std::vector<int> devices;
+            for (unsigned d = 0; d < gpus; ++d) devices.push_back((int)d);
+            rt::TiledRender tiled(width, height, scene, devices);
+            for (unsigned d = 0; d < gpus; ++d) std::cout << "device " << d << ": " << tiled.GetContext(d).DeviceName() << std::endl;
+            if (!save_cache.empty()) scene.SaveCache(save_cache.c_str(), tiled.GetAccelerationStructure().GetNodes());
+            rt::Camera cam = rt::DefaultCamera(width, height);
+            cam.aperture = aperture;
+            cam.focus_distance = focus;
+            tiled.SetCamera(cam);
+            tiled.SetMaxBounces(bounces);
+            tiled.EnableWhiteFurnace(furnace);
+            auto t0 = std::chrono::steady_clock::now();
+            tiled.RenderSamples(spp);
+            double t_render = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            std::vector<float> sum = tiled.GatherRadiance(0);
+            double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            rt_stats st = tiled.GetStats();
+            double rays = (double)st.closest_rays + (double)st.shadow_rays;
+            std::cout << spp << " spp on " << gpus << " GPUs in " << dt << " s (render " << t_render << " s, gather "
+                      << (dt - t_render) * 1e3 << " ms), " << rays / dt / 1e6 << " Mrays/s; tile seconds:";
+            for (double t : tiled.GetLastTileSeconds()) std::cout << " " << t;
+            std::cout << std::endl;
+            if (!out.empty())
+            {
+                for (float& v : sum) v /= (float)spp;
+                WritePFM(out.c_str(), sum, width, height);
+            }
+            return 0;
+        }
         rt::Render render(width, height, scene);
         std::cout << "device: " << render.GetContext().DeviceName() << std::endl;
         if (!save_cache.empty()) scene.SaveCache(save_cache.c_str(), render.GetAccelerationStructure().GetNodes());

@@ -1,4 +1,6 @@
 #include "render.hpp"
+#include <chrono>
+#include <thread>
 
 namespace rt
 {
@@ -68,5 +70,103 @@ void Render::RenderSamples(std::uint32_t n)
         camera_changed_ = false;
     }
     integrator_->IntegrateSamples(n);
+}
+
+TiledRender::TiledRender(std::uint32_t width, std::uint32_t height, Scene& scene, std::vector<int> const& devices,
+    std::uint32_t band_height)
+    : scene_(scene), width_(width), height_(height)
+{
+    if (devices.empty()) throw HIPException("TiledRender: no devices");
+    auto bvh = std::make_unique<Bvh>();
+    if (scene_.HasPrebuiltBvh()) bvh->AdoptNodes(scene_.GetPrebuiltNodes());
+    else bvh->BuildCPU(scene_.GetTriangles());
+    acc_structure_ = std::move(bvh);
+    scene_.Finalize();
+    for (std::size_t i = 0; i < devices.size(); ++i)
+    {
+        contexts_.push_back(std::make_unique<HIPContext>(devices[i]));
+        TileDesc tile;
+        tile.rank = (std::uint32_t)i;
+        tile.count = (std::uint32_t)devices.size();
+        tile.band_height = band_height;
+        integrators_.push_back(std::make_unique<HIPPathTraceIntegrator>(width_, height_, *acc_structure_, *contexts_[i], tile));
+        integrators_[i]->UploadGPUData(scene_, *acc_structure_);
+        integrators_[i]->SetResolveEveryFrame(false);
+    }
+    if (rt_group_create((int)devices.size(), devices.data(), &group_) != RT_OK)
+        throw HIPException(std::string("Failed to create the device group: ") + rt_group_last_error(nullptr));
+    tile_seconds_.assign(devices.size(), 0.0);
+    camera_ = DefaultCamera(width_, height_);
+}
+
+TiledRender::~TiledRender()
+{
+    rt_group_destroy(group_);
+    integrators_.clear();            // frames before their contexts
+    contexts_.clear();
+}
+
+void TiledRender::SetCamera(Camera const& camera)
+{
+    camera_ = camera;
+    camera_changed_ = true;
+}
+
+void TiledRender::SetMaxBounces(std::uint32_t max_bounces)
+{
+    for (auto& i : integrators_) i->SetMaxBounces(max_bounces);
+}
+
+void TiledRender::EnableWhiteFurnace(bool enable)
+{
+    for (auto& i : integrators_) i->EnableWhiteFurnace(enable);
+}
+
+void TiledRender::RenderSamples(std::uint32_t n)
+{
+    std::vector<std::thread> workers;
+    std::vector<std::string> errors(integrators_.size());
+    for (std::size_t i = 0; i < integrators_.size(); ++i)
+        workers.emplace_back([&, i]()
+        {
+            try
+            {
+                auto t0 = std::chrono::steady_clock::now();
+                integrators_[i]->SetCameraData(camera_);
+                if (camera_changed_) integrators_[i]->RequestReset();
+                integrators_[i]->IntegrateSamples(n);
+                contexts_[i]->Finish();
+                tile_seconds_[i] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            }
+            catch (std::exception& ex) { errors[i] = ex.what(); }
+        });
+    for (auto& w : workers) w.join();
+    camera_changed_ = false;
+    for (auto& e : errors) if (!e.empty()) throw HIPException(e);
+}
+
+std::vector<float> TiledRender::GatherRadiance(int root)
+{
+    std::vector<rt_frame*> frames;
+    for (auto& i : integrators_) frames.push_back(i->GetFrame());
+    std::vector<float> image((std::size_t)width_ * height_ * 4);
+    if (rt_group_gather_radiance(group_, frames.data(), root, image.data(), nullptr) != RT_OK)
+        throw HIPException(std::string("Radiance gather failed: ") + rt_group_last_error(group_));
+    return image;
+}
+
+rt_stats TiledRender::GetStats() const
+{
+    rt_stats sum = {};
+    for (auto& i : integrators_)
+    {
+        rt_stats st = i->GetStats();
+        sum.closest_rays += st.closest_rays;
+        sum.shadow_rays += st.shadow_rays;
+        sum.samples = st.samples;
+        sum.samples_in_flight = st.samples_in_flight;
+        sum.path_state_bytes += st.path_state_bytes;
+    }
+    return sum;
 }
 } // namespace rt

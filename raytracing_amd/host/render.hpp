@@ -3,6 +3,7 @@
 // window, GL framebuffer and ImGui).  RenderFrame() = one sample per pixel.
 #pragma once
 #include <memory>
+#include <vector>
 #include "bvh.hpp"
 #include "hip_pt_integrator.hpp"
 #include "scene.hpp"
@@ -33,6 +34,39 @@ private:
     std::shared_ptr<HIPContext> context_;
     std::unique_ptr<AccelerationStructure> acc_structure_;
     std::unique_ptr<HIPPathTraceIntegrator> integrator_;
+    Camera camera_;
+    bool camera_changed_ = true;
+};
+
+// One image over several GPUs of this process (no reference counterpart: the reference drives
+// devices_[0] only, src/gpu_wrappers/cl_context.cpp:89).  The scene and its BVH are built once and
+// uploaded to every device; device i renders the interleaved row bands of tile i
+// (rt_frame_desc) on its own host thread; GatherRadiance() is the one RCCL gather (rt_group_*).
+class TiledRender
+{
+public:
+    TiledRender(std::uint32_t width, std::uint32_t height, Scene& scene, std::vector<int> const& devices,
+        std::uint32_t band_height = 8);
+    ~TiledRender();
+    void SetCamera(Camera const& camera);
+    void SetMaxBounces(std::uint32_t max_bounces);
+    void EnableWhiteFurnace(bool enable);
+    void RenderSamples(std::uint32_t n);                  // every tile, concurrently; returns when all are enqueued and finished
+    std::vector<float> GatherRadiance(int root = 0);      // height x width x RGBA running sums, image order
+    rt_stats GetStats() const;                            // ray counters summed over the tiles
+    std::size_t GetTileCount() const { return integrators_.size(); }
+    std::vector<double> const& GetLastTileSeconds() const { return tile_seconds_; }
+    HIPContext& GetContext(std::size_t i) { return *contexts_[i]; }
+    AccelerationStructure const& GetAccelerationStructure() const { return *acc_structure_; }
+
+private:
+    Scene& scene_;
+    std::uint32_t width_, height_;
+    std::unique_ptr<AccelerationStructure> acc_structure_;
+    std::vector<std::unique_ptr<HIPContext>> contexts_;
+    std::vector<std::unique_ptr<HIPPathTraceIntegrator>> integrators_;
+    std::vector<double> tile_seconds_;
+    rt_group* group_ = nullptr;
     Camera camera_;
     bool camera_changed_ = true;
 };

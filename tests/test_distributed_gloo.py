@@ -62,3 +62,43 @@ def test_tile_rows_partition_every_row_exactly_once():
     # balance at the benchmark size: 720 rows, 8 ranks, bands of 8 -> 88..96 rows each
     sizes = [len(D.tile_rows(720, r, 8, 8)) for r in range(8)]
     assert max(sizes) - min(sizes) <= 8
+
+
+def _bench(*args, timeout=300):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + list(args), capture_output=True, text=True, timeout=timeout, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout            # rank 0 prints ONE JSON line
+    return json.loads(lines[0])
+
+
+def test_bench_launches_itself_for_n_gpus_and_reports_one_line():
+    """`python bench.py --gpus 2` as the driver runs `--gpus 1`: no launcher, the script re-executes itself under
+    torch.distributed.run, both ranks rendezvous, the tiles are gathered on rank 0 and ONE JSON line comes out.
+    (--plumbing-only: everything except the rendering, which needs a GPU.)"""
+    line = _bench("--gpus", "2", "--plumbing-only", "--width", "64", "--height", "50", "--steps", "3", "--warmup", "0")
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["warmup"] == 0
+    assert line["gather"]["nranks"] == 2 and line["gather"]["image_ok"] is True
+    assert line["plumbing_only"] is True and line["value"] is None
+
+
+def test_bench_under_an_external_launcher():
+    """The driver's own launch line: torch.distributed.run sets RANK / WORLD_SIZE and bench.py must not launch again."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--plumbing-only", "--width", "48",
+           "--height", "33", "--band-height", "4"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["gather"]["image_ok"] is True

@@ -584,7 +584,7 @@ def test_rt_render_cli(tmp_path):
     assert "Mrays/s" in r.stdout and "gfx950" in r.stdout
     raw = open(out, "rb").read()
     assert raw.startswith(b"PF\n64 48\n-1.0\n")
-    img = np.frombuffer(raw[len(b"PF\n64 48\n-1.0\n"):], np.float32).reshape(48, 64, 3)
+    img = np.frombuffer(raw[len(b"PF\n64 48\n-1.0\n"):], np.float32).reshape(48, 64, 3)[::-1]   # PFM: bottom row first
     scene = host.Scene(os.path.join(ROOT, "assets", "CornellBox.obj"))
     scene.add_directional_light((-0.6, -1.5, 3.5), (15.0, 10.0, 5.0))
     scene.build_bvh(); scene.finalize()
@@ -602,6 +602,45 @@ def test_rt_render_cli(tmp_path):
                          "--out", str(out2)], cwd=ROOT, capture_output=True, text=True, timeout=300)
     assert r2.returncode == 0, r2.stderr
     assert open(out2, "rb").read() == raw
+    # the multi-GPU path of the C++ host (TiledRender: device group + the one RCCL gather), on the GPUs there are
+    out3 = tmp_path / "img3.pfm"
+    r3 = subprocess.run([exe, "-w", "64", "-h", "48", "--scene", "assets/CornellBox.obj", "--spp", "4", "--bounces", "4",
+                         "--gpus", "1", "--tiled", "1", "--out", str(out3)], cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert r3.returncode == 0, r3.stderr
+    assert "on 1 GPUs" in r3.stdout and "gather" in r3.stdout
+    assert open(out3, "rb").read() == raw
+
+
+def test_device_group_gather_through_the_c_abi(ctx, golden_scenes):
+    """rt_group_*: the one RCCL gather below the C-ABI.  This box has one GPU, so the group has one rank
+    (RCCL refuses two ranks per device): communicator set-up, ncclGather, band re-assembly and read-back all run;
+    both ways of forming a group (all ranks in this process / one process per rank with a unique id)."""
+    w, h, b, spp = 72, 50, 4, 3           # 50 rows: the last band is short
+    sc = golden_scenes["coverage"]
+    cam = T.default_camera(w, h)
+    orc = _oracle.Oracle(w, h, sc)
+    orc.set_camera(cam); orc.set_max_bounces(b); orc.integrate(spp)
+    ctx.upload_scene(sc)
+    fr = capi.Frame(ctx, w, h)
+    fr.set_camera(cam); fr.set_max_bounces(b); fr.integrate(spp)
+    for make in (lambda: capi.Group.create([0]), lambda: capi.Group.join(1, 0, capi.Group.unique_id(), 0)):
+        g = make()
+        assert g.size() == 1 and g.local_ranks() == [0]
+        img = g.gather_radiance([fr.handle], 0, h, w)
+        assert np.array_equal(img, fr.radiance(), equal_nan=True)
+        assert np.array_equal(img[..., :3], orc.radiance()[..., :3], equal_nan=True)
+        assert g.device_image
+        # a frame that is not this rank's tile is refused
+        other = capi.Frame(ctx, w, h, tile_rank=0, tile_count=2)
+        with pytest.raises(capi.RtError, match="not the tile of this rank"):
+            g.gather_radiance([other.handle], 0, h, w)
+        with pytest.raises(capi.RtError, match="bad root"):
+            g.gather_radiance([fr.handle], 1, h, w)
+        g.close()
+    with pytest.raises(capi.RtError, match="one rank per device"):
+        capi.Group.create([0, 0])
+    with pytest.raises(capi.RtError, match="bad device ordinal"):
+        capi.Group.create([0, 7])
 
 
 def test_graft_entry_smoke():

@@ -17,7 +17,7 @@ for f in sorted(glob.glob(d + "/**/*counter_collection.csv", recursive=True)):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        if "k_trace" not in k and "k_shade" not in k:
+        if "k_trace" not in k and "k_shade" not in k and "k_flush" not in k and "k_raygen" not in k:
             continue
         short = k.split("(")[0].replace("void ", "")
         acc[short][r["Counter_Name"]].append(float(r["Counter_Value"]))
