@@ -252,7 +252,7 @@ def roofline_object(args, world, agg, prof, per_ray, spp_timed):
     out.update(bound=bound, achieved=round(units[bound], 4), peak=1.0,
                unit="busy fraction of the unit's calibrated ceiling (1.0 = saturated)", frac=round(units[bound], 4),
                traffic=k.get("hbm_bytes_per_launch"),
-               units=units, counters=k.get("per_ray"), source="profiles/r02_trace_counters.json (rocprofv3 --pmc passes of this "
+               units=units, counters_per_launch=k.get("per_launch"), source="profiles/r02_trace_counters.json (rocprofv3 --pmc passes of this "
                "workload at N = 1, round 2; ceilings: profiles/r02_issue_microbench.log)",
                hbm_counter=dict(GBs=k.get("hbm_GBs"), peak_GBs=HBM_PEAK_GBS, frac=k.get("hbm_frac")))
     return out
