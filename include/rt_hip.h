@@ -144,6 +144,11 @@ enum rt_option
                                        Results are identical for every value. */
     , RT_OPT_DEBUG_ALLOC_LIMIT = 13 /* test hook: per-path buffer allocations for more than this many samples in flight
                                        fail as if the device were out of memory (0 = off) */
+    , RT_OPT_PATH_STATE_LIMIT_MB = 14 /* upper bound (MiB) for the per-path buffers (ray queues + radiance log, 488 B per
+                                       path at 8 bounces): rt_integrate then runs every batch of samples chunk by chunk
+                                       over the tile's pixels instead of over the whole tile at once.  0 (default) = only
+                                       the built-in rule (at most half of the HBM).  Results are bit-identical for every
+                                       value: path ids, the log and the replay are per pixel. */
     , RT_OPT_TRACE_TUNE = 12       /* k_trace2 (variants 8, 9) loop thresholds: value & 255 = lanes that must hold an
                                        interior node for a wave to stay in the node loop, value >> 8 & 255 = lanes that
                                        must wait at a triangle for another pass of the triangle loop.  0 = defaults.
@@ -203,6 +208,11 @@ typedef struct rt_stats
     uint32_t samples_in_flight;        /* samples the per-path buffers hold at the moment */
     uint32_t samples_in_flight_limit;  /* != 0: a larger batch did not fit into device memory and was halved to this */
     uint64_t path_state_bytes;         /* size of the per-path buffers (ray queues + radiance log) */
+    uint32_t stack_spills;             /* traversal-stack pushes beyond the LDS entries (to the HBM spill area) since the last reset */
+    uint32_t slow_rays;                /* rays with a non-finite 1/dir component that k_trace_w4 handed to the BVH2 kernel */
+    uint32_t chunk_pixels;             /* pixels of the tile that travel through the wavefront loop together (the whole
+                                          tile unless RT_OPT_PATH_STATE_LIMIT_MB splits it) */
+    uint32_t reserved_;
 } rt_stats;
 int rt_frame_get_stats(rt_frame* frame, rt_stats* out);
 

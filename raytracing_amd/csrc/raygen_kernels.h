@@ -6,12 +6,14 @@
 // ---------------------------------------------------------------------------
 // sample begin + ray generation (raygeneration.cl:65-139)
 // ---------------------------------------------------------------------------
+// The tile may be rendered in CHUNKS of pixels (RT_OPT_PATH_STATE_LIMIT_MB): this launch covers local pixels
+// chunk_base .. chunk_base + chunk_count - 1; path ids are chunk-relative (slot * chunk_stride + pixel in chunk).
 __global__ __launch_bounds__(256) void k_raygen(DTile tile, rt_camera cam, uint32_t sample_base, uint32_t n_slots,
     float tan_half_fov, uint32_t prev_bounces, float4* __restrict__ o4, float4* __restrict__ d4,
-    float4* __restrict__ iv4, float4* __restrict__ thr, DCounters* __restrict__ counters)
+    float4* __restrict__ iv4, float4* __restrict__ thr, DCounters* __restrict__ counters, uint32_t chunk_base,
+    uint32_t chunk_count, uint32_t chunk_stride, uint32_t prev_accumulates)
 {
-    uint32_t n_local = tile.local_rows * tile.width;
-    uint32_t n_total = n_local * n_slots;                                // n_slots samples in flight
+    uint32_t n_total = chunk_count * n_slots;                            // n_slots samples in flight
     uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i == 0)
     {
@@ -22,8 +24,9 @@ __global__ __launch_bounds__(256) void k_raygen(DTile tile, rt_camera cam, uint3
         {
             c += counters->queue[b];
             s += counters->shadow[b];
-            counters->last_queue[b] = counters->queue[b];
-            counters->last_shadow[b] = counters->shadow[b];
+            // last_*: per-bounce counts of the most recent BATCH: the chunks of one batch add up
+            counters->last_queue[b] = (prev_accumulates ? counters->last_queue[b] : 0u) + counters->queue[b];
+            counters->last_shadow[b] = (prev_accumulates ? counters->last_shadow[b] : 0u) + counters->shadow[b];
         }
         counters->total_closest += c;
         counters->total_shadow += s;
@@ -39,8 +42,9 @@ __global__ __launch_bounds__(256) void k_raygen(DTile tile, rt_camera cam, uint3
     // a directional light are then almost parallel AND co-located).  Fewer distinct BVH
     // records per load instruction is what the L1 data path rewards.  The path id keeps the
     // slot-major form (slot * n_local + pixel) the radiance log is laid out by.
-    uint32_t lp = i / n_slots;                                           // local pixel of this tile
-    uint32_t slot = i - lp * n_slots;
+    uint32_t cp = i / n_slots;                                           // pixel of this chunk
+    uint32_t slot = i - cp * n_slots;
+    uint32_t lp = chunk_base + cp;                                       // local pixel of this tile
     uint32_t sample_idx = sample_base + slot;
     uint32_t ly = lp / tile.width;
     uint32_t pixel_x = lp - ly * tile.width;
@@ -82,14 +86,14 @@ __global__ __launch_bounds__(256) void k_raygen(DTile tile, rt_camera cam, uint3
     f3 d = normalize3(point_aimed - new_pos);
 
     o4[i] = make_float4(new_pos.x, new_pos.y, new_pos.z, RT_MAX_RENDER_DIST);
-    d4[i] = make_float4(d.x, d.y, d.z, __uint_as_float(slot * n_local + lp));   // path id
+    d4[i] = make_float4(d.x, d.y, d.z, __uint_as_float(slot * chunk_stride + cp));   // path id
     iv4[i] = ray_inverse(d);
     thr[i] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
 }
 
 
 // end-of-run fold of the per-bounce counters (same as the prologue of k_raygen)
-__global__ void k_fold_counters(DCounters* counters, uint32_t bounces)
+__global__ void k_fold_counters(DCounters* counters, uint32_t bounces, uint32_t prev_accumulates)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     unsigned long long c = 0, s = 0;
@@ -97,8 +101,8 @@ __global__ void k_fold_counters(DCounters* counters, uint32_t bounces)
     {
         c += counters->queue[b];
         s += counters->shadow[b];
-        counters->last_queue[b] = counters->queue[b];
-        counters->last_shadow[b] = counters->shadow[b];
+        counters->last_queue[b] = (prev_accumulates ? counters->last_queue[b] : 0u) + counters->queue[b];
+        counters->last_shadow[b] = (prev_accumulates ? counters->last_shadow[b] : 0u) + counters->shadow[b];
         counters->queue[b] = 0;
         counters->shadow[b] = 0;
     }

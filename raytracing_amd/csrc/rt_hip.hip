@@ -66,7 +66,14 @@ struct rt_frame
     uint32_t slots_opt = 0;        // RT_OPT_SAMPLES_IN_FLIGHT as set by the caller (0 = auto)
     uint32_t slots_limit = 0;      // != 0: a larger batch did not fit into device memory
     uint32_t cur_slots = 0;        // slots used by the batch in flight (0 = nothing pending)
-    uint32_t log_stride = 0;       // elements per log entry row = slots * n_local
+    uint32_t log_stride = 0;       // elements per log entry row = slots * chunk_pixels
+    // The tile can be rendered in chunks of pixels so that the per-path buffers respect RT_OPT_PATH_STATE_LIMIT_MB:
+    // every batch of samples then runs the whole wavefront loop chunk after chunk (path ids are chunk-relative).
+    uint32_t chunk_pixels = 0;     // pixels per chunk as allocated (n_local when the tile is not chunked)
+    uint32_t chunk_base = 0;       // first local pixel of the chunk in flight
+    uint32_t chunk_count = 0;      // pixels of the chunk in flight
+    uint32_t state_limit_mb = 0;   // RT_OPT_PATH_STATE_LIMIT_MB (0 = only the built-in 144 GB rule)
+    uint32_t fold_accumulates = 0; // the sequence in flight is a 2nd+ chunk of its batch: its counters ADD to last_*
     uint32_t log_entries = 0;      // rows allocated (>= 2 * (max_bounces + 1))
     bool shadow_pending = false;   // rt_shade issued, rt_intersect_shadow not yet
     DCounters* counters;
@@ -653,6 +660,19 @@ uint32_t slot_cap(const rt_frame* f)
     return f->slots_limit && f->slots_limit < cap ? f->slots_limit : cap;    // what the device could actually hold
 }
 
+// pixels per chunk for `slots` samples in flight under RT_OPT_PATH_STATE_LIMIT_MB (multiples of 4096 pixels)
+uint32_t chunk_for(const rt_frame* f, uint32_t slots)
+{
+    const uint64_t n = f->n_local ? f->n_local : 1;
+    if (!f->state_limit_mb) return (uint32_t)n;
+    const uint64_t per_pixel = (uint64_t)(slots ? slots : 1u) * bytes_per_path(f->max_bounces);
+    const uint64_t limit = (uint64_t)f->state_limit_mb << 20;
+    if (n * per_pixel <= limit) return (uint32_t)n;
+    uint64_t c = (limit / per_pixel) & ~4095ull;
+    if (c < 4096) c = 4096;
+    return (uint32_t)(c < n ? c : n);
+}
+
 int alloc_path_buffers(rt_frame* f, uint32_t slots)
 {
     rt_ctx* ctx = f->ctx;
@@ -661,7 +681,10 @@ int alloc_path_buffers(rt_frame* f, uint32_t slots)
     if (f->debug_alloc_limit && slots > f->debug_alloc_limit)
         return fail(ctx, "out of device memory for the per-path buffers (RT_OPT_DEBUG_ALLOC_LIMIT)");
     f->slots = slots ? slots : 1u;
-    uint64_t paths = (uint64_t)(f->n_local ? f->n_local : 1) * f->slots;
+    f->chunk_pixels = chunk_for(f, f->slots);
+    f->chunk_base = 0;
+    f->chunk_count = 0;
+    uint64_t paths = (uint64_t)f->chunk_pixels * f->slots;
     if (paths > 0xFFFFFFF0ull) return fail(ctx, "samples in flight x tile pixels exceeds the 32-bit path-id range");
     f->log_stride = (uint32_t)paths;
     f->log_entries = 2u * (f->max_bounces + 1u);
@@ -695,7 +718,7 @@ int ensure_slots(rt_frame* f, uint32_t want)
 {
     uint32_t cap = slot_cap(f);
     if (want > cap) want = cap;
-    if (want <= f->slots && 2u * (f->max_bounces + 1u) <= f->log_entries)
+    if (want <= f->slots && 2u * (f->max_bounces + 1u) <= f->log_entries && f->chunk_pixels == chunk_for(f, f->slots))
         return RT_OK;
     if (flush_log(f) != RT_OK) return RT_ERROR;
     HIPCHK(f->ctx, hipStreamSynchronize(f->ctx->stream));
@@ -716,12 +739,12 @@ int ensure_slots(rt_frame* f, uint32_t want)
 int flush_log(rt_frame* f)
 {
     rt_ctx* ctx = f->ctx;
-    if (f->cur_slots == 0 || f->n_local == 0) { f->cur_slots = 0; return RT_OK; }
+    if (f->cur_slots == 0 || f->n_local == 0 || f->chunk_count == 0) { f->cur_slots = 0; return RT_OK; }
     if (f->shadow_pending)
         return fail(ctx, "radiance requested between rt_shade and rt_intersect_shadow (direct samples still tentative)");
-    uint32_t blocks = (f->n_local + 255u) / 256u;
-    hipLaunchKernelGGL(k_flush, dim3(blocks), dim3(256), 0, ctx->stream, f->radiance, (const float4*)f->rlog, f->cnt,
-        f->n_local, f->cur_slots, f->log_stride);
+    uint32_t blocks = (f->chunk_count + 255u) / 256u;
+    hipLaunchKernelGGL(k_flush, dim3(blocks), dim3(256), 0, ctx->stream, f->radiance + f->chunk_base, (const float4*)f->rlog, f->cnt,
+        f->chunk_count, f->cur_slots, f->log_stride, f->chunk_pixels);
     if (hipGetLastError() != hipSuccess) return fail(ctx, "k_flush launch failed");
     f->cur_slots = 0;
     return RT_OK;
@@ -881,6 +904,21 @@ int rt_set_option(rt_frame* f, int option, uint32_t value)
     case RT_OPT_TRACE_PACKET_BOUNCES: f->packet_bounces = value; return RT_OK;
     case RT_OPT_TRACE_SELECT_FORM_BOX: f->select_form_box = value ? RT_SIGN_SLOW : 0u; return RT_OK;
     case RT_OPT_TRACE_TUNE: f->trace_tune = value; return RT_OK;
+    case RT_OPT_PATH_STATE_LIMIT_MB:
+        if (value != f->state_limit_mb)
+        {
+            if (flush_log(f) != RT_OK) return RT_ERROR;
+            HIPCHK(f->ctx, hipStreamSynchronize(f->ctx->stream));
+            uint32_t old = f->state_limit_mb;
+            f->state_limit_mb = value;
+            if (alloc_path_buffers(f, f->slots) != RT_OK)
+            {
+                f->state_limit_mb = old;
+                (void)alloc_path_buffers(f, f->slots);
+                return RT_ERROR;
+            }
+        }
+        return RT_OK;
     case RT_OPT_DEBUG_ALLOC_LIMIT: f->debug_alloc_limit = value; return RT_OK;
     case RT_OPT_TRACE_VARIANT:
         if (value > 11) return fail(f->ctx, "rt_set_option: unknown trace kernel variant");
@@ -964,7 +1002,8 @@ void launch_trace2(rt_frame* f, const float4* o4, const float4* d4, const float4
     if ((tune & 0xFFu) == 0u) tune |= 1u;
     hipLaunchKernelGGL((k_trace2<SHADOW, STACK>), dim3(blocks), dim3(64), 0, ctx->stream, ctx->scene.d, o4, d4, iv4, count,
         &f->counters->head[SHADOW ? 1 : 0][0], SHADOW ? (float4*)nullptr : f->hits,
-        SHADOW ? f->rlog : (float4*)nullptr, f->log_stride, f->select_form_box, f->spill, tune, (const uint32_t*)nullptr);
+        SHADOW ? f->rlog : (float4*)nullptr, f->log_stride, f->select_form_box, f->spill, tune, (const uint32_t*)nullptr,
+        &f->counters->stack_spills);
 }
 
 // k_trace_w4 over the 4-wide quantized tree, then k_trace2 over the (normally empty) list of rays it left out
@@ -982,11 +1021,12 @@ void launch_trace_w4(rt_frame* f, const float4* o4, const float4* d4, const floa
     const int s = SHADOW ? 1 : 0;
     hipLaunchKernelGGL((k_trace_w4<SHADOW, STACK>), dim3(blocks), dim3(64), 0, ctx->stream, ctx->scene.d, o4, d4, iv4, count,
         &f->counters->head[s][0], SHADOW ? (float4*)nullptr : f->hits, SHADOW ? f->rlog : (float4*)nullptr, f->log_stride,
-        f->spill, tune, f->slow_list, &f->counters->slow_count[s]);
+        f->spill, tune, f->slow_list, &f->counters->slow_count[s], &f->counters->stack_spills);
     uint32_t blocks2 = ((uint32_t)ctx->prop.multiProcessorCount * 8u + 7u) & ~7u;
     hipLaunchKernelGGL((k_trace2<SHADOW, 12>), dim3(blocks2), dim3(64), 0, ctx->stream, ctx->scene.d, o4, d4, iv4,
         (const uint32_t*)&f->counters->slow_count[s], &f->counters->slow_head[s][0], SHADOW ? (float4*)nullptr : f->hits,
-        SHADOW ? f->rlog : (float4*)nullptr, f->log_stride, f->select_form_box, f->spill, tune, (const uint32_t*)f->slow_list);
+        SHADOW ? f->rlog : (float4*)nullptr, f->log_stride, f->select_form_box, f->spill, tune, (const uint32_t*)f->slow_list,
+        &f->counters->stack_spills);
 }
 
 // Coherent launches (primary rays): packet traversal, node records through the scalar cache.
@@ -1020,7 +1060,7 @@ void launch_trace(rt_frame* f, const float4* o4, const float4* d4, const float4*
         // ~2 M paths up the persistent kernels win, and of those the 4-wide quantized tree:
         // 4214 (k_trace) / 4400 (k_trace2) / 5042 (k_trace_w4) Mrays/s on the headline workload
         // (profiles/r02_w4_tune_sweep.log)
-        uint64_t paths = (uint64_t)f->n_local * (f->cur_slots ? f->cur_slots : 1u);
+        uint64_t paths = (uint64_t)f->chunk_count * (f->cur_slots ? f->cur_slots : 1u);
         variant = paths >= 2000000ull ? 10u : 0u;
     }
     if ((variant == 10u || variant == 11u) && (!ctx->scene.d.wnodes && !(ctx->scene.d.w_entry_ref & RT_LEAF_BIT))) variant = 8u;
@@ -1060,6 +1100,9 @@ int rt_reset(rt_frame* f)                               // CLPathTraceIntegrator
     if (!f->denoiser) f->sample_count = 0;   // Reset() keeps the frame index while denoising (:499-504)
     f->prev_bounces = 0;
     f->cur_slots = 0;
+    f->chunk_base = 0;
+    f->chunk_count = 0;
+    f->fold_accumulates = 0;
     f->shadow_pending = false;
     HIPCHK(ctx, hipMemsetAsync(f->cnt, 0, (size_t)f->log_stride * sizeof(uint32_t), ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(f->radiance, 0, (size_t)(f->n_local ? f->n_local : 1) * sizeof(float4), ctx->stream));
@@ -1073,18 +1116,23 @@ namespace
 {
 // Primary rays for `n_slots` consecutive samples (sample indices sample_count ..
 // sample_count + n_slots - 1) in one launch; they then travel through the same queues.
-int generate_rays(rt_frame* f, uint32_t n_slots)
+int generate_rays(rt_frame* f, uint32_t n_slots, uint32_t chunk_base = 0)
 {
     rt_ctx* ctx = f->ctx;
     if (f->cur_slots != 0) return fail(ctx, "rt_generate_rays: the previous sample was not advanced (rt_advance_sample)");
-    if (ensure_slots(f, n_slots) != RT_OK) return RT_ERROR;
+    if (chunk_base == 0 && ensure_slots(f, n_slots) != RT_OK) return RT_ERROR;
     if (n_slots > f->slots) return fail(ctx, "rt_generate_rays: more samples than the frame can keep in flight");
+    if (chunk_base >= (f->n_local ? f->n_local : 1u)) return fail(ctx, "rt_generate_rays: chunk outside the tile");
+    f->chunk_base = chunk_base;
+    f->chunk_count = f->n_local - chunk_base < f->chunk_pixels ? f->n_local - chunk_base : f->chunk_pixels;
     float tan_half_fov = rt_tanf(0.5f * f->camera.fov);  // raygeneration.cl:108, uniform -> host
-    uint32_t blocks = (f->n_local * n_slots + 255u) / 256u;
+    uint32_t blocks = (f->chunk_count * n_slots + 255u) / 256u;
     if (blocks == 0) blocks = 1;
     KernelSpan span(f, 0);
     hipLaunchKernelGGL(k_raygen, dim3(blocks), dim3(256), 0, ctx->stream, f->tile, f->camera, f->sample_count, n_slots,
-        tan_half_fov, f->prev_bounces, f->o4[0], f->d4[0], f->iv4[0], f->thr[0], f->counters);
+        tan_half_fov, f->prev_bounces, f->o4[0], f->d4[0], f->iv4[0], f->thr[0], f->counters, f->chunk_base, f->chunk_count,
+        f->chunk_pixels, f->fold_accumulates);
+    f->fold_accumulates = chunk_base != 0 ? 1u : 0u;     // what the NEXT fold does with this sequence's counters
     f->prev_bounces = f->max_bounces;
     f->cur_slots = n_slots;
     HIPCHK(ctx, hipGetLastError());
@@ -1097,6 +1145,9 @@ extern "C" {
 int rt_generate_rays(rt_frame* f)                       // GenerateRays, :516-520
 {
     FRAME_PROLOGUE(f, "rt_generate_rays");
+    if (chunk_for(f, 1) < (f->n_local ? f->n_local : 1u))
+        return fail(ctx, "rt_generate_rays: RT_OPT_PATH_STATE_LIMIT_MB is too small for one sample of the whole tile "
+                         "(the stage API does not chunk; use rt_integrate)");
     return generate_rays(f, 1);
 }
 
@@ -1130,9 +1181,10 @@ int rt_shade(rt_frame* f, uint32_t bounce)              // ShadeMissedRays + Sha
     a.bn_rank = ctx->blue_noise ? ctx->blue_noise + 65536 + 131072 : nullptr;
     a.bounce = bounce; a.sample_base = f->sample_count;
     a.emit_outgoing = (f->drop_last && bounce >= f->max_bounces) ? 0u : 1u;
-    a.n_local = f->n_local ? f->n_local : 1; a.log_stride = f->log_stride;
+    a.n_local = f->chunk_pixels ? f->chunk_pixels : 1; a.log_stride = f->log_stride;
+    a.pix_base = f->chunk_base;
     if (2u * (bounce + 1u) > f->log_entries) return fail(ctx, "rt_shade: bounce beyond the configured max_bounces");
-    uint32_t blocks = (f->n_local * (f->cur_slots ? f->cur_slots : 1u) + RT_SHADE_BLOCK - 1u) / RT_SHADE_BLOCK;
+    uint32_t blocks = (f->chunk_count * (f->cur_slots ? f->cur_slots : 1u) + RT_SHADE_BLOCK - 1u) / RT_SHADE_BLOCK;
     if (blocks == 0) blocks = 1;
     f->shadow_pending = true;
     KernelSpan span(f, 2);
@@ -1229,18 +1281,25 @@ int rt_integrate(rt_frame* f, uint32_t n_samples)       // n x Integrator::Integ
     // ensure_slots may have halved the batch to fit the device (slots_limit): never ask for more than it got
     if (!per_frame) cap = slot_cap(f) < f->slots ? slot_cap(f) : f->slots;
     if (cap == 0) cap = 1;
+    if (per_frame && f->chunk_pixels < (f->n_local ? f->n_local : 1u))
+        return fail(ctx, "rt_integrate: AOVs / the denoiser need the whole tile in one chunk (raise RT_OPT_PATH_STATE_LIMIT_MB)");
     while (done < n_samples)
     {
         uint32_t batch = n_samples - done < cap ? n_samples - done : cap;
         if (per_frame) batch = 1;
         if (f->denoiser && rt_reset(f) != RT_OK) return RT_ERROR;   // integrator.cpp:29: Reset() every frame
-        if (generate_rays(f, batch) != RT_OK) return RT_ERROR;
-        for (uint32_t bounce = 0; bounce <= f->max_bounces; ++bounce)
+        // the whole wavefront loop per chunk of pixels (one chunk unless RT_OPT_PATH_STATE_LIMIT_MB bites)
+        for (uint32_t base = 0; base < (f->n_local ? f->n_local : 1u); base += f->chunk_pixels)
         {
-            if (rt_intersect(f, bounce) != RT_OK) return RT_ERROR;
-            if (bounce == 0 && per_frame && rt_compute_aovs(f) != RT_OK) return RT_ERROR;
-            if (rt_shade(f, bounce) != RT_OK) return RT_ERROR;
-            if (rt_intersect_shadow(f, bounce) != RT_OK) return RT_ERROR;
+            if (generate_rays(f, batch, base) != RT_OK) return RT_ERROR;
+            for (uint32_t bounce = 0; bounce <= f->max_bounces; ++bounce)
+            {
+                if (rt_intersect(f, bounce) != RT_OK) return RT_ERROR;
+                if (bounce == 0 && per_frame && rt_compute_aovs(f) != RT_OK) return RT_ERROR;
+                if (rt_shade(f, bounce) != RT_OK) return RT_ERROR;
+                if (rt_intersect_shadow(f, bounce) != RT_OK) return RT_ERROR;
+            }
+            if (base + f->chunk_pixels < f->n_local && flush_log(f) != RT_OK) return RT_ERROR;   // last chunk: rt_advance_sample
         }
         if (rt_advance_sample(f) != RT_OK) return RT_ERROR;
         if (f->denoiser && (rt_denoise(f) != RT_OK || rt_copy_history(f) != RT_OK)) return RT_ERROR;
@@ -1288,7 +1347,8 @@ int rt_frame_get_stats(rt_frame* f, rt_stats* out)
     if (!f || !out) return fail(nullptr, "rt_frame_get_stats: NULL argument");
     rt_ctx* ctx = f->ctx;
     (void)hipSetDevice(ctx->device);
-    hipLaunchKernelGGL(k_fold_counters, dim3(1), dim3(64), 0, ctx->stream, f->counters, f->prev_bounces);
+    hipLaunchKernelGGL(k_fold_counters, dim3(1), dim3(64), 0, ctx->stream, f->counters, f->prev_bounces, f->fold_accumulates);
+    f->fold_accumulates = 1;       // whatever is folded next belongs to the same batch's totals unless a new batch starts
     DCounters h;
     HIPCHK(ctx, hipMemcpyAsync(&h, f->counters, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -1298,6 +1358,9 @@ int rt_frame_get_stats(rt_frame* f, rt_stats* out)
     out->samples_in_flight = f->slots;
     out->samples_in_flight_limit = f->slots_limit;
     out->path_state_bytes = (uint64_t)f->log_stride * bytes_per_path(f->max_bounces);
+    out->chunk_pixels = f->chunk_pixels;
+    out->stack_spills = h.stack_spills;
+    out->slow_rays = h.slow_rays;
     for (int i = 0; i < 64; ++i) { out->last_active[i] = h.last_queue[i]; out->last_shadow[i] = h.last_shadow[i]; }
     return RT_OK;
 }
@@ -1363,7 +1426,7 @@ int rt_frame_debug_read_queue(rt_frame* f, int which, uint32_t bounce, rt_ray* r
         uint32_t pl;
         memcpy(&pl, &d[i].w, 4);
         uint32_t id = pl;
-        uint32_t local_pix = id % (f->n_local ? f->n_local : 1);
+        uint32_t local_pix = f->chunk_base + id % (f->chunk_pixels ? f->chunk_pixels : 1);
         if (which == 1)   // the deferred direct-light sample lives in the radiance log
         {
             float4 iv;

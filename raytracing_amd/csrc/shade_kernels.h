@@ -311,7 +311,8 @@ struct ShadeArgs
     float4* rlog; uint32_t* cnt;      // radiance log (see file header)
     const uint8_t* bn_sobol; const uint8_t* bn_scramble; const uint8_t* bn_rank;   // SamplerType::kBlueNoise tables
     DCounters* counters;
-    uint32_t bounce, sample_base, emit_outgoing, n_local, log_stride;
+    uint32_t bounce, sample_base, emit_outgoing, n_local, log_stride;   // n_local: pixels per chunk (path id = slot * n_local + pixel in chunk)
+    uint32_t pix_base;                                                  // first local pixel of the chunk
 };
 
 // SampleBlueNoise, sampling.h:40-61 (Heitz et al. 2019 tables, values 0..255).  The reference
@@ -372,8 +373,9 @@ __global__ __launch_bounds__(RT_SHADE_BLOCK) void k_shade(DScene sc, DTile tile,
         {
             // HitSurface, hit_surface.cl:79-184
             f3 incoming = F3(-rd.x, -rd.y, -rd.z);
-            uint32_t ly = pix / tile.width;
-            uint32_t px = pix - ly * tile.width;
+            uint32_t lp = a.pix_base + pix;                                  // local pixel of the tile
+            uint32_t ly = lp / tile.width;
+            uint32_t px = lp - ly * tile.width;
             uint32_t py = tile_global_row(tile, ly);
 
             const float4* tp = sc.tris_sh + (size_t)prim * 8;
@@ -495,14 +497,15 @@ __global__ __launch_bounds__(RT_SHADE_BLOCK) void k_shade(DScene sc, DTile tile,
 // by contribution -- the exact order in which the reference's kernels executed
 // `radiance[pixel] += ...` (miss.cl:75, hit_surface.cl:110, accumulate_direct_samples.cl:51).
 __global__ __launch_bounds__(256) void k_flush(float4* __restrict__ radiance, const float4* __restrict__ rlog,
-    uint32_t* __restrict__ cnt, uint32_t n_local, uint32_t n_slots, uint32_t log_stride)
+    uint32_t* __restrict__ cnt, uint32_t n_pixels, uint32_t n_slots, uint32_t log_stride, uint32_t id_stride)
 {
+    // radiance: already offset to the chunk's first pixel; id_stride: pixels per chunk as allocated
     uint32_t p = blockIdx.x * 256u + threadIdx.x;
-    if (p >= n_local) return;
+    if (p >= n_pixels) return;
     float4 r = radiance[p];
     for (uint32_t slot = 0; slot < n_slots; ++slot)
     {
-        uint32_t id = slot * n_local + p;
+        uint32_t id = slot * id_stride + p;
         uint32_t c = cnt[id];
         for (uint32_t k = 0; k < c; ++k)
         {

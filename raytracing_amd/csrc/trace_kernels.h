@@ -807,7 +807,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(STACK <= 10 
     const float4* __restrict__ iv4, const uint32_t* __restrict__ count_ptr, uint32_t* __restrict__ heads,
     float4* __restrict__ hits,
     float4* __restrict__ rlog, uint32_t log_stride, uint32_t force_sign_bits, uint2* __restrict__ spill, uint32_t tune,
-    const uint32_t* __restrict__ index_list /* nullptr: the whole queue; else queue entries to trace, *count_ptr of them */)
+    const uint32_t* __restrict__ index_list /* nullptr: the whole queue; else queue entries to trace, *count_ptr of them */,
+    uint32_t* __restrict__ spill_count /* statistics: pushes beyond the LDS stack */)
 {
     __shared__ uint2 stack[STACK][64];
     uint32_t* const stack32 = reinterpret_cast<uint32_t*>(&stack[0][0]);     // SHADOW: 2 * STACK entries of 4 bytes
@@ -989,7 +990,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(STACK <= 10 
                     if (SHADOW)
                     {
                         if (sp < 2 * STACK) stack32[sp * 64 + lane] = far_ref;
-                        else vspill32[(size_t)2 * spill_base + (uint32_t)(sp - 2 * STACK)] = far_ref;
+                        else { vspill32[(size_t)2 * spill_base + (uint32_t)(sp - 2 * STACK)] = far_ref; atomicAdd(spill_count, 1u); }
                     }
                     else
                     {
@@ -999,6 +1000,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(STACK <= 10 
                         {
                             vspill[(size_t)spill_base + (uint32_t)(sp - STACK)].x = far_ref;
                             vspill[(size_t)spill_base + (uint32_t)(sp - STACK)].y = far_entry;
+                            atomicAdd(spill_count, 1u);
                         }
                     }
                     ++sp;
@@ -1041,7 +1043,7 @@ template <bool SHADOW, int STACK>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_trace_w4(DScene sc, const float4* __restrict__ o4, const float4* __restrict__ d4,
     const float4* __restrict__ iv4, const uint32_t* __restrict__ count_ptr, uint32_t* __restrict__ heads,
     float4* __restrict__ hits, float4* __restrict__ rlog, uint32_t log_stride, uint2* __restrict__ spill, uint32_t tune,
-    uint32_t* __restrict__ slow_list, uint32_t* __restrict__ slow_count)
+    uint32_t* __restrict__ slow_list, uint32_t* __restrict__ slow_count, uint32_t* __restrict__ stat_counts /* [0] spills, [1] slow rays */)
 {
     __shared__ uint2 stack[STACK][64];
     uint32_t* const stack32 = reinterpret_cast<uint32_t*>(&stack[0][0]);     // SHADOW: 2 * STACK entries of 4 bytes
@@ -1073,7 +1075,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
         if (SHADOW)
         {
             if (sp < 2 * STACK) stack32[sp * 64 + lane] = r;
-            else vspill32[(size_t)2 * spill_base + (uint32_t)(sp - 2 * STACK)] = r;
+            else { vspill32[(size_t)2 * spill_base + (uint32_t)(sp - 2 * STACK)] = r; atomicAdd(&stat_counts[0], 1u); }
         }
         else
         {
@@ -1082,6 +1084,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
             {
                 vspill[(size_t)spill_base + (uint32_t)(sp - STACK)].x = r;
                 vspill[(size_t)spill_base + (uint32_t)(sp - STACK)].y = __float_as_uint(entry);
+                atomicAdd(&stat_counts[0], 1u);
             }
         }
         ++sp;
@@ -1149,7 +1152,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                 if (slow_m != 0ull)
                 {
                     uint32_t base = 0;
-                    if (lane == 0) base = atomicAdd(slow_count, (uint32_t)__popcll(slow_m));
+                    if (lane == 0) { base = atomicAdd(slow_count, (uint32_t)__popcll(slow_m)); atomicAdd(&stat_counts[1], (uint32_t)__popcll(slow_m)); }
                     base = __shfl(base, 0, 64);
                     if (slow)
                     {

@@ -1,0 +1,169 @@
+"""-m gpu: parity WHERE THE METRIC IS QUOTED (VERDICT r01 "what's weak" 1): the stand-ins of BASELINE configs 3, 4
+and 5 rendered with the production launch shape -- 128 samples of every pixel in flight, more than 2 M paths per
+launch, so that the automatic choice is the persistent wide-tree kernel (k_trace_w4, with k_trace2 behind it) and
+path ids, the radiance log and the work distribution run at depth -- compared BIT FOR BIT with the reference's own
+kernels (oracle/_ref, RefIntegrator) on the same scene, camera and samples.  Reference side of the comparison:
+src/kernels/cl/trace_bvh.cl:144-202, hit_surface.cl:30-186.  Triangle counts are reduced so the CPU reference
+finishes in seconds; bench.py repeats the comparison on the full 1080p frame of the full scene (`parity`).
+
+Also here: a tree deep enough that the traversal stack provably spills from LDS to HBM (rt_stats.stack_spills)."""
+import os
+import tempfile
+import numpy as np
+import pytest
+from tests import _oracle, _ref
+from raytracing_amd import capi, host, scenes as S, types as T
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIGHT = ((-0.6, -1.5, 3.5), (15.0, 10.0, 5.0))
+
+
+def _finish(scene):
+    scene.add_directional_light(*LIGHT)
+    scene.set_env_path(os.path.join(ROOT, "assets", "ibl", "CGSkies_0036_free.hdr"))
+    scene.build_bvh()
+    scene.finalize()
+    return scene.arrays()
+
+
+def _config3():
+    path = S.shader_balls_obj(tempfile.mkdtemp(prefix="rt_test_"), 6_000)
+    return _finish(host.Scene(path)), 3
+
+
+def _config4():
+    return _finish(host.Scene(arrays=S.city_block(300_000))), 8
+
+
+def _config5():
+    return _finish(host.Scene(arrays=S.dense_foliage(400_000))), 16
+
+
+@pytest.mark.skipif(not _ref.available(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("make", [_config3, _config4, _config5], ids=["config3_shader_balls", "config4_city_block", "config5_dense_foliage"])
+def test_production_launch_shape_matches_the_reference_kernels_bit_for_bit(make):
+    arrays, bounces = make()
+    w, h, spp = 192, 108, 128
+    assert w * h * spp >= 2_000_000                      # rt_hip.hip launch_trace: auto picks the persistent wide-tree kernel
+    cam = T.default_camera(w, h)
+    ctx = capi.Context(0)
+    ctx.upload_scene(arrays)
+    fr = capi.Frame(ctx, w, h)
+    fr.set_camera(cam)
+    fr.set_max_bounces(bounces)
+    assert fr.reserve_samples(spp) == spp
+    fr.integrate(spp)                                    # ONE batch: 128 samples of every pixel travel together
+    got = fr.radiance()[..., :3]
+    st = fr.stats()
+    assert st.samples_in_flight == spp and st.last_active[0] == w * h * spp
+    ri = _ref.RefIntegrator(w, h, arrays, threads=min(32, os.cpu_count() or 1))
+    ri.set_camera(cam)
+    ri.set_max_bounces(bounces)
+    ri.integrate(spp)
+    want = ri.radiance()[..., :3]
+    diff = ~((got == want) | (np.isnan(got) & np.isnan(want))).all(-1)
+    assert not diff.any(), "%d of %d pixels differ, first at %s" % (diff.sum(), diff.size, np.argwhere(diff)[:3].tolist())
+    assert (st.closest_rays, st.shadow_rays) == ri.ray_totals()
+    # the same batch through the BVH2 kernels gives the same bits (and the same counters)
+    fr.set_option(capi.OPT_TRACE_VARIANT, 8)
+    fr.reset()
+    fr.integrate(spp)
+    assert np.array_equal(fr.radiance()[..., :3], got, equal_nan=True)
+    fr.close()
+    ctx.close()
+
+
+@pytest.mark.parametrize("variant", [8, 10])
+def test_deep_tree_spills_the_traversal_stack_to_hbm_and_stays_exact(variant, env_map):
+    """65 536 large triangles stacked in depth along the view direction: every primary ray overlaps every box, so the
+    descent to the first leaf pushes one far child per BVH2 level (16+ levels) -- more than the 10 / 12 entries the
+    kernels keep in LDS.  rt_stats.stack_spills proves the HBM spill path ran; the image equals the oracle's."""
+    n = 65536
+    k = np.arange(n, dtype=np.float32)
+    y = 1.0 + k * np.float32(1.0 / 4096.0)
+    P = np.zeros((n, 3, 3), np.float32)
+    P[:, 0] = np.stack([np.full(n, -9.0, np.float32), y, np.full(n, -8.0, np.float32)], 1)
+    P[:, 1] = np.stack([np.full(n, 9.0, np.float32), y, np.full(n, -8.0, np.float32)], 1)
+    P[:, 2] = np.stack([np.zeros(n, np.float32), y, np.full(n, 12.0, np.float32)], 1)
+    N = np.tile(np.array([0, -1, 0], np.float32), (n, 3, 1))
+    tris = S.to_triangles([(P, N, np.zeros((n, 3, 2), np.float32), 0)])
+    mats = np.array([S.make_material(kd=(0.6, 0.6, 0.6), ks=(0.2, 0.2, 0.2), roughness=0.5)], dtype=T.packed_material)
+    s = host.Scene(arrays=dict(triangles=tris, materials=mats))
+    s.add_directional_light(*LIGHT)
+    s.build_bvh(); s.set_env_image(env_map); s.finalize()
+    arrays = s.arrays()
+    w, h, b, spp = 48, 32, 2, 2
+    cam = T.default_camera(w, h)
+    ctx = capi.Context(0)
+    ctx.upload_scene(arrays)
+    fr = capi.Frame(ctx, w, h)
+    fr.set_camera(cam); fr.set_max_bounces(b)
+    fr.set_option(capi.OPT_TRACE_VARIANT, variant)
+    fr.integrate(spp)
+    st = fr.stats()
+    assert st.stack_spills > 0
+    orc = _oracle.Oracle(w, h, arrays)
+    orc.set_camera(cam); orc.set_max_bounces(b); orc.integrate(spp)
+    assert np.array_equal(fr.radiance()[..., :3], orc.radiance()[..., :3], equal_nan=True)
+    assert (st.closest_rays, st.shadow_rays) == orc.ray_totals()
+    fr.close()
+    ctx.close()
+
+
+def test_shrinking_the_batch_on_device_memory_pressure_keeps_the_sum_exact(golden_scenes):
+    """rt_integrate itself triggers the 'halve the batch until it fits' fallback (no reservation first);
+    RT_OPT_DEBUG_ALLOC_LIMIT makes allocations above 3 samples in flight fail like a full device."""
+    w, h, b, spp = 64, 48, 5, 11
+    sc = golden_scenes["coverage"]
+    cam = T.default_camera(w, h)
+    ctx = capi.Context(0)
+    ctx.upload_scene(sc)
+    base = capi.Frame(ctx, w, h)
+    base.set_camera(cam); base.set_max_bounces(b); base.set_option(capi.OPT_SAMPLES_IN_FLIGHT, 1)
+    base.integrate(spp)
+    fr = capi.Frame(ctx, w, h)
+    fr.set_camera(cam); fr.set_max_bounces(b)
+    fr.set_option(capi.OPT_DEBUG_ALLOC_LIMIT, 3)
+    fr.integrate(spp)                                   # asks for 11 in flight, gets 2 (11 -> 5 -> 2), must not fail
+    st = fr.stats()
+    assert st.samples_in_flight <= 3 and st.samples_in_flight_limit == st.samples_in_flight
+    assert fr.sample_count() == spp
+    assert np.array_equal(fr.radiance(), base.radiance(), equal_nan=True)
+    fr.close(); base.close(); ctx.close()
+
+
+@pytest.mark.parametrize("variant", [5, 10])
+def test_bounded_path_state_renders_the_tile_in_chunks_bit_identically(variant, golden_scenes):
+    """RT_OPT_PATH_STATE_LIMIT_MB: the per-path buffers (ray queues + radiance log) are capped and every batch of
+    samples runs the wavefront loop chunk by chunk over the tile's pixels.  Same bits, same counters."""
+    w, h, b, spp = 160, 100, 6, 9
+    sc = golden_scenes["coverage"]
+    cam = T.default_camera(w, h)
+    ctx = capi.Context(0)
+    ctx.upload_scene(sc)
+    base = capi.Frame(ctx, w, h)
+    base.set_camera(cam); base.set_max_bounces(b); base.set_option(capi.OPT_SAMPLES_IN_FLIGHT, 4)
+    base.integrate(spp)
+    bs = base.stats()
+    assert bs.chunk_pixels == w * h
+    for tile in (dict(), dict(tile_rank=1, tile_count=2, band_height=4)):
+        ref = capi.Frame(ctx, w, h, **tile)
+        ref.set_camera(cam); ref.set_max_bounces(b); ref.set_option(capi.OPT_SAMPLES_IN_FLIGHT, 4); ref.integrate(spp)
+        fr = capi.Frame(ctx, w, h, **tile)
+        fr.set_camera(cam); fr.set_max_bounces(b)
+        fr.set_option(capi.OPT_SAMPLES_IN_FLIGHT, 4)
+        fr.set_option(capi.OPT_TRACE_VARIANT, variant)
+        fr.set_option(capi.OPT_PATH_STATE_LIMIT_MB, 8)       # 4 x 4096 pixels x ~460 B: 4096-pixel chunks
+        fr.integrate(spp)                                    # 4 + 4 + 1 samples, every batch in 2..4 chunks
+        st, rs = fr.stats(), ref.stats()
+        assert st.chunk_pixels == 4096 and st.path_state_bytes <= 8 << 20
+        assert np.array_equal(fr.radiance(), ref.radiance(), equal_nan=True)
+        assert (st.closest_rays, st.shadow_rays) == (rs.closest_rays, rs.shadow_rays)
+        assert list(st.last_active[: b + 1]) == list(rs.last_active[: b + 1])      # chunks of the last batch add up
+        # lifting the limit afterwards keeps accumulating exactly
+        fr.set_option(capi.OPT_PATH_STATE_LIMIT_MB, 0)
+        fr.integrate(3); ref.integrate(3)
+        assert np.array_equal(fr.radiance(), ref.radiance(), equal_nan=True)
+        fr.close(); ref.close()
+    base.close(); ctx.close()
