@@ -89,7 +89,7 @@ struct DCounters                  // one per frame, device memory
     // rays k_trace_w4 hands to the BVH2 kernel (non-finite 1/dir): list length and that launch's work heads
     uint32_t slow_count[2];
     uint32_t slow_head[2][8];
-    uint32_t stack_spills;        // traversal-stack pushes that went to the HBM spill area (k_trace2 / k_trace_w4), since the last reset
+    uint32_t stack_spills;        // lane-steps with stack entries in the HBM spill area (k_trace2 / k_trace_w4), since the last reset
     uint32_t slow_rays;           // rays k_trace_w4 handed to k_trace2, since the last reset
 };
 

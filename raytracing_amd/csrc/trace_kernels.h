@@ -831,6 +831,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(STACK <= 10 
     uint32_t ray_i = RT_INVALID_ID;                                          // != invalid while a result is owed
     uint32_t sign_bits = 0, hit_prim = RT_INVALID_ID;
     int sp = 0;
+    uint32_t n_spills = 0;                                                   // statistics (wave-uniform): lane-steps with entries in the HBM spill area
     rt_v2f oxy = {0.0f, 0.0f}, ixy = oxy;                                    // origin.xy and (1/dir).xy as register pairs
     float oz = 0.0f, iz = 0.0f;
     f3 dir = F3s(0.0f);
@@ -902,7 +903,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(STACK <= 10 
             }
         }
         if (__ballot(ref != RT_IDLE_REF) == 0ull) break;                    // queue dry and every ray retired
-
         // ---- B: triangles (trace_bvh.cl:28-73,155-169), one per waiting lane per pass ----
         {
             unsigned long long leaf_m = __ballot((int)ref < -1);
@@ -990,7 +990,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(STACK <= 10 
                     if (SHADOW)
                     {
                         if (sp < 2 * STACK) stack32[sp * 64 + lane] = far_ref;
-                        else { vspill32[(size_t)2 * spill_base + (uint32_t)(sp - 2 * STACK)] = far_ref; atomicAdd(spill_count, 1u); }
+                        else vspill32[(size_t)2 * spill_base + (uint32_t)(sp - 2 * STACK)] = far_ref;
                     }
                     else
                     {
@@ -1000,7 +1000,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(STACK <= 10 
                         {
                             vspill[(size_t)spill_base + (uint32_t)(sp - STACK)].x = far_ref;
                             vspill[(size_t)spill_base + (uint32_t)(sp - STACK)].y = far_entry;
-                            atomicAdd(spill_count, 1u);
                         }
                     }
                     ++sp;
@@ -1009,8 +1008,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(STACK <= 10 
                 else if (far_hit) ref = far_ref;
                 else pop();
             }
+            n_spills += (uint32_t)__popcll(__ballot(sp > (SHADOW ? 2 * STACK : STACK)));
         }
     }
+    if (lane == 0 && n_spills != 0u) atomicAdd(spill_count, n_spills);
 }
 
 // ---------------------------------------------------------------------------
@@ -1064,6 +1065,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
     uint32_t ray_i = RT_INVALID_ID;
     uint32_t sign_bits = 0, hit_prim = RT_INVALID_ID;
     int sp = 0;
+    uint32_t n_spills = 0;                                                   // statistics (wave-uniform): lane-steps with entries in the HBM spill area
     f3 org = F3s(0.0f), dir = F3s(0.0f), inv = F3s(0.0f);
     float t_max = 0.0f, hit_u = 0.0f, hit_v = 0.0f;
     uint32_t payload = 0, log_entry = 0;
@@ -1075,7 +1077,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
         if (SHADOW)
         {
             if (sp < 2 * STACK) stack32[sp * 64 + lane] = r;
-            else { vspill32[(size_t)2 * spill_base + (uint32_t)(sp - 2 * STACK)] = r; atomicAdd(&stat_counts[0], 1u); }
+            else vspill32[(size_t)2 * spill_base + (uint32_t)(sp - 2 * STACK)] = r;
         }
         else
         {
@@ -1084,7 +1086,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
             {
                 vspill[(size_t)spill_base + (uint32_t)(sp - STACK)].x = r;
                 vspill[(size_t)spill_base + (uint32_t)(sp - STACK)].y = __float_as_uint(entry);
-                atomicAdd(&stat_counts[0], 1u);
             }
         }
         ++sp;
@@ -1288,6 +1289,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                 if (e[0] < INF) ref = r[0];
                 else pop();
             }
+            n_spills += (uint32_t)__popcll(__ballot(sp > (SHADOW ? 2 * STACK : STACK)));
         }
     }
+    if (lane == 0 && n_spills != 0u) atomicAdd(&stat_counts[0], n_spills);
 }
