@@ -283,6 +283,7 @@ def main():
     ap.add_argument("--path-state-gb", type=float, default=0.0,
                     help="cap the per-path device buffers (ray queues + radiance log) at this many GiB per GPU: the tile is then "
                          "rendered chunk by chunk (RT_OPT_PATH_STATE_LIMIT_MB); 0 = the library's own rule (up to half of the HBM)")
+    ap.add_argument("--pipelines", type=int, default=None, help="RT_OPT_PIPELINES (library default: 2)")
     ap.add_argument("--debug-shared-gpu", action="store_true",
                     help="plumbing test only: all ranks share GPU 0 and gather over gloo (RCCL refuses two ranks per device)")
     ap.add_argument("--plumbing-only", action="store_true", help="no GPU: launch, rendezvous, gather and report only")
@@ -357,6 +358,8 @@ def main():
     # otherwise grow inside the first rt_integrate that asks for a larger batch)
     sps = args.samples_per_step or cfg["samples_per_step"]
     spp_timed, spp_warm = args.steps * sps, args.warmup * sps
+    if args.pipelines:
+        assert lib.rt_set_option(frame, capi.OPT_PIPELINES, args.pipelines) == 0
     if args.path_state_gb > 0:
         assert lib.rt_set_option(frame, capi.OPT_PATH_STATE_LIMIT_MB, int(args.path_state_gb * 1024)) == 0
     in_flight = render.reserve_samples(max(spp_timed, spp_warm))
@@ -452,7 +455,7 @@ def main():
                                          "CGSkies env map" % (args.width, args.height, args.bounces, sps),
                                 triangles=int(n_tris), width=args.width, height=args.height,
                                 max_bounces=args.bounces, samples_per_step=sps, spp=spp_timed, samples_in_flight=in_flight,
-                                path_state_GB=round(st1.path_state_bytes * world / 2 ** 30, 2), chunk_pixels=int(st1.chunk_pixels),
+                                path_state_GB=round(st1.path_state_bytes * world / 2 ** 30, 2), chunk_pixels=int(st1.chunk_pixels), pipelines=int(st1.pipelines),
                                 tiling="%d interleaved %d-row bands per GPU, 1 gather" % (world, args.band_height)
                                 if world > 1 else "single tile",
                                 rays_per_step=round(total_rays / args.steps, 1), non_finite_pixels=nan_px,

@@ -149,6 +149,11 @@ enum rt_option
                                        over the tile's pixels instead of over the whole tile at once.  0 (default) = only
                                        the built-in rule (at most half of the HBM).  Results are bit-identical for every
                                        value: path ids, the log and the replay are per pixel. */
+    , RT_OPT_PIPELINES = 15        /* 1..4 (default 2): pipes -- sets of per-path buffers, each with its own HIP stream --
+                                       rt_integrate deals the tile's chunks to when a batch is large (>= 2 samples in
+                                       flight, >= 4 M paths): the straggler tail of one chunk's launch then overlaps the
+                                       other chunk's next launch.  1 = everything on the context's stream.  Results are
+                                       bit-identical for every value. */
     , RT_OPT_TRACE_TUNE = 12       /* k_trace2 (variants 8, 9) loop thresholds: value & 255 = lanes that must hold an
                                        interior node for a wave to stay in the node loop, value >> 8 & 255 = lanes that
                                        must wait at a triangle for another pass of the triangle loop.  0 = defaults.
@@ -213,7 +218,7 @@ typedef struct rt_stats
     uint32_t slow_rays;                /* rays with a non-finite 1/dir component that k_trace_w4 handed to the BVH2 kernel */
     uint32_t chunk_pixels;             /* pixels of the tile that travel through the wavefront loop together (the whole
                                           tile unless RT_OPT_PATH_STATE_LIMIT_MB splits it) */
-    uint32_t reserved_;
+    uint32_t pipelines;                /* pipes (HIP streams) the chunks are dealt to */
 } rt_stats;
 int rt_frame_get_stats(rt_frame* frame, rt_stats* out);
 

@@ -21,7 +21,7 @@ class rt_stats(C.Structure):
     _fields_ = [("closest_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("samples", C.c_uint64),
                 ("last_active", C.c_uint32 * 64), ("last_shadow", C.c_uint32 * 64),
                 ("samples_in_flight", C.c_uint32), ("samples_in_flight_limit", C.c_uint32), ("path_state_bytes", C.c_uint64),
-                ("stack_spills", C.c_uint32), ("slow_rays", C.c_uint32), ("chunk_pixels", C.c_uint32), ("reserved_", C.c_uint32)]
+                ("stack_spills", C.c_uint32), ("slow_rays", C.c_uint32), ("chunk_pixels", C.c_uint32), ("pipelines", C.c_uint32)]
 
 
 class rt_profile(C.Structure):
@@ -63,7 +63,7 @@ EXPORTS = [
     "rt_group_gather_radiance", "rt_group_destroy", "rt_group_last_error",
 ]
 
-OPT_MAX_BOUNCES, OPT_WHITE_FURNACE, OPT_SAMPLER, OPT_AOV, OPT_DENOISER, OPT_DROP_LAST, OPT_PROFILE, OPT_TRACE_VARIANT, OPT_TRACE_WAVES, OPT_SAMPLES_IN_FLIGHT, OPT_SELECT_FORM_BOX, OPT_PACKET_BOUNCES, OPT_TRACE_TUNE, OPT_DEBUG_ALLOC_LIMIT, OPT_PATH_STATE_LIMIT_MB = range(15)
+OPT_MAX_BOUNCES, OPT_WHITE_FURNACE, OPT_SAMPLER, OPT_AOV, OPT_DENOISER, OPT_DROP_LAST, OPT_PROFILE, OPT_TRACE_VARIANT, OPT_TRACE_WAVES, OPT_SAMPLES_IN_FLIGHT, OPT_SELECT_FORM_BOX, OPT_PACKET_BOUNCES, OPT_TRACE_TUNE, OPT_DEBUG_ALLOC_LIMIT, OPT_PATH_STATE_LIMIT_MB, OPT_PIPELINES = range(16)
 
 
 def load():

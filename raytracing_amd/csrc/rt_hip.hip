@@ -50,35 +50,53 @@ struct rt_buffer
     size_t bytes;
 };
 
+#define RT_MAX_PIPES 4
+// Per-path state of one chunk in flight and the stream its launches go to (see rt_frame::ps).
+struct PathPipe
+{
+    hipStream_t stream = nullptr;      // pipe 0: the context's stream; others: their own
+    hipEvent_t done = nullptr;         // cross-stream ordering (fork_pipes / join_pipes)
+    // ray queues (ping-pong), hits, shadow queue
+    float4* o4[2] = {nullptr, nullptr}; float4* d4[2] = {nullptr, nullptr}; float4* iv4[2] = {nullptr, nullptr};
+    float4* thr[2] = {nullptr, nullptr};
+    float4* hits = nullptr;
+    float4* sh_o4 = nullptr; float4* sh_d4 = nullptr; float4* sh_iv4 = nullptr;
+    // radiance log (kernels_common.h header): cnt[id], rlog[entry][id]; id < slots * chunk_pixels
+    float4* rlog = nullptr; uint32_t* cnt = nullptr;
+    uint32_t* slow_list = nullptr;     // queue indices k_trace_w4 leaves to k_trace2 (one per path)
+    DCounters* counters = nullptr;
+    uint2* spill = nullptr;
+    uint32_t cur_slots = 0;            // slots used by the batch in flight on this pipe (0 = nothing pending)
+    uint32_t chunk_base = 0;           // first local pixel of the chunk in flight
+    uint32_t chunk_count = 0;          // pixels of the chunk in flight
+    uint32_t prev_bounces = 0;
+    uint32_t fold_accumulates = 0;     // the sequence in flight is a 2nd+ chunk of its batch: its counters ADD to last_*
+    bool shadow_pending = false;       // rt_shade issued, rt_intersect_shadow not yet
+};
+
 struct rt_frame
 {
     rt_ctx* ctx;
     DTile tile;
     uint32_t n_local;
-    // queues (ping-pong), hits, shadow queue, radiance
-    float4* o4[2]; float4* d4[2]; float4* iv4[2]; float4* thr[2];
-    float4* hits;
-    float4* sh_o4; float4* sh_d4; float4* sh_iv4;
     float4* radiance; float4* resolved;
-    // radiance log (kernels_common.h header): cnt[id], rlog[entry][id]; id < slots * n_local
-    float4* rlog = nullptr; uint32_t* cnt = nullptr;
+    // Per-path state lives in PIPES (PathPipe): the tile is cut into chunks of pixels and chunk c travels through
+    // the wavefront loop on pipe c % n_pipes, each pipe on its own HIP stream.  One chunk on one pipe is the plain
+    // case; two pipes let the straggler tail of one chunk's launch (a handful of very long rays keep a persistent
+    // trace kernel alive for ~1 ms while the machine idles) overlap with the other chunk's next launch.
+    PathPipe ps[RT_MAX_PIPES];
+    PathPipe* p = &ps[0];          // the pipe the stage functions work on
+    uint32_t pipelines = 2;        // RT_OPT_PIPELINES: pipes rt_integrate may use
+    uint32_t n_pipes = 1;          // pipes the current allocation holds
     uint32_t slots = 1;            // samples traced concurrently (resolved from slots_opt)
     uint32_t slots_opt = 0;        // RT_OPT_SAMPLES_IN_FLIGHT as set by the caller (0 = auto)
     uint32_t slots_limit = 0;      // != 0: a larger batch did not fit into device memory
-    uint32_t cur_slots = 0;        // slots used by the batch in flight (0 = nothing pending)
     uint32_t log_stride = 0;       // elements per log entry row = slots * chunk_pixels
-    // The tile can be rendered in chunks of pixels so that the per-path buffers respect RT_OPT_PATH_STATE_LIMIT_MB:
-    // every batch of samples then runs the whole wavefront loop chunk after chunk (path ids are chunk-relative).
+    // Chunks also bound memory: RT_OPT_PATH_STATE_LIMIT_MB caps the per-path buffers of all pipes together
+    // (path ids are chunk-relative, the radiance log is replayed per chunk).
     uint32_t chunk_pixels = 0;     // pixels per chunk as allocated (n_local when the tile is not chunked)
-    uint32_t chunk_base = 0;       // first local pixel of the chunk in flight
-    uint32_t chunk_count = 0;      // pixels of the chunk in flight
     uint32_t state_limit_mb = 0;   // RT_OPT_PATH_STATE_LIMIT_MB (0 = only the built-in 144 GB rule)
-    uint32_t fold_accumulates = 0; // the sequence in flight is a 2nd+ chunk of its batch: its counters ADD to last_*
     uint32_t log_entries = 0;      // rows allocated (>= 2 * (max_bounces + 1))
-    bool shadow_pending = false;   // rt_shade issued, rt_intersect_shadow not yet
-    DCounters* counters;
-    uint2* spill;
-    uint32_t* slow_list = nullptr;   // queue indices k_trace_w4 leaves to k_trace2 (one per path)
     uint32_t trace_blocks;       // v1 grid
     uint32_t trace_variant = 5;  // RT_OPT_TRACE_VARIANT (5 = auto)
     uint32_t trace_waves_per_cu = 0;   // RT_OPT_TRACE_WAVES_PER_CU (0 = LDS-limited residency)
@@ -99,7 +117,6 @@ struct rt_frame
     uint32_t white_furnace = 0;
     uint32_t drop_last = 1;
     uint32_t sample_count = 0;
-    uint32_t prev_bounces = 0;
     // RT_OPT_PROFILE_KERNELS
     uint32_t profile = 0;
     struct Span { hipEvent_t a, b; int cls; };
@@ -630,12 +647,14 @@ namespace
 {
 void free_path_buffers(rt_frame* f)
 {
-    void* ptrs[] = {f->o4[0], f->o4[1], f->d4[0], f->d4[1], f->iv4[0], f->iv4[1], f->thr[0], f->thr[1], f->hits,
-        f->sh_o4, f->sh_d4, f->sh_iv4, f->rlog, f->cnt, f->slow_list};
-    for (void* p : ptrs) if (p) (void)hipFree(p);
-    f->slow_list = nullptr;
-    for (int i = 0; i < 2; ++i) { f->o4[i] = nullptr; f->d4[i] = nullptr; f->iv4[i] = nullptr; f->thr[i] = nullptr; }
-    f->hits = nullptr; f->sh_o4 = nullptr; f->sh_d4 = nullptr; f->sh_iv4 = nullptr; f->rlog = nullptr; f->cnt = nullptr;
+    for (PathPipe& q : f->ps)
+    {
+        void* ptrs[] = {q.o4[0], q.o4[1], q.d4[0], q.d4[1], q.iv4[0], q.iv4[1], q.thr[0], q.thr[1], q.hits, q.sh_o4, q.sh_d4, q.sh_iv4,
+            q.rlog, q.cnt, q.slow_list};
+        for (void* p : ptrs) if (p) (void)hipFree(p);
+        for (int i = 0; i < 2; ++i) { q.o4[i] = nullptr; q.d4[i] = nullptr; q.iv4[i] = nullptr; q.thr[i] = nullptr; }
+        q.hits = nullptr; q.sh_o4 = nullptr; q.sh_d4 = nullptr; q.sh_iv4 = nullptr; q.rlog = nullptr; q.cnt = nullptr; q.slow_list = nullptr;
+    }
 }
 
 // Per-path state: ray queues for `slots` samples in flight and the radiance log
@@ -660,53 +679,128 @@ uint32_t slot_cap(const rt_frame* f)
     return f->slots_limit && f->slots_limit < cap ? f->slots_limit : cap;    // what the device could actually hold
 }
 
-// pixels per chunk for `slots` samples in flight under RT_OPT_PATH_STATE_LIMIT_MB (multiples of 4096 pixels)
-uint32_t chunk_for(const rt_frame* f, uint32_t slots)
+// How the tile is cut for `slots` samples in flight: number of pipes and pixels per chunk.
+//  * two (RT_OPT_PIPELINES) pipes when a batch is large enough for its launches to fill the machine twice over
+//    (>= 2 samples in flight and >= 4 M paths): the tile's halves then overlap each other's launch tails;
+//  * RT_OPT_PATH_STATE_LIMIT_MB bounds the per-path buffers of all pipes together: more, smaller chunks
+//    (multiples of 4096 pixels), still dealt round-robin to the pipes.
+void chunk_plan(const rt_frame* f, uint32_t slots, uint32_t& n_pipes, uint32_t& chunk_pixels)
 {
     const uint64_t n = f->n_local ? f->n_local : 1;
-    if (!f->state_limit_mb) return (uint32_t)n;
-    const uint64_t per_pixel = (uint64_t)(slots ? slots : 1u) * bytes_per_path(f->max_bounces);
-    const uint64_t limit = (uint64_t)f->state_limit_mb << 20;
-    if (n * per_pixel <= limit) return (uint32_t)n;
-    uint64_t c = (limit / per_pixel) & ~4095ull;
-    if (c < 4096) c = 4096;
-    return (uint32_t)(c < n ? c : n);
+    slots = slots ? slots : 1u;
+    n_pipes = 1;
+    if (f->pipelines > 1 && slots >= 2 && n * slots >= 4000000ull) n_pipes = f->pipelines < RT_MAX_PIPES ? f->pipelines : RT_MAX_PIPES;
+    uint64_t c = (n + n_pipes - 1) / n_pipes;                        // pixels per chunk without a memory limit
+    if (n_pipes > 1) c = (c + 63ull) & ~63ull;
+    if (f->state_limit_mb)
+    {
+        const uint64_t per_pixel = (uint64_t)slots * bytes_per_path(f->max_bounces);
+        const uint64_t limit = ((uint64_t)f->state_limit_mb << 20) / n_pipes;
+        if (c * per_pixel > limit)
+        {
+            c = (limit / per_pixel) & ~4095ull;
+            if (c < 4096) c = 4096;
+        }
+    }
+    chunk_pixels = (uint32_t)(c < n ? c : n);
+    if ((uint64_t)chunk_pixels * n_pipes > n + chunk_pixels) n_pipes = (uint32_t)((n + chunk_pixels - 1) / chunk_pixels);
+}
+
+uint32_t chunk_for(const rt_frame* f, uint32_t slots)
+{
+    uint32_t np, c;
+    chunk_plan(f, slots, np, c);
+    return c;
 }
 
 int alloc_path_buffers(rt_frame* f, uint32_t slots)
 {
     rt_ctx* ctx = f->ctx;
     free_path_buffers(f);
-    // test hook (tests/test_gpu_parity.py): pretend the device cannot hold more than N samples in flight
+    // test hook (tests/test_gpu_headline_parity.py): pretend the device cannot hold more than N samples in flight
     if (f->debug_alloc_limit && slots > f->debug_alloc_limit)
         return fail(ctx, "out of device memory for the per-path buffers (RT_OPT_DEBUG_ALLOC_LIMIT)");
     f->slots = slots ? slots : 1u;
-    f->chunk_pixels = chunk_for(f, f->slots);
-    f->chunk_base = 0;
-    f->chunk_count = 0;
+    chunk_plan(f, f->slots, f->n_pipes, f->chunk_pixels);
+    f->p = &f->ps[0];
     uint64_t paths = (uint64_t)f->chunk_pixels * f->slots;
     if (paths > 0xFFFFFFF0ull) return fail(ctx, "samples in flight x tile pixels exceeds the 32-bit path-id range");
     f->log_stride = (uint32_t)paths;
     f->log_entries = 2u * (f->max_bounces + 1u);
     size_t q = (size_t)(paths + 4) * sizeof(float4);   // +4: the unified 64-byte fetch of k_trace reads o4[i+2] / d4[i+2]
-    void** ptrs[] = {(void**)&f->o4[0], (void**)&f->o4[1], (void**)&f->d4[0], (void**)&f->d4[1], (void**)&f->iv4[0],
-        (void**)&f->iv4[1], (void**)&f->thr[0], (void**)&f->thr[1], (void**)&f->hits, (void**)&f->sh_o4,
-        (void**)&f->sh_d4, (void**)&f->sh_iv4};
     bool ok = true;
-    for (void** p : ptrs) ok = ok && hipMalloc(p, q) == hipSuccess;
-    ok = ok && hipMalloc((void**)&f->rlog, (size_t)f->log_entries * paths * sizeof(float4)) == hipSuccess;
-    ok = ok && hipMalloc((void**)&f->cnt, (size_t)paths * sizeof(uint32_t)) == hipSuccess;
-    ok = ok && hipMalloc((void**)&f->slow_list, (size_t)(paths + 64) * sizeof(uint32_t)) == hipSuccess;
+    for (uint32_t i = 0; i < f->n_pipes && ok; ++i)
+    {
+        PathPipe& pp = f->ps[i];
+        void** ptrs[] = {(void**)&pp.o4[0], (void**)&pp.o4[1], (void**)&pp.d4[0], (void**)&pp.d4[1], (void**)&pp.iv4[0],
+            (void**)&pp.iv4[1], (void**)&pp.thr[0], (void**)&pp.thr[1], (void**)&pp.hits, (void**)&pp.sh_o4,
+            (void**)&pp.sh_d4, (void**)&pp.sh_iv4};
+        for (void** p : ptrs) ok = ok && hipMalloc(p, q) == hipSuccess;
+        ok = ok && hipMalloc((void**)&pp.rlog, (size_t)f->log_entries * paths * sizeof(float4)) == hipSuccess;
+        ok = ok && hipMalloc((void**)&pp.cnt, (size_t)paths * sizeof(uint32_t)) == hipSuccess;
+        ok = ok && hipMalloc((void**)&pp.slow_list, (size_t)(paths + 64) * sizeof(uint32_t)) == hipSuccess;
+        // ordered on the context's stream: the pipes' streams wait for it before their first launch (fork_pipes)
+        ok = ok && hipMemsetAsync(pp.cnt, 0, (size_t)paths * sizeof(uint32_t), ctx->stream) == hipSuccess;
+        pp.cur_slots = 0;
+        pp.chunk_base = 0;
+        pp.chunk_count = 0;
+        pp.shadow_pending = false;
+    }
     if (!ok)
     {
         free_path_buffers(f);
         (void)hipGetLastError();      // the failed hipMalloc is handled here: do not let it surface at the next launch check
         return fail(ctx, "out of device memory for the per-path buffers");
     }
-    if (hipMemsetAsync(f->cnt, 0, (size_t)paths * sizeof(uint32_t), ctx->stream) != hipSuccess)
-        return fail(ctx, "hipMemsetAsync failed");
-    f->cur_slots = 0;
-    f->shadow_pending = false;
+    return RT_OK;
+}
+
+// Cross-stream ordering.  fork: the pipes' own streams wait for everything enqueued on the context's stream
+// so far; join: the context's stream waits for everything the pipes have been given.
+int fork_pipes(rt_frame* f)
+{
+    rt_ctx* ctx = f->ctx;
+    if (f->n_pipes <= 1) return RT_OK;
+    HIPCHK(ctx, hipEventRecord(f->ps[0].done, ctx->stream));
+    for (uint32_t i = 1; i < f->n_pipes; ++i) HIPCHK(ctx, hipStreamWaitEvent(f->ps[i].stream, f->ps[0].done, 0));
+    return RT_OK;
+}
+
+int join_pipes(rt_frame* f)
+{
+    rt_ctx* ctx = f->ctx;
+    for (uint32_t i = 1; i < RT_MAX_PIPES; ++i)
+    {
+        if (!f->ps[i].stream) continue;
+        HIPCHK(ctx, hipEventRecord(f->ps[i].done, f->ps[i].stream));
+        HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, f->ps[i].done, 0));
+    }
+    return RT_OK;
+}
+
+// stream, event, counters and spill area of pipes 0 .. count-1 (created once, kept for the frame's life)
+int ensure_pipe_resources(rt_frame* f, uint32_t count)
+{
+    rt_ctx* ctx = f->ctx;
+    if (count > RT_MAX_PIPES) count = RT_MAX_PIPES;
+    // worst case over the kernel variants: 32 one-wave blocks per CU, 8-entry LDS stack
+    const size_t spill_bytes = (size_t)ctx->prop.multiProcessorCount * 32 * 64 * (RT_W4_STACK_MAX - 8) * sizeof(uint2);
+    for (uint32_t i = 0; i < (count ? count : 1u); ++i)
+    {
+        PathPipe& q = f->ps[i];
+        if (!q.stream)
+        {
+            if (i == 0) q.stream = ctx->stream;
+            else HIPCHK(ctx, hipStreamCreateWithFlags(&q.stream, hipStreamNonBlocking));
+        }
+        if (!q.done) HIPCHK(ctx, hipEventCreateWithFlags(&q.done, hipEventDisableTiming));
+        if (!q.counters)
+        {
+            HIPCHK(ctx, hipMalloc((void**)&q.counters, sizeof(DCounters)));
+            HIPCHK(ctx, hipMemsetAsync(q.counters, 0, sizeof(DCounters), ctx->stream));
+        }
+        if (!q.spill) HIPCHK(ctx, hipMalloc((void**)&q.spill, spill_bytes));
+    }
     return RT_OK;
 }
 
@@ -720,7 +814,7 @@ int ensure_slots(rt_frame* f, uint32_t want)
     if (want > cap) want = cap;
     if (want <= f->slots && 2u * (f->max_bounces + 1u) <= f->log_entries && f->chunk_pixels == chunk_for(f, f->slots))
         return RT_OK;
-    if (flush_log(f) != RT_OK) return RT_ERROR;
+    if (flush_log(f) != RT_OK || join_pipes(f) != RT_OK) return RT_ERROR;
     HIPCHK(f->ctx, hipStreamSynchronize(f->ctx->stream));
     uint32_t keep = f->slots < cap ? f->slots : cap;
     uint32_t n = want > keep ? want : keep;
@@ -739,14 +833,14 @@ int ensure_slots(rt_frame* f, uint32_t want)
 int flush_log(rt_frame* f)
 {
     rt_ctx* ctx = f->ctx;
-    if (f->cur_slots == 0 || f->n_local == 0 || f->chunk_count == 0) { f->cur_slots = 0; return RT_OK; }
-    if (f->shadow_pending)
+    if (f->p->cur_slots == 0 || f->n_local == 0 || f->p->chunk_count == 0) { f->p->cur_slots = 0; return RT_OK; }
+    if (f->p->shadow_pending)
         return fail(ctx, "radiance requested between rt_shade and rt_intersect_shadow (direct samples still tentative)");
-    uint32_t blocks = (f->chunk_count + 255u) / 256u;
-    hipLaunchKernelGGL(k_flush, dim3(blocks), dim3(256), 0, ctx->stream, f->radiance + f->chunk_base, (const float4*)f->rlog, f->cnt,
-        f->chunk_count, f->cur_slots, f->log_stride, f->chunk_pixels);
+    uint32_t blocks = (f->p->chunk_count + 255u) / 256u;
+    hipLaunchKernelGGL(k_flush, dim3(blocks), dim3(256), 0, f->p->stream, f->radiance + f->p->chunk_base, (const float4*)f->p->rlog, f->p->cnt,
+        f->p->chunk_count, f->p->cur_slots, f->log_stride, f->chunk_pixels);
     if (hipGetLastError() != hipSuccess) return fail(ctx, "k_flush launch failed");
-    f->cur_slots = 0;
+    f->p->cur_slots = 0;
     return RT_OK;
 }
 
@@ -754,9 +848,9 @@ int flush_log(rt_frame* f)
 // keep the sample open -- later contributions append again from entry 0.
 int flush_log_keep(rt_frame* f)
 {
-    uint32_t keep = f->cur_slots;
+    uint32_t keep = f->p->cur_slots;
     int rc = flush_log(f);
-    f->cur_slots = keep;
+    f->p->cur_slots = keep;
     return rc;
 }
 } // namespace
@@ -788,10 +882,8 @@ int rt_frame_create(rt_ctx* ctx, const rt_frame_desc* fd, rt_frame** out)
     size_t n = f->n_local ? f->n_local : 1;
     f->trace_blocks = (uint32_t)ctx->prop.multiProcessorCount * 12u;
     f->trace_blocks = (f->trace_blocks + 7u) & ~7u;
-    for (int i = 0; i < 2; ++i) { f->o4[i] = nullptr; f->d4[i] = nullptr; f->iv4[i] = nullptr; f->thr[i] = nullptr; }
-    f->hits = nullptr; f->sh_o4 = nullptr; f->sh_d4 = nullptr; f->sh_iv4 = nullptr; f->radiance = nullptr;
+    f->radiance = nullptr;
     f->resolved = nullptr;
-    f->counters = nullptr; f->spill = nullptr;
     bool ok = true;
     ok = ok && hipMalloc((void**)&f->radiance, n * sizeof(float4)) == hipSuccess;
     ok = ok && hipMalloc((void**)&f->resolved, n * sizeof(float4)) == hipSuccess;
@@ -808,10 +900,7 @@ int rt_frame_create(rt_ctx* ctx, const rt_frame_desc* fd, rt_frame** out)
     ok = ok && hipMemsetAsync(f->prev_radiance, 0, n * sizeof(float4), ctx->stream) == hipSuccess;
     ok = ok && hipMemsetAsync(f->prev_depth, 0, n * sizeof(float), ctx->stream) == hipSuccess;
     ok = ok && alloc_path_buffers(f, 1) == RT_OK;     // grows on demand (ensure_slots)
-    ok = ok && hipMalloc((void**)&f->counters, sizeof(DCounters)) == hipSuccess;
-    // worst case over the kernel variants: 32 one-wave blocks per CU, 8-entry LDS stack
-    size_t spill_bytes = (size_t)ctx->prop.multiProcessorCount * 32 * 64 * (RT_W4_STACK_MAX - 8) * sizeof(uint2);
-    ok = ok && hipMalloc((void**)&f->spill, spill_bytes) == hipSuccess;
+    ok = ok && ensure_pipe_resources(f, f->pipelines) == RT_OK;
     if (!ok)
     {
         rt_frame_destroy(f);
@@ -829,11 +918,20 @@ int rt_frame_destroy(rt_frame* f)
 {
     if (!f) return RT_OK;
     (void)hipSetDevice(f->ctx->device);
+    for (PathPipe& q : f->ps) if (q.stream) (void)hipStreamSynchronize(q.stream);
     (void)hipStreamSynchronize(f->ctx->stream);
     free_path_buffers(f);
-    void* ptrs[] = {f->radiance, f->resolved, f->counters, f->spill, f->aov_buf.diffuse_albedo, f->aov_buf.depth,
+    void* ptrs[] = {f->radiance, f->resolved, f->aov_buf.diffuse_albedo, f->aov_buf.depth,
         f->aov_buf.normal, f->aov_buf.velocity, f->prev_radiance, f->prev_depth};
     for (void* p : ptrs) if (p) (void)hipFree(p);
+    for (uint32_t i = 0; i < RT_MAX_PIPES; ++i)
+    {
+        PathPipe& q = f->ps[i];
+        if (q.counters) (void)hipFree(q.counters);
+        if (q.spill) (void)hipFree(q.spill);
+        if (q.done) (void)hipEventDestroy(q.done);
+        if (i > 0 && q.stream) (void)hipStreamDestroy(q.stream);
+    }
     for (auto& s : f->spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
     for (auto e : f->event_pool) (void)hipEventDestroy(e);
     delete f;
@@ -904,6 +1002,17 @@ int rt_set_option(rt_frame* f, int option, uint32_t value)
     case RT_OPT_TRACE_PACKET_BOUNCES: f->packet_bounces = value; return RT_OK;
     case RT_OPT_TRACE_SELECT_FORM_BOX: f->select_form_box = value ? RT_SIGN_SLOW : 0u; return RT_OK;
     case RT_OPT_TRACE_TUNE: f->trace_tune = value; return RT_OK;
+    case RT_OPT_PIPELINES:
+        if (value == 0 || value > RT_MAX_PIPES) return fail(f->ctx, "rt_set_option: pipelines must be 1..RT_MAX_PIPES");
+        if (value != f->pipelines)
+        {
+            if (flush_log(f) != RT_OK || join_pipes(f) != RT_OK) return RT_ERROR;
+            HIPCHK(f->ctx, hipStreamSynchronize(f->ctx->stream));
+            if (ensure_pipe_resources(f, value) != RT_OK) return RT_ERROR;
+            f->pipelines = value;
+            return alloc_path_buffers(f, f->slots);
+        }
+        return RT_OK;
     case RT_OPT_PATH_STATE_LIMIT_MB:
         if (value != f->state_limit_mb)
         {
@@ -949,12 +1058,12 @@ struct KernelSpan
         if (!f->profile) return;
         auto get = [&]() { hipEvent_t e = nullptr; if (!f->event_pool.empty()) { e = f->event_pool.back(); f->event_pool.pop_back(); } else (void)hipEventCreate(&e); return e; };
         a = get(); b = get();
-        (void)hipEventRecord(a, f->ctx->stream);
+        (void)hipEventRecord(a, f->p->stream);
     }
     ~KernelSpan()
     {
         if (!a) return;
-        (void)hipEventRecord(b, f->ctx->stream);
+        (void)hipEventRecord(b, f->p->stream);
         f->spans.push_back({a, b, cls});
     }
 };
@@ -982,9 +1091,9 @@ void launch_trace_sm(rt_frame* f, const float4* o4, const float4* d4, const floa
     if (per_cu > 32u) per_cu = 32u;
     if (f->trace_waves_per_cu && f->trace_waves_per_cu < per_cu) per_cu = f->trace_waves_per_cu;
     uint32_t blocks = ((uint32_t)ctx->prop.multiProcessorCount * per_cu + 7u) & ~7u;
-    hipLaunchKernelGGL((k_trace<SHADOW, STACK>), dim3(blocks), dim3(64), 0, ctx->stream, ctx->scene.d, o4, d4, iv4, count,
-        &f->counters->head[SHADOW ? 1 : 0][0], SHADOW ? (float4*)nullptr : f->hits,
-        SHADOW ? f->rlog : (float4*)nullptr, f->log_stride, f->select_form_box, f->spill);
+    hipLaunchKernelGGL((k_trace<SHADOW, STACK>), dim3(blocks), dim3(64), 0, f->p->stream, ctx->scene.d, o4, d4, iv4, count,
+        &f->p->counters->head[SHADOW ? 1 : 0][0], SHADOW ? (float4*)nullptr : f->p->hits,
+        SHADOW ? f->p->rlog : (float4*)nullptr, f->log_stride, f->select_form_box, f->p->spill);
 }
 
 // k_trace2: separate wave-uniform loops (trace_kernels.h).  Same grid sizing as launch_trace_sm.
@@ -1000,10 +1109,10 @@ void launch_trace2(rt_frame* f, const float4* o4, const float4* d4, const float4
     uint32_t tune = f->trace_tune ? f->trace_tune : RT_TRACE2_DEFAULT_TUNE;
     if ((tune & 0xFFu) > 64u) tune = (tune & ~0xFFu) | 64u;
     if ((tune & 0xFFu) == 0u) tune |= 1u;
-    hipLaunchKernelGGL((k_trace2<SHADOW, STACK>), dim3(blocks), dim3(64), 0, ctx->stream, ctx->scene.d, o4, d4, iv4, count,
-        &f->counters->head[SHADOW ? 1 : 0][0], SHADOW ? (float4*)nullptr : f->hits,
-        SHADOW ? f->rlog : (float4*)nullptr, f->log_stride, f->select_form_box, f->spill, tune, (const uint32_t*)nullptr,
-        &f->counters->stack_spills);
+    hipLaunchKernelGGL((k_trace2<SHADOW, STACK>), dim3(blocks), dim3(64), 0, f->p->stream, ctx->scene.d, o4, d4, iv4, count,
+        &f->p->counters->head[SHADOW ? 1 : 0][0], SHADOW ? (float4*)nullptr : f->p->hits,
+        SHADOW ? f->p->rlog : (float4*)nullptr, f->log_stride, f->select_form_box, f->p->spill, tune, (const uint32_t*)nullptr,
+        &f->p->counters->stack_spills);
 }
 
 // k_trace_w4 over the 4-wide quantized tree, then k_trace2 over the (normally empty) list of rays it left out
@@ -1019,14 +1128,14 @@ void launch_trace_w4(rt_frame* f, const float4* o4, const float4* d4, const floa
     if ((tune & 0xFFu) > 64u) tune = (tune & ~0xFFu) | 64u;
     if ((tune & 0xFFu) == 0u) tune |= 1u;
     const int s = SHADOW ? 1 : 0;
-    hipLaunchKernelGGL((k_trace_w4<SHADOW, STACK>), dim3(blocks), dim3(64), 0, ctx->stream, ctx->scene.d, o4, d4, iv4, count,
-        &f->counters->head[s][0], SHADOW ? (float4*)nullptr : f->hits, SHADOW ? f->rlog : (float4*)nullptr, f->log_stride,
-        f->spill, tune, f->slow_list, &f->counters->slow_count[s], &f->counters->stack_spills);
+    hipLaunchKernelGGL((k_trace_w4<SHADOW, STACK>), dim3(blocks), dim3(64), 0, f->p->stream, ctx->scene.d, o4, d4, iv4, count,
+        &f->p->counters->head[s][0], SHADOW ? (float4*)nullptr : f->p->hits, SHADOW ? f->p->rlog : (float4*)nullptr, f->log_stride,
+        f->p->spill, tune, f->p->slow_list, &f->p->counters->slow_count[s], &f->p->counters->stack_spills);
     uint32_t blocks2 = ((uint32_t)ctx->prop.multiProcessorCount * 8u + 7u) & ~7u;
-    hipLaunchKernelGGL((k_trace2<SHADOW, 12>), dim3(blocks2), dim3(64), 0, ctx->stream, ctx->scene.d, o4, d4, iv4,
-        (const uint32_t*)&f->counters->slow_count[s], &f->counters->slow_head[s][0], SHADOW ? (float4*)nullptr : f->hits,
-        SHADOW ? f->rlog : (float4*)nullptr, f->log_stride, f->select_form_box, f->spill, tune, (const uint32_t*)f->slow_list,
-        &f->counters->stack_spills);
+    hipLaunchKernelGGL((k_trace2<SHADOW, 12>), dim3(blocks2), dim3(64), 0, f->p->stream, ctx->scene.d, o4, d4, iv4,
+        (const uint32_t*)&f->p->counters->slow_count[s], &f->p->counters->slow_head[s][0], SHADOW ? (float4*)nullptr : f->p->hits,
+        SHADOW ? f->p->rlog : (float4*)nullptr, f->log_stride, f->select_form_box, f->p->spill, tune, (const uint32_t*)f->p->slow_list,
+        &f->p->counters->stack_spills);
 }
 
 // Coherent launches (primary rays): packet traversal, node records through the scalar cache.
@@ -1040,9 +1149,9 @@ void launch_trace_packet(rt_frame* f, const float4* o4, const float4* d4, const 
     uint32_t per_cu = f->trace_waves_per_cu ? f->trace_waves_per_cu : 32u;
     if (per_cu > 32u) per_cu = 32u;
     uint32_t blocks = ((uint32_t)ctx->prop.multiProcessorCount * per_cu + 7u) & ~7u;
-    hipLaunchKernelGGL((k_trace_packet<SHADOW>), dim3(blocks), dim3(64), 0, ctx->stream, ctx->scene.d, o4, d4, iv4, count,
-        &f->counters->head[SHADOW ? 1 : 0][0], SHADOW ? (float4*)nullptr : f->hits,
-        SHADOW ? f->rlog : (float4*)nullptr, f->log_stride, f->select_form_box);
+    hipLaunchKernelGGL((k_trace_packet<SHADOW>), dim3(blocks), dim3(64), 0, f->p->stream, ctx->scene.d, o4, d4, iv4, count,
+        &f->p->counters->head[SHADOW ? 1 : 0][0], SHADOW ? (float4*)nullptr : f->p->hits,
+        SHADOW ? f->p->rlog : (float4*)nullptr, f->log_stride, f->select_form_box);
 }
 
 template <bool SHADOW>
@@ -1060,7 +1169,7 @@ void launch_trace(rt_frame* f, const float4* o4, const float4* d4, const float4*
         // ~2 M paths up the persistent kernels win, and of those the 4-wide quantized tree:
         // 4214 (k_trace) / 4400 (k_trace2) / 5042 (k_trace_w4) Mrays/s on the headline workload
         // (profiles/r02_w4_tune_sweep.log)
-        uint64_t paths = (uint64_t)f->chunk_count * (f->cur_slots ? f->cur_slots : 1u);
+        uint64_t paths = (uint64_t)f->p->chunk_count * (f->p->cur_slots ? f->p->cur_slots : 1u);
         variant = paths >= 2000000ull ? 10u : 0u;
     }
     if ((variant == 10u || variant == 11u) && (!ctx->scene.d.wnodes && !(ctx->scene.d.w_entry_ref & RT_LEAF_BIT))) variant = 8u;
@@ -1070,8 +1179,8 @@ void launch_trace(rt_frame* f, const float4* o4, const float4* d4, const float4*
     {
     case 0:
         hipLaunchKernelGGL(k_trace_v1<SHADOW>, dim3(f->trace_waves_per_cu ? (((uint32_t)ctx->prop.multiProcessorCount *
-            (f->trace_waves_per_cu < 13u ? f->trace_waves_per_cu : 13u) + 7u) & ~7u) : f->trace_blocks), dim3(64), 0, ctx->stream, ctx->scene.d, o4, d4,
-            iv4, count, SHADOW ? (float4*)nullptr : f->hits, SHADOW ? f->rlog : (float4*)nullptr, f->log_stride, f->select_form_box, f->spill);
+            (f->trace_waves_per_cu < 13u ? f->trace_waves_per_cu : 13u) + 7u) & ~7u) : f->trace_blocks), dim3(64), 0, f->p->stream, ctx->scene.d, o4, d4,
+            iv4, count, SHADOW ? (float4*)nullptr : f->p->hits, SHADOW ? f->p->rlog : (float4*)nullptr, f->log_stride, f->select_form_box, f->p->spill);
         break;
     case 1: launch_trace_sm<SHADOW, 16>(f, o4, d4, iv4, count); break;
     case 2: launch_trace_sm<SHADOW, 24>(f, o4, d4, iv4, count); break;
@@ -1097,16 +1206,22 @@ int rt_reset(rt_frame* f)                               // CLPathTraceIntegrator
     if (!f) return fail(nullptr, "rt_reset: frame is NULL");
     rt_ctx* ctx = f->ctx;
     (void)hipSetDevice(ctx->device);
+    if (join_pipes(f) != RT_OK) return RT_ERROR;
     if (!f->denoiser) f->sample_count = 0;   // Reset() keeps the frame index while denoising (:499-504)
-    f->prev_bounces = 0;
-    f->cur_slots = 0;
-    f->chunk_base = 0;
-    f->chunk_count = 0;
-    f->fold_accumulates = 0;
-    f->shadow_pending = false;
-    HIPCHK(ctx, hipMemsetAsync(f->cnt, 0, (size_t)f->log_stride * sizeof(uint32_t), ctx->stream));
+    f->p = &f->ps[0];
+    for (uint32_t i = 0; i < RT_MAX_PIPES; ++i)
+    {
+        PathPipe& q = f->ps[i];
+        q.prev_bounces = 0;
+        q.cur_slots = 0;
+        q.chunk_base = 0;
+        q.chunk_count = 0;
+        q.fold_accumulates = 0;
+        q.shadow_pending = false;
+        if (q.cnt) HIPCHK(ctx, hipMemsetAsync(q.cnt, 0, (size_t)f->log_stride * sizeof(uint32_t), ctx->stream));
+        if (q.counters) HIPCHK(ctx, hipMemsetAsync(q.counters, 0, sizeof(DCounters), ctx->stream));
+    }
     HIPCHK(ctx, hipMemsetAsync(f->radiance, 0, (size_t)(f->n_local ? f->n_local : 1) * sizeof(float4), ctx->stream));
-    HIPCHK(ctx, hipMemsetAsync(f->counters, 0, sizeof(DCounters), ctx->stream));
     return RT_OK;
 }
 
@@ -1116,25 +1231,25 @@ namespace
 {
 // Primary rays for `n_slots` consecutive samples (sample indices sample_count ..
 // sample_count + n_slots - 1) in one launch; they then travel through the same queues.
-int generate_rays(rt_frame* f, uint32_t n_slots, uint32_t chunk_base = 0)
+int generate_rays(rt_frame* f, uint32_t n_slots, uint32_t chunk_base = 0, bool later_chunk_on_this_pipe = false)
 {
     rt_ctx* ctx = f->ctx;
-    if (f->cur_slots != 0) return fail(ctx, "rt_generate_rays: the previous sample was not advanced (rt_advance_sample)");
+    if (f->p->cur_slots != 0) return fail(ctx, "rt_generate_rays: the previous sample was not advanced (rt_advance_sample)");
     if (chunk_base == 0 && ensure_slots(f, n_slots) != RT_OK) return RT_ERROR;
     if (n_slots > f->slots) return fail(ctx, "rt_generate_rays: more samples than the frame can keep in flight");
     if (chunk_base >= (f->n_local ? f->n_local : 1u)) return fail(ctx, "rt_generate_rays: chunk outside the tile");
-    f->chunk_base = chunk_base;
-    f->chunk_count = f->n_local - chunk_base < f->chunk_pixels ? f->n_local - chunk_base : f->chunk_pixels;
+    f->p->chunk_base = chunk_base;
+    f->p->chunk_count = f->n_local - chunk_base < f->chunk_pixels ? f->n_local - chunk_base : f->chunk_pixels;
     float tan_half_fov = rt_tanf(0.5f * f->camera.fov);  // raygeneration.cl:108, uniform -> host
-    uint32_t blocks = (f->chunk_count * n_slots + 255u) / 256u;
+    uint32_t blocks = (f->p->chunk_count * n_slots + 255u) / 256u;
     if (blocks == 0) blocks = 1;
     KernelSpan span(f, 0);
-    hipLaunchKernelGGL(k_raygen, dim3(blocks), dim3(256), 0, ctx->stream, f->tile, f->camera, f->sample_count, n_slots,
-        tan_half_fov, f->prev_bounces, f->o4[0], f->d4[0], f->iv4[0], f->thr[0], f->counters, f->chunk_base, f->chunk_count,
-        f->chunk_pixels, f->fold_accumulates);
-    f->fold_accumulates = chunk_base != 0 ? 1u : 0u;     // what the NEXT fold does with this sequence's counters
-    f->prev_bounces = f->max_bounces;
-    f->cur_slots = n_slots;
+    hipLaunchKernelGGL(k_raygen, dim3(blocks), dim3(256), 0, f->p->stream, f->tile, f->camera, f->sample_count, n_slots,
+        tan_half_fov, f->p->prev_bounces, f->p->o4[0], f->p->d4[0], f->p->iv4[0], f->p->thr[0], f->p->counters, f->p->chunk_base, f->p->chunk_count,
+        f->chunk_pixels, f->p->fold_accumulates);
+    f->p->fold_accumulates = later_chunk_on_this_pipe ? 1u : 0u;     // what the NEXT fold does with this sequence's counters
+    f->p->prev_bounces = f->max_bounces;
+    f->p->cur_slots = n_slots;
     HIPCHK(ctx, hipGetLastError());
     return RT_OK;
 }
@@ -1157,7 +1272,7 @@ int rt_intersect(rt_frame* f, uint32_t bounce)          // IntersectRays, :522-5
     if (bounce > RT_MAX_BOUNCES_LIMIT) return fail(ctx, "rt_intersect: bounce out of range");
     uint32_t in = bounce & 1u;
     KernelSpan span(f, 1);
-    launch_trace<false>(f, f->o4[in], f->d4[in], f->iv4[in], &f->counters->queue[bounce], bounce);
+    launch_trace<false>(f, f->p->o4[in], f->p->d4[in], f->p->iv4[in], &f->p->counters->queue[bounce], bounce);
     HIPCHK(ctx, hipGetLastError());
     return RT_OK;
 }
@@ -1173,30 +1288,30 @@ int rt_shade(rt_frame* f, uint32_t bounce)              // ShadeMissedRays + Sha
     if (bounce > RT_MAX_BOUNCES_LIMIT) return fail(ctx, "rt_shade: bounce out of range");
     uint32_t in = bounce & 1u, out = (bounce + 1u) & 1u;
     ShadeArgs a;
-    a.in_o4 = f->o4[in]; a.in_d4 = f->d4[in]; a.in_thr = f->thr[in]; a.hits = f->hits;
-    a.out_o4 = f->o4[out]; a.out_d4 = f->d4[out]; a.out_iv4 = f->iv4[out]; a.out_thr = f->thr[out];
-    a.sh_o4 = f->sh_o4; a.sh_d4 = f->sh_d4; a.sh_iv4 = f->sh_iv4;
-    a.rlog = f->rlog; a.cnt = f->cnt; a.counters = f->counters;
+    a.in_o4 = f->p->o4[in]; a.in_d4 = f->p->d4[in]; a.in_thr = f->p->thr[in]; a.hits = f->p->hits;
+    a.out_o4 = f->p->o4[out]; a.out_d4 = f->p->d4[out]; a.out_iv4 = f->p->iv4[out]; a.out_thr = f->p->thr[out];
+    a.sh_o4 = f->p->sh_o4; a.sh_d4 = f->p->sh_d4; a.sh_iv4 = f->p->sh_iv4;
+    a.rlog = f->p->rlog; a.cnt = f->p->cnt; a.counters = f->p->counters;
     a.bn_sobol = ctx->blue_noise; a.bn_scramble = ctx->blue_noise ? ctx->blue_noise + 65536 : nullptr;
     a.bn_rank = ctx->blue_noise ? ctx->blue_noise + 65536 + 131072 : nullptr;
     a.bounce = bounce; a.sample_base = f->sample_count;
     a.emit_outgoing = (f->drop_last && bounce >= f->max_bounces) ? 0u : 1u;
     a.n_local = f->chunk_pixels ? f->chunk_pixels : 1; a.log_stride = f->log_stride;
-    a.pix_base = f->chunk_base;
+    a.pix_base = f->p->chunk_base;
     if (2u * (bounce + 1u) > f->log_entries) return fail(ctx, "rt_shade: bounce beyond the configured max_bounces");
-    uint32_t blocks = (f->chunk_count * (f->cur_slots ? f->cur_slots : 1u) + RT_SHADE_BLOCK - 1u) / RT_SHADE_BLOCK;
+    uint32_t blocks = (f->p->chunk_count * (f->p->cur_slots ? f->p->cur_slots : 1u) + RT_SHADE_BLOCK - 1u) / RT_SHADE_BLOCK;
     if (blocks == 0) blocks = 1;
-    f->shadow_pending = true;
+    f->p->shadow_pending = true;
     KernelSpan span(f, 2);
     const bool blue = f->sampler == 1;   // kernel variants are AOT (the reference rebuilds with -D..., :267-285)
     if (f->white_furnace && blue)
-        hipLaunchKernelGGL((k_shade<true, true>), dim3(blocks), dim3(RT_SHADE_BLOCK), 0, ctx->stream, ctx->scene.d, f->tile, a);
+        hipLaunchKernelGGL((k_shade<true, true>), dim3(blocks), dim3(RT_SHADE_BLOCK), 0, f->p->stream, ctx->scene.d, f->tile, a);
     else if (f->white_furnace)
-        hipLaunchKernelGGL((k_shade<true, false>), dim3(blocks), dim3(RT_SHADE_BLOCK), 0, ctx->stream, ctx->scene.d, f->tile, a);
+        hipLaunchKernelGGL((k_shade<true, false>), dim3(blocks), dim3(RT_SHADE_BLOCK), 0, f->p->stream, ctx->scene.d, f->tile, a);
     else if (blue)
-        hipLaunchKernelGGL((k_shade<false, true>), dim3(blocks), dim3(RT_SHADE_BLOCK), 0, ctx->stream, ctx->scene.d, f->tile, a);
+        hipLaunchKernelGGL((k_shade<false, true>), dim3(blocks), dim3(RT_SHADE_BLOCK), 0, f->p->stream, ctx->scene.d, f->tile, a);
     else
-        hipLaunchKernelGGL((k_shade<false, false>), dim3(blocks), dim3(RT_SHADE_BLOCK), 0, ctx->stream, ctx->scene.d, f->tile, a);
+        hipLaunchKernelGGL((k_shade<false, false>), dim3(blocks), dim3(RT_SHADE_BLOCK), 0, f->p->stream, ctx->scene.d, f->tile, a);
     HIPCHK(ctx, hipGetLastError());
     return RT_OK;
 }
@@ -1206,8 +1321,8 @@ int rt_intersect_shadow(rt_frame* f, uint32_t bounce)   // IntersectShadowRays +
     FRAME_PROLOGUE(f, "rt_intersect_shadow");
     if (bounce > RT_MAX_BOUNCES_LIMIT) return fail(ctx, "rt_intersect_shadow: bounce out of range");
     KernelSpan span(f, 3);
-    launch_trace<true>(f, f->sh_o4, f->sh_d4, f->sh_iv4, &f->counters->shadow[bounce], bounce);
-    f->shadow_pending = false;
+    launch_trace<true>(f, f->p->sh_o4, f->p->sh_d4, f->p->sh_iv4, &f->p->counters->shadow[bounce], bounce);
+    f->p->shadow_pending = false;
     HIPCHK(ctx, hipGetLastError());
     return RT_OK;
 }
@@ -1216,12 +1331,12 @@ int rt_compute_aovs(rt_frame* f)                        // ComputeAOVs, :541-562
 {
     FRAME_PROLOGUE(f, "rt_compute_aovs");
     if (f->aov == 0 && !f->denoiser) return RT_OK;      // outputs unobservable: skip the work
-    if (f->cur_slots != 1) return fail(ctx, "rt_compute_aovs: AOVs need one sample in flight (use the stage API or rt_integrate with the denoiser/AOV option set)");
+    if (f->p->cur_slots != 1) return fail(ctx, "rt_compute_aovs: AOVs need one sample in flight (use the stage API or rt_integrate with the denoiser/AOV option set)");
     if (f->n_local == 0) return RT_OK;
     uint32_t blocks = (f->n_local + 255u) / 256u;
     hipLaunchKernelGGL(k_aov_clear, dim3(blocks), dim3(256), 0, ctx->stream, f->aov_buf, f->n_local);
-    hipLaunchKernelGGL(k_aov, dim3(blocks), dim3(256), 0, ctx->stream, ctx->scene.d, (const float4*)f->o4[0],
-        (const float4*)f->d4[0], (const float4*)f->hits, (const uint32_t*)&f->counters->queue[0], f->camera, f->prev_camera,
+    hipLaunchKernelGGL(k_aov, dim3(blocks), dim3(256), 0, ctx->stream, ctx->scene.d, (const float4*)f->p->o4[0],
+        (const float4*)f->p->d4[0], (const float4*)f->p->hits, (const uint32_t*)&f->p->counters->queue[0], f->camera, f->prev_camera,
         rt_tanf(0.5f * f->camera.fov), rt_tanf(0.5f * f->prev_camera.fov), f->aov_buf);
     HIPCHK(ctx, hipGetLastError());
     return RT_OK;
@@ -1255,7 +1370,7 @@ int rt_advance_sample(rt_frame* f)                      // AdvanceSampleCount, :
 {
     if (!f) return fail(nullptr, "rt_advance_sample: frame is NULL");
     (void)hipSetDevice(f->ctx->device);
-    uint32_t n = f->cur_slots ? f->cur_slots : 1u;
+    uint32_t n = f->p->cur_slots ? f->p->cur_slots : 1u;
     if (flush_log(f) != RT_OK) return RT_ERROR;          // radiance_buffer_ += this sample's contributions
     f->sample_count += n;
     return RT_OK;
@@ -1283,29 +1398,39 @@ int rt_integrate(rt_frame* f, uint32_t n_samples)       // n x Integrator::Integ
     if (cap == 0) cap = 1;
     if (per_frame && f->chunk_pixels < (f->n_local ? f->n_local : 1u))
         return fail(ctx, "rt_integrate: AOVs / the denoiser need the whole tile in one chunk (raise RT_OPT_PATH_STATE_LIMIT_MB)");
-    while (done < n_samples)
+    if (fork_pipes(f) != RT_OK) return RT_ERROR;
+    int rc = RT_OK;
+    while (done < n_samples && rc == RT_OK)
     {
         uint32_t batch = n_samples - done < cap ? n_samples - done : cap;
         if (per_frame) batch = 1;
-        if (f->denoiser && rt_reset(f) != RT_OK) return RT_ERROR;   // integrator.cpp:29: Reset() every frame
-        // the whole wavefront loop per chunk of pixels (one chunk unless RT_OPT_PATH_STATE_LIMIT_MB bites)
-        for (uint32_t base = 0; base < (f->n_local ? f->n_local : 1u); base += f->chunk_pixels)
+        if (f->denoiser && rt_reset(f) != RT_OK) { rc = RT_ERROR; break; }   // integrator.cpp:29: Reset() every frame
+        // The whole wavefront loop per chunk of pixels; chunk c runs on pipe c % n_pipes (its own stream), so the
+        // chunks' launches overlap each other's tails.  A chunk always lands on the same pipe: its log replays
+        // (k_flush) stay in sample order.
+        uint32_t c = 0;
+        for (uint32_t base = 0; base < (f->n_local ? f->n_local : 1u) && rc == RT_OK; base += f->chunk_pixels, ++c)
         {
-            if (generate_rays(f, batch, base) != RT_OK) return RT_ERROR;
-            for (uint32_t bounce = 0; bounce <= f->max_bounces; ++bounce)
+            f->p = &f->ps[c % f->n_pipes];
+            if (generate_rays(f, batch, base, c >= f->n_pipes) != RT_OK) { rc = RT_ERROR; break; }
+            for (uint32_t bounce = 0; bounce <= f->max_bounces && rc == RT_OK; ++bounce)
             {
-                if (rt_intersect(f, bounce) != RT_OK) return RT_ERROR;
-                if (bounce == 0 && per_frame && rt_compute_aovs(f) != RT_OK) return RT_ERROR;
-                if (rt_shade(f, bounce) != RT_OK) return RT_ERROR;
-                if (rt_intersect_shadow(f, bounce) != RT_OK) return RT_ERROR;
+                if (rt_intersect(f, bounce) != RT_OK) rc = RT_ERROR;
+                else if (bounce == 0 && per_frame && rt_compute_aovs(f) != RT_OK) rc = RT_ERROR;
+                else if (rt_shade(f, bounce) != RT_OK) rc = RT_ERROR;
+                else if (rt_intersect_shadow(f, bounce) != RT_OK) rc = RT_ERROR;
             }
-            if (base + f->chunk_pixels < f->n_local && flush_log(f) != RT_OK) return RT_ERROR;   // last chunk: rt_advance_sample
+            if (rc == RT_OK && flush_log(f) != RT_OK) rc = RT_ERROR;          // radiance_buffer_ += this chunk's contributions
         }
-        if (rt_advance_sample(f) != RT_OK) return RT_ERROR;
-        if (f->denoiser && (rt_denoise(f) != RT_OK || rt_copy_history(f) != RT_OK)) return RT_ERROR;
+        f->p = &f->ps[0];
+        if (rc != RT_OK) break;
+        f->sample_count += batch;                                            // AdvanceSampleCount, :510-514
+        if (f->denoiser && (join_pipes(f) != RT_OK || rt_denoise(f) != RT_OK || rt_copy_history(f) != RT_OK)) rc = RT_ERROR;
         done += batch;
     }
-    return RT_OK;
+    f->p = &f->ps[0];
+    if (join_pipes(f) != RT_OK) return RT_ERROR;         // whatever follows on the context's stream sees every chunk
+    return rc;
 }
 
 // ---- output ----------------------------------------------------------------
@@ -1347,21 +1472,30 @@ int rt_frame_get_stats(rt_frame* f, rt_stats* out)
     if (!f || !out) return fail(nullptr, "rt_frame_get_stats: NULL argument");
     rt_ctx* ctx = f->ctx;
     (void)hipSetDevice(ctx->device);
-    hipLaunchKernelGGL(k_fold_counters, dim3(1), dim3(64), 0, ctx->stream, f->counters, f->prev_bounces, f->fold_accumulates);
-    f->fold_accumulates = 1;       // whatever is folded next belongs to the same batch's totals unless a new batch starts
-    DCounters h;
-    HIPCHK(ctx, hipMemcpyAsync(&h, f->counters, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    out->closest_rays = h.total_closest;
-    out->shadow_rays = h.total_shadow;
+    if (join_pipes(f) != RT_OK) return RT_ERROR;
+    memset(out, 0, sizeof(*out));
+    for (uint32_t i = 0; i < RT_MAX_PIPES; ++i)              // the pipes' counters add up
+    {
+        PathPipe& q = f->ps[i];
+        if (!q.counters) continue;
+        hipLaunchKernelGGL(k_fold_counters, dim3(1), dim3(64), 0, ctx->stream, q.counters, q.prev_bounces, q.fold_accumulates);
+        q.fold_accumulates = 1;       // whatever is folded next belongs to the same batch's totals unless a new batch starts
+        DCounters h;
+        HIPCHK(ctx, hipMemcpyAsync(&h, q.counters, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        out->closest_rays += h.total_closest;
+        out->shadow_rays += h.total_shadow;
+        out->stack_spills += h.stack_spills;
+        out->slow_rays += h.slow_rays;
+        if (i < f->n_pipes)
+            for (int b = 0; b < 64; ++b) { out->last_active[b] += h.last_queue[b]; out->last_shadow[b] += h.last_shadow[b]; }
+    }
     out->samples = f->sample_count;
     out->samples_in_flight = f->slots;
     out->samples_in_flight_limit = f->slots_limit;
-    out->path_state_bytes = (uint64_t)f->log_stride * bytes_per_path(f->max_bounces);
+    out->path_state_bytes = (uint64_t)f->log_stride * bytes_per_path(f->max_bounces) * f->n_pipes;
     out->chunk_pixels = f->chunk_pixels;
-    out->stack_spills = h.stack_spills;
-    out->slow_rays = h.slow_rays;
-    for (int i = 0; i < 64; ++i) { out->last_active[i] = h.last_queue[i]; out->last_shadow[i] = h.last_shadow[i]; }
+    out->pipelines = f->n_pipes;
     return RT_OK;
 }
 
@@ -1370,6 +1504,7 @@ int rt_frame_get_profile(rt_frame* f, rt_profile* out)
     if (!f || !out) return fail(nullptr, "rt_frame_get_profile: NULL argument");
     rt_ctx* ctx = f->ctx;
     (void)hipSetDevice(ctx->device);
+    if (join_pipes(f) != RT_OK) return RT_ERROR;
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     memset(out, 0, sizeof(*out));
     double* ms[4] = {&out->ms_raygen, &out->ms_trace_closest, &out->ms_shade, &out->ms_trace_shadow};
@@ -1407,7 +1542,7 @@ int rt_frame_debug_read_queue(rt_frame* f, int which, uint32_t bounce, rt_ray* r
     (void)hipSetDevice(ctx->device);
     if (bounce > RT_MAX_BOUNCES_LIMIT + 1) return fail(ctx, "rt_frame_debug_read_queue: bounce out of range");
     DCounters h;
-    HIPCHK(ctx, hipMemcpyAsync(&h, f->counters, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(&h, f->p->counters, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     uint32_t n = which == 0 ? h.queue[bounce] : h.shadow[bounce];
     if (n > f->log_stride) return fail(ctx, "rt_frame_debug_read_queue: corrupt counter");
@@ -1415,25 +1550,25 @@ int rt_frame_debug_read_queue(rt_frame* f, int which, uint32_t bounce, rt_ray* r
     if (n == 0) return RT_OK;
     if (!rays && !pixel_indices && !payload) return RT_OK;                 // size query (two-call pattern)
     if (n > capacity) return fail(ctx, "rt_frame_debug_read_queue: the queue holds more entries than the caller's arrays");
-    const float4* so = which == 0 ? f->o4[bounce & 1u] : f->sh_o4;
-    const float4* sdir = which == 0 ? f->d4[bounce & 1u] : f->sh_d4;
+    const float4* so = which == 0 ? f->p->o4[bounce & 1u] : f->p->sh_o4;
+    const float4* sdir = which == 0 ? f->p->d4[bounce & 1u] : f->p->sh_d4;
     std::vector<float4> o(n), d(n), p(n);
     HIPCHK(ctx, hipMemcpy(o.data(), so, (size_t)n * 16, hipMemcpyDeviceToHost));
     HIPCHK(ctx, hipMemcpy(d.data(), sdir, (size_t)n * 16, hipMemcpyDeviceToHost));
-    if (which == 0) HIPCHK(ctx, hipMemcpy(p.data(), f->thr[bounce & 1u], (size_t)n * 16, hipMemcpyDeviceToHost));
+    if (which == 0) HIPCHK(ctx, hipMemcpy(p.data(), f->p->thr[bounce & 1u], (size_t)n * 16, hipMemcpyDeviceToHost));
     for (uint32_t i = 0; i < n; ++i)
     {
         uint32_t pl;
         memcpy(&pl, &d[i].w, 4);
         uint32_t id = pl;
-        uint32_t local_pix = f->chunk_base + id % (f->chunk_pixels ? f->chunk_pixels : 1);
+        uint32_t local_pix = f->p->chunk_base + id % (f->chunk_pixels ? f->chunk_pixels : 1);
         if (which == 1)   // the deferred direct-light sample lives in the radiance log
         {
             float4 iv;
-            HIPCHK(ctx, hipMemcpy(&iv, f->sh_iv4 + i, 16, hipMemcpyDeviceToHost));
+            HIPCHK(ctx, hipMemcpy(&iv, f->p->sh_iv4 + i, 16, hipMemcpyDeviceToHost));
             uint32_t entry;
             memcpy(&entry, &iv.w, 4);
-            HIPCHK(ctx, hipMemcpy(&p[i], f->rlog + (size_t)(entry >> 8) * f->log_stride + id, 16, hipMemcpyDeviceToHost));
+            HIPCHK(ctx, hipMemcpy(&p[i], f->p->rlog + (size_t)(entry >> 8) * f->log_stride + id, 16, hipMemcpyDeviceToHost));
         }
         if (rays)
         {
@@ -1459,7 +1594,7 @@ int rt_frame_debug_read_hits(rt_frame* f, rt_hit* hits, uint32_t count)
     if (count > f->log_stride) return fail(ctx, "rt_frame_debug_read_hits: count too large");
     std::vector<float4> h(count ? count : 1);
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    HIPCHK(ctx, hipMemcpy(h.data(), f->hits, (size_t)count * 16, hipMemcpyDeviceToHost));
+    HIPCHK(ctx, hipMemcpy(h.data(), f->p->hits, (size_t)count * 16, hipMemcpyDeviceToHost));
     for (uint32_t i = 0; i < count; ++i)
     {
         hits[i].bc.x = h[i].x; hits[i].bc.y = h[i].y;

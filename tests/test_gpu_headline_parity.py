@@ -167,3 +167,38 @@ def test_bounded_path_state_renders_the_tile_in_chunks_bit_identically(variant, 
         assert np.array_equal(fr.radiance(), ref.radiance(), equal_nan=True)
         fr.close(); ref.close()
     base.close(); ctx.close()
+
+
+def test_pipelined_chunks_on_several_streams_are_bit_identical(golden_scenes):
+    """RT_OPT_PIPELINES: a large batch (>= 4 M paths) is cut into chunks that travel through the wavefront loop on
+    separate pipes (per-path buffers + HIP stream each) so that launch tails overlap.  1, 2, 3 and 4 pipes, with and
+    without a memory limit that makes more chunks than pipes: same bits, same counters."""
+    w, h, b, spp = 256, 160, 3, 128 + 40                 # 5.2 M paths per batch; a second, partial batch
+    sc = golden_scenes["coverage"]
+    cam = T.default_camera(w, h)
+    ctx = capi.Context(0)
+    ctx.upload_scene(sc)
+    results = []
+    for pipes, limit_mb in ((1, 0), (2, 0), (3, 0), (4, 0), (2, 512), (3, 700)):
+        fr = capi.Frame(ctx, w, h)
+        fr.set_camera(cam); fr.set_max_bounces(b)
+        fr.set_option(capi.OPT_PIPELINES, pipes)
+        fr.set_option(capi.OPT_SAMPLES_IN_FLIGHT, 128)
+        if limit_mb:
+            fr.set_option(capi.OPT_PATH_STATE_LIMIT_MB, limit_mb)
+        fr.integrate(spp)
+        st = fr.stats()
+        assert st.pipelines == pipes
+        if limit_mb:
+            assert st.path_state_bytes <= limit_mb << 20 and st.chunk_pixels * pipes < w * h      # more chunks than pipes
+        results.append((fr.radiance().copy(), st.closest_rays, st.shadow_rays, list(st.last_active[: b + 1])))
+        fr.close()
+    for r in results[1:]:
+        assert np.array_equal(r[0], results[0][0], equal_nan=True)
+        assert r[1:] == results[0][1:]
+    orc = _oracle.Oracle(w, h, sc)
+    orc.set_camera(cam); orc.set_max_bounces(b); orc.integrate(2)
+    fr = capi.Frame(ctx, w, h)
+    fr.set_camera(cam); fr.set_max_bounces(b); fr.set_option(capi.OPT_SAMPLES_IN_FLIGHT, 128); fr.integrate(2)
+    assert np.array_equal(fr.radiance()[..., :3], orc.radiance()[..., :3], equal_nan=True)
+    fr.close(); ctx.close()
