@@ -149,11 +149,11 @@ enum rt_option
                                        over the tile's pixels instead of over the whole tile at once.  0 (default) = only
                                        the built-in rule (at most half of the HBM).  Results are bit-identical for every
                                        value: path ids, the log and the replay are per pixel. */
-    , RT_OPT_PIPELINES = 15        /* 1..4 (default 2): pipes -- sets of per-path buffers, each with its own HIP stream --
+    , RT_OPT_PIPELINES = 15        /* 1..4 (default 1): pipes -- sets of per-path buffers, each with its own HIP stream --
                                        rt_integrate deals the tile's chunks to when a batch is large (>= 2 samples in
-                                       flight, >= 4 M paths): the straggler tail of one chunk's launch then overlaps the
-                                       other chunk's next launch.  1 = everything on the context's stream.  Results are
-                                       bit-identical for every value. */
+                                       flight, >= 4 M paths), so that chunks overlap.  Measured: no gain on MI355X
+                                       (profiles/r02_pipelines_sweep.log), hence off by default.  Results are bit-identical
+                                       for every value. */
     , RT_OPT_TRACE_TUNE = 12       /* k_trace2 (variants 8, 9) loop thresholds: value & 255 = lanes that must hold an
                                        interior node for a wave to stay in the node loop, value >> 8 & 255 = lanes that
                                        must wait at a triangle for another pass of the triangle loop.  0 = defaults.

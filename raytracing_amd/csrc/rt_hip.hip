@@ -82,11 +82,11 @@ struct rt_frame
     float4* radiance; float4* resolved;
     // Per-path state lives in PIPES (PathPipe): the tile is cut into chunks of pixels and chunk c travels through
     // the wavefront loop on pipe c % n_pipes, each pipe on its own HIP stream.  One chunk on one pipe is the plain
-    // case; two pipes let the straggler tail of one chunk's launch (a handful of very long rays keep a persistent
-    // trace kernel alive for ~1 ms while the machine idles) overlap with the other chunk's next launch.
+    // case.  More pipes let chunks overlap; measured on MI355X this does NOT pay (a trace launch costs ~0.8 ms
+    // beyond its rays whatever shares the machine with it: profiles/r02_pipelines_sweep.log), so the default is 1.
     PathPipe ps[RT_MAX_PIPES];
     PathPipe* p = &ps[0];          // the pipe the stage functions work on
-    uint32_t pipelines = 2;        // RT_OPT_PIPELINES: pipes rt_integrate may use
+    uint32_t pipelines = 1;        // RT_OPT_PIPELINES: pipes rt_integrate may use
     uint32_t n_pipes = 1;          // pipes the current allocation holds
     uint32_t slots = 1;            // samples traced concurrently (resolved from slots_opt)
     uint32_t slots_opt = 0;        // RT_OPT_SAMPLES_IN_FLIGHT as set by the caller (0 = auto)

@@ -189,6 +189,7 @@ def test_pipelined_chunks_on_several_streams_are_bit_identical(golden_scenes):
         fr.integrate(spp)
         st = fr.stats()
         assert st.pipelines == pipes
+        assert capi.Frame(ctx, 8, 8).stats().pipelines == 1          # default: one pipe
         if limit_mb:
             assert st.path_state_bytes <= limit_mb << 20 and st.chunk_pixels * pipes < w * h      # more chunks than pipes
         results.append((fr.radiance().copy(), st.closest_rays, st.shadow_rays, list(st.last_active[: b + 1])))
