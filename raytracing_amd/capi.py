@@ -60,7 +60,7 @@ EXPORTS = [
     "rt_frame_get_stats", "rt_frame_get_profile", "rt_frame_copy_radiance", "rt_frame_debug_read_queue", "rt_frame_debug_read_hits", "rt_debug_eval",
     "rt_debug_wide_bvh",
     "rt_group_create", "rt_group_unique_id", "rt_group_join", "rt_group_size", "rt_group_local_count", "rt_group_local_rank",
-    "rt_group_gather_radiance", "rt_group_destroy", "rt_group_last_error",
+    "rt_group_gather_radiance", "rt_group_destroy", "rt_group_last_error", "rt_group_denoise", "rt_group_create_local",
 ]
 
 OPT_MAX_BOUNCES, OPT_WHITE_FURNACE, OPT_SAMPLER, OPT_AOV, OPT_DENOISER, OPT_DROP_LAST, OPT_PROFILE, OPT_TRACE_VARIANT, OPT_TRACE_WAVES, OPT_SAMPLES_IN_FLIGHT, OPT_SELECT_FORM_BOX, OPT_PACKET_BOUNCES, OPT_TRACE_TUNE, OPT_DEBUG_ALLOC_LIMIT, OPT_PATH_STATE_LIMIT_MB, OPT_PIPELINES = range(16)
@@ -109,6 +109,7 @@ def load():
         "rt_group_local_count": (i32, [vp]), "rt_group_local_rank": (i32, [vp, i32]),
         "rt_group_gather_radiance": (i32, [vp, C.POINTER(vp), i32, vp, C.POINTER(vp)]), "rt_group_destroy": (i32, [vp]),
         "rt_group_last_error": (C.c_char_p, [vp]),
+        "rt_group_denoise": (i32, [vp, C.POINTER(vp), i32, vp, vp]), "rt_group_create_local": (i32, [i32, i32, C.POINTER(vp)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -326,6 +327,15 @@ class Group:
             raise RtError(lib.rt_group_last_error(None).decode())
         return cls(h)
 
+    @classmethod
+    def create_local(cls, n, device=0):
+        """n ranks on ONE device, device copies instead of RCCL: the test / plumbing transport."""
+        lib = load()
+        h = C.c_void_p()
+        if lib.rt_group_create_local(n, device, C.byref(h)) != 0:
+            raise RtError(lib.rt_group_last_error(None).decode())
+        return cls(h)
+
     @staticmethod
     def unique_id():
         lib = load()
@@ -362,6 +372,18 @@ class Group:
             raise RtError(self.lib.rt_group_last_error(self.handle).decode())
         self.device_image = dev.value
         return out
+
+    def denoise(self, frame_handles, root, height, width):
+        """Gather-then-denoise on the root (rt_group_denoise).  Returns (resolved, radiance) on the root's process."""
+        n = len(frame_handles)
+        arr = (C.c_void_p * n)(*[h if isinstance(h, int) else h.value for h in frame_handles])
+        owns_root = root in self.local_ranks()
+        res = np.zeros((height, width, 4), np.float32) if owns_root else None
+        rad = np.zeros((height, width, 4), np.float32) if owns_root else None
+        rc = self.lib.rt_group_denoise(self.handle, arr, root, res.ctypes.data if owns_root else None, rad.ctypes.data if owns_root else None)
+        if rc != 0:
+            raise RtError(self.lib.rt_group_last_error(self.handle).decode())
+        return res, rad
 
     def close(self):
         if self.handle:

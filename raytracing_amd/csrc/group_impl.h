@@ -92,8 +92,13 @@ struct rt_group
         size_t recv_elems = 0, image_elems = 0, send_elems = 0;
     };
     int nranks = 0;
+    bool local = false;                // rt_group_create_local: all ranks on ONE device, device copies instead of RCCL
     std::vector<Member> members;       // the ranks that live in this process
     std::string error;
+    // temporal denoiser across tiles (rt_group_denoise), on the root: full-image inputs and history
+    float4* dn_radiance = nullptr; float* dn_depth = nullptr; float2* dn_velocity = nullptr;
+    float4* dn_prev_radiance = nullptr; float* dn_prev_depth = nullptr; float4* dn_resolved = nullptr;
+    size_t dn_pixels = 0;
 };
 
 namespace
@@ -150,6 +155,22 @@ int rt_group_create(int n, const int* device_ordinals, rt_group** out)
     return RT_OK;
 }
 
+int rt_group_create_local(int n, int device_ordinal, rt_group** out)
+{
+    if (!out || n <= 0) return gfail(nullptr, "rt_group_create_local: bad argument");
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return gfail(nullptr, "rt_group_create_local: no HIP device");
+    if (device_ordinal < 0 || device_ordinal >= ndev) return gfail(nullptr, "rt_group_create_local: bad device ordinal");
+    rt_group* g = new rt_group;
+    g->nranks = n;
+    g->local = true;
+    g->members.resize((size_t)n);
+    for (int i = 0; i < n; ++i) { g->members[i].device = device_ordinal; g->members[i].rank = i; }
+    *out = g;
+    return RT_OK;
+}
+
 int rt_group_unique_id(void* id_bytes, size_t capacity)
 {
     if (!id_bytes || capacity < sizeof(ncclUniqueId)) return gfail(nullptr, "rt_group_unique_id: buffer smaller than RT_GROUP_ID_BYTES");
@@ -191,43 +212,107 @@ int rt_group_size(rt_group* g) { return g ? g->nranks : 0; }
 int rt_group_local_count(rt_group* g) { return g ? (int)g->members.size() : 0; }
 int rt_group_local_rank(rt_group* g, int i) { return g && i >= 0 && i < (int)g->members.size() ? g->members[(size_t)i].rank : -1; }
 
-int rt_group_gather_radiance(rt_group* g, rt_frame* const* frames, int root, float* host_rgba, void** device_rgba)
+} // extern "C"
+
+namespace
 {
-    if (!g || !frames) return gfail(g, "rt_group_gather_radiance: NULL argument");
-    if (root < 0 || root >= g->nranks) return gfail(g, "rt_group_gather_radiance: bad root");
-    RcclApi& api = rccl();
-    if (device_rgba) *device_rgba = nullptr;
-    const size_t nm = g->members.size();
-    // every member's frame must be the tile of its rank of the SAME image
+// checks that frames[i] is the tile of local member i of ONE image; returns that image's geometry and the
+// padded tile size (pixels of the largest tile)
+int check_tiles(rt_group* g, rt_frame* const* frames, const char* who, uint32_t& width, uint32_t& height, uint32_t& band_h, uint64_t& stride)
+{
     const rt_frame* f0 = frames[0];
-    if (!f0) return gfail(g, "rt_group_gather_radiance: NULL frame");
-    const uint32_t width = f0->tile.width, height = f0->tile.height, band_h = f0->tile.band_h;
-    uint64_t stride = 0;
+    if (!f0) return gfail(g, std::string(who) + ": NULL frame");
+    width = f0->tile.width; height = f0->tile.height; band_h = f0->tile.band_h;
+    stride = 0;
     for (int r = 0; r < g->nranks; ++r)
     {
         uint64_t p = tile_pixels(width, height, band_h, (uint32_t)r, (uint32_t)g->nranks);
         stride = p > stride ? p : stride;
     }
-    for (size_t i = 0; i < nm; ++i)
+    for (size_t i = 0; i < g->members.size(); ++i)
     {
         rt_frame* f = frames[i];
         rt_group::Member& m = g->members[i];
-        if (!f) return gfail(g, "rt_group_gather_radiance: NULL frame");
-        if (f->ctx->device != m.device) return gfail(g, "rt_group_gather_radiance: frame lives on another device than its rank");
+        if (!f) return gfail(g, std::string(who) + ": NULL frame");
+        if (f->ctx->device != m.device) return gfail(g, std::string(who) + ": frame lives on another device than its rank");
         if (f->tile.width != width || f->tile.height != height || f->tile.band_h != band_h || (int)f->tile.nranks != g->nranks ||
             (int)f->tile.rank != m.rank)
-            return gfail(g, "rt_group_gather_radiance: frame is not the tile of this rank (rt_frame_desc tile_rank / tile_count / band_height)");
+            return gfail(g, std::string(who) + ": frame is not the tile of this rank (rt_frame_desc tile_rank / tile_count / band_height)");
     }
+    return RT_OK;
+}
+
+// THE collective: every member's `send` (floats_per_rank floats) lands in the root's `recv` at rank * floats_per_rank.
+// RCCL ncclGather on the frames' streams; a local group (one device) copies instead.
+int exchange(rt_group* g, rt_frame* const* frames, int root, size_t floats_per_rank, const char* who)
+{
+    const size_t nm = g->members.size();
+    if (g->local)
+    {
+        rt_group::Member* rootm = nullptr;
+        size_t root_i = 0;
+        for (size_t i = 0; i < nm; ++i) if (g->members[i].rank == root) { rootm = &g->members[i]; root_i = i; }
+        if (!rootm) return gfail(g, std::string(who) + ": root is not in this process");
+        for (size_t i = 0; i < nm; ++i)
+            if (hipStreamSynchronize(frames[i]->ctx->stream) != hipSuccess) return gfail(g, std::string(who) + ": stream synchronisation failed");
+        for (size_t i = 0; i < nm; ++i)
+        {
+            hipError_t e = hipMemcpyAsync((float*)rootm->recv + (size_t)g->members[i].rank * floats_per_rank, g->members[i].send,
+                floats_per_rank * sizeof(float), hipMemcpyDeviceToDevice, frames[root_i]->ctx->stream);
+            if (e != hipSuccess) return gfail(g, std::string(who) + ": device copy: " + hipGetErrorString(e));
+        }
+        return RT_OK;
+    }
+    RcclApi& api = rccl();
+    ncclResult_t r = api.GroupStart();
+    for (size_t i = 0; i < nm && r == ncclSuccess; ++i)
+    {
+        rt_group::Member& m = g->members[i];
+        (void)hipSetDevice(m.device);
+        r = api.Gather(m.send, m.rank == root ? m.recv : nullptr, floats_per_rank, ncclFloat, root, m.comm, frames[i]->ctx->stream);
+    }
+    ncclResult_t r2 = api.GroupEnd();
+    if (r == ncclSuccess) r = r2;
+    if (r != ncclSuccess) return gfail(g, std::string(who) + ": ncclGather: " + api.GetErrorString(r));
+    return RT_OK;
+}
+
+// root: one section (COMPS floats per pixel, rank-major padded tiles) of the gathered buffer -> row-major image
+template <int COMPS>
+__global__ void k_group_assemble_n(const float* __restrict__ gathered, float* __restrict__ image, uint32_t width, uint32_t height,
+    uint32_t band_h, uint32_t nranks, uint64_t stride, uint64_t floats_per_rank, uint64_t section_offset)
+{
+    uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= (uint64_t)width * height) return;
+    uint32_t y = (uint32_t)(i / width), x = (uint32_t)(i - (uint64_t)y * width);
+    uint32_t band = y / band_h, r = band % nranks;
+    uint32_t ly = (band / nranks) * band_h + (y - band * band_h);
+    const float* src = gathered + (uint64_t)r * floats_per_rank + section_offset + ((uint64_t)ly * width + x) * COMPS;
+    for (int c = 0; c < COMPS; ++c) image[i * COMPS + c] = src[c];
+}
+} // namespace
+
+extern "C" {
+
+int rt_group_gather_radiance(rt_group* g, rt_frame* const* frames, int root, float* host_rgba, void** device_rgba)
+{
+    if (!g || !frames) return gfail(g, "rt_group_gather_radiance: NULL argument");
+    if (root < 0 || root >= g->nranks) return gfail(g, "rt_group_gather_radiance: bad root");
+    if (device_rgba) *device_rgba = nullptr;
+    const size_t nm = g->members.size();
+    uint32_t width, height, band_h;
+    uint64_t stride;
+    if (check_tiles(g, frames, "rt_group_gather_radiance", width, height, band_h, stride) != RT_OK) return RT_ERROR;
     // stage: running-sum radiance of every local tile into its padded send buffer (stream-ordered after the render)
     for (size_t i = 0; i < nm; ++i)
     {
         rt_frame* f = frames[i];
         rt_group::Member& m = g->members[i];
         if (hipSetDevice(m.device) != hipSuccess) return gfail(g, "rt_group_gather_radiance: hipSetDevice failed");
-        if (ensure(g, &m.send, &m.send_elems, (size_t)stride) != RT_OK) return RT_ERROR;
+        if (ensure(g, &m.send, &m.send_elems, (size_t)stride * 2) != RT_OK) return RT_ERROR;      // x2: room for rt_group_denoise's 7 floats
         if (m.rank == root)
         {
-            if (ensure(g, &m.recv, &m.recv_elems, (size_t)stride * (size_t)g->nranks) != RT_OK) return RT_ERROR;
+            if (ensure(g, &m.recv, &m.recv_elems, (size_t)stride * 2 * (size_t)g->nranks) != RT_OK) return RT_ERROR;
             if (ensure(g, &m.image, &m.image_elems, (size_t)width * height) != RT_OK) return RT_ERROR;
         }
         if (flush_log_keep(f) != RT_OK) return gfail(g, std::string("rt_group_gather_radiance: ") + f->ctx->error);
@@ -237,17 +322,7 @@ int rt_group_gather_radiance(rt_group* g, rt_frame* const* frames, int root, flo
             if (e != hipSuccess) return gfail(g, std::string("rt_group_gather_radiance: staging copy: ") + hipGetErrorString(e));
         }
     }
-    // the ONE collective (group call: all local ranks of this process enter it together)
-    ncclResult_t r = api.GroupStart();
-    for (size_t i = 0; i < nm && r == ncclSuccess; ++i)
-    {
-        rt_group::Member& m = g->members[i];
-        (void)hipSetDevice(m.device);
-        r = api.Gather(m.send, m.rank == root ? m.recv : nullptr, (size_t)stride * 4, ncclFloat, root, m.comm, frames[i]->ctx->stream);
-    }
-    ncclResult_t r2 = api.GroupEnd();
-    if (r == ncclSuccess) r = r2;
-    if (r != ncclSuccess) return gfail(g, std::string("rt_group_gather_radiance: ncclGather: ") + api.GetErrorString(r));
+    if (exchange(g, frames, root, (size_t)stride * 4, "rt_group_gather_radiance") != RT_OK) return RT_ERROR;
     // root: un-interleave the bands, hand the image over
     for (size_t i = 0; i < nm; ++i)
     {
@@ -273,16 +348,98 @@ int rt_group_gather_radiance(rt_group* g, rt_frame* const* frames, int root, flo
     return RT_OK;
 }
 
+// Temporal denoiser across tiles (denoiser.cl:27-79 reprojects across rows, so a tile cannot run it alone):
+// gather-then-denoise on the root.  Every rank has rendered ONE sample of its tile with RT_OPT_DENOISER on
+// (reset + sample + AOVs, integrator.cpp:29-46); one gather carries radiance, depth and motion vectors
+// (7 floats per pixel); the root runs TemporalAccumulation on the assembled frame against ITS history, copies
+// the history (cl_pt_integrator.cpp:670-675) and resolves (resolve_radiance.cl with ENABLE_DENOISER).
+int rt_group_denoise(rt_group* g, rt_frame* const* frames, int root, float* host_resolved_rgba, float* host_radiance_rgba)
+{
+    if (!g || !frames) return gfail(g, "rt_group_denoise: NULL argument");
+    if (root < 0 || root >= g->nranks) return gfail(g, "rt_group_denoise: bad root");
+    const size_t nm = g->members.size();
+    uint32_t width, height, band_h;
+    uint64_t stride;
+    if (check_tiles(g, frames, "rt_group_denoise", width, height, band_h, stride) != RT_OK) return RT_ERROR;
+    const size_t per_rank = (size_t)stride * 7;                          // radiance 4 | depth 1 | velocity 2
+    for (size_t i = 0; i < nm; ++i)
+    {
+        rt_frame* f = frames[i];
+        rt_group::Member& m = g->members[i];
+        if (!f->denoiser) return gfail(g, "rt_group_denoise: RT_OPT_DENOISER is off on a frame");
+        if (hipSetDevice(m.device) != hipSuccess) return gfail(g, "rt_group_denoise: hipSetDevice failed");
+        if (ensure(g, &m.send, &m.send_elems, (size_t)stride * 2) != RT_OK) return RT_ERROR;
+        if (m.rank == root && ensure(g, &m.recv, &m.recv_elems, (size_t)stride * 2 * (size_t)g->nranks) != RT_OK) return RT_ERROR;
+        if (flush_log_keep(f) != RT_OK) return gfail(g, std::string("rt_group_denoise: ") + f->ctx->error);
+        if (f->n_local)
+        {
+            float* send = (float*)m.send;
+            hipStream_t s = f->ctx->stream;
+            bool ok = hipMemcpyAsync(send, f->radiance, (size_t)f->n_local * 16, hipMemcpyDeviceToDevice, s) == hipSuccess &&
+                      hipMemcpyAsync(send + (size_t)stride * 4, f->aov_buf.depth, (size_t)f->n_local * 4, hipMemcpyDeviceToDevice, s) == hipSuccess &&
+                      hipMemcpyAsync(send + (size_t)stride * 5, f->aov_buf.velocity, (size_t)f->n_local * 8, hipMemcpyDeviceToDevice, s) == hipSuccess;
+            if (!ok) return gfail(g, "rt_group_denoise: staging copy failed");
+        }
+    }
+    if (exchange(g, frames, root, per_rank, "rt_group_denoise") != RT_OK) return RT_ERROR;
+    for (size_t i = 0; i < nm; ++i)
+    {
+        rt_group::Member& m = g->members[i];
+        hipStream_t s = frames[i]->ctx->stream;
+        (void)hipSetDevice(m.device);
+        if (m.rank == root)
+        {
+            const uint64_t n = (uint64_t)width * height;
+            if (g->dn_pixels != n)
+            {
+                for (void* p : {(void*)g->dn_radiance, (void*)g->dn_depth, (void*)g->dn_velocity, (void*)g->dn_prev_radiance,
+                         (void*)g->dn_prev_depth, (void*)g->dn_resolved})
+                    if (p) (void)hipFree(p);
+                bool ok = hipMalloc((void**)&g->dn_radiance, n * 16) == hipSuccess && hipMalloc((void**)&g->dn_depth, n * 4) == hipSuccess &&
+                          hipMalloc((void**)&g->dn_velocity, n * 8) == hipSuccess && hipMalloc((void**)&g->dn_prev_radiance, n * 16) == hipSuccess &&
+                          hipMalloc((void**)&g->dn_prev_depth, n * 4) == hipSuccess && hipMalloc((void**)&g->dn_resolved, n * 16) == hipSuccess;
+                ok = ok && hipMemsetAsync(g->dn_prev_radiance, 0, n * 16, s) == hipSuccess && hipMemsetAsync(g->dn_prev_depth, 0, n * 4, s) == hipSuccess;
+                if (!ok) { g->dn_pixels = 0; (void)hipGetLastError(); return gfail(g, "rt_group_denoise: out of device memory"); }
+                g->dn_pixels = n;
+            }
+            const dim3 grid((uint32_t)((n + 255u) / 256u)), block(256);
+            const float* recv = (const float*)m.recv;
+            hipLaunchKernelGGL((k_group_assemble_n<4>), grid, block, 0, s, recv, (float*)g->dn_radiance, width, height, band_h,
+                (uint32_t)g->nranks, stride, (uint64_t)per_rank, (uint64_t)0);
+            hipLaunchKernelGGL((k_group_assemble_n<1>), grid, block, 0, s, recv, g->dn_depth, width, height, band_h,
+                (uint32_t)g->nranks, stride, (uint64_t)per_rank, (uint64_t)stride * 4);
+            hipLaunchKernelGGL((k_group_assemble_n<2>), grid, block, 0, s, recv, (float*)g->dn_velocity, width, height, band_h,
+                (uint32_t)g->nranks, stride, (uint64_t)per_rank, (uint64_t)stride * 5);
+            hipLaunchKernelGGL(k_denoise, grid, block, 0, s, width, height, g->dn_radiance, (const float4*)g->dn_prev_radiance,
+                (const float*)g->dn_depth, (const float*)g->dn_prev_depth, (const float2*)g->dn_velocity);
+            bool ok = hipGetLastError() == hipSuccess &&
+                      hipMemcpyAsync(g->dn_prev_radiance, g->dn_radiance, n * 16, hipMemcpyDeviceToDevice, s) == hipSuccess &&
+                      hipMemcpyAsync(g->dn_prev_depth, g->dn_depth, n * 4, hipMemcpyDeviceToDevice, s) == hipSuccess;
+            DAov none = {nullptr, nullptr, nullptr, nullptr};
+            hipLaunchKernelGGL(k_resolve, grid, block, 0, s, (const float4*)g->dn_radiance, none, g->dn_resolved, (uint32_t)n, 1u, 0u, 1u);
+            ok = ok && hipGetLastError() == hipSuccess;
+            if (ok && host_resolved_rgba) ok = hipMemcpyAsync(host_resolved_rgba, g->dn_resolved, n * 16, hipMemcpyDeviceToHost, s) == hipSuccess;
+            if (ok && host_radiance_rgba) ok = hipMemcpyAsync(host_radiance_rgba, g->dn_radiance, n * 16, hipMemcpyDeviceToHost, s) == hipSuccess;
+            if (!ok) return gfail(g, "rt_group_denoise: denoise / resolve on the root failed");
+        }
+        hipError_t e = hipStreamSynchronize(s);
+        if (e != hipSuccess) return gfail(g, std::string("rt_group_denoise: ") + hipGetErrorString(e));
+    }
+    return RT_OK;
+}
+
 int rt_group_destroy(rt_group* g)
 {
     if (!g) return RT_OK;
-    RcclApi& api = rccl();
     for (auto& m : g->members)
     {
         (void)hipSetDevice(m.device);
         for (float4* p : {m.send, m.recv, m.image}) if (p) (void)hipFree(p);
-        if (m.comm && api.CommDestroy) (void)api.CommDestroy(m.comm);
+        if (m.comm && rccl().CommDestroy) (void)rccl().CommDestroy(m.comm);
     }
+    for (void* p : {(void*)g->dn_radiance, (void*)g->dn_depth, (void*)g->dn_velocity, (void*)g->dn_prev_radiance, (void*)g->dn_prev_depth,
+             (void*)g->dn_resolved})
+        if (p) (void)hipFree(p);
     delete g;
     return RT_OK;
 }

@@ -991,9 +991,9 @@ int rt_set_option(rt_frame* f, int option, uint32_t value)
         f->aov = value;
         return RT_OK;
     case RT_OPT_DENOISER:
-        if (value != 0 && f->tile.nranks != 1)
-            return fail(f->ctx, "rt_set_option: the temporal denoiser reprojects across rows and needs the whole image "
-                                "on one GPU (tile_count == 1)");
+        // On a tile (tile_count > 1) the frame only prepares the denoiser's inputs (reset every frame, one sample,
+        // depth and motion AOVs): the reprojection crosses tile rows, so TemporalAccumulation itself runs on the
+        // gathered image -- rt_group_denoise.
         f->denoiser = value ? 1 : 0;
         return RT_OK;
     case RT_OPT_TRACE_DROP_LAST_BOUNCE_RAYS: f->drop_last = value ? 1 : 0; return RT_OK;
@@ -1346,6 +1346,7 @@ int rt_denoise(rt_frame* f)                             // Denoise, :665-668
 {
     FRAME_PROLOGUE(f, "rt_denoise");
     if (!f->denoiser || f->n_local == 0) return RT_OK;
+    if (f->tile.nranks != 1) return RT_OK;               // a tile: rt_group_denoise does it on the gathered image
     if (flush_log(f) != RT_OK) return RT_ERROR;
     uint32_t blocks = (f->n_local + 255u) / 256u;
     hipLaunchKernelGGL(k_denoise, dim3(blocks), dim3(256), 0, ctx->stream, f->tile.width, f->tile.height, f->radiance,
@@ -1358,7 +1359,7 @@ int rt_denoise(rt_frame* f)                             // Denoise, :665-668
 int rt_copy_history(rt_frame* f)                        // CopyHistoryBuffers, :670-675
 {
     FRAME_PROLOGUE(f, "rt_copy_history");
-    if (!f->denoiser || f->n_local == 0) return RT_OK;
+    if (!f->denoiser || f->n_local == 0 || f->tile.nranks != 1) return RT_OK;
     HIPCHK(ctx, hipMemcpyAsync(f->prev_radiance, f->radiance, (size_t)f->n_local * sizeof(float4), hipMemcpyDeviceToDevice,
         ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(f->prev_depth, f->aov_buf.depth, (size_t)f->n_local * sizeof(float), hipMemcpyDeviceToDevice,

@@ -392,11 +392,37 @@ def test_aov_viewer_and_temporal_denoiser(ctx, golden_scenes, golden_radiance, k
         assert np.array_equal(v, want[k], equal_nan=True), k
 
 
-def test_denoiser_needs_the_whole_image(ctx, golden_scenes):
-    ctx.upload_scene(golden_scenes["cornell"])
-    t = capi.Frame(ctx, 32, 32, tile_rank=0, tile_count=2)
-    with pytest.raises(capi.RtError, match="whole image"):
-        t.set_option(capi.OPT_DENOISER, 1)            # reprojection crosses tile rows
+@pytest.mark.parametrize("tiles", [1, 2, 3])
+def test_temporal_denoiser_across_tiles_gather_then_denoise(ctx, golden_scenes, golden_radiance, tiles):
+    """The reprojection of TemporalAccumulation crosses tile rows (denoiser.cl:27-79), so with tiling the filter
+    runs on the root after ONE gather of radiance + depth + motion vectors (rt_group_denoise).  1, 2 and 3 tiles of
+    the golden moving-camera sequence (the reference kernels' own output) -- the tiles live on this box's one GPU
+    (rt_group_create_local: device copies instead of RCCL, which wants one device per rank)."""
+    g = golden_radiance
+    cam = g["aov_denoise/camera"]
+    w, h = 64, 48
+    ctx.upload_scene(golden_scenes["coverage"])
+    frames = [capi.Frame(ctx, w, h, tile_rank=r, tile_count=tiles, band_height=4) for r in range(tiles)]
+    grp = capi.Group.create_local(tiles, 0)
+    for fr in frames:
+        fr.set_max_bounces(3)
+        # the golden sequence shows the four AOVs first (4 frames with other cameras' history): replay them so
+        # that the frame's prev_camera chain matches, then switch the denoiser on
+        for aov in (1, 2, 3, 4):
+            fr.set_option(capi.OPT_AOV, aov); fr.set_camera(cam); fr.reset(); fr.integrate(1)
+        fr.set_option(capi.OPT_AOV, 0)
+        fr.set_option(capi.OPT_DENOISER, 1)
+        fr.reset()
+    for f in range(5):
+        c = cam.copy()
+        c["position"]["x"] = 0.02 * f
+        for fr in frames:
+            fr.set_camera(c)
+            fr.integrate(1)
+        resolved, radiance = grp.denoise([fr.handle for fr in frames], 0, h, w)
+        assert np.array_equal(resolved[..., :3], g["denoise%d/resolved" % f], equal_nan=True), f
+        assert np.array_equal(radiance[..., :3], g["denoise%d/radiance" % f], equal_nan=True), f
+    grp.close()
 
 
 def test_aov_viewer_is_tile_invariant(ctx, golden_scenes):
@@ -637,6 +663,15 @@ def test_device_group_gather_through_the_c_abi(ctx, golden_scenes):
         with pytest.raises(capi.RtError, match="bad root"):
             g.gather_radiance([fr.handle], 1, h, w)
         g.close()
+    # three tiles on this one GPU (local transport): padding of the short last tile, band re-assembly, any root
+    tiles = [capi.Frame(ctx, w, h, tile_rank=r, tile_count=3, band_height=4) for r in range(3)]
+    for t in tiles:
+        t.set_camera(cam); t.set_max_bounces(b); t.integrate(spp)
+    g = capi.Group.create_local(3, 0)
+    for root in (0, 2):
+        img = g.gather_radiance([t.handle for t in tiles], root, h, w)
+        assert np.array_equal(img, fr.radiance(), equal_nan=True)
+    g.close()
     with pytest.raises(capi.RtError, match="one rank per device"):
         capi.Group.create([0, 0])
     with pytest.raises(capi.RtError, match="bad device ordinal"):
