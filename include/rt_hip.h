@@ -117,8 +117,9 @@ enum rt_option
     RT_OPT_SAMPLER = 2,        /* Integrator::SetSamplerType: 0 = kRandom, 1 = kBlueNoise (-D BLUE_NOISE_SAMPLER) */
     RT_OPT_AOV = 3,            /* Integrator::SetAOV: 0 shaded colour, 1 diffuse albedo, 2 depth, 3 normal, 4 motion vectors
                                   (resolve_radiance.cl:25-29); per-pixel, so it works on tiles */
-    RT_OPT_DENOISER = 4,       /* Integrator::EnableDenoiser: temporal reprojection (denoiser.cl).  On a tile (tile_count > 1)
-                                  the frame prepares the inputs only and rt_group_denoise runs the filter on the gathered image */
+    RT_OPT_DENOISER = 4,       /* Integrator::EnableDenoiser: 1 = temporal reprojection (denoiser.cl) in the frame itself
+                                  (needs tile_count == 1: it reprojects across rows); 2 = the frame prepares the filter's
+                                  inputs only and rt_group_denoise runs it on the gathered image (the mode for tiles) */
     RT_OPT_TRACE_DROP_LAST_BOUNCE_RAYS = 5, /* 1 (default): do not emit the never-traced rays of the last bounce */
     RT_OPT_PROFILE_KERNELS = 6, /* 1: bracket every kernel launch with HIP events on the context stream */
     RT_OPT_TRACE_VARIANT = 7    /* traversal kernel: 0 = v1 per-ray loop; 1 .. 4, 6, 7 = one-fetch-per-iteration
@@ -262,7 +263,7 @@ int rt_group_local_rank(rt_group* group, int i);        /* global rank of local 
  * Stream-ordered after the frames' pending work; returns when the image is complete. */
 int rt_group_gather_radiance(rt_group* group, rt_frame* const* frames, int root, float* host_rgba, void** device_rgba);
 /* Temporal denoiser across tiles (denoiser.cl:27-79 reprojects across rows): after every rank has rendered ONE sample
- * of its tile with RT_OPT_DENOISER on, one gather carries radiance + depth + motion vectors to the root, which runs
+ * of its tile with RT_OPT_DENOISER = 2, one gather carries radiance + depth + motion vectors to the root, which runs
  * TemporalAccumulation against its own history, copies the history and resolves.  On the root's process:
  * host_resolved_rgba / host_radiance_rgba (each may be NULL) receive the tonemapped frame / the filtered radiance. */
 int rt_group_denoise(rt_group* group, rt_frame* const* frames, int root, float* host_resolved_rgba, float* host_radiance_rgba);

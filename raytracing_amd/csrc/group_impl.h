@@ -366,7 +366,7 @@ int rt_group_denoise(rt_group* g, rt_frame* const* frames, int root, float* host
     {
         rt_frame* f = frames[i];
         rt_group::Member& m = g->members[i];
-        if (!f->denoiser) return gfail(g, "rt_group_denoise: RT_OPT_DENOISER is off on a frame");
+        if (f->denoiser != 2) return gfail(g, "rt_group_denoise: the frames must run with RT_OPT_DENOISER = 2 (inputs only)");
         if (hipSetDevice(m.device) != hipSuccess) return gfail(g, "rt_group_denoise: hipSetDevice failed");
         if (ensure(g, &m.send, &m.send_elems, (size_t)stride * 2) != RT_OK) return RT_ERROR;
         if (m.rank == root && ensure(g, &m.recv, &m.recv_elems, (size_t)stride * 2 * (size_t)g->nranks) != RT_OK) return RT_ERROR;

@@ -991,10 +991,14 @@ int rt_set_option(rt_frame* f, int option, uint32_t value)
         f->aov = value;
         return RT_OK;
     case RT_OPT_DENOISER:
-        // On a tile (tile_count > 1) the frame only prepares the denoiser's inputs (reset every frame, one sample,
-        // depth and motion AOVs): the reprojection crosses tile rows, so TemporalAccumulation itself runs on the
-        // gathered image -- rt_group_denoise.
-        f->denoiser = value ? 1 : 0;
+        // 1: the frame runs TemporalAccumulation itself -- the reprojection crosses rows, so it needs the whole image;
+        // 2: the frame only prepares the filter's inputs (reset every frame, one sample, depth and motion AOVs) and
+        //    rt_group_denoise runs the filter on the gathered image: the mode for tiles.
+        if (value > 2) return fail(f->ctx, "rt_set_option: RT_OPT_DENOISER is 0, 1 or 2");
+        if (value == 1 && f->tile.nranks != 1)
+            return fail(f->ctx, "rt_set_option: the temporal denoiser reprojects across rows and needs the whole image "
+                                "on one GPU (tile_count == 1); on tiles use RT_OPT_DENOISER = 2 + rt_group_denoise");
+        f->denoiser = value;
         return RT_OK;
     case RT_OPT_TRACE_DROP_LAST_BOUNCE_RAYS: f->drop_last = value ? 1 : 0; return RT_OK;
     case RT_OPT_PROFILE_KERNELS: f->profile = value ? 1 : 0; return RT_OK;
@@ -1345,8 +1349,7 @@ int rt_compute_aovs(rt_frame* f)                        // ComputeAOVs, :541-562
 int rt_denoise(rt_frame* f)                             // Denoise, :665-668
 {
     FRAME_PROLOGUE(f, "rt_denoise");
-    if (!f->denoiser || f->n_local == 0) return RT_OK;
-    if (f->tile.nranks != 1) return RT_OK;               // a tile: rt_group_denoise does it on the gathered image
+    if (f->denoiser != 1 || f->n_local == 0) return RT_OK;   // 2: rt_group_denoise does it on the gathered image
     if (flush_log(f) != RT_OK) return RT_ERROR;
     uint32_t blocks = (f->n_local + 255u) / 256u;
     hipLaunchKernelGGL(k_denoise, dim3(blocks), dim3(256), 0, ctx->stream, f->tile.width, f->tile.height, f->radiance,
@@ -1359,7 +1362,7 @@ int rt_denoise(rt_frame* f)                             // Denoise, :665-668
 int rt_copy_history(rt_frame* f)                        // CopyHistoryBuffers, :670-675
 {
     FRAME_PROLOGUE(f, "rt_copy_history");
-    if (!f->denoiser || f->n_local == 0 || f->tile.nranks != 1) return RT_OK;
+    if (f->denoiser != 1 || f->n_local == 0) return RT_OK;
     HIPCHK(ctx, hipMemcpyAsync(f->prev_radiance, f->radiance, (size_t)f->n_local * sizeof(float4), hipMemcpyDeviceToDevice,
         ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(f->prev_depth, f->aov_buf.depth, (size_t)f->n_local * sizeof(float), hipMemcpyDeviceToDevice,

@@ -392,6 +392,14 @@ def test_aov_viewer_and_temporal_denoiser(ctx, golden_scenes, golden_radiance, k
         assert np.array_equal(v, want[k], equal_nan=True), k
 
 
+def test_denoiser_in_the_frame_needs_the_whole_image(ctx, golden_scenes):
+    ctx.upload_scene(golden_scenes["cornell"])
+    t = capi.Frame(ctx, 32, 32, tile_rank=0, tile_count=2)
+    with pytest.raises(capi.RtError, match="whole image"):
+        t.set_option(capi.OPT_DENOISER, 1)            # reprojection crosses tile rows: tiles use mode 2 + rt_group_denoise
+    t.set_option(capi.OPT_DENOISER, 2)
+
+
 @pytest.mark.parametrize("tiles", [1, 2, 3])
 def test_temporal_denoiser_across_tiles_gather_then_denoise(ctx, golden_scenes, golden_radiance, tiles):
     """The reprojection of TemporalAccumulation crosses tile rows (denoiser.cl:27-79), so with tiling the filter
@@ -411,7 +419,7 @@ def test_temporal_denoiser_across_tiles_gather_then_denoise(ctx, golden_scenes, 
         for aov in (1, 2, 3, 4):
             fr.set_option(capi.OPT_AOV, aov); fr.set_camera(cam); fr.reset(); fr.integrate(1)
         fr.set_option(capi.OPT_AOV, 0)
-        fr.set_option(capi.OPT_DENOISER, 1)
+        fr.set_option(capi.OPT_DENOISER, 2)          # inputs only: the filter runs on the gathered image
         fr.reset()
     for f in range(5):
         c = cam.copy()
