@@ -197,6 +197,15 @@ RTD_FN float rt_powf(float xf, float yf)
     double y = (double)yf;
     if (yf == 0.0f) return 1.0f;
     if (xf == 1.0f) return 1.0f;
+    /* pow(x, 5): Schlick's Fresnel term (bxdf.h:73), the only small-integer exponent on the path, evaluated twice
+     * per shaded hit.  Three binary64 products (relative error < 4e-16 before the one rounding to binary32) instead
+     * of exp(5 log x): the same definition for the kernels, the oracle and the reference shim, and with a literal
+     * exponent the compiler drops everything below.  Sign, zeros, infinities and NaN come out as pow's. */
+    if (yf == 5.0f)
+    {
+        double x2 = x * x;
+        return (float)(x2 * x2 * x);
+    }
     if (xf != xf || yf != yf) return xf + yf;
     /* is y an integer, and is it odd? (|y| >= 2^24 is always an even integer) */
     int y_is_int = 0, y_is_odd = 0;

@@ -341,8 +341,10 @@ namespace
 //                                          the cell sizes; axes = axis0 | axisA << 2 | axisB << 4)
 //         q1 = (lo.x, lo.y, lo.z, hi.x)    one byte per slot in every dword
 //         q2 = (hi.y, hi.z, ref0, ref1)    ref = wide node index | RT_LEAF_BIT + first triangle | RT_EMPTY_REF
-//         q3 = (ref2, ref3, -, -)
-struct WideNode { float ox, oy, oz; uint32_t meta; uint32_t lo[3]; uint32_t hi[3]; uint32_t ref[4]; uint32_t pad[2]; };
+//         q3 = (ref2, ref3, order, -)       order: for each of the 8 direction-sign octants o (bit a set = direction negative
+//                                          along axis a) three bits at 3 * o: swap the two halves | swap inside half 0 |
+//                                          swap inside half 1 (a half with an empty slot is never swapped inside)
+struct WideNode { float ox, oy, oz; uint32_t meta; uint32_t lo[3]; uint32_t hi[3]; uint32_t ref[4]; uint32_t order; uint32_t pad; };
 static_assert(sizeof(WideNode) == 64, "wide node record");
 
 // false: the tree does not qualify (non-finite or non-nested bounds, child order): k_trace2 is used
@@ -428,6 +430,14 @@ bool build_wide_bvh(const rt_bvh_node* nodes, uint32_t nn, std::vector<WideNode>
         r.ox = origin[0]; r.oy = origin[1]; r.oz = origin[2];
         r.meta = (uint32_t)(exps[0] + 127) | (uint32_t)(exps[1] + 127) << 8 | (uint32_t)(exps[2] + 127) << 16 |
                  (axes[0] | axes[1] << 2 | axes[2] << 4) << 24;
+        for (uint32_t o = 0; o < 8; ++o)
+        {
+            // trace_bvh.cl:181-190 at both BVH2 levels: the near child is the second one when the ray is negative along the split axis
+            uint32_t sw0 = (o >> axes[0]) & 1u;
+            uint32_t swa = slot[1] != RT_EMPTY_REF ? (o >> axes[1]) & 1u : 0u;
+            uint32_t swb = slot[3] != RT_EMPTY_REF ? (o >> axes[2]) & 1u : 0u;
+            r.order |= (sw0 | swa << 1 | swb << 2) << (3 * o);
+        }
         for (int k = 0; k < 4; ++k)
         {
             if (slot[k] == RT_EMPTY_REF)

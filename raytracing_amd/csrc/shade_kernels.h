@@ -180,6 +180,9 @@ RT_DEV f3 SampleBxdf(float s1, f2 s, Material material, f3 normal, f3 incoming, 
         return F3s(1.0f);
     }
 
+    // both lobes turn the same angle phi = 2 pi s.x (bxdf.h:36,159): one sincos for the wave instead of one per branch
+    double sd, cd;
+    rtd_sincos((double)(RT_TWO_PI * s.x), &sd, &cd);
     f3 bxdf;
     if (s1 <= specular_sampling_pdf)
     {
@@ -194,13 +197,10 @@ RT_DEV f3 SampleBxdf(float s1, f2 s, Material material, f3 normal, f3 incoming, 
         else
         {
             // GGX_Sample bxdf.h:157-168 (fp64 literals in the reference -> fp64 divide + sqrt)
-            float phi = RT_TWO_PI * s.x;
             float cos_theta = (float)(1.0 / __builtin_sqrt(1.0 + (double)(alpha * alpha * s.y) / (1.0 - (double)s.y)));
             float sin_theta = __builtin_sqrtf(cl_max(0.0f, 1.0f - cos_theta * cos_theta));
             f3 t, b;
             tangent_frame(normal, t, b);
-            double sd, cd;
-            rtd_sincos((double)phi, &sd, &cd);
             float cp = (float)cd, sn = (float)sd;
             f3 wh = normalize3(b * cp * sin_theta + t * sn * sin_theta + normal * cos_theta);
             outgoing = reflect3(-incoming, wh);
@@ -219,12 +219,9 @@ RT_DEV f3 SampleBxdf(float s1, f2 s, Material material, f3 normal, f3 incoming, 
     else
     {
         // SampleHemisphereCosine bxdf.h:33-54 + TangentToWorld utils.h:99-106
-        float phi = RT_TWO_PI * s.x;
         float sin_theta = __builtin_sqrtf(s.y);
         float cos_theta = __builtin_sqrtf(1.0f - s.y);
         pdf = cos_theta * RT_INV_PI;
-        double sd, cd;
-        rtd_sincos((double)phi, &sd, &cd);
         f3 tbn = F3((float)cd * sin_theta, (float)sd * sin_theta, cos_theta);
         f3 t, b;
         tangent_frame(normal, t, b);
@@ -451,7 +448,9 @@ __global__ __launch_bounds__(RT_SHADE_BLOCK) void k_shade(DScene sc, DTile tile,
                 }
             }
 
-            // Indirect lighting :148-184
+            // Indirect lighting :148-184.  On the last bounce the outgoing ray is never traced (and its throughput
+            // never read): the whole block is skipped, wave-uniformly.
+            if (a.emit_outgoing != 0)
             {
                 f2 s;
                 s.x = draw(2);
@@ -464,7 +463,7 @@ __global__ __launch_bounds__(RT_SHADE_BLOCK) void k_shade(DScene sc, DTile tile,
                 f3 throughput = F3s(0.0f);
                 if ((double)pdf > 0.0) throughput = bxdf / pdf;
                 f3 new_thr = hit_throughput * throughput;                 // throughputs[pixel] *= throughput
-                want_next = ((double)pdf > 0.0) && (a.emit_outgoing != 0);
+                want_next = (double)pdf > 0.0;
                 f3 oo = position + geometry_normal * RT_EPS * offset;
                 nx_o = make_float4(oo.x, oo.y, oo.z, RT_MAX_RENDER_DIST);
                 nx_d = make_float4(outgoing.x, outgoing.y, outgoing.z, rd.w);

@@ -1063,7 +1063,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
     RayPool pool = {0u, 0u, 0u, false};
     uint32_t ref = RT_IDLE_REF;                    // wide node | RT_LEAF_BIT (| RT_LEAF_CONT_BIT) + triangle | idle
     uint32_t ray_i = RT_INVALID_ID;
-    uint32_t sign_bits = 0, hit_prim = RT_INVALID_ID;
+    uint32_t sign_bits = 0, octant3 = 0, hit_prim = RT_INVALID_ID;          // octant3: shift of this ray's entry in a node's order table
     int sp = 0;
     uint32_t n_spills = 0;                                                   // statistics (wave-uniform): lane-steps with entries in the HBM spill area
     f3 org = F3s(0.0f), dir = F3s(0.0f), inv = F3s(0.0f);
@@ -1141,6 +1141,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                     t_max = q0.w;
                     inv = F3(q2.x, q2.y, q2.z);
                     sign_bits = __float_as_uint(q2.w) & 0xFFu;
+                    octant3 = 3u * (sign_bits & 7u);
                     if (SHADOW) { payload = __float_as_uint(q1.w); log_entry = __float_as_uint(q2.w) >> 8; }
                     hit_prim = RT_INVALID_ID;
                     hit_u = 0.0f; hit_v = 0.0f;
@@ -1240,8 +1241,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
             if ((int)ref >= 0)
             {
                 const float4* np = reinterpret_cast<const float4*>(node_base + (size_t)(ref << 6));
-                const float4 q0 = np[0], q1 = np[1], q2 = np[2];
-                const float2 q3 = *reinterpret_cast<const float2*>(np + 3);
+                const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
                 const uint32_t meta = __float_as_uint(q0.w);
                 const float cx = __uint_as_float((meta & 0xFFu) << 23), cy = __uint_as_float(((meta >> 8) & 0xFFu) << 23),
                             cz = __uint_as_float(((meta >> 16) & 0xFFu) << 23);
@@ -1271,11 +1271,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                 if (!SHADOW)
                 {
                     // the reference's order: near child first at both BVH2 levels (trace_bvh.cl:181-190)
-                    const uint32_t axes = meta >> 24;
-                    const bool sw0 = ((sign_bits >> (axes & 3u)) & 1u) != 0u, swa = ((sign_bits >> ((axes >> 2) & 3u)) & 1u) != 0u,
-                               swb = ((sign_bits >> ((axes >> 4) & 3u)) & 1u) != 0u;
-                    // slot 1 empty <=> child 0 of the BVH2 node is a leaf: nothing to swap inside that pair
-                    const bool pa = swa && r[1] != RT_EMPTY_REF, pb = swb && r[3] != RT_EMPTY_REF;
+                    // (the three decisions per direction octant are tabulated in the record: build_wide_bvh)
+                    const uint32_t sw = __float_as_uint(q3.z) >> octant3;
+                    const bool sw0 = (sw & 1u) != 0u, pa = (sw & 2u) != 0u, pb = (sw & 4u) != 0u;
                     uint32_t tr; float te;
                     tr = pa ? r[1] : r[0]; r[1] = pa ? r[0] : r[1]; r[0] = tr;  te = pa ? e[1] : e[0]; e[1] = pa ? e[0] : e[1]; e[0] = te;
                     tr = pb ? r[3] : r[2]; r[3] = pb ? r[2] : r[3]; r[2] = tr;  te = pb ? e[3] : e[2]; e[3] = pb ? e[2] : e[3]; e[2] = te;

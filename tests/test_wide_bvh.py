@@ -14,7 +14,7 @@ import pytest
 from raytracing_amd import capi, host, scenes as S, types as T
 
 LEAF, EMPTY = 0x80000000, 0xFFFFFFFF
-WIDE = np.dtype([("origin", "<f4", 3), ("meta", "<u4"), ("lo", "<u4", 3), ("hi", "<u4", 3), ("ref", "<u4", 4), ("pad", "<u4", 2)])
+WIDE = np.dtype([("origin", "<f4", 3), ("meta", "<u4"), ("lo", "<u4", 3), ("hi", "<u4", 3), ("ref", "<u4", 4), ("order", "<u4"), ("pad", "<u4")])
 assert WIDE.itemsize == 64
 
 
@@ -67,6 +67,12 @@ def check(nodes):
             else:
                 slots += [c[i] + 1, int(nodes["offset"][c[i]])]
                 assert ((axes >> (2 + 2 * i)) & 3) == (int(nodes["num_primitives_axis"][c[i]]) & 0xFFFF)
+        # the order table: per direction-sign octant, swap the halves / inside half 0 / inside half 1 (trace_bvh.cl:181-190)
+        ax = [axes & 3, (axes >> 2) & 3, (axes >> 4) & 3]
+        for o in range(8):
+            want = ((o >> ax[0]) & 1) | ((((o >> ax[1]) & 1) if slots[1] is not None else 0) << 1) | \
+                   ((((o >> ax[2]) & 1) if slots[3] is not None else 0) << 2)
+            assert (int(rec["order"]) >> (3 * o)) & 7 == want
         for k, child in enumerate(slots):
             ref = int(rec["ref"][k])
             if child is None:
