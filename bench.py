@@ -151,6 +151,7 @@ def cpu_legs(args, scene_arrays, cam_small, small_w, small_h, cam_full):
             rays = sum(ri.ray_totals()) - r0
             ref_img, ref_spp = ri.radiance()[..., :3].copy(), n + 1
             baseline = dict(value=round(rays / dt / 1e6, 3), unit="Mrays/s", cores=best_t, kind="reference",
+                            opencl_cpu_device=opencl_cpu_device(),
                             sample="%d spp of the same scene at %dx%d, %d bounces (%.1f s; the reference's unmodified "
                                    ".cl kernels compiled for x86-64, NDRange = parallel-for over %d threads -- the best of "
                                    "8/16/32/64/%d on this %d-CPU host; more threads are slower because of the reference's "
@@ -161,6 +162,40 @@ def cpu_legs(args, scene_arrays, cam_small, small_w, small_h, cam_full):
                             sample="1 spp of the same scene at %dx%d, %d bounces (%.1f s, oracle/oracle.c, scalar)"
                                    % (small_w, small_h, args.bounces, t_orc))
     return per_ray, baseline, ref_img, ref_spp
+
+
+def opencl_cpu_device():
+    """is there a real OpenCL CPU device on this box?  (clGetDeviceIDs(CL_DEVICE_TYPE_CPU) over
+    every platform of the ICD loader.)  Returns its name, or None -- in which case the x86-64 build of the reference's
+    unmodified .cl files (oracle/_ref) IS the 'OpenCL-on-CPU' baseline."""
+    import ctypes as C
+    for name in ("libOpenCL.so.1", "libOpenCL.so", "/opt/rocm/lib/libOpenCL.so.1"):
+        try:
+            cl = C.CDLL(name)
+            break
+        except OSError:
+            cl = None
+    if cl is None:
+        return None
+    try:
+        n = C.c_uint(0)
+        if cl.clGetPlatformIDs(0, None, C.byref(n)) != 0 or n.value == 0:
+            return None
+        plats = (C.c_void_p * n.value)()
+        cl.clGetPlatformIDs(n.value, plats, None)
+        CL_DEVICE_TYPE_CPU, CL_DEVICE_NAME = 1 << 1, 0x102B
+        for p in plats:
+            nd = C.c_uint(0)
+            if cl.clGetDeviceIDs(C.c_void_p(p), C.c_ulong(CL_DEVICE_TYPE_CPU), 0, None, C.byref(nd)) != 0 or nd.value == 0:
+                continue
+            devs = (C.c_void_p * nd.value)()
+            cl.clGetDeviceIDs(C.c_void_p(p), C.c_ulong(CL_DEVICE_TYPE_CPU), nd.value, devs, None)
+            buf = C.create_string_buffer(256)
+            cl.clGetDeviceInfo(C.c_void_p(devs[0]), CL_DEVICE_NAME, 256, buf, None)
+            return buf.value.decode(errors="replace")
+    except Exception:
+        return None
+    return None
 
 
 def free_port():
