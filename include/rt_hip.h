@@ -158,7 +158,8 @@ enum rt_option
                                        for every value. */
     , RT_OPT_TRACE_TUNE = 12       /* k_trace2 (variants 8, 9) loop thresholds: value & 255 = lanes that must hold an
                                        interior node for a wave to stay in the node loop, value >> 8 & 255 = lanes that
-                                       must wait at a triangle for another pass of the triangle loop.  0 = defaults.
+                                       must wait at a triangle for another pass of the triangle loop, value >> 16 & 255 = rays a wave takes
+                                       from the queue per hand-out / 16 (k_trace_w4).  0 = defaults.
                                        Results are identical for every value. */
 };
 int rt_set_option(rt_frame* frame, int option, uint32_t value);

@@ -766,7 +766,7 @@ struct RayPool { uint32_t next, end, regions_tried; bool exhausted; };     // wa
 
 // gives every lane with `wants` (and no ray yet) the next index, until all are served or the queue is dry
 RT_DEV void hand_out_rays(RayPool& p, uint32_t lane, uint32_t xcd, uint32_t per, uint32_t count, uint32_t* __restrict__ heads,
-    bool wants, uint32_t& ray_i)
+    bool wants, uint32_t& ray_i, uint32_t batch = RT_TRACE_BATCH)
 {
     unsigned long long need = __ballot(wants && ray_i == RT_INVALID_ID);
     while (need)
@@ -780,12 +780,12 @@ RT_DEV void hand_out_rays(RayPool& p, uint32_t lane, uint32_t xcd, uint32_t per,
                 uint32_t rb = x * per < count ? x * per : count;
                 uint32_t re = (x + 1u) * per < count ? (x + 1u) * per : count;
                 uint32_t b = 0;
-                if (lane == 0 && rb < re) b = atomicAdd(&heads[x], RT_TRACE_BATCH);
+                if (lane == 0 && rb < re) b = atomicAdd(&heads[x], batch);
                 b = __shfl(b, 0, 64);
                 if (rb < re && b < re - rb)
                 {
                     p.next = rb + b;
-                    p.end = (b + RT_TRACE_BATCH < re - rb) ? rb + b + RT_TRACE_BATCH : re;
+                    p.end = (b + batch < re - rb) ? rb + b + batch : re;
                     got = true;
                     break;
                 }
@@ -812,10 +812,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(STACK <= 10 
 {
     __shared__ uint2 stack[STACK][64];
     uint32_t* const stack32 = reinterpret_cast<uint32_t*>(&stack[0][0]);     // SHADOW: 2 * STACK entries of 4 bytes
-    // the spill area is touched through volatile pointers: it keeps the compiler from folding the
-    // LDS and the HBM side of a push / pop into one flat_load / flat_store on a selected address
-    volatile uint2* const vspill = spill;
-    volatile uint32_t* const vspill32 = reinterpret_cast<volatile uint32_t*>(spill);
+    // spill area: plain stores, but VOLATILE loads -- otherwise the compiler folds the LDS and the HBM side of a pop into
+    // one flat_load on a selected generic address (and the common LDS pop loses its ds_read_b64)
+    uint2* const vspill = spill;
+    uint32_t* const vspill32 = reinterpret_cast<uint32_t*>(spill);
+    const volatile uint2* const lspill = spill;
+    const volatile uint32_t* const lspill32 = reinterpret_cast<const volatile uint32_t*>(spill);
     const uint32_t lane = threadIdx.x;
     const uint32_t count = *count_ptr;
     if (count == 0) return;
@@ -849,7 +851,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(STACK <= 10 
             {
                 --sp;
                 if (sp < 2 * STACK) ref = stack32[sp * 64 + lane];
-                else ref = vspill32[(size_t)2 * spill_base + (uint32_t)(sp - 2 * STACK)];
+                else ref = lspill32[(size_t)2 * spill_base + (uint32_t)(sp - 2 * STACK)];
             }
         }
         else
@@ -858,7 +860,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(STACK <= 10 
                 --sp;
                 uint32_t ex, ey;
                 if (sp < STACK) { const uint2 e = stack[sp][lane]; ex = e.x; ey = e.y; }
-                else { ex = vspill[(size_t)spill_base + (uint32_t)(sp - STACK)].x; ey = vspill[(size_t)spill_base + (uint32_t)(sp - STACK)].y; }
+                else { ex = lspill[(size_t)spill_base + (uint32_t)(sp - STACK)].x; ey = lspill[(size_t)spill_base + (uint32_t)(sp - STACK)].y; }
                 if (t_max >= __uint_as_float(ey)) { ref = ex; break; }       // box re-test at pop time
             }
     };
@@ -998,8 +1000,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(STACK <= 10 
                         if (sp < STACK) stack[sp][lane] = make_uint2(far_ref, far_entry);
                         else
                         {
-                            vspill[(size_t)spill_base + (uint32_t)(sp - STACK)].x = far_ref;
-                            vspill[(size_t)spill_base + (uint32_t)(sp - STACK)].y = far_entry;
+                            vspill[(size_t)spill_base + (uint32_t)(sp - STACK)] = make_uint2(far_ref, far_entry);
                         }
                     }
                     ++sp;
@@ -1048,12 +1049,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
 {
     __shared__ uint2 stack[STACK][64];
     uint32_t* const stack32 = reinterpret_cast<uint32_t*>(&stack[0][0]);     // SHADOW: 2 * STACK entries of 4 bytes
-    volatile uint2* const vspill = spill;                                   // see k_trace2
-    volatile uint32_t* const vspill32 = reinterpret_cast<volatile uint32_t*>(spill);
+    uint2* const vspill = spill;                                            // see k_trace2: plain stores, volatile loads
+    uint32_t* const vspill32 = reinterpret_cast<uint32_t*>(spill);
+    const volatile uint2* const lspill = spill;
+    const volatile uint32_t* const lspill32 = reinterpret_cast<const volatile uint32_t*>(spill);
     const uint32_t lane = threadIdx.x;
     const uint32_t count = *count_ptr;
     if (count == 0) return;
     const uint32_t node_q = tune & 0xFFu, leaf_q = (tune >> 8) & 0xFFu;
+    const uint32_t grab = ((tune >> 16) & 0xFFu) ? ((tune >> 16) & 0xFFu) * 16u : RT_TRACE_BATCH;   // rays per hand-out
     const uint32_t xcd = blockIdx.x & 7u;
     const uint32_t per = (((count + 7u) >> 3) + 63u) & ~63u;
     const uint32_t spill_base = (blockIdx.x * 64u + lane) * (uint32_t)(RT_W4_STACK_MAX - STACK);
@@ -1084,8 +1088,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
             if (sp < STACK) stack[sp][lane] = make_uint2(r, __float_as_uint(entry));
             else
             {
-                vspill[(size_t)spill_base + (uint32_t)(sp - STACK)].x = r;
-                vspill[(size_t)spill_base + (uint32_t)(sp - STACK)].y = __float_as_uint(entry);
+                vspill[(size_t)spill_base + (uint32_t)(sp - STACK)] = make_uint2(r, __float_as_uint(entry));
             }
         }
         ++sp;
@@ -1099,7 +1102,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
             {
                 --sp;
                 if (sp < 2 * STACK) ref = stack32[sp * 64 + lane];
-                else ref = vspill32[(size_t)2 * spill_base + (uint32_t)(sp - 2 * STACK)];
+                else ref = lspill32[(size_t)2 * spill_base + (uint32_t)(sp - 2 * STACK)];
             }
         }
         else
@@ -1108,7 +1111,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                 --sp;
                 uint32_t ex, ey;
                 if (sp < STACK) { const uint2 e = stack[sp][lane]; ex = e.x; ey = e.y; }
-                else { ex = vspill[(size_t)spill_base + (uint32_t)(sp - STACK)].x; ey = vspill[(size_t)spill_base + (uint32_t)(sp - STACK)].y; }
+                else { ex = lspill[(size_t)spill_base + (uint32_t)(sp - STACK)].x; ey = lspill[(size_t)spill_base + (uint32_t)(sp - STACK)].y; }
                 if (t_max >= __uint_as_float(ey)) { ref = ex; break; }       // conservative entry distance: pre-cull only
             }
     };
@@ -1131,7 +1134,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
             }
             if (!pool.exhausted)
             {
-                hand_out_rays(pool, lane, xcd, per, count, heads, ref == RT_IDLE_REF, ray_i);
+                hand_out_rays(pool, lane, xcd, per, count, heads, ref == RT_IDLE_REF, ray_i, grab);
                 bool slow = false;
                 if (ref == RT_IDLE_REF && ray_i != RT_INVALID_ID)
                 {

@@ -15,7 +15,7 @@ ap.add_argument("--bounces", type=int, default=8)
 ap.add_argument("--waves", default="0")
 ap.add_argument("--slots", default="1")
 ap.add_argument("--select", default="0", help="RT_OPT_TRACE_SELECT_FORM_BOX values to sweep")
-ap.add_argument("--tune", default="0", help="RT_OPT_TRACE_TUNE values to sweep for variants 8 / 9: node_q or node_q:leaf_q")
+ap.add_argument("--tune", default="0", help="RT_OPT_TRACE_TUNE values to sweep for variants 8-11: node_q[:leaf_q[:rays per hand-out]]")
 ap.add_argument("--config", type=int, default=0, help="bench.py config (scene, frame, bounces) instead of --tris/--width/--height/--bounces")
 args = ap.parse_args()
 
@@ -39,7 +39,7 @@ lib.rt_set_option(frame, capi.OPT_PROFILE, 1)
 ref_img = None
 def parse_tune(t):
     a = t.split(":")
-    return int(a[0]) | ((int(a[1]) if len(a) > 1 else 0) << 8)
+    return int(a[0]) | ((int(a[1]) if len(a) > 1 else 0) << 8) | (((int(a[2]) // 16) if len(a) > 2 else 0) << 16)
 
 
 for v, wv, sl, sel, tune in [(int(x), int(w), int(z), int(q), parse_tune(t)) for x in args.variants.split(",") for w in args.waves.split(",")
@@ -64,5 +64,5 @@ for v, wv, sl, sel, tune in [(int(x), int(w), int(z), int(q), parse_tune(t)) for
     if ref_img is None:
         ref_img = img
     print("variant %d tune %d:%d waves %d slots %d select %d: %.2f ms/spp  %.1f Mrays/s | closest %.3f ms  shadow %.3f ms  shade %.3f ms per spp | closest %.0f Mrays/s shadow %.0f Mrays/s | identical=%s"
-          % (v, tune & 255, tune >> 8, wv, sl, sel, dt * 1e3 / args.spp, rays / dt / 1e6, prof.ms_trace_closest / args.spp, prof.ms_trace_shadow / args.spp,
+          % (v, tune & 255, (tune >> 8) & 255, wv, sl, sel, dt * 1e3 / args.spp, rays / dt / 1e6, prof.ms_trace_closest / args.spp, prof.ms_trace_shadow / args.spp,
              prof.ms_shade / args.spp, st.closest_rays / prof.ms_trace_closest / 1e3, st.shadow_rays / prof.ms_trace_shadow / 1e3, same), flush=True)
