@@ -125,7 +125,7 @@ enum rt_option
     RT_OPT_TRACE_VARIANT = 7    /* traversal kernel: 0 = v1 per-ray loop; 1 .. 4, 6, 7 = one-fetch-per-iteration
                                    state machine with a 16 / 24 / 12 / 8, 10 / 11 entry LDS stack; 8 / 9 = k_trace2
                                    (separate wave-uniform node / triangle / refill loops) with a 10+12 / 12+12 entry
-                                   stack (closest + shadow); 10 = k_trace_w4 (4-wide quantized tree, exact leaf
+                                   stack (closest + shadow); 10 (11..14: other LDS stack sizes) = k_trace_w4 (4-wide quantized tree, exact leaf
                                    re-test; rays it cannot take -- non-finite 1/dir -- go to k_trace2); 5 (default) = auto: 0 below 2 M paths per launch, 8
                                    above.  Results are identical for every value. */
     , RT_OPT_TRACE_WAVES_PER_CU = 8 /* persistent-grid size of the trace kernels in waves per CU (0 = as many as fit) */

@@ -1044,7 +1044,7 @@ int rt_set_option(rt_frame* f, int option, uint32_t value)
         return RT_OK;
     case RT_OPT_DEBUG_ALLOC_LIMIT: f->debug_alloc_limit = value; return RT_OK;
     case RT_OPT_TRACE_VARIANT:
-        if (value > 11) return fail(f->ctx, "rt_set_option: unknown trace kernel variant");
+        if (value > 14) return fail(f->ctx, "rt_set_option: unknown trace kernel variant");
         f->trace_variant = value;
         return RT_OK;
     default: return fail(f->ctx, "rt_set_option: unknown option");
@@ -1186,8 +1186,7 @@ void launch_trace(rt_frame* f, const float4* o4, const float4* d4, const float4*
         uint64_t paths = (uint64_t)f->p->chunk_count * (f->p->cur_slots ? f->p->cur_slots : 1u);
         variant = paths >= 2000000ull ? 10u : 0u;
     }
-    if ((variant == 10u || variant == 11u) && (!ctx->scene.d.wnodes && !(ctx->scene.d.w_entry_ref & RT_LEAF_BIT))) variant = 8u;
-    if ((variant == 10u || variant == 11u) && !ctx->scene.wide_ok) variant = 8u;
+    if (variant >= 10u && variant <= 14u && !ctx->scene.wide_ok) variant = 8u;
     if ((variant == 8u || variant == 9u) && !ctx->scene.offsets32) variant = 3u;
     switch (variant)
     {
@@ -1208,6 +1207,9 @@ void launch_trace(rt_frame* f, const float4* o4, const float4* d4, const float4*
     case 9: launch_trace2<SHADOW, 12>(f, o4, d4, iv4, count); break;
     case 10: launch_trace_w4<SHADOW, 12>(f, o4, d4, iv4, count); break;
     case 11: launch_trace_w4<SHADOW, 16>(f, o4, d4, iv4, count); break;
+    case 12: launch_trace_w4<SHADOW, 13>(f, o4, d4, iv4, count); break;
+    case 13: launch_trace_w4<SHADOW, 11>(f, o4, d4, iv4, count); break;
+    case 14: launch_trace_w4<SHADOW, 10>(f, o4, d4, iv4, count); break;
     default: launch_trace_sm<SHADOW, 12>(f, o4, d4, iv4, count); break;
     }
 }

@@ -1041,6 +1041,21 @@ RT_DEV float w4_plane(uint32_t word, int k, float cell, float origin)
     return __builtin_fmaf((float)((word >> (8 * k)) & 0xFFu), cell, origin);
 }
 
+// Reads from the per-lane HBM spill area of the traversal stack (rare path).  Inline assembly on purpose: see the note
+// at the use in k_trace_w4.  The wait inside covers every outstanding vector-memory operation of the wave.
+RT_DEV uint2 spill_load64(const uint2* p)
+{
+    unsigned long long v;
+    asm volatile("global_load_dwordx2 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return make_uint2((uint32_t)v, (uint32_t)(v >> 32));
+}
+RT_DEV uint32_t spill_load32(const uint32_t* p)
+{
+    uint32_t v;
+    asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+
 template <bool SHADOW, int STACK>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_trace_w4(DScene sc, const float4* __restrict__ o4, const float4* __restrict__ d4,
     const float4* __restrict__ iv4, const uint32_t* __restrict__ count_ptr, uint32_t* __restrict__ heads,
@@ -1049,17 +1064,24 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
 {
     __shared__ uint2 stack[STACK][64];
     uint32_t* const stack32 = reinterpret_cast<uint32_t*>(&stack[0][0]);     // SHADOW: 2 * STACK entries of 4 bytes
-    uint2* const vspill = spill;                                            // see k_trace2: plain stores, volatile loads
+    // spill area: plain (cached) stores; the loads go through spill_load*: written in C they are folded with the LDS side
+    // of the pop into one flat_load on a selected generic address, and the common LDS pop loses its ds_read_b64
+    uint2* const vspill = spill;
     uint32_t* const vspill32 = reinterpret_cast<uint32_t*>(spill);
-    const volatile uint2* const lspill = spill;
-    const volatile uint32_t* const lspill32 = reinterpret_cast<const volatile uint32_t*>(spill);
     const uint32_t lane = threadIdx.x;
     const uint32_t count = *count_ptr;
     if (count == 0) return;
     const uint32_t node_q = tune & 0xFFu, leaf_q = (tune >> 8) & 0xFFu;
-    const uint32_t grab = ((tune >> 16) & 0xFFu) ? ((tune >> 16) & 0xFFu) * 16u : RT_TRACE_BATCH;   // rays per hand-out
     const uint32_t xcd = blockIdx.x & 7u;
     const uint32_t per = (((count + 7u) >> 3) + 63u) & ~63u;
+    // rays a wave takes from the queue per hand-out: large, because every hand-out is one atomic on one of eight
+    // addresses that 6000 waves share (128 -> 512 rays: +3 %, profiles/r02_handout_sweep.log), but never so large that a
+    // wave would empty its region in fewer than ~4 hand-outs (small launches: late bounces, chunks, tiles)
+    uint32_t grab = ((tune >> 16) & 0xFFu) ? ((tune >> 16) & 0xFFu) * 16u : 512u;
+    {
+        const uint32_t fair = (per / ((gridDim.x >> 3) * 4u + 1u)) & ~63u;
+        grab = fair < grab ? (fair < 64u ? 64u : fair) : grab;
+    }
     const uint32_t spill_base = (blockIdx.x * 64u + lane) * (uint32_t)(RT_W4_STACK_MAX - STACK);
     const char* const node_base = reinterpret_cast<const char*>(sc.wnodes);
     const char* const tri_base = reinterpret_cast<const char*>(sc.tris_rt);
@@ -1102,7 +1124,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
             {
                 --sp;
                 if (sp < 2 * STACK) ref = stack32[sp * 64 + lane];
-                else ref = lspill32[(size_t)2 * spill_base + (uint32_t)(sp - 2 * STACK)];
+                else ref = spill_load32(vspill32 + (size_t)2 * spill_base + (uint32_t)(sp - 2 * STACK));
             }
         }
         else
@@ -1111,7 +1133,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                 --sp;
                 uint32_t ex, ey;
                 if (sp < STACK) { const uint2 e = stack[sp][lane]; ex = e.x; ey = e.y; }
-                else { ex = lspill[(size_t)spill_base + (uint32_t)(sp - STACK)].x; ey = lspill[(size_t)spill_base + (uint32_t)(sp - STACK)].y; }
+                else { const uint2 e = spill_load64(vspill + (size_t)spill_base + (uint32_t)(sp - STACK)); ex = e.x; ey = e.y; }
                 if (t_max >= __uint_as_float(ey)) { ref = ex; break; }       // conservative entry distance: pre-cull only
             }
     };

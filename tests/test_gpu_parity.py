@@ -264,7 +264,7 @@ def test_directly_against_the_reference_kernels(ctx, golden_scenes):
 
 
 @pytest.mark.parametrize("slots", [2, 3, 8])
-@pytest.mark.parametrize("variant", [0, 1, 3, 5, 6, 8, 9, 10, 11, 103, 208, 308, 210, 310])
+@pytest.mark.parametrize("variant", [0, 1, 3, 5, 6, 8, 9, 10, 11, 13, 14, 103, 208, 308, 210, 310])
 def test_samples_in_flight_and_kernel_variants_are_bit_invariant(ctx, golden_scenes, slots, variant):
     """RT_OPT_SAMPLES_IN_FLIGHT traces several samples of a pixel concurrently; the
     radiance log replays their contributions in the reference's order, so the sum

@@ -44,7 +44,7 @@ def parse_tune(t):
 
 for v, wv, sl, sel, tune in [(int(x), int(w), int(z), int(q), parse_tune(t)) for x in args.variants.split(",") for w in args.waves.split(",")
                              for z in args.slots.split(",") for q in args.select.split(",")
-                             for t in (args.tune.split(",") if int(x) in (8, 9, 10, 11) else ["0"])]:
+                             for t in (args.tune.split(",") if int(x) >= 8 else ["0"])]:
     assert lib.rt_set_option(frame, capi.OPT_TRACE_TUNE, tune) == 0
     assert lib.rt_set_option(frame, capi.OPT_SELECT_FORM_BOX, sel) == 0
     assert lib.rt_set_option(frame, capi.OPT_SAMPLES_IN_FLIGHT, sl) == 0
