@@ -97,6 +97,7 @@ struct rt_frame
     uint32_t chunk_pixels = 0;     // pixels per chunk as allocated (n_local when the tile is not chunked)
     uint32_t state_limit_mb = 0;   // RT_OPT_PATH_STATE_LIMIT_MB (0 = only the built-in 144 GB rule)
     uint32_t log_entries = 0;      // rows allocated (>= 2 * (max_bounces + 1))
+    bool fused = false;            // inside rt_integrate: whole samples, nothing reads the radiance between stages
     uint32_t trace_blocks;       // v1 grid
     uint32_t trace_variant = 5;  // RT_OPT_TRACE_VARIANT (5 = auto)
     uint32_t trace_waves_per_cu = 0;   // RT_OPT_TRACE_WAVES_PER_CU (0 = LDS-limited residency)
@@ -1314,6 +1315,8 @@ int rt_shade(rt_frame* f, uint32_t bounce)              // ShadeMissedRays + Sha
     a.emit_outgoing = (f->drop_last && bounce >= f->max_bounces) ? 0u : 1u;
     a.n_local = f->chunk_pixels ? f->chunk_pixels : 1; a.log_stride = f->log_stride;
     a.pix_base = f->p->chunk_base;
+    a.count_in_ray = f->fused ? 1u : 0u;
+    a.final_bounce = bounce >= f->max_bounces ? 1u : 0u;
     if (2u * (bounce + 1u) > f->log_entries) return fail(ctx, "rt_shade: bounce beyond the configured max_bounces");
     uint32_t blocks = (f->p->chunk_count * (f->p->cur_slots ? f->p->cur_slots : 1u) + RT_SHADE_BLOCK - 1u) / RT_SHADE_BLOCK;
     if (blocks == 0) blocks = 1;
@@ -1416,6 +1419,7 @@ int rt_integrate(rt_frame* f, uint32_t n_samples)       // n x Integrator::Integ
         return fail(ctx, "rt_integrate: AOVs / the denoiser need the whole tile in one chunk (raise RT_OPT_PATH_STATE_LIMIT_MB)");
     if (fork_pipes(f) != RT_OK) return RT_ERROR;
     int rc = RT_OK;
+    f->fused = true;
     while (done < n_samples && rc == RT_OK)
     {
         uint32_t batch = n_samples - done < cap ? n_samples - done : cap;
@@ -1445,6 +1449,7 @@ int rt_integrate(rt_frame* f, uint32_t n_samples)       // n x Integrator::Integ
         done += batch;
     }
     f->p = &f->ps[0];
+    f->fused = false;
     if (join_pipes(f) != RT_OK) return RT_ERROR;         // whatever follows on the context's stream sees every chunk
     return rc;
 }

@@ -310,6 +310,10 @@ struct ShadeArgs
     DCounters* counters;
     uint32_t bounce, sample_base, emit_outgoing, n_local, log_stride;   // n_local: pixels per chunk (path id = slot * n_local + pixel in chunk)
     uint32_t pix_base;                                                  // first local pixel of the chunk
+    uint32_t final_bounce;   // 1: no shade launch follows for these paths (bounce == max_bounces)
+    uint32_t count_in_ray;   // 1 (rt_integrate): a path's number of log entries travels with its ray (thr.w) and cnt[id] is
+                             // written once, when the path ends; 0 (stage API): cnt[id] is read and written at every bounce,
+                             // so that the radiance can be read between any two stages
 };
 
 // SampleBlueNoise, sampling.h:40-61 (Heitz et al. 2019 tables, values 0..255).  The reference
@@ -353,9 +357,9 @@ __global__ __launch_bounds__(RT_SHADE_BLOCK) void k_shade(DScene sc, DTile tile,
         uint32_t slot = id / a.n_local;
         uint32_t pix = id - slot * a.n_local;
         uint32_t sample_idx = a.sample_base + slot;
-        uint32_t nlog = a.cnt[id];                                         // contributions logged so far
-        float4* mylog = a.rlog + id;
         float4 thr4 = a.in_thr[i];
+        uint32_t nlog = a.count_in_ray ? __float_as_uint(thr4.w) : a.cnt[id];   // contributions logged so far
+        float4* mylog = a.rlog + id;
         f3 hit_throughput = F3(thr4.x, thr4.y, thr4.z);
 
         if (prim == RT_INVALID_ID)
@@ -470,7 +474,8 @@ __global__ __launch_bounds__(RT_SHADE_BLOCK) void k_shade(DScene sc, DTile tile,
                 nx_t = make_float4(new_thr.x, new_thr.y, new_thr.z, 0.0f);
             }
         }
-        a.cnt[id] = nlog;
+        nx_t.w = __uint_as_float(nlog);
+        if (!a.count_in_ray || ((!want_next || a.final_bounce) && nlog != 0u)) a.cnt[id] = nlog;   // the path's final count is what k_flush replays
     }
 
     uint32_t sidx, nidx;
