@@ -308,7 +308,13 @@ void LoadMtl(const std::string& path, std::vector<ObjMaterial>& materials, std::
 // ---------------------------------------------------------------------------
 Scene::Scene(const char* filename, float scale, bool flip_yz)
 {
-    if (IsCacheFile(filename)) LoadCache(filename);
+    if (IsCacheFile(filename))
+    {
+        LoadCache(filename);
+        // a cache holds the scene as it was loaded: scale and axis flip were applied when it was written
+        if (scale != 1.0f || flip_yz)
+            std::fprintf(stderr, "warning: %s is a scene cache; --scale / --flip_yz were fixed when it was written and are ignored\n", filename);
+    }
     else Load(filename, scale, flip_yz);
 }
 
@@ -377,7 +383,10 @@ void Scene::Load(const char* filename, float scale, bool flip_yz)
             if (poly.size() == 3) emit(0, 1, 2);
             else if (poly.size() == 4)
             {
-                // tinyobj quad rule: cut along the shorter diagonal
+                // tinyobj quad rule: cut along the shorter diagonal (the positions must exist: a face may name a
+                // vertex that is defined later or never -- the general index check comes after the parse)
+                for (const VertexIndex& q : poly)
+                    if (q.v < 0 || (size_t)q.v * 3 + 2 >= v.size()) throw std::runtime_error("Failed to load the scene!");
                 auto P = [&](int k, int c) { return v[(size_t)poly[k].v * 3 + c]; };
                 float e02x = P(2, 0) - P(0, 0), e02y = P(2, 1) - P(0, 1), e02z = P(2, 2) - P(0, 2);
                 float e13x = P(3, 0) - P(1, 0), e13y = P(3, 1) - P(1, 1), e13z = P(3, 2) - P(1, 2);
@@ -557,6 +566,7 @@ namespace
 bool OldDecrunch(unsigned char (*scan)[4], int len, FILE* f)
 {
     int rshift = 0;
+    unsigned char (*const first)[4] = scan;
     while (len > 0)
     {
         scan[0][0] = (unsigned char)fgetc(f);
@@ -566,7 +576,8 @@ bool OldDecrunch(unsigned char (*scan)[4], int len, FILE* f)
         if (feof(f)) return false;
         if (scan[0][0] == 1 && scan[0][1] == 1 && scan[0][2] == 1)
         {
-            for (unsigned char i = (unsigned char)(scan[0][3] << rshift); i > 0; i--)
+            if (scan == first) return false;                 // a run marker needs a previous pixel to repeat
+            for (unsigned char i = (unsigned char)(scan[0][3] << rshift); i > 0 && len > 0; i--)   // never past the scanline
             {
                 memcpy(&scan[0][0], &scan[-1][0], 4);
                 scan++;

@@ -125,5 +125,27 @@ void Scene::LoadCache(const char* path)
     ReadArray(in.f, textures_, h.counts[3], sum, path);
     ReadArray(in.f, texture_data_, h.counts[4], sum, path);
     if (sum.h != h.checksum) throw std::runtime_error(std::string("scene cache: checksum mismatch (corrupt file) ") + path);
+    // the checksum covers accidents, not a stale or hand-made file: Finalize() and the upload index these arrays on the host
+    auto bad = [&](const char* what) { return std::runtime_error(std::string("scene cache: inconsistent contents (") + what + ") in " + path); };
+    for (const Triangle& t : triangles_)
+        if (t.mtlIndex >= materials_.size()) throw bad("triangle material index");
+    for (std::size_t i = 0; i < prebuilt_nodes_.size(); ++i)
+    {
+        const LinearBVHNode& n = prebuilt_nodes_[i];
+        const std::uint32_t count = n.num_primitives_axis >> 16;
+        if (count != 0) { if ((std::uint64_t)n.offset + count > triangles_.size()) throw bad("leaf range"); }
+        else if (i + 1 >= prebuilt_nodes_.size() || n.offset <= i + 1 || n.offset >= prebuilt_nodes_.size() ||
+                 (n.num_primitives_axis & 0xFFFFu) > 2u) throw bad("child offset / split axis");
+    }
+    for (const Texture& t : textures_)
+        if (t.width <= 0 || t.height <= 0 || t.data_start < 0 ||
+            (std::uint64_t)t.data_start + (std::uint64_t)t.width * (std::uint64_t)t.height > texture_data_.size()) throw bad("texture range");
+    for (const PackedMaterial& m : materials_)
+    {
+        const std::uint32_t idx[6] = {m.diffuse_albedo >> 24, m.specular_albedo >> 24, (m.roughness_metalness >> 8) & 0xFFu,
+            m.roughness_metalness >> 24, (m.ior_emission_idx_transparency >> 8) & 0xFFu, m.ior_emission_idx_transparency >> 24};
+        for (std::uint32_t t : idx)
+            if (t != 0xFFu && t >= textures_.size()) throw bad("material texture index");
+    }
 }
 } // namespace rt

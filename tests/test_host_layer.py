@@ -208,6 +208,27 @@ def test_binary_scene_cache_round_trip(tmp_path):
     open(str(tmp_path / "flip.rtscene"), "wb").write(raw)
     with pytest.raises(host.RtError, match="checksum"):
         host.Scene(str(tmp_path / "flip.rtscene"))
+    # a file that is internally inconsistent although its checksum is right (stale / hand-made cache): the
+    # triangle arrays index materials on the host in Finalize(), so the loader checks the contents too
+    bad = {k: v.copy() for k, v in cov.items()}
+    bad["triangles"]["mtl_index"][3] = 10_000
+    sb = host.Scene(arrays=bad)
+    sb.build_bvh()
+    sb.save_cache(str(tmp_path / "bad.rtscene"))
+    with pytest.raises(host.RtError, match="inconsistent contents"):
+        host.Scene(str(tmp_path / "bad.rtscene"))
+
+
+def test_malformed_obj_faces_fail_cleanly(tmp_path):
+    """A quad that names a vertex defined nowhere must raise the loader's error, not read out of bounds
+    (the quad-diagonal rule looks at the positions before the general index check)."""
+    p = tmp_path / "bad.obj"
+    p.write_text("v 0 0 0\nv 1 0 0\nv 1 1 0\nf 1 2 3 9\n")
+    with pytest.raises(host.RtError, match="Failed to load the scene"):
+        host.Scene(str(p))
+    p.write_text("v 0 0 0\nv 1 0 0\nv 1 1 0\nf 1 2 3 -7\n")
+    with pytest.raises(host.RtError, match="Failed to load the scene"):
+        host.Scene(str(p))
 
 
 @pytest.mark.skipif(not _ref.available(), reason="oracle/_ref/libref.so not built")
