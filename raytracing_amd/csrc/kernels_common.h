@@ -17,7 +17,7 @@
 //                iv4[i] = (1/dir.xyz, sign bits) computed by the PRODUCER of the ray (all 64
 //                lanes busy) instead of by the traversal kernel (where ~2 lanes of a wave
 //                start a ray in any given iteration), thr[i] = (throughput.xyz, -).
-//                path id = pixel * n_slots + slot, where `slot` numbers the samples in flight
+//                path id = slot * n_pixels + pixel, where `slot` numbers the samples in flight
 //                (RT_OPT_SAMPLES_IN_FLIGHT); a shadow ray also carries the radiance-log entry
 //                of its deferred direct sample in iv4[i].w (sign bits | entry << 8)
 //   radiance log per path: cnt[id] + log[k][id] (float4) = the path's radiance

@@ -7,7 +7,7 @@
 // sample begin + ray generation (raygeneration.cl:65-139)
 // ---------------------------------------------------------------------------
 // The tile may be rendered in CHUNKS of pixels (RT_OPT_PATH_STATE_LIMIT_MB): this launch covers local pixels
-// chunk_base .. chunk_base + chunk_count - 1; path ids are chunk-relative (pixel in chunk * n_slots + slot; chunk_stride = pixels per chunk as allocated, unused here).
+// chunk_base .. chunk_base + chunk_count - 1; path ids are chunk-relative (slot * chunk_stride + pixel in chunk).
 __global__ __launch_bounds__(256) void k_raygen(DTile tile, rt_camera cam, uint32_t sample_base, uint32_t n_slots,
     float tan_half_fov, uint32_t prev_bounces, float4* __restrict__ o4, float4* __restrict__ d4,
     float4* __restrict__ iv4, float4* __restrict__ thr, DCounters* __restrict__ counters, uint32_t chunk_base,
@@ -40,10 +40,8 @@ __global__ __launch_bounds__(256) void k_raygen(DTile tile, rt_camera cam, uint3
     // a wave holds a few pixels x all their samples -- nearly identical primary rays, and
     // secondary/shadow rays that start from the same small surface patch (shadow rays towards
     // a directional light are then almost parallel AND co-located).  Fewer distinct BVH
-    // records per load instruction is what the L1 data path rewards.  The path id is pixel-major too
-    // (pixel in chunk * n_slots + slot = the queue position here): neighbours in a queue then have neighbouring ids
-    // all the way down the bounces, so the log / counter writes of k_shade and the retractions of the shadow
-    // kernel land in the same cache lines instead of n_pixels * 16 bytes apart.
+    // records per load instruction is what the L1 data path rewards.  The path id keeps the
+    // slot-major form (slot * n_local + pixel) the radiance log is laid out by.
     uint32_t cp = i / n_slots;                                           // pixel of this chunk
     uint32_t slot = i - cp * n_slots;
     uint32_t lp = chunk_base + cp;                                       // local pixel of this tile
@@ -88,7 +86,7 @@ __global__ __launch_bounds__(256) void k_raygen(DTile tile, rt_camera cam, uint3
     f3 d = normalize3(point_aimed - new_pos);
 
     o4[i] = make_float4(new_pos.x, new_pos.y, new_pos.z, RT_MAX_RENDER_DIST);
-    d4[i] = make_float4(d.x, d.y, d.z, __uint_as_float(cp * n_slots + slot));   // path id
+    d4[i] = make_float4(d.x, d.y, d.z, __uint_as_float(slot * chunk_stride + cp));   // path id
     iv4[i] = ray_inverse(d);
     thr[i] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
 }

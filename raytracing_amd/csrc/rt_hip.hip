@@ -849,7 +849,7 @@ int flush_log(rt_frame* f)
         return fail(ctx, "radiance requested between rt_shade and rt_intersect_shadow (direct samples still tentative)");
     uint32_t blocks = (f->p->chunk_count + 255u) / 256u;
     hipLaunchKernelGGL(k_flush, dim3(blocks), dim3(256), 0, f->p->stream, f->radiance + f->p->chunk_base, (const float4*)f->p->rlog, f->p->cnt,
-        f->p->chunk_count, f->p->cur_slots, f->log_stride);
+        f->p->chunk_count, f->p->cur_slots, f->log_stride, f->chunk_pixels);
     if (hipGetLastError() != hipSuccess) return fail(ctx, "k_flush launch failed");
     f->p->cur_slots = 0;
     return RT_OK;
@@ -1313,7 +1313,7 @@ int rt_shade(rt_frame* f, uint32_t bounce)              // ShadeMissedRays + Sha
     a.bn_rank = ctx->blue_noise ? ctx->blue_noise + 65536 + 131072 : nullptr;
     a.bounce = bounce; a.sample_base = f->sample_count;
     a.emit_outgoing = (f->drop_last && bounce >= f->max_bounces) ? 0u : 1u;
-    a.n_slots = f->p->cur_slots ? f->p->cur_slots : 1u; a.log_stride = f->log_stride;
+    a.n_local = f->chunk_pixels ? f->chunk_pixels : 1; a.log_stride = f->log_stride;
     a.pix_base = f->p->chunk_base;
     a.count_in_ray = f->fused ? 1u : 0u;
     a.final_bounce = bounce >= f->max_bounces ? 1u : 0u;
@@ -1582,7 +1582,7 @@ int rt_frame_debug_read_queue(rt_frame* f, int which, uint32_t bounce, rt_ray* r
         uint32_t pl;
         memcpy(&pl, &d[i].w, 4);
         uint32_t id = pl;
-        uint32_t local_pix = f->p->chunk_base + id / (f->p->cur_slots ? f->p->cur_slots : 1u);
+        uint32_t local_pix = f->p->chunk_base + id % (f->chunk_pixels ? f->chunk_pixels : 1);
         if (which == 1)   // the deferred direct-light sample lives in the radiance log
         {
             float4 iv;

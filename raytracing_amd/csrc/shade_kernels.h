@@ -308,7 +308,7 @@ struct ShadeArgs
     float4* rlog; uint32_t* cnt;      // radiance log (see file header)
     const uint8_t* bn_sobol; const uint8_t* bn_scramble; const uint8_t* bn_rank;   // SamplerType::kBlueNoise tables
     DCounters* counters;
-    uint32_t bounce, sample_base, emit_outgoing, n_slots, log_stride;   // n_slots: samples of the batch in flight (path id = pixel in chunk * n_slots + slot)
+    uint32_t bounce, sample_base, emit_outgoing, n_local, log_stride;   // n_local: pixels per chunk (path id = slot * n_local + pixel in chunk)
     uint32_t pix_base;                                                  // first local pixel of the chunk
     uint32_t final_bounce;   // 1: no shade launch follows for these paths (bounce == max_bounces)
     uint32_t count_in_ray;   // 1 (rt_integrate): a path's number of log entries travels with its ray (thr.w) and cnt[id] is
@@ -353,9 +353,9 @@ __global__ __launch_bounds__(RT_SHADE_BLOCK) void k_shade(DScene sc, DTile tile,
         float4 hit = a.hits[i];
         float4 rd = a.in_d4[i];
         uint32_t prim = __float_as_uint(hit.z);
-        uint32_t id = __float_as_uint(rd.w);                               // pixel in chunk * n_slots + slot
-        uint32_t pix = id / a.n_slots;
-        uint32_t slot = id - pix * a.n_slots;
+        uint32_t id = __float_as_uint(rd.w);                               // slot * n_local + local pixel
+        uint32_t slot = id / a.n_local;
+        uint32_t pix = id - slot * a.n_local;
         uint32_t sample_idx = a.sample_base + slot;
         float4 thr4 = a.in_thr[i];
         uint32_t nlog = a.count_in_ray ? __float_as_uint(thr4.w) : a.cnt[id];   // contributions logged so far
@@ -501,15 +501,15 @@ __global__ __launch_bounds__(RT_SHADE_BLOCK) void k_shade(DScene sc, DTile tile,
 // by contribution -- the exact order in which the reference's kernels executed
 // `radiance[pixel] += ...` (miss.cl:75, hit_surface.cl:110, accumulate_direct_samples.cl:51).
 __global__ __launch_bounds__(256) void k_flush(float4* __restrict__ radiance, const float4* __restrict__ rlog,
-    uint32_t* __restrict__ cnt, uint32_t n_pixels, uint32_t n_slots, uint32_t log_stride)
+    uint32_t* __restrict__ cnt, uint32_t n_pixels, uint32_t n_slots, uint32_t log_stride, uint32_t id_stride)
 {
-    // radiance: already offset to the chunk's first pixel.  A thread walks the n_slots consecutive ids of its pixel.
+    // radiance: already offset to the chunk's first pixel; id_stride: pixels per chunk as allocated
     uint32_t p = blockIdx.x * 256u + threadIdx.x;
     if (p >= n_pixels) return;
     float4 r = radiance[p];
     for (uint32_t slot = 0; slot < n_slots; ++slot)
     {
-        uint32_t id = p * n_slots + slot;
+        uint32_t id = slot * id_stride + p;
         uint32_t c = cnt[id];
         for (uint32_t k = 0; k < c; ++k)
         {
