@@ -41,7 +41,10 @@ __global__ __launch_bounds__(256) void k_raygen(DTile tile, rt_camera cam, uint3
     // secondary/shadow rays that start from the same small surface patch (shadow rays towards
     // a directional light are then almost parallel AND co-located).  Fewer distinct BVH
     // records per load instruction is what the L1 data path rewards.  The path id keeps the
-    // slot-major form (slot * n_local + pixel) the radiance log is laid out by.
+    // slot-major form (slot * n_local + pixel) the radiance log is laid out by.  (Pixel-major ids were tried in
+    // round 2: k_shade's log writes and the shadow kernel's retractions then share cache lines, -5 % / -2 % on those
+    // kernels, but k_flush -- one thread per pixel walking its samples in order -- loses its coalescing and goes from
+    // 3.7 to 20 ms per batch: a net loss.)
     uint32_t cp = i / n_slots;                                           // pixel of this chunk
     uint32_t slot = i - cp * n_slots;
     uint32_t lp = chunk_base + cp;                                       // local pixel of this tile
