@@ -156,6 +156,9 @@ enum rt_option
                                        flight, >= 4 M paths), so that chunks overlap.  Measured: no gain on MI355X
                                        (profiles/r02_pipelines_sweep.log), hence off by default.  Results are bit-identical
                                        for every value. */
+    , RT_OPT_SHADE_PARTITION = 16  /* 1 (default): k_shade processes each block's 512 queue entries hits first, misses last,
+                                       so that a wave runs either the surface code or the environment lookup, not both.
+                                       Results are identical for both values. */
     , RT_OPT_TRACE_TUNE = 12       /* k_trace2 (variants 8, 9) loop thresholds: value & 255 = lanes that must hold an
                                        interior node for a wave to stay in the node loop, value >> 8 & 255 = lanes that
                                        must wait at a triangle for another pass of the triangle loop, value >> 16 & 255 = rays a wave takes

@@ -310,6 +310,7 @@ struct ShadeArgs
     DCounters* counters;
     uint32_t bounce, sample_base, emit_outgoing, n_local, log_stride;   // n_local: pixels per chunk (path id = slot * n_local + pixel in chunk)
     uint32_t pix_base;                                                  // first local pixel of the chunk
+    uint32_t partition;      // 1: hits first / misses last inside every block (RT_OPT_SHADE_PARTITION)
     uint32_t final_bounce;   // 1: no shade launch follows for these paths (bounce == max_bounces)
     uint32_t count_in_ray;   // 1 (rt_integrate): a path's number of log entries travels with its ray (thr.w) and cnt[id] is
                              // written once, when the path ends; 0 (stage API): cnt[id] is read and written at every bounce,
@@ -336,12 +337,43 @@ template <bool FURNACE, bool BLUE>
 __global__ __launch_bounds__(RT_SHADE_BLOCK) void k_shade(DScene sc, DTile tile, ShadeArgs a)
 {
     const uint32_t count = a.counters->queue[a.bounce];
-    const uint32_t i = blockIdx.x * RT_SHADE_BLOCK + threadIdx.x;
     // the closest-hit trace of this bounce has completed (stream order): rewind the
     // work heads for the shadow trace of this bounce and the closest trace of the next
-    if (i < 16) { a.counters->head[i >> 3][i & 7] = 0; a.counters->slow_head[i >> 3][i & 7] = 0; }
-    if (i < 2) a.counters->slow_count[i] = 0;
+    {
+        const uint32_t g = blockIdx.x * RT_SHADE_BLOCK + threadIdx.x;
+        if (g < 16) { a.counters->head[g >> 3][g & 7] = 0; a.counters->slow_head[g >> 3][g & 7] = 0; }
+        if (g < 2) a.counters->slow_count[g] = 0;
+    }
     if (blockIdx.x * RT_SHADE_BLOCK >= count) return;                    // whole block idle (uniform)
+    // Hits first, misses last inside the block's 512 queue entries: a wave then holds (almost) only hits or only
+    // misses, and the two divergent halves of the kernel -- SampleSky's fp64 atan2 / acos for an escaped ray,
+    // material + light + BSDF code for a hit -- are no longer both executed by every wave.  (Round 1 tried this when
+    // the kernel was bound by its scattered counter traffic: no gain; with that gone the vector ALU is its busiest
+    // unit and the partition pays.)  Any order of the entries gives the same image: everything is keyed by path id.
+    uint32_t i = blockIdx.x * RT_SHADE_BLOCK + threadIdx.x;
+    if (a.partition)
+    {
+        __shared__ uint16_t s_perm[RT_SHADE_BLOCK];
+        __shared__ uint32_t s_hit[RT_SHADE_BLOCK / 64], s_miss[RT_SHADE_BLOCK / 64];
+        const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+        const bool valid = i < count;
+        const bool is_miss = valid && __float_as_uint(a.hits[valid ? i : 0u].z) == RT_INVALID_ID;
+        const unsigned long long mh = __ballot(valid && !is_miss), mm = __ballot(is_miss);
+        if (lane == 0) { s_hit[wave] = (uint32_t)__popcll(mh); s_miss[wave] = (uint32_t)__popcll(mm); }
+        __syncthreads();
+        uint32_t hits_before = 0, miss_before = 0, hits_total = 0;
+        for (uint32_t w = 0; w < RT_SHADE_BLOCK / 64; ++w)
+        {
+            hits_total += s_hit[w];
+            if (w < wave) { hits_before += s_hit[w]; miss_before += s_miss[w]; }
+        }
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        if (valid)
+            s_perm[is_miss ? hits_total + miss_before + (uint32_t)__popcll(mm & lt) : hits_before + (uint32_t)__popcll(mh & lt)] =
+                (uint16_t)threadIdx.x;
+        __syncthreads();
+        if (valid) i = blockIdx.x * RT_SHADE_BLOCK + s_perm[threadIdx.x];   // valid entries are a prefix of the block
+    }
     const bool active = i < count;
 
     bool want_shadow = false, want_next = false;

@@ -125,6 +125,7 @@ def test_random_scene_matches_oracle_bit_for_bit(ctx, env_map, seed):
     fr.set_option(capi.OPT_SAMPLES_IN_FLIGHT, int(rng.integers(0, 5)))
     fr.set_option(capi.OPT_TRACE_VARIANT, int(rng.choice([0, 3, 5, 6, 8, 9, 10, 10, 10, 11])))
     fr.set_option(capi.OPT_TRACE_TUNE, int(rng.choice([0, 0, 24 | (4 << 8), 56 | (32 << 8), 64 | (1 << 8)])))
+    fr.set_option(capi.OPT_SHADE_PARTITION, int(seed & 1))
     fr.set_option(capi.OPT_PACKET_BOUNCES, int(rng.choice([0, 0, 1, 2 | 1 << 8])))
     fr.integrate(spp)
     orc = _oracle.Oracle(w, h, sc, furnace=furnace)
