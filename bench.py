@@ -319,6 +319,9 @@ def main():
                     help="cap the per-path device buffers (ray queues + radiance log) at this many GiB per GPU: the tile is then "
                          "rendered chunk by chunk (RT_OPT_PATH_STATE_LIMIT_MB); 0 = the library's own rule (up to half of the HBM)")
     ap.add_argument("--pipelines", type=int, default=None, help="RT_OPT_PIPELINES (library default: 2)")
+    ap.add_argument("--trace-tune", type=lambda x: int(x, 0), default=0, help="RT_OPT_TRACE_TUNE (0 = defaults)")
+    ap.add_argument("--overlap-shadow", type=int, default=None, help="RT_OPT_OVERLAP_SHADOW (default: the library's, 1)")
+    ap.add_argument("--samples-in-flight", type=int, default=0, help="RT_OPT_SAMPLES_IN_FLIGHT (0 = automatic)")
     ap.add_argument("--shade-partition", type=int, default=None, help="RT_OPT_SHADE_PARTITION (library default: 1)")
     ap.add_argument("--trace-waves", type=int, default=0, help="RT_OPT_TRACE_WAVES_PER_CU (0 = as many as fit)")
     ap.add_argument("--debug-shared-gpu", action="store_true",
@@ -397,8 +400,14 @@ def main():
     spp_timed, spp_warm = args.steps * sps, args.warmup * sps
     if args.pipelines:
         assert lib.rt_set_option(frame, capi.OPT_PIPELINES, args.pipelines) == 0
+    if args.samples_in_flight:
+        assert lib.rt_set_option(frame, capi.OPT_SAMPLES_IN_FLIGHT, args.samples_in_flight) == 0
     if args.shade_partition is not None:
         assert lib.rt_set_option(frame, capi.OPT_SHADE_PARTITION, args.shade_partition) == 0
+    if args.trace_tune:
+        assert lib.rt_set_option(frame, capi.OPT_TRACE_TUNE, args.trace_tune) == 0
+    if args.overlap_shadow is not None:
+        assert lib.rt_set_option(frame, capi.OPT_OVERLAP_SHADOW, args.overlap_shadow) == 0
     if args.trace_waves:
         assert lib.rt_set_option(frame, capi.OPT_TRACE_WAVES, args.trace_waves) == 0
     if args.path_state_gb > 0:

@@ -159,6 +159,11 @@ enum rt_option
     , RT_OPT_SHADE_PARTITION = 16  /* 1 (default): k_shade processes each block's 512 queue entries hits first, misses last,
                                        so that a wave runs either the surface code or the environment lookup, not both.
                                        Results are identical for both values. */
+    , RT_OPT_OVERLAP_SHADOW = 17   /* 1 (default): inside rt_integrate the shadow trace of bounce b runs on a second,
+                                       lower-priority stream beside the closest-hit trace and k_shade of bounce b + 1
+                                       (both sides depend on k_shade(b) only; the shadow queue is double-buffered), so the
+                                       ~0.8 ms in which a launch's last rays drain does not idle the machine.
+                                       0: every launch on one stream.  Results are identical for both values. */
     , RT_OPT_TRACE_TUNE = 12       /* k_trace2 (variants 8, 9) loop thresholds: value & 255 = lanes that must hold an
                                        interior node for a wave to stay in the node loop, value >> 8 & 255 = lanes that
                                        must wait at a triangle for another pass of the triangle loop, value >> 16 & 255 = rays a wave takes
@@ -284,6 +289,11 @@ int rt_frame_debug_read_queue(rt_frame* frame, int which, uint32_t bounce, rt_ra
     rt_float4* payload /* throughput (which=0) or direct light sample (which=1) */,
     uint32_t capacity /* elements the arrays can hold; all arrays NULL = size query */, uint32_t* count);
 int rt_frame_debug_read_hits(rt_frame* frame, rt_hit* hits, uint32_t count);
+
+/* Launch timeline of the closest-hit wide-tree kernel (k_trace_w4), per bounce: when its first wave started, when
+ * the first wave found the queue dry, when its last wave left, in ticks of the 100 MHz wall clock.  arm = 1 clears
+ * the record and starts recording, arm = 0 stops and reads out[64][3] (0 where nothing ran).  tools/launch_timeline.py */
+int rt_frame_debug_timeline(rt_frame* frame, int arm, unsigned long long* out);
 
 /* The 4-wide quantized tree rt_scene_upload builds for k_trace_w4 from the reference's LinearBVHNode[]
  * (host only, no device needed): 64-byte records {origin.xyz, meta, lo[3], hi[3], ref[4], pad[2]} --

@@ -84,13 +84,17 @@ struct DCounters                  // one per frame, device memory
     unsigned long long total_closest, total_shadow, samples;
     uint32_t last_queue[64], last_shadow[64];
     // work-distribution heads of the persistent trace kernels: one per XCD and per
-    // kernel flavour (0 = closest, 1 = shadow), offsets inside the XCD's region
-    uint32_t head[2][8];
+    // kernel flavour (0 = closest, 1 / 2 = shadow rays of an even / odd bounce: the shadow trace of bounce b may
+    // still be running while k_shade of bounce b + 1 prepares the next one), offsets inside the XCD's region
+    uint32_t head[3][8];
     // rays k_trace_w4 hands to the BVH2 kernel (non-finite 1/dir): list length and that launch's work heads
-    uint32_t slow_count[2];
-    uint32_t slow_head[2][8];
+    uint32_t slow_count[4];       // per flavour ([3] unused)
+    uint32_t slow_head[3][8];
     uint32_t stack_spills;        // lane-steps with stack entries in the HBM spill area (k_trace2 / k_trace_w4), since the last reset
     uint32_t slow_rays;           // rays k_trace_w4 handed to k_trace2, since the last reset
+    // launch timeline of k_trace_w4<closest> per bounce (rt_frame_debug_timeline), 100 MHz wall clock:
+    // first wave started, first wave found the queue dry, last wave left
+    unsigned long long tl_start[64], tl_dry[64], tl_end[64];
 };
 
 // ray_inv_dir and ray_sign of TraceBvh (trace_bvh.cl:125-129), packed as (inv.xyz, sign bits)

@@ -33,7 +33,7 @@ __global__ __launch_bounds__(256) void k_raygen(DTile tile, rt_camera cam, uint3
         for (uint32_t b = 0; b < 64; ++b) { counters->queue[b] = 0; counters->shadow[b] = 0; }
         counters->queue[0] = n_total;                                    // raygeneration.cl:135-138
     }
-    if (i < 16) counters->head[i >> 3][i & 7] = 0;                       // the next trace launches start from 0
+    if (i < 24) counters->head[i >> 3][i & 7] = 0;                       // the next trace launches start from 0
     if (i >= n_total) return;
 
     // queue order is PIXEL-major: the n_slots samples of a pixel sit next to each other, so

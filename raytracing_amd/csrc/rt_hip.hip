@@ -60,7 +60,15 @@ struct PathPipe
     float4* o4[2] = {nullptr, nullptr}; float4* d4[2] = {nullptr, nullptr}; float4* iv4[2] = {nullptr, nullptr};
     float4* thr[2] = {nullptr, nullptr};
     float4* hits = nullptr;
-    float4* sh_o4 = nullptr; float4* sh_d4 = nullptr; float4* sh_iv4 = nullptr;
+    // shadow queue, two of them: bounce b fills [b & 1] while the shadow trace of bounce b - 1 may still read the other
+    float4* sh_o4[2] = {nullptr, nullptr}; float4* sh_d4[2] = {nullptr, nullptr}; float4* sh_iv4[2] = {nullptr, nullptr};
+    // the shadow trace's own stream (rt_integrate: it runs beside the next bounce's closest-hit trace and k_shade,
+    // filling the tail of one and the ramp of the other), its spill area and slow-ray list
+    hipStream_t side = nullptr;
+    hipEvent_t ev_shaded = nullptr, ev_shadow[2] = {nullptr, nullptr};
+    bool shadow_in_flight[2] = {false, false};   // ev_shadow[i] recorded and not yet waited for by the main stream
+    uint2* sh_spill = nullptr;
+    uint32_t* sh_slow_list = nullptr;
     // radiance log (kernels_common.h header): cnt[id], rlog[entry][id]; id < slots * chunk_pixels
     float4* rlog = nullptr; uint32_t* cnt = nullptr;
     uint32_t* slow_list = nullptr;     // queue indices k_trace_w4 leaves to k_trace2 (one per path)
@@ -104,6 +112,12 @@ struct rt_frame
     uint32_t packet_bounces = 0;       // RT_OPT_TRACE_PACKET_BOUNCES: closest | shadow << 8 bounce counts for k_trace_packet
     uint32_t select_form_box = 0;      // RT_OPT_TRACE_SELECT_FORM_BOX: every ray takes the select-form slab test
     uint32_t trace_tune = 0;           // RT_OPT_TRACE_TUNE: k_trace2 loop thresholds (0 = defaults)
+    uint32_t timeline = 0;             // rt_frame_debug_timeline armed: k_trace_w4<closest> records its launch timeline
+    uint32_t timeline_bounce = 0;
+    uint32_t overlap_shadow = 1;       // RT_OPT_OVERLAP_SHADOW
+    bool side_active = false;          // inside rt_integrate with overlap_shadow: shadow traces go to PathPipe::side
+    // where the next trace launch goes (set by rt_intersect / rt_intersect_shadow)
+    hipStream_t tl_stream = nullptr; uint2* tl_spill = nullptr; uint32_t* tl_slow_list = nullptr; uint32_t tl_flavour = 0;
     uint32_t shade_partition = 1;      // RT_OPT_SHADE_PARTITION: k_shade sorts each block's entries hits first / misses last
     uint32_t debug_alloc_limit = 0;    // RT_OPT_DEBUG_ALLOC_LIMIT: allocations above this many samples in flight fail
     // integrator state
@@ -661,17 +675,21 @@ void free_path_buffers(rt_frame* f)
 {
     for (PathPipe& q : f->ps)
     {
-        void* ptrs[] = {q.o4[0], q.o4[1], q.d4[0], q.d4[1], q.iv4[0], q.iv4[1], q.thr[0], q.thr[1], q.hits, q.sh_o4, q.sh_d4, q.sh_iv4,
-            q.rlog, q.cnt, q.slow_list};
+        void* ptrs[] = {q.o4[0], q.o4[1], q.d4[0], q.d4[1], q.iv4[0], q.iv4[1], q.thr[0], q.thr[1], q.hits, q.sh_o4[0], q.sh_d4[0],
+            q.sh_iv4[0], q.sh_o4[1], q.sh_d4[1], q.sh_iv4[1], q.rlog, q.cnt, q.slow_list, q.sh_slow_list};
         for (void* p : ptrs) if (p) (void)hipFree(p);
-        for (int i = 0; i < 2; ++i) { q.o4[i] = nullptr; q.d4[i] = nullptr; q.iv4[i] = nullptr; q.thr[i] = nullptr; }
-        q.hits = nullptr; q.sh_o4 = nullptr; q.sh_d4 = nullptr; q.sh_iv4 = nullptr; q.rlog = nullptr; q.cnt = nullptr; q.slow_list = nullptr;
+        for (int i = 0; i < 2; ++i)
+        {
+            q.o4[i] = nullptr; q.d4[i] = nullptr; q.iv4[i] = nullptr; q.thr[i] = nullptr;
+            q.sh_o4[i] = nullptr; q.sh_d4[i] = nullptr; q.sh_iv4[i] = nullptr;
+        }
+        q.hits = nullptr; q.rlog = nullptr; q.cnt = nullptr; q.slow_list = nullptr; q.sh_slow_list = nullptr;
     }
 }
 
 // Per-path state: ray queues for `slots` samples in flight and the radiance log
 // with 2 * (max_bounces + 1) entries per path.  (Re)allocated when either changes.
-size_t bytes_per_path(uint32_t max_bounces) { return 12u * 16u + 4u + 4u + 32u * (max_bounces + 1u); }
+size_t bytes_per_path(uint32_t max_bounces) { return 15u * 16u + 4u + 8u + 32u * (max_bounces + 1u); }
 
 // auto: the largest power of two <= 1024 that keeps tile pixels x samples inside 32-bit path
 // ids and the per-path buffers under ~144 GB (half of the 288 GB of HBM)
@@ -745,12 +763,13 @@ int alloc_path_buffers(rt_frame* f, uint32_t slots)
     {
         PathPipe& pp = f->ps[i];
         void** ptrs[] = {(void**)&pp.o4[0], (void**)&pp.o4[1], (void**)&pp.d4[0], (void**)&pp.d4[1], (void**)&pp.iv4[0],
-            (void**)&pp.iv4[1], (void**)&pp.thr[0], (void**)&pp.thr[1], (void**)&pp.hits, (void**)&pp.sh_o4,
-            (void**)&pp.sh_d4, (void**)&pp.sh_iv4};
+            (void**)&pp.iv4[1], (void**)&pp.thr[0], (void**)&pp.thr[1], (void**)&pp.hits, (void**)&pp.sh_o4[0],
+            (void**)&pp.sh_d4[0], (void**)&pp.sh_iv4[0], (void**)&pp.sh_o4[1], (void**)&pp.sh_d4[1], (void**)&pp.sh_iv4[1]};
         for (void** p : ptrs) ok = ok && hipMalloc(p, q) == hipSuccess;
         ok = ok && hipMalloc((void**)&pp.rlog, (size_t)f->log_entries * paths * sizeof(float4)) == hipSuccess;
         ok = ok && hipMalloc((void**)&pp.cnt, (size_t)paths * sizeof(uint32_t)) == hipSuccess;
         ok = ok && hipMalloc((void**)&pp.slow_list, (size_t)(paths + 64) * sizeof(uint32_t)) == hipSuccess;
+        ok = ok && hipMalloc((void**)&pp.sh_slow_list, (size_t)(paths + 64) * sizeof(uint32_t)) == hipSuccess;
         // ordered on the context's stream: the pipes' streams wait for it before their first launch (fork_pipes)
         ok = ok && hipMemsetAsync(pp.cnt, 0, (size_t)paths * sizeof(uint32_t), ctx->stream) == hipSuccess;
         pp.cur_slots = 0;
@@ -806,17 +825,38 @@ int ensure_pipe_resources(rt_frame* f, uint32_t count)
             else HIPCHK(ctx, hipStreamCreateWithFlags(&q.stream, hipStreamNonBlocking));
         }
         if (!q.done) HIPCHK(ctx, hipEventCreateWithFlags(&q.done, hipEventDisableTiming));
+        if (!q.side)
+        {
+            // lower priority than the main stream: when both have workgroups waiting, the closest-hit trace and
+            // k_shade (the critical chain of a bounce) get the free slots first
+            int lo = 0, hi = 0;
+            (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+            HIPCHK(ctx, hipStreamCreateWithPriority(&q.side, hipStreamNonBlocking, lo));
+            HIPCHK(ctx, hipEventCreateWithFlags(&q.ev_shaded, hipEventDisableTiming));
+            for (hipEvent_t& e : q.ev_shadow) HIPCHK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        }
         if (!q.counters)
         {
             HIPCHK(ctx, hipMalloc((void**)&q.counters, sizeof(DCounters)));
             HIPCHK(ctx, hipMemsetAsync(q.counters, 0, sizeof(DCounters), ctx->stream));
         }
         if (!q.spill) HIPCHK(ctx, hipMalloc((void**)&q.spill, spill_bytes));
+        if (!q.sh_spill) HIPCHK(ctx, hipMalloc((void**)&q.sh_spill, spill_bytes));
     }
     return RT_OK;
 }
 
 int flush_log(rt_frame* f);
+
+// The main stream of the current pipe waits for the shadow trace that last used shadow queue `q` (rt_integrate runs
+// those on PathPipe::side); nothing to do when none is outstanding.
+int wait_shadow(rt_frame* f, uint32_t q)
+{
+    if (!f->p->shadow_in_flight[q]) return RT_OK;
+    HIPCHK(f->ctx, hipStreamWaitEvent(f->p->stream, f->p->ev_shadow[q], 0));
+    f->p->shadow_in_flight[q] = false;
+    return RT_OK;
+}
 
 // Grows the per-path buffers to hold `want` samples in flight (clamped to slot_cap); they
 // are sized by the largest batch actually requested, not by the cap.
@@ -848,6 +888,7 @@ int flush_log(rt_frame* f)
     if (f->p->cur_slots == 0 || f->n_local == 0 || f->p->chunk_count == 0) { f->p->cur_slots = 0; return RT_OK; }
     if (f->p->shadow_pending)
         return fail(ctx, "radiance requested between rt_shade and rt_intersect_shadow (direct samples still tentative)");
+    if (wait_shadow(f, 0) != RT_OK || wait_shadow(f, 1) != RT_OK) return RT_ERROR;   // their verdicts are in the log
     uint32_t blocks = (f->p->chunk_count + 255u) / 256u;
     hipLaunchKernelGGL(k_flush, dim3(blocks), dim3(256), 0, f->p->stream, f->radiance + f->p->chunk_base, (const float4*)f->p->rlog, f->p->cnt,
         f->p->chunk_count, f->p->cur_slots, f->log_stride, f->chunk_pixels);
@@ -941,7 +982,12 @@ int rt_frame_destroy(rt_frame* f)
         PathPipe& q = f->ps[i];
         if (q.counters) (void)hipFree(q.counters);
         if (q.spill) (void)hipFree(q.spill);
+        if (q.sh_spill) (void)hipFree(q.sh_spill);
         if (q.done) (void)hipEventDestroy(q.done);
+        if (q.side) (void)hipStreamSynchronize(q.side);
+        if (q.ev_shaded) (void)hipEventDestroy(q.ev_shaded);
+        for (hipEvent_t e : q.ev_shadow) if (e) (void)hipEventDestroy(e);
+        if (q.side) (void)hipStreamDestroy(q.side);
         if (i > 0 && q.stream) (void)hipStreamDestroy(q.stream);
     }
     for (auto& s : f->spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
@@ -1019,6 +1065,7 @@ int rt_set_option(rt_frame* f, int option, uint32_t value)
     case RT_OPT_TRACE_SELECT_FORM_BOX: f->select_form_box = value ? RT_SIGN_SLOW : 0u; return RT_OK;
     case RT_OPT_TRACE_TUNE: f->trace_tune = value; return RT_OK;
     case RT_OPT_SHADE_PARTITION: f->shade_partition = value ? 1u : 0u; return RT_OK;
+    case RT_OPT_OVERLAP_SHADOW: f->overlap_shadow = value ? 1u : 0u; return RT_OK;
     case RT_OPT_PIPELINES:
         if (value == 0 || value > RT_MAX_PIPES) return fail(f->ctx, "rt_set_option: pipelines must be 1..RT_MAX_PIPES");
         if (value != f->pipelines)
@@ -1069,18 +1116,18 @@ namespace
 // RAII bracket: records a start event now and a stop event at scope exit
 struct KernelSpan
 {
-    rt_frame* f; int cls; hipEvent_t a = nullptr, b = nullptr;
-    KernelSpan(rt_frame* f_, int cls_) : f(f_), cls(cls_)
+    rt_frame* f; int cls; hipStream_t st; hipEvent_t a = nullptr, b = nullptr;
+    KernelSpan(rt_frame* f_, int cls_, hipStream_t stream = nullptr) : f(f_), cls(cls_), st(stream ? stream : f_->p->stream)
     {
         if (!f->profile) return;
         auto get = [&]() { hipEvent_t e = nullptr; if (!f->event_pool.empty()) { e = f->event_pool.back(); f->event_pool.pop_back(); } else (void)hipEventCreate(&e); return e; };
         a = get(); b = get();
-        (void)hipEventRecord(a, f->p->stream);
+        (void)hipEventRecord(a, st);
     }
     ~KernelSpan()
     {
         if (!a) return;
-        (void)hipEventRecord(b, f->p->stream);
+        (void)hipEventRecord(b, st);
         f->spans.push_back({a, b, cls});
     }
 };
@@ -1108,9 +1155,9 @@ void launch_trace_sm(rt_frame* f, const float4* o4, const float4* d4, const floa
     if (per_cu > 32u) per_cu = 32u;
     if (f->trace_waves_per_cu && f->trace_waves_per_cu < per_cu) per_cu = f->trace_waves_per_cu;
     uint32_t blocks = ((uint32_t)ctx->prop.multiProcessorCount * per_cu + 7u) & ~7u;
-    hipLaunchKernelGGL((k_trace<SHADOW, STACK>), dim3(blocks), dim3(64), 0, f->p->stream, ctx->scene.d, o4, d4, iv4, count,
-        &f->p->counters->head[SHADOW ? 1 : 0][0], SHADOW ? (float4*)nullptr : f->p->hits,
-        SHADOW ? f->p->rlog : (float4*)nullptr, f->log_stride, f->select_form_box, f->p->spill);
+    hipLaunchKernelGGL((k_trace<SHADOW, STACK>), dim3(blocks), dim3(64), 0, f->tl_stream, ctx->scene.d, o4, d4, iv4, count,
+        &f->p->counters->head[f->tl_flavour][0], SHADOW ? (float4*)nullptr : f->p->hits,
+        SHADOW ? f->p->rlog : (float4*)nullptr, f->log_stride, f->select_form_box, f->tl_spill);
 }
 
 // k_trace2: separate wave-uniform loops (trace_kernels.h).  Same grid sizing as launch_trace_sm.
@@ -1126,9 +1173,9 @@ void launch_trace2(rt_frame* f, const float4* o4, const float4* d4, const float4
     uint32_t tune = f->trace_tune ? f->trace_tune : RT_TRACE2_DEFAULT_TUNE;
     if ((tune & 0xFFu) > 64u) tune = (tune & ~0xFFu) | 64u;
     if ((tune & 0xFFu) == 0u) tune |= 1u;
-    hipLaunchKernelGGL((k_trace2<SHADOW, STACK>), dim3(blocks), dim3(64), 0, f->p->stream, ctx->scene.d, o4, d4, iv4, count,
-        &f->p->counters->head[SHADOW ? 1 : 0][0], SHADOW ? (float4*)nullptr : f->p->hits,
-        SHADOW ? f->p->rlog : (float4*)nullptr, f->log_stride, f->select_form_box, f->p->spill, tune, (const uint32_t*)nullptr,
+    hipLaunchKernelGGL((k_trace2<SHADOW, STACK>), dim3(blocks), dim3(64), 0, f->tl_stream, ctx->scene.d, o4, d4, iv4, count,
+        &f->p->counters->head[f->tl_flavour][0], SHADOW ? (float4*)nullptr : f->p->hits,
+        SHADOW ? f->p->rlog : (float4*)nullptr, f->log_stride, f->select_form_box, f->tl_spill, tune, (const uint32_t*)nullptr,
         &f->p->counters->stack_spills);
 }
 
@@ -1144,14 +1191,20 @@ void launch_trace_w4(rt_frame* f, const float4* o4, const float4* d4, const floa
     uint32_t tune = f->trace_tune ? f->trace_tune : RT_TRACE2_DEFAULT_TUNE;
     if ((tune & 0xFFu) > 64u) tune = (tune & ~0xFFu) | 64u;
     if ((tune & 0xFFu) == 0u) tune |= 1u;
-    const int s = SHADOW ? 1 : 0;
-    hipLaunchKernelGGL((k_trace_w4<SHADOW, STACK>), dim3(blocks), dim3(64), 0, f->p->stream, ctx->scene.d, o4, d4, iv4, count,
-        &f->p->counters->head[s][0], SHADOW ? (float4*)nullptr : f->p->hits, SHADOW ? f->p->rlog : (float4*)nullptr, f->log_stride,
-        f->p->spill, tune, f->p->slow_list, &f->p->counters->slow_count[s], &f->p->counters->stack_spills);
+    const uint32_t s = f->tl_flavour;
+    unsigned long long* const no_timeline = nullptr;
+    if (!SHADOW && STACK == 12 && f->timeline)          // tools/launch_timeline.py: the instrumented instance
+        hipLaunchKernelGGL((k_trace_w4<false, 12, true>), dim3(blocks), dim3(64), 0, f->tl_stream, ctx->scene.d, o4, d4, iv4, count,
+            &f->p->counters->head[s][0], f->p->hits, (float4*)nullptr, f->log_stride, f->tl_spill, tune, f->tl_slow_list,
+            &f->p->counters->slow_count[s], &f->p->counters->stack_spills, &f->p->counters->tl_start[f->timeline_bounce & 63u]);
+    else
+        hipLaunchKernelGGL((k_trace_w4<SHADOW, STACK>), dim3(blocks), dim3(64), 0, f->tl_stream, ctx->scene.d, o4, d4, iv4, count,
+            &f->p->counters->head[s][0], SHADOW ? (float4*)nullptr : f->p->hits, SHADOW ? f->p->rlog : (float4*)nullptr, f->log_stride,
+            f->tl_spill, tune, f->tl_slow_list, &f->p->counters->slow_count[s], &f->p->counters->stack_spills, no_timeline);
     uint32_t blocks2 = ((uint32_t)ctx->prop.multiProcessorCount * 8u + 7u) & ~7u;
-    hipLaunchKernelGGL((k_trace2<SHADOW, 12>), dim3(blocks2), dim3(64), 0, f->p->stream, ctx->scene.d, o4, d4, iv4,
+    hipLaunchKernelGGL((k_trace2<SHADOW, 12>), dim3(blocks2), dim3(64), 0, f->tl_stream, ctx->scene.d, o4, d4, iv4,
         (const uint32_t*)&f->p->counters->slow_count[s], &f->p->counters->slow_head[s][0], SHADOW ? (float4*)nullptr : f->p->hits,
-        SHADOW ? f->p->rlog : (float4*)nullptr, f->log_stride, f->select_form_box, f->p->spill, tune, (const uint32_t*)f->p->slow_list,
+        SHADOW ? f->p->rlog : (float4*)nullptr, f->log_stride, f->select_form_box, f->tl_spill, tune, (const uint32_t*)f->tl_slow_list,
         &f->p->counters->stack_spills);
 }
 
@@ -1166,8 +1219,8 @@ void launch_trace_packet(rt_frame* f, const float4* o4, const float4* d4, const 
     uint32_t per_cu = f->trace_waves_per_cu ? f->trace_waves_per_cu : 32u;
     if (per_cu > 32u) per_cu = 32u;
     uint32_t blocks = ((uint32_t)ctx->prop.multiProcessorCount * per_cu + 7u) & ~7u;
-    hipLaunchKernelGGL((k_trace_packet<SHADOW>), dim3(blocks), dim3(64), 0, f->p->stream, ctx->scene.d, o4, d4, iv4, count,
-        &f->p->counters->head[SHADOW ? 1 : 0][0], SHADOW ? (float4*)nullptr : f->p->hits,
+    hipLaunchKernelGGL((k_trace_packet<SHADOW>), dim3(blocks), dim3(64), 0, f->tl_stream, ctx->scene.d, o4, d4, iv4, count,
+        &f->p->counters->head[f->tl_flavour][0], SHADOW ? (float4*)nullptr : f->p->hits,
         SHADOW ? f->p->rlog : (float4*)nullptr, f->log_stride, f->select_form_box);
 }
 
@@ -1195,8 +1248,8 @@ void launch_trace(rt_frame* f, const float4* o4, const float4* d4, const float4*
     {
     case 0:
         hipLaunchKernelGGL(k_trace_v1<SHADOW>, dim3(f->trace_waves_per_cu ? (((uint32_t)ctx->prop.multiProcessorCount *
-            (f->trace_waves_per_cu < 13u ? f->trace_waves_per_cu : 13u) + 7u) & ~7u) : f->trace_blocks), dim3(64), 0, f->p->stream, ctx->scene.d, o4, d4,
-            iv4, count, SHADOW ? (float4*)nullptr : f->p->hits, SHADOW ? f->p->rlog : (float4*)nullptr, f->log_stride, f->select_form_box, f->p->spill);
+            (f->trace_waves_per_cu < 13u ? f->trace_waves_per_cu : 13u) + 7u) & ~7u) : f->trace_blocks), dim3(64), 0, f->tl_stream, ctx->scene.d, o4, d4,
+            iv4, count, SHADOW ? (float4*)nullptr : f->p->hits, SHADOW ? f->p->rlog : (float4*)nullptr, f->log_stride, f->select_form_box, f->tl_spill);
         break;
     case 1: launch_trace_sm<SHADOW, 16>(f, o4, d4, iv4, count); break;
     case 2: launch_trace_sm<SHADOW, 24>(f, o4, d4, iv4, count); break;
@@ -1290,6 +1343,8 @@ int rt_intersect(rt_frame* f, uint32_t bounce)          // IntersectRays, :522-5
     FRAME_PROLOGUE(f, "rt_intersect");
     if (bounce > RT_MAX_BOUNCES_LIMIT) return fail(ctx, "rt_intersect: bounce out of range");
     uint32_t in = bounce & 1u;
+    f->timeline_bounce = bounce;
+    f->tl_stream = f->p->stream; f->tl_spill = f->p->spill; f->tl_slow_list = f->p->slow_list; f->tl_flavour = 0;
     KernelSpan span(f, 1);
     launch_trace<false>(f, f->p->o4[in], f->p->d4[in], f->p->iv4[in], &f->p->counters->queue[bounce], bounce);
     HIPCHK(ctx, hipGetLastError());
@@ -1309,7 +1364,7 @@ int rt_shade(rt_frame* f, uint32_t bounce)              // ShadeMissedRays + Sha
     ShadeArgs a;
     a.in_o4 = f->p->o4[in]; a.in_d4 = f->p->d4[in]; a.in_thr = f->p->thr[in]; a.hits = f->p->hits;
     a.out_o4 = f->p->o4[out]; a.out_d4 = f->p->d4[out]; a.out_iv4 = f->p->iv4[out]; a.out_thr = f->p->thr[out];
-    a.sh_o4 = f->p->sh_o4; a.sh_d4 = f->p->sh_d4; a.sh_iv4 = f->p->sh_iv4;
+    a.sh_o4 = f->p->sh_o4[bounce & 1u]; a.sh_d4 = f->p->sh_d4[bounce & 1u]; a.sh_iv4 = f->p->sh_iv4[bounce & 1u];
     a.rlog = f->p->rlog; a.cnt = f->p->cnt; a.counters = f->p->counters;
     a.bn_sobol = ctx->blue_noise; a.bn_scramble = ctx->blue_noise ? ctx->blue_noise + 65536 : nullptr;
     a.bn_rank = ctx->blue_noise ? ctx->blue_noise + 65536 + 131072 : nullptr;
@@ -1324,6 +1379,8 @@ int rt_shade(rt_frame* f, uint32_t bounce)              // ShadeMissedRays + Sha
     uint32_t blocks = (f->p->chunk_count * (f->p->cur_slots ? f->p->cur_slots : 1u) + RT_SHADE_BLOCK - 1u) / RT_SHADE_BLOCK;
     if (blocks == 0) blocks = 1;
     f->p->shadow_pending = true;
+    // this bounce refills shadow queue [bounce & 1] and rewinds its work heads: the shadow trace of bounce - 2 is done with them
+    if (wait_shadow(f, bounce & 1u) != RT_OK) return RT_ERROR;
     KernelSpan span(f, 2);
     const bool blue = f->sampler == 1;   // kernel variants are AOT (the reference rebuilds with -D..., :267-285)
     if (f->white_furnace && blue)
@@ -1335,6 +1392,7 @@ int rt_shade(rt_frame* f, uint32_t bounce)              // ShadeMissedRays + Sha
     else
         hipLaunchKernelGGL((k_shade<false, false>), dim3(blocks), dim3(RT_SHADE_BLOCK), 0, f->p->stream, ctx->scene.d, f->tile, a);
     HIPCHK(ctx, hipGetLastError());
+    if (f->side_active) HIPCHK(ctx, hipEventRecord(f->p->ev_shaded, f->p->stream));
     return RT_OK;
 }
 
@@ -1342,10 +1400,21 @@ int rt_intersect_shadow(rt_frame* f, uint32_t bounce)   // IntersectShadowRays +
 {
     FRAME_PROLOGUE(f, "rt_intersect_shadow");
     if (bounce > RT_MAX_BOUNCES_LIMIT) return fail(ctx, "rt_intersect_shadow: bounce out of range");
-    KernelSpan span(f, 3);
-    launch_trace<true>(f, f->p->sh_o4, f->p->sh_d4, f->p->sh_iv4, &f->p->counters->shadow[bounce], bounce);
+    const uint32_t q = bounce & 1u;
+    f->tl_stream = f->side_active ? f->p->side : f->p->stream;
+    f->tl_spill = f->p->sh_spill; f->tl_slow_list = f->p->sh_slow_list; f->tl_flavour = 1u + q;
+    if (f->side_active) HIPCHK(ctx, hipStreamWaitEvent(f->p->side, f->p->ev_shaded, 0));
+    {
+        KernelSpan span(f, 3, f->tl_stream);
+        launch_trace<true>(f, f->p->sh_o4[q], f->p->sh_d4[q], f->p->sh_iv4[q], &f->p->counters->shadow[bounce], bounce);
+    }
     f->p->shadow_pending = false;
     HIPCHK(ctx, hipGetLastError());
+    if (f->side_active)
+    {
+        HIPCHK(ctx, hipEventRecord(f->p->ev_shadow[q], f->p->side));
+        f->p->shadow_in_flight[q] = true;
+    }
     return RT_OK;
 }
 
@@ -1423,6 +1492,7 @@ int rt_integrate(rt_frame* f, uint32_t n_samples)       // n x Integrator::Integ
     if (fork_pipes(f) != RT_OK) return RT_ERROR;
     int rc = RT_OK;
     f->fused = true;
+    f->side_active = f->overlap_shadow != 0 && !per_frame;
     while (done < n_samples && rc == RT_OK)
     {
         uint32_t batch = n_samples - done < cap ? n_samples - done : cap;
@@ -1436,12 +1506,19 @@ int rt_integrate(rt_frame* f, uint32_t n_samples)       // n x Integrator::Integ
         {
             f->p = &f->ps[c % f->n_pipes];
             if (generate_rays(f, batch, base, c >= f->n_pipes) != RT_OK) { rc = RT_ERROR; break; }
+            // Per bounce: closest-hit trace, k_shade, shadow trace.  The shadow trace of bounce b and the closest-hit
+            // trace of bounce b + 1 both depend on k_shade(b) only, and k_shade(b + 1) on the latter only (the shadow
+            // queue is double-buffered): with overlap_shadow the shadow trace goes to the pipe's side stream, AFTER the
+            // next closest-hit launch has been enqueued -- it moves in as that launch's last rays drain and leaves as
+            // k_shade(b + 1) moves in, so neither tail idles the machine (tools/launch_timeline.py: 0.75-0.95 ms each).
+            if (rt_intersect(f, 0) != RT_OK) rc = RT_ERROR;
             for (uint32_t bounce = 0; bounce <= f->max_bounces && rc == RT_OK; ++bounce)
             {
-                if (rt_intersect(f, bounce) != RT_OK) rc = RT_ERROR;
-                else if (bounce == 0 && per_frame && rt_compute_aovs(f) != RT_OK) rc = RT_ERROR;
+                if (bounce == 0 && per_frame && rt_compute_aovs(f) != RT_OK) rc = RT_ERROR;
                 else if (rt_shade(f, bounce) != RT_OK) rc = RT_ERROR;
+                else if (f->side_active && bounce < f->max_bounces && rt_intersect(f, bounce + 1u) != RT_OK) rc = RT_ERROR;
                 else if (rt_intersect_shadow(f, bounce) != RT_OK) rc = RT_ERROR;
+                else if (!f->side_active && bounce < f->max_bounces && rt_intersect(f, bounce + 1u) != RT_OK) rc = RT_ERROR;
             }
             if (rc == RT_OK && flush_log(f) != RT_OK) rc = RT_ERROR;          // radiance_buffer_ += this chunk's contributions
         }
@@ -1453,6 +1530,7 @@ int rt_integrate(rt_frame* f, uint32_t n_samples)       // n x Integrator::Integ
     }
     f->p = &f->ps[0];
     f->fused = false;
+    f->side_active = false;
     if (join_pipes(f) != RT_OK) return RT_ERROR;         // whatever follows on the context's stream sees every chunk
     return rc;
 }
@@ -1574,8 +1652,8 @@ int rt_frame_debug_read_queue(rt_frame* f, int which, uint32_t bounce, rt_ray* r
     if (n == 0) return RT_OK;
     if (!rays && !pixel_indices && !payload) return RT_OK;                 // size query (two-call pattern)
     if (n > capacity) return fail(ctx, "rt_frame_debug_read_queue: the queue holds more entries than the caller's arrays");
-    const float4* so = which == 0 ? f->p->o4[bounce & 1u] : f->p->sh_o4;
-    const float4* sdir = which == 0 ? f->p->d4[bounce & 1u] : f->p->sh_d4;
+    const float4* so = which == 0 ? f->p->o4[bounce & 1u] : f->p->sh_o4[bounce & 1u];
+    const float4* sdir = which == 0 ? f->p->d4[bounce & 1u] : f->p->sh_d4[bounce & 1u];
     std::vector<float4> o(n), d(n), p(n);
     HIPCHK(ctx, hipMemcpy(o.data(), so, (size_t)n * 16, hipMemcpyDeviceToHost));
     HIPCHK(ctx, hipMemcpy(d.data(), sdir, (size_t)n * 16, hipMemcpyDeviceToHost));
@@ -1589,7 +1667,7 @@ int rt_frame_debug_read_queue(rt_frame* f, int which, uint32_t bounce, rt_ray* r
         if (which == 1)   // the deferred direct-light sample lives in the radiance log
         {
             float4 iv;
-            HIPCHK(ctx, hipMemcpy(&iv, f->p->sh_iv4 + i, 16, hipMemcpyDeviceToHost));
+            HIPCHK(ctx, hipMemcpy(&iv, f->p->sh_iv4[bounce & 1u] + i, 16, hipMemcpyDeviceToHost));
             uint32_t entry;
             memcpy(&entry, &iv.w, 4);
             HIPCHK(ctx, hipMemcpy(&p[i], f->p->rlog + (size_t)(entry >> 8) * f->log_stride + id, 16, hipMemcpyDeviceToHost));
@@ -1624,6 +1702,38 @@ int rt_frame_debug_read_hits(rt_frame* f, rt_hit* hits, uint32_t count)
         hits[i].bc.x = h[i].x; hits[i].bc.y = h[i].y;
         memcpy(&hits[i].primitive_id, &h[i].z, 4);
         hits[i].t = h[i].w;
+    }
+    return RT_OK;
+}
+
+// Debug: launch timeline of the closest-hit wide-tree kernel.  arm = 1 clears the slots and starts recording
+// (pipe 0); arm = 0 reads them: out[b] = {first wave started, first wave found the queue dry, last wave left} of the
+// most recent bounce-b launch, in ticks of the 100 MHz wall clock; 0 where nothing ran.
+int rt_frame_debug_timeline(rt_frame* f, int arm, unsigned long long* out /* [64][3] when reading */)
+{
+    if (!f) return fail(nullptr, "rt_frame_debug_timeline: frame is NULL");
+    rt_ctx* ctx = f->ctx;
+    (void)hipSetDevice(ctx->device);
+    if (join_pipes(f) != RT_OK) return RT_ERROR;
+    DCounters* c = f->ps[0].counters;
+    if (arm)
+    {
+        HIPCHK(ctx, hipMemsetAsync(c->tl_start, 0xFF, sizeof(c->tl_start) + sizeof(c->tl_dry), ctx->stream));
+        HIPCHK(ctx, hipMemsetAsync(c->tl_end, 0, sizeof(c->tl_end), ctx->stream));
+        f->timeline = 1;
+        return RT_OK;
+    }
+    if (!out) return fail(ctx, "rt_frame_debug_timeline: NULL output");
+    f->timeline = 0;
+    std::vector<unsigned long long> h(192);
+    HIPCHK(ctx, hipMemcpyAsync(h.data(), c->tl_start, 192 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    for (int b = 0; b < 64; ++b)
+    {
+        bool ran = h[128 + b] != 0ull;
+        out[b * 3 + 0] = ran ? h[b] : 0ull;
+        out[b * 3 + 1] = ran && h[64 + b] != ~0ull ? h[64 + b] : 0ull;
+        out[b * 3 + 2] = h[128 + b];
     }
     return RT_OK;
 }

@@ -341,8 +341,14 @@ __global__ __launch_bounds__(RT_SHADE_BLOCK) void k_shade(DScene sc, DTile tile,
     // work heads for the shadow trace of this bounce and the closest trace of the next
     {
         const uint32_t g = blockIdx.x * RT_SHADE_BLOCK + threadIdx.x;
-        if (g < 16) { a.counters->head[g >> 3][g & 7] = 0; a.counters->slow_head[g >> 3][g & 7] = 0; }
-        if (g < 2) a.counters->slow_count[g] = 0;
+        // the work heads of the two launches this bounce feeds: closest of bounce + 1, shadow of this bounce (flavour
+        // 1 + (bounce & 1); the other shadow flavour may still be in use by the previous bounce's shadow trace)
+        if (g < 16)
+        {
+            const uint32_t fl = g < 8 ? 0u : 1u + (a.bounce & 1u);
+            a.counters->head[fl][g & 7] = 0; a.counters->slow_head[fl][g & 7] = 0;
+            if ((g & 7) == 0) a.counters->slow_count[fl] = 0;
+        }
     }
     if (blockIdx.x * RT_SHADE_BLOCK >= count) return;                    // whole block idle (uniform)
     // Hits first, misses last inside the block's 512 queue entries: a wave then holds (almost) only hits or only

@@ -1056,11 +1056,12 @@ RT_DEV uint32_t spill_load32(const uint32_t* p)
     return v;
 }
 
-template <bool SHADOW, int STACK>
+template <bool SHADOW, int STACK, bool TIMELINE = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_trace_w4(DScene sc, const float4* __restrict__ o4, const float4* __restrict__ d4,
     const float4* __restrict__ iv4, const uint32_t* __restrict__ count_ptr, uint32_t* __restrict__ heads,
     float4* __restrict__ hits, float4* __restrict__ rlog, uint32_t log_stride, uint2* __restrict__ spill, uint32_t tune,
-    uint32_t* __restrict__ slow_list, uint32_t* __restrict__ slow_count, uint32_t* __restrict__ stat_counts /* [0] spills, [1] slow rays */)
+    uint32_t* __restrict__ slow_list, uint32_t* __restrict__ slow_count, uint32_t* __restrict__ stat_counts /* [0] spills, [1] slow rays */,
+    unsigned long long* __restrict__ timeline /* nullptr, or {start, dry, end} slots of this launch (rt_frame_debug_timeline) */)
 {
     __shared__ uint2 stack[STACK][64];
     uint32_t* const stack32 = reinterpret_cast<uint32_t*>(&stack[0][0]);     // SHADOW: 2 * STACK entries of 4 bytes
@@ -1071,6 +1072,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
     const uint32_t lane = threadIdx.x;
     const uint32_t count = *count_ptr;
     if (count == 0) return;
+    bool dry_noted = false;
+    if (TIMELINE && lane == 0) atomicMin(&timeline[0], wall_clock64());
     const uint32_t node_q = tune & 0xFFu, leaf_q = (tune >> 8) & 0xFFu;
     const uint32_t xcd = blockIdx.x & 7u;
     const uint32_t per = (((count + 7u) >> 3) + 63u) & ~63u;
@@ -1082,6 +1085,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
         const uint32_t fair = (per / ((gridDim.x >> 3) * 4u + 1u)) & ~63u;
         grab = fair < grab ? (fair < 64u ? 64u : fair) : grab;
     }
+    // (Tapering the hand-outs towards the end of the region does not shorten the tail of a launch -- 0.75-0.95 ms
+    // after the first wave finds the queue dry, tools/launch_timeline.py -- by more than 0.1 ms: the tail is single
+    // long rays on nearly empty waves, not the size of the last hand-outs.  profiles/r02_taper_sweep.log)
     const uint32_t spill_base = (blockIdx.x * 64u + lane) * (uint32_t)(RT_W4_STACK_MAX - STACK);
     const char* const node_base = reinterpret_cast<const char*>(sc.wnodes);
     const char* const tri_base = reinterpret_cast<const char*>(sc.tris_rt);
@@ -1189,6 +1195,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                     }
                 }
             }
+        }
+        if (TIMELINE && pool.exhausted && !dry_noted)
+        {
+            dry_noted = true;
+            if (lane == 0) atomicMin(&timeline[64], wall_clock64());
         }
         if (__ballot(ref != RT_IDLE_REF) == 0ull)
         {
@@ -1316,4 +1327,5 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
         }
     }
     if (lane == 0 && n_spills != 0u) atomicAdd(&stat_counts[0], n_spills);
+    if (TIMELINE && lane == 0) atomicMax(&timeline[128], wall_clock64());
 }
