@@ -292,7 +292,10 @@ int rt_frame_debug_read_hits(rt_frame* frame, rt_hit* hits, uint32_t count);
 
 /* Launch timeline of the closest-hit wide-tree kernel (k_trace_w4), per bounce: when its first wave started, when
  * the first wave found the queue dry, when its last wave left, in ticks of the 100 MHz wall clock.  arm = 1 clears
- * the record and starts recording, arm = 0 stops and reads out[64][3] (0 where nothing ran).  tools/launch_timeline.py */
+ * the record and starts recording, arm = 0 stops and reads out[64][6] (0 where nothing ran): the three times, the
+ * most traversal steps any ray took, the slowest ray's ticks from hand-out to retirement and its steps; then
+ * out[384 + i] = waves (of all recorded launches) that left in the i-th 25 us after their launch's queue ran dry.
+ * tools/launch_timeline.py */
 int rt_frame_debug_timeline(rt_frame* frame, int arm, unsigned long long* out);
 
 /* The 4-wide quantized tree rt_scene_upload builds for k_trace_w4 from the reference's LinearBVHNode[]

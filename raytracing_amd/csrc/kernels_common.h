@@ -95,6 +95,11 @@ struct DCounters                  // one per frame, device memory
     // launch timeline of k_trace_w4<closest> per bounce (rt_frame_debug_timeline), 100 MHz wall clock:
     // first wave started, first wave found the queue dry, last wave left
     unsigned long long tl_start[64], tl_dry[64], tl_end[64];
+    // ... of its slowest ray: most traversal steps (wide nodes + triangles) any ray took, and the ticks from hand-out to
+    // retirement (high bits) and steps (low 24 bits) of the ray that took longest ...
+    unsigned long long tl_ray_steps[64], tl_ray_ticks[64];
+    // ... and when its waves left, in 25 us bins after the first wave found the queue dry (all recorded launches together)
+    unsigned long long tl_exit_hist[64];
 };
 
 // ray_inv_dir and ray_sign of TraceBvh (trace_bvh.cl:125-129), packed as (inv.xyz, sign bits)

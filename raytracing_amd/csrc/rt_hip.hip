@@ -1196,11 +1196,12 @@ void launch_trace_w4(rt_frame* f, const float4* o4, const float4* d4, const floa
     if (!SHADOW && STACK == 12 && f->timeline)          // tools/launch_timeline.py: the instrumented instance
         hipLaunchKernelGGL((k_trace_w4<false, 12, true>), dim3(blocks), dim3(64), 0, f->tl_stream, ctx->scene.d, o4, d4, iv4, count,
             &f->p->counters->head[s][0], f->p->hits, (float4*)nullptr, f->log_stride, f->tl_spill, tune, f->tl_slow_list,
-            &f->p->counters->slow_count[s], &f->p->counters->stack_spills, &f->p->counters->tl_start[f->timeline_bounce & 63u]);
+            &f->p->counters->slow_count[s], &f->p->counters->stack_spills, &f->p->counters->tl_start[f->timeline_bounce & 63u],
+            f->timeline_bounce & 63u);
     else
         hipLaunchKernelGGL((k_trace_w4<SHADOW, STACK>), dim3(blocks), dim3(64), 0, f->tl_stream, ctx->scene.d, o4, d4, iv4, count,
             &f->p->counters->head[s][0], SHADOW ? (float4*)nullptr : f->p->hits, SHADOW ? f->p->rlog : (float4*)nullptr, f->log_stride,
-            f->tl_spill, tune, f->tl_slow_list, &f->p->counters->slow_count[s], &f->p->counters->stack_spills, no_timeline);
+            f->tl_spill, tune, f->tl_slow_list, &f->p->counters->slow_count[s], &f->p->counters->stack_spills, no_timeline, 0u);
     uint32_t blocks2 = ((uint32_t)ctx->prop.multiProcessorCount * 8u + 7u) & ~7u;
     hipLaunchKernelGGL((k_trace2<SHADOW, 12>), dim3(blocks2), dim3(64), 0, f->tl_stream, ctx->scene.d, o4, d4, iv4,
         (const uint32_t*)&f->p->counters->slow_count[s], &f->p->counters->slow_head[s][0], SHADOW ? (float4*)nullptr : f->p->hits,
@@ -1708,8 +1709,10 @@ int rt_frame_debug_read_hits(rt_frame* f, rt_hit* hits, uint32_t count)
 
 // Debug: launch timeline of the closest-hit wide-tree kernel.  arm = 1 clears the slots and starts recording
 // (pipe 0); arm = 0 reads them: out[b] = {first wave started, first wave found the queue dry, last wave left} of the
-// most recent bounce-b launch, in ticks of the 100 MHz wall clock; 0 where nothing ran.
-int rt_frame_debug_timeline(rt_frame* f, int arm, unsigned long long* out /* [64][3] when reading */)
+// most recent bounce-b launch, in ticks of the 100 MHz wall clock (0 where nothing ran), then the most traversal steps
+// any ray took and the slowest ray's ticks from hand-out to retirement and its steps; after those 64 x 6 values, out[384 + i] =
+// waves (of all recorded launches) that left in the i-th 25 us after their launch's queue ran dry.
+int rt_frame_debug_timeline(rt_frame* f, int arm, unsigned long long* out /* [64][6] + [64] when reading */)
 {
     if (!f) return fail(nullptr, "rt_frame_debug_timeline: frame is NULL");
     rt_ctx* ctx = f->ctx;
@@ -1719,22 +1722,27 @@ int rt_frame_debug_timeline(rt_frame* f, int arm, unsigned long long* out /* [64
     if (arm)
     {
         HIPCHK(ctx, hipMemsetAsync(c->tl_start, 0xFF, sizeof(c->tl_start) + sizeof(c->tl_dry), ctx->stream));
-        HIPCHK(ctx, hipMemsetAsync(c->tl_end, 0, sizeof(c->tl_end), ctx->stream));
+        HIPCHK(ctx, hipMemsetAsync(c->tl_end, 0, sizeof(c->tl_end) + sizeof(c->tl_ray_steps) + sizeof(c->tl_ray_ticks) + sizeof(c->tl_exit_hist),
+            ctx->stream));
         f->timeline = 1;
         return RT_OK;
     }
     if (!out) return fail(ctx, "rt_frame_debug_timeline: NULL output");
     f->timeline = 0;
-    std::vector<unsigned long long> h(192);
-    HIPCHK(ctx, hipMemcpyAsync(h.data(), c->tl_start, 192 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    std::vector<unsigned long long> h(384);
+    HIPCHK(ctx, hipMemcpyAsync(h.data(), c->tl_start, 384 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     for (int b = 0; b < 64; ++b)
     {
         bool ran = h[128 + b] != 0ull;
-        out[b * 3 + 0] = ran ? h[b] : 0ull;
-        out[b * 3 + 1] = ran && h[64 + b] != ~0ull ? h[64 + b] : 0ull;
-        out[b * 3 + 2] = h[128 + b];
+        out[b * 6 + 0] = ran ? h[b] : 0ull;
+        out[b * 6 + 1] = ran && h[64 + b] != ~0ull ? h[64 + b] : 0ull;
+        out[b * 6 + 2] = h[128 + b];
+        out[b * 6 + 3] = h[192 + b];                    // most steps any ray took
+        out[b * 6 + 4] = h[256 + b] >> 24;              // the slowest ray: ticks from hand-out to retirement ...
+        out[b * 6 + 5] = h[256 + b] & 0xFFFFFFull;      // ... and its steps
     }
+    for (int b = 0; b < 64; ++b) out[384 + b] = h[320 + b];   // waves that left in the b-th 25 us after the queue ran dry
     return RT_OK;
 }
 

@@ -1061,7 +1061,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
     const float4* __restrict__ iv4, const uint32_t* __restrict__ count_ptr, uint32_t* __restrict__ heads,
     float4* __restrict__ hits, float4* __restrict__ rlog, uint32_t log_stride, uint2* __restrict__ spill, uint32_t tune,
     uint32_t* __restrict__ slow_list, uint32_t* __restrict__ slow_count, uint32_t* __restrict__ stat_counts /* [0] spills, [1] slow rays */,
-    unsigned long long* __restrict__ timeline /* nullptr, or {start, dry, end} slots of this launch (rt_frame_debug_timeline) */)
+    unsigned long long* __restrict__ timeline /* TIMELINE: DCounters::tl_start + timeline_slot (rt_frame_debug_timeline) */,
+    uint32_t timeline_slot)
 {
     __shared__ uint2 stack[STACK][64];
     uint32_t* const stack32 = reinterpret_cast<uint32_t*>(&stack[0][0]);     // SHADOW: 2 * STACK entries of 4 bytes
@@ -1074,6 +1075,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
     if (count == 0) return;
     bool dry_noted = false;
     if (TIMELINE && lane == 0) atomicMin(&timeline[0], wall_clock64());
+    uint32_t tl_steps = 0, tl_max_steps = 0;                                 // TIMELINE only
+    unsigned long long tl_t0 = 0, tl_max_ticks = 0, tl_steps_of_slowest = 0;
     const uint32_t node_q = tune & 0xFFu, leaf_q = (tune >> 8) & 0xFFu;
     const uint32_t xcd = blockIdx.x & 7u;
     const uint32_t per = (((count + 7u) >> 3) + 63u) & ~63u;
@@ -1158,6 +1161,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                 }
                 else
                     hits[ray_i] = make_float4(hit_u, hit_v, __uint_as_float(hit_prim), t_max);
+                if (TIMELINE)
+                {
+                    const unsigned long long dt = wall_clock64() - tl_t0;
+                    if (dt > tl_max_ticks) { tl_max_ticks = dt; tl_steps_of_slowest = tl_steps; }
+                    tl_max_steps = tl_steps > tl_max_steps ? tl_steps : tl_max_steps;
+                }
                 ray_i = RT_INVALID_ID;
             }
             if (!pool.exhausted)
@@ -1177,6 +1186,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                     hit_prim = RT_INVALID_ID;
                     hit_u = 0.0f; hit_v = 0.0f;
                     sp = 0;
+                    if (TIMELINE) { tl_steps = 0; tl_t0 = wall_clock64(); }
                     slow = (sign_bits & RT_SIGN_SLOW) != 0u;
                     if (!slow) ref = sc.w_entry_ref;
                 }
@@ -1216,6 +1226,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                 {
                     if ((int)ref < -1)
                     {
+                        if (TIMELINE) ++tl_steps;
                         const uint32_t prim = ref & ~(RT_LEAF_BIT | RT_LEAF_CONT_BIT);
                         const float4* tp = reinterpret_cast<const float4*>(tri_base + (size_t)(prim << 6));
                         const float4 q0 = tp[0], q1 = tp[1], q2 = tp[2], q3 = tp[3];
@@ -1276,6 +1287,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
             }
             if ((int)ref >= 0)
             {
+                if (TIMELINE) ++tl_steps;
                 const float4* np = reinterpret_cast<const float4*>(node_base + (size_t)(ref << 6));
                 const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
                 const uint32_t meta = __float_as_uint(q0.w);
@@ -1327,5 +1339,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
         }
     }
     if (lane == 0 && n_spills != 0u) atomicAdd(&stat_counts[0], n_spills);
-    if (TIMELINE && lane == 0) atomicMax(&timeline[128], wall_clock64());
+    if (TIMELINE)
+    {
+        if (lane == 0)
+        {
+            const unsigned long long now = wall_clock64();
+            atomicMax(&timeline[128], now);
+            const unsigned long long dry = __atomic_load_n(&timeline[64], __ATOMIC_RELAXED);
+            const unsigned long long bin = now > dry ? (now - dry) / 2500ull : 0ull;
+            atomicAdd(&timeline[320ull - timeline_slot + (bin < 63ull ? bin : 63ull)], 1ull);   // DCounters::tl_exit_hist
+        }
+        atomicMax(&timeline[192], (unsigned long long)tl_max_steps);
+        atomicMax(&timeline[256], (tl_max_ticks << 24) | (tl_steps_of_slowest & 0xFFFFFFull));
+    }
 }
