@@ -458,6 +458,29 @@ def main():
     agg = agg.numpy()
     dt_max = float(tmax[0].item())
     full = gather(True)                                      # untimed: the image for the checks below
+    # One more step, untimed, with every launch on one stream: in the timed region the shadow trace of bounce b runs
+    # beside the closest-hit trace of bounce b + 1 (RT_OPT_OVERLAP_SHADOW), so the launch durations there include the
+    # sharing; this step gives the kernels' durations alone on the machine (what the rocprofv3 --pmc passes see).
+    isolated = None
+    overlap_on = args.overlap_shadow is None or args.overlap_shadow != 0
+    if world == 1 and overlap_on:
+        assert lib.rt_set_option(frame, capi.OPT_OVERLAP_SHADOW, 0) == 0
+        lib.rt_set_option(frame, capi.OPT_PROFILE, 1)
+        st_a = render.stats()
+        render.render_samples(sps)
+        render.finish()
+        st_b = render.stats()
+        prof_iso = capi.rt_profile()
+        lib.rt_frame_get_profile(frame, prof_iso)
+        lib.rt_set_option(frame, capi.OPT_PROFILE, 0)
+        assert lib.rt_set_option(frame, capi.OPT_OVERLAP_SHADOW, 1) == 0
+        n_iso = max(prof_iso.n_trace_closest, 1)
+        rays_iso = float(st_b.closest_rays - st_a.closest_rays)
+        isolated = dict(what="one more step of %d spp with RT_OPT_OVERLAP_SHADOW = 0 (untimed): each kernel alone on the machine" % sps,
+                        avg_launch_ms=round(prof_iso.ms_trace_closest / n_iso, 5), rays_per_launch=round(rays_iso / n_iso, 1),
+                        mrays_per_s=round(rays_iso / (prof_iso.ms_trace_closest * 1e-3) / 1e6, 1) if prof_iso.ms_trace_closest > 0 else 0.0,
+                        kernel_ms_per_spp=dict(trace_closest=round(prof_iso.ms_trace_closest / sps, 4), trace_shadow=round(prof_iso.ms_trace_shadow / sps, 4),
+                                               shade=round(prof_iso.ms_shade / sps, 4), raygen=round(prof_iso.ms_raygen / sps, 4)))
 
     if rank == 0:
         assert full is not None
@@ -488,6 +511,11 @@ def main():
             # NaN pixels are legal in the reference arithmetic (inf * 0 in the mirror branch) but must be rare
             assert nan_px <= 1e-4 * args.width * args.height, "too many non-finite pixels: %d" % nan_px
         roofline = roofline_object(args, world, agg, prof, per_ray, spp_timed)
+        if overlap_on:
+            roofline["live"]["concurrent"] = ("the shadow trace of the previous bounce runs beside this launch on a second stream "
+                                              "(RT_OPT_OVERLAP_SHADOW = 1): these durations include the sharing")
+        if isolated is not None:
+            roofline["live_isolated"] = isolated
         name, cus, mem = render_ctx_info(capi, host, render)
         if world == 1:
             gather_info = dict(transport="none (single tile, device copy)", ms=round(float(tmax[2].item()) * 1e3, 3), nranks=1)

@@ -109,9 +109,10 @@ RT_DEV float4 ray_inverse(f3 dir)
     f3 inv = F3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
     uint32_t sign_bits = (inv.x < 0.0f ? 1u : 0u) | (inv.y < 0.0f ? 2u : 0u) | (inv.z < 0.0f ? 4u : 0u);
     // a non-finite component (dir component 0, denormal or NaN) can make the slab test produce
-    // 0 * inf = NaN: such rays keep the select-form min/max of the reference (box_test)
-    const float inf = __builtin_inff();
-    if (!(__builtin_fabsf(inv.x) < inf && __builtin_fabsf(inv.y) < inf && __builtin_fabsf(inv.z) < inf))
+    // 0 * inf = NaN: such rays keep the select-form min/max of the reference (box_test).  So do rays with a
+    // component of 1/dir beyond 2^96: k_trace_w4's one-fma slab distances must not overflow (trace_kernels.h).
+    const float lim = 0x1p96f;
+    if (!(__builtin_fabsf(inv.x) < lim && __builtin_fabsf(inv.y) < lim && __builtin_fabsf(inv.z) < lim))
         sign_bits |= RT_SIGN_SLOW;
     return make_float4(inv.x, inv.y, inv.z, __uint_as_float(sign_bits));
 }

@@ -436,7 +436,9 @@ bool build_wide_bvh(const rt_bvh_node* nodes, uint32_t nn, std::vector<WideNode>
             if (extent > 0.0) e = std::max(e, (int)std::ceil(std::log2(extent / 254.0)));
             while (std::ldexp(254.0, e) < extent) ++e;
             while (amax > 0.0 && amax / std::ldexp(1.0, e) >= 8388608.0 - 256.0) ++e;
-            if (e > 127) return false;
+            // k_trace_w4 evaluates slab distances as q * (cell * inv) + (origin - org) * inv: bounded operands keep that
+            // finite for every ray it accepts (trace_kernels.h, loop C)
+            if (e > 20 || amax >= 268435456.0) return false;
             const double cell = std::ldexp(1.0, e);
             const double o = std::floor((double)nmin[a] / cell) * cell;
             origin[a] = (float)o;

@@ -1187,7 +1187,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                     hit_u = 0.0f; hit_v = 0.0f;
                     sp = 0;
                     if (TIMELINE) { tl_steps = 0; tl_t0 = wall_clock64(); }
-                    slow = (sign_bits & RT_SIGN_SLOW) != 0u;
+                    // RT_SIGN_SLOW, or an origin so far out that the one-fma slab distances of loop C could overflow
+                    slow = (sign_bits & RT_SIGN_SLOW) != 0u ||
+                           !(hw_max3(__builtin_fabsf(org.x), __builtin_fabsf(org.y), __builtin_fabsf(org.z)) < 0x1p29f);
                     if (!slow) ref = sc.w_entry_ref;
                 }
                 // rays this kernel does not take: hand their queue index to the BVH2 kernel's list
@@ -1293,25 +1295,43 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                 const uint32_t meta = __float_as_uint(q0.w);
                 const float cx = __uint_as_float((meta & 0xFFu) << 23), cy = __uint_as_float(((meta >> 8) & 0xFFu) << 23),
                             cz = __uint_as_float(((meta >> 16) & 0xFFu) << 23);
-                // near / far plane words per axis, chosen by the ray's direction sign (for a finite non-zero
-                // 1/dir this IS min / max of the two products: the expression is monotone in the bound)
+                // near / far plane words per axis, chosen by the ray's direction sign
                 const bool nx = (sign_bits & 1u) != 0u, ny = (sign_bits & 2u) != 0u, nz = (sign_bits & 4u) != 0u;
                 const uint32_t lox = __float_as_uint(q1.x), loy = __float_as_uint(q1.y), loz = __float_as_uint(q1.z);
                 const uint32_t hix = __float_as_uint(q1.w), hiy = __float_as_uint(q2.x), hiz = __float_as_uint(q2.y);
                 const uint32_t nwx = nx ? hix : lox, fwx = nx ? lox : hix;
                 const uint32_t nwy = ny ? hiy : loy, fwy = ny ? loy : hiy;
                 const uint32_t nwz = nz ? hiz : loz, fwz = nz ? loz : hiz;
+                // Slab distance of grid plane q along an axis: the reference's expression on the dequantised plane is
+                // E(q) = fl(fl(fl(q * cell + origin) - org) * inv) (the inner fl is exact, build_wide_bvh), monotone in q, so
+                // "leaf box passes => stored box passes" holds for E exactly.  Evaluated here as one fma per plane,
+                // F(q) = fl(q * a + b) with a = cell * inv (exact: cell is a power of two), b = fl(fl(origin - org) * inv):
+                // both round the same real number T(q) = (q * cell + origin - org) * inv, |E - T| <= 2.1 u M and
+                // |F - T| <= 4 u M with u = 2^-24 and M = 255 |a| + |b| >= |q a| + |b| -- so the near planes take
+                // b - 2^-20 M and the far planes b + 2^-20 M (16 u M, plus 2^-120 against results in the denormal range):
+                // F_near <= E_near and F_far >= E_far, the stored box only ever grows, interior culling only ever visits
+                // MORE.  Leaves are re-tested with the reference's expression when they are reached, as before.
+                // No overflow: |inv| < 2^96 (ray_inverse: other rays are RT_SIGN_SLOW), cell <= 2^20 and |origin| < 2^28
+                // (build_wide_bvh), |org| < 2^29 (checked when the ray starts) => |q a| + |b| < 2^127.
+                const float ax = cx * inv.x, ay = cy * inv.y, az = cz * inv.z;
+                const float bx = (q0.x - org.x) * inv.x, by = (q0.y - org.y) * inv.y, bz = (q0.z - org.z) * inv.z;
+                const float mx = __builtin_fmaf(255.0f, __builtin_fabsf(ax), __builtin_fabsf(bx)) + 0x1p-100f;
+                const float my = __builtin_fmaf(255.0f, __builtin_fabsf(ay), __builtin_fabsf(by)) + 0x1p-100f;
+                const float mz = __builtin_fmaf(255.0f, __builtin_fabsf(az), __builtin_fabsf(bz)) + 0x1p-100f;
+                const float bnx = __builtin_fmaf(-0x1p-20f, mx, bx), bfx = __builtin_fmaf(0x1p-20f, mx, bx);
+                const float bny = __builtin_fmaf(-0x1p-20f, my, by), bfy = __builtin_fmaf(0x1p-20f, my, by);
+                const float bnz = __builtin_fmaf(-0x1p-20f, mz, bz), bfz = __builtin_fmaf(0x1p-20f, mz, bz);
                 uint32_t r[4] = {__float_as_uint(q2.z), __float_as_uint(q2.w), __float_as_uint(q3.x), __float_as_uint(q3.y)};
                 float e[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
                 {
-                    const float tnx = (w4_plane(nwx, k, cx, q0.x) - org.x) * inv.x;
-                    const float tny = (w4_plane(nwy, k, cy, q0.y) - org.y) * inv.y;
-                    const float tnz = (w4_plane(nwz, k, cz, q0.z) - org.z) * inv.z;
-                    const float tfx = (w4_plane(fwx, k, cx, q0.x) - org.x) * inv.x;
-                    const float tfy = (w4_plane(fwy, k, cy, q0.y) - org.y) * inv.y;
-                    const float tfz = (w4_plane(fwz, k, cz, q0.z) - org.z) * inv.z;
+                    const float tnx = __builtin_fmaf((float)((nwx >> (8 * k)) & 0xFFu), ax, bnx);
+                    const float tny = __builtin_fmaf((float)((nwy >> (8 * k)) & 0xFFu), ay, bny);
+                    const float tnz = __builtin_fmaf((float)((nwz >> (8 * k)) & 0xFFu), az, bnz);
+                    const float tfx = __builtin_fmaf((float)((fwx >> (8 * k)) & 0xFFu), ax, bfx);
+                    const float tfy = __builtin_fmaf((float)((fwy >> (8 * k)) & 0xFFu), ay, bfy);
+                    const float tfz = __builtin_fmaf((float)((fwz >> (8 * k)) & 0xFFu), az, bfz);
                     const float entry = hw_max(hw_max3(tnx, tny, tnz), t_min);
                     const float exit = hw_min(hw_min3(tfx, tfy, tfz), t_max);
                     e[k] = (exit >= entry && r[k] != RT_EMPTY_REF) ? entry : INF;      // INF = slot not visited
