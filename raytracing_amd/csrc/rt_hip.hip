@@ -1204,8 +1204,13 @@ void launch_trace_w4(rt_frame* f, const float4* o4, const float4* d4, const floa
         hipLaunchKernelGGL((k_trace_w4<SHADOW, STACK>), dim3(blocks), dim3(64), 0, f->tl_stream, ctx->scene.d, o4, d4, iv4, count,
             &f->p->counters->head[s][0], SHADOW ? (float4*)nullptr : f->p->hits, SHADOW ? f->p->rlog : (float4*)nullptr, f->log_stride,
             f->tl_spill, tune, f->tl_slow_list, &f->p->counters->slow_count[s], &f->p->counters->stack_spills, no_timeline, 0u);
-    uint32_t blocks2 = ((uint32_t)ctx->prop.multiProcessorCount * 8u + 7u) & ~7u;
-    hipLaunchKernelGGL((k_trace2<SHADOW, 12>), dim3(blocks2), dim3(64), 0, f->tl_stream, ctx->scene.d, o4, d4, iv4,
+    // The follow-up over the (normally empty) slow list: one wave per CU with a one-entry LDS stack (the rest of the stack
+    // lives in the spill area) -- 512 bytes of LDS and a few registers, so it finds room beside the resident waves of the
+    // OTHER stream's persistent launch (RT_OPT_OVERLAP_SHADOW) instead of waiting for that launch to end: with the
+    // 6 KiB blocks of the ordinary k_trace2 the closest-hit follow-up sat 2.8 ms on average behind the shadow trace
+    // (profiles/r02_final_rocprofv3_kernel_stats_overlap.csv) with k_shade queued behind it.
+    uint32_t blocks2 = ((uint32_t)ctx->prop.multiProcessorCount + 7u) & ~7u;
+    hipLaunchKernelGGL((k_trace2<SHADOW, 1>), dim3(blocks2), dim3(64), 0, f->tl_stream, ctx->scene.d, o4, d4, iv4,
         (const uint32_t*)&f->p->counters->slow_count[s], &f->p->counters->slow_head[s][0], SHADOW ? (float4*)nullptr : f->p->hits,
         SHADOW ? f->p->rlog : (float4*)nullptr, f->log_stride, f->select_form_box, f->tl_spill, tune, (const uint32_t*)f->tl_slow_list,
         &f->p->counters->stack_spills);
