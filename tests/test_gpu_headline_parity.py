@@ -203,3 +203,66 @@ def test_pipelined_chunks_on_several_streams_are_bit_identical(golden_scenes):
     fr.set_camera(cam); fr.set_max_bounces(b); fr.set_option(capi.OPT_SAMPLES_IN_FLIGHT, 128); fr.integrate(2)
     assert np.array_equal(fr.radiance()[..., :3], orc.radiance()[..., :3], equal_nan=True)
     fr.close(); ctx.close()
+
+
+def test_shadow_trace_on_the_side_stream_and_launch_timeline(golden_scenes):
+    """RT_OPT_OVERLAP_SHADOW: inside rt_integrate the shadow trace of bounce b runs on a second stream beside the
+    closest-hit trace and k_shade of bounce b + 1 (double-buffered shadow queue, work heads per flavour).  On and off,
+    alone and combined with several pipes / a memory limit / the stage API in between: same bits, same counters.
+    Also rt_frame_debug_timeline (tools/launch_timeline.py): the instrumented kernel instance changes nothing and its
+    record is plausible."""
+    import ctypes as C
+    w, h, b, spp = 256, 160, 4, 128 + 24                 # 5.2 M paths per batch (k_trace_w4), a second, partial batch
+    sc = golden_scenes["coverage"]
+    cam = T.default_camera(w, h)
+    ctx = capi.Context(0)
+    ctx.upload_scene(sc)
+    lib = capi.load()
+    results = []
+    for overlap, pipes, limit_mb, timeline in ((1, 1, 0, 0), (0, 1, 0, 0), (1, 2, 0, 0), (1, 1, 600, 0), (0, 2, 600, 0), (1, 1, 0, 1), (0, 1, 0, 1)):
+        fr = capi.Frame(ctx, w, h)
+        fr.set_camera(cam); fr.set_max_bounces(b)
+        fr.set_option(capi.OPT_OVERLAP_SHADOW, overlap)
+        fr.set_option(capi.OPT_PIPELINES, pipes)
+        fr.set_option(capi.OPT_SAMPLES_IN_FLIGHT, 128)
+        if limit_mb:
+            fr.set_option(capi.OPT_PATH_STATE_LIMIT_MB, limit_mb)
+        if timeline:
+            assert lib.rt_frame_debug_timeline(fr.handle, 1, None) == 0
+        fr.integrate(spp)
+        if timeline:
+            out = (C.c_ulonglong * 448)()
+            assert lib.rt_frame_debug_timeline(fr.handle, 0, out) == 0
+            for bounce in range(b + 1):
+                t0, dry, t1, most, ticks, steps = [out[6 * bounce + k] for k in range(6)]
+                assert 0 < t0 <= dry <= t1 and t1 - t0 < 100_000_000          # a launch takes well under a second
+                assert 0 < steps <= most < 4096 and 0 < ticks <= t1 - t0
+            assert out[6 * (b + 1) + 2] == 0                                  # nothing ran beyond max_bounces
+            assert sum(out[384 + i] for i in range(64)) > 0                   # waves were counted leaving
+        st = fr.stats()
+        results.append((fr.radiance().copy(), st.closest_rays, st.shadow_rays, list(st.last_active[: b + 1])))
+        fr.close()
+    for r in results[1:]:
+        assert np.array_equal(r[0], results[0][0], equal_nan=True)
+        assert r[1:] == results[0][1:]
+    # the stage API (everything on one stream) between two rt_integrate calls of a frame that overlaps
+    fr = capi.Frame(ctx, w, h)
+    fr.set_camera(cam); fr.set_max_bounces(b); fr.set_option(capi.OPT_SAMPLES_IN_FLIGHT, 128)
+    ref = capi.Frame(ctx, w, h)
+    ref.set_camera(cam); ref.set_max_bounces(b); ref.set_option(capi.OPT_SAMPLES_IN_FLIGHT, 128); ref.set_option(capi.OPT_OVERLAP_SHADOW, 0)
+    for f in (fr, ref):
+        f.integrate(130)
+        f.generate_rays()
+        for bounce in range(b + 1):
+            f.intersect(bounce); f.shade(bounce); f.intersect_shadow(bounce)
+        f.advance_sample()
+        f.integrate(3)
+    assert np.array_equal(fr.radiance(), ref.radiance(), equal_nan=True)
+    orc = _oracle.Oracle(w, h, sc)
+    orc.set_camera(cam); orc.set_max_bounces(b); orc.integrate(2)
+    f2 = capi.Frame(ctx, w, h)
+    f2.set_camera(cam); f2.set_max_bounces(b); f2.set_option(capi.OPT_SAMPLES_IN_FLIGHT, 128); f2.integrate(2)
+    assert np.array_equal(f2.radiance()[..., :3], orc.radiance()[..., :3], equal_nan=True)
+    for f in (fr, ref, f2):
+        f.close()
+    ctx.close()
