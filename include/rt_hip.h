@@ -156,9 +156,11 @@ enum rt_option
                                        flight, >= 4 M paths), so that chunks overlap.  Measured: no gain on MI355X
                                        (profiles/r02_pipelines_sweep.log), hence off by default.  Results are bit-identical
                                        for every value. */
-    , RT_OPT_SHADE_PARTITION = 16  /* 1 (default): k_shade processes each block's 512 queue entries hits first, misses last,
-                                       so that a wave runs either the surface code or the environment lookup, not both.
-                                       Results are identical for both values. */
+    , RT_OPT_SHADE_PARTITION = 16  /* bit 0: k_shade processes each block's 512 queue entries hits first, misses last, so that
+                                       a wave runs either the surface code or the environment lookup, not both; bit 1: each
+                                       block's outgoing and shadow rays enter their queues grouped by direction octant, so that
+                                       a wave of the next trace launch holds rays that start near each other and point the
+                                       same way (closest-hit trace -2.8 %).  Default 3.  Results are identical for every value. */
     , RT_OPT_OVERLAP_SHADOW = 17   /* 1 (default): inside rt_integrate the shadow trace of bounce b runs on a second,
                                        lower-priority stream beside the closest-hit trace and k_shade of bounce b + 1
                                        (both sides depend on k_shade(b) only; the shadow queue is double-buffered), so the

@@ -118,7 +118,7 @@ struct rt_frame
     bool side_active = false;          // inside rt_integrate with overlap_shadow: shadow traces go to PathPipe::side
     // where the next trace launch goes (set by rt_intersect / rt_intersect_shadow)
     hipStream_t tl_stream = nullptr; uint2* tl_spill = nullptr; uint32_t* tl_slow_list = nullptr; uint32_t tl_flavour = 0;
-    uint32_t shade_partition = 1;      // RT_OPT_SHADE_PARTITION: k_shade sorts each block's entries hits first / misses last
+    uint32_t shade_partition = 3;      // RT_OPT_SHADE_PARTITION: bit 0: k_shade sorts each block's entries hits first / misses last; bit 1: groups its output rays by octant
     uint32_t debug_alloc_limit = 0;    // RT_OPT_DEBUG_ALLOC_LIMIT: allocations above this many samples in flight fail
     // integrator state
     rt_camera camera;
@@ -1066,7 +1066,7 @@ int rt_set_option(rt_frame* f, int option, uint32_t value)
     case RT_OPT_TRACE_PACKET_BOUNCES: f->packet_bounces = value; return RT_OK;
     case RT_OPT_TRACE_SELECT_FORM_BOX: f->select_form_box = value ? RT_SIGN_SLOW : 0u; return RT_OK;
     case RT_OPT_TRACE_TUNE: f->trace_tune = value; return RT_OK;
-    case RT_OPT_SHADE_PARTITION: f->shade_partition = value ? 1u : 0u; return RT_OK;
+    case RT_OPT_SHADE_PARTITION: f->shade_partition = value & 3u; return RT_OK;
     case RT_OPT_OVERLAP_SHADOW: f->overlap_shadow = value ? 1u : 0u; return RT_OK;
     case RT_OPT_PIPELINES:
         if (value == 0 || value > RT_MAX_PIPES) return fail(f->ctx, "rt_set_option: pipelines must be 1..RT_MAX_PIPES");

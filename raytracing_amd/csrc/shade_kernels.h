@@ -300,6 +300,52 @@ RT_DEV void block_append2(bool want_a, bool want_b, uint32_t* counter_a, uint32_
     idx_b = pb + (uint32_t)__popcll(mb & lt);
 }
 
+// The same, with each block's entries grouped by a 3-bit key (the direction octant of the ray): a wave of the next
+// trace launch then holds rays that start near each other AND point into the same octant.  Queue order is free: results
+// are replayed per path (k_flush), counters count.
+template <uint32_t KEYS>
+RT_DEV void block_append2_keyed(bool want_a, uint32_t key_a, bool want_b, uint32_t key_b, uint32_t* counter_a, uint32_t* counter_b,
+    uint32_t& idx_a, uint32_t& idx_b)
+{
+    constexpr uint32_t W = RT_SHADE_BLOCK / 64, N = KEYS * W;                  // (key, wave) cells per queue, key-major
+    static_assert(2u * N <= RT_SHADE_BLOCK, "one thread per cell");
+    __shared__ uint32_t s_cnt[2][KEYS][W];                                    // counts, then their exclusive prefix
+    __shared__ uint32_t s_base[2];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    uint32_t rank_a = 0, rank_b = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < KEYS; ++k)
+    {
+        const unsigned long long ma = __ballot(want_a && key_a == k), mb = __ballot(want_b && key_b == k);
+        if (lane == 0) { s_cnt[0][k][wave] = (uint32_t)__popcll(ma); s_cnt[1][k][wave] = (uint32_t)__popcll(mb); }
+        if (key_a == k) rank_a = (uint32_t)__popcll(ma & lt);
+        if (key_b == k) rank_b = (uint32_t)__popcll(mb & lt);
+    }
+    __syncthreads();
+    uint32_t mine = 0, before = 0;
+    const uint32_t q = threadIdx.x / N, cell = threadIdx.x % N;
+    if (threadIdx.x < 2u * N)
+    {
+        const uint32_t* c = &s_cnt[q][0][0];
+        mine = c[cell];
+        for (uint32_t i = 0; i < cell; ++i) before += c[i];
+    }
+    __syncthreads();
+    if (threadIdx.x < 2u * N)
+    {
+        (&s_cnt[q][0][0])[cell] = before;
+        if (cell == N - 1u)
+        {
+            const uint32_t total = before + mine;
+            s_base[q] = total ? atomicAdd(q == 0 ? counter_a : counter_b, total) : 0u;
+        }
+    }
+    __syncthreads();
+    idx_a = s_base[0] + s_cnt[0][key_a % KEYS][wave] + rank_a;
+    idx_b = s_base[1] + s_cnt[1][key_b % KEYS][wave] + rank_b;
+}
+
 struct ShadeArgs
 {
     const float4* in_o4; const float4* in_d4; const float4* in_thr; const float4* hits;
@@ -310,7 +356,8 @@ struct ShadeArgs
     DCounters* counters;
     uint32_t bounce, sample_base, emit_outgoing, n_local, log_stride;   // n_local: pixels per chunk (path id = slot * n_local + pixel in chunk)
     uint32_t pix_base;                                                  // first local pixel of the chunk
-    uint32_t partition;      // 1: hits first / misses last inside every block (RT_OPT_SHADE_PARTITION)
+    uint32_t partition;      // RT_OPT_SHADE_PARTITION: bit 0 = hits first / misses last inside every block, bit 1 = each block's
+                             // outgoing and shadow rays grouped by direction octant
     uint32_t final_bounce;   // 1: no shade launch follows for these paths (bounce == max_bounces)
     uint32_t count_in_ray;   // 1 (rt_integrate): a path's number of log entries travels with its ray (thr.w) and cnt[id] is
                              // written once, when the path ends; 0 (stage API): cnt[id] is read and written at every bounce,
@@ -517,7 +564,15 @@ __global__ __launch_bounds__(RT_SHADE_BLOCK) void k_shade(DScene sc, DTile tile,
     }
 
     uint32_t sidx, nidx;
-    block_append2(want_shadow, want_next, &a.counters->shadow[a.bounce], &a.counters->queue[a.bounce + 1], sidx, nidx);
+    if (a.partition & 2u)
+    {
+        // (16 groups -- the octant, then whether the direction leans to x or to y -- trace no faster and cost k_shade more)
+        const uint32_t key_s = (sh_d.x < 0.0f ? 1u : 0u) | (sh_d.y < 0.0f ? 2u : 0u) | (sh_d.z < 0.0f ? 4u : 0u);
+        const uint32_t key_n = (nx_d.x < 0.0f ? 1u : 0u) | (nx_d.y < 0.0f ? 2u : 0u) | (nx_d.z < 0.0f ? 4u : 0u);
+        block_append2_keyed<8>(want_shadow, key_s, want_next, key_n, &a.counters->shadow[a.bounce], &a.counters->queue[a.bounce + 1], sidx, nidx);
+    }
+    else
+        block_append2(want_shadow, want_next, &a.counters->shadow[a.bounce], &a.counters->queue[a.bounce + 1], sidx, nidx);
     if (want_shadow)
     {
         a.sh_o4[sidx] = sh_o;

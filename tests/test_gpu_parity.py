@@ -280,7 +280,7 @@ def test_samples_in_flight_and_kernel_variants_are_bit_invariant(ctx, golden_sce
     fr.set_max_bounces(b)
     fr.set_option(capi.OPT_SAMPLES_IN_FLIGHT, slots)
     fr.set_option(capi.OPT_TRACE_VARIANT, variant % 100)
-    fr.set_option(capi.OPT_SHADE_PARTITION, (variant + slots) & 1)     # k_shade with and without the hits-first partition
+    fr.set_option(capi.OPT_SHADE_PARTITION, (variant + slots) & 3)     # k_shade with and without the hits-first partition
     fr.set_option(capi.OPT_PACKET_BOUNCES, (3 | 2 << 8) if variant == 103 else 0)   # 103: packet kernel, closest bounces 0..2, shadow 0..1
     # 208 / 308: k_trace2 with extreme loop thresholds (every lane leaves the node loop at once / nobody until all are done)
     # 10 / 11: k_trace_w4 (4-wide quantized tree); 210 / 310: the same with extreme thresholds

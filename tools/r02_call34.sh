@@ -1,0 +1,15 @@
+#!/bin/bash
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/r02_call35
+mkdir -p $O
+cd $R
+timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz.py -x -q -m gpu 2>&1 | grep -E "passed|failed|Error|error|Timeout|assert" | tail -5
+for rep in 1 2; do
+for sp in 3 7; do
+timeout 300 python bench.py --steps 4 --warmup 1 --shade-partition $sp --no-cpu-baseline > $O/b.json 2> $O/b.err
+python - <<PY
+import json
+d=json.loads(open("$O/b.json").read().strip().splitlines()[-1])
+print("rep $rep partition $sp:", d["value"], "Mrays/s", d["ms_per_spp"], "ms/spp", d["roofline"].get("live_isolated", {}).get("kernel_ms_per_spp"))
+PY
+done; done
