@@ -85,7 +85,17 @@ typedef struct rt_scene_desc
     const rt_light* lights;               uint32_t num_lights;
     const uint32_t* emissive_indices;     uint32_t num_emissive;    /* uploaded, unused (hit_surface.cl:39) */
     const float* env_rgba;                uint32_t env_width, env_height;  /* Scene::GetEnvImage(), float RGBA */
+    /* ---- opt-in extensions.  NULL / 0 = the reference's behaviour, bit for bit. ---- */
+    const uint16_t* material_texture_indices;   /* 6 per material -- diffuse, specular, roughness, metalness, emission,
+                                                   transparency; 0xFFFF = none.  When given, these replace the 8-bit texture
+                                                   indices packed into rt_packed_material and with them the 255-texture limit
+                                                   (INVALID_TEXTURE_IDX 0xFF, constants.h:35; PackAlbedo's assert, scene.cpp:55) */
+    uint32_t flags;                             /* RT_SCENE_* */
 } rt_scene_desc;
+/* rt_scene_desc::flags */
+#define RT_SCENE_EMISSIVE_NEE 1u   /* next-event estimation also samples the emissive triangles of emissive_indices (which the
+                                      reference collects, scene.cpp:324-339, and passes to a kernel that ignores them,
+                                      hit_surface.cl:39).  Changes the estimator, not the expected image: DESIGN.md section 7b */
 
 int rt_scene_upload(rt_ctx* ctx, const rt_scene_desc* scene);
 

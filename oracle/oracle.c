@@ -97,6 +97,12 @@ typedef struct orc
     uint32_t* texture_data; uint32_t n_texture_data;
     rt_light* lights; uint32_t n_lights;
     float* env; uint32_t env_w, env_h;
+    /* opt-in extensions of this repository (include/rt_hip.h, rt_scene_desc) -- NOT reference behaviour,
+     * restated here so that the HIP path can be checked against something: */
+    uint16_t* tex16;             /* 6 texture indices per material (0xFFFF = none) replacing the packed 8-bit ones, or NULL */
+    uint32_t* emissive; uint32_t n_emissive_tris;
+    int emissive_nee;            /* RT_SCENE_EMISSIVE_NEE */
+    uint8_t* prev_delta;         /* per pixel: the path's last scattering event was a delta one (or it is a camera ray) */
 
     /* statistics */
     uint64_t total_closest, total_shadow;
@@ -439,32 +445,37 @@ static v3 UnpackRGBE(uint32_t rgbe)
     return V3((float)r * f, (float)g * f, (float)b * f);
 }
 
-/* material.h:319-369 */
-static void ApplyTextures(orc* o, rt_packed_material in, Material* out, v2 uv)
+/* material.h:319-369; mtl = the material's index (wide texture indices, when the extension is on) */
+static void ApplyTextures(orc* o, uint32_t mtl, Material* out, v2 uv)
 {
+    rt_packed_material in = o->materials[mtl];
+    const uint16_t* wide = o->tex16 ? o->tex16 + (size_t)mtl * 6u : NULL;
+    const uint32_t none = wide ? 0xFFFFu : RT_INVALID_TEXTURE_IDX;
     uint32_t idx;
     out->diffuse_albedo = UnpackRGBTex(in.diffuse_albedo, &idx);
-    if (idx != RT_INVALID_TEXTURE_IDX) out->diffuse_albedo = pow3(SampleTexture(o, o->textures[idx], uv), 2.2f);
+    if (wide) idx = wide[0];
+    if (idx != none) out->diffuse_albedo = pow3(SampleTexture(o, o->textures[idx], uv), 2.2f);
     out->specular_albedo = UnpackRGBTex(in.specular_albedo, &idx);
-    if (idx != RT_INVALID_TEXTURE_IDX) out->specular_albedo = pow3(SampleTexture(o, o->textures[idx], uv), 2.2f);
+    if (wide) idx = wide[1];
+    if (idx != none) out->specular_albedo = pow3(SampleTexture(o, o->textures[idx], uv), 2.2f);
     out->emission = UnpackRGBE(in.emission);
 
     uint32_t d = in.roughness_metalness;                                  /* utils.h:160-174 */
     out->roughness = (float)((d >> 0) & 0xFF) / 255.0f;
-    uint32_t roughness_idx = (d >> 8) & 0xFF;
+    uint32_t roughness_idx = wide ? wide[2] : (d >> 8) & 0xFF;
     out->metalness = (float)((d >> 16) & 0xFF) / 255.0f;
-    uint32_t metalness_idx = (d >> 24) & 0xFF;
-    if (roughness_idx != RT_INVALID_TEXTURE_IDX) out->roughness = SampleTexture(o, o->textures[roughness_idx], uv).x;
-    if (metalness_idx != RT_INVALID_TEXTURE_IDX) out->metalness = SampleTexture(o, o->textures[metalness_idx], uv).x;
+    uint32_t metalness_idx = wide ? wide[3] : (d >> 24) & 0xFF;
+    if (roughness_idx != none) out->roughness = SampleTexture(o, o->textures[roughness_idx], uv).x;
+    if (metalness_idx != none) out->metalness = SampleTexture(o, o->textures[metalness_idx], uv).x;
 
     d = in.ior_emission_idx_transparency;                                 /* utils.h:176-190 */
     out->ior = (float)((d >> 0) & 0xFF) / 25.5f;
-    uint32_t emission_idx = (d >> 8) & 0xFF;
+    uint32_t emission_idx = wide ? wide[4] : (d >> 8) & 0xFF;
     out->transparency = (float)((d >> 16) & 0xFF) / 255.0f;
-    uint32_t transparency_idx = (d >> 24) & 0xFF;
-    if (emission_idx != RT_INVALID_TEXTURE_IDX)
+    uint32_t transparency_idx = wide ? wide[5] : (d >> 24) & 0xFF;
+    if (emission_idx != none)
         out->emission = v_mul(out->emission, pow3(SampleTexture(o, o->textures[emission_idx], uv), 2.2f));
-    if (transparency_idx != RT_INVALID_TEXTURE_IDX)
+    if (transparency_idx != none)
         out->transparency *= SampleTexture(o, o->textures[transparency_idx], uv).x;
 }
 
@@ -550,8 +561,9 @@ static v3 EvaluateMaterial(const Material* m, v3 normal, v3 incoming, v3 outgoin
 
 /* material.h:171-241 (with SampleSpecular :66-103, SampleDiffuse :51-64, SampleTransparency :105-117) */
 static v3 SampleBxdf(const orc* o, float s1, v2 s, Material material, v3 normal, v3 incoming, v3* outgoing,
-    float* pdf, float* offset)
+    float* pdf, float* offset, int* delta /* extension: the event chosen has a delta distribution */)
 {
+    *delta = 0;
     if (o->furnace)
     {
         material.diffuse_albedo = V3(1.0f, 1.0f, 1.0f);
@@ -575,6 +587,7 @@ static v3 SampleBxdf(const orc* o, float s1, v2 s, Material material, v3 normal,
         *pdf = 1.0f;
         *outgoing = v_neg(incoming);
         *offset = -1.0f;
+        *delta = 1;
         return V3(1.0f, 1.0f, 1.0f);
     }
 
@@ -588,6 +601,7 @@ static v3 SampleBxdf(const orc* o, float s1, v2 s, Material material, v3 normal,
             *pdf = 1.0f;
             float n_dot_o = v_dot(*outgoing, normal);
             spec = 1.0f / n_dot_o;
+            *delta = 1;
         }
         else
         {
@@ -644,6 +658,66 @@ static v3 Light_Sample(const orc* o, v3 position, float s, v3* outgoing, float* 
     return light_radiance;
 }
 
+/* Extension RT_SCENE_EMISSIVE_NEE (not in the reference: scene.cpp:324-339 collects the emissive triangles,
+ * hit_surface.cl:39 receives and ignores them).  Light_Sample over n = analytic lights + emissive triangles: index
+ * from s as in light.h:41, selection pdf 1 / n.  An emissive triangle is sampled uniformly by area with u1 = the
+ * fraction of s * n left over by the index and u2 = the BSDF-layer sample of this bounce; it emits from its front side
+ * only, as in the reference (whose traversal culls back faces).  Returned: radiance * cos_l * area / d^2, so
+ * that the caller's  radiance * throughput * brdf / pdf * cos  is the area-sampling estimator; `outgoing` stops short
+ * of the sampled point, so that the shadow ray does not see the emitter itself (below). */
+static v3 Light_SampleWithEmissive(orc* o, v3 position, float s, float s2, v3* outgoing, float* pdf)
+{
+    const uint32_t n_analytic = o->scene_info.analytic_light_count;
+    const uint32_t count = n_analytic + o->n_emissive_tris;
+    int light_idx = i_clamp((int)(s * (float)count), 0, (int)count - 1);
+    *pdf = 1.0f / (float)count;
+    if ((uint32_t)light_idx < n_analytic)
+    {
+        rt_light light = o->lights[light_idx];
+        v3 light_radiance = f3(light.radiance);
+        if (light.type == RT_LIGHT_TYPE_POINT)
+        {
+            v3 to_light = v_sub(f3(light.origin), position);
+            float sq_length = v_dot(to_light, to_light);
+            light_radiance = v_divs(light_radiance, sq_length);
+            *outgoing = to_light;
+        }
+        else
+            *outgoing = v_scale(f3(light.origin), RT_MAX_RENDER_DIST);
+        return light_radiance;
+    }
+    const rt_triangle* tri = &o->triangles[o->emissive[(uint32_t)light_idx - n_analytic]];
+    float u1 = s * (float)count - (float)light_idx;
+    u1 = f_min(f_max(u1, 0.0f), 1.0f);
+    float su = __builtin_sqrtf(u1);
+    float b0 = 1.0f - su, b1 = s2 * su;
+    float b2 = 1.0f - b0 - b1;
+    v3 p1 = f3(tri->v1.position), p2 = f3(tri->v2.position), p3 = f3(tri->v3.position);
+    v3 lp = v_add(v_add(v_scale(p1, b0), v_scale(p2, b1)), v_scale(p3, b2));
+    v2 uv;
+    uv.x = tri->v1.texcoord.x * b0 + tri->v2.texcoord.x * b1 + tri->v3.texcoord.x * b2;
+    uv.y = tri->v1.texcoord.y * b0 + tri->v2.texcoord.y * b1 + tri->v3.texcoord.y * b2;
+    Material lm;
+    ApplyTextures(o, tri->mtl_index, &lm, uv);
+    v3 nl = v_cross(v_sub(p2, p1), v_sub(p3, p1));                        /* length = 2 * area */
+    v3 to_light = v_sub(lp, position);
+    float d2 = v_dot(to_light, to_light);
+    float g = 0.0f;
+    /* The reference's ray-triangle test culls back faces (trace_bvh.cl:28-73: det = -dir . nl < 1e-8 -> no hit), so a
+     * triangle is visible -- and its emission counted (hit_surface.cl:107-112) -- only from the side its normal
+     * points to.  The same rule here: */
+    const float dist = __builtin_sqrtf(d2);
+    const float nd = -v_dot(nl, to_light);                                /* 2 * area * d * cos_l, > 0 on the front side */
+    if (d2 > 0.0f && nd / dist >= 1e-8f) g = (nd * 0.5f) / (dist * d2);   /* cos_l * area / d^2 */
+    /* The shadow ray starts at position + normal * EPS (hit_surface.cl:131) but is aimed from `position`: it reaches the
+     * emitter's plane up to EPS / |cos_l| EARLIER than d.  Stop short by twice that plus 2^-10 d, as a fraction of d;
+     * samples for which nothing is left (grazing or touching the emitter: |cos_l| * area / d^2 -> 0 there) are dropped. */
+    float keep = 1.0f - 0.0009765625f - (2.0f * RT_EPS) * __builtin_sqrtf(v_dot(nl, nl)) / nd;
+    if (!(keep > 0.0f) || !(g > 0.0f)) { keep = 1.0f; g = 0.0f; }
+    *outgoing = v_scale(to_light, keep);
+    return v_scale(lm.emission, g);
+}
+
 /* ---- HitSurface, hit_surface.cl:30-186 ---------------------------------- */
 static void HitSurface(orc* o, uint32_t bounce, uint32_t ray_idx)
 {
@@ -673,10 +747,14 @@ static void HitSurface(orc* o, uint32_t bounce, uint32_t ray_idx)
         v_scale(f3(tri->v3.normal), bv)));
 
     Material material;
-    ApplyTextures(o, o->materials[tri->mtl_index], &material, texcoord);
+    ApplyTextures(o, tri->mtl_index, &material, texcoord);
     v3 hit_throughput = f3(o->throughputs[pixel_idx]);
 
-    if (!o->furnace)                                                      /* :107-112 */
+    /* Extension RT_SCENE_EMISSIVE_NEE: light that next-event estimation already gathers from the emissive triangles must
+     * not be counted again when a scattered ray happens to hit one: emission is added for camera rays and after delta
+     * events (which next-event estimation cannot sample) only. */
+    const int count_emission = !o->emissive_nee || bounce == 0 || o->prev_delta[pixel_idx];
+    if (!o->furnace && count_emission)                                    /* :107-112 */
     {
         if (material.emission.x * 1.0f + material.emission.y * 1.0f + material.emission.z * 1.0f > 0.0f)
         {
@@ -693,7 +771,15 @@ static void HitSurface(orc* o, uint32_t bounce, uint32_t ray_idx)
         float s_light = SampleRandom((uint32_t)x, (uint32_t)y, sample_idx, bounce, 4);
         v3 outgoing;
         float pdf;
-        v3 light_radiance = Light_Sample(o, position, s_light, &outgoing, &pdf);
+        v3 light_radiance;
+        if (!o->emissive_nee)
+            light_radiance = Light_Sample(o, position, s_light, &outgoing, &pdf);
+        else
+        {
+            /* one light out of the analytic lights AND the emissive triangles, uniformly */
+            float s_layer = SampleRandom((uint32_t)x, (uint32_t)y, sample_idx, bounce, 1);
+            light_radiance = Light_SampleWithEmissive(o, position, s_light, s_layer, &outgoing, &pdf);
+        }
         float distance_to_light = v_length(outgoing);
         outgoing = v_normalize(outgoing);
         v3 brdf = EvaluateMaterial(&material, normal, incoming, outgoing);
@@ -726,7 +812,9 @@ static void HitSurface(orc* o, uint32_t bounce, uint32_t ray_idx)
         v3 throughput = V3(0.0f, 0.0f, 0.0f);
         v3 outgoing;
         float offset;
-        v3 bxdf = SampleBxdf(o, s1, s, material, normal, incoming, &outgoing, &pdf, &offset);
+        int delta;
+        v3 bxdf = SampleBxdf(o, s1, s, material, normal, incoming, &outgoing, &pdf, &offset, &delta);
+        if (o->prev_delta) o->prev_delta[pixel_idx] = (uint8_t)delta;
         if ((double)pdf > 0.0) throughput = v_divs(bxdf, pdf);
         o->throughputs[pixel_idx].x *= throughput.x;
         o->throughputs[pixel_idx].y *= throughput.y;
@@ -779,7 +867,7 @@ static void GenerateAOV(orc* o, uint32_t ray_idx)
     v3 normal = v_normalize(v_add(v_add(v_scale(f3(tri->v1.normal), w0), v_scale(f3(tri->v2.normal), bu)),
         v_scale(f3(tri->v3.normal), bv)));
     Material material;
-    ApplyTextures(o, o->materials[tri->mtl_index], &material, texcoord);
+    ApplyTextures(o, tri->mtl_index, &material, texcoord);
     o->diffuse_albedo[pixel_idx].x = material.diffuse_albedo.x;
     o->diffuse_albedo[pixel_idx].y = material.diffuse_albedo.y;
     o->diffuse_albedo[pixel_idx].z = material.diffuse_albedo.z;
@@ -871,6 +959,7 @@ ORC_EXPORT void orc_destroy(void* h)
     free(o->diffuse_albedo); free(o->depth); free(o->normal); free(o->velocity); free(o->prev_radiance); free(o->prev_depth);
     free(o->triangles); free(o->nodes); free(o->materials); free(o->textures); free(o->texture_data);
     free(o->lights); free(o->env);
+    free(o->tex16); free(o->emissive); free(o->prev_delta);
     free(o);
 }
 
@@ -888,7 +977,8 @@ ORC_EXPORT void orc_upload(void* h, const rt_triangle* tris, uint32_t ntris, con
     const uint32_t* emissive, uint32_t nemissive, const float* env_rgba, uint32_t env_w, uint32_t env_h)
 {
     orc* o = (orc*)h;
-    (void)emissive;   /* emissive_indices is bound but never read by the kernels (hit_surface.cl:39) */
+    /* emissive_indices is bound but never read by the reference's kernels (hit_surface.cl:39); kept for the extension */
+    o->emissive = (uint32_t*)dup_mem(emissive, (size_t)nemissive * 4); o->n_emissive_tris = nemissive;
     o->triangles = (rt_triangle*)dup_mem(tris, (size_t)ntris * sizeof(rt_triangle)); o->n_triangles = ntris;
     o->nodes = (rt_bvh_node*)dup_mem(nodes, (size_t)nnodes * sizeof(rt_bvh_node)); o->n_nodes = nnodes;
     o->materials = (rt_packed_material*)dup_mem(mats, (size_t)nmats * sizeof(rt_packed_material)); o->n_materials = nmats;
@@ -898,6 +988,18 @@ ORC_EXPORT void orc_upload(void* h, const rt_triangle* tris, uint32_t ntris, con
     o->env = (float*)dup_mem(env_rgba, (size_t)env_w * env_h * 16); o->env_w = env_w; o->env_h = env_h;
     o->scene_info.analytic_light_count = nlights;
     o->scene_info.emissive_count = nemissive;
+}
+
+/* opt-in extensions (rt_scene_desc::material_texture_indices / flags); call after orc_upload */
+ORC_EXPORT void orc_set_extensions(void* h, const uint16_t* material_texture_indices, uint32_t flags)
+{
+    orc* o = (orc*)h;
+    free(o->tex16); o->tex16 = NULL;
+    if (material_texture_indices)
+        o->tex16 = (uint16_t*)dup_mem(material_texture_indices, (size_t)o->n_materials * 6 * sizeof(uint16_t));
+    o->emissive_nee = (flags & 1u) && o->n_emissive_tris ? 1 : 0;
+    free(o->prev_delta); o->prev_delta = NULL;
+    if (o->emissive_nee) o->prev_delta = (uint8_t*)calloc((size_t)o->width * o->height, 1);
 }
 
 ORC_EXPORT void orc_set_camera(void* h, const rt_camera* cam)           /* cl_pt_integrator.cpp:365-371 */

@@ -38,7 +38,11 @@ class rt_scene_desc(C.Structure):
                 ("texture_data", C.c_void_p), ("num_texture_data", C.c_uint32),
                 ("lights", C.c_void_p), ("num_lights", C.c_uint32),
                 ("emissive_indices", C.c_void_p), ("num_emissive", C.c_uint32),
-                ("env_rgba", C.c_void_p), ("env_width", C.c_uint32), ("env_height", C.c_uint32)]
+                ("env_rgba", C.c_void_p), ("env_width", C.c_uint32), ("env_height", C.c_uint32),
+                ("material_texture_indices", C.c_void_p), ("flags", C.c_uint32)]
+
+
+SCENE_EMISSIVE_NEE = 1
 
 
 class rt_frame_desc(C.Structure):
@@ -158,7 +162,7 @@ class Context:
     def upload_scene(self, scene):
         """scene: dict with triangles (BVH order), nodes, materials, textures,
         texture_data, lights, emissive, env (H x W x 4 float32)."""
-        s = {k: np.ascontiguousarray(v) for k, v in scene.items() if k != "scene_info"}
+        s = {k: np.ascontiguousarray(v) for k, v in scene.items() if k not in ("scene_info", "flags")}
         for key, dt in (("triangles", T.triangle), ("nodes", T.bvh_node), ("materials", T.packed_material),
                         ("textures", T.texture), ("lights", T.light)):
             if s[key].dtype != dt:
@@ -169,6 +173,14 @@ class Context:
                           p(s["materials"]), len(s["materials"]), p(s["textures"]), len(s["textures"]),
                           p(s["texture_data"]), len(s["texture_data"]), p(s["lights"]), len(s["lights"]),
                           p(s["emissive"]), len(s["emissive"]), p(env), env.shape[1], env.shape[0])
+        # opt-in extensions: 6 x uint16 texture indices per material, RT_SCENE_* flags
+        tex16 = s.get("material_texture_indices")
+        if tex16 is not None:
+            tex16 = np.ascontiguousarray(tex16, np.uint16)
+            if tex16.size != 6 * len(s["materials"]):
+                raise RtError("scene['material_texture_indices'] needs 6 entries per material")
+            d.material_texture_indices = tex16.ctypes.data
+        d.flags = int(scene.get("flags", 0))
         _check(self.lib, self.handle, self.lib.rt_scene_upload(self.handle, C.byref(d)))
 
     def debug_eval(self, fn, a, b=None):

@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void k_aov(DScene sc, const float4* __restrict
     texcoord.y = q1.w * w0 + q3.w * bu + q5.w * bv;
     f3 normal = normalize3(n1 * w0 + n2 * bu + n3 * bv);
     Material material;
-    ApplyTextures(sc, sc.materials[__float_as_uint(q6.x)], material, texcoord);
+    ApplyTextures(sc, __float_as_uint(q6.x), material, texcoord);
     aov.diffuse_albedo[pix] = make_float4(material.diffuse_albedo.x, material.diffuse_albedo.y, material.diffuse_albedo.z, 0.0f);
     aov.depth[pix] = length3(F3(ro.x, ro.y, ro.z) - position);
     aov.normal[pix] = make_float4(normal.x, normal.y, normal.z, 0.0f);

@@ -21,6 +21,7 @@ struct Scene
     void* nodes = nullptr; void* tris_rt = nullptr; void* tris_sh = nullptr; void* materials = nullptr;
     void* textures = nullptr; void* texture_data = nullptr; void* lights = nullptr; void* env = nullptr;
     void* emissive = nullptr;
+    void* mat_tex16 = nullptr;
     void* wnodes = nullptr;   // 4-wide quantized BVH (build_wide_bvh); nullptr when the tree does not qualify
     DScene d = {};
     bool valid = false;
@@ -168,7 +169,7 @@ int dev_alloc_copy(rt_ctx* ctx, void** out, const void* src, size_t bytes)
 
 void free_scene(Scene& s)
 {
-    void* ptrs[] = {s.nodes, s.tris_rt, s.tris_sh, s.materials, s.textures, s.texture_data, s.lights, s.env, s.emissive, s.wnodes};
+    void* ptrs[] = {s.nodes, s.tris_rt, s.tris_sh, s.materials, s.textures, s.texture_data, s.lights, s.env, s.emissive, s.wnodes, s.mat_tex16};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     s = Scene();
 }
@@ -574,10 +575,17 @@ int rt_scene_upload(rt_ctx* ctx, const rt_scene_desc* sd)
         const rt_packed_material& m = sd->materials[i];
         const uint32_t idx[6] = {m.diffuse_albedo >> 24, m.specular_albedo >> 24, (m.roughness_metalness >> 8) & 0xFFu,
             m.roughness_metalness >> 24, (m.ior_emission_idx_transparency >> 8) & 0xFFu, m.ior_emission_idx_transparency >> 24};
-        for (uint32_t t : idx)
-            if (t != RT_INVALID_TEXTURE_IDX && t >= sd->num_textures)
-                return fail(ctx, "rt_scene_upload: material references a texture that does not exist");
+        if (!sd->material_texture_indices)
+            for (uint32_t t : idx)
+                if (t != RT_INVALID_TEXTURE_IDX && t >= sd->num_textures)
+                    return fail(ctx, "rt_scene_upload: material references a texture that does not exist");
     }
+    if (sd->material_texture_indices)          // the wide indices replace the packed ones (rt_scene_desc)
+        for (size_t i = 0; i < (size_t)sd->num_materials * 6; ++i)
+            if (sd->material_texture_indices[i] != 0xFFFFu && sd->material_texture_indices[i] >= sd->num_textures)
+                return fail(ctx, "rt_scene_upload: material_texture_indices references a texture that does not exist");
+    for (uint32_t i = 0; i < sd->num_emissive; ++i)
+        if (sd->emissive_indices[i] >= nt) return fail(ctx, "rt_scene_upload: emissive index outside the triangle array");
     for (uint32_t i = 0; i < sd->num_textures; ++i)
     {
         const rt_texture& t = sd->textures[i];
@@ -639,6 +647,8 @@ int rt_scene_upload(rt_ctx* ctx, const rt_scene_desc* sd)
     rc |= dev_alloc_copy(ctx, &s.lights, lights.data(), lights.size() * sizeof(float4));
     rc |= dev_alloc_copy(ctx, &s.env, sd->env_rgba, (size_t)sd->env_width * sd->env_height * 16);
     rc |= dev_alloc_copy(ctx, &s.emissive, sd->emissive_indices, (size_t)sd->num_emissive * 4);
+    if (sd->material_texture_indices)
+        rc |= dev_alloc_copy(ctx, &s.mat_tex16, sd->material_texture_indices, (size_t)sd->num_materials * 6 * sizeof(uint16_t));
     // the 4-wide quantized tree for k_trace_w4 (optional: trees that do not qualify keep the BVH2 kernels)
     std::vector<WideNode> wide;
     uint32_t w_entry = 0;
@@ -658,6 +668,10 @@ int rt_scene_upload(rt_ctx* ctx, const rt_scene_desc* sd)
     s.d.gamma_lut = ctx->gamma_lut;
     s.d.env_w = (int)sd->env_width;
     s.d.env_h = (int)sd->env_height;
+    s.d.mat_tex16 = (const uint16_t*)s.mat_tex16;
+    s.d.emissive = (const uint32_t*)s.emissive;
+    s.d.emissive_count = sd->num_emissive;
+    s.d.emissive_nee = (sd->flags & RT_SCENE_EMISSIVE_NEE) && sd->num_emissive ? 1u : 0u;
     s.d.light_count = sd->num_lights;
     s.d.wnodes = have_wide ? (const float4*)s.wnodes : nullptr;
     s.d.w_entry_ref = w_entry;
@@ -1391,14 +1405,21 @@ int rt_shade(rt_frame* f, uint32_t bounce)              // ShadeMissedRays + Sha
     if (wait_shadow(f, bounce & 1u) != RT_OK) return RT_ERROR;
     KernelSpan span(f, 2);
     const bool blue = f->sampler == 1;   // kernel variants are AOT (the reference rebuilds with -D..., :267-285)
-    if (f->white_furnace && blue)
-        hipLaunchKernelGGL((k_shade<true, true>), dim3(blocks), dim3(RT_SHADE_BLOCK), 0, f->p->stream, ctx->scene.d, f->tile, a);
-    else if (f->white_furnace)
-        hipLaunchKernelGGL((k_shade<true, false>), dim3(blocks), dim3(RT_SHADE_BLOCK), 0, f->p->stream, ctx->scene.d, f->tile, a);
-    else if (blue)
-        hipLaunchKernelGGL((k_shade<false, true>), dim3(blocks), dim3(RT_SHADE_BLOCK), 0, f->p->stream, ctx->scene.d, f->tile, a);
-    else
-        hipLaunchKernelGGL((k_shade<false, false>), dim3(blocks), dim3(RT_SHADE_BLOCK), 0, f->p->stream, ctx->scene.d, f->tile, a);
+    const bool nee = ctx->scene.d.emissive_nee != 0;     // opt-in extension (rt_scene_desc::flags)
+#define RT_LAUNCH_SHADE(FURNACE, BLUE, NEE) \
+    hipLaunchKernelGGL((k_shade<FURNACE, BLUE, NEE>), dim3(blocks), dim3(RT_SHADE_BLOCK), 0, f->p->stream, ctx->scene.d, f->tile, a)
+    if (nee)
+    {
+        if (f->white_furnace && blue) RT_LAUNCH_SHADE(true, true, true);
+        else if (f->white_furnace) RT_LAUNCH_SHADE(true, false, true);
+        else if (blue) RT_LAUNCH_SHADE(false, true, true);
+        else RT_LAUNCH_SHADE(false, false, true);
+    }
+    else if (f->white_furnace && blue) RT_LAUNCH_SHADE(true, true, false);
+    else if (f->white_furnace) RT_LAUNCH_SHADE(true, false, false);
+    else if (blue) RT_LAUNCH_SHADE(false, true, false);
+    else RT_LAUNCH_SHADE(false, false, false);
+#undef RT_LAUNCH_SHADE
     HIPCHK(ctx, hipGetLastError());
     if (f->side_active) HIPCHK(ctx, hipEventRecord(f->p->ev_shaded, f->p->stream));
     return RT_OK;

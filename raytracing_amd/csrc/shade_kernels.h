@@ -59,13 +59,20 @@ RT_DEV f3 UnpackRGBTex(uint32_t data, uint32_t& idx)                    // utils
     return F3(r / 255.0f, g / 255.0f, b / 255.0f);
 }
 
-RT_DEV void ApplyTextures(const DScene& sc, rt_packed_material in, Material& out, f2 uv)   // material.h:319-369
+// mtl: the material's index (for the wide texture indices of rt_scene_desc::material_texture_indices, when given)
+RT_DEV void ApplyTextures(const DScene& sc, uint32_t mtl, Material& out, f2 uv)   // material.h:319-369
 {
+    const rt_packed_material in = sc.materials[mtl];
+    // texture index of slot k: the packed 8-bit field (0xFF = none), or the 16-bit side table (0xFFFF = none)
+    const uint16_t* wide = sc.mat_tex16 ? sc.mat_tex16 + (size_t)mtl * 6u : nullptr;
+    const uint32_t none = wide ? 0xFFFFu : RT_INVALID_TEXTURE_IDX;
     uint32_t idx;
     out.diffuse_albedo = UnpackRGBTex(in.diffuse_albedo, idx);
-    if (idx != RT_INVALID_TEXTURE_IDX) out.diffuse_albedo = SampleTextureGamma(sc, idx, uv);
+    if (wide) idx = wide[0];
+    if (idx != none) out.diffuse_albedo = SampleTextureGamma(sc, idx, uv);
     out.specular_albedo = UnpackRGBTex(in.specular_albedo, idx);
-    if (idx != RT_INVALID_TEXTURE_IDX) out.specular_albedo = SampleTextureGamma(sc, idx, uv);
+    if (wide) idx = wide[1];
+    if (idx != none) out.specular_albedo = SampleTextureGamma(sc, idx, uv);
     {
         uint32_t rgbe = in.emission;                                     // utils.h:149-158
         int r = (int)(rgbe & 0xFF), g = (int)((rgbe >> 8) & 0xFF), b = (int)((rgbe >> 16) & 0xFF);
@@ -75,19 +82,19 @@ RT_DEV void ApplyTextures(const DScene& sc, rt_packed_material in, Material& out
     }
     uint32_t d = in.roughness_metalness;                                 // utils.h:160-174
     out.roughness = (float)(d & 0xFF) / 255.0f;
-    uint32_t roughness_idx = (d >> 8) & 0xFF;
+    uint32_t roughness_idx = wide ? wide[2] : (d >> 8) & 0xFF;
     out.metalness = (float)((d >> 16) & 0xFF) / 255.0f;
-    uint32_t metalness_idx = (d >> 24) & 0xFF;
-    if (roughness_idx != RT_INVALID_TEXTURE_IDX) out.roughness = SampleTexture(sc, roughness_idx, uv).x;
-    if (metalness_idx != RT_INVALID_TEXTURE_IDX) out.metalness = SampleTexture(sc, metalness_idx, uv).x;
+    uint32_t metalness_idx = wide ? wide[3] : (d >> 24) & 0xFF;
+    if (roughness_idx != none) out.roughness = SampleTexture(sc, roughness_idx, uv).x;
+    if (metalness_idx != none) out.metalness = SampleTexture(sc, metalness_idx, uv).x;
     d = in.ior_emission_idx_transparency;                                // utils.h:176-190
     out.ior = (float)(d & 0xFF) / 25.5f;
-    uint32_t emission_idx = (d >> 8) & 0xFF;
+    uint32_t emission_idx = wide ? wide[4] : (d >> 8) & 0xFF;
     out.transparency = (float)((d >> 16) & 0xFF) / 255.0f;
-    uint32_t transparency_idx = (d >> 24) & 0xFF;
-    if (emission_idx != RT_INVALID_TEXTURE_IDX)
+    uint32_t transparency_idx = wide ? wide[5] : (d >> 24) & 0xFF;
+    if (emission_idx != none)
         out.emission = out.emission * SampleTextureGamma(sc, emission_idx, uv);
-    if (transparency_idx != RT_INVALID_TEXTURE_IDX)
+    if (transparency_idx != none)
         out.transparency *= SampleTexture(sc, transparency_idx, uv).x;
 }
 
@@ -152,8 +159,9 @@ RT_DEV f3 EvaluateMaterial(const Material& m, f3 normal, f3 incoming, f3 outgoin
 // material.h:171-241 with SampleSpecular :66-103, SampleDiffuse :51-64, SampleTransparency :105-117
 template <bool FURNACE>
 RT_DEV f3 SampleBxdf(float s1, f2 s, Material material, f3 normal, f3 incoming, f3& outgoing, float& pdf,
-    float& offset)
+    float& offset, bool& delta /* the event chosen has a delta distribution (RT_SCENE_EMISSIVE_NEE) */)
 {
+    delta = false;
     if (FURNACE)
     {
         material.diffuse_albedo = F3s(1.0f);
@@ -177,6 +185,7 @@ RT_DEV f3 SampleBxdf(float s1, f2 s, Material material, f3 normal, f3 incoming, 
         pdf = 1.0f;
         outgoing = -incoming;
         offset = -1.0f;
+        delta = true;
         return F3s(1.0f);
     }
 
@@ -193,6 +202,7 @@ RT_DEV f3 SampleBxdf(float s1, f2 s, Material material, f3 normal, f3 incoming, 
             pdf = 1.0f;
             float n_dot_o = dot3(outgoing, normal);
             spec = 1.0f / n_dot_o;
+            delta = true;
         }
         else
         {
@@ -380,7 +390,9 @@ RT_DEV float SampleBlueNoise(const ShadeArgs& a, uint32_t px, uint32_t py, uint3
     return (0.5f + (float)value) / 256.0f;
 }
 
-template <bool FURNACE, bool BLUE>
+// NEE: the scene asked for next-event estimation over the emissive triangles too (RT_SCENE_EMISSIVE_NEE, an opt-in
+// extension: DESIGN.md 7b); the other instances are the reference's estimator.
+template <bool FURNACE, bool BLUE, bool NEE = false>
 __global__ __launch_bounds__(RT_SHADE_BLOCK) void k_shade(DScene sc, DTile tile, ShadeArgs a)
 {
     const uint32_t count = a.counters->queue[a.bounce];
@@ -430,6 +442,7 @@ __global__ __launch_bounds__(RT_SHADE_BLOCK) void k_shade(DScene sc, DTile tile,
     const bool active = i < count;
 
     bool want_shadow = false, want_next = false;
+    uint32_t next_flag = 0;            // NEE: bit 31 of the outgoing ray's log-count word = "this event was a delta one"
     float4 sh_o = make_float4(0, 0, 0, 0), sh_d = sh_o, nx_o = sh_o, nx_d = sh_o, nx_t = sh_o;
     uint32_t sh_entry = 0;
 
@@ -443,7 +456,9 @@ __global__ __launch_bounds__(RT_SHADE_BLOCK) void k_shade(DScene sc, DTile tile,
         uint32_t pix = id - slot * a.n_local;
         uint32_t sample_idx = a.sample_base + slot;
         float4 thr4 = a.in_thr[i];
-        uint32_t nlog = a.count_in_ray ? __float_as_uint(thr4.w) : a.cnt[id];   // contributions logged so far
+        uint32_t nlog = a.count_in_ray ? (__float_as_uint(thr4.w) & 0x7FFFFFFFu) : a.cnt[id];   // contributions logged so far
+        // NEE: bit 31 of the same word = the path's last scattering event was a delta one (set by the previous bounce)
+        const bool prev_delta = NEE && (__float_as_uint(thr4.w) >> 31) != 0u;
         float4* mylog = a.rlog + id;
         f3 hit_throughput = F3(thr4.x, thr4.y, thr4.z);
 
@@ -478,9 +493,11 @@ __global__ __launch_bounds__(RT_SHADE_BLOCK) void k_shade(DScene sc, DTile tile,
             f3 normal = normalize3(n1 * w0 + n2 * bu + n3 * bv);
 
             Material material;
-            ApplyTextures(sc, sc.materials[__float_as_uint(q6.x)], material, texcoord);
+            ApplyTextures(sc, __float_as_uint(q6.x), material, texcoord);
 
-            if (!FURNACE)
+            // NEE: light gathered from the emissive triangles by next-event estimation is not counted again when a
+            // scattered ray happens to hit one -- emission is added for camera rays and after delta events only
+            if (!FURNACE && (!NEE || a.bounce == 0u || prev_delta))
             {
                 if (material.emission.x * 1.0f + material.emission.y * 1.0f + material.emission.z * 1.0f > 0.0f)
                 {
@@ -501,22 +518,62 @@ __global__ __launch_bounds__(RT_SHADE_BLOCK) void k_shade(DScene sc, DTile tile,
             // Direct lighting :115-145 (Light_Sample light.h:30-65)
             {
                 float s_light = draw(4);
-                int light_idx = cl_clampi((int)(s_light * (float)sc.light_count), 0, (int)sc.light_count - 1);
-                float4 lo = sc.lights[light_idx * 3 + 0], lr = sc.lights[light_idx * 3 + 1];
-                uint32_t ltype = __float_as_uint(sc.lights[light_idx * 3 + 2].x);
-                float pdf = 1.0f / (float)sc.light_count;
-                f3 light_radiance = xyz(lr);
+                const uint32_t n_lights = NEE ? sc.light_count + sc.emissive_count : sc.light_count;
+                int light_idx = cl_clampi((int)(s_light * (float)n_lights), 0, (int)n_lights - 1);
+                float pdf = 1.0f / (float)n_lights;
+                f3 light_radiance;
                 f3 outgoing;
-                if (ltype == RT_LIGHT_TYPE_POINT)
+                if (!NEE || (uint32_t)light_idx < sc.light_count)
                 {
-                    f3 to_light = xyz(lo) - position;
-                    float sq_length = dot3(to_light, to_light);
-                    light_radiance = light_radiance / sq_length;
-                    outgoing = to_light;
+                    float4 lo = sc.lights[light_idx * 3 + 0], lr = sc.lights[light_idx * 3 + 1];
+                    uint32_t ltype = __float_as_uint(sc.lights[light_idx * 3 + 2].x);
+                    light_radiance = xyz(lr);
+                    if (ltype == RT_LIGHT_TYPE_POINT)
+                    {
+                        f3 to_light = xyz(lo) - position;
+                        float sq_length = dot3(to_light, to_light);
+                        light_radiance = light_radiance / sq_length;
+                        outgoing = to_light;
+                    }
+                    else
+                    {
+                        outgoing = xyz(lo) * RT_MAX_RENDER_DIST;
+                    }
                 }
                 else
                 {
-                    outgoing = xyz(lo) * RT_MAX_RENDER_DIST;
+                    // an emissive triangle, sampled uniformly by area: u1 = what the index left of s * n, u2 = the
+                    // BSDF-layer sample of this bounce (oracle.c: Light_SampleWithEmissive, the same operations)
+                    const uint32_t lt = sc.emissive[(uint32_t)light_idx - sc.light_count];
+                    float u1 = s_light * (float)n_lights - (float)light_idx;
+                    u1 = cl_min(cl_max(u1, 0.0f), 1.0f);
+                    const float su = __builtin_sqrtf(u1);
+                    const float b0 = 1.0f - su, b1 = draw(1) * su;
+                    const float b2 = 1.0f - b0 - b1;
+                    const float4* lq = sc.tris_sh + (size_t)lt * 8;
+                    const float4 l0 = lq[0], l1 = lq[1], l2 = lq[2], l3 = lq[3], l4 = lq[4], l5 = lq[5], l6 = lq[6];
+                    const f3 a1 = xyz(l0), a2 = xyz(l1), a3 = xyz(l2);
+                    const f3 lp = a1 * b0 + a2 * b1 + a3 * b2;
+                    f2 luv;
+                    luv.x = l0.w * b0 + l2.w * b1 + l4.w * b2;
+                    luv.y = l1.w * b0 + l3.w * b1 + l5.w * b2;
+                    Material lm;
+                    ApplyTextures(sc, __float_as_uint(l6.x), lm, luv);
+                    const f3 nl = cross3(a2 - a1, a3 - a1);                  // length = 2 * area
+                    const f3 to_light = lp - position;
+                    const float d2 = dot3(to_light, to_light);
+                    float g = 0.0f;
+                    // front side only: the reference's ray-triangle test culls back faces (det = -dir . nl < 1e-8), so a
+                    // triangle is visible, and its emission counted, only from the side its normal points to
+                    const float dist = __builtin_sqrtf(d2);
+                    const float nd = -dot3(nl, to_light);                    // 2 * area * d * cos_l
+                    if (d2 > 0.0f && nd / dist >= 1e-8f) g = (nd * 0.5f) / (dist * d2);   // cos_l * area / d^2
+                    // the shadow ray starts EPS along the normal but is aimed from `position`: it meets the emitter's plane
+                    // up to EPS / |cos_l| early.  Stop short by twice that + 2^-10 d; drop what leaves nothing (oracle.c)
+                    float keep = 1.0f - 0.0009765625f - (2.0f * RT_EPS) * __builtin_sqrtf(dot3(nl, nl)) / nd;
+                    if (!(keep > 0.0f) || !(g > 0.0f)) { keep = 1.0f; g = 0.0f; }
+                    outgoing = to_light * keep;
+                    light_radiance = lm.emission * g;
                 }
                 float distance_to_light = length3(outgoing);
                 outgoing = normalize3(outgoing);
@@ -548,7 +605,9 @@ __global__ __launch_bounds__(RT_SHADE_BLOCK) void k_shade(DScene sc, DTile tile,
                 float pdf = 0.0f;
                 f3 outgoing;
                 float offset;
-                f3 bxdf = SampleBxdf<FURNACE>(s1, s, material, normal, incoming, outgoing, pdf, offset);
+                bool delta;
+                f3 bxdf = SampleBxdf<FURNACE>(s1, s, material, normal, incoming, outgoing, pdf, offset, delta);
+                if (NEE && delta) next_flag = 0x80000000u;
                 f3 throughput = F3s(0.0f);
                 if ((double)pdf > 0.0) throughput = bxdf / pdf;
                 f3 new_thr = hit_throughput * throughput;                 // throughputs[pixel] *= throughput
@@ -559,7 +618,7 @@ __global__ __launch_bounds__(RT_SHADE_BLOCK) void k_shade(DScene sc, DTile tile,
                 nx_t = make_float4(new_thr.x, new_thr.y, new_thr.z, 0.0f);
             }
         }
-        nx_t.w = __uint_as_float(nlog);
+        nx_t.w = __uint_as_float(nlog | next_flag);
         if (!a.count_in_ray || ((!want_next || a.final_bounce) && nlog != 0u)) a.cnt[id] = nlog;   // the path's final count is what k_flush replays
     }
 

@@ -27,6 +27,7 @@ def load():
     sig = {
         "orc_create": (vp, [u32, u32, C.c_int]), "orc_destroy": (None, [vp]),
         "orc_upload": (None, [vp, vp, u32, vp, u32, vp, u32, vp, u32, vp, u32, vp, u32, vp, u32, vp, u32, u32]),
+        "orc_set_extensions": (None, [vp, vp, u32]),
         "orc_set_camera": (None, [vp, vp]), "orc_set_max_bounces": (None, [vp, u32]),
         "orc_request_reset": (None, [vp]), "orc_integrate": (None, [vp]),
         "orc_resolve": (vp, [vp]), "orc_radiance": (vp, [vp]), "orc_sample_count": (u32, [vp]),
@@ -68,13 +69,21 @@ class Oracle:
         self.lib = load()
         self.w, self.h = width, height
         self.handle = self.lib.orc_create(width, height, int(furnace))
-        s = {k: np.ascontiguousarray(v) for k, v in scene.items()}
+        s = {k: np.ascontiguousarray(v) for k, v in scene.items() if k not in ("flags",)}
         p = lambda a: a.ctypes.data if a.size else None
         env = s["env"]
         self.lib.orc_upload(self.handle, p(s["triangles"]), len(s["triangles"]), p(s["nodes"]), len(s["nodes"]),
                             p(s["materials"]), len(s["materials"]), p(s["textures"]), len(s["textures"]),
                             p(s["texture_data"]), len(s["texture_data"]), p(s["lights"]), len(s["lights"]),
                             p(s["emissive"]), len(s["emissive"]), p(env), env.shape[1], env.shape[0])
+        # this repository's opt-in extensions (rt_scene_desc::material_texture_indices / flags)
+        tex16 = s.get("material_texture_indices")
+        flags = int(scene.get("flags", 0))
+        if tex16 is not None or flags:
+            if tex16 is not None:
+                tex16 = np.ascontiguousarray(tex16, np.uint16)
+                assert tex16.size == 6 * len(s["materials"])
+            self.lib.orc_set_extensions(self.handle, tex16.ctypes.data if tex16 is not None else None, flags)
 
     def set_camera(self, cam):
         self._cam = np.ascontiguousarray(cam)
