@@ -85,7 +85,7 @@ CONFIGS = {
 def build_scene(args, host, S):
     if getattr(args, "scene", None):
         # a real asset: OBJ/MTL through the C++ loader, or a binary cache written by rt_render --save-cache
-        scene = host.Scene(args.scene, scale=args.scale, flip_yz=args.flip_yz)
+        scene = host.Scene(args.scene, scale=args.scale, flip_yz=args.flip_yz, wide_texture_indices=getattr(args, "wide_texture_indices", False))
     elif args.config == 3:
         import tempfile
         path = S.shader_balls_obj(tempfile.mkdtemp(prefix="rt_bench_"), 100_000)
@@ -307,6 +307,7 @@ def main():
                     "e.g. --scene exterior.obj --flip-yz --scale 0.01 for Bistro (run_bistro.bat:15)")
     ap.add_argument("--scale", type=float, default=1.0)
     ap.add_argument("--flip-yz", action="store_true")
+    ap.add_argument("--wide-texture-indices", action="store_true", help="with --scene: load more than 255 textures (opt-in extension)")
     ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--bounces", type=int, default=None)

@@ -11,7 +11,8 @@ LIB_PATH = os.path.join(_HERE, "librt_host.so")
 _lib = None
 
 EXPORTS = [
-    "rth_last_error", "rth_scene_load", "rth_scene_from_arrays", "rth_scene_destroy",
+    "rth_last_error", "rth_scene_load", "rth_scene_load_ex", "rth_scene_set_material_texture_indices", "rth_scene_set_emissive_nee",
+    "rth_scene_emissive_nee", "rth_scene_from_arrays", "rth_scene_destroy",
     "rth_scene_add_directional_light", "rth_scene_add_point_light", "rth_scene_set_env_path",
     "rth_scene_set_env_image", "rth_scene_finalize", "rth_bvh_build", "rth_bvh_destroy", "rth_bvh_num_nodes",
     "rth_bvh_nodes", "rth_load_hdr", "rth_load_tga", "rth_load_png", "rth_loaded_image_data", "rth_default_camera",
@@ -35,7 +36,9 @@ def load():
     vp, u32, f32, i32, cp = C.c_void_p, C.c_uint32, C.c_float, C.c_int, C.c_char_p
     sig = {
         "rth_last_error": (cp, []),
-        "rth_scene_load": (vp, [cp, f32, i32]),
+        "rth_scene_load": (vp, [cp, f32, i32]), "rth_scene_load_ex": (vp, [cp, f32, i32, u32]),
+        "rth_scene_set_material_texture_indices": (i32, [vp, vp, u32]), "rth_scene_set_emissive_nee": (None, [vp, i32]),
+        "rth_scene_emissive_nee": (i32, [vp]),
         "rth_scene_from_arrays": (vp, [vp, u32, vp, u32, vp, u32, vp, u32]),
         "rth_scene_destroy": (None, [vp]),
         "rth_scene_add_directional_light": (None, [vp] + [f32] * 6),
@@ -62,7 +65,7 @@ def load():
         "rth_render_set_aov": (i32, [vp, i32]), "rth_render_resolve": (i32, [vp, vp]),
         "rth_render_set_blue_noise_path": (i32, [vp, cp]),
     }
-    for name in ("triangles", "materials", "textures", "texture_data", "lights", "emissive"):
+    for name in ("triangles", "materials", "textures", "texture_data", "lights", "emissive", "material_texture_indices"):
         sig["rth_scene_num_" + name] = (u32, [vp])
         sig["rth_scene_" + name] = (vp, [vp])
     sig["rth_scene_env_width"] = (u32, [vp])
@@ -130,7 +133,8 @@ class Scene:
     _GETTERS = (("triangles", T.triangle), ("materials", T.packed_material), ("textures", T.texture),
                 ("texture_data", np.uint32), ("lights", T.light), ("emissive", np.uint32))
 
-    def __init__(self, path=None, scale=1.0, flip_yz=False, arrays=None):
+    def __init__(self, path=None, scale=1.0, flip_yz=False, arrays=None, wide_texture_indices=False, emissive_nee=False):
+        """wide_texture_indices / emissive_nee: this repository's opt-in extensions (rt::Scene::Options)"""
         self.lib = load()
         self.bvh = None
         if arrays is not None:
@@ -140,8 +144,15 @@ class Scene:
             td = a.get("texture_data", np.zeros(0, np.uint32))
             self.handle = self.lib.rth_scene_from_arrays(p(a["triangles"]), len(a["triangles"]), p(a["materials"]),
                                                          len(a["materials"]), p(tex), len(tex), p(td), len(td))
+            if self.handle and a.get("material_texture_indices") is not None:
+                t16 = np.ascontiguousarray(a["material_texture_indices"], np.uint16)
+                if self.lib.rth_scene_set_material_texture_indices(self.handle, t16.ctypes.data, t16.size):
+                    raise _err(self.lib)
+            if self.handle and emissive_nee:
+                self.lib.rth_scene_set_emissive_nee(self.handle, 1)
         else:
-            self.handle = self.lib.rth_scene_load(path.encode(), scale, int(flip_yz))
+            self.handle = self.lib.rth_scene_load_ex(path.encode(), scale, int(flip_yz),
+                                                     (1 if wide_texture_indices else 0) | (2 if emissive_nee else 0))
         if not self.handle:
             raise _err(self.lib)
 
@@ -186,6 +197,12 @@ class Scene:
         out["env"] = _arr(self.lib.rth_scene_env_data(self.handle), w * h * 4, np.float32).reshape(h, w, 4)
         if self.bvh:
             out["nodes"] = _arr(self.lib.rth_bvh_nodes(self.bvh), self.lib.rth_bvh_num_nodes(self.bvh), T.bvh_node)
+        # opt-in extensions, present only when used (capi.Context.upload_scene / tests/_oracle.py read the same keys)
+        n16 = self.lib.rth_scene_num_material_texture_indices(self.handle)
+        if n16:
+            out["material_texture_indices"] = _arr(self.lib.rth_scene_material_texture_indices(self.handle), n16, np.uint16).reshape(-1, 6)
+        if self.lib.rth_scene_emissive_nee(self.handle):
+            out["flags"] = 1
         return out
 
     def close(self):

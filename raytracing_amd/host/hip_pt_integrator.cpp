@@ -98,6 +98,9 @@ void HIPPathTraceIntegrator::UploadGPUData(Scene const& scene, AccelerationStruc
     sd.num_lights = (uint32_t)scene.GetLights().size();
     sd.emissive_indices = scene.GetEmissiveIndices().data();
     sd.num_emissive = (uint32_t)scene.GetEmissiveIndices().size();
+    // opt-in extensions (rt_scene_desc): both absent = the reference's behaviour
+    sd.material_texture_indices = scene.GetMaterialTextureIndices().empty() ? nullptr : scene.GetMaterialTextureIndices().data();
+    sd.flags = scene.GetEmissiveNee() ? RT_SCENE_EMISSIVE_NEE : 0u;
     sd.env_rgba = (const float*)env.data.data();
     sd.env_width = env.width;
     sd.env_height = env.height;

@@ -27,6 +27,20 @@ void* rth_scene_load(const char* path, float scale, int flip_yz)
     return guard([&]() -> void* { return new rt::Scene(path, scale, flip_yz != 0); }, nullptr);
 }
 
+// options: rt::Scene::Options (1 = wide texture indices, 2 = emissive-triangle next-event estimation)
+void* rth_scene_load_ex(const char* path, float scale, int flip_yz, unsigned options)
+{
+    return guard([&]() -> void* { return new rt::Scene(path, scale, flip_yz != 0, options); }, nullptr);
+}
+int rth_scene_set_material_texture_indices(void* s, const uint16_t* idx, uint32_t n)
+{
+    return guard([&]() { ((rt::Scene*)s)->SetMaterialTextureIndices(std::vector<uint16_t>(idx, idx + n)); return 0; }, 1);
+}
+void rth_scene_set_emissive_nee(void* s, int enable) { ((rt::Scene*)s)->SetEmissiveNee(enable != 0); }
+int rth_scene_emissive_nee(void* s) { return ((rt::Scene*)s)->GetEmissiveNee() ? 1 : 0; }
+uint32_t rth_scene_num_material_texture_indices(void* s) { return (uint32_t)((rt::Scene*)s)->GetMaterialTextureIndices().size(); }
+const void* rth_scene_material_texture_indices(void* s) { return ((rt::Scene*)s)->GetMaterialTextureIndices().data(); }
+
 void* rth_scene_from_arrays(const rt_triangle* tris, uint32_t ntris, const rt_packed_material* mats, uint32_t nmats,
     const rt_texture* tex, uint32_t ntex, const uint32_t* texdata, uint32_t ntexdata)
 {

@@ -27,6 +27,7 @@ int main(int argc, char** argv)
         std::string scene_path = "assets/ShaderBalls.obj", out, save_cache;
         float scale = 1.0f, aperture = 0.0f, focus = 10.0f;
         bool flip_yz = false, furnace = false, tiled_path = false;
+        unsigned scene_options = 0;      // rt::Scene::Options (opt-in extensions)
         for (int i = 1; i < argc; ++i)
         {
             auto next = [&]() -> const char* { if (i + 1 >= argc) { std::cerr << "missing value for " << argv[i] << "\n"; exit(2); } return argv[++i]; };
@@ -44,16 +45,20 @@ int main(int argc, char** argv)
             else if (!strcmp(argv[i], "--save-cache")) save_cache = next();
             else if (!strcmp(argv[i], "--gpus")) gpus = (unsigned)atoi(next());
             else if (!strcmp(argv[i], "--tiled")) tiled_path = atoi(next()) != 0;      // take the TiledRender path even with one GPU
+            else if (!strcmp(argv[i], "--wide_texture_indices")) { if (atoi(next()) != 0) scene_options |= rt::Scene::kWideTextureIndices; }
+            else if (!strcmp(argv[i], "--emissive_nee")) { if (atoi(next()) != 0) scene_options |= rt::Scene::kEmissiveNee; }
             else if (!strcmp(argv[i], "--help"))
             {
                 std::cout << "rt_render -w W -h H --scene file.obj [--scale s] [--flip_yz 0|1] [--spp n] [--bounces b]"
                              " [--furnace 0|1] [--aperture a] [--focus d] [--out image.pfm] [--save-cache scene.rtscene] [--gpus n]\n"
                              "  --gpus n tiles the image over devices 0..n-1 (interleaved 8-row bands, one RCCL gather)\n"
-                             "  --scene also accepts a file written by --save-cache (parsed scene + BVH)\n";
+                             "  --scene also accepts a file written by --save-cache (parsed scene + BVH)\n"
+                             "  extensions (off = the reference's behaviour): --wide_texture_indices 1 loads scenes with more than 255\n"
+                             "  textures; --emissive_nee 1 adds the emissive triangles to next-event estimation\n";
                 return 0;
             }
         }
-        rt::Scene scene(scene_path.c_str(), scale, flip_yz);
+        rt::Scene scene(scene_path.c_str(), scale, flip_yz, scene_options);
         scene.AddDirectionalLight({-0.6f, -1.5f, 3.5f}, {15.0f, 10.0f, 5.0f});   // main.cpp:58
         if (gpus > 1 || tiled_path)
         {

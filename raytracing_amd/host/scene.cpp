@@ -306,8 +306,12 @@ void LoadMtl(const std::string& path, std::vector<ObjMaterial>& materials, std::
 // ---------------------------------------------------------------------------
 // Scene
 // ---------------------------------------------------------------------------
-Scene::Scene(const char* filename, float scale, bool flip_yz)
+Scene::Scene(const char* filename, float scale, bool flip_yz) : Scene(filename, scale, flip_yz, 0u) {}
+
+Scene::Scene(const char* filename, float scale, bool flip_yz, unsigned options)
 {
+    wide_texture_indices_ = (options & kWideTextureIndices) != 0;
+    emissive_nee_ = (options & kEmissiveNee) != 0;
     if (IsCacheFile(filename))
     {
         LoadCache(filename);
@@ -323,6 +327,16 @@ Scene::Scene(std::vector<Triangle> triangles, std::vector<PackedMaterial> materi
     : triangles_(std::move(triangles)), materials_(std::move(materials)), textures_(std::move(textures)),
       texture_data_(std::move(texture_data))
 {
+}
+
+void Scene::SetMaterialTextureIndices(std::vector<std::uint16_t> indices)
+{
+    if (!indices.empty() && indices.size() != materials_.size() * 6)
+        throw std::runtime_error("SetMaterialTextureIndices: 6 entries per material expected");
+    for (std::uint16_t t : indices)
+        if (t != 0xFFFFu && t >= textures_.size()) throw std::runtime_error("SetMaterialTextureIndices: texture index out of range");
+    material_texture_indices_ = std::move(indices);
+    wide_texture_indices_ = !material_texture_indices_.empty();
 }
 
 void Scene::Load(const char* filename, float scale, bool flip_yz)
@@ -431,18 +445,30 @@ void Scene::Load(const char* filename, float scale, bool flip_yz)
     materials_.resize(obj_materials.size());
     const float kGamma = 2.2f;
     const std::uint32_t kInvalidTextureIndex = 0xFF;
+    // wide mode (extension): the index goes to the 16-bit side table and the packed 8-bit field says "none"
+    std::vector<std::uint16_t> wide;
+    if (wide_texture_indices_) wide.assign(obj_materials.size() * 6, 0xFFFFu);
+    size_t wide_at = 0;
     auto tex = [&](const std::string& name) -> std::uint32_t
     {
-        return name.empty() ? kInvalidTextureIndex : (std::uint32_t)LoadTexture(folder + "/" + name);
+        const size_t slot = wide_at++;
+        if (name.empty()) return kInvalidTextureIndex;
+        const std::uint32_t idx = (std::uint32_t)LoadTexture(folder + "/" + name);
+        if (!wide_texture_indices_) return idx;
+        wide[slot] = (std::uint16_t)idx;
+        return kInvalidTextureIndex;
     };
     for (size_t i = 0; i < obj_materials.size(); ++i)
     {
         const ObjMaterial& in = obj_materials[i];
         PackedMaterial& out = materials_[i];
+        wide_at = i * 6;      // slot order of rt_scene_desc::material_texture_indices: diffuse, specular, roughness, metalness, emission, transparency
+        const std::uint32_t didx = tex(in.diffuse_tex);
+        const std::uint32_t sidx = tex(in.specular_tex);
         out.diffuse_albedo = PackAlbedo(std::pow(in.diffuse[0], kGamma), std::pow(in.diffuse[1], kGamma),
-            std::pow(in.diffuse[2], kGamma), tex(in.diffuse_tex));
+            std::pow(in.diffuse[2], kGamma), didx);
         out.specular_albedo = PackAlbedo(std::pow(in.specular[0], kGamma), std::pow(in.specular[1], kGamma),
-            std::pow(in.specular[2], kGamma), tex(in.specular_tex));
+            std::pow(in.specular[2], kGamma), sidx);
         out.emission = PackRGBE(in.emission[0], in.emission[1], in.emission[2]);
         std::uint32_t ridx = tex(in.roughness_tex);
         std::uint32_t midx = tex(in.metallic_tex);
@@ -451,6 +477,7 @@ void Scene::Load(const char* filename, float scale, bool flip_yz)
         std::uint32_t tidx = tex(in.alpha_tex);
         out.ior_emission_idx_transparency = PackIorEmissionIdxTransparency(in.ior, eidx, in.transmittance[0], tidx);
     }
+    material_texture_indices_ = std::move(wide);
 
     // triangles (scene.cpp:188-270)
     auto flip = [flip_yz](float3& p)
@@ -503,7 +530,9 @@ std::size_t Scene::LoadTexture(const std::string& filename)   // scene.cpp:276-3
     else if (ext == ".png") ok = LoadPNG(filename.c_str(), image);
     else if (ext == ".jpg") ok = LoadJPEG(filename.c_str(), image);
     if (!ok) throw std::runtime_error("Failed to load file " + filename);
-    if (textures_.size() >= 255) throw std::runtime_error("More than 255 textures (8-bit texture index, constants.h:35)");
+    if (!wide_texture_indices_ && textures_.size() >= 255)
+        throw std::runtime_error("More than 255 textures (8-bit texture index, constants.h:35); load with Scene::kWideTextureIndices (rt_render --wide_texture_indices)");
+    if (textures_.size() >= 0xFFFFu) throw std::runtime_error("More than 65535 textures");
     Texture t;
     t.width = (int)image.width;
     t.height = (int)image.height;

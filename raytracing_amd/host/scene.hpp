@@ -21,6 +21,13 @@ public:
     // OBJ + MTL from disk (main.cpp:56); throws std::runtime_error on failure.  A file written
     // by SaveCache is recognised by its magic and loaded as is (scale / flip_yz are baked in).
     Scene(const char* filename, float scale, bool flip_yz);
+    // ... with opt-in extensions (not in the reference; include/rt_hip.h, rt_scene_desc):
+    //   kWideTextureIndices: texture indices are kept 16 bits wide in a side table, lifting the 255-texture limit of the
+    //                        packed material (PackAlbedo's assert, scene.cpp:55; constants.h:35) -- a scene with more
+    //                        textures fails to load without it
+    //   kEmissiveNee:        next-event estimation also samples the emissive triangles (GetEmissiveIndices)
+    enum Options : unsigned { kWideTextureIndices = 1u, kEmissiveNee = 2u };
+    Scene(const char* filename, float scale, bool flip_yz, unsigned options);
     // Caller-built arrays (procedural scenes / binary caches); no file IO.
     Scene(std::vector<Triangle> triangles, std::vector<PackedMaterial> materials, std::vector<Texture> textures,
         std::vector<std::uint32_t> texture_data);
@@ -51,6 +58,12 @@ public:
     std::vector<Light> const& GetLights() const { return lights_; }
     std::vector<std::uint32_t> const& GetEmissiveIndices() const { return emissive_indices_; }
     SceneInfo const& GetSceneInfo() const { return scene_info_; }
+    // extensions: 6 texture indices per material (diffuse, specular, roughness, metalness, emission, transparency;
+    // 0xFFFF = none), empty unless kWideTextureIndices / SetMaterialTextureIndices; and the RT_SCENE_* flags
+    std::vector<std::uint16_t> const& GetMaterialTextureIndices() const { return material_texture_indices_; }
+    void SetMaterialTextureIndices(std::vector<std::uint16_t> indices);   // for caller-built arrays
+    void SetEmissiveNee(bool enable) { emissive_nee_ = enable; }
+    bool GetEmissiveNee() const { return emissive_nee_; }
     Image const& GetEnvImage() const { return env_image_; }
 
 private:
@@ -67,6 +80,9 @@ private:
     std::vector<Light> lights_;
     std::vector<std::uint32_t> emissive_indices_;
     std::vector<LinearBVHNode> prebuilt_nodes_;             // from a cache file: Bvh adopts them instead of building
+    std::vector<std::uint16_t> material_texture_indices_;   // extension: see GetMaterialTextureIndices
+    bool wide_texture_indices_ = false;
+    bool emissive_nee_ = false;
     SceneInfo scene_info_ = {};
     Image env_image_;
     std::string env_path_ = "assets/ibl/CGSkies_0036_free.hdr";

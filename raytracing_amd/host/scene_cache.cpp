@@ -9,6 +9,8 @@
 //   magic "RTSCENE\1" | u32 version | u32 sizeof(Triangle) | u32 sizeof(LinearBVHNode) |
 //   u32 sizeof(PackedMaterial) | u64 counts[5] (triangles, nodes, materials, textures,
 //   texture words) | u64 checksum of the payload
+// Version 2 (written only when the scene carries the wide texture indices of Scene::kWideTextureIndices) appends
+// u64 count + that many uint16 (6 per material) after the five arrays; version 1 files stay byte-identical.
 #include "scene.hpp"
 #include <cstdio>
 #include <cstring>
@@ -19,7 +21,7 @@ namespace rt
 namespace
 {
 constexpr char kMagic[8] = {'R', 'T', 'S', 'C', 'E', 'N', 'E', 1};
-constexpr std::uint32_t kVersion = 1;
+constexpr std::uint32_t kVersion = 1, kVersionWideTextures = 2;
 
 struct Header
 {
@@ -90,7 +92,7 @@ void Scene::SaveCache(const char* path, std::vector<LinearBVHNode> const& nodes)
     if (!out.f) throw std::runtime_error(std::string("scene cache: cannot create ") + path);
     Header h = {};
     std::memcpy(h.magic, kMagic, 8);
-    h.version = kVersion;
+    h.version = material_texture_indices_.empty() ? kVersion : kVersionWideTextures;
     h.triangle_size = sizeof(Triangle); h.node_size = sizeof(LinearBVHNode); h.material_size = sizeof(PackedMaterial);
     h.counts[0] = triangles_.size(); h.counts[1] = nodes.size(); h.counts[2] = materials_.size();
     h.counts[3] = textures_.size(); h.counts[4] = texture_data_.size();
@@ -101,6 +103,13 @@ void Scene::SaveCache(const char* path, std::vector<LinearBVHNode> const& nodes)
     WriteArray(out.f, materials_, sum, path);
     WriteArray(out.f, textures_, sum, path);
     WriteArray(out.f, texture_data_, sum, path);
+    if (h.version == kVersionWideTextures)
+    {
+        const std::uint64_t n = material_texture_indices_.size();
+        if (std::fwrite(&n, sizeof(n), 1, out.f) != 1) throw std::runtime_error(std::string("scene cache: short write to ") + path);
+        sum.Add(&n, sizeof(n));
+        WriteArray(out.f, material_texture_indices_, sum, path);
+    }
     h.checksum = sum.h;
     if (std::fseek(out.f, 0, SEEK_SET) != 0 || std::fwrite(&h, sizeof(h), 1, out.f) != 1)
         throw std::runtime_error(std::string("scene cache: cannot finish ") + path);
@@ -113,7 +122,7 @@ void Scene::LoadCache(const char* path)
     Header h;
     if (std::fread(&h, sizeof(h), 1, in.f) != 1 || std::memcmp(h.magic, kMagic, 8) != 0)
         throw std::runtime_error(std::string("scene cache: not a scene cache: ") + path);
-    if (h.version != kVersion || h.triangle_size != sizeof(Triangle) || h.node_size != sizeof(LinearBVHNode) ||
+    if ((h.version != kVersion && h.version != kVersionWideTextures) || h.triangle_size != sizeof(Triangle) || h.node_size != sizeof(LinearBVHNode) ||
         h.material_size != sizeof(PackedMaterial))
         throw std::runtime_error(std::string("scene cache: written by an incompatible version: ") + path);
     if (h.counts[0] == 0 || h.counts[1] == 0 || h.counts[0] > 0xFFFFFFFFull || h.counts[1] > 0xFFFFFFFFull)
@@ -124,6 +133,16 @@ void Scene::LoadCache(const char* path)
     ReadArray(in.f, materials_, h.counts[2], sum, path);
     ReadArray(in.f, textures_, h.counts[3], sum, path);
     ReadArray(in.f, texture_data_, h.counts[4], sum, path);
+    material_texture_indices_.clear();
+    if (h.version == kVersionWideTextures)
+    {
+        std::uint64_t n = 0;
+        if (std::fread(&n, sizeof(n), 1, in.f) != 1 || n != h.counts[2] * 6)
+            throw std::runtime_error(std::string("scene cache: truncated or inconsistent texture index table in ") + path);
+        sum.Add(&n, sizeof(n));
+        ReadArray(in.f, material_texture_indices_, n, sum, path);
+    }
+    wide_texture_indices_ = !material_texture_indices_.empty();
     if (sum.h != h.checksum) throw std::runtime_error(std::string("scene cache: checksum mismatch (corrupt file) ") + path);
     // the checksum covers accidents, not a stale or hand-made file: Finalize() and the upload index these arrays on the host
     auto bad = [&](const char* what) { return std::runtime_error(std::string("scene cache: inconsistent contents (") + what + ") in " + path); };
@@ -144,8 +163,11 @@ void Scene::LoadCache(const char* path)
     {
         const std::uint32_t idx[6] = {m.diffuse_albedo >> 24, m.specular_albedo >> 24, (m.roughness_metalness >> 8) & 0xFFu,
             m.roughness_metalness >> 24, (m.ior_emission_idx_transparency >> 8) & 0xFFu, m.ior_emission_idx_transparency >> 24};
-        for (std::uint32_t t : idx)
-            if (t != 0xFFu && t >= textures_.size()) throw bad("material texture index");
+        if (material_texture_indices_.empty())
+            for (std::uint32_t t : idx)
+                if (t != 0xFFu && t >= textures_.size()) throw bad("material texture index");
     }
+    for (std::uint16_t t : material_texture_indices_)
+        if (t != 0xFFFFu && t >= textures_.size()) throw bad("wide material texture index");
 }
 } // namespace rt

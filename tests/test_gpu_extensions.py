@@ -189,3 +189,49 @@ def test_emissive_nee_gathers_the_same_light_with_far_less_noise(env_map):
         return float(np.abs(a - bimg).mean() / (0.5 * (a + bimg).mean()))      # mean absolute difference / mean level
     assert noise(on, b) * 2.0 < noise(sc, b + 1)               # oracle: 0.116 vs 0.327
     ctx.close()
+
+
+def test_extensions_through_the_cpp_host_layer(tmp_path, env_map):
+    """rt::Scene options -> HIPPathTraceIntegrator::UploadGPUData -> rt_scene_desc: the C++ layer renders what the
+    C-ABI renders from the same arrays + extension data."""
+    from tests.test_host_layer import _many_textures_obj
+    w, h, b, spp = 64, 48, 3, 3
+    ctx = capi.Context(0)
+    # wide texture indices: OBJ with 300 textures, loaded by the C++ loader
+    s = host.Scene(_many_textures_obj(tmp_path, 300), wide_texture_indices=True)
+    s.add_directional_light((-0.3, -0.5, 0.8), (5.0, 5.0, 5.0))
+    s.set_env_image(env_map)
+    cam = T.default_camera(w, h)
+    for k, v in zip("xyz", (1.5, 0.5, 3.0)):
+        cam["position"][k] = np.float32(v)
+    for k, v in zip("xyz", (0.0, 0.0, -1.0)):
+        cam["front"][k] = np.float32(v)
+    for k, v in zip("xyz", (0.0, 1.0, 0.0)):
+        cam["up"][k] = np.float32(v)
+    r = host.Render(w, h, s)
+    r.set_camera(cam); r.set_max_bounces(b)
+    r.render_samples(spp)
+    through_cpp = r.radiance().copy()
+    arrays = r.scene_arrays()
+    assert arrays["material_texture_indices"].shape == (300, 6) and int(arrays["material_texture_indices"].min()) < 300
+    direct, _ = _render(ctx, arrays, w, h, cam, b, spp)
+    assert np.array_equal(through_cpp, direct, equal_nan=True)
+    want, _ = _oracle_render(arrays, w, h, cam, b, spp)
+    assert np.array_equal(direct[..., :3], want[..., :3], equal_nan=True)
+    assert len(np.unique(direct[..., 0])) > 50                # the textured wall is in view
+    del r
+    # emissive NEE: the flag set on the scene object
+    box = lit_box(env_map)
+    s2 = host.Scene(arrays=dict(triangles=box["triangles"], materials=box["materials"]), emissive_nee=True)
+    s2.set_env_image(np.zeros_like(env_map))
+    cam2 = box_camera(w, h)
+    r2 = host.Render(w, h, s2)
+    r2.set_camera(cam2); r2.set_max_bounces(b)
+    r2.render_samples(spp)
+    arrays2 = r2.scene_arrays()
+    assert arrays2["flags"] == capi.SCENE_EMISSIVE_NEE and len(arrays2["emissive"]) == 2
+    direct2, _ = _render(ctx, arrays2, w, h, cam2, b, spp)
+    assert np.array_equal(r2.radiance(), direct2, equal_nan=True)
+    want2, _ = _oracle_render(arrays2, w, h, cam2, b, spp)
+    assert np.array_equal(direct2[..., :3], want2[..., :3], equal_nan=True)
+    ctx.close()

@@ -427,3 +427,66 @@ def test_png_and_tga_texels_identical_to_stb_image(tmp_path):
     hdr = bytes([0, 0, 2, 0, 0, 0, 0, 0, 0, 0, 0, 0, w, 0, h, 0, 32, 8])
     (tmp_path / "a.tga").write_bytes(hdr + rgb[::-1, :, [2, 1, 0, 3]].tobytes())
     assert np.array_equal(host.load_tga(str(tmp_path / "a.tga")), _ref.load_stb(str(tmp_path / "a.tga")))
+
+
+def _many_textures_obj(tmp_path, n):
+    """n materials, one 2x2 TGA texture each, one triangle per material"""
+    hdr = bytes([0, 0, 2, 0, 0, 0, 0, 0, 0, 0, 0, 0, 2, 0, 2, 0, 24, 0x20])      # uncompressed true colour, top-left origin
+    mtl, obj = [], ["mtllib many.mtl", "vn 0 0 1", "vt 0 0", "vt 1 0", "vt 0 1"]
+    for i in range(n):
+        (tmp_path / ("t%03d.tga" % i)).write_bytes(hdr + bytes([(i * 7) % 256, i // 256, i % 256] * 4))
+        mtl.append("newmtl m%d\nKd 1 1 1\nmap_Kd t%03d.tga\n%s" % (i, i, "map_Ke t%03d.tga\nKe 1 1 1\n" % ((i * 3) % n) if i % 50 == 0 else ""))
+        x = 0.01 * i
+        obj += ["v %g 0 0" % x, "v %g 0 0" % (x + 0.009), "v %g 1 0" % x, "usemtl m%d" % i,
+                "f %d/1/1 %d/2/1 %d/3/1" % (3 * i + 1, 3 * i + 2, 3 * i + 3)]
+    (tmp_path / "many.mtl").write_text("\n".join(mtl))
+    (tmp_path / "many.obj").write_text("\n".join(obj) + "\n")
+    return str(tmp_path / "many.obj")
+
+
+def test_more_than_255_textures_need_the_wide_index_extension(tmp_path):
+    """The reference packs texture indices into 8 bits (constants.h:35; PackAlbedo asserts, scene.cpp:55).  The loader
+    refuses a 256th texture unless asked for the 16-bit side table (Scene::kWideTextureIndices); that table, not the packed
+    fields, then names the textures, survives the binary cache, and equals the packed fields on a small scene."""
+    path = _many_textures_obj(tmp_path, 300)
+    with pytest.raises(host.RtError, match="More than 255 textures"):
+        host.Scene(path)
+    s = host.Scene(path, wide_texture_indices=True)
+    nodes = s.build_bvh()
+    s.finalize()
+    a = s.arrays()
+    assert len(a["textures"]) == 300 and a["material_texture_indices"].shape == (300, 6)
+    t16 = a["material_texture_indices"]
+    def file_of(tex):                                                           # which t%03d.tga a texture index holds
+        texel = int(a["texture_data"][int(a["textures"][tex]["data_start"])])
+        return next(i for i in range(300) if (texel & 0xFF, (texel >> 8) & 0xFF, (texel >> 16) & 0xFF) == (i % 256, i // 256, (i * 7) % 256))
+    assert [file_of(int(t)) for t in t16[:, 0]] == list(range(300))            # map_Kd of material i is file i
+    assert int(t16[:, 0].max()) > 255
+    assert file_of(int(t16[250, 4])) == (250 * 3) % 300 and int(t16[1, 4]) == 0xFFFF     # map_Ke on every 50th material
+    assert (t16[:, [1, 2, 3, 5]] == 0xFFFF).all()
+    m = a["materials"]
+    assert ((m["diffuse_albedo"] >> 24) == 0xFF).all()                          # the packed fields say "none"
+    # the binary cache keeps the table (format version 2) ...
+    cache = str(tmp_path / "many.rtscene")
+    s.save_cache(cache)
+    c = host.Scene(cache)
+    cn = c.build_bvh()
+    b = c.arrays()
+    assert T.records_equal(nodes, cn) and np.array_equal(b["material_texture_indices"], t16)
+    # ... and a scene without it still writes the version-1 file
+    small = host.Scene(arrays=S.coverage_scene()); small.build_bvh()
+    small.save_cache(str(tmp_path / "small.rtscene"))
+    assert open(str(tmp_path / "small.rtscene"), "rb").read(12)[8:12] == (1).to_bytes(4, "little")
+    assert open(cache, "rb").read(12)[8:12] == (2).to_bytes(4, "little")
+    # under the limit both modes name the same textures
+    path_small = _many_textures_obj(tmp_path, 40)
+    p8 = host.Scene(path_small).arrays()
+    p16 = host.Scene(path_small, wide_texture_indices=True).arrays()
+    packed = np.stack([p8["materials"]["diffuse_albedo"] >> 24, p8["materials"]["specular_albedo"] >> 24,
+                       (p8["materials"]["roughness_metalness"] >> 8) & 0xFF, p8["materials"]["roughness_metalness"] >> 24,
+                       (p8["materials"]["ior_emission_idx_transparency"] >> 8) & 0xFF,
+                       p8["materials"]["ior_emission_idx_transparency"] >> 24], axis=1)
+    assert np.array_equal(np.where(packed == 0xFF, 0xFFFF, packed), p16["material_texture_indices"])
+    assert "material_texture_indices" not in p8
+    # the NEE flag travels with the scene object
+    assert "flags" not in p8 and host.Scene(path_small, emissive_nee=True).arrays()["flags"] == 1
