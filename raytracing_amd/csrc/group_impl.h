@@ -280,7 +280,7 @@ int exchange(rt_group* g, rt_frame* const* frames, int root, size_t floats_per_r
 // root: one section (COMPS floats per pixel, rank-major padded tiles) of the gathered buffer -> row-major image
 template <int COMPS>
 __global__ void k_group_assemble_n(const float* __restrict__ gathered, float* __restrict__ image, uint32_t width, uint32_t height,
-    uint32_t band_h, uint32_t nranks, uint64_t stride, uint64_t floats_per_rank, uint64_t section_offset)
+    uint32_t band_h, uint32_t nranks, uint64_t floats_per_rank, uint64_t section_offset)
 {
     uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
     if (i >= (uint64_t)width * height) return;
@@ -405,11 +405,11 @@ int rt_group_denoise(rt_group* g, rt_frame* const* frames, int root, float* host
             const dim3 grid((uint32_t)((n + 255u) / 256u)), block(256);
             const float* recv = (const float*)m.recv;
             hipLaunchKernelGGL((k_group_assemble_n<4>), grid, block, 0, s, recv, (float*)g->dn_radiance, width, height, band_h,
-                (uint32_t)g->nranks, stride, (uint64_t)per_rank, (uint64_t)0);
+                (uint32_t)g->nranks, (uint64_t)per_rank, (uint64_t)0);
             hipLaunchKernelGGL((k_group_assemble_n<1>), grid, block, 0, s, recv, g->dn_depth, width, height, band_h,
-                (uint32_t)g->nranks, stride, (uint64_t)per_rank, (uint64_t)stride * 4);
+                (uint32_t)g->nranks, (uint64_t)per_rank, (uint64_t)stride * 4);
             hipLaunchKernelGGL((k_group_assemble_n<2>), grid, block, 0, s, recv, (float*)g->dn_velocity, width, height, band_h,
-                (uint32_t)g->nranks, stride, (uint64_t)per_rank, (uint64_t)stride * 5);
+                (uint32_t)g->nranks, (uint64_t)per_rank, (uint64_t)stride * 5);
             hipLaunchKernelGGL(k_denoise, grid, block, 0, s, width, height, g->dn_radiance, (const float4*)g->dn_prev_radiance,
                 (const float*)g->dn_depth, (const float*)g->dn_prev_depth, (const float2*)g->dn_velocity);
             bool ok = hipGetLastError() == hipSuccess &&

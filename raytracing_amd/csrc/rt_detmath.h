@@ -8,7 +8,7 @@
  * defined up to the builtin library of the device it runs on.  This project
  * pins ONE conformant definition -- evaluate in IEEE-754 binary64 with a fixed
  * sequence of + - * / sqrt operations, round once to binary32 -- and uses it in
- *   (1) the HIP kernels (raytracing_amd/csrc/*_kernels.h),
+ *   (1) the HIP kernels (raytracing_amd/csrc/, the ..._kernels.h files),
  *   (2) the C restatement oracle (oracle/oracle.c),
  *   (3) the builtin shim under the reference's own unmodified .cl kernels
  *       (oracle/ref_shim/cl_builtins.cpp, the reference-kernel build).

@@ -1024,22 +1024,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(STACK <= 10 
 // both: one 64-byte record holds the four grandchildren of a BVH2 node as 8-bit boxes, so a ray
 // makes ~half as many node visits and each visit costs the same four accesses.
 //
-// Exactness (see build_wide_bvh): interior boxes contain the reference's boxes and are evaluated
-// with the reference's own expression after an EXACT dequantisation, so culling is conservative;
+// Exactness (see build_wide_bvh): interior boxes contain the reference's boxes, dequantise EXACTLY, and
+// their slab distances are evaluated with one fma per plane plus an outward margin that covers the
+// difference to the reference's own expression (loop C below), so culling is conservative;
 // every leaf is re-tested with its exact fp32 bounds and the current t_max when it is reached, in the
 // reference's depth-first near/far order; shadow rays only need the boolean, which no superset can
-// change.  Rays whose 1/dir has a non-finite component (RT_SIGN_SLOW: NaNs break the monotonicity
-// argument) are not traced here: their queue indices go to `slow_list` and k_trace2 runs over
-// that list afterwards.
+// change.  Rays whose 1/dir has a non-finite or huge component (RT_SIGN_SLOW: NaNs break the
+// monotonicity argument, huge values could overflow) are not traced here: their queue indices go to
+// `slow_list` and k_trace2 runs over that list afterwards.
 //   stack entry: (ref, entry distance) as in k_trace2; up to three pushes per visit.
 #define RT_LEAF_CONT_BIT 0x40000000u      // the leaf's box has been tested: this is its 2nd+ triangle
 #define RT_W4_STACK_MAX 104               // <= 3 pending slots per wide level, <= 33 wide levels + slack
-
-RT_DEV float w4_plane(uint32_t word, int k, float cell, float origin)
-{
-    // exact: origin is a multiple of cell and |origin / cell| + 255 < 2^24 (build_wide_bvh)
-    return __builtin_fmaf((float)((word >> (8 * k)) & 0xFFu), cell, origin);
-}
 
 // Reads from the per-lane HBM spill area of the traversal stack (rare path).  Inline assembly on purpose: see the note
 // at the use in k_trace_w4.  The wait inside covers every outstanding vector-memory operation of the wave.
