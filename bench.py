@@ -325,6 +325,8 @@ def main():
     ap.add_argument("--samples-in-flight", type=int, default=0, help="RT_OPT_SAMPLES_IN_FLIGHT (0 = automatic)")
     ap.add_argument("--shade-partition", type=int, default=None, help="RT_OPT_SHADE_PARTITION (library default: 1)")
     ap.add_argument("--trace-waves", type=int, default=0, help="RT_OPT_TRACE_WAVES_PER_CU (0 = as many as fit)")
+    ap.add_argument("--trace-variant", type=int, default=None, help="RT_OPT_TRACE_VARIANT (default: the library's automatic choice)")
+    ap.add_argument("--shade-waves", type=int, default=None, help="RT_OPT_SHADE_WAVES (default: the library's, 0)")
     ap.add_argument("--debug-shared-gpu", action="store_true",
                     help="plumbing test only: all ranks share GPU 0 and gather over gloo (RCCL refuses two ranks per device)")
     ap.add_argument("--plumbing-only", action="store_true", help="no GPU: launch, rendezvous, gather and report only")
@@ -411,6 +413,10 @@ def main():
         assert lib.rt_set_option(frame, capi.OPT_OVERLAP_SHADOW, args.overlap_shadow) == 0
     if args.trace_waves:
         assert lib.rt_set_option(frame, capi.OPT_TRACE_WAVES, args.trace_waves) == 0
+    if args.trace_variant is not None:
+        assert lib.rt_set_option(frame, capi.OPT_TRACE_VARIANT, args.trace_variant) == 0
+    if args.shade_waves is not None:
+        assert lib.rt_set_option(frame, capi.OPT_SHADE_WAVES, args.shade_waves) == 0
     if args.path_state_gb > 0:
         assert lib.rt_set_option(frame, capi.OPT_PATH_STATE_LIMIT_MB, int(args.path_state_gb * 1024)) == 0
     in_flight = render.reserve_samples(max(spp_timed, spp_warm))

@@ -392,8 +392,12 @@ RT_DEV float SampleBlueNoise(const ShadeArgs& a, uint32_t px, uint32_t py, uint3
 
 // NEE: the scene asked for next-event estimation over the emissive triangles too (RT_SCENE_EMISSIVE_NEE, an opt-in
 // extension: DESIGN.md 7b); the other instances are the reference's estimator.
-template <bool FURNACE, bool BLUE, bool NEE = false>
-__global__ __launch_bounds__(RT_SHADE_BLOCK) void k_shade(DScene sc, DTile tile, ShadeArgs a)
+// WAVES: register budget as waves per SIMD the compiler must reach (RT_OPT_SHADE_WAVES).  The kernel waits on dependent
+// gathers (hit -> shading record -> material -> texels) more than it computes, so residency is what hides its latency:
+// 2 = no constraint beyond the block size, the compiler settles at 78 VGPRs = 6 waves; 7 (72 VGPRs, 7 dwords of scratch) and 8 (64 VGPRs, 21 dwords) trade a few
+// spilled values for more waves in flight.
+template <bool FURNACE, bool BLUE, bool NEE = false, int WAVES = 2>
+__global__ __launch_bounds__(RT_SHADE_BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES, 8))) void k_shade(DScene sc, DTile tile, ShadeArgs a)
 {
     const uint32_t count = a.counters->queue[a.bounce];
     // the closest-hit trace of this bounce has completed (stream order): rewind the
