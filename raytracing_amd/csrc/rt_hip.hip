@@ -952,6 +952,12 @@ int rt_frame_create(rt_ctx* ctx, const rt_frame_desc* fd, rt_frame** out)
     (void)hipSetDevice(ctx->device);
     rt_frame* f = new rt_frame();
     f->ctx = ctx;
+    {
+        // A/B runs of whole suites: RT_SHADE_WAVES_DEFAULT in the environment sets the initial RT_OPT_SHADE_WAVES
+        const char* e = getenv("RT_SHADE_WAVES_DEFAULT");
+        const long v = e ? strtol(e, nullptr, 10) : 0;
+        if (v == 7 || v == 8) f->shade_waves = (uint32_t)v;
+    }
     f->tile.width = fd->width; f->tile.height = fd->height;
     f->tile.band_h = fd->band_height; f->tile.rank = fd->tile_rank; f->tile.nranks = fd->tile_count;
     uint32_t rows = 0;

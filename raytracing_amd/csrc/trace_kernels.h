@@ -44,6 +44,7 @@ RT_DEV float hw_min(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=
 RT_DEV float hw_max(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 RT_DEV float hw_min3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 RT_DEV float hw_max3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+RT_DEV float hw_max0(float a) { float r; asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(a)); return r; }   // max(a, +0.0) without a register for the zero
 
 // Child-pair record (64 bytes, one per interior node of the reference BVH2), laid out so that the
 // six (bound - origin) * inv_dir products of a child come out of packed-fp32 instructions without
@@ -833,7 +834,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(STACK <= 10 
     uint32_t ray_i = RT_INVALID_ID;                                          // != invalid while a result is owed
     uint32_t sign_bits = 0, hit_prim = RT_INVALID_ID;
     int sp = 0;
-    uint32_t n_spills = 0;                                                   // statistics (wave-uniform): lane-steps with entries in the HBM spill area
+    // statistics: lane-steps with entries in the HBM spill area, counted wave-wide once per pass of loop C -- or, RAYMARGIN,
+    // entries written to the spill area, counted per lane where they are written (nothing in the hot loop)
+    uint32_t n_spills = 0;
     rt_v2f oxy = {0.0f, 0.0f}, ixy = oxy;                                    // origin.xy and (1/dir).xy as register pairs
     float oz = 0.0f, iz = 0.0f;
     f3 dir = F3s(0.0f);
@@ -1111,7 +1114,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RAYMARGIN ? 
     uint32_t ray_i = RT_INVALID_ID;
     uint32_t sign_bits = 0, octant3 = 0, hit_prim = RT_INVALID_ID;          // octant3: shift of this ray's entry in a node's order table
     int sp = 0;
-    uint32_t n_spills = 0;                                                   // statistics (wave-uniform): lane-steps with entries in the HBM spill area
+    // statistics: lane-steps with entries in the HBM spill area, counted wave-wide once per pass of loop C -- or, RAYMARGIN,
+    // entries written to the spill area, counted per lane where they are written (nothing in the hot loop)
+    uint32_t n_spills = 0;
     f3 org = F3s(0.0f), dir = F3s(0.0f), inv = F3s(0.0f);
     f3 dl = F3s(0.0f);                            // RAYMARGIN: the ray's slab-distance margin per axis
     float t_max = 0.0f, hit_u = 0.0f, hit_v = 0.0f;
@@ -1124,7 +1129,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RAYMARGIN ? 
         if (SHADOW)
         {
             if (sp < 2 * STACK) stack32[sp * 64 + lane] = r;
-            else vspill32[(size_t)2 * spill_base + (uint32_t)(sp - 2 * STACK)] = r;
+            else
+            {
+                vspill32[(size_t)2 * spill_base + (uint32_t)(sp - 2 * STACK)] = r;
+                if (RAYMARGIN) ++n_spills;                                   // per lane: entries written to the spill area
+            }
         }
         else
         {
@@ -1132,6 +1141,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RAYMARGIN ? 
             else
             {
                 vspill[(size_t)spill_base + (uint32_t)(sp - STACK)] = make_uint2(r, __float_as_uint(entry));
+                if (RAYMARGIN) ++n_spills;
             }
         }
         ++sp;
@@ -1382,7 +1392,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RAYMARGIN ? 
                     const float tfx = __builtin_fmaf((float)((fwx >> (8 * k)) & 0xFFu), ax, bfx);
                     const float tfy = __builtin_fmaf((float)((fwy >> (8 * k)) & 0xFFu), ay, bfy);
                     const float tfz = __builtin_fmaf((float)((fwz >> (8 * k)) & 0xFFu), az, bfz);
-                    const float entry = hw_max(hw_max3(tnx, tny, tnz), t_min);
+                    const float entry = RAYMARGIN ? hw_max0(hw_max3(tnx, tny, tnz)) : hw_max(hw_max3(tnx, tny, tnz), t_min);   // t_min = 0
                     const float exit = hw_min(hw_min3(tfx, tfy, tfz), t_max);
                     e[k] = (exit >= entry && r[k] != RT_EMPTY_REF) ? entry : INF;      // INF = slot not visited
                 }
@@ -1405,10 +1415,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RAYMARGIN ? 
                 if (e[0] < INF) ref = r[0];
                 else pop();
             }
-            n_spills += (uint32_t)__popcll(__ballot(sp > (SHADOW ? 2 * STACK : STACK)));
+            if (!RAYMARGIN) n_spills += (uint32_t)__popcll(__ballot(sp > (SHADOW ? 2 * STACK : STACK)));
         }
     }
-    if (lane == 0 && n_spills != 0u) atomicAdd(&stat_counts[0], n_spills);
+    if ((RAYMARGIN || lane == 0) && n_spills != 0u) atomicAdd(&stat_counts[0], n_spills);
     if (TIMELINE)
     {
         if (lane == 0)
