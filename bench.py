@@ -327,6 +327,8 @@ def main():
     ap.add_argument("--trace-waves", type=int, default=0, help="RT_OPT_TRACE_WAVES_PER_CU (0 = as many as fit)")
     ap.add_argument("--trace-variant", type=int, default=None, help="RT_OPT_TRACE_VARIANT (default: the library's automatic choice)")
     ap.add_argument("--shade-waves", type=int, default=None, help="RT_OPT_SHADE_WAVES (default: the library's, 0)")
+    ap.add_argument("--packet-bounces", type=lambda x: int(x, 0), default=None,
+                    help="RT_OPT_TRACE_PACKET_BOUNCES: closest | shadow << 8 bounce counts traced by the packet kernel (default 0)")
     ap.add_argument("--debug-shared-gpu", action="store_true",
                     help="plumbing test only: all ranks share GPU 0 and gather over gloo (RCCL refuses two ranks per device)")
     ap.add_argument("--plumbing-only", action="store_true", help="no GPU: launch, rendezvous, gather and report only")
@@ -417,6 +419,8 @@ def main():
         assert lib.rt_set_option(frame, capi.OPT_TRACE_VARIANT, args.trace_variant) == 0
     if args.shade_waves is not None:
         assert lib.rt_set_option(frame, capi.OPT_SHADE_WAVES, args.shade_waves) == 0
+    if args.packet_bounces is not None:
+        assert lib.rt_set_option(frame, capi.OPT_PACKET_BOUNCES, args.packet_bounces) == 0
     if args.path_state_gb > 0:
         assert lib.rt_set_option(frame, capi.OPT_PATH_STATE_LIMIT_MB, int(args.path_state_gb * 1024)) == 0
     in_flight = render.reserve_samples(max(spp_timed, spp_warm))
@@ -544,6 +548,7 @@ def main():
                                 tiling="%d interleaved %d-row bands per GPU, 1 gather" % (world, args.band_height)
                                 if world > 1 else "single tile",
                                 rays_per_step=round(total_rays / args.steps, 1), non_finite_pixels=nan_px,
+                                stack_spill_lane_steps=int(st1.stack_spills), rays_left_to_the_bvh2_kernel=int(st1.slow_rays),
                                 setup_s=round(t_setup, 2), device=name),
                     ranks=dict(render_ms_min=round(float(tmin[0].item()) * 1e3, 3), render_ms_max=round(float(tmax[1].item()) * 1e3, 3)),
                     gather=gather_info, roofline=roofline, parity=parity, cpu_baseline=baseline)

@@ -282,7 +282,9 @@ RT_DEV f3 SampleSky(const DScene& sc, f3 dir)
 // (hit_surface.cl:138,173).  Same-address L2 atomics retire at ~10 ns each on
 // MI355X, so at ~20 M rays per launch even one atomic per wave (600 k of them) was
 // the shade kernel's bottleneck; per 512-thread block it is 8x fewer.
+#ifndef RT_SHADE_BLOCK
 #define RT_SHADE_BLOCK 512
+#endif
 RT_DEV void block_append2(bool want_a, bool want_b, uint32_t* counter_a, uint32_t* counter_b, uint32_t& idx_a,
     uint32_t& idx_b)
 {
@@ -426,7 +428,14 @@ __global__ __launch_bounds__(RT_SHADE_BLOCK) __attribute__((amdgpu_waves_per_eu(
         __shared__ uint32_t s_hit[RT_SHADE_BLOCK / 64], s_miss[RT_SHADE_BLOCK / 64];
         const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
         const bool valid = i < count;
-        const bool is_miss = valid && __float_as_uint(a.hits[valid ? i : 0u].z) == RT_INVALID_ID;
+        const uint32_t prim0 = __float_as_uint(a.hits[valid ? i : 0u].z);
+        const bool is_miss = valid && prim0 == RT_INVALID_ID;
+#ifdef RT_SHADE_PREFETCH
+        // experiment: touch the 128-byte shading record of THIS entry now; the thread of this block that shades the entry
+        // after the permutation then finds the line in the CU's L1 instead of starting the gather after two barriers
+        float touched = 0.0f;
+        if (valid && !is_miss) touched = sc.tris_sh[(size_t)prim0 * 8].x;
+#endif
         const unsigned long long mh = __ballot(valid && !is_miss), mm = __ballot(is_miss);
         if (lane == 0) { s_hit[wave] = (uint32_t)__popcll(mh); s_miss[wave] = (uint32_t)__popcll(mm); }
         __syncthreads();
@@ -442,6 +451,9 @@ __global__ __launch_bounds__(RT_SHADE_BLOCK) __attribute__((amdgpu_waves_per_eu(
                 (uint16_t)threadIdx.x;
         __syncthreads();
         if (valid) i = blockIdx.x * RT_SHADE_BLOCK + s_perm[threadIdx.x];   // valid entries are a prefix of the block
+#ifdef RT_SHADE_PREFETCH
+        asm volatile("" :: "v"(touched));                                   // the touch load completes here at the latest
+#endif
     }
     const bool active = i < count;
 

@@ -1059,6 +1059,9 @@ RT_DEV uint32_t spill_load32(const uint32_t* p)
 template <int K>
 RT_DEV float w4_cell(uint32_t meta)
 {
+#ifdef RT_W4_NO_SDWA
+    return __uint_as_float(((meta >> (8 * K)) & 0xFFu) << 23);
+#endif
     uint32_t r;
     if (K == 0) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "s"(23u), "v"(meta));
     else if (K == 1) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "s"(23u), "v"(meta));

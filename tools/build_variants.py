@@ -1,0 +1,17 @@
+"""Compile-time A/B variants of librt_hip.so for experiments on the GPU box: each variant is the same source built with
+extra -D macros into raytracing_amd/variants/<name>/librt_hip.so (git-ignored like every built .so, shipped by gpurun).
+A call script swaps one in with `cp raytracing_amd/variants/<name>/librt_hip.so raytracing_amd/librt_hip.so` (the box
+works on a scratch copy of the tree).  usage: python tools/build_variants.py name=-DMACRO[,-DMACRO2] ..."""
+import os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from raytracing_amd import _build
+procs = []
+for spec in sys.argv[1:]:
+    name, macros = spec.split("=", 1)
+    d = os.path.join(ROOT, "raytracing_amd", "variants", name)
+    os.makedirs(d, exist_ok=True)
+    cmd = [_build.hipcc()] + _build.HIP_FLAGS + _build.INC + macros.split(",") + [os.path.join(_build.CSRC, "rt_hip.hip"), "-o", os.path.join(d, "librt_hip.so")]
+    procs.append((name, subprocess.Popen(cmd, cwd=ROOT, stderr=subprocess.DEVNULL)))
+for name, p in procs:
+    print(name, "ok" if p.wait() == 0 else "FAILED")
