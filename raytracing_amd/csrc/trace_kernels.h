@@ -1332,8 +1332,34 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RAYMARGIN ? 
             {
                 if (TIMELINE) ++tl_steps;
                 const float4* np = reinterpret_cast<const float4*>(node_base + (size_t)(ref << 6));
+#ifdef RT_W4_EXTRA_ACCESS
+                // sensitivity experiment (tools/build_variants.py): RT_W4_EXTRA_ACCESS more 16-byte L1 accesses per visit, to a
+                // line the visit fetches anyway (no extra miss, no extra round trip) -- what does an ACCESS cost?
+                typedef float rt_v4f __attribute__((ext_vector_type(4)));
+                rt_v4f extra_q[RT_W4_EXTRA_ACCESS];
+#pragma unroll
+                for (int x = 0; x < RT_W4_EXTRA_ACCESS; ++x)
+                    asm volatile("global_load_dwordx4 %0, %1, %2 offset:16" : "=&v"(extra_q[x]) : "v"(ref << 6), "s"(node_base));
+#endif
                 const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
                 const uint32_t meta = __float_as_uint(q0.w);
+#ifdef RT_W4_EXTRA_ACCESS
+#pragma unroll
+                for (int x = 0; x < RT_W4_EXTRA_ACCESS; ++x) asm volatile("" :: "v"(extra_q[x]), "v"(meta));   // after the wait for the record
+#endif
+#ifdef RT_W4_EXTRA_VALU
+                // ... and RT_W4_EXTRA_VALU more v_fma_f32 per visit: what does a vector instruction cost?
+                {
+                    float xa = q0.x, xb = q0.y;
+#pragma unroll
+                    for (int x = 0; x < RT_W4_EXTRA_VALU / 2; ++x)
+                    {
+                        asm volatile("v_fma_f32 %0, %0, %0, %1" : "+v"(xa) : "v"(xb));
+                        asm volatile("v_fma_f32 %0, %0, %0, %1" : "+v"(xb) : "v"(xa));
+                    }
+                    asm volatile("" :: "v"(xa), "v"(xb));
+                }
+#endif
                 const float cx = __uint_as_float((meta & 0xFFu) << 23), cy = __uint_as_float(((meta >> 8) & 0xFFu) << 23),
                             cz = __uint_as_float(((meta >> 16) & 0xFFu) << 23);
                 // near / far plane words per axis, chosen by the ray's direction sign
