@@ -326,7 +326,6 @@ def main():
     ap.add_argument("--shade-partition", type=int, default=None, help="RT_OPT_SHADE_PARTITION (library default: 1)")
     ap.add_argument("--trace-waves", type=int, default=0, help="RT_OPT_TRACE_WAVES_PER_CU (0 = as many as fit)")
     ap.add_argument("--trace-variant", type=int, default=None, help="RT_OPT_TRACE_VARIANT (default: the library's automatic choice)")
-    ap.add_argument("--shade-waves", type=int, default=None, help="RT_OPT_SHADE_WAVES (default: the library's, 0)")
     ap.add_argument("--packet-bounces", type=lambda x: int(x, 0), default=None,
                     help="RT_OPT_TRACE_PACKET_BOUNCES: closest | shadow << 8 bounce counts traced by the packet kernel (default 0)")
     ap.add_argument("--debug-shared-gpu", action="store_true",
@@ -417,8 +416,6 @@ def main():
         assert lib.rt_set_option(frame, capi.OPT_TRACE_WAVES, args.trace_waves) == 0
     if args.trace_variant is not None:
         assert lib.rt_set_option(frame, capi.OPT_TRACE_VARIANT, args.trace_variant) == 0
-    if args.shade_waves is not None:
-        assert lib.rt_set_option(frame, capi.OPT_SHADE_WAVES, args.shade_waves) == 0
     if args.packet_bounces is not None:
         assert lib.rt_set_option(frame, capi.OPT_PACKET_BOUNCES, args.packet_bounces) == 0
     if args.path_state_gb > 0:

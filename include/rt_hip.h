@@ -136,9 +136,8 @@ enum rt_option
                                    state machine with a 16 / 24 / 12 / 8, 10 / 11 entry LDS stack; 8 / 9 = k_trace2
                                    (separate wave-uniform node / triangle / refill loops) with a 10+12 / 12+12 entry
                                    stack (closest + shadow); 10 (11..14: other LDS stack sizes) = k_trace_w4 (4-wide quantized tree, exact leaf
-                                   re-test; rays it cannot take -- non-finite 1/dir -- go to k_trace2); 15 = k_trace_w4 with its
-                                   slab-distance margin computed once per ray instead of once per node visit;
-                                   5 (default) = auto: 0 below 2 M paths per launch, k_trace_w4 above.  Results are identical for every value. */
+                                   re-test; rays it cannot take -- non-finite 1/dir -- go to k_trace2); 5 (default) = auto: 0 below 2 M paths per launch, 8
+                                   above.  Results are identical for every value. */
     , RT_OPT_TRACE_WAVES_PER_CU = 8 /* persistent-grid size of the trace kernels in waves per CU (0 = as many as fit) */
     , RT_OPT_SAMPLES_IN_FLIGHT = 9  /* rt_integrate traces this many consecutive samples per pixel concurrently
                                        (1..1024, allocated at once; 0 = auto, the default: up to the largest power
@@ -177,9 +176,6 @@ enum rt_option
                                        (both sides depend on k_shade(b) only; the shadow queue is double-buffered), so the
                                        ~0.8 ms in which a launch's last rays drain does not idle the machine.
                                        0: every launch on one stream.  Results are identical for both values. */
-    , RT_OPT_SHADE_WAVES = 18      /* register budget of the production k_shade instance (random sampler, no furnace, no
-                                       extensions) in waves per SIMD: 0 (default) = the compiler's choice (6), 7 or 8 = instances
-                                       held to 72 / 64 VGPRs.  Results are identical for every value. */
     , RT_OPT_TRACE_TUNE = 12       /* k_trace2 (variants 8, 9) loop thresholds: value & 255 = lanes that must hold an
                                        interior node for a wave to stay in the node loop, value >> 8 & 255 = lanes that
                                        must wait at a triangle for another pass of the triangle loop, value >> 16 & 255 = rays a wave takes
@@ -319,9 +315,6 @@ int rt_frame_debug_timeline(rt_frame* frame, int arm, unsigned long long* out);
  * see build_wide_bvh in rt_hip.hip.  records may be NULL (count query).  Fails when the tree does not qualify. */
 int rt_debug_wide_bvh(const rt_bvh_node* nodes, uint32_t num_nodes, void* records, uint32_t capacity, uint32_t* num_records,
     uint32_t* entry_ref);
-/* ... and what rt_scene_upload keeps about ALL of its records for the per-ray slab-distance margin of k_trace_w4's
- * RT_OPT_TRACE_VARIANT 15: out9 = largest 255 * cell per axis [3], smallest frame origin [3], largest frame origin [3]. */
-int rt_debug_wide_bvh_frame_bounds(const rt_bvh_node* nodes, uint32_t num_nodes, float* out9);
 
 /* ---- kernel self-test hooks (known-answer tests of the device math):
  * evaluates fn over n inputs on the device.  fn: 0 sin, 1 cos, 2 tan, 3 pow(a,b),

@@ -62,12 +62,12 @@ EXPORTS = [
     "rt_compute_aovs", "rt_denoise", "rt_copy_history",
     "rt_frame_resolve", "rt_frame_read_radiance", "rt_frame_radiance_device_ptr", "rt_frame_sample_count",
     "rt_frame_get_stats", "rt_frame_get_profile", "rt_frame_copy_radiance", "rt_frame_debug_read_queue", "rt_frame_debug_read_hits", "rt_debug_eval",
-    "rt_debug_wide_bvh", "rt_debug_wide_bvh_frame_bounds", "rt_frame_debug_timeline",
+    "rt_debug_wide_bvh", "rt_frame_debug_timeline",
     "rt_group_create", "rt_group_unique_id", "rt_group_join", "rt_group_size", "rt_group_local_count", "rt_group_local_rank",
     "rt_group_gather_radiance", "rt_group_destroy", "rt_group_last_error", "rt_group_denoise", "rt_group_create_local",
 ]
 
-OPT_MAX_BOUNCES, OPT_WHITE_FURNACE, OPT_SAMPLER, OPT_AOV, OPT_DENOISER, OPT_DROP_LAST, OPT_PROFILE, OPT_TRACE_VARIANT, OPT_TRACE_WAVES, OPT_SAMPLES_IN_FLIGHT, OPT_SELECT_FORM_BOX, OPT_PACKET_BOUNCES, OPT_TRACE_TUNE, OPT_DEBUG_ALLOC_LIMIT, OPT_PATH_STATE_LIMIT_MB, OPT_PIPELINES, OPT_SHADE_PARTITION, OPT_OVERLAP_SHADOW, OPT_SHADE_WAVES = range(19)
+OPT_MAX_BOUNCES, OPT_WHITE_FURNACE, OPT_SAMPLER, OPT_AOV, OPT_DENOISER, OPT_DROP_LAST, OPT_PROFILE, OPT_TRACE_VARIANT, OPT_TRACE_WAVES, OPT_SAMPLES_IN_FLIGHT, OPT_SELECT_FORM_BOX, OPT_PACKET_BOUNCES, OPT_TRACE_TUNE, OPT_DEBUG_ALLOC_LIMIT, OPT_PATH_STATE_LIMIT_MB, OPT_PIPELINES, OPT_SHADE_PARTITION, OPT_OVERLAP_SHADOW = range(18)
 
 
 def load():
@@ -108,7 +108,6 @@ def load():
         "rt_frame_debug_read_hits": (i32, [vp, vp, u32]),
         "rt_debug_eval": (i32, [vp, i32, vp, vp, vp, u32]),
         "rt_debug_wide_bvh": (i32, [vp, u32, vp, u32, C.POINTER(u32), C.POINTER(u32)]),
-        "rt_debug_wide_bvh_frame_bounds": (i32, [vp, u32, vp]),
         "rt_frame_debug_timeline": (i32, [vp, i32, vp]),
         "rt_group_create": (i32, [i32, C.POINTER(i32), C.POINTER(vp)]), "rt_group_unique_id": (i32, [vp, sz]),
         "rt_group_join": (i32, [i32, i32, vp, i32, C.POINTER(vp)]), "rt_group_size": (i32, [vp]),

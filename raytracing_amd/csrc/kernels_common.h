@@ -62,11 +62,6 @@ struct DScene
     uint32_t w_entry_ref;         // wide node 0, or RT_LEAF_BIT | first triangle when the root is a leaf
     float root_min[3];
     float root_max[3];
-    // over all wide nodes (build_wide_bvh): the largest 255 * cell per axis and the range of the frame origins --
-    // what k_trace_w4<.., RAYMARGIN> bounds a ray's slab-distance margin with once per ray instead of once per node
-    float w4_k[3];
-    float w4_omin[3];
-    float w4_omax[3];
     // opt-in extensions (rt_scene_desc): nullptr / 0 = the reference's behaviour
     const uint16_t* mat_tex16;    // 6 texture indices per material (0xFFFF = none) replacing the packed 8-bit ones
     const uint32_t* emissive;     // emissive triangle indices (Scene::GetEmissiveIndices)

@@ -120,7 +120,6 @@ struct rt_frame
     bool side_active = false;          // inside rt_integrate with overlap_shadow: shadow traces go to PathPipe::side
     // where the next trace launch goes (set by rt_intersect / rt_intersect_shadow)
     hipStream_t tl_stream = nullptr; uint2* tl_spill = nullptr; uint32_t* tl_slow_list = nullptr; uint32_t tl_flavour = 0;
-    uint32_t shade_waves = 0;          // RT_OPT_SHADE_WAVES: 0 = the compiler's register budget, 7 / 8 = k_shade instances held to 72 / 64 VGPRs
     uint32_t shade_partition = 3;      // RT_OPT_SHADE_PARTITION: bit 0: k_shade sorts each block's entries hits first / misses last; bit 1: groups its output rays by octant
     uint32_t debug_alloc_limit = 0;    // RT_OPT_DEBUG_ALLOC_LIMIT: allocations above this many samples in flight fail
     // integrator state
@@ -366,12 +365,8 @@ namespace
 struct WideNode { float ox, oy, oz; uint32_t meta; uint32_t lo[3]; uint32_t hi[3]; uint32_t ref[4]; uint32_t order; uint32_t pad; };
 static_assert(sizeof(WideNode) == 64, "wide node record");
 
-// What the per-ray margin of k_trace_w4<.., RAYMARGIN> needs to know about ALL wide nodes: the largest 255 * cell
-// per axis and the range of the frame origins (all exactly representable in binary32).
-struct WideFrameBounds { float k[3] = {0, 0, 0}; float omin[3] = {0, 0, 0}; float omax[3] = {0, 0, 0}; };
-
 // false: the tree does not qualify (non-finite or non-nested bounds, child order): k_trace2 is used
-bool build_wide_bvh(const rt_bvh_node* nodes, uint32_t nn, std::vector<WideNode>& out, uint32_t& entry_ref, WideFrameBounds* fb = nullptr)
+bool build_wide_bvh(const rt_bvh_node* nodes, uint32_t nn, std::vector<WideNode>& out, uint32_t& entry_ref)
 {
     auto is_leaf = [&](uint32_t i) { return (nodes[i].num_primitives_axis >> 16) != 0; };
     out.clear();
@@ -453,14 +448,6 @@ bool build_wide_bvh(const rt_bvh_node* nodes, uint32_t nn, std::vector<WideNode>
             exps[a] = e;
         }
         r.ox = origin[0]; r.oy = origin[1]; r.oz = origin[2];
-        if (fb)
-            for (int a = 0; a < 3; ++a)
-            {
-                const float k255 = (float)std::ldexp(255.0, exps[a]);        // exact: e <= 20
-                fb->k[a] = w == 0 || k255 > fb->k[a] ? k255 : fb->k[a];
-                fb->omin[a] = w == 0 || origin[a] < fb->omin[a] ? origin[a] : fb->omin[a];
-                fb->omax[a] = w == 0 || origin[a] > fb->omax[a] ? origin[a] : fb->omax[a];
-            }
         r.meta = (uint32_t)(exps[0] + 127) | (uint32_t)(exps[1] + 127) << 8 | (uint32_t)(exps[2] + 127) << 16 |
                  (axes[0] | axes[1] << 2 | axes[2] << 4) << 24;
         for (uint32_t o = 0; o < 8; ++o)
@@ -666,8 +653,7 @@ int rt_scene_upload(rt_ctx* ctx, const rt_scene_desc* sd)
     // the 4-wide quantized tree for k_trace_w4 (optional: trees that do not qualify keep the BVH2 kernels)
     std::vector<WideNode> wide;
     uint32_t w_entry = 0;
-    WideFrameBounds wfb;
-    const bool have_wide = ctx->build_wide && (uint64_t)nt * 64 <= 0xFFFFFFFFull && build_wide_bvh(sd->nodes, nn, wide, w_entry, &wfb);
+    const bool have_wide = ctx->build_wide && (uint64_t)nt * 64 <= 0xFFFFFFFFull && build_wide_bvh(sd->nodes, nn, wide, w_entry);
     if (have_wide) rc |= dev_alloc_copy(ctx, &s.wnodes, wide.data(), wide.size() * sizeof(WideNode));
     if (rc != RT_OK) { free_scene(s); return RT_ERROR; }
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // host staging vectors die here
@@ -690,7 +676,6 @@ int rt_scene_upload(rt_ctx* ctx, const rt_scene_desc* sd)
     s.d.light_count = sd->num_lights;
     s.d.wnodes = have_wide ? (const float4*)s.wnodes : nullptr;
     s.d.w_entry_ref = w_entry;
-    for (int a = 0; a < 3; ++a) { s.d.w4_k[a] = wfb.k[a]; s.d.w4_omin[a] = wfb.omin[a]; s.d.w4_omax[a] = wfb.omax[a]; }
     s.n_wide = have_wide ? (uint32_t)wide.size() : 0u;
     s.wide_ok = have_wide;
     s.offsets32 = (uint64_t)(n_interior + 1) * 64 <= 0xFFFFFFFFull && (uint64_t)nt * 64 <= 0xFFFFFFFFull;
@@ -952,12 +937,6 @@ int rt_frame_create(rt_ctx* ctx, const rt_frame_desc* fd, rt_frame** out)
     (void)hipSetDevice(ctx->device);
     rt_frame* f = new rt_frame();
     f->ctx = ctx;
-    {
-        // A/B runs of whole suites: RT_SHADE_WAVES_DEFAULT in the environment sets the initial RT_OPT_SHADE_WAVES
-        const char* e = getenv("RT_SHADE_WAVES_DEFAULT");
-        const long v = e ? strtol(e, nullptr, 10) : 0;
-        if (v == 7 || v == 8) f->shade_waves = (uint32_t)v;
-    }
     f->tile.width = fd->width; f->tile.height = fd->height;
     f->tile.band_h = fd->band_height; f->tile.rank = fd->tile_rank; f->tile.nranks = fd->tile_count;
     uint32_t rows = 0;
@@ -1104,10 +1083,6 @@ int rt_set_option(rt_frame* f, int option, uint32_t value)
     case RT_OPT_TRACE_TUNE: f->trace_tune = value; return RT_OK;
     case RT_OPT_SHADE_PARTITION: f->shade_partition = value & 3u; return RT_OK;
     case RT_OPT_OVERLAP_SHADOW: f->overlap_shadow = value ? 1u : 0u; return RT_OK;
-    case RT_OPT_SHADE_WAVES:
-        if (value != 0 && value != 7 && value != 8) return fail(f->ctx, "rt_set_option: RT_OPT_SHADE_WAVES is 0 (default), 7 or 8");
-        f->shade_waves = value;
-        return RT_OK;
     case RT_OPT_PIPELINES:
         if (value == 0 || value > RT_MAX_PIPES) return fail(f->ctx, "rt_set_option: pipelines must be 1..RT_MAX_PIPES");
         if (value != f->pipelines)
@@ -1136,7 +1111,7 @@ int rt_set_option(rt_frame* f, int option, uint32_t value)
         return RT_OK;
     case RT_OPT_DEBUG_ALLOC_LIMIT: f->debug_alloc_limit = value; return RT_OK;
     case RT_OPT_TRACE_VARIANT:
-        if (value > 15) return fail(f->ctx, "rt_set_option: unknown trace kernel variant");
+        if (value > 14) return fail(f->ctx, "rt_set_option: unknown trace kernel variant");
         f->trace_variant = value;
         return RT_OK;
     default: return fail(f->ctx, "rt_set_option: unknown option");
@@ -1222,7 +1197,7 @@ void launch_trace2(rt_frame* f, const float4* o4, const float4* d4, const float4
 }
 
 // k_trace_w4 over the 4-wide quantized tree, then k_trace2 over the (normally empty) list of rays it left out
-template <bool SHADOW, int STACK, bool RAYMARGIN = false>
+template <bool SHADOW, int STACK>
 void launch_trace_w4(rt_frame* f, const float4* o4, const float4* d4, const float4* iv4, const uint32_t* count)
 {
     rt_ctx* ctx = f->ctx;
@@ -1241,7 +1216,7 @@ void launch_trace_w4(rt_frame* f, const float4* o4, const float4* d4, const floa
             &f->p->counters->slow_count[s], &f->p->counters->stack_spills, &f->p->counters->tl_start[f->timeline_bounce & 63u],
             f->timeline_bounce & 63u);
     else
-        hipLaunchKernelGGL((k_trace_w4<SHADOW, STACK, false, RAYMARGIN>), dim3(blocks), dim3(64), 0, f->tl_stream, ctx->scene.d, o4, d4, iv4, count,
+        hipLaunchKernelGGL((k_trace_w4<SHADOW, STACK>), dim3(blocks), dim3(64), 0, f->tl_stream, ctx->scene.d, o4, d4, iv4, count,
             &f->p->counters->head[s][0], SHADOW ? (float4*)nullptr : f->p->hits, SHADOW ? f->p->rlog : (float4*)nullptr, f->log_stride,
             f->tl_spill, tune, f->tl_slow_list, &f->p->counters->slow_count[s], &f->p->counters->stack_spills, no_timeline, 0u);
     // The follow-up over the (normally empty) slow list: one wave per CU with a one-entry LDS stack (the rest of the stack
@@ -1288,16 +1263,16 @@ void launch_trace(rt_frame* f, const float4* o4, const float4* d4, const float4*
         // 4214 (k_trace) / 4400 (k_trace2) / 5042 (k_trace_w4) Mrays/s on the headline workload
         // (profiles/r02_w4_tune_sweep.log)
         uint64_t paths = (uint64_t)f->p->chunk_count * (f->p->cur_slots ? f->p->cur_slots : 1u);
-        // (RT_TRACE_AUTO_WIDE_VARIANT in the environment picks another k_trace_w4 instance for A/B runs of the whole suite)
+        // (RT_TRACE_AUTO_WIDE_VARIANT in the environment picks another k_trace_w4 instance: A/B runs of whole suites)
         static const uint32_t wide_variant = []() -> uint32_t
         {
             const char* e = getenv("RT_TRACE_AUTO_WIDE_VARIANT");
             const long v = e ? strtol(e, nullptr, 10) : 0;
-            return v >= 10 && v <= 15 ? (uint32_t)v : 10u;
+            return v >= 10 && v <= 14 ? (uint32_t)v : 10u;
         }();
         variant = paths >= 2000000ull ? wide_variant : 0u;
     }
-    if (variant >= 10u && variant <= 15u && !ctx->scene.wide_ok) variant = 8u;
+    if (variant >= 10u && variant <= 14u && !ctx->scene.wide_ok) variant = 8u;
     if ((variant == 8u || variant == 9u) && !ctx->scene.offsets32) variant = 3u;
     switch (variant)
     {
@@ -1321,7 +1296,6 @@ void launch_trace(rt_frame* f, const float4* o4, const float4* d4, const float4*
     case 12: launch_trace_w4<SHADOW, 13>(f, o4, d4, iv4, count); break;
     case 13: launch_trace_w4<SHADOW, 11>(f, o4, d4, iv4, count); break;
     case 14: launch_trace_w4<SHADOW, 10>(f, o4, d4, iv4, count); break;
-    case 15: launch_trace_w4<SHADOW, 12, true>(f, o4, d4, iv4, count); break;
     default: launch_trace_sm<SHADOW, 12>(f, o4, d4, iv4, count); break;
     }
 }
@@ -1452,10 +1426,6 @@ int rt_shade(rt_frame* f, uint32_t bounce)              // ShadeMissedRays + Sha
     else if (f->white_furnace && blue) RT_LAUNCH_SHADE(true, true, false);
     else if (f->white_furnace) RT_LAUNCH_SHADE(true, false, false);
     else if (blue) RT_LAUNCH_SHADE(false, true, false);
-    else if (f->shade_waves == 7u)
-        hipLaunchKernelGGL((k_shade<false, false, false, 7>), dim3(blocks), dim3(RT_SHADE_BLOCK), 0, f->p->stream, ctx->scene.d, f->tile, a);
-    else if (f->shade_waves == 8u)
-        hipLaunchKernelGGL((k_shade<false, false, false, 8>), dim3(blocks), dim3(RT_SHADE_BLOCK), 0, f->p->stream, ctx->scene.d, f->tile, a);
     else RT_LAUNCH_SHADE(false, false, false);
 #undef RT_LAUNCH_SHADE
     HIPCHK(ctx, hipGetLastError());
@@ -1809,18 +1779,6 @@ int rt_frame_debug_timeline(rt_frame* f, int arm, unsigned long long* out /* [64
         out[b * 6 + 5] = h[256 + b] & 0xFFFFFFull;      // ... and its steps
     }
     for (int b = 0; b < 64; ++b) out[384 + b] = h[320 + b];   // waves that left in the b-th 25 us after the queue ran dry
-    return RT_OK;
-}
-
-int rt_debug_wide_bvh_frame_bounds(const rt_bvh_node* nodes, uint32_t num_nodes, float* out9)
-{
-    if (!nodes || num_nodes == 0 || !out9) return fail(nullptr, "rt_debug_wide_bvh_frame_bounds: NULL argument");
-    std::vector<WideNode> wide;
-    uint32_t entry = 0;
-    WideFrameBounds fb;
-    if (!build_wide_bvh(nodes, num_nodes, wide, entry, &fb))
-        return fail(nullptr, "rt_debug_wide_bvh_frame_bounds: the tree does not qualify for the 4-wide layout");
-    for (int a = 0; a < 3; ++a) { out9[a] = fb.k[a]; out9[3 + a] = fb.omin[a]; out9[6 + a] = fb.omax[a]; }
     return RT_OK;
 }
 

@@ -282,7 +282,7 @@ RT_DEV f3 SampleSky(const DScene& sc, f3 dir)
 // (hit_surface.cl:138,173).  Same-address L2 atomics retire at ~10 ns each on
 // MI355X, so at ~20 M rays per launch even one atomic per wave (600 k of them) was
 // the shade kernel's bottleneck; per 512-thread block it is 8x fewer.
-#ifndef RT_SHADE_BLOCK
+#ifndef RT_SHADE_BLOCK            // 256 measured no different (profiles/r02_variants_ab_call41.log)
 #define RT_SHADE_BLOCK 512
 #endif
 RT_DEV void block_append2(bool want_a, bool want_b, uint32_t* counter_a, uint32_t* counter_b, uint32_t& idx_a,
@@ -394,12 +394,8 @@ RT_DEV float SampleBlueNoise(const ShadeArgs& a, uint32_t px, uint32_t py, uint3
 
 // NEE: the scene asked for next-event estimation over the emissive triangles too (RT_SCENE_EMISSIVE_NEE, an opt-in
 // extension: DESIGN.md 7b); the other instances are the reference's estimator.
-// WAVES: register budget as waves per SIMD the compiler must reach (RT_OPT_SHADE_WAVES).  The kernel waits on dependent
-// gathers (hit -> shading record -> material -> texels) more than it computes, so residency is what hides its latency:
-// 2 = no constraint beyond the block size, the compiler settles at 78 VGPRs = 6 waves; 7 (72 VGPRs, 7 dwords of scratch) and 8 (64 VGPRs, 21 dwords) trade a few
-// spilled values for more waves in flight.
-template <bool FURNACE, bool BLUE, bool NEE = false, int WAVES = 2>
-__global__ __launch_bounds__(RT_SHADE_BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES, 8))) void k_shade(DScene sc, DTile tile, ShadeArgs a)
+template <bool FURNACE, bool BLUE, bool NEE = false>
+__global__ __launch_bounds__(RT_SHADE_BLOCK) void k_shade(DScene sc, DTile tile, ShadeArgs a)
 {
     const uint32_t count = a.counters->queue[a.bounce];
 #ifdef RT_SHADE_LDS_PAD
@@ -432,14 +428,7 @@ __global__ __launch_bounds__(RT_SHADE_BLOCK) __attribute__((amdgpu_waves_per_eu(
         __shared__ uint32_t s_hit[RT_SHADE_BLOCK / 64], s_miss[RT_SHADE_BLOCK / 64];
         const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
         const bool valid = i < count;
-        const uint32_t prim0 = __float_as_uint(a.hits[valid ? i : 0u].z);
-        const bool is_miss = valid && prim0 == RT_INVALID_ID;
-#ifdef RT_SHADE_PREFETCH
-        // experiment: touch the 128-byte shading record of THIS entry now; the thread of this block that shades the entry
-        // after the permutation then finds the line in the CU's L1 instead of starting the gather after two barriers
-        float touched = 0.0f;
-        if (valid && !is_miss) touched = sc.tris_sh[(size_t)prim0 * 8].x;
-#endif
+        const bool is_miss = valid && __float_as_uint(a.hits[valid ? i : 0u].z) == RT_INVALID_ID;
         const unsigned long long mh = __ballot(valid && !is_miss), mm = __ballot(is_miss);
         if (lane == 0) { s_hit[wave] = (uint32_t)__popcll(mh); s_miss[wave] = (uint32_t)__popcll(mm); }
         __syncthreads();
@@ -455,9 +444,6 @@ __global__ __launch_bounds__(RT_SHADE_BLOCK) __attribute__((amdgpu_waves_per_eu(
                 (uint16_t)threadIdx.x;
         __syncthreads();
         if (valid) i = blockIdx.x * RT_SHADE_BLOCK + s_perm[threadIdx.x];   // valid entries are a prefix of the block
-#ifdef RT_SHADE_PREFETCH
-        asm volatile("" :: "v"(touched));                                   // the touch load completes here at the latest
-#endif
     }
     const bool active = i < count;
 
@@ -501,7 +487,8 @@ __global__ __launch_bounds__(RT_SHADE_BLOCK) __attribute__((amdgpu_waves_per_eu(
 
             const float4* tp = sc.tris_sh + (size_t)prim * 8;
 #ifdef RT_SHADE_EXTRA_ACCESS
-            // sensitivity experiment (tools/build_variants.py): more 16-byte accesses to the record's own line per surface hit
+            // sensitivity experiment (tools/build_variants.py, profiles/r02_shade_sensitivity_access_valu_residency.log): more
+            // 16-byte accesses to the record's own line per surface hit
             typedef float rt_v4f __attribute__((ext_vector_type(4)));
             rt_v4f extra_q[RT_SHADE_EXTRA_ACCESS];
 #pragma unroll
@@ -514,7 +501,7 @@ __global__ __launch_bounds__(RT_SHADE_BLOCK) __attribute__((amdgpu_waves_per_eu(
 #endif
 #ifdef RT_SHADE_EXTRA_VALU
             {
-                float xa = q0.x, xb = q0.y;
+                float xa = q0.x, xb = q0.y;                                      // ... more v_fma_f32 per surface hit
 #pragma unroll
                 for (int x = 0; x < RT_SHADE_EXTRA_VALU / 2; ++x)
                 {

@@ -44,7 +44,6 @@ RT_DEV float hw_min(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=
 RT_DEV float hw_max(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 RT_DEV float hw_min3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 RT_DEV float hw_max3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
-RT_DEV float hw_max0(float a) { float r; asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(a)); return r; }   // max(a, +0.0) without a register for the zero
 
 // Child-pair record (64 bytes, one per interior node of the reference BVH2), laid out so that the
 // six (bound - origin) * inv_dir products of a child come out of packed-fp32 instructions without
@@ -834,9 +833,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(STACK <= 10 
     uint32_t ray_i = RT_INVALID_ID;                                          // != invalid while a result is owed
     uint32_t sign_bits = 0, hit_prim = RT_INVALID_ID;
     int sp = 0;
-    // statistics: lane-steps with entries in the HBM spill area, counted wave-wide once per pass of loop C -- or, RAYMARGIN,
-    // entries written to the spill area, counted per lane where they are written (nothing in the hot loop)
-    uint32_t n_spills = 0;
+    uint32_t n_spills = 0;                                                   // statistics (wave-uniform): lane-steps with entries in the HBM spill area
     rt_v2f oxy = {0.0f, 0.0f}, ixy = oxy;                                    // origin.xy and (1/dir).xy as register pairs
     float oz = 0.0f, iz = 0.0f;
     f3 dir = F3s(0.0f);
@@ -1054,27 +1051,8 @@ RT_DEV uint32_t spill_load32(const uint32_t* p)
     return v;
 }
 
-// The biased exponent in byte K of a wide node's meta word as the power of two it stands for (the cell size along one
-// axis): one SDWA shift instead of shift + mask.
-template <int K>
-RT_DEV float w4_cell(uint32_t meta)
-{
-#ifdef RT_W4_NO_SDWA
-    return __uint_as_float(((meta >> (8 * K)) & 0xFFu) << 23);
-#endif
-    uint32_t r;
-    if (K == 0) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "s"(23u), "v"(meta));
-    else if (K == 1) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "s"(23u), "v"(meta));
-    else asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "s"(23u), "v"(meta));
-    return __uint_as_float(r);
-}
-
-// RAYMARGIN (RT_OPT_TRACE_VARIANT 15): the outward margin of the one-fma slab distances is computed once per RAY from
-// bounds over all wide nodes instead of once per node visit, and the cell sizes are decoded with one SDWA shift each:
-// 9 vector instructions fewer per visit (of ~126) for 3 more live registers (72 VGPRs: still 7 waves per SIMD, no
-// scratch; a per-ray org * inv for a one-fma plane offset would save 3 more but needs 76 -- one wave less).  See loop C.
-template <bool SHADOW, int STACK, bool TIMELINE = false, bool RAYMARGIN = false>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RAYMARGIN ? 7 : 4, 8))) void k_trace_w4(DScene sc, const float4* __restrict__ o4, const float4* __restrict__ d4,
+template <bool SHADOW, int STACK, bool TIMELINE = false>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_trace_w4(DScene sc, const float4* __restrict__ o4, const float4* __restrict__ d4,
     const float4* __restrict__ iv4, const uint32_t* __restrict__ count_ptr, uint32_t* __restrict__ heads,
     float4* __restrict__ hits, float4* __restrict__ rlog, uint32_t log_stride, uint2* __restrict__ spill, uint32_t tune,
     uint32_t* __restrict__ slow_list, uint32_t* __restrict__ slow_count, uint32_t* __restrict__ stat_counts /* [0] spills, [1] slow rays */,
@@ -1117,11 +1095,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RAYMARGIN ? 
     uint32_t ray_i = RT_INVALID_ID;
     uint32_t sign_bits = 0, octant3 = 0, hit_prim = RT_INVALID_ID;          // octant3: shift of this ray's entry in a node's order table
     int sp = 0;
-    // statistics: lane-steps with entries in the HBM spill area, counted wave-wide once per pass of loop C -- or, RAYMARGIN,
-    // entries written to the spill area, counted per lane where they are written (nothing in the hot loop)
-    uint32_t n_spills = 0;
+    uint32_t n_spills = 0;                                                   // statistics (wave-uniform): lane-steps with entries in the HBM spill area
     f3 org = F3s(0.0f), dir = F3s(0.0f), inv = F3s(0.0f);
-    f3 dl = F3s(0.0f);                            // RAYMARGIN: the ray's slab-distance margin per axis
     float t_max = 0.0f, hit_u = 0.0f, hit_v = 0.0f;
     uint32_t payload = 0, log_entry = 0;
     const float t_min = 0.0f;
@@ -1132,11 +1107,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RAYMARGIN ? 
         if (SHADOW)
         {
             if (sp < 2 * STACK) stack32[sp * 64 + lane] = r;
-            else
-            {
-                vspill32[(size_t)2 * spill_base + (uint32_t)(sp - 2 * STACK)] = r;
-                if (RAYMARGIN) ++n_spills;                                   // per lane: entries written to the spill area
-            }
+            else vspill32[(size_t)2 * spill_base + (uint32_t)(sp - 2 * STACK)] = r;
         }
         else
         {
@@ -1144,7 +1115,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RAYMARGIN ? 
             else
             {
                 vspill[(size_t)spill_base + (uint32_t)(sp - STACK)] = make_uint2(r, __float_as_uint(entry));
-                if (RAYMARGIN) ++n_spills;
             }
         }
         ++sp;
@@ -1215,22 +1185,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RAYMARGIN ? 
                     // RT_SIGN_SLOW, or an origin so far out that the one-fma slab distances of loop C could overflow
                     slow = (sign_bits & RT_SIGN_SLOW) != 0u ||
                            !(hw_max3(__builtin_fabsf(org.x), __builtin_fabsf(org.y), __builtin_fabsf(org.z)) < 0x1p29f);
-                    if (RAYMARGIN)
-                    {
-                        // M >= 255 |a| + |b| for EVERY wide node (a, b: loop C): 255 * cell <= w4_k, the node's frame
-                        // origin lies in [w4_omin, w4_omax], so |origin - org| <= max of the two ends.  The factor
-                        // 1 + 2^-10 covers the roundings of this very computation (4 u) and of b (2 u).  Finite: w4_k < 2^28,
-                        // |origin| < 2^28 (build_wide_bvh), |org| < 2^29 (above), |inv| < 2^96 (ray_inverse).
-                        const float dx = hw_max(__builtin_fabsf(sc.w4_omin[0] - org.x), __builtin_fabsf(sc.w4_omax[0] - org.x));
-                        const float dy = hw_max(__builtin_fabsf(sc.w4_omin[1] - org.y), __builtin_fabsf(sc.w4_omax[1] - org.y));
-                        const float dz = hw_max(__builtin_fabsf(sc.w4_omin[2] - org.z), __builtin_fabsf(sc.w4_omax[2] - org.z));
-                        const float Mx = (sc.w4_k[0] + dx) * __builtin_fabsf(inv.x);
-                        const float My = (sc.w4_k[1] + dy) * __builtin_fabsf(inv.y);
-                        const float Mz = (sc.w4_k[2] + dz) * __builtin_fabsf(inv.z);
-                        // dl = 8 u M (1 + 2^-10) + 2^-120, u = 2^-24: what loop C needs is 6.1 u M (see there)
-                        dl = F3(__builtin_fmaf(Mx, 0x1.004p-21f, 0x1p-120f), __builtin_fmaf(My, 0x1.004p-21f, 0x1p-120f),
-                                __builtin_fmaf(Mz, 0x1.004p-21f, 0x1p-120f));
-                    }
                     if (!slow) ref = sc.w_entry_ref;
                 }
                 // rays this kernel does not take: hand their queue index to the BVH2 kernel's list
@@ -1333,8 +1287,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RAYMARGIN ? 
                 if (TIMELINE) ++tl_steps;
                 const float4* np = reinterpret_cast<const float4*>(node_base + (size_t)(ref << 6));
 #ifdef RT_W4_EXTRA_ACCESS
-                // sensitivity experiment (tools/build_variants.py): RT_W4_EXTRA_ACCESS more 16-byte L1 accesses per visit, to a
-                // line the visit fetches anyway (no extra miss, no extra round trip) -- what does an ACCESS cost?
+                // sensitivity experiment (tools/build_variants.py, profiles/r02_trace_sensitivity_access_vs_valu.log):
+                // RT_W4_EXTRA_ACCESS more 16-byte L1 accesses per visit, to a line the visit fetches anyway (no extra miss, no
+                // extra round trip) -- what does an ACCESS cost?
                 typedef float rt_v4f __attribute__((ext_vector_type(4)));
                 rt_v4f extra_q[RT_W4_EXTRA_ACCESS];
 #pragma unroll
@@ -1380,36 +1335,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RAYMARGIN ? 
                 // MORE.  Leaves are re-tested with the reference's expression when they are reached, as before.
                 // No overflow: |inv| < 2^96 (ray_inverse: other rays are RT_SIGN_SLOW), cell <= 2^20 and |origin| < 2^28
                 // (build_wide_bvh), |org| < 2^29 (checked when the ray starts) => |q a| + |b| < 2^127.
-                float ax, ay, az, bnx, bny, bnz, bfx, bfy, bfz;
-                if (RAYMARGIN)
-                {
-                    // The same a and b as below, with the margin dl computed once per ray (A) from
-                    // M_ray = (w4_k + max |origin - org|) |inv| >= 255 |a| + |b| = M of EVERY node.  With x = origin - org,
-                    // b = x inv (1+e1)(1+e2), bn = (b - dl)(1+e3), F = (q a + bn)(1+e4), |e| <= u:
-                    //   F - (T - dl) = q a e4 + (b - x inv) + (b - dl) e3 + bn e4,  |.| <= u (255 |a| + 4 |b|) + 2 u dl <= 4 u M + 2 u dl,
-                    // and |E - T| <= 2.1 u M, so dl (1 - 2 u) >= 6.1 u M keeps F_near <= E_near (F_far >= E_far likewise);
-                    // dl = 8 u M_ray (1 + 2^-10) + 2^-120 (results in the denormal range) has 30 % to spare.
-                    // tests/test_wide_bvh.py reproduces this arithmetic bit for bit on the host and checks the two inequalities.
-                    // The margin is 2^-21 of the scene's extent seen from the ray's origin instead of 2^-20 of the node's
-                    // distance: below a tenth of a cell of the finest nodes, so the superset of visited nodes hardly grows --
-                    // for 9 vector instructions fewer per visit.
-                    ax = w4_cell<0>(meta) * inv.x; ay = w4_cell<1>(meta) * inv.y; az = w4_cell<2>(meta) * inv.z;
-                    const float bx = (q0.x - org.x) * inv.x, by = (q0.y - org.y) * inv.y, bz = (q0.z - org.z) * inv.z;
-                    bnx = bx - dl.x; bfx = bx + dl.x;
-                    bny = by - dl.y; bfy = by + dl.y;
-                    bnz = bz - dl.z; bfz = bz + dl.z;
-                }
-                else
-                {
-                    ax = cx * inv.x; ay = cy * inv.y; az = cz * inv.z;
-                    const float bx = (q0.x - org.x) * inv.x, by = (q0.y - org.y) * inv.y, bz = (q0.z - org.z) * inv.z;
-                    const float mx = __builtin_fmaf(255.0f, __builtin_fabsf(ax), __builtin_fabsf(bx)) + 0x1p-100f;
-                    const float my = __builtin_fmaf(255.0f, __builtin_fabsf(ay), __builtin_fabsf(by)) + 0x1p-100f;
-                    const float mz = __builtin_fmaf(255.0f, __builtin_fabsf(az), __builtin_fabsf(bz)) + 0x1p-100f;
-                    bnx = __builtin_fmaf(-0x1p-20f, mx, bx); bfx = __builtin_fmaf(0x1p-20f, mx, bx);
-                    bny = __builtin_fmaf(-0x1p-20f, my, by); bfy = __builtin_fmaf(0x1p-20f, my, by);
-                    bnz = __builtin_fmaf(-0x1p-20f, mz, bz); bfz = __builtin_fmaf(0x1p-20f, mz, bz);
-                }
+                const float ax = cx * inv.x, ay = cy * inv.y, az = cz * inv.z;
+                const float bx = (q0.x - org.x) * inv.x, by = (q0.y - org.y) * inv.y, bz = (q0.z - org.z) * inv.z;
+                const float mx = __builtin_fmaf(255.0f, __builtin_fabsf(ax), __builtin_fabsf(bx)) + 0x1p-100f;
+                const float my = __builtin_fmaf(255.0f, __builtin_fabsf(ay), __builtin_fabsf(by)) + 0x1p-100f;
+                const float mz = __builtin_fmaf(255.0f, __builtin_fabsf(az), __builtin_fabsf(bz)) + 0x1p-100f;
+                const float bnx = __builtin_fmaf(-0x1p-20f, mx, bx), bfx = __builtin_fmaf(0x1p-20f, mx, bx);
+                const float bny = __builtin_fmaf(-0x1p-20f, my, by), bfy = __builtin_fmaf(0x1p-20f, my, by);
+                const float bnz = __builtin_fmaf(-0x1p-20f, mz, bz), bfz = __builtin_fmaf(0x1p-20f, mz, bz);
                 uint32_t r[4] = {__float_as_uint(q2.z), __float_as_uint(q2.w), __float_as_uint(q3.x), __float_as_uint(q3.y)};
                 float e[4];
 #pragma unroll
@@ -1421,7 +1354,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RAYMARGIN ? 
                     const float tfx = __builtin_fmaf((float)((fwx >> (8 * k)) & 0xFFu), ax, bfx);
                     const float tfy = __builtin_fmaf((float)((fwy >> (8 * k)) & 0xFFu), ay, bfy);
                     const float tfz = __builtin_fmaf((float)((fwz >> (8 * k)) & 0xFFu), az, bfz);
-                    const float entry = RAYMARGIN ? hw_max0(hw_max3(tnx, tny, tnz)) : hw_max(hw_max3(tnx, tny, tnz), t_min);   // t_min = 0
+                    const float entry = hw_max(hw_max3(tnx, tny, tnz), t_min);
                     const float exit = hw_min(hw_min3(tfx, tfy, tfz), t_max);
                     e[k] = (exit >= entry && r[k] != RT_EMPTY_REF) ? entry : INF;      // INF = slot not visited
                 }
@@ -1444,10 +1377,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RAYMARGIN ? 
                 if (e[0] < INF) ref = r[0];
                 else pop();
             }
-            if (!RAYMARGIN) n_spills += (uint32_t)__popcll(__ballot(sp > (SHADOW ? 2 * STACK : STACK)));
+            n_spills += (uint32_t)__popcll(__ballot(sp > (SHADOW ? 2 * STACK : STACK)));
         }
     }
-    if ((RAYMARGIN || lane == 0) && n_spills != 0u) atomicAdd(&stat_counts[0], n_spills);
+    if (lane == 0 && n_spills != 0u) atomicAdd(&stat_counts[0], n_spills);
     if (TIMELINE)
     {
         if (lane == 0)
