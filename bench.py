@@ -44,6 +44,8 @@ Extra objects on the JSON line:
                ceilings from tools/issue_microbench.hip); `bound` = the unit nearest its
                ceiling, `frac` <= 1 by construction.  Launch duration and rays per launch
                are measured live (HIP events on the library's stream).
+               `sensitivity`: measured change of the kernel's time for one more access / more vector
+               instructions per node visit / fewer resident waves (profiles/r02_kernel_sensitivity.json).
   parity       at N = 1: the frame the cpu_baseline leg renders with the reference's own
                kernels is rendered again on the GPU (same samples, outside the timed
                region) and compared: bit_identical, rel_l2, non-finite pixels on both sides.
@@ -67,6 +69,7 @@ import numpy as np  # noqa: E402
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 LIGHT = ((-0.6, -1.5, 3.5), (15.0, 10.0, 5.0))   # reference main.cpp:58
 COUNTERS_FILE = os.path.join(ROOT, "profiles", "r02_trace_counters.json")
+SENSITIVITY_FILE = os.path.join(ROOT, "profiles", "r02_kernel_sensitivity.json")
 
 
 # BASELINE.json configs (index = position in "configs"); config 1 is the CPU plumbing case.
@@ -290,6 +293,14 @@ def roofline_object(args, world, agg, prof, per_ray, spp_timed):
                units=units, counters_per_launch=k.get("per_launch"), source="profiles/r02_trace_counters.json (rocprofv3 --pmc passes of this "
                "workload at N = 1, round 2; ceilings: profiles/r02_issue_microbench.log)",
                hbm_counter=dict(GBs=k.get("hbm_GBs"), peak_GBs=HBM_PEAK_GBS, frac=k.get("hbm_frac")))
+    try:
+        # how the kernel's time responds to one more L1 access / 16 more vector instructions per node visit / fewer resident
+        # waves (measured with compile-time variants; only meaningful for the headline workload it was measured on)
+        if args.config == 4:
+            sens = json.load(open(SENSITIVITY_FILE))
+            out["sensitivity"] = dict(sens["k_trace_w4_closest"], source="profiles/r02_kernel_sensitivity.json (gpurun calls 43 / 44, round 2)")
+    except Exception:
+        pass
     return out
 
 
@@ -319,11 +330,11 @@ def main():
     ap.add_argument("--path-state-gb", type=float, default=0.0,
                     help="cap the per-path device buffers (ray queues + radiance log) at this many GiB per GPU: the tile is then "
                          "rendered chunk by chunk (RT_OPT_PATH_STATE_LIMIT_MB); 0 = the library's own rule (up to half of the HBM)")
-    ap.add_argument("--pipelines", type=int, default=None, help="RT_OPT_PIPELINES (library default: 2)")
+    ap.add_argument("--pipelines", type=int, default=None, help="RT_OPT_PIPELINES (library default: 1)")
     ap.add_argument("--trace-tune", type=lambda x: int(x, 0), default=0, help="RT_OPT_TRACE_TUNE (0 = defaults)")
     ap.add_argument("--overlap-shadow", type=int, default=None, help="RT_OPT_OVERLAP_SHADOW (default: the library's, 1)")
     ap.add_argument("--samples-in-flight", type=int, default=0, help="RT_OPT_SAMPLES_IN_FLIGHT (0 = automatic)")
-    ap.add_argument("--shade-partition", type=int, default=None, help="RT_OPT_SHADE_PARTITION (library default: 1)")
+    ap.add_argument("--shade-partition", type=int, default=None, help="RT_OPT_SHADE_PARTITION (library default: 3)")
     ap.add_argument("--trace-waves", type=int, default=0, help="RT_OPT_TRACE_WAVES_PER_CU (0 = as many as fit)")
     ap.add_argument("--trace-variant", type=int, default=None, help="RT_OPT_TRACE_VARIANT (default: the library's automatic choice)")
     ap.add_argument("--packet-bounces", type=lambda x: int(x, 0), default=None,
