@@ -62,7 +62,7 @@ EXPORTS = [
     "rt_compute_aovs", "rt_denoise", "rt_copy_history",
     "rt_frame_resolve", "rt_frame_read_radiance", "rt_frame_radiance_device_ptr", "rt_frame_sample_count",
     "rt_frame_get_stats", "rt_frame_get_profile", "rt_frame_copy_radiance", "rt_frame_debug_read_queue", "rt_frame_debug_read_hits", "rt_debug_eval",
-    "rt_debug_wide_bvh", "rt_debug_wide_bvh_ex", "rt_frame_debug_timeline",
+    "rt_debug_wide_bvh", "rt_frame_debug_timeline",
     "rt_group_create", "rt_group_unique_id", "rt_group_join", "rt_group_size", "rt_group_local_count", "rt_group_local_rank",
     "rt_group_gather_radiance", "rt_group_destroy", "rt_group_last_error", "rt_group_denoise", "rt_group_create_local",
 ]
@@ -108,7 +108,6 @@ def load():
         "rt_frame_debug_read_hits": (i32, [vp, vp, u32]),
         "rt_debug_eval": (i32, [vp, i32, vp, vp, vp, u32]),
         "rt_debug_wide_bvh": (i32, [vp, u32, vp, u32, C.POINTER(u32), C.POINTER(u32)]),
-        "rt_debug_wide_bvh_ex": (i32, [vp, u32, u32, vp, u32, C.POINTER(u32), C.POINTER(u32)]),
         "rt_frame_debug_timeline": (i32, [vp, i32, vp]),
         "rt_group_create": (i32, [i32, C.POINTER(i32), C.POINTER(vp)]), "rt_group_unique_id": (i32, [vp, sz]),
         "rt_group_join": (i32, [i32, i32, vp, i32, C.POINTER(vp)]), "rt_group_size": (i32, [vp]),
@@ -156,10 +155,6 @@ class Context:
 
     def set_treelet_nodes(self, n):
         _check(self.lib, self.handle, self.lib.rt_ctx_set_option(self.handle, 0, n))
-
-    def set_wide_bvh(self, mode):
-        """RT_CTX_OPT_WIDE_BVH: 0 = BVH2 records only, 1 = largest-area-first collapse (default), 2 = two BVH2 levels per record."""
-        _check(self.lib, self.handle, self.lib.rt_ctx_set_option(self.handle, 1, mode))
 
     def finish(self):
         _check(self.lib, self.handle, self.lib.rt_finish(self.handle))

@@ -40,7 +40,7 @@ struct rt_ctx
     std::string error;
     Scene scene;
     uint32_t treelet_nodes = 7;   // RT_CTX_OPT_TREELET_NODES
-    uint32_t build_wide = 1;      // RT_CTX_OPT_WIDE_BVH: 0 none, 1 largest-area-first collapse, 2 two-level fold
+    uint32_t build_wide = 1;      // RT_CTX_OPT_WIDE_BVH
     uint8_t* blue_noise = nullptr;   // sobol[65536] | scramblingTile[131072] | rankingTile[131072]
     float* gamma_lut = nullptr;      // pow(byte / 255, 2.2f), 256 entries (k_fill_gamma_lut)
 };
@@ -271,12 +271,7 @@ int rt_ctx_set_option(rt_ctx* ctx, int option, uint32_t value)
         ctx->treelet_nodes = value;
         return RT_OK;
     }
-    if (option == RT_CTX_OPT_WIDE_BVH)
-    {
-        if (value > 2) return fail(ctx, "rt_ctx_set_option: RT_CTX_OPT_WIDE_BVH is 0, 1 or 2");
-        ctx->build_wide = value;
-        return RT_OK;
-    }
+    if (option == RT_CTX_OPT_WIDE_BVH) { ctx->build_wide = value ? 1u : 0u; return RT_OK; }
     return fail(ctx, "rt_ctx_set_option: unknown option");
 }
 
@@ -360,26 +355,18 @@ namespace
 //    (bvh.hpp:73, checked below), so a leaf's box passing implies that all its ancestors' boxes
 //    pass: the reference tests the triangles of a leaf iff that leaf's own box test passes at that
 //    point of the traversal -- which is exactly what the kernel evaluates.
-// Record: q0 = (origin.xyz, meta)   meta = ex | ey << 8 | ez << 16 | slots << 24 (biased exponents of
-//                                          the cell sizes; slots = number of filled slots, informational)
+// Record: q0 = (origin.xyz, meta)   meta = ex | ey << 8 | ez << 16 | axes << 24 (biased exponents of
+//                                          the cell sizes; axes = axis0 | axisA << 2 | axisB << 4)
 //         q1 = (lo.x, lo.y, lo.z, hi.x)    one byte per slot in every dword
 //         q2 = (hi.y, hi.z, ref0, ref1)    ref = wide node index | RT_LEAF_BIT + first triangle | RT_EMPTY_REF
-//         q3 = (ref2, ref3, order[0], order[1])  the reference's visit order of the slots, per direction-sign octant o (bit a set =
-//                                          direction negative along axis a): byte o & 3 of order[o >> 2] holds the slot visited
-//                                          1st, 2nd, 3rd, 4th in bits 0-1, 2-3, 4-5, 6-7 (empty slots last)
-// Which BVH2 nodes become the slots of a wide node ("collapse"): RT_WIDE_COLLAPSE_FOLD = the four grandchildren (a child that
-// is a leaf fills one slot); RT_WIDE_COLLAPSE_GREEDY (default) = starting from the two children, the interior slot with the
-// largest surface area is opened (replaced in place by its two children) until four slots are filled -- the cut through the
-// BVH2 then follows the geometry (big boxes are opened first) instead of the depth: 8 % lower SAH node cost on the benchmark
-// scene.  Slots stay in the reference's depth-first order either way, and the order bytes tabulate the reference's
-// near-child-first rule (trace_bvh.cl:181-190) over the up to three BVH2 nodes opened inside the record, so the leaves are
-// reached in exactly the reference's sequence whatever the shape of the cut.
-struct WideNode { float ox, oy, oz; uint32_t meta; uint32_t lo[3]; uint32_t hi[3]; uint32_t ref[4]; uint32_t order[2]; };
-enum { RT_WIDE_COLLAPSE_FOLD = 0, RT_WIDE_COLLAPSE_GREEDY = 1 };
+//         q3 = (ref2, ref3, order, -)       order: for each of the 8 direction-sign octants o (bit a set = direction negative
+//                                          along axis a) three bits at 3 * o: swap the two halves | swap inside half 0 |
+//                                          swap inside half 1 (a half with an empty slot is never swapped inside)
+struct WideNode { float ox, oy, oz; uint32_t meta; uint32_t lo[3]; uint32_t hi[3]; uint32_t ref[4]; uint32_t order; uint32_t pad; };
 static_assert(sizeof(WideNode) == 64, "wide node record");
 
 // false: the tree does not qualify (non-finite or non-nested bounds, child order): k_trace2 is used
-bool build_wide_bvh(const rt_bvh_node* nodes, uint32_t nn, std::vector<WideNode>& out, uint32_t& entry_ref, int collapse = RT_WIDE_COLLAPSE_GREEDY)
+bool build_wide_bvh(const rt_bvh_node* nodes, uint32_t nn, std::vector<WideNode>& out, uint32_t& entry_ref)
 {
     auto is_leaf = [&](uint32_t i) { return (nodes[i].num_primitives_axis >> 16) != 0; };
     out.clear();
@@ -404,69 +391,14 @@ bool build_wide_bvh(const rt_bvh_node* nodes, uint32_t nn, std::vector<WideNode>
     std::vector<uint32_t> wide_of(nn, RT_EMPTY_REF), todo, order, depth_of;
     todo.push_back(0);
     depth_of.push_back(1);
-    auto area_of = [&](uint32_t i)
+    auto slots_of = [&](uint32_t n, uint32_t slot[4], uint32_t axes[3])
     {
-        const double ex = (double)nodes[i].bounds_max.x - (double)nodes[i].bounds_min.x, ey = (double)nodes[i].bounds_max.y - (double)nodes[i].bounds_min.y,
-                     ez = (double)nodes[i].bounds_max.z - (double)nodes[i].bounds_min.z;
-        return ex * ey + ey * ez + ex * ez;
-    };
-    // the slots of the wide node rooted at BVH2 interior node n, in the reference's depth-first order (unused ones =
-    // RT_EMPTY_REF, at the end), and per octant the order in which the reference visits them (byte: 4 x 2-bit slot numbers)
-    auto slots_of = [&](uint32_t n, uint32_t slot[4], uint8_t perm[8])
-    {
-        uint32_t cut[4] = {n + 1, nodes[n].offset, RT_EMPTY_REF, RT_EMPTY_REF};
-        uint32_t opened[3] = {n, RT_EMPTY_REF, RT_EMPTY_REF};
-        int cnt = 2, n_open = 1;
-        auto open_at = [&](int i)
+        const uint32_t c[2] = {n + 1, nodes[n].offset};
+        axes[0] = nodes[n].num_primitives_axis & 0xFFFFu;
+        for (int i = 0; i < 2; ++i)
         {
-            const uint32_t c = cut[i];
-            for (int k = cnt; k > i + 1; --k) cut[k] = cut[k - 1];
-            cut[i] = c + 1; cut[i + 1] = nodes[c].offset;
-            opened[n_open++] = c;
-            ++cnt;
-        };
-        if (collapse == RT_WIDE_COLLAPSE_FOLD)
-        {
-            if (!is_leaf(cut[1])) open_at(1);                              // second child first: the first one's index stays 0
-            if (!is_leaf(cut[0])) open_at(0);
-        }
-        else
-            while (cnt < 4)
-            {
-                int best = -1;
-                double best_area = -1.0;
-                for (int i = 0; i < cnt; ++i)
-                    if (!is_leaf(cut[i]) && area_of(cut[i]) > best_area) { best = i; best_area = area_of(cut[i]); }
-                if (best < 0) break;
-                open_at(best);
-            }
-        for (int k = 0; k < 4; ++k) slot[k] = cut[k];
-        for (uint32_t o = 0; o < 8; ++o)
-        {
-            // the reference's traversal over the opened nodes: near child first = the SECOND child when the ray is negative
-            // along the node's split axis (trace_bvh.cl:181-190)
-            uint32_t seq[4], n_seq = 0, st[8], n_st = 0;
-            st[n_st++] = n;
-            while (n_st)
-            {
-                const uint32_t x = st[--n_st];
-                bool is_open = false;
-                for (int k = 0; k < n_open; ++k) is_open = is_open || opened[k] == x;
-                if (!is_open)
-                {
-                    for (int k = 0; k < cnt; ++k) if (cut[k] == x) seq[n_seq++] = (uint32_t)k;
-                    continue;
-                }
-                const uint32_t axis = nodes[x].num_primitives_axis & 0xFFFFu;
-                const bool neg = ((o >> axis) & 1u) != 0u;
-                const uint32_t first = neg ? nodes[x].offset : x + 1, second = neg ? x + 1 : nodes[x].offset;
-                st[n_st++] = second;                                       // popped after `first`
-                st[n_st++] = first;
-            }
-            uint32_t used = 0, byte = 0;
-            for (uint32_t j = 0; j < n_seq; ++j) { byte |= seq[j] << (2 * j); used |= 1u << seq[j]; }
-            for (uint32_t k = 0, j = n_seq; k < 4; ++k) if (!(used & (1u << k))) { byte |= k << (2 * j); ++j; }
-            perm[o] = (uint8_t)byte;
+            if (is_leaf(c[i])) { slot[2 * i] = c[i]; slot[2 * i + 1] = RT_EMPTY_REF; axes[1 + i] = 0; }
+            else { slot[2 * i] = c[i] + 1; slot[2 * i + 1] = nodes[c[i]].offset; axes[1 + i] = nodes[c[i]].num_primitives_axis & 0xFFFFu; }
         }
     };
     while (!todo.empty())
@@ -477,9 +409,8 @@ bool build_wide_bvh(const rt_bvh_node* nodes, uint32_t nn, std::vector<WideNode>
         if (depth > 33u) return false;                                     // <= 3 pending slots per level must fit RT_W4_STACK_MAX
         wide_of[n] = (uint32_t)order.size();
         order.push_back(n);
-        uint32_t slot[4];
-        uint8_t perm[8];
-        slots_of(n, slot, perm);
+        uint32_t slot[4], axes[3];
+        slots_of(n, slot, axes);
         for (int k = 3; k >= 0; --k)
             if (slot[k] != RT_EMPTY_REF && !is_leaf(slot[k])) { todo.push_back(slot[k]); depth_of.push_back(depth + 1u); }
     }
@@ -489,9 +420,8 @@ bool build_wide_bvh(const rt_bvh_node* nodes, uint32_t nn, std::vector<WideNode>
     for (size_t w = 0; w < order.size(); ++w)
     {
         const uint32_t n = order[w];
-        uint32_t slot[4];
-        uint8_t perm[8];
-        slots_of(n, slot, perm);
+        uint32_t slot[4], axes[3];
+        slots_of(n, slot, axes);
         WideNode& r = out[w];
         memset(&r, 0, sizeof(r));
         const float nmin[3] = {nodes[n].bounds_min.x, nodes[n].bounds_min.y, nodes[n].bounds_min.z};
@@ -518,10 +448,16 @@ bool build_wide_bvh(const rt_bvh_node* nodes, uint32_t nn, std::vector<WideNode>
             exps[a] = e;
         }
         r.ox = origin[0]; r.oy = origin[1]; r.oz = origin[2];
-        uint32_t n_slots = 0;
-        for (int k = 0; k < 4; ++k) n_slots += slot[k] != RT_EMPTY_REF ? 1u : 0u;
-        r.meta = (uint32_t)(exps[0] + 127) | (uint32_t)(exps[1] + 127) << 8 | (uint32_t)(exps[2] + 127) << 16 | n_slots << 24;
-        for (uint32_t o = 0; o < 8; ++o) r.order[o >> 2] |= (uint32_t)perm[o] << (8 * (o & 3u));
+        r.meta = (uint32_t)(exps[0] + 127) | (uint32_t)(exps[1] + 127) << 8 | (uint32_t)(exps[2] + 127) << 16 |
+                 (axes[0] | axes[1] << 2 | axes[2] << 4) << 24;
+        for (uint32_t o = 0; o < 8; ++o)
+        {
+            // trace_bvh.cl:181-190 at both BVH2 levels: the near child is the second one when the ray is negative along the split axis
+            uint32_t sw0 = (o >> axes[0]) & 1u;
+            uint32_t swa = slot[1] != RT_EMPTY_REF ? (o >> axes[1]) & 1u : 0u;
+            uint32_t swb = slot[3] != RT_EMPTY_REF ? (o >> axes[2]) & 1u : 0u;
+            r.order |= (sw0 | swa << 1 | swb << 2) << (3 * o);
+        }
         for (int k = 0; k < 4; ++k)
         {
             if (slot[k] == RT_EMPTY_REF)
@@ -717,11 +653,7 @@ int rt_scene_upload(rt_ctx* ctx, const rt_scene_desc* sd)
     // the 4-wide quantized tree for k_trace_w4 (optional: trees that do not qualify keep the BVH2 kernels)
     std::vector<WideNode> wide;
     uint32_t w_entry = 0;
-    uint32_t wide_mode = ctx->build_wide;
-    if (const char* e = getenv("RT_WIDE_BVH"))                            // A/B runs of whole suites: overrides the context option
-        if (e[0] >= '0' && e[0] <= '2' && e[1] == 0) wide_mode = (uint32_t)(e[0] - '0');
-    const bool have_wide = wide_mode && (uint64_t)nt * 64 <= 0xFFFFFFFFull &&
-                           build_wide_bvh(sd->nodes, nn, wide, w_entry, wide_mode == 2u ? RT_WIDE_COLLAPSE_FOLD : RT_WIDE_COLLAPSE_GREEDY);
+    const bool have_wide = ctx->build_wide && (uint64_t)nt * 64 <= 0xFFFFFFFFull && build_wide_bvh(sd->nodes, nn, wide, w_entry);
     if (have_wide) rc |= dev_alloc_copy(ctx, &s.wnodes, wide.data(), wide.size() * sizeof(WideNode));
     if (rc != RT_OK) { free_scene(s); return RT_ERROR; }
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // host staging vectors die here
@@ -1853,17 +1785,10 @@ int rt_frame_debug_timeline(rt_frame* f, int arm, unsigned long long* out /* [64
 int rt_debug_wide_bvh(const rt_bvh_node* nodes, uint32_t num_nodes, void* records, uint32_t capacity, uint32_t* num_records,
     uint32_t* entry_ref)
 {
-    return rt_debug_wide_bvh_ex(nodes, num_nodes, 1u, records, capacity, num_records, entry_ref);
-}
-
-int rt_debug_wide_bvh_ex(const rt_bvh_node* nodes, uint32_t num_nodes, uint32_t wide_bvh_option, void* records, uint32_t capacity,
-    uint32_t* num_records, uint32_t* entry_ref)
-{
     if (!nodes || num_nodes == 0 || !num_records || !entry_ref) return fail(nullptr, "rt_debug_wide_bvh: NULL argument");
-    if (wide_bvh_option != 1u && wide_bvh_option != 2u) return fail(nullptr, "rt_debug_wide_bvh: the collapse rule is 1 or 2 (RT_CTX_OPT_WIDE_BVH)");
     std::vector<WideNode> wide;
     uint32_t entry = 0;
-    if (!build_wide_bvh(nodes, num_nodes, wide, entry, wide_bvh_option == 2u ? RT_WIDE_COLLAPSE_FOLD : RT_WIDE_COLLAPSE_GREEDY))
+    if (!build_wide_bvh(nodes, num_nodes, wide, entry))
         return fail(nullptr, "rt_debug_wide_bvh: the tree does not qualify for the 4-wide layout (bounds not finite / not nested, or too deep)");
     *num_records = (uint32_t)wide.size();
     *entry_ref = entry;

@@ -1093,7 +1093,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
     RayPool pool = {0u, 0u, 0u, false};
     uint32_t ref = RT_IDLE_REF;                    // wide node | RT_LEAF_BIT (| RT_LEAF_CONT_BIT) + triangle | idle
     uint32_t ray_i = RT_INVALID_ID;
-    uint32_t sign_bits = 0, octant3 = 0, hit_prim = RT_INVALID_ID;          // octant3: shift of this ray's byte in a node's order words
+    uint32_t sign_bits = 0, octant3 = 0, hit_prim = RT_INVALID_ID;          // octant3: shift of this ray's entry in a node's order table
     int sp = 0;
     uint32_t n_spills = 0;                                                   // statistics (wave-uniform): lane-steps with entries in the HBM spill area
     f3 org = F3s(0.0f), dir = F3s(0.0f), inv = F3s(0.0f);
@@ -1176,7 +1176,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                     t_max = q0.w;
                     inv = F3(q2.x, q2.y, q2.z);
                     sign_bits = __float_as_uint(q2.w) & 0xFFu;
-                    octant3 = 8u * (sign_bits & 3u);
+                    octant3 = 3u * (sign_bits & 7u);
                     if (SHADOW) { payload = __float_as_uint(q1.w); log_entry = __float_as_uint(q2.w) >> 8; }
                     hit_prim = RT_INVALID_ID;
                     hit_u = 0.0f; hit_v = 0.0f;
@@ -1360,21 +1360,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                 }
                 if (!SHADOW)
                 {
-                    // the reference's order: near child first at every BVH2 node opened inside this record (trace_bvh.cl:181-190);
-                    // the resulting sequence of the slots is tabulated per direction octant in the record (build_wide_bvh):
-                    // 2 bits per position
-                    const uint32_t pm = ((sign_bits & 4u) ? __float_as_uint(q3.w) : __float_as_uint(q3.z)) >> octant3;   // octant3 = 8 * (octant & 3)
-                    uint32_t pr[4]; float pe[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                    {
-                        const bool b0 = (pm & (1u << (2 * j))) != 0u, b1 = (pm & (2u << (2 * j))) != 0u;
-                        const uint32_t ra = b0 ? r[1] : r[0], rb = b0 ? r[3] : r[2];
-                        const float ea = b0 ? e[1] : e[0], eb = b0 ? e[3] : e[2];
-                        pr[j] = b1 ? rb : ra; pe[j] = b1 ? eb : ea;
-                    }
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) { r[j] = pr[j]; e[j] = pe[j]; }
+                    // the reference's order: near child first at both BVH2 levels (trace_bvh.cl:181-190)
+                    // (the three decisions per direction octant are tabulated in the record: build_wide_bvh)
+                    const uint32_t sw = __float_as_uint(q3.z) >> octant3;
+                    const bool sw0 = (sw & 1u) != 0u, pa = (sw & 2u) != 0u, pb = (sw & 4u) != 0u;
+                    uint32_t tr; float te;
+                    tr = pa ? r[1] : r[0]; r[1] = pa ? r[0] : r[1]; r[0] = tr;  te = pa ? e[1] : e[0]; e[1] = pa ? e[0] : e[1]; e[0] = te;
+                    tr = pb ? r[3] : r[2]; r[3] = pb ? r[2] : r[3]; r[2] = tr;  te = pb ? e[3] : e[2]; e[3] = pb ? e[2] : e[3]; e[2] = te;
+                    tr = sw0 ? r[2] : r[0]; r[2] = sw0 ? r[0] : r[2]; r[0] = tr;  te = sw0 ? e[2] : e[0]; e[2] = sw0 ? e[0] : e[2]; e[0] = te;
+                    tr = sw0 ? r[3] : r[1]; r[3] = sw0 ? r[1] : r[3]; r[1] = tr;  te = sw0 ? e[3] : e[1]; e[3] = sw0 ? e[1] : e[3]; e[1] = te;
                 }
                 // visit position 0 next, positions 3..1 wait on the stack (deepest first)
                 if (e[3] < INF) push(r[3], e[3]);

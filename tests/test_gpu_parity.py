@@ -517,33 +517,6 @@ def _tiny_scene(env, tris_spec):
     return s.arrays()
 
 
-@pytest.mark.parametrize("mode", [1, 2, 0])
-def test_wide_tree_collapse_rules_give_the_same_bits(golden_scenes, mode):
-    """RT_CTX_OPT_WIDE_BVH: which BVH2 nodes become the slots of a wide record (largest surface area opened first / always
-    the four grandchildren) changes the cut, never the order in which the reference's leaves are reached; 0 = no wide tree
-    (k_trace_w4 requests fall back to the BVH2 kernel)."""
-    w, h, b, spp = 96, 72, 6, 5
-    sc = golden_scenes["coverage"]
-    cam = T.default_camera(w, h)
-    ctx = capi.Context(0)
-    ctx.set_wide_bvh(mode)
-    ctx.upload_scene(sc)
-    orc = _oracle.Oracle(w, h, sc)
-    orc.set_camera(cam); orc.set_max_bounces(b); orc.integrate(spp)
-    for variant, tune in ((10, 0), (10, 1 | (1 << 8)), (11, 64 | (64 << 8))):
-        fr = capi.Frame(ctx, w, h)
-        fr.set_camera(cam); fr.set_max_bounces(b)
-        fr.set_option(capi.OPT_SAMPLES_IN_FLIGHT, 3)
-        fr.set_option(capi.OPT_TRACE_VARIANT, variant)
-        fr.set_option(capi.OPT_TRACE_TUNE, tune)
-        fr.integrate(spp)
-        assert np.array_equal(fr.radiance()[..., :3], orc.radiance()[..., :3], equal_nan=True), (mode, variant, tune)
-        st = fr.stats()
-        assert (st.closest_rays, st.shadow_rays) == orc.ray_totals()
-        fr.close()
-    ctx.close()
-
-
 @pytest.mark.parametrize("variant", [0, 3, 4, 8, 9, 10])
 def test_degenerate_bvhs(ctx, env_map, variant):
     """Root-is-a-leaf trees (1 triangle), 2-triangle trees, a leaf with many coincident-centroid

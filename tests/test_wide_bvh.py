@@ -4,10 +4,9 @@ the invariants the exactness argument of DESIGN.md rests on.
   * every slot box, dequantised EXACTLY in binary32 the way the kernel does it
     (fma(q, cell, origin)), contains the reference node's box;
   * origin + q * cell is exactly representable for q = 0..255 (no rounding in the dequantisation);
-  * the slots of a record are the cut through the reference BVH2 its collapse rule prescribes (the four
-    grandchildren, or largest surface area opened first), in the reference's depth-first order; the order bytes
-    give, per direction-sign octant, the sequence in which the reference's near-child-first loop reaches them;
-    the leaves reachable from the wide tree are exactly the reference's leaves, each once;
+  * slots 0,1 / 2,3 are the children of BVH2 child 0 / 1 in the reference's order, the three
+    split axes are the reference's, and the leaves reachable from the wide tree are exactly the
+    reference's leaves, each once;
   * trees that do not qualify (bounds not nested / not finite) are refused."""
 import ctypes as C
 import numpy as np
@@ -15,19 +14,19 @@ import pytest
 from raytracing_amd import capi, host, scenes as S, types as T
 
 LEAF, EMPTY = 0x80000000, 0xFFFFFFFF
-WIDE = np.dtype([("origin", "<f4", 3), ("meta", "<u4"), ("lo", "<u4", 3), ("hi", "<u4", 3), ("ref", "<u4", 4), ("order", "<u4", 2)])
+WIDE = np.dtype([("origin", "<f4", 3), ("meta", "<u4"), ("lo", "<u4", 3), ("hi", "<u4", 3), ("ref", "<u4", 4), ("order", "<u4"), ("pad", "<u4")])
 assert WIDE.itemsize == 64
 
 
-def wide_of(nodes, option=1):
+def wide_of(nodes):
     lib = capi.load()
     n, entry = C.c_uint32(), C.c_uint32()
     nodes = np.ascontiguousarray(nodes)
-    rc = lib.rt_debug_wide_bvh_ex(nodes.ctypes.data, len(nodes), option, None, 0, C.byref(n), C.byref(entry))
+    rc = lib.rt_debug_wide_bvh(nodes.ctypes.data, len(nodes), None, 0, C.byref(n), C.byref(entry))
     if rc != 0:
         raise capi.RtError(lib.rt_last_error(None).decode())
     out = np.zeros(n.value, WIDE)
-    assert lib.rt_debug_wide_bvh_ex(nodes.ctypes.data, len(nodes), option, out.ctypes.data, len(out), C.byref(n), C.byref(entry)) == 0
+    assert lib.rt_debug_wide_bvh(nodes.ctypes.data, len(nodes), out.ctypes.data, len(out), C.byref(n), C.byref(entry)) == 0
     return out, entry.value
 
 
@@ -38,55 +37,8 @@ def bvh_of(tris, mats):
     return a["nodes"].copy(), a["triangles"].copy()
 
 
-def expected_cut(nodes, is_leaf, area, n, option):
-    """The BVH2 nodes that become the slots of the wide node rooted at interior node n (depth-first order) and the nodes
-    opened on the way: option 2 = the grandchildren, option 1 = open the interior slot with the largest surface area
-    (first one on ties) until four slots are filled."""
-    off = nodes["offset"]
-    cut, opened = [n + 1, int(off[n])], [n]
-    if option == 2:
-        new = []
-        for c in cut:
-            if is_leaf[c]:
-                new.append(c)
-            else:
-                new += [c + 1, int(off[c])]
-                opened.append(c)
-        return new, opened
-    while len(cut) < 4:
-        best, bi = -1.0, -1
-        for i, c in enumerate(cut):
-            if not is_leaf[c] and area[c] > best:
-                best, bi = area[c], i
-        if bi < 0:
-            break
-        c = cut[bi]
-        cut[bi:bi + 1] = [c + 1, int(off[c])]
-        opened.append(c)
-    return cut, opened
-
-
-def expected_order(nodes, cut, opened, n, octant):
-    """Slot numbers in the order the reference's loop reaches them for rays of this direction-sign octant: at every opened
-    node the near child first = the SECOND child when the ray is negative along the split axis (trace_bvh.cl:181-190)."""
-    seq = []
-
-    def visit(x):
-        if x not in opened:
-            seq.append(cut.index(x))
-            return
-        axis = int(nodes["num_primitives_axis"][x]) & 0xFFFF
-        a, b = x + 1, int(nodes["offset"][x])
-        if (octant >> axis) & 1:
-            a, b = b, a
-        visit(a)
-        visit(b)
-    visit(n)
-    return seq + [k for k in range(4) if k not in seq]
-
-
-def check(nodes, option=1):
-    wide, entry = wide_of(nodes, option)
+def check(nodes):
+    wide, entry = wide_of(nodes)
     is_leaf = (nodes["num_primitives_axis"] >> 16) != 0
     if is_leaf[0]:
         assert len(wide) == 0 and entry == (LEAF | int(nodes["offset"][0]))
@@ -94,8 +46,6 @@ def check(nodes, option=1):
     assert entry == 0
     bmin = np.stack([nodes["bounds_min"][c] for c in "xyz"], 1)
     bmax = np.stack([nodes["bounds_max"][c] for c in "xyz"], 1)
-    ext = bmax.astype(np.float64) - bmin.astype(np.float64)
-    area = ext[:, 0] * ext[:, 1] + ext[:, 1] * ext[:, 2] + ext[:, 0] * ext[:, 2]
     # walk the wide tree together with the BVH2: wide node w <-> BVH2 interior node n
     seen_leaves, seen_wide = [], set()
     todo = [(0, 0)]
@@ -107,19 +57,26 @@ def check(nodes, option=1):
         rec = wide[w]
         meta = int(rec["meta"])
         cell = [f32(2.0) ** f32(((meta >> (8 * a)) & 0xFF) - 127) for a in range(3)]
-        cut, opened = expected_cut(nodes, is_leaf, area, n, option)
-        assert (meta >> 24) == len(cut) and len(opened) <= 3
-        slots = cut + [None] * (4 - len(cut))
-        # the order bytes: per direction-sign octant, the reference's sequence of the slots
+        axes = meta >> 24
+        c = [n + 1, int(nodes["offset"][n])]
+        assert (axes & 3) == (int(nodes["num_primitives_axis"][n]) & 0xFFFF)
+        slots = []
+        for i in range(2):
+            if is_leaf[c[i]]:
+                slots += [c[i], None]
+            else:
+                slots += [c[i] + 1, int(nodes["offset"][c[i]])]
+                assert ((axes >> (2 + 2 * i)) & 3) == (int(nodes["num_primitives_axis"][c[i]]) & 0xFFFF)
+        # the order table: per direction-sign octant, swap the halves / inside half 0 / inside half 1 (trace_bvh.cl:181-190)
+        ax = [axes & 3, (axes >> 2) & 3, (axes >> 4) & 3]
         for o in range(8):
-            want = expected_order(nodes, cut, opened, n, o)
-            byte = (int(rec["order"][o >> 2]) >> (8 * (o & 3))) & 0xFF
-            assert [(byte >> (2 * j)) & 3 for j in range(4)] == want, (w, o)
+            want = ((o >> ax[0]) & 1) | ((((o >> ax[1]) & 1) if slots[1] is not None else 0) << 1) | \
+                   ((((o >> ax[2]) & 1) if slots[3] is not None else 0) << 2)
+            assert (int(rec["order"]) >> (3 * o)) & 7 == want
         for k, child in enumerate(slots):
             ref = int(rec["ref"][k])
             if child is None:
                 assert ref == EMPTY
-                assert all((int(rec["lo"][a]) >> (8 * k)) & 0xFF == 255 and (int(rec["hi"][a]) >> (8 * k)) & 0xFF == 0 for a in range(3))
                 continue
             for a in range(3):
                 qlo, qhi = (int(rec["lo"][a]) >> (8 * k)) & 0xFF, (int(rec["hi"][a]) >> (8 * k)) & 0xFF
@@ -150,14 +107,12 @@ def test_wide_tree_of_the_cornell_box_and_a_dense_mesh():
     import os
     s = host.Scene(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "assets", "CornellBox.obj"))
     s.build_bvh()
-    for option in (1, 2):
-        check(s.arrays()["nodes"].copy(), option)
+    check(s.arrays()["nodes"].copy())
     tris, mats = S.cornell_blob(20_000, 2_000)
     nodes, _ = bvh_of(tris, mats)
+    wide = check(nodes)
     n_interior = int(((nodes["num_primitives_axis"] >> 16) == 0).sum())
-    for option in (1, 2):
-        wide = check(nodes, option)
-        assert 0.4 * n_interior < len(wide) < 0.75 * n_interior   # two or three BVH2 nodes per record
+    assert 0.4 * n_interior < len(wide) < 0.75 * n_interior       # two BVH2 levels per record
 
 
 @pytest.mark.parametrize("seed", range(6))
@@ -175,7 +130,7 @@ def test_wide_tree_of_random_soups_with_extreme_coordinates(seed):
     tris = S.to_triangles([(P, N, np.zeros((n, 3, 2), np.float32), 0)])
     mats = np.array([S.make_material(kd=(0.7, 0.7, 0.7))], dtype=T.packed_material)
     nodes, _ = bvh_of(tris, mats)
-    check(nodes, 1 + seed % 2)
+    check(nodes)
 
 
 def test_trees_that_do_not_qualify_are_refused():
@@ -203,12 +158,8 @@ def test_trees_that_do_not_qualify_are_refused():
                 c["bounds_max"][ax][k] = 0.5 if leaf else 1.0
         return c
     with pytest.raises(capi.RtError, match="does not qualify"):
-        wide_of(chain(80), 2)                                  # two BVH2 levels per record: 40 wide levels
-    with pytest.raises(capi.RtError, match="does not qualify"):
-        wide_of(chain(120), 1)                                 # largest-area-first opens two more nodes of a chain per record
-    check(chain(20), 1)
-    check(chain(20), 2)
-    check(chain(80), 1)
+        wide_of(chain(80))
+    check(chain(20))
 
 
 # ---- the one-fma slab distances of k_trace_w4 (loop C), reproduced exactly on the host ------------------------------
