@@ -237,7 +237,8 @@ typedef struct rt_stats
     uint32_t samples_in_flight_limit;  /* != 0: a larger batch did not fit into device memory and was halved to this */
     uint64_t path_state_bytes;         /* size of the per-path buffers (ray queues + radiance log) */
     uint32_t stack_spills;             /* lane-steps of the traversal kernels with stack entries in the HBM spill area (beyond the
-                                          LDS entries) since the last reset */
+                                          LDS entries) since the last reset; a 32-bit diagnostic that wraps (the headline
+                                          workload adds ~1.3 M per sample per pixel of the frame: read it over short runs) */
     uint32_t slow_rays;                /* rays with a non-finite 1/dir component that k_trace_w4 handed to the BVH2 kernel */
     uint32_t chunk_pixels;             /* pixels of the tile that travel through the wavefront loop together (the whole
                                           tile unless RT_OPT_PATH_STATE_LIMIT_MB splits it) */
