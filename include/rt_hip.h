@@ -136,8 +136,9 @@ enum rt_option
                                    state machine with a 16 / 24 / 12 / 8, 10 / 11 entry LDS stack; 8 / 9 = k_trace2
                                    (separate wave-uniform node / triangle / refill loops) with a 10+12 / 12+12 entry
                                    stack (closest + shadow); 10 (11..14: other LDS stack sizes) = k_trace_w4 (4-wide quantized tree, exact leaf
-                                   re-test; rays it cannot take -- non-finite 1/dir -- go to k_trace2); 5 (default) = auto: 0 below 2 M paths per launch, 8
-                                   above.  Results are identical for every value. */
+                                   re-test; rays it cannot take -- non-finite 1/dir -- go to k_trace2); 15 = k_trace_w4 visiting the first
+                                   passing slot directly instead of through the stack; 5 (default) = auto: 0 below 2 M paths
+                                   per launch, 10 above.  Results are identical for every value. */
     , RT_OPT_TRACE_WAVES_PER_CU = 8 /* persistent-grid size of the trace kernels in waves per CU (0 = as many as fit) */
     , RT_OPT_SAMPLES_IN_FLIGHT = 9  /* rt_integrate traces this many consecutive samples per pixel concurrently
                                        (1..1024, allocated at once; 0 = auto, the default: up to the largest power

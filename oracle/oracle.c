@@ -1222,6 +1222,168 @@ ORC_EXPORT void* orc_buffer(void* h, const char* name)
     return NULL;
 }
 
+/* ---- the 4-wide quantized traversal of the HIP path, restated on the CPU --------------------------------------
+ * NOT a reference function: this is k_trace_w4 (raytracing_amd/csrc/trace_kernels.h) ray by ray, over the records
+ * build_wide_bvh (rt_hip.hip) makes, with the kernel's own arithmetic -- exact dequantisation, ONE fma per plane with
+ * the outward 2^-20 M margin, the per-octant order table, pops pre-culled by the stored entry distance, every leaf
+ * re-tested with its exact bounds and the ray's current t_max -- so that tests/test_wide_traversal_oracle.py can show on
+ * the CPU, against TraceOne above (trace_bvh.cl:99-211), that the wide walk reaches the reference's leaves in the
+ * reference's order and returns the reference's hits bit for bit, and so that the walk's statistics (visits, pushes,
+ * culled pops, stack depth) can be had without a GPU.  Rays the kernel hands to its BVH2 follow-up (non-finite or huge
+ * 1/dir, far origins) take TraceOne here as well. */
+typedef struct { float ox, oy, oz; uint32_t meta; uint32_t lo[3]; uint32_t hi[3]; uint32_t ref[4]; uint32_t order; uint32_t pad; } orc_wide_node;
+#define ORC_LEAF_BIT 0x80000000u
+#define ORC_EMPTY_REF 0xFFFFFFFFu
+
+static inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+static inline float w_max3(float a, float b, float c) { return f_max(f_max(a, b), c); }
+static inline float w_min3(float a, float b, float c) { return f_min(f_min(a, b), c); }
+
+/* counters: 0 rays, 1 wide-node visits, 2 leaf arrivals, 3 leaf box tests failed, 4 triangle tests, 5 pushes,
+ * 6 pops culled by their entry distance, 7 deepest stack, 8 rays left to the BVH2 walk, 9 slots that passed their box test */
+ORC_EXPORT int orc_wide_trace(void* h, const void* wide_records, uint32_t n_wide, uint32_t entry_ref, const rt_ray* rays,
+    uint32_t n_rays, int shadow, rt_hit* hits_out, uint32_t* shadow_out, uint64_t* counters)
+{
+    orc* o = (orc*)h;
+    const int direct = (shadow & 2) != 0;                                /* bit 1 of `shadow`: the direct form of the walk */
+    shadow &= 1;
+    const orc_wide_node* wn = (const orc_wide_node*)wide_records;
+    /* leaf ref (first triangle) -> the BVH2 leaf node that holds its exact bounds and primitive count */
+    uint32_t* leaf_of = (uint32_t*)malloc(((size_t)o->n_triangles + 1) * sizeof(uint32_t));
+    if (!leaf_of) return 1;
+    memset(leaf_of, 0xFF, ((size_t)o->n_triangles + 1) * sizeof(uint32_t));
+    for (uint32_t i = 0; i < o->n_nodes; ++i)
+        if ((o->nodes[i].num_primitives_axis >> 16) != 0 && o->nodes[i].offset < o->n_triangles) leaf_of[o->nodes[i].offset] = i;
+    const float INF = __builtin_inff();
+    int rc = 0;
+    for (uint32_t ri = 0; ri < n_rays && rc == 0; ++ri)
+    {
+        const rt_ray ray = rays[ri];
+        const v3 org = V3(ray.origin.x, ray.origin.y, ray.origin.z), dir = V3(ray.direction.x, ray.direction.y, ray.direction.z);
+        const float t_min = 0.0f;                                        /* the HIP queues carry no t_min: it is 0 */
+        float t_max = ray.direction.w;
+        const v3 inv = V3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
+        const uint32_t sign_bits = (inv.x < 0.0f ? 1u : 0u) | (inv.y < 0.0f ? 2u : 0u) | (inv.z < 0.0f ? 4u : 0u);
+        counters[0]++;
+        /* ray_inverse (kernels_common.h) + the origin test at the ray's start (k_trace_w4, phase A) */
+        const float lim = 0x1p96f;
+        const int slow = !(__builtin_fabsf(inv.x) < lim && __builtin_fabsf(inv.y) < lim && __builtin_fabsf(inv.z) < lim) ||
+                         !(w_max3(__builtin_fabsf(org.x), __builtin_fabsf(org.y), __builtin_fabsf(org.z)) < 0x1p29f) || ray.origin.w != 0.0f;
+        if (slow)
+        {
+            counters[8]++;
+            rt_hit hh; uint32_t sh = RT_INVALID_ID;
+            TraceOne(o, rays, ri, shadow, &hh, &sh);
+            if (shadow) shadow_out[ri] = sh; else hits_out[ri] = hh;
+            continue;
+        }
+        rt_hit hit; memset(&hit, 0, sizeof(hit)); hit.primitive_id = RT_INVALID_ID;
+        uint32_t shadow_hit = RT_INVALID_ID;
+        struct { uint32_t ref; float entry; } stack[128];
+        int sp = 0;
+        uint32_t ref = entry_ref;
+        int have = 1;
+        while (have)
+        {
+            if (ref & ORC_LEAF_BIT)
+            {
+                /* B: the leaf's exact box with the CURRENT t_max (the reference's RayBounds on the leaf node), then its
+                 * triangles in array order */
+                counters[2]++;
+                const uint32_t first = ref & ~ORC_LEAF_BIT;
+                const uint32_t leaf = first <= o->n_triangles ? leaf_of[first] : RT_INVALID_ID;
+                if (leaf == RT_INVALID_ID) { rc = 2; break; }
+                int stop = 0;
+                if (RayBounds(&o->nodes[leaf], org, inv, t_min, t_max))
+                {
+                    const uint32_t np = o->nodes[leaf].num_primitives_axis >> 16;
+                    for (uint32_t i = 0; i < np && !stop; ++i)
+                    {
+                        counters[4]++;
+                        float u, v, t;
+                        if (RayTriangle(org, dir, t_min, t_max, &o->triangles[first + i], &u, &v, &t))
+                        {
+                            hit.bc.x = u; hit.bc.y = v; hit.t = t; hit.primitive_id = first + i;
+                            t_max = t;
+                            if (shadow) { shadow_hit = 0; stop = 1; }
+                        }
+                    }
+                }
+                else counters[3]++;
+                if (stop) break;
+            }
+            else
+            {
+                /* C: one wide node */
+                if (ref >= n_wide) { rc = 3; break; }
+                counters[1]++;
+                const orc_wide_node* n = &wn[ref];
+                const float cx = u2f((n->meta & 0xFFu) << 23), cy = u2f(((n->meta >> 8) & 0xFFu) << 23), cz = u2f(((n->meta >> 16) & 0xFFu) << 23);
+                const int nx = (sign_bits & 1u) != 0u, ny = (sign_bits & 2u) != 0u, nz = (sign_bits & 4u) != 0u;
+                const uint32_t nwx = nx ? n->hi[0] : n->lo[0], fwx = nx ? n->lo[0] : n->hi[0];
+                const uint32_t nwy = ny ? n->hi[1] : n->lo[1], fwy = ny ? n->lo[1] : n->hi[1];
+                const uint32_t nwz = nz ? n->hi[2] : n->lo[2], fwz = nz ? n->lo[2] : n->hi[2];
+                const float ax = cx * inv.x, ay = cy * inv.y, az = cz * inv.z;
+                const float bx = (n->ox - org.x) * inv.x, by = (n->oy - org.y) * inv.y, bz = (n->oz - org.z) * inv.z;
+                const float mx = __builtin_fmaf(255.0f, __builtin_fabsf(ax), __builtin_fabsf(bx)) + 0x1p-100f;
+                const float my = __builtin_fmaf(255.0f, __builtin_fabsf(ay), __builtin_fabsf(by)) + 0x1p-100f;
+                const float mz = __builtin_fmaf(255.0f, __builtin_fabsf(az), __builtin_fabsf(bz)) + 0x1p-100f;
+                const float bnx = __builtin_fmaf(-0x1p-20f, mx, bx), bfx = __builtin_fmaf(0x1p-20f, mx, bx);
+                const float bny = __builtin_fmaf(-0x1p-20f, my, by), bfy = __builtin_fmaf(0x1p-20f, my, by);
+                const float bnz = __builtin_fmaf(-0x1p-20f, mz, bz), bfz = __builtin_fmaf(0x1p-20f, mz, bz);
+                uint32_t r[4] = {n->ref[0], n->ref[1], n->ref[2], n->ref[3]};
+                float e[4];
+                for (int k = 0; k < 4; ++k)
+                {
+                    const float tnx = __builtin_fmaf((float)((nwx >> (8 * k)) & 0xFFu), ax, bnx);
+                    const float tny = __builtin_fmaf((float)((nwy >> (8 * k)) & 0xFFu), ay, bny);
+                    const float tnz = __builtin_fmaf((float)((nwz >> (8 * k)) & 0xFFu), az, bnz);
+                    const float tfx = __builtin_fmaf((float)((fwx >> (8 * k)) & 0xFFu), ax, bfx);
+                    const float tfy = __builtin_fmaf((float)((fwy >> (8 * k)) & 0xFFu), ay, bfy);
+                    const float tfz = __builtin_fmaf((float)((fwz >> (8 * k)) & 0xFFu), az, bfz);
+                    const float entry = f_max(w_max3(tnx, tny, tnz), t_min);
+                    const float exit = f_min(w_min3(tfx, tfy, tfz), t_max);
+                    e[k] = (exit >= entry && r[k] != ORC_EMPTY_REF) ? entry : INF;
+                    if (e[k] < INF) counters[9]++;
+                }
+                if (!shadow)
+                {
+                    const uint32_t sw = n->order >> (3u * (sign_bits & 7u));
+                    const int sw0 = (sw & 1u) != 0u, pa = (sw & 2u) != 0u, pb = (sw & 4u) != 0u;
+                    uint32_t tr; float te;
+#define ORC_SWAP(c, i, j) if (c) { tr = r[i]; r[i] = r[j]; r[j] = tr; te = e[i]; e[i] = e[j]; e[j] = te; }
+                    ORC_SWAP(pa, 0, 1) ORC_SWAP(pb, 2, 3) ORC_SWAP(sw0, 0, 2) ORC_SWAP(sw0, 1, 3)
+#undef ORC_SWAP
+                }
+                /* plain form: positions 3..1 wait on the stack, position 0 is visited next if it passed.  direct form
+                 * (RT_OPT_TRACE_VARIANT 15): the FIRST passing position is visited next, only the later ones are pushed. */
+                int first = 0;
+                if (direct) { while (first < 4 && !(e[first] < INF)) ++first; }
+                for (int k = 3; k >= first + 1; --k)
+                    if (e[k] < INF)
+                    {
+                        if (sp >= 128) { rc = 4; break; }
+                        stack[sp].ref = r[k]; stack[sp].entry = e[k]; ++sp; counters[5]++;
+                        if ((uint64_t)sp > counters[7]) counters[7] = (uint64_t)sp;
+                    }
+                if (rc) break;
+                if (first < 4 && e[first] < INF) { ref = r[first]; continue; }
+            }
+            /* pop: closest-hit rays skip entries whose (conservative) entry distance lies behind the current t_max */
+            have = 0;
+            while (sp > 0)
+            {
+                --sp;
+                if (shadow || t_max >= stack[sp].entry) { ref = stack[sp].ref; have = 1; break; }
+                counters[6]++;
+            }
+        }
+        if (shadow) shadow_out[ri] = shadow_hit; else hits_out[ri] = hit;
+    }
+    free(leaf_of);
+    return rc;
+}
+
 /* known-answer access to the leaf functions (tests/test_oracle_kat.py) */
 ORC_EXPORT uint32_t orc_wang_hash(uint32_t x) { return WangHash(x); }
 ORC_EXPORT float orc_sample_random(uint32_t x, uint32_t y, uint32_t s, uint32_t b, uint32_t t)

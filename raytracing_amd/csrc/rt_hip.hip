@@ -1111,7 +1111,7 @@ int rt_set_option(rt_frame* f, int option, uint32_t value)
         return RT_OK;
     case RT_OPT_DEBUG_ALLOC_LIMIT: f->debug_alloc_limit = value; return RT_OK;
     case RT_OPT_TRACE_VARIANT:
-        if (value > 14) return fail(f->ctx, "rt_set_option: unknown trace kernel variant");
+        if (value > 15) return fail(f->ctx, "rt_set_option: unknown trace kernel variant");
         f->trace_variant = value;
         return RT_OK;
     default: return fail(f->ctx, "rt_set_option: unknown option");
@@ -1197,7 +1197,7 @@ void launch_trace2(rt_frame* f, const float4* o4, const float4* d4, const float4
 }
 
 // k_trace_w4 over the 4-wide quantized tree, then k_trace2 over the (normally empty) list of rays it left out
-template <bool SHADOW, int STACK>
+template <bool SHADOW, int STACK, bool DIRECT = false>
 void launch_trace_w4(rt_frame* f, const float4* o4, const float4* d4, const float4* iv4, const uint32_t* count)
 {
     rt_ctx* ctx = f->ctx;
@@ -1216,7 +1216,7 @@ void launch_trace_w4(rt_frame* f, const float4* o4, const float4* d4, const floa
             &f->p->counters->slow_count[s], &f->p->counters->stack_spills, &f->p->counters->tl_start[f->timeline_bounce & 63u],
             f->timeline_bounce & 63u);
     else
-        hipLaunchKernelGGL((k_trace_w4<SHADOW, STACK>), dim3(blocks), dim3(64), 0, f->tl_stream, ctx->scene.d, o4, d4, iv4, count,
+        hipLaunchKernelGGL((k_trace_w4<SHADOW, STACK, false, DIRECT>), dim3(blocks), dim3(64), 0, f->tl_stream, ctx->scene.d, o4, d4, iv4, count,
             &f->p->counters->head[s][0], SHADOW ? (float4*)nullptr : f->p->hits, SHADOW ? f->p->rlog : (float4*)nullptr, f->log_stride,
             f->tl_spill, tune, f->tl_slow_list, &f->p->counters->slow_count[s], &f->p->counters->stack_spills, no_timeline, 0u);
     // The follow-up over the (normally empty) slow list: one wave per CU with a one-entry LDS stack (the rest of the stack
@@ -1268,11 +1268,11 @@ void launch_trace(rt_frame* f, const float4* o4, const float4* d4, const float4*
         {
             const char* e = getenv("RT_TRACE_AUTO_WIDE_VARIANT");
             const long v = e ? strtol(e, nullptr, 10) : 0;
-            return v >= 10 && v <= 14 ? (uint32_t)v : 10u;
+            return v >= 10 && v <= 15 ? (uint32_t)v : 10u;
         }();
         variant = paths >= 2000000ull ? wide_variant : 0u;
     }
-    if (variant >= 10u && variant <= 14u && !ctx->scene.wide_ok) variant = 8u;
+    if (variant >= 10u && variant <= 15u && !ctx->scene.wide_ok) variant = 8u;
     if ((variant == 8u || variant == 9u) && !ctx->scene.offsets32) variant = 3u;
     switch (variant)
     {
@@ -1296,6 +1296,7 @@ void launch_trace(rt_frame* f, const float4* o4, const float4* d4, const float4*
     case 12: launch_trace_w4<SHADOW, 13>(f, o4, d4, iv4, count); break;
     case 13: launch_trace_w4<SHADOW, 11>(f, o4, d4, iv4, count); break;
     case 14: launch_trace_w4<SHADOW, 10>(f, o4, d4, iv4, count); break;
+    case 15: launch_trace_w4<SHADOW, 12, true>(f, o4, d4, iv4, count); break;
     default: launch_trace_sm<SHADOW, 12>(f, o4, d4, iv4, count); break;
     }
 }

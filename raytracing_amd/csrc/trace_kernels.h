@@ -1051,7 +1051,13 @@ RT_DEV uint32_t spill_load32(const uint32_t* p)
     return v;
 }
 
-template <bool SHADOW, int STACK, bool TIMELINE = false>
+// DIRECT (RT_OPT_TRACE_VARIANT 15): of the slots that pass their box test the FIRST in visit order is visited next and only
+// the later ones go to the stack.  The plain form pushes positions 3..1 and visits position 0 if it passed -- with 1.2 of 4
+// slots passing per visit (tools/wide_walk_stats.py) the passing slot is usually not position 0, so it is written to the LDS
+// stack and popped right back: an LDS round trip in the middle of the ray's dependent chain.  Same sequence of nodes (an entry
+// popped right after its push always passes the pre-cull: entry <= exit <= t_max), checked on the CPU by the restatement in
+// oracle/oracle.c (tests/test_wide_traversal_oracle.py).
+template <bool SHADOW, int STACK, bool TIMELINE = false, bool DIRECT = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_trace_w4(DScene sc, const float4* __restrict__ o4, const float4* __restrict__ d4,
     const float4* __restrict__ iv4, const uint32_t* __restrict__ count_ptr, uint32_t* __restrict__ heads,
     float4* __restrict__ hits, float4* __restrict__ rlog, uint32_t log_stride, uint2* __restrict__ spill, uint32_t tune,
@@ -1370,12 +1376,28 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                     tr = sw0 ? r[2] : r[0]; r[2] = sw0 ? r[0] : r[2]; r[0] = tr;  te = sw0 ? e[2] : e[0]; e[2] = sw0 ? e[0] : e[2]; e[0] = te;
                     tr = sw0 ? r[3] : r[1]; r[3] = sw0 ? r[1] : r[3]; r[1] = tr;  te = sw0 ? e[3] : e[1]; e[3] = sw0 ? e[1] : e[3]; e[1] = te;
                 }
-                // visit position 0 next, positions 3..1 wait on the stack (deepest first)
-                if (e[3] < INF) push(r[3], e[3]);
-                if (e[2] < INF) push(r[2], e[2]);
-                if (e[1] < INF) push(r[1], e[1]);
-                if (e[0] < INF) ref = r[0];
-                else pop();
+                if (DIRECT)
+                {
+                    // the first passing position is visited next, the later ones wait on the stack (deepest first)
+                    const bool v0 = e[0] < INF, v1 = e[1] < INF, v2 = e[2] < INF, v3 = e[3] < INF;
+                    if (v3 && (v0 || v1 || v2)) push(r[3], e[3]);
+                    if (v2 && (v0 || v1)) push(r[2], e[2]);
+                    if (v1 && v0) push(r[1], e[1]);
+                    if (v0) ref = r[0];
+                    else if (v1) ref = r[1];
+                    else if (v2) ref = r[2];
+                    else if (v3) ref = r[3];
+                    else pop();
+                }
+                else
+                {
+                    // visit position 0 next, positions 3..1 wait on the stack (deepest first)
+                    if (e[3] < INF) push(r[3], e[3]);
+                    if (e[2] < INF) push(r[2], e[2]);
+                    if (e[1] < INF) push(r[1], e[1]);
+                    if (e[0] < INF) ref = r[0];
+                    else pop();
+                }
             }
             n_spills += (uint32_t)__popcll(__ballot(sp > (SHADOW ? 2 * STACK : STACK)));
         }

@@ -43,6 +43,7 @@ def load():
         "orc_wang_hash": (u32, [u32]), "orc_sample_random": (f32, [u32] * 5),
         "orc_tanf": (f32, [f32]), "orc_sinf": (f32, [f32]), "orc_cosf": (f32, [f32]),
         "orc_powf": (f32, [f32, f32]), "orc_atan2f": (f32, [f32, f32]), "orc_acosf": (f32, [f32]),
+        "orc_wide_trace": (C.c_int, [vp, vp, u32, u32, vp, u32, C.c_int, vp, vp, vp]),
     }
     for k, (res, args) in sig.items():
         f = getattr(lib, k)
@@ -137,6 +138,25 @@ class Oracle:
 
     def stage(self, name, *args):
         getattr(self.lib, "orc_stage_" + name)(self.handle, *args)
+
+    WIDE_COUNTERS = ("rays", "wide_visits", "leaf_arrivals", "leaf_box_fails", "triangle_tests", "pushes", "culled_pops",
+                     "deepest_stack", "rays_left_to_bvh2", "slots_passed")
+
+    def wide_trace(self, wide_records, entry_ref, rays, shadow, counters=None, direct=False):
+        """k_trace_w4's walk restated on the CPU (oracle.c: orc_wide_trace) over the records of rt_debug_wide_bvh, for the
+        rays given (records of types.ray).  Returns hits (types.hit) or, shadow, the shadow-hit words; adds to `counters`
+        (np.uint64[10], WIDE_COUNTERS) when given."""
+        rays = np.ascontiguousarray(rays)
+        wide = np.ascontiguousarray(wide_records)
+        cnt = counters if counters is not None else np.zeros(10, np.uint64)
+        hits = np.zeros(len(rays), np.dtype([("bc", "<f4", 2), ("primitive_id", "<u4"), ("t", "<f4")]))
+        sh = np.zeros(len(rays), np.uint32)
+        rc = self.lib.orc_wide_trace(self.handle, wide.ctypes.data if len(wide) else None, len(wide), entry_ref,
+                                     rays.ctypes.data if len(rays) else None, len(rays), int(bool(shadow)) | (2 if direct else 0), hits.ctypes.data, sh.ctypes.data,
+                                     cnt.ctypes.data)
+        if rc != 0:
+            raise RuntimeError("orc_wide_trace failed: %d" % rc)
+        return sh if shadow else hits
 
     def __del__(self):
         try:
