@@ -74,7 +74,7 @@ def test_production_launch_shape_matches_the_reference_kernels_bit_for_bit(make)
     ctx.close()
 
 
-@pytest.mark.parametrize("variant", [8, 10, 15])
+@pytest.mark.parametrize("variant", [8, 10])
 def test_deep_tree_spills_the_traversal_stack_to_hbm_and_stays_exact(variant, env_map):
     """65 536 large triangles stacked in depth along the view direction: every primary ray overlaps every box, so the
     descent to the first leaf pushes one far child per BVH2 level (16+ levels) -- more than the 10 / 12 entries the
