@@ -1241,8 +1241,12 @@ static inline float w_min3(float a, float b, float c) { return f_min(f_min(a, b)
 
 /* counters: 0 rays, 1 wide-node visits, 2 leaf arrivals, 3 leaf box tests failed, 4 triangle tests, 5 pushes,
  * 6 pops culled by their entry distance, 7 deepest stack, 8 rays left to the BVH2 walk, 9 slots that passed their box test */
-ORC_EXPORT int orc_wide_trace(void* h, const void* wide_records, uint32_t n_wide, uint32_t entry_ref, const rt_ray* rays,
-    uint32_t n_rays, int shadow, rt_hit* hits_out, uint32_t* shadow_out, uint64_t* counters)
+/* events (optional): per ray up to `stride` bytes, one per step of the walk in order -- 'N' a wide-node visit, 'L' a leaf
+ * arrival (exact box test + first triangle), 'T' a further triangle of that leaf -- and lengths[ray] = steps taken (may exceed
+ * stride: the tail is not recorded); what tools/wave_schedule_model.py replays lane by lane */
+static int wide_trace_impl(void* h, const void* wide_records, uint32_t n_wide, uint32_t entry_ref, const rt_ray* rays,
+    uint32_t n_rays, int shadow, rt_hit* hits_out, uint32_t* shadow_out, uint64_t* counters, uint8_t* events, uint32_t stride,
+    uint32_t* lengths)
 {
     orc* o = (orc*)h;
     const int direct = (shadow & 2) != 0;                                /* bit 1 of `shadow`: the direct form of the walk */
@@ -1265,6 +1269,9 @@ ORC_EXPORT int orc_wide_trace(void* h, const void* wide_records, uint32_t n_wide
         const v3 inv = V3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
         const uint32_t sign_bits = (inv.x < 0.0f ? 1u : 0u) | (inv.y < 0.0f ? 2u : 0u) | (inv.z < 0.0f ? 4u : 0u);
         counters[0]++;
+        uint32_t n_ev = 0;
+#define ORC_EVENT(c) do { if (events && n_ev < stride) events[(size_t)ri * stride + n_ev] = (uint8_t)(c); ++n_ev; } while (0)
+        if (lengths) lengths[ri] = 0;
         /* ray_inverse (kernels_common.h) + the origin test at the ray's start (k_trace_w4, phase A) */
         const float lim = 0x1p96f;
         const int slow = !(__builtin_fabsf(inv.x) < lim && __builtin_fabsf(inv.y) < lim && __builtin_fabsf(inv.z) < lim) ||
@@ -1290,6 +1297,7 @@ ORC_EXPORT int orc_wide_trace(void* h, const void* wide_records, uint32_t n_wide
                 /* B: the leaf's exact box with the CURRENT t_max (the reference's RayBounds on the leaf node), then its
                  * triangles in array order */
                 counters[2]++;
+                ORC_EVENT('L');
                 const uint32_t first = ref & ~ORC_LEAF_BIT;
                 const uint32_t leaf = first <= o->n_triangles ? leaf_of[first] : RT_INVALID_ID;
                 if (leaf == RT_INVALID_ID) { rc = 2; break; }
@@ -1300,6 +1308,7 @@ ORC_EXPORT int orc_wide_trace(void* h, const void* wide_records, uint32_t n_wide
                     for (uint32_t i = 0; i < np && !stop; ++i)
                     {
                         counters[4]++;
+                        if (i > 0) ORC_EVENT('T');
                         float u, v, t;
                         if (RayTriangle(org, dir, t_min, t_max, &o->triangles[first + i], &u, &v, &t))
                         {
@@ -1317,6 +1326,7 @@ ORC_EXPORT int orc_wide_trace(void* h, const void* wide_records, uint32_t n_wide
                 /* C: one wide node */
                 if (ref >= n_wide) { rc = 3; break; }
                 counters[1]++;
+                ORC_EVENT('N');
                 const orc_wide_node* n = &wn[ref];
                 const float cx = u2f((n->meta & 0xFFu) << 23), cy = u2f(((n->meta >> 8) & 0xFFu) << 23), cz = u2f(((n->meta >> 16) & 0xFFu) << 23);
                 const int nx = (sign_bits & 1u) != 0u, ny = (sign_bits & 2u) != 0u, nz = (sign_bits & 4u) != 0u;
@@ -1379,9 +1389,24 @@ ORC_EXPORT int orc_wide_trace(void* h, const void* wide_records, uint32_t n_wide
             }
         }
         if (shadow) shadow_out[ri] = shadow_hit; else hits_out[ri] = hit;
+        if (lengths) lengths[ri] = n_ev;
     }
+#undef ORC_EVENT
     free(leaf_of);
     return rc;
+}
+
+ORC_EXPORT int orc_wide_trace(void* h, const void* wide_records, uint32_t n_wide, uint32_t entry_ref, const rt_ray* rays,
+    uint32_t n_rays, int shadow, rt_hit* hits_out, uint32_t* shadow_out, uint64_t* counters)
+{
+    return wide_trace_impl(h, wide_records, n_wide, entry_ref, rays, n_rays, shadow, hits_out, shadow_out, counters, NULL, 0, NULL);
+}
+
+ORC_EXPORT int orc_wide_trace_events(void* h, const void* wide_records, uint32_t n_wide, uint32_t entry_ref, const rt_ray* rays,
+    uint32_t n_rays, int shadow, rt_hit* hits_out, uint32_t* shadow_out, uint64_t* counters, uint8_t* events, uint32_t stride,
+    uint32_t* lengths)
+{
+    return wide_trace_impl(h, wide_records, n_wide, entry_ref, rays, n_rays, shadow, hits_out, shadow_out, counters, events, stride, lengths);
 }
 
 /* known-answer access to the leaf functions (tests/test_oracle_kat.py) */

@@ -44,6 +44,7 @@ def load():
         "orc_tanf": (f32, [f32]), "orc_sinf": (f32, [f32]), "orc_cosf": (f32, [f32]),
         "orc_powf": (f32, [f32, f32]), "orc_atan2f": (f32, [f32, f32]), "orc_acosf": (f32, [f32]),
         "orc_wide_trace": (C.c_int, [vp, vp, u32, u32, vp, u32, C.c_int, vp, vp, vp]),
+        "orc_wide_trace_events": (C.c_int, [vp, vp, u32, u32, vp, u32, C.c_int, vp, vp, vp, vp, u32, vp]),
     }
     for k, (res, args) in sig.items():
         f = getattr(lib, k)
@@ -157,6 +158,22 @@ class Oracle:
         if rc != 0:
             raise RuntimeError("orc_wide_trace failed: %d" % rc)
         return sh if shadow else hits
+
+    def wide_trace_events(self, wide_records, entry_ref, rays, shadow, stride=192, direct=False):
+        """The step sequence of every ray's walk: (events uint8[n, stride] of b'N' / b'L' / b'T', lengths uint32[n])."""
+        rays = np.ascontiguousarray(rays)
+        wide = np.ascontiguousarray(wide_records)
+        cnt = np.zeros(10, np.uint64)
+        hits = np.zeros(len(rays), np.dtype([("bc", "<f4", 2), ("primitive_id", "<u4"), ("t", "<f4")]))
+        sh = np.zeros(len(rays), np.uint32)
+        ev = np.zeros((len(rays), stride), np.uint8)
+        ln = np.zeros(len(rays), np.uint32)
+        rc = self.lib.orc_wide_trace_events(self.handle, wide.ctypes.data if len(wide) else None, len(wide), entry_ref,
+                                            rays.ctypes.data if len(rays) else None, len(rays), int(bool(shadow)) | (2 if direct else 0),
+                                            hits.ctypes.data, sh.ctypes.data, cnt.ctypes.data, ev.ctypes.data, stride, ln.ctypes.data)
+        if rc != 0:
+            raise RuntimeError("orc_wide_trace_events failed: %d" % rc)
+        return ev, ln
 
     def __del__(self):
         try:
