@@ -20,7 +20,11 @@
  * appends (hit_surface.cl:138,173), so intermediate buffers compare directly.
  *
  * Extra (not in the reference): traversal counters n_nodes / n_tris per ray
- * class -- the "algorithmic bytes" inputs of SURVEY.md section 8(d).
+ * class -- the "algorithmic bytes" inputs of SURVEY.md section 8(d); the opt-in
+ * extensions of rt_scene_desc (marked where they appear); and, at the end of the
+ * file, orc_wide_trace: the HIP path's own 4-wide quantized walk (k_trace_w4)
+ * restated ray by ray, so that tests/test_wide_traversal_oracle.py can pin THAT
+ * algorithm to TraceOne below (= trace_bvh.cl:99-211) on the CPU.
  */
 #include <stdint.h>
 #include <stdlib.h>
