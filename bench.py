@@ -337,8 +337,6 @@ def main():
     ap.add_argument("--shade-partition", type=int, default=None, help="RT_OPT_SHADE_PARTITION (library default: 3)")
     ap.add_argument("--trace-waves", type=int, default=0, help="RT_OPT_TRACE_WAVES_PER_CU (0 = as many as fit)")
     ap.add_argument("--trace-variant", type=int, default=None, help="RT_OPT_TRACE_VARIANT (default: the library's automatic choice)")
-    ap.add_argument("--packet-bounces", type=lambda x: int(x, 0), default=None,
-                    help="RT_OPT_TRACE_PACKET_BOUNCES: closest | shadow << 8 bounce counts traced by the packet kernel (default 0)")
     ap.add_argument("--debug-shared-gpu", action="store_true",
                     help="plumbing test only: all ranks share GPU 0 and gather over gloo (RCCL refuses two ranks per device)")
     ap.add_argument("--plumbing-only", action="store_true", help="no GPU: launch, rendezvous, gather and report only")
@@ -427,8 +425,6 @@ def main():
         assert lib.rt_set_option(frame, capi.OPT_TRACE_WAVES, args.trace_waves) == 0
     if args.trace_variant is not None:
         assert lib.rt_set_option(frame, capi.OPT_TRACE_VARIANT, args.trace_variant) == 0
-    if args.packet_bounces is not None:
-        assert lib.rt_set_option(frame, capi.OPT_PACKET_BOUNCES, args.packet_bounces) == 0
     if args.path_state_gb > 0:
         assert lib.rt_set_option(frame, capi.OPT_PATH_STATE_LIMIT_MB, int(args.path_state_gb * 1024)) == 0
     in_flight = render.reserve_samples(max(spp_timed, spp_warm))

@@ -132,13 +132,13 @@ enum rt_option
                                   inputs only and rt_group_denoise runs it on the gathered image (the mode for tiles) */
     RT_OPT_TRACE_DROP_LAST_BOUNCE_RAYS = 5, /* 1 (default): do not emit the never-traced rays of the last bounce */
     RT_OPT_PROFILE_KERNELS = 6, /* 1: bracket every kernel launch with HIP events on the context stream */
-    RT_OPT_TRACE_VARIANT = 7    /* traversal kernel: 0 = v1 per-ray loop; 1 .. 4, 6, 7 = one-fetch-per-iteration
-                                   state machine with a 16 / 24 / 12 / 8, 10 / 11 entry LDS stack; 8 / 9 = k_trace2
-                                   (separate wave-uniform node / triangle / refill loops) with a 10+12 / 12+12 entry
-                                   stack (closest + shadow); 10 (11..14: other LDS stack sizes) = k_trace_w4 (4-wide quantized tree, exact leaf
-                                   re-test; rays it cannot take -- non-finite 1/dir -- go to k_trace2); 15 = k_trace_w4 visiting the first
-                                   passing slot directly instead of through the stack; 5 (default) = auto: 0 below 2 M paths
-                                   per launch, 10 above.  Results are identical for every value. */
+    RT_OPT_TRACE_VARIANT = 7    /* traversal kernel: 0 = k_trace_v1 (per-ray loop; tiny launches); 8 / 9 = k_trace2 (exact BVH2
+                                   walk in separate wave-uniform node / triangle / refill loops) with a 10+12 / 12+12 entry
+                                   LDS stack (closest + shadow); 10 (11: 16-entry LDS stack) = k_trace_w4 (4-wide quantized
+                                   tree, exact leaf re-test; rays it cannot take -- non-finite 1/dir -- go to k_trace2);
+                                   5 (default) = auto: k_trace_w4 wherever the tree qualifies.  Results are identical for
+                                   every value.  (1..4, 6, 7 -- round 1's flat state-machine kernel -- and 12..15 -- stack-size
+                                   sweeps and the direct-visit form, which now IS k_trace_w4 -- were removed in round 3.) */
     , RT_OPT_TRACE_WAVES_PER_CU = 8 /* persistent-grid size of the trace kernels in waves per CU (0 = as many as fit) */
     , RT_OPT_SAMPLES_IN_FLIGHT = 9  /* rt_integrate traces this many consecutive samples per pixel concurrently
                                        (1..1024, allocated at once; 0 = auto, the default: up to the largest power
@@ -149,12 +149,8 @@ enum rt_option
                                        slab test (trace_bvh.cl:85-97); by default only rays whose 1/dir has a
                                        non-finite component do (the only ones for which v_min/v_max_f32 could
                                        differ).  Results are identical for both values. */
-    , RT_OPT_TRACE_PACKET_BOUNCES = 11 /* closest-hit bounces below (value & 255) and shadow-ray bounces below
-                                       (value >> 8 & 255) are traced by the packet kernel: the 64
-                                       consecutive queue entries of a wave walk the tree together and node /
-                                       triangle records are fetched once per wave by the scalar unit.  Default 0
-                                       (off): it pays only for coherent rays over geometry coarser than a pixel.
-                                       Results are identical for every value. */
+    , RT_OPT_TRACE_PACKET_BOUNCES = 11 /* removed in round 3 (the packet kernel lost on every measured launch:
+                                       profiles/r02_packet_kernel_on_coherent_bounces.log); only 0 is accepted */
     , RT_OPT_DEBUG_ALLOC_LIMIT = 13 /* test hook: per-path buffer allocations for more than this many samples in flight
                                        fail as if the device were out of memory (0 = off) */
     , RT_OPT_PATH_STATE_LIMIT_MB = 14 /* upper bound (MiB) for the per-path buffers (ray queues + radiance log, 488 B per
@@ -177,10 +173,15 @@ enum rt_option
                                        (both sides depend on k_shade(b) only; the shadow queue is double-buffered), so the
                                        ~0.8 ms in which a launch's last rays drain does not idle the machine.
                                        0: every launch on one stream.  Results are identical for both values. */
+    , RT_OPT_SMALL_LAUNCH_PATHS = 18 /* the automatic kernel choice (RT_OPT_TRACE_VARIANT = 5) takes k_trace_v1 for batches of
+                                       fewer paths than this (default 2 000 000; 0 = always the wide-tree kernel).  Results are
+                                       identical for every value. */
     , RT_OPT_TRACE_TUNE = 12       /* k_trace2 (variants 8, 9) loop thresholds: value & 255 = lanes that must hold an
                                        interior node for a wave to stay in the node loop, value >> 8 & 255 = lanes that
                                        must wait at a triangle for another pass of the triangle loop, value >> 16 & 255 = rays a wave takes
-                                       from the queue per hand-out / 16 (k_trace_w4).  0 = defaults.
+                                       from the queue per hand-out / 16 (k_trace_w4), value >> 24 = the fewest rays per lane a wave of
+                                       the persistent grid is started for (k_trace_w4: the grid follows the live queue counter, the
+                                       reference's "@TODO: use indirect dispatch"; 255 = every wave).  0 in a field = its default.
                                        Results are identical for every value. */
 };
 int rt_set_option(rt_frame* frame, int option, uint32_t value);
@@ -280,6 +281,10 @@ int rt_group_join(int nranks, int rank, const void* id_bytes, int device_ordinal
 int rt_group_size(rt_group* group);                     /* ranks in the group */
 int rt_group_local_count(rt_group* group);              /* ranks living in this process */
 int rt_group_local_rank(rt_group* group, int i);        /* global rank of local member i */
+/* What RCCL reports for the communicator of local member i: *comm_ranks = ncclCommCount, *comm_user_rank =
+ * ncclCommUserRank (either may be NULL).  rt_group_size echoes the caller's argument; this is the library's own
+ * count, the evidence that the gather really spans N ranks.  A local group (no RCCL) reports 0 / -1. */
+int rt_group_comm_count(rt_group* group, int i, int* comm_ranks, int* comm_user_rank);
 /* frames[i] = the frame of local member i (its tile_rank must be that member's rank, tile_count the group
  * size).  On the process that owns `root`: host_rgba (may be NULL) receives height x width RGBA32F running
  * sums in image order, *device_rgba (may be NULL) the device copy of the same (valid until the next gather).

@@ -63,11 +63,11 @@ EXPORTS = [
     "rt_frame_resolve", "rt_frame_read_radiance", "rt_frame_radiance_device_ptr", "rt_frame_sample_count",
     "rt_frame_get_stats", "rt_frame_get_profile", "rt_frame_copy_radiance", "rt_frame_debug_read_queue", "rt_frame_debug_read_hits", "rt_debug_eval",
     "rt_debug_wide_bvh", "rt_frame_debug_timeline",
-    "rt_group_create", "rt_group_unique_id", "rt_group_join", "rt_group_size", "rt_group_local_count", "rt_group_local_rank",
+    "rt_group_create", "rt_group_unique_id", "rt_group_join", "rt_group_size", "rt_group_local_count", "rt_group_local_rank", "rt_group_comm_count",
     "rt_group_gather_radiance", "rt_group_destroy", "rt_group_last_error", "rt_group_denoise", "rt_group_create_local",
 ]
 
-OPT_MAX_BOUNCES, OPT_WHITE_FURNACE, OPT_SAMPLER, OPT_AOV, OPT_DENOISER, OPT_DROP_LAST, OPT_PROFILE, OPT_TRACE_VARIANT, OPT_TRACE_WAVES, OPT_SAMPLES_IN_FLIGHT, OPT_SELECT_FORM_BOX, OPT_PACKET_BOUNCES, OPT_TRACE_TUNE, OPT_DEBUG_ALLOC_LIMIT, OPT_PATH_STATE_LIMIT_MB, OPT_PIPELINES, OPT_SHADE_PARTITION, OPT_OVERLAP_SHADOW = range(18)
+OPT_MAX_BOUNCES, OPT_WHITE_FURNACE, OPT_SAMPLER, OPT_AOV, OPT_DENOISER, OPT_DROP_LAST, OPT_PROFILE, OPT_TRACE_VARIANT, OPT_TRACE_WAVES, OPT_SAMPLES_IN_FLIGHT, OPT_SELECT_FORM_BOX, OPT_PACKET_BOUNCES, OPT_TRACE_TUNE, OPT_DEBUG_ALLOC_LIMIT, OPT_PATH_STATE_LIMIT_MB, OPT_PIPELINES, OPT_SHADE_PARTITION, OPT_OVERLAP_SHADOW, OPT_SMALL_LAUNCH_PATHS = range(19)
 
 
 def load():
@@ -112,6 +112,7 @@ def load():
         "rt_group_create": (i32, [i32, C.POINTER(i32), C.POINTER(vp)]), "rt_group_unique_id": (i32, [vp, sz]),
         "rt_group_join": (i32, [i32, i32, vp, i32, C.POINTER(vp)]), "rt_group_size": (i32, [vp]),
         "rt_group_local_count": (i32, [vp]), "rt_group_local_rank": (i32, [vp, i32]),
+        "rt_group_comm_count": (i32, [vp, i32, C.POINTER(i32), C.POINTER(i32)]),
         "rt_group_gather_radiance": (i32, [vp, C.POINTER(vp), i32, vp, C.POINTER(vp)]), "rt_group_destroy": (i32, [vp]),
         "rt_group_last_error": (C.c_char_p, [vp]),
         "rt_group_denoise": (i32, [vp, C.POINTER(vp), i32, vp, vp]), "rt_group_create_local": (i32, [i32, i32, C.POINTER(vp)]),
@@ -371,6 +372,14 @@ class Group:
 
     def local_ranks(self):
         return [self.lib.rt_group_local_rank(self.handle, i) for i in range(self.lib.rt_group_local_count(self.handle))]
+
+    def comm_count(self, i=0):
+        """(ncclCommCount, ncclCommUserRank) of local member i's communicator -- RCCL's own word on how many ranks the
+        gather spans; (0, -1) for a local group (device copies, no RCCL)."""
+        n, r = C.c_int(0), C.c_int(-1)
+        if self.lib.rt_group_comm_count(self.handle, i, C.byref(n), C.byref(r)) != 0:
+            raise RtError(self.lib.rt_group_last_error(self.handle).decode())
+        return n.value, r.value
 
     def gather_radiance(self, frame_handles, root, height, width, want_host=True):
         """frame_handles: rt_frame* of the local members, in member order.  Returns the image (numpy,

@@ -23,6 +23,8 @@ struct RcclApi
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
     ncclResult_t (*Gather)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
@@ -47,6 +49,8 @@ RcclApi& rccl()
         api.CommInitRank = (decltype(api.CommInitRank))sym("ncclCommInitRank");
         api.CommInitAll = (decltype(api.CommInitAll))sym("ncclCommInitAll");
         api.CommDestroy = (decltype(api.CommDestroy))sym("ncclCommDestroy");
+        api.CommCount = (decltype(api.CommCount))sym("ncclCommCount");
+        api.CommUserRank = (decltype(api.CommUserRank))sym("ncclCommUserRank");
         api.Gather = (decltype(api.Gather))sym("ncclGather");
         api.GroupStart = (decltype(api.GroupStart))sym("ncclGroupStart");
         api.GroupEnd = (decltype(api.GroupEnd))sym("ncclGroupEnd");
@@ -209,6 +213,27 @@ int rt_group_join(int nranks, int rank, const void* id_bytes, int device_ordinal
 }
 
 int rt_group_size(rt_group* g) { return g ? g->nranks : 0; }
+
+// What RCCL itself says about the communicator of local member i: ncclCommCount (ranks) and ncclCommUserRank.  This is the
+// proof that the collective spans the ranks the caller believes it does (rt_group_size only echoes the caller's argument).
+// A local group (rt_group_create_local: device copies, no RCCL) reports 0 ranks.
+int rt_group_comm_count(rt_group* g, int i, int* comm_ranks, int* comm_user_rank)
+{
+    if (!g || i < 0 || i >= (int)g->members.size()) return gfail(g, "rt_group_comm_count: bad argument");
+    if (comm_ranks) *comm_ranks = 0;
+    if (comm_user_rank) *comm_user_rank = -1;
+    if (g->local) return RT_OK;
+    RcclApi& api = rccl();
+    if (!api.error.empty()) return gfail(g, "rt_group_comm_count: " + api.error);
+    rt_group::Member& m = g->members[(size_t)i];
+    int n = 0, r = -1;
+    ncclResult_t e = api.CommCount(m.comm, &n);
+    if (e == ncclSuccess) e = api.CommUserRank(m.comm, &r);
+    if (e != ncclSuccess) return gfail(g, std::string("rt_group_comm_count: ") + api.GetErrorString(e));
+    if (comm_ranks) *comm_ranks = n;
+    if (comm_user_rank) *comm_user_rank = r;
+    return RT_OK;
+}
 int rt_group_local_count(rt_group* g) { return g ? (int)g->members.size() : 0; }
 int rt_group_local_rank(rt_group* g, int i) { return g && i >= 0 && i < (int)g->members.size() ? g->members[(size_t)i].rank : -1; }
 
@@ -392,14 +417,22 @@ int rt_group_denoise(rt_group* g, rt_frame* const* frames, int root, float* host
             const uint64_t n = (uint64_t)width * height;
             if (g->dn_pixels != n)
             {
-                for (void* p : {(void*)g->dn_radiance, (void*)g->dn_depth, (void*)g->dn_velocity, (void*)g->dn_prev_radiance,
-                         (void*)g->dn_prev_depth, (void*)g->dn_resolved})
-                    if (p) (void)hipFree(p);
+                auto free_dn = [&]()
+                {
+                    for (void** p : {(void**)&g->dn_radiance, (void**)&g->dn_depth, (void**)&g->dn_velocity, (void**)&g->dn_prev_radiance,
+                             (void**)&g->dn_prev_depth, (void**)&g->dn_resolved})
+                    {
+                        if (*p) (void)hipFree(*p);
+                        *p = nullptr;                                       // never freed twice, whatever fails below
+                    }
+                    g->dn_pixels = 0;
+                };
+                free_dn();
                 bool ok = hipMalloc((void**)&g->dn_radiance, n * 16) == hipSuccess && hipMalloc((void**)&g->dn_depth, n * 4) == hipSuccess &&
                           hipMalloc((void**)&g->dn_velocity, n * 8) == hipSuccess && hipMalloc((void**)&g->dn_prev_radiance, n * 16) == hipSuccess &&
                           hipMalloc((void**)&g->dn_prev_depth, n * 4) == hipSuccess && hipMalloc((void**)&g->dn_resolved, n * 16) == hipSuccess;
                 ok = ok && hipMemsetAsync(g->dn_prev_radiance, 0, n * 16, s) == hipSuccess && hipMemsetAsync(g->dn_prev_depth, 0, n * 4, s) == hipSuccess;
-                if (!ok) { g->dn_pixels = 0; (void)hipGetLastError(); return gfail(g, "rt_group_denoise: out of device memory"); }
+                if (!ok) { free_dn(); (void)hipGetLastError(); return gfail(g, "rt_group_denoise: out of device memory"); }
                 g->dn_pixels = n;
             }
             const dim3 grid((uint32_t)((n + 255u) / 256u)), block(256);

@@ -29,6 +29,10 @@ struct Scene
     uint32_t n_wide = 0;      // wide nodes (0 with a leaf root)
     bool wide_ok = false;     // build_wide_bvh succeeded (k_trace_w4 usable)
     bool offsets32 = false;   // node and trace-triangle arrays below 4 GiB: k_trace2 addresses them with 32-bit byte offsets
+    // a quarter or more of the shadow rays will have a non-finite 1/dir component (directional lights along a coordinate
+    // axis, e.g. an overhead light (0, -1, 0)): k_trace_w4 would hand every one of them to its small follow-up launch,
+    // so the automatic choice traces the shadow queue with k_trace2 (select-form slab test inline, full residency)
+    bool slow_shadow = false;
 };
 } // namespace
 
@@ -110,8 +114,8 @@ struct rt_frame
     bool fused = false;            // inside rt_integrate: whole samples, nothing reads the radiance between stages
     uint32_t trace_blocks;       // v1 grid
     uint32_t trace_variant = 5;  // RT_OPT_TRACE_VARIANT (5 = auto)
+    uint64_t small_launch_paths = 2000000ull;   // auto: batches with fewer paths take k_trace_v1 (RT_OPT_SMALL_LAUNCH_PATHS)
     uint32_t trace_waves_per_cu = 0;   // RT_OPT_TRACE_WAVES_PER_CU (0 = LDS-limited residency)
-    uint32_t packet_bounces = 0;       // RT_OPT_TRACE_PACKET_BOUNCES: closest | shadow << 8 bounce counts for k_trace_packet
     uint32_t select_form_box = 0;      // RT_OPT_TRACE_SELECT_FORM_BOX: every ray takes the select-form slab test
     uint32_t trace_tune = 0;           // RT_OPT_TRACE_TUNE: k_trace2 loop thresholds (0 = defaults)
     uint32_t timeline = 0;             // rt_frame_debug_timeline armed: k_trace_w4<closest> records its launch timeline
@@ -407,6 +411,8 @@ bool build_wide_bvh(const rt_bvh_node* nodes, uint32_t nn, std::vector<WideNode>
         todo.pop_back();
         depth_of.pop_back();
         if (depth > 33u) return false;                                     // <= 3 pending slots per level must fit RT_W4_STACK_MAX
+        // a node reached twice (several parents share a child) is not a tree: the walk below would append once per PATH
+        if (wide_of[n] != RT_EMPTY_REF || order.size() >= nn) return false;
         wide_of[n] = (uint32_t)order.size();
         order.push_back(n);
         uint32_t slot[4], axes[3];
@@ -570,6 +576,20 @@ int rt_scene_upload(rt_ctx* ctx, const rt_scene_desc* sd)
         lights[(size_t)i * 3 + 1] = make_float4(l.radiance.x, l.radiance.y, l.radiance.z, 0.0f);
         lights[(size_t)i * 3 + 2] = make_float4(ft, 0.0f, 0.0f, 0.0f);
     }
+    {
+        // shadow rays towards a directional light all share its direction (light.h:57-61: origin * 20000, normalised again
+        // by HitSurface): a zero or tiny component makes 1/dir non-finite (RT_SIGN_SLOW) for every one of them
+        uint32_t slow_lights = 0;
+        for (uint32_t i = 0; i < sd->num_lights; ++i)
+        {
+            const rt_light& l = sd->lights[i];
+            if (l.type == RT_LIGHT_TYPE_POINT) continue;
+            const double len = std::sqrt((double)l.origin.x * l.origin.x + (double)l.origin.y * l.origin.y + (double)l.origin.z * l.origin.z);
+            const double lim = len * 0x1p-95;
+            if (!(std::fabs((double)l.origin.x) > lim && std::fabs((double)l.origin.y) > lim && std::fabs((double)l.origin.z) > lim)) ++slow_lights;
+        }
+        s.slow_shadow = slow_lights != 0 && 4u * slow_lights >= sd->num_lights;
+    }
     for (uint32_t i = 0; i < sd->num_materials; ++i)
     {
         // every 8-bit texture slot of a packed material: 0xFF = none (constants.h:35), else an index into textures
@@ -690,6 +710,13 @@ namespace
 {
 void free_path_buffers(rt_frame* f)
 {
+    // a shadow trace may still be running on a pipe's side stream (rt_integrate overlaps it with the next bounce, and an
+    // rt_integrate that failed mid-bounce never waited for it): nothing is freed under it
+    for (PathPipe& q : f->ps)
+    {
+        if (q.side) (void)hipStreamSynchronize(q.side);
+        q.shadow_in_flight[0] = q.shadow_in_flight[1] = false;
+    }
     for (PathPipe& q : f->ps)
     {
         void* ptrs[] = {q.o4[0], q.o4[1], q.d4[0], q.d4[1], q.iv4[0], q.iv4[1], q.thr[0], q.thr[1], q.hits, q.sh_o4[0], q.sh_d4[0],
@@ -864,6 +891,7 @@ int ensure_pipe_resources(rt_frame* f, uint32_t count)
 }
 
 int flush_log(rt_frame* f);
+int ensure_whole_tile(rt_frame* f);
 
 // The main stream of the current pipe waits for the shadow trace that last used shadow queue `q` (rt_integrate runs
 // those on PathPipe::side); nothing to do when none is outstanding.
@@ -896,6 +924,18 @@ int ensure_slots(rt_frame* f, uint32_t want)
         f->slots_limit = n;
     }
     return RT_OK;
+}
+
+// The stage API and the per-frame features (AOVs, denoiser) trace ONE sample of the WHOLE tile.  The buffers may have
+// been cut into chunks for an earlier, larger batch under RT_OPT_PATH_STATE_LIMIT_MB (ensure_slots keeps an allocation
+// that is large enough in SLOTS): re-allocate for one sample in flight, which the caller has checked does fit.
+int ensure_whole_tile(rt_frame* f)
+{
+    if (f->chunk_pixels >= (f->n_local ? f->n_local : 1u)) return RT_OK;
+    if (f->p->cur_slots != 0) return fail(f->ctx, "rt_generate_rays: the previous sample was not advanced (rt_advance_sample)");
+    if (flush_log(f) != RT_OK || join_pipes(f) != RT_OK) return RT_ERROR;
+    HIPCHK(f->ctx, hipStreamSynchronize(f->ctx->stream));
+    return alloc_path_buffers(f, 1);
 }
 
 // Adds the logged contributions of the batch in flight to the running sum.
@@ -988,7 +1028,11 @@ int rt_frame_destroy(rt_frame* f)
 {
     if (!f) return RT_OK;
     (void)hipSetDevice(f->ctx->device);
-    for (PathPipe& q : f->ps) if (q.stream) (void)hipStreamSynchronize(q.stream);
+    for (PathPipe& q : f->ps)
+    {
+        if (q.stream) (void)hipStreamSynchronize(q.stream);
+        if (q.side) (void)hipStreamSynchronize(q.side);
+    }
     (void)hipStreamSynchronize(f->ctx->stream);
     free_path_buffers(f);
     void* ptrs[] = {f->radiance, f->resolved, f->aov_buf.diffuse_albedo, f->aov_buf.depth,
@@ -1078,7 +1122,9 @@ int rt_set_option(rt_frame* f, int option, uint32_t value)
     case RT_OPT_TRACE_DROP_LAST_BOUNCE_RAYS: f->drop_last = value ? 1 : 0; return RT_OK;
     case RT_OPT_PROFILE_KERNELS: f->profile = value ? 1 : 0; return RT_OK;
     case RT_OPT_TRACE_WAVES_PER_CU: f->trace_waves_per_cu = value; return RT_OK;
-    case RT_OPT_TRACE_PACKET_BOUNCES: f->packet_bounces = value; return RT_OK;
+    case RT_OPT_TRACE_PACKET_BOUNCES:
+        if (value != 0) return fail(f->ctx, "rt_set_option: the packet kernel was removed (RT_OPT_TRACE_PACKET_BOUNCES accepts only 0)");
+        return RT_OK;
     case RT_OPT_TRACE_SELECT_FORM_BOX: f->select_form_box = value ? RT_SIGN_SLOW : 0u; return RT_OK;
     case RT_OPT_TRACE_TUNE: f->trace_tune = value; return RT_OK;
     case RT_OPT_SHADE_PARTITION: f->shade_partition = value & 3u; return RT_OK;
@@ -1110,8 +1156,9 @@ int rt_set_option(rt_frame* f, int option, uint32_t value)
         }
         return RT_OK;
     case RT_OPT_DEBUG_ALLOC_LIMIT: f->debug_alloc_limit = value; return RT_OK;
+    case RT_OPT_SMALL_LAUNCH_PATHS: f->small_launch_paths = value; return RT_OK;
     case RT_OPT_TRACE_VARIANT:
-        if (value > 15) return fail(f->ctx, "rt_set_option: unknown trace kernel variant");
+        if (!(value == 0 || value == 5 || (value >= 8 && value <= 11))) return fail(f->ctx, "rt_set_option: unknown trace kernel variant (0, 5, 8..11)");
         f->trace_variant = value;
         return RT_OK;
     default: return fail(f->ctx, "rt_set_option: unknown option");
@@ -1160,25 +1207,10 @@ struct KernelSpan
 
 namespace
 {
-// Trace kernel variants (RT_OPT_TRACE_VARIANT): 0 = v1 (per-ray loop, 24-entry LDS
-// stack); 1..4 = the one-fetch-per-iteration state machine with a 16 / 24 / 12 / 8
-// entry LDS stack (deeper entries spill to HBM).  One-wave blocks; the persistent
-// grid is sized to the LDS-limited residency: 160 KiB / (entries * 512 B) per CU.
-template <bool SHADOW, int STACK>
-void launch_trace_sm(rt_frame* f, const float4* o4, const float4* d4, const float4* iv4, const uint32_t* count)
-{
-    rt_ctx* ctx = f->ctx;
-    uint32_t per_cu = (160u * 1024u) / (STACK * 512u);
-    if (per_cu > 32u) per_cu = 32u;
-    if (f->trace_waves_per_cu && f->trace_waves_per_cu < per_cu) per_cu = f->trace_waves_per_cu;
-    uint32_t blocks = ((uint32_t)ctx->prop.multiProcessorCount * per_cu + 7u) & ~7u;
-    hipLaunchKernelGGL((k_trace<SHADOW, STACK>), dim3(blocks), dim3(64), 0, f->tl_stream, ctx->scene.d, o4, d4, iv4, count,
-        &f->p->counters->head[f->tl_flavour][0], SHADOW ? (float4*)nullptr : f->p->hits,
-        SHADOW ? f->p->rlog : (float4*)nullptr, f->log_stride, f->select_form_box, f->tl_spill);
-}
-
-// k_trace2: separate wave-uniform loops (trace_kernels.h).  Same grid sizing as launch_trace_sm.
+// k_trace2: separate wave-uniform loops (trace_kernels.h).  One-wave blocks; the persistent grid is sized to the
+// LDS-limited residency: 160 KiB / (entries * 512 B) per CU.
 #define RT_TRACE2_DEFAULT_TUNE (32u | (8u << 8))     // profiles/r02_ktrace2_tune_sweep.log, r02_w4_tune_sweep.log
+#define RT_W4_DEFAULT_RAYS_PER_LANE 0u               // k_trace_w4's live-counter grid (trace_kernels.h); 0 = every wave
 template <bool SHADOW, int STACK>
 void launch_trace2(rt_frame* f, const float4* o4, const float4* d4, const float4* iv4, const uint32_t* count)
 {
@@ -1197,7 +1229,7 @@ void launch_trace2(rt_frame* f, const float4* o4, const float4* d4, const float4
 }
 
 // k_trace_w4 over the 4-wide quantized tree, then k_trace2 over the (normally empty) list of rays it left out
-template <bool SHADOW, int STACK, bool DIRECT = false>
+template <bool SHADOW, int STACK>
 void launch_trace_w4(rt_frame* f, const float4* o4, const float4* d4, const float4* iv4, const uint32_t* count)
 {
     rt_ctx* ctx = f->ctx;
@@ -1205,9 +1237,14 @@ void launch_trace_w4(rt_frame* f, const float4* o4, const float4* d4, const floa
     if (per_cu > 32u) per_cu = 32u;
     if (f->trace_waves_per_cu && f->trace_waves_per_cu < per_cu) per_cu = f->trace_waves_per_cu;
     uint32_t blocks = ((uint32_t)ctx->prop.multiProcessorCount * per_cu + 7u) & ~7u;
-    uint32_t tune = f->trace_tune ? f->trace_tune : RT_TRACE2_DEFAULT_TUNE;
-    if ((tune & 0xFFu) > 64u) tune = (tune & ~0xFFu) | 64u;
-    if ((tune & 0xFFu) == 0u) tune |= 1u;
+    // RT_OPT_TRACE_TUNE, field by field (0 = that field's default)
+    const uint32_t t = f->trace_tune;
+    uint32_t node_q = (t & 0xFFu) ? (t & 0xFFu) : (RT_TRACE2_DEFAULT_TUNE & 0xFFu);
+    const uint32_t leaf_q = ((t >> 8) & 0xFFu) ? ((t >> 8) & 0xFFu) : ((RT_TRACE2_DEFAULT_TUNE >> 8) & 0xFFu);
+    if (node_q > 64u) node_q = 64u;
+    uint32_t rays_per_lane = (t >> 24) ? (t >> 24) : RT_W4_DEFAULT_RAYS_PER_LANE;
+    if (rays_per_lane == 255u) rays_per_lane = 0u;                          // 255 = every wave of the residency-sized grid
+    const uint32_t tune = node_q | leaf_q << 8 | (t & 0xFF0000u) | rays_per_lane << 24;
     const uint32_t s = f->tl_flavour;
     unsigned long long* const no_timeline = nullptr;
     if (!SHADOW && STACK == 12 && f->timeline)          // tools/launch_timeline.py: the instrumented instance
@@ -1216,35 +1253,22 @@ void launch_trace_w4(rt_frame* f, const float4* o4, const float4* d4, const floa
             &f->p->counters->slow_count[s], &f->p->counters->stack_spills, &f->p->counters->tl_start[f->timeline_bounce & 63u],
             f->timeline_bounce & 63u);
     else
-        hipLaunchKernelGGL((k_trace_w4<SHADOW, STACK, false, DIRECT>), dim3(blocks), dim3(64), 0, f->tl_stream, ctx->scene.d, o4, d4, iv4, count,
+        hipLaunchKernelGGL((k_trace_w4<SHADOW, STACK, false>), dim3(blocks), dim3(64), 0, f->tl_stream, ctx->scene.d, o4, d4, iv4, count,
             &f->p->counters->head[s][0], SHADOW ? (float4*)nullptr : f->p->hits, SHADOW ? f->p->rlog : (float4*)nullptr, f->log_stride,
             f->tl_spill, tune, f->tl_slow_list, &f->p->counters->slow_count[s], &f->p->counters->stack_spills, no_timeline, 0u);
-    // The follow-up over the (normally empty) slow list: one wave per CU with a one-entry LDS stack (the rest of the stack
-    // lives in the spill area) -- 512 bytes of LDS and a few registers, so it finds room beside the resident waves of the
+    // The follow-up over the (normally empty) slow list: waves with a two-entry LDS stack (the rest of the stack
+    // lives in the spill area) -- 1 KiB of LDS and a few registers, so it finds room beside the resident waves of the
     // OTHER stream's persistent launch (RT_OPT_OVERLAP_SHADOW) instead of waiting for that launch to end: with the
     // 6 KiB blocks of the ordinary k_trace2 the closest-hit follow-up sat 2.8 ms on average behind the shadow trace
     // (profiles/r02_final_rocprofv3_kernel_stats_overlap.csv) with k_shade queued behind it.
-    uint32_t blocks2 = ((uint32_t)ctx->prop.multiProcessorCount + 7u) & ~7u;
-    hipLaunchKernelGGL((k_trace2<SHADOW, 1>), dim3(blocks2), dim3(64), 0, f->tl_stream, ctx->scene.d, o4, d4, iv4,
+    // Four such waves per CU (4 KiB of LDS beside the other launch's 26 x 6 KiB): with an empty list they leave at once;
+    // with a long one (every shadow ray towards an axis-aligned point-light arrangement, say) the list is not serialised
+    // onto one wave per CU.  Scenes whose directional lights make MOST shadow rays slow never get here (Scene::slow_shadow).
+    uint32_t blocks2 = ((uint32_t)ctx->prop.multiProcessorCount * 4u + 7u) & ~7u;
+    hipLaunchKernelGGL((k_trace2<SHADOW, 2>), dim3(blocks2), dim3(64), 0, f->tl_stream, ctx->scene.d, o4, d4, iv4,
         (const uint32_t*)&f->p->counters->slow_count[s], &f->p->counters->slow_head[s][0], SHADOW ? (float4*)nullptr : f->p->hits,
-        SHADOW ? f->p->rlog : (float4*)nullptr, f->log_stride, f->select_form_box, f->tl_spill, tune, (const uint32_t*)f->tl_slow_list,
+        SHADOW ? f->p->rlog : (float4*)nullptr, f->log_stride, f->select_form_box, f->tl_spill, tune & 0xFFFFu, (const uint32_t*)f->tl_slow_list,
         &f->p->counters->stack_spills);
-}
-
-// Coherent launches (primary rays): packet traversal, node records through the scalar cache.
-// Measured (profiles/r01_packet_kernel_experiment.log): 1.19x on the primary rays of the
-// city-block scene, but slower where triangles are smaller than a pixel's footprint (the 64
-// samples of a pixel part ways in the bottom levels) -- hence opt-in.  One-wave blocks, 1 KiB of LDS each: residency is register-bound.
-template <bool SHADOW>
-void launch_trace_packet(rt_frame* f, const float4* o4, const float4* d4, const float4* iv4, const uint32_t* count)
-{
-    rt_ctx* ctx = f->ctx;
-    uint32_t per_cu = f->trace_waves_per_cu ? f->trace_waves_per_cu : 32u;
-    if (per_cu > 32u) per_cu = 32u;
-    uint32_t blocks = ((uint32_t)ctx->prop.multiProcessorCount * per_cu + 7u) & ~7u;
-    hipLaunchKernelGGL((k_trace_packet<SHADOW>), dim3(blocks), dim3(64), 0, f->tl_stream, ctx->scene.d, o4, d4, iv4, count,
-        &f->p->counters->head[f->tl_flavour][0], SHADOW ? (float4*)nullptr : f->p->hits,
-        SHADOW ? f->p->rlog : (float4*)nullptr, f->log_stride, f->select_form_box);
 }
 
 template <bool SHADOW>
@@ -1252,28 +1276,22 @@ void launch_trace(rt_frame* f, const float4* o4, const float4* d4, const float4*
     uint32_t bounce)
 {
     rt_ctx* ctx = f->ctx;
-    if (bounce < ((f->packet_bounces >> (SHADOW ? 8 : 0)) & 0xFFu)) { launch_trace_packet<SHADOW>(f, o4, d4, iv4, count); return; }
+    (void)bounce;
     uint32_t variant = f->trace_variant;
     if (variant == 5)
     {
-        // auto: with few rays per launch (one or two samples of a 720p frame in flight, the
-        // interactive RenderFrame() case) every lane gets only ~3 rays and the per-ray loop of
-        // v1 wins (measured 770 vs 600 Mrays/s, profiles/r01_variants_3_samples_in_flight.log); from
-        // ~2 M paths up the persistent kernels win, and of those the 4-wide quantized tree:
-        // 4214 (k_trace) / 4400 (k_trace2) / 5042 (k_trace_w4) Mrays/s on the headline workload
-        // (profiles/r02_w4_tune_sweep.log)
-        uint64_t paths = (uint64_t)f->p->chunk_count * (f->p->cur_slots ? f->p->cur_slots : 1u);
-        // (RT_TRACE_AUTO_WIDE_VARIANT in the environment picks another k_trace_w4 instance: A/B runs of whole suites)
-        static const uint32_t wide_variant = []() -> uint32_t
-        {
-            const char* e = getenv("RT_TRACE_AUTO_WIDE_VARIANT");
-            const long v = e ? strtol(e, nullptr, 10) : 0;
-            return v >= 10 && v <= 15 ? (uint32_t)v : 10u;
-        }();
-        variant = paths >= 2000000ull ? wide_variant : 0u;
+        // auto: the 4-wide quantized tree wherever it was built -- 4214 (round 1's k_trace) / 4400 (k_trace2) / 5042
+        // (k_trace_w4) Mrays/s on the headline workload when it was introduced (profiles/r02_w4_tune_sweep.log).
+        // Scenes whose directional lights make most shadow rays "slow" (Scene::slow_shadow) trace the shadow queue with
+        // k_trace2, which handles such rays inline.
+        variant = (SHADOW && ctx->scene.slow_shadow) ? 8u : 10u;
+        // with few rays per launch (one or two samples of a 720p frame in flight) the per-ray loop of v1 won in round 1
+        // (770 vs 600 Mrays/s, profiles/r01_variants_3_samples_in_flight.log)
+        const uint64_t paths = (uint64_t)f->p->chunk_count * (f->p->cur_slots ? f->p->cur_slots : 1u);
+        if (paths < f->small_launch_paths) variant = 0u;
     }
-    if (variant >= 10u && variant <= 15u && !ctx->scene.wide_ok) variant = 8u;
-    if ((variant == 8u || variant == 9u) && !ctx->scene.offsets32) variant = 3u;
+    if ((variant == 10u || variant == 11u) && !ctx->scene.wide_ok) variant = 8u;
+    if ((variant == 8u || variant == 9u) && !ctx->scene.offsets32) variant = 0u;
     switch (variant)
     {
     case 0:
@@ -1281,23 +1299,13 @@ void launch_trace(rt_frame* f, const float4* o4, const float4* d4, const float4*
             (f->trace_waves_per_cu < 13u ? f->trace_waves_per_cu : 13u) + 7u) & ~7u) : f->trace_blocks), dim3(64), 0, f->tl_stream, ctx->scene.d, o4, d4,
             iv4, count, SHADOW ? (float4*)nullptr : f->p->hits, SHADOW ? f->p->rlog : (float4*)nullptr, f->log_stride, f->select_form_box, f->tl_spill);
         break;
-    case 1: launch_trace_sm<SHADOW, 16>(f, o4, d4, iv4, count); break;
-    case 2: launch_trace_sm<SHADOW, 24>(f, o4, d4, iv4, count); break;
-    case 4: launch_trace_sm<SHADOW, 8>(f, o4, d4, iv4, count); break;
-    case 6: launch_trace_sm<SHADOW, 10>(f, o4, d4, iv4, count); break;
-    case 7: launch_trace_sm<SHADOW, 11>(f, o4, d4, iv4, count); break;
     case 8:
         if (!SHADOW && ctx->scene.d.entry_ref < 4000000u) launch_trace2<SHADOW, 10>(f, o4, d4, iv4, count);
         else launch_trace2<SHADOW, 12>(f, o4, d4, iv4, count);
         break;
     case 9: launch_trace2<SHADOW, 12>(f, o4, d4, iv4, count); break;
-    case 10: launch_trace_w4<SHADOW, 12>(f, o4, d4, iv4, count); break;
     case 11: launch_trace_w4<SHADOW, 16>(f, o4, d4, iv4, count); break;
-    case 12: launch_trace_w4<SHADOW, 13>(f, o4, d4, iv4, count); break;
-    case 13: launch_trace_w4<SHADOW, 11>(f, o4, d4, iv4, count); break;
-    case 14: launch_trace_w4<SHADOW, 10>(f, o4, d4, iv4, count); break;
-    case 15: launch_trace_w4<SHADOW, 12, true>(f, o4, d4, iv4, count); break;
-    default: launch_trace_sm<SHADOW, 12>(f, o4, d4, iv4, count); break;
+    default: launch_trace_w4<SHADOW, 12>(f, o4, d4, iv4, count); break;
     }
 }
 } // namespace
@@ -1366,6 +1374,7 @@ int rt_generate_rays(rt_frame* f)                       // GenerateRays, :516-52
     if (chunk_for(f, 1) < (f->n_local ? f->n_local : 1u))
         return fail(ctx, "rt_generate_rays: RT_OPT_PATH_STATE_LIMIT_MB is too small for one sample of the whole tile "
                          "(the stage API does not chunk; use rt_integrate)");
+    if (ensure_whole_tile(f) != RT_OK) return RT_ERROR;
     return generate_rays(f, 1);
 }
 
@@ -1525,6 +1534,7 @@ int rt_integrate(rt_frame* f, uint32_t n_samples)       // n x Integrator::Integ
     // ensure_slots may have halved the batch to fit the device (slots_limit): never ask for more than it got
     if (!per_frame) cap = slot_cap(f) < f->slots ? slot_cap(f) : f->slots;
     if (cap == 0) cap = 1;
+    if (per_frame && chunk_for(f, 1) >= (f->n_local ? f->n_local : 1u) && ensure_whole_tile(f) != RT_OK) return RT_ERROR;
     if (per_frame && f->chunk_pixels < (f->n_local ? f->n_local : 1u))
         return fail(ctx, "rt_integrate: AOVs / the denoiser need the whole tile in one chunk (raise RT_OPT_PATH_STATE_LIMIT_MB)");
     if (fork_pipes(f) != RT_OK) return RT_ERROR;
@@ -1569,6 +1579,12 @@ int rt_integrate(rt_frame* f, uint32_t n_samples)       // n x Integrator::Integ
     f->p = &f->ps[0];
     f->fused = false;
     f->side_active = false;
+    if (rc != RT_OK)
+        for (PathPipe& q : f->ps)                        // a failed batch leaves no shadow trace running behind the caller's back
+        {
+            if (q.side) (void)hipStreamSynchronize(q.side);
+            q.shadow_in_flight[0] = q.shadow_in_flight[1] = false;
+        }
     if (join_pipes(f) != RT_OK) return RT_ERROR;         // whatever follows on the context's stream sees every chunk
     return rc;
 }

@@ -398,10 +398,6 @@ template <bool FURNACE, bool BLUE, bool NEE = false>
 __global__ __launch_bounds__(RT_SHADE_BLOCK) void k_shade(DScene sc, DTile tile, ShadeArgs a)
 {
     const uint32_t count = a.counters->queue[a.bounce];
-#ifdef RT_SHADE_LDS_PAD
-    // residency experiment: RT_SHADE_LDS_PAD bytes of unused LDS per block cap the blocks per CU
-    { __shared__ volatile char s_pad[RT_SHADE_LDS_PAD]; s_pad[threadIdx.x] = 0; }
-#endif
     // the closest-hit trace of this bounce has completed (stream order): rewind the
     // work heads for the shadow trace of this bounce and the closest trace of the next
     {
@@ -486,31 +482,7 @@ __global__ __launch_bounds__(RT_SHADE_BLOCK) void k_shade(DScene sc, DTile tile,
             uint32_t py = tile_global_row(tile, ly);
 
             const float4* tp = sc.tris_sh + (size_t)prim * 8;
-#ifdef RT_SHADE_EXTRA_ACCESS
-            // sensitivity experiment (tools/build_variants.py, profiles/r02_shade_sensitivity_access_valu_residency.log): more
-            // 16-byte accesses to the record's own line per surface hit
-            typedef float rt_v4f __attribute__((ext_vector_type(4)));
-            rt_v4f extra_q[RT_SHADE_EXTRA_ACCESS];
-#pragma unroll
-            for (int x = 0; x < RT_SHADE_EXTRA_ACCESS; ++x) asm volatile("global_load_dwordx4 %0, %1, off offset:112" : "=&v"(extra_q[x]) : "v"(tp));
-#endif
             float4 q0 = tp[0], q1 = tp[1], q2 = tp[2], q3 = tp[3], q4 = tp[4], q5 = tp[5], q6 = tp[6];
-#ifdef RT_SHADE_EXTRA_ACCESS
-#pragma unroll
-            for (int x = 0; x < RT_SHADE_EXTRA_ACCESS; ++x) asm volatile("" :: "v"(extra_q[x]), "v"(q6.x), "v"(q0.x));
-#endif
-#ifdef RT_SHADE_EXTRA_VALU
-            {
-                float xa = q0.x, xb = q0.y;                                      // ... more v_fma_f32 per surface hit
-#pragma unroll
-                for (int x = 0; x < RT_SHADE_EXTRA_VALU / 2; ++x)
-                {
-                    asm volatile("v_fma_f32 %0, %0, %0, %1" : "+v"(xa) : "v"(xb));
-                    asm volatile("v_fma_f32 %0, %0, %0, %1" : "+v"(xb) : "v"(xa));
-                }
-                asm volatile("" :: "v"(xa), "v"(xb));
-            }
-#endif
             f3 p1 = xyz(q0), p2 = xyz(q1), p3 = xyz(q2);
             f3 n1 = xyz(q3), n2 = xyz(q4), n3 = xyz(q5);
             float bu = hit.x, bv = hit.y;

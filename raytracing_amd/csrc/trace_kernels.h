@@ -1,6 +1,8 @@
 // trace_kernels.h -- BVH traversal (trace_bvh.cl, + accumulate_direct_samples.cl for shadow rays):
-// the slab / triangle tests, k_trace_v1 (per-ray loop), k_trace (one 64-byte fetch per lane per
-// iteration, the default) and k_trace_packet (wave-uniform traversal through the scalar cache).
+// the slab / triangle tests, k_trace_v1 (per-ray loop: tiny launches), k_trace2 (exact BVH2 walk in three wave-uniform
+// loops: the fallback and the hand-over kernel) and k_trace_w4 (4-wide quantised tree: the production kernel).
+// Round 1's flat state-machine kernel and the packet kernel lost on every measured launch and were removed in round 3
+// (their measurements: profiles/r01_*, r02_packet_kernel_on_coherent_bounces.log).
 #pragma once
 #include "kernels_common.h"
 
@@ -220,500 +222,7 @@ __global__ __launch_bounds__(64) void k_trace_v1(DScene sc, const float4* __rest
 }
 
 
-// ---------------------------------------------------------------------------
-// k_trace: persistent "one fetch per iteration" traversal (the production kernel)
-// ---------------------------------------------------------------------------
-// What bounds this kernel is the chain of dependent HBM/L2 round trips per ray
-// (~46 box tests + ~2.5 triangle tests per ray on the 890 k-triangle stand-in),
-// not arithmetic.  v1 above pays (a) one round trip for the node branch PLUS one
-// for the leaf branch whenever a wave has lanes in both, and (b) idles lanes
-// whose ray finished until the slowest ray of the wave is done.  Here every lane
-// is a small state machine and every loop iteration issues exactly ONE 64-byte
-// record fetch per lane -- the next ray (o4/d4), a child-pair node, or a
-// triangle -- through the same four load instructions, so the wave pays one
-// memory round trip per iteration whatever mix of states it holds, and a lane
-// that finishes pulls a new ray in the very next iteration (wave-level pool of
-// ray indices, refilled RT_TRACE_BATCH at a time from a per-XCD queue head with
-// one atomic; exhausted XCD regions steal from the next region).
-// The arithmetic per record is unchanged from v1 (bit-identical results).
-#define RT_TRACE_BATCH 128u
-#define RT_TRACE_REFILL_QUORUM 12u   // finished lanes served together (measured: 8..24 within 2 %)
-#define RT_TRACE_LEAF_QUORUM 8u      // lanes at a triangle tested together (measured: 6..10 within 1 %)
-enum { ST_NEED = 0, ST_RAY = 1, ST_TRAV = 2, ST_DONE = 3 };
-
-template <bool SHADOW, int STACK>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(STACK <= 10 ? 8 : 6, 8))) void k_trace(DScene sc, const float4* __restrict__ o4, const float4* __restrict__ d4,
-    const float4* __restrict__ iv4, const uint32_t* __restrict__ count_ptr, uint32_t* __restrict__ heads,
-    float4* __restrict__ hits,
-    float4* __restrict__ rlog, uint32_t log_stride, uint32_t force_sign_bits, uint2* __restrict__ spill)
-{
-    __shared__ uint2 stack[STACK][64];
-    uint32_t* const stack32 = reinterpret_cast<uint32_t*>(&stack[0][0]);     // SHADOW: 2 * STACK entries of 4 bytes
-    uint32_t* const spill32 = reinterpret_cast<uint32_t*>(spill);
-    const uint32_t lane = threadIdx.x;
-    const uint32_t count = *count_ptr;
-    if (count == 0) return;
-    const uint32_t xcd = blockIdx.x & 7u;
-    // eight contiguous regions of the queue, 64-ray aligned, one per XCD (L2 affinity)
-    const uint32_t per = (((count + 7u) >> 3) + 63u) & ~63u;
-    // per-lane spill area, addressed on demand (keeps two VGPRs free: 64 registers = 8 waves per SIMD)
-    const uint32_t spill_base = (blockIdx.x * 64u + lane) * (uint32_t)(RT_TRACE_STACK_MAX - STACK);
-
-    uint32_t pool_next = 0, pool_end = 0, regions_tried = 0;   // wave-uniform
-    uint32_t state = ST_NEED;
-    uint32_t ray_i = 0, ref = 0, sign_bits = 0, hit_prim = RT_INVALID_ID;
-    int sp = 0;
-    f3 org = F3s(0.0f), dir = F3s(0.0f), inv = F3s(0.0f);
-    float t_max = 0.0f, hit_u = 0.0f, hit_v = 0.0f;
-    uint32_t payload = 0, log_entry = 0;                                     // SHADOW: path id, radiance-log entry
-    bool pending = false;                                                    // a finished ray's result not yet stored
-    const float t_min = 0.0f;
-
-    for (;;)
-    {
-        // ---- hand new ray indices to the lanes that need one --------------------
-        unsigned long long need = __ballot(state == ST_NEED);
-        const unsigned long long have_nodes = __ballot(state == ST_TRAV && !(ref & RT_LEAF_BIT));
-        // Lanes whose ray has finished wait until RT_TRACE_REFILL_QUORUM of them can be served
-        // together (or nothing else is left to do): result stores, the refill hand-out and the
-        // ray-start code then run once per ~8 iterations instead of every iteration -- with 64
-        // lanes in mixed states every divergent branch costs its full instruction count whenever
-        // ONE lane takes it.  Same for triangles below (RT_TRACE_LEAF_QUORUM).  Waiting lanes issue
-        // no loads.
-        if ((uint32_t)__popcll(need) < RT_TRACE_REFILL_QUORUM && have_nodes != 0ull) need = 0ull;
-        if (need && state == ST_NEED && pending)
-        {
-            // results of the rays that finished since the last refill
-            if (SHADOW)
-            {
-                // AccumulateDirectSamples fused (accumulate_direct_samples.cl:46-52): k_shade
-                // logged the direct sample tentatively; an occluded ray (it stopped on its
-                // first accepted triangle, hit_prim set) retracts it.  Store only, no wait.
-                if (hit_prim != RT_INVALID_ID)
-                    rlog[(size_t)log_entry * log_stride + payload] = make_float4(0, 0, 0, 0);
-            }
-            else
-            {
-                hits[ray_i] = make_float4(hit_u, hit_v, __uint_as_float(hit_prim), t_max);
-            }
-            pending = false;
-        }
-        while (need)
-        {
-            if (pool_next >= pool_end)
-            {
-                bool got = false;
-                while (regions_tried < 8u)
-                {
-                    uint32_t x = (xcd + regions_tried) & 7u;
-                    uint32_t rb = x * per < count ? x * per : count;
-                    uint32_t re = (x + 1u) * per < count ? (x + 1u) * per : count;
-                    uint32_t b = 0;
-                    if (lane == 0 && rb < re) b = atomicAdd(&heads[x], RT_TRACE_BATCH);
-                    b = __shfl(b, 0, 64);
-                    if (rb < re && b < re - rb)
-                    {
-                        pool_next = rb + b;
-                        pool_end = (b + RT_TRACE_BATCH < re - rb) ? rb + b + RT_TRACE_BATCH : re;
-                        got = true;
-                        break;
-                    }
-                    ++regions_tried;
-                }
-                if (!got)
-                {
-                    if (state == ST_NEED) state = ST_DONE;
-                    break;
-                }
-            }
-            uint32_t avail = pool_end - pool_next;
-            uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
-            uint32_t n = (uint32_t)__popcll(need);
-            if (state == ST_NEED && rank < avail)
-            {
-                ray_i = pool_next + rank;
-                state = ST_RAY;
-            }
-            pool_next += n < avail ? n : avail;
-            need = __ballot(state == ST_NEED);
-        }
-        if (__ballot(state != ST_DONE) == 0ull) break;
-
-        // ---- ONE 64-byte record per lane: ray | node | triangle -----------------
-        // (the L1 sees one access per lane per load instruction: only child-pair nodes use
-        // the fourth 16 bytes, so triangle and ray lanes skip that load)
-        const float4 *p0, *p1, *p2;
-        const bool is_node = state == ST_TRAV && !(ref & RT_LEAF_BIT);
-        if (state == ST_RAY) { p0 = o4 + ray_i; p1 = d4 + ray_i; p2 = iv4 + ray_i; }
-        else
-        {
-            const float4* base = (ref & RT_LEAF_BIT) ? sc.tris_rt + (size_t)(ref & ~RT_LEAF_BIT) * 4
-                                                     : sc.nodes + (size_t)ref * 4;
-            p0 = base; p1 = base + 1; p2 = base + 2;
-        }
-        const unsigned long long node_m = __ballot(is_node);
-        const unsigned long long tri_m = __ballot(state == ST_TRAV && (ref & RT_LEAF_BIT));
-        const unsigned long long ray_m = __ballot(state == ST_RAY);
-        const bool do_tri = (uint32_t)__popcll(tri_m) >= RT_TRACE_LEAF_QUORUM || node_m == 0ull;
-        const bool do_ray = ray_m != 0ull;               // RAY lanes exist only right after a refill
-        const bool go = is_node || (state == ST_RAY && do_ray) || (state == ST_TRAV && (ref & RT_LEAF_BIT) && do_tri);
-        float4 q0, q1, q2, q3;
-        if (go)
-        {
-            q0 = *p0; q1 = *p1; q2 = *p2;
-            if (is_node) q3 = p2[1];
-        }
-        if (SHADOW && state == ST_RAY && do_ray) { payload = __float_as_uint(q1.w); log_entry = __float_as_uint(q2.w) >> 8; }
-
-        bool finished = false, need_pop = false;
-        if (state == ST_RAY && do_ray)
-        {
-            // ray start: registers only.  1/dir and the sign bits come from the producer
-            // (ray_inverse); the root box test (trace_bvh.cl:146-148, first iteration) is the
-            // ordinary node test of the "super-root" record entry_ref in the next iteration.
-            org = F3(q0.x, q0.y, q0.z);
-            dir = F3(q1.x, q1.y, q1.z);
-            t_max = q0.w;
-            inv = F3(q2.x, q2.y, q2.z);
-            sign_bits = (__float_as_uint(q2.w) & 0xFFu) | force_sign_bits;
-            hit_prim = RT_INVALID_ID;
-            hit_u = 0.0f; hit_v = 0.0f;
-            sp = 0;
-            ref = sc.entry_ref;
-            state = ST_TRAV;
-        }
-        else if (state == ST_TRAV && go)
-        {
-            if (ref & RT_LEAF_BIT)
-            {
-                // one triangle of a leaf (trace_bvh.cl:28-73,155-169)
-                uint32_t prim = ref & ~RT_LEAF_BIT;
-                bool last = q0.w != 0.0f;
-                f3 p1 = F3(q0.x, q0.y, q0.z), e1 = F3(q1.x, q1.y, q1.z), e2 = F3(q2.x, q2.y, q2.z);
-                f3 pvec = cross3(dir, e2);
-                float det = dot3(e1, pvec);
-                if (!(det < 1e-8f || -det > 1e-8f))
-                {
-                    float inv_det = 1.0f / det;
-                    f3 tvec = org - p1;
-                    float u = dot3(tvec, pvec) * inv_det;
-                    if (!(u < 0.0f || u > 1.0f))
-                    {
-                        f3 qvec = cross3(tvec, e1);
-                        float v = dot3(dir, qvec) * inv_det;
-                        if (!(v < 0.0f || u + v > 1.0f))
-                        {
-                            float t = dot3(e2, qvec) * inv_det;
-                            if (!(t < t_min || t > t_max))
-                            {
-                                hit_u = u; hit_v = v; hit_prim = prim;
-                                t_max = t;                                   // :162
-                                if (SHADOW) finished = true;                 // goto endtrace, :164-167
-                            }
-                        }
-                    }
-                }
-                if (!finished)
-                {
-                    if (last) need_pop = true;
-                    else ref = ref + 1u;
-                }
-            }
-            else
-            {
-                uint32_t c0 = __float_as_uint(q3.x), c1 = __float_as_uint(q3.y), axis = __float_as_uint(q3.z);
-                float a0, a1;
-                bool h0, h1;
-                if (sign_bits & RT_SIGN_SLOW)
-                {
-                    h0 = box_test(RT_NODE_C0(q0, q1, q2), org, inv, t_min, t_max, a0);
-                    h1 = box_test(RT_NODE_C1(q0, q1, q2), org, inv, t_min, t_max, a1);
-                }
-                else
-                {
-                    h0 = box_test_fast(RT_NODE_C0(q0, q1, q2), org, inv, t_min, t_max, a0);
-                    h1 = box_test_fast(RT_NODE_C1(q0, q1, q2), org, inv, t_min, t_max, a1);
-                }
-                h1 = h1 && (c1 != RT_EMPTY_REF);
-                bool swap = (sign_bits >> axis) & 1u;                        // :181-190
-                uint32_t near_ref = swap ? c1 : c0, far_ref = swap ? c0 : c1;
-                bool near_hit = swap ? h1 : h0, far_hit = swap ? h0 : h1;
-                float far_entry = swap ? a0 : a1;
-                if (near_hit)
-                {
-                    if (far_hit)
-                    {
-                        if (SHADOW)
-                        {
-                            // t_max of a shadow ray never changes (it stops at its first accepted
-                            // triangle), so a child that passes the box test now passes it at pop
-                            // time: the entry is the reference alone and twice as many fit in LDS
-                            if (sp < 2 * STACK) stack32[sp * 64 + lane] = far_ref;
-                            else spill32[(size_t)2 * spill_base + (uint32_t)(sp - 2 * STACK)] = far_ref;
-                        }
-                        else
-                        {
-                            uint2 e = make_uint2(far_ref, __float_as_uint(far_entry));
-                            if (sp < STACK) stack[sp][lane] = e;
-                            else spill[(size_t)spill_base + (uint32_t)(sp - STACK)] = e;
-                        }
-                        ++sp;
-                    }
-                    ref = near_ref;
-                }
-                else if (far_hit) ref = far_ref;
-                else need_pop = true;
-            }
-            if (need_pop)
-            {
-                finished = true;
-                if (SHADOW)
-                {
-                    if (sp > 0)
-                    {
-                        --sp;
-                        ref = (sp < 2 * STACK) ? stack32[sp * 64 + lane] : spill32[(size_t)2 * spill_base + (uint32_t)(sp - 2 * STACK)];
-                        finished = false;
-                    }
-                }
-                else
-                    while (sp > 0)
-                    {
-                        --sp;
-                        uint2 e = (sp < STACK) ? stack[sp][lane] : spill[(size_t)spill_base + (uint32_t)(sp - STACK)];
-                        if (t_max >= __uint_as_float(e.y))                   // box re-test at pop time
-                        {
-                            ref = e.x;
-                            finished = false;
-                            break;
-                        }
-                    }
-            }
-        }
-
-        if (finished) { state = ST_NEED; pending = true; }   // result stored at the next refill
-    }
-}
-
-// ---------------------------------------------------------------------------
-// Packet traversal for COHERENT ray batches (primary rays and the shadow rays of the first
-// hit): the 64 consecutive queue entries of a wave -- samples of one pixel, or neighbouring
-// pixels -- walk the tree TOGETHER.  The current node is wave-uniform, so its 64-byte record
-// is fetched once per wave by the scalar unit (s_load_dwordx16 through the scalar cache: no
-// vector-memory instruction, no L1 access, no per-lane address arithmetic) and the box /
-// triangle tests read it from SGPRs; the stack holds wave-uniform entries.
-//
-// Exactness: lanes are grouped by their three direction sign bits, so every lane of a group
-// orders children exactly as the reference does for its ray (trace_bvh.cl:181-190).  A lane
-// takes part in a node visit iff its OWN box test of that node passes with its OWN current
-// t_max -- the reference's pop-time test (trace_bvh.cl:146-148): for the near child that is
-// the test made while the parent is visited (nothing happens to the ray in between); a far
-// child is pushed as (parent, child index, lanes that hit the parent) when any lane hits it
-// now (a lane that misses it now misses it later, t_max only shrinks), and when it is popped
-// the parent record is fetched again and those lanes re-run the full box test with their
-// current t_max.  Each lane therefore sees exactly its reference sequence of nodes and
-// triangles -- a subsequence of the packet's -- and produces the same hit.
-RT_DEV uint32_t uniform_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
-
-struct Rec64 { float4 a, b, c, d; };
-typedef float rt_v4f __attribute__((ext_vector_type(4)));
-typedef const __attribute__((address_space(4))) rt_v4f* const_v4f_ptr;     // constant address space -> s_load
-RT_DEV Rec64 scalar_fetch(const float4* base, uint32_t uniform_index)
-{
-    const_v4f_ptr p = (const_v4f_ptr)(uintptr_t)(base + (size_t)uniform_u32(uniform_index) * 4);
-    rt_v4f a = p[0], b = p[1], c = p[2], d = p[3];
-    Rec64 r;
-    r.a = make_float4(a.x, a.y, a.z, a.w); r.b = make_float4(b.x, b.y, b.z, b.w);
-    r.c = make_float4(c.x, c.y, c.z, c.w); r.d = make_float4(d.x, d.y, d.z, d.w);
-    return r;
-}
-
-RT_DEV bool packet_box(bool slow, float bminx, float bminy, float bminz, float bmaxx, float bmaxy, float bmaxz, f3 org, f3 inv,
-    float t_max)
-{
-    float entry;
-    return slow ? box_test(bminx, bminy, bminz, bmaxx, bmaxy, bmaxz, org, inv, 0.0f, t_max, entry)
-                : box_test_fast(bminx, bminy, bminz, bmaxx, bmaxy, bmaxz, org, inv, 0.0f, t_max, entry);
-}
-
-template <bool SHADOW>
-__global__ __launch_bounds__(64) void k_trace_packet(DScene sc, const float4* __restrict__ o4, const float4* __restrict__ d4,
-    const float4* __restrict__ iv4, const uint32_t* __restrict__ count_ptr, uint32_t* __restrict__ heads,
-    float4* __restrict__ hits, float4* __restrict__ rlog, uint32_t log_stride, uint32_t force_sign_bits)
-{
-    __shared__ uint4 pstack[RT_TRACE_STACK_MAX + 1];                         // wave-uniform entries
-    const uint32_t lane = threadIdx.x;
-    const uint32_t count = *count_ptr;
-    if (count == 0) return;
-    const uint32_t xcd = blockIdx.x & 7u;
-    const uint32_t per = (((count + 7u) >> 3) + 63u) & ~63u;                 // the XCD regions of k_trace
-    const unsigned long long lane_bit = 1ull << lane;
-    uint32_t regions_tried = 0;
-
-    for (;;)
-    {
-        // ---- next packet: 64 consecutive queue entries of this XCD's region (then steal) ----
-        uint32_t base = 0, end = 0;
-        bool got = false;
-        while (regions_tried < 8u)
-        {
-            uint32_t x = (xcd + regions_tried) & 7u;
-            uint32_t rb = x * per < count ? x * per : count;
-            uint32_t re = (x + 1u) * per < count ? (x + 1u) * per : count;
-            uint32_t b = 0;
-            if (lane == 0 && rb < re) b = atomicAdd(&heads[x], 64u);
-            b = uniform_u32(b);
-            if (rb < re && b < re - rb) { base = rb + b; end = re; got = true; break; }
-            ++regions_tried;
-        }
-        if (!got) break;
-
-        const uint32_t i = base + lane;
-        const bool valid = i < end;
-        f3 org = F3s(0.0f), dir = F3s(0.0f), inv = F3s(0.0f);
-        float t_max = 0.0f, hit_u = 0.0f, hit_v = 0.0f;
-        uint32_t sign_bits = 0, hit_prim = RT_INVALID_ID, payload = 0, log_entry = 0;
-        if (valid)
-        {
-            float4 q0 = o4[i], q1 = d4[i], q2 = iv4[i];
-            org = F3(q0.x, q0.y, q0.z); t_max = q0.w;
-            dir = F3(q1.x, q1.y, q1.z); payload = __float_as_uint(q1.w);
-            inv = F3(q2.x, q2.y, q2.z);
-            sign_bits = (__float_as_uint(q2.w) & 0xFFu) | force_sign_bits;
-            log_entry = __float_as_uint(q2.w) >> 8;
-        }
-
-        unsigned long long todo = __ballot(valid);
-        while (todo)
-        {
-            // one group = the lanes that share the first pending lane's direction signs
-            const uint32_t first = (uint32_t)__ffsll((long long)todo) - 1u;
-            const uint32_t sgn = uniform_u32((uint32_t)__shfl((int)(sign_bits & 7u), (int)first, 64));
-            const unsigned long long group = __ballot(valid && (sign_bits & 7u) == sgn) & todo;
-            todo &= ~group;
-            const bool slow = __ballot((group & lane_bit) && (sign_bits & RT_SIGN_SLOW)) != 0ull;   // wave-uniform
-
-            unsigned long long alive = group;          // SHADOW: lanes leave on their first accepted hit
-            unsigned long long mask = group;           // lanes taking part in the current visit
-            uint32_t ref = sc.entry_ref;
-            int sp = 0;
-            for (;;)
-            {
-                bool need_pop = false;
-                if (ref & RT_LEAF_BIT)
-                {
-                    uint32_t prim = ref & ~RT_LEAF_BIT;
-                    for (;;)
-                    {
-                        const Rec64 t = scalar_fetch(sc.tris_rt, prim);
-                        const bool last = t.a.w != 0.0f;
-                        bool accepted = false;
-                        if (mask & alive & lane_bit)
-                        {
-                            // RayTriangle, trace_bvh.cl:28-73,155-169
-                            f3 p1 = F3(t.a.x, t.a.y, t.a.z), e1 = F3(t.b.x, t.b.y, t.b.z), e2 = F3(t.c.x, t.c.y, t.c.z);
-                            f3 pvec = cross3(dir, e2);
-                            float det = dot3(e1, pvec);
-                            if (!(det < 1e-8f || -det > 1e-8f))
-                            {
-                                float inv_det = 1.0f / det;
-                                f3 tvec = org - p1;
-                                float u = dot3(tvec, pvec) * inv_det;
-                                if (!(u < 0.0f || u > 1.0f))
-                                {
-                                    f3 qvec = cross3(tvec, e1);
-                                    float v = dot3(dir, qvec) * inv_det;
-                                    if (!(v < 0.0f || u + v > 1.0f))
-                                    {
-                                        float tt = dot3(e2, qvec) * inv_det;
-                                        if (!(tt < 0.0f || tt > t_max))
-                                        {
-                                            hit_u = u; hit_v = v; hit_prim = prim;
-                                            t_max = tt;
-                                            accepted = true;
-                                        }
-                                    }
-                                }
-                            }
-                        }
-                        if (SHADOW) alive &= ~__ballot(accepted);            // goto endtrace, :164-167
-                        if (last || (mask & alive) == 0ull) break;
-                        ++prim;
-                    }
-                    need_pop = true;
-                }
-                else
-                {
-                    const Rec64 n = scalar_fetch(sc.nodes, ref);
-                    const uint32_t c0 = __float_as_uint(n.d.x), c1 = __float_as_uint(n.d.y), axis = __float_as_uint(n.d.z);
-                    bool h0 = false, h1 = false;
-                    if (mask & alive & lane_bit)
-                    {
-                        h0 = packet_box(slow, RT_NODE_C0(n.a, n.b, n.c), org, inv, t_max);
-                        h1 = packet_box(slow, RT_NODE_C1(n.a, n.b, n.c), org, inv, t_max);
-                    }
-                    const unsigned long long m0 = __ballot(h0);
-                    const unsigned long long m1 = c1 != RT_EMPTY_REF ? __ballot(h1) : 0ull;
-                    const bool swap = (sgn >> axis) & 1u;                    // :181-190, the same for the whole group
-                    const unsigned long long m_near = swap ? m1 : m0, m_far = swap ? m0 : m1;
-                    const uint32_t near_ref = swap ? c1 : c0, far_ref = swap ? c0 : c1;
-                    if (m_near)
-                    {
-                        if (m_far)
-                        {
-                            const unsigned long long pm = mask & alive;
-                            if (lane == 0) pstack[sp] = make_uint4(ref, swap ? 0u : 1u, (uint32_t)pm, (uint32_t)(pm >> 32));
-                            ++sp;
-                        }
-                        ref = near_ref; mask = m_near;
-                    }
-                    else if (m_far) { ref = far_ref; mask = m_far; }
-                    else need_pop = true;
-                }
-                if (need_pop)
-                {
-                    bool found = false;
-                    while (sp > 0 && alive)
-                    {
-                        --sp;
-                        const uint4 e = pstack[sp];
-                        const uint32_t pref = uniform_u32(e.x), cidx = uniform_u32(e.y);
-                        const unsigned long long pm =
-                            (((unsigned long long)uniform_u32(e.w) << 32) | uniform_u32(e.z)) & alive;
-                        if (pm == 0ull) continue;
-                        const Rec64 n = scalar_fetch(sc.nodes, pref);
-                        bool h = false;
-                        if (pm & lane_bit)
-                            h = cidx ? packet_box(slow, RT_NODE_C1(n.a, n.b, n.c), org, inv, t_max)
-                                     : packet_box(slow, RT_NODE_C0(n.a, n.b, n.c), org, inv, t_max);
-                        const unsigned long long m = __ballot(h);
-                        if (m)
-                        {
-                            ref = cidx ? __float_as_uint(n.d.y) : __float_as_uint(n.d.x);
-                            mask = m;
-                            found = true;
-                            break;
-                        }
-                    }
-                    if (!found) break;
-                }
-            }
-        }
-
-        if (valid)
-        {
-            if (SHADOW)
-            {
-                if (hit_prim != RT_INVALID_ID)
-                    rlog[(size_t)log_entry * log_stride + payload] = make_float4(0, 0, 0, 0);
-            }
-            else
-            {
-                hits[i] = make_float4(hit_u, hit_v, __uint_as_float(hit_prim), t_max);
-            }
-        }
-    }
-}
+#define RT_TRACE_BATCH 128u        // ray indices a wave takes from its queue region per hand-out (k_trace2; k_trace_w4 picks its own)
 
 // ---------------------------------------------------------------------------
 // k_trace2: persistent traversal with SEPARATE wave-uniform loops (round 2)
@@ -1051,13 +560,12 @@ RT_DEV uint32_t spill_load32(const uint32_t* p)
     return v;
 }
 
-// DIRECT (RT_OPT_TRACE_VARIANT 15): of the slots that pass their box test the FIRST in visit order is visited next and only
-// the later ones go to the stack.  The plain form pushes positions 3..1 and visits position 0 if it passed -- with 1.2 of 4
-// slots passing per visit (tools/wide_walk_stats.py) the passing slot is usually not position 0, so it is written to the LDS
-// stack and popped right back: an LDS round trip in the middle of the ray's dependent chain.  Same sequence of nodes (an entry
-// popped right after its push always passes the pre-cull: entry <= exit <= t_max), checked on the CPU by the restatement in
-// oracle/oracle.c (tests/test_wide_traversal_oracle.py).
-template <bool SHADOW, int STACK, bool TIMELINE = false, bool DIRECT = false>
+// Of the slots that pass their box test the FIRST in visit order is visited next and only the later ones go to the stack
+// (round 2 pushed positions 3..1 and popped the first passing one right back: with 1.2 of 4 slots passing per visit that
+// was 18.4 pushes per closest-hit ray instead of 8.6; same sequence of nodes -- an entry popped right after its push always
+// passes the pre-cull: entry <= exit <= t_max -- shown on the CPU by the restatement in oracle/oracle.c,
+// tests/test_wide_traversal_oracle.py; on the GPU: profiles/r03_call01_direct_variant_*).
+template <bool SHADOW, int STACK, bool TIMELINE = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_trace_w4(DScene sc, const float4* __restrict__ o4, const float4* __restrict__ d4,
     const float4* __restrict__ iv4, const uint32_t* __restrict__ count_ptr, uint32_t* __restrict__ heads,
     float4* __restrict__ hits, float4* __restrict__ rlog, uint32_t log_stride, uint2* __restrict__ spill, uint32_t tune,
@@ -1079,6 +587,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
     uint32_t tl_steps = 0, tl_max_steps = 0;                                 // TIMELINE only
     unsigned long long tl_t0 = 0, tl_max_ticks = 0, tl_steps_of_slowest = 0;
     const uint32_t node_q = tune & 0xFFu, leaf_q = (tune >> 8) & 0xFFu;
+    // Grid sized from the LIVE counter (the reference launches width x height work-items whatever the queue holds:
+    // "@TODO: use indirect dispatch", cl_pt_integrator.cpp:534,575).  The host launches the residency-sized persistent grid
+    // without knowing `count`; with few rays (one sample per pixel in flight, late bounces) every lane of that grid gets a
+    // handful of rays and the whole launch is its tail (DESIGN.md "Where a launch's time goes"): tune bits 24..31 = the
+    // fewest rays per lane a wave is worth starting for, waves beyond that leave at once and the rest see a grid of n_blocks.
+    uint32_t n_blocks = gridDim.x;
+    if ((tune >> 24) != 0u)
+    {
+        const uint32_t want = ((count / (64u * (tune >> 24)) + 7u) & ~7u);
+        n_blocks = want < 8u ? 8u : (want < n_blocks ? want : n_blocks);
+        if (blockIdx.x >= n_blocks) return;
+    }
     const uint32_t xcd = blockIdx.x & 7u;
     const uint32_t per = (((count + 7u) >> 3) + 63u) & ~63u;
     // rays a wave takes from the queue per hand-out: large, because every hand-out is one atomic on one of eight
@@ -1086,7 +606,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
     // wave would empty its region in fewer than ~4 hand-outs (small launches: late bounces, chunks, tiles)
     uint32_t grab = ((tune >> 16) & 0xFFu) ? ((tune >> 16) & 0xFFu) * 16u : 512u;
     {
-        const uint32_t fair = (per / ((gridDim.x >> 3) * 4u + 1u)) & ~63u;
+        const uint32_t fair = (per / ((n_blocks >> 3) * 4u + 1u)) & ~63u;
         grab = fair < grab ? (fair < 64u ? 64u : fair) : grab;
     }
     // (Tapering the hand-outs towards the end of the region does not shorten the tail of a launch -- 0.75-0.95 ms
@@ -1292,35 +812,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
             {
                 if (TIMELINE) ++tl_steps;
                 const float4* np = reinterpret_cast<const float4*>(node_base + (size_t)(ref << 6));
-#ifdef RT_W4_EXTRA_ACCESS
-                // sensitivity experiment (tools/build_variants.py, profiles/r02_trace_sensitivity_access_vs_valu.log):
-                // RT_W4_EXTRA_ACCESS more 16-byte L1 accesses per visit, to a line the visit fetches anyway (no extra miss, no
-                // extra round trip) -- what does an ACCESS cost?
-                typedef float rt_v4f __attribute__((ext_vector_type(4)));
-                rt_v4f extra_q[RT_W4_EXTRA_ACCESS];
-#pragma unroll
-                for (int x = 0; x < RT_W4_EXTRA_ACCESS; ++x)
-                    asm volatile("global_load_dwordx4 %0, %1, %2 offset:16" : "=&v"(extra_q[x]) : "v"(ref << 6), "s"(node_base));
-#endif
                 const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
                 const uint32_t meta = __float_as_uint(q0.w);
-#ifdef RT_W4_EXTRA_ACCESS
-#pragma unroll
-                for (int x = 0; x < RT_W4_EXTRA_ACCESS; ++x) asm volatile("" :: "v"(extra_q[x]), "v"(meta));   // after the wait for the record
-#endif
-#ifdef RT_W4_EXTRA_VALU
-                // ... and RT_W4_EXTRA_VALU more v_fma_f32 per visit: what does a vector instruction cost?
-                {
-                    float xa = q0.x, xb = q0.y;
-#pragma unroll
-                    for (int x = 0; x < RT_W4_EXTRA_VALU / 2; ++x)
-                    {
-                        asm volatile("v_fma_f32 %0, %0, %0, %1" : "+v"(xa) : "v"(xb));
-                        asm volatile("v_fma_f32 %0, %0, %0, %1" : "+v"(xb) : "v"(xa));
-                    }
-                    asm volatile("" :: "v"(xa), "v"(xb));
-                }
-#endif
                 const float cx = __uint_as_float((meta & 0xFFu) << 23), cy = __uint_as_float(((meta >> 8) & 0xFFu) << 23),
                             cz = __uint_as_float(((meta >> 16) & 0xFFu) << 23);
                 // near / far plane words per axis, chosen by the ray's direction sign
@@ -1376,7 +869,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                     tr = sw0 ? r[2] : r[0]; r[2] = sw0 ? r[0] : r[2]; r[0] = tr;  te = sw0 ? e[2] : e[0]; e[2] = sw0 ? e[0] : e[2]; e[0] = te;
                     tr = sw0 ? r[3] : r[1]; r[3] = sw0 ? r[1] : r[3]; r[1] = tr;  te = sw0 ? e[3] : e[1]; e[3] = sw0 ? e[1] : e[3]; e[1] = te;
                 }
-                if (DIRECT)
                 {
                     // the first passing position is visited next, the later ones wait on the stack (deepest first)
                     const bool v0 = e[0] < INF, v1 = e[1] < INF, v2 = e[2] < INF, v3 = e[3] < INF;
@@ -1387,15 +879,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                     else if (v1) ref = r[1];
                     else if (v2) ref = r[2];
                     else if (v3) ref = r[3];
-                    else pop();
-                }
-                else
-                {
-                    // visit position 0 next, positions 3..1 wait on the stack (deepest first)
-                    if (e[3] < INF) push(r[3], e[3]);
-                    if (e[2] < INF) push(r[2], e[2]);
-                    if (e[1] < INF) push(r[1], e[1]);
-                    if (e[0] < INF) ref = r[0];
                     else pop();
                 }
             }

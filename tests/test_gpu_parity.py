@@ -264,7 +264,7 @@ def test_directly_against_the_reference_kernels(ctx, golden_scenes):
 
 
 @pytest.mark.parametrize("slots", [2, 3, 8])
-@pytest.mark.parametrize("variant", [0, 1, 3, 5, 6, 8, 9, 10, 11, 13, 14, 103, 208, 308, 210, 310])
+@pytest.mark.parametrize("variant", [0, 5, 8, 9, 10, 11, 208, 308, 210, 310, 410, 510])
 def test_samples_in_flight_and_kernel_variants_are_bit_invariant(ctx, golden_scenes, slots, variant):
     """RT_OPT_SAMPLES_IN_FLIGHT traces several samples of a pixel concurrently; the
     radiance log replays their contributions in the reference's order, so the sum
@@ -281,10 +281,12 @@ def test_samples_in_flight_and_kernel_variants_are_bit_invariant(ctx, golden_sce
     fr.set_option(capi.OPT_SAMPLES_IN_FLIGHT, slots)
     fr.set_option(capi.OPT_TRACE_VARIANT, variant % 100)
     fr.set_option(capi.OPT_SHADE_PARTITION, (variant + slots) & 3)     # k_shade with and without the hits-first partition
-    fr.set_option(capi.OPT_PACKET_BOUNCES, (3 | 2 << 8) if variant == 103 else 0)   # 103: packet kernel, closest bounces 0..2, shadow 0..1
     # 208 / 308: k_trace2 with extreme loop thresholds (every lane leaves the node loop at once / nobody until all are done)
-    # 10 / 11: k_trace_w4 (4-wide quantized tree); 210 / 310: the same with extreme thresholds
-    fr.set_option(capi.OPT_TRACE_TUNE, {208: 64 | (64 << 8), 308: 1 | (1 << 8), 210: 64 | (64 << 8), 310: 1 | (1 << 8)}.get(variant, 0))
+    # 10 / 11: k_trace_w4 (4-wide quantized tree); 210 / 310: the same with extreme thresholds; 410 / 510: its grid cut down
+    # to the live queue counter (a wave per >= 3 / >= 200 rays per lane: a handful of waves, then the minimum of 8)
+    fr.set_option(capi.OPT_TRACE_TUNE, {208: 64 | (64 << 8), 308: 1 | (1 << 8), 210: 64 | (64 << 8), 310: 1 | (1 << 8),
+                                        410: 3 << 24, 510: (200 << 24) | (4 << 16)}.get(variant, 0))
+    fr.set_option(capi.OPT_SMALL_LAUNCH_PATHS, 0 if variant == 5 and slots == 3 else 2000000)   # auto without the v1 rule too
     fr.integrate(spp)
     assert fr.sample_count() == spp
     assert np.array_equal(fr.radiance(), base.radiance(), equal_nan=True)
@@ -517,7 +519,7 @@ def _tiny_scene(env, tris_spec):
     return s.arrays()
 
 
-@pytest.mark.parametrize("variant", [0, 3, 4, 8, 9, 10])
+@pytest.mark.parametrize("variant", [0, 8, 9, 10, 11])
 def test_degenerate_bvhs(ctx, env_map, variant):
     """Root-is-a-leaf trees (1 triangle), 2-triangle trees, a leaf with many coincident-centroid
     triangles (the reference's 'all centroids equal' leaf, bvh.cpp:112-123), and a long chain of
