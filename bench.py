@@ -261,6 +261,31 @@ def plumbing_only(args, rank, world):
     return 0
 
 
+def per_frame_leg(args, render, lib, frame, capi, frames):
+    """The reference's own call pattern (src/render.cpp:172-204): K x Render::RenderFrame() = Integrator::Integrate()
+    through the fifteen stage hooks, ONE sample per pixel per call, each frame ending with ResolveRadiance and its
+    host synchronisation (cl_pt_integrator.cpp:677-684).  Untimed by the headline; reported beside it."""
+    assert lib.rt_reset(frame) == 0
+    render.set_resolve_every_frame(True)
+    for _ in range(3):
+        render.render_frame()
+    render.finish()
+    st0 = render.stats()
+    t0 = time.perf_counter()
+    for _ in range(frames):
+        render.render_frame()
+    render.finish()
+    dt = time.perf_counter() - t0
+    st1 = render.stats()
+    render.set_resolve_every_frame(False)
+    rays = float((st1.closest_rays - st0.closest_rays) + (st1.shadow_rays - st0.shadow_rays))
+    return dict(mrays_per_s=round(rays / dt / 1e6, 1), ms_per_frame=round(dt * 1e3 / frames, 4), frames=frames,
+                rays_per_frame=round(rays / frames, 1), samples_in_flight=1, resolve_every_frame=True,
+                call_pattern="K x Render::RenderFrame() -> Integrator::Integrate() through the 15 stage hooks of HIPPathTraceIntegrator, "
+                             "1 sample per pixel per call, ResolveRadiance + host sync every frame (src/render.cpp:197, "
+                             "src/integrator/integrator.cpp:27-59)")
+
+
 def roofline_object(args, world, agg, prof, per_ray, spp_timed):
     """The dominant kernel against calibrated ceilings (see the module docstring)."""
     n_launch = max(prof.n_trace_closest, 1) * world
@@ -337,6 +362,10 @@ def main():
     ap.add_argument("--shade-partition", type=int, default=None, help="RT_OPT_SHADE_PARTITION (library default: 3)")
     ap.add_argument("--trace-waves", type=int, default=0, help="RT_OPT_TRACE_WAVES_PER_CU (0 = as many as fit)")
     ap.add_argument("--trace-variant", type=int, default=None, help="RT_OPT_TRACE_VARIANT (default: the library's automatic choice)")
+    ap.add_argument("--small-launch-paths", type=int, default=None, help="RT_OPT_SMALL_LAUNCH_PATHS (library default 2000000)")
+    ap.add_argument("--per-frame-frames", type=int, default=48, help="frames of the per_frame leg (the reference's call pattern, "
+                    "one Integrate() per frame); 0 = skip it")
+    ap.add_argument("--per-frame-only", action="store_true", help="run only the per_frame leg and print its object (tuning runs)")
     ap.add_argument("--debug-shared-gpu", action="store_true",
                     help="plumbing test only: all ranks share GPU 0 and gather over gloo (RCCL refuses two ranks per device)")
     ap.add_argument("--plumbing-only", action="store_true", help="no GPU: launch, rendezvous, gather and report only")
@@ -427,6 +456,15 @@ def main():
         assert lib.rt_set_option(frame, capi.OPT_TRACE_VARIANT, args.trace_variant) == 0
     if args.path_state_gb > 0:
         assert lib.rt_set_option(frame, capi.OPT_PATH_STATE_LIMIT_MB, int(args.path_state_gb * 1024)) == 0
+    if args.small_launch_paths is not None:
+        assert lib.rt_set_option(frame, capi.OPT_SMALL_LAUNCH_PATHS, args.small_launch_paths) == 0
+    if args.per_frame_only:
+        pf = per_frame_leg(args, render, lib, frame, capi, max(args.per_frame_frames, 1))
+        if rank == 0:
+            print(json.dumps(dict(per_frame=pf, config=dict(width=args.width, height=args.height, max_bounces=args.bounces, config=args.config,
+                                                            trace_tune=args.trace_tune, small_launch_paths=args.small_launch_paths,
+                                                            trace_variant=args.trace_variant, overlap_shadow=args.overlap_shadow))), flush=True)
+        return 0
     in_flight = render.reserve_samples(max(spp_timed, spp_warm))
 
     # ---- warm-up ------------------------------------------------------------
@@ -497,6 +535,10 @@ def main():
                         kernel_ms_per_spp=dict(trace_closest=round(prof_iso.ms_trace_closest / sps, 4), trace_shadow=round(prof_iso.ms_trace_shadow / sps, 4),
                                                shade=round(prof_iso.ms_shade / sps, 4), raygen=round(prof_iso.ms_raygen / sps, 4)))
 
+    per_frame = None
+    if world == 1 and args.per_frame_frames > 0:
+        per_frame = per_frame_leg(args, render, lib, frame, capi, args.per_frame_frames)
+
     if rank == 0:
         assert full is not None
         total_rays = agg[0] + agg[1]
@@ -555,7 +597,7 @@ def main():
                                 stack_spill_lane_steps=int(st1.stack_spills), rays_left_to_the_bvh2_kernel=int(st1.slow_rays),
                                 setup_s=round(t_setup, 2), device=name),
                     ranks=dict(render_ms_min=round(float(tmin[0].item()) * 1e3, 3), render_ms_max=round(float(tmax[1].item()) * 1e3, 3)),
-                    gather=gather_info, roofline=roofline, parity=parity, cpu_baseline=baseline)
+                    gather=gather_info, per_frame=per_frame, roofline=roofline, parity=parity, cpu_baseline=baseline)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -153,7 +153,7 @@ enum rt_option
                                        profiles/r02_packet_kernel_on_coherent_bounces.log); only 0 is accepted */
     , RT_OPT_DEBUG_ALLOC_LIMIT = 13 /* test hook: per-path buffer allocations for more than this many samples in flight
                                        fail as if the device were out of memory (0 = off) */
-    , RT_OPT_PATH_STATE_LIMIT_MB = 14 /* upper bound (MiB) for the per-path buffers (ray queues + radiance log, 488 B per
+    , RT_OPT_PATH_STATE_LIMIT_MB = 14 /* upper bound (MiB) for the per-path buffers (ray queues + radiance log, 412 B per
                                        path at 8 bounces): rt_integrate then runs every batch of samples chunk by chunk
                                        over the tile's pixels instead of over the whole tile at once.  0 (default) = only
                                        the built-in rule (at most half of the HBM).  Results are bit-identical for every

@@ -13,14 +13,15 @@
 //   reset_radiance.cl / increment_counter.cl       -> hipMemsetAsync / host scalar
 //
 // Device data layout (HBM), chosen for coalesced 16-byte accesses:
-//   ray queues   SoA: o4[i] = (origin.xyz, t_max), d4[i] = (dir.xyz, path id bits),
-//                iv4[i] = (1/dir.xyz, sign bits) computed by the PRODUCER of the ray (all 64
-//                lanes busy) instead of by the traversal kernel (where ~2 lanes of a wave
-//                start a ray in any given iteration), thr[i] = (throughput.xyz, -).
+//   ray queues   SoA: o4[i] = (origin.xyz, t_max), d4[i] = (dir.xyz, path id bits), thr[i] = (throughput.xyz,
+//                log entries so far).  1/dir and the direction signs are computed by the CONSUMER when a lane starts
+//                the ray (three IEEE divides per ray in the traversal kernel's refill phase): rounds 1-2 kept a third
+//                16-byte record per ray for them, written by the producer -- 56 bytes of per-path state and one access
+//                per ray more than this.
 //                path id = slot * n_pixels + pixel, where `slot` numbers the samples in flight
 //                (RT_OPT_SAMPLES_IN_FLIGHT); a shadow ray also carries the radiance-log entry
-//                of its deferred direct sample in iv4[i].w (sign bits | entry << 8)
-//   radiance log per path: cnt[id] + log[k][id] (float4) = the path's radiance
+//                of its deferred direct sample in sh_aux[i]
+//   radiance log per path: cnt[id] + log[k][id] (3 floats, 12 bytes) = the path's radiance
 //                contributions in the order the reference adds them (miss or emission,
 //                then direct light, per bounce).  k_flush replays them pixel by pixel,
 //                sample by sample, so the fp32 sum is associated exactly as in the
@@ -40,8 +41,15 @@
 #define RT_EMPTY_REF 0xFFFFFFFFu
 #define RT_TRACE_STACK_LDS 24     // per-lane stack entries kept in LDS
 #define RT_TRACE_STACK_MAX 64     // the reference's nodesToVisit[64] (trace_bvh.cl:142)
-// A shadow ray carries its path id in direction.w and, in the w of its 1/direction record,
-// sign bits | RT_SIGN_SLOW | (radiance-log entry of its deferred direct sample << 8).
+// A shadow ray carries its path id in direction.w and the radiance-log entry of its deferred direct sample in sh_aux.
+
+// one entry of the radiance log: RGB, 12 bytes (global_load/store_dwordx3)
+struct rt_rgb { float x, y, z; };
+RT_DEV void log_store(float* __restrict__ rlog, size_t index, float x, float y, float z)
+{
+    rt_rgb v = {x, y, z};
+    *reinterpret_cast<rt_rgb*>(rlog + 3 * index) = v;
+}
 
 struct DScene
 {

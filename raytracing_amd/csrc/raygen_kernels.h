@@ -10,7 +10,7 @@
 // chunk_base .. chunk_base + chunk_count - 1; path ids are chunk-relative (slot * chunk_stride + pixel in chunk).
 __global__ __launch_bounds__(256) void k_raygen(DTile tile, rt_camera cam, uint32_t sample_base, uint32_t n_slots,
     float tan_half_fov, uint32_t prev_bounces, float4* __restrict__ o4, float4* __restrict__ d4,
-    float4* __restrict__ iv4, float4* __restrict__ thr, DCounters* __restrict__ counters, uint32_t chunk_base,
+    float4* __restrict__ thr, DCounters* __restrict__ counters, uint32_t chunk_base,
     uint32_t chunk_count, uint32_t chunk_stride, uint32_t prev_accumulates)
 {
     uint32_t n_total = chunk_count * n_slots;                            // n_slots samples in flight
@@ -90,7 +90,6 @@ __global__ __launch_bounds__(256) void k_raygen(DTile tile, rt_camera cam, uint3
 
     o4[i] = make_float4(new_pos.x, new_pos.y, new_pos.z, RT_MAX_RENDER_DIST);
     d4[i] = make_float4(d.x, d.y, d.z, __uint_as_float(slot * chunk_stride + cp));   // path id
-    iv4[i] = ray_inverse(d);
     thr[i] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
 }
 

@@ -63,11 +63,11 @@ struct PathPipe
     hipStream_t stream = nullptr;      // pipe 0: the context's stream; others: their own
     hipEvent_t done = nullptr;         // cross-stream ordering (fork_pipes / join_pipes)
     // ray queues (ping-pong), hits, shadow queue
-    float4* o4[2] = {nullptr, nullptr}; float4* d4[2] = {nullptr, nullptr}; float4* iv4[2] = {nullptr, nullptr};
+    float4* o4[2] = {nullptr, nullptr}; float4* d4[2] = {nullptr, nullptr};
     float4* thr[2] = {nullptr, nullptr};
     float4* hits = nullptr;
     // shadow queue, two of them: bounce b fills [b & 1] while the shadow trace of bounce b - 1 may still read the other
-    float4* sh_o4[2] = {nullptr, nullptr}; float4* sh_d4[2] = {nullptr, nullptr}; float4* sh_iv4[2] = {nullptr, nullptr};
+    float4* sh_o4[2] = {nullptr, nullptr}; float4* sh_d4[2] = {nullptr, nullptr}; uint32_t* sh_aux[2] = {nullptr, nullptr};
     // the shadow trace's own stream (rt_integrate: it runs beside the next bounce's closest-hit trace and k_shade,
     // filling the tail of one and the ramp of the other), its spill area and slow-ray list
     hipStream_t side = nullptr;
@@ -76,7 +76,7 @@ struct PathPipe
     uint2* sh_spill = nullptr;
     uint32_t* sh_slow_list = nullptr;
     // radiance log (kernels_common.h header): cnt[id], rlog[entry][id]; id < slots * chunk_pixels
-    float4* rlog = nullptr; uint32_t* cnt = nullptr;
+    float* rlog = nullptr; uint32_t* cnt = nullptr;   // rlog: 3 floats per entry
     uint32_t* slow_list = nullptr;     // queue indices k_trace_w4 leaves to k_trace2 (one per path)
     DCounters* counters = nullptr;
     uint2* spill = nullptr;
@@ -121,7 +121,7 @@ struct rt_frame
     uint32_t timeline = 0;             // rt_frame_debug_timeline armed: k_trace_w4<closest> records its launch timeline
     uint32_t timeline_bounce = 0;
     uint32_t overlap_shadow = 1;       // RT_OPT_OVERLAP_SHADOW
-    bool side_active = false;          // inside rt_integrate with overlap_shadow: shadow traces go to PathPipe::side
+    bool side_active = false;          // shadow traces go to PathPipe::side (set per stage call: side_on())
     // where the next trace launch goes (set by rt_intersect / rt_intersect_shadow)
     hipStream_t tl_stream = nullptr; uint2* tl_spill = nullptr; uint32_t* tl_slow_list = nullptr; uint32_t tl_flavour = 0;
     uint32_t shade_partition = 3;      // RT_OPT_SHADE_PARTITION: bit 0: k_shade sorts each block's entries hits first / misses last; bit 1: groups its output rays by octant
@@ -719,13 +719,13 @@ void free_path_buffers(rt_frame* f)
     }
     for (PathPipe& q : f->ps)
     {
-        void* ptrs[] = {q.o4[0], q.o4[1], q.d4[0], q.d4[1], q.iv4[0], q.iv4[1], q.thr[0], q.thr[1], q.hits, q.sh_o4[0], q.sh_d4[0],
-            q.sh_iv4[0], q.sh_o4[1], q.sh_d4[1], q.sh_iv4[1], q.rlog, q.cnt, q.slow_list, q.sh_slow_list};
+        void* ptrs[] = {q.o4[0], q.o4[1], q.d4[0], q.d4[1], q.thr[0], q.thr[1], q.hits, q.sh_o4[0], q.sh_d4[0],
+            q.sh_aux[0], q.sh_o4[1], q.sh_d4[1], q.sh_aux[1], q.rlog, q.cnt, q.slow_list, q.sh_slow_list};
         for (void* p : ptrs) if (p) (void)hipFree(p);
         for (int i = 0; i < 2; ++i)
         {
-            q.o4[i] = nullptr; q.d4[i] = nullptr; q.iv4[i] = nullptr; q.thr[i] = nullptr;
-            q.sh_o4[i] = nullptr; q.sh_d4[i] = nullptr; q.sh_iv4[i] = nullptr;
+            q.o4[i] = nullptr; q.d4[i] = nullptr; q.thr[i] = nullptr;
+            q.sh_o4[i] = nullptr; q.sh_d4[i] = nullptr; q.sh_aux[i] = nullptr;
         }
         q.hits = nullptr; q.rlog = nullptr; q.cnt = nullptr; q.slow_list = nullptr; q.sh_slow_list = nullptr;
     }
@@ -733,7 +733,9 @@ void free_path_buffers(rt_frame* f)
 
 // Per-path state: ray queues for `slots` samples in flight and the radiance log
 // with 2 * (max_bounces + 1) entries per path.  (Re)allocated when either changes.
-size_t bytes_per_path(uint32_t max_bounces) { return 15u * 16u + 4u + 8u + 32u * (max_bounces + 1u); }
+// ray queues o4, d4, thr (x2), hits, shadow queue o4, d4 (x2) = 11 x 16; sh_aux (x2), cnt, two slow lists = 5 x 4;
+// log: 2 (B + 1) entries of 12 bytes.  412 bytes at 8 bounces (rounds 1-2: 540).
+size_t bytes_per_path(uint32_t max_bounces) { return 11u * 16u + 5u * 4u + 24u * (max_bounces + 1u); }
 
 // auto: the largest power of two <= 1024 that keeps tile pixels x samples inside 32-bit path
 // ids and the per-path buffers under ~144 GB (half of the 288 GB of HBM)
@@ -801,16 +803,17 @@ int alloc_path_buffers(rt_frame* f, uint32_t slots)
     if (paths > 0xFFFFFFF0ull) return fail(ctx, "samples in flight x tile pixels exceeds the 32-bit path-id range");
     f->log_stride = (uint32_t)paths;
     f->log_entries = 2u * (f->max_bounces + 1u);
-    size_t q = (size_t)(paths + 4) * sizeof(float4);   // +4: the unified 64-byte fetch of k_trace reads o4[i+2] / d4[i+2]
+    size_t q = (size_t)(paths + 4) * sizeof(float4);
     bool ok = true;
     for (uint32_t i = 0; i < f->n_pipes && ok; ++i)
     {
         PathPipe& pp = f->ps[i];
-        void** ptrs[] = {(void**)&pp.o4[0], (void**)&pp.o4[1], (void**)&pp.d4[0], (void**)&pp.d4[1], (void**)&pp.iv4[0],
-            (void**)&pp.iv4[1], (void**)&pp.thr[0], (void**)&pp.thr[1], (void**)&pp.hits, (void**)&pp.sh_o4[0],
-            (void**)&pp.sh_d4[0], (void**)&pp.sh_iv4[0], (void**)&pp.sh_o4[1], (void**)&pp.sh_d4[1], (void**)&pp.sh_iv4[1]};
+        void** ptrs[] = {(void**)&pp.o4[0], (void**)&pp.o4[1], (void**)&pp.d4[0], (void**)&pp.d4[1],
+            (void**)&pp.thr[0], (void**)&pp.thr[1], (void**)&pp.hits, (void**)&pp.sh_o4[0],
+            (void**)&pp.sh_d4[0], (void**)&pp.sh_o4[1], (void**)&pp.sh_d4[1]};
         for (void** p : ptrs) ok = ok && hipMalloc(p, q) == hipSuccess;
-        ok = ok && hipMalloc((void**)&pp.rlog, (size_t)f->log_entries * paths * sizeof(float4)) == hipSuccess;
+        for (uint32_t*& p : pp.sh_aux) ok = ok && hipMalloc((void**)&p, (size_t)(paths + 4) * sizeof(uint32_t)) == hipSuccess;
+        ok = ok && hipMalloc((void**)&pp.rlog, (size_t)f->log_entries * paths * 3u * sizeof(float) + 16u) == hipSuccess;
         ok = ok && hipMalloc((void**)&pp.cnt, (size_t)paths * sizeof(uint32_t)) == hipSuccess;
         ok = ok && hipMalloc((void**)&pp.slow_list, (size_t)(paths + 64) * sizeof(uint32_t)) == hipSuccess;
         ok = ok && hipMalloc((void**)&pp.sh_slow_list, (size_t)(paths + 64) * sizeof(uint32_t)) == hipSuccess;
@@ -903,6 +906,12 @@ int wait_shadow(rt_frame* f, uint32_t q)
     return RT_OK;
 }
 
+// Does the shadow trace of this bounce go to the pipe's side stream?  Inside rt_integrate AND through the stage API (the
+// reference's own call pattern, one Integrate() per frame: its launches are small, and the shadow trace of bounce b beside
+// the closest-hit trace of bounce b + 1 fills the machine twice as well).  Everything that reads what a shadow trace writes
+// waits for it: k_shade(b + 2) (wait_shadow), the log replay (flush_log), rt_reset, the debug readers.
+bool side_on(const rt_frame* f) { return f->overlap_shadow != 0 && !(f->denoiser || f->aov != 0); }
+
 // Grows the per-path buffers to hold `want` samples in flight (clamped to slot_cap); they
 // are sized by the largest batch actually requested, not by the cap.
 int ensure_slots(rt_frame* f, uint32_t want)
@@ -947,7 +956,7 @@ int flush_log(rt_frame* f)
         return fail(ctx, "radiance requested between rt_shade and rt_intersect_shadow (direct samples still tentative)");
     if (wait_shadow(f, 0) != RT_OK || wait_shadow(f, 1) != RT_OK) return RT_ERROR;   // their verdicts are in the log
     uint32_t blocks = (f->p->chunk_count + 255u) / 256u;
-    hipLaunchKernelGGL(k_flush, dim3(blocks), dim3(256), 0, f->p->stream, f->radiance + f->p->chunk_base, (const float4*)f->p->rlog, f->p->cnt,
+    hipLaunchKernelGGL(k_flush, dim3(blocks), dim3(256), 0, f->p->stream, f->radiance + f->p->chunk_base, (const float*)f->p->rlog, f->p->cnt,
         f->p->chunk_count, f->p->cur_slots, f->log_stride, f->chunk_pixels);
     if (hipGetLastError() != hipSuccess) return fail(ctx, "k_flush launch failed");
     f->p->cur_slots = 0;
@@ -1212,7 +1221,7 @@ namespace
 #define RT_TRACE2_DEFAULT_TUNE (32u | (8u << 8))     // profiles/r02_ktrace2_tune_sweep.log, r02_w4_tune_sweep.log
 #define RT_W4_DEFAULT_RAYS_PER_LANE 0u               // k_trace_w4's live-counter grid (trace_kernels.h); 0 = every wave
 template <bool SHADOW, int STACK>
-void launch_trace2(rt_frame* f, const float4* o4, const float4* d4, const float4* iv4, const uint32_t* count)
+void launch_trace2(rt_frame* f, const float4* o4, const float4* d4, const uint32_t* aux, const uint32_t* count)
 {
     rt_ctx* ctx = f->ctx;
     uint32_t per_cu = (160u * 1024u) / (STACK * 512u);
@@ -1222,15 +1231,15 @@ void launch_trace2(rt_frame* f, const float4* o4, const float4* d4, const float4
     uint32_t tune = f->trace_tune ? f->trace_tune : RT_TRACE2_DEFAULT_TUNE;
     if ((tune & 0xFFu) > 64u) tune = (tune & ~0xFFu) | 64u;
     if ((tune & 0xFFu) == 0u) tune |= 1u;
-    hipLaunchKernelGGL((k_trace2<SHADOW, STACK>), dim3(blocks), dim3(64), 0, f->tl_stream, ctx->scene.d, o4, d4, iv4, count,
+    hipLaunchKernelGGL((k_trace2<SHADOW, STACK>), dim3(blocks), dim3(64), 0, f->tl_stream, ctx->scene.d, o4, d4, aux, count,
         &f->p->counters->head[f->tl_flavour][0], SHADOW ? (float4*)nullptr : f->p->hits,
-        SHADOW ? f->p->rlog : (float4*)nullptr, f->log_stride, f->select_form_box, f->tl_spill, tune, (const uint32_t*)nullptr,
+        SHADOW ? f->p->rlog : (float*)nullptr, f->log_stride, f->select_form_box, f->tl_spill, tune, (const uint32_t*)nullptr,
         &f->p->counters->stack_spills);
 }
 
 // k_trace_w4 over the 4-wide quantized tree, then k_trace2 over the (normally empty) list of rays it left out
 template <bool SHADOW, int STACK>
-void launch_trace_w4(rt_frame* f, const float4* o4, const float4* d4, const float4* iv4, const uint32_t* count)
+void launch_trace_w4(rt_frame* f, const float4* o4, const float4* d4, const uint32_t* aux, const uint32_t* count)
 {
     rt_ctx* ctx = f->ctx;
     uint32_t per_cu = (160u * 1024u) / (STACK * 512u);
@@ -1248,13 +1257,13 @@ void launch_trace_w4(rt_frame* f, const float4* o4, const float4* d4, const floa
     const uint32_t s = f->tl_flavour;
     unsigned long long* const no_timeline = nullptr;
     if (!SHADOW && STACK == 12 && f->timeline)          // tools/launch_timeline.py: the instrumented instance
-        hipLaunchKernelGGL((k_trace_w4<false, 12, true>), dim3(blocks), dim3(64), 0, f->tl_stream, ctx->scene.d, o4, d4, iv4, count,
-            &f->p->counters->head[s][0], f->p->hits, (float4*)nullptr, f->log_stride, f->tl_spill, tune, f->tl_slow_list,
+        hipLaunchKernelGGL((k_trace_w4<false, 12, true>), dim3(blocks), dim3(64), 0, f->tl_stream, ctx->scene.d, o4, d4, aux, count,
+            &f->p->counters->head[s][0], f->p->hits, (float*)nullptr, f->log_stride, f->tl_spill, tune, f->tl_slow_list,
             &f->p->counters->slow_count[s], &f->p->counters->stack_spills, &f->p->counters->tl_start[f->timeline_bounce & 63u],
             f->timeline_bounce & 63u);
     else
-        hipLaunchKernelGGL((k_trace_w4<SHADOW, STACK, false>), dim3(blocks), dim3(64), 0, f->tl_stream, ctx->scene.d, o4, d4, iv4, count,
-            &f->p->counters->head[s][0], SHADOW ? (float4*)nullptr : f->p->hits, SHADOW ? f->p->rlog : (float4*)nullptr, f->log_stride,
+        hipLaunchKernelGGL((k_trace_w4<SHADOW, STACK, false>), dim3(blocks), dim3(64), 0, f->tl_stream, ctx->scene.d, o4, d4, aux, count,
+            &f->p->counters->head[s][0], SHADOW ? (float4*)nullptr : f->p->hits, SHADOW ? f->p->rlog : (float*)nullptr, f->log_stride,
             f->tl_spill, tune, f->tl_slow_list, &f->p->counters->slow_count[s], &f->p->counters->stack_spills, no_timeline, 0u);
     // The follow-up over the (normally empty) slow list: waves with a two-entry LDS stack (the rest of the stack
     // lives in the spill area) -- 1 KiB of LDS and a few registers, so it finds room beside the resident waves of the
@@ -1265,14 +1274,14 @@ void launch_trace_w4(rt_frame* f, const float4* o4, const float4* d4, const floa
     // with a long one (every shadow ray towards an axis-aligned point-light arrangement, say) the list is not serialised
     // onto one wave per CU.  Scenes whose directional lights make MOST shadow rays slow never get here (Scene::slow_shadow).
     uint32_t blocks2 = ((uint32_t)ctx->prop.multiProcessorCount * 4u + 7u) & ~7u;
-    hipLaunchKernelGGL((k_trace2<SHADOW, 2>), dim3(blocks2), dim3(64), 0, f->tl_stream, ctx->scene.d, o4, d4, iv4,
+    hipLaunchKernelGGL((k_trace2<SHADOW, 2>), dim3(blocks2), dim3(64), 0, f->tl_stream, ctx->scene.d, o4, d4, aux,
         (const uint32_t*)&f->p->counters->slow_count[s], &f->p->counters->slow_head[s][0], SHADOW ? (float4*)nullptr : f->p->hits,
-        SHADOW ? f->p->rlog : (float4*)nullptr, f->log_stride, f->select_form_box, f->tl_spill, tune & 0xFFFFu, (const uint32_t*)f->tl_slow_list,
+        SHADOW ? f->p->rlog : (float*)nullptr, f->log_stride, f->select_form_box, f->tl_spill, tune & 0xFFFFu, (const uint32_t*)f->tl_slow_list,
         &f->p->counters->stack_spills);
 }
 
 template <bool SHADOW>
-void launch_trace(rt_frame* f, const float4* o4, const float4* d4, const float4* iv4, const uint32_t* count,
+void launch_trace(rt_frame* f, const float4* o4, const float4* d4, const uint32_t* aux, const uint32_t* count,
     uint32_t bounce)
 {
     rt_ctx* ctx = f->ctx;
@@ -1297,15 +1306,15 @@ void launch_trace(rt_frame* f, const float4* o4, const float4* d4, const float4*
     case 0:
         hipLaunchKernelGGL(k_trace_v1<SHADOW>, dim3(f->trace_waves_per_cu ? (((uint32_t)ctx->prop.multiProcessorCount *
             (f->trace_waves_per_cu < 13u ? f->trace_waves_per_cu : 13u) + 7u) & ~7u) : f->trace_blocks), dim3(64), 0, f->tl_stream, ctx->scene.d, o4, d4,
-            iv4, count, SHADOW ? (float4*)nullptr : f->p->hits, SHADOW ? f->p->rlog : (float4*)nullptr, f->log_stride, f->select_form_box, f->tl_spill);
+            aux, count, SHADOW ? (float4*)nullptr : f->p->hits, SHADOW ? f->p->rlog : (float*)nullptr, f->log_stride, f->select_form_box, f->tl_spill);
         break;
     case 8:
-        if (!SHADOW && ctx->scene.d.entry_ref < 4000000u) launch_trace2<SHADOW, 10>(f, o4, d4, iv4, count);
-        else launch_trace2<SHADOW, 12>(f, o4, d4, iv4, count);
+        if (!SHADOW && ctx->scene.d.entry_ref < 4000000u) launch_trace2<SHADOW, 10>(f, o4, d4, aux, count);
+        else launch_trace2<SHADOW, 12>(f, o4, d4, aux, count);
         break;
-    case 9: launch_trace2<SHADOW, 12>(f, o4, d4, iv4, count); break;
-    case 11: launch_trace_w4<SHADOW, 16>(f, o4, d4, iv4, count); break;
-    default: launch_trace_w4<SHADOW, 12>(f, o4, d4, iv4, count); break;
+    case 9: launch_trace2<SHADOW, 12>(f, o4, d4, aux, count); break;
+    case 11: launch_trace_w4<SHADOW, 16>(f, o4, d4, aux, count); break;
+    default: launch_trace_w4<SHADOW, 12>(f, o4, d4, aux, count); break;
     }
 }
 } // namespace
@@ -1319,6 +1328,11 @@ int rt_reset(rt_frame* f)                               // CLPathTraceIntegrator
     (void)hipSetDevice(ctx->device);
     if (join_pipes(f) != RT_OK) return RT_ERROR;
     if (!f->denoiser) f->sample_count = 0;   // Reset() keeps the frame index while denoising (:499-504)
+    for (uint32_t i = 0; i < RT_MAX_PIPES; ++i)           // a shadow trace still running on a side stream writes the log
+    {
+        f->p = &f->ps[i];
+        if (f->p->stream && (wait_shadow(f, 0) != RT_OK || wait_shadow(f, 1) != RT_OK)) { f->p = &f->ps[0]; return RT_ERROR; }
+    }
     f->p = &f->ps[0];
     for (uint32_t i = 0; i < RT_MAX_PIPES; ++i)
     {
@@ -1356,7 +1370,7 @@ int generate_rays(rt_frame* f, uint32_t n_slots, uint32_t chunk_base = 0, bool l
     if (blocks == 0) blocks = 1;
     KernelSpan span(f, 0);
     hipLaunchKernelGGL(k_raygen, dim3(blocks), dim3(256), 0, f->p->stream, f->tile, f->camera, f->sample_count, n_slots,
-        tan_half_fov, f->p->prev_bounces, f->p->o4[0], f->p->d4[0], f->p->iv4[0], f->p->thr[0], f->p->counters, f->p->chunk_base, f->p->chunk_count,
+        tan_half_fov, f->p->prev_bounces, f->p->o4[0], f->p->d4[0], f->p->thr[0], f->p->counters, f->p->chunk_base, f->p->chunk_count,
         f->chunk_pixels, f->p->fold_accumulates);
     f->p->fold_accumulates = later_chunk_on_this_pipe ? 1u : 0u;     // what the NEXT fold does with this sequence's counters
     f->p->prev_bounces = f->max_bounces;
@@ -1386,7 +1400,7 @@ int rt_intersect(rt_frame* f, uint32_t bounce)          // IntersectRays, :522-5
     f->timeline_bounce = bounce;
     f->tl_stream = f->p->stream; f->tl_spill = f->p->spill; f->tl_slow_list = f->p->slow_list; f->tl_flavour = 0;
     KernelSpan span(f, 1);
-    launch_trace<false>(f, f->p->o4[in], f->p->d4[in], f->p->iv4[in], &f->p->counters->queue[bounce], bounce);
+    launch_trace<false>(f, f->p->o4[in], f->p->d4[in], (const uint32_t*)nullptr, &f->p->counters->queue[bounce], bounce);
     HIPCHK(ctx, hipGetLastError());
     return RT_OK;
 }
@@ -1403,8 +1417,8 @@ int rt_shade(rt_frame* f, uint32_t bounce)              // ShadeMissedRays + Sha
     uint32_t in = bounce & 1u, out = (bounce + 1u) & 1u;
     ShadeArgs a;
     a.in_o4 = f->p->o4[in]; a.in_d4 = f->p->d4[in]; a.in_thr = f->p->thr[in]; a.hits = f->p->hits;
-    a.out_o4 = f->p->o4[out]; a.out_d4 = f->p->d4[out]; a.out_iv4 = f->p->iv4[out]; a.out_thr = f->p->thr[out];
-    a.sh_o4 = f->p->sh_o4[bounce & 1u]; a.sh_d4 = f->p->sh_d4[bounce & 1u]; a.sh_iv4 = f->p->sh_iv4[bounce & 1u];
+    a.out_o4 = f->p->o4[out]; a.out_d4 = f->p->d4[out]; a.out_thr = f->p->thr[out];
+    a.sh_o4 = f->p->sh_o4[bounce & 1u]; a.sh_d4 = f->p->sh_d4[bounce & 1u]; a.sh_aux = f->p->sh_aux[bounce & 1u];
     a.rlog = f->p->rlog; a.cnt = f->p->cnt; a.counters = f->p->counters;
     a.bn_sobol = ctx->blue_noise; a.bn_scramble = ctx->blue_noise ? ctx->blue_noise + 65536 : nullptr;
     a.bn_rank = ctx->blue_noise ? ctx->blue_noise + 65536 + 131072 : nullptr;
@@ -1439,6 +1453,7 @@ int rt_shade(rt_frame* f, uint32_t bounce)              // ShadeMissedRays + Sha
     else RT_LAUNCH_SHADE(false, false, false);
 #undef RT_LAUNCH_SHADE
     HIPCHK(ctx, hipGetLastError());
+    f->side_active = side_on(f);
     if (f->side_active) HIPCHK(ctx, hipEventRecord(f->p->ev_shaded, f->p->stream));
     return RT_OK;
 }
@@ -1453,7 +1468,7 @@ int rt_intersect_shadow(rt_frame* f, uint32_t bounce)   // IntersectShadowRays +
     if (f->side_active) HIPCHK(ctx, hipStreamWaitEvent(f->p->side, f->p->ev_shaded, 0));
     {
         KernelSpan span(f, 3, f->tl_stream);
-        launch_trace<true>(f, f->p->sh_o4[q], f->p->sh_d4[q], f->p->sh_iv4[q], &f->p->counters->shadow[bounce], bounce);
+        launch_trace<true>(f, f->p->sh_o4[q], f->p->sh_d4[q], (const uint32_t*)f->p->sh_aux[q], &f->p->counters->shadow[bounce], bounce);
     }
     f->p->shadow_pending = false;
     HIPCHK(ctx, hipGetLastError());
@@ -1540,7 +1555,7 @@ int rt_integrate(rt_frame* f, uint32_t n_samples)       // n x Integrator::Integ
     if (fork_pipes(f) != RT_OK) return RT_ERROR;
     int rc = RT_OK;
     f->fused = true;
-    f->side_active = f->overlap_shadow != 0 && !per_frame;
+    f->side_active = side_on(f);
     while (done < n_samples && rc == RT_OK)
     {
         uint32_t batch = n_samples - done < cap ? n_samples - done : cap;
@@ -1578,7 +1593,6 @@ int rt_integrate(rt_frame* f, uint32_t n_samples)       // n x Integrator::Integ
     }
     f->p = &f->ps[0];
     f->fused = false;
-    f->side_active = false;
     if (rc != RT_OK)
         for (PathPipe& q : f->ps)                        // a failed batch leaves no shadow trace running behind the caller's back
         {
@@ -1697,6 +1711,7 @@ int rt_frame_debug_read_queue(rt_frame* f, int which, uint32_t bounce, rt_ray* r
     rt_ctx* ctx = f->ctx;
     (void)hipSetDevice(ctx->device);
     if (bounce > RT_MAX_BOUNCES_LIMIT + 1) return fail(ctx, "rt_frame_debug_read_queue: bounce out of range");
+    if (f->p->side) HIPCHK(ctx, hipStreamSynchronize(f->p->side));      // a shadow trace may be retracting log entries
     DCounters h;
     HIPCHK(ctx, hipMemcpyAsync(&h, f->p->counters, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -1720,11 +1735,10 @@ int rt_frame_debug_read_queue(rt_frame* f, int which, uint32_t bounce, rt_ray* r
         uint32_t local_pix = f->p->chunk_base + id % (f->chunk_pixels ? f->chunk_pixels : 1);
         if (which == 1)   // the deferred direct-light sample lives in the radiance log
         {
-            float4 iv;
-            HIPCHK(ctx, hipMemcpy(&iv, f->p->sh_iv4[bounce & 1u] + i, 16, hipMemcpyDeviceToHost));
-            uint32_t entry;
-            memcpy(&entry, &iv.w, 4);
-            HIPCHK(ctx, hipMemcpy(&p[i], f->p->rlog + (size_t)(entry >> 8) * f->log_stride + id, 16, hipMemcpyDeviceToHost));
+            uint32_t entry = 0;
+            HIPCHK(ctx, hipMemcpy(&entry, f->p->sh_aux[bounce & 1u] + i, 4, hipMemcpyDeviceToHost));
+            p[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            HIPCHK(ctx, hipMemcpy(&p[i], f->p->rlog + 3u * ((size_t)entry * f->log_stride + id), 12, hipMemcpyDeviceToHost));
         }
         if (rays)
         {

@@ -361,9 +361,9 @@ RT_DEV void block_append2_keyed(bool want_a, uint32_t key_a, bool want_b, uint32
 struct ShadeArgs
 {
     const float4* in_o4; const float4* in_d4; const float4* in_thr; const float4* hits;
-    float4* out_o4; float4* out_d4; float4* out_iv4; float4* out_thr;
-    float4* sh_o4; float4* sh_d4; float4* sh_iv4;
-    float4* rlog; uint32_t* cnt;      // radiance log (see file header)
+    float4* out_o4; float4* out_d4; float4* out_thr;
+    float4* sh_o4; float4* sh_d4; uint32_t* sh_aux;   // sh_aux[i]: radiance-log entry of shadow ray i's deferred direct sample
+    float* rlog; uint32_t* cnt;       // radiance log, 3 floats per entry (kernels_common.h header)
     const uint8_t* bn_sobol; const uint8_t* bn_scramble; const uint8_t* bn_rank;   // SamplerType::kBlueNoise tables
     DCounters* counters;
     uint32_t bounce, sample_base, emit_outgoing, n_local, log_stride;   // n_local: pixels per chunk (path id = slot * n_local + pixel in chunk)
@@ -461,7 +461,6 @@ __global__ __launch_bounds__(RT_SHADE_BLOCK) void k_shade(DScene sc, DTile tile,
         uint32_t nlog = a.count_in_ray ? (__float_as_uint(thr4.w) & 0x7FFFFFFFu) : a.cnt[id];   // contributions logged so far
         // NEE: bit 31 of the same word = the path's last scattering event was a delta one (set by the previous bounce)
         const bool prev_delta = NEE && (__float_as_uint(thr4.w) >> 31) != 0u;
-        float4* mylog = a.rlog + id;
         f3 hit_throughput = F3(thr4.x, thr4.y, thr4.z);
 
         if (prim == RT_INVALID_ID)
@@ -469,7 +468,7 @@ __global__ __launch_bounds__(RT_SHADE_BLOCK) void k_shade(DScene sc, DTile tile,
             // Miss, miss.cl:65-76
             f3 sky = FURNACE ? F3s(0.5f) : SampleSky(sc, F3(rd.x, rd.y, rd.z));
             f3 add = sky * hit_throughput;
-            mylog[(size_t)nlog * a.log_stride] = make_float4(add.x, add.y, add.z, 0.0f);   // radiance[pix] += ...
+            log_store(a.rlog, (size_t)nlog * a.log_stride + id, add.x, add.y, add.z);   // radiance[pix] += ...
             ++nlog;
         }
         else
@@ -504,7 +503,7 @@ __global__ __launch_bounds__(RT_SHADE_BLOCK) void k_shade(DScene sc, DTile tile,
                 if (material.emission.x * 1.0f + material.emission.y * 1.0f + material.emission.z * 1.0f > 0.0f)
                 {
                     f3 e = hit_throughput * material.emission;
-                    mylog[(size_t)nlog * a.log_stride] = make_float4(e.x, e.y, e.z, 0.0f);         // radiance[pix] += ...
+                    log_store(a.rlog, (size_t)nlog * a.log_stride + id, e.x, e.y, e.z);         // radiance[pix] += ...
                     ++nlog;
                 }
             }
@@ -591,7 +590,7 @@ __global__ __launch_bounds__(RT_SHADE_BLOCK) void k_shade(DScene sc, DTile tile,
                 {
                     // deferred direct sample (direct_light_samples_buffer_): logged now, retracted
                     // by the shadow trace if the light turns out to be occluded
-                    mylog[(size_t)nlog * a.log_stride] = make_float4(lsamp.x, lsamp.y, lsamp.z, 0.0f);
+                    log_store(a.rlog, (size_t)nlog * a.log_stride + id, lsamp.x, lsamp.y, lsamp.z);
                     ++nlog;
                 }
             }
@@ -638,15 +637,12 @@ __global__ __launch_bounds__(RT_SHADE_BLOCK) void k_shade(DScene sc, DTile tile,
     {
         a.sh_o4[sidx] = sh_o;
         a.sh_d4[sidx] = sh_d;
-        float4 siv = ray_inverse(F3(sh_d.x, sh_d.y, sh_d.z));
-        siv.w = __uint_as_float(__float_as_uint(siv.w) | (sh_entry << 8));
-        a.sh_iv4[sidx] = siv;
+        a.sh_aux[sidx] = sh_entry;
     }
     if (want_next)
     {
         a.out_o4[nidx] = nx_o;
         a.out_d4[nidx] = nx_d;
-        a.out_iv4[nidx] = ray_inverse(F3(nx_d.x, nx_d.y, nx_d.z));
         a.out_thr[nidx] = nx_t;
     }
 }
@@ -654,7 +650,7 @@ __global__ __launch_bounds__(RT_SHADE_BLOCK) void k_shade(DScene sc, DTile tile,
 // Replays the radiance log: for every pixel, sample slot by sample slot, contribution
 // by contribution -- the exact order in which the reference's kernels executed
 // `radiance[pixel] += ...` (miss.cl:75, hit_surface.cl:110, accumulate_direct_samples.cl:51).
-__global__ __launch_bounds__(256) void k_flush(float4* __restrict__ radiance, const float4* __restrict__ rlog,
+__global__ __launch_bounds__(256) void k_flush(float4* __restrict__ radiance, const float* __restrict__ rlog,
     uint32_t* __restrict__ cnt, uint32_t n_pixels, uint32_t n_slots, uint32_t log_stride, uint32_t id_stride)
 {
     // radiance: already offset to the chunk's first pixel; id_stride: pixels per chunk as allocated
@@ -667,7 +663,7 @@ __global__ __launch_bounds__(256) void k_flush(float4* __restrict__ radiance, co
         uint32_t c = cnt[id];
         for (uint32_t k = 0; k < c; ++k)
         {
-            float4 v = rlog[(size_t)k * log_stride + id];
+            const rt_rgb v = *reinterpret_cast<const rt_rgb*>(rlog + 3 * ((size_t)k * log_stride + id));
             r.x += v.x; r.y += v.y; r.z += v.z;
         }
         if (c) cnt[id] = 0;

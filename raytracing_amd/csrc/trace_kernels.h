@@ -70,8 +70,8 @@ RT_DEV bool box_test_fast(float bminx, float bminy, float bminz, float bmaxx, fl
 
 template <bool SHADOW>
 __global__ __launch_bounds__(64) void k_trace_v1(DScene sc, const float4* __restrict__ o4, const float4* __restrict__ d4,
-    const float4* __restrict__ iv4, const uint32_t* __restrict__ count_ptr, float4* __restrict__ hits,
-    float4* __restrict__ rlog, uint32_t log_stride, uint32_t /*force_sign_bits: v1 always uses box_test*/,
+    const uint32_t* __restrict__ aux /* shadow rays: log entry of the deferred direct sample */, const uint32_t* __restrict__ count_ptr,
+    float4* __restrict__ hits, float* __restrict__ rlog, uint32_t log_stride, uint32_t /*force_sign_bits: v1 always uses box_test*/,
     uint2* __restrict__ spill)
 {
     __shared__ uint2 stack[RT_TRACE_STACK_LDS][64];
@@ -210,8 +210,7 @@ __global__ __launch_bounds__(64) void k_trace_v1(DScene sc, const float4* __rest
             // logged the direct sample tentatively; an occluded ray retracts it
             if (occluded)
             {
-                uint32_t entry = __float_as_uint(iv4[i].w) >> 8;
-                rlog[(size_t)entry * log_stride + __float_as_uint(rd.w)] = make_float4(0, 0, 0, 0);
+                log_store(rlog, (size_t)aux[i] * log_stride + __float_as_uint(rd.w), 0.0f, 0.0f, 0.0f);
             }
         }
         else
@@ -313,9 +312,10 @@ RT_DEV void hand_out_rays(RayPool& p, uint32_t lane, uint32_t xcd, uint32_t per,
 
 template <bool SHADOW, int STACK>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(STACK <= 10 ? 8 : 6, 8))) void k_trace2(DScene sc, const float4* __restrict__ o4, const float4* __restrict__ d4,
-    const float4* __restrict__ iv4, const uint32_t* __restrict__ count_ptr, uint32_t* __restrict__ heads,
+    const uint32_t* __restrict__ aux /* shadow rays: log entry of the deferred direct sample */, const uint32_t* __restrict__ count_ptr,
+    uint32_t* __restrict__ heads,
     float4* __restrict__ hits,
-    float4* __restrict__ rlog, uint32_t log_stride, uint32_t force_sign_bits, uint2* __restrict__ spill, uint32_t tune,
+    float* __restrict__ rlog, uint32_t log_stride, uint32_t force_sign_bits, uint2* __restrict__ spill, uint32_t tune,
     const uint32_t* __restrict__ index_list /* nullptr: the whole queue; else queue entries to trace, *count_ptr of them */,
     uint32_t* __restrict__ spill_count /* statistics: pushes beyond the LDS stack */)
 {
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(STACK <= 10 
                 {
                     // AccumulateDirectSamples fused: an occluded ray retracts its tentative direct sample
                     if (hit_prim != RT_INVALID_ID)
-                        rlog[(size_t)log_entry * log_stride + payload] = make_float4(0, 0, 0, 0);
+                        log_store(rlog, (size_t)log_entry * log_stride + payload, 0.0f, 0.0f, 0.0f);
                 }
                 else
                     hits[ray_i] = make_float4(hit_u, hit_v, __uint_as_float(hit_prim), t_max);
@@ -399,13 +399,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(STACK <= 10 
                     // ray start: 1/dir and the sign bits come from the producer; the root box test is
                     // the ordinary node test of the super-root record (see k_trace)
                     if (index_list) ray_i = index_list[ray_i];
-                    float4 q0 = o4[ray_i], q1 = d4[ray_i], q2 = iv4[ray_i];
+                    const float4 q0 = o4[ray_i], q1 = d4[ray_i];
+                    if (SHADOW) { payload = __float_as_uint(q1.w); log_entry = aux[ray_i]; }
                     oxy = (rt_v2f){q0.x, q0.y}; oz = q0.z;
                     dir = F3(q1.x, q1.y, q1.z);
                     t_max = q0.w;
+                    const float4 q2 = ray_inverse(dir);                      // trace_bvh.cl:125-129
                     ixy = (rt_v2f){q2.x, q2.y}; iz = q2.z;
                     sign_bits = (__float_as_uint(q2.w) & 0xFFu) | force_sign_bits;
-                    if (SHADOW) { payload = __float_as_uint(q1.w); log_entry = __float_as_uint(q2.w) >> 8; }
                     hit_prim = RT_INVALID_ID;
                     hit_u = 0.0f; hit_v = 0.0f;
                     sp = 0;
@@ -567,8 +568,9 @@ RT_DEV uint32_t spill_load32(const uint32_t* p)
 // tests/test_wide_traversal_oracle.py; on the GPU: profiles/r03_call01_direct_variant_*).
 template <bool SHADOW, int STACK, bool TIMELINE = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_trace_w4(DScene sc, const float4* __restrict__ o4, const float4* __restrict__ d4,
-    const float4* __restrict__ iv4, const uint32_t* __restrict__ count_ptr, uint32_t* __restrict__ heads,
-    float4* __restrict__ hits, float4* __restrict__ rlog, uint32_t log_stride, uint2* __restrict__ spill, uint32_t tune,
+    const uint32_t* __restrict__ aux /* shadow rays: log entry of the deferred direct sample */, const uint32_t* __restrict__ count_ptr,
+    uint32_t* __restrict__ heads,
+    float4* __restrict__ hits, float* __restrict__ rlog, uint32_t log_stride, uint2* __restrict__ spill, uint32_t tune,
     uint32_t* __restrict__ slow_list, uint32_t* __restrict__ slow_count, uint32_t* __restrict__ stat_counts /* [0] spills, [1] slow rays */,
     unsigned long long* __restrict__ timeline /* TIMELINE: DCounters::tl_start + timeline_slot (rt_frame_debug_timeline) */,
     uint32_t timeline_slot)
@@ -678,7 +680,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                 if (SHADOW)
                 {
                     if (hit_prim != RT_INVALID_ID)
-                        rlog[(size_t)log_entry * log_stride + payload] = make_float4(0, 0, 0, 0);
+                        log_store(rlog, (size_t)log_entry * log_stride + payload, 0.0f, 0.0f, 0.0f);
                 }
                 else
                     hits[ray_i] = make_float4(hit_u, hit_v, __uint_as_float(hit_prim), t_max);
@@ -696,14 +698,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                 bool slow = false;
                 if (ref == RT_IDLE_REF && ray_i != RT_INVALID_ID)
                 {
-                    float4 q0 = o4[ray_i], q1 = d4[ray_i], q2 = iv4[ray_i];
+                    const float4 q0 = o4[ray_i], q1 = d4[ray_i];
+                    if (SHADOW) { payload = __float_as_uint(q1.w); log_entry = aux[ray_i]; }
                     org = F3(q0.x, q0.y, q0.z);
                     dir = F3(q1.x, q1.y, q1.z);
                     t_max = q0.w;
+                    const float4 q2 = ray_inverse(dir);                      // trace_bvh.cl:125-129
                     inv = F3(q2.x, q2.y, q2.z);
                     sign_bits = __float_as_uint(q2.w) & 0xFFu;
                     octant3 = 3u * (sign_bits & 7u);
-                    if (SHADOW) { payload = __float_as_uint(q1.w); log_entry = __float_as_uint(q2.w) >> 8; }
                     hit_prim = RT_INVALID_ID;
                     hit_u = 0.0f; hit_v = 0.0f;
                     sp = 0;

@@ -10,7 +10,7 @@
 //   * 16-bit samples are reduced to their high byte,
 //   * palette images expand to RGB (RGBA when a tRNS chunk is present),
 //   * a tRNS colour key on grey / RGB images adds an alpha channel (0 for the key).
-// Adam7-interlaced files are rejected (not needed by any asset the path uses).
+// Adam7-interlaced files (PNG spec 8.2: seven reduced images, each filtered on its own) are decoded pass by pass.
 #include <cstdio>
 #include <cstring>
 #include <vector>
@@ -68,7 +68,7 @@ bool LoadPNG(const char* filename, Image& res)
         else if (!memcmp(type, "IEND", 4)) done = true;
         pos += 12 + (size_t)len;
     }
-    if (!have_ihdr || w == 0 || h == 0 || interlace != 0) return false;
+    if (!have_ihdr || w == 0 || h == 0 || interlace > 1) return false;
     int samples;   // samples per pixel in the file
     switch (color)
     {
@@ -81,38 +81,73 @@ bool LoadPNG(const char* filename, Image& res)
     }
     if (!(depth == 8 || depth == 16 || ((color == 0 || color == 3) && (depth == 1 || depth == 2 || depth == 4)))) return false;
     if (color == 3 && (depth == 16 || plte.empty())) return false;
-    size_t bpp_bits = (size_t)samples * depth;
-    size_t stride = ((size_t)w * bpp_bits + 7) / 8;
-    size_t fb = bpp_bits >= 8 ? bpp_bits / 8 : 1;   // filter byte distance
-    std::vector<unsigned char> raw((stride + 1) * h);
+    const size_t bpp_bits = (size_t)samples * depth;
+    const size_t fb = bpp_bits >= 8 ? bpp_bits / 8 : 1;   // filter byte distance
+    // the reduced images of the file: one (the whole image), or the seven Adam7 passes (PNG spec 8.2)
+    struct Pass { std::uint32_t x0, y0, dx, dy, pw, ph; size_t stride; };
+    std::vector<Pass> passes;
+    if (!interlace) passes.push_back({0, 0, 1, 1, w, h, 0});
+    else
+    {
+        static const std::uint32_t X0[7] = {0, 4, 0, 2, 0, 1, 0}, Y0[7] = {0, 0, 4, 0, 2, 0, 1};
+        static const std::uint32_t DX[7] = {8, 8, 4, 4, 2, 2, 1}, DY[7] = {8, 8, 8, 4, 4, 2, 2};
+        for (int i = 0; i < 7; ++i)
+        {
+            const std::uint32_t pw = w > X0[i] ? (w - X0[i] + DX[i] - 1) / DX[i] : 0, ph = h > Y0[i] ? (h - Y0[i] + DY[i] - 1) / DY[i] : 0;
+            if (pw && ph) passes.push_back({X0[i], Y0[i], DX[i], DY[i], pw, ph, 0});
+        }
+    }
+    size_t raw_size = 0;
+    for (Pass& ps : passes) { ps.stride = ((size_t)ps.pw * bpp_bits + 7) / 8; raw_size += (ps.stride + 1) * ps.ph; }
+    std::vector<unsigned char> raw(raw_size);
     uLongf raw_len = (uLongf)raw.size();
     if (uncompress(raw.data(), &raw_len, idat.data(), (uLong)idat.size()) != Z_OK || raw_len != raw.size()) return false;
 
-    // unfilter in place (PNG spec 9.2)
-    std::vector<unsigned char> img(stride * h);
-    for (std::uint32_t y = 0; y < h; ++y)
+    // unfilter every reduced image on its own (PNG spec 9.2) and scatter its samples (file bit depth) to their pixels
+    std::vector<std::uint16_t> smp((size_t)w * h * samples);
+    size_t in_pos = 0;
+    for (const Pass& ps : passes)
     {
-        const unsigned char* in = &raw[(stride + 1) * y];
-        unsigned char* out = &img[stride * y];
-        const unsigned char* up = y ? &img[stride * (y - 1)] : nullptr;
-        int ft = in[0];
-        for (size_t x = 0; x < stride; ++x)
+        std::vector<unsigned char> img(ps.stride * ps.ph);
+        for (std::uint32_t y = 0; y < ps.ph; ++y)
         {
-            int a = x >= fb ? out[x - fb] : 0;
-            int b = up ? up[x] : 0;
-            int c = (up && x >= fb) ? up[x - fb] : 0;
-            int v = in[1 + x];
-            switch (ft)
+            const unsigned char* in = &raw[in_pos + (ps.stride + 1) * y];
+            unsigned char* out = &img[ps.stride * y];
+            const unsigned char* up = y ? &img[ps.stride * (y - 1)] : nullptr;
+            int ft = in[0];
+            for (size_t x = 0; x < ps.stride; ++x)
             {
-            case 0: break;
-            case 1: v += a; break;
-            case 2: v += b; break;
-            case 3: v += (a + b) >> 1; break;
-            case 4: v += paeth(a, b, c); break;
-            default: return false;
+                int a = x >= fb ? out[x - fb] : 0;
+                int b = up ? up[x] : 0;
+                int c = (up && x >= fb) ? up[x - fb] : 0;
+                int v = in[1 + x];
+                switch (ft)
+                {
+                case 0: break;
+                case 1: v += a; break;
+                case 2: v += b; break;
+                case 3: v += (a + b) >> 1; break;
+                case 4: v += paeth(a, b, c); break;
+                default: return false;
+                }
+                out[x] = (unsigned char)v;
             }
-            out[x] = (unsigned char)v;
+            for (std::uint32_t x = 0; x < ps.pw; ++x)
+                for (int k = 0; k < samples; ++k)
+                {
+                    const size_t i = (size_t)x * samples + k;
+                    unsigned v;
+                    if (depth == 8) v = out[i];
+                    else if (depth == 16) v = (unsigned)out[2 * i] << 8 | out[2 * i + 1];
+                    else
+                    {
+                        const size_t bit = i * depth;
+                        v = (out[bit >> 3] >> (8 - depth - (bit & 7))) & ((1u << depth) - 1u);
+                    }
+                    smp[((size_t)(ps.y0 + y * ps.dy) * w + (ps.x0 + x * ps.dx)) * samples + k] = (std::uint16_t)v;
+                }
         }
+        in_pos += (ps.stride + 1) * ps.ph;
     }
 
     // expand to 8-bit samples per pixel, n output channels (stb conventions)
@@ -122,24 +157,18 @@ bool LoadPNG(const char* filename, Image& res)
     std::vector<unsigned char> px((size_t)w * h * n);
     for (std::uint32_t y = 0; y < h; ++y)
     {
-        const unsigned char* row = &img[stride * y];
         for (std::uint32_t x = 0; x < w; ++x)
         {
             unsigned s8[4] = {0, 0, 0, 0};
             unsigned s16[4] = {0, 0, 0, 0};
             for (int k = 0; k < samples; ++k)
             {
-                size_t i = (size_t)x * samples + k;
-                if (depth == 8) { s8[k] = row[i]; s16[k] = row[i]; }
-                else if (depth == 16) { s16[k] = (unsigned)row[2 * i] << 8 | row[2 * i + 1]; s8[k] = row[2 * i]; }
-                else
-                {
-                    size_t bit = i * depth;
-                    unsigned v = (row[bit >> 3] >> (8 - depth - (bit & 7))) & ((1u << depth) - 1u);
-                    s16[k] = v;
-                    // stb scales 1/2/4-bit grey to 0..255; palette indices stay as they are
-                    s8[k] = color == 3 ? v : v * (depth == 1 ? 255u : depth == 2 ? 85u : 17u);
-                }
+                const unsigned v = smp[((size_t)y * w + x) * samples + k];
+                s16[k] = v;
+                if (depth == 8) s8[k] = v;
+                else if (depth == 16) s8[k] = v >> 8;
+                // stb scales 1/2/4-bit grey to 0..255; palette indices stay as they are
+                else s8[k] = color == 3 ? v : v * (depth == 1 ? 255u : depth == 2 ? 85u : 17u);
             }
             unsigned char* o = &px[((size_t)y * w + x) * n];
             if (color == 3)

@@ -445,18 +445,18 @@ void Scene::Load(const char* filename, float scale, bool flip_yz)
     materials_.resize(obj_materials.size());
     const float kGamma = 2.2f;
     const std::uint32_t kInvalidTextureIndex = 0xFF;
-    // wide mode (extension): the index goes to the 16-bit side table and the packed 8-bit field says "none"
-    std::vector<std::uint16_t> wide;
-    if (wide_texture_indices_) wide.assign(obj_materials.size() * 6, 0xFFFFu);
+    // wide mode (extension): the index goes to the 16-bit side table and the packed 8-bit field says "none".  Asked for by
+    // the caller (Scene::kWideTextureIndices) or switched on -- with a warning -- when the scene turns out to hold more
+    // textures than the reference's 8-bit fields can name (Bistro does): the table is always filled, and adopted afterwards.
+    std::vector<std::uint16_t> wide(obj_materials.size() * 6, 0xFFFFu);
     size_t wide_at = 0;
     auto tex = [&](const std::string& name) -> std::uint32_t
     {
         const size_t slot = wide_at++;
         if (name.empty()) return kInvalidTextureIndex;
         const std::uint32_t idx = (std::uint32_t)LoadTexture(folder + "/" + name);
-        if (!wide_texture_indices_) return idx;
         wide[slot] = (std::uint16_t)idx;
-        return kInvalidTextureIndex;
+        return idx < kInvalidTextureIndex ? idx : kInvalidTextureIndex;
     };
     for (size_t i = 0; i < obj_materials.size(); ++i)
     {
@@ -477,7 +477,25 @@ void Scene::Load(const char* filename, float scale, bool flip_yz)
         std::uint32_t tidx = tex(in.alpha_tex);
         out.ior_emission_idx_transparency = PackIorEmissionIdxTransparency(in.ior, eidx, in.transmittance[0], tidx);
     }
-    material_texture_indices_ = std::move(wide);
+    if (!wide_texture_indices_ && textures_.size() > 255)
+    {
+        std::fprintf(stderr, "warning: %s uses %zu textures, more than the 255 the reference's 8-bit texture indices can name "
+                             "(constants.h:35, scene.cpp:55); switching to 16-bit texture indices (Scene::kWideTextureIndices)\n",
+            filename, textures_.size());
+        wide_texture_indices_ = true;
+    }
+    if (wide_texture_indices_)
+    {
+        for (PackedMaterial& m : materials_)           // the packed fields say "none": the side table names the textures
+        {
+            m.diffuse_albedo |= 0xFF000000u;
+            m.specular_albedo |= 0xFF000000u;
+            m.roughness_metalness |= 0xFF00FF00u;
+            m.ior_emission_idx_transparency |= 0xFF00FF00u;
+        }
+        material_texture_indices_ = std::move(wide);
+    }
+    else material_texture_indices_.clear();
 
     // triangles (scene.cpp:188-270)
     auto flip = [flip_yz](float3& p)
@@ -530,8 +548,6 @@ std::size_t Scene::LoadTexture(const std::string& filename)   // scene.cpp:276-3
     else if (ext == ".png") ok = LoadPNG(filename.c_str(), image);
     else if (ext == ".jpg") ok = LoadJPEG(filename.c_str(), image);
     if (!ok) throw std::runtime_error("Failed to load file " + filename);
-    if (!wide_texture_indices_ && textures_.size() >= 255)
-        throw std::runtime_error("More than 255 textures (8-bit texture index, constants.h:35); load with Scene::kWideTextureIndices (rt_render --wide_texture_indices)");
     if (textures_.size() >= 0xFFFFu) throw std::runtime_error("More than 65535 textures");
     Texture t;
     t.width = (int)image.width;

@@ -299,14 +299,9 @@ class TestAgainstReferenceHost:
 # ---------------------------------------------------------------------------
 # PNG textures (png_loader.cpp) -- what LoadSTB/stb_image would hand to the path
 # ---------------------------------------------------------------------------
-def _write_png(path, pixels, color, depth=8, palette=None, trns=None, filters=None):
-    """Minimal PNG writer for tests: pixels = uint array [h, w, samples]."""
-    import struct
-    import zlib
+def _png_rows(pixels, depth, filters, row0=0):
+    """filtered scanlines (PNG spec 9.2) of one (reduced) image: pixels = uint array [h, w, samples]"""
     h, w, s = pixels.shape
-    def chunk(tag, data):
-        c = struct.pack(">I", len(data)) + tag + data
-        return c + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
     rows = []
     prev = None
     for y in range(h):
@@ -319,7 +314,7 @@ def _write_png(path, pixels, color, depth=8, palette=None, trns=None, filters=No
             bits += "0" * (-len(bits) % 8)
             raw = bytes(int(bits[i:i + 8], 2) for i in range(0, len(bits), 8))
         raw = np.frombuffer(raw, np.uint8).astype(np.int32)
-        ft = filters[y % len(filters)] if filters else 0
+        ft = filters[(y + row0) % len(filters)] if filters else 0
         bpp = max(1, s * depth // 8)
         a = np.concatenate([np.zeros(bpp, np.int32), raw[:-bpp]]) if len(raw) > bpp else np.zeros_like(raw)
         b = prev if prev is not None else np.zeros_like(raw)
@@ -335,7 +330,26 @@ def _write_png(path, pixels, color, depth=8, palette=None, trns=None, filters=No
             enc = raw - pred
         rows.append(bytes([ft]) + (enc & 0xFF).astype(np.uint8).tobytes())
         prev = raw
-    data = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, color, 0, 0, 0))
+    return rows
+
+
+def _write_png(path, pixels, color, depth=8, palette=None, trns=None, filters=None, interlace=False):
+    """Minimal PNG writer for tests: pixels = uint array [h, w, samples]; interlace = Adam7 (PNG spec 8.2)."""
+    import struct
+    import zlib
+    h, w, s = pixels.shape
+    def chunk(tag, data):
+        c = struct.pack(">I", len(data)) + tag + data
+        return c + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
+    if not interlace:
+        rows = _png_rows(pixels, depth, filters)
+    else:
+        rows = []
+        for i, (x0, y0, dx, dy) in enumerate(((0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (0, 2, 2, 4), (1, 0, 2, 2), (0, 1, 1, 2))):
+            sub = pixels[y0::dy, x0::dx]
+            if sub.shape[0] and sub.shape[1]:
+                rows += _png_rows(sub, depth, filters, row0=i)
+    data = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, color, 0, 0, 1 if interlace else 0))
     if palette is not None:
         data += chunk(b"PLTE", bytes(palette))
     if trns is not None:
@@ -356,6 +370,8 @@ def _png_cases(rng):
         ("pal4t", rng.randint(0, 4, (5, 6, 1)), 3, 4, [255, 0, 0, 0, 255, 0, 0, 0, 255, 9, 8, 7], [0, 128]),
         ("grey2", rng.randint(0, 4, (4, 7, 1)), 0, 2, None, None),
         ("rgb8key", np.tile(np.array([[[1, 2, 3], [9, 9, 9]]]), (3, 2, 1)), 2, 8, None, [0, 1, 0, 2, 0, 3]),
+        ("rgb8_larger", rng.randint(0, 256, (19, 23, 3)), 2, 8, None, None),
+        ("grey1_larger", rng.randint(0, 2, (17, 21, 1)), 0, 1, None, None),
     ]
 
 
@@ -365,6 +381,9 @@ def test_png_loader_expected_texels(tmp_path):
         p = str(tmp_path / (name + ".png"))
         _write_png(p, px, color, depth, pal, trns, filters=[0, 1, 2, 3, 4])
         got = host.load_png(p)
+        pi = str(tmp_path / (name + "_adam7.png"))
+        _write_png(pi, px, color, depth, pal, trns, filters=[4, 0, 3, 1, 2], interlace=True)
+        assert np.array_equal(host.load_png(pi), got), name + " (Adam7)"
         h, w, s = px.shape
         v = px.astype(np.uint32)
         if depth == 16:
@@ -422,6 +441,8 @@ def test_png_and_tga_texels_identical_to_stb_image(tmp_path):
         p = str(tmp_path / (name + ".png"))
         _write_png(p, px, color, depth, pal, trns, filters=[4, 3, 2, 1, 0])
         assert np.array_equal(host.load_png(p), _ref.load_stb(p)), name
+        _write_png(p, px, color, depth, pal, trns, filters=[1, 4, 2, 0, 3], interlace=True)       # Adam7, pinned to stb as well
+        assert np.array_equal(host.load_png(p), _ref.load_stb(p)), name + " (Adam7)"
     w, h = 6, 4
     rgb = rng.randint(0, 256, size=(h, w, 4)).astype(np.uint8)
     hdr = bytes([0, 0, 2, 0, 0, 0, 0, 0, 0, 0, 0, 0, w, 0, h, 0, 32, 8])
@@ -446,12 +467,14 @@ def _many_textures_obj(tmp_path, n):
 
 def test_more_than_255_textures_need_the_wide_index_extension(tmp_path):
     """The reference packs texture indices into 8 bits (constants.h:35; PackAlbedo asserts, scene.cpp:55).  The loader
-    refuses a 256th texture unless asked for the 16-bit side table (Scene::kWideTextureIndices); that table, not the packed
+    switches to the 16-bit side table at the 256th texture (with a warning; Scene::kWideTextureIndices asks for it up front); that table, not the packed
     fields, then names the textures, survives the binary cache, and equals the packed fields on a small scene."""
     path = _many_textures_obj(tmp_path, 300)
-    with pytest.raises(host.RtError, match="More than 255 textures"):
-        host.Scene(path)
+    auto = host.Scene(path).arrays()                                            # not asked for: switched on with a warning, not refused
+    assert auto["material_texture_indices"].shape == (300, 6) and len(auto["textures"]) == 300
     s = host.Scene(path, wide_texture_indices=True)
+    assert np.array_equal(s.arrays()["material_texture_indices"], auto["material_texture_indices"])
+    assert np.array_equal(s.arrays()["materials"], auto["materials"])
     nodes = s.build_bvh()
     s.finalize()
     a = s.arrays()
