@@ -37,18 +37,23 @@ the gather then goes through gloo): plumbing check on a one-GPU box.
 (synthetic tiles, no rendering, "value": null).
 
 Extra objects on the JSON line:
-  roofline     the dominant kernel (closest-hit traversal) against CALIBRATED ceilings:
-               busy fractions of the vector ALU, the scalar ALU and the L1/texture-address
-               path and the HBM rate from rocprofv3 --pmc passes of this workload
-               (profiles/r02_trace_counters.json, made by tools/make_counters_json.py;
-               ceilings from tools/issue_microbench.hip); `bound` = the unit nearest its
-               ceiling, `frac` <= 1 by construction.  Launch duration and rays per launch
-               are measured live (HIP events on the library's stream).
-               `sensitivity`: measured change of the kernel's time for one more access / more vector
-               instructions per node visit / fewer resident waves (profiles/r02_kernel_sensitivity.json).
+  per_frame    the reference's OWN call pattern beside the headline: K x Render::RenderFrame() =
+               Integrator::Integrate() through the fifteen stage hooks, one sample per pixel per call,
+               ResolveRadiance + host sync every frame (src/render.cpp:197): mrays_per_s, ms_per_frame.
+  roofline     the dominant kernel (closest-hit traversal).  bound "hbm": `achieved` = HBM GB/s from the
+               rocprofv3 --pmc passes of this workload (profiles/r03_trace_counters.json, made by
+               tools/pmc_bench2.sh + tools/make_counters_json.py), `frac` = achieved / 8 TB/s, `traffic` =
+               HBM bytes per launch, next to SURVEY 8d's algorithmic bytes; `units` = busy fractions of the
+               vector ALU / scalar ALU / L1-texture-address path against calibrated ceilings;
+               `latency_ceiling` = the kernel's useful traversal steps per second against the bare
+               visit chain's (tools/visit_microbench.hip); `counters.stale` = the counter file was
+               collected from another code object than the library now running.  Launch duration and
+               rays per launch are measured live (HIP events on the library's streams).
   parity       at N = 1: the frame the cpu_baseline leg renders with the reference's own
                kernels is rendered again on the GPU (same samples, outside the timed
-               region) and compared: bit_identical, rel_l2, non-finite pixels on both sides.
+               region) and compared: bit_identical, rel_l2, non-finite pixels on both sides;
+               rel_l2_vs_libm_build: the same frame rendered by the reference kernels over glibc's libm
+               instead of the project's rt_detmath.h (an independent pin of the transcendentals).
   cpu_baseline the reference's own OpenCL kernels compiled for x86-64 (oracle/_ref, kind
                "reference") or the C restatement (kind "port"), timed on this box's host
                cores on a bounded sample.
@@ -68,7 +73,8 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 LIGHT = ((-0.6, -1.5, 3.5), (15.0, 10.0, 5.0))   # reference main.cpp:58
-COUNTERS_FILE = os.path.join(ROOT, "profiles", "r02_trace_counters.json")
+COUNTERS_FILE = os.path.join(ROOT, "profiles", "r03_trace_counters.json")
+VISIT_MICROBENCH_FILE = os.path.join(ROOT, "profiles", "r03_visit_microbench.json")
 SENSITIVITY_FILE = os.path.join(ROOT, "profiles", "r02_kernel_sensitivity.json")
 
 
@@ -85,7 +91,13 @@ CONFIGS = {
 }
 
 
-def build_scene(args, host, S):
+def finish_scene(scene):
+    scene.add_directional_light(*LIGHT)
+    scene.set_env_path(os.path.join(ROOT, "assets", "ibl", "CGSkies_0036_free.hdr"))
+    return scene, scene.lib.rth_scene_num_triangles(scene.handle)
+
+
+def build_scene(args, host, S, finish=True):
     if getattr(args, "scene", None):
         # a real asset: OBJ/MTL through the C++ loader, or a binary cache written by rt_render --save-cache
         scene = host.Scene(args.scene, scale=args.scale, flip_yz=args.flip_yz, wide_texture_indices=getattr(args, "wide_texture_indices", False))
@@ -100,9 +112,9 @@ def build_scene(args, host, S):
     else:
         tris, mats = S.cornell_blob(args.blob_tris, args.ball_tris)
         scene = host.Scene(arrays=dict(triangles=tris, materials=mats))
-    scene.add_directional_light(*LIGHT)
-    scene.set_env_path(os.path.join(ROOT, "assets", "ibl", "CGSkies_0036_free.hdr"))
-    return scene, scene.lib.rth_scene_num_triangles(scene.handle)
+    if not finish:
+        return scene
+    return finish_scene(scene)
 
 
 def cpu_legs(args, scene_arrays, cam_small, small_w, small_h, cam_full):
@@ -113,13 +125,45 @@ def cpu_legs(args, scene_arrays, cam_small, small_w, small_h, cam_full):
     orc.set_camera(cam_small)
     orc.set_max_bounces(args.bounces)
     t0 = time.time()
-    orc.integrate(1)
+    # one sample, stage by stage (the schedule of Integrator::Integrate), so that the queues of every bounce can also be
+    # walked by the CPU restatement of k_trace_w4 (oracle.c: orc_wide_trace): steps per ray of the production kernel
+    wide_cnt = {False: np.zeros(10, np.uint64), True: np.zeros(10, np.uint64)}
+    try:
+        from tests.test_wide_bvh import wide_of
+        from raytracing_amd import types as T
+        wide, wide_entry = wide_of(scene_arrays["nodes"])
+    except Exception:
+        wide = None
+    n_small = small_w * small_h
+    orc.stage("reset"); orc.stage("generate_rays")
+    c = s = 0
+    for bounce in range(args.bounces + 1):
+        k = int(orc.buffer("ray_counter%d" % (bounce & 1), np.uint32, 1)[0])
+        c += k
+        if wide is not None:
+            orc.wide_trace(wide, wide_entry, orc.buffer("rays%d" % (bounce & 1), T.ray, n_small)[:k], False, wide_cnt[False], direct=True)
+        orc.stage("intersect", bounce)
+        for stg, sargs in (("shade_miss", (bounce,)), ("clear_counters", (bounce,)), ("shade_hits", (bounce,))):
+            orc.stage(stg, *sargs)
+        ks = int(orc.buffer("shadow_ray_counter", np.uint32, 1)[0])
+        s += ks
+        if wide is not None:
+            orc.wide_trace(wide, wide_entry, orc.buffer("shadow_rays", T.ray, n_small)[:ks], True, wide_cnt[True], direct=True)
+        orc.stage("intersect_shadow")
+        orc.stage("accumulate")
+    orc.stage("advance")
     t_orc = time.time() - t0
-    c, s = orc.ray_totals()
     st = orc.stats()
     per_ray = dict(closest_nodes=st["closest_nodes"] / max(c, 1), closest_tris=st["closest_tris"] / max(c, 1),
                    shadow_nodes=st["shadow_nodes"] / max(s, 1), shadow_tris=st["shadow_tris"] / max(s, 1))
-    baseline, ref_img, ref_spp = None, None, 0
+    if wide is not None:
+        for key, cnt in (("closest", wide_cnt[False]), ("shadow", wide_cnt[True])):
+            r = max(int(cnt[0]), 1)
+            # a step = one pass of a lane through loop C (a wide node) or loop B (a leaf arrival whose exact box fails, or
+            # one triangle): wide_visits + leaf_box_fails + triangle_tests (Oracle.WIDE_COUNTERS)
+            per_ray[key + "_wide_visits"] = float(cnt[1]) / r
+            per_ray[key + "_steps"] = float(cnt[1] + cnt[3] + cnt[4]) / r
+    baseline, ref_img, ref_spp, libm_img = None, None, 0, None
     if not args.no_cpu_baseline and args.gpus == 1:          # the CPU baseline is timed at N = 1 only
         cores = os.cpu_count() or 1
         if _ref.available():
@@ -153,6 +197,18 @@ def cpu_legs(args, scene_arrays, cam_small, small_w, small_h, cam_full):
             dt = time.time() - t0
             rays = sum(ri.ray_totals()) - r0
             ref_img, ref_spp = ri.radiance()[..., :3].copy(), n + 1
+            # the same frame, same samples, by the reference kernels over glibc's libm instead of rt_detmath.h: an
+            # INDEPENDENT pin of the transcendentals all three sides otherwise share (OpenCL leaves their rounding
+            # implementation-defined; the tolerance of the north star, 1e-4, is what such a difference may cost)
+            libm_img = None
+            if _ref.available(libm=True):
+                del ri
+                rl = _ref.RefIntegrator(args.width, args.height, scene_arrays, threads=best_t, libm=True)
+                rl.set_camera(cam_full)
+                rl.set_max_bounces(args.bounces)
+                rl.integrate(ref_spp)
+                libm_img = rl.radiance()[..., :3].copy()
+                del rl
             baseline = dict(value=round(rays / dt / 1e6, 3), unit="Mrays/s", cores=best_t, kind="reference",
                             opencl_cpu_device=opencl_cpu_device(),
                             sample="%d spp of the same scene at %dx%d, %d bounces (%.1f s; the reference's unmodified "
@@ -164,7 +220,7 @@ def cpu_legs(args, scene_arrays, cam_small, small_w, small_h, cam_full):
             baseline = dict(value=(c + s) / t_orc / 1e6, unit="Mrays/s", cores=1, kind="port",
                             sample="1 spp of the same scene at %dx%d, %d bounces (%.1f s, oracle/oracle.c, scalar)"
                                    % (small_w, small_h, args.bounces, t_orc))
-    return per_ray, baseline, ref_img, ref_spp
+    return per_ray, baseline, ref_img, ref_spp, libm_img
 
 
 def opencl_cpu_device():
@@ -261,12 +317,12 @@ def plumbing_only(args, rank, world):
     return 0
 
 
-def per_frame_leg(args, render, lib, frame, capi, frames):
+def per_frame_leg(args, render, lib, frame, capi, frames, resolve=True):
     """The reference's own call pattern (src/render.cpp:172-204): K x Render::RenderFrame() = Integrator::Integrate()
     through the fifteen stage hooks, ONE sample per pixel per call, each frame ending with ResolveRadiance and its
     host synchronisation (cl_pt_integrator.cpp:677-684).  Untimed by the headline; reported beside it."""
     assert lib.rt_reset(frame) == 0
-    render.set_resolve_every_frame(True)
+    render.set_resolve_every_frame(resolve)
     for _ in range(3):
         render.render_frame()
     render.finish()
@@ -280,14 +336,26 @@ def per_frame_leg(args, render, lib, frame, capi, frames):
     render.set_resolve_every_frame(False)
     rays = float((st1.closest_rays - st0.closest_rays) + (st1.shadow_rays - st0.shadow_rays))
     return dict(mrays_per_s=round(rays / dt / 1e6, 1), ms_per_frame=round(dt * 1e3 / frames, 4), frames=frames,
-                rays_per_frame=round(rays / frames, 1), samples_in_flight=1, resolve_every_frame=True,
+                rays_per_frame=round(rays / frames, 1), samples_in_flight=1, resolve_every_frame=bool(resolve),
                 call_pattern="K x Render::RenderFrame() -> Integrator::Integrate() through the 15 stage hooks of HIPPathTraceIntegrator, "
                              "1 sample per pixel per call, ResolveRadiance + host sync every frame (src/render.cpp:197, "
                              "src/integrator/integrator.cpp:27-59)")
 
 
-def roofline_object(args, world, agg, prof, per_ray, spp_timed):
-    """The dominant kernel against calibrated ceilings (see the module docstring)."""
+def roofline_object(args, world, agg, prof, per_ray, spp_timed, isolated):
+    """`roofline` for the dominant kernel, the closest-hit traversal (k_trace_w4<closest>).  Every number follows a stated
+    formula from (a) what this run measured live with HIP events on the library's streams and (b) committed counter files
+    under profiles/, each tied to the code object it was collected from (`stale` when that is not the library running now).
+
+      bound / achieved / peak / frac   the north star's quantity: HBM traffic the counters saw per launch / launch duration,
+                                       against the 8 TB/s peak.  frac = achieved / peak.
+      traffic                          HBM bytes per launch = (FETCH_SIZE x 0.99 + WRITE_SIZE) KiB (tools/make_counters_json.py)
+      algorithmic                      SURVEY 8d's per-ray byte model x rays per launch, and traffic / algorithmic
+      units                            busy fractions of the units the kernel can saturate, against calibrated ceilings
+      latency_ceiling                  useful wide-tree steps per second of the kernel against the rate of the BARE visit chain
+                                       (tools/visit_microbench.hip: fetch a 64-byte node -> dequantise -> 4 slab tests -> order ->
+                                       LDS push / pop, every lane busy, nothing else) at its best residency and the kernel's own
+                                       L1 / L2 hit mix:  ceiling_grays = visits_per_s / steps_per_ray."""
     n_launch = max(prof.n_trace_closest, 1) * world
     ms_sum = agg[2]
     avg_ms = ms_sum / n_launch
@@ -298,32 +366,76 @@ def roofline_object(args, world, agg, prof, per_ray, spp_timed):
                 mrays_per_s=round(agg[0] / (ms_sum * 1e-3) / 1e6, 1) if ms_sum > 0 else 0.0,
                 kernel_ms_per_spp=dict(trace_closest=round(agg[2] / world / spp_timed, 4), trace_shadow=round(agg[3] / world / spp_timed, 4),
                                         shade=round(agg[4] / world / spp_timed, 4), raygen=round(agg[5] / world / spp_timed, 4)),
-                algorithmic_bytes_per_ray=round(bytes_closest, 1), nodes_per_ray=round(per_ray["closest_nodes"], 2),
-                tris_per_ray=round(per_ray["closest_tris"], 2))
-    alg_gbs = (agg[0] * bytes_closest) / (ms_sum * 1e-3) / 1e9 if ms_sum > 0 else 0.0
-    out = dict(bound="unknown", achieved=None, peak=None, unit=None, frac=None, traffic=None, live=live,
-               hbm_algorithmic=dict(GBs=round(alg_gbs, 1), peak_GBs=HBM_PEAK_GBS, ratio=round(alg_gbs / HBM_PEAK_GBS, 4),
-                                    note="SURVEY 8d byte model (48 + 32 n_nodes + 36 n_tris per ray on the reference BVH2): a "
-                                         "cache-blind count of LOGICAL bytes, not HBM traffic -- kept for continuity, not a ceiling"))
+                note="HIP-event SPANS inside the timed region: the shadow trace of bounce b runs beside the closest-hit trace of "
+                     "bounce b + 1 on a second stream, so these spans overlap and are NOT a cost breakdown (their sum exceeds "
+                     "ms_per_spp); live_isolated has the costs")
+    # the kernel alone on the machine (one more, untimed step with every launch on one stream) is what the counters describe
+    iso_ms = isolated["avg_launch_ms"] if isolated else avg_ms
+    iso_rays = isolated["rays_per_launch"] if isolated else rays_per_launch
+    achieved_grays = iso_rays / (iso_ms * 1e-3) / 1e9 if iso_ms > 0 else 0.0
+    alg_bytes = iso_rays * bytes_closest
+    out = dict(kernel="k_trace_w4<closest> (the dominant kernel: %.0f %% of the kernels' time)" %
+               (100.0 * (isolated["kernel_ms_per_spp"]["trace_closest"] / max(sum(isolated["kernel_ms_per_spp"].values()), 1e-9)) if isolated else 0.0),
+               bound="hbm", achieved=None, peak=HBM_PEAK_GBS, unit="GB/s", frac=None, traffic=None, live=live,
+               algorithmic=dict(bytes_per_ray=round(bytes_closest, 1), nodes_per_ray=round(per_ray["closest_nodes"], 2),
+                                tris_per_ray=round(per_ray["closest_tris"], 2), bytes_per_launch=round(alg_bytes, 0),
+                                GBs=round(alg_bytes / (iso_ms * 1e-3) / 1e9, 1) if iso_ms > 0 else None,
+                                ratio_to_hbm_peak=round(alg_bytes / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if iso_ms > 0 else None,
+                                note="SURVEY 8d byte model (48 + 32 n_nodes + 36 n_tris per ray on the reference's BVH2): LOGICAL "
+                                     "bytes of the reference's walk; the kernel visits a quarter as many (wide, 8-bit) nodes and "
+                                     "serves them from L1 / L2, so this is a count, not traffic and not a ceiling"))
+    from raytracing_amd import codeobj
+    running = codeobj.code_object_sha256()
     try:
-        pmc = json.load(open(COUNTERS_FILE))["config_%d" % args.config]
+        doc = json.load(open(COUNTERS_FILE))
+        k = doc["config_%d" % args.config]["closest"]
     except Exception:
-        return out
-    k = pmc["closest"]
-    units = {n: k[n] for n in ("valu_busy", "salu_busy", "l1_ta_busy", "hbm_frac") if k.get(n) is not None}
-    bound = max(units, key=units.get)
-    out.update(bound=bound, achieved=round(units[bound], 4), peak=1.0,
-               unit="busy fraction of the unit's calibrated ceiling (1.0 = saturated)", frac=round(units[bound], 4),
-               traffic=k.get("hbm_bytes_per_launch"),
-               units=units, counters_per_launch=k.get("per_launch"), source="profiles/r02_trace_counters.json (rocprofv3 --pmc passes of this "
-               "workload at N = 1, round 2; ceilings: profiles/r02_issue_microbench.log)",
-               hbm_counter=dict(GBs=k.get("hbm_GBs"), peak_GBs=HBM_PEAK_GBS, frac=k.get("hbm_frac")))
+        out["counters"] = dict(file=os.path.relpath(COUNTERS_FILE, ROOT), error="no counters for this config: achieved / frac / traffic unavailable")
+        k = None
+    if k is not None:
+        stale = doc.get("_code_object_sha256") != running
+        traffic = float(k["hbm_bytes_per_launch"])
+        achieved = traffic / (float(k["avg_launch_ms"]) * 1e-3) / 1e9
+        out.update(achieved=round(achieved, 1), frac=round(achieved / HBM_PEAK_GBS, 4), traffic=round(traffic, 0),
+                   formula="achieved = traffic / avg_launch_ms of the profiled launches (%.3f ms; this run, alone on the machine: %.3f ms); "
+                           "frac = achieved / peak; traffic = (FETCH_SIZE x 0.99 + WRITE_SIZE) KiB per launch" % (k["avg_launch_ms"], iso_ms),
+                   stale=bool(stale))
+        out["algorithmic"]["traffic_over_algorithmic"] = round(traffic / alg_bytes, 4) if alg_bytes > 0 else None
+        out["units"] = dict(valu_busy=round(k["valu_busy"], 4), salu_busy=round(k["salu_busy"], 4), l1_ta_busy=round(k["l1_ta_busy"], 4),
+                            hbm_frac=round(k["hbm_frac"], 4), valu_fast_opcode_fraction=k.get("valu_fast_opcode_fraction"),
+                            l1_accesses_per_clock_per_cu=round(k["per_launch"]["l1_accesses"] / k["cycles_per_launch"] / 256.0, 3),
+                            note="busy fraction of each unit's calibrated ceiling (tools/make_counters_json.py; 1.0 = saturated): "
+                                 "the vector ALU and the L1 / texture-address path are both near theirs, HBM is not")
+        out["counters"] = dict(file=os.path.relpath(COUNTERS_FILE, ROOT), per_launch=k.get("per_launch"), launches_profiled=k.get("launches_profiled"),
+                               code_object_sha256=doc.get("_code_object_sha256"), running_code_object_sha256=running, stale=bool(stale),
+                               how=doc.get("_how"))
+    # the latency / visit-rate ceiling
     try:
-        # how the kernel's time responds to one more L1 access / 16 more vector instructions per node visit / fewer resident
-        # waves (measured with compile-time variants; only meaningful for the headline workload it was measured on)
+        mb = json.load(open(VISIT_MICROBENCH_FILE))
+        runs = [r for r in mb["runs"] if r["kernel"] == "closest"]
+        best = max(runs, key=lambda r: r["gvisits_per_s"])
+        alone = min(runs, key=lambda r: r["waves_per_cu"])
+        at26 = [r for r in runs if r["waves_per_cu"] == 26]
+        steps = per_ray.get("closest_steps")
+        if steps:
+            ceiling = best["gvisits_per_s"] / steps
+            out["latency_ceiling"] = dict(
+                visit_ns_alone=alone["ns_per_visit"], visit_ns_at_26_waves_per_cu=at26[0]["ns_per_visit"] if at26 else None,
+                best_gvisits_per_s=best["gvisits_per_s"], best_at_waves_per_cu=best["waves_per_cu"],
+                l1_hit=mb.get("l1_hit"), l2_hit=mb.get("l2_hit"),
+                steps_per_ray=round(steps, 2), wide_visits_per_ray=round(per_ray.get("closest_wide_visits", 0.0), 2),
+                achieved_gsteps_per_s=round(achieved_grays * steps, 1), ceiling_grays=round(ceiling, 3), achieved_grays=round(achieved_grays, 3),
+                frac_of_ceiling=round(achieved_grays / ceiling, 4) if ceiling > 0 else None,
+                formula="ceiling_grays = best_gvisits_per_s / steps_per_ray; achieved_grays = rays per launch / launch duration (the kernel "
+                        "alone on the machine); steps_per_ray = wide-node visits + leaf passes per ray, counted by the CPU restatement of "
+                        "the walk (oracle.c: orc_wide_trace) on a 320x180 frame of the same scene",
+                source=os.path.relpath(VISIT_MICROBENCH_FILE, ROOT) + " (tools/visit_microbench.hip on MI355X)")
+    except Exception:
+        pass
+    try:
         if args.config == 4:
             sens = json.load(open(SENSITIVITY_FILE))
-            out["sensitivity"] = dict(sens["k_trace_w4_closest"], source="profiles/r02_kernel_sensitivity.json (gpurun calls 43 / 44, round 2)")
+            out["sensitivity"] = dict(sens["k_trace_w4_closest"], source="profiles/r02_kernel_sensitivity.json (round 2's kernel: gpurun calls 43 / 44)")
     except Exception:
         pass
     return out
@@ -369,6 +481,7 @@ def main():
     ap.add_argument("--debug-shared-gpu", action="store_true",
                     help="plumbing test only: all ranks share GPU 0 and gather over gloo (RCCL refuses two ranks per device)")
     ap.add_argument("--plumbing-only", action="store_true", help="no GPU: launch, rendezvous, gather and report only")
+    ap.add_argument("--no-scene-cache", action="store_true", help="N > 1: every rank builds the scene and the BVH itself")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
     args.width = args.width or cfg["width"]
@@ -405,11 +518,33 @@ def main():
             group = capi.Group.join(world, rank, ids[0], local_rank)
 
     # ---- setup (untimed): scene, BVH, upload -------------------------------
-    scene, n_tris = build_scene(args, host, S)
     t0 = time.time()
+    if world > 1 and not args.no_scene_cache:
+        # ONE rank parses / generates the scene and builds the BVH; it leaves both in a binary scene cache
+        # (Scene::SaveCache) the other ranks load -- N ranks on one host would otherwise do the same host work N times
+        import tempfile
+        cache = os.path.join(tempfile.gettempdir(), "rt_bench_%s_%d.rtscene" % (os.environ.get("MASTER_PORT", "0"), os.getppid()))
+        if rank == 0:
+            raw = build_scene(args, host, S, finish=False)
+            raw.save_cache(cache)
+            raw.close()
+        dist.barrier()
+        scene, n_tris = finish_scene(host.Scene(cache))
+        scene_source = "rank 0 built the scene + BVH once and wrote a scene cache; every rank loaded it"
+    else:
+        scene, n_tris = build_scene(args, host, S)
+        scene_source = "built by this rank"
+    t_scene = time.time() - t0
     render = host.Render(args.width, args.height, scene, device=local_rank, tile_rank=rank, tile_count=world,
-                         band_height=args.band_height)      # builds the BVH, finalises, uploads
+                         band_height=args.band_height)      # builds the BVH (or adopts the cached one), finalises, uploads
     t_setup = time.time() - t0
+    if world > 1 and not args.no_scene_cache:
+        dist.barrier()
+        if rank == 0:
+            try:
+                os.remove(cache)
+            except OSError:
+                pass
     cam = host.default_camera(args.width, args.height)
     render.set_camera(cam)
     render.set_max_bounces(args.bounces)
@@ -510,6 +645,14 @@ def main():
         dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
     agg = agg.numpy()
     dt_max = float(tmax[0].item())
+    # every rank's own numbers, so that imbalance is attributable (not only min / max)
+    mine = dict(rank=rank, render_ms=round(t_render * 1e3, 3), gather_ms=round((t_local - t_render) * 1e3, 3), setup_s=round(t_setup, 2),
+                scene_s=round(t_scene, 2), rows=int(local_rows), rays=float(closest + shadow),
+                rccl=(list(group.comm_count()) if group is not None else None))
+    per_rank = [mine]
+    if world > 1:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
     full = gather(True)                                      # untimed: the image for the checks below
     # One more step, untimed, with every launch on one stream: in the timed region the shadow trace of bounce b runs
     # beside the closest-hit trace of bounce b + 1 (RT_OPT_OVERLAP_SHADOW), so the launch durations there include the
@@ -547,7 +690,7 @@ def main():
         # CPU legs on a reduced frame of the same scene (bounded, see docstring)
         small_w, small_h = 320, 180          # oracle counters + CPU baseline frame
         arrays = render.scene_arrays()
-        per_ray, baseline, ref_img, ref_spp = cpu_legs(args, arrays, host.default_camera(small_w, small_h), small_w, small_h, cam)
+        per_ray, baseline, ref_img, ref_spp, libm_img = cpu_legs(args, arrays, host.default_camera(small_w, small_h), small_w, small_h, cam)
         parity = None
         if ref_img is not None and world == 1:
             # the SAME samples on the GPU (outside the timed region), compared with the reference kernels' image
@@ -563,22 +706,31 @@ def main():
                           tolerance=1e-4, nan_pixels_ref=int((~np.isfinite(ref_img).all(-1)).sum()),
                           nan_pixels_hip=int((~np.isfinite(got).all(-1)).sum()),
                           differing_pixels=int((~((got == ref_img) | (np.isnan(got) & np.isnan(ref_img))).all(-1)).sum()))
+            if libm_img is not None:
+                finl = np.isfinite(libm_img).all(-1) & np.isfinite(got).all(-1)
+                numl = np.linalg.norm((got[finl].astype(np.float64) - libm_img[finl]).ravel())
+                denl = np.linalg.norm(libm_img[finl].astype(np.float64).ravel())
+                parity["rel_l2_vs_libm_build"] = float(numl / denl) if denl > 0 else 0.0
+                parity["libm_build"] = ("oracle/_ref/libref_libm.so: the same reference kernels with glibc libm builtins instead of "
+                                        "raytracing_amd/csrc/rt_detmath.h, same frame and samples; %d pixels differ" %
+                                        int((~((got == libm_img) | (np.isnan(got) & np.isnan(libm_img))).all(-1)).sum()))
+                parity["libm_build_within_tolerance"] = bool(parity["rel_l2_vs_libm_build"] < 1e-4)     # reported, not asserted: the bit-exact pin is libref.so
             assert parity["rel_l2"] < 1e-4, "radiance differs from the reference kernels: %r" % parity
         else:
             # NaN pixels are legal in the reference arithmetic (inf * 0 in the mirror branch) but must be rare
             assert nan_px <= 1e-4 * args.width * args.height, "too many non-finite pixels: %d" % nan_px
-        roofline = roofline_object(args, world, agg, prof, per_ray, spp_timed)
-        if overlap_on:
-            roofline["live"]["concurrent"] = ("the shadow trace of the previous bounce runs beside this launch on a second stream "
-                                              "(RT_OPT_OVERLAP_SHADOW = 1): these durations include the sharing")
+        roofline = roofline_object(args, world, agg, prof, per_ray, spp_timed, isolated)
         if isolated is not None:
             roofline["live_isolated"] = isolated
         name, cus, mem = render_ctx_info(capi, host, render)
         if world == 1:
             gather_info = dict(transport="none (single tile, device copy)", ms=round(float(tmax[2].item()) * 1e3, 3), nranks=1)
         else:
+            rccl_counts = sorted({r["rccl"][0] for r in per_rank if r["rccl"]})
             gather_info = dict(transport="gloo over host memory (--debug-shared-gpu)" if group is None else
                                "RCCL ncclGather over xGMI (rt_group_gather_radiance)", nranks=world,
+                               rccl_nranks=(rccl_counts[0] if len(rccl_counts) == 1 else rccl_counts) if rccl_counts else None,   # ncclCommCount on every rank
+                               rccl_user_ranks=[r["rccl"][1] for r in per_rank] if rccl_counts else None,
                                ms_max=round(float(tmax[2].item()) * 1e3, 3), bytes_per_rank=int(D.max_tile_rows(args.height, world, args.band_height)) * args.width * 16)
         line = dict(metric="Mrays/s (all bounces+shadow)", value=round(value, 2), unit="Mrays/s", n_gpus=world,
                     steps=args.steps, warmup=args.warmup, ms_per_step=round(dt_max * 1e3 / args.steps, 4),
@@ -595,8 +747,13 @@ def main():
                                 if world > 1 else "single tile",
                                 rays_per_step=round(total_rays / args.steps, 1), non_finite_pixels=nan_px,
                                 stack_spill_lane_steps=int(st1.stack_spills), rays_left_to_the_bvh2_kernel=int(st1.slow_rays),
-                                setup_s=round(t_setup, 2), device=name),
-                    ranks=dict(render_ms_min=round(float(tmin[0].item()) * 1e3, 3), render_ms_max=round(float(tmax[1].item()) * 1e3, 3)),
+                                setup_s=round(t_setup, 2), scene_s=round(t_scene, 2),     # scene_s: parse / generate (or load the cache); setup_s: + BVH, wide collapse, upload
+                                device=name),
+                    ranks=dict(render_ms_min=round(float(tmin[0].item()) * 1e3, 3), render_ms_max=round(float(tmax[1].item()) * 1e3, 3),
+                               render_ms=[r["render_ms"] for r in per_rank], gather_ms=[r["gather_ms"] for r in per_rank],
+                               setup_s=[r["setup_s"] for r in per_rank], setup_s_max=max(r["setup_s"] for r in per_rank),
+                               scene_s=[r["scene_s"] for r in per_rank], rows=[r["rows"] for r in per_rank],
+                               mrays=[round(r["rays"] / 1e6, 1) for r in per_rank], scene=scene_source),
                     gather=gather_info, per_frame=per_frame, roofline=roofline, parity=parity, cpu_baseline=baseline)
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -44,6 +44,12 @@ const char* rt_last_error(rt_ctx* ctx);
 int rt_ctx_device_info(rt_ctx* ctx, char* name, size_t name_len, int* compute_units, size_t* hbm_bytes);
 /* the hipStream_t of this context (for interop with other HIP libraries) */
 void* rt_ctx_stream(rt_ctx* ctx);
+/* Page-lock a caller-owned host buffer (and release it): read-backs into it -- rt_frame_resolve every frame in the
+ * reference's call pattern (cl_pt_integrator.cpp:677-684 has the GL image for that; headless there is only the host) --
+ * then run at the PCIe rate instead of through the runtime's staging copies.  Optional: every entry point works with
+ * pageable memory. */
+int rt_host_register(rt_ctx* ctx, void* host_ptr, size_t bytes);
+int rt_host_unregister(rt_ctx* ctx, void* host_ptr);
 /* context options, effective at the next rt_scene_upload */
 enum rt_ctx_option
 {
@@ -173,15 +179,19 @@ enum rt_option
                                        (both sides depend on k_shade(b) only; the shadow queue is double-buffered), so the
                                        ~0.8 ms in which a launch's last rays drain does not idle the machine.
                                        0: every launch on one stream.  Results are identical for both values. */
-    , RT_OPT_SMALL_LAUNCH_PATHS = 18 /* the automatic kernel choice (RT_OPT_TRACE_VARIANT = 5) takes k_trace_v1 for batches of
-                                       fewer paths than this (default 2 000 000; 0 = always the wide-tree kernel).  Results are
-                                       identical for every value. */
+    , RT_OPT_SMALL_LAUNCH_PATHS = 18 /* trace launches of fewer rays than this run k_trace_w4 in CHUNK mode -- a wave takes 64
+                                       consecutive rays, finishes all of them, takes the next 64; chunks are assigned statically,
+                                       no refill of single lanes, no hand-out atomics -- decided inside the kernel from the live
+                                       queue counter.  It is what makes the reference's own call pattern (one Integrate() per
+                                       frame, one sample per pixel in flight) fast, and the late bounces of any batch.  Default
+                                       3 000 000; 0 = never.  Results are identical for every value. */
     , RT_OPT_TRACE_TUNE = 12       /* k_trace2 (variants 8, 9) loop thresholds: value & 255 = lanes that must hold an
                                        interior node for a wave to stay in the node loop, value >> 8 & 255 = lanes that
                                        must wait at a triangle for another pass of the triangle loop, value >> 16 & 255 = rays a wave takes
-                                       from the queue per hand-out / 16 (k_trace_w4), value >> 24 = the fewest rays per lane a wave of
+                                       from the queue per hand-out / 16 (k_trace_w4; 7 bits), value >> 24 = the fewest rays per lane a wave of
                                        the persistent grid is started for (k_trace_w4: the grid follows the live queue counter, the
-                                       reference's "@TODO: use indirect dispatch"; 255 = every wave).  0 in a field = its default.
+                                       reference's "@TODO: use indirect dispatch"; 255 = every wave), bit 23 = chunk mode for every
+                                       launch (RT_OPT_SMALL_LAUNCH_PATHS).  0 in a field = its default.
                                        Results are identical for every value. */
 };
 int rt_set_option(rt_frame* frame, int option, uint32_t value);

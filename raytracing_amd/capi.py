@@ -52,7 +52,7 @@ class rt_frame_desc(C.Structure):
 
 EXPORTS = [
     "rt_ctx_create", "rt_ctx_destroy", "rt_finish", "rt_last_error", "rt_ctx_device_info", "rt_ctx_stream",
-    "rt_ctx_set_option", "rt_upload_blue_noise_tables",
+    "rt_ctx_set_option", "rt_upload_blue_noise_tables", "rt_host_register", "rt_host_unregister",
     "rt_buffer_create", "rt_buffer_destroy", "rt_buffer_write", "rt_buffer_read", "rt_buffer_copy",
     "rt_buffer_device_ptr", "rt_buffer_size", "rt_scene_upload", "rt_frame_create", "rt_frame_destroy",
     "rt_frame_local_rows", "rt_frame_global_row", "rt_set_option", "rt_set_camera", "rt_reset",
@@ -84,6 +84,7 @@ def load():
         "rt_ctx_device_info": (i32, [vp, C.c_char_p, sz, C.POINTER(i32), C.POINTER(sz)]),
         "rt_ctx_stream": (vp, [vp]), "rt_ctx_set_option": (i32, [vp, i32, u32]),
         "rt_upload_blue_noise_tables": (i32, [vp, vp, vp, vp]),
+        "rt_host_register": (i32, [vp, vp, sz]), "rt_host_unregister": (i32, [vp, vp]),
         "rt_buffer_create": (i32, [vp, sz, vp, C.POINTER(vp)]), "rt_buffer_destroy": (i32, [vp]),
         "rt_buffer_write": (i32, [vp, sz, vp, sz]), "rt_buffer_read": (i32, [vp, sz, vp, sz]),
         "rt_buffer_copy": (i32, [vp, vp, sz, sz, sz]), "rt_buffer_device_ptr": (vp, [vp]),

@@ -114,7 +114,7 @@ struct rt_frame
     bool fused = false;            // inside rt_integrate: whole samples, nothing reads the radiance between stages
     uint32_t trace_blocks;       // v1 grid
     uint32_t trace_variant = 5;  // RT_OPT_TRACE_VARIANT (5 = auto)
-    uint64_t small_launch_paths = 2000000ull;   // auto: batches with fewer paths take k_trace_v1 (RT_OPT_SMALL_LAUNCH_PATHS)
+    uint64_t small_launch_paths = 3000000ull;   // RT_OPT_SMALL_LAUNCH_PATHS: launches of fewer rays run k_trace_w4 in chunk mode
     uint32_t trace_waves_per_cu = 0;   // RT_OPT_TRACE_WAVES_PER_CU (0 = LDS-limited residency)
     uint32_t select_form_box = 0;      // RT_OPT_TRACE_SELECT_FORM_BOX: every ray takes the select-form slab test
     uint32_t trace_tune = 0;           // RT_OPT_TRACE_TUNE: k_trace2 loop thresholds (0 = defaults)
@@ -244,6 +244,23 @@ int rt_ctx_device_info(rt_ctx* ctx, char* name, size_t name_len, int* compute_un
 }
 
 void* rt_ctx_stream(rt_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+int rt_host_register(rt_ctx* ctx, void* host_ptr, size_t bytes)
+{
+    if (!ctx || !host_ptr || bytes == 0) return fail(ctx, "rt_host_register: bad argument");
+    (void)hipSetDevice(ctx->device);
+    HIPCHK(ctx, hipHostRegister(host_ptr, bytes, hipHostRegisterDefault));
+    return RT_OK;
+}
+
+int rt_host_unregister(rt_ctx* ctx, void* host_ptr)
+{
+    if (!ctx || !host_ptr) return fail(ctx, "rt_host_unregister: bad argument");
+    (void)hipSetDevice(ctx->device);
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipHostUnregister(host_ptr));
+    return RT_OK;
+}
 
 // The sampler tables CLPathTraceIntegrator uploads in its ctor (cl_pt_integrator.cpp:222-235)
 int rt_upload_blue_noise_tables(rt_ctx* ctx, const int* sobol_256spp_256d, const int* scramblingTile, const int* rankingTile)
@@ -1255,16 +1272,17 @@ void launch_trace_w4(rt_frame* f, const float4* o4, const float4* d4, const uint
     if (rays_per_lane == 255u) rays_per_lane = 0u;                          // 255 = every wave of the residency-sized grid
     const uint32_t tune = node_q | leaf_q << 8 | (t & 0xFF0000u) | rays_per_lane << 24;
     const uint32_t s = f->tl_flavour;
+    const uint32_t chunk_below = f->small_launch_paths > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)f->small_launch_paths;
     unsigned long long* const no_timeline = nullptr;
     if (!SHADOW && STACK == 12 && f->timeline)          // tools/launch_timeline.py: the instrumented instance
         hipLaunchKernelGGL((k_trace_w4<false, 12, true>), dim3(blocks), dim3(64), 0, f->tl_stream, ctx->scene.d, o4, d4, aux, count,
             &f->p->counters->head[s][0], f->p->hits, (float*)nullptr, f->log_stride, f->tl_spill, tune, f->tl_slow_list,
             &f->p->counters->slow_count[s], &f->p->counters->stack_spills, &f->p->counters->tl_start[f->timeline_bounce & 63u],
-            f->timeline_bounce & 63u);
+            f->timeline_bounce & 63u, chunk_below);
     else
         hipLaunchKernelGGL((k_trace_w4<SHADOW, STACK, false>), dim3(blocks), dim3(64), 0, f->tl_stream, ctx->scene.d, o4, d4, aux, count,
             &f->p->counters->head[s][0], SHADOW ? (float4*)nullptr : f->p->hits, SHADOW ? f->p->rlog : (float*)nullptr, f->log_stride,
-            f->tl_spill, tune, f->tl_slow_list, &f->p->counters->slow_count[s], &f->p->counters->stack_spills, no_timeline, 0u);
+            f->tl_spill, tune, f->tl_slow_list, &f->p->counters->slow_count[s], &f->p->counters->stack_spills, no_timeline, 0u, chunk_below);
     // The follow-up over the (normally empty) slow list: waves with a two-entry LDS stack (the rest of the stack
     // lives in the spill area) -- 1 KiB of LDS and a few registers, so it finds room beside the resident waves of the
     // OTHER stream's persistent launch (RT_OPT_OVERLAP_SHADOW) instead of waiting for that launch to end: with the
@@ -1294,10 +1312,11 @@ void launch_trace(rt_frame* f, const float4* o4, const float4* d4, const uint32_
         // Scenes whose directional lights make most shadow rays "slow" (Scene::slow_shadow) trace the shadow queue with
         // k_trace2, which handles such rays inline.
         variant = (SHADOW && ctx->scene.slow_shadow) ? 8u : 10u;
-        // with few rays per launch (one or two samples of a 720p frame in flight) the per-ray loop of v1 won in round 1
-        // (770 vs 600 Mrays/s, profiles/r01_variants_3_samples_in_flight.log)
+        // k_trace_w4 switches to its chunk mode by itself when a launch is small (RT_OPT_SMALL_LAUNCH_PATHS, decided in the
+        // kernel from the live queue counter).  Without the wide tree, small batches take the per-ray loop of v1, which
+        // beats the refilling BVH2 kernel there (1511 vs 737 Mrays/s at one 1080p sample in flight, profiles/r03_call02_*)
         const uint64_t paths = (uint64_t)f->p->chunk_count * (f->p->cur_slots ? f->p->cur_slots : 1u);
-        if (paths < f->small_launch_paths) variant = 0u;
+        if ((variant == 8u || !ctx->scene.wide_ok) && paths < 2000000ull) variant = 0u;
     }
     if ((variant == 10u || variant == 11u) && !ctx->scene.wide_ok) variant = 8u;
     if ((variant == 8u || variant == 9u) && !ctx->scene.offsets32) variant = 0u;

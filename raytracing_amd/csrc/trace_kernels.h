@@ -561,6 +561,71 @@ RT_DEV uint32_t spill_load32(const uint32_t* p)
     return v;
 }
 
+// One visit of a wide node (the body of k_trace_w4's loop C; also timed on its own by tools/visit_microbench.hip):
+// the four slots' conservative slab tests and, for closest-hit rays, the reference's visit order.  Out: r[k] / e[k] =
+// ref and entry distance of the slot visited k-th, e[k] = +inf for a slot that is empty or missed.
+template <bool SHADOW>
+RT_DEV void w4_test_slots(const float4 q0, const float4 q1, const float4 q2, const float4 q3, const f3 org, const f3 inv,
+    const uint32_t sign_bits, const uint32_t octant3, const float t_min, const float t_max, uint32_t (&r)[4], float (&e)[4])
+{
+    const float INF = __builtin_inff();
+    const uint32_t meta = __float_as_uint(q0.w);
+    const float cx = __uint_as_float((meta & 0xFFu) << 23), cy = __uint_as_float(((meta >> 8) & 0xFFu) << 23),
+                cz = __uint_as_float(((meta >> 16) & 0xFFu) << 23);
+    // near / far plane words per axis, chosen by the ray's direction sign
+    const bool nx = (sign_bits & 1u) != 0u, ny = (sign_bits & 2u) != 0u, nz = (sign_bits & 4u) != 0u;
+    const uint32_t lox = __float_as_uint(q1.x), loy = __float_as_uint(q1.y), loz = __float_as_uint(q1.z);
+    const uint32_t hix = __float_as_uint(q1.w), hiy = __float_as_uint(q2.x), hiz = __float_as_uint(q2.y);
+    const uint32_t nwx = nx ? hix : lox, fwx = nx ? lox : hix;
+    const uint32_t nwy = ny ? hiy : loy, fwy = ny ? loy : hiy;
+    const uint32_t nwz = nz ? hiz : loz, fwz = nz ? loz : hiz;
+    // Slab distance of grid plane q along an axis: the reference's expression on the dequantised plane is
+    // E(q) = fl(fl(fl(q * cell + origin) - org) * inv) (the inner fl is exact, build_wide_bvh), monotone in q, so
+    // "leaf box passes => stored box passes" holds for E exactly.  Evaluated here as one fma per plane,
+    // F(q) = fl(q * a + b) with a = cell * inv (exact: cell is a power of two), b = fl(fl(origin - org) * inv):
+    // both round the same real number T(q) = (q * cell + origin - org) * inv, |E - T| <= 2.1 u M and
+    // |F - T| <= 4 u M with u = 2^-24 and M = 255 |a| + |b| >= |q a| + |b| -- so the near planes take
+    // b - 2^-20 M and the far planes b + 2^-20 M (16 u M, plus 2^-120 against results in the denormal range):
+    // F_near <= E_near and F_far >= E_far, the stored box only ever grows, interior culling only ever visits
+    // MORE.  Leaves are re-tested with the reference's expression when they are reached, as before.
+    // No overflow: |inv| < 2^96 (ray_inverse: other rays are RT_SIGN_SLOW), cell <= 2^20 and |origin| < 2^28
+    // (build_wide_bvh), |org| < 2^29 (checked when the ray starts) => |q a| + |b| < 2^127.
+    const float ax = cx * inv.x, ay = cy * inv.y, az = cz * inv.z;
+    const float bx = (q0.x - org.x) * inv.x, by = (q0.y - org.y) * inv.y, bz = (q0.z - org.z) * inv.z;
+    const float mx = __builtin_fmaf(255.0f, __builtin_fabsf(ax), __builtin_fabsf(bx)) + 0x1p-100f;
+    const float my = __builtin_fmaf(255.0f, __builtin_fabsf(ay), __builtin_fabsf(by)) + 0x1p-100f;
+    const float mz = __builtin_fmaf(255.0f, __builtin_fabsf(az), __builtin_fabsf(bz)) + 0x1p-100f;
+    const float bnx = __builtin_fmaf(-0x1p-20f, mx, bx), bfx = __builtin_fmaf(0x1p-20f, mx, bx);
+    const float bny = __builtin_fmaf(-0x1p-20f, my, by), bfy = __builtin_fmaf(0x1p-20f, my, by);
+    const float bnz = __builtin_fmaf(-0x1p-20f, mz, bz), bfz = __builtin_fmaf(0x1p-20f, mz, bz);
+    r[0] = __float_as_uint(q2.z); r[1] = __float_as_uint(q2.w); r[2] = __float_as_uint(q3.x); r[3] = __float_as_uint(q3.y);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+    {
+        const float tnx = __builtin_fmaf((float)((nwx >> (8 * k)) & 0xFFu), ax, bnx);
+        const float tny = __builtin_fmaf((float)((nwy >> (8 * k)) & 0xFFu), ay, bny);
+        const float tnz = __builtin_fmaf((float)((nwz >> (8 * k)) & 0xFFu), az, bnz);
+        const float tfx = __builtin_fmaf((float)((fwx >> (8 * k)) & 0xFFu), ax, bfx);
+        const float tfy = __builtin_fmaf((float)((fwy >> (8 * k)) & 0xFFu), ay, bfy);
+        const float tfz = __builtin_fmaf((float)((fwz >> (8 * k)) & 0xFFu), az, bfz);
+        const float entry = hw_max(hw_max3(tnx, tny, tnz), t_min);
+        const float exit = hw_min(hw_min3(tfx, tfy, tfz), t_max);
+        e[k] = (exit >= entry && r[k] != RT_EMPTY_REF) ? entry : INF;      // INF = slot not visited
+    }
+    if (!SHADOW)
+    {
+        // the reference's order: near child first at both BVH2 levels (trace_bvh.cl:181-190)
+        // (the three decisions per direction octant are tabulated in the record: build_wide_bvh)
+        const uint32_t sw = __float_as_uint(q3.z) >> octant3;
+        const bool sw0 = (sw & 1u) != 0u, pa = (sw & 2u) != 0u, pb = (sw & 4u) != 0u;
+        uint32_t tr; float te;
+        tr = pa ? r[1] : r[0]; r[1] = pa ? r[0] : r[1]; r[0] = tr;  te = pa ? e[1] : e[0]; e[1] = pa ? e[0] : e[1]; e[0] = te;
+        tr = pb ? r[3] : r[2]; r[3] = pb ? r[2] : r[3]; r[2] = tr;  te = pb ? e[3] : e[2]; e[3] = pb ? e[2] : e[3]; e[2] = te;
+        tr = sw0 ? r[2] : r[0]; r[2] = sw0 ? r[0] : r[2]; r[0] = tr;  te = sw0 ? e[2] : e[0]; e[2] = sw0 ? e[0] : e[2]; e[0] = te;
+        tr = sw0 ? r[3] : r[1]; r[3] = sw0 ? r[1] : r[3]; r[1] = tr;  te = sw0 ? e[3] : e[1]; e[3] = sw0 ? e[1] : e[3]; e[1] = te;
+    }
+}
+
 // Of the slots that pass their box test the FIRST in visit order is visited next and only the later ones go to the stack
 // (round 2 pushed positions 3..1 and popped the first passing one right back: with 1.2 of 4 slots passing per visit that
 // was 18.4 pushes per closest-hit ray instead of 8.6; same sequence of nodes -- an entry popped right after its push always
@@ -573,7 +638,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
     float4* __restrict__ hits, float* __restrict__ rlog, uint32_t log_stride, uint2* __restrict__ spill, uint32_t tune,
     uint32_t* __restrict__ slow_list, uint32_t* __restrict__ slow_count, uint32_t* __restrict__ stat_counts /* [0] spills, [1] slow rays */,
     unsigned long long* __restrict__ timeline /* TIMELINE: DCounters::tl_start + timeline_slot (rt_frame_debug_timeline) */,
-    uint32_t timeline_slot)
+    uint32_t timeline_slot, uint32_t chunk_below /* launches of fewer rays run in chunk mode (below) */)
 {
     __shared__ uint2 stack[STACK][64];
     uint32_t* const stack32 = reinterpret_cast<uint32_t*>(&stack[0][0]);     // SHADOW: 2 * STACK entries of 4 bytes
@@ -606,7 +671,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
     // rays a wave takes from the queue per hand-out: large, because every hand-out is one atomic on one of eight
     // addresses that 6000 waves share (128 -> 512 rays: +3 %, profiles/r02_handout_sweep.log), but never so large that a
     // wave would empty its region in fewer than ~4 hand-outs (small launches: late bounces, chunks, tiles)
-    uint32_t grab = ((tune >> 16) & 0xFFu) ? ((tune >> 16) & 0xFFu) * 16u : 512u;
+    // CHUNK mode (tune bit 23): a wave takes 64 rays, finishes ALL of them, then takes the next 64 -- no refill of single
+    // lanes.  Lane utilisation inside a chunk falls as its rays finish, but the rays in flight when the queue runs dry are
+    // ordinary rays, not the long ones a refilling wave accumulates (length-biased sampling: DESIGN.md "Where a launch's time
+    // goes"), so a launch ends one chunk after its queue does: the mode for launches that are all tail (one sample per pixel in flight)
+    // -- decided here, from the live queue counter (the host does not know it): small launches (a frame's single sample per
+    // pixel, the late bounces of any batch) are all tail in refill mode; 2430 vs 849 Mrays/s at one 1080p sample in flight,
+    // equal at ~8, 3340 vs 5940 at 64 (profiles/r03_call05_chunk_vs_refill_cfg4.log).
+    const bool chunk_mode = (tune & 0x800000u) != 0u || count < chunk_below;
+    uint32_t grab = ((tune >> 16) & 0x7Fu) ? ((tune >> 16) & 0x7Fu) * 16u : 512u;
+    if (chunk_mode) grab = 64u;
     {
         const uint32_t fair = (per / ((n_blocks >> 3) * 4u + 1u)) & ~63u;
         grab = fair < grab ? (fair < 64u ? 64u : fair) : grab;
@@ -619,6 +693,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
     const char* const tri_base = reinterpret_cast<const char*>(sc.tris_rt);
 
     RayPool pool = {0u, 0u, 0u, false};
+    uint32_t chunk_next = blockIdx.x >> 3;         // chunk mode: this wave's next chunk of its XCD's region
     uint32_t ref = RT_IDLE_REF;                    // wide node | RT_LEAF_BIT (| RT_LEAF_CONT_BIT) + triangle | idle
     uint32_t ray_i = RT_INVALID_ID;
     uint32_t sign_bits = 0, octant3 = 0, hit_prim = RT_INVALID_ID;          // octant3: shift of this ray's entry in a node's order table
@@ -673,7 +748,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
     for (;;)
     {
         // ---- A: retire finished rays, start new ones -------------------------------------
-        if (__ballot(ref == RT_IDLE_REF) != 0ull)
+        const unsigned long long idle_m = __ballot(ref == RT_IDLE_REF);
+        if (chunk_mode ? idle_m == ~0ull : idle_m != 0ull)
         {
             if (ref == RT_IDLE_REF && ray_i != RT_INVALID_ID)
             {
@@ -694,7 +770,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
             }
             if (!pool.exhausted)
             {
-                hand_out_rays(pool, lane, xcd, per, count, heads, ref == RT_IDLE_REF, ray_i, grab);
+                if (chunk_mode)
+                {
+                    // static assignment, no atomics: wave `slot` of this XCD takes chunks slot, slot + waves per XCD, ... of
+                    // the XCD's region (64 rays per hand-out through the shared heads costs one same-address atomic per 64
+                    // rays -- ~11 M of those per second machine-wide: profiles/r02_handout_sweep.log, r03_call03_*)
+                    const uint32_t rb = xcd * per < count ? xcd * per : count;
+                    const uint32_t re = (xcd + 1u) * per < count ? (xcd + 1u) * per : count;
+                    const uint32_t at = rb + chunk_next * 64u;               // chunk_next: wave-uniform
+                    if (at >= re) pool.exhausted = true;
+                    else if (at + lane < re) ray_i = at + lane;
+                    chunk_next += n_blocks >> 3;
+                }
+                else
+                    hand_out_rays(pool, lane, xcd, per, count, heads, ref == RT_IDLE_REF, ray_i, grab);
                 bool slow = false;
                 if (ref == RT_IDLE_REF && ray_i != RT_INVALID_ID)
                 {
@@ -808,7 +897,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
             if (node_m == 0ull) break;
             if ((uint32_t)__popcll(node_m) < node_q)
             {
-                const unsigned long long waiting = __ballot((int)ref < -1 || (ref == RT_IDLE_REF && !pool.exhausted));
+                const unsigned long long waiting = __ballot((int)ref < -1 || (ref == RT_IDLE_REF && !pool.exhausted && !chunk_mode));
                 if (waiting != 0ull) break;
             }
             if ((int)ref >= 0)
@@ -816,62 +905,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                 if (TIMELINE) ++tl_steps;
                 const float4* np = reinterpret_cast<const float4*>(node_base + (size_t)(ref << 6));
                 const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
-                const uint32_t meta = __float_as_uint(q0.w);
-                const float cx = __uint_as_float((meta & 0xFFu) << 23), cy = __uint_as_float(((meta >> 8) & 0xFFu) << 23),
-                            cz = __uint_as_float(((meta >> 16) & 0xFFu) << 23);
-                // near / far plane words per axis, chosen by the ray's direction sign
-                const bool nx = (sign_bits & 1u) != 0u, ny = (sign_bits & 2u) != 0u, nz = (sign_bits & 4u) != 0u;
-                const uint32_t lox = __float_as_uint(q1.x), loy = __float_as_uint(q1.y), loz = __float_as_uint(q1.z);
-                const uint32_t hix = __float_as_uint(q1.w), hiy = __float_as_uint(q2.x), hiz = __float_as_uint(q2.y);
-                const uint32_t nwx = nx ? hix : lox, fwx = nx ? lox : hix;
-                const uint32_t nwy = ny ? hiy : loy, fwy = ny ? loy : hiy;
-                const uint32_t nwz = nz ? hiz : loz, fwz = nz ? loz : hiz;
-                // Slab distance of grid plane q along an axis: the reference's expression on the dequantised plane is
-                // E(q) = fl(fl(fl(q * cell + origin) - org) * inv) (the inner fl is exact, build_wide_bvh), monotone in q, so
-                // "leaf box passes => stored box passes" holds for E exactly.  Evaluated here as one fma per plane,
-                // F(q) = fl(q * a + b) with a = cell * inv (exact: cell is a power of two), b = fl(fl(origin - org) * inv):
-                // both round the same real number T(q) = (q * cell + origin - org) * inv, |E - T| <= 2.1 u M and
-                // |F - T| <= 4 u M with u = 2^-24 and M = 255 |a| + |b| >= |q a| + |b| -- so the near planes take
-                // b - 2^-20 M and the far planes b + 2^-20 M (16 u M, plus 2^-120 against results in the denormal range):
-                // F_near <= E_near and F_far >= E_far, the stored box only ever grows, interior culling only ever visits
-                // MORE.  Leaves are re-tested with the reference's expression when they are reached, as before.
-                // No overflow: |inv| < 2^96 (ray_inverse: other rays are RT_SIGN_SLOW), cell <= 2^20 and |origin| < 2^28
-                // (build_wide_bvh), |org| < 2^29 (checked when the ray starts) => |q a| + |b| < 2^127.
-                const float ax = cx * inv.x, ay = cy * inv.y, az = cz * inv.z;
-                const float bx = (q0.x - org.x) * inv.x, by = (q0.y - org.y) * inv.y, bz = (q0.z - org.z) * inv.z;
-                const float mx = __builtin_fmaf(255.0f, __builtin_fabsf(ax), __builtin_fabsf(bx)) + 0x1p-100f;
-                const float my = __builtin_fmaf(255.0f, __builtin_fabsf(ay), __builtin_fabsf(by)) + 0x1p-100f;
-                const float mz = __builtin_fmaf(255.0f, __builtin_fabsf(az), __builtin_fabsf(bz)) + 0x1p-100f;
-                const float bnx = __builtin_fmaf(-0x1p-20f, mx, bx), bfx = __builtin_fmaf(0x1p-20f, mx, bx);
-                const float bny = __builtin_fmaf(-0x1p-20f, my, by), bfy = __builtin_fmaf(0x1p-20f, my, by);
-                const float bnz = __builtin_fmaf(-0x1p-20f, mz, bz), bfz = __builtin_fmaf(0x1p-20f, mz, bz);
-                uint32_t r[4] = {__float_as_uint(q2.z), __float_as_uint(q2.w), __float_as_uint(q3.x), __float_as_uint(q3.y)};
+                uint32_t r[4];
                 float e[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-                {
-                    const float tnx = __builtin_fmaf((float)((nwx >> (8 * k)) & 0xFFu), ax, bnx);
-                    const float tny = __builtin_fmaf((float)((nwy >> (8 * k)) & 0xFFu), ay, bny);
-                    const float tnz = __builtin_fmaf((float)((nwz >> (8 * k)) & 0xFFu), az, bnz);
-                    const float tfx = __builtin_fmaf((float)((fwx >> (8 * k)) & 0xFFu), ax, bfx);
-                    const float tfy = __builtin_fmaf((float)((fwy >> (8 * k)) & 0xFFu), ay, bfy);
-                    const float tfz = __builtin_fmaf((float)((fwz >> (8 * k)) & 0xFFu), az, bfz);
-                    const float entry = hw_max(hw_max3(tnx, tny, tnz), t_min);
-                    const float exit = hw_min(hw_min3(tfx, tfy, tfz), t_max);
-                    e[k] = (exit >= entry && r[k] != RT_EMPTY_REF) ? entry : INF;      // INF = slot not visited
-                }
-                if (!SHADOW)
-                {
-                    // the reference's order: near child first at both BVH2 levels (trace_bvh.cl:181-190)
-                    // (the three decisions per direction octant are tabulated in the record: build_wide_bvh)
-                    const uint32_t sw = __float_as_uint(q3.z) >> octant3;
-                    const bool sw0 = (sw & 1u) != 0u, pa = (sw & 2u) != 0u, pb = (sw & 4u) != 0u;
-                    uint32_t tr; float te;
-                    tr = pa ? r[1] : r[0]; r[1] = pa ? r[0] : r[1]; r[0] = tr;  te = pa ? e[1] : e[0]; e[1] = pa ? e[0] : e[1]; e[0] = te;
-                    tr = pb ? r[3] : r[2]; r[3] = pb ? r[2] : r[3]; r[2] = tr;  te = pb ? e[3] : e[2]; e[3] = pb ? e[2] : e[3]; e[2] = te;
-                    tr = sw0 ? r[2] : r[0]; r[2] = sw0 ? r[0] : r[2]; r[0] = tr;  te = sw0 ? e[2] : e[0]; e[2] = sw0 ? e[0] : e[2]; e[0] = te;
-                    tr = sw0 ? r[3] : r[1]; r[3] = sw0 ? r[1] : r[3]; r[1] = tr;  te = sw0 ? e[3] : e[1]; e[3] = sw0 ? e[1] : e[3]; e[1] = te;
-                }
+                w4_test_slots<SHADOW>(q0, q1, q2, q3, org, inv, sign_bits, octant3, t_min, t_max, r, e);
                 {
                     // the first passing position is visited next, the later ones wait on the stack (deepest first)
                     const bool v0 = e[0] < INF, v1 = e[1] < INF, v2 = e[2] < INF, v3 = e[3] < INF;

@@ -74,10 +74,18 @@ HIPPathTraceIntegrator::HIPPathTraceIntegrator(std::uint32_t width, std::uint32_
     rt_frame_desc fd = {width, height, tile.rank, tile.count, tile.band_height};
     Check(rt_frame_create(context_.Get(), &fd, &frame_));
     resolved_.assign((size_t)rt_frame_local_rows(frame_) * width * 4, 0.0f);
+    // ResolveRadiance() lands here every frame (the reference resolves into a GL image, cl_pt_integrator.cpp:677-684):
+    // page-locked, the read-back runs at the PCIe rate.  Best effort -- a refusal only costs speed.
+    resolved_pinned_ = !resolved_.empty() &&
+        rt_host_register(context_.Get(), resolved_.data(), resolved_.size() * sizeof(float)) == RT_OK;
     CreateKernels();
 }
 
-HIPPathTraceIntegrator::~HIPPathTraceIntegrator() { rt_frame_destroy(frame_); }
+HIPPathTraceIntegrator::~HIPPathTraceIntegrator()
+{
+    if (resolved_pinned_) rt_host_unregister(context_.Get(), resolved_.data());
+    rt_frame_destroy(frame_);
+}
 
 void HIPPathTraceIntegrator::UploadGPUData(Scene const& scene, AccelerationStructure const& acc_structure)
 {

@@ -99,6 +99,7 @@ private:
     HIPContext& context_;
     rt_frame* frame_ = nullptr;
     std::vector<float> resolved_;
+    bool resolved_pinned_ = false;     // resolved_ is page-locked (rt_host_register)
     bool resolve_every_frame_ = true;
     std::string blue_noise_path_ = "assets/blue_noise/heitz2019_256spp_256d.bin";
 };

@@ -26,7 +26,7 @@ int main(int argc, char** argv)
         unsigned width = 1280, height = 720, spp = 16, bounces = 3, gpus = 1;
         std::string scene_path = "assets/ShaderBalls.obj", out, save_cache;
         float scale = 1.0f, aperture = 0.0f, focus = 10.0f;
-        bool flip_yz = false, furnace = false, tiled_path = false;
+        bool flip_yz = false, furnace = false, tiled_path = false, shared_device = false, plan_only = false;
         unsigned scene_options = 0;      // rt::Scene::Options (opt-in extensions)
         for (int i = 1; i < argc; ++i)
         {
@@ -45,27 +45,47 @@ int main(int argc, char** argv)
             else if (!strcmp(argv[i], "--save-cache")) save_cache = next();
             else if (!strcmp(argv[i], "--gpus")) gpus = (unsigned)atoi(next());
             else if (!strcmp(argv[i], "--tiled")) tiled_path = atoi(next()) != 0;      // take the TiledRender path even with one GPU
+            else if (!strcmp(argv[i], "--shared_device")) shared_device = atoi(next()) != 0;   // all tiles on GPU 0 (device copies instead of RCCL)
+            else if (!strcmp(argv[i], "--plan")) plan_only = atoi(next()) != 0;              // print the tiling and exit: no GPU, no scene
             else if (!strcmp(argv[i], "--wide_texture_indices")) { if (atoi(next()) != 0) scene_options |= rt::Scene::kWideTextureIndices; }
             else if (!strcmp(argv[i], "--emissive_nee")) { if (atoi(next()) != 0) scene_options |= rt::Scene::kEmissiveNee; }
             else if (!strcmp(argv[i], "--help"))
             {
                 std::cout << "rt_render -w W -h H --scene file.obj [--scale s] [--flip_yz 0|1] [--spp n] [--bounces b]"
                              " [--furnace 0|1] [--aperture a] [--focus d] [--out image.pfm] [--save-cache scene.rtscene] [--gpus n]\n"
-                             "  --gpus n tiles the image over devices 0..n-1 (interleaved 8-row bands, one RCCL gather)\n"
+                             "  --gpus n tiles the image over devices 0..n-1 (interleaved 8-row bands, one RCCL gather);\n"
+                             "  --shared_device 1 puts all n tiles on GPU 0 (device copies instead of RCCL); --plan 1 prints the tiling and exits\n"
                              "  --scene also accepts a file written by --save-cache (parsed scene + BVH)\n"
                              "  extensions (off = the reference's behaviour): --wide_texture_indices 1 loads scenes with more than 255\n"
                              "  textures; --emissive_nee 1 adds the emissive triangles to next-event estimation\n";
                 return 0;
             }
         }
+        if (plan_only)
+        {
+            // which rows each GPU renders (TiledRender::TileRows = rt_frame_desc's rule); needs neither a GPU nor the scene
+            std::size_t total = 0;
+            for (unsigned r = 0; r < gpus; ++r)
+            {
+                std::vector<std::uint32_t> rows = rt::TiledRender::TileRows(height, r, gpus);
+                total += rows.size();
+                std::cout << "tile " << r << " of " << gpus << ": " << rows.size() << " rows x " << width << " =";
+                for (std::uint32_t y : rows) std::cout << " " << y;
+                std::cout << std::endl;
+            }
+            std::cout << "total rows " << total << " of " << height << std::endl;
+            return total == height ? 0 : 1;
+        }
         rt::Scene scene(scene_path.c_str(), scale, flip_yz, scene_options);
         scene.AddDirectionalLight({-0.6f, -1.5f, 3.5f}, {15.0f, 10.0f, 5.0f});   // main.cpp:58
         if (gpus > 1 || tiled_path)
         {
             std::vector<int> devices;
-            for (unsigned d = 0; d < gpus; ++d) devices.push_back((int)d);
+            for (unsigned d = 0; d < gpus; ++d) devices.push_back(shared_device ? 0 : (int)d);
             rt::TiledRender tiled(width, height, scene, devices);
-            for (unsigned d = 0; d < gpus; ++d) std::cout << "device " << d << ": " << tiled.GetContext(d).DeviceName() << std::endl;
+            for (unsigned d = 0; d < gpus; ++d) std::cout << "tile " << d << " on device " << devices[d] << ": " << tiled.GetContext(d).DeviceName() << std::endl;
+            std::cout << "gather: " << (tiled.GetRcclRanks() ? "RCCL ncclGather, communicator of " + std::to_string(tiled.GetRcclRanks()) + " ranks"
+                                                              : std::string("device copies on one GPU (local group)")) << std::endl;
             if (!save_cache.empty()) scene.SaveCache(save_cache.c_str(), tiled.GetAccelerationStructure().GetNodes());
             rt::Camera cam = rt::DefaultCamera(width, height);
             cam.aperture = aperture;

@@ -93,7 +93,11 @@ TiledRender::TiledRender(std::uint32_t width, std::uint32_t height, Scene& scene
         integrators_[i]->UploadGPUData(scene_, *acc_structure_);
         integrators_[i]->SetResolveEveryFrame(false);
     }
-    if (rt_group_create((int)devices.size(), devices.data(), &group_) != RT_OK)
+    bool shared = devices.size() > 1;
+    for (int d : devices) shared = shared && d == devices[0];
+    const int rc = shared ? rt_group_create_local((int)devices.size(), devices[0], &group_)
+                          : rt_group_create((int)devices.size(), devices.data(), &group_);
+    if (rc != RT_OK)
         throw HIPException(std::string("Failed to create the device group: ") + rt_group_last_error(nullptr));
     tile_seconds_.assign(devices.size(), 0.0);
     camera_ = DefaultCamera(width_, height_);
@@ -104,6 +108,22 @@ TiledRender::~TiledRender()
     rt_group_destroy(group_);
     integrators_.clear();            // frames before their contexts
     contexts_.clear();
+}
+
+std::vector<std::uint32_t> TiledRender::TileRows(std::uint32_t height, std::uint32_t rank, std::uint32_t count, std::uint32_t band_height)
+{
+    std::vector<std::uint32_t> rows;
+    if (count == 0 || band_height == 0) return rows;
+    for (std::uint64_t band = rank; band * band_height < height; band += count)
+        for (std::uint64_t y = band * band_height; y < height && y < (band + 1) * band_height; ++y) rows.push_back((std::uint32_t)y);
+    return rows;
+}
+
+int TiledRender::GetRcclRanks() const
+{
+    int n = 0;
+    if (rt_group_comm_count(group_, 0, &n, nullptr) != RT_OK) throw HIPException(rt_group_last_error(group_));
+    return n;
 }
 
 void TiledRender::SetCamera(Camera const& camera)

@@ -45,8 +45,13 @@ private:
 class TiledRender
 {
 public:
+    // devices[i] = the GPU of tile i.  All entries equal = every tile on ONE device, exchanged by device copies
+    // (rt_group_create_local: RCCL refuses two ranks per GPU) -- the way to run the whole tiled path on a one-GPU box.
     TiledRender(std::uint32_t width, std::uint32_t height, Scene& scene, std::vector<int> const& devices,
         std::uint32_t band_height = 8);
+    // The image rows tile `rank` of `count` owns: bands of band_height rows dealt round-robin (rt_frame_desc); no device needed.
+    static std::vector<std::uint32_t> TileRows(std::uint32_t height, std::uint32_t rank, std::uint32_t count, std::uint32_t band_height = 8);
+    int GetRcclRanks() const;                             // ncclCommCount of the group's communicator (0: local group)
     ~TiledRender();
     void SetCamera(Camera const& camera);
     void SetMaxBounces(std::uint32_t max_bounces);

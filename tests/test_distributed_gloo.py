@@ -11,6 +11,8 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 from raytracing_amd import distributed as D
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 
 def _free_port():
     s = socket.socket()
@@ -102,3 +104,21 @@ def test_bench_under_an_external_launcher():
     assert len(lines) == 1
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["gather"]["image_ok"] is True
+
+
+def test_rt_render_plans_the_same_tiles_as_the_python_side():
+    """`rt_render --gpus N --plan 1` prints TiledRender::TileRows -- the rows every GPU of the C++ multi-GPU path renders
+    (rt_frame_desc's band rule) -- without touching a GPU: it must be the partition raytracing_amd.distributed.tile_rows
+    (bench.py's gloo / RCCL assembly) uses, cover every row once, for even and ragged heights."""
+    import subprocess
+    exe = os.path.join(ROOT, "raytracing_amd", "rt_render")
+    for gpus, height in ((2, 1080), (8, 1080), (3, 50), (8, 7), (5, 2160)):
+        r = subprocess.run([exe, "--gpus", str(gpus), "-w", "64", "-h", str(height), "--plan", "1"], capture_output=True, text=True, timeout=60)
+        assert r.returncode == 0, r.stdout + r.stderr
+        seen = []
+        for rank in range(gpus):
+            line = [l for l in r.stdout.splitlines() if l.startswith("tile %d of %d:" % (rank, gpus))][0]
+            rows = [int(x) for x in line.split("=")[1].split()]
+            assert rows == D.tile_rows(height, rank, gpus, 8).tolist()
+            seen += rows
+        assert sorted(seen) == list(range(height))

@@ -264,7 +264,7 @@ def test_directly_against_the_reference_kernels(ctx, golden_scenes):
 
 
 @pytest.mark.parametrize("slots", [2, 3, 8])
-@pytest.mark.parametrize("variant", [0, 5, 8, 9, 10, 11, 208, 308, 210, 310, 410, 510])
+@pytest.mark.parametrize("variant", [0, 5, 8, 9, 10, 11, 208, 308, 210, 310, 410, 510, 610, 710])
 def test_samples_in_flight_and_kernel_variants_are_bit_invariant(ctx, golden_scenes, slots, variant):
     """RT_OPT_SAMPLES_IN_FLIGHT traces several samples of a pixel concurrently; the
     radiance log replays their contributions in the reference's order, so the sum
@@ -285,7 +285,9 @@ def test_samples_in_flight_and_kernel_variants_are_bit_invariant(ctx, golden_sce
     # 10 / 11: k_trace_w4 (4-wide quantized tree); 210 / 310: the same with extreme thresholds; 410 / 510: its grid cut down
     # to the live queue counter (a wave per >= 3 / >= 200 rays per lane: a handful of waves, then the minimum of 8)
     fr.set_option(capi.OPT_TRACE_TUNE, {208: 64 | (64 << 8), 308: 1 | (1 << 8), 210: 64 | (64 << 8), 310: 1 | (1 << 8),
-                                        410: 3 << 24, 510: (200 << 24) | (4 << 16)}.get(variant, 0))
+                                        410: 3 << 24, 510: (200 << 24) | (4 << 16),
+                                        # 610 / 710: chunk mode (64 rays per wave at a time, static chunks, no refill), whole grid / a few waves
+                                        610: 1 << 23, 710: (1 << 23) | (5 << 24) | 1 | (64 << 8)}.get(variant, 0))
     fr.set_option(capi.OPT_SMALL_LAUNCH_PATHS, 0 if variant == 5 and slots == 3 else 2000000)   # auto without the v1 rule too
     fr.integrate(spp)
     assert fr.sample_count() == spp
@@ -645,7 +647,16 @@ def test_rt_render_cli(tmp_path):
                          "--gpus", "1", "--tiled", "1", "--out", str(out3)], cwd=ROOT, capture_output=True, text=True, timeout=300)
     assert r3.returncode == 0, r3.stderr
     assert "on 1 GPUs" in r3.stdout and "gather" in r3.stdout
+    assert "RCCL ncclGather, communicator of 1 ranks" in r3.stdout          # ncclCommCount, not the caller's own argument
     assert open(out3, "rb").read() == raw
+    # ... and with three tiles: scene built once, one context + integrator + host thread per tile, band assembly -- all three
+    # on this box's one GPU (device copies instead of RCCL, which refuses several ranks per device)
+    out4 = tmp_path / "img4.pfm"
+    r4 = subprocess.run([exe, "-w", "64", "-h", "48", "--scene", "assets/CornellBox.obj", "--spp", "4", "--bounces", "4",
+                         "--gpus", "3", "--shared_device", "1", "--out", str(out4)], cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert r4.returncode == 0, r4.stderr
+    assert "on 3 GPUs" in r4.stdout and "device copies on one GPU (local group)" in r4.stdout and "tile 2 on device 0" in r4.stdout
+    assert open(out4, "rb").read() == raw
 
 
 def test_device_group_gather_through_the_c_abi(ctx, golden_scenes):

@@ -11,8 +11,15 @@ tools/issue_microbench.hip on the same counters, plus HBM traffic.  bench.py rea
   L1/TA  TA_TA_BUSY_sum / TAs / cycles: 0.99 for saturating divergent dwordx4 loads.
   HBM    (FETCH_SIZE x 0.99 + WRITE_SIZE) KiB per launch / duration against 8 TB/s (FETCH_SIZE calibration:
          profiles/r01_final_fetch_size_calibration.txt).
-usage: python tools/make_counters_json.py <pmc dir> <config> <out.json> closest=<f2> shadow=<f2> shade=<f2>"""
-import csv, glob, json, sys, collections
+  The fraction f of a TRACE kernel is its DYNAMIC mix: per-loop static opcode counts weighted by how often each loop's body runs
+  (tools/isa_mix.py --loops, pass counts from tools/wave_schedule_model.py); k_shade has no loops worth weighting (static mix).
+  The file records the SHA-256 of the code object the counters were collected from (raytracing_amd/codeobj.py):
+  bench.py marks `roofline.stale` when the library it runs is another one.
+usage: python tools/make_counters_json.py <pmc dir> <config> <out.json> closest=<f2> shadow=<f2> shade=<f2>
+       (values as printed by tools/isa_mix.py; run on the tree the counters were collected from)"""
+import csv, glob, json, os, sys, collections
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from raytracing_amd import codeobj
 
 d, config, out = sys.argv[1], sys.argv[2], sys.argv[3]
 mix = dict(a.split("=") for a in sys.argv[4:])
@@ -63,7 +70,8 @@ for key, match in KERNELS.items():
                        "l2_hit_rate": mean("tcc", "TCC_HIT_sum", match) / mean("tcc", "TCC_REQ_sum", match)},
     }
 doc["config_%s" % config] = entry
-doc["_how"] = "tools/pmc_bench2.sh + tools/make_counters_json.py (see its docstring for every ceiling)"
+doc["_how"] = "tools/pmc_bench2.sh + tools/make_counters_json.py (see its docstring for every ceiling); VALU mix: tools/isa_mix.py --loops"
+doc["_code_object_sha256"] = codeobj.code_object_sha256()
 json.dump(doc, open(out, "w"), indent=1)
 for k, e in entry.items():
     print(k, {n: round(e[n], 4) for n in ("valu_busy", "salu_busy", "l1_ta_busy", "hbm_frac", "avg_launch_ms")})

@@ -1,6 +1,6 @@
 """Sweep of the library's small-launch settings on the reference's own call pattern: one Integrate() per frame, one
 sample per pixel in flight (bench.py's `per_frame` leg), scene built once.
-usage: python tools/per_frame_sweep.py [--config 4] [--frames 32] [--settings name:tune:small_launch_paths:overlap:variant ...]
+usage: python tools/per_frame_sweep.py [--config 4] [--frames 32] [--settings name:tune:small_launch_paths:overlap:variant[:resolve] ...]
   tune = RT_OPT_TRACE_TUNE (hex ok; bits 24..31 = fewest rays per lane a wave of k_trace_w4's grid is started for),
   small_launch_paths = RT_OPT_SMALL_LAUNCH_PATHS, overlap = RT_OPT_OVERLAP_SHADOW, variant = RT_OPT_TRACE_VARIANT"""
 import argparse, json, os, sys
@@ -28,12 +28,14 @@ def main():
     frame = host.load().rth_render_frame_handle(render.handle)
     lib = capi.load()
     for spec in a.settings:
-        name, tune, small, overlap, variant = spec.split(":")
+        parts = spec.split(":")
+        name, tune, small, overlap, variant = parts[:5]
+        resolve = int(parts[5]) if len(parts) > 5 else 1            # 0: no ResolveRadiance + read-back per frame (diagnostic)
         assert lib.rt_set_option(frame, capi.OPT_TRACE_TUNE, int(tune, 0)) == 0
         assert lib.rt_set_option(frame, capi.OPT_SMALL_LAUNCH_PATHS, int(small)) == 0
         assert lib.rt_set_option(frame, capi.OPT_OVERLAP_SHADOW, int(overlap)) == 0
         assert lib.rt_set_option(frame, capi.OPT_TRACE_VARIANT, int(variant)) == 0
-        pf = bench.per_frame_leg(args, render, lib, frame, capi, a.frames)
+        pf = bench.per_frame_leg(args, render, lib, frame, capi, a.frames, resolve=bool(resolve))
         print("%-28s %8.1f Mrays/s  %8.3f ms/frame  (%d x %d, %d bounces, %d tris)" %
               (name, pf["mrays_per_s"], pf["ms_per_frame"], args.width, args.height, args.bounces, n_tris), flush=True)
 

@@ -38,6 +38,8 @@ lib = capi.load()
 lib.rt_set_option(frame, capi.OPT_PROFILE, 1)
 ref_img = None
 def parse_tune(t):
+    if t.lower().startswith("0x"):
+        return int(t, 16)                      # the raw RT_OPT_TRACE_TUNE word (bit 23 = chunk mode, bits 24..31 = rays per lane)
     a = t.split(":")
     return int(a[0]) | ((int(a[1]) if len(a) > 1 else 0) << 8) | (((int(a[2]) // 16) if len(a) > 2 else 0) << 16)
 
@@ -46,16 +48,18 @@ for v, wv, sl, sel, tune in [(int(x), int(w), int(z), int(q), parse_tune(t)) for
                              for z in args.slots.split(",") for q in args.select.split(",")
                              for t in (args.tune.split(",") if int(x) >= 8 else ["0"])]:
     assert lib.rt_set_option(frame, capi.OPT_TRACE_TUNE, tune) == 0
+    assert lib.rt_set_option(frame, capi.OPT_SMALL_LAUNCH_PATHS, 0) == 0       # the variant asked for, whatever the launch size
     assert lib.rt_set_option(frame, capi.OPT_SELECT_FORM_BOX, sel) == 0
     assert lib.rt_set_option(frame, capi.OPT_SAMPLES_IN_FLIGHT, sl) == 0
     assert lib.rt_set_option(frame, capi.OPT_TRACE_VARIANT, v) == 0
     assert lib.rt_set_option(frame, capi.OPT_TRACE_WAVES, wv) == 0
     render.set_max_bounces(args.bounces)      # requests a reset
-    render.render_samples(2); render.finish()
+    render.render_samples(max(2, sl)); render.finish()
     prof = capi.rt_profile(); lib.rt_frame_get_profile(frame, prof)
     render.set_max_bounces(args.bounces)
     st0 = render.stats()
-    t = time.perf_counter(); render.render_samples(args.spp); render.finish(); dt = time.perf_counter() - t
+    spp = max(args.spp, 2 * sl)
+    t = time.perf_counter(); render.render_samples(spp); render.finish(); dt = time.perf_counter() - t
     lib.rt_frame_get_profile(frame, prof)
     st = render.stats()
     rays = st.closest_rays + st.shadow_rays
@@ -63,6 +67,6 @@ for v, wv, sl, sel, tune in [(int(x), int(w), int(z), int(q), parse_tune(t)) for
     same = True if ref_img is None else np.array_equal(img, ref_img, equal_nan=True)
     if ref_img is None:
         ref_img = img
-    print("variant %d tune %d:%d waves %d slots %d select %d: %.2f ms/spp  %.1f Mrays/s | closest %.3f ms  shadow %.3f ms  shade %.3f ms per spp | closest %.0f Mrays/s shadow %.0f Mrays/s | identical=%s"
-          % (v, tune & 255, (tune >> 8) & 255, wv, sl, sel, dt * 1e3 / args.spp, rays / dt / 1e6, prof.ms_trace_closest / args.spp, prof.ms_trace_shadow / args.spp,
-             prof.ms_shade / args.spp, st.closest_rays / prof.ms_trace_closest / 1e3, st.shadow_rays / prof.ms_trace_shadow / 1e3, same), flush=True)
+    print("variant %d tune 0x%08x waves %d slots %d select %d: %.2f ms/spp  %.1f Mrays/s | closest %.3f ms  shadow %.3f ms  shade %.3f ms per spp | closest %.0f Mrays/s shadow %.0f Mrays/s | identical=%s"
+          % (v, tune, wv, sl, sel, dt * 1e3 / spp, rays / dt / 1e6, prof.ms_trace_closest / spp, prof.ms_trace_shadow / spp,
+             prof.ms_shade / spp, st.closest_rays / prof.ms_trace_closest / 1e3, st.shadow_rays / prof.ms_trace_shadow / 1e3, same), flush=True)

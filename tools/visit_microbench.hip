@@ -1,0 +1,155 @@
+// visit_microbench.hip -- the LATENCY ceiling of the wide-tree walk (VERDICT r02 "next round" 2): the dependent chain of ONE
+// wide-node visit of k_trace_w4's loop C, on its own and at the kernel's residency.
+//
+//   fetch the 64-byte record of the current node (4 x global_load_dwordx4 through an SGPR base + 32-bit offset)
+//   -> w4_test_slots (the kernel's own code, raytracing_amd/csrc/trace_kernels.h: dequantise, 4 slab tests, visit order)
+//   -> push the later passing slots to the per-lane LDS stack, pop when nothing passes
+//   -> the NEXT node depends on all of it
+//
+// Every lane runs such a chain over a table of random wide nodes; where the next record lies is drawn so that a stated
+// fraction of the fetches hit L1 (a 16 KiB hot set per CU-sized group), L2 (4 MiB) or neither (1 GiB table) -- the hit mix
+// of the production kernel from its PMC counters (profiles/r0X_trace_counters.json: l1_hit_rate, l2_hit_rate).
+// Reported per configuration (waves per CU, hit mix): ns per visit of a lane's chain, and visits per second of the machine.
+// bench.py turns that into  ceiling = resident lanes x lane utilisation / visit latency / steps per ray.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -Iinclude -Iraytracing_amd/csrc tools/visit_microbench.hip -o tools/bin/visit_mb
+// usage: tools/bin/visit_mb [l1_hit l2_hit] [steps]      (defaults 0.93 0.85 4096)   prints one JSON object
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include <random>
+#include "trace_kernels.h"
+
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+
+struct Rec { float ox, oy, oz; uint32_t meta; uint32_t lo[3]; uint32_t hi[3]; uint32_t ref[4]; uint32_t order; uint32_t pad; };
+static_assert(sizeof(Rec) == 64, "wide node record");
+
+// one wave per block, 12-entry LDS stack like the production instance (6 KiB per wave -> 26 waves per CU)
+template <bool SHADOW>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_visit_chain(const float4* __restrict__ nodes, uint32_t n_hot,
+    uint32_t n_l2, uint32_t n_all, uint32_t thr_l1, uint32_t thr_l2, uint32_t steps, float* __restrict__ out)
+{
+    __shared__ uint2 stack[12][64];
+    const uint32_t lane = threadIdx.x;
+    const char* const node_base = reinterpret_cast<const char*>(nodes);
+    // a ray per lane: origin inside the unit cube the nodes live in, direction from a hash
+    uint32_t h = (blockIdx.x * 64u + lane) * 2654435761u + 12345u;
+    auto rnd = [&]() { h ^= h << 13; h ^= h >> 17; h ^= h << 5; return h; };
+    const f3 org = F3((rnd() & 0xFFFF) * (1.0f / 65536.0f), (rnd() & 0xFFFF) * (1.0f / 65536.0f), (rnd() & 0xFFFF) * (1.0f / 65536.0f));
+    f3 dir = F3((rnd() & 0xFFFF) * (2.0f / 65536.0f) - 1.0f, (rnd() & 0xFFFF) * (2.0f / 65536.0f) - 1.0f, (rnd() & 0xFFFF) * (2.0f / 65536.0f) - 1.0f);
+    dir.x = dir.x == 0.0f ? 0.5f : dir.x; dir.y = dir.y == 0.0f ? 0.5f : dir.y; dir.z = dir.z == 0.0f ? 0.5f : dir.z;
+    const f3 inv = F3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
+    const uint32_t sign_bits = (inv.x < 0.0f ? 1u : 0u) | (inv.y < 0.0f ? 2u : 0u) | (inv.z < 0.0f ? 4u : 0u);
+    const uint32_t octant3 = 3u * sign_bits;
+    const float t_min = 0.0f, INF = __builtin_inff();
+    float t_max = 1.0e4f;
+    int sp = 0;
+    // the hot set of this block's CU-sized neighbourhood: blocks that share a CU mostly share it
+    const uint32_t hot_base = ((blockIdx.x >> 3) % 64u) * n_hot;
+    uint32_t ref = hot_base + (lane % n_hot);
+    float acc = 0.0f;
+    for (uint32_t s = 0; s < steps; ++s)
+    {
+        const float4* np = reinterpret_cast<const float4*>(node_base + (size_t)(ref << 6));
+        const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
+        uint32_t r[4];
+        float e[4];
+        w4_test_slots<SHADOW>(q0, q1, q2, q3, org, inv, sign_bits, octant3, t_min, t_max, r, e);
+        // the kernel's direct-visit step: later passing slots to the stack, the first one next, pop when none passes
+        const bool v0 = e[0] < INF, v1 = e[1] < INF, v2 = e[2] < INF, v3 = e[3] < INF;
+        uint32_t next;
+        if (v3 && (v0 || v1 || v2)) { stack[sp % 12][lane] = make_uint2(r[3], __float_as_uint(e[3])); ++sp; }
+        if (v2 && (v0 || v1)) { stack[sp % 12][lane] = make_uint2(r[2], __float_as_uint(e[2])); ++sp; }
+        if (v1 && v0) { stack[sp % 12][lane] = make_uint2(r[1], __float_as_uint(e[1])); ++sp; }
+        if (v0) next = r[0];
+        else if (v1) next = r[1];
+        else if (v2) next = r[2];
+        else if (v3) next = r[3];
+        else
+        {
+            next = ref * 2246822519u + s;                                    // stack empty: "the next ray"
+            while (sp > 0)
+            {
+                --sp;
+                const uint2 en = stack[sp % 12][lane];
+                if (t_max >= __uint_as_float(en.y)) { next = en.x; break; }
+            }
+        }
+        acc += e[0] < INF ? e[0] : 0.0f;
+        if (sp > 9) sp = 3;                                                  // keep the synthetic stack shallow
+        // where the next record lies: L1-hot set / L2-resident set / anywhere, by the hit mix asked for
+        const uint32_t pick = (next ^ (next >> 15)) * 2654435761u;
+        const uint32_t where = pick >> 8;                                    // 24 bits
+        ref = where < thr_l1 ? hot_base + (pick % n_hot) : (where < thr_l2 ? (pick % n_l2) : (pick % n_all));
+    }
+    out[blockIdx.x * 64u + lane] = acc + (float)sp;
+}
+
+int main(int argc, char** argv)
+{
+    const double l1_hit = argc > 2 ? atof(argv[1]) : 0.93, l2_hit = argc > 2 ? atof(argv[2]) : 0.85;
+    const uint32_t steps = argc > 3 ? (uint32_t)atoi(argv[3]) : 4096u;
+    hipDeviceProp_t prop;
+    CHECK(hipGetDeviceProperties(&prop, 0));
+    const uint32_t cus = (uint32_t)prop.multiProcessorCount;
+    const uint32_t n_hot = 256u;                    // 16 KiB per neighbourhood
+    const uint32_t n_l2 = 65536u;                   // 4 MiB
+    const uint32_t n_all = 1u << 24;                // 1 GiB
+    std::vector<Rec> host((size_t)n_all);
+    std::mt19937 gen(7);
+    for (size_t i = 0; i < host.size(); ++i)
+    {
+        Rec& r = host[i];
+        r.ox = 0.0f; r.oy = 0.0f; r.oz = 0.0f;
+        r.meta = 119u | 119u << 8 | 119u << 16;     // cell 2^-8: the node spans the unit cube
+        for (int a = 0; a < 3; ++a)
+        {
+            r.lo[a] = 0; r.hi[a] = 0;
+            for (int k = 0; k < 4; ++k)
+            {
+                uint32_t lo = gen() % 200u, hi = lo + 8u + gen() % 48u;     // a slot covers ~1/6 of each axis: ~1.2 of 4 pass, as measured
+                if (gen() % 3u == 0u) { lo = 0; hi = 255; }                  // ... with some that span the axis
+                r.lo[a] |= lo << (8 * k); r.hi[a] |= (hi > 255u ? 255u : hi) << (8 * k);
+            }
+        }
+        for (int k = 0; k < 4; ++k) r.ref[k] = gen() & (n_all - 1u);
+        r.order = gen() & 0xFFFFFFu;
+        r.pad = 0;
+    }
+    float4* d_nodes = nullptr;
+    float* d_out = nullptr;
+    CHECK(hipMalloc((void**)&d_nodes, host.size() * sizeof(Rec)));
+    CHECK(hipMemcpy(d_nodes, host.data(), host.size() * sizeof(Rec), hipMemcpyHostToDevice));
+    CHECK(hipMalloc((void**)&d_out, (size_t)cus * 32 * 64 * sizeof(float)));
+    const uint32_t thr_l1 = (uint32_t)(l1_hit * 16777216.0), thr_l2 = thr_l1 + (uint32_t)((1.0 - l1_hit) * l2_hit * 16777216.0);
+    hipEvent_t a, b;
+    CHECK(hipEventCreate(&a));
+    CHECK(hipEventCreate(&b));
+    printf("{\"device\": \"%s\", \"compute_units\": %u, \"l1_hit\": %.4f, \"l2_hit\": %.4f, \"steps\": %u, \"runs\": [", prop.gcnArchName, cus, l1_hit, l2_hit, steps);
+    bool first = true;
+    for (int shadow = 0; shadow < 2; ++shadow)
+        for (uint32_t wpc : {1u, 4u, 8u, 16u, 26u})
+        {
+            const uint32_t blocks = cus * wpc;
+            float ms = 0.0f;
+            for (int rep = 0; rep < 2; ++rep)       // the first run warms the caches
+            {
+                CHECK(hipEventRecord(a));
+                if (shadow) hipLaunchKernelGGL(k_visit_chain<true>, dim3(blocks), dim3(64), 0, 0, d_nodes, n_hot, n_l2, n_all, thr_l1, thr_l2, steps, d_out);
+                else hipLaunchKernelGGL(k_visit_chain<false>, dim3(blocks), dim3(64), 0, 0, d_nodes, n_hot, n_l2, n_all, thr_l1, thr_l2, steps, d_out);
+                CHECK(hipEventRecord(b));
+                CHECK(hipEventSynchronize(b));
+                CHECK(hipEventElapsedTime(&ms, a, b));
+            }
+            const double ns_per_visit = (double)ms * 1e6 / steps;
+            const double visits_per_s = (double)blocks * 64.0 * steps / ((double)ms * 1e-3);
+            printf("%s{\"kernel\": \"%s\", \"waves_per_cu\": %u, \"ms\": %.4f, \"ns_per_visit\": %.2f, \"gvisits_per_s\": %.3f}", first ? "" : ", ",
+                shadow ? "shadow" : "closest", wpc, ms, ns_per_visit, visits_per_s * 1e-9);
+            first = false;
+        }
+    printf("]}\n");
+    return 0;
+}
