@@ -147,9 +147,8 @@ enum rt_option
                                    sweeps and the direct-visit form, which now IS k_trace_w4 -- were removed in round 3.) */
     , RT_OPT_TRACE_WAVES_PER_CU = 8 /* persistent-grid size of the trace kernels in waves per CU (0 = as many as fit) */
     , RT_OPT_SAMPLES_IN_FLIGHT = 9  /* rt_integrate traces this many consecutive samples per pixel concurrently
-                                       (1..1024, allocated at once; 0 = auto, the default: up to the largest power
-                                       of two <= 1024 whose per-path buffers stay under ~144 GB, allocated as
-                                       batches ask for them).  Results are bit-identical for every value: contributions
+                                       (1..1024, allocated at once; 0 = auto, the default: as many (<= 1024) as keep
+                                       the per-path buffers under ~144 GB, allocated as batches ask for them).  Results are bit-identical for every value: contributions
                                        are logged per path and replayed in the reference's order. */
     , RT_OPT_TRACE_SELECT_FORM_BOX = 10 /* validation: 1 = every ray uses the reference's compare+select min/max in the
                                        slab test (trace_bvh.cl:85-97); by default only rays whose 1/dir has a

@@ -754,15 +754,24 @@ void free_path_buffers(rt_frame* f)
 // log: 2 (B + 1) entries of 12 bytes.  412 bytes at 8 bounces (rounds 1-2: 540).
 size_t bytes_per_path(uint32_t max_bounces) { return 11u * 16u + 5u * 4u + 24u * (max_bounces + 1u); }
 
-// auto: the largest power of two <= 1024 that keeps tile pixels x samples inside 32-bit path
-// ids and the per-path buffers under ~144 GB (half of the 288 GB of HBM)
+// auto: the most samples (<= 1024; a multiple of 8 above 8, of 16 above 64 -- rounds 1-2 took powers of two, which left up to
+// half of the budget unused: a 4K frame with 16 bounces got 16 samples in flight where 24 fit) that keep tile pixels x
+// samples inside 32-bit path ids and the per-path buffers under 144 GiB (half of the 288 GB of HBM)
 uint32_t auto_slots(uint32_t n_local, uint32_t max_bounces)
 {
     const uint64_t n = n_local ? n_local : 1;
     const uint64_t max_paths = 0xFFFFFFF0ull;
-    uint32_t s = 1024;
-    while (s > 1 && (s * n > max_paths || s * n * bytes_per_path(max_bounces) > (144ull << 30))) s >>= 1;
-    return s;
+    const uint64_t by_memory = (144ull << 30) / (n * bytes_per_path(max_bounces));
+    const uint64_t by_ids = max_paths / n;
+    uint64_t s = by_memory < by_ids ? by_memory : by_ids;
+    // ... and no more than fill a launch: beyond ~270 M paths in flight (128 samples of a 1080p frame) a larger batch buys
+    // nothing (176 in flight, 140 GB: 6112 Mrays/s; 128, 102 GB: 6195 -- profiles/r03_call02_bench.json, r03_mid_bench.json)
+    const uint64_t by_fill = (270000000ull + n - 1) / n;
+    if (s > by_fill) s = by_fill;
+    if (s > 1024) s = 1024;
+    if (s > 64) s &= ~15ull;
+    else if (s > 8) s &= ~7ull;
+    return s ? (uint32_t)s : 1u;
 }
 
 // the most samples rt_integrate will trace together
@@ -1577,7 +1586,10 @@ int rt_integrate(rt_frame* f, uint32_t n_samples)       // n x Integrator::Integ
     f->side_active = side_on(f);
     while (done < n_samples && rc == RT_OK)
     {
-        uint32_t batch = n_samples - done < cap ? n_samples - done : cap;
+        // batches of (nearly) equal size: 1024 samples with room for 160 in flight go as 7 x 146-147, not 6 x 160 + 64 --
+        // every launch costs its tail whatever its size (DESIGN.md "Where a launch's time goes")
+        const uint32_t left = n_samples - done, n_batches = (left + cap - 1u) / cap;
+        uint32_t batch = (left + n_batches - 1u) / n_batches;
         if (per_frame) batch = 1;
         if (f->denoiser && rt_reset(f) != RT_OK) { rc = RT_ERROR; break; }   // integrator.cpp:29: Reset() every frame
         // The whole wavefront loop per chunk of pixels; chunk c runs on pipe c % n_pipes (its own stream), so the

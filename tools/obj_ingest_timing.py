@@ -13,10 +13,10 @@ from raytracing_amd import host, scenes as S
 def write_obj(path, arrays):
     tris = arrays["triangles"]
     n = len(tris)
-    P = np.stack([tris["v1"]["position"], tris["v2"]["position"], tris["v3"]["position"]], 1)[..., :3].reshape(-1, 3)
-    N = np.stack([tris["v1"]["normal"], tris["v2"]["normal"], tris["v3"]["normal"]], 1)[..., :3].reshape(-1, 3)
-    UV = np.stack([tris["v1"]["texcoord"], tris["v2"]["texcoord"], tris["v3"]["texcoord"]], 1)[..., :2].reshape(-1, 2)
-    mtl = tris["mtlIndex"]
+    raw = np.ascontiguousarray(tris).view(np.float32).reshape(n, 40)          # 3 vertices x (position, texcoord, normal) x 4 floats + 4 words
+    V = raw[:, :36].reshape(n, 3, 3, 4)
+    P, UV, N = V[:, :, 0, :3].reshape(-1, 3), V[:, :, 1, :2].reshape(-1, 2), V[:, :, 2, :3].reshape(-1, 3)
+    mtl = tris["mtl_index"]
     with open(path, "w") as f:
         f.write("mtllib %s\n" % os.path.basename(path).replace(".obj", ".mtl"))
         f.write("".join("v %.9g %.9g %.9g\n" % tuple(p) for p in P))
