@@ -1254,6 +1254,7 @@ static int wide_trace_impl(void* h, const void* wide_records, uint32_t n_wide, u
 {
     orc* o = (orc*)h;
     const int direct = (shadow & 2) != 0;                                /* bit 1 of `shadow`: the direct form of the walk */
+    const int ordered_shadow = (shadow & 4) != 0;                        /* bit 2: shadow rays visit slots near-first too (analysis) */
     shadow &= 1;
     const orc_wide_node* wn = (const orc_wide_node*)wide_records;
     /* leaf ref (first triangle) -> the BVH2 leaf node that holds its exact bounds and primitive count */
@@ -1360,7 +1361,7 @@ static int wide_trace_impl(void* h, const void* wide_records, uint32_t n_wide, u
                     e[k] = (exit >= entry && r[k] != ORC_EMPTY_REF) ? entry : INF;
                     if (e[k] < INF) counters[9]++;
                 }
-                if (!shadow)
+                if (!shadow || ordered_shadow)
                 {
                     const uint32_t sw = n->order >> (3u * (sign_bits & 7u));
                     const int sw0 = (sw & 1u) != 0u, pa = (sw & 2u) != 0u, pb = (sw & 4u) != 0u;
