@@ -523,7 +523,8 @@ def main():
         # ONE rank parses / generates the scene and builds the BVH; it leaves both in a binary scene cache
         # (Scene::SaveCache) the other ranks load -- N ranks on one host would otherwise do the same host work N times
         import tempfile
-        cache = os.path.join(tempfile.gettempdir(), "rt_bench_%s_%d.rtscene" % (os.environ.get("MASTER_PORT", "0"), os.getppid()))
+        cache = os.path.join(tempfile.gettempdir(), "rt_bench_%s_%s_cfg%d.rtscene" % (os.environ.get("MASTER_ADDR", "local").replace(":", "_"),
+                                                                                   os.environ.get("MASTER_PORT", "0"), args.config))
         if rank == 0:
             raw = build_scene(args, host, S, finish=False)
             raw.save_cache(cache)

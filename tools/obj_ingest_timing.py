@@ -49,7 +49,7 @@ if __name__ == "__main__":
     n = write_obj(obj, arrays)
     with open(obj.replace(".obj", ".mtl"), "w") as f:       # plain materials: the parse + build times are what is measured
         for m in range(len(arrays["materials"])):
-            f.write("newmtl m%d\nKd 0.7 0.7 0.7\nKs 0.04 0.04 0.04\nPr 0.5\n" % m)
+            f.write("newmtl m%d\nKd %.2f %.2f %.2f\nKs 0.04 0.04 0.04\nPr 0.5\nTf 1 1 1\n" % (m, 0.3 + 0.5 * ((m * 7) % 10) / 10.0, 0.3 + 0.5 * ((m * 3) % 10) / 10.0, 0.6))   # Tf 1: opaque (transparency < 0.5 = pass-through, material.h:171-241)
     t_write = time.time() - t0
     size = os.path.getsize(obj)
     t0 = time.time(); s = host.Scene(obj); t_parse = time.time() - t0
