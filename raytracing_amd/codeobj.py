@@ -1,5 +1,5 @@
-"""Identity of the device code inside librt_hip.so: SHA-256 of the ELF section that holds the gfx950 code objects
-(.hip_fatbin).  Counter files under profiles/ record it (tools/make_counters_json.py) and bench.py compares, so a
+"""Identity of the device code inside librt_hip.so: SHA-256 over the instructions and kernel descriptors of the gfx950
+code objects in its .hip_fatbin section.  Counter files under profiles/ record it (tools/make_counters_json.py) and bench.py compares, so a
 `roofline` read from counters of OTHER kernels says so (`stale: true`)."""
 import hashlib
 import os
@@ -29,13 +29,60 @@ def section_bytes(path, name):
     return None
 
 
+def _elf_sections(data):
+    """{name: bytes} of a 64-bit little-endian ELF image held in memory"""
+    shoff, = struct.unpack_from("<Q", data, 0x28)
+    shentsize, shnum, shstrndx = struct.unpack_from("<HHH", data, 0x3A)
+    def sh(i):
+        n, t, fl, addr, off, size = struct.unpack_from("<IIQQQQ", data, shoff + i * shentsize)
+        return n, t, off, size
+    _, _, stroff, strsize = sh(shstrndx)
+    names = data[stroff:stroff + strsize]
+    out = {}
+    for i in range(shnum):
+        n, t, off, size = sh(i)
+        name = names[n:names.index(b"\0", n)].decode()
+        out[name] = b"" if t == 8 else data[off:off + size]            # SHT_NOBITS has no bytes in the file
+    return out
+
+
+def device_code_objects(path=LIB):
+    """[(target triple, ELF image)] of the clang offload bundle in .hip_fatbin"""
+    blob = section_bytes(path, ".hip_fatbin")
+    magic = b"__CLANG_OFFLOAD_BUNDLE__"
+    if not blob or blob[:len(magic)] != magic:
+        return []
+    n, = struct.unpack_from("<Q", blob, len(magic))
+    pos = len(magic) + 8
+    out = []
+    for _ in range(n):
+        off, size, tlen = struct.unpack_from("<QQQ", blob, pos)
+        triple = blob[pos + 24:pos + 24 + tlen].decode()
+        pos += 24 + tlen
+        if size and blob[off:off + 4] == b"\x7fELF":
+            out.append((triple, blob[off:off + size]))
+    return out
+
+
 def code_object_sha256(path=LIB):
-    """hex digest of the .hip_fatbin section (None if the library is not built or has no such section)"""
+    """hex digest of the device CODE of the library: the .text (instructions) and .rodata (kernel descriptors) sections of
+    every gfx code object in .hip_fatbin.  Symbol tables are left out on purpose: clang names a per-translation-unit symbol
+    (__hip_cuid_...) after the source PATH, so the same source built in another directory differs there and nowhere else.
+    None if the library is not built or holds no code object."""
     try:
-        blob = section_bytes(path, ".hip_fatbin")
-    except (OSError, ValueError):
+        objs = device_code_objects(path)
+    except (OSError, ValueError, struct.error):
         return None
-    return hashlib.sha256(blob).hexdigest() if blob else None
+    if not objs:
+        return None
+    h = hashlib.sha256()
+    for triple, image in objs:
+        sec = _elf_sections(image)
+        h.update(triple.encode())
+        for name in (".text", ".rodata"):
+            h.update(name.encode())
+            h.update(sec.get(name, b""))
+    return h.hexdigest()
 
 
 if __name__ == "__main__":
