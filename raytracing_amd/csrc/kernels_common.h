@@ -4,9 +4,9 @@
 //
 // Reference kernels replaced (src/kernels/cl/):
 //   raygeneration.cl:65-139                        -> k_raygen
-//   trace_bvh.cl:99-211                            -> k_trace<false>
+//   trace_bvh.cl:99-211                            -> k_trace_w4<false> (k_trace2<false>, k_trace_v1<false>)
 //   trace_bvh.cl (-D SHADOW_RAYS) + accumulate_direct_samples.cl:27-53
-//                                                  -> k_trace<true>
+//                                                  -> k_trace_w4<true>  (k_trace2<true>,  k_trace_v1<true>)
 //   miss.cl:41-77 + hit_surface.cl:30-186 + clear_counter.cl (x2)
 //                                                  -> k_shade
 //   resolve_radiance.cl:31-86                      -> k_resolve
@@ -26,11 +26,11 @@
 //                then direct light, per bounce).  k_flush replays them pixel by pixel,
 //                sample by sample, so the fp32 sum is associated exactly as in the
 //                reference although several samples are traced concurrently.
-//   BVH          one 64-byte "child-pair" record per INTERIOR node of the
-//                reference BVH2: both children's boxes + refs in one line, so
-//                one dependent fetch serves two box tests (the reference needs
-//                one 48-byte fetch per box).  Topology, near/far rule and
-//                cull decisions are exactly the reference's (see k_trace).
+//   BVH          wnodes: one 64-byte record per TWO levels of the reference BVH2 (4 slots, 8-bit boxes on an exactly
+//                representable grid, per-octant visit order): the tree k_trace_w4 walks (build_wide_bvh, rt_hip.hip);
+//                nodes: one 64-byte "child-pair" record per INTERIOR node of the reference BVH2: both children's exact
+//                boxes + refs in one line (k_trace2, k_trace_v1).  Topology, near/far rule and cull decisions are
+//                exactly the reference's (trace_kernels.h).
 //   trace tris   64 B, line aligned: (p1, last-in-leaf flag), e1 = p2-p1, e2 = p3-p1, spare
 //   shade tris   128 B, line aligned: p1..p3, n1..n3, uv1..uv3, material
 #pragma once

@@ -226,7 +226,7 @@ __global__ __launch_bounds__(64) void k_trace_v1(DScene sc, const float4* __rest
 // ---------------------------------------------------------------------------
 // k_trace2: persistent traversal with SEPARATE wave-uniform loops (round 2)
 // ---------------------------------------------------------------------------
-// rocprofv3 on k_trace (profiles/r01_final_pmc_summary.txt) shows one VALU issued per SIMD
+// rocprofv3 on round 1's flat state-machine kernel (profiles/r01_final_pmc_summary.txt) shows one VALU issued per SIMD
 // every 4.03 cycles -- the vector ALU's issue rate (tools/issue_microbench.hip) -- at ~124
 // wave-instructions per ray, of which the box tests themselves need ~35.  The rest is the price
 // of the single flat loop: every iteration walks through the ray-start, triangle and node code
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(64) void k_trace_v1(DScene sc, const float4* __rest
 // so the hot loop C contains nothing but the node fetch, the two slab tests, the push and
 // the pop.  Lanes that reach a leaf or finish their ray sit out C until fewer than node_q
 // lanes are left in it; then B and A serve everybody who waits, together.  The per-lane
-// sequence of node visits, triangle tests and t_max updates is exactly k_trace's (and the
+// sequence of node visits, triangle tests and t_max updates is exactly k_trace_v1's (and the
 // reference's): only the interleaving between lanes changes.
 #define RT_IDLE_REF 0xFFFFFFFFu
 typedef float rt_v2f __attribute__((ext_vector_type(2)));
@@ -332,7 +332,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(STACK <= 10 
     if (count == 0) return;
     const uint32_t node_q = tune & 0xFFu, leaf_q = (tune >> 8) & 0xFFu;
     const uint32_t xcd = blockIdx.x & 7u;
-    const uint32_t per = (((count + 7u) >> 3) + 63u) & ~63u;                 // the XCD regions of k_trace
+    const uint32_t per = (((count + 7u) >> 3) + 63u) & ~63u;                 // one 64-aligned eighth of the queue per XCD
     const uint32_t spill_base = (blockIdx.x * 64u + lane) * (uint32_t)(RT_TRACE_STACK_MAX - STACK);
     const char* const node_base = reinterpret_cast<const char*>(sc.nodes);   // 32-bit byte offsets: the arrays
     const char* const tri_base = reinterpret_cast<const char*>(sc.tris_rt);  // stay below 4 GiB (rt_scene_upload)
@@ -397,7 +397,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(STACK <= 10 
                 if (ref == RT_IDLE_REF && ray_i != RT_INVALID_ID)
                 {
                     // ray start: 1/dir and the sign bits come from the producer; the root box test is
-                    // the ordinary node test of the super-root record (see k_trace)
+                    // the ordinary node test of the super-root record (rt_scene_upload)
                     if (index_list) ray_i = index_list[ray_i];
                     const float4 q0 = o4[ray_i], q1 = d4[ray_i];
                     if (SHADOW) { payload = __float_as_uint(q1.w); log_entry = aux[ray_i]; }

@@ -13,7 +13,7 @@
 // bench.py turns that into  ceiling = resident lanes x lane utilisation / visit latency / steps per ray.
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -Iinclude -Iraytracing_amd/csrc tools/visit_microbench.hip -o tools/bin/visit_mb
-// usage: tools/bin/visit_mb [l1_hit l2_hit] [steps]      (defaults 0.93 0.85 4096)   prints one JSON object
+// usage: tools/bin/visit_mb [l1_hit l2_hit] [steps] [1 = also the quad-cooperative fetch variant]   (defaults 0.93 0.85 4096 0)   prints one JSON object
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -28,11 +28,15 @@ struct Rec { float ox, oy, oz; uint32_t meta; uint32_t lo[3]; uint32_t hi[3]; ui
 static_assert(sizeof(Rec) == 64, "wide node record");
 
 // one wave per block, 12-entry LDS stack like the production instance (6 KiB per wave -> 26 waves per CU)
-template <bool SHADOW>
+// COOP: quad-cooperative fetch -- load instruction j of a lane reads the quarter (lane & 3) of the record quad member j
+// wants, so the four lanes of a quad read ONE 64-byte record per instruction (one L1 look-up instead of four); the quarters
+// are handed to their owners through a padded LDS staging buffer (4 x ds_write_b128, 4 x ds_read_b128, 4 KiB per wave).
+template <bool SHADOW, bool COOP = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_visit_chain(const float4* __restrict__ nodes, uint32_t n_hot,
     uint32_t n_l2, uint32_t n_all, uint32_t thr_l1, uint32_t thr_l2, uint32_t steps, float* __restrict__ out)
 {
     __shared__ uint2 stack[12][64];
+    __shared__ float4 stage[COOP ? 4 : 1][COOP ? 65 : 1];
     const uint32_t lane = threadIdx.x;
     const char* const node_base = reinterpret_cast<const char*>(nodes);
     // a ray per lane: origin inside the unit cube the nodes live in, direction from a hash
@@ -53,8 +57,25 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
     float acc = 0.0f;
     for (uint32_t s = 0; s < steps; ++s)
     {
-        const float4* np = reinterpret_cast<const float4*>(node_base + (size_t)(ref << 6));
-        const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
+        float4 q0, q1, q2, q3;
+        if (COOP)
+        {
+            const uint32_t m = lane & 3u, qb = lane & ~3u;
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j)
+            {
+                const uint32_t ref_j = (uint32_t)__shfl((int)ref, (int)(qb + j), 64);
+                stage[m][qb + j] = *reinterpret_cast<const float4*>(node_base + (size_t)(ref_j << 6) + (m << 4));
+            }
+            __syncthreads();                                                 // one-wave block: orders the LDS writes before the reads
+            q0 = stage[0][lane]; q1 = stage[1][lane]; q2 = stage[2][lane]; q3 = stage[3][lane];
+            __syncthreads();
+        }
+        else
+        {
+            const float4* np = reinterpret_cast<const float4*>(node_base + (size_t)(ref << 6));
+            q0 = np[0]; q1 = np[1]; q2 = np[2]; q3 = np[3];
+        }
         uint32_t r[4];
         float e[4];
         w4_test_slots<SHADOW>(q0, q1, q2, q3, org, inv, sign_bits, octant3, t_min, t_max, r, e);
@@ -130,15 +151,18 @@ int main(int argc, char** argv)
     CHECK(hipEventCreate(&b));
     printf("{\"device\": \"%s\", \"compute_units\": %u, \"l1_hit\": %.4f, \"l2_hit\": %.4f, \"steps\": %u, \"runs\": [", prop.gcnArchName, cus, l1_hit, l2_hit, steps);
     bool first = true;
-    for (int shadow = 0; shadow < 2; ++shadow)
-        for (uint32_t wpc : {1u, 4u, 8u, 16u, 26u})
+    const bool coop_too = argc > 4 && atoi(argv[4]) != 0;
+    for (int shadow = 0; shadow < (coop_too ? 3 : 2); ++shadow)
+        for (uint32_t wpc : {1u, 4u, 8u, 12u, 16u, 20u, 26u})
         {
+            if (shadow == 2 && wpc > 16u) continue;   // the staging buffer: 10 KiB of LDS per wave, 15 waves per CU
             const uint32_t blocks = cus * wpc;
             float ms = 0.0f;
             for (int rep = 0; rep < 2; ++rep)       // the first run warms the caches
             {
                 CHECK(hipEventRecord(a));
-                if (shadow) hipLaunchKernelGGL(k_visit_chain<true>, dim3(blocks), dim3(64), 0, 0, d_nodes, n_hot, n_l2, n_all, thr_l1, thr_l2, steps, d_out);
+                if (shadow == 2) hipLaunchKernelGGL((k_visit_chain<false, true>), dim3(blocks), dim3(64), 0, 0, d_nodes, n_hot, n_l2, n_all, thr_l1, thr_l2, steps, d_out);
+                else if (shadow) hipLaunchKernelGGL(k_visit_chain<true>, dim3(blocks), dim3(64), 0, 0, d_nodes, n_hot, n_l2, n_all, thr_l1, thr_l2, steps, d_out);
                 else hipLaunchKernelGGL(k_visit_chain<false>, dim3(blocks), dim3(64), 0, 0, d_nodes, n_hot, n_l2, n_all, thr_l1, thr_l2, steps, d_out);
                 CHECK(hipEventRecord(b));
                 CHECK(hipEventSynchronize(b));
@@ -147,7 +171,7 @@ int main(int argc, char** argv)
             const double ns_per_visit = (double)ms * 1e6 / steps;
             const double visits_per_s = (double)blocks * 64.0 * steps / ((double)ms * 1e-3);
             printf("%s{\"kernel\": \"%s\", \"waves_per_cu\": %u, \"ms\": %.4f, \"ns_per_visit\": %.2f, \"gvisits_per_s\": %.3f}", first ? "" : ", ",
-                shadow ? "shadow" : "closest", wpc, ms, ns_per_visit, visits_per_s * 1e-9);
+                shadow == 2 ? "closest, quad-cooperative fetch" : (shadow ? "shadow" : "closest"), wpc, ms, ns_per_visit, visits_per_s * 1e-9);
             first = false;
         }
     printf("]}\n");
