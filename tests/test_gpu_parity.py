@@ -674,6 +674,7 @@ def test_device_group_gather_through_the_c_abi(ctx, golden_scenes):
     for make in (lambda: capi.Group.create([0]), lambda: capi.Group.join(1, 0, capi.Group.unique_id(), 0)):
         g = make()
         assert g.size() == 1 and g.local_ranks() == [0]
+        assert g.comm_count() == (1, 0)                   # ncclCommCount / ncclCommUserRank: RCCL's own word, not the caller's argument
         img = g.gather_radiance([fr.handle], 0, h, w)
         assert np.array_equal(img, fr.radiance(), equal_nan=True)
         assert np.array_equal(img[..., :3], orc.radiance()[..., :3], equal_nan=True)
@@ -690,6 +691,7 @@ def test_device_group_gather_through_the_c_abi(ctx, golden_scenes):
     for t in tiles:
         t.set_camera(cam); t.set_max_bounces(b); t.integrate(spp)
     g = capi.Group.create_local(3, 0)
+    assert g.comm_count(1) == (0, -1)                     # a local group has no RCCL communicator
     for root in (0, 2):
         img = g.gather_radiance([t.handle for t in tiles], root, h, w)
         assert np.array_equal(img, fr.radiance(), equal_nan=True)
