@@ -45,7 +45,7 @@ def _config5():
 def test_production_launch_shape_matches_the_reference_kernels_bit_for_bit(make):
     arrays, bounces = make()
     w, h, spp = 192, 108, 128
-    assert w * h * spp >= 2_000_000                      # rt_hip.hip launch_trace: auto picks the persistent wide-tree kernel
+    assert w * h * spp >= 2_000_000                      # a production-sized batch: > 2 M paths per launch at bounce 0
     cam = T.default_camera(w, h)
     ctx = capi.Context(0)
     ctx.upload_scene(arrays)
@@ -65,6 +65,17 @@ def test_production_launch_shape_matches_the_reference_kernels_bit_for_bit(make)
     diff = ~((got == want) | (np.isnan(got) & np.isnan(want))).all(-1)
     assert not diff.any(), "%d of %d pixels differ, first at %s" % (diff.sum(), diff.size, np.argwhere(diff)[:3].tolist())
     assert (st.closest_rays, st.shadow_rays) == ri.ray_totals()
+    # Round 3: launches below RT_OPT_SMALL_LAUNCH_PATHS (3 M rays) run k_trace_w4 in chunk mode -- at this frame size that is
+    # every launch of the batch above.  The same batch with that switched off (every launch REFILLING, the regime of the
+    # headline's 100 M-ray launches) and with it forced on must give the same bits and counters.
+    for small in (0, 4000000000):
+        fr.set_option(capi.OPT_SMALL_LAUNCH_PATHS, small)
+        fr.reset()
+        fr.integrate(spp)
+        assert np.array_equal(fr.radiance()[..., :3], got, equal_nan=True), small
+        st2 = fr.stats()
+        assert (st2.closest_rays, st2.shadow_rays) == ri.ray_totals()
+    fr.set_option(capi.OPT_SMALL_LAUNCH_PATHS, 3000000)
     # the same batch through the BVH2 kernels gives the same bits (and the same counters)
     fr.set_option(capi.OPT_TRACE_VARIANT, 8)
     fr.reset()
@@ -74,8 +85,8 @@ def test_production_launch_shape_matches_the_reference_kernels_bit_for_bit(make)
     ctx.close()
 
 
-@pytest.mark.parametrize("variant", [8, 10])
-def test_deep_tree_spills_the_traversal_stack_to_hbm_and_stays_exact(variant, env_map):
+@pytest.mark.parametrize("variant,small", [(8, 0), (10, 0), (10, 3000000)], ids=["k_trace2", "k_trace_w4_refilling", "k_trace_w4_chunk_mode"])
+def test_deep_tree_spills_the_traversal_stack_to_hbm_and_stays_exact(variant, small, env_map):
     """65 536 large triangles stacked in depth along the view direction: every primary ray overlaps every box, so the
     descent to the first leaf pushes one far child per BVH2 level (16+ levels) -- more than the 10 / 12 entries the
     kernels keep in LDS.  rt_stats.stack_spills proves the HBM spill path ran; the image equals the oracle's."""
@@ -100,6 +111,7 @@ def test_deep_tree_spills_the_traversal_stack_to_hbm_and_stays_exact(variant, en
     fr = capi.Frame(ctx, w, h)
     fr.set_camera(cam); fr.set_max_bounces(b)
     fr.set_option(capi.OPT_TRACE_VARIANT, variant)
+    fr.set_option(capi.OPT_SMALL_LAUNCH_PATHS, small)
     fr.integrate(spp)
     st = fr.stats()
     assert st.stack_spills > 0

@@ -288,7 +288,9 @@ def test_samples_in_flight_and_kernel_variants_are_bit_invariant(ctx, golden_sce
                                         410: 3 << 24, 510: (200 << 24) | (4 << 16),
                                         # 610 / 710: chunk mode (64 rays per wave at a time, static chunks, no refill), whole grid / a few waves
                                         610: 1 << 23, 710: (1 << 23) | (5 << 24) | 1 | (64 << 8)}.get(variant, 0))
-    fr.set_option(capi.OPT_SMALL_LAUNCH_PATHS, 0 if variant == 5 and slots == 3 else 2000000)   # auto without the v1 rule too
+    # launches this small would all run in chunk mode (RT_OPT_SMALL_LAUNCH_PATHS, 3 M rays): keep the REFILLING form under test
+    # for the explicit variants (610 / 710 force chunk mode through the tune word), the automatic choice (5) takes both
+    fr.set_option(capi.OPT_SMALL_LAUNCH_PATHS, 3000000 if variant == 5 and slots != 3 else 0)
     fr.integrate(spp)
     assert fr.sample_count() == spp
     assert np.array_equal(fr.radiance(), base.radiance(), equal_nan=True)
@@ -541,6 +543,7 @@ def test_degenerate_bvhs(ctx, env_map, variant):
         ctx.upload_scene(sc)
         fr = capi.Frame(ctx, 48, 40)
         fr.set_camera(cam); fr.set_max_bounces(3); fr.set_option(capi.OPT_TRACE_VARIANT, variant)
+        fr.set_option(capi.OPT_SMALL_LAUNCH_PATHS, 0 if variant == 11 else 3000000)      # 11: the refilling form, 10: chunk mode (launches this small)
         fr.integrate(3)
         orc = _oracle.Oracle(48, 40, sc)
         orc.set_camera(cam); orc.set_max_bounces(3); orc.integrate(3)
