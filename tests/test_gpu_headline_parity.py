@@ -181,6 +181,45 @@ def test_bounded_path_state_renders_the_tile_in_chunks_bit_identically(variant, 
     base.close(); ctx.close()
 
 
+def test_stage_api_after_a_chunked_batch_renders_the_whole_tile(golden_scenes):
+    """with RT_OPT_PATH_STATE_LIMIT_MB set, an rt_integrate with several samples in flight leaves the
+    per-path buffers cut into chunks of pixels; a stage-API sample afterwards (the reference's Integrate() through the hooks:
+    rt_generate_rays ... rt_advance_sample) must render the WHOLE tile -- one sample of it fits -- not the first chunk only
+    (round 2 advanced the sample count over a partial image without an error).  Same for the per-frame features."""
+    w, h, b = 160, 100, 4
+    sc = golden_scenes["coverage"]
+    cam = T.default_camera(w, h)
+    ctx = capi.Context(0)
+    ctx.upload_scene(sc)
+    fr = capi.Frame(ctx, w, h)
+    fr.set_camera(cam); fr.set_max_bounces(b)
+    fr.set_option(capi.OPT_SAMPLES_IN_FLIGHT, 4)
+    fr.set_option(capi.OPT_PATH_STATE_LIMIT_MB, 8)
+    fr.integrate(4)
+    assert fr.stats().chunk_pixels < w * h                       # the batch really ran in chunks
+    def stage_sample():
+        fr.generate_rays()
+        for bounce in range(b + 1):
+            fr.intersect(bounce); fr.shade(bounce); fr.intersect_shadow(bounce)
+        fr.advance_sample()
+    stage_sample()
+    assert fr.stats().chunk_pixels == w * h                      # re-allocated for one sample of the whole tile
+    stage_sample()
+    orc = _oracle.Oracle(w, h, sc)
+    orc.set_camera(cam); orc.set_max_bounces(b); orc.integrate(6)
+    assert fr.sample_count() == 6
+    assert np.array_equal(fr.radiance()[..., :3], orc.radiance()[..., :3], equal_nan=True)
+    st = fr.stats()
+    assert (st.closest_rays, st.shadow_rays) == orc.ray_totals()
+    # ... and rt_integrate with a per-frame feature (the AOV viewer needs the whole tile in one chunk) after chunked batches
+    fr.integrate(4)
+    assert fr.stats().chunk_pixels < w * h
+    fr.set_option(capi.OPT_AOV, 3)
+    fr.integrate(1)
+    assert fr.stats().chunk_pixels == w * h and fr.sample_count() == 11
+    fr.close(); ctx.close()
+
+
 def test_pipelined_chunks_on_several_streams_are_bit_identical(golden_scenes):
     """RT_OPT_PIPELINES: a large batch (>= 4 M paths) is cut into chunks that travel through the wavefront loop on
     separate pipes (per-path buffers + HIP stream each) so that launch tails overlap.  1, 2, 3 and 4 pipes, with and

@@ -585,6 +585,10 @@ def test_axis_aligned_rays_and_select_form_slab_test(ctx, env_map, golden_scenes
             fr.integrate(4)
             imgs.append(fr.radiance()[..., :3].copy())
             st = fr.stats()
+            if sc is not golden_scenes["coverage"]:
+                # the overhead light makes every shadow ray "slow": the automatic choice sees that at upload and traces the
+                # shadow queue with k_trace2 (nothing handed over); k_trace_w4 asked for explicitly hands every one of them over
+                assert (st.slow_rays >= st.shadow_rays > 0) if select == 2 else (st.slow_rays < st.shadow_rays // 4)
         orc = _oracle.Oracle(w, h, sc)
         orc.set_camera(cam); orc.set_max_bounces(bounces); orc.integrate(4)
         assert np.array_equal(imgs[0], imgs[1], equal_nan=True)
