@@ -21,6 +21,9 @@
 #include <iostream>
 #include <sstream>
 #include <stdexcept>
+#include <cctype>
+#include <dirent.h>
+#include <sys/stat.h>
 
 namespace rt
 {
@@ -236,6 +239,48 @@ bool GetLine(std::istream& is, std::string& line)   // handles \n, \r\n and a mi
     return true;
 }
 
+// The file a material's map_* line names, as a Windows program would find it: the reference runs on Windows only
+// (src/utils/window.cpp:30-35), where `textures\\Wall_Diffuse.PNG` and `Textures/wall_diffuse.png` are the same file, and the
+// assets it is pointed at (Bistro) are authored there.  Backslashes become slashes; a component that does not exist as
+// written is looked up ignoring case.  A name that exists as written is returned unchanged.
+std::string ResolveAssetPath(const std::string& folder, std::string name)
+{
+    for (char& c : name) if (c == '\\') c = '/';
+    std::string direct = folder + "/" + name;
+    struct stat st;
+    if (stat(direct.c_str(), &st) == 0) return direct;
+    std::string cur = folder;
+    size_t pos = 0;
+    while (pos <= name.size())
+    {
+        size_t next = name.find('/', pos);
+        std::string part = name.substr(pos, next == std::string::npos ? std::string::npos : next - pos);
+        pos = next == std::string::npos ? name.size() + 1 : next + 1;
+        if (part.empty() || part == ".") continue;
+        std::string cand = cur + "/" + part;
+        if (stat(cand.c_str(), &st) != 0)
+        {
+            std::string found;
+            if (DIR* d = opendir(cur.c_str()))
+            {
+                while (dirent* e = readdir(d))
+                {
+                    std::string n = e->d_name;
+                    if (n.size() != part.size()) continue;
+                    bool same = true;
+                    for (size_t i = 0; i < n.size() && same; ++i) same = std::tolower((unsigned char)n[i]) == std::tolower((unsigned char)part[i]);
+                    if (same && (found.empty() || n < found)) found = n;      // deterministic when several names differ by case only
+                }
+                closedir(d);
+            }
+            if (found.empty()) return direct;                                 // not there: the caller reports the name as written
+            cand = cur + "/" + found;
+        }
+        cur = cand;
+    }
+    return cur;
+}
+
 std::string TextureName(const char* token)
 {
     // last whitespace-separated word (map options such as -o/-s/-bm precede the file name)
@@ -433,7 +478,7 @@ void Scene::Load(const char* filename, float scale, bool flip_yz)
             while (ss >> lib)
             {
                 size_t before = obj_materials.size();
-                LoadMtl(mtl_base + lib, obj_materials, material_map);
+                LoadMtl(folder.empty() ? mtl_base + lib : ResolveAssetPath(folder, lib), obj_materials, material_map);
                 if (obj_materials.size() > before) break;   // first library that loads wins
             }
             continue;
@@ -454,7 +499,7 @@ void Scene::Load(const char* filename, float scale, bool flip_yz)
     {
         const size_t slot = wide_at++;
         if (name.empty()) return kInvalidTextureIndex;
-        const std::uint32_t idx = (std::uint32_t)LoadTexture(folder + "/" + name);
+        const std::uint32_t idx = (std::uint32_t)LoadTexture(ResolveAssetPath(folder, name));
         wide[slot] = (std::uint16_t)idx;
         return idx < kInvalidTextureIndex ? idx : kInvalidTextureIndex;
     };
@@ -542,6 +587,7 @@ std::size_t Scene::LoadTexture(const std::string& filename)   // scene.cpp:276-3
     size_t dot = filename.find_last_of('.');
     if (dot == std::string::npos) throw std::runtime_error("Invalid texture extension");
     std::string ext = filename.substr(dot);
+    for (char& c : ext) c = (char)std::tolower((unsigned char)c);            // ".PNG": stb_image decides by content, the reference by strcmp
     Image image;
     bool ok = false;
     if (ext == ".tga") ok = LoadTGA(filename.c_str(), image);

@@ -513,3 +513,32 @@ def test_more_than_255_textures_need_the_wide_index_extension(tmp_path):
     assert "material_texture_indices" not in p8
     # the NEE flag travels with the scene object
     assert "flags" not in p8 and host.Scene(path_small, emissive_nee=True).arrays()["flags"] == 1
+
+
+def test_assets_authored_on_windows_load_on_linux(tmp_path):
+    """The reference is a Windows program (src/utils/window.cpp:30-35) and the assets it is pointed at (Bistro,
+    run_bistro.bat:15) are authored there: CRLF line ends, backslashes in map_* / mtllib paths, file names whose case does not
+    match the directory.  On Windows those are the same files; the loader finds them here too (and a name that exists as
+    written always wins)."""
+    (tmp_path / "Textures").mkdir()
+    rng = np.random.RandomState(3)
+    px = rng.randint(0, 256, (4, 4, 3))
+    _write_png(str(tmp_path / "Textures" / "Wall_Diffuse.png"), px, 2)
+    (tmp_path / "Scene.MTL").write_bytes(b"newmtl m\r\nKd 1 1 1\r\nTf 1 1 1\r\nmap_Kd textures\\wall_diffuse.PNG\r\n")
+    (tmp_path / "t.obj").write_bytes(b"mtllib scene.mtl\r\nv 0 0 0\r\nv 1 0 0\r\nv 0 1 0\r\nvn 0 0 1\r\nvt 0 0\r\nvt 1 0\r\nvt 0 1\r\n"
+                                     b"usemtl m\r\nf 1/1/1 2/2/1 3/3/1\r\n")
+    a = host.Scene(str(tmp_path / "t.obj")).arrays()
+    assert len(a["triangles"]) == 1 and len(a["textures"]) == 1 and (int(a["textures"][0]["width"]), int(a["textures"][0]["height"])) == (4, 4)
+    assert (int(a["materials"][0]["diffuse_albedo"]) >> 24) == 0                 # the texture is bound to the material
+    want = (px[..., 0].astype(np.uint32) | px[..., 1].astype(np.uint32) << 8 | px[..., 2].astype(np.uint32) << 16).ravel()
+    assert np.array_equal(a["texture_data"], want)
+    # a file that exists exactly as written is taken, whatever else is in the directory
+    _write_png(str(tmp_path / "Textures" / "wall_diffuse.PNG"), 255 - px, 2)
+    (tmp_path / "textures").mkdir()
+    _write_png(str(tmp_path / "textures" / "wall_diffuse.PNG"), px // 2, 2)
+    b = host.Scene(str(tmp_path / "t.obj")).arrays()
+    assert np.array_equal(b["texture_data"], ((px // 2)[..., 0].astype(np.uint32) | (px // 2)[..., 1].astype(np.uint32) << 8 | (px // 2)[..., 2].astype(np.uint32) << 16).ravel())
+    (tmp_path / "t.mtl").write_bytes(b"newmtl m\nKd 1 1 1\nmap_Kd textures\\nowhere.png\n")
+    (tmp_path / "u.obj").write_bytes(b"mtllib t.mtl\nv 0 0 0\nv 1 0 0\nv 0 1 0\nusemtl m\nf 1 2 3\n")
+    with pytest.raises(host.RtError, match="Failed to load file"):
+        host.Scene(str(tmp_path / "u.obj"))
