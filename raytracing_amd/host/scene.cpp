@@ -283,11 +283,36 @@ std::string ResolveAssetPath(const std::string& folder, std::string name)
 
 std::string TextureName(const char* token)
 {
-    // last whitespace-separated word (map options such as -o/-s/-bm precede the file name)
+    // What tinyobjloader hands the reference for a map_* line (tiny_obj_loader.h:1191-1270, ParseTextureNameAndOption): options
+    // first -- each followed by a fixed number of words: one for -blendu -blendv -clamp -boost -bm -type -texres -imfchan
+    // -colorspace, two for -mm, THREE for -o -s -t (it reads three reals whatever follows: `-s 1 1 wall.png` eats the name) --
+    // then the REST of the line is the file name, blanks included.
     std::string s(token);
-    while (!s.empty() && (s.back() == ' ' || s.back() == '\t')) s.pop_back();
-    size_t p = s.find_last_of(" \t");
-    return p == std::string::npos ? s : s.substr(p + 1);
+    while (!s.empty() && (s.back() == ' ' || s.back() == '\t' || s.back() == '\r' || s.back() == '\n')) s.pop_back();
+    size_t p = 0;
+    auto skip_blanks = [&]() { while (p < s.size() && (s[p] == ' ' || s[p] == '\t')) ++p; };
+    auto skip_word = [&]() { skip_blanks(); while (p < s.size() && s[p] != ' ' && s[p] != '\t') ++p; };
+    static const struct { const char* name; int words; } kOptions[] = {
+        {"-blendu", 1}, {"-blendv", 1}, {"-clamp", 1}, {"-boost", 1}, {"-bm", 1}, {"-type", 1}, {"-texres", 1}, {"-imfchan", 1},
+        {"-colorspace", 1}, {"-mm", 2}, {"-o", 3}, {"-s", 3}, {"-t", 3}};
+    for (;;)
+    {
+        skip_blanks();
+        if (p >= s.size()) return std::string();
+        bool option = false;
+        for (const auto& o : kOptions)
+        {
+            const size_t n = strlen(o.name);
+            if (s.compare(p, n, o.name) == 0 && p + n < s.size() && (s[p + n] == ' ' || s[p + n] == '\t'))
+            {
+                p += n;
+                for (int w = 0; w < o.words; ++w) skip_word();
+                option = true;
+                break;
+            }
+        }
+        if (!option) return s.substr(p);
+    }
 }
 
 void LoadMtl(const std::string& path, std::vector<ObjMaterial>& materials, std::unordered_map<std::string, int>& map)

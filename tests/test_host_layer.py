@@ -291,6 +291,28 @@ class TestAgainstReferenceHost:
         rm = _ref._arr(lib.refh_materials(h), lib.refh_num_materials(h), T.packed_material)
         assert T.records_equal(rt, mine["triangles"]) and T.records_equal(rm, mine["materials"])
 
+    def test_map_options_and_file_names_parsed_like_tinyobjloader(self, tmp_path):
+        """map_* lines as the reference's tinyobjloader reads them (tiny_obj_loader.h:1191-1270): options with their fixed
+        number of words first, then the REST of the line is the file name -- blanks included -- and `-s 1 1 name` reads the
+        name as the third real (no texture).  Materials, the texture table and the texels equal the reference Scene's."""
+        rng = np.random.RandomState(9)
+        for i, name in enumerate(("plain.png", "with blank.png", "scaled.png", "eaten.png", "bump.png")):
+            _write_png(str(tmp_path / name), rng.randint(0, 256, (2 + i, 3, 3)), 2)
+        mtl = ("newmtl a\nKd 1 1 1\nTf 1 1 1\nmap_Kd plain.png\nmap_Ks -clamp on with blank.png\n"
+               "newmtl b\nKd 1 1 1\nTf 1 1 1\nmap_Kd -s 2 2 2 -o 0.5 0 0 scaled.png\nmap_Pr -s 1 1 eaten.png\nmap_Pm -bm 0.3 -mm 0 1 bump.png\n")
+        meshes = [S.quad((-1, -1, 0), (1, -1, 0), (1, 1, 0), (-1, 1, 0)) + (0,), S.quad((-1, -1, 1), (1, -1, 1), (1, 1, 1), (-1, 1, 1)) + (1,)]
+        S.write_obj(str(tmp_path / "t.obj"), meshes, ["a", "b"], mtl)
+        mine = host.Scene(str(tmp_path / "t.obj")).arrays()
+        lib = _ref.load()
+        h = lib.refh_scene_load(str(tmp_path / "t.obj").encode(), 1.0, 0)
+        assert h
+        rm = _ref._arr(lib.refh_materials(h), lib.refh_num_materials(h), T.packed_material)
+        rtx = _ref._arr(lib.refh_textures(h), lib.refh_num_textures(h), T.texture)
+        rtd = _ref._arr(lib.refh_texture_data(h), lib.refh_num_texture_data(h), np.uint32)
+        assert T.records_equal(rm, mine["materials"])
+        assert len(rtx) == len(mine["textures"]) == 4 and T.records_equal(rtx, mine["textures"])          # eaten.png is not loaded
+        assert np.array_equal(rtd, mine["texture_data"])
+
     def test_hdr_loader_identical_to_reference(self, env_map):
         ref = _ref.load_hdr(os.path.join(ROOT, "assets", "ibl", "CGSkies_0036_free.hdr"))
         assert np.array_equal(ref.view(np.uint32), env_map.view(np.uint32))
