@@ -474,7 +474,8 @@ def main():
     ap.add_argument("--shade-partition", type=int, default=None, help="RT_OPT_SHADE_PARTITION (library default: 3)")
     ap.add_argument("--trace-waves", type=int, default=0, help="RT_OPT_TRACE_WAVES_PER_CU (0 = as many as fit)")
     ap.add_argument("--trace-variant", type=int, default=None, help="RT_OPT_TRACE_VARIANT (default: the library's automatic choice)")
-    ap.add_argument("--small-launch-paths", type=int, default=None, help="RT_OPT_SMALL_LAUNCH_PATHS (library default 2000000)")
+    ap.add_argument("--small-launch-paths", type=int, default=None, help="RT_OPT_SMALL_LAUNCH_PATHS (library default 3000000)")
+    ap.add_argument("--compact-log", type=int, default=None, help="RT_OPT_COMPACT_LOG (library default 1)")
     ap.add_argument("--per-frame-frames", type=int, default=48, help="frames of the per_frame leg (the reference's call pattern, "
                     "one Integrate() per frame); 0 = skip it")
     ap.add_argument("--per-frame-only", action="store_true", help="run only the per_frame leg and print its object (tuning runs)")
@@ -594,6 +595,8 @@ def main():
         assert lib.rt_set_option(frame, capi.OPT_PATH_STATE_LIMIT_MB, int(args.path_state_gb * 1024)) == 0
     if args.small_launch_paths is not None:
         assert lib.rt_set_option(frame, capi.OPT_SMALL_LAUNCH_PATHS, args.small_launch_paths) == 0
+    if args.compact_log is not None:
+        assert lib.rt_set_option(frame, capi.OPT_COMPACT_LOG, args.compact_log) == 0
     if args.per_frame_only:
         pf = per_frame_leg(args, render, lib, frame, capi, max(args.per_frame_frames, 1))
         if rank == 0:
@@ -750,6 +753,7 @@ def main():
                                 if world > 1 else "single tile",
                                 rays_per_step=round(total_rays / args.steps, 1), non_finite_pixels=nan_px,
                                 stack_spill_lane_steps=int(st1.stack_spills), rays_left_to_the_bvh2_kernel=int(st1.slow_rays),
+                                log_inline_entries=int(st1.log_inline_entries), log_fallbacks=int(st1.log_fallbacks),   # 0 inline = the full log layout
                                 setup_s=round(t_setup, 2), scene_s=round(t_scene, 2),     # scene_s: parse / generate (or load the cache); setup_s: + BVH, wide collapse, upload
                                 device=name),
                     ranks=dict(render_ms_min=round(float(tmin[0].item()) * 1e3, 3), render_ms_max=round(float(tmax[1].item()) * 1e3, 3),

@@ -184,6 +184,14 @@ enum rt_option
                                        queue counter.  It is what makes the reference's own call pattern (one Integrate() per
                                        frame, one sample per pixel in flight) fast, and the late bounces of any batch.  Default
                                        3 000 000; 0 = never.  Results are identical for every value. */
+    , RT_OPT_COMPACT_LOG = 19      /* 1: rt_integrate batches of >= 8 samples in flight keep the radiance log COMPACT: six inline
+                                       entries per path (a path of the benchmark scene logs 2.7 on average, 1 % more than six) +
+                                       overflow blocks, bump-allocated one bounce ahead, for an eighth of the paths -- 290 instead
+                                       of 412 bytes per path at 8 bounces, 314 instead of 604 at 16 -- at ~1.5 % of the throughput
+                                       (k_shade's allocation step).  A batch that runs the pool dry (long-lived paths: a closed,
+                                       lit room) is discarded and repeated in the full layout, which the frame then keeps
+                                       (rt_stats.log_fallbacks).  0 (default): the full layout.  Results are bit-identical. */
+    , RT_OPT_DEBUG_LOG_POOL_DIV = 20 /* test hook: the overflow pool holds paths / value blocks (default 8) */
     , RT_OPT_TRACE_TUNE = 12       /* k_trace2 (variants 8, 9) loop thresholds: value & 255 = lanes that must hold an
                                        interior node for a wave to stay in the node loop, value >> 8 & 255 = lanes that
                                        must wait at a triangle for another pass of the triangle loop, value >> 16 & 255 = rays a wave takes
@@ -254,6 +262,9 @@ typedef struct rt_stats
     uint32_t chunk_pixels;             /* pixels of the tile that travel through the wavefront loop together (the whole
                                           tile unless RT_OPT_PATH_STATE_LIMIT_MB splits it) */
     uint32_t pipelines;                /* pipes (HIP streams) the chunks are dealt to */
+    uint32_t log_inline_entries;       /* != 0: the radiance log is in its compact layout with this many inline entries per path
+                                          (RT_OPT_COMPACT_LOG); 0: the full layout, 2 (max_bounces + 1) entries per path */
+    uint32_t log_fallbacks;            /* batches whose overflow pool ran dry and that were repeated in the full layout */
 } rt_stats;
 int rt_frame_get_stats(rt_frame* frame, rt_stats* out);
 

@@ -51,6 +51,36 @@ RT_DEV void log_store(float* __restrict__ rlog, size_t index, float x, float y, 
     *reinterpret_cast<rt_rgb*>(rlog + 3 * index) = v;
 }
 
+// Where the entries of a path's radiance log live.  FULL layout (inline_entries = 2 (B + 1), the worst case a path can
+// log): entry k of path id at row-major index k * stride + id.  COMPACT layout (round 3; rt_integrate with many samples in
+// flight): only the first inline_entries (6) rows exist for every path -- a path of the benchmark scene logs 2.7 entries on
+// average, 1 % of the paths more than 6 -- and a path that is about to need a 7th gets an OVERFLOW BLOCK for its entries
+// inline_entries .. 2 (B + 1) - 1 from a bump-allocated pool of ovf_blocks blocks (k_shade, one bounce ahead, one atomic per
+// 512-path block): entry k >= inline_entries of a path with block `slot` at inline_entries * stride + (k - inline_entries) *
+// ovf_blocks + slot.  A pool that runs dry raises DCounters::log_ovf_flag; the host then discards the batch and repeats it in
+// the full layout (rt_integrate), so the sum is exact either way.
+struct DLog
+{
+    float* rlog;                  // 3 floats per entry
+    uint32_t* cnt;                // entries of path id (k_flush replays that many)
+    uint32_t* ovf_slot;           // compact: the overflow block of path id (RT_EMPTY_REF: none); nullptr in the full layout
+    uint32_t stride;              // paths per row
+    uint32_t inline_entries;
+    uint32_t ovf_blocks;
+};
+// index of entry k of path id (in entries), or ~0 when the entry has no home (pool dry: the batch is being discarded)
+RT_DEV size_t log_index(const DLog& L, uint32_t k, uint32_t id, uint32_t slot)
+{
+    if (k < L.inline_entries) return (size_t)k * L.stride + id;
+    if (slot >= L.ovf_blocks) return ~(size_t)0;
+    return (size_t)L.inline_entries * L.stride + (size_t)(k - L.inline_entries) * L.ovf_blocks + slot;
+}
+RT_DEV void log_put(const DLog& L, uint32_t k, uint32_t id, uint32_t slot, float x, float y, float z)
+{
+    const size_t i = log_index(L, k, id, slot);
+    if (i != ~(size_t)0) log_store(L.rlog, i, x, y, z);
+}
+
 struct DScene
 {
     const float4* nodes;          // 4 x float4 per interior node
@@ -113,6 +143,8 @@ struct DCounters                  // one per frame, device memory
     unsigned long long tl_ray_steps[64], tl_ray_ticks[64];
     // ... and when its waves left, in 25 us bins after the first wave found the queue dry (all recorded launches together)
     unsigned long long tl_exit_hist[64];
+    // compact radiance log (DLog): next free overflow block of the batch in flight, and "the pool ran dry"
+    uint32_t log_ovf_next, log_ovf_flag;
 };
 
 // ray_inv_dir and ray_sign of TraceBvh (trace_bvh.cl:125-129), packed as (inv.xyz, sign bits)

@@ -77,6 +77,7 @@ struct PathPipe
     uint32_t* sh_slow_list = nullptr;
     // radiance log (kernels_common.h header): cnt[id], rlog[entry][id]; id < slots * chunk_pixels
     float* rlog = nullptr; uint32_t* cnt = nullptr;   // rlog: 3 floats per entry
+    uint32_t* ovf_slot = nullptr;      // compact log layout: a path's overflow block (DLog, kernels_common.h)
     uint32_t* slow_list = nullptr;     // queue indices k_trace_w4 leaves to k_trace2 (one per path)
     DCounters* counters = nullptr;
     uint2* spill = nullptr;
@@ -110,7 +111,15 @@ struct rt_frame
     // (path ids are chunk-relative, the radiance log is replayed per chunk).
     uint32_t chunk_pixels = 0;     // pixels per chunk as allocated (n_local when the tile is not chunked)
     uint32_t state_limit_mb = 0;   // RT_OPT_PATH_STATE_LIMIT_MB (0 = only the built-in 144 GB rule)
-    uint32_t log_entries = 0;      // rows allocated (>= 2 * (max_bounces + 1))
+    uint32_t log_entries = 0;      // entries a path may log: 2 * (max_bounces + 1)
+    // Radiance-log layout (DLog): compact = log_inline rows for every path + a pool of log_ovf_blocks overflow blocks;
+    // full = every row for every path (log_inline == log_entries, no pool).
+    uint32_t log_inline = 0, log_ovf_blocks = 0;
+    uint32_t compact_log_opt = 0;  // RT_OPT_COMPACT_LOG: 1 = the compact layout for batches of >= 8 samples in flight, 0 (default) = always the full layout
+    uint32_t log_pool_div = 8;     // the pool holds paths / log_pool_div blocks (RT_OPT_DEBUG_LOG_POOL_DIV: test hook)
+    bool log_full_forced = false;  // a batch ran its pool dry: this frame stays on the full layout (until bounces / scene change)
+    uint32_t fallback_limit_mb = 0;   // ... within the bytes the compact layout held (chunk_plan)
+    uint32_t log_fallbacks = 0;    // batches repeated in the full layout
     bool fused = false;            // inside rt_integrate: whole samples, nothing reads the radiance between stages
     uint32_t trace_blocks;       // v1 grid
     uint32_t trace_variant = 5;  // RT_OPT_TRACE_VARIANT (5 = auto)
@@ -737,31 +746,47 @@ void free_path_buffers(rt_frame* f)
     for (PathPipe& q : f->ps)
     {
         void* ptrs[] = {q.o4[0], q.o4[1], q.d4[0], q.d4[1], q.thr[0], q.thr[1], q.hits, q.sh_o4[0], q.sh_d4[0],
-            q.sh_aux[0], q.sh_o4[1], q.sh_d4[1], q.sh_aux[1], q.rlog, q.cnt, q.slow_list, q.sh_slow_list};
+            q.sh_aux[0], q.sh_o4[1], q.sh_d4[1], q.sh_aux[1], q.rlog, q.cnt, q.slow_list, q.sh_slow_list, q.ovf_slot};
         for (void* p : ptrs) if (p) (void)hipFree(p);
         for (int i = 0; i < 2; ++i)
         {
             q.o4[i] = nullptr; q.d4[i] = nullptr; q.thr[i] = nullptr;
             q.sh_o4[i] = nullptr; q.sh_d4[i] = nullptr; q.sh_aux[i] = nullptr;
         }
-        q.hits = nullptr; q.rlog = nullptr; q.cnt = nullptr; q.slow_list = nullptr; q.sh_slow_list = nullptr;
+        q.hits = nullptr; q.rlog = nullptr; q.cnt = nullptr; q.slow_list = nullptr; q.sh_slow_list = nullptr; q.ovf_slot = nullptr;
     }
 }
 
 // Per-path state: ray queues for `slots` samples in flight and the radiance log
 // with 2 * (max_bounces + 1) entries per path.  (Re)allocated when either changes.
+// Compact radiance log (kernels_common.h, DLog): six inline entries per path + overflow blocks for an eighth of the paths.
+#define RT_LOG_INLINE 6u
+// may a batch of `slots` samples in flight use the compact layout?  (It pays from ~10 entries per path up, needs batches large
+// enough for the pool's statistics, and one pipe: the pool-dry check synchronises the host with the chunk's stream.)
+bool log_is_compact(const rt_frame* f, uint32_t slots)
+{
+    return f->compact_log_opt && !f->log_full_forced && slots >= 8u && f->pipelines == 1u && 2u * (f->max_bounces + 1u) >= RT_LOG_INLINE + 4u;
+}
+
 // ray queues o4, d4, thr (x2), hits, shadow queue o4, d4 (x2) = 11 x 16; sh_aux (x2), cnt, two slow lists = 5 x 4;
-// log: 2 (B + 1) entries of 12 bytes.  412 bytes at 8 bounces (rounds 1-2: 540).
-size_t bytes_per_path(uint32_t max_bounces) { return 11u * 16u + 5u * 4u + 24u * (max_bounces + 1u); }
+// log, full layout: 2 (B + 1) entries of 12 bytes -- 412 bytes at 8 bounces (rounds 1-2: 540); compact layout: 6 inline
+// entries + the path's share of the overflow pool + its block index -- 290 bytes at 8 bounces, 314 at 16.
+size_t bytes_per_path(const rt_frame* f, uint32_t slots)
+{
+    const size_t entries = 2u * (f->max_bounces + 1u);
+    if (!log_is_compact(f, slots)) return 11u * 16u + 5u * 4u + 12u * entries;
+    return 11u * 16u + 5u * 4u + 4u + 12u * RT_LOG_INLINE + (12u * (entries - RT_LOG_INLINE) + f->log_pool_div - 1u) / f->log_pool_div;
+}
 
 // auto: the most samples (<= 1024; a multiple of 8 above 8, of 16 above 64 -- rounds 1-2 took powers of two, which left up to
 // half of the budget unused: a 4K frame with 16 bounces got 16 samples in flight where 24 fit) that keep tile pixels x
 // samples inside 32-bit path ids and the per-path buffers under 144 GiB (half of the 288 GB of HBM)
-uint32_t auto_slots(uint32_t n_local, uint32_t max_bounces)
+uint32_t auto_slots(const rt_frame* f)
 {
-    const uint64_t n = n_local ? n_local : 1;
+    const uint64_t n = f->n_local ? f->n_local : 1;
     const uint64_t max_paths = 0xFFFFFFF0ull;
-    const uint64_t by_memory = (144ull << 30) / (n * bytes_per_path(max_bounces));
+    uint64_t by_memory = (144ull << 30) / (n * bytes_per_path(f, 1024u));        // the compact layout, if this frame may use it ...
+    if (by_memory < 8u) by_memory = (144ull << 30) / (n * bytes_per_path(f, 1u));  // ... which takes 8 samples in flight
     const uint64_t by_ids = max_paths / n;
     uint64_t s = by_memory < by_ids ? by_memory : by_ids;
     // ... and no more than fill a launch: beyond ~270 M paths in flight (128 samples of a 1080p frame) a larger batch buys
@@ -777,7 +802,7 @@ uint32_t auto_slots(uint32_t n_local, uint32_t max_bounces)
 // the most samples rt_integrate will trace together
 uint32_t slot_cap(const rt_frame* f)
 {
-    uint32_t cap = f->slots_opt ? f->slots_opt : auto_slots(f->n_local, f->max_bounces);
+    uint32_t cap = f->slots_opt ? f->slots_opt : auto_slots(f);
     return f->slots_limit && f->slots_limit < cap ? f->slots_limit : cap;    // what the device could actually hold
 }
 
@@ -794,10 +819,14 @@ void chunk_plan(const rt_frame* f, uint32_t slots, uint32_t& n_pipes, uint32_t& 
     if (f->pipelines > 1 && slots >= 2 && n * slots >= 4000000ull) n_pipes = f->pipelines < RT_MAX_PIPES ? f->pipelines : RT_MAX_PIPES;
     uint64_t c = (n + n_pipes - 1) / n_pipes;                        // pixels per chunk without a memory limit
     if (n_pipes > 1) c = (c + 63ull) & ~63ull;
-    if (f->state_limit_mb)
+    // the caller's limit, and -- after a batch had to fall back from the compact to the full log layout -- the library's own
+    // 144 GiB rule (the full layout then runs the same batch size in more chunks instead of asking for more memory than that)
+    const uint64_t limit_mb = f->state_limit_mb && f->fallback_limit_mb ? (f->state_limit_mb < f->fallback_limit_mb ? f->state_limit_mb : f->fallback_limit_mb)
+                                                                         : (f->state_limit_mb ? f->state_limit_mb : f->fallback_limit_mb);
+    if (limit_mb)
     {
-        const uint64_t per_pixel = (uint64_t)slots * bytes_per_path(f->max_bounces);
-        const uint64_t limit = ((uint64_t)f->state_limit_mb << 20) / n_pipes;
+        const uint64_t per_pixel = (uint64_t)slots * bytes_per_path(f, slots);
+        const uint64_t limit = (limit_mb << 20) / n_pipes;
         if (c * per_pixel > limit)
         {
             c = (limit / per_pixel) & ~4095ull;
@@ -829,6 +858,10 @@ int alloc_path_buffers(rt_frame* f, uint32_t slots)
     if (paths > 0xFFFFFFF0ull) return fail(ctx, "samples in flight x tile pixels exceeds the 32-bit path-id range");
     f->log_stride = (uint32_t)paths;
     f->log_entries = 2u * (f->max_bounces + 1u);
+    const bool compact = log_is_compact(f, f->slots);
+    f->log_inline = compact ? RT_LOG_INLINE : f->log_entries;
+    f->log_ovf_blocks = compact ? (uint32_t)(paths / f->log_pool_div > 64u ? paths / f->log_pool_div : 64u) : 0u;
+    const size_t log_elems = (size_t)f->log_inline * paths + (size_t)(f->log_entries - f->log_inline) * f->log_ovf_blocks;
     size_t q = (size_t)(paths + 4) * sizeof(float4);
     bool ok = true;
     for (uint32_t i = 0; i < f->n_pipes && ok; ++i)
@@ -839,7 +872,8 @@ int alloc_path_buffers(rt_frame* f, uint32_t slots)
             (void**)&pp.sh_d4[0], (void**)&pp.sh_o4[1], (void**)&pp.sh_d4[1]};
         for (void** p : ptrs) ok = ok && hipMalloc(p, q) == hipSuccess;
         for (uint32_t*& p : pp.sh_aux) ok = ok && hipMalloc((void**)&p, (size_t)(paths + 4) * sizeof(uint32_t)) == hipSuccess;
-        ok = ok && hipMalloc((void**)&pp.rlog, (size_t)f->log_entries * paths * 3u * sizeof(float) + 16u) == hipSuccess;
+        ok = ok && hipMalloc((void**)&pp.rlog, log_elems * 3u * sizeof(float) + 16u) == hipSuccess;
+        if (compact) ok = ok && hipMalloc((void**)&pp.ovf_slot, (size_t)(paths + 4) * sizeof(uint32_t)) == hipSuccess;
         ok = ok && hipMalloc((void**)&pp.cnt, (size_t)paths * sizeof(uint32_t)) == hipSuccess;
         ok = ok && hipMalloc((void**)&pp.slow_list, (size_t)(paths + 64) * sizeof(uint32_t)) == hipSuccess;
         ok = ok && hipMalloc((void**)&pp.sh_slow_list, (size_t)(paths + 64) * sizeof(uint32_t)) == hipSuccess;
@@ -944,7 +978,8 @@ int ensure_slots(rt_frame* f, uint32_t want)
 {
     uint32_t cap = slot_cap(f);
     if (want > cap) want = cap;
-    if (want <= f->slots && 2u * (f->max_bounces + 1u) <= f->log_entries && f->chunk_pixels == chunk_for(f, f->slots))
+    if (want <= f->slots && 2u * (f->max_bounces + 1u) <= f->log_entries && f->chunk_pixels == chunk_for(f, f->slots) &&
+        (f->log_ovf_blocks != 0u) == log_is_compact(f, f->slots))
         return RT_OK;
     if (flush_log(f) != RT_OK || join_pipes(f) != RT_OK) return RT_ERROR;
     HIPCHK(f->ctx, hipStreamSynchronize(f->ctx->stream));
@@ -959,6 +994,15 @@ int ensure_slots(rt_frame* f, uint32_t want)
         f->slots_limit = n;
     }
     return RT_OK;
+}
+
+// the radiance log of the current pipe as the kernels see it
+DLog dlog(const rt_frame* f)
+{
+    DLog L;
+    L.rlog = f->p->rlog; L.cnt = f->p->cnt; L.ovf_slot = f->log_ovf_blocks ? f->p->ovf_slot : nullptr;
+    L.stride = f->log_stride; L.inline_entries = f->log_inline; L.ovf_blocks = f->log_ovf_blocks;
+    return L;
 }
 
 // The stage API and the per-frame features (AOVs, denoiser) trace ONE sample of the WHOLE tile.  The buffers may have
@@ -982,8 +1026,8 @@ int flush_log(rt_frame* f)
         return fail(ctx, "radiance requested between rt_shade and rt_intersect_shadow (direct samples still tentative)");
     if (wait_shadow(f, 0) != RT_OK || wait_shadow(f, 1) != RT_OK) return RT_ERROR;   // their verdicts are in the log
     uint32_t blocks = (f->p->chunk_count + 255u) / 256u;
-    hipLaunchKernelGGL(k_flush, dim3(blocks), dim3(256), 0, f->p->stream, f->radiance + f->p->chunk_base, (const float*)f->p->rlog, f->p->cnt,
-        f->p->chunk_count, f->p->cur_slots, f->log_stride, f->chunk_pixels);
+    hipLaunchKernelGGL(k_flush, dim3(blocks), dim3(256), 0, f->p->stream, f->radiance + f->p->chunk_base, dlog(f),
+        f->p->chunk_count, f->p->cur_slots, f->chunk_pixels);
     if (hipGetLastError() != hipSuccess) return fail(ctx, "k_flush launch failed");
     f->p->cur_slots = 0;
     return RT_OK;
@@ -1113,6 +1157,8 @@ int rt_set_option(rt_frame* f, int option, uint32_t value)
             if (flush_log(f) != RT_OK) return RT_ERROR;
             HIPCHK(f->ctx, hipStreamSynchronize(f->ctx->stream));
             f->max_bounces = value;
+            f->log_full_forced = false;               // another path length: the compact layout gets another chance
+            f->fallback_limit_mb = 0;
             return ensure_slots(f, 1);                // log rows / payload split follow max_bounces
         }
         return RT_OK;
@@ -1192,6 +1238,15 @@ int rt_set_option(rt_frame* f, int option, uint32_t value)
         return RT_OK;
     case RT_OPT_DEBUG_ALLOC_LIMIT: f->debug_alloc_limit = value; return RT_OK;
     case RT_OPT_SMALL_LAUNCH_PATHS: f->small_launch_paths = value; return RT_OK;
+    case RT_OPT_COMPACT_LOG:
+    case RT_OPT_DEBUG_LOG_POOL_DIV:
+        if (option == RT_OPT_DEBUG_LOG_POOL_DIV && value == 0) return fail(f->ctx, "rt_set_option: RT_OPT_DEBUG_LOG_POOL_DIV must be >= 1");
+        if (flush_log(f) != RT_OK) return RT_ERROR;
+        HIPCHK(f->ctx, hipStreamSynchronize(f->ctx->stream));
+        if (option == RT_OPT_COMPACT_LOG) f->compact_log_opt = value ? 1u : 0u; else f->log_pool_div = value;
+        f->log_full_forced = false;
+        f->fallback_limit_mb = 0;
+        return alloc_path_buffers(f, f->slots);
     case RT_OPT_TRACE_VARIANT:
         if (!(value == 0 || value == 5 || (value >= 8 && value <= 11))) return fail(f->ctx, "rt_set_option: unknown trace kernel variant (0, 5, 8..11)");
         f->trace_variant = value;
@@ -1259,7 +1314,7 @@ void launch_trace2(rt_frame* f, const float4* o4, const float4* d4, const uint32
     if ((tune & 0xFFu) == 0u) tune |= 1u;
     hipLaunchKernelGGL((k_trace2<SHADOW, STACK>), dim3(blocks), dim3(64), 0, f->tl_stream, ctx->scene.d, o4, d4, aux, count,
         &f->p->counters->head[f->tl_flavour][0], SHADOW ? (float4*)nullptr : f->p->hits,
-        SHADOW ? f->p->rlog : (float*)nullptr, f->log_stride, f->select_form_box, f->tl_spill, tune, (const uint32_t*)nullptr,
+        dlog(f), f->select_form_box, f->tl_spill, tune, (const uint32_t*)nullptr,
         &f->p->counters->stack_spills);
 }
 
@@ -1285,12 +1340,12 @@ void launch_trace_w4(rt_frame* f, const float4* o4, const float4* d4, const uint
     unsigned long long* const no_timeline = nullptr;
     if (!SHADOW && STACK == 12 && f->timeline)          // tools/launch_timeline.py: the instrumented instance
         hipLaunchKernelGGL((k_trace_w4<false, 12, true>), dim3(blocks), dim3(64), 0, f->tl_stream, ctx->scene.d, o4, d4, aux, count,
-            &f->p->counters->head[s][0], f->p->hits, (float*)nullptr, f->log_stride, f->tl_spill, tune, f->tl_slow_list,
+            &f->p->counters->head[s][0], f->p->hits, dlog(f), f->tl_spill, tune, f->tl_slow_list,
             &f->p->counters->slow_count[s], &f->p->counters->stack_spills, &f->p->counters->tl_start[f->timeline_bounce & 63u],
             f->timeline_bounce & 63u, chunk_below);
     else
         hipLaunchKernelGGL((k_trace_w4<SHADOW, STACK, false>), dim3(blocks), dim3(64), 0, f->tl_stream, ctx->scene.d, o4, d4, aux, count,
-            &f->p->counters->head[s][0], SHADOW ? (float4*)nullptr : f->p->hits, SHADOW ? f->p->rlog : (float*)nullptr, f->log_stride,
+            &f->p->counters->head[s][0], SHADOW ? (float4*)nullptr : f->p->hits, dlog(f),
             f->tl_spill, tune, f->tl_slow_list, &f->p->counters->slow_count[s], &f->p->counters->stack_spills, no_timeline, 0u, chunk_below);
     // The follow-up over the (normally empty) slow list: waves with a two-entry LDS stack (the rest of the stack
     // lives in the spill area) -- 1 KiB of LDS and a few registers, so it finds room beside the resident waves of the
@@ -1303,7 +1358,7 @@ void launch_trace_w4(rt_frame* f, const float4* o4, const float4* d4, const uint
     uint32_t blocks2 = ((uint32_t)ctx->prop.multiProcessorCount * 4u + 7u) & ~7u;
     hipLaunchKernelGGL((k_trace2<SHADOW, 2>), dim3(blocks2), dim3(64), 0, f->tl_stream, ctx->scene.d, o4, d4, aux,
         (const uint32_t*)&f->p->counters->slow_count[s], &f->p->counters->slow_head[s][0], SHADOW ? (float4*)nullptr : f->p->hits,
-        SHADOW ? f->p->rlog : (float*)nullptr, f->log_stride, f->select_form_box, f->tl_spill, tune & 0xFFFFu, (const uint32_t*)f->tl_slow_list,
+        dlog(f), f->select_form_box, f->tl_spill, tune & 0xFFFFu, (const uint32_t*)f->tl_slow_list,
         &f->p->counters->stack_spills);
 }
 
@@ -1334,7 +1389,7 @@ void launch_trace(rt_frame* f, const float4* o4, const float4* d4, const uint32_
     case 0:
         hipLaunchKernelGGL(k_trace_v1<SHADOW>, dim3(f->trace_waves_per_cu ? (((uint32_t)ctx->prop.multiProcessorCount *
             (f->trace_waves_per_cu < 13u ? f->trace_waves_per_cu : 13u) + 7u) & ~7u) : f->trace_blocks), dim3(64), 0, f->tl_stream, ctx->scene.d, o4, d4,
-            aux, count, SHADOW ? (float4*)nullptr : f->p->hits, SHADOW ? f->p->rlog : (float*)nullptr, f->log_stride, f->select_form_box, f->tl_spill);
+            aux, count, SHADOW ? (float4*)nullptr : f->p->hits, dlog(f), f->select_form_box, f->tl_spill);
         break;
     case 8:
         if (!SHADOW && ctx->scene.d.entry_ref < 4000000u) launch_trace2<SHADOW, 10>(f, o4, d4, aux, count);
@@ -1447,12 +1502,12 @@ int rt_shade(rt_frame* f, uint32_t bounce)              // ShadeMissedRays + Sha
     a.in_o4 = f->p->o4[in]; a.in_d4 = f->p->d4[in]; a.in_thr = f->p->thr[in]; a.hits = f->p->hits;
     a.out_o4 = f->p->o4[out]; a.out_d4 = f->p->d4[out]; a.out_thr = f->p->thr[out];
     a.sh_o4 = f->p->sh_o4[bounce & 1u]; a.sh_d4 = f->p->sh_d4[bounce & 1u]; a.sh_aux = f->p->sh_aux[bounce & 1u];
-    a.rlog = f->p->rlog; a.cnt = f->p->cnt; a.counters = f->p->counters;
+    a.log = dlog(f); a.counters = f->p->counters;
     a.bn_sobol = ctx->blue_noise; a.bn_scramble = ctx->blue_noise ? ctx->blue_noise + 65536 : nullptr;
     a.bn_rank = ctx->blue_noise ? ctx->blue_noise + 65536 + 131072 : nullptr;
     a.bounce = bounce; a.sample_base = f->sample_count;
     a.emit_outgoing = (f->drop_last && bounce >= f->max_bounces) ? 0u : 1u;
-    a.n_local = f->chunk_pixels ? f->chunk_pixels : 1; a.log_stride = f->log_stride;
+    a.n_local = f->chunk_pixels ? f->chunk_pixels : 1;
     a.pix_base = f->p->chunk_base;
     a.count_in_ray = f->fused ? 1u : 0u;
     a.partition = f->shade_partition;
@@ -1467,7 +1522,8 @@ int rt_shade(rt_frame* f, uint32_t bounce)              // ShadeMissedRays + Sha
     const bool blue = f->sampler == 1;   // kernel variants are AOT (the reference rebuilds with -D..., :267-285)
     const bool nee = ctx->scene.d.emissive_nee != 0;     // opt-in extension (rt_scene_desc::flags)
 #define RT_LAUNCH_SHADE(FURNACE, BLUE, NEE) \
-    hipLaunchKernelGGL((k_shade<FURNACE, BLUE, NEE>), dim3(blocks), dim3(RT_SHADE_BLOCK), 0, f->p->stream, ctx->scene.d, f->tile, a)
+    do { if (f->log_ovf_blocks) hipLaunchKernelGGL((k_shade<FURNACE, BLUE, NEE, true>), dim3(blocks), dim3(RT_SHADE_BLOCK), 0, f->p->stream, ctx->scene.d, f->tile, a); \
+         else hipLaunchKernelGGL((k_shade<FURNACE, BLUE, NEE, false>), dim3(blocks), dim3(RT_SHADE_BLOCK), 0, f->p->stream, ctx->scene.d, f->tile, a); } while (0)
     if (nee)
     {
         if (f->white_furnace && blue) RT_LAUNCH_SHADE(true, true, true);
@@ -1596,7 +1652,7 @@ int rt_integrate(rt_frame* f, uint32_t n_samples)       // n x Integrator::Integ
         // chunks' launches overlap each other's tails.  A chunk always lands on the same pipe: its log replays
         // (k_flush) stay in sample order.
         uint32_t c = 0;
-        for (uint32_t base = 0; base < (f->n_local ? f->n_local : 1u) && rc == RT_OK; base += f->chunk_pixels, ++c)
+        for (uint32_t base = 0; base < (f->n_local ? f->n_local : 1u) && rc == RT_OK; ++c)
         {
             f->p = &f->ps[c % f->n_pipes];
             if (generate_rays(f, batch, base, c >= f->n_pipes) != RT_OK) { rc = RT_ERROR; break; }
@@ -1614,7 +1670,43 @@ int rt_integrate(rt_frame* f, uint32_t n_samples)       // n x Integrator::Integ
                 else if (rt_intersect_shadow(f, bounce) != RT_OK) rc = RT_ERROR;
                 else if (!f->side_active && bounce < f->max_bounces && rt_intersect(f, bounce + 1u) != RT_OK) rc = RT_ERROR;
             }
+            // Compact log layout: did this sequence run the overflow pool dry?  (The one host synchronisation of a batch; the
+            // full layout has none.)  If so nothing of it has reached the radiance yet: drop it, switch the frame to the full
+            // layout within the same memory, and run the SAME chunk again -- the sum stays exact.
+            if (rc == RT_OK && f->log_ovf_blocks != 0u)
+            {
+                uint32_t dry = 0;
+                if (wait_shadow(f, 0) != RT_OK || wait_shadow(f, 1) != RT_OK) { rc = RT_ERROR; break; }
+                if (hipMemcpyAsync(&dry, &f->p->counters->log_ovf_flag, sizeof(dry), hipMemcpyDeviceToHost, f->p->stream) != hipSuccess ||
+                    hipStreamSynchronize(f->p->stream) != hipSuccess)
+                {
+                    rc = fail(ctx, "rt_integrate: reading the log-pool flag failed");
+                    break;
+                }
+                if (dry)
+                {
+                    const uint64_t held = (uint64_t)f->log_stride * bytes_per_path(f, f->slots) * f->n_pipes;
+                    if (hipMemsetAsync(f->p->counters->queue, 0, sizeof(f->p->counters->queue) + sizeof(f->p->counters->shadow), f->p->stream) != hipSuccess ||
+                        hipMemsetAsync(&f->p->counters->log_ovf_flag, 0, sizeof(uint32_t), f->p->stream) != hipSuccess ||
+                        hipStreamSynchronize(f->p->stream) != hipSuccess)
+                    {
+                        rc = fail(ctx, "rt_integrate: discarding a batch failed");
+                        break;
+                    }
+                    f->p->cur_slots = 0;
+                    f->p->shadow_pending = false;
+                    f->log_full_forced = true;
+                    // the full layout takes more bytes per path: it may use what the library would have given it in the first
+                    // place (half of the HBM), and beyond that runs the same batch size in more chunks
+                    f->fallback_limit_mb = 144u << 10;
+                    (void)held;
+                    ++f->log_fallbacks;
+                    if (alloc_path_buffers(f, f->slots) != RT_OK) { rc = RT_ERROR; break; }     // cnt starts from zero again
+                    continue;                                                                   // the same `base`, the new chunk size
+                }
+            }
             if (rc == RT_OK && flush_log(f) != RT_OK) rc = RT_ERROR;          // radiance_buffer_ += this chunk's contributions
+            base += f->chunk_pixels;
         }
         f->p = &f->ps[0];
         if (rc != RT_OK) break;
@@ -1694,7 +1786,9 @@ int rt_frame_get_stats(rt_frame* f, rt_stats* out)
     out->samples = f->sample_count;
     out->samples_in_flight = f->slots;
     out->samples_in_flight_limit = f->slots_limit;
-    out->path_state_bytes = (uint64_t)f->log_stride * bytes_per_path(f->max_bounces) * f->n_pipes;
+    out->path_state_bytes = (uint64_t)f->log_stride * bytes_per_path(f, f->log_ovf_blocks ? f->slots : 1u) * f->n_pipes;
+    out->log_inline_entries = f->log_ovf_blocks ? f->log_inline : 0u;
+    out->log_fallbacks = f->log_fallbacks;
     out->chunk_pixels = f->chunk_pixels;
     out->pipelines = f->n_pipes;
     return RT_OK;
@@ -1769,7 +1863,11 @@ int rt_frame_debug_read_queue(rt_frame* f, int which, uint32_t bounce, rt_ray* r
             uint32_t entry = 0;
             HIPCHK(ctx, hipMemcpy(&entry, f->p->sh_aux[bounce & 1u] + i, 4, hipMemcpyDeviceToHost));
             p[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            HIPCHK(ctx, hipMemcpy(&p[i], f->p->rlog + 3u * ((size_t)entry * f->log_stride + id), 12, hipMemcpyDeviceToHost));
+            uint32_t oblk = 0;
+            if (entry >= f->log_inline) HIPCHK(ctx, hipMemcpy(&oblk, f->p->ovf_slot + id, 4, hipMemcpyDeviceToHost));
+            const size_t at = entry < f->log_inline ? (size_t)entry * f->log_stride + id
+                                                    : (size_t)f->log_inline * f->log_stride + (size_t)(entry - f->log_inline) * f->log_ovf_blocks + oblk;
+            HIPCHK(ctx, hipMemcpy(&p[i], f->p->rlog + 3u * at, 12, hipMemcpyDeviceToHost));
         }
         if (rays)
         {

@@ -358,15 +358,36 @@ RT_DEV void block_append2_keyed(bool want_a, uint32_t key_a, bool want_b, uint32
     idx_b = s_base[1] + s_cnt[1][key_b % KEYS][wave] + rank_b;
 }
 
+// Bump allocation for the threads of a block that `want` one item each: ONE atomic per block (see block_append2).
+RT_DEV uint32_t block_alloc(bool want, uint32_t* counter)
+{
+    __shared__ uint32_t s_n[RT_SHADE_BLOCK / 64];
+    __shared__ uint32_t s_b;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const unsigned long long m = __ballot(want);
+    if (lane == 0) s_n[wave] = (uint32_t)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+        uint32_t total = 0;
+        for (uint32_t w = 0; w < RT_SHADE_BLOCK / 64; ++w) total += s_n[w];
+        s_b = total ? atomicAdd(counter, total) : 0u;
+    }
+    __syncthreads();
+    uint32_t at = s_b;
+    for (uint32_t w = 0; w < wave; ++w) at += s_n[w];
+    return at + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+}
+
 struct ShadeArgs
 {
     const float4* in_o4; const float4* in_d4; const float4* in_thr; const float4* hits;
     float4* out_o4; float4* out_d4; float4* out_thr;
     float4* sh_o4; float4* sh_d4; uint32_t* sh_aux;   // sh_aux[i]: radiance-log entry of shadow ray i's deferred direct sample
-    float* rlog; uint32_t* cnt;       // radiance log, 3 floats per entry (kernels_common.h header)
+    DLog log;                         // radiance log (kernels_common.h): entries, counts, overflow blocks
     const uint8_t* bn_sobol; const uint8_t* bn_scramble; const uint8_t* bn_rank;   // SamplerType::kBlueNoise tables
     DCounters* counters;
-    uint32_t bounce, sample_base, emit_outgoing, n_local, log_stride;   // n_local: pixels per chunk (path id = slot * n_local + pixel in chunk)
+    uint32_t bounce, sample_base, emit_outgoing, n_local;   // n_local: pixels per chunk (path id = slot * n_local + pixel in chunk)
     uint32_t pix_base;                                                  // first local pixel of the chunk
     uint32_t partition;      // RT_OPT_SHADE_PARTITION: bit 0 = hits first / misses last inside every block, bit 1 = each block's
                              // outgoing and shadow rays grouped by direction octant
@@ -394,8 +415,10 @@ RT_DEV float SampleBlueNoise(const ShadeArgs& a, uint32_t px, uint32_t py, uint3
 
 // NEE: the scene asked for next-event estimation over the emissive triangles too (RT_SCENE_EMISSIVE_NEE, an opt-in
 // extension: DESIGN.md 7b); the other instances are the reference's estimator.
-template <bool FURNACE, bool BLUE, bool NEE = false>
-__global__ __launch_bounds__(RT_SHADE_BLOCK) void k_shade(DScene sc, DTile tile, ShadeArgs a)
+// COMPACT: the radiance log is in its compact layout (DLog; RT_OPT_COMPACT_LOG): separate instances, so that the default ones
+// carry none of its code.
+template <bool FURNACE, bool BLUE, bool NEE = false, bool COMPACT = false>
+__global__ __launch_bounds__(RT_SHADE_BLOCK) __attribute__((amdgpu_waves_per_eu(NEE ? 5 : 6))) void k_shade(DScene sc, DTile tile, ShadeArgs a)
 {
     const uint32_t count = a.counters->queue[a.bounce];
     // the closest-hit trace of this bounce has completed (stream order): rewind the
@@ -444,6 +467,7 @@ __global__ __launch_bounds__(RT_SHADE_BLOCK) void k_shade(DScene sc, DTile tile,
     const bool active = i < count;
 
     bool want_shadow = false, want_next = false;
+    bool no_block = false;             // compact log: this path has no overflow block yet
     uint32_t next_flag = 0;            // NEE: bit 31 of the outgoing ray's log-count word = "this event was a delta one"
     float4 sh_o = make_float4(0, 0, 0, 0), sh_d = sh_o, nx_o = sh_o, nx_d = sh_o, nx_t = sh_o;
     uint32_t sh_entry = 0;
@@ -458,7 +482,18 @@ __global__ __launch_bounds__(RT_SHADE_BLOCK) void k_shade(DScene sc, DTile tile,
         uint32_t pix = id - slot * a.n_local;
         uint32_t sample_idx = a.sample_base + slot;
         float4 thr4 = a.in_thr[i];
-        uint32_t nlog = a.count_in_ray ? (__float_as_uint(thr4.w) & 0x7FFFFFFFu) : a.cnt[id];   // contributions logged so far
+        uint32_t nlog = a.count_in_ray ? (__float_as_uint(thr4.w) & 0x7FFFFFFFu) : a.log.cnt[id];   // contributions logged so far
+        // compact log: this bounce may write entries nlog and nlog + 1; those beyond the inline rows go to the path's overflow
+        // block, which the previous bounce allocated (below) whenever that could happen
+        uint32_t oblk = RT_EMPTY_REF;
+        if (COMPACT && nlog + 1u >= a.log.inline_entries) oblk = a.log.ovf_slot[id];
+        no_block = oblk == RT_EMPTY_REF;
+        // one entry of this path's log (the full layout: row nlog, column id)
+        auto put = [&](float x, float y, float z)
+        {
+            if (COMPACT) log_put(a.log, nlog, id, oblk, x, y, z);
+            else log_store(a.log.rlog, (size_t)nlog * a.log.stride + id, x, y, z);
+        };
         // NEE: bit 31 of the same word = the path's last scattering event was a delta one (set by the previous bounce)
         const bool prev_delta = NEE && (__float_as_uint(thr4.w) >> 31) != 0u;
         f3 hit_throughput = F3(thr4.x, thr4.y, thr4.z);
@@ -468,7 +503,7 @@ __global__ __launch_bounds__(RT_SHADE_BLOCK) void k_shade(DScene sc, DTile tile,
             // Miss, miss.cl:65-76
             f3 sky = FURNACE ? F3s(0.5f) : SampleSky(sc, F3(rd.x, rd.y, rd.z));
             f3 add = sky * hit_throughput;
-            log_store(a.rlog, (size_t)nlog * a.log_stride + id, add.x, add.y, add.z);   // radiance[pix] += ...
+            put(add.x, add.y, add.z);   // radiance[pix] += ...
             ++nlog;
         }
         else
@@ -503,7 +538,7 @@ __global__ __launch_bounds__(RT_SHADE_BLOCK) void k_shade(DScene sc, DTile tile,
                 if (material.emission.x * 1.0f + material.emission.y * 1.0f + material.emission.z * 1.0f > 0.0f)
                 {
                     f3 e = hit_throughput * material.emission;
-                    log_store(a.rlog, (size_t)nlog * a.log_stride + id, e.x, e.y, e.z);         // radiance[pix] += ...
+                    put(e.x, e.y, e.z);         // radiance[pix] += ...
                     ++nlog;
                 }
             }
@@ -590,7 +625,7 @@ __global__ __launch_bounds__(RT_SHADE_BLOCK) void k_shade(DScene sc, DTile tile,
                 {
                     // deferred direct sample (direct_light_samples_buffer_): logged now, retracted
                     // by the shadow trace if the light turns out to be occluded
-                    log_store(a.rlog, (size_t)nlog * a.log_stride + id, lsamp.x, lsamp.y, lsamp.z);
+                    put(lsamp.x, lsamp.y, lsamp.z);
                     ++nlog;
                 }
             }
@@ -620,7 +655,20 @@ __global__ __launch_bounds__(RT_SHADE_BLOCK) void k_shade(DScene sc, DTile tile,
             }
         }
         nx_t.w = __uint_as_float(nlog | next_flag);
-        if (!a.count_in_ray || ((!want_next || a.final_bounce) && nlog != 0u)) a.cnt[id] = nlog;   // the path's final count is what k_flush replays
+        if (!a.count_in_ray || ((!want_next || a.final_bounce) && nlog != 0u)) a.log.cnt[id] = nlog;   // the path's final count is what k_flush replays
+    }
+    // Compact log: the next bounce writes entries nlog, nlog + 1 -- a path that goes on and could cross the inline rows gets its
+    // overflow block now (nx_t.w = its entries so far, nx_d.w = its id).  Entries so far <= 2 (bounce + 1): before that reaches
+    // inline_entries - 1 no path of the launch can want one.
+    if (COMPACT && 2u * (a.bounce + 1u) + 1u >= a.log.inline_entries && !a.final_bounce)
+    {
+        const bool want_block = want_next && no_block && (__float_as_uint(nx_t.w) & 0x7FFFFFFFu) + 1u >= a.log.inline_entries;
+        const uint32_t blk = block_alloc(want_block, &a.counters->log_ovf_next);
+        if (want_block)
+        {
+            if (blk >= a.log.ovf_blocks) a.counters->log_ovf_flag = 1u;      // pool dry: the host repeats this batch in the full layout
+            a.log.ovf_slot[__float_as_uint(nx_d.w)] = blk < a.log.ovf_blocks ? blk : RT_EMPTY_REF;
+        }
     }
 
     uint32_t sidx, nidx;
@@ -650,8 +698,7 @@ __global__ __launch_bounds__(RT_SHADE_BLOCK) void k_shade(DScene sc, DTile tile,
 // Replays the radiance log: for every pixel, sample slot by sample slot, contribution
 // by contribution -- the exact order in which the reference's kernels executed
 // `radiance[pixel] += ...` (miss.cl:75, hit_surface.cl:110, accumulate_direct_samples.cl:51).
-__global__ __launch_bounds__(256) void k_flush(float4* __restrict__ radiance, const float* __restrict__ rlog,
-    uint32_t* __restrict__ cnt, uint32_t n_pixels, uint32_t n_slots, uint32_t log_stride, uint32_t id_stride)
+__global__ __launch_bounds__(256) void k_flush(float4* __restrict__ radiance, DLog log, uint32_t n_pixels, uint32_t n_slots, uint32_t id_stride)
 {
     // radiance: already offset to the chunk's first pixel; id_stride: pixels per chunk as allocated
     uint32_t p = blockIdx.x * 256u + threadIdx.x;
@@ -660,13 +707,14 @@ __global__ __launch_bounds__(256) void k_flush(float4* __restrict__ radiance, co
     for (uint32_t slot = 0; slot < n_slots; ++slot)
     {
         uint32_t id = slot * id_stride + p;
-        uint32_t c = cnt[id];
+        uint32_t c = log.cnt[id];
+        const uint32_t oblk = c > log.inline_entries ? log.ovf_slot[id] : 0u;       // compact layout: the path's overflow block
         for (uint32_t k = 0; k < c; ++k)
         {
-            const rt_rgb v = *reinterpret_cast<const rt_rgb*>(rlog + 3 * ((size_t)k * log_stride + id));
+            const rt_rgb v = *reinterpret_cast<const rt_rgb*>(log.rlog + 3 * log_index(log, k, id, oblk));
             r.x += v.x; r.y += v.y; r.z += v.z;
         }
-        if (c) cnt[id] = 0;
+        if (c) log.cnt[id] = 0;
     }
     radiance[p] = r;
 }

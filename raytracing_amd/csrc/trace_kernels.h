@@ -68,10 +68,18 @@ RT_DEV bool box_test_fast(float bminx, float bminy, float bminz, float bmaxx, fl
     return tmax >= tmin;
 }
 
+// AccumulateDirectSamples fused (accumulate_direct_samples.cl:46-52): k_shade logged the direct sample tentatively; an occluded
+// shadow ray zeroes that entry (adding +0.0 is the identity).  Entries beyond the inline rows live in the path's overflow block.
+RT_DEV void log_retract(const DLog& L, uint32_t entry, uint32_t id)
+{
+    const uint32_t slot = entry < L.inline_entries ? 0u : L.ovf_slot[id];
+    log_put(L, entry, id, slot, 0.0f, 0.0f, 0.0f);
+}
+
 template <bool SHADOW>
 __global__ __launch_bounds__(64) void k_trace_v1(DScene sc, const float4* __restrict__ o4, const float4* __restrict__ d4,
     const uint32_t* __restrict__ aux /* shadow rays: log entry of the deferred direct sample */, const uint32_t* __restrict__ count_ptr,
-    float4* __restrict__ hits, float* __restrict__ rlog, uint32_t log_stride, uint32_t /*force_sign_bits: v1 always uses box_test*/,
+    float4* __restrict__ hits, DLog log, uint32_t /*force_sign_bits: v1 always uses box_test*/,
     uint2* __restrict__ spill)
 {
     __shared__ uint2 stack[RT_TRACE_STACK_LDS][64];
@@ -210,7 +218,7 @@ __global__ __launch_bounds__(64) void k_trace_v1(DScene sc, const float4* __rest
             // logged the direct sample tentatively; an occluded ray retracts it
             if (occluded)
             {
-                log_store(rlog, (size_t)aux[i] * log_stride + __float_as_uint(rd.w), 0.0f, 0.0f, 0.0f);
+                log_retract(log, aux[i], __float_as_uint(rd.w));
             }
         }
         else
@@ -315,7 +323,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(STACK <= 10 
     const uint32_t* __restrict__ aux /* shadow rays: log entry of the deferred direct sample */, const uint32_t* __restrict__ count_ptr,
     uint32_t* __restrict__ heads,
     float4* __restrict__ hits,
-    float* __restrict__ rlog, uint32_t log_stride, uint32_t force_sign_bits, uint2* __restrict__ spill, uint32_t tune,
+    DLog log, uint32_t force_sign_bits, uint2* __restrict__ spill, uint32_t tune,
     const uint32_t* __restrict__ index_list /* nullptr: the whole queue; else queue entries to trace, *count_ptr of them */,
     uint32_t* __restrict__ spill_count /* statistics: pushes beyond the LDS stack */)
 {
@@ -385,7 +393,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(STACK <= 10 
                 {
                     // AccumulateDirectSamples fused: an occluded ray retracts its tentative direct sample
                     if (hit_prim != RT_INVALID_ID)
-                        log_store(rlog, (size_t)log_entry * log_stride + payload, 0.0f, 0.0f, 0.0f);
+                        log_retract(log, log_entry, payload);
                 }
                 else
                     hits[ray_i] = make_float4(hit_u, hit_v, __uint_as_float(hit_prim), t_max);
@@ -635,7 +643,7 @@ template <bool SHADOW, int STACK, bool TIMELINE = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_trace_w4(DScene sc, const float4* __restrict__ o4, const float4* __restrict__ d4,
     const uint32_t* __restrict__ aux /* shadow rays: log entry of the deferred direct sample */, const uint32_t* __restrict__ count_ptr,
     uint32_t* __restrict__ heads,
-    float4* __restrict__ hits, float* __restrict__ rlog, uint32_t log_stride, uint2* __restrict__ spill, uint32_t tune,
+    float4* __restrict__ hits, DLog log, uint2* __restrict__ spill, uint32_t tune,
     uint32_t* __restrict__ slow_list, uint32_t* __restrict__ slow_count, uint32_t* __restrict__ stat_counts /* [0] spills, [1] slow rays */,
     unsigned long long* __restrict__ timeline /* TIMELINE: DCounters::tl_start + timeline_slot (rt_frame_debug_timeline) */,
     uint32_t timeline_slot, uint32_t chunk_below /* launches of fewer rays run in chunk mode (below) */)
@@ -756,7 +764,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                 if (SHADOW)
                 {
                     if (hit_prim != RT_INVALID_ID)
-                        log_store(rlog, (size_t)log_entry * log_stride + payload, 0.0f, 0.0f, 0.0f);
+                        log_retract(log, log_entry, payload);
                 }
                 else
                     hits[ray_i] = make_float4(hit_u, hit_v, __uint_as_float(hit_prim), t_max);

@@ -136,6 +136,11 @@ def test_random_scene_matches_oracle_bit_for_bit(ctx, env_map, seed):
     fr.set_option(capi.OPT_TRACE_VARIANT, int(os.environ.get("RT_FUZZ_VARIANT", variant)))   # a campaign on one kernel
     fr.set_option(capi.OPT_TRACE_TUNE, int(rng.choice([0, (2 << 24) | (1 << 23), 24 | (4 << 8), 56 | (32 << 8) | (7 << 24), 64 | (1 << 8) | (1 << 23)])))
     fr.set_option(capi.OPT_SHADE_PARTITION, int(seed & 3))            # bit 0: hits first, bit 1: outputs grouped by octant
+    if seed % 3 == 0:                                                  # the compact radiance log, with a pool small enough to run dry now and then
+        fr.set_option(capi.OPT_COMPACT_LOG, 1)
+        fr.set_option(capi.OPT_DEBUG_LOG_POOL_DIV, 8 if seed % 2 else 64)
+        if seed % 9 == 0:
+            fr.set_option(capi.OPT_SAMPLES_IN_FLIGHT, 8)
     fr.set_option(capi.OPT_SMALL_LAUNCH_PATHS, int(rng.choice([3000000, 0, 4000000000, 700])))   # chunk mode below this many rays per launch: default, never, always, for the last bounces
     fr.integrate(spp)
     orc = _oracle.Oracle(w, h, sc, furnace=furnace)

@@ -181,6 +181,43 @@ def test_bounded_path_state_renders_the_tile_in_chunks_bit_identically(variant, 
     base.close(); ctx.close()
 
 
+def test_compact_radiance_log_and_its_fallback_are_bit_identical():
+    """RT_OPT_COMPACT_LOG = 1 (round 3, opt-in): batches of >= 8 samples in flight keep six inline log entries per path plus bump-allocated
+    overflow blocks for an eighth of the paths instead of the 2 (B + 1) worst case.  Same bits and counters as the full layout
+    and as the oracle, with a third less path state; a pool that runs dry (here: shrunk to 64 blocks by the test hook) makes
+    rt_integrate discard the batch and repeat it in the full layout -- once, the frame then stays there -- still the same bits."""
+    w, h, b, spp = 96, 64, 8, 24
+    sc = _finish(host.Scene(arrays=S.city_block(40_000)))     # an open scene: a few per cent of its paths outgrow six entries
+    cam = T.default_camera(w, h)
+    orc = _oracle.Oracle(w, h, sc)
+    orc.set_camera(cam); orc.set_max_bounces(b); orc.integrate(spp)
+    want = orc.radiance()[..., :3]
+    ctx = capi.Context(0)
+    ctx.upload_scene(sc)
+    results = {}
+    for name, opts in (("full", {}), ("compact", {capi.OPT_COMPACT_LOG: 1}),
+                       ("fallback", {capi.OPT_COMPACT_LOG: 1, capi.OPT_DEBUG_LOG_POOL_DIV: 1000000000}),
+                       ("compact_chunked", {capi.OPT_COMPACT_LOG: 1, capi.OPT_PATH_STATE_LIMIT_MB: 12})):
+        fr = capi.Frame(ctx, w, h)
+        fr.set_camera(cam); fr.set_max_bounces(b)
+        fr.set_option(capi.OPT_SAMPLES_IN_FLIGHT, 8)
+        for k, v in opts.items():
+            fr.set_option(k, v)
+        fr.integrate(spp)                                    # three batches of 8
+        st = fr.stats()
+        got = fr.radiance()[..., :3]
+        assert np.array_equal(got, want, equal_nan=True), name
+        assert (st.closest_rays, st.shadow_rays) == orc.ray_totals(), name
+        results[name] = (st.log_inline_entries, st.log_fallbacks, st.path_state_bytes, st.chunk_pixels)
+        fr.close()
+    assert results["full"][:2] == (0, 0) and results["compact"][:2] == (6, 0), results
+    assert results["compact"][2] < 0.75 * results["full"][2]                   # 290 vs 412 bytes per path at 8 bounces
+    assert results["fallback"][:2] == (0, 1)                                  # one batch repeated, then the full layout for good
+    assert results["fallback"][2] == results["full"][2] and results["fallback"][3] == w * h     # ... as if it had started there
+    assert results["compact_chunked"][0] == 6 and results["compact_chunked"][3] < w * h
+    ctx.close()
+
+
 def test_stage_api_after_a_chunked_batch_renders_the_whole_tile(golden_scenes):
     """with RT_OPT_PATH_STATE_LIMIT_MB set, an rt_integrate with several samples in flight leaves the
     per-path buffers cut into chunks of pixels; a stage-API sample afterwards (the reference's Integrate() through the hooks:

@@ -291,6 +291,7 @@ def test_samples_in_flight_and_kernel_variants_are_bit_invariant(ctx, golden_sce
     # launches this small would all run in chunk mode (RT_OPT_SMALL_LAUNCH_PATHS, 3 M rays): keep the REFILLING form under test
     # for the explicit variants (610 / 710 force chunk mode through the tune word), the automatic choice (5) takes both
     fr.set_option(capi.OPT_SMALL_LAUNCH_PATHS, 3000000 if variant == 5 and slots != 3 else 0)
+    fr.set_option(capi.OPT_COMPACT_LOG, 1 if slots == 8 and variant in (5, 9, 10, 610) else 0)     # the compact log layout takes batches of 8
     fr.integrate(spp)
     assert fr.sample_count() == spp
     assert np.array_equal(fr.radiance(), base.radiance(), equal_nan=True)
