@@ -190,7 +190,9 @@ enum rt_option
                                        of 412 bytes per path at 8 bounces, 314 instead of 604 at 16 -- at ~1.5 % of the throughput
                                        (k_shade's allocation step).  A batch that runs the pool dry (long-lived paths: a closed,
                                        lit room) is discarded and repeated in the full layout, which the frame then keeps
-                                       (rt_stats.log_fallbacks).  0 (default): the full layout.  Results are bit-identical. */
+                                       (rt_stats.log_fallbacks).  0: always the full layout.  2 (default): compact exactly when the
+                                       caller bounds the path state (RT_OPT_PATH_STATE_LIMIT_MB != 0: larger chunks, +2.9 % at
+                                       32 GiB), full otherwise.  Results are bit-identical for every value. */
     , RT_OPT_DEBUG_LOG_POOL_DIV = 20 /* test hook: the overflow pool holds paths / value blocks (default 8) */
     , RT_OPT_TRACE_TUNE = 12       /* k_trace2 (variants 8, 9) loop thresholds: value & 255 = lanes that must hold an
                                        interior node for a wave to stay in the node loop, value >> 8 & 255 = lanes that

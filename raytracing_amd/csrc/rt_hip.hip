@@ -115,7 +115,8 @@ struct rt_frame
     // Radiance-log layout (DLog): compact = log_inline rows for every path + a pool of log_ovf_blocks overflow blocks;
     // full = every row for every path (log_inline == log_entries, no pool).
     uint32_t log_inline = 0, log_ovf_blocks = 0;
-    uint32_t compact_log_opt = 0;  // RT_OPT_COMPACT_LOG: 1 = the compact layout for batches of >= 8 samples in flight, 0 (default) = always the full layout
+    uint32_t compact_log_opt = 2;  // RT_OPT_COMPACT_LOG: 0 = always the full layout, 1 = compact for batches of >= 8 samples in flight,
+                                   // 2 (default) = compact when the caller bounds the path state (RT_OPT_PATH_STATE_LIMIT_MB)
     uint32_t log_pool_div = 8;     // the pool holds paths / log_pool_div blocks (RT_OPT_DEBUG_LOG_POOL_DIV: test hook)
     bool log_full_forced = false;  // a batch ran its pool dry: this frame stays on the full layout (until bounces / scene change)
     uint32_t fallback_limit_mb = 0;   // ... within the bytes the compact layout held (chunk_plan)
@@ -765,7 +766,8 @@ void free_path_buffers(rt_frame* f)
 // enough for the pool's statistics, and one pipe: the pool-dry check synchronises the host with the chunk's stream.)
 bool log_is_compact(const rt_frame* f, uint32_t slots)
 {
-    return f->compact_log_opt && !f->log_full_forced && slots >= 8u && f->pipelines == 1u && 2u * (f->max_bounces + 1u) >= RT_LOG_INLINE + 4u;
+    const bool asked = f->compact_log_opt == 1u || (f->compact_log_opt == 2u && f->state_limit_mb != 0u);
+    return asked && !f->log_full_forced && slots >= 8u && f->pipelines == 1u && 2u * (f->max_bounces + 1u) >= RT_LOG_INLINE + 4u;
 }
 
 // ray queues o4, d4, thr (x2), hits, shadow queue o4, d4 (x2) = 11 x 16; sh_aux (x2), cnt, two slow lists = 5 x 4;
@@ -1243,7 +1245,8 @@ int rt_set_option(rt_frame* f, int option, uint32_t value)
         if (option == RT_OPT_DEBUG_LOG_POOL_DIV && value == 0) return fail(f->ctx, "rt_set_option: RT_OPT_DEBUG_LOG_POOL_DIV must be >= 1");
         if (flush_log(f) != RT_OK) return RT_ERROR;
         HIPCHK(f->ctx, hipStreamSynchronize(f->ctx->stream));
-        if (option == RT_OPT_COMPACT_LOG) f->compact_log_opt = value ? 1u : 0u; else f->log_pool_div = value;
+        if (option == RT_OPT_COMPACT_LOG && value > 2u) return fail(f->ctx, "rt_set_option: RT_OPT_COMPACT_LOG is 0, 1 or 2");
+        if (option == RT_OPT_COMPACT_LOG) f->compact_log_opt = value; else f->log_pool_div = value;
         f->log_full_forced = false;
         f->fallback_limit_mb = 0;
         return alloc_path_buffers(f, f->slots);

@@ -195,9 +195,9 @@ def test_compact_radiance_log_and_its_fallback_are_bit_identical():
     ctx = capi.Context(0)
     ctx.upload_scene(sc)
     results = {}
-    for name, opts in (("full", {}), ("compact", {capi.OPT_COMPACT_LOG: 1}),
+    for name, opts in (("full", {capi.OPT_COMPACT_LOG: 0}), ("compact", {capi.OPT_COMPACT_LOG: 1}),
                        ("fallback", {capi.OPT_COMPACT_LOG: 1, capi.OPT_DEBUG_LOG_POOL_DIV: 1000000000}),
-                       ("compact_chunked", {capi.OPT_COMPACT_LOG: 1, capi.OPT_PATH_STATE_LIMIT_MB: 12})):
+                       ("compact_chunked", {capi.OPT_PATH_STATE_LIMIT_MB: 12})):     # the default: compact when the caller bounds the state
         fr = capi.Frame(ctx, w, h)
         fr.set_camera(cam); fr.set_max_bounces(b)
         fr.set_option(capi.OPT_SAMPLES_IN_FLIGHT, 8)
