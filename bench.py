@@ -131,7 +131,7 @@ def cpu_legs(args, scene_arrays, cam_small, small_w, small_h, cam_full):
     try:
         from tests.test_wide_bvh import wide_of
         from raytracing_amd import types as T
-        wide, wide_entry = wide_of(scene_arrays["nodes"])
+        wide, wide_entry = wide_of(scene_arrays["nodes"], getattr(args, "wide_collapse", 1))
     except Exception:
         wide = None
     n_small = small_w * small_h
@@ -475,6 +475,8 @@ def main():
     ap.add_argument("--trace-waves", type=int, default=0, help="RT_OPT_TRACE_WAVES_PER_CU (0 = as many as fit)")
     ap.add_argument("--trace-variant", type=int, default=None, help="RT_OPT_TRACE_VARIANT (default: the library's automatic choice)")
     ap.add_argument("--small-launch-paths", type=int, default=None, help="RT_OPT_SMALL_LAUNCH_PATHS (library default 3000000)")
+    ap.add_argument("--wide-collapse", type=int, default=1, choices=(1, 2),
+                    help="RT_CTX_OPT_WIDE_BVH: 1 = SAH-optimal frontier per wide record (library default), 2 = two BVH2 levels per record (A/B)")
     ap.add_argument("--compact-log", type=int, default=None, help="RT_OPT_COMPACT_LOG (library default 1)")
     ap.add_argument("--per-frame-frames", type=int, default=48, help="frames of the per_frame leg (the reference's call pattern, "
                     "one Integrate() per frame); 0 = skip it")
@@ -540,6 +542,8 @@ def main():
     render = host.Render(args.width, args.height, scene, device=local_rank, tile_rank=rank, tile_count=world,
                          band_height=args.band_height)      # builds the BVH (or adopts the cached one), finalises, uploads
     t_setup = time.time() - t0
+    if args.wide_collapse != 1:
+        render.set_wide_bvh(args.wide_collapse)               # A/B: uploads the scene again with the other collapse
     if world > 1 and not args.no_scene_cache:
         dist.barrier()
         if rank == 0:

@@ -55,8 +55,9 @@ enum rt_ctx_option
 {
     RT_CTX_OPT_TREELET_NODES = 0   /* BVH record layout: interior nodes per contiguous breadth-first cluster
                                       (default 7; 1 = the reference's depth-first order).  Layout only. */
-    , RT_CTX_OPT_WIDE_BVH = 1      /* 1 (default): also build the 4-wide quantized tree of k_trace_w4 (two BVH2 levels
-                                      per 64-byte record); 0: BVH2 records only */
+    , RT_CTX_OPT_WIDE_BVH = 1      /* 1 (default): also build the 4-wide quantized tree of k_trace_w4, each 64-byte record
+                                      folding the SAH-optimal frontier of up to four BVH2 nodes; 2: two BVH2 levels per
+                                      record (round 2's rule); 0: BVH2 records only */
 };
 int rt_ctx_set_option(rt_ctx* ctx, int option, uint32_t value);
 /* The blue-noise sampler tables (src/utils/blue_noise_sampler.hpp: sobol_256spp_256d[256*256],
@@ -340,10 +341,12 @@ int rt_frame_debug_read_hits(rt_frame* frame, rt_hit* hits, uint32_t count);
 int rt_frame_debug_timeline(rt_frame* frame, int arm, unsigned long long* out);
 
 /* The 4-wide quantized tree rt_scene_upload builds for k_trace_w4 from the reference's LinearBVHNode[]
- * (host only, no device needed): 64-byte records {origin.xyz, meta, lo[3], hi[3], ref[4], pad[2]} --
- * see build_wide_bvh in rt_hip.hip.  records may be NULL (count query).  Fails when the tree does not qualify. */
-int rt_debug_wide_bvh(const rt_bvh_node* nodes, uint32_t num_nodes, void* records, uint32_t capacity, uint32_t* num_records,
-    uint32_t* entry_ref);
+ * (host only, no device needed): 64-byte records {origin.xyz, meta, lo[3], hi[3], ref[4], order (64 bits)} --
+ * see build_wide_bvh in rt_hip.hip.  collapse: 1 = the SAH-optimal frontier per record (what rt_scene_upload uses),
+ * 2 = two BVH2 levels per record (RT_CTX_OPT_WIDE_BVH's values).  records may be NULL (count query); roots (optional, with
+ * records) receives the index of the BVH2 node each record folds.  Fails when the tree does not qualify. */
+int rt_debug_wide_bvh(const rt_bvh_node* nodes, uint32_t num_nodes, int collapse, void* records, uint32_t* roots, uint32_t capacity,
+    uint32_t* num_records, uint32_t* entry_ref);
 
 /* ---- kernel self-test hooks (known-answer tests of the device math):
  * evaluates fn over n inputs on the device.  fn: 0 sin, 1 cos, 2 tan, 3 pow(a,b),

@@ -1363,11 +1363,13 @@ static int wide_trace_impl(void* h, const void* wide_records, uint32_t n_wide, u
                 }
                 if (!shadow || ordered_shadow)
                 {
-                    const uint32_t sw = n->order >> (3u * (sign_bits & 7u));
-                    const int sw0 = (sw & 1u) != 0u, pa = (sw & 2u) != 0u, pb = (sw & 4u) != 0u;
+                    /* four conditional exchanges bring the occupied slots into the reference's visit order for this direction
+                     * octant, whatever the shape of the BVH2 subtree the record folds (build_wide_bvh stores the slots where
+                     * that is possible and tabulates the settings) */
+                    const uint32_t sw = n->order >> (4u * (sign_bits & 7u));
                     uint32_t tr; float te;
 #define ORC_SWAP(c, i, j) if (c) { tr = r[i]; r[i] = r[j]; r[j] = tr; te = e[i]; e[i] = e[j]; e[j] = te; }
-                    ORC_SWAP(pa, 0, 1) ORC_SWAP(pb, 2, 3) ORC_SWAP(sw0, 0, 2) ORC_SWAP(sw0, 1, 3)
+                    ORC_SWAP(sw & 1u, 0, 1) ORC_SWAP(sw & 2u, 2, 3) ORC_SWAP(sw & 4u, 0, 2) ORC_SWAP(sw & 8u, 1, 3)
 #undef ORC_SWAP
                 }
                 /* plain form: positions 3..1 wait on the stack, position 0 is visited next if it passed.  direct form

@@ -109,7 +109,7 @@ def load():
         "rt_frame_debug_read_queue": (i32, [vp, i32, u32, vp, vp, vp, u32, C.POINTER(u32)]),
         "rt_frame_debug_read_hits": (i32, [vp, vp, u32]),
         "rt_debug_eval": (i32, [vp, i32, vp, vp, vp, u32]),
-        "rt_debug_wide_bvh": (i32, [vp, u32, vp, u32, C.POINTER(u32), C.POINTER(u32)]),
+        "rt_debug_wide_bvh": (i32, [vp, u32, i32, vp, vp, u32, C.POINTER(u32), C.POINTER(u32)]),
         "rt_frame_debug_timeline": (i32, [vp, i32, vp]),
         "rt_group_create": (i32, [i32, C.POINTER(i32), C.POINTER(vp)]), "rt_group_unique_id": (i32, [vp, sz]),
         "rt_group_join": (i32, [i32, i32, vp, i32, C.POINTER(vp)]), "rt_group_size": (i32, [vp]),
@@ -158,6 +158,10 @@ class Context:
 
     def set_treelet_nodes(self, n):
         _check(self.lib, self.handle, self.lib.rt_ctx_set_option(self.handle, 0, n))
+
+    def set_wide_bvh(self, mode):
+        """RT_CTX_OPT_WIDE_BVH: 1 = SAH-optimal frontier per wide record (default), 2 = two BVH2 levels per record, 0 = none"""
+        _check(self.lib, self.handle, self.lib.rt_ctx_set_option(self.handle, 1, mode))
 
     def finish(self):
         _check(self.lib, self.handle, self.lib.rt_finish(self.handle))

@@ -10,6 +10,8 @@
 #include <algorithm>
 #include <string>
 #include <vector>
+#include <map>
+#include <array>
 #include "rt_hip.h"
 #include "kernels.h"
 
@@ -302,7 +304,7 @@ int rt_ctx_set_option(rt_ctx* ctx, int option, uint32_t value)
         ctx->treelet_nodes = value;
         return RT_OK;
     }
-    if (option == RT_CTX_OPT_WIDE_BVH) { ctx->build_wide = value ? 1u : 0u; return RT_OK; }
+    if (option == RT_CTX_OPT_WIDE_BVH) { ctx->build_wide = value > 2u ? 1u : value; return RT_OK; }
     return fail(ctx, "rt_ctx_set_option: unknown option");
 }
 
@@ -386,18 +388,31 @@ namespace
 //    (bvh.hpp:73, checked below), so a leaf's box passing implies that all its ancestors' boxes
 //    pass: the reference tests the triangles of a leaf iff that leaf's own box test passes at that
 //    point of the traversal -- which is exactly what the kernel evaluates.
-// Record: q0 = (origin.xyz, meta)   meta = ex | ey << 8 | ez << 16 | axes << 24 (biased exponents of
-//                                          the cell sizes; axes = axis0 | axisA << 2 | axisB << 4)
+// Record: q0 = (origin.xyz, meta)   meta = ex | ey << 8 | ez << 16 | occupied slots << 24 (biased exponents of the cell sizes)
 //         q1 = (lo.x, lo.y, lo.z, hi.x)    one byte per slot in every dword
 //         q2 = (hi.y, hi.z, ref0, ref1)    ref = wide node index | RT_LEAF_BIT + first triangle | RT_EMPTY_REF
 //         q3 = (ref2, ref3, order, -)       order: for each of the 8 direction-sign octants o (bit a set = direction negative
-//                                          along axis a) three bits at 3 * o: swap the two halves | swap inside half 0 |
-//                                          swap inside half 1 (a half with an empty slot is never swapped inside)
+//                                          along axis a) four bits at 4 * o = the conditional exchanges of slots (0,1), (2,3),
+//                                          (0,2), (1,3), made in that order, that bring the occupied slots into the
+//                                          reference's visit order (see `arrange` in build_wide_bvh)
 struct WideNode { float ox, oy, oz; uint32_t meta; uint32_t lo[3]; uint32_t hi[3]; uint32_t ref[4]; uint32_t order; uint32_t pad; };
 static_assert(sizeof(WideNode) == 64, "wide node record");
 
+// Which BVH2 nodes become the four slots of a record (`collapse`):
+//  RT_WIDE_TWO_LEVELS  the grandchildren (a child that is a leaf fills one slot): round 2's rule;
+//  RT_WIDE_SAH         the frontier that minimises the expected number of wide-node visits: a record rooted at BVH2 node n
+//                      is visited when a ray passes n's slot box (probability ~ area(n)), the interior nodes between n and
+//                      its slots are never tested at all, leaves are what they are -- so the cost of a collapse is the sum of
+//                      area(root) over its records, minimised exactly by a small dynamic programme over (node, slots to
+//                      spend) (Ylitie, Karras, Laine 2017, section 4.1, for 4 slots and with the reference's leaves kept).
+//                      The frontier of a record is then any of the five binary-tree shapes with four leaves (or fewer slots).
+// The visit order of the slots stays the reference's for every shape: depth-first over the folded BVH2 nodes, the second
+// child first where the ray is negative along that node's split axis (trace_bvh.cl:181-190).
+enum { RT_WIDE_TWO_LEVELS = 0, RT_WIDE_SAH = 1 };
+
 // false: the tree does not qualify (non-finite or non-nested bounds, child order): k_trace2 is used
-bool build_wide_bvh(const rt_bvh_node* nodes, uint32_t nn, std::vector<WideNode>& out, uint32_t& entry_ref)
+bool build_wide_bvh(const rt_bvh_node* nodes, uint32_t nn, int collapse, std::vector<WideNode>& out, uint32_t& entry_ref,
+    std::vector<uint32_t>* roots = nullptr /* the BVH2 node each record folds (tests) */)
 {
     auto is_leaf = [&](uint32_t i) { return (nodes[i].num_primitives_axis >> 16) != 0; };
     out.clear();
@@ -418,20 +433,142 @@ bool build_wide_bvh(const rt_bvh_node* nodes, uint32_t nn, std::vector<WideNode>
                 return false;
         }
     }
+    // the collapse: split[n][k] = slots given to n's first child when n is folded with k slots to spend (k = 2..4, the second
+    // child gets the rest); a child with i >= 2 slots is folded too iff open[c] has bit i set, otherwise it is one slot
+    std::vector<uint8_t> split((size_t)nn * 5u, 0), open(nn, 0);
+    if (collapse == RT_WIDE_SAH)
+    {
+        // T[n] = cost of the best collapse of n's subtree with a record rooted at n; F[n][k] = the same without the root's own
+        // visit, n's subtree covered by k slots.  Children have larger indices than their parent (pass 0): one backward sweep.
+        std::vector<double> T(nn, 0.0), F((size_t)nn * 5u, 0.0);
+        auto G = [&](uint32_t c, uint32_t i) { return is_leaf(c) ? 0.0 : (i >= 2u ? std::min(T[c], F[(size_t)c * 5u + i]) : T[c]); };
+        for (uint32_t n = nn; n-- > 0;)
+        {
+            if (is_leaf(n)) continue;
+            const uint32_t l = n + 1, r = nodes[n].offset;
+            for (uint32_t k = 2; k <= 4; ++k)
+            {
+                double best = 0.0; uint32_t at = 0;
+                for (uint32_t i = 1; i < k; ++i)
+                {
+                    const double c = G(l, i) + G(r, k - i);
+                    if (at == 0 || c < best) { best = c; at = i; }
+                }
+                F[(size_t)n * 5u + k] = best;
+                split[(size_t)n * 5u + k] = (uint8_t)at;
+            }
+            const rt_bvh_node& b = nodes[n];
+            const double dx = (double)b.bounds_max.x - b.bounds_min.x, dy = (double)b.bounds_max.y - b.bounds_min.y,
+                         dz = (double)b.bounds_max.z - b.bounds_min.z;
+            T[n] = (dx * dy + dy * dz + dz * dx) + F[(size_t)n * 5u + 4u];
+            for (uint32_t i = 2; i <= 4; ++i)
+                if (F[(size_t)n * 5u + i] < T[n]) open[n] |= (uint8_t)(1u << i);
+        }
+    }
+    else
+    {
+        for (uint32_t n = 0; n < nn; ++n)
+        {
+            if (is_leaf(n)) continue;
+            split[(size_t)n * 5u + 4u] = 2; split[(size_t)n * 5u + 3u] = 2; split[(size_t)n * 5u + 2u] = 1;
+            open[n] = 1u << 2;                                              // a child with two slots to spend shows its children
+        }
+    }
+    // One record: its slots in the BVH2's depth-first order and, per direction-sign octant, the positions in visit order.
+    struct Fold { uint32_t slot[4]; uint32_t n_slots; uint8_t visit[8][4]; };
+    struct Local
+    {
+        const rt_bvh_node* nodes; const std::vector<uint8_t>& split; const std::vector<uint8_t>& open;
+        bool leaf(uint32_t i) const { return (nodes[i].num_primitives_axis >> 16) != 0; }
+        // n folded with k slots to spend: appends n's slots to `f` and returns, per octant, their positions in visit order
+        void fold(uint32_t n, uint32_t k, Fold& f, uint8_t (&visit)[8][4], uint32_t& count) const
+        {
+            const uint32_t c[2] = {n + 1, nodes[n].offset};
+            const uint32_t give[2] = {split[(size_t)n * 5u + k], k - split[(size_t)n * 5u + k]};
+            uint8_t part[2][8][4];
+            uint32_t len[2] = {0, 0};
+            for (int i = 0; i < 2; ++i)
+            {
+                if (!leaf(c[i]) && give[i] >= 2u && ((open[c[i]] >> give[i]) & 1u)) fold(c[i], give[i], f, part[i], len[i]);
+                else
+                {
+                    for (int o = 0; o < 8; ++o) part[i][o][0] = (uint8_t)f.n_slots;
+                    f.slot[f.n_slots++] = c[i];
+                    len[i] = 1;
+                }
+            }
+            const uint32_t axis = nodes[n].num_primitives_axis & 0xFFFFu;
+            for (uint32_t o = 0; o < 8; ++o)
+            {
+                // trace_bvh.cl:181-190: the near child is the second one when the ray is negative along the split axis
+                const int first = (int)((o >> axis) & 1u);
+                uint32_t at = 0;
+                for (uint32_t j = 0; j < len[first]; ++j) visit[o][at++] = part[first][o][j];
+                for (uint32_t j = 0; j < len[first ^ 1]; ++j) visit[o][at++] = part[first ^ 1][o][j];
+            }
+            count = len[0] + len[1];
+        }
+    } local{nodes, split, open};
+    auto fold_of = [&](uint32_t n, Fold& f)
+    {
+        f.n_slots = 0;
+        for (int k = 0; k < 4; ++k) f.slot[k] = RT_EMPTY_REF;
+        uint32_t count = 0;
+        local.fold(n, 4u, f, f.visit, count);
+    };
+    // Where the slots of a record are stored.  The kernel brings them into visit order with FOUR conditional exchanges --
+    // (0,1), (2,3), (0,2), (1,3), one table bit each per direction octant: two instructions more than the three decisions
+    // round 2 tabulated for the one shape it folded -- and that network does not realise every permutation; but for each of
+    // the five shapes (and their smaller relatives) there is a placement of the slots for which it realises all the orders
+    // the shape can ask for (exhaustive search: tests/test_wide_bvh.py).  Found here by trying the 24 placements, once per
+    // distinct (slot count, eight visit orders); depth-first order is tried first, which is what the balanced shape keeps.
+    struct Arrangement { uint8_t place[4]; uint32_t order; };
+    std::map<std::array<uint8_t, 33>, Arrangement> arrangements;
+    auto arrange = [&](const Fold& f) -> const Arrangement*
+    {
+        std::array<uint8_t, 33> key{};
+        key[0] = (uint8_t)f.n_slots;
+        for (int o = 0; o < 8; ++o)
+            for (uint32_t j = 0; j < f.n_slots; ++j) key[1 + 4 * o + j] = f.visit[o][j];
+        auto it = arrangements.find(key);
+        if (it != arrangements.end()) return &it->second;
+        uint8_t place[4] = {0, 1, 2, 3};                                   // place[j] = slot position of the j-th node in depth-first order
+        do
+        {
+            uint8_t node_at[4] = {255, 255, 255, 255};
+            for (uint32_t j = 0; j < f.n_slots; ++j) node_at[place[j]] = (uint8_t)j;
+            Arrangement a{};
+            bool all = true;
+            for (uint32_t o = 0; o < 8 && all; ++o)
+            {
+                bool found = false;
+                for (uint32_t bits = 0; bits < 16u && !found; ++bits)
+                {
+                    uint8_t pos[4] = {0, 1, 2, 3};
+                    static const int ex[4][2] = {{0, 1}, {2, 3}, {0, 2}, {1, 3}};
+                    for (int c = 0; c < 4; ++c)
+                        if ((bits >> c) & 1u) std::swap(pos[ex[c][0]], pos[ex[c][1]]);
+                    // the occupied slots, in the order the kernel will look at them, must be the reference's visit order
+                    uint32_t at = 0;
+                    bool same = true;
+                    for (int k = 0; k < 4 && same; ++k)
+                        if (node_at[pos[k]] != 255) same = node_at[pos[k]] == f.visit[o][at++];
+                    if (same) { a.order |= bits << (4u * o); found = true; }
+                }
+                all = found;
+            }
+            if (all)
+            {
+                memcpy(a.place, place, 4);
+                return &arrangements.emplace(key, a).first->second;
+            }
+        } while (std::next_permutation(place, place + 4));
+        return nullptr;
+    };
     // pass 1: wide nodes in depth-first order (slot 0's subtree first), like the reference's flattening
     std::vector<uint32_t> wide_of(nn, RT_EMPTY_REF), todo, order, depth_of;
     todo.push_back(0);
     depth_of.push_back(1);
-    auto slots_of = [&](uint32_t n, uint32_t slot[4], uint32_t axes[3])
-    {
-        const uint32_t c[2] = {n + 1, nodes[n].offset};
-        axes[0] = nodes[n].num_primitives_axis & 0xFFFFu;
-        for (int i = 0; i < 2; ++i)
-        {
-            if (is_leaf(c[i])) { slot[2 * i] = c[i]; slot[2 * i + 1] = RT_EMPTY_REF; axes[1 + i] = 0; }
-            else { slot[2 * i] = c[i] + 1; slot[2 * i + 1] = nodes[c[i]].offset; axes[1 + i] = nodes[c[i]].num_primitives_axis & 0xFFFFu; }
-        }
-    };
     while (!todo.empty())
     {
         uint32_t n = todo.back(), depth = depth_of.back();
@@ -442,10 +579,10 @@ bool build_wide_bvh(const rt_bvh_node* nodes, uint32_t nn, std::vector<WideNode>
         if (wide_of[n] != RT_EMPTY_REF || order.size() >= nn) return false;
         wide_of[n] = (uint32_t)order.size();
         order.push_back(n);
-        uint32_t slot[4], axes[3];
-        slots_of(n, slot, axes);
+        Fold f;
+        fold_of(n, f);
         for (int k = 3; k >= 0; --k)
-            if (slot[k] != RT_EMPTY_REF && !is_leaf(slot[k])) { todo.push_back(slot[k]); depth_of.push_back(depth + 1u); }
+            if (f.slot[k] != RT_EMPTY_REF && !is_leaf(f.slot[k])) { todo.push_back(f.slot[k]); depth_of.push_back(depth + 1u); }
     }
     if (order.size() >= (1u << 26)) return false;                          // 32-bit byte offsets in the kernel
     // pass 2: records
@@ -453,8 +590,12 @@ bool build_wide_bvh(const rt_bvh_node* nodes, uint32_t nn, std::vector<WideNode>
     for (size_t w = 0; w < order.size(); ++w)
     {
         const uint32_t n = order[w];
-        uint32_t slot[4], axes[3];
-        slots_of(n, slot, axes);
+        Fold f;
+        fold_of(n, f);
+        const Arrangement* arr = arrange(f);
+        if (!arr) return false;                                            // cannot happen (every shape has an arrangement: tests/test_wide_bvh.py)
+        uint32_t slot[4] = {RT_EMPTY_REF, RT_EMPTY_REF, RT_EMPTY_REF, RT_EMPTY_REF};
+        for (uint32_t j = 0; j < f.n_slots; ++j) slot[arr->place[j]] = f.slot[j];
         WideNode& r = out[w];
         memset(&r, 0, sizeof(r));
         const float nmin[3] = {nodes[n].bounds_min.x, nodes[n].bounds_min.y, nodes[n].bounds_min.z};
@@ -481,16 +622,8 @@ bool build_wide_bvh(const rt_bvh_node* nodes, uint32_t nn, std::vector<WideNode>
             exps[a] = e;
         }
         r.ox = origin[0]; r.oy = origin[1]; r.oz = origin[2];
-        r.meta = (uint32_t)(exps[0] + 127) | (uint32_t)(exps[1] + 127) << 8 | (uint32_t)(exps[2] + 127) << 16 |
-                 (axes[0] | axes[1] << 2 | axes[2] << 4) << 24;
-        for (uint32_t o = 0; o < 8; ++o)
-        {
-            // trace_bvh.cl:181-190 at both BVH2 levels: the near child is the second one when the ray is negative along the split axis
-            uint32_t sw0 = (o >> axes[0]) & 1u;
-            uint32_t swa = slot[1] != RT_EMPTY_REF ? (o >> axes[1]) & 1u : 0u;
-            uint32_t swb = slot[3] != RT_EMPTY_REF ? (o >> axes[2]) & 1u : 0u;
-            r.order |= (sw0 | swa << 1 | swb << 2) << (3 * o);
-        }
+        r.meta = (uint32_t)(exps[0] + 127) | (uint32_t)(exps[1] + 127) << 8 | (uint32_t)(exps[2] + 127) << 16 | f.n_slots << 24;
+        r.order = arr->order;
         for (int k = 0; k < 4; ++k)
         {
             if (slot[k] == RT_EMPTY_REF)
@@ -515,6 +648,7 @@ bool build_wide_bvh(const rt_bvh_node* nodes, uint32_t nn, std::vector<WideNode>
         }
     }
     entry_ref = 0;
+    if (roots) *roots = order;
     return true;
 }
 
@@ -700,7 +834,10 @@ int rt_scene_upload(rt_ctx* ctx, const rt_scene_desc* sd)
     // the 4-wide quantized tree for k_trace_w4 (optional: trees that do not qualify keep the BVH2 kernels)
     std::vector<WideNode> wide;
     uint32_t w_entry = 0;
-    const bool have_wide = ctx->build_wide && (uint64_t)nt * 64 <= 0xFFFFFFFFull && build_wide_bvh(sd->nodes, nn, wide, w_entry);
+    // (a SAH collapse can be deeper than the kernel's stack bound allows where two levels at a time are not: try both)
+    const bool have_wide = ctx->build_wide && (uint64_t)nt * 64 <= 0xFFFFFFFFull &&
+        ((ctx->build_wide != 2u && build_wide_bvh(sd->nodes, nn, RT_WIDE_SAH, wide, w_entry)) ||
+         build_wide_bvh(sd->nodes, nn, RT_WIDE_TWO_LEVELS, wide, w_entry));
     if (have_wide) rc |= dev_alloc_copy(ctx, &s.wnodes, wide.data(), wide.size() * sizeof(WideNode));
     if (rc != RT_OK) { free_scene(s); return RT_ERROR; }
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // host staging vectors die here
@@ -1945,13 +2082,14 @@ int rt_frame_debug_timeline(rt_frame* f, int arm, unsigned long long* out /* [64
     return RT_OK;
 }
 
-int rt_debug_wide_bvh(const rt_bvh_node* nodes, uint32_t num_nodes, void* records, uint32_t capacity, uint32_t* num_records,
-    uint32_t* entry_ref)
+int rt_debug_wide_bvh(const rt_bvh_node* nodes, uint32_t num_nodes, int collapse, void* records, uint32_t* roots, uint32_t capacity,
+    uint32_t* num_records, uint32_t* entry_ref)
 {
     if (!nodes || num_nodes == 0 || !num_records || !entry_ref) return fail(nullptr, "rt_debug_wide_bvh: NULL argument");
     std::vector<WideNode> wide;
     uint32_t entry = 0;
-    if (!build_wide_bvh(nodes, num_nodes, wide, entry))
+    std::vector<uint32_t> folded;
+    if (!build_wide_bvh(nodes, num_nodes, collapse == 2 ? RT_WIDE_TWO_LEVELS : RT_WIDE_SAH, wide, entry, &folded))
         return fail(nullptr, "rt_debug_wide_bvh: the tree does not qualify for the 4-wide layout (bounds not finite / not nested, or too deep)");
     *num_records = (uint32_t)wide.size();
     *entry_ref = entry;
@@ -1959,6 +2097,7 @@ int rt_debug_wide_bvh(const rt_bvh_node* nodes, uint32_t num_nodes, void* record
     {
         if (wide.size() > capacity) return fail(nullptr, "rt_debug_wide_bvh: capacity too small");
         memcpy(records, wide.data(), wide.size() * sizeof(WideNode));
+        if (roots) memcpy(roots, folded.data(), folded.size() * sizeof(uint32_t));
     }
     return RT_OK;
 }

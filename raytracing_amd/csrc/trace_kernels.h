@@ -574,7 +574,7 @@ RT_DEV uint32_t spill_load32(const uint32_t* p)
 // ref and entry distance of the slot visited k-th, e[k] = +inf for a slot that is empty or missed.
 template <bool SHADOW>
 RT_DEV void w4_test_slots(const float4 q0, const float4 q1, const float4 q2, const float4 q3, const f3 org, const f3 inv,
-    const uint32_t sign_bits, const uint32_t octant3, const float t_min, const float t_max, uint32_t (&r)[4], float (&e)[4])
+    const uint32_t sign_bits, const uint32_t octant4, const float t_min, const float t_max, uint32_t (&r)[4], float (&e)[4])
 {
     const float INF = __builtin_inff();
     const uint32_t meta = __float_as_uint(q0.w);
@@ -622,15 +622,16 @@ RT_DEV void w4_test_slots(const float4 q0, const float4 q1, const float4 q2, con
     }
     if (!SHADOW)
     {
-        // the reference's order: near child first at both BVH2 levels (trace_bvh.cl:181-190)
-        // (the three decisions per direction octant are tabulated in the record: build_wide_bvh)
-        const uint32_t sw = __float_as_uint(q3.z) >> octant3;
-        const bool sw0 = (sw & 1u) != 0u, pa = (sw & 2u) != 0u, pb = (sw & 4u) != 0u;
-        uint32_t tr; float te;
-        tr = pa ? r[1] : r[0]; r[1] = pa ? r[0] : r[1]; r[0] = tr;  te = pa ? e[1] : e[0]; e[1] = pa ? e[0] : e[1]; e[0] = te;
-        tr = pb ? r[3] : r[2]; r[3] = pb ? r[2] : r[3]; r[2] = tr;  te = pb ? e[3] : e[2]; e[3] = pb ? e[2] : e[3]; e[2] = te;
-        tr = sw0 ? r[2] : r[0]; r[2] = sw0 ? r[0] : r[2]; r[0] = tr;  te = sw0 ? e[2] : e[0]; e[2] = sw0 ? e[0] : e[2]; e[0] = te;
-        tr = sw0 ? r[3] : r[1]; r[3] = sw0 ? r[1] : r[3]; r[1] = tr;  te = sw0 ? e[3] : e[1]; e[3] = sw0 ? e[1] : e[3]; e[1] = te;
+        // the reference's order: depth-first over the BVH2 nodes this record folds, near child first at each of them
+        // (trace_bvh.cl:181-190).  The folded subtree has any of the five shapes a binary tree with four leaves can have
+        // (build_wide_bvh picks the frontier by SAH); the record stores the slots where these four conditional exchanges
+        // can produce every order its shape asks for, and their settings per direction octant (4 bits each).
+        const uint32_t sw = __float_as_uint(q3.z) >> octant4;
+        uint32_t tr; float te; bool p;
+        p = (sw & 1u) != 0u; tr = p ? r[1] : r[0]; r[1] = p ? r[0] : r[1]; r[0] = tr;  te = p ? e[1] : e[0]; e[1] = p ? e[0] : e[1]; e[0] = te;
+        p = (sw & 2u) != 0u; tr = p ? r[3] : r[2]; r[3] = p ? r[2] : r[3]; r[2] = tr;  te = p ? e[3] : e[2]; e[3] = p ? e[2] : e[3]; e[2] = te;
+        p = (sw & 4u) != 0u; tr = p ? r[2] : r[0]; r[2] = p ? r[0] : r[2]; r[0] = tr;  te = p ? e[2] : e[0]; e[2] = p ? e[0] : e[2]; e[0] = te;
+        p = (sw & 8u) != 0u; tr = p ? r[3] : r[1]; r[3] = p ? r[1] : r[3]; r[1] = tr;  te = p ? e[3] : e[1]; e[3] = p ? e[1] : e[3]; e[1] = te;
     }
 }
 
@@ -704,7 +705,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
     uint32_t chunk_next = blockIdx.x >> 3;         // chunk mode: this wave's next chunk of its XCD's region
     uint32_t ref = RT_IDLE_REF;                    // wide node | RT_LEAF_BIT (| RT_LEAF_CONT_BIT) + triangle | idle
     uint32_t ray_i = RT_INVALID_ID;
-    uint32_t sign_bits = 0, octant3 = 0, hit_prim = RT_INVALID_ID;          // octant3: shift of this ray's entry in a node's order table
+    uint32_t sign_bits = 0, octant4 = 0, hit_prim = RT_INVALID_ID;          // octant4: shift of this ray's entry in a node's order table
     int sp = 0;
     uint32_t n_spills = 0;                                                   // statistics (wave-uniform): lane-steps with entries in the HBM spill area
     f3 org = F3s(0.0f), dir = F3s(0.0f), inv = F3s(0.0f);
@@ -803,7 +804,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                     const float4 q2 = ray_inverse(dir);                      // trace_bvh.cl:125-129
                     inv = F3(q2.x, q2.y, q2.z);
                     sign_bits = __float_as_uint(q2.w) & 0xFFu;
-                    octant3 = 3u * (sign_bits & 7u);
+                    octant4 = 4u * (sign_bits & 7u);
                     hit_prim = RT_INVALID_ID;
                     hit_u = 0.0f; hit_v = 0.0f;
                     sp = 0;
@@ -915,7 +916,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                 const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
                 uint32_t r[4];
                 float e[4];
-                w4_test_slots<SHADOW>(q0, q1, q2, q3, org, inv, sign_bits, octant3, t_min, t_max, r, e);
+                w4_test_slots<SHADOW>(q0, q1, q2, q3, org, inv, sign_bits, octant4, t_min, t_max, r, e);
                 {
                     // the first passing position is visited next, the later ones wait on the stack (deepest first)
                     const bool v0 = e[0] < INF, v1 = e[1] < INF, v2 = e[2] < INF, v3 = e[3] < INF;

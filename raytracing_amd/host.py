@@ -23,6 +23,7 @@ EXPORTS = [
     "rth_render_read_radiance", "rth_render_read_resolved", "rth_render_stats", "rth_render_frame_handle",
     "rth_render_ctx_handle", "rth_render_num_nodes", "rth_render_nodes", "rth_render_set_aov", "rth_render_resolve",
     "rth_render_set_blue_noise_path", "rth_render_reserve_samples", "rth_scene_save_cache", "rth_load_jpeg",
+    "rth_render_upload_gpu_data",
 ]
 
 
@@ -60,7 +61,7 @@ def load():
         "rth_render_local_rows": (u32, [vp]), "rth_render_global_row": (u32, [vp, u32]),
         "rth_render_sample_count": (u32, [vp]), "rth_render_read_radiance": (i32, [vp, vp]),
         "rth_render_read_resolved": (i32, [vp, vp]), "rth_render_stats": (i32, [vp, C.POINTER(rt_stats)]),
-        "rth_render_frame_handle": (vp, [vp]), "rth_render_ctx_handle": (vp, [vp]),
+        "rth_render_frame_handle": (vp, [vp]), "rth_render_ctx_handle": (vp, [vp]), "rth_render_upload_gpu_data": (i32, [vp]),
         "rth_render_num_nodes": (u32, [vp]), "rth_render_nodes": (vp, [vp]),
         "rth_render_set_aov": (i32, [vp, i32]), "rth_render_resolve": (i32, [vp, vp]),
         "rth_render_set_blue_noise_path": (i32, [vp, cp]),
@@ -249,6 +250,14 @@ class Render:
         self._c(self.lib.rth_render_set_sampler(self.handle, int(e)))
     def enable_denoiser(self, e): self._c(self.lib.rth_render_enable_denoiser(self.handle, int(e)))
     def set_aov(self, aov): self._c(self.lib.rth_render_set_aov(self.handle, int(aov)))
+
+    def set_wide_bvh(self, mode):
+        """RT_CTX_OPT_WIDE_BVH (1 = SAH-optimal frontier per wide record, the default; 2 = two BVH2 levels per record; 0 = none),
+        then the scene is uploaded again: A/B runs and tools."""
+        from . import capi
+        if capi.load().rt_ctx_set_option(self.lib.rth_render_ctx_handle(self.handle), 1, mode):
+            raise _err(self.lib)
+        self._c(self.lib.rth_render_upload_gpu_data(self.handle))
 
     def resolve_now(self):
         out = np.zeros((self.local_rows, self.width, 4), np.float32)

@@ -211,5 +211,6 @@ uint32_t rth_render_num_nodes(void* r) { return (uint32_t)((rt::Render*)r)->GetA
 const void* rth_render_nodes(void* r) { return ((rt::Render*)r)->GetAccelerationStructure().GetNodes().data(); }
 void* rth_render_frame_handle(void* r) { return ((rt::Render*)r)->GetIntegrator().GetFrame(); }
 void* rth_render_ctx_handle(void* r) { return ((rt::Render*)r)->GetContext().Get(); }
+int rth_render_upload_gpu_data(void* r) { return guard([&]() { ((rt::Render*)r)->UploadGPUData(); return 0; }, 1); }
 
 } // extern "C"

@@ -24,6 +24,8 @@ public:
     void SetCamera(Camera const& camera);
     HIPPathTraceIntegrator& GetIntegrator() { return *integrator_; }
     HIPContext& GetContext() { return *context_; }
+    // Uploads the scene again (after an rt_ctx_set_option that changes the device-side layout: tools, A/B runs)
+    void UploadGPUData() { integrator_->UploadGPUData(scene_, *acc_structure_); }
     AccelerationStructure const& GetAccelerationStructure() const { return *acc_structure_; }
     std::uint32_t GetWidth() const { return width_; }
     std::uint32_t GetHeight() const { return height_; }

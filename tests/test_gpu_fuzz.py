@@ -126,7 +126,9 @@ def test_random_scene_matches_oracle_bit_for_bit(ctx, env_map, seed):
     spp = int(rng.integers(1, 9))
     furnace = bool(rng.random() < 0.2)
     blue = bool(rng.random() < 0.3)
+    ctx.set_wide_bvh(2 if seed % 4 == 1 else 1)                       # the wide tree's collapse: SAH-optimal (default) / two BVH2 levels per record
     ctx.upload_scene(sc)
+    ctx.set_wide_bvh(1)
     fr = capi.Frame(ctx, w, h)
     fr.set_camera(cam); fr.set_max_bounces(bounces)
     fr.set_option(capi.OPT_WHITE_FURNACE, int(furnace))

@@ -274,7 +274,11 @@ def test_samples_in_flight_and_kernel_variants_are_bit_invariant(ctx, golden_sce
     sc = golden_scenes["coverage"]
     cam = T.default_camera(w, h)
     base = render(ctx, sc, w, h, cam, b, spp, slots=1)
-    ctx.upload_scene(sc)
+    ctx.set_wide_bvh(2 if variant in (11, 310, 510) else 1)           # the wide tree's collapse: two BVH2 levels per record / SAH-optimal (default)
+    try:
+        ctx.upload_scene(sc)
+    finally:
+        ctx.set_wide_bvh(1)
     fr = capi.Frame(ctx, w, h)
     fr.set_camera(cam)
     fr.set_max_bounces(b)

@@ -47,7 +47,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
     dir.x = dir.x == 0.0f ? 0.5f : dir.x; dir.y = dir.y == 0.0f ? 0.5f : dir.y; dir.z = dir.z == 0.0f ? 0.5f : dir.z;
     const f3 inv = F3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
     const uint32_t sign_bits = (inv.x < 0.0f ? 1u : 0u) | (inv.y < 0.0f ? 2u : 0u) | (inv.z < 0.0f ? 4u : 0u);
-    const uint32_t octant3 = 3u * sign_bits;
+    const uint32_t octant4 = 4u * sign_bits;
     const float t_min = 0.0f, INF = __builtin_inff();
     float t_max = 1.0e4f;
     int sp = 0;
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
         }
         uint32_t r[4];
         float e[4];
-        w4_test_slots<SHADOW>(q0, q1, q2, q3, org, inv, sign_bits, octant3, t_min, t_max, r, e);
+        w4_test_slots<SHADOW>(q0, q1, q2, q3, org, inv, sign_bits, octant4, t_min, t_max, r, e);
         // the kernel's direct-visit step: later passing slots to the stack, the first one next, pop when none passes
         const bool v0 = e[0] < INF, v1 = e[1] < INF, v2 = e[2] < INF, v3 = e[3] < INF;
         uint32_t next;
@@ -137,7 +137,7 @@ int main(int argc, char** argv)
             }
         }
         for (int k = 0; k < 4; ++k) r.ref[k] = gen() & (n_all - 1u);
-        r.order = gen() & 0xFFFFFFu;
+        r.order = gen();
         r.pad = 0;
     }
     float4* d_nodes = nullptr;

@@ -16,6 +16,7 @@ ap.add_argument("--triangles", type=int, default=2_800_000)
 ap.add_argument("--width", type=int, default=480)
 ap.add_argument("--height", type=int, default=270)
 ap.add_argument("--bounces", type=int, default=8)
+ap.add_argument("--collapse", type=int, default=1, help="1 = SAH-optimal frontier per record, 2 = two BVH2 levels per record")
 a = ap.parse_args()
 scene = host.Scene(arrays=S.city_block(a.triangles))
 scene.add_directional_light((-0.6, -1.5, 3.5), (15.0, 10.0, 5.0))
@@ -23,7 +24,7 @@ scene.set_env_path(os.path.join(ROOT, "assets", "ibl", "CGSkies_0036_free.hdr"))
 scene.build_bvh(); scene.finalize()
 arrays = scene.arrays()
 t0 = time.time()
-wide, entry = wide_of(arrays["nodes"])
+wide, entry = wide_of(arrays["nodes"], a.collapse)
 print("%d triangles, %d BVH2 nodes, %d wide nodes (%.1f s)" % (len(arrays["triangles"]), len(arrays["nodes"]), len(wide), time.time() - t0))
 w, h, n = a.width, a.height, a.width * a.height
 orc = _oracle.Oracle(w, h, arrays)
