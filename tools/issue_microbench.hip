@@ -69,6 +69,43 @@ VALU_KERNEL(k_mov, ASM8(OP_MOV))
 VALU_KERNEL(k_cnd, ASM8(OP_CND))
 VALU_KERNEL(k_cmpcnd, ASM8(OP_CMPCND))     // 64 instructions per REP4
 VALU_KERNEL(k_and, ASM8(OP_AND))
+// round 3: the opcodes loop C of k_trace_w4 is made of, to see which of its selects / conversions / tests have a cheaper form
+#define OP_BFI(r) "v_bfi_b32 " #r ", %8, " #r ", %9\n"
+#define OP_XOR(r) "v_xor_b32 " #r ", " #r ", %8\n"
+#define OP_BFEI(r) "v_bfe_i32 " #r ", " #r ", 2, 5\n"
+#define OP_BFEU(r) "v_bfe_u32 " #r ", " #r ", 2, 5\n"
+#define OP_CVTUB(r) "v_cvt_f32_ubyte1 " #r ", " #r "\n"
+#define OP_CVTU(r) "v_cvt_f32_u32 " #r ", " #r "\n"
+#define OP_PERM(r) "v_perm_b32 " #r ", " #r ", %8, %9\n"
+#define OP_MAX3(r) "v_max3_f32 " #r ", " #r ", %8, %9\n"
+#define OP_MED3(r) "v_med3_f32 " #r ", " #r ", %8, %9\n"
+#define OP_CMPS(r) "v_cmp_lt_f32 s[20:21], " #r ", %8\n"
+#define OP_CNDS(r) "v_cndmask_b32 " #r ", " #r ", %8, s[22:23]\n"
+#define OP_LSHR(r) "v_lshrrev_b32 " #r ", 3, " #r "\n"
+#define OP_ANDOR(r) "v_and_or_b32 " #r ", " #r ", %8, %9\n"
+#define OP_FMAC(r) "v_fmac_f32 " #r ", %8, %9\n"
+#define ASM8C(OP)                                                                                      \
+    asm volatile(OP(%0) OP(%1) OP(%2) OP(%3) OP(%4) OP(%5) OP(%6) OP(%7)                              \
+                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)     \
+                 : "v"(b), "v"(c) : "s20", "s21");
+#define ASM8M(OP)                                                                                      \
+    asm volatile("s_mov_b32 s22, 0x55555555\n s_mov_b32 s23, 0x55555555\n" OP(%0) OP(%1) OP(%2) OP(%3) OP(%4) OP(%5) OP(%6) OP(%7)  \
+                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)     \
+                 : "v"(b), "v"(c) : "s22", "s23");
+VALU_KERNEL(k_bfi, ASM8(OP_BFI))
+VALU_KERNEL(k_xor, ASM8(OP_XOR))
+VALU_KERNEL(k_bfei, ASM8(OP_BFEI))
+VALU_KERNEL(k_bfeu, ASM8(OP_BFEU))
+VALU_KERNEL(k_cvtub, ASM8(OP_CVTUB))
+VALU_KERNEL(k_cvtu, ASM8(OP_CVTU))
+VALU_KERNEL(k_perm, ASM8(OP_PERM))
+VALU_KERNEL(k_max3, ASM8(OP_MAX3))
+VALU_KERNEL(k_med3, ASM8(OP_MED3))
+VALU_KERNEL(k_cmps, ASM8C(OP_CMPS))
+VALU_KERNEL(k_cnds, ASM8M(OP_CNDS))        // (+ one s_mov per 8)
+VALU_KERNEL(k_lshr, ASM8(OP_LSHR))
+VALU_KERNEL(k_andor, ASM8(OP_ANDOR))
+VALU_KERNEL(k_fmac, ASM8(OP_FMAC))
 
 // packed fp32: two floats per lane per instruction
 __global__ __launch_bounds__(64) void k_pkfma(unsigned iters, float* out, unsigned long long* cyc)
@@ -234,6 +271,11 @@ int main(int argc, char** argv)
             {"v_cndmask_b32", k_cnd, 32, false}, {"v_cmp_lt_f32+v_cndmask_b32", k_cmpcnd, 64, false},
             {"v_and_b32", k_and, 32, false}, {"v_pk_fma_f32", k_pkfma, 32, false}, {"v_fma_f64", k_fma64, 32, false},
             {"v_lshl_add_u64", k_lshladd64, 32, false}, {"s_add_u32", k_salu, 32, true},
+            {"v_bfi_b32", k_bfi, 32, false}, {"v_xor_b32", k_xor, 32, false}, {"v_bfe_i32", k_bfei, 32, false}, {"v_bfe_u32", k_bfeu, 32, false},
+            {"v_cvt_f32_ubyte1", k_cvtub, 32, false}, {"v_cvt_f32_u32", k_cvtu, 32, false}, {"v_perm_b32", k_perm, 32, false},
+            {"v_max3_f32", k_max3, 32, false}, {"v_med3_f32", k_med3, 32, false}, {"v_cmp_lt_f32 -> sgpr pair", k_cmps, 32, false},
+            {"v_cndmask_b32 (sgpr mask)", k_cnds, 32, false}, {"v_lshrrev_b32", k_lshr, 32, false}, {"v_and_or_b32", k_andor, 32, false},
+            {"v_fmac_f32", k_fmac, 32, false},
         };
         for (auto& k : ks)
         {
