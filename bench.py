@@ -662,6 +662,43 @@ def main():
         per_rank = [None] * world
         dist.all_gather_object(per_rank, mine)
     full = gather(True)                                      # untimed: the image for the checks below
+    # N > 1: the gathered frame against the reference's own kernels (untimed, bounded: 2 samples of the full frame on rank 0's
+    # host cores, the same 2 samples by the N tiles, one more gather).  Reported, never fatal: a failure here must not cost
+    # the line its measurement.
+    tiled_parity = None
+    if world > 1 and not args.no_cpu_baseline:
+        n_ref, ref_frame, note = [0], None, None
+        if rank == 0:
+            try:
+                from tests import _ref
+                if _ref.available():
+                    t_ref = time.time()
+                    ri = _ref.RefIntegrator(args.width, args.height, render.scene_arrays(), threads=min(16, os.cpu_count() or 1))
+                    ri.set_camera(cam)
+                    ri.set_max_bounces(args.bounces)
+                    ri.integrate(2)
+                    ref_frame, n_ref = ri.radiance()[..., :3].copy(), [2]
+                    note = "oracle/_ref (the reference's own kernels), 2 spp at %dx%d, %d bounces, %.1f s on rank 0's host" % (
+                        args.width, args.height, args.bounces, time.time() - t_ref)
+                    del ri
+            except Exception as e:                          # noqa: BLE001 -- reported in the line
+                note = "reference leg failed: %r" % (e,)
+        dist.broadcast_object_list(n_ref, src=0)
+        if n_ref[0]:
+            try:
+                assert lib.rt_reset(frame) == 0
+                render.render_samples(n_ref[0])
+                sync()
+                got_full = gather(True)
+                if rank == 0:
+                    got = got_full[..., :3].numpy()
+                    same = (got == ref_frame) | (np.isnan(got) & np.isnan(ref_frame))
+                    tiled_parity = dict(against=note, tiles=world, bit_identical=bool(same.all()), differing_pixels=int((~same.all(-1)).sum()),
+                                        what="the frame gathered from the %d tiles (the same collective as the timed one), same samples" % world)
+            except Exception as e:                          # noqa: BLE001
+                tiled_parity = dict(against=note, tiles=world, error=repr(e))
+        elif rank == 0:
+            tiled_parity = dict(against=note or "oracle/_ref not built on this box", tiles=world, bit_identical=None)
     # One more step, untimed, with every launch on one stream: in the timed region the shadow trace of bounce b runs
     # beside the closest-hit trace of bounce b + 1 (RT_OPT_OVERLAP_SHADOW), so the launch durations there include the
     # sharing; this step gives the kernels' durations alone on the machine (what the rocprofv3 --pmc passes see).
@@ -699,7 +736,7 @@ def main():
         small_w, small_h = 320, 180          # oracle counters + CPU baseline frame
         arrays = render.scene_arrays()
         per_ray, baseline, ref_img, ref_spp, libm_img = cpu_legs(args, arrays, host.default_camera(small_w, small_h), small_w, small_h, cam)
-        parity = None
+        parity = tiled_parity
         if ref_img is not None and world == 1:
             # the SAME samples on the GPU (outside the timed region), compared with the reference kernels' image
             assert lib.rt_reset(frame) == 0

@@ -40,3 +40,24 @@ def test_bench_py_renders_a_scene_file_with_textures(tmp_path):
     assert line["per_frame"]["mrays_per_s"] > 0 and line["per_frame"]["frames"] == 4
     assert line["roofline"]["bound"] == "hbm" and line["roofline"]["live"]["rays_per_launch"] > 0
     assert line["config"]["non_finite_pixels"] <= 0.01 * 480 * 270      # the mirror balls' inf * 0 (material.h:79-81,230), as in the reference
+
+
+def test_bench_py_two_tiles_gather_the_reference_kernels_frame(tmp_path):
+    """bench.py --gpus 2 the way the driver launches it, on the ONE GPU a test box has (--debug-shared-gpu: both ranks on
+    device 0, the gather over gloo instead of RCCL): two processes, interleaved bands, scene built once and loaded from
+    rank 0's cache, one line -- whose `parity` says that the frame gathered from the two tiles is, bit for bit, the frame
+    the reference's own kernels render (the leg bench.py runs at every N > 1)."""
+    from tests import _ref
+    if not _ref.available():
+        pytest.skip("oracle/_ref is not built here")
+    obj = S.shader_balls_obj(str(tmp_path), 2000)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--debug-shared-gpu", "--scene", obj, "--width", "320",
+                        "--height", "200", "--bounces", "5", "--steps", "1", "--warmup", "1", "--samples-per-step", "8"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and line["scaling"] == "strong"
+    assert len(line["ranks"]["render_ms"]) == 2 and sum(line["ranks"]["rows"]) == 200
+    p = line["parity"]
+    assert p["tiles"] == 2 and p["bit_identical"] is True and p["differing_pixels"] == 0, p
+    assert line["cpu_baseline"] is None                                 # timed at N = 1 only
