@@ -11,6 +11,8 @@
 #include <string>
 #include <vector>
 #include <map>
+#include <thread>
+#include <atomic>
 #include <array>
 #include "rt_hip.h"
 #include "kernels.h"
@@ -523,8 +525,8 @@ bool build_wide_bvh(const rt_bvh_node* nodes, uint32_t nn, int collapse, std::ve
     // the shape can ask for (exhaustive search: tests/test_wide_bvh.py).  Found here by trying the 24 placements, once per
     // distinct (slot count, eight visit orders); depth-first order is tried first, which is what the balanced shape keeps.
     struct Arrangement { uint8_t place[4]; uint32_t order; };
-    std::map<std::array<uint8_t, 33>, Arrangement> arrangements;
-    auto arrange = [&](const Fold& f) -> const Arrangement*
+    typedef std::map<std::array<uint8_t, 33>, Arrangement> ArrangementCache;
+    auto arrange = [&](const Fold& f, ArrangementCache& arrangements) -> const Arrangement*
     {
         std::array<uint8_t, 33> key{};
         key[0] = (uint8_t)f.n_slots;
@@ -585,14 +587,14 @@ bool build_wide_bvh(const rt_bvh_node* nodes, uint32_t nn, int collapse, std::ve
             if (f.slot[k] != RT_EMPTY_REF && !is_leaf(f.slot[k])) { todo.push_back(f.slot[k]); depth_of.push_back(depth + 1u); }
     }
     if (order.size() >= (1u << 26)) return false;                          // 32-bit byte offsets in the kernel
-    // pass 2: records
+    // pass 2: records (independent of each other: host threads, each with its own cache of arrangements)
     out.resize(order.size());
-    for (size_t w = 0; w < order.size(); ++w)
+    auto make_record = [&](size_t w, ArrangementCache& cache) -> bool
     {
         const uint32_t n = order[w];
         Fold f;
         fold_of(n, f);
-        const Arrangement* arr = arrange(f);
+        const Arrangement* arr = arrange(f, cache);
         if (!arr) return false;                                            // cannot happen (every shape has an arrangement: tests/test_wide_bvh.py)
         uint32_t slot[4] = {RT_EMPTY_REF, RT_EMPTY_REF, RT_EMPTY_REF, RT_EMPTY_REF};
         for (uint32_t j = 0; j < f.n_slots; ++j) slot[arr->place[j]] = f.slot[j];
@@ -646,6 +648,23 @@ bool build_wide_bvh(const rt_bvh_node* nodes, uint32_t nn, int collapse, std::ve
                 r.hi[a] |= (uint32_t)hi << (8 * k);
             }
         }
+        return true;
+    };
+    {
+        const size_t n_records = order.size();
+        const unsigned n_threads = (unsigned)std::min<size_t>(std::max(1u, std::min(std::thread::hardware_concurrency(), 32u)), n_records / 4096 + 1);
+        std::atomic<bool> ok{true};
+        auto run = [&](size_t w0, size_t w1)
+        {
+            ArrangementCache cache;
+            for (size_t w = w0; w < w1 && ok.load(std::memory_order_relaxed); ++w)
+                if (!make_record(w, cache)) ok.store(false);
+        };
+        std::vector<std::thread> pool;
+        for (unsigned t = 1; t < n_threads; ++t) pool.emplace_back(run, n_records * t / n_threads, n_records * (t + 1) / n_threads);
+        run(0, n_records / n_threads);
+        for (auto& th : pool) th.join();
+        if (!ok) return false;
     }
     entry_ref = 0;
     if (roots) *roots = order;

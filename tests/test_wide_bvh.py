@@ -250,6 +250,7 @@ def test_wide_tree_of_the_cornell_box_and_a_dense_mesh():
     assert 0.4 * n_interior < len(wide) < 0.75 * n_interior       # two BVH2 levels per record
     sah = check(nodes)
     assert n_interior / 3 <= len(sah) < len(wide)                 # at most three interior nodes folded per record
+    assert wide_of(nodes)[0].tobytes() == sah.tobytes()           # (records are made by several host threads: same bytes every time)
 
 
 @pytest.mark.parametrize("seed", range(6))
