@@ -483,6 +483,8 @@ def main():
     ap.add_argument("--per-frame-only", action="store_true", help="run only the per_frame leg and print its object (tuning runs)")
     ap.add_argument("--debug-shared-gpu", action="store_true",
                     help="plumbing test only: all ranks share GPU 0 and gather over gloo (RCCL refuses two ranks per device)")
+    ap.add_argument("--debug-try-rccl", action="store_true", help="with --debug-shared-gpu: ask RCCL for the communicator anyway (it refuses two ranks "
+                    "per device): exercises the agreement that falls back to the gloo gather")
     ap.add_argument("--plumbing-only", action="store_true", help="no GPU: launch, rendezvous, gather and report only")
     ap.add_argument("--no-scene-cache", action="store_true", help="N > 1: every rank builds the scene and the BVH itself")
     args = ap.parse_args()
@@ -509,16 +511,35 @@ def main():
     if args.debug_shared_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    group = None
+    group, rccl_fallback = None, None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # control plane only (group id, barriers, timing reductions): gloo.  The data-path collective is RCCL
         # behind the C-ABI (rt_group_gather_radiance).
         dist.init_process_group("gloo", rank=rank, world_size=world)
-        if not args.debug_shared_gpu:
-            ids = [capi.Group.unique_id() if rank == 0 else None]
+        if not args.debug_shared_gpu or args.debug_try_rccl:
+            # RCCL communicator over the C-ABI.  If it cannot be had on EVERY rank (library missing, init error), all ranks
+            # agree to gather over gloo through host memory instead and the line says so: a run on a node this code has
+            # never seen must not lose its measurement to the transport.
+            try:
+                ids = [capi.Group.unique_id() if rank == 0 else None]
+            except Exception as e:                          # noqa: BLE001
+                ids, rccl_fallback = [None], "rt_group_unique_id: %r" % (e,)
             dist.broadcast_object_list(ids, src=0)
-            group = capi.Group.join(world, rank, ids[0], local_rank)
+            if ids[0] is not None:
+                try:
+                    group = capi.Group.join(world, rank, ids[0], local_rank)
+                except Exception as e:                      # noqa: BLE001
+                    rccl_fallback = "rt_group_join on rank %d: %r" % (rank, e)
+            okay = torch.tensor([1 if group is not None else 0], dtype=torch.int32)
+            dist.all_reduce(okay, op=dist.ReduceOp.MIN)
+            if int(okay.item()) == 0:
+                if group is not None:
+                    group.close()
+                    group = None
+                reasons = [None] * world
+                dist.all_gather_object(reasons, rccl_fallback)
+                rccl_fallback = next((r for r in reasons if r), "another rank could not join")
 
     # ---- setup (untimed): scene, BVH, upload -------------------------------
     t0 = time.time()
@@ -613,7 +634,23 @@ def main():
     # ---- warm-up ------------------------------------------------------------
     render.render_samples(spp_warm) if spp_warm > 0 else None
     if args.warmup > 0:     # the gather path too (first use sets up the RCCL channels)
-        gather(False)
+        if group is not None:
+            try:
+                gather(False)
+                sync()
+                failed = None
+            except Exception as e:                          # noqa: BLE001
+                failed = "rt_group_gather_radiance on rank %d: %r" % (rank, e)
+            okay = torch.tensor([0 if failed else 1], dtype=torch.int32)
+            dist.all_reduce(okay, op=dist.ReduceOp.MIN)
+            if int(okay.item()) == 0:                       # same agreement as at start-up: everybody falls back to gloo
+                reasons = [None] * world
+                dist.all_gather_object(reasons, failed)
+                rccl_fallback = next((r for r in reasons if r), "the gather failed on another rank")
+                group.close()
+                group = None
+        if group is None:
+            gather(False)
     sync()
     # the timed region starts from a reset accumulation (sample indices 0..K-1, counters at 0)
     assert lib.rt_reset(frame) == 0
@@ -774,7 +811,8 @@ def main():
             gather_info = dict(transport="none (single tile, device copy)", ms=round(float(tmax[2].item()) * 1e3, 3), nranks=1)
         else:
             rccl_counts = sorted({r["rccl"][0] for r in per_rank if r["rccl"]})
-            gather_info = dict(transport="gloo over host memory (--debug-shared-gpu)" if group is None else
+            gather_info = dict(transport=("gloo over host memory (--debug-shared-gpu)" if rccl_fallback is None else
+                                          "gloo over host memory -- RCCL FALLBACK: %s" % rccl_fallback) if group is None else
                                "RCCL ncclGather over xGMI (rt_group_gather_radiance)", nranks=world,
                                rccl_nranks=(rccl_counts[0] if len(rccl_counts) == 1 else rccl_counts) if rccl_counts else None,   # ncclCommCount on every rank
                                rccl_user_ranks=[r["rccl"][1] for r in per_rank] if rccl_counts else None,

@@ -51,13 +51,16 @@ def test_bench_py_two_tiles_gather_the_reference_kernels_frame(tmp_path):
     if not _ref.available():
         pytest.skip("oracle/_ref is not built here")
     obj = S.shader_balls_obj(str(tmp_path), 2000)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--debug-shared-gpu", "--scene", obj, "--width", "320",
-                        "--height", "200", "--bounces", "5", "--steps", "1", "--warmup", "1", "--samples-per-step", "8"],
-                       cwd=ROOT, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stderr[-2000:]
-    line = json.loads(r.stdout.strip().splitlines()[-1])
-    assert line["n_gpus"] == 2 and line["value"] > 0 and line["scaling"] == "strong"
-    assert len(line["ranks"]["render_ms"]) == 2 and sum(line["ranks"]["rows"]) == 200
-    p = line["parity"]
-    assert p["tiles"] == 2 and p["bit_identical"] is True and p["differing_pixels"] == 0, p
-    assert line["cpu_baseline"] is None                                 # timed at N = 1 only
+    for extra in ([], ["--debug-try-rccl"]):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--debug-shared-gpu", "--scene", obj, "--width", "320",
+                            "--height", "200", "--bounces", "5", "--steps", "1", "--warmup", "1", "--samples-per-step", "8"] + extra,
+                           cwd=ROOT, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = json.loads(r.stdout.strip().splitlines()[-1])
+        assert line["n_gpus"] == 2 and line["value"] > 0 and line["scaling"] == "strong"
+        assert len(line["ranks"]["render_ms"]) == 2 and sum(line["ranks"]["rows"]) == 200
+        p = line["parity"]
+        assert p["tiles"] == 2 and p["bit_identical"] is True and p["differing_pixels"] == 0, p
+        assert line["cpu_baseline"] is None                             # timed at N = 1 only
+        # --debug-try-rccl: RCCL refuses two ranks on one device; every rank then agrees on the gloo gather and the line says why
+        assert ("RCCL FALLBACK" in line["gather"]["transport"]) == bool(extra), line["gather"]
