@@ -26,8 +26,9 @@
 //                then direct light, per bounce).  k_flush replays them pixel by pixel,
 //                sample by sample, so the fp32 sum is associated exactly as in the
 //                reference although several samples are traced concurrently.
-//   BVH          wnodes: one 64-byte record per TWO levels of the reference BVH2 (4 slots, 8-bit boxes on an exactly
-//                representable grid, per-octant visit order): the tree k_trace_w4 walks (build_wide_bvh, rt_hip.hip);
+//   BVH          wnodes: one 64-byte record per folded piece of the reference BVH2 (a node and up to two more interior
+//                nodes below it: 4 slots = the piece's frontier, 8-bit boxes on an exactly representable grid, per-octant
+//                visit order): the tree k_trace_w4 walks (build_wide_bvh, rt_hip.hip);
 //                nodes: one 64-byte "child-pair" record per INTERIOR node of the reference BVH2: both children's exact
 //                boxes + refs in one line (k_trace2, k_trace_v1).  Topology, near/far rule and cull decisions are
 //                exactly the reference's (trace_kernels.h).

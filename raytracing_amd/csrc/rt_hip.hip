@@ -372,9 +372,9 @@ size_t rt_buffer_size(rt_buffer* buf) { return buf ? buf->bytes : 0; }
 namespace
 {
 // ---- 4-wide quantized BVH (k_trace_w4) --------------------------------------
-// Two levels of the reference BVH2 (LinearBVHNode[], bvh.cpp:223-245) are folded into one 64-byte
-// record: up to four "slots" = the grandchildren of a BVH2 node (a child that is a leaf fills one
-// slot).  Slot boxes are stored as 8-bit grid coordinates relative to a per-node frame
+// A connected piece of the reference BVH2 (LinearBVHNode[], bvh.cpp:223-245) -- a node and up to two more interior
+// nodes below it -- is folded into one 64-byte record: up to four "slots" = the frontier of that piece (which
+// frontier: `collapse`, below).  Slot boxes are stored as 8-bit grid coordinates relative to a per-node frame
 // (origin, power-of-two cell size per axis), rounded OUTWARD.
 //
 // Why results stay bit-identical to the reference ("wide traversal"):
@@ -385,8 +385,8 @@ namespace
 //    hence "true box passes  =>  stored box passes": interior culling only ever visits MORE;
 //  * every leaf is box-tested again with its exact fp32 bounds and the ray's current t_max when it
 //    is reached (the bounds travel in the leaf's first triangle record), and leaves are reached in
-//    the reference's depth-first near/far order (slot order = BVH2 order, swapped per level by the
-//    ray's sign along that level's split axis).  Node bounds are exact unions of their children's
+//    the reference's depth-first near/far order (the slots are brought into that order per direction octant by
+//    tabulated exchanges, see `arrange`).  Node bounds are exact unions of their children's
 //    (bvh.hpp:73, checked below), so a leaf's box passing implies that all its ancestors' boxes
 //    pass: the reference tests the triangles of a leaf iff that leaf's own box test passes at that
 //    point of the traversal -- which is exactly what the kernel evaluates.

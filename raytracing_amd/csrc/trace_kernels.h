@@ -539,8 +539,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(STACK <= 10 
 // k_trace2 moves ~137 sixteen-byte L1 accesses per ray and the CU's L1 retires ~1.05 of them per
 // clock whatever the instruction count (profiles/r02_ktrace2_pmc.txt: VALU -43 %, time -7 %): the
 // kernel is bound by the NUMBER of accesses and of dependent round trips.  The wide tree halves
-// both: one 64-byte record holds the four grandchildren of a BVH2 node as 8-bit boxes, so a ray
-// makes ~half as many node visits and each visit costs the same four accesses.
+// both: one 64-byte record holds four descendants of a BVH2 node (the frontier of up to three folded interior nodes,
+// picked by SAH: build_wide_bvh) as 8-bit boxes, so a ray makes fewer than half as many node visits and each visit costs
+// the same four accesses.
 //
 // Exactness (see build_wide_bvh): interior boxes contain the reference's boxes, dequantise EXACTLY, and
 // their slab distances are evaluated with one fma per plane plus an outward margin that covers the
