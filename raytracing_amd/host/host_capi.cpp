@@ -47,7 +47,7 @@ void* rth_scene_from_arrays(const rt_triangle* tris, uint32_t ntris, const rt_pa
     return guard([&]() -> void*
     {
         std::vector<rt::Triangle> t(ntris);
-        if (ntris) memcpy(t.data(), tris, (size_t)ntris * sizeof(rt_triangle));
+        if (ntris) memcpy(static_cast<void*>(t.data()), tris, (size_t)ntris * sizeof(rt_triangle));
         std::vector<rt::PackedMaterial> m(mats, mats + nmats);
         std::vector<rt::Texture> tx(tex, tex + ntex);
         std::vector<uint32_t> td(texdata, texdata + ntexdata);
