@@ -477,6 +477,10 @@ def main():
     ap.add_argument("--small-launch-paths", type=int, default=None, help="RT_OPT_SMALL_LAUNCH_PATHS (library default 3000000)")
     ap.add_argument("--wide-collapse", type=int, default=1, choices=(1, 2),
                     help="RT_CTX_OPT_WIDE_BVH: 1 = SAH-optimal frontier per wide record (library default), 2 = two BVH2 levels per record (A/B)")
+    ap.add_argument("--shadow-tree", type=int, default=None, help="RT_CTX_OPT_SHADOW_TREE (library default 1: the backend's own tree for shadow rays "
+                    "where it measures cheaper; 2 always; 3 always, surface-area metric; 0 shared with the closest-hit rays).  Bit-identical for every value.")
+    ap.add_argument("--closest-tree", type=int, default=None, help="RT_CTX_OPT_CLOSEST_TREE (library default 0 = bit-identical; 1 / 2 = TOLERANCE mode: "
+                    "an own tree for closest-hit rays where it measures cheaper / always)")
     ap.add_argument("--compact-log", type=int, default=None, help="RT_OPT_COMPACT_LOG (library default 1)")
     ap.add_argument("--per-frame-frames", type=int, default=48, help="frames of the per_frame leg (the reference's call pattern, "
                     "one Integrate() per frame); 0 = skip it")
@@ -565,6 +569,13 @@ def main():
     t_setup = time.time() - t0
     if args.wide_collapse != 1:
         render.set_wide_bvh(args.wide_collapse)               # A/B: uploads the scene again with the other collapse
+    if args.shadow_tree is not None or args.closest_tree is not None:
+        if args.shadow_tree is not None:
+            render.set_shadow_tree(args.shadow_tree, upload=False)
+        if args.closest_tree is not None:
+            render.set_closest_tree(args.closest_tree, upload=False)
+        render.set_wide_bvh(args.wide_collapse)               # ... and uploads again
+    tree_report = render.tree_report()
     if world > 1 and not args.no_scene_cache:
         dist.barrier()
         if rank == 0:
@@ -833,6 +844,7 @@ def main():
                                 rays_per_step=round(total_rays / args.steps, 1), non_finite_pixels=nan_px,
                                 stack_spill_lane_steps=int(st1.stack_spills), rays_left_to_the_bvh2_kernel=int(st1.slow_rays),
                                 log_inline_entries=int(st1.log_inline_entries), log_fallbacks=int(st1.log_fallbacks),   # 0 inline = the full log layout
+                                trees=tree_report.strip().split("\n"),    # what rt_scene_upload measured when it chose the shadow (/ closest-hit) tree
                                 setup_s=round(t_setup, 2), scene_s=round(t_scene, 2),     # scene_s: parse / generate (or load the cache); setup_s: + BVH, wide collapse, upload
                                 device=name),
                     ranks=dict(render_ms_min=round(float(tmin[0].item()) * 1e3, 3), render_ms_max=round(float(tmax[1].item()) * 1e3, 3),

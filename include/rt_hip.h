@@ -58,6 +58,21 @@ enum rt_ctx_option
     , RT_CTX_OPT_WIDE_BVH = 1      /* 1 (default): also build the 4-wide quantized tree of k_trace_w4, each 64-byte record
                                       folding the SAH-optimal frontier of up to four BVH2 nodes; 2: two BVH2 levels per
                                       record (round 2's rule); 0: BVH2 records only */
+    , RT_CTX_OPT_SHADOW_TREE = 2   /* 1 (default): shadow rays walk a 4-wide tree of the backend's own where that is cheaper --
+                                      built over the reference's LEAVES (src/bvh.cpp:67-221 fixes only those for an any-hit
+                                      query) by a full-sweep SAH on the projected area along the scene's directional lights
+                                      (+ 50 % isotropic; surface area when there are only point lights); rt_scene_upload
+                                      walks it and the reference's topology with proxy shadow rays and keeps the own tree if it
+                                      saves more than 2 % of the steps (rt_scene_tree_report).  Verdicts equal TraceBvh
+                                      -DSHADOW_RAYS bit for bit on either (trace_bvh.cl:107-109,164-167).  2: the own tree
+                                      unconditionally; 3: the own tree with the surface-area metric (A/B); 0: shadow rays share
+                                      the closest-hit tree */
+    , RT_CTX_OPT_CLOSEST_TREE = 3  /* 0 (default): closest-hit rays walk the reference's topology in the reference's order
+                                      (bit-identical radiance).  1 (measured like the shadow tree) / 2 (unconditionally):
+                                      TOLERANCE MODE -- they walk an own surface-area tree, near child first on ITS split axes:
+                                      the hit differs from TraceBvh's where two candidate hits tie within the rounding of
+                                      RayTriangle (trace_bvh.cl:157-162); validated by rel-L2 < 1e-4 and a differing-pixel
+                                      count against oracle/_ref, never the default */
 };
 int rt_ctx_set_option(rt_ctx* ctx, int option, uint32_t value);
 /* The blue-noise sampler tables (src/utils/blue_noise_sampler.hpp: sobol_256spp_256d[256*256],
@@ -347,6 +362,22 @@ int rt_frame_debug_timeline(rt_frame* frame, int arm, unsigned long long* out);
  * records) receives the index of the BVH2 node each record folds.  Fails when the tree does not qualify. */
 int rt_debug_wide_bvh(const rt_bvh_node* nodes, uint32_t num_nodes, int collapse, void* records, uint32_t* roots, uint32_t capacity,
     uint32_t* num_records, uint32_t* entry_ref);
+
+/* What the last rt_scene_upload measured when it chose the trees (one line per ray population; "" when it had no choice) */
+const char* rt_scene_tree_report(rt_ctx* ctx);
+/* The tree rt_scene_upload would give the shadow (shadow != 0) or closest-hit rays of this scene under RT_CTX_OPT_SHADOW_TREE /
+ * RT_CTX_OPT_CLOSEST_TREE = mode (host only; needs sd->triangles, nodes, lights): its records and the report line. */
+int rt_debug_choose_tree(const rt_scene_desc* sd, int shadow, uint32_t mode, void* records, uint32_t capacity, uint32_t* num_records,
+    uint32_t* entry_ref, char* report, size_t report_len);
+/* The backend's own binary tree over the LEAVES of a reference LinearBVHNode[] (own_bvh.h; host only): same linear layout,
+ * leaves copied.  Metric of a box = iso_weight * (dx dy + dy dz + dz dx) / 2 + sum over dirs of the projected area along
+ * that unit direction (3 floats each).  out_nodes may be NULL (count query: 2 * leaves - 1). */
+int rt_debug_own_bvh(const rt_bvh_node* nodes, uint32_t num_nodes, double iso_weight, const float* dirs, uint32_t n_dirs,
+    rt_bvh_node* out_nodes, uint32_t capacity, uint32_t* num_out);
+/* rt_debug_wide_bvh with collapse = 1 and the SAH collapse weighing boxes by that metric (what rt_scene_upload does for
+ * the own trees) */
+int rt_debug_wide_bvh_metric(const rt_bvh_node* nodes, uint32_t num_nodes, double iso_weight, const float* dirs, uint32_t n_dirs,
+    void* records, uint32_t capacity, uint32_t* num_records, uint32_t* entry_ref);
 
 /* ---- kernel self-test hooks (known-answer tests of the device math):
  * evaluates fn over n inputs on the device.  fn: 0 sin, 1 cos, 2 tan, 3 pow(a,b),

@@ -63,7 +63,7 @@ EXPORTS = [
     "rt_compute_aovs", "rt_denoise", "rt_copy_history",
     "rt_frame_resolve", "rt_frame_read_radiance", "rt_frame_radiance_device_ptr", "rt_frame_sample_count",
     "rt_frame_get_stats", "rt_frame_get_profile", "rt_frame_copy_radiance", "rt_frame_debug_read_queue", "rt_frame_debug_read_hits", "rt_debug_eval",
-    "rt_debug_wide_bvh", "rt_frame_debug_timeline",
+    "rt_debug_wide_bvh", "rt_frame_debug_timeline", "rt_debug_own_bvh", "rt_debug_wide_bvh_metric", "rt_scene_tree_report", "rt_debug_choose_tree",
     "rt_group_create", "rt_group_unique_id", "rt_group_join", "rt_group_size", "rt_group_local_count", "rt_group_local_rank", "rt_group_comm_count",
     "rt_group_gather_radiance", "rt_group_destroy", "rt_group_last_error", "rt_group_denoise", "rt_group_create_local",
 ]
@@ -111,6 +111,10 @@ def load():
         "rt_debug_eval": (i32, [vp, i32, vp, vp, vp, u32]),
         "rt_debug_wide_bvh": (i32, [vp, u32, i32, vp, vp, u32, C.POINTER(u32), C.POINTER(u32)]),
         "rt_frame_debug_timeline": (i32, [vp, i32, vp]),
+        "rt_scene_tree_report": (C.c_char_p, [vp]),
+        "rt_debug_choose_tree": (i32, [C.POINTER(rt_scene_desc), i32, u32, vp, u32, C.POINTER(u32), C.POINTER(u32), C.c_char_p, sz]),
+        "rt_debug_own_bvh": (i32, [vp, u32, C.c_double, vp, u32, vp, u32, C.POINTER(u32)]),
+        "rt_debug_wide_bvh_metric": (i32, [vp, u32, C.c_double, vp, u32, vp, u32, C.POINTER(u32), C.POINTER(u32)]),
         "rt_group_create": (i32, [i32, C.POINTER(i32), C.POINTER(vp)]), "rt_group_unique_id": (i32, [vp, sz]),
         "rt_group_join": (i32, [i32, i32, vp, i32, C.POINTER(vp)]), "rt_group_size": (i32, [vp]),
         "rt_group_local_count": (i32, [vp]), "rt_group_local_rank": (i32, [vp, i32]),
@@ -130,6 +134,25 @@ def _check(lib, ctx, rc):
     if rc != 0:
         msg = lib.rt_last_error(ctx)
         raise RtError(msg.decode() if msg else "unknown error")
+
+
+def choose_tree(scene, shadow=True, mode=1):
+    """rt_debug_choose_tree (host only, no GPU): the 4-wide tree rt_scene_upload would give this scene's shadow / closest-hit
+    rays under RT_CTX_OPT_SHADOW_TREE / RT_CTX_OPT_CLOSEST_TREE = mode.  scene: dict with triangles, nodes, lights.
+    Returns (records as bytes-compatible uint8[n, 64], entry_ref, report)."""
+    lib = load()
+    tris, nodes, lights = (np.ascontiguousarray(scene[k]) for k in ("triangles", "nodes", "lights"))
+    d = rt_scene_desc()
+    d.triangles, d.num_triangles, d.nodes, d.num_nodes = tris.ctypes.data, len(tris), nodes.ctypes.data, len(nodes)
+    d.lights, d.num_lights = (lights.ctypes.data if len(lights) else None), len(lights)
+    n, entry = C.c_uint32(), C.c_uint32()
+    rep = C.create_string_buffer(2048)
+    if lib.rt_debug_choose_tree(C.byref(d), int(bool(shadow)), mode, None, 0, C.byref(n), C.byref(entry), rep, len(rep)):
+        raise RtError(lib.rt_last_error(None).decode())
+    out = np.zeros((n.value, 64), np.uint8)
+    if lib.rt_debug_choose_tree(C.byref(d), int(bool(shadow)), mode, out.ctypes.data, n.value, C.byref(n), C.byref(entry), rep, len(rep)):
+        raise RtError(lib.rt_last_error(None).decode())
+    return out, entry.value, rep.value.decode()
 
 
 class Context:
@@ -162,6 +185,18 @@ class Context:
     def set_wide_bvh(self, mode):
         """RT_CTX_OPT_WIDE_BVH: 1 = SAH-optimal frontier per wide record (default), 2 = two BVH2 levels per record, 0 = none"""
         _check(self.lib, self.handle, self.lib.rt_ctx_set_option(self.handle, 1, mode))
+
+    def set_shadow_tree(self, mode):
+        """RT_CTX_OPT_SHADOW_TREE (effective at the next upload_scene): 1 default (own tree where it measures cheaper), 2 own always,
+        3 own with the surface-area metric, 0 shared with the closest-hit rays.  Results are bit-identical for every value."""
+        _check(self.lib, self.handle, self.lib.rt_ctx_set_option(self.handle, 2, mode))
+
+    def set_closest_tree(self, mode):
+        """RT_CTX_OPT_CLOSEST_TREE: 0 default (bit-identical), 1 / 2 = tolerance mode (own tree where cheaper / always)"""
+        _check(self.lib, self.handle, self.lib.rt_ctx_set_option(self.handle, 3, mode))
+
+    def tree_report(self):
+        return self.lib.rt_scene_tree_report(self.handle).decode()
 
     def finish(self):
         _check(self.lib, self.handle, self.lib.rt_finish(self.handle))

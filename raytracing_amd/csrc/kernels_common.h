@@ -99,6 +99,8 @@ struct DScene
     uint32_t entry_ref;           // "super-root" record: child 0 = (root box, root_ref), child 1 empty
     const float4* wnodes;         // 4-wide quantized nodes (k_trace_w4), 4 x float4 each; nullptr = not built
     uint32_t w_entry_ref;         // wide node 0, or RT_LEAF_BIT | first triangle when the root is a leaf
+    const float4* wnodes_sh;      // the tree the SHADOW rays walk: the backend's own over the reference's leaves (own_bvh.h), or wnodes
+    uint32_t w_sh_entry_ref;
     float root_min[3];
     float root_max[3];
     // opt-in extensions (rt_scene_desc): nullptr / 0 = the reference's behaviour

@@ -1,0 +1,268 @@
+// own_bvh.h -- a binary BVH of the backend's OWN over the reference's LEAVES (host code; rt_scene_upload, round 4).
+//
+// Why a second tree is legal for shadow rays (DESIGN.md "a tree of its own"): the reference's any-hit query
+// (trace_bvh.cl -DSHADOW_RAYS, :107-109,164-167) never changes t_max, so its verdict is
+//     OR over the leaves L whose RayBounds passes (then every ancestor's passes: bounds are exact unions, bvh.hpp:73)
+//        OR over the triangles T of L of RayTriangle(T)
+// -- a boolean that does not depend on the order in which leaves are reached nor on what sits ABOVE the leaves.  Any tree
+// whose leaves are exactly the reference's leaves (same exact box, same triangles in the same array) and whose interior
+// boxes contain the boxes below them gives the same boolean when interior culling is conservative and every leaf is
+// decided by the reference's own expression on its exact box -- which is what k_trace_w4 already does.  So this file only
+// has to produce a BETTER binary tree over those leaves; build_wide_bvh then folds it into 4-wide records exactly as it
+// folds the reference's tree, and the kernel does not change at all.
+//
+// What "better" means here, and what src/bvh.cpp:67-221 (the builder this one is not bound to) leaves on the table:
+//  * the reference splits along ONE axis (the longest of the centroid bounds) at one of 11 bucket borders; this builder
+//    sweeps EVERY border between two sorted centroids on all three axes (binned with 256 / 64 bins above 768 leaves);
+//  * the cost of a box is the probability that a ray of the population the tree serves crosses it.  For rays of every
+//    direction that is the surface area; shadow rays towards a directional light all share ONE direction d, and a line
+//    of direction d crosses a box with probability proportional to its PROJECTED area |d.x| dy dz + |d.y| dz dx +
+//    |d.z| dx dy.  The metric is a mixture: one projected-area term per directional light, one isotropic term (half the
+//    average of the projected area over all directions = (dx dy + dy dz + dz dx) / 2) per point light or per unit of
+//    `iso_weight` (Metric below) -- with no directional term it is the ordinary surface-area heuristic.
+// The same builder with the isotropic metric gives the closest-hit tree of the opt-in tolerance mode
+// (RT_CTX_OPT_CLOSEST_TREE): near child first by the sign of the ray along each node's split axis, like the reference, but
+// on this topology -- identical results except where two candidate hits tie to within the rounding of the ray-triangle
+// test (DESIGN.md has the argument and the measured differing-pixel counts).
+//
+// Output: rt_bvh_node[] in the reference's own linear layout (bvh.cpp:223-245: first child at i + 1, second child at
+// `offset`, split axis in the low half of num_primitives_axis), leaves copied from the reference's array.
+#pragma once
+#include <stdint.h>
+#include <string.h>
+#include <math.h>
+#include <algorithm>
+#include <array>
+#include <atomic>
+#include <thread>
+#include <vector>
+#include "rt_types.h"
+
+namespace ownbvh
+{
+struct Metric
+{
+    double iso = 1.0;                       // weight of the isotropic term
+    std::vector<std::array<double, 3>> dirs; // |d| components of unit directions, one projected-area term each
+    double of(const float mn[3], const float mx[3]) const
+    {
+        const double dx = (double)mx[0] - mn[0], dy = (double)mx[1] - mn[1], dz = (double)mx[2] - mn[2];
+        double m = iso * 0.5 * (dx * dy + dy * dz + dz * dx);
+        for (const auto& d : dirs) m += d[0] * dy * dz + d[1] * dz * dx + d[2] * dx * dy;
+        return m;
+    }
+};
+
+struct Prim { float mn[3], mx[3], c[3]; uint32_t leaf; };
+
+struct Builder
+{
+    const rt_bvh_node* ref;
+    Metric metric;
+    std::vector<Prim> prims;
+    std::vector<rt_bvh_node> out;
+    struct Task { uint32_t b, e, pos; };
+    std::vector<Task> tasks;
+    uint32_t grain = 16384;
+
+    static void grow(float mn[3], float mx[3], const Prim& p)
+    {
+        for (int a = 0; a < 3; ++a) { mn[a] = p.mn[a] < mn[a] ? p.mn[a] : mn[a]; mx[a] = p.mx[a] > mx[a] ? p.mx[a] : mx[a]; }
+    }
+    void write_leaf(uint32_t pos, const Prim& p)
+    {
+        rt_bvh_node n = ref[p.leaf];
+        n.num_primitives_axis &= 0xFFFF0000u;
+        out[pos] = n;
+    }
+    void write_interior(uint32_t pos, const float mn[3], const float mx[3], uint32_t axis, uint32_t second)
+    {
+        rt_bvh_node n;
+        memset(&n, 0, sizeof(n));
+        n.bounds_min.x = mn[0]; n.bounds_min.y = mn[1]; n.bounds_min.z = mn[2];
+        n.bounds_max.x = mx[0]; n.bounds_max.y = mx[1]; n.bounds_max.z = mx[2];
+        n.offset = second;
+        n.num_primitives_axis = axis;
+        out[pos] = n;
+    }
+
+    // Splits prims[b, e) (n >= 2) in place; returns the first index of the upper part and the axis.  Cost of a candidate:
+    // metric(lower box) * leaves below it + metric(upper box) * leaves above it (the greedy top-down SAH; interior boxes
+    // are all that is paid for here -- every leaf is one reference leaf whichever tree it hangs in).
+    uint32_t split(uint32_t b, uint32_t e, uint32_t& axis_out, std::vector<double>& scratch, std::vector<uint32_t>& order)
+    {
+        const uint32_t n = e - b;
+        float cmn[3] = {INFINITY, INFINITY, INFINITY}, cmx[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (uint32_t i = b; i < e; ++i)
+            for (int a = 0; a < 3; ++a) { cmn[a] = std::min(cmn[a], prims[i].c[a]); cmx[a] = std::max(cmx[a], prims[i].c[a]); }
+        double best = INFINITY; int best_axis = -1; uint32_t best_at = 0; float best_plane = 0.0f; bool best_binned = false;
+        const float NINF = -INFINITY;
+        if (n > 768u)
+        {
+            // binned: 256 (64 below 32 Ki leaves) bins over the centroid bounds of every axis
+            const int NB = n > 32768u ? 256 : 64;
+            struct Bin { float mn[3], mx[3]; uint32_t count; };
+            Bin bins[256];
+            for (int a = 0; a < 3; ++a)
+            {
+                if (!(cmx[a] > cmn[a])) continue;
+                for (int j = 0; j < NB; ++j) { Bin& bn = bins[j]; for (int k = 0; k < 3; ++k) { bn.mn[k] = INFINITY; bn.mx[k] = NINF; } bn.count = 0; }
+                const double scale = NB / ((double)cmx[a] - cmn[a]);
+                auto bin_of = [&](const Prim& p) { int k = (int)(((double)p.c[a] - cmn[a]) * scale); return k < 0 ? 0 : (k >= NB ? NB - 1 : k); };
+                for (uint32_t i = b; i < e; ++i) { Bin& bn = bins[bin_of(prims[i])]; grow(bn.mn, bn.mx, prims[i]); ++bn.count; }
+                scratch.assign(NB, 0.0);
+                float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {NINF, NINF, NINF};
+                uint32_t cnt = 0;
+                for (int k = NB - 1; k > 0; --k)
+                {
+                    if (bins[k].count) { for (int q = 0; q < 3; ++q) { mn[q] = std::min(mn[q], bins[k].mn[q]); mx[q] = std::max(mx[q], bins[k].mx[q]); } cnt += bins[k].count; }
+                    scratch[k] = cnt ? metric.of(mn, mx) * cnt : INFINITY;       // cost of the upper part [k, NB)
+                }
+                for (int q = 0; q < 3; ++q) { mn[q] = INFINITY; mx[q] = NINF; }
+                cnt = 0;
+                for (int k = 0; k < NB - 1; ++k)
+                {
+                    if (bins[k].count) { for (int q = 0; q < 3; ++q) { mn[q] = std::min(mn[q], bins[k].mn[q]); mx[q] = std::max(mx[q], bins[k].mx[q]); } cnt += bins[k].count; }
+                    if (cnt == 0 || cnt == n) continue;
+                    const double c = metric.of(mn, mx) * cnt + scratch[k + 1];
+                    if (c < best) { best = c; best_axis = a; best_at = (uint32_t)k; best_binned = true; }
+                }
+            }
+            if (best_axis >= 0)
+            {
+                const int a = best_axis;
+                const double scale = NB / ((double)cmx[a] - cmn[a]);
+                auto bin_of = [&](const Prim& p) { int k = (int)(((double)p.c[a] - cmn[a]) * scale); return k < 0 ? 0 : (k >= NB ? NB - 1 : k); };
+                Prim* mid = std::partition(&prims[b], &prims[b] + n, [&](const Prim& p) { return (uint32_t)bin_of(p) <= best_at; });
+                axis_out = (uint32_t)a;
+                return (uint32_t)(mid - &prims[0]);
+            }
+        }
+        else
+        {
+            // full sweep: every border between two consecutive centroids, all three axes
+            typedef std::pair<float, uint32_t> Key;                        // (centroid, reference leaf): a total order
+            std::vector<Key> keys(n), best_keys;
+            std::vector<uint32_t> at(n);                                   // position in prims[] of the k-th key
+            scratch.resize(n);
+            order.resize(n);
+            for (int a = 0; a < 3; ++a)
+            {
+                if (!(cmx[a] > cmn[a])) continue;
+                for (uint32_t i = 0; i < n; ++i) keys[i] = Key(prims[b + i].c[a], i);
+                std::sort(keys.begin(), keys.end(), [&](const Key& x, const Key& y)
+                    { return x.first < y.first || (x.first == y.first && prims[b + x.second].leaf < prims[b + y.second].leaf); });
+                float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {NINF, NINF, NINF};
+                for (uint32_t i = n; i-- > 1;) { grow(mn, mx, prims[b + keys[i].second]); scratch[i] = metric.of(mn, mx) * (n - i); }
+                for (int q = 0; q < 3; ++q) { mn[q] = INFINITY; mx[q] = NINF; }
+                bool improved = false;
+                for (uint32_t i = 1; i < n; ++i)
+                {
+                    grow(mn, mx, prims[b + keys[i - 1].second]);
+                    const double c = metric.of(mn, mx) * i + scratch[i];
+                    if (c < best) { best = c; best_axis = a; best_at = i; improved = true; }
+                }
+                if (improved) for (uint32_t i = 0; i < n; ++i) order[i] = keys[i].second;
+            }
+            if (best_axis >= 0)
+            {
+                // apply: the `best_at` lowest in that axis' order go first
+                std::vector<Prim> tmp(n);
+                for (uint32_t i = 0; i < n; ++i) tmp[i] = prims[b + order[i]];
+                std::copy(tmp.begin(), tmp.end(), prims.begin() + b);
+                axis_out = (uint32_t)best_axis;
+                (void)best_plane; (void)best_binned;
+                return b + best_at;
+            }
+        }
+        // all centroids coincide (or the bins could not separate them): halve by reference order
+        std::sort(&prims[b], &prims[b] + n, [](const Prim& x, const Prim& y) { return x.leaf < y.leaf; });
+        int a = 0;
+        for (int q = 1; q < 3; ++q) if (cmx[q] - cmn[q] > cmx[a] - cmn[a]) a = q;
+        axis_out = (uint32_t)a;
+        return b + n / 2;
+    }
+
+    // a subtree over n leaves takes 2 n - 1 records: first child at pos + 1, second at pos + 2 * (leaves of the first)
+    void build(uint32_t b, uint32_t e, uint32_t pos, bool collect, std::vector<double>& scratch, std::vector<uint32_t>& order)
+    {
+        for (;;)
+        {
+            const uint32_t n = e - b;
+            if (n == 1) { write_leaf(pos, prims[b]); return; }
+            if (collect && n <= grain) { tasks.push_back({b, e, pos}); return; }
+            float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+            for (uint32_t i = b; i < e; ++i) grow(mn, mx, prims[i]);
+            uint32_t axis = 0;
+            const uint32_t mid = split(b, e, axis, scratch, order);
+            const uint32_t nl = mid - b;
+            write_interior(pos, mn, mx, axis, pos + 2u * nl);
+            build(b, mid, pos + 1u, collect, scratch, order);
+            b = mid; pos = pos + 2u * nl;                                 // the second child: iterate
+        }
+    }
+};
+
+// nodes[nn]: the reference's LinearBVHNode[] (validated by the caller: build_wide_bvh's pass 0 has the same requirements).
+// false: nothing to do (leaf root) or the array is not a tree.
+inline bool build(const rt_bvh_node* nodes, uint32_t nn, const Metric& metric, std::vector<rt_bvh_node>& out)
+{
+    out.clear();
+    if (nn == 0 || (nodes[0].num_primitives_axis >> 16) != 0) return false;
+    Builder B;
+    B.ref = nodes;
+    B.metric = metric;
+    {
+        std::vector<uint32_t> todo{0u};
+        size_t seen = 0;
+        while (!todo.empty())
+        {
+            const uint32_t i = todo.back();
+            todo.pop_back();
+            if (++seen > nn) return false;
+            const rt_bvh_node& n = nodes[i];
+            if ((n.num_primitives_axis >> 16) != 0)
+            {
+                Prim p;
+                p.mn[0] = n.bounds_min.x; p.mn[1] = n.bounds_min.y; p.mn[2] = n.bounds_min.z;
+                p.mx[0] = n.bounds_max.x; p.mx[1] = n.bounds_max.y; p.mx[2] = n.bounds_max.z;
+                for (int a = 0; a < 3; ++a)
+                {
+                    if (!std::isfinite(p.mn[a]) || !std::isfinite(p.mx[a])) return false;
+                    p.c[a] = 0.5f * p.mn[a] + 0.5f * p.mx[a];
+                }
+                p.leaf = i;
+                B.prims.push_back(p);
+                continue;
+            }
+            if (i + 1 >= nn || n.offset >= nn || n.offset <= i + 1) return false;
+            todo.push_back(n.offset);
+            todo.push_back(i + 1);
+        }
+    }
+    const uint32_t np = (uint32_t)B.prims.size();
+    if (np < 2) return false;
+    B.out.resize((size_t)2 * np - 1);
+    std::vector<double> scratch;
+    std::vector<uint32_t> order;
+    B.build(0, np, 0, true, scratch, order);                              // the top of the tree; subtrees of <= grain leaves become tasks
+    {
+        const unsigned n_threads = (unsigned)std::min<size_t>(std::max(1u, std::min(std::thread::hardware_concurrency(), 32u)), B.tasks.size());
+        std::atomic<size_t> next{0};
+        // largest first: the pool drains evenly
+        std::sort(B.tasks.begin(), B.tasks.end(), [](const Builder::Task& x, const Builder::Task& y) { return x.e - x.b > y.e - y.b; });
+        auto run = [&]()
+        {
+            std::vector<double> s;
+            std::vector<uint32_t> o;
+            for (size_t t; (t = next.fetch_add(1)) < B.tasks.size();) B.build(B.tasks[t].b, B.tasks[t].e, B.tasks[t].pos, false, s, o);
+        };
+        std::vector<std::thread> pool;
+        for (unsigned t = 1; t < n_threads; ++t) pool.emplace_back(run);
+        run();
+        for (auto& th : pool) th.join();
+    }
+    out.swap(B.out);
+    return true;
+}
+} // namespace ownbvh

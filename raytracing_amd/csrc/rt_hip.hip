@@ -16,6 +16,8 @@
 #include <array>
 #include "rt_hip.h"
 #include "kernels.h"
+#include "own_bvh.h"
+#include "tree_select.h"
 
 namespace
 {
@@ -28,6 +30,10 @@ struct Scene
     void* emissive = nullptr;
     void* mat_tex16 = nullptr;
     void* wnodes = nullptr;   // 4-wide quantized BVH (build_wide_bvh); nullptr when the tree does not qualify
+    void* wnodes_sh = nullptr;   // the shadow rays' own 4-wide tree (own_bvh.h over the reference's leaves); nullptr = they share wnodes
+    void* wnodes_cl = nullptr;   // RT_CTX_OPT_CLOSEST_TREE = 1 (tolerance mode): the closest-hit rays' own tree
+    uint32_t n_wide_sh = 0, n_wide_cl = 0;
+    std::string tree_report;     // what rt_scene_upload measured when it chose the trees (rt_scene_tree_report)
     DScene d = {};
     bool valid = false;
     uint32_t n_wide = 0;      // wide nodes (0 with a leaf root)
@@ -49,6 +55,9 @@ struct rt_ctx
     Scene scene;
     uint32_t treelet_nodes = 7;   // RT_CTX_OPT_TREELET_NODES
     uint32_t build_wide = 1;      // RT_CTX_OPT_WIDE_BVH
+    uint32_t shadow_tree = 1;     // RT_CTX_OPT_SHADOW_TREE: 1 = shadow rays walk the backend's own tree where it measures cheaper (exact either way),
+                                  // 2 = own unconditionally, 3 = own with the surface-area metric (A/B), 0 = they share the closest-hit tree
+    uint32_t closest_tree = 0;    // RT_CTX_OPT_CLOSEST_TREE: 1 / 2 as above; != 0 is the tolerance mode (NOT bit-exact)
     uint8_t* blue_noise = nullptr;   // sobol[65536] | scramblingTile[131072] | rankingTile[131072]
     float* gamma_lut = nullptr;      // pow(byte / 255, 2.2f), 256 entries (k_fill_gamma_lut)
 };
@@ -188,7 +197,7 @@ int dev_alloc_copy(rt_ctx* ctx, void** out, const void* src, size_t bytes)
 
 void free_scene(Scene& s)
 {
-    void* ptrs[] = {s.nodes, s.tris_rt, s.tris_sh, s.materials, s.textures, s.texture_data, s.lights, s.env, s.emissive, s.wnodes, s.mat_tex16};
+    void* ptrs[] = {s.nodes, s.tris_rt, s.tris_sh, s.materials, s.textures, s.texture_data, s.lights, s.env, s.emissive, s.wnodes, s.mat_tex16, s.wnodes_sh, s.wnodes_cl};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     s = Scene();
 }
@@ -307,6 +316,8 @@ int rt_ctx_set_option(rt_ctx* ctx, int option, uint32_t value)
         return RT_OK;
     }
     if (option == RT_CTX_OPT_WIDE_BVH) { ctx->build_wide = value > 2u ? 1u : value; return RT_OK; }
+    if (option == RT_CTX_OPT_SHADOW_TREE) { ctx->shadow_tree = value > 3u ? 1u : value; return RT_OK; }
+    if (option == RT_CTX_OPT_CLOSEST_TREE) { ctx->closest_tree = value > 2u ? 1u : value; return RT_OK; }
     return fail(ctx, "rt_ctx_set_option: unknown option");
 }
 
@@ -414,7 +425,8 @@ enum { RT_WIDE_TWO_LEVELS = 0, RT_WIDE_SAH = 1 };
 
 // false: the tree does not qualify (non-finite or non-nested bounds, child order): k_trace2 is used
 bool build_wide_bvh(const rt_bvh_node* nodes, uint32_t nn, int collapse, std::vector<WideNode>& out, uint32_t& entry_ref,
-    std::vector<uint32_t>* roots = nullptr /* the BVH2 node each record folds (tests) */)
+    std::vector<uint32_t>* roots = nullptr /* the BVH2 node each record folds (tests) */,
+    const ownbvh::Metric* metric = nullptr /* what "area" means for the SAH collapse (own_bvh.h); nullptr = surface area */)
 {
     auto is_leaf = [&](uint32_t i) { return (nodes[i].num_primitives_axis >> 16) != 0; };
     out.clear();
@@ -462,7 +474,8 @@ bool build_wide_bvh(const rt_bvh_node* nodes, uint32_t nn, int collapse, std::ve
             const rt_bvh_node& b = nodes[n];
             const double dx = (double)b.bounds_max.x - b.bounds_min.x, dy = (double)b.bounds_max.y - b.bounds_min.y,
                          dz = (double)b.bounds_max.z - b.bounds_min.z;
-            T[n] = (dx * dy + dy * dz + dz * dx) + F[(size_t)n * 5u + 4u];
+            const float bmn[3] = {b.bounds_min.x, b.bounds_min.y, b.bounds_min.z}, bmx[3] = {b.bounds_max.x, b.bounds_max.y, b.bounds_max.z};
+            T[n] = (metric ? metric->of(bmn, bmx) : dx * dy + dy * dz + dz * dx) + F[(size_t)n * 5u + 4u];
             for (uint32_t i = 2; i <= 4; ++i)
                 if (F[(size_t)n * 5u + i] < T[n]) open[n] |= (uint8_t)(1u << i);
         }
@@ -643,6 +656,10 @@ bool build_wide_bvh(const rt_bvh_node* nodes, uint32_t nn, int collapse, std::ve
                 const double cell = std::ldexp(1.0, exps[a]);
                 double lo = std::floor(((double)cmin[a] - (double)origin[a]) / cell);
                 double hi = std::ceil(((double)cmax[a] - (double)origin[a]) / cell);
+                // the difference above is rounded (a bound of 1e-17 beside an origin of -0.2 vanishes in it): settle the
+                // containment on the grid points themselves, which are exact in binary32 and binary64 alike
+                while ((double)origin[a] + lo * cell > (double)cmin[a]) lo -= 1.0;
+                while ((double)origin[a] + hi * cell < (double)cmax[a]) hi += 1.0;
                 if (lo < 0.0 || hi > 255.0 || lo > hi) return false;      // cannot happen: the child is inside the node
                 r.lo[a] |= (uint32_t)lo << (8 * k);
                 r.hi[a] |= (uint32_t)hi << (8 * k);
@@ -671,6 +688,77 @@ bool build_wide_bvh(const rt_bvh_node* nodes, uint32_t nn, int collapse, std::ve
     return true;
 }
 
+// The ray population a shadow tree serves (own_bvh.h): shadow rays go to the analytic lights only (hit_surface.cl:114-146,
+// light.h:30-65), one uniformly chosen per hit -- towards a directional light they all share its direction, towards a point
+// light they come from everywhere.
+ownbvh::Metric shadow_metric(const rt_light* lights, uint32_t n, double iso_share)
+{
+    ownbvh::Metric m;
+    m.iso = 0.0;
+    for (uint32_t i = 0; i < n; ++i)
+    {
+        const rt_light& l = lights[i];
+        const double len = std::sqrt((double)l.origin.x * l.origin.x + (double)l.origin.y * l.origin.y + (double)l.origin.z * l.origin.z);
+        if (l.type == RT_LIGHT_TYPE_POINT || !(len > 0.0) || !std::isfinite(len)) { m.iso += 1.0; continue; }
+        m.dirs.push_back({std::fabs(l.origin.x / len), std::fabs(l.origin.y / len), std::fabs(l.origin.z / len)});
+    }
+    if (m.dirs.empty()) m.iso = 1.0;
+    else m.iso += iso_share * (double)m.dirs.size();   // some isotropy keeps boxes that are thin along d from growing without bound
+    return m;
+}
+
+// Which tree a ray population walks: the candidate of own_bvh.h against the reference's own topology (`ref_wide`), both
+// walked by proxy rays of that population (tree_select.h).  mode 1: own only if it saves more than 2 % of the steps;
+// mode 2: own whatever it costs (A/B runs); mode 3 (shadow): own with the plain surface-area metric, unconditionally (A/B).
+struct OwnTree
+{
+    std::vector<WideNode> wide; uint32_t entry = 0; bool ok = false; const char* name = ""; std::thread worker;
+    void start(const rt_scene_desc* sd, bool shadow, uint32_t mode)
+    {
+        ownbvh::Metric m;
+        name = "own: surface area";
+        if (shadow && mode != 3u)
+        {
+            ownbvh::Metric d = shadow_metric(sd->lights, sd->num_lights, 0.5);
+            if (!d.dirs.empty()) { m = d; name = "own: projected area along the directional lights + 50 % isotropic"; }
+        }
+        worker = std::thread([this, sd, m]()
+        {
+            std::vector<rt_bvh_node> own;
+            ok = ownbvh::build(sd->nodes, sd->num_nodes, m, own) && build_wide_bvh(own.data(), (uint32_t)own.size(), RT_WIDE_SAH, wide, entry, nullptr, &m) && !wide.empty();
+        });
+    }
+    void join() { if (worker.joinable()) worker.join(); }
+    ~OwnTree() { join(); }
+};
+
+// true: walk the own tree; false: keep the reference topology
+bool choose_tree(const rt_scene_desc* sd, const std::vector<WideNode>& ref_wide, uint32_t ref_entry, bool shadow, uint32_t mode,
+    OwnTree& own, std::string& report)
+{
+    own.join();
+    char line[320];
+    if (!own.ok) { report += shadow ? "shadow tree: the own tree does not qualify -> reference topology\n" : "closest-hit tree: the own tree does not qualify -> reference topology\n"; return false; }
+    if (mode >= 2u)
+    {
+        snprintf(line, sizeof(line), "%s tree: %s, forced (not measured)\n", shadow ? "shadow" : "closest-hit", own.name);
+        report += line;
+        return true;
+    }
+    const uint32_t nt = sd->num_triangles, nn = sd->num_nodes;
+    std::vector<uint32_t> leaf_of_first(nt, 0u);
+    for (uint32_t i = 0; i < nn; ++i)
+        if ((sd->nodes[i].num_primitives_axis >> 16) != 0 && sd->nodes[i].offset < nt) leaf_of_first[sd->nodes[i].offset] = i;
+    const std::vector<treesel::ProxyRay> rays = treesel::proxy_rays(sd->triangles, nt, sd->lights, sd->num_lights, 8192u, shadow);
+    if (rays.empty()) { report += shadow ? "shadow tree: no lights, nothing to measure -> reference topology\n" : "closest-hit tree: nothing to measure -> reference topology\n"; return false; }
+    const double c_ref = treesel::walk_cost((const treesel::Record*)ref_wide.data(), (uint32_t)ref_wide.size(), ref_entry, sd->nodes, leaf_of_first.data(), sd->triangles, rays, shadow);
+    const double c_own = treesel::walk_cost((const treesel::Record*)own.wide.data(), (uint32_t)own.wide.size(), own.entry, sd->nodes, leaf_of_first.data(), sd->triangles, rays, shadow);
+    const bool pick = c_own < 0.98 * c_ref;
+    snprintf(line, sizeof(line), "%s tree: reference topology %.2f steps per proxy ray, %s %.2f -> %s\n", shadow ? "shadow" : "closest-hit", c_ref, own.name, c_own,
+        pick ? "own" : "reference topology");
+    report += line;
+    return pick;
+}
 } // namespace
 
 extern "C" {
@@ -689,6 +777,11 @@ int rt_scene_upload(rt_ctx* ctx, const rt_scene_desc* sd)
     free_scene(ctx->scene);
     Scene& s = ctx->scene;
     const uint32_t nt = sd->num_triangles, nn = sd->num_nodes;
+    // the trees of the backend's own (below, "Trees of the backend's own") are built on worker threads meanwhile
+    OwnTree own_sh, own_cl;
+    const bool may_own = ctx->build_wide == 1u && (uint64_t)nt * 64 <= 0xFFFFFFFFull && (sd->nodes[0].num_primitives_axis >> 16) == 0;
+    if (may_own && ctx->shadow_tree) own_sh.start(sd, true, ctx->shadow_tree);
+    if (may_own && ctx->closest_tree) own_cl.start(sd, false, ctx->closest_tree);
 
     // --- BVH re-layout: LinearBVHNode[] (bvh.cpp:223-245) -> child-pair records
     // Record order = cache-friendly "treelet" layout: a breadth-first cluster of up to
@@ -858,6 +951,24 @@ int rt_scene_upload(rt_ctx* ctx, const rt_scene_desc* sd)
         ((ctx->build_wide != 2u && build_wide_bvh(sd->nodes, nn, RT_WIDE_SAH, wide, w_entry)) ||
          build_wide_bvh(sd->nodes, nn, RT_WIDE_TWO_LEVELS, wide, w_entry));
     if (have_wide) rc |= dev_alloc_copy(ctx, &s.wnodes, wide.data(), wide.size() * sizeof(WideNode));
+    // Trees of the backend's own over the reference's leaves (own_bvh.h): one for the shadow rays (exact: an any-hit verdict
+    // does not depend on what sits above the leaves) and -- opt-in, tolerance mode -- one for the closest-hit rays.  Which
+    // candidate a population walks is MEASURED with proxy rays (tree_select.h); the reference's own topology is a candidate,
+    // so the choice is never worse than sharing on that measure.
+    bool have_sh = false, have_cl = false;
+    s.tree_report.clear();
+    own_sh.join(); own_cl.join();
+    if (have_wide && !wide.empty() && may_own && ctx->shadow_tree)
+    {
+        have_sh = choose_tree(sd, wide, w_entry, true, ctx->shadow_tree, own_sh, s.tree_report);
+        if (have_sh) rc |= dev_alloc_copy(ctx, &s.wnodes_sh, own_sh.wide.data(), own_sh.wide.size() * sizeof(WideNode));
+    }
+    if (have_wide && !wide.empty() && may_own && ctx->closest_tree)
+    {
+        have_cl = choose_tree(sd, wide, w_entry, false, ctx->closest_tree, own_cl, s.tree_report);
+        if (have_cl) rc |= dev_alloc_copy(ctx, &s.wnodes_cl, own_cl.wide.data(), own_cl.wide.size() * sizeof(WideNode));
+    }
+    const uint32_t w_entry_sh = own_sh.entry, w_entry_cl = own_cl.entry;
     if (rc != RT_OK) { free_scene(s); return RT_ERROR; }
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // host staging vectors die here
 
@@ -879,7 +990,12 @@ int rt_scene_upload(rt_ctx* ctx, const rt_scene_desc* sd)
     s.d.light_count = sd->num_lights;
     s.d.wnodes = have_wide ? (const float4*)s.wnodes : nullptr;
     s.d.w_entry_ref = w_entry;
+    s.d.wnodes_sh = have_sh ? (const float4*)s.wnodes_sh : s.d.wnodes;
+    s.d.w_sh_entry_ref = have_sh ? w_entry_sh : w_entry;
+    if (have_cl) { s.d.wnodes = (const float4*)s.wnodes_cl; s.d.w_entry_ref = w_entry_cl; }
     s.n_wide = have_wide ? (uint32_t)wide.size() : 0u;
+    s.n_wide_sh = have_sh ? (uint32_t)own_sh.wide.size() : 0u;
+    s.n_wide_cl = have_cl ? (uint32_t)own_cl.wide.size() : 0u;
     s.wide_ok = have_wide;
     s.offsets32 = (uint64_t)(n_interior + 1) * 64 <= 0xFFFFFFFFull && (uint64_t)nt * 64 <= 0xFFFFFFFFull;
     s.valid = true;
@@ -2117,6 +2233,71 @@ int rt_debug_wide_bvh(const rt_bvh_node* nodes, uint32_t num_nodes, int collapse
         if (wide.size() > capacity) return fail(nullptr, "rt_debug_wide_bvh: capacity too small");
         memcpy(records, wide.data(), wide.size() * sizeof(WideNode));
         if (roots) memcpy(roots, folded.data(), folded.size() * sizeof(uint32_t));
+    }
+    return RT_OK;
+}
+
+const char* rt_scene_tree_report(rt_ctx* ctx) { return ctx ? ctx->scene.tree_report.c_str() : ""; }
+
+int rt_debug_choose_tree(const rt_scene_desc* sd, int shadow, uint32_t mode, void* records, uint32_t capacity, uint32_t* num_records,
+    uint32_t* entry_ref, char* report, size_t report_len)
+{
+    if (!sd || !sd->nodes || !sd->triangles || !num_records || !entry_ref) return fail(nullptr, "rt_debug_choose_tree: NULL argument");
+    std::vector<WideNode> ref_wide;
+    uint32_t ref_entry = 0;
+    if (!build_wide_bvh(sd->nodes, sd->num_nodes, RT_WIDE_SAH, ref_wide, ref_entry) || ref_wide.empty())
+        return fail(nullptr, "rt_debug_choose_tree: the tree does not qualify for the 4-wide layout");
+    std::string rep;
+    OwnTree own;
+    own.start(sd, shadow != 0, mode);
+    const bool picked = choose_tree(sd, ref_wide, ref_entry, shadow != 0, mode, own, rep);
+    const std::vector<WideNode>& w = picked ? own.wide : ref_wide;
+    *num_records = (uint32_t)w.size();
+    *entry_ref = picked ? own.entry : ref_entry;
+    if (report && report_len) snprintf(report, report_len, "%s", rep.c_str());
+    if (records)
+    {
+        if (w.size() > capacity) return fail(nullptr, "rt_debug_choose_tree: capacity too small");
+        memcpy(records, w.data(), w.size() * sizeof(WideNode));
+    }
+    return RT_OK;
+}
+
+int rt_debug_own_bvh(const rt_bvh_node* nodes, uint32_t num_nodes, double iso_weight, const float* dirs, uint32_t n_dirs,
+    rt_bvh_node* out_nodes, uint32_t capacity, uint32_t* num_out)
+{
+    if (!nodes || num_nodes == 0 || !num_out) return fail(nullptr, "rt_debug_own_bvh: NULL argument");
+    ownbvh::Metric m;
+    m.iso = iso_weight;
+    for (uint32_t i = 0; i < n_dirs && dirs; ++i) m.dirs.push_back({std::fabs((double)dirs[3 * i]), std::fabs((double)dirs[3 * i + 1]), std::fabs((double)dirs[3 * i + 2])});
+    std::vector<rt_bvh_node> own;
+    if (!ownbvh::build(nodes, num_nodes, m, own)) return fail(nullptr, "rt_debug_own_bvh: nothing to build (leaf root) or the node array is not a tree");
+    *num_out = (uint32_t)own.size();
+    if (out_nodes)
+    {
+        if (own.size() > capacity) return fail(nullptr, "rt_debug_own_bvh: capacity too small");
+        memcpy(out_nodes, own.data(), own.size() * sizeof(rt_bvh_node));
+    }
+    return RT_OK;
+}
+
+int rt_debug_wide_bvh_metric(const rt_bvh_node* nodes, uint32_t num_nodes, double iso_weight, const float* dirs, uint32_t n_dirs,
+    void* records, uint32_t capacity, uint32_t* num_records, uint32_t* entry_ref)
+{
+    if (!nodes || num_nodes == 0 || !num_records || !entry_ref) return fail(nullptr, "rt_debug_wide_bvh_metric: NULL argument");
+    ownbvh::Metric m;
+    m.iso = iso_weight;
+    for (uint32_t i = 0; i < n_dirs && dirs; ++i) m.dirs.push_back({std::fabs((double)dirs[3 * i]), std::fabs((double)dirs[3 * i + 1]), std::fabs((double)dirs[3 * i + 2])});
+    std::vector<WideNode> wide;
+    uint32_t entry = 0;
+    if (!build_wide_bvh(nodes, num_nodes, RT_WIDE_SAH, wide, entry, nullptr, &m))
+        return fail(nullptr, "rt_debug_wide_bvh_metric: the tree does not qualify for the 4-wide layout");
+    *num_records = (uint32_t)wide.size();
+    *entry_ref = entry;
+    if (records)
+    {
+        if (wide.size() > capacity) return fail(nullptr, "rt_debug_wide_bvh_metric: capacity too small");
+        memcpy(records, wide.data(), wide.size() * sizeof(WideNode));
     }
     return RT_OK;
 }

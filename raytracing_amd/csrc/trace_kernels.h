@@ -699,8 +699,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
     // after the first wave finds the queue dry, tools/launch_timeline.py -- by more than 0.1 ms: the tail is single
     // long rays on nearly empty waves, not the size of the last hand-outs.  profiles/r02_taper_sweep.log)
     const uint32_t spill_base = (blockIdx.x * 64u + lane) * (uint32_t)(RT_W4_STACK_MAX - STACK);
-    const char* const node_base = reinterpret_cast<const char*>(sc.wnodes);
+    const char* const node_base = reinterpret_cast<const char*>(SHADOW ? sc.wnodes_sh : sc.wnodes);
     const char* const tri_base = reinterpret_cast<const char*>(sc.tris_rt);
+    const uint32_t entry_ref = SHADOW ? sc.w_sh_entry_ref : sc.w_entry_ref;
 
     RayPool pool = {0u, 0u, 0u, false};
     uint32_t chunk_next = blockIdx.x >> 3;         // chunk mode: this wave's next chunk of its XCD's region
@@ -813,7 +814,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                     // RT_SIGN_SLOW, or an origin so far out that the one-fma slab distances of loop C could overflow
                     slow = (sign_bits & RT_SIGN_SLOW) != 0u ||
                            !(hw_max3(__builtin_fabsf(org.x), __builtin_fabsf(org.y), __builtin_fabsf(org.z)) < 0x1p29f);
-                    if (!slow) ref = sc.w_entry_ref;
+                    if (!slow) ref = entry_ref;
                 }
                 // rays this kernel does not take: hand their queue index to the BVH2 kernel's list
                 const unsigned long long slow_m = __ballot(slow);

@@ -259,6 +259,28 @@ class Render:
             raise _err(self.lib)
         self._c(self.lib.rth_render_upload_gpu_data(self.handle))
 
+    def set_ctx_option(self, option, value, upload=True):
+        """rt_ctx_set_option on this Render's context (then the scene is uploaded again, as the options take effect there)"""
+        from . import capi
+        if capi.load().rt_ctx_set_option(self.lib.rth_render_ctx_handle(self.handle), option, value):
+            raise _err(self.lib)
+        if upload:
+            self._c(self.lib.rth_render_upload_gpu_data(self.handle))
+
+    def set_shadow_tree(self, mode, upload=True):
+        """RT_CTX_OPT_SHADOW_TREE: 1 (default) = the backend's own tree for shadow rays where it measures cheaper, 2 = always,
+        3 = always, surface-area metric, 0 = shadow rays share the closest-hit tree.  Bit-identical results for every value."""
+        self.set_ctx_option(2, mode, upload)
+
+    def set_closest_tree(self, mode, upload=True):
+        """RT_CTX_OPT_CLOSEST_TREE: 0 (default) = the reference's topology and order (bit-identical); 1 / 2 = TOLERANCE mode,
+        an own tree for closest-hit rays where it measures cheaper / always."""
+        self.set_ctx_option(3, mode, upload)
+
+    def tree_report(self):
+        from . import capi
+        return capi.load().rt_scene_tree_report(self.lib.rth_render_ctx_handle(self.handle)).decode()
+
     def resolve_now(self):
         out = np.zeros((self.local_rows, self.width, 4), np.float32)
         self._c(self.lib.rth_render_resolve(self.handle, out.ctypes.data))
