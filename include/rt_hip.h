@@ -63,7 +63,7 @@ enum rt_ctx_option
                                       query) by a full-sweep SAH on the projected area along the scene's directional lights
                                       (+ 50 % isotropic; surface area when there are only point lights); rt_scene_upload
                                       walks it and the reference's topology with proxy shadow rays and keeps the own tree if it
-                                      saves more than 2 % of the steps (rt_scene_tree_report).  Verdicts equal TraceBvh
+                                      saves more than 10 % of the steps (rt_scene_tree_report).  Verdicts equal TraceBvh
                                       -DSHADOW_RAYS bit for bit on either (trace_bvh.cl:107-109,164-167).  2: the own tree
                                       unconditionally; 3: the own tree with the surface-area metric (A/B); 0: shadow rays share
                                       the closest-hit tree */

@@ -708,7 +708,8 @@ ownbvh::Metric shadow_metric(const rt_light* lights, uint32_t n, double iso_shar
 }
 
 // Which tree a ray population walks: the candidate of own_bvh.h against the reference's own topology (`ref_wide`), both
-// walked by proxy rays of that population (tree_select.h).  mode 1: own only if it saves more than 2 % of the steps;
+// walked by proxy rays of that population (tree_select.h).  mode 1: own only if it saves more than 10 % of the steps (the proxy rays are not the
+// camera's: a tree that promised 6 % fewer steps on the ShaderBalls-class scene made its shadow trace 10 % slower, profiles/r04_call01_*);
 // mode 2: own whatever it costs (A/B runs); mode 3 (shadow): own with the plain surface-area metric, unconditionally (A/B).
 struct OwnTree
 {
@@ -753,7 +754,7 @@ bool choose_tree(const rt_scene_desc* sd, const std::vector<WideNode>& ref_wide,
     if (rays.empty()) { report += shadow ? "shadow tree: no lights, nothing to measure -> reference topology\n" : "closest-hit tree: nothing to measure -> reference topology\n"; return false; }
     const double c_ref = treesel::walk_cost((const treesel::Record*)ref_wide.data(), (uint32_t)ref_wide.size(), ref_entry, sd->nodes, leaf_of_first.data(), sd->triangles, rays, shadow);
     const double c_own = treesel::walk_cost((const treesel::Record*)own.wide.data(), (uint32_t)own.wide.size(), own.entry, sd->nodes, leaf_of_first.data(), sd->triangles, rays, shadow);
-    const bool pick = c_own < 0.98 * c_ref;
+    const bool pick = c_own < 0.90 * c_ref;
     snprintf(line, sizeof(line), "%s tree: reference topology %.2f steps per proxy ray, %s %.2f -> %s\n", shadow ? "shadow" : "closest-hit", c_ref, own.name, c_own,
         pick ? "own" : "reference topology");
     report += line;
