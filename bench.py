@@ -75,11 +75,15 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MI
 LIGHT = ((-0.6, -1.5, 3.5), (15.0, 10.0, 5.0))   # reference main.cpp:58
 COUNTERS_FILE = os.path.join(ROOT, "profiles", "r03_trace_counters.json")
 VISIT_MICROBENCH_FILE = os.path.join(ROOT, "profiles", "r03_visit_microbench.json")
-SENSITIVITY_FILE = os.path.join(ROOT, "profiles", "r02_kernel_sensitivity.json")
 
 
+SURVEY_A_ACTIVE = [65536, 65536, 51957, 44567, 38383]      # CornellBox.obj 256x256, sample 0, max_bounces 4
+SURVEY_A_SHADOW = [48811, 30720, 25639, 22474, 19484]
 # BASELINE.json configs (index = position in "configs"); config 1 is the CPU plumbing case.
 CONFIGS = {
+    1: dict(width=256, height=256, bounces=4, samples_per_step=1, name="BASELINE configs[0] exactly: assets/CornellBox.obj as shipped, the reference's default "
+            "camera and light (camera_controller.cpp:30-41, main.cpp:58), sampler kRandom; on the GPU here, with the reference's own "
+            "kernels on the host cores as cpu_baseline (the config's own definition: SURVEY 8d 'Config 1')"),
     2: dict(width=1280, height=720, bounces=8, samples_per_step=256, name="BASELINE configs[1] stand-in: Cornell shell + %(blob)d-tri displaced "
             "blob (dragon mtl) + %(ball)d-tri sphere (teapot mtl)"),
     3: dict(width=1920, height=1080, bounces=3, samples_per_step=128, name="BASELINE configs[2] stand-in: ShaderBalls.mtl 3x3 material grid on "
@@ -101,6 +105,8 @@ def build_scene(args, host, S, finish=True):
     if getattr(args, "scene", None):
         # a real asset: OBJ/MTL through the C++ loader, or a binary cache written by rt_render --save-cache
         scene = host.Scene(args.scene, scale=args.scale, flip_yz=args.flip_yz, wide_texture_indices=getattr(args, "wide_texture_indices", False))
+    elif args.config == 1:
+        scene = host.Scene(os.path.join(ROOT, "assets", "CornellBox.obj"))     # the one asset of BASELINE's configs the repository holds
     elif args.config == 3:
         import tempfile
         path = S.shader_balls_obj(tempfile.mkdtemp(prefix="rt_bench_"), 100_000)
@@ -342,7 +348,7 @@ def per_frame_leg(args, render, lib, frame, capi, frames, resolve=True):
                              "src/integrator/integrator.cpp:27-59)")
 
 
-def roofline_object(args, world, agg, prof, per_ray, spp_timed, isolated):
+def roofline_object(args, world, live_step, per_ray, isolated):
     """`roofline` for the dominant kernel, the closest-hit traversal (k_trace_w4<closest>).  Every number follows a stated
     formula from (a) what this run measured live with HIP events on the library's streams and (b) committed counter files
     under profiles/, each tied to the code object it was collected from (`stale` when that is not the library running now).
@@ -356,19 +362,13 @@ def roofline_object(args, world, agg, prof, per_ray, spp_timed, isolated):
                                        (tools/visit_microbench.hip: fetch a 64-byte node -> dequantise -> 4 slab tests -> order ->
                                        LDS push / pop, every lane busy, nothing else) at its best residency and the kernel's own
                                        L1 / L2 hit mix:  ceiling_grays = visits_per_s / steps_per_ray."""
-    n_launch = max(prof.n_trace_closest, 1) * world
-    ms_sum = agg[2]
-    avg_ms = ms_sum / n_launch
-    rays_per_launch = agg[0] / n_launch
     bytes_closest = 48.0 + 32.0 * per_ray["closest_nodes"] + 36.0 * per_ray["closest_tris"]     # SURVEY 8d, per ray
-    live = dict(kernel="closest-hit traversal (k_trace_w4<closest> + its k_trace2 follow-up)",
-                rays_per_launch=round(rays_per_launch, 1), avg_launch_ms=round(avg_ms, 5),
-                mrays_per_s=round(agg[0] / (ms_sum * 1e-3) / 1e6, 1) if ms_sum > 0 else 0.0,
-                kernel_ms_per_spp=dict(trace_closest=round(agg[2] / world / spp_timed, 4), trace_shadow=round(agg[3] / world / spp_timed, 4),
-                                        shade=round(agg[4] / world / spp_timed, 4), raygen=round(agg[5] / world / spp_timed, 4)),
-                note="HIP-event SPANS inside the timed region: the shadow trace of bounce b runs beside the closest-hit trace of "
-                     "bounce b + 1 on a second stream, so these spans overlap and are NOT a cost breakdown (their sum exceeds "
-                     "ms_per_spp); live_isolated has the costs")
+    avg_ms = live_step["avg_launch_ms"] if live_step else 0.0
+    rays_per_launch = live_step["rays_per_launch"] if live_step else 0.0
+    live = dict(live_step or {}, kernel="closest-hit traversal (k_trace_w4<closest> + its k_trace2 follow-up)",
+                note="HIP-event SPANS of one more, UNTIMED step in the timed region's own mode (the timed region itself carries no "
+                     "instrumentation): the shadow trace of bounce b runs beside the closest-hit trace of bounce b + 1 on a second "
+                     "stream, so these spans overlap and are NOT a cost breakdown (their sum exceeds ms_per_spp); live_isolated has the costs")
     # the kernel alone on the machine (one more, untimed step with every launch on one stream) is what the counters describe
     iso_ms = isolated["avg_launch_ms"] if isolated else avg_ms
     iso_rays = isolated["rays_per_launch"] if isolated else rays_per_launch
@@ -432,12 +432,6 @@ def roofline_object(args, world, agg, prof, per_ray, spp_timed, isolated):
                 source=os.path.relpath(VISIT_MICROBENCH_FILE, ROOT) + " (tools/visit_microbench.hip on MI355X)")
     except Exception:
         pass
-    try:
-        if args.config == 4:
-            sens = json.load(open(SENSITIVITY_FILE))
-            out["sensitivity"] = dict(sens["k_trace_w4_closest"], source="profiles/r02_kernel_sensitivity.json (round 2's kernel: gpurun calls 43 / 44)")
-    except Exception:
-        pass
     return out
 
 
@@ -481,7 +475,7 @@ def main():
                     "where it measures cheaper; 2 always; 3 always, surface-area metric; 0 shared with the closest-hit rays).  Bit-identical for every value.")
     ap.add_argument("--closest-tree", type=int, default=None, help="RT_CTX_OPT_CLOSEST_TREE (library default 0 = bit-identical; 1 / 2 = TOLERANCE mode: "
                     "an own tree for closest-hit rays where it measures cheaper / always)")
-    ap.add_argument("--compact-log", type=int, default=None, help="RT_OPT_COMPACT_LOG (library default 1)")
+    ap.add_argument("--compact-log", type=int, default=None, help="RT_OPT_COMPACT_LOG (library default 2: compact only when the path state is bounded; 1 = always for batches of >= 8 samples; 0 = never)")
     ap.add_argument("--per-frame-frames", type=int, default=48, help="frames of the per_frame leg (the reference's call pattern, "
                     "one Integrate() per frame); 0 = skip it")
     ap.add_argument("--per-frame-only", action="store_true", help="run only the per_frame leg and print its object (tuning runs)")
@@ -666,9 +660,7 @@ def main():
     # the timed region starts from a reset accumulation (sample indices 0..K-1, counters at 0)
     assert lib.rt_reset(frame) == 0
     st0 = render.stats()
-    lib.rt_set_option(frame, capi.OPT_PROFILE, 1)
-    prof = capi.rt_profile()
-    lib.rt_frame_get_profile(frame, prof)                  # drain
+    lib.rt_set_option(frame, capi.OPT_PROFILE, 0)          # nothing but the work inside the timed region: no event pairs around the launches
     if world > 1:
         dist.barrier()
     sync()
@@ -687,12 +679,9 @@ def main():
     dt = time.perf_counter() - t0
 
     st1 = render.stats()
-    lib.rt_frame_get_profile(frame, prof)
-    lib.rt_set_option(frame, capi.OPT_PROFILE, 0)
     closest = st1.closest_rays - st0.closest_rays
     shadow = st1.shadow_rays - st0.shadow_rays
-    agg = torch.tensor([float(closest), float(shadow), prof.ms_trace_closest, prof.ms_trace_shadow, prof.ms_shade,
-                        prof.ms_raygen], dtype=torch.float64)
+    agg = torch.tensor([float(closest), float(shadow)], dtype=torch.float64)
     tmax = torch.tensor([dt, t_render, t_local - t_render], dtype=torch.float64)
     tmin = torch.tensor([t_render], dtype=torch.float64)
     if world > 1:
@@ -704,6 +693,10 @@ def main():
     # every rank's own numbers, so that imbalance is attributable (not only min / max)
     mine = dict(rank=rank, render_ms=round(t_render * 1e3, 3), gather_ms=round((t_local - t_render) * 1e3, 3), setup_s=round(t_setup, 2),
                 scene_s=round(t_scene, 2), rows=int(local_rows), rays=float(closest + shadow),
+                # did the launches stay full as the tile shrank?  samples this rank keeps in flight, and the closest-hit rays of an
+                # average launch (bounce 0 carries rows x width x in_flight of them)
+                in_flight=int(in_flight), rays_per_launch=round(float(closest) / max(-(-spp_timed // max(int(in_flight), 1)) * (args.bounces + 1), 1), 1),
+                rays_in_first_launch=int(local_rows) * args.width * int(in_flight),
                 rccl=(list(group.comm_count()) if group is not None else None))
     per_rank = [mine]
     if world > 1:
@@ -750,26 +743,32 @@ def main():
     # One more step, untimed, with every launch on one stream: in the timed region the shadow trace of bounce b runs
     # beside the closest-hit trace of bounce b + 1 (RT_OPT_OVERLAP_SHADOW), so the launch durations there include the
     # sharing; this step gives the kernels' durations alone on the machine (what the rocprofv3 --pmc passes see).
-    isolated = None
-    overlap_on = args.overlap_shadow is None or args.overlap_shadow != 0
-    if world == 1 and overlap_on:
-        assert lib.rt_set_option(frame, capi.OPT_OVERLAP_SHADOW, 0) == 0
+    def profiled_step(overlap, what):
+        """one more step of sps samples, UNTIMED, with HIP-event pairs around every launch (RT_OPT_PROFILE_KERNELS)"""
+        assert lib.rt_set_option(frame, capi.OPT_OVERLAP_SHADOW, 1 if overlap else 0) == 0
         lib.rt_set_option(frame, capi.OPT_PROFILE, 1)
+        p = capi.rt_profile()
+        lib.rt_frame_get_profile(frame, p)                  # drain
         st_a = render.stats()
         render.render_samples(sps)
         render.finish()
         st_b = render.stats()
-        prof_iso = capi.rt_profile()
-        lib.rt_frame_get_profile(frame, prof_iso)
+        lib.rt_frame_get_profile(frame, p)
         lib.rt_set_option(frame, capi.OPT_PROFILE, 0)
-        assert lib.rt_set_option(frame, capi.OPT_OVERLAP_SHADOW, 1) == 0
-        n_iso = max(prof_iso.n_trace_closest, 1)
-        rays_iso = float(st_b.closest_rays - st_a.closest_rays)
-        isolated = dict(what="one more step of %d spp with RT_OPT_OVERLAP_SHADOW = 0 (untimed): each kernel alone on the machine" % sps,
-                        avg_launch_ms=round(prof_iso.ms_trace_closest / n_iso, 5), rays_per_launch=round(rays_iso / n_iso, 1),
-                        mrays_per_s=round(rays_iso / (prof_iso.ms_trace_closest * 1e-3) / 1e6, 1) if prof_iso.ms_trace_closest > 0 else 0.0,
-                        kernel_ms_per_spp=dict(trace_closest=round(prof_iso.ms_trace_closest / sps, 4), trace_shadow=round(prof_iso.ms_trace_shadow / sps, 4),
-                                               shade=round(prof_iso.ms_shade / sps, 4), raygen=round(prof_iso.ms_raygen / sps, 4)))
+        n = max(p.n_trace_closest, 1)
+        rays = float(st_b.closest_rays - st_a.closest_rays)
+        return dict(what=what, avg_launch_ms=round(p.ms_trace_closest / n, 5), rays_per_launch=round(rays / n, 1),
+                    mrays_per_s=round(rays / (p.ms_trace_closest * 1e-3) / 1e6, 1) if p.ms_trace_closest > 0 else 0.0,
+                    kernel_ms_per_spp=dict(trace_closest=round(p.ms_trace_closest / sps, 4), trace_shadow=round(p.ms_trace_shadow / sps, 4),
+                                           shade=round(p.ms_shade / sps, 4), raygen=round(p.ms_raygen / sps, 4)))
+
+    isolated, live_step = None, None
+    overlap_on = args.overlap_shadow is None or args.overlap_shadow != 0
+    if world == 1:
+        live_step = profiled_step(overlap_on, "one more step of %d spp in the timed region's mode (untimed, instrumented)" % sps)
+        if overlap_on:
+            isolated = profiled_step(False, "one more step of %d spp with RT_OPT_OVERLAP_SHADOW = 0 (untimed): each kernel alone on the machine" % sps)
+            assert lib.rt_set_option(frame, capi.OPT_OVERLAP_SHADOW, 1) == 0
 
     per_frame = None
     if world == 1 and args.per_frame_frames > 0:
@@ -808,13 +807,26 @@ def main():
                                         "raytracing_amd/csrc/rt_detmath.h, same frame and samples; %d pixels differ" %
                                         int((~((got == libm_img) | (np.isnan(got) & np.isnan(libm_img))).all(-1)).sum()))
                 parity["libm_build_within_tolerance"] = bool(parity["rel_l2_vs_libm_build"] < 1e-4)     # reported, not asserted: the bit-exact pin is libref.so
-            assert parity["rel_l2"] < 1e-4, "radiance differs from the reference kernels: %r" % parity
+            assert parity["rel_l2"] < 1e-4 or args.closest_tree, "radiance differs from the reference kernels: %r" % parity
+            if args.config == 1 and world == 1:
+                # BASELINE configs[0] has published per-sample counts (SURVEY.md 8d "Config 1" / Appendix A: the reference's own
+                # Scene + Bvh + unmodified kernels over glibc libm, sample index 0): the GPU's queue counters for that sample
+                assert lib.rt_reset(frame) == 0
+                render.render_samples(1)
+                s1 = render.stats()
+                parity["config_1_sample_0"] = dict(
+                    closest_rays=int(s1.closest_rays), shadow_rays=int(s1.shadow_rays),
+                    active_per_bounce=[int(x) for x in s1.last_active[:args.bounces + 1]], shadow_per_bounce=[int(x) for x in s1.last_shadow[:args.bounces + 1]],
+                    survey_appendix_a=dict(closest_rays=265979, shadow_rays=147128, active_per_bounce=SURVEY_A_ACTIVE, shadow_per_bounce=SURVEY_A_SHADOW),
+                    equals_survey=bool(int(s1.closest_rays) == 265979 and int(s1.shadow_rays) == 147128 and
+                                       [int(x) for x in s1.last_active[:5]] == SURVEY_A_ACTIVE and [int(x) for x in s1.last_shadow[:5]] == SURVEY_A_SHADOW)
+                    if (args.width, args.height, args.bounces) == (256, 256, 4) else None)
         else:
             # NaN pixels are legal in the reference arithmetic (inf * 0 in the mirror branch, material.h:79-81,230: coarse
             # mirror spheres produce them by the hundred, and the reference produces the same ones -- `parity` compares them
             # when the CPU leg runs); reported as config.non_finite_pixels, and a frame FULL of them is a bug
             assert nan_px <= 1e-2 * args.width * args.height, "too many non-finite pixels: %d" % nan_px
-        roofline = roofline_object(args, world, agg, prof, per_ray, spp_timed, isolated)
+        roofline = roofline_object(args, world, live_step, per_ray, isolated)
         if isolated is not None:
             roofline["live_isolated"] = isolated
         name, cus, mem = render_ctx_info(capi, host, render)
@@ -831,7 +843,7 @@ def main():
         line = dict(metric="Mrays/s (all bounces+shadow)", value=round(value, 2), unit="Mrays/s", n_gpus=world,
                     steps=args.steps, warmup=args.warmup, ms_per_step=round(dt_max * 1e3 / args.steps, 4),
                     ms_per_spp=round(dt_max * 1e3 / spp_timed, 4),
-                    higher_is_better=True, scaling="strong", vs_baseline=None, dtype="f32", data="real" if args.scene else "synthetic",
+                    higher_is_better=True, scaling="strong", vs_baseline=None, dtype="f32", data="real" if (args.scene or args.config == 1) else "synthetic",
                     config=dict(workload=(("scene file %s (scale %g, flip_yz %d)" % (os.path.basename(args.scene), args.scale, args.flip_yz))
                                           if args.scene else (cfg["name"] % dict(blob=args.blob_tris, ball=args.ball_tris))) +
                                          ", %dx%d, %d-bounce, %d spp per step, default camera, directional light + "
@@ -851,7 +863,9 @@ def main():
                                render_ms=[r["render_ms"] for r in per_rank], gather_ms=[r["gather_ms"] for r in per_rank],
                                setup_s=[r["setup_s"] for r in per_rank], setup_s_max=max(r["setup_s"] for r in per_rank),
                                scene_s=[r["scene_s"] for r in per_rank], rows=[r["rows"] for r in per_rank],
-                               mrays=[round(r["rays"] / 1e6, 1) for r in per_rank], scene=scene_source),
+                               mrays=[round(r["rays"] / 1e6, 1) for r in per_rank], scene=scene_source,
+                               in_flight=[r["in_flight"] for r in per_rank], rays_per_launch=[r["rays_per_launch"] for r in per_rank],
+                               rays_in_first_launch=[r["rays_in_first_launch"] for r in per_rank]),
                     gather=gather_info, per_frame=per_frame, roofline=roofline, parity=parity, cpu_baseline=baseline)
         print(json.dumps(line), flush=True)
     if world > 1:

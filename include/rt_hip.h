@@ -314,6 +314,10 @@ int rt_frame_copy_radiance(rt_frame* frame, void* device_dst);
 typedef struct rt_group rt_group;
 #define RT_GROUP_ID_BYTES 128
 int rt_group_create(int n, const int* device_ordinals, rt_group** out);
+/* rt_group_create without this library's own one-rank-per-device check, so that the list reaches ncclCommInitAll whatever it
+ * holds and RCCL's own answer comes back through rt_group_last_error: the wiring test of the in-process path on a one-GPU box
+ * ({0, 0} must fail with RCCL's refusal).  Not for products. */
+int rt_group_create_unchecked(int n, const int* device_ordinals, rt_group** out);
 int rt_group_unique_id(void* id_bytes, size_t capacity);
 int rt_group_join(int nranks, int rank, const void* id_bytes, int device_ordinal, rt_group** out);
 int rt_group_size(rt_group* group);                     /* ranks in the group */

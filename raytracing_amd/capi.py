@@ -66,6 +66,7 @@ EXPORTS = [
     "rt_debug_wide_bvh", "rt_frame_debug_timeline", "rt_debug_own_bvh", "rt_debug_wide_bvh_metric", "rt_scene_tree_report", "rt_debug_choose_tree",
     "rt_group_create", "rt_group_unique_id", "rt_group_join", "rt_group_size", "rt_group_local_count", "rt_group_local_rank", "rt_group_comm_count",
     "rt_group_gather_radiance", "rt_group_destroy", "rt_group_last_error", "rt_group_denoise", "rt_group_create_local",
+    "rt_group_create_unchecked",
 ]
 
 OPT_MAX_BOUNCES, OPT_WHITE_FURNACE, OPT_SAMPLER, OPT_AOV, OPT_DENOISER, OPT_DROP_LAST, OPT_PROFILE, OPT_TRACE_VARIANT, OPT_TRACE_WAVES, OPT_SAMPLES_IN_FLIGHT, OPT_SELECT_FORM_BOX, OPT_PACKET_BOUNCES, OPT_TRACE_TUNE, OPT_DEBUG_ALLOC_LIMIT, OPT_PATH_STATE_LIMIT_MB, OPT_PIPELINES, OPT_SHADE_PARTITION, OPT_OVERLAP_SHADOW, OPT_SMALL_LAUNCH_PATHS, OPT_COMPACT_LOG, OPT_DEBUG_LOG_POOL_DIV = range(21)
@@ -115,7 +116,8 @@ def load():
         "rt_debug_choose_tree": (i32, [C.POINTER(rt_scene_desc), i32, u32, vp, u32, C.POINTER(u32), C.POINTER(u32), C.c_char_p, sz]),
         "rt_debug_own_bvh": (i32, [vp, u32, C.c_double, vp, u32, vp, u32, C.POINTER(u32)]),
         "rt_debug_wide_bvh_metric": (i32, [vp, u32, C.c_double, vp, u32, vp, u32, C.POINTER(u32), C.POINTER(u32)]),
-        "rt_group_create": (i32, [i32, C.POINTER(i32), C.POINTER(vp)]), "rt_group_unique_id": (i32, [vp, sz]),
+        "rt_group_create": (i32, [i32, C.POINTER(i32), C.POINTER(vp)]), "rt_group_create_unchecked": (i32, [i32, C.POINTER(i32), C.POINTER(vp)]),
+        "rt_group_unique_id": (i32, [vp, sz]),
         "rt_group_join": (i32, [i32, i32, vp, i32, C.POINTER(vp)]), "rt_group_size": (i32, [vp]),
         "rt_group_local_count": (i32, [vp]), "rt_group_local_rank": (i32, [vp, i32]),
         "rt_group_comm_count": (i32, [vp, i32, C.POINTER(i32), C.POINTER(i32)]),
@@ -374,11 +376,12 @@ class Group:
         self.handle = handle
 
     @classmethod
-    def create(cls, devices):
+    def create(cls, devices, unchecked=False):
+        """unchecked: rt_group_create_unchecked -- the device list goes to ncclCommInitAll as it is (wiring test)"""
         lib = load()
         arr = (C.c_int * len(devices))(*devices)
         h = C.c_void_p()
-        if lib.rt_group_create(len(devices), arr, C.byref(h)) != 0:
+        if (lib.rt_group_create_unchecked if unchecked else lib.rt_group_create)(len(devices), arr, C.byref(h)) != 0:
             raise RtError(lib.rt_group_last_error(None).decode())
         return cls(h)
 

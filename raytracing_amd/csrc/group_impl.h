@@ -134,7 +134,15 @@ extern "C" {
 
 const char* rt_group_last_error(rt_group* g) { return g ? g->error.c_str() : g_thread_error.c_str(); }
 
-int rt_group_create(int n, const int* device_ordinals, rt_group** out)
+static int group_create_impl(int n, const int* device_ordinals, rt_group** out, bool check_duplicates);
+int rt_group_create(int n, const int* device_ordinals, rt_group** out) { return group_create_impl(n, device_ordinals, out, true); }
+// The same call WITHOUT this library's own one-rank-per-device check: whatever the device list, it reaches ncclCommInitAll, and
+// what RCCL answers comes back through rt_group_last_error.  For the wiring test a one-GPU box allows -- {0, 0} must fail with
+// RCCL's own refusal, which proves the in-process path (`rt_render --gpus N`, TiledRender) is wired to the library up to
+// communicator creation -- not for products.
+int rt_group_create_unchecked(int n, const int* device_ordinals, rt_group** out) { return group_create_impl(n, device_ordinals, out, false); }
+
+static int group_create_impl(int n, const int* device_ordinals, rt_group** out, bool check_duplicates)
 {
     if (!out || n <= 0 || !device_ordinals) return gfail(nullptr, "rt_group_create: bad argument");
     *out = nullptr;
@@ -145,7 +153,7 @@ int rt_group_create(int n, const int* device_ordinals, rt_group** out)
     for (int i = 0; i < n; ++i)
     {
         if (device_ordinals[i] < 0 || device_ordinals[i] >= ndev) return gfail(nullptr, "rt_group_create: bad device ordinal");
-        for (int j = 0; j < i; ++j)
+        for (int j = 0; j < i && check_duplicates; ++j)
             if (device_ordinals[j] == device_ordinals[i]) return gfail(nullptr, "rt_group_create: one rank per device (RCCL refuses two ranks on one GPU)");
     }
     std::vector<ncclComm_t> comms((size_t)n);

@@ -58,6 +58,7 @@ struct rt_ctx
     uint32_t shadow_tree = 1;     // RT_CTX_OPT_SHADOW_TREE: 1 = shadow rays walk the backend's own tree where it measures cheaper (exact either way),
                                   // 2 = own unconditionally, 3 = own with the surface-area metric (A/B), 0 = they share the closest-hit tree
     uint32_t closest_tree = 0;    // RT_CTX_OPT_CLOSEST_TREE: 1 / 2 as above; != 0 is the tolerance mode (NOT bit-exact)
+    std::vector<rt_frame*> frames;   // the frames alive on this context (rt_finish waits for their side streams too)
     uint8_t* blue_noise = nullptr;   // sobol[65536] | scramblingTile[131072] | rankingTile[131072]
     float* gamma_lut = nullptr;      // pow(byte / 255, 2.2f), 256 entries (k_fill_gamma_lut)
 };
@@ -169,6 +170,8 @@ struct rt_frame
     std::vector<hipEvent_t> event_pool;
 };
 
+int sync_frame_streams(rt_frame* f);
+
 namespace
 {
 int fail(rt_ctx* ctx, const std::string& msg)
@@ -253,7 +256,12 @@ int rt_ctx_destroy(rt_ctx* ctx)
 int rt_finish(rt_ctx* ctx)
 {
     if (!ctx) return fail(nullptr, "rt_finish: ctx is NULL");
+    (void)hipSetDevice(ctx->device);
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    // ... and for whatever the frames put on streams of their own: chunks on other pipes, shadow traces on the side streams
+    // (the stage API sends them there too since round 3) -- Finish() means everything (cl_context.cpp:115-118)
+    for (rt_frame* f : ctx->frames)
+        if (sync_frame_streams(f) != RT_OK) return RT_ERROR;
     return RT_OK;
 }
 
@@ -999,6 +1007,10 @@ int rt_scene_upload(rt_ctx* ctx, const rt_scene_desc* sd)
     s.n_wide_cl = have_cl ? (uint32_t)own_cl.wide.size() : 0u;
     s.wide_ok = have_wide;
     s.offsets32 = (uint64_t)(n_interior + 1) * 64 <= 0xFFFFFFFFull && (uint64_t)nt * 64 <= 0xFFFFFFFFull;
+    if (!s.offsets32)
+        fprintf(stderr, "rt_scene_upload: warning: the node or trace-triangle records reach 4 GiB (%u interior nodes, %u triangles): k_trace_w4 and k_trace2 "
+                        "address them with 32-bit byte offsets, so every launch takes the per-ray kernel k_trace_v1 -- correct, and several times slower\n",
+            n_interior, nt);
     s.valid = true;
     return RT_OK;
 }
@@ -1228,7 +1240,7 @@ int ensure_pipe_resources(rt_frame* f, uint32_t count)
     return RT_OK;
 }
 
-int flush_log(rt_frame* f);
+int flush_log(rt_frame* f, bool keep_open = false);
 int ensure_whole_tile(rt_frame* f);
 
 // The main stream of the current pipe waits for the shadow trace that last used shadow queue `q` (rt_integrate runs
@@ -1293,7 +1305,7 @@ int ensure_whole_tile(rt_frame* f)
 }
 
 // Adds the logged contributions of the batch in flight to the running sum.
-int flush_log(rt_frame* f)
+int flush_log(rt_frame* f, bool keep_open)
 {
     rt_ctx* ctx = f->ctx;
     if (f->p->cur_slots == 0 || f->n_local == 0 || f->p->chunk_count == 0) { f->p->cur_slots = 0; return RT_OK; }
@@ -1302,18 +1314,34 @@ int flush_log(rt_frame* f)
     if (wait_shadow(f, 0) != RT_OK || wait_shadow(f, 1) != RT_OK) return RT_ERROR;   // their verdicts are in the log
     uint32_t blocks = (f->p->chunk_count + 255u) / 256u;
     hipLaunchKernelGGL(k_flush, dim3(blocks), dim3(256), 0, f->p->stream, f->radiance + f->p->chunk_base, dlog(f),
-        f->p->chunk_count, f->p->cur_slots, f->chunk_pixels);
+        f->p->chunk_count, f->p->cur_slots, f->chunk_pixels, keep_open && f->log_ovf_blocks != 0u ? 1u : 0u);
     if (hipGetLastError() != hipSuccess) return fail(ctx, "k_flush launch failed");
     f->p->cur_slots = 0;
     return RT_OK;
 }
 
+} // namespace
+
+// waits (host side) for every stream a frame launches on besides the context's own
+int sync_frame_streams(rt_frame* f)
+{
+    rt_ctx* ctx = f->ctx;
+    for (PathPipe& q : f->ps)
+    {
+        if (q.stream && q.stream != ctx->stream) HIPCHK(ctx, hipStreamSynchronize(q.stream));
+        if (q.side) HIPCHK(ctx, hipStreamSynchronize(q.side));
+    }
+    return RT_OK;
+}
+
+namespace
+{
 // Mid-sample read (stage API / debugging): apply what has been logged so far but
 // keep the sample open -- later contributions append again from entry 0.
 int flush_log_keep(rt_frame* f)
 {
     uint32_t keep = f->p->cur_slots;
-    int rc = flush_log(f);
+    int rc = flush_log(f, true);
     f->p->cur_slots = keep;
     return rc;
 }
@@ -1375,6 +1403,7 @@ int rt_frame_create(rt_ctx* ctx, const rt_frame_desc* fd, rt_frame** out)
     memset(&f->camera_last, 0, sizeof(f->camera_last));
     memset(&f->prev_camera, 0, sizeof(f->prev_camera));
     *out = f;
+    ctx->frames.push_back(f);
     return rt_reset(f);                                  // the reference ctor ends with Reset(), cl_pt_integrator.cpp:258
 }
 
@@ -1382,6 +1411,7 @@ int rt_frame_destroy(rt_frame* f)
 {
     if (!f) return RT_OK;
     (void)hipSetDevice(f->ctx->device);
+    f->ctx->frames.erase(std::remove(f->ctx->frames.begin(), f->ctx->frames.end(), f), f->ctx->frames.end());
     for (PathPipe& q : f->ps)
     {
         if (q.stream) (void)hipStreamSynchronize(q.stream);
@@ -2041,7 +2071,7 @@ int rt_frame_get_stats(rt_frame* f, rt_stats* out)
     if (!f || !out) return fail(nullptr, "rt_frame_get_stats: NULL argument");
     rt_ctx* ctx = f->ctx;
     (void)hipSetDevice(ctx->device);
-    if (join_pipes(f) != RT_OK) return RT_ERROR;
+    if (join_pipes(f) != RT_OK || sync_frame_streams(f) != RT_OK) return RT_ERROR;   // a shadow trace on a side stream still counts rays
     memset(out, 0, sizeof(*out));
     for (uint32_t i = 0; i < RT_MAX_PIPES; ++i)              // the pipes' counters add up
     {
@@ -2075,7 +2105,7 @@ int rt_frame_get_profile(rt_frame* f, rt_profile* out)
     if (!f || !out) return fail(nullptr, "rt_frame_get_profile: NULL argument");
     rt_ctx* ctx = f->ctx;
     (void)hipSetDevice(ctx->device);
-    if (join_pipes(f) != RT_OK) return RT_ERROR;
+    if (join_pipes(f) != RT_OK || sync_frame_streams(f) != RT_OK) return RT_ERROR;   // spans on the side streams end when their launches do
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     memset(out, 0, sizeof(*out));
     double* ms[4] = {&out->ms_raygen, &out->ms_trace_closest, &out->ms_shade, &out->ms_trace_shadow};

@@ -698,7 +698,11 @@ __global__ __launch_bounds__(RT_SHADE_BLOCK) __attribute__((amdgpu_waves_per_eu(
 // Replays the radiance log: for every pixel, sample slot by sample slot, contribution
 // by contribution -- the exact order in which the reference's kernels executed
 // `radiance[pixel] += ...` (miss.cl:75, hit_surface.cl:110, accumulate_direct_samples.cl:51).
-__global__ __launch_bounds__(256) void k_flush(float4* __restrict__ radiance, DLog log, uint32_t n_pixels, uint32_t n_slots, uint32_t id_stride)
+// keep_open (a mid-sample read through the stage API on a COMPACT allocation): the sample goes on, and its count and its
+// overflow block must stay what k_shade knows them to be -- the entries replayed here are zeroed instead (adding +0.0 again
+// at the sample's end is the identity), the count is kept.  The full layout restarts the count at 0 as it always did.
+__global__ __launch_bounds__(256) void k_flush(float4* __restrict__ radiance, DLog log, uint32_t n_pixels, uint32_t n_slots, uint32_t id_stride,
+    uint32_t keep_open)
 {
     // radiance: already offset to the chunk's first pixel; id_stride: pixels per chunk as allocated
     uint32_t p = blockIdx.x * 256u + threadIdx.x;
@@ -711,10 +715,13 @@ __global__ __launch_bounds__(256) void k_flush(float4* __restrict__ radiance, DL
         const uint32_t oblk = c > log.inline_entries ? log.ovf_slot[id] : 0u;       // compact layout: the path's overflow block
         for (uint32_t k = 0; k < c; ++k)
         {
-            const rt_rgb v = *reinterpret_cast<const rt_rgb*>(log.rlog + 3 * log_index(log, k, id, oblk));
+            const size_t at = log_index(log, k, id, oblk);
+            if (at == ~(size_t)0) continue;                                          // no home (pool ran dry: log_put skipped it too)
+            const rt_rgb v = *reinterpret_cast<const rt_rgb*>(log.rlog + 3 * at);
             r.x += v.x; r.y += v.y; r.z += v.z;
+            if (keep_open) log_store(log.rlog, at, 0.0f, 0.0f, 0.0f);
         }
-        if (c) log.cnt[id] = 0;
+        if (c && !keep_open) log.cnt[id] = 0;
     }
     radiance[p] = r;
 }

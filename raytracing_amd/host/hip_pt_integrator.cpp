@@ -73,12 +73,23 @@ HIPPathTraceIntegrator::HIPPathTraceIntegrator(std::uint32_t width, std::uint32_
 {
     rt_frame_desc fd = {width, height, tile.rank, tile.count, tile.band_height};
     Check(rt_frame_create(context_.Get(), &fd, &frame_));
-    resolved_.assign((size_t)rt_frame_local_rows(frame_) * width * 4, 0.0f);
+    // a constructor that throws runs no destructor: whatever follows the frame's creation gives it back itself
+    try
+    {
+        resolved_.assign((size_t)rt_frame_local_rows(frame_) * width * 4, 0.0f);
+        CreateKernels();
+    }
+    catch (...)
+    {
+        rt_frame_destroy(frame_);
+        frame_ = nullptr;
+        throw;
+    }
     // ResolveRadiance() lands here every frame (the reference resolves into a GL image, cl_pt_integrator.cpp:677-684):
-    // page-locked, the read-back runs at the PCIe rate.  Best effort -- a refusal only costs speed.
+    // page-locked, the read-back runs at the PCIe rate.  Best effort -- a refusal only costs speed.  Registered LAST: nothing
+    // after it can throw and leave the vector's memory freed while still page-locked.
     resolved_pinned_ = !resolved_.empty() &&
         rt_host_register(context_.Get(), resolved_.data(), resolved_.size() * sizeof(float)) == RT_OK;
-    CreateKernels();
 }
 
 HIPPathTraceIntegrator::~HIPPathTraceIntegrator()

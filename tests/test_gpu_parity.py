@@ -710,6 +710,15 @@ def test_device_group_gather_through_the_c_abi(ctx, golden_scenes):
     g.close()
     with pytest.raises(capi.RtError, match="one rank per device"):
         capi.Group.create([0, 0])
+    # The same list past this library's own check: it reaches ncclCommInitAll -- the in-process path `rt_render --gpus N` and
+    # TiledRender use -- and the refusal that comes back is RCCL'S (an ncclResult string, not this library's sentence): the
+    # wiring up to communicator creation, proven with the one GPU there is.
+    with pytest.raises(capi.RtError) as e:
+        capi.Group.create([0, 0], unchecked=True)
+    assert "ncclCommInitAll" in str(e.value) and "one rank per device" not in str(e.value), str(e.value)
+    g = capi.Group.create([0], unchecked=True)             # ... and one rank still forms a communicator through that entry point
+    assert g.comm_count() == (1, 0)
+    g.close()
     with pytest.raises(capi.RtError, match="bad device ordinal"):
         capi.Group.create([0, 7])
 

@@ -60,17 +60,16 @@ def test_code_object_identity_and_the_stale_flag_of_the_roofline(tmp_path):
     assert codeobj.code_object_sha256(str(tmp_path / "missing.so")) is None
     k = dict(avg_launch_ms=14.7, hbm_bytes_per_launch=8.0e9, valu_busy=0.86, salu_busy=0.5, l1_ta_busy=0.79, hbm_frac=0.068,
              cycles_per_launch=3.45e7, per_launch=dict(l1_accesses=7.6e9), launches_profiled=27)
-    class Prof: n_trace_closest = 9
+    live = dict(avg_launch_ms=15.0, rays_per_launch=1.0e8, mrays_per_s=6666.7, kernel_ms_per_spp=dict(trace_closest=1.05, trace_shadow=0.5, shade=0.4, raygen=0.02))
     per_ray = dict(closest_nodes=77.7, closest_tris=2.9, closest_steps=24.07, closest_wide_visits=20.9)
     iso = dict(avg_launch_ms=14.7, rays_per_launch=1.0e8, kernel_ms_per_spp=dict(trace_closest=1.03, trace_shadow=0.36, shade=0.37, raygen=0.02))
     args = type("A", (), dict(config=4))()
-    agg = [9.0e8, 4.0e8, 9 * 15.0, 9 * 5.0, 9 * 5.5, 0.3]
     old = bench.COUNTERS_FILE
     try:
         for recorded, want_stale in ((digest, False), ("0" * 64, True)):
             bench.COUNTERS_FILE = str(tmp_path / "counters.json")
             json.dump({"config_4": {"closest": k}, "_code_object_sha256": recorded, "_how": "test"}, open(bench.COUNTERS_FILE, "w"))
-            r = bench.roofline_object(args, 1, agg, Prof, per_ray, 128, iso)
+            r = bench.roofline_object(args, 1, live, per_ray, iso)
             assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
             assert abs(r["achieved"] - 8.0e9 / 14.7e-3 / 1e9) < 0.1 and abs(r["frac"] - r["achieved"] / 8000.0) < 1e-4     # the stated formula
             assert r["traffic"] == 8.0e9 and r["stale"] is want_stale and r["counters"]["stale"] is want_stale
@@ -78,7 +77,7 @@ def test_code_object_identity_and_the_stale_flag_of_the_roofline(tmp_path):
             lc = r["latency_ceiling"]
             assert abs(lc["ceiling_grays"] - lc["best_gvisits_per_s"] / 24.07) < 1e-3 and abs(lc["frac_of_ceiling"] - lc["achieved_grays"] / lc["ceiling_grays"]) < 1e-3
         bench.COUNTERS_FILE = str(tmp_path / "none.json")
-        r = bench.roofline_object(args, 1, agg, Prof, per_ray, 128, iso)
+        r = bench.roofline_object(args, 1, live, per_ray, iso)
         assert r["achieved"] is None and "error" in r["counters"]                 # says so instead of silently changing `bound`
     finally:
         bench.COUNTERS_FILE = old
