@@ -475,6 +475,9 @@ def main():
                     "where it measures cheaper; 2 always; 3 always, surface-area metric; 0 shared with the closest-hit rays).  Bit-identical for every value.")
     ap.add_argument("--closest-tree", type=int, default=None, help="RT_CTX_OPT_CLOSEST_TREE (library default 0 = bit-identical; 1 / 2 = TOLERANCE mode: "
                     "an own tree for closest-hit rays where it measures cheaper / always)")
+    ap.add_argument("--tail-lanes", type=int, default=None, help="RT_OPT_TRACE_TAIL_LANES (library default 16; 0 = loop D off)")
+    ap.add_argument("--libm-series", default=None, help="sample counts (e.g. 1,2,4,8) of parity.rel_l2_vs_libm_build_series: the HIP path against the "
+                    "reference's kernels over glibc libm on a 960x540 frame of the same scene (default: 1,2,4,8 for --config 5, off elsewhere; '' = off)")
     ap.add_argument("--compact-log", type=int, default=None, help="RT_OPT_COMPACT_LOG (library default 2: compact only when the path state is bounded; 1 = always for batches of >= 8 samples; 0 = never)")
     ap.add_argument("--per-frame-frames", type=int, default=48, help="frames of the per_frame leg (the reference's call pattern, "
                     "one Integrate() per frame); 0 = skip it")
@@ -627,6 +630,8 @@ def main():
         assert lib.rt_set_option(frame, capi.OPT_SMALL_LAUNCH_PATHS, args.small_launch_paths) == 0
     if args.compact_log is not None:
         assert lib.rt_set_option(frame, capi.OPT_COMPACT_LOG, args.compact_log) == 0
+    if args.tail_lanes is not None:
+        assert lib.rt_set_option(frame, capi.OPT_TRACE_TAIL_LANES, args.tail_lanes) == 0
     if args.per_frame_only:
         pf = per_frame_leg(args, render, lib, frame, capi, max(args.per_frame_frames, 1))
         if rank == 0:
@@ -808,6 +813,32 @@ def main():
                                         int((~((got == libm_img) | (np.isnan(got) & np.isnan(libm_img))).all(-1)).sum()))
                 parity["libm_build_within_tolerance"] = bool(parity["rel_l2_vs_libm_build"] < 1e-4)     # reported, not asserted: the bit-exact pin is libref.so
             assert parity["rel_l2"] < 1e-4 or args.closest_tree, "radiance differs from the reference kernels: %r" % parity
+            if (args.libm_series or (args.libm_series is None and args.config == 5)) and libm_img is not None:
+                # How the distance to the libm build falls with the sample count (tools/libm_tolerance_series.py): a reduced
+                # frame of the same scene, the same sample indices on both sides, bounded to a few seconds of host time
+                try:
+                    import importlib.util
+                    spec = importlib.util.spec_from_file_location("libm_tolerance_series", os.path.join(ROOT, "tools", "libm_tolerance_series.py"))
+                    lts = importlib.util.module_from_spec(spec)
+                    spec.loader.exec_module(lts)
+                    sw, sh = 960, 540
+                    r2 = host.Render(sw, sh, scene)
+                    cam2 = host.default_camera(sw, sh)
+                    r2.set_camera(cam2)
+                    r2.set_max_bounces(args.bounces)
+                    state = dict(done=0)
+                    def hip_image_at(n):
+                        r2.render_samples(n - state["done"]); state["done"] = n
+                        return r2.radiance()
+                    spps = [int(x) for x in (args.libm_series or "1,2,4,8").split(",")]
+                    pts = lts.series(arrays, sw, sh, args.bounces, spps, cam2, hip_image_at, min(64, os.cpu_count() or 1))
+                    slope, c1, cross = lts.fit([p["spp"] for p in pts], [p["rel_l2"] for p in pts])
+                    parity["rel_l2_vs_libm_build_series"] = dict(frame="%dx%d of the same scene, %d bounces, sample indices 0..n-1 on both sides" % (sw, sh, args.bounces),
+                                                                 points=pts, fitted_slope=slope, fitted_rel_l2_at_1_spp=c1, crosses_1e_4_at_spp=cross,
+                                                                 longer_series="profiles/r04_libm_tolerance_series_cfg5.json (2 .. 128 spp, tools/libm_tolerance_series.py)")
+                    r2.close()
+                except Exception as e:                      # noqa: BLE001 -- reported, never fatal to the measurement
+                    parity["rel_l2_vs_libm_build_series"] = dict(error=repr(e))
             if args.config == 1 and world == 1:
                 # BASELINE configs[0] has published per-sample counts (SURVEY.md 8d "Config 1" / Appendix A: the reference's own
                 # Scene + Bvh + unmodified kernels over glibc libm, sample index 0): the GPU's queue counters for that sample

@@ -642,13 +642,14 @@ RT_DEV void w4_test_slots(const float4 q0, const float4 q1, const float4 q2, con
 // passes the pre-cull: entry <= exit <= t_max -- shown on the CPU by the restatement in oracle/oracle.c,
 // tests/test_wide_traversal_oracle.py; on the GPU: profiles/r03_call01_direct_variant_*).
 template <bool SHADOW, int STACK, bool TIMELINE = false>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_trace_w4(DScene sc, const float4* __restrict__ o4, const float4* __restrict__ d4,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((STACK <= 12 && !TIMELINE) ? 7 : 4, 8))) void k_trace_w4(DScene sc, const float4* __restrict__ o4, const float4* __restrict__ d4,
     const uint32_t* __restrict__ aux /* shadow rays: log entry of the deferred direct sample */, const uint32_t* __restrict__ count_ptr,
     uint32_t* __restrict__ heads,
     float4* __restrict__ hits, DLog log, uint2* __restrict__ spill, uint32_t tune,
     uint32_t* __restrict__ slow_list, uint32_t* __restrict__ slow_count, uint32_t* __restrict__ stat_counts /* [0] spills, [1] slow rays */,
     unsigned long long* __restrict__ timeline /* TIMELINE: DCounters::tl_start + timeline_slot (rt_frame_debug_timeline) */,
-    uint32_t timeline_slot, uint32_t chunk_below /* launches of fewer rays run in chunk mode (below) */)
+    uint32_t timeline_slot, uint32_t chunk_below /* launches of fewer rays run in chunk mode (below) */,
+    uint32_t tail_q /* loop D: with this many or fewer lanes busy and nothing to refill the others with, one fused pass serves all */)
 {
     __shared__ uint2 stack[STACK][64];
     uint32_t* const stack32 = reinterpret_cast<uint32_t*>(&stack[0][0]);     // SHADOW: 2 * STACK entries of 4 bytes
@@ -756,6 +757,70 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
             }
     };
 
+    // One step of a lane that stands at a leaf (loop B, loop D): `q` = the 64-byte record of triangle `prim`
+    auto leaf_step = [&](const float4 q0, const float4 q1, const float4 q2, const float4 q3, const uint32_t prim)
+    {
+        if (TIMELINE) ++tl_steps;
+        bool inside = true;
+        if (!(ref & RT_LEAF_CONT_BIT))
+        {
+            // the reference's RayBounds on the leaf node (trace_bvh.cl:146-148) with the current t_max
+            float entry;
+            inside = box_test_fast(q1.w, q2.w, q3.x, q3.y, q3.z, q3.w, org, inv, t_min, t_max, entry);
+        }
+        if (!inside) pop();
+        else
+        {
+            const bool last = q0.w != 0.0f;
+            bool accepted = false;
+            f3 p1 = F3(q0.x, q0.y, q0.z), e1 = F3(q1.x, q1.y, q1.z), e2 = F3(q2.x, q2.y, q2.z);
+            f3 pvec = cross3(dir, e2);
+            float det = dot3(e1, pvec);
+            if (!(det < 1e-8f || -det > 1e-8f))
+            {
+                float inv_det = 1.0f / det;
+                f3 tvec = org - p1;
+                float u = dot3(tvec, pvec) * inv_det;
+                if (!(u < 0.0f || u > 1.0f))
+                {
+                    f3 qvec = cross3(tvec, e1);
+                    float v = dot3(dir, qvec) * inv_det;
+                    if (!(v < 0.0f || u + v > 1.0f))
+                    {
+                        float t = dot3(e2, qvec) * inv_det;
+                        if (!(t < t_min || t > t_max))
+                        {
+                            hit_u = u; hit_v = v; hit_prim = prim;
+                            t_max = t;                       // :162
+                            accepted = true;
+                        }
+                    }
+                }
+            }
+            if (SHADOW && accepted) ref = RT_IDLE_REF;       // goto endtrace, :164-167
+            else if (last) pop();
+            else ref = (RT_LEAF_BIT | RT_LEAF_CONT_BIT) | (prim + 1u);
+        }
+    };
+    // One step of a lane that stands at a wide node (loop C, loop D): `q` = its 64-byte record
+    auto node_step = [&](const float4 q0, const float4 q1, const float4 q2, const float4 q3)
+    {
+        if (TIMELINE) ++tl_steps;
+        uint32_t r[4];
+        float e[4];
+        w4_test_slots<SHADOW>(q0, q1, q2, q3, org, inv, sign_bits, octant4, t_min, t_max, r, e);
+        // the first passing position is visited next, the later ones wait on the stack (deepest first)
+        const bool v0 = e[0] < INF, v1 = e[1] < INF, v2 = e[2] < INF, v3 = e[3] < INF;
+        if (v3 && (v0 || v1 || v2)) push(r[3], e[3]);
+        if (v2 && (v0 || v1)) push(r[2], e[2]);
+        if (v1 && v0) push(r[1], e[1]);
+        if (v0) ref = r[0];
+        else if (v1) ref = r[1];
+        else if (v2) ref = r[2];
+        else if (v3) ref = r[3];
+        else pop();
+    };
+
     for (;;)
     {
         // ---- A: retire finished rays, start new ones -------------------------------------
@@ -843,6 +908,32 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
             continue;                                                        // a whole wave of rays went to the slow list
         }
 
+        // ---- D: the tail ---------------------------------------------------------------------
+        // Loops B and C serve ONE kind of lane per pass, which is what makes a pass cheap while most lanes of the wave have work.
+        // When few are left and none can be refilled (the queue is dry, or this is a chunk that must finish before the next
+        // starts), a pass is a memory round trip for whoever it serves and a wasted one for the others -- and the launch ends
+        // when its LONGEST ray does: ~190 dependent steps on 100 M-ray launches, the 0.3 ms floor of every launch of the
+        // reference's one-sample-per-frame pattern (DESIGN.md "Where a launch's time goes").  Here every busy lane fetches its
+        // next 64-byte record -- wide node or triangle, the same four loads -- and takes its step in the SAME pass: one round
+        // trip per step of every ray.  Per lane the sequence of nodes, leaves and t_max is unchanged.
+        if (tail_q != 0u && (chunk_mode || pool.exhausted) && (uint32_t)__popcll(__ballot(ref != RT_IDLE_REF)) <= tail_q)
+        {
+            do
+            {
+                if (ref != RT_IDLE_REF)
+                {
+                    const bool at_leaf = (int)ref < -1;
+                    const uint32_t prim = ref & ~(RT_LEAF_BIT | RT_LEAF_CONT_BIT);
+                    const float4* rp = reinterpret_cast<const float4*>(at_leaf ? tri_base + (size_t)(prim << 6) : node_base + (size_t)(ref << 6));
+                    const float4 q0 = rp[0], q1 = rp[1], q2 = rp[2], q3 = rp[3];
+                    if (at_leaf) leaf_step(q0, q1, q2, q3, prim);
+                    else node_step(q0, q1, q2, q3);
+                }
+                n_spills += (uint32_t)__popcll(__ballot(sp > (SHADOW ? 2 * STACK : STACK)));
+            } while (__ballot(ref != RT_IDLE_REF) != 0ull);
+            continue;                                                        // phase A retires everybody
+        }
+
         // ---- B: leaves: exact box re-test on arrival, then one triangle per pass ----------
         {
             unsigned long long leaf_m = __ballot((int)ref < -1);
@@ -852,50 +943,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                 {
                     if ((int)ref < -1)
                     {
-                        if (TIMELINE) ++tl_steps;
                         const uint32_t prim = ref & ~(RT_LEAF_BIT | RT_LEAF_CONT_BIT);
                         const float4* tp = reinterpret_cast<const float4*>(tri_base + (size_t)(prim << 6));
                         const float4 q0 = tp[0], q1 = tp[1], q2 = tp[2], q3 = tp[3];
-                        bool inside = true;
-                        if (!(ref & RT_LEAF_CONT_BIT))
-                        {
-                            // the reference's RayBounds on the leaf node (trace_bvh.cl:146-148) with the current t_max
-                            float entry;
-                            inside = box_test_fast(q1.w, q2.w, q3.x, q3.y, q3.z, q3.w, org, inv, t_min, t_max, entry);
-                        }
-                        if (!inside) pop();
-                        else
-                        {
-                            const bool last = q0.w != 0.0f;
-                            bool accepted = false;
-                            f3 p1 = F3(q0.x, q0.y, q0.z), e1 = F3(q1.x, q1.y, q1.z), e2 = F3(q2.x, q2.y, q2.z);
-                            f3 pvec = cross3(dir, e2);
-                            float det = dot3(e1, pvec);
-                            if (!(det < 1e-8f || -det > 1e-8f))
-                            {
-                                float inv_det = 1.0f / det;
-                                f3 tvec = org - p1;
-                                float u = dot3(tvec, pvec) * inv_det;
-                                if (!(u < 0.0f || u > 1.0f))
-                                {
-                                    f3 qvec = cross3(tvec, e1);
-                                    float v = dot3(dir, qvec) * inv_det;
-                                    if (!(v < 0.0f || u + v > 1.0f))
-                                    {
-                                        float t = dot3(e2, qvec) * inv_det;
-                                        if (!(t < t_min || t > t_max))
-                                        {
-                                            hit_u = u; hit_v = v; hit_prim = prim;
-                                            t_max = t;                       // :162
-                                            accepted = true;
-                                        }
-                                    }
-                                }
-                            }
-                            if (SHADOW && accepted) ref = RT_IDLE_REF;       // goto endtrace, :164-167
-                            else if (last) pop();
-                            else ref = (RT_LEAF_BIT | RT_LEAF_CONT_BIT) | (prim + 1u);
-                        }
+                        leaf_step(q0, q1, q2, q3, prim);
                     }
                     leaf_m = __ballot((int)ref < -1);
                 } while ((uint32_t)__popcll(leaf_m) >= leaf_q && leaf_m != 0ull);
@@ -913,24 +964,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
             }
             if ((int)ref >= 0)
             {
-                if (TIMELINE) ++tl_steps;
                 const float4* np = reinterpret_cast<const float4*>(node_base + (size_t)(ref << 6));
                 const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
-                uint32_t r[4];
-                float e[4];
-                w4_test_slots<SHADOW>(q0, q1, q2, q3, org, inv, sign_bits, octant4, t_min, t_max, r, e);
-                {
-                    // the first passing position is visited next, the later ones wait on the stack (deepest first)
-                    const bool v0 = e[0] < INF, v1 = e[1] < INF, v2 = e[2] < INF, v3 = e[3] < INF;
-                    if (v3 && (v0 || v1 || v2)) push(r[3], e[3]);
-                    if (v2 && (v0 || v1)) push(r[2], e[2]);
-                    if (v1 && v0) push(r[1], e[1]);
-                    if (v0) ref = r[0];
-                    else if (v1) ref = r[1];
-                    else if (v2) ref = r[2];
-                    else if (v3) ref = r[3];
-                    else pop();
-                }
+                node_step(q0, q1, q2, q3);
             }
             n_spills += (uint32_t)__popcll(__ballot(sp > (SHADOW ? 2 * STACK : STACK)));
         }
