@@ -210,11 +210,13 @@ enum rt_option
                                        caller bounds the path state (RT_OPT_PATH_STATE_LIMIT_MB != 0: larger chunks, +2.9 % at
                                        32 GiB), full otherwise.  Results are bit-identical for every value. */
     , RT_OPT_DEBUG_LOG_POOL_DIV = 20 /* test hook: the overflow pool holds paths / value blocks (default 8) */
-    , RT_OPT_TRACE_TAIL_LANES = 21  /* k_trace_w4's loop D: when this many or fewer lanes of a wave are still busy and none of the
-                                       others can be refilled (queue dry, or a chunk of a small launch), every busy lane fetches
-                                       its next record -- wide node or triangle -- and takes its step in the SAME pass: one memory
-                                       round trip per step of the wave's last, longest rays instead of one per kind of lane.
-                                       Default 16; 0 = off.  Results are identical for every value. */
+    , RT_OPT_TRACE_TAIL_LANES = 21  /* k_trace_w4's loop D, in the instance that launches known to be small take (a batch of fewer
+                                       than RT_OPT_SMALL_LAUNCH_PATHS paths: the reference's one-sample-per-frame pattern): when
+                                       this many or fewer lanes of a wave are still busy and none of the others can be refilled,
+                                       every busy lane fetches its next record -- wide node or triangle -- and takes its step
+                                       in the SAME pass: one memory round trip per step of the chunk's last, longest rays
+                                       instead of one per kind of lane.  Default 40 (sweep: 2228 / 2332 / 2479 / 2501 / 2488
+                                       Mrays/s per frame at 0 / 16 / 32 / 40 / 48); 0 = off.  Results are identical for every value. */
     , RT_OPT_TRACE_TUNE = 12       /* k_trace2 (variants 8, 9) loop thresholds: value & 255 = lanes that must hold an
                                        interior node for a wave to stay in the node loop, value >> 8 & 255 = lanes that
                                        must wait at a triangle for another pass of the triangle loop, value >> 16 & 255 = rays a wave takes

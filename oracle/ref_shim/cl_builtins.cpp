@@ -210,8 +210,12 @@ float4 shim_read_imagef(ShimImage* img, void* /*sampler*/, float2 coord)
     float v = (coord.y - __builtin_floorf(coord.y)) * (float)h;
     float fu = __builtin_floorf(u - 0.5f);
     float fv = __builtin_floorf(v - 0.5f);
-    int i0 = (int)fu;
-    int j0 = (int)fv;
+    // OpenCL leaves read_imagef undefined for NaN coordinates (6.12.14); they DO occur: acos of a direction component one ulp
+    // above 1 (miss.cl:34), once in ~1e9 escaped rays.  x86 converts NaN to INT_MIN (an address far outside the image: the
+    // reference's kernels crashed here in a 128-spp run of the config-5 stand-in), gfx950 to 0.  Defined for the project: texel
+    // (0, 0), and the NaN weights make the sample NaN -- what the GPU path always produced.
+    int i0 = fu != fu ? 0 : (int)fu;
+    int j0 = fv != fv ? 0 : (int)fv;
     int i1 = i0 + 1;
     int j1 = j0 + 1;
     if (i0 < 0) i0 = w + i0;

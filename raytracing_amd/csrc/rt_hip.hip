@@ -140,7 +140,7 @@ struct rt_frame
     uint32_t trace_variant = 5;  // RT_OPT_TRACE_VARIANT (5 = auto)
     uint64_t small_launch_paths = 3000000ull;   // RT_OPT_SMALL_LAUNCH_PATHS: launches of fewer rays run k_trace_w4 in chunk mode
     uint32_t trace_waves_per_cu = 0;   // RT_OPT_TRACE_WAVES_PER_CU (0 = LDS-limited residency)
-    uint32_t trace_tail_lanes = 16;    // RT_OPT_TRACE_TAIL_LANES: k_trace_w4's loop D (0 = off)
+    uint32_t trace_tail_lanes = 40;    // RT_OPT_TRACE_TAIL_LANES: k_trace_w4's loop D (0 = off); sweep: profiles/r04_call04_kernel_ab.log
     uint32_t select_form_box = 0;      // RT_OPT_TRACE_SELECT_FORM_BOX: every ray takes the select-form slab test
     uint32_t trace_tune = 0;           // RT_OPT_TRACE_TUNE: k_trace2 loop thresholds (0 = defaults)
     uint32_t timeline = 0;             // rt_frame_debug_timeline armed: k_trace_w4<closest> records its launch timeline
@@ -1646,15 +1646,23 @@ void launch_trace_w4(rt_frame* f, const float4* o4, const float4* d4, const uint
     const uint32_t s = f->tl_flavour;
     const uint32_t chunk_below = f->small_launch_paths > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)f->small_launch_paths;
     unsigned long long* const no_timeline = nullptr;
+    // the instance with loop D (the fused tail pass) where the whole batch is a small launch: the kernel then runs in chunk
+    // mode whatever its live counter says (count <= paths < chunk_below)
+    const uint64_t paths = (uint64_t)f->p->chunk_count * (f->p->cur_slots ? f->p->cur_slots : 1u);
+    const bool tail = STACK == 12 && f->trace_tail_lanes != 0u && paths < (uint64_t)chunk_below;
     if (!SHADOW && STACK == 12 && f->timeline)          // tools/launch_timeline.py: the instrumented instance
-        hipLaunchKernelGGL((k_trace_w4<false, 12, true>), dim3(blocks), dim3(64), 0, f->tl_stream, ctx->scene.d, o4, d4, aux, count,
+        hipLaunchKernelGGL((k_trace_w4<false, 12, true, false>), dim3(blocks), dim3(64), 0, f->tl_stream, ctx->scene.d, o4, d4, aux, count,
             &f->p->counters->head[s][0], f->p->hits, dlog(f), f->tl_spill, tune, f->tl_slow_list,
             &f->p->counters->slow_count[s], &f->p->counters->stack_spills, &f->p->counters->tl_start[f->timeline_bounce & 63u],
-            f->timeline_bounce & 63u, chunk_below, f->trace_tail_lanes);
-    else
-        hipLaunchKernelGGL((k_trace_w4<SHADOW, STACK, false>), dim3(blocks), dim3(64), 0, f->tl_stream, ctx->scene.d, o4, d4, aux, count,
+            f->timeline_bounce & 63u, chunk_below, 0u);
+    else if (tail)
+        hipLaunchKernelGGL((k_trace_w4<SHADOW, 12, false, true>), dim3(blocks), dim3(64), 0, f->tl_stream, ctx->scene.d, o4, d4, aux, count,
             &f->p->counters->head[s][0], SHADOW ? (float4*)nullptr : f->p->hits, dlog(f),
             f->tl_spill, tune, f->tl_slow_list, &f->p->counters->slow_count[s], &f->p->counters->stack_spills, no_timeline, 0u, chunk_below, f->trace_tail_lanes);
+    else
+        hipLaunchKernelGGL((k_trace_w4<SHADOW, STACK, false, false>), dim3(blocks), dim3(64), 0, f->tl_stream, ctx->scene.d, o4, d4, aux, count,
+            &f->p->counters->head[s][0], SHADOW ? (float4*)nullptr : f->p->hits, dlog(f),
+            f->tl_spill, tune, f->tl_slow_list, &f->p->counters->slow_count[s], &f->p->counters->stack_spills, no_timeline, 0u, chunk_below, 0u);
     // The follow-up over the (normally empty) slow list: waves with a two-entry LDS stack (the rest of the stack
     // lives in the spill area) -- 1 KiB of LDS and a few registers, so it finds room beside the resident waves of the
     // OTHER stream's persistent launch (RT_OPT_OVERLAP_SHADOW) instead of waiting for that launch to end: with the

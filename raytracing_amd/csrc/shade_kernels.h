@@ -257,7 +257,10 @@ RT_DEV f3 SampleSky(const DScene& sc, f3 dir)
     float v = (cy - __builtin_floorf(cy)) * (float)h;
     float fu = __builtin_floorf(u - 0.5f);
     float fv = __builtin_floorf(v - 0.5f);
-    int i0 = (int)fu, j0 = (int)fv;
+    // NaN coordinates (acos of a component one ulp above 1: OpenCL leaves the read undefined): texel (0, 0), NaN weights, a NaN
+    // sample -- stated here instead of left to what v_cvt_i32_f32 does with a NaN; the shim under the reference's kernels and
+    // oracle.c define the same (x86's conversion gave INT_MIN there, an address outside the image)
+    int i0 = fu != fu ? 0 : (int)fu, j0 = fv != fv ? 0 : (int)fv;
     int i1 = i0 + 1, j1 = j0 + 1;
     if (i0 < 0) i0 = w + i0;
     if (i1 > w - 1) i1 = i1 - w;

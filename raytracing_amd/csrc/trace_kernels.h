@@ -641,8 +641,12 @@ RT_DEV void w4_test_slots(const float4 q0, const float4 q1, const float4 q2, con
 // was 18.4 pushes per closest-hit ray instead of 8.6; same sequence of nodes -- an entry popped right after its push always
 // passes the pre-cull: entry <= exit <= t_max -- shown on the CPU by the restatement in oracle/oracle.c,
 // tests/test_wide_traversal_oracle.py; on the GPU: profiles/r03_call01_direct_variant_*).
-template <bool SHADOW, int STACK, bool TIMELINE = false>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((STACK <= 12 && !TIMELINE) ? 7 : 4, 8))) void k_trace_w4(DScene sc, const float4* __restrict__ o4, const float4* __restrict__ d4,
+// TAIL: the instance with loop D (below) for launches the host KNOWS to be small (at most RT_OPT_SMALL_LAUNCH_PATHS paths in the
+// batch: every launch of the reference's one-sample-per-frame pattern).  It is an instance of its own because the extra loop
+// costs the three hot loops their register allocation: 75 VGPRs (6 waves per SIMD instead of 7), or 72 with five dwords of
+// phase A spilled -- either way ~2 % of a large launch (profiles/r04_call04_kernel_ab.log), which has no use for loop D.
+template <bool SHADOW, int STACK, bool TIMELINE = false, bool TAIL = false>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TAIL ? 7 : 4, 8))) void k_trace_w4(DScene sc, const float4* __restrict__ o4, const float4* __restrict__ d4,
     const uint32_t* __restrict__ aux /* shadow rays: log entry of the deferred direct sample */, const uint32_t* __restrict__ count_ptr,
     uint32_t* __restrict__ heads,
     float4* __restrict__ hits, DLog log, uint2* __restrict__ spill, uint32_t tune,
@@ -916,7 +920,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((STACK <= 12
         // reference's one-sample-per-frame pattern (DESIGN.md "Where a launch's time goes").  Here every busy lane fetches its
         // next 64-byte record -- wide node or triangle, the same four loads -- and takes its step in the SAME pass: one round
         // trip per step of every ray.  Per lane the sequence of nodes, leaves and t_max is unchanged.
-        if (tail_q != 0u && (chunk_mode || pool.exhausted) && (uint32_t)__popcll(__ballot(ref != RT_IDLE_REF)) <= tail_q)
+        if (TAIL && tail_q != 0u && (chunk_mode || pool.exhausted) && (uint32_t)__popcll(__ballot(ref != RT_IDLE_REF)) <= tail_q)
         {
             do
             {
