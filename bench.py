@@ -344,8 +344,10 @@ def per_frame_leg(args, render, lib, frame, capi, frames, resolve=True):
     return dict(mrays_per_s=round(rays / dt / 1e6, 1), ms_per_frame=round(dt * 1e3 / frames, 4), frames=frames,
                 rays_per_frame=round(rays / frames, 1), samples_in_flight=1, resolve_every_frame=bool(resolve),
                 call_pattern="K x Render::RenderFrame() -> Integrator::Integrate() through the 15 stage hooks of HIPPathTraceIntegrator, "
-                             "1 sample per pixel per call, ResolveRadiance + host sync every frame (src/render.cpp:197, "
-                             "src/integrator/integrator.cpp:27-59)")
+                             "1 sample per pixel per call, ResolveRadiance + Finish() (host sync on the frame's kernels) every frame "
+                             "(src/render.cpp:197, src/integrator/integrator.cpp:27-59, cl_pt_integrator.cpp:677-684); the resolved image "
+                             "travels to the host on a copy stream while the next frame is traced (rt_frame_present: the reference "
+                             "resolves into a GL image and reads nothing back); the last image's arrival is inside the timed region")
 
 
 def roofline_object(args, world, live_step, per_ray, isolated):

@@ -261,6 +261,13 @@ int rt_frame_reserve_samples(rt_frame* frame, uint32_t n_samples, uint32_t* rese
  * local_rows x width, row-major.  rt_frame_read_radiance returns the running
  * SUM over samples (radiance_buffer_), rt_frame_resolve the tonemapped image. */
 int rt_frame_resolve(rt_frame* frame, float* host_rgba);
+/* The same stage as the reference runs it every frame -- ResolveRadiance, then Finish() (cl_pt_integrator.cpp:677-684): when
+ * this returns every kernel of the frame has run, and the tonemapped image is ON ITS WAY to host_rgba (a copy stream of its
+ * own, double-buffered on the device: the reference resolves into a GL image and nothing crosses PCIe; headless the image
+ * overlaps the next frame's tracing instead).  host_rgba holds the frame after rt_frame_present_wait (or the next
+ * rt_frame_resolve / rt_frame_destroy); presenting again into the same buffer is fine (the copies are ordered). */
+int rt_frame_present(rt_frame* frame, float* host_rgba);
+int rt_frame_present_wait(rt_frame* frame);
 int rt_frame_read_radiance(rt_frame* frame, float* host_rgba);
 /* device pointer of the running-sum radiance (float4[local_rows*width]) for
  * device-side gathers (RCCL) without a host bounce */

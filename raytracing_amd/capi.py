@@ -61,7 +61,7 @@ EXPORTS = [
     "rt_shade", "rt_intersect_shadow", "rt_accumulate_direct", "rt_advance_sample", "rt_integrate",
     "rt_frame_reserve_samples",
     "rt_compute_aovs", "rt_denoise", "rt_copy_history",
-    "rt_frame_resolve", "rt_frame_read_radiance", "rt_frame_radiance_device_ptr", "rt_frame_sample_count",
+    "rt_frame_resolve", "rt_frame_present", "rt_frame_present_wait", "rt_frame_read_radiance", "rt_frame_radiance_device_ptr", "rt_frame_sample_count",
     "rt_frame_get_stats", "rt_frame_get_profile", "rt_frame_copy_radiance", "rt_frame_debug_read_queue", "rt_frame_debug_read_hits", "rt_debug_eval",
     "rt_debug_wide_bvh", "rt_frame_debug_timeline", "rt_debug_own_bvh", "rt_debug_wide_bvh_metric", "rt_scene_tree_report", "rt_debug_choose_tree",
     "rt_group_create", "rt_group_unique_id", "rt_group_join", "rt_group_size", "rt_group_local_count", "rt_group_local_rank", "rt_group_comm_count",
@@ -102,7 +102,8 @@ def load():
         "rt_advance_sample": (i32, [vp]), "rt_integrate": (i32, [vp, u32]),
         "rt_frame_reserve_samples": (i32, [vp, u32, C.POINTER(C.c_uint32)]),
         "rt_compute_aovs": (i32, [vp]), "rt_denoise": (i32, [vp]), "rt_copy_history": (i32, [vp]),
-        "rt_frame_resolve": (i32, [vp, vp]), "rt_frame_read_radiance": (i32, [vp, vp]),
+        "rt_frame_resolve": (i32, [vp, vp]), "rt_frame_present": (i32, [vp, vp]), "rt_frame_present_wait": (i32, [vp]),
+        "rt_frame_read_radiance": (i32, [vp, vp]),
         "rt_frame_radiance_device_ptr": (vp, [vp]), "rt_frame_sample_count": (u32, [vp]),
         "rt_frame_get_stats": (i32, [vp, C.POINTER(rt_stats)]),
         "rt_frame_get_profile": (i32, [vp, C.POINTER(rt_profile)]),

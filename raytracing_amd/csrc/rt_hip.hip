@@ -109,6 +109,12 @@ struct rt_frame
     DTile tile;
     uint32_t n_local;
     float4* radiance; float4* resolved;
+    // rt_frame_present: the resolved image goes to the host on a stream of its own while the next frame is traced
+    float4* resolved_b = nullptr;      // the second device image (double buffering)
+    hipStream_t present_stream = nullptr;
+    hipEvent_t ev_resolved[2] = {nullptr, nullptr}, ev_copied[2] = {nullptr, nullptr};
+    uint32_t present_flip = 0;
+    bool present_pending = false;
     // Per-path state lives in PIPES (PathPipe): the tile is cut into chunks of pixels and chunk c travels through
     // the wavefront loop on pipe c % n_pipes, each pipe on its own HIP stream.  One chunk on one pipe is the plain
     // case.  More pipes let chunks overlap; measured on MI355X this does NOT pay (a trace launch costs ~0.8 ms
@@ -1332,6 +1338,8 @@ int sync_frame_streams(rt_frame* f)
         if (q.stream && q.stream != ctx->stream) HIPCHK(ctx, hipStreamSynchronize(q.stream));
         if (q.side) HIPCHK(ctx, hipStreamSynchronize(q.side));
     }
+    if (f->present_stream) HIPCHK(ctx, hipStreamSynchronize(f->present_stream));   // an image on its way to the host (rt_frame_present)
+    f->present_pending = false;
     return RT_OK;
 }
 
@@ -1436,6 +1444,10 @@ int rt_frame_destroy(rt_frame* f)
         if (q.side) (void)hipStreamDestroy(q.side);
         if (i > 0 && q.stream) (void)hipStreamDestroy(q.stream);
     }
+    if (f->present_stream) { (void)hipStreamSynchronize(f->present_stream); (void)hipStreamDestroy(f->present_stream); }
+    for (hipEvent_t e : f->ev_resolved) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : f->ev_copied) if (e) (void)hipEventDestroy(e);
+    if (f->resolved_b) (void)hipFree(f->resolved_b);
     for (auto& s : f->spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
     for (auto e : f->event_pool) (void)hipEventDestroy(e);
     delete f;
@@ -2043,12 +2055,60 @@ int rt_integrate(rt_frame* f, uint32_t n_samples)       // n x Integrator::Integ
 }
 
 // ---- output ----------------------------------------------------------------
+int rt_frame_present_wait(rt_frame* f)
+{
+    if (!f) return fail(nullptr, "rt_frame_present_wait: frame is NULL");
+    if (!f->present_pending) return RT_OK;
+    (void)hipSetDevice(f->ctx->device);
+    HIPCHK(f->ctx, hipStreamSynchronize(f->present_stream));
+    f->present_pending = false;
+    return RT_OK;
+}
+
+// ResolveRadiance + Finish() AS THE REFERENCE HAS THEM (cl_pt_integrator.cpp:677-684): the kernels have finished when this
+// returns; the resolved image is on its way.  The reference resolves into a GL image its window blits later -- nothing crosses
+// PCIe at all; headless, the image has to reach the host, and it does so on a copy stream of its own, double-buffered on the
+// device, while the next frame's rays are already being traced (0.6 of the 4.7 ms of a 1080p frame were this read-back).
+int rt_frame_present(rt_frame* f, float* host_rgba)
+{
+    if (!f || !host_rgba) return fail(nullptr, "rt_frame_present: NULL argument");
+    rt_ctx* ctx = f->ctx;
+    (void)hipSetDevice(ctx->device);
+    if (f->n_local == 0) return RT_OK;
+    if (!f->present_stream)
+    {
+        HIPCHK(ctx, hipStreamCreateWithFlags(&f->present_stream, hipStreamNonBlocking));
+        for (hipEvent_t& e : f->ev_resolved) HIPCHK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        for (hipEvent_t& e : f->ev_copied) HIPCHK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        HIPCHK(ctx, hipMalloc((void**)&f->resolved_b, (size_t)f->n_local * sizeof(float4)));
+        HIPCHK(ctx, hipEventRecord(f->ev_copied[0], f->present_stream));
+        HIPCHK(ctx, hipEventRecord(f->ev_copied[1], f->present_stream));
+    }
+    if (flush_log(f) != RT_OK) return RT_ERROR;
+    const uint32_t i = f->present_flip & 1u;
+    float4* image = i ? f->resolved_b : f->resolved;
+    HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, f->ev_copied[i], 0));      // the copy that last read this device image (two frames ago)
+    uint32_t blocks = (f->n_local + 255u) / 256u;
+    hipLaunchKernelGGL(k_resolve, dim3(blocks), dim3(256), 0, ctx->stream, (const float4*)f->radiance, f->aov_buf,
+        image, f->n_local, f->sample_count, f->aov, f->denoiser);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipEventRecord(f->ev_resolved[i], ctx->stream));
+    HIPCHK(ctx, hipStreamWaitEvent(f->present_stream, f->ev_resolved[i], 0));
+    HIPCHK(ctx, hipMemcpyAsync(host_rgba, image, (size_t)f->n_local * sizeof(float4), hipMemcpyDeviceToHost, f->present_stream));
+    HIPCHK(ctx, hipEventRecord(f->ev_copied[i], f->present_stream));
+    f->present_flip ^= 1u;
+    f->present_pending = true;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));      // Finish(), :682: every kernel of the frame has run
+    return RT_OK;
+}
+
 int rt_frame_resolve(rt_frame* f, float* host_rgba)     // ResolveRadiance, :677-684
 {
     if (!f || !host_rgba) return fail(nullptr, "rt_frame_resolve: NULL argument");
     rt_ctx* ctx = f->ctx;
     (void)hipSetDevice(ctx->device);
     if (f->n_local == 0) return RT_OK;
+    if (rt_frame_present_wait(f) != RT_OK) return RT_ERROR;                // an image still travelling to (possibly) the same host buffer
     if (flush_log(f) != RT_OK) return RT_ERROR;
     uint32_t blocks = (f->n_local + 255u) / 256u;
     hipLaunchKernelGGL(k_resolve, dim3(blocks), dim3(256), 0, ctx->stream, (const float4*)f->radiance, f->aov_buf,

@@ -92,8 +92,15 @@ HIPPathTraceIntegrator::HIPPathTraceIntegrator(std::uint32_t width, std::uint32_
         rt_host_register(context_.Get(), resolved_.data(), resolved_.size() * sizeof(float)) == RT_OK;
 }
 
+std::vector<float> const& HIPPathTraceIntegrator::GetResolvedImage() const
+{
+    Check(rt_frame_present_wait(frame_));
+    return resolved_;
+}
+
 HIPPathTraceIntegrator::~HIPPathTraceIntegrator()
 {
+    if (frame_) rt_frame_present_wait(frame_);
     if (resolved_pinned_) rt_host_unregister(context_.Get(), resolved_.data());
     rt_frame_destroy(frame_);
 }
@@ -185,7 +192,9 @@ void HIPPathTraceIntegrator::CopyHistoryBuffers() { Check(rt_copy_history(frame_
 
 void HIPPathTraceIntegrator::ResolveRadiance()
 {
-    if (resolve_every_frame_) Check(rt_frame_resolve(frame_, resolved_.data()));
+    // the frame's kernels have finished when this returns (Finish(), cl_pt_integrator.cpp:682); the image travels to
+    // resolved_ meanwhile and GetResolvedImage() waits for it
+    if (resolve_every_frame_) Check(rt_frame_present(frame_, resolved_.data()));
 }
 
 void HIPPathTraceIntegrator::IntegrateSamples(std::uint32_t n_samples)

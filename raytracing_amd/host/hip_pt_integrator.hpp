@@ -63,7 +63,7 @@ public:
     // number of samples the device will trace together.
     std::uint32_t ReserveSamples(std::uint32_t n_samples);
     // Headless outputs (the reference writes a GL-shared image in ResolveRadiance).
-    std::vector<float> const& GetResolvedImage() const { return resolved_; }   // local_rows x width x RGBA
+    std::vector<float> const& GetResolvedImage() const;   // local_rows x width x RGBA; waits for the image of the last frame to arrive
     std::vector<float> ReadRadianceSum() const;
     std::vector<float> const& ResolveNow();      // runs the resolve stage and returns the image
     std::uint32_t GetSampleCount() const;
