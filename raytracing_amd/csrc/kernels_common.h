@@ -123,6 +123,7 @@ RT_DEV uint32_t tile_global_row(const DTile& t, uint32_t ly)
     return (band * t.nranks + t.rank) * t.band_h + (ly - band * t.band_h);
 }
 
+#define RT_LOG_SUBPOOLS 64u        // the overflow pool of the compact log is handed out from this many bump counters (k_shade)
 struct DCounters                  // one per frame, device memory
 {
     uint32_t queue[64];           // queue[b]  = rays in the incoming queue of bounce b
@@ -147,7 +148,7 @@ struct DCounters                  // one per frame, device memory
     // ... and when its waves left, in 25 us bins after the first wave found the queue dry (all recorded launches together)
     unsigned long long tl_exit_hist[64];
     // compact radiance log (DLog): next free overflow block of the batch in flight, and "the pool ran dry"
-    uint32_t log_ovf_next, log_ovf_flag;
+    uint32_t log_ovf_next[RT_LOG_SUBPOOLS], log_ovf_flag;
 };
 
 // ray_inv_dir and ray_sign of TraceBvh (trace_bvh.cl:125-129), packed as (inv.xyz, sign bits)

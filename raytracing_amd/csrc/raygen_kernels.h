@@ -32,8 +32,8 @@ __global__ __launch_bounds__(256) void k_raygen(DTile tile, rt_camera cam, uint3
         counters->total_shadow += s;
         for (uint32_t b = 0; b < 64; ++b) { counters->queue[b] = 0; counters->shadow[b] = 0; }
         counters->queue[0] = n_total;                                    // raygeneration.cl:135-138
-        counters->log_ovf_next = 0;                                      // a new sequence: its log's overflow pool is empty
     }
+    if (i < RT_LOG_SUBPOOLS) counters->log_ovf_next[i] = 0;              // a new sequence: its log's overflow pool is empty
     if (i < 24) counters->head[i >> 3][i & 7] = 0;                       // the next trace launches start from 0
     if (i >= n_total) return;
 

@@ -2094,7 +2094,18 @@ int rt_frame_present(rt_frame* f, float* host_rgba)
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipEventRecord(f->ev_resolved[i], ctx->stream));
     HIPCHK(ctx, hipStreamWaitEvent(f->present_stream, f->ev_resolved[i], 0));
-    HIPCHK(ctx, hipMemcpyAsync(host_rgba, image, (size_t)f->n_local * sizeof(float4), hipMemcpyDeviceToHost, f->present_stream));
+    // page-locked destinations (rt_host_register) are written by a small grid of our own; anything else by the runtime's copy
+    void* mapped = nullptr;
+    if (hipHostGetDevicePointer(&mapped, host_rgba, 0) == hipSuccess && mapped)
+    {
+        hipLaunchKernelGGL(k_copy_to_host, dim3(64), dim3(256), 0, f->present_stream, (const float4*)image, (float4*)mapped, f->n_local);
+        HIPCHK(ctx, hipGetLastError());
+    }
+    else
+    {
+        (void)hipGetLastError();
+        HIPCHK(ctx, hipMemcpyAsync(host_rgba, image, (size_t)f->n_local * sizeof(float4), hipMemcpyDeviceToHost, f->present_stream));
+    }
     HIPCHK(ctx, hipEventRecord(f->ev_copied[i], f->present_stream));
     f->present_flip ^= 1u;
     f->present_pending = true;

@@ -361,27 +361,6 @@ RT_DEV void block_append2_keyed(bool want_a, uint32_t key_a, bool want_b, uint32
     idx_b = s_base[1] + s_cnt[1][key_b % KEYS][wave] + rank_b;
 }
 
-// Bump allocation for the threads of a block that `want` one item each: ONE atomic per block (see block_append2).
-RT_DEV uint32_t block_alloc(bool want, uint32_t* counter)
-{
-    __shared__ uint32_t s_n[RT_SHADE_BLOCK / 64];
-    __shared__ uint32_t s_b;
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const unsigned long long m = __ballot(want);
-    if (lane == 0) s_n[wave] = (uint32_t)__popcll(m);
-    __syncthreads();
-    if (threadIdx.x == 0)
-    {
-        uint32_t total = 0;
-        for (uint32_t w = 0; w < RT_SHADE_BLOCK / 64; ++w) total += s_n[w];
-        s_b = total ? atomicAdd(counter, total) : 0u;
-    }
-    __syncthreads();
-    uint32_t at = s_b;
-    for (uint32_t w = 0; w < wave; ++w) at += s_n[w];
-    return at + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-}
-
 struct ShadeArgs
 {
     const float4* in_o4; const float4* in_d4; const float4* in_thr; const float4* hits;
@@ -666,11 +645,26 @@ __global__ __launch_bounds__(RT_SHADE_BLOCK) __attribute__((amdgpu_waves_per_eu(
     if (COMPACT && 2u * (a.bounce + 1u) + 1u >= a.log.inline_entries && !a.final_bounce)
     {
         const bool want_block = want_next && no_block && (__float_as_uint(nx_t.w) & 0x7FFFFFFFu) + 1u >= a.log.inline_entries;
-        const uint32_t blk = block_alloc(want_block, &a.counters->log_ovf_next);
-        if (want_block)
+        // Per WAVE, and only in waves where somebody wants one (a tenth of the paths ever do): one atomic on one of
+        // RT_LOG_SUBPOOLS bump counters, each owning an equal share of the pool -- no block-wide barrier on k_shade's critical
+        // path (round 3 allocated per 512-thread block: two __syncthreads and 0.024 ms per sample, which is why the compact
+        // layout was not the default).  A share that runs dry raises the flag like the whole pool did.
+        const unsigned long long wm = __ballot(want_block);
+        if (wm != 0ull)
         {
-            if (blk >= a.log.ovf_blocks) a.counters->log_ovf_flag = 1u;      // pool dry: the host repeats this batch in the full layout
-            a.log.ovf_slot[__float_as_uint(nx_d.w)] = blk < a.log.ovf_blocks ? blk : RT_EMPTY_REF;
+            const uint32_t lane = threadIdx.x & 63u;
+            const uint32_t pool = (blockIdx.x * (RT_SHADE_BLOCK / 64u) + (threadIdx.x >> 6)) & (RT_LOG_SUBPOOLS - 1u);
+            const uint32_t share = a.log.ovf_blocks / RT_LOG_SUBPOOLS;
+            uint32_t base = 0;
+            const int first = __builtin_ctzll(wm);
+            if ((int)lane == first) base = atomicAdd(&a.counters->log_ovf_next[pool], (uint32_t)__popcll(wm));
+            base = (uint32_t)__shfl((int)base, first, 64);
+            if (want_block)
+            {
+                const uint32_t k = base + (uint32_t)__popcll(wm & ((1ull << lane) - 1ull));
+                if (k >= share) a.counters->log_ovf_flag = 1u;               // dry: the host repeats this batch in the full layout
+                a.log.ovf_slot[__float_as_uint(nx_d.w)] = k < share ? pool * share + k : RT_EMPTY_REF;
+            }
         }
     }
 

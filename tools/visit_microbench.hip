@@ -7,8 +7,11 @@
 //   -> the NEXT node depends on all of it
 //
 // Every lane runs such a chain over a table of random wide nodes; where the next record lies is drawn so that a stated
-// fraction of the fetches hit L1 (a 16 KiB hot set per CU-sized group), L2 (4 MiB) or neither (1 GiB table) -- the hit mix
-// of the production kernel from its PMC counters (profiles/r0X_trace_counters.json: l1_hit_rate, l2_hit_rate).
+// fraction of the fetches hit L1 (a 16 KiB hot set PER COMPUTE UNIT: the wave reads which CU it runs on -- HW_ID / XCC_ID --
+// so the hot set stays one CU's however many waves share it; round 3 tied it to the block index, and at the kernel's own
+// residency of 26 waves per CU that put 26 hot sets behind one L1: the curve collapsed exactly where it mattered), L2 (the
+// 32 hot sets + a 2 MiB set per XCD) or neither (1 GiB table) -- the hit mix of the production kernel from its PMC counters
+// (profiles/r0X_trace_counters.json: l1_hit_rate, l2_hit_rate).
 // Reported per configuration (waves per CU, hit mix): ns per visit of a lane's chain, and visits per second of the machine.
 // bench.py turns that into  ceiling = resident lanes x lane utilisation / visit latency / steps per ray.
 //
@@ -51,8 +54,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
     const float t_min = 0.0f, INF = __builtin_inff();
     float t_max = 1.0e4f;
     int sp = 0;
-    // the hot set of this block's CU-sized neighbourhood: blocks that share a CU mostly share it
-    const uint32_t hot_base = ((blockIdx.x >> 3) % 64u) * n_hot;
+    // the hot set of the compute unit this wave runs on (gfx9 HW_ID: cu_id 11:8, sh_id 12, se_id 15:13; XCC_ID 3:0)
+    uint32_t hw_id, xcc_id;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
+    const uint32_t cu_slot = ((xcc_id & 0xFu) << 8) | ((hw_id >> 8) & 0xFFu);           // < 4096
+    const uint32_t hot_base = cu_slot * n_hot;
+    // the L2-resident set of this XCD (each XCD has an L2 of its own): after the hot sets of all CUs
+    const uint32_t l2_base = 4096u * n_hot + (xcc_id & 0xFu) * n_l2;
     uint32_t ref = hot_base + (lane % n_hot);
     float acc = 0.0f;
     for (uint32_t s = 0; s < steps; ++s)
@@ -104,7 +113,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
         // where the next record lies: L1-hot set / L2-resident set / anywhere, by the hit mix asked for
         const uint32_t pick = (next ^ (next >> 15)) * 2654435761u;
         const uint32_t where = pick >> 8;                                    // 24 bits
-        ref = where < thr_l1 ? hot_base + (pick % n_hot) : (where < thr_l2 ? (pick % n_l2) : (pick % n_all));
+        ref = where < thr_l1 ? hot_base + (pick % n_hot) : (where < thr_l2 ? l2_base + (pick % n_l2) : (pick % n_all));
     }
     out[blockIdx.x * 64u + lane] = acc + (float)sp;
 }
@@ -117,7 +126,7 @@ int main(int argc, char** argv)
     CHECK(hipGetDeviceProperties(&prop, 0));
     const uint32_t cus = (uint32_t)prop.multiProcessorCount;
     const uint32_t n_hot = 256u;                    // 16 KiB per neighbourhood
-    const uint32_t n_l2 = 65536u;                   // 4 MiB
+    const uint32_t n_l2 = 32768u;                   // 2 MiB per XCD (half of its L2)
     const uint32_t n_all = 1u << 24;                // 1 GiB
     std::vector<Rec> host((size_t)n_all);
     std::mt19937 gen(7);
@@ -153,7 +162,7 @@ int main(int argc, char** argv)
     bool first = true;
     const bool coop_too = argc > 4 && atoi(argv[4]) != 0;
     for (int shadow = 0; shadow < (coop_too ? 3 : 2); ++shadow)
-        for (uint32_t wpc : {1u, 4u, 8u, 12u, 16u, 20u, 26u})
+        for (uint32_t wpc : {1u, 4u, 8u, 12u, 16u, 20u, 24u, 26u})
         {
             if (shadow == 2 && wpc > 16u) continue;   // the staging buffer: 10 KiB of LDS per wave, 15 waves per CU
             const uint32_t blocks = cus * wpc;
