@@ -1259,6 +1259,8 @@ static int wide_trace_impl(void* h, const void* wide_records, uint32_t n_wide, u
     orc* o = (orc*)h;
     const int direct = (shadow & 2) != 0;                                /* bit 1 of `shadow`: the direct form of the walk */
     const int ordered_shadow = (shadow & 4) != 0;                        /* bit 2: shadow rays visit slots near-first too (analysis) */
+    const int by_distance = (shadow & 8) != 0;                           /* bit 3: slots visited by entry distance instead of the record's
+                                                                          * order table (analysis of the tolerance mode: tools/own_tree_study.py) */
     shadow &= 1;
     const orc_wide_node* wn = (const orc_wide_node*)wide_records;
     /* leaf ref (first triangle) -> the BVH2 leaf node that holds its exact bounds and primitive count */
@@ -1365,7 +1367,16 @@ static int wide_trace_impl(void* h, const void* wide_records, uint32_t n_wide, u
                     e[k] = (exit >= entry && r[k] != ORC_EMPTY_REF) ? entry : INF;
                     if (e[k] < INF) counters[9]++;
                 }
-                if (!shadow || ordered_shadow)
+                if (by_distance)
+                {
+                    for (int i = 1; i < 4; ++i)
+                        for (int j = i; j > 0 && e[j] < e[j - 1]; --j)
+                        {
+                            const uint32_t tr = r[j]; r[j] = r[j - 1]; r[j - 1] = tr;
+                            const float te = e[j]; e[j] = e[j - 1]; e[j - 1] = te;
+                        }
+                }
+                else if (!shadow || ordered_shadow)
                 {
                     /* four conditional exchanges bring the occupied slots into the reference's visit order for this direction
                      * octant, whatever the shape of the BVH2 subtree the record folds (build_wide_bvh stores the slots where

@@ -138,17 +138,3 @@ __global__ __launch_bounds__(256) void k_resolve(const float4* __restrict__ radi
         out[i] = make_float4(hx / (hx + 1.0f), hy / (hy + 1.0f), hz / (hz + 1.0f), 1.0f);
     }
 }
-
-// rt_frame_present: the resolved image travels to (page-locked, device-mapped) host memory in a DELIBERATELY small grid.
-// The runtime's own device-to-host copy of a registered buffer is a blit kernel that fills the machine with waves waiting on
-// PCIe (441 us for a 1080p frame; the next frame's first launches queued behind it: k_raygen 23 -> 422 us,
-// profiles/r04_call06_per_frame_gantt.log); PCIe is saturated by a few thousand lanes, so 64 blocks carry it and the other
-// CUs trace.
-__global__ __launch_bounds__(256) void k_copy_to_host(const float4* __restrict__ src, float4* __restrict__ dst, uint32_t n)
-{
-    typedef float rt_v4f __attribute__((ext_vector_type(4)));
-    const rt_v4f* s = reinterpret_cast<const rt_v4f*>(src);
-    rt_v4f* d = reinterpret_cast<rt_v4f*>(dst);
-    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u)
-        __builtin_nontemporal_store(s[i], &d[i]);
-}

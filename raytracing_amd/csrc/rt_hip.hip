@@ -2077,7 +2077,9 @@ int rt_frame_present(rt_frame* f, float* host_rgba)
     if (f->n_local == 0) return RT_OK;
     if (!f->present_stream)
     {
-        HIPCHK(ctx, hipStreamCreateWithFlags(&f->present_stream, hipStreamNonBlocking));
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        HIPCHK(ctx, hipStreamCreateWithPriority(&f->present_stream, hipStreamNonBlocking, lo));
         for (hipEvent_t& e : f->ev_resolved) HIPCHK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
         for (hipEvent_t& e : f->ev_copied) HIPCHK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
         HIPCHK(ctx, hipMalloc((void**)&f->resolved_b, (size_t)f->n_local * sizeof(float4)));
@@ -2094,18 +2096,11 @@ int rt_frame_present(rt_frame* f, float* host_rgba)
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipEventRecord(f->ev_resolved[i], ctx->stream));
     HIPCHK(ctx, hipStreamWaitEvent(f->present_stream, f->ev_resolved[i], 0));
-    // page-locked destinations (rt_host_register) are written by a small grid of our own; anything else by the runtime's copy
-    void* mapped = nullptr;
-    if (hipHostGetDevicePointer(&mapped, host_rgba, 0) == hipSuccess && mapped)
-    {
-        hipLaunchKernelGGL(k_copy_to_host, dim3(64), dim3(256), 0, f->present_stream, (const float4*)image, (float4*)mapped, f->n_local);
-        HIPCHK(ctx, hipGetLastError());
-    }
-    else
-    {
-        (void)hipGetLastError();
-        HIPCHK(ctx, hipMemcpyAsync(host_rgba, image, (size_t)f->n_local * sizeof(float4), hipMemcpyDeviceToHost, f->present_stream));
-    }
+    // (The runtime's copy of a page-locked destination is a blit kernel, 441 us for a 1080p image; a 64-block copy kernel of our
+    // own that left the other CUs alone was tried and is SLOWER end to end -- it holds PCIe for milliseconds and every persistent
+    // grid launched meanwhile finds part of its residency taken: 4.22 instead of 3.70 ms per frame, profiles/r04_call07_*.  The
+    // stream's low priority is what keeps the blit's workgroups behind the next frame's first launches.)
+    HIPCHK(ctx, hipMemcpyAsync(host_rgba, image, (size_t)f->n_local * sizeof(float4), hipMemcpyDeviceToHost, f->present_stream));
     HIPCHK(ctx, hipEventRecord(f->ev_copied[i], f->present_stream));
     f->present_flip ^= 1u;
     f->present_pending = true;

@@ -649,21 +649,33 @@ __global__ __launch_bounds__(RT_SHADE_BLOCK) __attribute__((amdgpu_waves_per_eu(
         // RT_LOG_SUBPOOLS bump counters, each owning an equal share of the pool -- no block-wide barrier on k_shade's critical
         // path (round 3 allocated per 512-thread block: two __syncthreads and 0.024 ms per sample, which is why the compact
         // layout was not the default).  A share that runs dry raises the flag like the whole pool did.
-        const unsigned long long wm = __ballot(want_block);
+        unsigned long long wm = __ballot(want_block);
         if (wm != 0ull)
         {
             const uint32_t lane = threadIdx.x & 63u;
-            const uint32_t pool = (blockIdx.x * (RT_SHADE_BLOCK / 64u) + (threadIdx.x >> 6)) & (RT_LOG_SUBPOOLS - 1u);
+            const uint32_t home = blockIdx.x * (RT_SHADE_BLOCK / 64u) + (threadIdx.x >> 6);
             const uint32_t share = a.log.ovf_blocks / RT_LOG_SUBPOOLS;
-            uint32_t base = 0;
-            const int first = __builtin_ctzll(wm);
-            if ((int)lane == first) base = atomicAdd(&a.counters->log_ovf_next[pool], (uint32_t)__popcll(wm));
-            base = (uint32_t)__shfl((int)base, first, 64);
+            uint32_t got = RT_EMPTY_REF;
+            // the wave's own share first, then up to seven others (a share that is full does not end the batch while its
+            // neighbours have room: small launches use few shares, late bounces use them unevenly)
+            for (uint32_t attempt = 0; attempt < 8u && wm != 0ull; ++attempt)
+            {
+                const uint32_t pool = (home + attempt * 9u) & (RT_LOG_SUBPOOLS - 1u);
+                uint32_t base = 0;
+                const int first = __builtin_ctzll(wm);
+                if ((int)lane == first) base = atomicAdd(&a.counters->log_ovf_next[pool], (uint32_t)__popcll(wm));
+                base = (uint32_t)__shfl((int)base, first, 64);
+                if (want_block && got == RT_EMPTY_REF)
+                {
+                    const uint32_t k = base + (uint32_t)__popcll(wm & ((1ull << lane) - 1ull));
+                    if (k < share) got = pool * share + k;
+                }
+                wm = __ballot(want_block && got == RT_EMPTY_REF);
+            }
             if (want_block)
             {
-                const uint32_t k = base + (uint32_t)__popcll(wm & ((1ull << lane) - 1ull));
-                if (k >= share) a.counters->log_ovf_flag = 1u;               // dry: the host repeats this batch in the full layout
-                a.log.ovf_slot[__float_as_uint(nx_d.w)] = k < share ? pool * share + k : RT_EMPTY_REF;
+                if (got == RT_EMPTY_REF) a.counters->log_ovf_flag = 1u;      // dry: the host repeats this batch in the full layout
+                a.log.ovf_slot[__float_as_uint(nx_d.w)] = got;
             }
         }
     }

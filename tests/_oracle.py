@@ -143,7 +143,7 @@ class Oracle:
     WIDE_COUNTERS = ("rays", "wide_visits", "leaf_arrivals", "leaf_box_fails", "triangle_tests", "pushes", "culled_pops",
                      "deepest_stack", "rays_left_to_bvh2", "slots_passed")
 
-    def wide_trace(self, wide_records, entry_ref, rays, shadow, counters=None, direct=False, ordered_shadow=False):
+    def wide_trace(self, wide_records, entry_ref, rays, shadow, counters=None, direct=False, ordered_shadow=False, by_distance=False):
         """k_trace_w4's walk restated on the CPU (oracle.c: orc_wide_trace) over the records of rt_debug_wide_bvh, for the
         rays given (records of types.ray).  Returns hits (types.hit) or, shadow, the shadow-hit words; adds to `counters`
         (np.uint64[10], WIDE_COUNTERS) when given."""
@@ -153,7 +153,7 @@ class Oracle:
         hits = np.zeros(len(rays), np.dtype([("bc", "<f4", 2), ("primitive_id", "<u4"), ("t", "<f4")]))
         sh = np.zeros(len(rays), np.uint32)
         rc = self.lib.orc_wide_trace(self.handle, wide.ctypes.data if len(wide) else None, len(wide), entry_ref,
-                                     rays.ctypes.data if len(rays) else None, len(rays), int(bool(shadow)) | (2 if direct else 0) | (4 if ordered_shadow else 0),
+                                     rays.ctypes.data if len(rays) else None, len(rays), int(bool(shadow)) | (2 if direct else 0) | (4 if ordered_shadow else 0) | (8 if by_distance else 0),
                                      hits.ctypes.data, sh.ctypes.data, cnt.ctypes.data)
         if rc != 0:
             raise RuntimeError("orc_wide_trace failed: %d" % rc)

@@ -79,6 +79,8 @@ if __name__ == "__main__":
     orc.set_camera(host.default_camera(w, h)); orc.set_max_bounces(a.bounces)
     orc.stage("reset"); orc.stage("generate_rays")
     tot = {(k, s): np.zeros(10, np.uint64) for k in trees for s in (False, True)}
+    dist_tot = {k: np.zeros(10, np.uint64) for k in trees}                  # closest-hit rays, slots visited by entry distance
+    dist_differ = {k: 0 for k in trees}
     differ = {k: 0 for k in trees}
     differ_t = {k: 0 for k in trees}
     for bounce in range(a.bounces + 1):
@@ -95,6 +97,10 @@ if __name__ == "__main__":
             bad |= hit & ((got["t"] != want["t"]) | (np.ascontiguousarray(got["bc"]).view(np.float32).reshape(-1, 2) != np.ascontiguousarray(want["bc"]).view(np.float32).reshape(-1, 2)).any(1))
             differ[name] += int(bad.sum())
             differ_t[name] += int((hit & (got["t"] != want["t"])).sum())
+            c = np.zeros(10, np.uint64)
+            gd = orc.wide_trace(wide, entry, rays, False, c, direct=True, by_distance=True)
+            dist_tot[name] += c
+            dist_differ[name] += int(((gd["primitive_id"] != want["primitive_id"]) | (hit & (gd["t"] != want["t"]))).sum())
         for st, args in (("shade_miss", (bounce,)), ("clear_counters", (bounce,)), ("shade_hits", (bounce,))):
             orc.stage(st, *args)
         ks = int(orc.buffer("shadow_ray_counter", np.uint32, 1)[0])
@@ -113,3 +119,8 @@ if __name__ == "__main__":
         steps = (int(c[1]) + int(c[4]) + int(c[3])) / r          # wide-node visits + leaf passes (a failed box test is a pass too)
         print("%-48s %-8s %10d %8.2f %8.2f %8.2f %8.2f %8.2f %6d%s" % (name, "shadow" if sh else "closest", c[0], c[1] / r, c[2] / r, c[4] / r, steps, c[5] / r, c[7],
             "" if sh else " | %d of %d (%.2e), of which %d in t" % (differ[name], c[0], differ[name] / r, differ_t[name])))
+    print("closest-hit rays with the slots of a record visited by ENTRY DISTANCE instead of the order table (5 compare-exchanges on computed keys "
+          "instead of 4 tabulated ones: ~ +15 vector instructions per visit):")
+    for name, c in dist_tot.items():
+        r = max(int(c[0]), 1)
+        print("%-48s %8.2f visits %8.2f steps | %d hits differ" % (name, c[1] / r, (int(c[1]) + int(c[4]) + int(c[3])) / r, dist_differ[name]))

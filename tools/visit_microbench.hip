@@ -38,8 +38,11 @@ template <bool SHADOW, bool COOP = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_visit_chain(const float4* __restrict__ nodes, uint32_t n_hot,
     uint32_t n_l2, uint32_t n_all, uint32_t thr_l1, uint32_t thr_l2, uint32_t steps, float* __restrict__ out)
 {
-    __shared__ uint2 stack[12][64];
-    __shared__ float4 stage[COOP ? 4 : 1][COOP ? 65 : 1];
+    __shared__ uint2 stack[12][64];                  // 6144 bytes exactly, like the production instance: 26 waves per CU fit (round 3's build declared a
+                                                     // 16-byte dummy beside it for the non-cooperative instances -- one LDS granule more, 24 per CU, and the
+                                                     // 26-waves point of its sweep ran in two rounds: THAT was the collapse at the kernel's own residency)
+    extern __shared__ float4 stage_dyn[];            // COOP only: 4 x 65 float4, passed as dynamic shared memory
+    float4 (*stage)[65] = reinterpret_cast<float4 (*)[65]>(stage_dyn);
     const uint32_t lane = threadIdx.x;
     const char* const node_base = reinterpret_cast<const char*>(nodes);
     // a ray per lane: origin inside the unit cube the nodes live in, direction from a hash
@@ -170,7 +173,7 @@ int main(int argc, char** argv)
             for (int rep = 0; rep < 2; ++rep)       // the first run warms the caches
             {
                 CHECK(hipEventRecord(a));
-                if (shadow == 2) hipLaunchKernelGGL((k_visit_chain<false, true>), dim3(blocks), dim3(64), 0, 0, d_nodes, n_hot, n_l2, n_all, thr_l1, thr_l2, steps, d_out);
+                if (shadow == 2) hipLaunchKernelGGL((k_visit_chain<false, true>), dim3(blocks), dim3(64), 4 * 65 * sizeof(float4), 0, d_nodes, n_hot, n_l2, n_all, thr_l1, thr_l2, steps, d_out);
                 else if (shadow) hipLaunchKernelGGL(k_visit_chain<true>, dim3(blocks), dim3(64), 0, 0, d_nodes, n_hot, n_l2, n_all, thr_l1, thr_l2, steps, d_out);
                 else hipLaunchKernelGGL(k_visit_chain<false>, dim3(blocks), dim3(64), 0, 0, d_nodes, n_hot, n_l2, n_all, thr_l1, thr_l2, steps, d_out);
                 CHECK(hipEventRecord(b));

@@ -15,7 +15,7 @@ from tests.test_wide_bvh import wide_of
 N, L, TT = ord("N"), ord("L"), ord("T")
 
 
-def replay(ev, ln, node_q, leaf_q, direct_steps=None):
+def replay(ev, ln, node_q, leaf_q, direct_steps=None, refill_q=1):
     """One persistent wave draining the queue `ev` (rays x steps).  Returns passes and lane-steps per loop."""
     n = len(ln)
     stride = ev.shape[1]
@@ -36,7 +36,9 @@ def replay(ev, ln, node_q, leaf_q, direct_steps=None):
     while True:
         k = kind()
         idle = k == 0
-        if idle.any():
+        # (refill_q: phase A waits until that many lanes are idle, unless the node loop has nothing to run on -- a policy question
+        # this model can price: --refill-quorum)
+        if idle.any() and (int(idle.sum()) >= refill_q or int((k == N).sum()) < node_q or nxt >= n):
             # A: retire finished rays, hand out new ones
             need = np.where(idle)[0]
             take = min(len(need), n - nxt)
@@ -89,6 +91,7 @@ def main():
     ap.add_argument("--height", type=int, default=180)
     ap.add_argument("--bounces", type=int, default=8)
     ap.add_argument("--rays-per-queue", type=int, default=12000, help="rays of each queue the model wave drains")
+    ap.add_argument("--refill-quorum", default="1", help="comma-separated quorums of phase A to price at 32:8 (1 = the kernel's rule: any idle lane)")
     a = ap.parse_args()
     scene = host.Scene(arrays=S.city_block(a.triangles))
     scene.add_directional_light((-0.6, -1.5, 3.5), (15.0, 10.0, 5.0))
@@ -130,5 +133,25 @@ def main():
                      100.0 * (Ln["B"] + Ln["C"]) / max(tot, 1) / 64.0, tot / (steps / 64.0)))
 
 
+    return queues
+
+
+def price_refill(queues, quorums, cost=dict(A=220, B=140, C=179)):
+    """vector instructions per ray (static per-pass counts of the three loops, tools/isa_mix.py --loops) for each refill quorum"""
+    for flavour in ("closest", "shadow"):
+        rays = sum(len(ln) for ev, ln in queues[flavour])
+        for rq in quorums:
+            P = dict(A=0, B=0, C=0)
+            for ev, ln in queues[flavour]:
+                p, l = replay(ev, ln, 32, 8, refill_q=rq)
+                for key in P:
+                    P[key] += p[key]
+            print("%s  refill quorum %2d: passes per ray A %.3f B %.3f C %.3f -> %.1f vector instructions per ray" % (
+                flavour, rq, P["A"] / rays, P["B"] / rays, P["C"] / rays, sum(cost[k] * P[k] for k in P) / rays))
+
+
 if __name__ == "__main__":
-    main()
+    q = main()
+    rq = [int(x) for x in sys.argv[sys.argv.index("--refill-quorum") + 1].split(",")] if "--refill-quorum" in sys.argv else []
+    if rq:
+        price_refill(q, rq)
