@@ -161,11 +161,14 @@ int main(int argc, char** argv)
     hipEvent_t a, b;
     CHECK(hipEventCreate(&a));
     CHECK(hipEventCreate(&b));
-    printf("{\"device\": \"%s\", \"compute_units\": %u, \"l1_hit\": %.4f, \"l2_hit\": %.4f, \"steps\": %u, \"runs\": [", prop.gcnArchName, cus, l1_hit, l2_hit, steps);
+    // how many of these one-wave blocks (6144 bytes of LDS, like the production instance) the runtime says fit on a CU
+    int resident = 0;
+    CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, k_visit_chain<false>, 64, 0));
+    printf("{\"device\": \"%s\", \"compute_units\": %u, \"l1_hit\": %.4f, \"l2_hit\": %.4f, \"steps\": %u, \"resident_blocks_per_cu\": %d, \"runs\": [", prop.gcnArchName, cus, l1_hit, l2_hit, steps, resident);
     bool first = true;
     const bool coop_too = argc > 4 && atoi(argv[4]) != 0;
     for (int shadow = 0; shadow < (coop_too ? 3 : 2); ++shadow)
-        for (uint32_t wpc : {1u, 4u, 8u, 12u, 16u, 20u, 24u, 26u})
+        for (uint32_t wpc : {1u, 4u, 8u, 12u, 16u, 20u, 24u, 25u, 26u})
         {
             if (shadow == 2 && wpc > 16u) continue;   // the staging buffer: 10 KiB of LDS per wave, 15 waves per CU
             const uint32_t blocks = cus * wpc;
