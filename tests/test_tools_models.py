@@ -75,7 +75,14 @@ def test_code_object_identity_and_the_stale_flag_of_the_roofline(tmp_path):
             assert r["traffic"] == 8.0e9 and r["stale"] is want_stale and r["counters"]["stale"] is want_stale
             assert r["units"]["valu_busy"] == 0.86 and r["algorithmic"]["traffic_over_algorithmic"] < 0.1
             lc = r["latency_ceiling"]
-            assert abs(lc["ceiling_grays"] - lc["best_gvisits_per_s"] / 24.07) < 1e-3 and abs(lc["frac_of_ceiling"] - lc["achieved_grays"] / lc["ceiling_grays"]) < 1e-3
+            # the visit-rate ceiling is quoted AT THE KERNEL'S RESIDENCY, not at the best point of the sweep (a bench the product
+            # beats at its operating point is a model, not a ceiling)
+            assert abs(lc["ceiling_grays"] - lc["gvisits_per_s_at_residency"] / 24.07) < 1e-3 and abs(lc["frac_of_ceiling"] - lc["achieved_grays"] / lc["ceiling_grays"]) < 1e-3
+            assert lc["resident_waves_per_cu"] in (24, 25, 26)
+            c = r["ceilings"]
+            assert abs(c["grays"]["valu_issue"] - c["achieved_grays"] / 0.86) < 2e-3 and abs(c["grays"]["l1_texture_address"] - c["achieved_grays"] / 0.79) < 2e-3
+            assert set(c["grays"]) == {"valu_issue", "l1_texture_address", "hbm"} and "MODEL" in lc["is_a"]
+            assert c["binding"] == min(c["grays"], key=c["grays"].get) and abs(c["frac_of_ceiling"] - c["achieved_grays"] / min(c["grays"].values())) < 1e-3
         bench.COUNTERS_FILE = str(tmp_path / "none.json")
         r = bench.roofline_object(args, 1, live, per_ray, iso)
         assert r["achieved"] is None and "error" in r["counters"]                 # says so instead of silently changing `bound`
