@@ -146,6 +146,8 @@ struct rt_frame
     uint32_t trace_variant = 5;  // RT_OPT_TRACE_VARIANT (5 = auto)
     uint64_t small_launch_paths = 3000000ull;   // RT_OPT_SMALL_LAUNCH_PATHS: launches of fewer rays run k_trace_w4 in chunk mode
     uint32_t trace_waves_per_cu = 0;   // RT_OPT_TRACE_WAVES_PER_CU (0 = LDS-limited residency)
+    uint64_t trace_tail_paths = 50000000ull;  // RT_OPT_TRACE_TAIL_PATHS: batches of fewer paths launch the instance with loop D (8 / 16 / 32 / 64 / 128 samples of
+                                              // a 1080p frame in flight: +4.4 / +2.6 / +0.1 / -1.3 / -1.4 %, profiles/r04_call10.log, r04_call11.log)
     uint32_t trace_tail_lanes = 40;    // RT_OPT_TRACE_TAIL_LANES: k_trace_w4's loop D (0 = off); sweep: profiles/r04_call04_kernel_ab.log
     uint32_t select_form_box = 0;      // RT_OPT_TRACE_SELECT_FORM_BOX: every ray takes the select-form slab test
     uint32_t trace_tune = 0;           // RT_OPT_TRACE_TUNE: k_trace2 loop thresholds (0 = defaults)
@@ -1557,6 +1559,7 @@ int rt_set_option(rt_frame* f, int option, uint32_t value)
     case RT_OPT_DEBUG_ALLOC_LIMIT: f->debug_alloc_limit = value; return RT_OK;
     case RT_OPT_SMALL_LAUNCH_PATHS: f->small_launch_paths = value; return RT_OK;
     case RT_OPT_TRACE_TAIL_LANES: f->trace_tail_lanes = value > 64u ? 64u : value; return RT_OK;
+    case RT_OPT_TRACE_TAIL_PATHS: f->trace_tail_paths = value; return RT_OK;
     case RT_OPT_COMPACT_LOG:
     case RT_OPT_DEBUG_LOG_POOL_DIV:
         if (option == RT_OPT_DEBUG_LOG_POOL_DIV && value == 0) return fail(f->ctx, "rt_set_option: RT_OPT_DEBUG_LOG_POOL_DIV must be >= 1");
@@ -1661,7 +1664,7 @@ void launch_trace_w4(rt_frame* f, const float4* o4, const float4* d4, const uint
     // the instance with loop D (the fused tail pass) where the whole batch is a small launch: the kernel then runs in chunk
     // mode whatever its live counter says (count <= paths < chunk_below)
     const uint64_t paths = (uint64_t)f->p->chunk_count * (f->p->cur_slots ? f->p->cur_slots : 1u);
-    const bool tail = STACK == 12 && f->trace_tail_lanes != 0u && paths < (uint64_t)chunk_below;
+    const bool tail = STACK == 12 && f->trace_tail_lanes != 0u && paths < f->trace_tail_paths;
     if (!SHADOW && STACK == 12 && f->timeline)          // tools/launch_timeline.py: the instrumented instance
         hipLaunchKernelGGL((k_trace_w4<false, 12, true, false>), dim3(blocks), dim3(64), 0, f->tl_stream, ctx->scene.d, o4, d4, aux, count,
             &f->p->counters->head[s][0], f->p->hits, dlog(f), f->tl_spill, tune, f->tl_slow_list,
