@@ -314,6 +314,17 @@ class Frame:
         self._c(self.lib.rt_frame_resolve(self.handle, out.ctypes.data))
         return out
 
+    def present(self, out=None):
+        """rt_frame_present: resolve + Finish() on the frame's kernels; the image travels to `out` (kept alive by the caller) on a
+        copy stream and is complete after present_wait().  Returns `out`."""
+        if out is None:
+            out = np.zeros((self.local_rows, self.width, 4), np.float32)
+        self._c(self.lib.rt_frame_present(self.handle, out.ctypes.data))
+        return out
+
+    def present_wait(self):
+        self._c(self.lib.rt_frame_present_wait(self.handle))
+
     def radiance_device_ptr(self):
         return self.lib.rt_frame_radiance_device_ptr(self.handle)
 

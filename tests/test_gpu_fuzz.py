@@ -127,8 +127,12 @@ def test_random_scene_matches_oracle_bit_for_bit(ctx, env_map, seed):
     furnace = bool(rng.random() < 0.2)
     blue = bool(rng.random() < 0.3)
     ctx.set_wide_bvh(2 if seed % 4 == 1 else 1)                       # the wide tree's collapse: SAH-optimal (default) / two BVH2 levels per record
+    # the shadow rays' tree (round 4; keyed by the seed: the random stream of the other choices stays as it was): measured choice
+    # (default) / the backend's own tree forced / own with the surface-area metric / shared with the closest-hit rays -- same bits
+    ctx.set_shadow_tree((1, 2, 3, 2, 0)[seed % 5])
     ctx.upload_scene(sc)
     ctx.set_wide_bvh(1)
+    ctx.set_shadow_tree(1)
     fr = capi.Frame(ctx, w, h)
     fr.set_camera(cam); fr.set_max_bounces(bounces)
     fr.set_option(capi.OPT_WHITE_FURNACE, int(furnace))
@@ -143,6 +147,9 @@ def test_random_scene_matches_oracle_bit_for_bit(ctx, env_map, seed):
         fr.set_option(capi.OPT_DEBUG_LOG_POOL_DIV, 8 if seed % 2 else 64)
         if seed % 9 == 0:
             fr.set_option(capi.OPT_SAMPLES_IN_FLIGHT, 8)
+    # k_trace_w4's loop D (round 4): the instance that has it for every launch / none, and when it takes over a wave's last lanes
+    fr.set_option(capi.OPT_TRACE_TAIL_PATHS, (4000000000, 0, 50000000)[seed % 3])
+    fr.set_option(capi.OPT_TRACE_TAIL_LANES, (40, 1, 64, 16, 0)[(seed // 3) % 5])
     fr.set_option(capi.OPT_SMALL_LAUNCH_PATHS, int(rng.choice([3000000, 0, 4000000000, 700])))   # chunk mode below this many rays per launch: default, never, always, for the last bounces
     fr.integrate(spp)
     orc = _oracle.Oracle(w, h, sc, furnace=furnace)

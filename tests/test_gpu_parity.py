@@ -723,6 +723,37 @@ def test_device_group_gather_through_the_c_abi(ctx, golden_scenes):
         capi.Group.create([0, 7])
 
 
+def test_presented_frames_equal_resolved_frames(ctx, golden_scenes):
+    """rt_frame_present (round 4): ResolveRadiance + Finish() as the reference has them -- the frame's kernels have finished when it
+    returns, the image travels to the host meanwhile, double-buffered on the device.  Frame by frame it is the image
+    rt_frame_resolve returns; presenting again into the same buffer, or resolving while an image is still travelling, is safe."""
+    w, h, b = 96, 60, 4
+    sc = golden_scenes["coverage"]
+    cam = T.default_camera(w, h)
+    ctx.upload_scene(sc)
+    a, p = capi.Frame(ctx, w, h), capi.Frame(ctx, w, h)
+    for f in (a, p):
+        f.set_camera(cam); f.set_max_bounces(b)
+    buf = np.zeros((h, w, 4), np.float32)
+    other = np.zeros((h, w, 4), np.float32)
+    for frame_no in range(5):
+        a.integrate(1); p.integrate(1)
+        want = a.resolve()
+        got = p.present(buf if frame_no != 2 else other)    # the third frame into another buffer: copies to different destinations are ordered too
+        p.present_wait()
+        assert np.array_equal(got, want, equal_nan=True), frame_no
+    # back to back without waiting: the copies are ordered, the last one wins
+    p.integrate(1); p.present(buf); p.integrate(1); p.present(buf)
+    a.integrate(2)
+    p.present_wait()
+    assert np.array_equal(buf, a.resolve(), equal_nan=True)
+    # a synchronous resolve while a presented image is still on its way waits for it first
+    p.integrate(1); a.integrate(1)
+    p.present(buf)
+    assert np.array_equal(p.resolve(), a.resolve(), equal_nan=True)
+    a.close(); p.close()
+
+
 def test_graft_entry_smoke():
     """The driver's round-end smoke check: one small invocation of the hot path against the oracle."""
     import __graft_entry__
