@@ -219,8 +219,6 @@ enum rt_option
                                        Mrays/s per frame at 0 / 16 / 32 / 40 / 48); 0 = off.  Results are identical for every value. */
     , RT_OPT_TRACE_TAIL_PATHS = 22  /* batches of fewer paths than this (tile pixels x samples in flight; default 50 000 000: it pays up to ~16 samples of a 1080p frame in flight and costs ~1.4 % at 128) launch the
                                        k_trace_w4 instance that has loop D.  Results are identical for every value. */
-    , RT_OPT_FIRST_BOUNCE_REFILL = 23 /* camera-ray launches (bounce 0) of at least this many rays run k_trace_w4 in refill mode whatever
-                                       RT_OPT_SMALL_LAUNCH_PATHS says (0 = off).  Results are identical for every value. */
     , RT_OPT_TRACE_TUNE = 12       /* k_trace2 (variants 8, 9) loop thresholds: value & 255 = lanes that must hold an
                                        interior node for a wave to stay in the node loop, value >> 8 & 255 = lanes that
                                        must wait at a triangle for another pass of the triangle loop, value >> 16 & 255 = rays a wave takes

@@ -146,7 +146,6 @@ struct rt_frame
     uint32_t trace_variant = 5;  // RT_OPT_TRACE_VARIANT (5 = auto)
     uint64_t small_launch_paths = 3000000ull;   // RT_OPT_SMALL_LAUNCH_PATHS: launches of fewer rays run k_trace_w4 in chunk mode
     uint32_t trace_waves_per_cu = 0;   // RT_OPT_TRACE_WAVES_PER_CU (0 = LDS-limited residency)
-    uint64_t first_bounce_refill = 0;          // RT_OPT_FIRST_BOUNCE_REFILL: camera-ray launches of at least this many rays refill (0 = off)
     uint64_t trace_tail_paths = 50000000ull;  // RT_OPT_TRACE_TAIL_PATHS: batches of fewer paths launch the instance with loop D (8 / 16 / 32 / 64 / 128 samples of
                                               // a 1080p frame in flight: +4.4 / +2.6 / +0.1 / -1.3 / -1.4 %, profiles/r04_call10.log, r04_call11.log)
     uint32_t trace_tail_lanes = 40;    // RT_OPT_TRACE_TAIL_LANES: k_trace_w4's loop D (0 = off); sweep: profiles/r04_call04_kernel_ab.log
@@ -1561,7 +1560,6 @@ int rt_set_option(rt_frame* f, int option, uint32_t value)
     case RT_OPT_SMALL_LAUNCH_PATHS: f->small_launch_paths = value; return RT_OK;
     case RT_OPT_TRACE_TAIL_LANES: f->trace_tail_lanes = value > 64u ? 64u : value; return RT_OK;
     case RT_OPT_TRACE_TAIL_PATHS: f->trace_tail_paths = value; return RT_OK;
-    case RT_OPT_FIRST_BOUNCE_REFILL: f->first_bounce_refill = value; return RT_OK;
     case RT_OPT_COMPACT_LOG:
     case RT_OPT_DEBUG_LOG_POOL_DIV:
         if (option == RT_OPT_DEBUG_LOG_POOL_DIV && value == 0) return fail(f->ctx, "rt_set_option: RT_OPT_DEBUG_LOG_POOL_DIV must be >= 1");
@@ -1645,7 +1643,7 @@ void launch_trace2(rt_frame* f, const float4* o4, const float4* d4, const uint32
 
 // k_trace_w4 over the 4-wide quantized tree, then k_trace2 over the (normally empty) list of rays it left out
 template <bool SHADOW, int STACK>
-void launch_trace_w4(rt_frame* f, const float4* o4, const float4* d4, const uint32_t* aux, const uint32_t* count, uint32_t bounce)
+void launch_trace_w4(rt_frame* f, const float4* o4, const float4* d4, const uint32_t* aux, const uint32_t* count, uint32_t /*bounce*/)
 {
     rt_ctx* ctx = f->ctx;
     uint32_t per_cu = (160u * 1024u) / (STACK * 512u);
@@ -1661,10 +1659,9 @@ void launch_trace_w4(rt_frame* f, const float4* o4, const float4* d4, const uint
     if (rays_per_lane == 255u) rays_per_lane = 0u;                          // 255 = every wave of the residency-sized grid
     const uint32_t tune = node_q | leaf_q << 8 | (t & 0xFF0000u) | rays_per_lane << 24;
     const uint32_t s = f->tl_flavour;
-    uint32_t chunk_below = f->small_launch_paths > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)f->small_launch_paths;
-    // Camera rays are the one launch whose rays are all alike -- neighbouring pixels, ~17 steps each, no long stragglers: refilling
-    // lanes keeps them busy and leaves almost no tail, where chunks of 64 idle as their rays finish (RT_OPT_FIRST_BOUNCE_REFILL)
-    if (!SHADOW && bounce == 0u && f->first_bounce_refill && (uint64_t)f->p->chunk_count * (f->p->cur_slots ? f->p->cur_slots : 1u) >= f->first_bounce_refill) chunk_below = 0u;
+    const uint32_t chunk_below = f->small_launch_paths > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)f->small_launch_paths;
+    // (Camera-ray launches refilled instead of chunked -- coherent rays, short tails? -- measured: 2477 instead of 2876 Mrays/s per frame,
+    // profiles/r04_call14.log: a refilling launch of any size pays its ~0.6 ms drain.)
     unsigned long long* const no_timeline = nullptr;
     // the instance with loop D (the fused tail pass) where the whole batch is a small launch: the kernel then runs in chunk
     // mode whatever its live counter says (count <= paths < chunk_below)
