@@ -498,6 +498,7 @@ def main():
     ap.add_argument("--closest-tree", type=int, default=None, help="RT_CTX_OPT_CLOSEST_TREE (library default 0 = bit-identical; 1 / 2 = TOLERANCE mode: "
                     "an own tree for closest-hit rays where it measures cheaper / always)")
     ap.add_argument("--tail-lanes", type=int, default=None, help="RT_OPT_TRACE_TAIL_LANES (library default 40; 0 = loop D off)")
+    ap.add_argument("--chunk-refill", type=int, default=None, help="RT_OPT_CHUNK_REFILL (library default 1)")
     ap.add_argument("--tail-paths", type=int, default=None, help="RT_OPT_TRACE_TAIL_PATHS (library default 50000000)")
     ap.add_argument("--libm-series", default=None, help="sample counts (e.g. 1,2,4,8) of parity.rel_l2_vs_libm_build_series: the HIP path against the "
                     "reference's kernels over glibc libm on a 960x540 frame of the same scene (default: 1,2,4,8 for --config 5, off elsewhere; '' = off)")
@@ -655,6 +656,8 @@ def main():
         assert lib.rt_set_option(frame, capi.OPT_COMPACT_LOG, args.compact_log) == 0
     if args.tail_lanes is not None:
         assert lib.rt_set_option(frame, capi.OPT_TRACE_TAIL_LANES, args.tail_lanes) == 0
+    if args.chunk_refill is not None:
+        assert lib.rt_set_option(frame, capi.OPT_CHUNK_REFILL, args.chunk_refill) == 0
     if args.tail_paths is not None:
         assert lib.rt_set_option(frame, capi.OPT_TRACE_TAIL_PATHS, args.tail_paths) == 0
     if args.per_frame_only:

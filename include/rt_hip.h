@@ -219,6 +219,10 @@ enum rt_option
                                        Mrays/s per frame at 0 / 16 / 32 / 40 / 48); 0 = off.  Results are identical for every value. */
     , RT_OPT_TRACE_TAIL_PATHS = 22  /* batches of fewer paths than this (tile pixels x samples in flight; default 50 000 000: it pays up to ~16 samples of a 1080p frame in flight and costs ~1.4 % at 128) launch the
                                        k_trace_w4 instance that has loop D.  Results are identical for every value. */
+    , RT_OPT_CHUNK_REFILL = 23      /* k_trace_w4's chunk mode (small launches): 1 (default) = a wave's statically assigned chunks are its
+                                       private queue and a lane that finishes takes the next ray of it at once (no atomics, no
+                                       machine-wide tail); 0 = round 3's form, a wave finishes all 64 rays of a chunk before it takes
+                                       the next.  Results are identical for both. */
     , RT_OPT_TRACE_TUNE = 12       /* k_trace2 (variants 8, 9) loop thresholds: value & 255 = lanes that must hold an
                                        interior node for a wave to stay in the node loop, value >> 8 & 255 = lanes that
                                        must wait at a triangle for another pass of the triangle loop, value >> 16 & 255 = rays a wave takes

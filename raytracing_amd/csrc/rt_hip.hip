@@ -146,6 +146,7 @@ struct rt_frame
     uint32_t trace_variant = 5;  // RT_OPT_TRACE_VARIANT (5 = auto)
     uint64_t small_launch_paths = 3000000ull;   // RT_OPT_SMALL_LAUNCH_PATHS: launches of fewer rays run k_trace_w4 in chunk mode
     uint32_t trace_waves_per_cu = 0;   // RT_OPT_TRACE_WAVES_PER_CU (0 = LDS-limited residency)
+    uint32_t chunk_refill = 1;                 // RT_OPT_CHUNK_REFILL: chunk mode refills idle lanes from the wave's own chunks
     uint64_t trace_tail_paths = 50000000ull;  // RT_OPT_TRACE_TAIL_PATHS: batches of fewer paths launch the instance with loop D (8 / 16 / 32 / 64 / 128 samples of
                                               // a 1080p frame in flight: +4.4 / +2.6 / +0.1 / -1.3 / -1.4 %, profiles/r04_call10.log, r04_call11.log)
     uint32_t trace_tail_lanes = 40;    // RT_OPT_TRACE_TAIL_LANES: k_trace_w4's loop D (0 = off); sweep: profiles/r04_call04_kernel_ab.log
@@ -1560,6 +1561,7 @@ int rt_set_option(rt_frame* f, int option, uint32_t value)
     case RT_OPT_SMALL_LAUNCH_PATHS: f->small_launch_paths = value; return RT_OK;
     case RT_OPT_TRACE_TAIL_LANES: f->trace_tail_lanes = value > 64u ? 64u : value; return RT_OK;
     case RT_OPT_TRACE_TAIL_PATHS: f->trace_tail_paths = value; return RT_OK;
+    case RT_OPT_CHUNK_REFILL: f->chunk_refill = value ? 1u : 0u; return RT_OK;
     case RT_OPT_COMPACT_LOG:
     case RT_OPT_DEBUG_LOG_POOL_DIV:
         if (option == RT_OPT_DEBUG_LOG_POOL_DIV && value == 0) return fail(f->ctx, "rt_set_option: RT_OPT_DEBUG_LOG_POOL_DIV must be >= 1");
@@ -1671,15 +1673,15 @@ void launch_trace_w4(rt_frame* f, const float4* o4, const float4* d4, const uint
         hipLaunchKernelGGL((k_trace_w4<false, 12, true, false>), dim3(blocks), dim3(64), 0, f->tl_stream, ctx->scene.d, o4, d4, aux, count,
             &f->p->counters->head[s][0], f->p->hits, dlog(f), f->tl_spill, tune, f->tl_slow_list,
             &f->p->counters->slow_count[s], &f->p->counters->stack_spills, &f->p->counters->tl_start[f->timeline_bounce & 63u],
-            f->timeline_bounce & 63u, chunk_below, 0u);
+            f->timeline_bounce & 63u, chunk_below, 0u, f->chunk_refill);
     else if (tail)
         hipLaunchKernelGGL((k_trace_w4<SHADOW, 12, false, true>), dim3(blocks), dim3(64), 0, f->tl_stream, ctx->scene.d, o4, d4, aux, count,
             &f->p->counters->head[s][0], SHADOW ? (float4*)nullptr : f->p->hits, dlog(f),
-            f->tl_spill, tune, f->tl_slow_list, &f->p->counters->slow_count[s], &f->p->counters->stack_spills, no_timeline, 0u, chunk_below, f->trace_tail_lanes);
+            f->tl_spill, tune, f->tl_slow_list, &f->p->counters->slow_count[s], &f->p->counters->stack_spills, no_timeline, 0u, chunk_below, f->trace_tail_lanes, f->chunk_refill);
     else
         hipLaunchKernelGGL((k_trace_w4<SHADOW, STACK, false, false>), dim3(blocks), dim3(64), 0, f->tl_stream, ctx->scene.d, o4, d4, aux, count,
             &f->p->counters->head[s][0], SHADOW ? (float4*)nullptr : f->p->hits, dlog(f),
-            f->tl_spill, tune, f->tl_slow_list, &f->p->counters->slow_count[s], &f->p->counters->stack_spills, no_timeline, 0u, chunk_below, 0u);
+            f->tl_spill, tune, f->tl_slow_list, &f->p->counters->slow_count[s], &f->p->counters->stack_spills, no_timeline, 0u, chunk_below, 0u, f->chunk_refill);
     // The follow-up over the (normally empty) slow list: waves with a two-entry LDS stack (the rest of the stack
     // lives in the spill area) -- 1 KiB of LDS and a few registers, so it finds room beside the resident waves of the
     // OTHER stream's persistent launch (RT_OPT_OVERLAP_SHADOW) instead of waiting for that launch to end: with the

@@ -653,7 +653,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TAIL ? 7 : 4
     uint32_t* __restrict__ slow_list, uint32_t* __restrict__ slow_count, uint32_t* __restrict__ stat_counts /* [0] spills, [1] slow rays */,
     unsigned long long* __restrict__ timeline /* TIMELINE: DCounters::tl_start + timeline_slot (rt_frame_debug_timeline) */,
     uint32_t timeline_slot, uint32_t chunk_below /* launches of fewer rays run in chunk mode (below) */,
-    uint32_t tail_q /* loop D: with this many or fewer lanes busy and nothing to refill the others with, one fused pass serves all */)
+    uint32_t tail_q /* loop D: with this many or fewer lanes busy and nothing to refill the others with, one fused pass serves all */,
+    uint32_t chunk_refill /* chunk mode: idle lanes take the next rays of the wave's OWN chunks at once (below) */)
 {
     __shared__ uint2 stack[STACK][64];
     uint32_t* const stack32 = reinterpret_cast<uint32_t*>(&stack[0][0]);     // SHADOW: 2 * STACK entries of 4 bytes
@@ -829,7 +830,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TAIL ? 7 : 4
     {
         // ---- A: retire finished rays, start new ones -------------------------------------
         const unsigned long long idle_m = __ballot(ref == RT_IDLE_REF);
-        if (chunk_mode ? idle_m == ~0ull : idle_m != 0ull)
+        if ((chunk_mode && !(TAIL && chunk_refill)) ? idle_m == ~0ull : idle_m != 0ull)
         {
             if (ref == RT_IDLE_REF && ray_i != RT_INVALID_ID)
             {
@@ -850,7 +851,36 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TAIL ? 7 : 4
             }
             if (!pool.exhausted)
             {
-                if (chunk_mode)
+                if (TAIL && chunk_mode && chunk_refill)
+                {
+                    // STATIC chunks, REFILLED lanes (round 4; in the TAIL instance only: in the plain one the extra hand-out path costs the hot
+                    // loops 2 % through their register allocation, profiles/r04_call18.log): the wave's chunks -- slot, slot + waves per XCD, ... of its XCD's
+                    // region, as below -- are its private queue, and a lane that has finished takes the next ray of it at once
+                    // instead of idling until the slowest of its 64 is done.  No atomics (what made refilling from the shared
+                    // heads unusable for small launches: one same-address atomic per 64 rays), and each lane still traces a
+                    // handful of rays, so the drain at the end is one wave's last rays, not a machine-wide tail.
+                    const uint32_t rb = xcd * per < count ? xcd * per : count;
+                    const uint32_t re = (xcd + 1u) * per < count ? (xcd + 1u) * per : count;
+                    unsigned long long need = __ballot(ref == RT_IDLE_REF && ray_i == RT_INVALID_ID);
+                    while (need != 0ull)
+                    {
+                        if (pool.next >= pool.end)
+                        {
+                            const uint32_t at = rb + chunk_next * 64u;
+                            if (at >= re) { pool.exhausted = true; break; }
+                            pool.next = at;
+                            pool.end = at + 64u < re ? at + 64u : re;
+                            chunk_next += n_blocks >> 3;
+                        }
+                        const uint32_t avail = pool.end - pool.next;
+                        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
+                        const uint32_t n = (uint32_t)__popcll(need);
+                        if (ref == RT_IDLE_REF && ray_i == RT_INVALID_ID && rank < avail) ray_i = pool.next + rank;
+                        pool.next += n < avail ? n : avail;
+                        need = __ballot(ref == RT_IDLE_REF && ray_i == RT_INVALID_ID);
+                    }
+                }
+                else if (chunk_mode)
                 {
                     // static assignment, no atomics: wave `slot` of this XCD takes chunks slot, slot + waves per XCD, ... of
                     // the XCD's region (64 rays per hand-out through the shared heads costs one same-address atomic per 64
@@ -920,7 +950,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TAIL ? 7 : 4
         // reference's one-sample-per-frame pattern (DESIGN.md "Where a launch's time goes").  Here every busy lane fetches its
         // next 64-byte record -- wide node or triangle, the same four loads -- and takes its step in the SAME pass: one round
         // trip per step of every ray.  Per lane the sequence of nodes, leaves and t_max is unchanged.
-        if (TAIL && tail_q != 0u && (chunk_mode || pool.exhausted) && (uint32_t)__popcll(__ballot(ref != RT_IDLE_REF)) <= tail_q)
+        if (TAIL && tail_q != 0u && ((chunk_mode && !chunk_refill) || pool.exhausted) && (uint32_t)__popcll(__ballot(ref != RT_IDLE_REF)) <= tail_q)
         {
             do
             {
@@ -963,7 +993,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TAIL ? 7 : 4
             if (node_m == 0ull) break;
             if ((uint32_t)__popcll(node_m) < node_q)
             {
-                const unsigned long long waiting = __ballot((int)ref < -1 || (ref == RT_IDLE_REF && !pool.exhausted && !chunk_mode));
+                const unsigned long long waiting = __ballot((int)ref < -1 || (ref == RT_IDLE_REF && !pool.exhausted && (!chunk_mode || (TAIL && chunk_refill))));
                 if (waiting != 0ull) break;
             }
             if ((int)ref >= 0)

@@ -150,6 +150,7 @@ def test_random_scene_matches_oracle_bit_for_bit(ctx, env_map, seed):
     # k_trace_w4's loop D (round 4): the instance that has it for every launch / none, and when it takes over a wave's last lanes
     fr.set_option(capi.OPT_TRACE_TAIL_PATHS, (4000000000, 0, 50000000)[seed % 3])
     fr.set_option(capi.OPT_TRACE_TAIL_LANES, (40, 1, 64, 16, 0)[(seed // 3) % 5])
+    fr.set_option(capi.OPT_CHUNK_REFILL, 0 if seed % 4 == 2 else 1)    # chunk mode: round 3's form / lanes refilled from the wave's own chunks
     fr.set_option(capi.OPT_SMALL_LAUNCH_PATHS, int(rng.choice([3000000, 0, 4000000000, 700])))   # chunk mode below this many rays per launch: default, never, always, for the last bounces
     fr.integrate(spp)
     orc = _oracle.Oracle(w, h, sc, furnace=furnace)

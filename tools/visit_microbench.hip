@@ -121,6 +121,76 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
     out[blockIdx.x * 64u + lane] = acc + (float)sp;
 }
 
+// TWO independent chains per lane ("two node fetches in flight per lane"): the same visit, twice per pass,
+// the two fetches issued together -- does the memory-level parallelism buy visits per second at the kernel's residency, or do the
+// L1 / texture-address path and the vector ALU (both near their ceilings in the production kernel) take it back?
+template <bool SHADOW>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_visit_chain2(const float4* __restrict__ nodes, uint32_t n_hot,
+    uint32_t n_l2, uint32_t n_all, uint32_t thr_l1, uint32_t thr_l2, uint32_t steps, float* __restrict__ out)
+{
+    __shared__ uint2 stack[12][64];
+    const uint32_t lane = threadIdx.x;
+    const char* const node_base = reinterpret_cast<const char*>(nodes);
+    uint32_t h = (blockIdx.x * 64u + lane) * 2654435761u + 12345u;
+    auto rnd = [&]() { h ^= h << 13; h ^= h >> 17; h ^= h << 5; return h; };
+    const f3 org = F3((rnd() & 0xFFFF) * (1.0f / 65536.0f), (rnd() & 0xFFFF) * (1.0f / 65536.0f), (rnd() & 0xFFFF) * (1.0f / 65536.0f));
+    f3 dir = F3((rnd() & 0xFFFF) * (2.0f / 65536.0f) - 1.0f, (rnd() & 0xFFFF) * (2.0f / 65536.0f) - 1.0f, (rnd() & 0xFFFF) * (2.0f / 65536.0f) - 1.0f);
+    dir.x = dir.x == 0.0f ? 0.5f : dir.x; dir.y = dir.y == 0.0f ? 0.5f : dir.y; dir.z = dir.z == 0.0f ? 0.5f : dir.z;
+    const f3 inv = F3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
+    const uint32_t sign_bits = (inv.x < 0.0f ? 1u : 0u) | (inv.y < 0.0f ? 2u : 0u) | (inv.z < 0.0f ? 4u : 0u);
+    const uint32_t octant4 = 4u * sign_bits;
+    const float t_min = 0.0f, INF = __builtin_inff();
+    const float t_max = 1.0e4f;
+    int sp = 0;
+    uint32_t hw_id, xcc_id;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
+    const uint32_t hot_base = (((xcc_id & 0xFu) << 8) | ((hw_id >> 8) & 0xFFu)) * n_hot;
+    const uint32_t l2_base = 4096u * n_hot + (xcc_id & 0xFu) * n_l2;
+    uint32_t ref[2] = {hot_base + (lane % n_hot), hot_base + ((lane * 7u + 3u) % n_hot)};
+    float acc = 0.0f;
+    for (uint32_t s = 0; s < steps; s += 2u)
+    {
+        const float4* np0 = reinterpret_cast<const float4*>(node_base + (size_t)(ref[0] << 6));
+        const float4* np1 = reinterpret_cast<const float4*>(node_base + (size_t)(ref[1] << 6));
+        const float4 a0 = np0[0], a1 = np0[1], a2 = np0[2], a3 = np0[3];
+        const float4 b0 = np1[0], b1 = np1[1], b2 = np1[2], b3 = np1[3];
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+        {
+            uint32_t r[4];
+            float e[4];
+            if (c == 0) w4_test_slots<SHADOW>(a0, a1, a2, a3, org, inv, sign_bits, octant4, t_min, t_max, r, e);
+            else w4_test_slots<SHADOW>(b0, b1, b2, b3, org, inv, sign_bits, octant4, t_min, t_max, r, e);
+            const bool v0 = e[0] < INF, v1 = e[1] < INF, v2 = e[2] < INF, v3 = e[3] < INF;
+            uint32_t next;
+            if (v3 && (v0 || v1 || v2)) { stack[sp % 12][lane] = make_uint2(r[3], __float_as_uint(e[3])); ++sp; }
+            if (v2 && (v0 || v1)) { stack[sp % 12][lane] = make_uint2(r[2], __float_as_uint(e[2])); ++sp; }
+            if (v1 && v0) { stack[sp % 12][lane] = make_uint2(r[1], __float_as_uint(e[1])); ++sp; }
+            if (v0) next = r[0];
+            else if (v1) next = r[1];
+            else if (v2) next = r[2];
+            else if (v3) next = r[3];
+            else
+            {
+                next = ref[c] * 2246822519u + s;
+                while (sp > 0)
+                {
+                    --sp;
+                    const uint2 en = stack[sp % 12][lane];
+                    if (t_max >= __uint_as_float(en.y)) { next = en.x; break; }
+                }
+            }
+            acc += e[0] < INF ? e[0] : 0.0f;
+            if (sp > 9) sp = 3;
+            const uint32_t pick = (next ^ (next >> 15)) * 2654435761u;
+            const uint32_t where = pick >> 8;
+            ref[c] = where < thr_l1 ? hot_base + (pick % n_hot) : (where < thr_l2 ? l2_base + (pick % n_l2) : (pick % n_all));
+        }
+    }
+    out[blockIdx.x * 64u + lane] = acc + (float)sp;
+}
+
 int main(int argc, char** argv)
 {
     const double l1_hit = argc > 2 ? atof(argv[1]) : 0.93, l2_hit = argc > 2 ? atof(argv[2]) : 0.85;
@@ -167,16 +237,18 @@ int main(int argc, char** argv)
     printf("{\"device\": \"%s\", \"compute_units\": %u, \"l1_hit\": %.4f, \"l2_hit\": %.4f, \"steps\": %u, \"resident_blocks_per_cu\": %d, \"runs\": [", prop.gcnArchName, cus, l1_hit, l2_hit, steps, resident);
     bool first = true;
     const bool coop_too = argc > 4 && atoi(argv[4]) != 0;
-    for (int shadow = 0; shadow < (coop_too ? 3 : 2); ++shadow)
+    for (int shadow = 0; shadow < (coop_too ? 5 : 4); ++shadow)
         for (uint32_t wpc : {1u, 4u, 8u, 12u, 16u, 20u, 24u, 25u, 26u})
         {
-            if (shadow == 2 && wpc > 16u) continue;   // the staging buffer: 10 KiB of LDS per wave, 15 waves per CU
+            if (shadow == 4 && wpc > 16u) continue;   // the staging buffer: 10 KiB of LDS per wave, 15 waves per CU
             const uint32_t blocks = cus * wpc;
             float ms = 0.0f;
             for (int rep = 0; rep < 2; ++rep)       // the first run warms the caches
             {
                 CHECK(hipEventRecord(a));
-                if (shadow == 2) hipLaunchKernelGGL((k_visit_chain<false, true>), dim3(blocks), dim3(64), 4 * 65 * sizeof(float4), 0, d_nodes, n_hot, n_l2, n_all, thr_l1, thr_l2, steps, d_out);
+                if (shadow == 2) hipLaunchKernelGGL(k_visit_chain2<false>, dim3(blocks), dim3(64), 0, 0, d_nodes, n_hot, n_l2, n_all, thr_l1, thr_l2, steps, d_out);
+                else if (shadow == 3) hipLaunchKernelGGL(k_visit_chain2<true>, dim3(blocks), dim3(64), 0, 0, d_nodes, n_hot, n_l2, n_all, thr_l1, thr_l2, steps, d_out);
+                else if (shadow == 4) hipLaunchKernelGGL((k_visit_chain<false, true>), dim3(blocks), dim3(64), 4 * 65 * sizeof(float4), 0, d_nodes, n_hot, n_l2, n_all, thr_l1, thr_l2, steps, d_out);
                 else if (shadow) hipLaunchKernelGGL(k_visit_chain<true>, dim3(blocks), dim3(64), 0, 0, d_nodes, n_hot, n_l2, n_all, thr_l1, thr_l2, steps, d_out);
                 else hipLaunchKernelGGL(k_visit_chain<false>, dim3(blocks), dim3(64), 0, 0, d_nodes, n_hot, n_l2, n_all, thr_l1, thr_l2, steps, d_out);
                 CHECK(hipEventRecord(b));
@@ -186,7 +258,7 @@ int main(int argc, char** argv)
             const double ns_per_visit = (double)ms * 1e6 / steps;
             const double visits_per_s = (double)blocks * 64.0 * steps / ((double)ms * 1e-3);
             printf("%s{\"kernel\": \"%s\", \"waves_per_cu\": %u, \"ms\": %.4f, \"ns_per_visit\": %.2f, \"gvisits_per_s\": %.3f}", first ? "" : ", ",
-                shadow == 2 ? "closest, quad-cooperative fetch" : (shadow ? "shadow" : "closest"), wpc, ms, ns_per_visit, visits_per_s * 1e-9);
+                shadow == 4 ? "closest, quad-cooperative fetch" : (shadow == 3 ? "shadow, two chains per lane" : (shadow == 2 ? "closest, two chains per lane" : (shadow ? "shadow" : "closest"))), wpc, ms, ns_per_visit, visits_per_s * 1e-9);
             first = false;
         }
     printf("]}\n");
