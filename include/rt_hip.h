@@ -199,7 +199,9 @@ enum rt_option
                                        no refill of single lanes, no hand-out atomics -- decided inside the kernel from the live
                                        queue counter.  It is what makes the reference's own call pattern (one Integrate() per
                                        frame, one sample per pixel in flight) fast, and the late bounces of any batch.  Default
-                                       3 000 000; 0 = never.  Results are identical for every value. */
+                                       3 000 000 -- 8 000 000 in the instance small batches launch (RT_OPT_TRACE_TAIL_PATHS), whose
+                                       chunks refill their lanes; setting the option sets both; 0 = never.  Results are identical
+                                       for every value. */
     , RT_OPT_COMPACT_LOG = 19      /* 1: rt_integrate batches of >= 8 samples in flight keep the radiance log COMPACT: six inline
                                        entries per path (a path of the benchmark scene logs 2.7 on average, 1 % more than six) +
                                        overflow blocks, bump-allocated one bounce ahead, for an eighth of the paths -- 290 instead

@@ -145,6 +145,7 @@ struct rt_frame
     uint32_t trace_blocks;       // v1 grid
     uint32_t trace_variant = 5;  // RT_OPT_TRACE_VARIANT (5 = auto)
     uint64_t small_launch_paths = 3000000ull;   // RT_OPT_SMALL_LAUNCH_PATHS: launches of fewer rays run k_trace_w4 in chunk mode
+    bool small_launch_set = false;              // ... set by the caller (otherwise the loop-D instance uses 8 M: launch_trace_w4)
     uint32_t trace_waves_per_cu = 0;   // RT_OPT_TRACE_WAVES_PER_CU (0 = LDS-limited residency)
     uint32_t chunk_refill = 1;                 // RT_OPT_CHUNK_REFILL: chunk mode refills idle lanes from the wave's own chunks
     uint64_t trace_tail_paths = 50000000ull;  // RT_OPT_TRACE_TAIL_PATHS: batches of fewer paths launch the instance with loop D (8 / 16 / 32 / 64 / 128 samples of
@@ -1558,7 +1559,7 @@ int rt_set_option(rt_frame* f, int option, uint32_t value)
         }
         return RT_OK;
     case RT_OPT_DEBUG_ALLOC_LIMIT: f->debug_alloc_limit = value; return RT_OK;
-    case RT_OPT_SMALL_LAUNCH_PATHS: f->small_launch_paths = value; return RT_OK;
+    case RT_OPT_SMALL_LAUNCH_PATHS: f->small_launch_paths = value; f->small_launch_set = true; return RT_OK;
     case RT_OPT_TRACE_TAIL_LANES: f->trace_tail_lanes = value > 64u ? 64u : value; return RT_OK;
     case RT_OPT_TRACE_TAIL_PATHS: f->trace_tail_paths = value; return RT_OK;
     case RT_OPT_CHUNK_REFILL: f->chunk_refill = value ? 1u : 0u; return RT_OK;
@@ -1661,14 +1662,18 @@ void launch_trace_w4(rt_frame* f, const float4* o4, const float4* d4, const uint
     if (rays_per_lane == 255u) rays_per_lane = 0u;                          // 255 = every wave of the residency-sized grid
     const uint32_t tune = node_q | leaf_q << 8 | (t & 0xFF0000u) | rays_per_lane << 24;
     const uint32_t s = f->tl_flavour;
-    const uint32_t chunk_below = f->small_launch_paths > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)f->small_launch_paths;
+    // the instance with loop D and refilled chunks (below): static assignment stays ahead of the shared work heads up to larger launches
+    // there -- 8 M rays instead of 3 M (4 / 8 / 16 samples of a 1080p frame in flight: +2.7 / +8.4 / +4.8 %, profiles/r04_call20.log)
+    const uint64_t batch_paths = (uint64_t)f->p->chunk_count * (f->p->cur_slots ? f->p->cur_slots : 1u);
+    const bool tail_instance = STACK == 12 && f->trace_tail_lanes != 0u && batch_paths < f->trace_tail_paths && !(!SHADOW && f->timeline);
+    const uint64_t small = f->small_launch_set || !tail_instance ? f->small_launch_paths : 8000000ull;
+    const uint32_t chunk_below = small > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)small;
     // (Camera-ray launches refilled instead of chunked -- coherent rays, short tails? -- measured: 2477 instead of 2876 Mrays/s per frame,
     // profiles/r04_call14.log: a refilling launch of any size pays its ~0.6 ms drain.)
     unsigned long long* const no_timeline = nullptr;
     // the instance with loop D (the fused tail pass) where the whole batch is a small launch: the kernel then runs in chunk
     // mode whatever its live counter says (count <= paths < chunk_below)
-    const uint64_t paths = (uint64_t)f->p->chunk_count * (f->p->cur_slots ? f->p->cur_slots : 1u);
-    const bool tail = STACK == 12 && f->trace_tail_lanes != 0u && paths < f->trace_tail_paths;
+    const bool tail = tail_instance;
     if (!SHADOW && STACK == 12 && f->timeline)          // tools/launch_timeline.py: the instrumented instance
         hipLaunchKernelGGL((k_trace_w4<false, 12, true, false>), dim3(blocks), dim3(64), 0, f->tl_stream, ctx->scene.d, o4, d4, aux, count,
             &f->p->counters->head[s][0], f->p->hits, dlog(f), f->tl_spill, tune, f->tl_slow_list,
