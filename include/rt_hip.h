@@ -219,7 +219,7 @@ enum rt_option
                                        in the SAME pass: one memory round trip per step of the chunk's last, longest rays
                                        instead of one per kind of lane.  Default 40 (sweep: 2228 / 2332 / 2479 / 2501 / 2488
                                        Mrays/s per frame at 0 / 16 / 32 / 40 / 48); 0 = off.  Results are identical for every value. */
-    , RT_OPT_TRACE_TAIL_PATHS = 22  /* batches of fewer paths than this (tile pixels x samples in flight; default 50 000 000: it pays up to ~16 samples of a 1080p frame in flight and costs ~1.4 % at 128) launch the
+    , RT_OPT_TRACE_TAIL_PATHS = 22  /* batches of fewer paths than this (tile pixels x samples in flight; default 100 000 000: it pays up to ~32 samples of a 1080p frame in flight and costs 2 - 3 % at 128) launch the
                                        k_trace_w4 instance that has loop D.  Results are identical for every value. */
     , RT_OPT_CHUNK_REFILL = 23      /* k_trace_w4's chunk mode (small launches): 1 (default) = a wave's statically assigned chunks are its
                                        private queue and a lane that finishes takes the next ray of it at once (no atomics, no

@@ -148,8 +148,8 @@ struct rt_frame
     bool small_launch_set = false;              // ... set by the caller (otherwise the loop-D instance uses 8 M: launch_trace_w4)
     uint32_t trace_waves_per_cu = 0;   // RT_OPT_TRACE_WAVES_PER_CU (0 = LDS-limited residency)
     uint32_t chunk_refill = 1;                 // RT_OPT_CHUNK_REFILL: chunk mode refills idle lanes from the wave's own chunks
-    uint64_t trace_tail_paths = 50000000ull;  // RT_OPT_TRACE_TAIL_PATHS: batches of fewer paths launch the instance with loop D (8 / 16 / 32 / 64 / 128 samples of
-                                              // a 1080p frame in flight: +4.4 / +2.6 / +0.1 / -1.3 / -1.4 %, profiles/r04_call10.log, r04_call11.log)
+    uint64_t trace_tail_paths = 100000000ull; // RT_OPT_TRACE_TAIL_PATHS: batches of fewer paths launch the instance with loop D and refilled chunks (8 / 16 / 32 / 64 /
+                                              // 128 samples of a 1080p frame in flight: +8 / +5 / +2.3 / -1.6 / -2.8 %, profiles/r04_call20_21.log, r04_call22.log)
     uint32_t trace_tail_lanes = 40;    // RT_OPT_TRACE_TAIL_LANES: k_trace_w4's loop D (0 = off); sweep: profiles/r04_call04_kernel_ab.log
     uint32_t select_form_box = 0;      // RT_OPT_TRACE_SELECT_FORM_BOX: every ray takes the select-form slab test
     uint32_t trace_tune = 0;           // RT_OPT_TRACE_TUNE: k_trace2 loop thresholds (0 = defaults)
