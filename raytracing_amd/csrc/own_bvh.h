@@ -95,7 +95,7 @@ struct Builder
         float cmn[3] = {INFINITY, INFINITY, INFINITY}, cmx[3] = {-INFINITY, -INFINITY, -INFINITY};
         for (uint32_t i = b; i < e; ++i)
             for (int a = 0; a < 3; ++a) { cmn[a] = std::min(cmn[a], prims[i].c[a]); cmx[a] = std::max(cmx[a], prims[i].c[a]); }
-        double best = INFINITY; int best_axis = -1; uint32_t best_at = 0; float best_plane = 0.0f; bool best_binned = false;
+        double best = INFINITY; int best_axis = -1; uint32_t best_at = 0;
         const float NINF = -INFINITY;
         if (n > 768u)
         {
@@ -125,7 +125,7 @@ struct Builder
                     if (bins[k].count) { for (int q = 0; q < 3; ++q) { mn[q] = std::min(mn[q], bins[k].mn[q]); mx[q] = std::max(mx[q], bins[k].mx[q]); } cnt += bins[k].count; }
                     if (cnt == 0 || cnt == n) continue;
                     const double c = metric.of(mn, mx) * cnt + scratch[k + 1];
-                    if (c < best) { best = c; best_axis = a; best_at = (uint32_t)k; best_binned = true; }
+                    if (c < best) { best = c; best_axis = a; best_at = (uint32_t)k; }
                 }
             }
             if (best_axis >= 0)
@@ -171,7 +171,6 @@ struct Builder
                 for (uint32_t i = 0; i < n; ++i) tmp[i] = prims[b + order[i]];
                 std::copy(tmp.begin(), tmp.end(), prims.begin() + b);
                 axis_out = (uint32_t)best_axis;
-                (void)best_plane; (void)best_binned;
                 return b + best_at;
             }
         }

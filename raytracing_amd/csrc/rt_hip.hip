@@ -181,7 +181,7 @@ struct rt_frame
     std::vector<hipEvent_t> event_pool;
 };
 
-int sync_frame_streams(rt_frame* f);
+static int sync_frame_streams(rt_frame* f);
 
 namespace
 {
@@ -1334,7 +1334,7 @@ int flush_log(rt_frame* f, bool keep_open)
 } // namespace
 
 // waits (host side) for every stream a frame launches on besides the context's own
-int sync_frame_streams(rt_frame* f)
+static int sync_frame_streams(rt_frame* f)
 {
     rt_ctx* ctx = f->ctx;
     for (PathPipe& q : f->ps)
@@ -2088,14 +2088,26 @@ int rt_frame_present(rt_frame* f, float* host_rgba)
     if (f->n_local == 0) return RT_OK;
     if (!f->present_stream)
     {
+        // all or nothing: a frame whose second image could not be allocated keeps presenting through rt_frame_resolve's path
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-        HIPCHK(ctx, hipStreamCreateWithPriority(&f->present_stream, hipStreamNonBlocking, lo));
-        for (hipEvent_t& e : f->ev_resolved) HIPCHK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        for (hipEvent_t& e : f->ev_copied) HIPCHK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        HIPCHK(ctx, hipMalloc((void**)&f->resolved_b, (size_t)f->n_local * sizeof(float4)));
-        HIPCHK(ctx, hipEventRecord(f->ev_copied[0], f->present_stream));
-        HIPCHK(ctx, hipEventRecord(f->ev_copied[1], f->present_stream));
+        hipStream_t st = nullptr;
+        hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+        float4* second = nullptr;
+        bool ok = hipStreamCreateWithPriority(&st, hipStreamNonBlocking, lo) == hipSuccess;
+        for (hipEvent_t& e : ev) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipMalloc((void**)&second, (size_t)f->n_local * sizeof(float4)) == hipSuccess;
+        ok = ok && hipEventRecord(ev[2], st) == hipSuccess && hipEventRecord(ev[3], st) == hipSuccess;
+        if (!ok)
+        {
+            (void)hipGetLastError();
+            if (second) (void)hipFree(second);
+            for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e);
+            if (st) (void)hipStreamDestroy(st);
+            return rt_frame_resolve(f, host_rgba);       // the synchronous form: same image, no overlap
+        }
+        f->present_stream = st; f->resolved_b = second;
+        f->ev_resolved[0] = ev[0]; f->ev_resolved[1] = ev[1]; f->ev_copied[0] = ev[2]; f->ev_copied[1] = ev[3];
     }
     if (flush_log(f) != RT_OK) return RT_ERROR;
     const uint32_t i = f->present_flip & 1u;
