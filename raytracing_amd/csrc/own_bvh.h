@@ -196,8 +196,10 @@ struct Builder
             const uint32_t mid = split(b, e, axis, scratch, order);
             const uint32_t nl = mid - b;
             write_interior(pos, mn, mx, axis, pos + 2u * nl);
-            build(b, mid, pos + 1u, collect, scratch, order);
-            b = mid; pos = pos + 2u * nl;                                 // the second child: iterate
+            // recurse into the SMALLER part, iterate on the larger: the positions of both are known (pos + 1 and pos + 2 nl), so the
+            // order does not matter and the recursion is at most log2(n) deep however lopsided the splits are
+            if (nl <= n - nl) { build(b, mid, pos + 1u, collect, scratch, order); b = mid; pos = pos + 2u * nl; }
+            else { build(mid, e, pos + 2u * nl, collect, scratch, order); e = mid; pos = pos + 1u; }
         }
     }
 };

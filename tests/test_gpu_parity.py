@@ -144,6 +144,48 @@ def test_stage_level_parity_rekeyed_by_pixel(ctx, golden_scenes):
                               orc.buffer("radiance", np.float32, n * 4).reshape(n, 4)[:, :3])
 
 
+def test_mid_sample_reads_on_a_compact_log_allocation(ctx, golden_scenes):
+    """the stage API on an allocation rt_integrate left in the COMPACT log layout (six inline entries + overflow blocks),
+    with the radiance read between the stages: the replay then zeroes what it has added and keeps every path's count and block
+    (k_flush keep_open) -- the sum stays the reference's after every bounce, no block is allocated twice, nothing is read before
+    the log."""
+    w, h, bounces = 56, 40, 7
+    sc = golden_scenes["coverage"]
+    cam = T.default_camera(w, h)
+    ctx.upload_scene(sc)
+    fr = capi.Frame(ctx, w, h)
+    fr.set_camera(cam)
+    fr.set_max_bounces(bounces)
+    fr.set_option(capi.OPT_SAMPLES_IN_FLIGHT, 8)
+    fr.set_option(capi.OPT_COMPACT_LOG, 1)
+    fr.integrate(8)
+    assert fr.stats().log_inline_entries == 6                       # the compact layout is what is allocated
+    orc = _oracle.Oracle(w, h, sc)
+    orc.set_camera(cam)
+    orc.set_max_bounces(bounces)
+    orc.integrate(8)
+    n = w * h
+    for sample in range(2):                                          # two more samples through the fifteen hooks' C calls
+        fr.generate_rays()
+        orc.stage("generate_rays")
+        for bounce in range(bounces + 1):
+            fr.intersect(bounce)
+            orc.stage("intersect", bounce)
+            fr.shade(bounce)
+            for st in ("shade_miss", "clear_counters", "shade_hits"):
+                orc.stage(st, bounce)
+            fr.intersect_shadow(bounce)
+            orc.stage("intersect_shadow")
+            orc.stage("accumulate")
+            assert np.array_equal(fr.radiance()[..., :3].reshape(n, 3), orc.buffer("radiance", np.float32, n * 4).reshape(n, 4)[:, :3]), (sample, bounce)
+        fr.advance_sample()
+        orc.stage("advance")
+    st = fr.stats()
+    assert st.log_fallbacks == 0 and (st.closest_rays, st.shadow_rays) == orc.ray_totals()
+    assert np.array_equal(fr.radiance()[..., :3], orc.radiance()[..., :3])
+    fr.close()
+
+
 @pytest.mark.parametrize("world,band", [(2, 8), (3, 4), (8, 8)])
 def test_tiling_is_bit_invariant(ctx, golden_scenes, world, band):
     """Image-space sharding (the multi-GPU partition) cannot change a pixel."""

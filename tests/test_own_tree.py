@@ -194,6 +194,28 @@ def test_shadow_verdicts_on_random_soups(seed, env_map):
     assert out["reference"]["differ"] == 0 and out["reference"]["shadow"][0] > 0
 
 
+def test_own_tree_on_a_lopsided_scene(env_map):
+    """Triangles whose sizes and spacings grow geometrically along a line: every SAH split peels off one end, the kind of input that
+    makes a top-down builder recurse as deep as it has leaves.  own_bvh.h recurses into the smaller part only; the tree it builds
+    is valid, and too deep a fold falls back to the reference topology instead of failing the upload."""
+    n = 6000
+    k = np.arange(n, dtype=np.float64)
+    x = 1.0005 ** k * 1e-3 * (1.0 + k)                                      # monotone, geometric spacing
+    P = np.zeros((n, 3, 3), np.float64)
+    P[:, 0] = np.stack([x, np.zeros(n), np.zeros(n)], 1)
+    P[:, 1] = P[:, 0] + np.stack([1e-4 * (1.0 + k), np.zeros(n), np.zeros(n)], 1)
+    P[:, 2] = P[:, 0] + np.stack([np.zeros(n), 1e-4 * (1.0 + k), np.full(n, 1e-4)], 1)
+    P = P.astype(np.float32)
+    N = np.zeros((n, 3, 3), np.float32); N[..., 2] = 1.0
+    tris = S.to_triangles([(P, N, np.zeros((n, 3, 2), np.float32), 0)])
+    mats = np.array([S.make_material(kd=(0.7, 0.6, 0.5))], dtype=T.packed_material)
+    arrays = _finish(host.Scene(arrays=dict(triangles=tris, materials=mats)), env_map, point=False)
+    own = own_tree(arrays["nodes"])
+    check_own_structure(arrays["nodes"], own)
+    rec, entry, report = capi.choose_tree(arrays, True, 1)                  # never raises: an own tree that does not qualify is just not taken
+    assert "shadow tree" in report
+
+
 def test_rt_scene_upload_measures_before_it_switches(env_map):
     tris, mats = S.cornell_blob(30_000, 3_000)
     arrays = _finish(host.Scene(arrays=dict(triangles=tris, materials=mats)), env_map, point=False)
