@@ -1431,6 +1431,131 @@ ORC_EXPORT int orc_wide_trace_events(void* h, const void* wide_records, uint32_t
     return wide_trace_impl(h, wide_records, n_wide, entry_ref, rays, n_rays, shadow, hits_out, shadow_out, counters, events, stride, lengths);
 }
 
+/* ---- what would a W-wide tree cost?  (analysis only: tools/own_tree_study.py; nothing of the product is restated here) -------------
+ * The SAH-optimal fold of a BVH2 -- the dynamic programme of build_wide_bvh (rt_hip.hip), for any width W -- and a walk of it with
+ * EXACT boxes: a record visit tests its <= W slots, closest-hit rays take the passing ones nearest first, leaves cost one pass per
+ * triangle.  counters: 0 rays, 1 record visits, 2 leaf arrivals, 3 triangle tests, 4 slots tested, 5 records in the tree.
+ * `nodes` / `nn`: the BVH2 to fold (NULL: the oracle's own, i.e. the reference's); its leaves must be the oracle's leaves. */
+typedef struct { const rt_bvh_node* nodes; uint32_t nn; uint32_t W; uint8_t* split; uint32_t* open; } nw_fold;
+static int nw_leaf(const nw_fold* f, uint32_t i) { return (f->nodes[i].num_primitives_axis >> 16) != 0; }
+static void nw_frontier(const nw_fold* f, uint32_t n, uint32_t k, uint32_t* out, uint32_t* count)
+{
+    const uint32_t c[2] = {n + 1, f->nodes[n].offset};
+    const uint32_t give[2] = {f->split[(size_t)n * (f->W + 1) + k], k - f->split[(size_t)n * (f->W + 1) + k]};
+    for (int i = 0; i < 2; ++i)
+    {
+        if (!nw_leaf(f, c[i]) && give[i] >= 2u && ((f->open[c[i]] >> give[i]) & 1u)) nw_frontier(f, c[i], give[i], out, count);
+        else out[(*count)++] = c[i];
+    }
+}
+ORC_EXPORT int orc_nwide_stats(void* h, uint32_t W, const rt_bvh_node* nodes, uint32_t nn, const rt_ray* rays, uint32_t n_rays, int shadow, uint64_t* counters)
+{
+    orc* o = (orc*)h;
+    if (W < 2 || W > 16) return 1;
+    if (!nodes) { nodes = o->nodes; nn = o->n_nodes; }
+    nw_fold f = {nodes, nn, W, NULL, NULL};
+    f.split = (uint8_t*)calloc((size_t)nn * (W + 1), 1);
+    f.open = (uint32_t*)calloc(nn, sizeof(uint32_t));
+    double* T = (double*)calloc(nn, sizeof(double));
+    double* F = (double*)calloc((size_t)nn * (W + 1), sizeof(double));
+    if (!f.split || !f.open || !T || !F) return 2;
+#define NW_G(c, i) (nw_leaf(&f, (c)) ? 0.0 : ((i) >= 2u ? (T[c] < F[(size_t)(c) * (W + 1) + (i)] ? T[c] : F[(size_t)(c) * (W + 1) + (i)]) : T[c]))
+    for (uint32_t n = nn; n-- > 0;)
+    {
+        if (nw_leaf(&f, n)) continue;
+        const uint32_t l = n + 1, r = nodes[n].offset;
+        for (uint32_t k = 2; k <= W; ++k)
+        {
+            double best = 0.0; uint32_t at = 0;
+            for (uint32_t i = 1; i < k; ++i)
+            {
+                const double c = NW_G(l, i) + NW_G(r, k - i);
+                if (at == 0 || c < best) { best = c; at = i; }
+            }
+            F[(size_t)n * (W + 1) + k] = best;
+            f.split[(size_t)n * (W + 1) + k] = (uint8_t)at;
+        }
+        const double dx = (double)nodes[n].bounds_max.x - nodes[n].bounds_min.x, dy = (double)nodes[n].bounds_max.y - nodes[n].bounds_min.y,
+                     dz = (double)nodes[n].bounds_max.z - nodes[n].bounds_min.z;
+        T[n] = (dx * dy + dy * dz + dz * dx) + F[(size_t)n * (W + 1) + W];
+        for (uint32_t i = 2; i <= W; ++i)
+            if (F[(size_t)n * (W + 1) + i] < T[n]) f.open[n] |= 1u << i;
+    }
+#undef NW_G
+    /* records in the tree */
+    {
+        uint32_t* todo = (uint32_t*)malloc((size_t)nn * sizeof(uint32_t));
+        uint32_t top = 0, recs = 0;
+        if (!nw_leaf(&f, 0)) todo[top++] = 0;
+        while (top)
+        {
+            const uint32_t n = todo[--top];
+            ++recs;
+            uint32_t slots[16], cnt = 0;
+            nw_frontier(&f, n, W, slots, &cnt);
+            for (uint32_t k = 0; k < cnt; ++k) if (!nw_leaf(&f, slots[k])) todo[top++] = slots[k];
+        }
+        counters[5] = recs;
+        free(todo);
+    }
+    for (uint32_t ri = 0; ri < n_rays; ++ri)
+    {
+        const rt_ray ray = rays[ri];
+        const v3 org = V3(ray.origin.x, ray.origin.y, ray.origin.z), dir = V3(ray.direction.x, ray.direction.y, ray.direction.z);
+        const v3 inv = V3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
+        const float t_min = ray.origin.w;
+        float t_max = ray.direction.w;
+        counters[0]++;
+        struct { uint32_t node; float entry; } stack[256];
+        int sp = 0, done = 0;
+        if (RayBounds(&nodes[0], org, inv, t_min, t_max)) { stack[sp].node = 0; stack[sp].entry = t_min; ++sp; }
+        while (sp > 0 && !done)
+        {
+            --sp;
+            const uint32_t n = stack[sp].node;
+            if (!shadow && stack[sp].entry > t_max) continue;
+            if (nw_leaf(&f, n))
+            {
+                counters[2]++;
+                const uint32_t first = nodes[n].offset, np = nodes[n].num_primitives_axis >> 16;
+                for (uint32_t i = 0; i < np && !done; ++i)
+                {
+                    counters[3]++;
+                    float u, v, t;
+                    if (RayTriangle(org, dir, t_min, t_max, &o->triangles[first + i], &u, &v, &t)) { t_max = t; if (shadow) done = 1; }
+                }
+                continue;
+            }
+            counters[1]++;
+            uint32_t slots[16], cnt = 0;
+            nw_frontier(&f, n, W, slots, &cnt);
+            uint32_t pr[16]; float pe[16]; int np = 0;
+            for (uint32_t k = 0; k < cnt; ++k)
+            {
+                counters[4]++;
+                const rt_bvh_node* b = &nodes[slots[k]];
+                /* the slab test of RayBounds, keeping the entry distance */
+                const float t0x = (b->bounds_min.x - org.x) * inv.x, t1x = (b->bounds_max.x - org.x) * inv.x;
+                const float t0y = (b->bounds_min.y - org.y) * inv.y, t1y = (b->bounds_max.y - org.y) * inv.y;
+                const float t0z = (b->bounds_min.z - org.z) * inv.z, t1z = (b->bounds_max.z - org.z) * inv.z;
+                const float en = f_max(f_max(f_max(f_min(t0x, t1x), f_min(t0y, t1y)), f_min(t0z, t1z)), t_min);
+                const float ex = f_min(f_min(f_min(f_max(t0x, t1x), f_max(t0y, t1y)), f_max(t0z, t1z)), t_max);
+                if (ex >= en) { pr[np] = slots[k]; pe[np] = en; ++np; }
+            }
+            if (!shadow)
+                for (int i = 1; i < np; ++i)
+                    for (int j = i; j > 0 && pe[j] < pe[j - 1]; --j)
+                    {
+                        const uint32_t tr = pr[j]; pr[j] = pr[j - 1]; pr[j - 1] = tr;
+                        const float te = pe[j]; pe[j] = pe[j - 1]; pe[j - 1] = te;
+                    }
+            for (int i = np - 1; i >= 0 && sp < 256; --i) { stack[sp].node = pr[i]; stack[sp].entry = pe[i]; ++sp; }
+        }
+    }
+    free(f.split); free(f.open); free(T); free(F);
+    return 0;
+}
+
 /* known-answer access to the leaf functions (tests/test_oracle_kat.py) */
 ORC_EXPORT uint32_t orc_wang_hash(uint32_t x) { return WangHash(x); }
 ORC_EXPORT float orc_sample_random(uint32_t x, uint32_t y, uint32_t s, uint32_t b, uint32_t t)

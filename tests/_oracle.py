@@ -159,6 +159,20 @@ class Oracle:
             raise RuntimeError("orc_wide_trace failed: %d" % rc)
         return sh if shadow else hits
 
+    def nwide_stats(self, width, rays, shadow, nodes=None):
+        """orc_nwide_stats: the SAH-optimal `width`-wide fold of a BVH2 (default: the oracle's own = the reference's) walked with exact
+        boxes.  Returns dict(rays, visits, leaf_arrivals, triangle_tests, slots_tested, records)."""
+        rays = np.ascontiguousarray(rays)
+        cnt = np.zeros(6, np.uint64)
+        self.lib.orc_nwide_stats.restype = C.c_int
+        self.lib.orc_nwide_stats.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p]
+        nd = np.ascontiguousarray(nodes) if nodes is not None else None
+        rc = self.lib.orc_nwide_stats(self.handle, width, nd.ctypes.data if nd is not None else None, len(nd) if nd is not None else 0,
+                                      rays.ctypes.data if len(rays) else None, len(rays), int(bool(shadow)), cnt.ctypes.data)
+        if rc != 0:
+            raise RuntimeError("orc_nwide_stats failed: %d" % rc)
+        return dict(zip(("rays", "visits", "leaf_arrivals", "triangle_tests", "slots_tested", "records"), (int(x) for x in cnt)))
+
     def wide_trace_events(self, wide_records, entry_ref, rays, shadow, stride=192, direct=False):
         """The step sequence of every ray's walk: (events uint8[n, stride] of b'N' / b'L' / b'T', lengths uint32[n])."""
         rays = np.ascontiguousarray(rays)

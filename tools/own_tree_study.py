@@ -79,6 +79,9 @@ if __name__ == "__main__":
     orc.set_camera(host.default_camera(w, h)); orc.set_max_bounces(a.bounces)
     orc.stage("reset"); orc.stage("generate_rays")
     tot = {(k, s): np.zeros(10, np.uint64) for k in trees for s in (False, True)}
+    widths = (4, 8, 16)
+    nw = {(t, wd, sh): dict(rays=0, visits=0, leaf_arrivals=0, triangle_tests=0, slots_tested=0, records=0) for t in ("reference topology", "own, surface area") for wd in widths for sh in (False, True)}
+    nw_nodes = {"reference topology": None, "own, surface area": own_iso}
     dist_tot = {k: np.zeros(10, np.uint64) for k in trees}                  # closest-hit rays, slots visited by entry distance
     dist_differ = {k: 0 for k in trees}
     differ = {k: 0 for k in trees}
@@ -101,6 +104,11 @@ if __name__ == "__main__":
             gd = orc.wide_trace(wide, entry, rays, False, c, direct=True, by_distance=True)
             dist_tot[name] += c
             dist_differ[name] += int(((gd["primitive_id"] != want["primitive_id"]) | (hit & (gd["t"] != want["t"]))).sum())
+        for tname, nd in nw_nodes.items():
+            for wd in widths:
+                r_ = orc.nwide_stats(wd, rays, False, nd)
+                for key, val in r_.items():
+                    nw[(tname, wd, False)][key] = val if key == "records" else nw[(tname, wd, False)][key] + val
         for st, args in (("shade_miss", (bounce,)), ("clear_counters", (bounce,)), ("shade_hits", (bounce,))):
             orc.stage(st, *args)
         ks = int(orc.buffer("shadow_ray_counter", np.uint32, 1)[0])
@@ -112,6 +120,11 @@ if __name__ == "__main__":
             got = orc.wide_trace(wide, entry, srays, True, c, direct=True)
             assert np.array_equal(got, swant), "shadow verdicts differ on the tree '%s' at bounce %d" % (name, bounce)
             m = tot[(name, True)][7]; tot[(name, True)] += c; tot[(name, True)][7] = max(m, c[7])
+        for tname, nd in nw_nodes.items():
+            for wd in widths:
+                r_ = orc.nwide_stats(wd, srays, True, nd)
+                for key, val in r_.items():
+                    nw[(tname, wd, True)][key] = val if key == "records" else nw[(tname, wd, True)][key] + val
         orc.stage("accumulate")
     print("%-48s %-8s %10s %8s %8s %8s %8s %8s %6s | closest hits that differ from the reference's" % ("tree", "rays", "count", "visits", "leaves", "tris", "steps", "pushes", "stack"))
     for (name, sh), c in tot.items():
@@ -124,3 +137,9 @@ if __name__ == "__main__":
     for name, c in dist_tot.items():
         r = max(int(c[0]), 1)
         print("%-48s %8.2f visits %8.2f steps | %d hits differ" % (name, c[1] / r, (int(c[1]) + int(c[4]) + int(c[3])) / r, dist_differ[name]))
+    print("wider records, priced on the same queues (SAH-optimal fold for each width, EXACT boxes, closest-hit slots nearest first; 4-wide here = the "
+          "production fold without its 8-bit rounding and with distance order): record visits + triangle passes per ray, slots tested per ray")
+    for (tname, wd, sh), c in nw.items():
+        r = max(c["rays"], 1)
+        print("%-22s %2d-wide %-8s %8.2f visits %8.2f steps %8.1f slot tests per ray   %9d records" % (
+            tname, wd, "shadow" if sh else "closest", c["visits"] / r, (c["visits"] + c["triangle_tests"]) / r, c["slots_tested"] / r, c["records"]))
