@@ -233,3 +233,25 @@ def test_rt_scene_upload_measures_before_it_switches(env_map):
     arrays["lights"] = arrays["lights"][:0]
     rec, entry, report = capi.choose_tree(arrays, True, 1)
     assert "-> reference topology" in report and rec.tobytes() == ref.tobytes()
+
+
+def test_wider_folds_priced_on_real_queues(golden_scenes):
+    """orc_nwide_stats (the analysis behind DESIGN's 8-wide decision): the SAH-optimal W-wide fold of a BVH2 walked with exact boxes.
+    Wider records mean fewer record visits (and, on large scenes, more slot tests per ray) -- here: the walk terminates on the
+    reference's tree and on an own one, and visits and records are monotone in W."""
+    sc = golden_scenes["coverage"]
+    w, h, b = 64, 48, 4
+    orc = _oracle.Oracle(w, h, sc)
+    orc.set_camera(T.default_camera(w, h)); orc.set_max_bounces(b)
+    orc.stage("reset"); orc.stage("generate_rays")
+    n = w * h
+    rays = orc.buffer("rays0", T.ray, n)[: int(orc.buffer("ray_counter0", np.uint32, 1)[0])].copy()
+    own = own_tree(sc["nodes"])
+    for nodes in (None, own):
+        prev = None
+        for width in (2, 4, 8, 16):
+            st = orc.nwide_stats(width, rays, False, nodes)
+            assert st["rays"] == len(rays) and st["visits"] > 0 and st["records"] > 0
+            if prev is not None:
+                assert st["visits"] <= prev["visits"] and st["records"] <= prev["records"]
+            prev = st
