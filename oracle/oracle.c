@@ -1448,7 +1448,45 @@ static void nw_frontier(const nw_fold* f, uint32_t n, uint32_t k, uint32_t* out,
         else out[(*count)++] = c[i];
     }
 }
+/* counts[n] += 1 for every ray whose box test of BVH2 node n passes with the ray's INITIAL t_max: how often a record rooted at n
+ * would be visited at most -- a measured visit probability to fold with instead of the surface area (analysis) */
+ORC_EXPORT int orc_node_pass_counts(void* h, const rt_ray* rays, uint32_t n_rays, double* counts)
+{
+    orc* o = (orc*)h;
+    const rt_bvh_node* nodes = o->nodes;
+    for (uint32_t ri = 0; ri < n_rays; ++ri)
+    {
+        const rt_ray ray = rays[ri];
+        const v3 org = V3(ray.origin.x, ray.origin.y, ray.origin.z), dir = V3(ray.direction.x, ray.direction.y, ray.direction.z);
+        const v3 inv = V3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
+        uint32_t stack[128]; int sp = 0;
+        stack[sp++] = 0;
+        while (sp > 0)
+        {
+            const uint32_t n = stack[--sp];
+            if (!RayBounds(&nodes[n], org, inv, ray.origin.w, ray.direction.w)) continue;
+            counts[n] += 1.0;
+            if ((nodes[n].num_primitives_axis >> 16) != 0 || sp > 125) continue;
+            stack[sp++] = nodes[n].offset;
+            stack[sp++] = n + 1;
+        }
+    }
+    return 0;
+}
+
+static int nwide_stats_impl(void* h, uint32_t W, const rt_bvh_node* nodes, uint32_t nn, const rt_ray* rays, uint32_t n_rays, int shadow, uint64_t* counters,
+    const double* weights);
 ORC_EXPORT int orc_nwide_stats(void* h, uint32_t W, const rt_bvh_node* nodes, uint32_t nn, const rt_ray* rays, uint32_t n_rays, int shadow, uint64_t* counters)
+{
+    return nwide_stats_impl(h, W, nodes, nn, rays, n_rays, shadow, counters, NULL);
+}
+/* the same with the fold's cost of a record = weights[root] instead of its surface area */
+ORC_EXPORT int orc_nwide_stats_weighted(void* h, uint32_t W, const double* weights, const rt_ray* rays, uint32_t n_rays, int shadow, uint64_t* counters)
+{
+    return nwide_stats_impl(h, W, NULL, 0, rays, n_rays, shadow, counters, weights);
+}
+static int nwide_stats_impl(void* h, uint32_t W, const rt_bvh_node* nodes, uint32_t nn, const rt_ray* rays, uint32_t n_rays, int shadow, uint64_t* counters,
+    const double* weights)
 {
     orc* o = (orc*)h;
     if (W < 2 || W > 16) return 1;
@@ -1477,7 +1515,7 @@ ORC_EXPORT int orc_nwide_stats(void* h, uint32_t W, const rt_bvh_node* nodes, ui
         }
         const double dx = (double)nodes[n].bounds_max.x - nodes[n].bounds_min.x, dy = (double)nodes[n].bounds_max.y - nodes[n].bounds_min.y,
                      dz = (double)nodes[n].bounds_max.z - nodes[n].bounds_min.z;
-        T[n] = (dx * dy + dy * dz + dz * dx) + F[(size_t)n * (W + 1) + W];
+        T[n] = (weights ? weights[n] : dx * dy + dy * dz + dz * dx) + F[(size_t)n * (W + 1) + W];
         for (uint32_t i = 2; i <= W; ++i)
             if (F[(size_t)n * (W + 1) + i] < T[n]) f.open[n] |= 1u << i;
     }
