@@ -497,6 +497,8 @@ def main():
                     "where it measures cheaper; 2 always; 3 always, surface-area metric; 0 shared with the closest-hit rays).  Bit-identical for every value.")
     ap.add_argument("--closest-tree", type=int, default=None, help="RT_CTX_OPT_CLOSEST_TREE (library default 0 = bit-identical; 1 / 2 = TOLERANCE mode: "
                     "an own tree for closest-hit rays where it measures cheaper / always)")
+    ap.add_argument("--adaptive-fold", type=int, default=None, help="RT_CTX_OPT_ADAPTIVE_FOLD (library default 0; 3 = the first integrate probes the frame's own rays, "
+                    "both 4-wide trees are folded again for their measured box-pass frequencies, and the warm-up waits for the new fold).  Bit-identical for every value.")
     ap.add_argument("--tail-lanes", type=int, default=None, help="RT_OPT_TRACE_TAIL_LANES (library default 40; 0 = loop D off)")
     ap.add_argument("--chunk-refill", type=int, default=None, help="RT_OPT_CHUNK_REFILL (library default 1)")
     ap.add_argument("--tail-paths", type=int, default=None, help="RT_OPT_TRACE_TAIL_PATHS (library default 100000000)")
@@ -590,7 +592,9 @@ def main():
     t_setup = time.time() - t0
     if args.wide_collapse != 1:
         render.set_wide_bvh(args.wide_collapse)               # A/B: uploads the scene again with the other collapse
-    if args.shadow_tree is not None or args.closest_tree is not None:
+    if args.shadow_tree is not None or args.closest_tree is not None or args.adaptive_fold is not None:
+        if args.adaptive_fold is not None:
+            render.set_adaptive_fold(args.adaptive_fold, upload=False)
         if args.shadow_tree is not None:
             render.set_shadow_tree(args.shadow_tree, upload=False)
         if args.closest_tree is not None:
@@ -918,7 +922,7 @@ def main():
                                 rays_per_step=round(total_rays / args.steps, 1), non_finite_pixels=nan_px,
                                 stack_spill_lane_steps=int(st1.stack_spills), rays_left_to_the_bvh2_kernel=int(st1.slow_rays),
                                 log_inline_entries=int(st1.log_inline_entries), log_fallbacks=int(st1.log_fallbacks),   # 0 inline = the full log layout
-                                trees=tree_report.strip().split("\n"),    # what rt_scene_upload measured when it chose the shadow (/ closest-hit) tree
+                                trees=(render.tree_report() if args.adaptive_fold else tree_report).strip().split("\n"),    # what rt_scene_upload measured when it chose the shadow (/ closest-hit) tree
                                 setup_s=round(t_setup, 2), scene_s=round(t_scene, 2),     # scene_s: parse / generate (or load the cache); setup_s: + BVH, wide collapse, upload
                                 device=name),
                     ranks=dict(render_ms_min=round(float(tmin[0].item()) * 1e3, 3), render_ms_max=round(float(tmax[1].item()) * 1e3, 3),

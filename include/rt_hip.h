@@ -73,6 +73,16 @@ enum rt_ctx_option
                                       the hit differs from TraceBvh's where two candidate hits tie within the rounding of
                                       RayTriangle (trace_bvh.cl:157-162); validated by rel-L2 < 1e-4 and a differing-pixel
                                       count against oracle/_ref, never the default */
+    , RT_CTX_OPT_ADAPTIVE_FOLD = 4 /* 0 (default this round): the 4-wide trees keep the fold rt_scene_upload made (optimal for the
+                                      surface-area visit probability).  Bit 0: the first rt_integrate of an uploaded scene traces
+                                      a small probe frame through the stage API (same camera, 1/k of the resolution), counts on
+                                      the host how often those rays pass each box of the binary tree, and re-folds both 4-wide
+                                      trees to be optimal for THOSE frequencies; the new records replace the old ones between two
+                                      rt_integrate calls once a worker thread has them.  EXACT: a fold decides which interior
+                                      boxes are tested, never a hit or a verdict.  Bit 1: rt_integrate waits
+                                      for the new fold (reproducible timing: bench.py, tests).  Bit 2: also for trees of fewer than
+                                      8192 nodes (tests).  Takes effect at the next rt_scene_upload; the fold is adapted once, to
+                                      the first camera (a moved camera keeps a valid, possibly less apt fold). */
 };
 int rt_ctx_set_option(rt_ctx* ctx, int option, uint32_t value);
 /* The blue-noise sampler tables (src/utils/blue_noise_sampler.hpp: sobol_256spp_256d[256*256],
@@ -404,6 +414,12 @@ int rt_debug_own_bvh(const rt_bvh_node* nodes, uint32_t num_nodes, double iso_we
  * the own trees) */
 int rt_debug_wide_bvh_metric(const rt_bvh_node* nodes, uint32_t num_nodes, double iso_weight, const float* dirs, uint32_t n_dirs,
     void* records, uint32_t capacity, uint32_t* num_records, uint32_t* entry_ref);
+
+/* RT_CTX_OPT_ADAPTIVE_FOLD's host half on its own (no device): the fold of `nodes` adapted to n_rays rays (origins_tmax: x, y, z, t_max per
+ * ray; directions: x, y, z, - per ray) -- its records (and, optional, the node each one tests), and cost2 = {the surface-area fold's, the adapted
+ * fold's} box passes at record roots per ray; *cheaper = the adapted fold would be adopted. */
+int rt_debug_adapt_fold(const rt_bvh_node* nodes, uint32_t num_nodes, const float* origins_tmax, const float* directions, uint32_t n_rays,
+    void* records, uint32_t* roots, uint32_t capacity, uint32_t* num_records, uint32_t* entry_ref, double* cost2, int* cheaper);
 
 /* ---- kernel self-test hooks (known-answer tests of the device math):
  * evaluates fn over n inputs on the device.  fn: 0 sin, 1 cos, 2 tan, 3 pow(a,b),

@@ -63,7 +63,7 @@ EXPORTS = [
     "rt_compute_aovs", "rt_denoise", "rt_copy_history",
     "rt_frame_resolve", "rt_frame_present", "rt_frame_present_wait", "rt_frame_read_radiance", "rt_frame_radiance_device_ptr", "rt_frame_sample_count",
     "rt_frame_get_stats", "rt_frame_get_profile", "rt_frame_copy_radiance", "rt_frame_debug_read_queue", "rt_frame_debug_read_hits", "rt_debug_eval",
-    "rt_debug_wide_bvh", "rt_frame_debug_timeline", "rt_debug_own_bvh", "rt_debug_wide_bvh_metric", "rt_scene_tree_report", "rt_debug_choose_tree",
+    "rt_debug_wide_bvh", "rt_frame_debug_timeline", "rt_debug_own_bvh", "rt_debug_wide_bvh_metric", "rt_scene_tree_report", "rt_debug_choose_tree", "rt_debug_adapt_fold",
     "rt_group_create", "rt_group_unique_id", "rt_group_join", "rt_group_size", "rt_group_local_count", "rt_group_local_rank", "rt_group_comm_count",
     "rt_group_gather_radiance", "rt_group_destroy", "rt_group_last_error", "rt_group_denoise", "rt_group_create_local",
     "rt_group_create_unchecked",
@@ -117,6 +117,7 @@ def load():
         "rt_debug_choose_tree": (i32, [C.POINTER(rt_scene_desc), i32, u32, vp, u32, C.POINTER(u32), C.POINTER(u32), C.c_char_p, sz]),
         "rt_debug_own_bvh": (i32, [vp, u32, C.c_double, vp, u32, vp, u32, C.POINTER(u32)]),
         "rt_debug_wide_bvh_metric": (i32, [vp, u32, C.c_double, vp, u32, vp, u32, C.POINTER(u32), C.POINTER(u32)]),
+        "rt_debug_adapt_fold": (i32, [vp, u32, vp, vp, u32, vp, vp, u32, C.POINTER(u32), C.POINTER(u32), C.POINTER(C.c_double), C.POINTER(i32)]),
         "rt_group_create": (i32, [i32, C.POINTER(i32), C.POINTER(vp)]), "rt_group_create_unchecked": (i32, [i32, C.POINTER(i32), C.POINTER(vp)]),
         "rt_group_unique_id": (i32, [vp, sz]),
         "rt_group_join": (i32, [i32, i32, vp, i32, C.POINTER(vp)]), "rt_group_size": (i32, [vp]),
@@ -158,6 +159,25 @@ def choose_tree(scene, shadow=True, mode=1):
     return out, entry.value, rep.value.decode()
 
 
+def adapt_fold(nodes, origins_tmax, directions):
+    """rt_debug_adapt_fold (host only, no GPU): RT_CTX_OPT_ADAPTIVE_FOLD's re-fold of the LinearBVHNode[] `nodes` for the rays given
+    (origins_tmax float32[n, 4] = x, y, z, t_max; directions float32[n, 4] = x, y, z, -).
+    Returns (records uint8[n, 64], entry_ref, roots uint32[n], (cost of the surface-area fold, cost of the adapted fold), adopted)."""
+    lib = load()
+    nodes = np.ascontiguousarray(nodes)
+    o = np.ascontiguousarray(origins_tmax, np.float32).reshape(-1, 4)
+    d = np.ascontiguousarray(directions, np.float32).reshape(-1, 4)
+    assert len(o) == len(d)
+    n, entry, cheaper = C.c_uint32(), C.c_uint32(), C.c_int()
+    cost = (C.c_double * 2)()
+    out = np.zeros((len(nodes), 64), np.uint8)                  # a fold never has more records than the tree has nodes
+    roots = np.zeros(len(nodes), np.uint32)
+    if lib.rt_debug_adapt_fold(nodes.ctypes.data, len(nodes), o.ctypes.data, d.ctypes.data, len(o), out.ctypes.data, roots.ctypes.data, len(out), C.byref(n), C.byref(entry),
+                               cost, C.byref(cheaper)):
+        raise RtError(lib.rt_last_error(None).decode())
+    return out[:n.value].copy(), entry.value, roots[:n.value].copy(), (cost[0], cost[1]), bool(cheaper.value)
+
+
 class Context:
     """CLContext replacement (src/gpu_wrappers/cl_context.hpp:37-65)."""
 
@@ -197,6 +217,11 @@ class Context:
     def set_closest_tree(self, mode):
         """RT_CTX_OPT_CLOSEST_TREE: 0 default (bit-identical), 1 / 2 = tolerance mode (own tree where cheaper / always)"""
         _check(self.lib, self.handle, self.lib.rt_ctx_set_option(self.handle, 3, mode))
+
+    def set_adaptive_fold(self, mode):
+        """RT_CTX_OPT_ADAPTIVE_FOLD (effective at the next upload_scene): bit 0 = the first integrate() probes the frame's own rays and the
+        4-wide trees are folded again for them (exact), bit 1 = integrate() waits for the new fold, bit 2 = small trees too."""
+        _check(self.lib, self.handle, self.lib.rt_ctx_set_option(self.handle, 4, mode))
 
     def tree_report(self):
         return self.lib.rt_scene_tree_report(self.handle).decode()

@@ -277,6 +277,11 @@ class Render:
         an own tree for closest-hit rays where it measures cheaper / always."""
         self.set_ctx_option(3, mode, upload)
 
+    def set_adaptive_fold(self, mode, upload=True):
+        """RT_CTX_OPT_ADAPTIVE_FOLD: bit 0 = the first frame probes its own rays and both 4-wide trees are folded again for them (exact; the
+        report line appears in tree_report() once the fold is adopted), bit 1 = the frame waits for it, bit 2 = small trees too."""
+        self.set_ctx_option(4, mode, upload)
+
     def tree_report(self):
         from . import capi
         return capi.load().rt_scene_tree_report(self.lib.rth_render_ctx_handle(self.handle)).decode()

@@ -193,6 +193,61 @@ def test_mid_sample_reads_on_a_compact_log_allocation(ctx):
     fr.close()
 
 
+@pytest.mark.parametrize("mode,shadow_tree", [(7, 1), (7, 0), (7, 2), (5, 1)])
+def test_adaptive_fold_is_adopted_and_changes_no_bit(ctx, mode, shadow_tree):
+    """RT_CTX_OPT_ADAPTIVE_FOLD (round 4, opt-in): the first rt_integrate traces a probe frame, a worker thread folds both 4-wide trees again
+    for the probe rays' measured box passes, and the records are replaced between two rt_integrate calls -- waiting for the worker (bit 1)
+    or whenever it is ready (mode 5: the frame goes on meanwhile).  Whatever the fold and whenever it arrives: the reference's radiance,
+    bit for bit.  shadow_tree 0 / 1 / 2: the shadow rays share the closest-hit records, walk the measured choice, or
+    walk the backend's own binary tree (whose fold is then the one adapted).  The host half alone: tests/test_adaptive_fold.py."""
+    import time
+    w, h, bounces = 96, 64, 5
+    scene = host.Scene(arrays=S.city_block(40_000))
+    scene.add_directional_light((-0.6, -1.5, 3.5), (15.0, 10.0, 5.0))
+    scene.set_env_path(os.path.join(ROOT, "assets", "ibl", "CGSkies_0036_free.hdr"))
+    scene.build_bvh()
+    scene.finalize()
+    sc = scene.arrays()
+    cam = T.default_camera(w, h)
+    ctx.set_adaptive_fold(mode)
+    ctx.set_shadow_tree(shadow_tree)
+    try:
+        ctx.upload_scene(sc)
+    finally:
+        ctx.set_adaptive_fold(0)
+        ctx.set_shadow_tree(1)
+    assert "adaptive fold" not in ctx.tree_report()
+    fr = capi.Frame(ctx, w, h)
+    fr.set_camera(cam)
+    fr.set_max_bounces(bounces)
+    fr.integrate(2)                                                  # the probe; with bit 1 the new fold is in place when this returns
+    for _ in range(400):
+        if "adaptive fold" in ctx.tree_report():
+            break
+        assert not mode & 2, ctx.tree_report()
+        time.sleep(0.02)
+        fr.integrate(1)                                              # the frame goes on with the fold it has
+    report = ctx.tree_report()
+    assert "adaptive fold:" in report and "closest-hit" in report and "adopted" in report, report
+    fr.integrate(3)                                                  # ... and with the new one
+    spp = fr.sample_count()
+    orc = _oracle.Oracle(w, h, sc)
+    orc.set_camera(cam)
+    orc.set_max_bounces(bounces)
+    orc.integrate(spp)
+    assert np.array_equal(fr.radiance()[..., :3], orc.radiance()[..., :3]), report
+    fr.close()
+    # the next upload starts from the surface-area fold again, and does not adapt unless asked to
+    ctx.upload_scene(sc)
+    plain = capi.Frame(ctx, w, h)
+    plain.set_camera(cam)
+    plain.set_max_bounces(bounces)
+    plain.integrate(spp)
+    assert "adaptive fold" not in ctx.tree_report()
+    assert np.array_equal(plain.radiance()[..., :3], orc.radiance()[..., :3])
+    plain.close()
+
+
 @pytest.mark.parametrize("world,band", [(2, 8), (3, 4), (8, 8)])
 def test_tiling_is_bit_invariant(ctx, golden_scenes, world, band):
     """Image-space sharding (the multi-GPU partition) cannot change a pixel."""

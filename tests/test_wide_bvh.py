@@ -49,8 +49,9 @@ def area(nodes, n):
     return d[0] * d[1] + d[1] * d[2] + d[2] * d[0]
 
 
-def check(nodes, collapse=1):
-    wide, entry, roots = wide_of(nodes, collapse, with_roots=True)
+def check(nodes, collapse=1, fold=None):
+    """fold: (records, entry, roots) of another fold of `nodes` to validate instead (the adapted folds of tests/test_adaptive_fold.py)"""
+    wide, entry, roots = fold if fold is not None else wide_of(nodes, collapse, with_roots=True)
     is_leaf = (nodes["num_primitives_axis"] >> 16) != 0
     if is_leaf[0]:
         assert len(wide) == 0 and entry == (LEAF | int(nodes["offset"][0]))
