@@ -395,7 +395,9 @@ def roofline_object(args, world, live_step, per_ray, isolated):
         out["counters"] = dict(file=os.path.relpath(COUNTERS_FILE, ROOT), error="no counters for this config: achieved / frac / traffic unavailable")
         k = None
     if k is not None:
-        stale = doc.get("_code_object_sha256") != running
+        # the counters speak for one code object AND one fold of the trees (the same kernel visits fewer records on an adapted fold)
+        fold_now = "adapted to the frame's rays" if args.adaptive_fold else "surface area"
+        stale = doc.get("_code_object_sha256") != running or doc.get("_fold", "surface area") != fold_now
         traffic = float(k["hbm_bytes_per_launch"])
         achieved = traffic / (float(k["avg_launch_ms"]) * 1e-3) / 1e9
         out.update(achieved=round(achieved, 1), frac=round(achieved / HBM_PEAK_GBS, 4), traffic=round(traffic, 0),
@@ -409,7 +411,7 @@ def roofline_object(args, world, live_step, per_ray, isolated):
                             note="busy fraction of each unit's calibrated ceiling (tools/make_counters_json.py; 1.0 = saturated): "
                                  "the vector ALU and the L1 / texture-address path are both near theirs, HBM is not")
         out["counters"] = dict(file=os.path.relpath(COUNTERS_FILE, ROOT), per_launch=k.get("per_launch"), launches_profiled=k.get("launches_profiled"),
-                               code_object_sha256=doc.get("_code_object_sha256"), running_code_object_sha256=running, stale=bool(stale),
+                               code_object_sha256=doc.get("_code_object_sha256"), running_code_object_sha256=running, fold=doc.get("_fold", "surface area"), running_fold=fold_now, stale=bool(stale),
                                how=doc.get("_how"))
     # Ceilings in the metric's own unit (Grays/s of this kernel alone on the machine), one per resource the counters or a
     # micro-benchmark can speak for; frac_of_ceiling = achieved / the lowest of them.
@@ -497,8 +499,9 @@ def main():
                     "where it measures cheaper; 2 always; 3 always, surface-area metric; 0 shared with the closest-hit rays).  Bit-identical for every value.")
     ap.add_argument("--closest-tree", type=int, default=None, help="RT_CTX_OPT_CLOSEST_TREE (library default 0 = bit-identical; 1 / 2 = TOLERANCE mode: "
                     "an own tree for closest-hit rays where it measures cheaper / always)")
-    ap.add_argument("--adaptive-fold", type=int, default=None, help="RT_CTX_OPT_ADAPTIVE_FOLD (library default 0; 3 = the first integrate probes the frame's own rays, "
-                    "both 4-wide trees are folded again for their measured box-pass frequencies, and the warm-up waits for the new fold).  Bit-identical for every value.")
+    ap.add_argument("--adaptive-fold", type=int, default=3, help="RT_CTX_OPT_ADAPTIVE_FOLD (library default 1: the first integrate probes the frame's own rays, "
+                    "a worker thread folds both 4-wide trees again for their measured box passes, the records are replaced when ready; 3 (here): the warm-up "
+                    "waits for the new fold, so that every timed step runs on it; 0 = the upload's surface-area fold).  Bit-identical for every value.")
     ap.add_argument("--tail-lanes", type=int, default=None, help="RT_OPT_TRACE_TAIL_LANES (library default 40; 0 = loop D off)")
     ap.add_argument("--chunk-refill", type=int, default=None, help="RT_OPT_CHUNK_REFILL (library default 1)")
     ap.add_argument("--tail-paths", type=int, default=None, help="RT_OPT_TRACE_TAIL_PATHS (library default 100000000)")
@@ -592,8 +595,8 @@ def main():
     t_setup = time.time() - t0
     if args.wide_collapse != 1:
         render.set_wide_bvh(args.wide_collapse)               # A/B: uploads the scene again with the other collapse
-    if args.shadow_tree is not None or args.closest_tree is not None or args.adaptive_fold is not None:
-        if args.adaptive_fold is not None:
+    if args.shadow_tree is not None or args.closest_tree is not None or args.adaptive_fold != 1:
+        if args.adaptive_fold != 1:
             render.set_adaptive_fold(args.adaptive_fold, upload=False)
         if args.shadow_tree is not None:
             render.set_shadow_tree(args.shadow_tree, upload=False)
@@ -922,7 +925,7 @@ def main():
                                 rays_per_step=round(total_rays / args.steps, 1), non_finite_pixels=nan_px,
                                 stack_spill_lane_steps=int(st1.stack_spills), rays_left_to_the_bvh2_kernel=int(st1.slow_rays),
                                 log_inline_entries=int(st1.log_inline_entries), log_fallbacks=int(st1.log_fallbacks),   # 0 inline = the full log layout
-                                trees=(render.tree_report() if args.adaptive_fold else tree_report).strip().split("\n"),    # what rt_scene_upload measured when it chose the shadow (/ closest-hit) tree
+                                trees=(render.tree_report() if args.adaptive_fold else tree_report).strip().split("\n"), adaptive_fold=args.adaptive_fold,    # what rt_scene_upload measured when it chose the shadow (/ closest-hit) tree
                                 setup_s=round(t_setup, 2), scene_s=round(t_scene, 2),     # scene_s: parse / generate (or load the cache); setup_s: + BVH, wide collapse, upload
                                 device=name),
                     ranks=dict(render_ms_min=round(float(tmin[0].item()) * 1e3, 3), render_ms_max=round(float(tmax[1].item()) * 1e3, 3),

@@ -73,16 +73,18 @@ enum rt_ctx_option
                                       the hit differs from TraceBvh's where two candidate hits tie within the rounding of
                                       RayTriangle (trace_bvh.cl:157-162); validated by rel-L2 < 1e-4 and a differing-pixel
                                       count against oracle/_ref, never the default */
-    , RT_CTX_OPT_ADAPTIVE_FOLD = 4 /* 0 (default this round): the 4-wide trees keep the fold rt_scene_upload made (optimal for the
-                                      surface-area visit probability).  Bit 0: the first rt_integrate of an uploaded scene traces
-                                      a small probe frame through the stage API (same camera, 1/k of the resolution), counts on
-                                      the host how often those rays pass each box of the binary tree, and re-folds both 4-wide
-                                      trees to be optimal for THOSE frequencies; the new records replace the old ones between two
-                                      rt_integrate calls once a worker thread has them.  EXACT: a fold decides which interior
-                                      boxes are tested, never a hit or a verdict.  Bit 1: rt_integrate waits
-                                      for the new fold (reproducible timing: bench.py, tests).  Bit 2: also for trees of fewer than
-                                      8192 nodes (tests).  Takes effect at the next rt_scene_upload; the fold is adapted once, to
-                                      the first camera (a moved camera keeps a valid, possibly less apt fold). */
+    , RT_CTX_OPT_ADAPTIVE_FOLD = 4 /* The 4-wide trees start with the fold rt_scene_upload makes (optimal for the surface-area visit
+                                      probability).  Bit 0 (default: 1): the first rt_integrate of an uploaded scene traces a small
+                                      probe frame through the stage API (same camera, 1/k of the resolution, ~32 K paths), the host
+                                      counts how often those rays pass each box of the binary tree, and a worker thread folds both
+                                      4-wide trees again to be optimal for THOSE frequencies; the new records replace the old ones
+                                      between two rt_integrate calls once they are ready, and again whenever a frame's camera has
+                                      left the view they were made for (3 % of the scene's diagonal, 20 degrees, a tenth of the
+                                      field of view).  EXACT: a fold decides which interior boxes are tested, never a hit or a
+                                      verdict.  Bit 1: rt_integrate waits for the new fold (reproducible
+                                      timing: bench.py, tests).  Bit 2: also for trees of fewer than 8192 nodes (tests).  0: off.
+                                      Takes effect at the next rt_scene_upload; rt_scene_tree_report carries the latest
+                                      adaptation's line. */
 };
 int rt_ctx_set_option(rt_ctx* ctx, int option, uint32_t value);
 /* The blue-noise sampler tables (src/utils/blue_noise_sampler.hpp: sobol_256spp_256d[256*256],

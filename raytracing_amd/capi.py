@@ -159,6 +159,9 @@ def choose_tree(scene, shadow=True, mode=1):
     return out, entry.value, rep.value.decode()
 
 
+ADAPTIVE_FOLD_DEFAULT = 1      # rt_ctx's RT_CTX_OPT_ADAPTIVE_FOLD as created (rt_hip.hip)
+
+
 def adapt_fold(nodes, origins_tmax, directions):
     """rt_debug_adapt_fold (host only, no GPU): RT_CTX_OPT_ADAPTIVE_FOLD's re-fold of the LinearBVHNode[] `nodes` for the rays given
     (origins_tmax float32[n, 4] = x, y, z, t_max; directions float32[n, 4] = x, y, z, -).

@@ -63,8 +63,8 @@ struct rt_ctx
     uint32_t shadow_tree = 1;     // RT_CTX_OPT_SHADOW_TREE: 1 = shadow rays walk the backend's own tree where it measures cheaper (exact either way),
                                   // 2 = own unconditionally, 3 = own with the surface-area metric (A/B), 0 = they share the closest-hit tree
     uint32_t closest_tree = 0;    // RT_CTX_OPT_CLOSEST_TREE: 1 / 2 as above; != 0 is the tolerance mode (NOT bit-exact)
-    uint32_t adaptive_fold = 0;   // RT_CTX_OPT_ADAPTIVE_FOLD: bit 0 = re-fold the 4-wide trees for the rays the first rt_integrate actually traces (exact:
-                                  // a fold decides which boxes are tested, never a result), bit 1 = rt_integrate waits for the new fold instead of
+    uint32_t adaptive_fold = 1;   // RT_CTX_OPT_ADAPTIVE_FOLD: bit 0 = re-fold the 4-wide trees for the rays rt_integrate actually traces (exact: a fold
+                                  // decides which boxes are tested, never a result), bit 1 = rt_integrate waits for the new fold instead of
                                   // adopting it when it is ready, bit 2 = also for scenes too small to profit (tests)
     std::vector<rt_frame*> frames;   // the frames alive on this context (rt_finish waits for their side streams too)
     uint8_t* blue_noise = nullptr;   // sobol[65536] | scramblingTile[131072] | rankingTile[131072]
@@ -801,11 +801,15 @@ bool choose_tree(const rt_scene_desc* sd, const std::vector<WideNode>& ref_wide,
 // Exact by construction: every fold of the same binary tree tests the same leaves in the same order (build_wide_bvh).
 struct FoldAdapt
 {
-    enum { ARMED = 1, COMPUTING = 2, DONE = 3 };
+    enum { ARMED = 1, COMPUTING = 2, IDLE = 3, OFF = 4 };   // IDLE: adapted to `camera`; a frame whose camera has moved away arms it again
     int state = ARMED;
     uint32_t mode = 1;                                 // ctx->adaptive_fold at upload
+    uint32_t adaptations = 0;                          // folds adopted so far
+    rt_camera camera;                                  // the probe's camera
+    double scene_diagonal = 0.0;
     std::vector<rt_bvh_node> bvh2, bvh2_sh;            // the reference's tree; the shadow rays' own binary tree (empty: they walk the reference's)
     std::vector<uint32_t> roots, roots_sh;             // the binary-tree node each record of the CURRENT folds tests
+    std::vector<uint32_t> roots_new, roots_sh_new;     // ... of the adapted folds
     std::vector<float4> o, d, sh_o, sh_d;              // the probe's rays (o.w = t_max: the hit distance where there was one)
     std::vector<WideNode> wide, wide_sh;               // the adapted folds
     uint32_t entry = 0, entry_sh = 0;
@@ -896,10 +900,11 @@ bool refold_for_rays(const std::vector<rt_bvh_node>& tree, const std::vector<flo
 void fold_adapt_worker(FoldAdapt* a)
 {
     const auto t0 = std::chrono::steady_clock::now();
-    std::vector<rt_bvh_node>& sh_tree = a->bvh2_sh.empty() ? a->bvh2 : a->bvh2_sh;
-    const std::vector<uint32_t>& sh_roots = a->bvh2_sh.empty() ? a->roots : a->roots_sh;
-    std::thread shadow([&]() { a->ok_sh = refold_for_rays(sh_tree, a->sh_o, a->sh_d, sh_roots, a->wide_sh, a->entry_sh, a->cost[1], a->cancel); });
-    a->ok = refold_for_rays(a->bvh2, a->o, a->d, a->roots, a->wide, a->entry, a->cost[0], a->cancel);
+    // the shadow rays' records fold either their own binary tree or, like the closest-hit records (but on their own now), the reference's
+    const std::vector<rt_bvh_node>& sh_tree = a->bvh2_sh.empty() ? a->bvh2 : a->bvh2_sh;
+    const std::vector<uint32_t>& sh_roots = a->roots_sh.empty() ? a->roots : a->roots_sh;
+    std::thread shadow([&]() { a->ok_sh = refold_for_rays(sh_tree, a->sh_o, a->sh_d, sh_roots, a->wide_sh, a->entry_sh, a->cost[1], a->cancel, &a->roots_sh_new); });
+    a->ok = refold_for_rays(a->bvh2, a->o, a->d, a->roots, a->wide, a->entry, a->cost[0], a->cancel, &a->roots_new);
     shadow.join();
     a->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     a->finished.store(true);
@@ -1121,6 +1126,11 @@ int rt_scene_upload(rt_ctx* ctx, const rt_scene_desc* sd)
     {
         FoldAdapt* a = new FoldAdapt();
         a->mode = ctx->adaptive_fold;
+        memset(&a->camera, 0, sizeof(a->camera));
+        {
+            const double ex = (double)root.bounds_max.x - root.bounds_min.x, ey = (double)root.bounds_max.y - root.bounds_min.y, ez = (double)root.bounds_max.z - root.bounds_min.z;
+            a->scene_diagonal = std::sqrt(ex * ex + ey * ey + ez * ez);
+        }
         a->bvh2.assign(sd->nodes, sd->nodes + nn);
         a->roots = std::move(wide_roots);
         if (have_sh) { a->bvh2_sh = std::move(own_sh.bvh2); a->roots_sh = std::move(own_sh.roots); }
@@ -2102,6 +2112,7 @@ int rt_frame_reserve_samples(rt_frame* f, uint32_t n_samples, uint32_t* reserved
 static int fold_probe(rt_frame* f, FoldAdapt& a)
 {
     rt_ctx* ctx = f->ctx;
+    a.o.clear(); a.d.clear(); a.sh_o.clear(); a.sh_d.clear();
     const uint64_t pixels = (uint64_t)f->tile.width * f->tile.height;
     uint32_t k = 1;
     while (pixels / ((uint64_t)k * k) > 32768u) ++k;
@@ -2170,7 +2181,8 @@ static int fold_adopt(rt_ctx* ctx)
     Scene& s = ctx->scene;
     FoldAdapt* a = s.adapt;
     if (a->worker.joinable()) a->worker.join();
-    a->state = FoldAdapt::DONE;
+    a->state = FoldAdapt::IDLE;
+    a->finished.store(false);
     char line[400];
     int rc = RT_OK;
     void *new_cl = nullptr, *new_sh = nullptr;
@@ -2178,13 +2190,16 @@ static int fold_adopt(rt_ctx* ctx)
     if (rc == RT_OK && a->ok) rc = dev_alloc_copy(ctx, &new_cl, a->wide.data(), a->wide.size() * sizeof(WideNode));
     if (rc == RT_OK && a->ok_sh) rc = dev_alloc_copy(ctx, &new_sh, a->wide_sh.data(), a->wide_sh.size() * sizeof(WideNode));
     if (rc == RT_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail(ctx, "rt_integrate: uploading the adapted fold failed");
+    const size_t at = s.tree_report.find("adaptive fold");              // one line, the latest adaptation's
+    if (at != std::string::npos) s.tree_report.erase(at);
     if (rc != RT_OK)
     {
-        // the scene keeps the fold it has: a failed adaptation costs nothing but itself
+        // the scene keeps the fold it has: a failed adaptation costs nothing but itself (and is not tried again)
         (void)hipGetLastError();
         if (new_cl) (void)hipFree(new_cl);
         if (new_sh) (void)hipFree(new_sh);
         s.tree_report += "adaptive fold: not adopted (device allocation or copy failed)\n";
+        a->state = FoldAdapt::OFF;
     }
     else
     {
@@ -2194,43 +2209,65 @@ static int fold_adopt(rt_ctx* ctx)
             void* old = s.wnodes;
             s.wnodes = new_cl;
             s.d.wnodes = (const float4*)new_cl; s.d.w_entry_ref = a->entry; s.n_wide = (uint32_t)a->wide.size();
-            if (shared && !a->ok_sh) s.wnodes_sh = old;                 // ... and keep walking the old ones (theirs now)
+            if (shared && !a->ok_sh) { s.wnodes_sh = old; a->roots_sh = a->roots; }   // ... and keep walking the old ones (theirs now)
             else (void)hipFree(old);
+            a->roots.swap(a->roots_new);
         }
         if (a->ok_sh)
         {
             if (s.wnodes_sh) (void)hipFree(s.wnodes_sh);
             s.wnodes_sh = new_sh;
             s.d.wnodes_sh = (const float4*)new_sh; s.d.w_sh_entry_ref = a->entry_sh; s.n_wide_sh = (uint32_t)a->wide_sh.size();
+            a->roots_sh.swap(a->roots_sh_new);
         }
-        snprintf(line, sizeof(line), "adaptive fold: %zu closest-hit and %zu shadow probe rays; box passes per probe ray at record roots: closest-hit %.2f -> %.2f (%s), "
-            "shadow %.2f -> %.2f (%s); %.2f s on a worker thread\n", a->o.size(), a->sh_o.size(), a->cost[0][0], a->cost[0][1], a->ok ? "adopted" : "kept",
+        if (a->ok || a->ok_sh) ++a->adaptations;
+        snprintf(line, sizeof(line), "adaptive fold (probe %u): %zu closest-hit and %zu shadow probe rays; box passes per probe ray at record roots: closest-hit %.2f -> %.2f (%s), "
+            "shadow %.2f -> %.2f (%s); %.2f s on a worker thread\n", a->adaptations, a->o.size(), a->sh_o.size(), a->cost[0][0], a->cost[0][1], a->ok ? "adopted" : "kept",
             a->cost[1][0], a->cost[1][1], a->ok_sh ? "adopted" : "kept", a->seconds);
         s.tree_report += line;
     }
-    // the host copies have served
-    for (auto* v : {&a->bvh2, &a->bvh2_sh}) std::vector<rt_bvh_node>().swap(*v);
+    // the rays and the records have served; the binary trees stay for the next camera
     for (auto* v : {&a->o, &a->d, &a->sh_o, &a->sh_d}) std::vector<float4>().swap(*v);
     for (auto* v : {&a->wide, &a->wide_sh}) std::vector<WideNode>().swap(*v);
-    for (auto* v : {&a->roots, &a->roots_sh}) std::vector<uint32_t>().swap(*v);
+    for (auto* v : {&a->roots_new, &a->roots_sh_new}) std::vector<uint32_t>().swap(*v);
     return RT_OK;
+}
+
+// Has the camera left the view the folds were adapted to?  (tools/fold_weight_study.py --views: a fold adapted to one view costs another view
+// 0 .. + 2 % against the surface-area fold as a rule and up to + 11 % -- street level seen with a fold made from above -- while its own view
+// gains 2 .. 14 %.)  Position by 3 % of the scene's diagonal, direction by 20 degrees, field of view by a tenth.
+static bool fold_view_left(const FoldAdapt& a, const rt_camera& c)
+{
+    const double dx = (double)c.position.x - a.camera.position.x, dy = (double)c.position.y - a.camera.position.y, dz = (double)c.position.z - a.camera.position.z;
+    if (std::sqrt(dx * dx + dy * dy + dz * dz) > 0.03 * a.scene_diagonal) return true;
+    const double la = std::sqrt((double)a.camera.front.x * a.camera.front.x + (double)a.camera.front.y * a.camera.front.y + (double)a.camera.front.z * a.camera.front.z);
+    const double lc = std::sqrt((double)c.front.x * c.front.x + (double)c.front.y * c.front.y + (double)c.front.z * c.front.z);
+    const double dot = (double)c.front.x * a.camera.front.x + (double)c.front.y * a.camera.front.y + (double)c.front.z * a.camera.front.z;
+    if (la > 0.0 && lc > 0.0 && !(dot >= 0.9396926 * la * lc)) return true;
+    return std::fabs((double)c.fov - a.camera.fov) > 0.1 * std::fabs((double)a.camera.fov);
 }
 
 static int fold_adapt_hook(rt_frame* f)
 {
     Scene& s = f->ctx->scene;
     FoldAdapt* a = s.adapt;
-    if (!a || a->state == FoldAdapt::DONE) return RT_OK;
+    if (!a || a->state == FoldAdapt::OFF) return RT_OK;
+    if (a->state == FoldAdapt::IDLE && !(f->denoiser || f->aov != 0 || f->n_local == 0) && fold_view_left(*a, f->camera)) a->state = FoldAdapt::ARMED;
     if (a->state == FoldAdapt::ARMED)
     {
         if (f->denoiser || f->aov != 0 || f->n_local == 0) return RT_OK;     // another frame of this scene will do
+        a->camera = f->camera;
         if (fold_probe(f, *a) != RT_OK || a->o.empty())
         {
-            a->state = FoldAdapt::DONE;
-            s.tree_report += "adaptive fold: the probe frame failed (" + f->ctx->error + ") -> the upload's fold stays\n";
+            a->state = FoldAdapt::OFF;
+            const size_t at = s.tree_report.find("adaptive fold");
+            if (at != std::string::npos) s.tree_report.erase(at);
+            s.tree_report += "adaptive fold: the probe frame failed (" + f->ctx->error + ") -> the fold stays as it is\n";
             return RT_OK;
         }
         a->state = FoldAdapt::COMPUTING;
+        a->ok = a->ok_sh = false;
+        a->finished.store(false);
         a->worker = std::thread(fold_adapt_worker, a);
     }
     if (a->state == FoldAdapt::COMPUTING && ((a->mode & 2u) || a->finished.load())) return fold_adopt(f->ctx);

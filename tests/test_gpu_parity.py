@@ -193,13 +193,14 @@ def test_mid_sample_reads_on_a_compact_log_allocation(ctx):
     fr.close()
 
 
-@pytest.mark.parametrize("mode,shadow_tree", [(7, 1), (7, 0), (7, 2), (5, 1)])
+@pytest.mark.parametrize("mode,shadow_tree", [(7, 1), (7, 0), (7, 2), (5, 1), (1, 1)])
 def test_adaptive_fold_is_adopted_and_changes_no_bit(ctx, mode, shadow_tree):
-    """RT_CTX_OPT_ADAPTIVE_FOLD (round 4, opt-in): the first rt_integrate traces a probe frame, a worker thread folds both 4-wide trees again
-    for the probe rays' measured box passes, and the records are replaced between two rt_integrate calls -- waiting for the worker (bit 1)
-    or whenever it is ready (mode 5: the frame goes on meanwhile).  Whatever the fold and whenever it arrives: the reference's radiance,
-    bit for bit.  shadow_tree 0 / 1 / 2: the shadow rays share the closest-hit records, walk the measured choice, or
-    walk the backend's own binary tree (whose fold is then the one adapted).  The host half alone: tests/test_adaptive_fold.py."""
+    """RT_CTX_OPT_ADAPTIVE_FOLD (round 4; on by default as mode 1): the first rt_integrate traces a probe frame, a worker thread folds both
+    4-wide trees again for the probe rays' measured box passes, and the records are replaced between two rt_integrate calls -- waiting
+    for the worker (bit 1) or whenever it is ready (modes 5 and 1: the frame goes on meanwhile) -- and again when a frame looks at the
+    scene from somewhere else.  Whatever the fold and whenever it arrives: the reference's radiance, bit for bit.  shadow_tree 0 / 1 / 2:
+    the shadow rays share the closest-hit records, walk the measured choice, or walk the backend's own binary tree (whose fold is then the
+    one adapted).  The host half alone: tests/test_adaptive_fold.py."""
     import time
     w, h, bounces = 96, 64, 5
     scene = host.Scene(arrays=S.city_block(40_000))
@@ -208,43 +209,71 @@ def test_adaptive_fold_is_adopted_and_changes_no_bit(ctx, mode, shadow_tree):
     scene.build_bvh()
     scene.finalize()
     sc = scene.arrays()
-    cam = T.default_camera(w, h)
+    assert len(sc["nodes"]) >= 8192                                  # mode 1 (the default) adapts trees of this size without being forced to
     ctx.set_adaptive_fold(mode)
     ctx.set_shadow_tree(shadow_tree)
     try:
         ctx.upload_scene(sc)
     finally:
-        ctx.set_adaptive_fold(0)
+        ctx.set_adaptive_fold(capi.ADAPTIVE_FOLD_DEFAULT)
         ctx.set_shadow_tree(1)
     assert "adaptive fold" not in ctx.tree_report()
-    fr = capi.Frame(ctx, w, h)
-    fr.set_camera(cam)
-    fr.set_max_bounces(bounces)
-    fr.integrate(2)                                                  # the probe; with bit 1 the new fold is in place when this returns
-    for _ in range(400):
-        if "adaptive fold" in ctx.tree_report():
-            break
-        assert not mode & 2, ctx.tree_report()
-        time.sleep(0.02)
-        fr.integrate(1)                                              # the frame goes on with the fold it has
-    report = ctx.tree_report()
-    assert "adaptive fold:" in report and "closest-hit" in report and "adopted" in report, report
-    fr.integrate(3)                                                  # ... and with the new one
-    spp = fr.sample_count()
-    orc = _oracle.Oracle(w, h, sc)
-    orc.set_camera(cam)
-    orc.set_max_bounces(bounces)
-    orc.integrate(spp)
-    assert np.array_equal(fr.radiance()[..., :3], orc.radiance()[..., :3]), report
-    fr.close()
-    # the next upload starts from the surface-area fold again, and does not adapt unless asked to
-    ctx.upload_scene(sc)
+
+    def frame_of(cam, probe):
+        """a frame of `cam`, integrated until the fold of probe number `probe` is in place and then some more; against the oracle"""
+        fr = capi.Frame(ctx, w, h)
+        fr.set_camera(cam)
+        fr.set_max_bounces(bounces)
+        fr.integrate(2)                                              # the probe; with bit 1 the new fold is in place when this returns
+        tag = "adaptive fold (probe %d)" % probe
+        for _ in range(500):
+            if tag in ctx.tree_report():
+                break
+            assert not mode & 2, ctx.tree_report()
+            time.sleep(0.02)
+            fr.integrate(1)                                          # the frame goes on with the fold it has
+        report = ctx.tree_report()
+        assert tag in report and "closest-hit" in report and "adopted" in report and report.count("adaptive fold") == 1, report
+        fr.integrate(3)                                              # ... and with the new one
+        spp = fr.sample_count()
+        orc = _oracle.Oracle(w, h, sc)
+        orc.set_camera(cam)
+        orc.set_max_bounces(bounces)
+        orc.integrate(spp)
+        assert np.array_equal(fr.radiance()[..., :3], orc.radiance()[..., :3]), report
+        fr.close()
+        return spp, orc.radiance()[..., :3]
+
+    cam = T.default_camera(w, h)
+    spp, want = frame_of(cam, 1)
+    # the same view again: nothing to adapt to
+    again = capi.Frame(ctx, w, h)
+    again.set_camera(cam)
+    again.set_max_bounces(bounces)
+    again.integrate(spp)
+    assert "adaptive fold (probe 1)" in ctx.tree_report()
+    assert np.array_equal(again.radiance()[..., :3], want)
+    again.close()
+    # from the far end of the block, looking back: the view has left the one the folds were made for
+    far = T.default_camera(w, h)
+    f = np.array([-0.3, -1.0, -0.05]); f /= np.linalg.norm(f)
+    r = np.cross(f, [0.0, 0.0, 1.0]); r /= np.linalg.norm(r)
+    u = np.cross(r, f)
+    for i, k in enumerate("xyz"):
+        far["position"][k] = (18.0, 56.0, 1.5)[i]; far["front"][k] = f[i]; far["up"][k] = u[i]
+    frame_of(far, 2)
+    # the next upload starts from the surface-area fold again, and with the option off stays there
+    ctx.set_adaptive_fold(0)
+    try:
+        ctx.upload_scene(sc)
+    finally:
+        ctx.set_adaptive_fold(capi.ADAPTIVE_FOLD_DEFAULT)
     plain = capi.Frame(ctx, w, h)
     plain.set_camera(cam)
     plain.set_max_bounces(bounces)
     plain.integrate(spp)
     assert "adaptive fold" not in ctx.tree_report()
-    assert np.array_equal(plain.radiance()[..., :3], orc.radiance()[..., :3])
+    assert np.array_equal(plain.radiance()[..., :3], want)
     plain.close()
 
 

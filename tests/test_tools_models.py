@@ -63,12 +63,18 @@ def test_code_object_identity_and_the_stale_flag_of_the_roofline(tmp_path):
     live = dict(avg_launch_ms=15.0, rays_per_launch=1.0e8, mrays_per_s=6666.7, kernel_ms_per_spp=dict(trace_closest=1.05, trace_shadow=0.5, shade=0.4, raygen=0.02))
     per_ray = dict(closest_nodes=77.7, closest_tris=2.9, closest_steps=24.07, closest_wide_visits=20.9)
     iso = dict(avg_launch_ms=14.7, rays_per_launch=1.0e8, kernel_ms_per_spp=dict(trace_closest=1.03, trace_shadow=0.36, shade=0.37, raygen=0.02))
-    args = type("A", (), dict(config=4))()
     old = bench.COUNTERS_FILE
     try:
-        for recorded, want_stale in ((digest, False), ("0" * 64, True)):
+        # ... or when the counters were collected on another FOLD of the trees than the run walks (round 4: the same code object visits fewer
+        # records on a fold adapted to the frame's rays; a file without the field is of the surface-area fold)
+        for recorded, fold, adaptive, want_stale in ((digest, "adapted to the frame's rays", 3, False), ("0" * 64, "adapted to the frame's rays", 3, True),
+                                                     (digest, None, 0, False), (digest, None, 3, True), (digest, "adapted to the frame's rays", 0, True)):
+            args = type("A", (), dict(config=4, adaptive_fold=adaptive))()
             bench.COUNTERS_FILE = str(tmp_path / "counters.json")
-            json.dump({"config_4": {"closest": k}, "_code_object_sha256": recorded, "_how": "test"}, open(bench.COUNTERS_FILE, "w"))
+            doc = {"config_4": {"closest": k}, "_code_object_sha256": recorded, "_how": "test"}
+            if fold is not None:
+                doc["_fold"] = fold
+            json.dump(doc, open(bench.COUNTERS_FILE, "w"))
             r = bench.roofline_object(args, 1, live, per_ray, iso)
             assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
             assert abs(r["achieved"] - 8.0e9 / 14.7e-3 / 1e9) < 0.1 and abs(r["frac"] - r["achieved"] / 8000.0) < 1e-4     # the stated formula

@@ -27,15 +27,30 @@ KERNELS = {"closest": "k_trace_w4<false", "shadow": "k_trace_w4<true", "shade": 
 CUS, SIMDS = 256, 1024
 
 
+# Launches that count: those of at least 3 % of the kernel's longest launch in the same pass.  (RT_CTX_OPT_ADAPTIVE_FOLD's probe frame puts
+# a few dozen launches of ~32 K paths in front of the frame's own of ~265 M: they would not move a busy FRACTION, but they would deflate every
+# per-launch mean by their share of the launch COUNT.  The frame's smallest launch, the last bounce, is above a tenth of its largest.)
+MIN_SHARE = 0.03
+
+
 def mean(passname, counter, match):
     vals = []
     for f in glob.glob("%s/%s/**/*counter_collection.csv" % (d, passname), recursive=True):
-        vals += [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if r["Counter_Name"] == counter and match in r["Kernel_Name"]]
+        rows = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == counter and match in r["Kernel_Name"]]
+        if not rows:
+            continue
+        dur = [float(r["End_Timestamp"]) - float(r["Start_Timestamp"]) for r in rows]
+        vals += [float(r["Counter_Value"]) for r, t in zip(rows, dur) if t >= MIN_SHARE * max(dur)]
     return sum(vals) / len(vals) if vals else None
 
 
 def launches(match):
-    for f in glob.glob("%s/stats/**/*kernel_stats.csv" % d, recursive=True):
+    for f in glob.glob("%s/stats/**/*kernel_trace.csv" % d, recursive=True):
+        dur = [float(r["End_Timestamp"]) - float(r["Start_Timestamp"]) for r in csv.DictReader(open(f)) if match in r["Kernel_Name"]]
+        dur = [t for t in dur if t >= MIN_SHARE * max(dur)]
+        if dur:
+            return len(dur), sum(dur) / len(dur) * 1e-6
+    for f in glob.glob("%s/stats/**/*kernel_stats.csv" % d, recursive=True):      # the summary alone (the trace was too large to keep)
         for r in csv.DictReader(open(f)):
             if match in r["Name"]:
                 return int(r["Calls"]), float(r["AverageNs"]) * 1e-6
@@ -72,6 +87,7 @@ for key, match in KERNELS.items():
 doc["config_%s" % config] = entry
 doc["_how"] = "tools/pmc_bench2.sh + tools/make_counters_json.py (see its docstring for every ceiling); VALU mix: tools/isa_mix.py --loops"
 doc["_code_object_sha256"] = codeobj.code_object_sha256()
+doc["_fold"] = os.environ.get("RT_COUNTERS_FOLD", "surface area")      # which fold of the trees the profiled runs walked (bench.py --adaptive-fold)
 json.dump(doc, open(out, "w"), indent=1)
 for k, e in entry.items():
     print(k, {n: round(e[n], 4) for n in ("valu_busy", "salu_busy", "l1_ta_busy", "hbm_frac", "avg_launch_ms")})
