@@ -84,7 +84,9 @@ enum rt_ctx_option
                                       verdict.  Bit 1: rt_integrate waits for the new fold (reproducible
                                       timing: bench.py, tests).  Bit 2: also for trees of fewer than 8192 nodes (tests).  0: off.
                                       Takes effect at the next rt_scene_upload; rt_scene_tree_report carries the latest
-                                      adaptation's line. */
+                                      adaptation's line.  Costs: a host copy of the binary tree(s), 48 bytes per node, for as long
+                                      as the scene lives; a 5 ms probe per adaptation; the worker gives up within milliseconds
+                                      when the scene is uploaded again. */
 };
 int rt_ctx_set_option(rt_ctx* ctx, int option, uint32_t value);
 /* The blue-noise sampler tables (src/utils/blue_noise_sampler.hpp: sobol_256spp_256d[256*256],

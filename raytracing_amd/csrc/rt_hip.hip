@@ -456,8 +456,10 @@ enum { RT_WIDE_TWO_LEVELS = 0, RT_WIDE_SAH = 1 };
 bool build_wide_bvh(const rt_bvh_node* nodes, uint32_t nn, int collapse, std::vector<WideNode>& out, uint32_t& entry_ref,
     std::vector<uint32_t>* roots = nullptr /* the BVH2 node each record folds (tests) */,
     const ownbvh::Metric* metric = nullptr /* what "area" means for the SAH collapse (own_bvh.h); nullptr = surface area */,
-    const double* weights = nullptr /* per BVH2 node: replaces the area altogether (a MEASURED visit frequency: FoldAdapt) */)
+    const double* weights = nullptr /* per BVH2 node: replaces the area altogether (a MEASURED visit frequency: FoldAdapt) */,
+    const std::atomic<bool>* cancel = nullptr /* set by another thread: give up (false) at the next check -- a scene uploaded again does not wait */)
 {
+    auto cancelled = [&]() { return cancel && cancel->load(std::memory_order_relaxed); };
     auto is_leaf = [&](uint32_t i) { return (nodes[i].num_primitives_axis >> 16) != 0; };
     out.clear();
     if (is_leaf(0)) { entry_ref = RT_LEAF_BIT | nodes[0].offset; return true; }
@@ -488,6 +490,7 @@ bool build_wide_bvh(const rt_bvh_node* nodes, uint32_t nn, int collapse, std::ve
         auto G = [&](uint32_t c, uint32_t i) { return is_leaf(c) ? 0.0 : (i >= 2u ? std::min(T[c], F[(size_t)c * 5u + i]) : T[c]); };
         for (uint32_t n = nn; n-- > 0;)
         {
+            if ((n & 0xFFFFu) == 0u && cancelled()) return false;
             if (is_leaf(n)) continue;
             const uint32_t l = n + 1, r = nodes[n].offset;
             for (uint32_t k = 2; k <= 4; ++k)
@@ -619,6 +622,7 @@ bool build_wide_bvh(const rt_bvh_node* nodes, uint32_t nn, int collapse, std::ve
         uint32_t n = todo.back(), depth = depth_of.back();
         todo.pop_back();
         depth_of.pop_back();
+        if ((order.size() & 0xFFFFu) == 0u && cancelled()) return false;
         if (depth > 33u) return false;                                     // <= 3 pending slots per level must fit RT_W4_STACK_MAX
         // a node reached twice (several parents share a child) is not a tree: the walk below would append once per PATH
         if (wide_of[n] != RT_EMPTY_REF || order.size() >= nn) return false;
@@ -705,7 +709,7 @@ bool build_wide_bvh(const rt_bvh_node* nodes, uint32_t nn, int collapse, std::ve
         {
             ArrangementCache cache;
             for (size_t w = w0; w < w1 && ok.load(std::memory_order_relaxed); ++w)
-                if (!make_record(w, cache)) ok.store(false);
+                if (((w & 0x3FFFu) == 0u && cancelled()) || !make_record(w, cache)) ok.store(false);
         };
         std::vector<std::thread> pool;
         for (unsigned t = 1; t < n_threads; ++t) pool.emplace_back(run, n_records * t / n_threads, n_records * (t + 1) / n_threads);
@@ -888,7 +892,7 @@ bool refold_for_rays(const std::vector<rt_bvh_node>& tree, const std::vector<flo
     const double prior = 0.05 * total / area_sum;
     for (uint32_t n = 0; n < nn; ++n) w[n] = (double)counts[n] + prior * w[n];
     std::vector<uint32_t> roots_new;
-    if (!build_wide_bvh(tree.data(), nn, RT_WIDE_SAH, out, entry, &roots_new, nullptr, w.data()) || out.empty()) return false;
+    if (!build_wide_bvh(tree.data(), nn, RT_WIDE_SAH, out, entry, &roots_new, nullptr, w.data(), &cancel) || out.empty()) return false;
     cost[0] = cost[1] = 0.0;
     for (uint32_t r : roots_now) if (r < nn) cost[0] += w[r];
     for (uint32_t r : roots_new) cost[1] += w[r];
