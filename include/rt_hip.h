@@ -403,7 +403,9 @@ int rt_frame_debug_timeline(rt_frame* frame, int arm, unsigned long long* out);
 int rt_debug_wide_bvh(const rt_bvh_node* nodes, uint32_t num_nodes, int collapse, void* records, uint32_t* roots, uint32_t capacity,
     uint32_t* num_records, uint32_t* entry_ref);
 
-/* What the last rt_scene_upload measured when it chose the trees (one line per ray population; "" when it had no choice) */
+/* What the last rt_scene_upload measured when it chose the trees (one line per ray population; "" when it had no choice), then the
+ * latest fold adaptation's line (RT_CTX_OPT_ADAPTIVE_FOLD).  The pointer is valid until the next rt_integrate or rt_scene_upload on
+ * this context (an adaptation rewrites its line): copy it. */
 const char* rt_scene_tree_report(rt_ctx* ctx);
 /* The tree rt_scene_upload would give the shadow (shadow != 0) or closest-hit rays of this scene under RT_CTX_OPT_SHADOW_TREE /
  * RT_CTX_OPT_CLOSEST_TREE = mode (host only; needs sd->triangles, nodes, lights): its records and the report line. */
