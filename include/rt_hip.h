@@ -427,6 +427,10 @@ int rt_debug_wide_bvh_metric(const rt_bvh_node* nodes, uint32_t num_nodes, doubl
 int rt_debug_adapt_fold(const rt_bvh_node* nodes, uint32_t num_nodes, const float* origins_tmax, const float* directions, uint32_t n_rays,
     void* records, uint32_t* roots, uint32_t capacity, uint32_t* num_records, uint32_t* entry_ref, double* cost2, int* cheaper);
 
+/* RT_CTX_OPT_ADAPTIVE_FOLD's trigger on its own (host only): 1 when camera `now` has left the view the folds were adapted to -- position by more
+ * than 3 % of scene_diagonal, direction by more than 20 degrees, field of view by more than a tenth -- else 0; -1 on a NULL argument. */
+int rt_debug_fold_view_left(const rt_camera* adapted, const rt_camera* now, double scene_diagonal);
+
 /* ---- kernel self-test hooks (known-answer tests of the device math):
  * evaluates fn over n inputs on the device.  fn: 0 sin, 1 cos, 2 tan, 3 pow(a,b),
  * 4 atan2(a,b), 5 acos, 6 sqrt, 7 a/b, 8 SampleRandom(bits of a.. as uints) */

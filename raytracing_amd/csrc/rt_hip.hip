@@ -2787,6 +2787,16 @@ int rt_debug_adapt_fold(const rt_bvh_node* nodes, uint32_t num_nodes, const floa
     return RT_OK;
 }
 
+// RT_CTX_OPT_ADAPTIVE_FOLD's trigger on its own: has camera `now` left the view the folds were adapted to (`adapted`), in a scene of this diagonal?
+int rt_debug_fold_view_left(const rt_camera* adapted, const rt_camera* now, double scene_diagonal)
+{
+    if (!adapted || !now) return -1;
+    FoldAdapt a;
+    a.camera = *adapted;
+    a.scene_diagonal = scene_diagonal;
+    return fold_view_left(a, *now) ? 1 : 0;
+}
+
 int rt_debug_eval(rt_ctx* ctx, int fn, const float* a, const float* b, float* out, uint32_t n)
 {
     if (!ctx || !a || !out) return fail(ctx, "rt_debug_eval: NULL argument");

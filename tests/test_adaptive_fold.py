@@ -133,3 +133,34 @@ def test_rays_that_pass_nothing_leave_the_fold_alone(golden_scenes):
     o = np.array([[1e6, 1e6, 1e6, 1.0]], np.float32); d = np.array([[1.0, 0.0, 0.0, 0.0]], np.float32)
     with pytest.raises(capi.RtError):
         capi.adapt_fold(arrays["nodes"], o, d)
+
+
+def test_when_the_camera_has_left_the_view():
+    """fold_view_left (rt_hip.hip): the thresholds that arm a new adaptation -- 3 % of the scene's diagonal, 20 degrees, a tenth of the field of view"""
+    lib = capi.load()
+    base = T.default_camera(64, 64)
+
+    def left(cam, diagonal=100.0):
+        a, b = np.ascontiguousarray(base), np.ascontiguousarray(cam)
+        return lib.rt_debug_fold_view_left(a.ctypes.data, b.ctypes.data, diagonal)
+
+    assert left(base) == 0
+    for dx, want in ((2.9, 0), (3.1, 1)):                           # 3 % of a diagonal of 100
+        cam = base.copy(); cam["position"]["x"] = float(base["position"]["x"]) + dx
+        assert left(cam) == want, dx
+    cam = base.copy(); cam["position"]["z"] = float(base["position"]["z"]) + 2.0
+    assert left(cam, 100.0) == 0 and left(cam, 50.0) == 1           # the same step in a smaller scene
+    f = np.array([float(base["front"][k]) for k in "xyz"])
+    side = np.cross(f, [0.0, 0.0, 1.0]); side /= np.linalg.norm(side)
+    for deg, want in ((19.0, 0), (21.0, 1), (180.0, 1)):
+        g = np.cos(np.radians(deg)) * f + np.sin(np.radians(deg)) * side
+        cam = base.copy()
+        for i, k in enumerate("xyz"):
+            cam["front"][k] = g[i]
+        assert left(cam) == want, deg
+    for scale, want in ((1.09, 0), (1.11, 1), (0.89, 1)):
+        cam = base.copy(); cam["fov"] = np.float32(float(base["fov"]) * scale)
+        assert left(cam) == want, scale
+    cam = base.copy(); cam["position"]["x"] = np.float32(np.nan)
+    assert left(cam) in (0, 1)                                      # no crash on garbage; whatever it answers, results do not depend on it
+    assert lib.rt_debug_fold_view_left(None, None, 1.0) == -1
