@@ -128,6 +128,32 @@ def test_adapted_folds_of_random_soups(seed, env_map):
     exercise(arrays, 40, 30, 4)
 
 
+def test_adapted_fold_of_the_shadow_rays_own_tree(env_map):
+    """The shadow rays' own binary tree (own_bvh.h) is what FoldAdapt folds again when rt_scene_upload chose it: verdicts stay the reference
+    loop's, and the adapted fold of the own tree is cheaper than its projected-area fold for rays it has not seen."""
+    from tests.test_own_tree import own_tree, wide_metric, check_own_structure, light_dir
+    scene = host.Scene(arrays=S.city_block(20000))
+    arrays = _finish(scene, env_map, point=False)
+    nodes = arrays["nodes"]
+    d = light_dir()
+    own = own_tree(nodes, 0.5, [d])
+    check_own_structure(nodes, own)
+    area_wide, area_entry = wide_metric(own, 0.5, [d])
+    orc, q = queues_of(arrays, 96, 54, 4)
+    so = np.concatenate([as_probe(s[::2])[0] for _, _, s, _ in q]); sdir = np.concatenate([as_probe(s[::2])[1] for _, _, s, _ in q])
+    rec, entry, roots, cost, adopted = capi.adapt_fold(own, so, sdir)
+    wide = rec.view(WIDE).reshape(-1)
+    check(own, 1, fold=(wide, entry, roots))
+    assert adopted and cost[1] < cost[0]
+    v_area, v_adapted = np.zeros(10, np.uint64), np.zeros(10, np.uint64)
+    for rays, hits, srays, verdicts in q:
+        for direct in (False, True):
+            assert np.array_equal(orc.wide_trace(wide, entry, srays, True, None, direct=direct), verdicts)
+        orc.wide_trace(area_wide, area_entry, srays[1::2], True, v_area, direct=True)
+        orc.wide_trace(wide, entry, srays[1::2], True, v_adapted, direct=True)
+    assert int(v_adapted[1]) < int(v_area[1]), (int(v_adapted[1]), int(v_area[1]))
+
+
 def test_rays_that_pass_nothing_leave_the_fold_alone(golden_scenes):
     arrays = next(iter(golden_scenes.values()))
     o = np.array([[1e6, 1e6, 1e6, 1.0]], np.float32); d = np.array([[1.0, 0.0, 0.0, 0.0]], np.float32)
