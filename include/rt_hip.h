@@ -82,7 +82,12 @@ enum rt_ctx_option
                                       left the view they were made for (3 % of the scene's diagonal, 20 degrees, a tenth of the
                                       field of view).  EXACT: a fold decides which interior boxes are tested, never a hit or a
                                       verdict.  Bit 1: rt_integrate waits for the new fold (reproducible
-                                      timing: bench.py, tests).  Bit 2: also for trees of fewer than 8192 nodes (tests).  0: off.
+                                      timing: bench.py, tests).  Bit 2: also for trees of fewer than 8192 nodes (tests).  Bit 3
+                                      (opt-in; built at the end of round 4, exact, its speed not yet measured on the device): the
+                                      shadow rays' BINARY tree is first rotated for the probe rays' measured crossings
+                                      (tree_rotate.h: - 9 % steps per shadow ray on the headline scene, - 27 % on a 300 K one, on
+                                      the CPU walk, out of sample) -- any tree over the reference's leaves gives an any-hit
+                                      query the reference's verdict.  0: off.
                                       Takes effect at the next rt_scene_upload; rt_scene_tree_report carries the latest
                                       adaptation's line.  Costs: a host copy of the binary tree(s), 48 bytes per node, for as long
                                       as the scene lives; a 5 ms probe per adaptation; the worker gives up within milliseconds

@@ -18,6 +18,7 @@
 #include "kernels.h"
 #include "own_bvh.h"
 #include "tree_select.h"
+#include "tree_rotate.h"
 #include <chrono>
 
 namespace
@@ -65,7 +66,8 @@ struct rt_ctx
     uint32_t closest_tree = 0;    // RT_CTX_OPT_CLOSEST_TREE: 1 / 2 as above; != 0 is the tolerance mode (NOT bit-exact)
     uint32_t adaptive_fold = 1;   // RT_CTX_OPT_ADAPTIVE_FOLD: bit 0 = re-fold the 4-wide trees for the rays rt_integrate actually traces (exact: a fold
                                   // decides which boxes are tested, never a result), bit 1 = rt_integrate waits for the new fold instead of
-                                  // adopting it when it is ready, bit 2 = also for scenes too small to profit (tests)
+                                  // adopting it when it is ready, bit 2 = also for scenes too small to profit (tests), bit 3 = the shadow rays'
+                                  // binary tree is rotated for the probe rays' crossings before it is folded (tree_rotate.h; opt-in)
     std::vector<rt_frame*> frames;   // the frames alive on this context (rt_finish waits for their side streams too)
     uint8_t* blue_noise = nullptr;   // sobol[65536] | scramblingTile[131072] | rankingTile[131072]
     float* gamma_lut = nullptr;      // pow(byte / 255, 2.2f), 256 entries (k_fill_gamma_lut)
@@ -346,7 +348,7 @@ int rt_ctx_set_option(rt_ctx* ctx, int option, uint32_t value)
     if (option == RT_CTX_OPT_WIDE_BVH) { ctx->build_wide = value > 2u ? 1u : value; return RT_OK; }
     if (option == RT_CTX_OPT_SHADOW_TREE) { ctx->shadow_tree = value > 3u ? 1u : value; return RT_OK; }
     if (option == RT_CTX_OPT_CLOSEST_TREE) { ctx->closest_tree = value > 2u ? 1u : value; return RT_OK; }
-    if (option == RT_CTX_OPT_ADAPTIVE_FOLD) { ctx->adaptive_fold = value & 7u; return RT_OK; }
+    if (option == RT_CTX_OPT_ADAPTIVE_FOLD) { ctx->adaptive_fold = value & 15u; return RT_OK; }
     return fail(ctx, "rt_ctx_set_option: unknown option");
 }
 
@@ -814,6 +816,8 @@ struct FoldAdapt
     std::vector<rt_bvh_node> bvh2, bvh2_sh;            // the reference's tree; the shadow rays' own binary tree (empty: they walk the reference's)
     std::vector<uint32_t> roots, roots_sh;             // the binary-tree node each record of the CURRENT folds tests
     std::vector<uint32_t> roots_new, roots_sh_new;     // ... of the adapted folds
+    std::vector<rt_bvh_node> bvh2_sh_new;              // mode bit 3: the shadow rays' binary tree after tree_rotate.h's rotations (when that is what was folded)
+    uint32_t rotations = 0;                            // ... how many (0: the fold is of the tree as it was)
     std::vector<float4> o, d, sh_o, sh_d;              // the probe's rays (o.w = t_max: the hit distance where there was one)
     std::vector<WideNode> wide, wide_sh;               // the adapted folds
     uint32_t entry = 0, entry_sh = 0;
@@ -901,13 +905,40 @@ bool refold_for_rays(const std::vector<rt_bvh_node>& tree, const std::vector<flo
     return cost[1] < cost[0];
 }
 
+// The shadow rays' side of an adaptation.  Their verdict does not depend on the tree above the reference's leaves (own_bvh.h), so with mode bit 3
+// the binary tree itself is first rotated for the probe rays' measured crossings (tree_rotate.h) and then folded; whichever of the two folds --
+// of the tree as it was, of the rotated tree -- costs the probe rays less is the candidate.
+bool adapt_shadow_side(FoldAdapt* a)
+{
+    const std::vector<rt_bvh_node>& tree = a->bvh2_sh.empty() ? a->bvh2 : a->bvh2_sh;
+    const std::vector<uint32_t>& roots = a->roots_sh.empty() ? a->roots : a->roots_sh;
+    a->rotations = 0;
+    a->bvh2_sh_new.clear();
+    bool ok = refold_for_rays(tree, a->sh_o, a->sh_d, roots, a->wide_sh, a->entry_sh, a->cost[1], a->cancel, &a->roots_sh_new);
+    if (!(a->mode & 8u) || a->sh_o.empty() || a->cancel.load()) return ok;
+    std::vector<rt_bvh_node> rotated;
+    double crossings[2] = {0.0, 0.0};
+    const uint32_t made = treerot::rotate(tree.data(), (uint32_t)tree.size(), (const float*)a->sh_o.data(), (const float*)a->sh_d.data(), a->sh_o.size(), 8, rotated, crossings, &a->cancel);
+    if (made == 0 || rotated.size() != tree.size() || a->cancel.load()) return ok;
+    std::vector<WideNode> wide;
+    std::vector<uint32_t> roots_rot;
+    uint32_t entry = 0;
+    double cost[2] = {0.0, 0.0};
+    const std::vector<uint32_t> top{0u};                                   // (the rotated tree has no current fold: only cost[1] is read)
+    (void)refold_for_rays(rotated, a->sh_o, a->sh_d, top, wide, entry, cost, a->cancel, &roots_rot);
+    if (wide.empty() || roots_rot.empty() || a->cancel.load()) return ok;
+    const double current = a->cost[1][0] > 0.0 ? a->cost[1][0] : INFINITY, plain = ok ? a->cost[1][1] : current;
+    if (!(cost[1] < plain)) return ok;
+    a->wide_sh.swap(wide); a->entry_sh = entry; a->roots_sh_new.swap(roots_rot); a->bvh2_sh_new.swap(rotated);
+    a->cost[1][1] = cost[1];
+    a->rotations = made;
+    return cost[1] < current;
+}
+
 void fold_adapt_worker(FoldAdapt* a)
 {
     const auto t0 = std::chrono::steady_clock::now();
-    // the shadow rays' records fold either their own binary tree or, like the closest-hit records (but on their own now), the reference's
-    const std::vector<rt_bvh_node>& sh_tree = a->bvh2_sh.empty() ? a->bvh2 : a->bvh2_sh;
-    const std::vector<uint32_t>& sh_roots = a->roots_sh.empty() ? a->roots : a->roots_sh;
-    std::thread shadow([&]() { a->ok_sh = refold_for_rays(sh_tree, a->sh_o, a->sh_d, sh_roots, a->wide_sh, a->entry_sh, a->cost[1], a->cancel, &a->roots_sh_new); });
+    std::thread shadow([a]() { a->ok_sh = adapt_shadow_side(a); });
     a->ok = refold_for_rays(a->bvh2, a->o, a->d, a->roots, a->wide, a->entry, a->cost[0], a->cancel, &a->roots_new);
     shadow.join();
     a->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -2223,17 +2254,25 @@ static int fold_adopt(rt_ctx* ctx)
             s.wnodes_sh = new_sh;
             s.d.wnodes_sh = (const float4*)new_sh; s.d.w_sh_entry_ref = a->entry_sh; s.n_wide_sh = (uint32_t)a->wide_sh.size();
             a->roots_sh.swap(a->roots_sh_new);
+            if (a->rotations != 0) a->bvh2_sh.swap(a->bvh2_sh_new);          // the shadow rays' binary tree from now on
         }
         if (a->ok || a->ok_sh) ++a->adaptations;
         snprintf(line, sizeof(line), "adaptive fold (probe %u): %zu closest-hit and %zu shadow probe rays; box passes per probe ray at record roots: closest-hit %.2f -> %.2f (%s), "
             "shadow %.2f -> %.2f (%s); %.2f s on a worker thread\n", a->adaptations, a->o.size(), a->sh_o.size(), a->cost[0][0], a->cost[0][1], a->ok ? "adopted" : "kept",
             a->cost[1][0], a->cost[1][1], a->ok_sh ? "adopted" : "kept", a->seconds);
         s.tree_report += line;
+        if (a->ok_sh && a->rotations != 0)
+        {
+            s.tree_report.pop_back();
+            snprintf(line, sizeof(line), "; the shadow rays' binary tree rotated for the probe rays' crossings first (%u rotations)\n", a->rotations);
+            s.tree_report += line;
+        }
     }
     // the rays and the records have served; the binary trees stay for the next camera
     for (auto* v : {&a->o, &a->d, &a->sh_o, &a->sh_d}) std::vector<float4>().swap(*v);
     for (auto* v : {&a->wide, &a->wide_sh}) std::vector<WideNode>().swap(*v);
     for (auto* v : {&a->roots_new, &a->roots_sh_new}) std::vector<uint32_t>().swap(*v);
+    std::vector<rt_bvh_node>().swap(a->bvh2_sh_new);
     return RT_OK;
 }
 
@@ -2271,6 +2310,7 @@ static int fold_adapt_hook(rt_frame* f)
         }
         a->state = FoldAdapt::COMPUTING;
         a->ok = a->ok_sh = false;
+        a->cost[0][0] = a->cost[0][1] = a->cost[1][0] = a->cost[1][1] = 0.0;
         a->finished.store(false);
         a->worker = std::thread(fold_adapt_worker, a);
     }
@@ -2795,6 +2835,21 @@ int rt_debug_fold_view_left(const rt_camera* adapted, const rt_camera* now, doub
     a.camera = *adapted;
     a.scene_diagonal = scene_diagonal;
     return fold_view_left(a, *now) ? 1 : 0;
+}
+
+// tree_rotate.h on its own (host only): the binary tree `nodes` rotated for the rays given (as rt_debug_adapt_fold takes them); out_nodes[num_nodes]
+int rt_debug_rotate_tree(const rt_bvh_node* nodes, uint32_t num_nodes, const float* origins_tmax, const float* directions, uint32_t n_rays, int max_passes,
+    rt_bvh_node* out_nodes, double* cost2, uint32_t* rotations)
+{
+    if (!nodes || num_nodes == 0 || !origins_tmax || !directions || !out_nodes) return fail(nullptr, "rt_debug_rotate_tree: NULL argument");
+    std::vector<rt_bvh_node> out;
+    double cost[2] = {0.0, 0.0};
+    const uint32_t made = treerot::rotate(nodes, num_nodes, origins_tmax, directions, n_rays, max_passes, out, cost);
+    if (out.size() != num_nodes) return fail(nullptr, "rt_debug_rotate_tree: the node array is not a tree");
+    memcpy(out_nodes, out.data(), out.size() * sizeof(rt_bvh_node));
+    if (cost2) { cost2[0] = cost[0]; cost2[1] = cost[1]; }
+    if (rotations) *rotations = made;
+    return RT_OK;
 }
 
 int rt_debug_eval(rt_ctx* ctx, int fn, const float* a, const float* b, float* out, uint32_t n)

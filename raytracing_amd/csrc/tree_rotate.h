@@ -1,0 +1,207 @@
+// tree_rotate.h -- local search on a binary tree over the reference's leaves with a MEASURED objective (host code; round 4, analysis /
+// opt-in: RT_CTX_OPT_ADAPTIVE_FOLD bit 3).
+//
+// For any-hit (shadow) rays every binary tree over the reference's leaves gives the reference's verdict (own_bvh.h), so the tree may be
+// whatever is cheapest for the rays that are actually traced.  own_bvh.h builds one from a geometric model of those rays (projected area
+// along the lights); once a probe frame exists (rt_hip.hip: FoldAdapt) the model can be replaced by counting: the cost of an interior node
+// is the number of probe rays whose segment crosses its box -- that is how often a walk visits it -- and the tree's cost the sum over its
+// interior nodes.  This file lowers that sum by TREE ROTATIONS (Kensler 2008, "Tree rotations for improving bounding volume hierarchies",
+// with the surface area replaced by the crossing count): at a node n = (L, R) with L = (L1, L2), exchanging R with L1 or L2 changes one box
+// only -- L's -- and the rays that can cross the new box are among those crossing n, which each node keeps as a list.  Leaves, their boxes
+// and their triangles are never touched; the boxes of all other nodes stay exact unions by construction.
+#pragma once
+#include <stdint.h>
+#include <string.h>
+#include <math.h>
+#include <algorithm>
+#include <atomic>
+#include <vector>
+#include "rt_types.h"
+
+namespace treerot
+{
+struct Ray { float o[3], inv[3], t_max; };
+
+struct Tree
+{
+    // pointer form: node i has children kid[i][0..1] (RT_NONE for a leaf), box mn/mx, and for a leaf the reference node it copies
+    static constexpr uint32_t NONE = 0xFFFFFFFFu;
+    std::vector<uint32_t> kid0, kid1, leaf_ref;
+    std::vector<float> mn, mx;                                  // 3 floats per node
+    std::vector<std::vector<uint32_t>> rays;                    // the probe rays crossing each interior node's box (empty for leaves)
+    uint32_t root = 0;
+    bool leaf(uint32_t i) const { return kid0[i] == NONE; }
+};
+
+inline bool crosses(const Ray& r, const float* mn, const float* mx)
+{
+    float t0 = 0.0f, t1 = r.t_max;
+    for (int a = 0; a < 3; ++a)
+    {
+        const float ta = (mn[a] - r.o[a]) * r.inv[a], tb = (mx[a] - r.o[a]) * r.inv[a];
+        t0 = fmaxf(t0, fminf(ta, tb));
+        t1 = fminf(t1, fmaxf(ta, tb));
+    }
+    return t0 <= t1;
+}
+
+// nodes: a binary tree in the reference's linear layout (validated by the caller).  Returns the number of rotations made; `out` is the
+// rotated tree in the same layout (split axis of an interior node = the axis along which its children's box centres are farthest apart).
+// cost[0] / cost[1] = sum of crossing counts over interior nodes before / after, per ray.
+inline uint32_t rotate(const rt_bvh_node* nodes, uint32_t nn, const float* origins_tmax, const float* directions, size_t n_rays, int max_passes,
+    std::vector<rt_bvh_node>& out, double cost[2], const std::atomic<bool>* cancel = nullptr)
+{
+    out.clear();
+    cost[0] = cost[1] = 0.0;
+    if (nn == 0 || n_rays == 0) return 0;
+    Tree t;
+    t.kid0.assign(nn, Tree::NONE); t.kid1.assign(nn, Tree::NONE); t.leaf_ref.assign(nn, Tree::NONE);
+    t.mn.resize((size_t)nn * 3); t.mx.resize((size_t)nn * 3);
+    t.rays.resize(nn);
+    for (uint32_t i = 0; i < nn; ++i)
+    {
+        const rt_bvh_node& n = nodes[i];
+        t.mn[3 * (size_t)i] = n.bounds_min.x; t.mn[3 * (size_t)i + 1] = n.bounds_min.y; t.mn[3 * (size_t)i + 2] = n.bounds_min.z;
+        t.mx[3 * (size_t)i] = n.bounds_max.x; t.mx[3 * (size_t)i + 1] = n.bounds_max.y; t.mx[3 * (size_t)i + 2] = n.bounds_max.z;
+        if ((n.num_primitives_axis >> 16) != 0) t.leaf_ref[i] = i;
+        else
+        {
+            if (i + 1 >= nn || n.offset >= nn || n.offset <= i + 1) return 0;
+            t.kid0[i] = i + 1; t.kid1[i] = n.offset;
+        }
+    }
+    std::vector<Ray> rays(n_rays);
+    for (size_t r = 0; r < n_rays; ++r)
+    {
+        Ray& q = rays[r];
+        for (int a = 0; a < 3; ++a) { q.o[a] = origins_tmax[4 * r + a]; q.inv[a] = 1.0f / directions[4 * r + a]; }
+        q.t_max = origins_tmax[4 * r + 3];
+    }
+    // the lists: every ray walks the tree once
+    {
+        std::vector<uint32_t> stack;
+        for (size_t r = 0; r < n_rays; ++r)
+        {
+            stack.assign(1, 0u);
+            while (!stack.empty())
+            {
+                const uint32_t i = stack.back();
+                stack.pop_back();
+                if (!crosses(rays[r], &t.mn[3 * (size_t)i], &t.mx[3 * (size_t)i])) continue;
+                if (t.leaf(i)) continue;
+                t.rays[i].push_back((uint32_t)r);
+                stack.push_back(t.kid1[i]);
+                stack.push_back(t.kid0[i]);
+            }
+            if ((r & 1023u) == 0u && cancel && cancel->load(std::memory_order_relaxed)) return 0;
+        }
+    }
+    auto total = [&]() { double s = 0.0; for (uint32_t i = 0; i < nn; ++i) s += (double)t.rays[i].size(); return s / (double)n_rays; };
+    cost[0] = total();
+    // rotations, top-down over the nodes rays reach (a node without rays has nothing to gain), repeated until a pass changes little
+    uint32_t rotations = 0;
+    std::vector<uint32_t> order, keep;
+    for (int pass = 0; pass < max_passes; ++pass)
+    {
+        uint32_t made = 0;
+        order.assign(1, t.root);
+        for (size_t head = 0; head < order.size(); ++head)
+        {
+            const uint32_t n = order[head];
+            if (t.leaf(n) || t.rays[n].empty()) continue;
+            if ((head & 4095u) == 0u && cancel && cancel->load(std::memory_order_relaxed)) return 0;
+            // candidates: exchange one child of n with one grandchild under the OTHER child
+            long best_gain = 0; int best_side = -1, best_g = -1;
+            std::vector<uint32_t> best_list;
+            for (int side = 0; side < 2; ++side)
+            {
+                const uint32_t c = side ? t.kid1[n] : t.kid0[n];             // the child that is opened
+                const uint32_t other = side ? t.kid0[n] : t.kid1[n];          // the child that moves down
+                if (t.leaf(c)) continue;
+                for (int g = 0; g < 2; ++g)
+                {
+                    const uint32_t up = g ? t.kid1[c] : t.kid0[c];            // the grandchild that moves up
+                    const uint32_t stay = g ? t.kid0[c] : t.kid1[c];
+                    (void)up;
+                    float bmn[3], bmx[3];
+                    for (int a = 0; a < 3; ++a)
+                    {
+                        bmn[a] = std::min(t.mn[3 * (size_t)other + a], t.mn[3 * (size_t)stay + a]);
+                        bmx[a] = std::max(t.mx[3 * (size_t)other + a], t.mx[3 * (size_t)stay + a]);
+                    }
+                    keep.clear();
+                    for (uint32_t r : t.rays[n]) if (crosses(rays[r], bmn, bmx)) keep.push_back(r);
+                    const long gain = (long)t.rays[c].size() - (long)keep.size();   // c's box becomes (other + stay)'s
+                    if (gain > best_gain) { best_gain = gain; best_side = side; best_g = g; best_list = keep; }
+                }
+            }
+            if (best_side >= 0)
+            {
+                const uint32_t c = best_side ? t.kid1[n] : t.kid0[n];
+                const uint32_t other = best_side ? t.kid0[n] : t.kid1[n];
+                const uint32_t up = best_g ? t.kid1[c] : t.kid0[c];
+                const uint32_t stay = best_g ? t.kid0[c] : t.kid1[c];
+                // n = (c, other), c = (up, stay)  ->  n = (c, up), c = (other, stay)
+                (best_side ? t.kid0[n] : t.kid1[n]) = up;
+                t.kid0[c] = other; t.kid1[c] = stay;
+                for (int a = 0; a < 3; ++a)
+                {
+                    t.mn[3 * (size_t)c + a] = std::min(t.mn[3 * (size_t)other + a], t.mn[3 * (size_t)stay + a]);
+                    t.mx[3 * (size_t)c + a] = std::max(t.mx[3 * (size_t)other + a], t.mx[3 * (size_t)stay + a]);
+                }
+                t.rays[c].swap(best_list);
+                ++made;
+            }
+            order.push_back(t.kid0[n]);
+            order.push_back(t.kid1[n]);
+        }
+        rotations += made;
+        if (made == 0) break;
+    }
+    cost[1] = total();
+    // back to the linear layout: depth first, first child at i + 1
+    out.resize(nn);
+    struct Item { uint32_t node, pos; };
+    std::vector<uint32_t> size(nn, 1u);
+    {
+        // subtree sizes, children before parents: an explicit post-order
+        std::vector<std::pair<uint32_t, int>> st{{t.root, 0}};
+        while (!st.empty())
+        {
+            auto& top = st.back();
+            const uint32_t i = top.first;
+            if (t.leaf(i)) { st.pop_back(); continue; }
+            if (top.second == 0) { top.second = 1; st.push_back({t.kid0[i], 0}); }
+            else if (top.second == 1) { top.second = 2; st.push_back({t.kid1[i], 0}); }
+            else { size[i] = 1u + size[t.kid0[i]] + size[t.kid1[i]]; st.pop_back(); }
+        }
+    }
+    if (size[t.root] != nn) { out.clear(); return 0; }
+    std::vector<Item> st{{t.root, 0u}};
+    while (!st.empty())
+    {
+        const Item it = st.back();
+        st.pop_back();
+        const uint32_t i = it.node;
+        rt_bvh_node n;
+        memset(&n, 0, sizeof(n));
+        if (t.leaf(i)) { n = nodes[t.leaf_ref[i]]; n.num_primitives_axis &= 0xFFFF0000u; out[it.pos] = n; continue; }
+        n.bounds_min.x = t.mn[3 * (size_t)i]; n.bounds_min.y = t.mn[3 * (size_t)i + 1]; n.bounds_min.z = t.mn[3 * (size_t)i + 2];
+        n.bounds_max.x = t.mx[3 * (size_t)i]; n.bounds_max.y = t.mx[3 * (size_t)i + 1]; n.bounds_max.z = t.mx[3 * (size_t)i + 2];
+        const uint32_t a = t.kid0[i], b = t.kid1[i];
+        int axis = 0; float far = -1.0f;
+        for (int k = 0; k < 3; ++k)
+        {
+            const float ca = t.mn[3 * (size_t)a + k] + t.mx[3 * (size_t)a + k], cb = t.mn[3 * (size_t)b + k] + t.mx[3 * (size_t)b + k];
+            const float d = fabsf(ca - cb);
+            if (d > far) { far = d; axis = k; }
+        }
+        n.offset = it.pos + 1u + size[a];
+        n.num_primitives_axis = (uint32_t)axis;
+        out[it.pos] = n;
+        st.push_back({b, it.pos + 1u + size[a]});
+        st.push_back({a, it.pos + 1u});
+    }
+    return rotations;
+}
+} // namespace treerot

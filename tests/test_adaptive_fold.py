@@ -154,6 +154,64 @@ def test_adapted_fold_of_the_shadow_rays_own_tree(env_map):
     assert int(v_adapted[1]) < int(v_area[1]), (int(v_adapted[1]), int(v_area[1]))
 
 
+def rotated_and_checked(arrays, w, h, bounces):
+    """tree_rotate.h (RT_CTX_OPT_ADAPTIVE_FOLD bit 3): the reference's tree and the backend's own, each rotated for every second shadow ray's
+    crossings, are still binary trees over exactly the reference's leaves with exact-union boxes; their adapted folds are valid folds; and the
+    walk over them returns the reference loop's verdict for every shadow ray.  Returns the wide visits of the unseen rays per tree."""
+    from tests.test_own_tree import own_tree, check_own_structure, light_dir
+    nodes = arrays["nodes"]
+    orc, q = queues_of(arrays, w, h, bounces)
+    so = np.concatenate([as_probe(s[::2])[0] for _, _, s, _ in q]); sdir = np.concatenate([as_probe(s[::2])[1] for _, _, s, _ in q])
+    if len(so) == 0:
+        return None
+    visits = {}
+    for name, tree in (("reference", nodes), ("own", own_tree(nodes, 0.5, [light_dir()]))):
+        rot, crossings, made = capi.rotate_tree(tree, so, sdir, 8)
+        check_own_structure(nodes, rot)
+        assert crossings[1] <= crossings[0] and (made == 0) == (crossings[1] == crossings[0])
+        for label, t in ((name, tree), (name + " rotated", rot)):
+            rec, entry, roots, cost, adopted = capi.adapt_fold(t, so, sdir)
+            wide = rec.view(WIDE).reshape(-1)
+            check(t, 1, fold=(wide, entry, roots))
+            v = np.zeros(10, np.uint64)
+            for rays, hits, srays, verdicts in q:
+                for direct in (False, True):
+                    assert np.array_equal(orc.wide_trace(wide, entry, srays, True, None, direct=direct), verdicts), (label, direct)
+                orc.wide_trace(wide, entry, srays[1::2], True, v, direct=True)
+            visits[label] = int(v[1])
+    return visits
+
+
+def test_rotated_shadow_trees_on_the_golden_scenes(golden_scenes):
+    for name, arrays in golden_scenes.items():
+        rotated_and_checked(arrays, 24, 16, 3)
+
+
+def test_rotated_shadow_tree_of_a_city_block_is_cheaper_for_rays_it_has_not_seen(env_map):
+    scene = host.Scene(arrays=S.city_block(20000))
+    arrays = _finish(scene, env_map, point=False)
+    v = rotated_and_checked(arrays, 96, 54, 4)
+    assert v["own rotated"] < 0.97 * v["own"] and v["reference rotated"] < 0.97 * v["reference"], v
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_rotated_shadow_trees_of_random_soups(seed, env_map):
+    rng = np.random.default_rng(700 + seed)
+    n = int(rng.integers(60, 700))
+    P = rng.normal(size=(n, 1, 3)) * 1.2 + rng.normal(size=(n, 3, 3)) * float(10.0 ** rng.uniform(-1.2, 0.0)) + np.array([0.0, 2.5, 1.0])
+    P = P.astype(np.float32)
+    if seed % 2:
+        P[: n // 4] = P[0]
+    N = np.cross(P[:, 1] - P[:, 0], P[:, 2] - P[:, 0])
+    N = (N / np.maximum(np.linalg.norm(N, axis=1, keepdims=True), 1e-20)).astype(np.float32)[:, None, :].repeat(3, 1)
+    tris = S.to_triangles([(P, N, np.zeros((n, 3, 2), np.float32), 0)])
+    mats = np.array([S.make_material(kd=(0.7, 0.6, 0.5), ks=(0.3, 0.3, 0.3), roughness=0.3)], dtype=T.packed_material)
+    arrays = _finish(host.Scene(arrays=dict(triangles=tris, materials=mats)), env_map)
+    if (arrays["nodes"]["num_primitives_axis"][0] >> 16) != 0:
+        pytest.skip("a single leaf: no tree to rotate")
+    rotated_and_checked(arrays, 40, 30, 4)
+
+
 def test_rays_that_pass_nothing_leave_the_fold_alone(golden_scenes):
     arrays = next(iter(golden_scenes.values()))
     o = np.array([[1e6, 1e6, 1e6, 1.0]], np.float32); d = np.array([[1.0, 0.0, 0.0, 0.0]], np.float32)

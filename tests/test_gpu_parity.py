@@ -193,14 +193,15 @@ def test_mid_sample_reads_on_a_compact_log_allocation(ctx):
     fr.close()
 
 
-@pytest.mark.parametrize("mode,shadow_tree", [(7, 1), (7, 0), (7, 2), (5, 1), (1, 1)])
+@pytest.mark.parametrize("mode,shadow_tree", [(7, 1), (7, 0), (7, 2), (5, 1), (1, 1), (15, 1), (15, 0), (9, 2)])
 def test_adaptive_fold_is_adopted_and_changes_no_bit(ctx, mode, shadow_tree):
     """RT_CTX_OPT_ADAPTIVE_FOLD (round 4; on by default as mode 1): the first rt_integrate traces a probe frame, a worker thread folds both
     4-wide trees again for the probe rays' measured box passes, and the records are replaced between two rt_integrate calls -- waiting
     for the worker (bit 1) or whenever it is ready (modes 5 and 1: the frame goes on meanwhile) -- and again when a frame looks at the
     scene from somewhere else.  Whatever the fold and whenever it arrives: the reference's radiance, bit for bit.  shadow_tree 0 / 1 / 2:
     the shadow rays share the closest-hit records, walk the measured choice, or walk the backend's own binary tree (whose fold is then the
-    one adapted).  The host half alone: tests/test_adaptive_fold.py."""
+    one adapted).  Bit 3 (modes 15, 9): the shadow rays' BINARY tree is rotated for the probe rays' crossings before it is folded
+    (tree_rotate.h) -- another topology over the reference's leaves, the same verdicts.  The host half alone: tests/test_adaptive_fold.py."""
     import time
     w, h, bounces = 96, 64, 5
     scene = host.Scene(arrays=S.city_block(40_000))
@@ -219,7 +220,7 @@ def test_adaptive_fold_is_adopted_and_changes_no_bit(ctx, mode, shadow_tree):
         ctx.set_shadow_tree(1)
     assert "adaptive fold" not in ctx.tree_report()
 
-    def frame_of(cam, probe):
+    def frame_of(cam, probe, rotated):
         """a frame of `cam`, integrated until the fold of probe number `probe` is in place and then some more; against the oracle"""
         fr = capi.Frame(ctx, w, h)
         fr.set_camera(cam)
@@ -234,6 +235,7 @@ def test_adaptive_fold_is_adopted_and_changes_no_bit(ctx, mode, shadow_tree):
             fr.integrate(1)                                          # the frame goes on with the fold it has
         report = ctx.tree_report()
         assert tag in report and "closest-hit" in report and "adopted" in report and report.count("adaptive fold") == 1, report
+        assert rotated is None or ("rotated" in report) == rotated, report
         fr.integrate(3)                                              # ... and with the new one
         spp = fr.sample_count()
         orc = _oracle.Oracle(w, h, sc)
@@ -245,7 +247,7 @@ def test_adaptive_fold_is_adopted_and_changes_no_bit(ctx, mode, shadow_tree):
         return spp, orc.radiance()[..., :3]
 
     cam = T.default_camera(w, h)
-    spp, want = frame_of(cam, 1)
+    spp, want = frame_of(cam, 1, bool(mode & 8))
     # the same view again: nothing to adapt to
     again = capi.Frame(ctx, w, h)
     again.set_camera(cam)
@@ -261,7 +263,7 @@ def test_adaptive_fold_is_adopted_and_changes_no_bit(ctx, mode, shadow_tree):
     u = np.cross(r, f)
     for i, k in enumerate("xyz"):
         far["position"][k] = (18.0, 56.0, 1.5)[i]; far["front"][k] = f[i]; far["up"][k] = u[i]
-    frame_of(far, 2)
+    frame_of(far, 2, None if mode & 8 else False)       # (whether rotating AGAIN pays for the second view is the worker's business)
     # the next upload starts from the surface-area fold again, and with the option off stays there
     ctx.set_adaptive_fold(0)
     try:
