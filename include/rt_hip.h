@@ -432,6 +432,12 @@ int rt_debug_wide_bvh_metric(const rt_bvh_node* nodes, uint32_t num_nodes, doubl
 int rt_debug_adapt_fold(const rt_bvh_node* nodes, uint32_t num_nodes, const float* origins_tmax, const float* directions, uint32_t n_rays,
     void* records, uint32_t* roots, uint32_t capacity, uint32_t* num_records, uint32_t* entry_ref, double* cost2, int* cheaper);
 
+/* RT_CTX_OPT_ADAPTIVE_FOLD bit 3's tree search on its own (host only; raytracing_amd/csrc/tree_rotate.h): the binary tree `nodes` (reference
+ * layout) rotated to lower the number of box crossings of the rays given (as rt_debug_adapt_fold takes them) -- out_nodes[num_nodes] holds a binary
+ * tree over the same leaves in the same layout; cost2 = crossings of interior boxes per ray before / after; *rotations = how many were made. */
+int rt_debug_rotate_tree(const rt_bvh_node* nodes, uint32_t num_nodes, const float* origins_tmax, const float* directions, uint32_t n_rays, int max_passes,
+    rt_bvh_node* out_nodes, double* cost2, uint32_t* rotations);
+
 /* RT_CTX_OPT_ADAPTIVE_FOLD's trigger on its own (host only): 1 when camera `now` has left the view the folds were adapted to -- position by more
  * than 3 % of scene_diagonal, direction by more than 20 degrees, field of view by more than a tenth -- else 0; -1 on a NULL argument. */
 int rt_debug_fold_view_left(const rt_camera* adapted, const rt_camera* now, double scene_diagonal);
