@@ -20,7 +20,7 @@ except Exception as e:
 PY
 }
 for cfg in 4 2 3 1 5; do
-  for fold in 3 0; do
+  for fold in 3 11 0; do      # 3: the adapted fold (default), 11: + the shadow rays' tree rotated first (bit 3, untimed so far), 0: the upload's fold
     extra=""; [ $cfg = 1 ] && extra="--steps 64 --warmup 4"; [ $cfg = 5 ] && extra="--cpu-seconds 5"
     python bench.py --config $cfg --adaptive-fold $fold $extra > $O/bench_cfg${cfg}_fold${fold}.json 2>> $O/bench.err; el $(line bench_cfg${cfg}_fold${fold})
   done
