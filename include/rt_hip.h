@@ -85,7 +85,7 @@ enum rt_ctx_option
                                       timing: bench.py, tests).  Bit 2: also for trees of fewer than 8192 nodes (tests).  Bit 3
                                       (opt-in; built at the end of round 4, exact, its speed not yet measured on the device): the
                                       shadow rays' BINARY tree is first rotated for the probe rays' measured crossings
-                                      (tree_rotate.h: - 9 % steps per shadow ray on the headline scene, - 27 % on a 300 K one, on
+                                      (tree_rotate.h: - 13 % steps per shadow ray on the headline scene, - 29 % on a 300 K one, on
                                       the CPU walk, out of sample) -- any tree over the reference's leaves gives an any-hit
                                       query the reference's verdict.  0: off.
                                       Takes effect at the next rt_scene_upload; rt_scene_tree_report carries the latest
@@ -436,7 +436,8 @@ int rt_debug_adapt_fold(const rt_bvh_node* nodes, uint32_t num_nodes, const floa
  * layout) rotated to lower the number of box crossings of the rays given (as rt_debug_adapt_fold takes them) -- out_nodes[num_nodes] holds a binary
  * tree over the same leaves in the same layout; cost2 = crossings of interior boxes per ray before / after; *rotations = how many were made. */
 int rt_debug_rotate_tree(const rt_bvh_node* nodes, uint32_t num_nodes, const float* origins_tmax, const float* directions, uint32_t n_rays, int max_passes,
-    rt_bvh_node* out_nodes, double* cost2, uint32_t* rotations);
+    rt_bvh_node* out_nodes, double* cost2, uint32_t* rotations, int moves /* bit 0: child <-> grandchild, bit 1: grandchild <-> grandchild */,
+    double min_gain /* a move must save more than this share of the crossings at its node */);
 
 /* RT_CTX_OPT_ADAPTIVE_FOLD's trigger on its own (host only): 1 when camera `now` has left the view the folds were adapted to -- position by more
  * than 3 % of scene_diagonal, direction by more than 20 degrees, field of view by more than a tenth -- else 0; -1 on a NULL argument. */

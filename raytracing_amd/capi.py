@@ -118,7 +118,7 @@ def load():
         "rt_debug_own_bvh": (i32, [vp, u32, C.c_double, vp, u32, vp, u32, C.POINTER(u32)]),
         "rt_debug_wide_bvh_metric": (i32, [vp, u32, C.c_double, vp, u32, vp, u32, C.POINTER(u32), C.POINTER(u32)]),
         "rt_debug_fold_view_left": (i32, [vp, vp, C.c_double]),
-        "rt_debug_rotate_tree": (i32, [vp, u32, vp, vp, u32, i32, vp, C.POINTER(C.c_double), C.POINTER(u32)]),
+        "rt_debug_rotate_tree": (i32, [vp, u32, vp, vp, u32, i32, vp, C.POINTER(C.c_double), C.POINTER(u32), i32, C.c_double]),
         "rt_debug_adapt_fold": (i32, [vp, u32, vp, vp, u32, vp, vp, u32, C.POINTER(u32), C.POINTER(u32), C.POINTER(C.c_double), C.POINTER(i32)]),
         "rt_group_create": (i32, [i32, C.POINTER(i32), C.POINTER(vp)]), "rt_group_create_unchecked": (i32, [i32, C.POINTER(i32), C.POINTER(vp)]),
         "rt_group_unique_id": (i32, [vp, sz]),
@@ -183,7 +183,7 @@ def adapt_fold(nodes, origins_tmax, directions):
     return out[:n.value].copy(), entry.value, roots[:n.value].copy(), (cost[0], cost[1]), bool(cheaper.value)
 
 
-def rotate_tree(nodes, origins_tmax, directions, max_passes=8):
+def rotate_tree(nodes, origins_tmax, directions, max_passes=8, moves=3, min_gain=0.03):
     """rt_debug_rotate_tree (host only): tree_rotate.h's local search on the binary tree `nodes` for the rays given.
     Returns (rotated nodes, (crossings per ray before, after), rotations made)."""
     lib = load()
@@ -193,7 +193,7 @@ def rotate_tree(nodes, origins_tmax, directions, max_passes=8):
     out = np.zeros(len(nodes), nodes.dtype)
     cost = (C.c_double * 2)()
     made = C.c_uint32()
-    if lib.rt_debug_rotate_tree(nodes.ctypes.data, len(nodes), o.ctypes.data, d.ctypes.data, len(o), max_passes, out.ctypes.data, cost, C.byref(made)):
+    if lib.rt_debug_rotate_tree(nodes.ctypes.data, len(nodes), o.ctypes.data, d.ctypes.data, len(o), max_passes, out.ctypes.data, cost, C.byref(made), moves, min_gain):
         raise RtError(lib.rt_last_error(None).decode())
     return out, (cost[0], cost[1]), made.value
 

@@ -2839,12 +2839,12 @@ int rt_debug_fold_view_left(const rt_camera* adapted, const rt_camera* now, doub
 
 // tree_rotate.h on its own (host only): the binary tree `nodes` rotated for the rays given (as rt_debug_adapt_fold takes them); out_nodes[num_nodes]
 int rt_debug_rotate_tree(const rt_bvh_node* nodes, uint32_t num_nodes, const float* origins_tmax, const float* directions, uint32_t n_rays, int max_passes,
-    rt_bvh_node* out_nodes, double* cost2, uint32_t* rotations)
+    rt_bvh_node* out_nodes, double* cost2, uint32_t* rotations, int moves, double min_gain)
 {
     if (!nodes || num_nodes == 0 || !origins_tmax || !directions || !out_nodes) return fail(nullptr, "rt_debug_rotate_tree: NULL argument");
     std::vector<rt_bvh_node> out;
     double cost[2] = {0.0, 0.0};
-    const uint32_t made = treerot::rotate(nodes, num_nodes, origins_tmax, directions, n_rays, max_passes, out, cost);
+    const uint32_t made = treerot::rotate(nodes, num_nodes, origins_tmax, directions, n_rays, max_passes, out, cost, nullptr, moves, min_gain);
     if (out.size() != num_nodes) return fail(nullptr, "rt_debug_rotate_tree: the node array is not a tree");
     memcpy(out_nodes, out.data(), out.size() * sizeof(rt_bvh_node));
     if (cost2) { cost2[0] = cost[0]; cost2[1] = cost[1]; }

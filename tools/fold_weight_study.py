@@ -16,7 +16,13 @@ default   folds the reference's BVH2 of the benchmark scene with (a) the surface
 --views   four cameras (default; far end looking back; from above; a side street): each view's fold walked by every view's rays.  Own view: -2.4 ...
           -14.2 %; another view's fold: 0 ... +2 % as a rule, +5 % and +11 % in the worst pairs -- hence FoldAdapt adapts again when the camera
           has left the view (fold_view_left).
-usage: NT=2800000 python tools/fold_weight_study.py [--kernel | --views]     (logs: profiles/r04_fold_weight_study*.log)"""
+--tree    beyond the fold (RT_CTX_OPT_ADAPTIVE_FOLD bit 3): for shadow rays the BINARY tree is free too (any tree over the reference's leaves gives an
+          any-hit query the reference's verdict), so it is rotated for the probe rays' measured box crossings (csrc/tree_rotate.h) and then folded.
+          Steps per unseen shadow ray (400x225 frame; probe 240x135), verdicts asserted equal to the reference loop's for every tree:
+          2.8 M triangles: reference topology 14.84, the backend's own tree 13.16 (production), own + rotations 11.43 (-13 %; child<->grandchild
+          moves alone 11.98); 300 K triangles: 8.81 / 6.51 / 4.60 (-29 %).  A move has to save 3 % of the crossings at its node: taking every gain
+          fits the sample (5.01 instead of 4.60).  Dead ends on the way (a per-leaf mass term in own_bvh.h's greedy cost): DESIGN.md section 8.
+usage: NT=2800000 python tools/fold_weight_study.py [--kernel | --views | --tree]     (logs: profiles/r04_fold_weight_study*.log)"""
 import sys, os, ctypes as C, time, argparse
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); os.chdir(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -26,7 +32,7 @@ from tests.test_wide_bvh import WIDE, wide_of
 from tests.test_adaptive_fold import as_probe, same_hits
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--kernel", action="store_true"); ap.add_argument("--views", action="store_true")
+ap.add_argument("--kernel", action="store_true"); ap.add_argument("--views", action="store_true"); ap.add_argument("--tree", action="store_true")
 args = ap.parse_args()
 scene = host.Scene(arrays=S.city_block(int(os.environ.get("NT", "2800000")))); scene.add_directional_light((-0.6, -1.5, 3.5), (15, 10, 5))
 scene.set_env_path("assets/ibl/CGSkies_0036_free.hdr"); scene.build_bvh(); scene.finalize()
@@ -81,6 +87,30 @@ if args.kernel:
     for k, v in V.items():
         r = float(v[0])
         print("%-32s rays %9d  wide visits %.3f  leaf arrivals %.3f  triangle tests %.3f  steps %.3f  slots passed %.3f" % (k, v[0], v[1] / r, v[2] / r, v[4] / r, (v[1] + v[4]) / r, v[9] / r), flush=True)
+    sys.exit(0)
+
+if args.tree:
+    from tests.test_own_tree import own_tree
+    ld = np.array([-0.6, -1.5, 3.5]); ld /= np.linalg.norm(ld)
+    _, qp = queues(T.default_camera(240, 135), 240, 135)
+    _, _, so, sd = probe_arrays(qp)
+    print("shadow probe rays", len(so), flush=True)
+    trees = {"reference topology": nodes, "the backend's own tree (production)": own_tree(nodes, 0.5, [ld])}
+    for base in list(trees):
+        for moves, mg in ((1, 0.0), (3, 0.0), (3, 0.03), (3, 0.1)):
+            t0 = time.time(); rot, crossings, made = capi.rotate_tree(trees[base], so, sd, 8, moves, mg)
+            print("%s, moves %d, min gain %.2f: %d rotations in %.1f s, interior boxes crossed per probe ray %.2f -> %.2f" % (base, moves, mg, made, time.time() - t0, crossings[0], crossings[1]), flush=True)
+            trees[base + " + rotations (moves %d, min gain %.2f)" % (moves, mg)] = rot
+    orc, q = queues(T.default_camera(400, 225), 400, 225)
+    for name, tree in trees.items():
+        rec, entry, roots, cost, adopted = capi.adapt_fold(tree, so, sd)
+        wide = rec.view(WIDE).reshape(-1)
+        V = np.zeros(10, np.uint64)
+        for rays, hits, srays, verdicts in q:
+            assert np.array_equal(orc.wide_trace(wide, entry, srays, True, V, direct=True), verdicts)
+        r = float(V[0])
+        print("%-72s adapted fold: box passes at record roots per probe ray %.2f -> %.2f | unseen shadow rays: wide visits %.3f leaf arrivals %.3f triangle tests %.3f steps %.3f" % (
+            name, cost[0], cost[1], V[1] / r, V[2] / r, V[4] / r, (V[1] + V[4]) / r), flush=True)
     sys.exit(0)
 
 if args.views:
