@@ -432,6 +432,13 @@ int rt_debug_wide_bvh_metric(const rt_bvh_node* nodes, uint32_t num_nodes, doubl
 int rt_debug_adapt_fold(const rt_bvh_node* nodes, uint32_t num_nodes, const float* origins_tmax, const float* directions, uint32_t n_rays,
     void* records, uint32_t* roots, uint32_t capacity, uint32_t* num_records, uint32_t* entry_ref, double* cost2, int* cheaper);
 
+/* The shadow side of an adaptation exactly as the worker thread runs it (host only): `nodes` = the shadow rays' current binary tree under its
+ * surface-area fold, `mode` = RT_CTX_OPT_ADAPTIVE_FOLD's value (bit 3: rotate the tree first, keep whichever fold is cheaper).  Out: the candidate's
+ * records (+ the node each one tests), the tree they fold (out_tree[num_nodes]), cost2 = {current, candidate} box passes at record roots per ray,
+ * *rotations.  Returns 1 = would be adopted, 0 = kept, < 0 = error (rt_last_error(NULL)). */
+int rt_debug_adapt_shadow_side(const rt_bvh_node* nodes, uint32_t num_nodes, const float* origins_tmax, const float* directions, uint32_t n_rays, uint32_t mode,
+    void* records, uint32_t* roots, uint32_t capacity, uint32_t* num_records, uint32_t* entry_ref, rt_bvh_node* out_tree, double* cost2, uint32_t* rotations);
+
 /* RT_CTX_OPT_ADAPTIVE_FOLD bit 3's tree search on its own (host only; raytracing_amd/csrc/tree_rotate.h): the binary tree `nodes` (reference
  * layout) rotated to lower the number of box crossings of the rays given (as rt_debug_adapt_fold takes them) -- out_nodes[num_nodes] holds a binary
  * tree over the same leaves in the same layout; cost2 = crossings of interior boxes per ray before / after; *rotations = how many were made. */

@@ -63,7 +63,7 @@ EXPORTS = [
     "rt_compute_aovs", "rt_denoise", "rt_copy_history",
     "rt_frame_resolve", "rt_frame_present", "rt_frame_present_wait", "rt_frame_read_radiance", "rt_frame_radiance_device_ptr", "rt_frame_sample_count",
     "rt_frame_get_stats", "rt_frame_get_profile", "rt_frame_copy_radiance", "rt_frame_debug_read_queue", "rt_frame_debug_read_hits", "rt_debug_eval",
-    "rt_debug_wide_bvh", "rt_frame_debug_timeline", "rt_debug_own_bvh", "rt_debug_wide_bvh_metric", "rt_scene_tree_report", "rt_debug_choose_tree", "rt_debug_adapt_fold", "rt_debug_rotate_tree", "rt_debug_fold_view_left",
+    "rt_debug_wide_bvh", "rt_frame_debug_timeline", "rt_debug_own_bvh", "rt_debug_wide_bvh_metric", "rt_scene_tree_report", "rt_debug_choose_tree", "rt_debug_adapt_fold", "rt_debug_adapt_shadow_side", "rt_debug_rotate_tree", "rt_debug_fold_view_left",
     "rt_group_create", "rt_group_unique_id", "rt_group_join", "rt_group_size", "rt_group_local_count", "rt_group_local_rank", "rt_group_comm_count",
     "rt_group_gather_radiance", "rt_group_destroy", "rt_group_last_error", "rt_group_denoise", "rt_group_create_local",
     "rt_group_create_unchecked",
@@ -119,6 +119,7 @@ def load():
         "rt_debug_wide_bvh_metric": (i32, [vp, u32, C.c_double, vp, u32, vp, u32, C.POINTER(u32), C.POINTER(u32)]),
         "rt_debug_fold_view_left": (i32, [vp, vp, C.c_double]),
         "rt_debug_rotate_tree": (i32, [vp, u32, vp, vp, u32, i32, vp, C.POINTER(C.c_double), C.POINTER(u32), i32, C.c_double]),
+        "rt_debug_adapt_shadow_side": (i32, [vp, u32, vp, vp, u32, u32, vp, vp, u32, C.POINTER(u32), C.POINTER(u32), vp, C.POINTER(C.c_double), C.POINTER(u32)]),
         "rt_debug_adapt_fold": (i32, [vp, u32, vp, vp, u32, vp, vp, u32, C.POINTER(u32), C.POINTER(u32), C.POINTER(C.c_double), C.POINTER(i32)]),
         "rt_group_create": (i32, [i32, C.POINTER(i32), C.POINTER(vp)]), "rt_group_create_unchecked": (i32, [i32, C.POINTER(i32), C.POINTER(vp)]),
         "rt_group_unique_id": (i32, [vp, sz]),
@@ -181,6 +182,25 @@ def adapt_fold(nodes, origins_tmax, directions):
                                cost, C.byref(cheaper)):
         raise RtError(lib.rt_last_error(None).decode())
     return out[:n.value].copy(), entry.value, roots[:n.value].copy(), (cost[0], cost[1]), bool(cheaper.value)
+
+
+def adapt_shadow_side(nodes, origins_tmax, directions, mode):
+    """rt_debug_adapt_shadow_side (host only): what FoldAdapt's worker does for the shadow rays under RT_CTX_OPT_ADAPTIVE_FOLD = mode.
+    Returns (records uint8[n, 64], entry_ref, roots, the tree the records fold, (current cost, candidate cost), rotations, adopted)."""
+    lib = load()
+    nodes = np.ascontiguousarray(nodes)
+    o = np.ascontiguousarray(origins_tmax, np.float32).reshape(-1, 4)
+    d = np.ascontiguousarray(directions, np.float32).reshape(-1, 4)
+    n, entry, made = C.c_uint32(), C.c_uint32(), C.c_uint32()
+    cost = (C.c_double * 2)()
+    out = np.zeros((len(nodes), 64), np.uint8)
+    roots = np.zeros(len(nodes), np.uint32)
+    tree = np.zeros(len(nodes), nodes.dtype)
+    rc = lib.rt_debug_adapt_shadow_side(nodes.ctypes.data, len(nodes), o.ctypes.data, d.ctypes.data, len(o), mode, out.ctypes.data, roots.ctypes.data, len(out),
+                                        C.byref(n), C.byref(entry), tree.ctypes.data, cost, C.byref(made))
+    if rc < 0:
+        raise RtError(lib.rt_last_error(None).decode())
+    return out[:n.value].copy(), entry.value, roots[:n.value].copy(), tree, (cost[0], cost[1]), made.value, bool(rc)
 
 
 def rotate_tree(nodes, origins_tmax, directions, max_passes=8, moves=3, min_gain=0.03):

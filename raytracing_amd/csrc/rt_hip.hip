@@ -2837,6 +2837,41 @@ int rt_debug_fold_view_left(const rt_camera* adapted, const rt_camera* now, doub
     return fold_view_left(a, *now) ? 1 : 0;
 }
 
+// FoldAdapt's shadow side exactly as the worker runs it (adapt_shadow_side; host only): `nodes` is the shadow rays' current binary tree under its surface-area
+// fold, `mode` RT_CTX_OPT_ADAPTIVE_FOLD's value (bit 3 = rotate first).  Out: the candidate's records, the tree they fold (out_tree[num_nodes]; `nodes`
+// again when nothing was rotated), cost2 = {current, candidate}, *rotations, return value 1 = would be adopted, 0 = kept, < 0 = error.
+int rt_debug_adapt_shadow_side(const rt_bvh_node* nodes, uint32_t num_nodes, const float* origins_tmax, const float* directions, uint32_t n_rays, uint32_t mode,
+    void* records, uint32_t* roots, uint32_t capacity, uint32_t* num_records, uint32_t* entry_ref, rt_bvh_node* out_tree, double* cost2, uint32_t* rotations)
+{
+    if (!nodes || num_nodes == 0 || !origins_tmax || !directions || !num_records || !entry_ref) { fail(nullptr, "rt_debug_adapt_shadow_side: NULL argument"); return -1; }
+    FoldAdapt a;
+    a.mode = mode;
+    a.bvh2.assign(nodes, nodes + num_nodes);
+    std::vector<WideNode> wide;
+    uint32_t entry = 0;
+    if (!build_wide_bvh(nodes, num_nodes, RT_WIDE_SAH, wide, entry, &a.roots) || wide.empty()) { fail(nullptr, "rt_debug_adapt_shadow_side: the tree does not qualify for the 4-wide layout"); return -1; }
+    a.sh_o.resize(n_rays); a.sh_d.resize(n_rays);
+    for (uint32_t i = 0; i < n_rays; ++i)
+    {
+        a.sh_o[i] = make_float4(origins_tmax[4 * i], origins_tmax[4 * i + 1], origins_tmax[4 * i + 2], origins_tmax[4 * i + 3]);
+        a.sh_d[i] = make_float4(directions[4 * i], directions[4 * i + 1], directions[4 * i + 2], 0.0f);
+    }
+    const bool adopted = adapt_shadow_side(&a);
+    if (a.wide_sh.empty()) { fail(nullptr, "rt_debug_adapt_shadow_side: no candidate (no ray passed the root box, or the folds are too deep)"); return -1; }
+    *num_records = (uint32_t)a.wide_sh.size();
+    *entry_ref = a.entry_sh;
+    if (cost2) { cost2[0] = a.cost[1][0]; cost2[1] = a.cost[1][1]; }
+    if (rotations) *rotations = a.rotations;
+    if (records)
+    {
+        if (a.wide_sh.size() > capacity) { fail(nullptr, "rt_debug_adapt_shadow_side: capacity too small"); return -1; }
+        memcpy(records, a.wide_sh.data(), a.wide_sh.size() * sizeof(WideNode));
+        if (roots) memcpy(roots, a.roots_sh_new.data(), a.roots_sh_new.size() * sizeof(uint32_t));
+    }
+    if (out_tree) memcpy(out_tree, a.rotations != 0 ? a.bvh2_sh_new.data() : nodes, (size_t)num_nodes * sizeof(rt_bvh_node));
+    return adopted ? 1 : 0;
+}
+
 // tree_rotate.h on its own (host only): the binary tree `nodes` rotated for the rays given (as rt_debug_adapt_fold takes them); out_nodes[num_nodes]
 int rt_debug_rotate_tree(const rt_bvh_node* nodes, uint32_t num_nodes, const float* origins_tmax, const float* directions, uint32_t n_rays, int max_passes,
     rt_bvh_node* out_nodes, double* cost2, uint32_t* rotations, int moves, double min_gain)

@@ -212,6 +212,32 @@ def test_rotated_shadow_trees_of_random_soups(seed, env_map):
     rotated_and_checked(arrays, 40, 30, 4)
 
 
+def test_the_workers_shadow_side_picks_the_cheaper_candidate(env_map):
+    """adapt_shadow_side (rt_hip.hip) as the worker thread runs it: without bit 3 the fold of the tree as it is; with it the rotated tree's fold
+    when that costs the probe rays less -- and whichever it hands over is a valid fold of the tree it names, with the reference's verdicts."""
+    from tests.test_own_tree import check_own_structure
+    scene = host.Scene(arrays=S.city_block(20000))
+    arrays = _finish(scene, env_map, point=False)
+    nodes = arrays["nodes"]
+    orc, q = queues_of(arrays, 96, 54, 4)
+    so = np.concatenate([as_probe(s[::2])[0] for _, _, s, _ in q]); sdir = np.concatenate([as_probe(s[::2])[1] for _, _, s, _ in q])
+    got = {}
+    for mode in (5, 13):
+        rec, entry, roots, tree, cost, made, adopted = capi.adapt_shadow_side(nodes, so, sdir, mode)
+        wide = rec.view(WIDE).reshape(-1)
+        assert adopted and cost[1] < cost[0]
+        assert (made != 0) == bool(mode & 8)
+        if made:
+            check_own_structure(nodes, tree)
+        else:
+            assert np.array_equal(tree, nodes)
+        check(tree, 1, fold=(wide, entry, roots))
+        for rays, hits, srays, verdicts in q:
+            assert np.array_equal(orc.wide_trace(wide, entry, srays, True, None, direct=True), verdicts)
+        got[mode] = cost
+    assert got[13][0] == got[5][0] and got[13][1] < got[5][1]        # the same current fold; the rotated tree's fold is the cheaper candidate
+
+
 def test_rays_that_pass_nothing_leave_the_fold_alone(golden_scenes):
     arrays = next(iter(golden_scenes.values()))
     o = np.array([[1e6, 1e6, 1e6, 1.0]], np.float32); d = np.array([[1.0, 0.0, 0.0, 0.0]], np.float32)
