@@ -92,9 +92,10 @@ if args.kernel:
 if args.tree:
     from tests.test_own_tree import own_tree
     ld = np.array([-0.6, -1.5, 3.5]); ld /= np.linalg.norm(ld)
-    _, qp = queues(T.default_camera(240, 135), 240, 135)
+    pw, ph = int(os.environ.get("PROBE_W", "240")), int(os.environ.get("PROBE_H", "135"))      # (a larger probe: does the search fit its sample less?)
+    _, qp = queues(T.default_camera(pw, ph), pw, ph)
     _, _, so, sd = probe_arrays(qp)
-    print("shadow probe rays", len(so), flush=True)
+    print("shadow probe rays", len(so), "of a %dx%d probe frame" % (pw, ph), flush=True)
     trees = {"reference topology": nodes, "the backend's own tree (production)": own_tree(nodes, 0.5, [ld])}
     for base in list(trees):
         for moves, mg in ((1, 0.0), (3, 0.0), (3, 0.03), (3, 0.1)):
