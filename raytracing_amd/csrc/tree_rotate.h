@@ -52,9 +52,10 @@ inline bool crosses(const Ray& r, const float* mn, const float* mx)
 inline uint32_t rotate(const rt_bvh_node* nodes, uint32_t nn, const float* origins_tmax, const float* directions, size_t n_rays, int max_passes,
     std::vector<rt_bvh_node>& out, double cost[2], const std::atomic<bool>* cancel = nullptr,
     int moves = 3 /* bit 0: child <-> grandchild, bit 1: grandchild <-> grandchild */,
-    double min_gain = 0.03 /* a move must save more than this share of the crossings of the node it is made at: the probe is a SAMPLE, and a search
-                              that takes every gain fits it -- 0 / 0.03 / 0.1: 5.01 / 4.60 / 4.64 steps per unseen shadow ray on a 300 K-triangle scene,
-                              both move kinds; 11.43 at 0.03 against 11.98 with the first kind alone on the 2.8 M one (tools/fold_weight_study.py --tree) */)
+    double min_gain = 0.03 /* a move must save more than this share of the crossings of the node it is made at: a search that takes every small gain
+                              locks itself in (a probe twice as large changes nothing, so it is the greed, not the sample) -- 0 / 0.03 / 0.1: 5.01 /
+                              4.60 / 4.64 steps per unseen shadow ray on a 300 K-triangle scene with both move kinds; 11.43 at 0.03 against 11.98 with
+                              the first kind alone on the 2.8 M one (tools/fold_weight_study.py --tree) */)
 {
     out.clear();
     cost[0] = cost[1] = 0.0;

@@ -20,8 +20,8 @@ default   folds the reference's BVH2 of the benchmark scene with (a) the surface
           any-hit query the reference's verdict), so it is rotated for the probe rays' measured box crossings (csrc/tree_rotate.h) and then folded.
           Steps per unseen shadow ray (400x225 frame; probe 240x135), verdicts asserted equal to the reference loop's for every tree:
           2.8 M triangles: reference topology 14.84, the backend's own tree 13.16 (production), own + rotations 11.43 (-13 %; child<->grandchild
-          moves alone 11.98); 300 K triangles: 8.81 / 6.51 / 4.60 (-29 %).  A move has to save 3 % of the crossings at its node: taking every gain
-          fits the sample (5.01 instead of 4.60).  Dead ends on the way (a per-leaf mass term in own_bvh.h's greedy cost): DESIGN.md section 8.
+          moves alone 11.98); 300 K triangles: 8.81 / 6.51 / 4.60 (-29 %).  A move has to save 3 % of the crossings at its node: taking every
+          small gain locks the search in (5.01 instead of 4.60; a probe twice as large, PROBE_W / PROBE_H, changes nothing).  Dead ends on the way (a per-leaf mass term in own_bvh.h's greedy cost): DESIGN.md section 8.
 usage: NT=2800000 python tools/fold_weight_study.py [--kernel | --views | --tree]     (logs: profiles/r04_fold_weight_study*.log)"""
 import sys, os, ctypes as C, time, argparse
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); os.chdir(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
