@@ -439,6 +439,12 @@ int rt_debug_adapt_fold(const rt_bvh_node* nodes, uint32_t num_nodes, const floa
 int rt_debug_adapt_shadow_side(const rt_bvh_node* nodes, uint32_t num_nodes, const float* origins_tmax, const float* directions, uint32_t n_rays, uint32_t mode,
     void* records, uint32_t* roots, uint32_t capacity, uint32_t* num_records, uint32_t* entry_ref, rt_bvh_node* out_tree, double* cost2, uint32_t* rotations);
 
+/* What rt_scene_upload / rt_ctx_destroy do to an adaptation in flight (host only): a worker is started on `nodes` and the rays given (used as both
+ * populations) and abandoned after delay_ms.  Returns the milliseconds abandoning took (the worker gives up at its next check), < 0 on an error;
+ * *had_finished = the worker was done already. */
+double rt_debug_fold_abandon(const rt_bvh_node* nodes, uint32_t num_nodes, const float* origins_tmax, const float* directions, uint32_t n_rays, uint32_t mode,
+    uint32_t delay_ms, int* had_finished);
+
 /* RT_CTX_OPT_ADAPTIVE_FOLD bit 3's tree search on its own (host only; raytracing_amd/csrc/tree_rotate.h): the binary tree `nodes` (reference
  * layout) rotated to lower the number of box crossings of the rays given (as rt_debug_adapt_fold takes them) -- out_nodes[num_nodes] holds a binary
  * tree over the same leaves in the same layout; cost2 = crossings of interior boxes per ray before / after; *rotations = how many were made. */

@@ -63,7 +63,7 @@ EXPORTS = [
     "rt_compute_aovs", "rt_denoise", "rt_copy_history",
     "rt_frame_resolve", "rt_frame_present", "rt_frame_present_wait", "rt_frame_read_radiance", "rt_frame_radiance_device_ptr", "rt_frame_sample_count",
     "rt_frame_get_stats", "rt_frame_get_profile", "rt_frame_copy_radiance", "rt_frame_debug_read_queue", "rt_frame_debug_read_hits", "rt_debug_eval",
-    "rt_debug_wide_bvh", "rt_frame_debug_timeline", "rt_debug_own_bvh", "rt_debug_wide_bvh_metric", "rt_scene_tree_report", "rt_debug_choose_tree", "rt_debug_adapt_fold", "rt_debug_adapt_shadow_side", "rt_debug_rotate_tree", "rt_debug_fold_view_left",
+    "rt_debug_wide_bvh", "rt_frame_debug_timeline", "rt_debug_own_bvh", "rt_debug_wide_bvh_metric", "rt_scene_tree_report", "rt_debug_choose_tree", "rt_debug_adapt_fold", "rt_debug_fold_abandon", "rt_debug_adapt_shadow_side", "rt_debug_rotate_tree", "rt_debug_fold_view_left",
     "rt_group_create", "rt_group_unique_id", "rt_group_join", "rt_group_size", "rt_group_local_count", "rt_group_local_rank", "rt_group_comm_count",
     "rt_group_gather_radiance", "rt_group_destroy", "rt_group_last_error", "rt_group_denoise", "rt_group_create_local",
     "rt_group_create_unchecked",
@@ -120,6 +120,7 @@ def load():
         "rt_debug_fold_view_left": (i32, [vp, vp, C.c_double]),
         "rt_debug_rotate_tree": (i32, [vp, u32, vp, vp, u32, i32, vp, C.POINTER(C.c_double), C.POINTER(u32), i32, C.c_double]),
         "rt_debug_adapt_shadow_side": (i32, [vp, u32, vp, vp, u32, u32, vp, vp, u32, C.POINTER(u32), C.POINTER(u32), vp, C.POINTER(C.c_double), C.POINTER(u32)]),
+        "rt_debug_fold_abandon": (C.c_double, [vp, u32, vp, vp, u32, u32, u32, C.POINTER(i32)]),
         "rt_debug_adapt_fold": (i32, [vp, u32, vp, vp, u32, vp, vp, u32, C.POINTER(u32), C.POINTER(u32), C.POINTER(C.c_double), C.POINTER(i32)]),
         "rt_group_create": (i32, [i32, C.POINTER(i32), C.POINTER(vp)]), "rt_group_create_unchecked": (i32, [i32, C.POINTER(i32), C.POINTER(vp)]),
         "rt_group_unique_id": (i32, [vp, sz]),

@@ -2872,6 +2872,34 @@ int rt_debug_adapt_shadow_side(const rt_bvh_node* nodes, uint32_t num_nodes, con
     return adopted ? 1 : 0;
 }
 
+// What rt_scene_upload / rt_ctx_destroy do to an adaptation in flight (host only): a FoldAdapt whose worker has just started on `nodes` and the rays
+// given is dropped after delay_ms; returns the milliseconds the drop took (the worker gives up at its next check), -1 on an argument error.
+double rt_debug_fold_abandon(const rt_bvh_node* nodes, uint32_t num_nodes, const float* origins_tmax, const float* directions, uint32_t n_rays, uint32_t mode,
+    uint32_t delay_ms, int* had_finished)
+{
+    if (!nodes || num_nodes == 0 || !origins_tmax || !directions) { fail(nullptr, "rt_debug_fold_abandon: NULL argument"); return -1.0; }
+    FoldAdapt* a = new FoldAdapt();
+    a->mode = mode;
+    a->bvh2.assign(nodes, nodes + num_nodes);
+    std::vector<WideNode> wide;
+    uint32_t entry = 0;
+    if (!build_wide_bvh(nodes, num_nodes, RT_WIDE_SAH, wide, entry, &a->roots) || wide.empty()) { delete a; fail(nullptr, "rt_debug_fold_abandon: the tree does not qualify"); return -1.0; }
+    a->o.resize(n_rays); a->d.resize(n_rays);
+    for (uint32_t i = 0; i < n_rays; ++i)
+    {
+        a->o[i] = make_float4(origins_tmax[4 * i], origins_tmax[4 * i + 1], origins_tmax[4 * i + 2], origins_tmax[4 * i + 3]);
+        a->d[i] = make_float4(directions[4 * i], directions[4 * i + 1], directions[4 * i + 2], 0.0f);
+    }
+    a->sh_o = a->o; a->sh_d = a->d;
+    a->state = FoldAdapt::COMPUTING;
+    a->worker = std::thread(fold_adapt_worker, a);
+    std::this_thread::sleep_for(std::chrono::milliseconds(delay_ms));
+    if (had_finished) *had_finished = a->finished.load() ? 1 : 0;
+    const auto t0 = std::chrono::steady_clock::now();
+    drop_fold_adapt(a);
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
+
 // tree_rotate.h on its own (host only): the binary tree `nodes` rotated for the rays given (as rt_debug_adapt_fold takes them); out_nodes[num_nodes]
 int rt_debug_rotate_tree(const rt_bvh_node* nodes, uint32_t num_nodes, const float* origins_tmax, const float* directions, uint32_t n_rays, int max_passes,
     rt_bvh_node* out_nodes, double* cost2, uint32_t* rotations, int moves, double min_gain)

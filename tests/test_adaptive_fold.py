@@ -238,6 +238,25 @@ def test_the_workers_shadow_side_picks_the_cheaper_candidate(env_map):
     assert got[13][0] == got[5][0] and got[13][1] < got[5][1]        # the same current fold; the rotated tree's fold is the cheaper candidate
 
 
+def test_an_adaptation_in_flight_is_abandoned_not_waited_for(env_map):
+    """rt_scene_upload / rt_ctx_destroy while the worker thread is counting, rotating or folding: the FoldAdapt is dropped, its worker sees the flag at
+    its next check and the drop returns -- in a small fraction of what the adaptation itself takes, whenever it comes."""
+    import ctypes as C
+    lib = capi.load()
+    scene = host.Scene(arrays=S.city_block(150_000))
+    arrays = _finish(scene, env_map, point=False)
+    nodes = np.ascontiguousarray(arrays["nodes"])
+    orc, q = queues_of(arrays, 160, 90, 4)
+    o = np.concatenate([as_probe(r, hh)[0] for r, hh, _, _ in q]); d = np.concatenate([as_probe(r)[1] for r, _, _, _ in q])
+    o, d = np.ascontiguousarray(o), np.ascontiguousarray(d)
+    done = C.c_int()
+    full = lib.rt_debug_fold_abandon(nodes.ctypes.data, len(nodes), o.ctypes.data, d.ctypes.data, len(o), 13, 4000, C.byref(done))
+    assert full >= 0 and done.value == 1                                # left alone, it finishes (well within 4 s) and the drop is a join of nothing
+    for delay in (0, 3, 15, 60):
+        ms = lib.rt_debug_fold_abandon(nodes.ctypes.data, len(nodes), o.ctypes.data, d.ctypes.data, len(o), 13, delay, C.byref(done))
+        assert 0 <= ms < 2000, (delay, ms)                              # (generous: a loaded CI host; the checks are a few milliseconds apart)
+
+
 def test_rays_that_pass_nothing_leave_the_fold_alone(golden_scenes):
     arrays = next(iter(golden_scenes.values()))
     o = np.array([[1e6, 1e6, 1e6, 1.0]], np.float32); d = np.array([[1.0, 0.0, 0.0, 0.0]], np.float32)
