@@ -87,7 +87,12 @@ enum rt_ctx_option
                                       shadow rays' BINARY tree is first rotated for the probe rays' measured crossings
                                       (tree_rotate.h: - 13 % steps per shadow ray on the headline scene, - 29 % on a 300 K one, on
                                       the CPU walk, out of sample) -- any tree over the reference's leaves gives an any-hit
-                                      query the reference's verdict.  0: off.
+                                      query the reference's verdict.  Bit 4 (opt-in, likewise): the slots of every shadow record are
+                                      stored likeliest occluder first -- k_trace_w4<shadow> looks at them in stored order, an
+                                      any-hit verdict is an OR, an occluded ray stops at its first hit: - 12 % steps per shadow
+                                      ray on the headline scene (a quarter of them occluded), on top of bit 3.  The host finds the
+                                      probe rays' nearest occluders itself and keeps the triangles' positions for that (36 bytes
+                                      each).  0: off.
                                       Takes effect at the next rt_scene_upload; rt_scene_tree_report carries the latest
                                       adaptation's line.  Costs: a host copy of the binary tree(s), 48 bytes per node, for as long
                                       as the scene lives; a 5 ms probe per adaptation; the worker gives up within milliseconds
@@ -437,7 +442,8 @@ int rt_debug_adapt_fold(const rt_bvh_node* nodes, uint32_t num_nodes, const floa
  * records (+ the node each one tests), the tree they fold (out_tree[num_nodes]), cost2 = {current, candidate} box passes at record roots per ray,
  * *rotations.  Returns 1 = would be adopted, 0 = kept, < 0 = error (rt_last_error(NULL)). */
 int rt_debug_adapt_shadow_side(const rt_bvh_node* nodes, uint32_t num_nodes, const float* origins_tmax, const float* directions, uint32_t n_rays, uint32_t mode,
-    void* records, uint32_t* roots, uint32_t capacity, uint32_t* num_records, uint32_t* entry_ref, rt_bvh_node* out_tree, double* cost2, uint32_t* rotations);
+    void* records, uint32_t* roots, uint32_t capacity, uint32_t* num_records, uint32_t* entry_ref, rt_bvh_node* out_tree, double* cost2, uint32_t* rotations,
+    const rt_triangle* triangles /* for mode bit 4 (may be NULL otherwise) */, uint32_t num_triangles, uint32_t* reordered /* records whose slots moved */);
 
 /* What rt_scene_upload / rt_ctx_destroy do to an adaptation in flight (host only): a worker is started on `nodes` and the rays given (used as both
  * populations) and abandoned after delay_ms.  Returns the milliseconds abandoning took (the worker gives up at its next check), < 0 on an error;

@@ -119,7 +119,7 @@ def load():
         "rt_debug_wide_bvh_metric": (i32, [vp, u32, C.c_double, vp, u32, vp, u32, C.POINTER(u32), C.POINTER(u32)]),
         "rt_debug_fold_view_left": (i32, [vp, vp, C.c_double]),
         "rt_debug_rotate_tree": (i32, [vp, u32, vp, vp, u32, i32, vp, C.POINTER(C.c_double), C.POINTER(u32), i32, C.c_double]),
-        "rt_debug_adapt_shadow_side": (i32, [vp, u32, vp, vp, u32, u32, vp, vp, u32, C.POINTER(u32), C.POINTER(u32), vp, C.POINTER(C.c_double), C.POINTER(u32)]),
+        "rt_debug_adapt_shadow_side": (i32, [vp, u32, vp, vp, u32, u32, vp, vp, u32, C.POINTER(u32), C.POINTER(u32), vp, C.POINTER(C.c_double), C.POINTER(u32), vp, u32, C.POINTER(u32)]),
         "rt_debug_fold_abandon": (C.c_double, [vp, u32, vp, vp, u32, u32, u32, C.POINTER(i32)]),
         "rt_debug_adapt_fold": (i32, [vp, u32, vp, vp, u32, vp, vp, u32, C.POINTER(u32), C.POINTER(u32), C.POINTER(C.c_double), C.POINTER(i32)]),
         "rt_group_create": (i32, [i32, C.POINTER(i32), C.POINTER(vp)]), "rt_group_create_unchecked": (i32, [i32, C.POINTER(i32), C.POINTER(vp)]),
@@ -185,23 +185,26 @@ def adapt_fold(nodes, origins_tmax, directions):
     return out[:n.value].copy(), entry.value, roots[:n.value].copy(), (cost[0], cost[1]), bool(cheaper.value)
 
 
-def adapt_shadow_side(nodes, origins_tmax, directions, mode):
-    """rt_debug_adapt_shadow_side (host only): what FoldAdapt's worker does for the shadow rays under RT_CTX_OPT_ADAPTIVE_FOLD = mode.
-    Returns (records uint8[n, 64], entry_ref, roots, the tree the records fold, (current cost, candidate cost), rotations, adopted)."""
+def adapt_shadow_side(nodes, origins_tmax, directions, mode, triangles=None):
+    """rt_debug_adapt_shadow_side (host only): what FoldAdapt's worker does for the shadow rays under RT_CTX_OPT_ADAPTIVE_FOLD = mode
+    (triangles: the scene's rt_triangle array, needed for bit 4).
+    Returns (records uint8[n, 64], entry_ref, roots, the tree the records fold, (current cost, candidate cost), rotations, adopted, records reordered)."""
     lib = load()
     nodes = np.ascontiguousarray(nodes)
     o = np.ascontiguousarray(origins_tmax, np.float32).reshape(-1, 4)
     d = np.ascontiguousarray(directions, np.float32).reshape(-1, 4)
-    n, entry, made = C.c_uint32(), C.c_uint32(), C.c_uint32()
+    tris = np.ascontiguousarray(triangles) if triangles is not None else None
+    n, entry, made, moved = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
     cost = (C.c_double * 2)()
     out = np.zeros((len(nodes), 64), np.uint8)
     roots = np.zeros(len(nodes), np.uint32)
     tree = np.zeros(len(nodes), nodes.dtype)
     rc = lib.rt_debug_adapt_shadow_side(nodes.ctypes.data, len(nodes), o.ctypes.data, d.ctypes.data, len(o), mode, out.ctypes.data, roots.ctypes.data, len(out),
-                                        C.byref(n), C.byref(entry), tree.ctypes.data, cost, C.byref(made))
+                                        C.byref(n), C.byref(entry), tree.ctypes.data, cost, C.byref(made),
+                                        tris.ctypes.data if tris is not None else None, len(tris) if tris is not None else 0, C.byref(moved))
     if rc < 0:
         raise RtError(lib.rt_last_error(None).decode())
-    return out[:n.value].copy(), entry.value, roots[:n.value].copy(), tree, (cost[0], cost[1]), made.value, bool(rc)
+    return out[:n.value].copy(), entry.value, roots[:n.value].copy(), tree, (cost[0], cost[1]), made.value, bool(rc), moved.value
 
 
 def rotate_tree(nodes, origins_tmax, directions, max_passes=8, moves=3, min_gain=0.03):

@@ -348,7 +348,7 @@ int rt_ctx_set_option(rt_ctx* ctx, int option, uint32_t value)
     if (option == RT_CTX_OPT_WIDE_BVH) { ctx->build_wide = value > 2u ? 1u : value; return RT_OK; }
     if (option == RT_CTX_OPT_SHADOW_TREE) { ctx->shadow_tree = value > 3u ? 1u : value; return RT_OK; }
     if (option == RT_CTX_OPT_CLOSEST_TREE) { ctx->closest_tree = value > 2u ? 1u : value; return RT_OK; }
-    if (option == RT_CTX_OPT_ADAPTIVE_FOLD) { ctx->adaptive_fold = value & 15u; return RT_OK; }
+    if (option == RT_CTX_OPT_ADAPTIVE_FOLD) { ctx->adaptive_fold = value & 31u; return RT_OK; }
     return fail(ctx, "rt_ctx_set_option: unknown option");
 }
 
@@ -816,6 +816,8 @@ struct FoldAdapt
     std::vector<rt_bvh_node> bvh2, bvh2_sh;            // the reference's tree; the shadow rays' own binary tree (empty: they walk the reference's)
     std::vector<uint32_t> roots, roots_sh;             // the binary-tree node each record of the CURRENT folds tests
     std::vector<uint32_t> roots_new, roots_sh_new;     // ... of the adapted folds
+    std::vector<float> tri9;                           // mode bit 4: the triangles' corner positions (9 floats each), for the host's occluder search
+    uint32_t reordered = 0;                            // ... shadow records whose slots changed places (0: placed as build_wide_bvh places them)
     std::vector<rt_bvh_node> bvh2_sh_new;              // mode bit 3: the shadow rays' binary tree after tree_rotate.h's rotations (when that is what was folded)
     uint32_t rotations = 0;                            // ... how many (0: the fold is of the tree as it was)
     std::vector<float4> o, d, sh_o, sh_d;              // the probe's rays (o.w = t_max: the hit distance where there was one)
@@ -905,10 +907,142 @@ bool refold_for_rays(const std::vector<rt_bvh_node>& tree, const std::vector<flo
     return cost[1] < cost[0];
 }
 
+// Mode bit 4: the ORDER in which a shadow ray looks at the slots of a record is free -- its verdict is an OR over the leaves it reaches -- and
+// k_trace_w4<shadow> takes them as they are stored (the exchange network is the closest-hit rays': trace_kernels.h, w4_test_slots).  An occluded
+// ray stops at its first hit, so each record's slots are stored likeliest occluder first: by how many probe shadow rays had their NEAREST occluder
+// in the slot's subtree.  (tools/fold_weight_study.py --order: - 12 % steps per shadow ray on the headline scene with a quarter of them
+// occluded, - 25 % for the occluded ones.)  The nearest occluder of a probe ray is found here, on the host: a plain closest-hit walk of the
+// reference's binary tree with Moeller-Trumbore in binary32 -- a statistic, not a result.
+void nearest_occluders(const std::vector<rt_bvh_node>& tree, const std::vector<float>& tri9, const std::vector<float4>& o, const std::vector<float4>& d,
+    std::vector<uint32_t>& prim, const std::atomic<bool>& cancel)
+{
+    const size_t n_rays = o.size();
+    const uint32_t nn = (uint32_t)tree.size(), nt = (uint32_t)(tri9.size() / 9);
+    prim.assign(n_rays, RT_INVALID_ID);
+    auto run = [&](size_t r0, size_t r1)
+    {
+        uint32_t stack[128];
+        for (size_t r = r0; r < r1 && !cancel.load(std::memory_order_relaxed); ++r)
+        {
+            const float org[3] = {o[r].x, o[r].y, o[r].z}, dir[3] = {d[r].x, d[r].y, d[r].z}, inv[3] = {1.0f / d[r].x, 1.0f / d[r].y, 1.0f / d[r].z};
+            float t_max = o[r].w;
+            int sp = 0;
+            stack[sp++] = 0;
+            while (sp > 0)
+            {
+                const uint32_t n = stack[--sp];
+                const rt_bvh_node& b = tree[n];
+                const float mn[3] = {b.bounds_min.x, b.bounds_min.y, b.bounds_min.z}, mx[3] = {b.bounds_max.x, b.bounds_max.y, b.bounds_max.z};
+                float t0 = 0.0f, t1 = t_max;
+                for (int a = 0; a < 3; ++a)
+                {
+                    const float ta = (mn[a] - org[a]) * inv[a], tb = (mx[a] - org[a]) * inv[a];
+                    t0 = std::fmax(t0, std::fmin(ta, tb));
+                    t1 = std::fmin(t1, std::fmax(ta, tb));
+                }
+                if (!(t0 <= t1)) continue;
+                const uint32_t count = b.num_primitives_axis >> 16;
+                if (count != 0)
+                {
+                    for (uint32_t k = 0; k < count && b.offset + k < nt; ++k)
+                    {
+                        const float* p = &tri9[(size_t)(b.offset + k) * 9];
+                        const float e1[3] = {p[3] - p[0], p[4] - p[1], p[5] - p[2]}, e2[3] = {p[6] - p[0], p[7] - p[1], p[8] - p[2]};
+                        const float pv[3] = {dir[1] * e2[2] - dir[2] * e2[1], dir[2] * e2[0] - dir[0] * e2[2], dir[0] * e2[1] - dir[1] * e2[0]};
+                        const float det = e1[0] * pv[0] + e1[1] * pv[1] + e1[2] * pv[2];
+                        if (!(std::fabs(det) > 1e-8f)) continue;
+                        const float id = 1.0f / det;
+                        const float tv[3] = {org[0] - p[0], org[1] - p[1], org[2] - p[2]};
+                        const float u = (tv[0] * pv[0] + tv[1] * pv[1] + tv[2] * pv[2]) * id;
+                        if (!(u >= 0.0f && u <= 1.0f)) continue;
+                        const float qv[3] = {tv[1] * e1[2] - tv[2] * e1[1], tv[2] * e1[0] - tv[0] * e1[2], tv[0] * e1[1] - tv[1] * e1[0]};
+                        const float v = (dir[0] * qv[0] + dir[1] * qv[1] + dir[2] * qv[2]) * id;
+                        if (!(v >= 0.0f && u + v <= 1.0f)) continue;
+                        const float t = (e2[0] * qv[0] + e2[1] * qv[1] + e2[2] * qv[2]) * id;
+                        if (t > 0.0f && t < t_max) { t_max = t; prim[r] = b.offset + k; }
+                    }
+                    continue;
+                }
+                if (sp > 125 || b.offset >= nn || n + 1u >= nn) continue;
+                stack[sp++] = b.offset;
+                stack[sp++] = n + 1u;
+            }
+        }
+    };
+    const unsigned n_threads = (unsigned)std::min<size_t>(std::max(1u, std::min(std::thread::hardware_concurrency(), 32u)), n_rays / 2048 + 1);
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < n_threads; ++t) pool.emplace_back(run, n_rays * t / n_threads, n_rays * (t + 1) / n_threads);
+    run(0, n_rays / n_threads);
+    for (auto& th : pool) th.join();
+}
+
+// The slots of every record of `wide` (a fold of `tree`, record w testing node roots[w]) stored by descending count of probe rays whose nearest
+// occluder (prim[]) lies in the slot's subtree; equal counts keep their places.  A pure permutation within each record.  Returns the records changed.
+uint32_t occluder_first(std::vector<WideNode>& wide, const std::vector<uint32_t>& roots, const std::vector<rt_bvh_node>& tree, const std::vector<uint32_t>& prim)
+{
+    const uint32_t nn = (uint32_t)tree.size();
+    if (wide.empty() || roots.size() != wide.size() || nn == 0) return 0;
+    std::vector<uint32_t> parent(nn, RT_EMPTY_REF), hit(nn, 0u);
+    uint32_t max_prim = 0;
+    for (uint32_t i = 0; i < nn; ++i)
+    {
+        const uint32_t count = tree[i].num_primitives_axis >> 16;
+        if (count != 0) { max_prim = std::max(max_prim, tree[i].offset + count); continue; }
+        if (i + 1u < nn) parent[i + 1u] = i;
+        if (tree[i].offset < nn) parent[tree[i].offset] = i;
+    }
+    std::vector<uint32_t> leaf_of(max_prim, RT_EMPTY_REF);                 // primitive -> the leaf node of `tree` that holds it
+    for (uint32_t i = 0; i < nn; ++i)
+    {
+        const uint32_t count = tree[i].num_primitives_axis >> 16;
+        for (uint32_t k = 0; k < count; ++k) leaf_of[tree[i].offset + k] = i;
+    }
+    for (uint32_t p : prim)
+    {
+        if (p >= max_prim) continue;
+        uint32_t guard = 0;
+        for (uint32_t n = leaf_of[p]; n != RT_EMPTY_REF && guard < 256u; n = parent[n], ++guard) ++hit[n];
+    }
+    uint32_t changed = 0;
+    for (size_t w = 0; w < wide.size(); ++w)
+    {
+        WideNode& r = wide[w];
+        uint32_t score[4]; int idx[4] = {0, 1, 2, 3};
+        bool any = false;
+        for (int k = 0; k < 4; ++k)
+        {
+            const uint32_t ref = r.ref[k];
+            uint32_t node = RT_EMPTY_REF;
+            if (ref == RT_EMPTY_REF) { score[k] = 0; continue; }
+            if (ref & RT_LEAF_BIT) { const uint32_t first = ref & ~RT_LEAF_BIT; node = first < max_prim ? leaf_of[first] : RT_EMPTY_REF; }
+            else if (ref < roots.size()) node = roots[ref];
+            score[k] = node < nn ? hit[node] + 1u : 1u;                    // occupied slots before empty ones
+            any = true;
+        }
+        if (!any) continue;
+        std::stable_sort(idx, idx + 4, [&](int x, int y) { return score[x] > score[y]; });
+        if (idx[0] == 0 && idx[1] == 1 && idx[2] == 2 && idx[3] == 3) continue;
+        WideNode q = r;
+        for (int a = 0; a < 3; ++a) { q.lo[a] = 0; q.hi[a] = 0; }
+        for (int k = 0; k < 4; ++k)
+        {
+            q.ref[k] = r.ref[idx[k]];
+            for (int a = 0; a < 3; ++a)
+            {
+                q.lo[a] |= ((r.lo[a] >> (8 * idx[k])) & 0xFFu) << (8 * k);
+                q.hi[a] |= ((r.hi[a] >> (8 * idx[k])) & 0xFFu) << (8 * k);
+            }
+        }
+        r = q;
+        ++changed;
+    }
+    return changed;
+}
+
 // The shadow rays' side of an adaptation.  Their verdict does not depend on the tree above the reference's leaves (own_bvh.h), so with mode bit 3
 // the binary tree itself is first rotated for the probe rays' measured crossings (tree_rotate.h) and then folded; whichever of the two folds --
 // of the tree as it was, of the rotated tree -- costs the probe rays less is the candidate.
-bool adapt_shadow_side(FoldAdapt* a)
+bool adapt_shadow_candidate(FoldAdapt* a)
 {
     const std::vector<rt_bvh_node>& tree = a->bvh2_sh.empty() ? a->bvh2 : a->bvh2_sh;
     const std::vector<uint32_t>& roots = a->roots_sh.empty() ? a->roots : a->roots_sh;
@@ -933,6 +1067,21 @@ bool adapt_shadow_side(FoldAdapt* a)
     a->cost[1][1] = cost[1];
     a->rotations = made;
     return cost[1] < current;
+}
+
+bool adapt_shadow_side(FoldAdapt* a)
+{
+    a->reordered = 0;
+    const bool ok = adapt_shadow_candidate(a);
+    if (ok && (a->mode & 16u) && !a->tri9.empty() && !a->wide_sh.empty() && !a->cancel.load())
+    {
+        // the candidate's slots, likeliest occluder first (mode bit 4)
+        std::vector<uint32_t> prim;
+        nearest_occluders(a->bvh2, a->tri9, a->sh_o, a->sh_d, prim, a->cancel);
+        const std::vector<rt_bvh_node>& tree = a->rotations != 0 ? a->bvh2_sh_new : (a->bvh2_sh.empty() ? a->bvh2 : a->bvh2_sh);
+        if (!a->cancel.load()) a->reordered = occluder_first(a->wide_sh, a->roots_sh_new, tree, prim);
+    }
+    return ok;
 }
 
 void fold_adapt_worker(FoldAdapt* a)
@@ -1169,6 +1318,16 @@ int rt_scene_upload(rt_ctx* ctx, const rt_scene_desc* sd)
         a->bvh2.assign(sd->nodes, sd->nodes + nn);
         a->roots = std::move(wide_roots);
         if (have_sh) { a->bvh2_sh = std::move(own_sh.bvh2); a->roots_sh = std::move(own_sh.roots); }
+        if (a->mode & 16u)
+        {
+            a->tri9.resize((size_t)nt * 9);
+            for (uint32_t i = 0; i < nt; ++i)
+            {
+                const rt_triangle& t = sd->triangles[i];
+                const rt_float3 v[3] = {t.v1.position, t.v2.position, t.v3.position};
+                for (int k = 0; k < 3; ++k) { a->tri9[(size_t)i * 9 + 3 * k] = v[k].x; a->tri9[(size_t)i * 9 + 3 * k + 1] = v[k].y; a->tri9[(size_t)i * 9 + 3 * k + 2] = v[k].z; }
+            }
+        }
         s.adapt = a;
     }
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // host staging vectors die here
@@ -2261,6 +2420,12 @@ static int fold_adopt(rt_ctx* ctx)
             "shadow %.2f -> %.2f (%s); %.2f s on a worker thread\n", a->adaptations, a->o.size(), a->sh_o.size(), a->cost[0][0], a->cost[0][1], a->ok ? "adopted" : "kept",
             a->cost[1][0], a->cost[1][1], a->ok_sh ? "adopted" : "kept", a->seconds);
         s.tree_report += line;
+        if (a->ok_sh && a->reordered != 0)
+        {
+            s.tree_report.pop_back();
+            snprintf(line, sizeof(line), "; %u shadow records' slots stored likeliest occluder first\n", a->reordered);
+            s.tree_report += line;
+        }
         if (a->ok_sh && a->rotations != 0)
         {
             s.tree_report.pop_back();
@@ -2841,11 +3006,21 @@ int rt_debug_fold_view_left(const rt_camera* adapted, const rt_camera* now, doub
 // fold, `mode` RT_CTX_OPT_ADAPTIVE_FOLD's value (bit 3 = rotate first).  Out: the candidate's records, the tree they fold (out_tree[num_nodes]; `nodes`
 // again when nothing was rotated), cost2 = {current, candidate}, *rotations, return value 1 = would be adopted, 0 = kept, < 0 = error.
 int rt_debug_adapt_shadow_side(const rt_bvh_node* nodes, uint32_t num_nodes, const float* origins_tmax, const float* directions, uint32_t n_rays, uint32_t mode,
-    void* records, uint32_t* roots, uint32_t capacity, uint32_t* num_records, uint32_t* entry_ref, rt_bvh_node* out_tree, double* cost2, uint32_t* rotations)
+    void* records, uint32_t* roots, uint32_t capacity, uint32_t* num_records, uint32_t* entry_ref, rt_bvh_node* out_tree, double* cost2, uint32_t* rotations,
+    const rt_triangle* triangles, uint32_t num_triangles, uint32_t* reordered)
 {
     if (!nodes || num_nodes == 0 || !origins_tmax || !directions || !num_records || !entry_ref) { fail(nullptr, "rt_debug_adapt_shadow_side: NULL argument"); return -1; }
     FoldAdapt a;
     a.mode = mode;
+    if (triangles && (mode & 16u))
+    {
+        a.tri9.resize((size_t)num_triangles * 9);
+        for (uint32_t i = 0; i < num_triangles; ++i)
+        {
+            const rt_float3 v[3] = {triangles[i].v1.position, triangles[i].v2.position, triangles[i].v3.position};
+            for (int k = 0; k < 3; ++k) { a.tri9[(size_t)i * 9 + 3 * k] = v[k].x; a.tri9[(size_t)i * 9 + 3 * k + 1] = v[k].y; a.tri9[(size_t)i * 9 + 3 * k + 2] = v[k].z; }
+        }
+    }
     a.bvh2.assign(nodes, nodes + num_nodes);
     std::vector<WideNode> wide;
     uint32_t entry = 0;
@@ -2862,6 +3037,7 @@ int rt_debug_adapt_shadow_side(const rt_bvh_node* nodes, uint32_t num_nodes, con
     *entry_ref = a.entry_sh;
     if (cost2) { cost2[0] = a.cost[1][0]; cost2[1] = a.cost[1][1]; }
     if (rotations) *rotations = a.rotations;
+    if (reordered) *reordered = a.reordered;
     if (records)
     {
         if (a.wide_sh.size() > capacity) { fail(nullptr, "rt_debug_adapt_shadow_side: capacity too small"); return -1; }

@@ -223,9 +223,9 @@ def test_the_workers_shadow_side_picks_the_cheaper_candidate(env_map):
     so = np.concatenate([as_probe(s[::2])[0] for _, _, s, _ in q]); sdir = np.concatenate([as_probe(s[::2])[1] for _, _, s, _ in q])
     got = {}
     for mode in (5, 13):
-        rec, entry, roots, tree, cost, made, adopted = capi.adapt_shadow_side(nodes, so, sdir, mode)
+        rec, entry, roots, tree, cost, made, adopted, moved = capi.adapt_shadow_side(nodes, so, sdir, mode)
         wide = rec.view(WIDE).reshape(-1)
-        assert adopted and cost[1] < cost[0]
+        assert adopted and cost[1] < cost[0] and moved == 0
         assert (made != 0) == bool(mode & 8)
         if made:
             check_own_structure(nodes, tree)
@@ -236,6 +236,43 @@ def test_the_workers_shadow_side_picks_the_cheaper_candidate(env_map):
             assert np.array_equal(orc.wide_trace(wide, entry, srays, True, None, direct=True), verdicts)
         got[mode] = cost
     assert got[13][0] == got[5][0] and got[13][1] < got[5][1]        # the same current fold; the rotated tree's fold is the cheaper candidate
+
+
+def test_occluder_first_slot_order_is_a_permutation_that_changes_no_verdict(env_map):
+    """Bit 4: k_trace_w4<shadow> looks at a record's slots in stored order and an any-hit verdict is an OR, so the worker may store them likeliest
+    occluder first (by the probe rays' nearest occluders, found on the host).  Per record a pure permutation of (ref, box bytes); the walk returns
+    the reference loop's verdict for every ray; occluded rays it has not seen take fewer steps."""
+    scene = host.Scene(arrays=S.city_block(20000))
+    arrays = _finish(scene, env_map, point=False)
+    nodes = arrays["nodes"]
+    orc, q = queues_of(arrays, 96, 54, 4)
+    so = np.concatenate([as_probe(s[::2])[0] for _, _, s, _ in q]); sdir = np.concatenate([as_probe(s[::2])[1] for _, _, s, _ in q])
+
+    def slots(wide):
+        """per record the set of (ref, lo bytes, hi bytes) of its four slots"""
+        lo = np.ascontiguousarray(wide["lo"]).view(np.uint8).reshape(len(wide), 3, 4)
+        hi = np.ascontiguousarray(wide["hi"]).view(np.uint8).reshape(len(wide), 3, 4)
+        return [sorted((int(wide["ref"][w][k]), lo[w, :, k].tobytes(), hi[w, :, k].tobytes()) for k in range(4)) for w in range(len(wide))]
+
+    for base_mode in (5, 13):
+        plain = capi.adapt_shadow_side(nodes, so, sdir, base_mode, arrays["triangles"])
+        first = capi.adapt_shadow_side(nodes, so, sdir, base_mode | 16, arrays["triangles"])
+        w0, w1 = plain[0].view(WIDE).reshape(-1), first[0].view(WIDE).reshape(-1)
+        assert plain[7] == 0 and first[7] > 0 and first[1] == plain[1] and np.array_equal(first[2], plain[2]) and np.array_equal(first[3], plain[3])
+        assert slots(w0) == slots(w1)                                   # the same slots in every record ...
+        assert int((w0["ref"] != w1["ref"]).any(1).sum()) == first[7]   # ... in another order in exactly the records it reports
+        for f in ("origin", "meta"):
+            assert np.array_equal(w0[f], w1[f])
+        steps = {}
+        for name, wide in (("as placed", w0), ("occluder first", w1)):
+            v = np.zeros(10, np.uint64)
+            for rays, hits, srays, verdicts in q:
+                for direct in (False, True):
+                    assert np.array_equal(orc.wide_trace(wide, first[1], srays, True, None, direct=direct), verdicts), (name, direct)
+                unseen = srays[1::2]; occluded = verdicts[1::2] != 0xFFFFFFFF
+                orc.wide_trace(wide, first[1], unseen[occluded], True, v, direct=True)
+            steps[name] = int(v[1] + v[4])
+        assert steps["occluder first"] < 0.97 * steps["as placed"], steps
 
 
 def test_an_adaptation_in_flight_is_abandoned_not_waited_for(env_map):

@@ -193,7 +193,13 @@ def test_mid_sample_reads_on_a_compact_log_allocation(ctx):
     fr.close()
 
 
-@pytest.mark.parametrize("mode,shadow_tree", [(7, 1), (7, 0), (7, 2), (5, 1), (1, 1), (15, 1), (15, 0), (9, 2)])
+# (bit 4 -- shadow records' slots stored likeliest occluder first -- was built after round 4's last GPU second: its host half is covered on the CPU,
+# tests/test_adaptive_fold.py; its two device runs are enabled by RT_TEST_ADAPTIVE_BIT4=1 -- tools/gpu_calls/r05_call01_*.sh sets it -- and join the
+# default list once they have passed on a device)
+_ADAPTIVE_MODES = [(7, 1), (7, 0), (7, 2), (5, 1), (1, 1), (15, 1), (15, 0), (9, 2)] + ([(31, 1), (31, 0)] if os.environ.get("RT_TEST_ADAPTIVE_BIT4") else [])
+
+
+@pytest.mark.parametrize("mode,shadow_tree", _ADAPTIVE_MODES)
 def test_adaptive_fold_is_adopted_and_changes_no_bit(ctx, mode, shadow_tree):
     """RT_CTX_OPT_ADAPTIVE_FOLD (round 4; on by default as mode 1): the first rt_integrate traces a probe frame, a worker thread folds both
     4-wide trees again for the probe rays' measured box passes, and the records are replaced between two rt_integrate calls -- waiting

@@ -22,7 +22,11 @@ default   folds the reference's BVH2 of the benchmark scene with (a) the surface
           2.8 M triangles: reference topology 14.84, the backend's own tree 13.16 (production), own + rotations 11.43 (-13 %; child<->grandchild
           moves alone 11.98); 300 K triangles: 8.81 / 6.51 / 4.60 (-29 %).  A move has to save 3 % of the crossings at its node: taking every
           small gain locks the search in (5.01 instead of 4.60; a probe twice as large, PROBE_W / PROBE_H, changes nothing).  Dead ends on the way (a per-leaf mass term in own_bvh.h's greedy cost): DESIGN.md section 8.
-usage: NT=2800000 python tools/fold_weight_study.py [--kernel | --views | --tree]     (logs: profiles/r04_fold_weight_study*.log)"""
+--order   and the ORDER of a shadow record's slots (bit 4): k_trace_w4<shadow> looks at them as stored and an occluded ray stops at its first hit, so the
+          worker stores them likeliest occluder first (by the probe rays' nearest occluders).  The worker's own code path (rt_debug_adapt_shadow_side)
+          on the backend's own tree, modes fold / + rotations / + occluder-first: 2.8 M triangles, 25 % of the shadow rays occluded: 13.16 / 11.43 /
+          10.05 steps per unseen shadow ray (occluded ones: 21.7 -> 16.2 by the order alone); 300 K triangles, 14 % occluded: 6.51 / 4.60 / 4.30.
+usage: NT=2800000 python tools/fold_weight_study.py [--kernel | --views | --tree | --order]     (logs: profiles/r04_fold_weight_study*.log)"""
 import sys, os, ctypes as C, time, argparse
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); os.chdir(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -32,7 +36,7 @@ from tests.test_wide_bvh import WIDE, wide_of
 from tests.test_adaptive_fold import as_probe, same_hits
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--kernel", action="store_true"); ap.add_argument("--views", action="store_true"); ap.add_argument("--tree", action="store_true")
+ap.add_argument("--kernel", action="store_true"); ap.add_argument("--views", action="store_true"); ap.add_argument("--tree", action="store_true"); ap.add_argument("--order", action="store_true")
 args = ap.parse_args()
 scene = host.Scene(arrays=S.city_block(int(os.environ.get("NT", "2800000")))); scene.add_directional_light((-0.6, -1.5, 3.5), (15, 10, 5))
 scene.set_env_path("assets/ibl/CGSkies_0036_free.hdr"); scene.build_bvh(); scene.finalize()
@@ -112,6 +116,29 @@ if args.tree:
         r = float(V[0])
         print("%-72s adapted fold: box passes at record roots per probe ray %.2f -> %.2f | unseen shadow rays: wide visits %.3f leaf arrivals %.3f triangle tests %.3f steps %.3f" % (
             name, cost[0], cost[1], V[1] / r, V[2] / r, V[4] / r, (V[1] + V[4]) / r), flush=True)
+    sys.exit(0)
+
+if args.order:
+    from tests.test_own_tree import own_tree
+    ld = np.array([-0.6, -1.5, 3.5]); ld /= np.linalg.norm(ld)
+    _, qp = queues(T.default_camera(240, 135), 240, 135)
+    _, _, so, sd = probe_arrays(qp)
+    vp = np.concatenate([v for _, _, _, v in qp])
+    print("shadow probe rays %d, %.1f %% of them occluded" % (len(so), 100.0 * (vp != 0xFFFFFFFF).mean()), flush=True)
+    own = own_tree(nodes, 0.5, [ld])
+    orc, q = queues(T.default_camera(400, 225), 400, 225)
+    for name, mode in (("fold adapted (production default)", 5), ("fold adapted, slots occluder first", 21), ("tree rotated + fold adapted", 13), ("tree rotated + fold adapted, slots occluder first", 29)):
+        t0 = time.time()
+        rec, entry, roots, tree, cost, made, adopted, moved = capi.adapt_shadow_side(own, so, sd, mode, arrays["triangles"])
+        dt = time.time() - t0
+        wide = rec.view(WIDE).reshape(-1)
+        V, Vo = np.zeros(10, np.uint64), np.zeros(10, np.uint64)
+        for rays, hits, srays, verdicts in q:
+            assert np.array_equal(orc.wide_trace(wide, entry, srays, True, V, direct=True), verdicts), name
+            orc.wide_trace(wide, entry, srays[verdicts != 0xFFFFFFFF], True, Vo, direct=True)
+        r, ro = float(V[0]), float(Vo[0])
+        print("%-52s %5.1f s on this host, %5d rotations, %6d records reordered | unseen shadow rays: steps %.3f (wide visits %.3f); the occluded %.0f %% of them: steps %.3f" % (
+            name, dt, made, moved, (V[1] + V[4]) / r, V[1] / r, 100 * ro / r, (Vo[1] + Vo[4]) / ro), flush=True)
     sys.exit(0)
 
 if args.views:

@@ -19,8 +19,9 @@ except Exception as e:
     print("$1: FAILED", e)
 PY
 }
+RT_TEST_ADAPTIVE_BIT4=1 timeout 300 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k adaptive_fold -p no:cacheprovider > $O/pytest_adaptive_fold_all_modes.log 2>&1; el adaptive-fold tests, bit 4 included: $(tail -1 $O/pytest_adaptive_fold_all_modes.log)
 for cfg in 4 2 3 1 5; do
-  for fold in 3 11 0; do      # 3: the adapted fold (default), 11: + the shadow rays' tree rotated first (bit 3, untimed so far), 0: the upload's fold
+  for fold in 3 11 27 0; do   # 3: the adapted fold (default), 11: + the shadow rays' tree rotated first (bit 3), 27: + slots likeliest occluder first (bit 4) -- both untimed so far, 0: the upload's fold
     extra=""; [ $cfg = 1 ] && extra="--steps 64 --warmup 4"; [ $cfg = 5 ] && extra="--cpu-seconds 5"
     python bench.py --config $cfg --adaptive-fold $fold $extra > $O/bench_cfg${cfg}_fold${fold}.json 2>> $O/bench.err; el $(line bench_cfg${cfg}_fold${fold})
   done
