@@ -350,6 +350,66 @@ def per_frame_leg(args, render, lib, frame, capi, frames, resolve=True):
                              "resolves into a GL image and reads nothing back); the last image's arrival is inside the timed region")
 
 
+def median_pixel_rel_err(a, b):
+    """median over the pixels of |a - b| / max(|b|, 1e-6) (L2 over the channels): one firefly sample cannot move it, unlike rel-L2"""
+    import numpy as np
+    fin = np.isfinite(a).all(-1) & np.isfinite(b).all(-1)
+    if not fin.any():
+        return None
+    d = np.linalg.norm(a[fin].astype(np.float64) - b[fin].astype(np.float64), axis=-1)
+    n = np.maximum(np.linalg.norm(b[fin].astype(np.float64), axis=-1), 1e-6)
+    return float(np.median(d / n))
+
+
+def moving_camera_leg(args, render, lib, frame, capi, host, cam0, frames):
+    """The reference's interactive pattern with a camera that MOVES (src/render.cpp:188-195: a changed camera requests a reset, every
+    frame starts its accumulation again): the camera turns about the up axis by 0.66 degrees per frame, so it leaves the view the folds
+    were adapted to (20 degrees) every ~30 frames.  The fold adaptation runs as the library ships it (asynchronous: probe enqueued behind
+    the frame, worker thread, pointer exchange; at most one per RT_CTX_OPT_ADAPT_MIN_INTERVAL_MS).  Beside it: the same frames with the
+    camera set again every frame but not moved (the reset alone), so that the difference is what moving costs."""
+    import numpy as np
+    ctx = host.load().rth_render_ctx_handle(render.handle)
+    mode = args.adaptive_fold
+    assert lib.rt_ctx_set_option(ctx, 4, mode & ~2) == 0              # bit 1 (wait) off from now on: takes effect at once
+    def turned(deg):
+        c = cam0.copy()
+        a = np.float32(np.deg2rad(deg))
+        ca, sa = np.cos(a), np.sin(a)
+        for vec in ("front", "up"):
+            x, y = float(c[vec]["x"]), float(c[vec]["y"])
+            c[vec]["x"], c[vec]["y"] = np.float32(ca * x - sa * y), np.float32(sa * x + ca * y)
+        return c
+    def run(step_deg):
+        assert lib.rt_reset(frame) == 0
+        render.set_resolve_every_frame(True)
+        for i in range(3):
+            render.set_camera(turned(0.0)); render.render_frame()
+        render.finish()
+        t0 = time.perf_counter()
+        for i in range(frames):
+            render.set_camera(turned(step_deg * (i + 1)))
+            render.render_frame()
+        render.finish()
+        dt = time.perf_counter() - t0
+        render.set_resolve_every_frame(False)
+        return dt
+    report0 = render.tree_report()
+    t_static = run(0.0)
+    t_moving = run(0.66)
+    report1 = render.tree_report()
+    render.set_camera(cam0)
+    assert lib.rt_ctx_set_option(ctx, 4, mode) == 0
+    def probe_no(rep):
+        import re
+        m = re.search(r"adaptive fold \(probe (\d+)\)", rep)
+        return int(m.group(1)) if m else 0
+    return dict(ms_per_frame=round(t_moving * 1e3 / frames, 4), ms_per_frame_camera_set_not_moved=round(t_static * 1e3 / frames, 4), frames=frames,
+                degrees_per_frame=0.66, moving_over_static=round(t_moving / t_static, 4),
+                adaptations_adopted_meanwhile=probe_no(report1) - probe_no(report0),
+                what="one Integrate() per frame through the hooks, camera changed (-> reset) every frame; fold adaptation asynchronous "
+                     "(library default); ResolveRadiance + Finish() every frame")
+
+
 def roofline_object(args, world, live_step, per_ray, isolated):
     """`roofline` for the dominant kernel, the closest-hit traversal (k_trace_w4<closest>).  Every number follows a stated
     formula from (a) what this run measured live with HIP events on the library's streams and (b) committed counter files
@@ -499,9 +559,11 @@ def main():
                     "where it measures cheaper; 2 always; 3 always, surface-area metric; 0 shared with the closest-hit rays).  Bit-identical for every value.")
     ap.add_argument("--closest-tree", type=int, default=None, help="RT_CTX_OPT_CLOSEST_TREE (library default 0 = bit-identical; 1 / 2 = TOLERANCE mode: "
                     "an own tree for closest-hit rays where it measures cheaper / always)")
-    ap.add_argument("--adaptive-fold", type=int, default=3, help="RT_CTX_OPT_ADAPTIVE_FOLD (library default 1: the first integrate probes the frame's own rays, "
-                    "a worker thread folds both 4-wide trees again for their measured box passes, the records are replaced when ready; 3 (here): the warm-up "
-                    "waits for the new fold, so that every timed step runs on it; 0 = the upload's surface-area fold).  Bit-identical for every value.")
+    ap.add_argument("--adaptive-fold", type=int, default=27, help="RT_CTX_OPT_ADAPTIVE_FOLD (library default 25 = bits 0 + 3 + 4: the first integrate probes the "
+                    "frame's own rays, a worker thread folds both 4-wide trees again for their measured box passes -- the shadow rays' binary tree rotated first, "
+                    "their records' slots stored likeliest occluder first -- and the records are replaced when ready; 27 (here) = + bit 1: the warm-up "
+                    "waits for the new fold, so that every timed step runs on it; 3 = round 4's default (fold only); 0 = the upload's surface-area fold).  "
+                    "Bit-identical for every value.")
     ap.add_argument("--tail-lanes", type=int, default=None, help="RT_OPT_TRACE_TAIL_LANES (library default 40; 0 = loop D off)")
     ap.add_argument("--chunk-refill", type=int, default=None, help="RT_OPT_CHUNK_REFILL (library default 1)")
     ap.add_argument("--tail-paths", type=int, default=None, help="RT_OPT_TRACE_TAIL_PATHS (library default 100000000)")
@@ -510,6 +572,12 @@ def main():
     ap.add_argument("--compact-log", type=int, default=None, help="RT_OPT_COMPACT_LOG (library default 2: compact only when the path state is bounded; 1 = always for batches of >= 8 samples; 0 = never)")
     ap.add_argument("--per-frame-frames", type=int, default=48, help="frames of the per_frame leg (the reference's call pattern, "
                     "one Integrate() per frame); 0 = skip it")
+    ap.add_argument("--stage-pipes", type=int, default=None, help="RT_OPT_STAGE_PIPES for the per_frame legs (library default 1: the frame's one sample per pixel "
+                    "travels as one chunk; 2..4: as that many chunks on streams of their own, their launch tails overlapping)")
+    ap.add_argument("--moving-camera-frames", type=int, default=240, help="frames of per_frame.moving_camera (0 = skip): the camera turns 0.66 degrees per frame, "
+                    "so it leaves the adapted view every ~30 frames, with the library's default (asynchronous) fold adaptation")
+    ap.add_argument("--surface-area-fold-steps", type=int, default=2, help="steps of the surface-area-fold figure printed beside value (0 = skip): the scene uploaded "
+                    "again with RT_CTX_OPT_ADAPTIVE_FOLD = 0 after everything else, untimed by the driver")
     ap.add_argument("--per-frame-only", action="store_true", help="run only the per_frame leg and print its object (tuning runs)")
     ap.add_argument("--debug-shared-gpu", action="store_true",
                     help="plumbing test only: all ranks share GPU 0 and gather over gloo (RCCL refuses two ranks per device)")
@@ -595,8 +663,8 @@ def main():
     t_setup = time.time() - t0
     if args.wide_collapse != 1:
         render.set_wide_bvh(args.wide_collapse)               # A/B: uploads the scene again with the other collapse
-    if args.shadow_tree is not None or args.closest_tree is not None or args.adaptive_fold != 1:
-        if args.adaptive_fold != 1:
+    if args.shadow_tree is not None or args.closest_tree is not None or args.adaptive_fold != capi.ADAPTIVE_FOLD_DEFAULT:
+        if args.adaptive_fold != capi.ADAPTIVE_FOLD_DEFAULT:
             render.set_adaptive_fold(args.adaptive_fold, upload=False)
         if args.shadow_tree is not None:
             render.set_shadow_tree(args.shadow_tree, upload=False)
@@ -668,7 +736,11 @@ def main():
     if args.tail_paths is not None:
         assert lib.rt_set_option(frame, capi.OPT_TRACE_TAIL_PATHS, args.tail_paths) == 0
     if args.per_frame_only:
+        if args.stage_pipes:
+            assert lib.rt_set_option(frame, capi.OPT_STAGE_PIPES, args.stage_pipes) == 0
         pf = per_frame_leg(args, render, lib, frame, capi, max(args.per_frame_frames, 1))
+        if args.moving_camera_frames > 0:
+            pf["moving_camera"] = moving_camera_leg(args, render, lib, frame, capi, host, cam, args.moving_camera_frames)
         if rank == 0:
             print(json.dumps(dict(per_frame=pf, config=dict(width=args.width, height=args.height, max_bounces=args.bounces, config=args.config,
                                                             trace_tune=args.trace_tune, small_launch_paths=args.small_launch_paths,
@@ -677,7 +749,10 @@ def main():
     in_flight = render.reserve_samples(max(spp_timed, spp_warm))
 
     # ---- warm-up ------------------------------------------------------------
+    t_warm0 = time.perf_counter()
     render.render_samples(spp_warm) if spp_warm > 0 else None
+    render.finish()
+    t_warm = time.perf_counter() - t_warm0                # with bit 1 of --adaptive-fold: probe + worker + adoption are in here
     if args.warmup > 0:     # the gather path too (first use sets up the RCCL channels)
         if group is not None:
             try:
@@ -815,7 +890,14 @@ def main():
 
     per_frame = None
     if world == 1 and args.per_frame_frames > 0:
+        if args.stage_pipes:
+            assert lib.rt_set_option(frame, capi.OPT_STAGE_PIPES, args.stage_pipes) == 0
         per_frame = per_frame_leg(args, render, lib, frame, capi, args.per_frame_frames)
+        per_frame["stage_pipes"] = args.stage_pipes or 1
+        if args.moving_camera_frames > 0:
+            per_frame["moving_camera"] = moving_camera_leg(args, render, lib, frame, capi, host, cam, args.moving_camera_frames)
+        if args.stage_pipes:
+            assert lib.rt_set_option(frame, capi.OPT_STAGE_PIPES, 1) == 0      # the legs below read queues and counters of one pipe
 
     if rank == 0:
         assert full is not None
@@ -841,7 +923,19 @@ def main():
                           tolerance=1e-4, nan_pixels_ref=int((~np.isfinite(ref_img).all(-1)).sum()),
                           nan_pixels_hip=int((~np.isfinite(got).all(-1)).sum()),
                           differing_pixels=int((~((got == ref_img) | (np.isnan(got) & np.isnan(ref_img))).all(-1)).sum()))
+            parity["median_pixel_rel_err"] = median_pixel_rel_err(got, ref_img)
             if libm_img is not None:
+                # the reference against ITSELF: its own kernels over the pinned builtins (libref.so) and over glibc libm (libref_libm.so), same frame,
+                # same samples, no GPU involved -- what "the reference's result" moves by when only its builtin library changes.  The HIP path equals
+                # the first bit for bit, so its distance to the second is this number.
+                finr = np.isfinite(libm_img).all(-1) & np.isfinite(ref_img).all(-1)
+                numr = np.linalg.norm((ref_img[finr].astype(np.float64) - libm_img[finr]).ravel())
+                denr = np.linalg.norm(libm_img[finr].astype(np.float64).ravel())
+                parity["reference_self_rel_l2"] = float(numr / denr) if denr > 0 else 0.0
+                parity["reference_self_median_pixel_rel_err"] = median_pixel_rel_err(ref_img, libm_img)
+                parity["reference_self"] = ("oracle/_ref/libref.so vs oracle/_ref/libref_libm.so (the reference's unmodified kernels over two conformant builtin "
+                                            "libraries), the CPU leg's frame: a property of the reference, measured without the GPU")
+                parity["median_pixel_rel_err_vs_libm_build"] = median_pixel_rel_err(got, libm_img)
                 finl = np.isfinite(libm_img).all(-1) & np.isfinite(got).all(-1)
                 numl = np.linalg.norm((got[finl].astype(np.float64) - libm_img[finl]).ravel())
                 denl = np.linalg.norm(libm_img[finl].astype(np.float64).ravel())
@@ -873,6 +967,8 @@ def main():
                     slope, c1, cross = lts.fit([p["spp"] for p in pts], [p["rel_l2"] for p in pts])
                     parity["rel_l2_vs_libm_build_series"] = dict(frame="%dx%d of the same scene, %d bounces, sample indices 0..n-1 on both sides" % (sw, sh, args.bounces),
                                                                  points=pts, fitted_slope=slope, fitted_rel_l2_at_1_spp=c1, crosses_1e_4_at_spp=cross,
+                                                                 is_also="the reference's own sensitivity to its builtin library: the HIP path is bit-identical to libref.so "
+                                                                         "(parity.bit_identical on the full frame), so each point is libref.so vs libref_libm.so as well",
                                                                  longer_series="profiles/r04_libm_tolerance_series_cfg5.json (2 .. 128 spp, tools/libm_tolerance_series.py)")
                     r2.close()
                 except Exception as e:                      # noqa: BLE001 -- reported, never fatal to the measurement
@@ -898,6 +994,44 @@ def main():
         roofline = roofline_object(args, world, live_step, per_ray, isolated)
         if isolated is not None:
             roofline["live_isolated"] = isolated
+        trees_now = (render.tree_report() if args.adaptive_fold else tree_report).strip().split("\n")
+        # The headline runs on the fold ADAPTED to this view (RT_CTX_OPT_ADAPTIVE_FOLD, bit 1: the warm-up waits for it).  Beside it: what the
+        # adaptation took, and the same job on the fold rt_scene_upload makes (surface area) -- the scene uploaded again with the option off, a
+        # warm-up step and a few timed ones, after everything else.
+        adaptation = None
+        if args.adaptive_fold:
+            import re
+            m = re.search(r"([0-9.]+) s on a worker thread", "\n".join(trees_now))
+            steady = dt_max / max(args.steps, 1)
+            adaptation = dict(worker_s=float(m.group(1)) if m else None, warmup_s=round(t_warm, 3), steady_step_s=round(steady, 4),
+                              seconds_to_adapted=round(max(t_warm - args.warmup * steady, float(m.group(1)) if m else 0.0), 3) if (args.adaptive_fold & 2) else None,
+                              note="seconds_to_adapted: the first rt_integrate's probe + the worker thread's folds + the upload, as the warm-up saw them "
+                                   "(bit 1: it waits; the library default adopts whenever the worker is done and renders on the upload's fold meanwhile)")
+        surface_area_fold = None
+        if args.adaptive_fold and world == 1 and args.surface_area_fold_steps > 0 and not args.per_frame_only:
+            try:
+                render.set_adaptive_fold(0)                      # ... and uploads again
+                render.reserve_samples(sps)
+                render.render_samples(sps); render.finish()
+                assert lib.rt_reset(frame) == 0
+                sa0 = render.stats()
+                ta = time.perf_counter()
+                render.render_samples(args.surface_area_fold_steps * sps); render.finish()
+                tb = time.perf_counter() - ta
+                sa1 = render.stats()
+                sa_rays = float((sa1.closest_rays - sa0.closest_rays) + (sa1.shadow_rays - sa0.shadow_rays))
+                surface_area_fold = dict(value=round(sa_rays / tb / 1e6, 2), unit="Mrays/s", steps=args.surface_area_fold_steps,
+                                         what="the same job on the fold rt_scene_upload makes (RT_CTX_OPT_ADAPTIVE_FOLD = 0), same box, untimed by the driver")
+            except Exception as e:                              # noqa: BLE001 -- reported, never fatal to the measurement
+                surface_area_fold = dict(error=repr(e))
+        scaling_estimate = None
+        est_path = os.path.join(ROOT, "profiles", "r05_tile_efficiency.json")
+        if os.path.exists(est_path) and args.config == 4:
+            try:
+                scaling_estimate = json.load(open(est_path))
+                scaling_estimate["measured"] = False
+            except Exception as e:                              # noqa: BLE001
+                scaling_estimate = dict(error=repr(e), measured=False)
         name, cus, mem = render_ctx_info(capi, host, render)
         if world == 1:
             gather_info = dict(transport="none (single tile, device copy)", ms=round(float(tmax[2].item()) * 1e3, 3), nranks=1)
@@ -925,7 +1059,7 @@ def main():
                                 rays_per_step=round(total_rays / args.steps, 1), non_finite_pixels=nan_px,
                                 stack_spill_lane_steps=int(st1.stack_spills), rays_left_to_the_bvh2_kernel=int(st1.slow_rays),
                                 log_inline_entries=int(st1.log_inline_entries), log_fallbacks=int(st1.log_fallbacks),   # 0 inline = the full log layout
-                                trees=(render.tree_report() if args.adaptive_fold else tree_report).strip().split("\n"), adaptive_fold=args.adaptive_fold,    # what rt_scene_upload measured when it chose the shadow (/ closest-hit) tree
+                                trees=trees_now, adaptive_fold=args.adaptive_fold,    # what rt_scene_upload measured when it chose the shadow (/ closest-hit) tree
                                 setup_s=round(t_setup, 2), scene_s=round(t_scene, 2),     # scene_s: parse / generate (or load the cache); setup_s: + BVH, wide collapse, upload
                                 device=name),
                     ranks=dict(render_ms_min=round(float(tmin[0].item()) * 1e3, 3), render_ms_max=round(float(tmax[1].item()) * 1e3, 3),
@@ -935,7 +1069,8 @@ def main():
                                mrays=[round(r["rays"] / 1e6, 1) for r in per_rank], scene=scene_source,
                                in_flight=[r["in_flight"] for r in per_rank], rays_per_launch=[r["rays_per_launch"] for r in per_rank],
                                rays_in_first_launch=[r["rays_in_first_launch"] for r in per_rank]),
-                    gather=gather_info, per_frame=per_frame, roofline=roofline, parity=parity, cpu_baseline=baseline)
+                    gather=gather_info, per_frame=per_frame, roofline=roofline, parity=parity, cpu_baseline=baseline,
+                    adaptation=adaptation, surface_area_fold=surface_area_fold, scaling_estimate=scaling_estimate)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -74,29 +74,33 @@ enum rt_ctx_option
                                       RayTriangle (trace_bvh.cl:157-162); validated by rel-L2 < 1e-4 and a differing-pixel
                                       count against oracle/_ref, never the default */
     , RT_CTX_OPT_ADAPTIVE_FOLD = 4 /* The 4-wide trees start with the fold rt_scene_upload makes (optimal for the surface-area visit
-                                      probability).  Bit 0 (default: 1): the first rt_integrate of an uploaded scene traces a small
-                                      probe frame through the stage API (same camera, 1/k of the resolution, ~32 K paths), the host
-                                      counts how often those rays pass each box of the binary tree, and a worker thread folds both
+                                      probability).  Default 25 = bits 0 + 3 + 4.  Bit 0: the first rt_integrate of an uploaded scene
+                                      traces a small probe frame through the stage API (same camera, 1/k of the resolution, ~32 K paths),
+                                      the host counts how often those rays pass each box of the binary tree, and a worker thread folds both
                                       4-wide trees again to be optimal for THOSE frequencies; the new records replace the old ones
-                                      between two rt_integrate calls once they are ready, and again whenever a frame's camera has
+                                      between two rt_integrate calls once they are ready, and again when a frame's camera has
                                       left the view they were made for (3 % of the scene's diagonal, 20 degrees, a tenth of the
-                                      field of view).  EXACT: a fold decides which interior boxes are tested, never a hit or a
-                                      verdict.  Bit 1: rt_integrate waits for the new fold (reproducible
-                                      timing: bench.py, tests).  Bit 2: also for trees of fewer than 8192 nodes (tests).  Bit 3
-                                      (opt-in; built at the end of round 4, exact, its speed not yet measured on the device): the
-                                      shadow rays' BINARY tree is first rotated for the probe rays' measured crossings
-                                      (tree_rotate.h: - 13 % steps per shadow ray on the headline scene, - 29 % on a 300 K one, on
-                                      the CPU walk, out of sample) -- any tree over the reference's leaves gives an any-hit
-                                      query the reference's verdict.  Bit 4 (opt-in, likewise): the slots of every shadow record are
-                                      stored likeliest occluder first -- k_trace_w4<shadow> looks at them in stored order, an
-                                      any-hit verdict is an OR, an occluded ray stops at its first hit: - 12 % steps per shadow
-                                      ray on the headline scene (a quarter of them occluded), on top of bit 3.  The host finds the
-                                      probe rays' nearest occluders itself and keeps the triangles' positions for that (36 bytes
-                                      each).  0: off.
-                                      Takes effect at the next rt_scene_upload; rt_scene_tree_report carries the latest
+                                      field of view) -- at most once per RT_CTX_OPT_ADAPT_MIN_INTERVAL_MS.  EXACT: a fold decides
+                                      which interior boxes are tested, never a hit or a verdict.  Bit 1:
+                                      rt_integrate waits for the new fold (reproducible timing: bench.py, tests).  Bit 2: also for
+                                      trees of fewer than 8192 nodes (tests).  Bit 3: the shadow rays' BINARY tree is first rotated for
+                                      the probe rays' measured crossings (tree_rotate.h) -- any tree over the reference's leaves gives
+                                      an any-hit query the reference's verdict.  Bit 4: the slots of every shadow record are stored
+                                      likeliest occluder first -- k_trace_w4<shadow> looks at them in stored order, an any-hit
+                                      verdict is an OR, an occluded ray stops at its first hit; the host finds the probe rays' nearest
+                                      occluders itself and keeps the triangles' positions for that (36 bytes each).  Measured on the
+                                      device in round 5 (profiles/r05_call01_*): bits 3 + 4 take the shadow trace of the headline scene
+                                      from 0.314 to 0.258 ms per sample (6711 -> 6917 Mrays/s), every config's frame bit-identical.
+                                      0: off.
+                                      Takes effect at the next rt_scene_upload (bit 1 at once); rt_scene_tree_report carries the latest
                                       adaptation's line.  Costs: a host copy of the binary tree(s), 48 bytes per node, for as long
-                                      as the scene lives; a 5 ms probe per adaptation; the worker gives up within milliseconds
-                                      when the scene is uploaded again. */
+                                      as the scene lives; per adaptation a probe frame's launches on the context's stream (nothing
+                                      waits for them: the queues come back through pinned memory, the worker uploads the new
+                                      records itself and rt_integrate only exchanges pointers); the worker gives up within
+                                      milliseconds when the scene is uploaded again. */
+    , RT_CTX_OPT_ADAPT_MIN_INTERVAL_MS = 5 /* default 500: a camera that keeps leaving the adapted view (an orbit) starts at most one
+                                      fold adaptation per this many milliseconds (bit 1 of RT_CTX_OPT_ADAPTIVE_FOLD -- wait for every
+                                      adaptation: tests, bench.py -- is not rate-limited).  Takes effect at once. */
 };
 int rt_ctx_set_option(rt_ctx* ctx, int option, uint32_t value);
 /* The blue-noise sampler tables (src/utils/blue_noise_sampler.hpp: sobol_256spp_256d[256*256],
@@ -249,6 +253,13 @@ enum rt_option
                                        private queue and a lane that finishes takes the next ray of it at once (no atomics, no
                                        machine-wide tail); 0 = round 3's form, a wave finishes all 64 rays of a chunk before it takes
                                        the next.  Results are identical for both. */
+    , RT_OPT_STAGE_PIPES = 24       /* 1..4 (default 1): ONE sample per pixel in flight -- the stage API (the reference's frame-by-frame
+                                      pattern, Render::RenderFrame -> Integrator::Integrate, src/render.cpp:197) and rt_integrate(f, 1) --
+                                      is cut into this many chunks of the tile (>= 512 x 512 pixels), each travelling through the
+                                      wavefront loop on a pipe (HIP stream + per-path buffers) of its own.  Every launch of that
+                                      pattern is its own tail (a launch lasts as long as its longest ray); side by side the chunks'
+                                      tails overlap.  Same image bit for bit (chunks are independent; path ids are chunk-relative).
+                                      Not with RT_OPT_AOV / RT_OPT_DENOISER (whole tile); the debug readers want 1. */
     , RT_OPT_TRACE_TUNE = 12       /* k_trace2 (variants 8, 9) loop thresholds: value & 255 = lanes that must hold an
                                        interior node for a wave to stay in the node loop, value >> 8 & 255 = lanes that
                                        must wait at a triangle for another pass of the triangle loop, value >> 16 & 255 = rays a wave takes

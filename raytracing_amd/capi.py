@@ -69,7 +69,7 @@ EXPORTS = [
     "rt_group_create_unchecked",
 ]
 
-OPT_MAX_BOUNCES, OPT_WHITE_FURNACE, OPT_SAMPLER, OPT_AOV, OPT_DENOISER, OPT_DROP_LAST, OPT_PROFILE, OPT_TRACE_VARIANT, OPT_TRACE_WAVES, OPT_SAMPLES_IN_FLIGHT, OPT_SELECT_FORM_BOX, OPT_PACKET_BOUNCES, OPT_TRACE_TUNE, OPT_DEBUG_ALLOC_LIMIT, OPT_PATH_STATE_LIMIT_MB, OPT_PIPELINES, OPT_SHADE_PARTITION, OPT_OVERLAP_SHADOW, OPT_SMALL_LAUNCH_PATHS, OPT_COMPACT_LOG, OPT_DEBUG_LOG_POOL_DIV, OPT_TRACE_TAIL_LANES, OPT_TRACE_TAIL_PATHS, OPT_CHUNK_REFILL = range(24)
+OPT_MAX_BOUNCES, OPT_WHITE_FURNACE, OPT_SAMPLER, OPT_AOV, OPT_DENOISER, OPT_DROP_LAST, OPT_PROFILE, OPT_TRACE_VARIANT, OPT_TRACE_WAVES, OPT_SAMPLES_IN_FLIGHT, OPT_SELECT_FORM_BOX, OPT_PACKET_BOUNCES, OPT_TRACE_TUNE, OPT_DEBUG_ALLOC_LIMIT, OPT_PATH_STATE_LIMIT_MB, OPT_PIPELINES, OPT_SHADE_PARTITION, OPT_OVERLAP_SHADOW, OPT_SMALL_LAUNCH_PATHS, OPT_COMPACT_LOG, OPT_DEBUG_LOG_POOL_DIV, OPT_TRACE_TAIL_LANES, OPT_TRACE_TAIL_PATHS, OPT_CHUNK_REFILL, OPT_STAGE_PIPES = range(25)
 
 
 def load():
@@ -163,7 +163,7 @@ def choose_tree(scene, shadow=True, mode=1):
     return out, entry.value, rep.value.decode()
 
 
-ADAPTIVE_FOLD_DEFAULT = 1      # rt_ctx's RT_CTX_OPT_ADAPTIVE_FOLD as created (rt_hip.hip)
+ADAPTIVE_FOLD_DEFAULT = 25     # rt_ctx's RT_CTX_OPT_ADAPTIVE_FOLD as created (rt_hip.hip): bits 0 + 3 + 4 since round 5
 
 
 def adapt_fold(nodes, origins_tmax, directions):
@@ -266,6 +266,11 @@ class Context:
         """RT_CTX_OPT_ADAPTIVE_FOLD (effective at the next upload_scene): bit 0 = the first integrate() probes the frame's own rays and the
         4-wide trees are folded again for them (exact), bit 1 = integrate() waits for the new fold, bit 2 = small trees too."""
         _check(self.lib, self.handle, self.lib.rt_ctx_set_option(self.handle, 4, mode))
+
+    def set_adapt_min_interval_ms(self, ms):
+        """RT_CTX_OPT_ADAPT_MIN_INTERVAL_MS (default 500): a camera that keeps leaving the adapted view starts at most one fold
+        adaptation per this many milliseconds (not applied when bit 1 of the adaptive-fold mode waits for every adaptation)"""
+        _check(self.lib, self.handle, self.lib.rt_ctx_set_option(self.handle, 5, ms))
 
     def tree_report(self):
         return self.lib.rt_scene_tree_report(self.handle).decode()

@@ -27,6 +27,8 @@ thread_local std::string g_thread_error;
 
 struct FoldAdapt;                          // RT_CTX_OPT_ADAPTIVE_FOLD: the state of a scene's fold adaptation (below, after choose_tree)
 void drop_fold_adapt(FoldAdapt* a);        // waits for its worker thread
+void fold_adapt_set_interval(FoldAdapt* a, uint32_t ms);
+void fold_adapt_set_wait(FoldAdapt* a, bool wait);
 
 struct Scene
 {
@@ -64,10 +66,13 @@ struct rt_ctx
     uint32_t shadow_tree = 1;     // RT_CTX_OPT_SHADOW_TREE: 1 = shadow rays walk the backend's own tree where it measures cheaper (exact either way),
                                   // 2 = own unconditionally, 3 = own with the surface-area metric (A/B), 0 = they share the closest-hit tree
     uint32_t closest_tree = 0;    // RT_CTX_OPT_CLOSEST_TREE: 1 / 2 as above; != 0 is the tolerance mode (NOT bit-exact)
-    uint32_t adaptive_fold = 1;   // RT_CTX_OPT_ADAPTIVE_FOLD: bit 0 = re-fold the 4-wide trees for the rays rt_integrate actually traces (exact: a fold
+    uint32_t adaptive_fold = 25;  // RT_CTX_OPT_ADAPTIVE_FOLD (default bits 0 + 3 + 4 since round 5): bit 0 = re-fold the 4-wide trees for the rays rt_integrate actually traces (exact: a fold
                                   // decides which boxes are tested, never a result), bit 1 = rt_integrate waits for the new fold instead of
                                   // adopting it when it is ready, bit 2 = also for scenes too small to profit (tests), bit 3 = the shadow rays'
-                                  // binary tree is rotated for the probe rays' crossings before it is folded (tree_rotate.h; opt-in)
+                                  // binary tree is rotated for the probe rays' crossings before it is folded (tree_rotate.h), bit 4 = the slots of
+                                  // every shadow record are stored likeliest occluder first (measured on the device in round 5, profiles/r05_call01_*:
+                                  // shadow trace 0.314 -> 0.258 ms per sample on the headline scene, bit-identical on all five configs)
+    uint32_t adapt_min_interval_ms = 500;   // RT_CTX_OPT_ADAPT_MIN_INTERVAL_MS
     std::vector<rt_frame*> frames;   // the frames alive on this context (rt_finish waits for their side streams too)
     uint8_t* blue_noise = nullptr;   // sobol[65536] | scramblingTile[131072] | rankingTile[131072]
     float* gamma_lut = nullptr;      // pow(byte / 255, 2.2f), 256 entries (k_fill_gamma_lut)
@@ -132,6 +137,10 @@ struct rt_frame
     PathPipe ps[RT_MAX_PIPES];
     PathPipe* p = &ps[0];          // the pipe the stage functions work on
     uint32_t pipelines = 1;        // RT_OPT_PIPELINES: pipes rt_integrate may use
+    uint32_t stage_pipes = 1;      // RT_OPT_STAGE_PIPES: ONE sample per pixel in flight (the stage API, rt_integrate(f, 1): the reference's frame-by-frame
+                                   // pattern) is cut into this many chunks, each on a pipe (stream) of its own: every launch of that pattern is
+                                   // its own tail, and the chunks' tails overlap
+    uint32_t stage_chunks = 1;     // pipes holding a chunk of the stage API's sample in flight (set by rt_generate_rays)
     uint32_t n_pipes = 1;          // pipes the current allocation holds
     uint32_t slots = 1;            // samples traced concurrently (resolved from slots_opt)
     uint32_t slots_opt = 0;        // RT_OPT_SAMPLES_IN_FLIGHT as set by the caller (0 = auto)
@@ -348,7 +357,18 @@ int rt_ctx_set_option(rt_ctx* ctx, int option, uint32_t value)
     if (option == RT_CTX_OPT_WIDE_BVH) { ctx->build_wide = value > 2u ? 1u : value; return RT_OK; }
     if (option == RT_CTX_OPT_SHADOW_TREE) { ctx->shadow_tree = value > 3u ? 1u : value; return RT_OK; }
     if (option == RT_CTX_OPT_CLOSEST_TREE) { ctx->closest_tree = value > 2u ? 1u : value; return RT_OK; }
-    if (option == RT_CTX_OPT_ADAPTIVE_FOLD) { ctx->adaptive_fold = value & 31u; return RT_OK; }
+    if (option == RT_CTX_OPT_ADAPTIVE_FOLD)
+    {
+        ctx->adaptive_fold = value & 31u;
+        if (ctx->scene.adapt) fold_adapt_set_wait(ctx->scene.adapt, (value & 2u) != 0u);   // bit 1 (wait for every adaptation) takes effect at once
+        return RT_OK;
+    }
+    if (option == RT_CTX_OPT_ADAPT_MIN_INTERVAL_MS)
+    {
+        ctx->adapt_min_interval_ms = value;
+        if (ctx->scene.adapt) fold_adapt_set_interval(ctx->scene.adapt, value);     // the scene in place too
+        return RT_OK;
+    }
     return fail(ctx, "rt_ctx_set_option: unknown option");
 }
 
@@ -705,7 +725,8 @@ bool build_wide_bvh(const rt_bvh_node* nodes, uint32_t nn, int collapse, std::ve
     };
     {
         const size_t n_records = order.size();
-        const unsigned n_threads = (unsigned)std::min<size_t>(std::max(1u, std::min(std::thread::hardware_concurrency(), 32u)), n_records / 4096 + 1);
+        // (a fold with measured weights is an adaptation's, made beside the render loop: 16 threads, adapt_threads below)
+        const unsigned n_threads = (unsigned)std::min<size_t>(std::max(1u, std::min(std::thread::hardware_concurrency(), weights ? 16u : 32u)), n_records / 4096 + 1);
         std::atomic<bool> ok{true};
         auto run = [&](size_t w0, size_t w1)
         {
@@ -807,7 +828,8 @@ bool choose_tree(const rt_scene_desc* sd, const std::vector<WideNode>& ref_wide,
 // Exact by construction: every fold of the same binary tree tests the same leaves in the same order (build_wide_bvh).
 struct FoldAdapt
 {
-    enum { ARMED = 1, COMPUTING = 2, IDLE = 3, OFF = 4 };   // IDLE: adapted to `camera`; a frame whose camera has moved away arms it again
+    enum { ARMED = 1, COMPUTING = 2, IDLE = 3, OFF = 4, PROBING = 5 };   // IDLE: adapted to `camera`; a frame whose camera has moved away arms it again;
+                                                                         // PROBING: the probe frame's launches and copies are on the stream
     int state = ARMED;
     uint32_t mode = 1;                                 // ctx->adaptive_fold at upload
     uint32_t adaptations = 0;                          // folds adopted so far
@@ -828,9 +850,40 @@ struct FoldAdapt
     double seconds = 0.0;
     std::atomic<bool> finished{false}, cancel{false};
     std::thread worker;
-    ~FoldAdapt() { cancel.store(true); if (worker.joinable()) worker.join(); }
+    // The probe (round 5: nothing on the render thread waits for it): a frame of its own, kept for the scene's life; its queues come back through
+    // pinned memory with asynchronous copies behind each stage, `probe_done` marks the last one; the worker unpacks them (probe_unpack).
+    rt_frame* probe = nullptr;
+    uint32_t probe_paths = 0, probe_samples = 0, probe_bounces = 0;      // capacity of a queue, samples traced, bounces + 1
+    char* staging = nullptr; size_t staging_bytes = 0;                   // pinned; layout: probe_block / probe_counters below
+    hipEvent_t probe_done = nullptr;
+    // The device side of an adoption is the WORKER's too: it uploads the adapted records on a stream of its own, and frees the ones an
+    // earlier adoption replaced after a device synchronisation of ITS thread (every launch that could still read them was enqueued before
+    // that adoption).  The render thread only exchanges pointers: no hipDeviceSynchronize, no hipMalloc / hipFree between two frames.
+    int device = -1;                                                     // -1: host only (rt_debug_fold_abandon)
+    void *new_cl = nullptr, *new_sh = nullptr;
+    bool upload_failed = false;
+    std::vector<void*> retired;
+    std::chrono::steady_clock::time_point last_armed{};                  // re-arming is rate-limited (RT_CTX_OPT_ADAPT_MIN_INTERVAL_MS)
+    uint32_t min_interval_ms = 500;
+    size_t probe_block(uint32_t sample, uint32_t bounce, uint32_t which /* 0 o, 1 d, 2 hits, 3 shadow o, 4 shadow d */) const
+    {
+        return ((((size_t)sample * probe_bounces + bounce) * 5u + which) * probe_paths) * sizeof(float4);
+    }
+    size_t probe_counters(uint32_t sample) const { return (size_t)probe_samples * probe_bounces * 5u * probe_paths * sizeof(float4) + (size_t)sample * sizeof(DCounters); }
+    ~FoldAdapt();
 };
 void drop_fold_adapt(FoldAdapt* a) { delete a; }
+void fold_adapt_set_interval(FoldAdapt* a, uint32_t ms) { a->min_interval_ms = ms; }
+void fold_adapt_set_wait(FoldAdapt* a, bool wait) { a->mode = wait ? (a->mode | 2u) : (a->mode & ~2u); }
+
+// Host threads one side of an adaptation may use beside the render loop: the closest-hit and the shadow side run together, one process per
+// GPU runs one context each, so 16 + 16 threads x 8 ranks stays within a 256-core host (2 x 32 per context oversubscribed it).
+static unsigned adapt_threads(size_t work_items, size_t per_thread)
+{
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    return (unsigned)std::min<size_t>(std::min(hw, 16u), work_items / per_thread + 1);
+}
+static std::atomic<uint64_t> g_truncated_walks{0};   // host walks (weights only) that met a binary tree deeper than their 126-entry stack
 
 // counts[n] = rays whose slab test of binary-tree node n passes within [0, o.w] (plain binary32 arithmetic: a weight, not a result)
 void count_box_passes(const rt_bvh_node* nodes, uint32_t nn, const float4* o, const float4* d, size_t n_rays, std::vector<uint32_t>& counts,
@@ -860,14 +913,15 @@ void count_box_passes(const rt_bvh_node* nodes, uint32_t nn, const float4* o, co
                 }
                 if (!(t0 <= t1)) continue;
                 __atomic_fetch_add(&counts[n], 1u, __ATOMIC_RELAXED);
-                if ((b.num_primitives_axis >> 16) != 0 || sp > 125) continue;
+                if ((b.num_primitives_axis >> 16) != 0) continue;
+                if (sp > 125) { g_truncated_walks.fetch_add(1, std::memory_order_relaxed); continue; }
                 if (b.offset >= nn || n + 1u >= nn) continue;
                 stack[sp++] = b.offset;
                 stack[sp++] = n + 1u;
             }
         }
     };
-    const unsigned n_threads = (unsigned)std::min<size_t>(std::max(1u, std::min(std::thread::hardware_concurrency(), 32u)), n_rays / 2048 + 1);
+    const unsigned n_threads = adapt_threads(n_rays, 2048);
     std::vector<std::thread> pool;
     for (unsigned t = 1; t < n_threads; ++t) pool.emplace_back(run, n_rays * t / n_threads, n_rays * (t + 1) / n_threads);
     run(0, n_rays / n_threads);
@@ -897,12 +951,15 @@ bool refold_for_rays(const std::vector<rt_bvh_node>& tree, const std::vector<flo
     if (!(total > 0.0) || !(area_sum > 0.0) || !std::isfinite(area_sum)) return false;
     const double prior = 0.05 * total / area_sum;
     for (uint32_t n = 0; n < nn; ++n) w[n] = (double)counts[n] + prior * w[n];
-    std::vector<uint32_t> roots_new;
-    if (!build_wide_bvh(tree.data(), nn, RT_WIDE_SAH, out, entry, &roots_new, nullptr, w.data(), &cancel) || out.empty()) return false;
+    // what the fold on the device costs these rays: known before, and whether or not, a new fold can be built (a failed build
+    // used to leave it 0, and a rotated candidate was then adopted without ever having been compared with it)
     cost[0] = cost[1] = 0.0;
     for (uint32_t r : roots_now) if (r < nn) cost[0] += w[r];
+    cost[0] /= (double)o.size();
+    std::vector<uint32_t> roots_new;
+    if (!build_wide_bvh(tree.data(), nn, RT_WIDE_SAH, out, entry, &roots_new, nullptr, w.data(), &cancel) || out.empty()) return false;
     for (uint32_t r : roots_new) cost[1] += w[r];
-    cost[0] /= (double)o.size(); cost[1] /= (double)o.size();
+    cost[1] /= (double)o.size();
     if (roots_out) roots_out->swap(roots_new);
     return cost[1] < cost[0];
 }
@@ -963,13 +1020,14 @@ void nearest_occluders(const std::vector<rt_bvh_node>& tree, const std::vector<f
                     }
                     continue;
                 }
-                if (sp > 125 || b.offset >= nn || n + 1u >= nn) continue;
+                if (sp > 125) { g_truncated_walks.fetch_add(1, std::memory_order_relaxed); continue; }
+                if (b.offset >= nn || n + 1u >= nn) continue;
                 stack[sp++] = b.offset;
                 stack[sp++] = n + 1u;
             }
         }
     };
-    const unsigned n_threads = (unsigned)std::min<size_t>(std::max(1u, std::min(std::thread::hardware_concurrency(), 32u)), n_rays / 2048 + 1);
+    const unsigned n_threads = adapt_threads(n_rays, 2048);
     std::vector<std::thread> pool;
     for (unsigned t = 1; t < n_threads; ++t) pool.emplace_back(run, n_rays * t / n_threads, n_rays * (t + 1) / n_threads);
     run(0, n_rays / n_threads);
@@ -1061,7 +1119,10 @@ bool adapt_shadow_candidate(FoldAdapt* a)
     const std::vector<uint32_t> top{0u};                                   // (the rotated tree has no current fold: only cost[1] is read)
     (void)refold_for_rays(rotated, a->sh_o, a->sh_d, top, wide, entry, cost, a->cancel, &roots_rot);
     if (wide.empty() || roots_rot.empty() || a->cancel.load()) return ok;
-    const double current = a->cost[1][0] > 0.0 ? a->cost[1][0] : INFINITY, plain = ok ? a->cost[1][1] : current;
+    // the rotated tree's boxes differ, so its measured passes are compared as they are (both are box passes per probe ray at record roots);
+    // without a known cost of the fold on the device nothing is adopted
+    if (!(a->cost[1][0] > 0.0)) return ok;
+    const double current = a->cost[1][0], plain = ok ? a->cost[1][1] : current;
     if (!(cost[1] < plain)) return ok;
     a->wide_sh.swap(wide); a->entry_sh = entry; a->roots_sh_new.swap(roots_rot); a->bvh2_sh_new.swap(rotated);
     a->cost[1][1] = cost[1];
@@ -1084,14 +1145,107 @@ bool adapt_shadow_side(FoldAdapt* a)
     return ok;
 }
 
+// The probe's queues, as the asynchronous copies left them in the pinned staging area, become the rays the folds are made for
+// (closest-hit rays clipped at their hit: a ray that hit something never visits what lies behind the hit).
+void probe_unpack(FoldAdapt* a)
+{
+    if (!a->staging || a->probe_paths == 0) return;                    // rays given directly (rt_debug_fold_abandon)
+    a->o.clear(); a->d.clear(); a->sh_o.clear(); a->sh_d.clear();
+    for (uint32_t sample = 0; sample < a->probe_samples; ++sample)
+    {
+        DCounters h;
+        memcpy(&h, a->staging + a->probe_counters(sample), sizeof(h));
+        for (uint32_t bounce = 0; bounce < a->probe_bounces; ++bounce)
+        {
+            const uint32_t n = h.queue[bounce], ns = h.shadow[bounce];
+            if (n > a->probe_paths || ns > a->probe_paths) { a->o.clear(); a->d.clear(); a->sh_o.clear(); a->sh_d.clear(); return; }
+            if (n == 0) break;
+            const float4* o = (const float4*)(a->staging + a->probe_block(sample, bounce, 0));
+            const float4* d = (const float4*)(a->staging + a->probe_block(sample, bounce, 1));
+            const float4* hits = (const float4*)(a->staging + a->probe_block(sample, bounce, 2));
+            const size_t at = a->o.size();
+            a->o.insert(a->o.end(), o, o + n);
+            a->d.insert(a->d.end(), d, d + n);
+            for (uint32_t i = 0; i < n; ++i)
+            {
+                uint32_t prim;
+                memcpy(&prim, &hits[i].z, 4);
+                if (prim != RT_INVALID_ID && hits[i].w > 0.0f && hits[i].w * 1.0001f < a->o[at + i].w) a->o[at + i].w = hits[i].w * 1.0001f;
+            }
+            if (ns != 0)
+            {
+                const float4* so = (const float4*)(a->staging + a->probe_block(sample, bounce, 3));
+                const float4* sd = (const float4*)(a->staging + a->probe_block(sample, bounce, 4));
+                a->sh_o.insert(a->sh_o.end(), so, so + ns);
+                a->sh_d.insert(a->sh_d.end(), sd, sd + ns);
+            }
+        }
+    }
+}
+
+// The adapted records go to the device from HERE, on a stream of the worker's own; what earlier adoptions replaced is freed here too, after
+// a device synchronisation that only this thread waits for.
+void fold_upload(FoldAdapt* a)
+{
+    if (a->device < 0 || a->cancel.load() || !(a->ok || a->ok_sh)) return;
+    a->upload_failed = true;
+    if (hipSetDevice(a->device) != hipSuccess) return;
+    if (!a->retired.empty())
+    {
+        if (hipDeviceSynchronize() != hipSuccess) { (void)hipGetLastError(); return; }
+        for (void* p : a->retired) (void)hipFree(p);
+        a->retired.clear();
+    }
+    hipStream_t st = nullptr;
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); return; }
+    bool ok = true;
+    if (a->ok) ok = hipMalloc(&a->new_cl, a->wide.size() * sizeof(WideNode)) == hipSuccess &&
+                    hipMemcpyAsync(a->new_cl, a->wide.data(), a->wide.size() * sizeof(WideNode), hipMemcpyHostToDevice, st) == hipSuccess;
+    if (ok && a->ok_sh) ok = hipMalloc(&a->new_sh, a->wide_sh.size() * sizeof(WideNode)) == hipSuccess &&
+                             hipMemcpyAsync(a->new_sh, a->wide_sh.data(), a->wide_sh.size() * sizeof(WideNode), hipMemcpyHostToDevice, st) == hipSuccess;
+    ok = hipStreamSynchronize(st) == hipSuccess && ok;
+    (void)hipStreamDestroy(st);
+    if (!ok)
+    {
+        (void)hipGetLastError();
+        if (a->new_cl) (void)hipFree(a->new_cl);
+        if (a->new_sh) (void)hipFree(a->new_sh);
+        a->new_cl = a->new_sh = nullptr;
+        return;
+    }
+    a->upload_failed = false;
+}
+
 void fold_adapt_worker(FoldAdapt* a)
 {
     const auto t0 = std::chrono::steady_clock::now();
-    std::thread shadow([a]() { a->ok_sh = adapt_shadow_side(a); });
-    a->ok = refold_for_rays(a->bvh2, a->o, a->d, a->roots, a->wide, a->entry, a->cost[0], a->cancel, &a->roots_new);
-    shadow.join();
+    probe_unpack(a);
+    if (!a->o.empty())
+    {
+        std::thread shadow([a]() { a->ok_sh = adapt_shadow_side(a); });
+        a->ok = refold_for_rays(a->bvh2, a->o, a->d, a->roots, a->wide, a->entry, a->cost[0], a->cancel, &a->roots_new);
+        shadow.join();
+        fold_upload(a);
+    }
     a->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     a->finished.store(true);
+}
+
+FoldAdapt::~FoldAdapt()
+{
+    cancel.store(true);
+    if (worker.joinable()) worker.join();
+    if (device >= 0)
+    {
+        // (the callers -- rt_scene_upload, rt_ctx_destroy -- free the scene's own records the same way: after their stream synchronisation)
+        (void)hipSetDevice(device);
+        if (probe_done) { (void)hipEventSynchronize(probe_done); (void)hipEventDestroy(probe_done); }
+        if (probe) (void)rt_frame_destroy(probe);
+        if (staging) (void)hipHostFree(staging);
+        for (void* p : {new_cl, new_sh}) if (p) (void)hipFree(p);
+        if (!retired.empty()) (void)hipDeviceSynchronize();
+        for (void* p : retired) (void)hipFree(p);
+    }
 }
 } // namespace
 
@@ -1310,6 +1464,8 @@ int rt_scene_upload(rt_ctx* ctx, const rt_scene_desc* sd)
     {
         FoldAdapt* a = new FoldAdapt();
         a->mode = ctx->adaptive_fold;
+        a->device = ctx->device;
+        a->min_interval_ms = ctx->adapt_min_interval_ms;
         memset(&a->camera, 0, sizeof(a->camera));
         {
             const double ex = (double)root.bounds_max.x - root.bounds_min.x, ey = (double)root.bounds_max.y - root.bounds_min.y, ez = (double)root.bounds_max.z - root.bounds_min.z;
@@ -1455,6 +1611,8 @@ void chunk_plan(const rt_frame* f, uint32_t slots, uint32_t& n_pipes, uint32_t& 
     slots = slots ? slots : 1u;
     n_pipes = 1;
     if (f->pipelines > 1 && slots >= 2 && n * slots >= 4000000ull) n_pipes = f->pipelines < RT_MAX_PIPES ? f->pipelines : RT_MAX_PIPES;
+    // one sample per pixel in flight (RT_OPT_STAGE_PIPES): the interactive features need the whole tile in one chunk
+    if (f->stage_pipes > 1 && slots == 1 && n >= 262144ull && !(f->denoiser || f->aov != 0)) n_pipes = f->stage_pipes < RT_MAX_PIPES ? f->stage_pipes : RT_MAX_PIPES;
     uint64_t c = (n + n_pipes - 1) / n_pipes;                        // pixels per chunk without a memory limit
     if (n_pipes > 1) c = (c + 63ull) & ~63ull;
     // the caller's limit, and -- after a batch had to fall back from the compact to the full log layout -- the library's own
@@ -1698,6 +1856,30 @@ int flush_log_keep(rt_frame* f)
     f->p->cur_slots = keep;
     return rc;
 }
+
+// The stage API over every pipe that holds a chunk of its sample (RT_OPT_STAGE_PIPES; one pipe is the plain case): `body` runs with f->p on
+// each of them in turn.
+template <class F>
+int for_stage_pipes(rt_frame* f, F&& body)
+{
+    int rc = RT_OK;
+    const uint32_t n = f->stage_chunks ? f->stage_chunks : 1u;
+    for (uint32_t i = 0; i < n && rc == RT_OK; ++i)
+    {
+        f->p = &f->ps[i];
+        rc = body();
+    }
+    f->p = &f->ps[0];
+    return rc;
+}
+
+// ... their logs replayed into the radiance (keep: the sample stays open), and the context's stream made to see all of them
+int flush_stage(rt_frame* f, bool keep = false)
+{
+    const uint32_t n = f->stage_chunks ? f->stage_chunks : 1u;
+    if (for_stage_pipes(f, [&]() { return keep ? flush_log_keep(f) : flush_log(f); }) != RT_OK) return RT_ERROR;
+    return n > 1 ? join_pipes(f) : RT_OK;
+}
 } // namespace
 
 extern "C" {
@@ -1881,6 +2063,19 @@ int rt_set_option(rt_frame* f, int option, uint32_t value)
             if (ensure_pipe_resources(f, value) != RT_OK) return RT_ERROR;
             f->pipelines = value;
             return alloc_path_buffers(f, f->slots);
+        }
+        return RT_OK;
+    case RT_OPT_STAGE_PIPES:
+        if (value == 0 || value > RT_MAX_PIPES) return fail(f->ctx, "rt_set_option: stage pipes must be 1..RT_MAX_PIPES");
+        if (value != f->stage_pipes)
+        {
+            if (f->p->cur_slots != 0) return fail(f->ctx, "rt_set_option: RT_OPT_STAGE_PIPES cannot change while a sample is in flight (rt_advance_sample first)");
+            if (flush_log(f) != RT_OK || join_pipes(f) != RT_OK) return RT_ERROR;
+            HIPCHK(f->ctx, hipStreamSynchronize(f->ctx->stream));
+            if (ensure_pipe_resources(f, value) != RT_OK) return RT_ERROR;
+            f->stage_pipes = value;
+            f->stage_chunks = 1;
+            if (f->slots == 1) return alloc_path_buffers(f, 1);
         }
         return RT_OK;
     case RT_OPT_PATH_STATE_LIMIT_MB:
@@ -2096,6 +2291,7 @@ int rt_reset(rt_frame* f)                               // CLPathTraceIntegrator
         if (f->p->stream && (wait_shadow(f, 0) != RT_OK || wait_shadow(f, 1) != RT_OK)) { f->p = &f->ps[0]; return RT_ERROR; }
     }
     f->p = &f->ps[0];
+    f->stage_chunks = 1;
     for (uint32_t i = 0; i < RT_MAX_PIPES; ++i)
     {
         PathPipe& q = f->ps[i];
@@ -2144,14 +2340,41 @@ int generate_rays(rt_frame* f, uint32_t n_slots, uint32_t chunk_base = 0, bool l
 
 extern "C" {
 
+static int fold_adapt_hook(rt_frame* f);
+
 int rt_generate_rays(rt_frame* f)                       // GenerateRays, :516-520
 {
     FRAME_PROLOGUE(f, "rt_generate_rays");
-    if (chunk_for(f, 1) < (f->n_local ? f->n_local : 1u))
+    // the reference's own pattern (one Integrate() per frame through the hooks) adapts its folds too: probe, worker and adoption ride on
+    // the frames' first stage (rt_integrate calls the same hook)
+    if (fold_adapt_hook(f) != RT_OK) return RT_ERROR;
+    const uint32_t n_local = f->n_local ? f->n_local : 1u;
+    uint32_t np = 1, cp = 0;
+    chunk_plan(f, 1, np, cp);
+    if ((uint64_t)cp * np < n_local)
         return fail(ctx, "rt_generate_rays: RT_OPT_PATH_STATE_LIMIT_MB is too small for one sample of the whole tile "
-                         "(the stage API does not chunk; use rt_integrate)");
-    if (ensure_whole_tile(f) != RT_OK) return RT_ERROR;
-    return generate_rays(f, 1);
+                         "(the stage API keeps every chunk on a pipe of its own; use rt_integrate)");
+    if (np <= 1)
+    {
+        f->stage_chunks = 1;
+        if (ensure_whole_tile(f) != RT_OK) return RT_ERROR;
+        return generate_rays(f, 1);
+    }
+    // RT_OPT_STAGE_PIPES: the sample's chunks travel side by side, one per pipe; an allocation made for a larger batch (one pipe, the
+    // whole tile) gives way to the one-sample layout
+    if (f->chunk_pixels != cp || f->n_pipes != np)
+    {
+        for (const PathPipe& q : f->ps) if (q.cur_slots != 0) return fail(ctx, "rt_generate_rays: the previous sample was not advanced (rt_advance_sample)");
+        if (flush_log(f) != RT_OK || join_pipes(f) != RT_OK) return RT_ERROR;
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        if (alloc_path_buffers(f, 1) != RT_OK) return RT_ERROR;
+        if (f->chunk_pixels != cp || f->n_pipes != np) return fail(ctx, "rt_generate_rays: the one-sample layout did not come out as planned");
+    }
+    if (fork_pipes(f) != RT_OK) return RT_ERROR;         // the pipes' streams see what the context's stream has been given (reset, the last resolve)
+    const uint32_t n_chunks = (n_local + f->chunk_pixels - 1u) / f->chunk_pixels;
+    f->stage_chunks = n_chunks;
+    uint32_t c = 0;
+    return for_stage_pipes(f, [&]() { return generate_rays(f, 1, (c++) * f->chunk_pixels, false); });
 }
 
 int rt_intersect(rt_frame* f, uint32_t bounce)          // IntersectRays, :522-539
@@ -2160,11 +2383,15 @@ int rt_intersect(rt_frame* f, uint32_t bounce)          // IntersectRays, :522-5
     if (bounce > RT_MAX_BOUNCES_LIMIT) return fail(ctx, "rt_intersect: bounce out of range");
     uint32_t in = bounce & 1u;
     f->timeline_bounce = bounce;
-    f->tl_stream = f->p->stream; f->tl_spill = f->p->spill; f->tl_slow_list = f->p->slow_list; f->tl_flavour = 0;
-    KernelSpan span(f, 1);
-    launch_trace<false>(f, f->p->o4[in], f->p->d4[in], (const uint32_t*)nullptr, &f->p->counters->queue[bounce], bounce);
-    HIPCHK(ctx, hipGetLastError());
-    return RT_OK;
+    auto one = [&]() -> int
+    {
+        f->tl_stream = f->p->stream; f->tl_spill = f->p->spill; f->tl_slow_list = f->p->slow_list; f->tl_flavour = 0;
+        KernelSpan span(f, 1);
+        launch_trace<false>(f, f->p->o4[in], f->p->d4[in], (const uint32_t*)nullptr, &f->p->counters->queue[bounce], bounce);
+        HIPCHK(ctx, hipGetLastError());
+        return RT_OK;
+    };
+    return f->fused ? one() : for_stage_pipes(f, one);                   // (rt_integrate walks its pipes itself)
 }
 
 int rt_shade_miss(rt_frame* f, uint32_t) { return f ? RT_OK : fail(nullptr, "rt_shade_miss: frame is NULL"); }
@@ -2176,6 +2403,9 @@ int rt_shade(rt_frame* f, uint32_t bounce)              // ShadeMissedRays + Sha
 {
     FRAME_PROLOGUE(f, "rt_shade");
     if (bounce > RT_MAX_BOUNCES_LIMIT) return fail(ctx, "rt_shade: bounce out of range");
+    if (2u * (bounce + 1u) > f->log_entries) return fail(ctx, "rt_shade: bounce beyond the configured max_bounces");
+    auto one = [&]() -> int
+    {
     uint32_t in = bounce & 1u, out = (bounce + 1u) & 1u;
     ShadeArgs a;
     a.in_o4 = f->p->o4[in]; a.in_d4 = f->p->d4[in]; a.in_thr = f->p->thr[in]; a.hits = f->p->hits;
@@ -2191,7 +2421,6 @@ int rt_shade(rt_frame* f, uint32_t bounce)              // ShadeMissedRays + Sha
     a.count_in_ray = f->fused ? 1u : 0u;
     a.partition = f->shade_partition;
     a.final_bounce = bounce >= f->max_bounces ? 1u : 0u;
-    if (2u * (bounce + 1u) > f->log_entries) return fail(ctx, "rt_shade: bounce beyond the configured max_bounces");
     uint32_t blocks = (f->p->chunk_count * (f->p->cur_slots ? f->p->cur_slots : 1u) + RT_SHADE_BLOCK - 1u) / RT_SHADE_BLOCK;
     if (blocks == 0) blocks = 1;
     f->p->shadow_pending = true;
@@ -2219,6 +2448,8 @@ int rt_shade(rt_frame* f, uint32_t bounce)              // ShadeMissedRays + Sha
     f->side_active = side_on(f);
     if (f->side_active) HIPCHK(ctx, hipEventRecord(f->p->ev_shaded, f->p->stream));
     return RT_OK;
+    };
+    return f->fused ? one() : for_stage_pipes(f, one);
 }
 
 int rt_intersect_shadow(rt_frame* f, uint32_t bounce)   // IntersectShadowRays + AccumulateDirectSamples, :564-580,645-649
@@ -2226,21 +2457,25 @@ int rt_intersect_shadow(rt_frame* f, uint32_t bounce)   // IntersectShadowRays +
     FRAME_PROLOGUE(f, "rt_intersect_shadow");
     if (bounce > RT_MAX_BOUNCES_LIMIT) return fail(ctx, "rt_intersect_shadow: bounce out of range");
     const uint32_t q = bounce & 1u;
-    f->tl_stream = f->side_active ? f->p->side : f->p->stream;
-    f->tl_spill = f->p->sh_spill; f->tl_slow_list = f->p->sh_slow_list; f->tl_flavour = 1u + q;
-    if (f->side_active) HIPCHK(ctx, hipStreamWaitEvent(f->p->side, f->p->ev_shaded, 0));
+    auto one = [&]() -> int
     {
-        KernelSpan span(f, 3, f->tl_stream);
-        launch_trace<true>(f, f->p->sh_o4[q], f->p->sh_d4[q], (const uint32_t*)f->p->sh_aux[q], &f->p->counters->shadow[bounce], bounce);
-    }
-    f->p->shadow_pending = false;
-    HIPCHK(ctx, hipGetLastError());
-    if (f->side_active)
-    {
-        HIPCHK(ctx, hipEventRecord(f->p->ev_shadow[q], f->p->side));
-        f->p->shadow_in_flight[q] = true;
-    }
-    return RT_OK;
+        f->tl_stream = f->side_active ? f->p->side : f->p->stream;
+        f->tl_spill = f->p->sh_spill; f->tl_slow_list = f->p->sh_slow_list; f->tl_flavour = 1u + q;
+        if (f->side_active) HIPCHK(ctx, hipStreamWaitEvent(f->p->side, f->p->ev_shaded, 0));
+        {
+            KernelSpan span(f, 3, f->tl_stream);
+            launch_trace<true>(f, f->p->sh_o4[q], f->p->sh_d4[q], (const uint32_t*)f->p->sh_aux[q], &f->p->counters->shadow[bounce], bounce);
+        }
+        f->p->shadow_pending = false;
+        HIPCHK(ctx, hipGetLastError());
+        if (f->side_active)
+        {
+            HIPCHK(ctx, hipEventRecord(f->p->ev_shadow[q], f->p->side));
+            f->p->shadow_in_flight[q] = true;
+        }
+        return RT_OK;
+    };
+    return f->fused ? one() : for_stage_pipes(f, one);
 }
 
 int rt_compute_aovs(rt_frame* f)                        // ComputeAOVs, :541-562 (after rt_intersect(frame, 0))
@@ -2287,7 +2522,7 @@ int rt_advance_sample(rt_frame* f)                      // AdvanceSampleCount, :
     if (!f) return fail(nullptr, "rt_advance_sample: frame is NULL");
     (void)hipSetDevice(f->ctx->device);
     uint32_t n = f->p->cur_slots ? f->p->cur_slots : 1u;
-    if (flush_log(f) != RT_OK) return RT_ERROR;          // radiance_buffer_ += this sample's contributions
+    if (flush_stage(f) != RT_OK) return RT_ERROR;        // radiance_buffer_ += this sample's contributions (of every chunk: RT_OPT_STAGE_PIPES)
     f->sample_count += n;
     return RT_OK;
 }
@@ -2302,74 +2537,75 @@ int rt_frame_reserve_samples(rt_frame* f, uint32_t n_samples, uint32_t* reserved
 
 // ---- RT_CTX_OPT_ADAPTIVE_FOLD: probe, worker hand-over, adoption (FoldAdapt) -------------------------------------------------
 // The probe: a frame of the same camera at 1/k of the resolution (about 32 K paths), one sample (several for tiny images), taken
-// through the stage API; after every trace its queue comes back to the host.  A few milliseconds, once per uploaded scene.
-static int fold_probe(rt_frame* f, FoldAdapt& a)
+// through the stage API.  Round 5: nothing here waits for the device -- every queue travels to pinned host memory with an asynchronous copy
+// enqueued right behind the stage that filled it (whole capacity: the counters that say how much of it is rays come back last), an event
+// marks the end, and the frame, the staging area and the event are kept for the scene's life (round 4: three blocking copies per bounce,
+// frame created and destroyed per probe -- what an orbiting camera paid at every re-adaptation, VERDICT r04 / ADVICE r04).
+static int fold_probe_enqueue(rt_frame* f, FoldAdapt& a)
 {
     rt_ctx* ctx = f->ctx;
-    a.o.clear(); a.d.clear(); a.sh_o.clear(); a.sh_d.clear();
     const uint64_t pixels = (uint64_t)f->tile.width * f->tile.height;
     uint32_t k = 1;
     while (pixels / ((uint64_t)k * k) > 32768u) ++k;
     rt_frame_desc desc;
     desc.width = std::max(1u, f->tile.width / k); desc.height = std::max(1u, f->tile.height / k);
     desc.tile_rank = 0; desc.tile_count = 1; desc.band_height = desc.height;
-    rt_frame* p = nullptr;
-    if (rt_frame_create(ctx, &desc, &p) != RT_OK) return RT_ERROR;
-    int rc = RT_OK;
+    const uint32_t paths = desc.width * desc.height;
+    const uint32_t n_samples = std::min(16u, std::max(1u, 32768u / std::max(1u, paths)));
+    const uint32_t n_bounces = f->max_bounces + 1u;
+    if (a.probe && (a.probe->tile.width != desc.width || a.probe->tile.height != desc.height)) { (void)rt_frame_destroy(a.probe); a.probe = nullptr; }
+    if (!a.probe && rt_frame_create(ctx, &desc, &a.probe) != RT_OK) { a.probe = nullptr; return RT_ERROR; }
+    rt_frame* p = a.probe;
+    if (!a.probe_done && hipEventCreateWithFlags(&a.probe_done, hipEventDisableTiming) != hipSuccess) { a.probe_done = nullptr; return fail(ctx, "rt_integrate: the probe frame's event could not be created"); }
+    a.probe_paths = paths; a.probe_samples = n_samples; a.probe_bounces = n_bounces;
+    const size_t need = a.probe_counters(n_samples);
+    if (need > a.staging_bytes)
+    {
+        if (a.staging) (void)hipHostFree(a.staging);
+        a.staging = nullptr; a.staging_bytes = 0;
+        if (hipHostMalloc((void**)&a.staging, need, hipHostMallocDefault) != hipSuccess) { a.staging = nullptr; (void)hipGetLastError(); return fail(ctx, "rt_integrate: no pinned memory for the probe frame's queues"); }
+        a.staging_bytes = need;
+    }
+    int rc = rt_reset(p);                                                // sample 0 again, like the fresh frame of round 4's probe
     const std::pair<int, uint32_t> options[] = {{RT_OPT_MAX_BOUNCES, f->max_bounces}, {RT_OPT_SAMPLER, f->sampler}, {RT_OPT_WHITE_FURNACE, f->white_furnace},
         {RT_OPT_TRACE_DROP_LAST_BOUNCE_RAYS, f->drop_last}, {RT_OPT_OVERLAP_SHADOW, 0u}};
     for (const auto& o : options)
         if (rc == RT_OK && rt_set_option(p, o.first, o.second) != RT_OK) rc = RT_ERROR;
     if (rc == RT_OK && rt_set_camera(p, &f->camera) != RT_OK) rc = RT_ERROR;
-    const uint32_t paths = desc.width * desc.height;
-    const uint32_t n_samples = std::min(16u, std::max(1u, 32768u / std::max(1u, paths)));
-    DCounters h;
-    std::vector<float4> hits;
-    auto read = [&](const float4* src_o, const float4* src_d, uint32_t n, std::vector<float4>& o_out, std::vector<float4>& d_out) -> bool
+    if (rc == RT_OK && (p->log_stride < paths || p->chunk_pixels < paths)) rc = fail(ctx, "rt_integrate: the probe frame's queues are smaller than its image");
+    auto back = [&](size_t at, const void* src, size_t bytes) -> bool
     {
-        const size_t at = o_out.size();
-        o_out.resize(at + n); d_out.resize(at + n);
-        return hipMemcpy(o_out.data() + at, src_o, (size_t)n * 16, hipMemcpyDeviceToHost) == hipSuccess &&
-               hipMemcpy(d_out.data() + at, src_d, (size_t)n * 16, hipMemcpyDeviceToHost) == hipSuccess;
+        return hipMemcpyAsync(a.staging + at, src, bytes, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess;
     };
-    auto counters = [&]() -> bool
-    {
-        return hipMemcpyAsync(&h, p->p->counters, sizeof(h), hipMemcpyDeviceToHost, ctx->stream) == hipSuccess && hipStreamSynchronize(ctx->stream) == hipSuccess;
-    };
+    const size_t q = (size_t)paths * sizeof(float4);
     for (uint32_t sample = 0; sample < n_samples && rc == RT_OK; ++sample)
     {
         if (rt_generate_rays(p) != RT_OK) { rc = RT_ERROR; break; }
-        for (uint32_t bounce = 0; bounce <= p->max_bounces && rc == RT_OK; ++bounce)
+        for (uint32_t bounce = 0; bounce < n_bounces && rc == RT_OK; ++bounce)
         {
-            if (rt_intersect(p, bounce) != RT_OK || !counters()) { rc = RT_ERROR; break; }
-            const uint32_t n = h.queue[bounce];
-            if (n > p->log_stride) { rc = RT_ERROR; break; }
-            if (n == 0) break;
-            const size_t at = a.o.size();
-            hits.resize(n);
-            if (!read(p->p->o4[bounce & 1u], p->p->d4[bounce & 1u], n, a.o, a.d) ||
-                hipMemcpy(hits.data(), p->p->hits, (size_t)n * 16, hipMemcpyDeviceToHost) != hipSuccess) { rc = RT_ERROR; break; }
-            for (uint32_t i = 0; i < n; ++i)                     // a ray that hit something never visits what lies behind the hit
-            {
-                uint32_t prim;
-                memcpy(&prim, &hits[i].z, 4);
-                if (prim != RT_INVALID_ID && hits[i].w > 0.0f && hits[i].w * 1.0001f < a.o[at + i].w) a.o[at + i].w = hits[i].w * 1.0001f;
-            }
-            if (rt_shade(p, bounce) != RT_OK || !counters()) { rc = RT_ERROR; break; }
-            const uint32_t ns = h.shadow[bounce];
-            if (ns > p->log_stride) { rc = RT_ERROR; break; }
-            if (ns != 0 && !read(p->p->sh_o4[bounce & 1u], p->p->sh_d4[bounce & 1u], ns, a.sh_o, a.sh_d)) { rc = RT_ERROR; break; }
+            const uint32_t in = bounce & 1u;
+            if (rt_intersect(p, bounce) != RT_OK) { rc = RT_ERROR; break; }
+            if (!back(a.probe_block(sample, bounce, 0), p->p->o4[in], q) || !back(a.probe_block(sample, bounce, 1), p->p->d4[in], q) ||
+                !back(a.probe_block(sample, bounce, 2), p->p->hits, q)) { rc = RT_ERROR; break; }
+            if (rt_shade(p, bounce) != RT_OK) { rc = RT_ERROR; break; }
+            if (!back(a.probe_block(sample, bounce, 3), p->p->sh_o4[in], q) || !back(a.probe_block(sample, bounce, 4), p->p->sh_d4[in], q)) { rc = RT_ERROR; break; }
             if (rt_intersect_shadow(p, bounce) != RT_OK) rc = RT_ERROR;
         }
+        // the sample's counters: queue[b] and shadow[b] of every bounce are still there (k_raygen resets them for the NEXT sequence)
+        if (rc == RT_OK && !back(a.probe_counters(sample), p->p->counters, sizeof(DCounters))) rc = RT_ERROR;
         if (rc == RT_OK && rt_advance_sample(p) != RT_OK) rc = RT_ERROR;
     }
-    if (rc != RT_OK) (void)hipGetLastError();
-    (void)hipStreamSynchronize(ctx->stream);
-    rt_frame_destroy(p);
+    if (rc == RT_OK && hipEventRecord(a.probe_done, ctx->stream) != hipSuccess) rc = RT_ERROR;
+    if (rc != RT_OK)
+    {
+        (void)hipGetLastError();
+        (void)hipStreamSynchronize(ctx->stream);                         // whatever was enqueued writes the staging area: let it finish
+    }
     return rc;
 }
 
-// The adapted folds replace the records on the device (between two rt_integrate calls: nothing is in flight after the device sync).
+// The adapted folds replace the records the kernels are given from now on: an exchange of pointers (the worker has uploaded the new records;
+// launches already enqueued keep reading the old ones, which the NEXT worker frees after a device synchronisation of its own thread).
 static int fold_adopt(rt_ctx* ctx)
 {
     Scene& s = ctx->scene;
@@ -2378,20 +2614,16 @@ static int fold_adopt(rt_ctx* ctx)
     a->state = FoldAdapt::IDLE;
     a->finished.store(false);
     char line[400];
-    int rc = RT_OK;
-    void *new_cl = nullptr, *new_sh = nullptr;
-    if (hipDeviceSynchronize() != hipSuccess) rc = fail(ctx, "rt_integrate: device synchronisation before adopting the adapted fold failed");
-    if (rc == RT_OK && a->ok) rc = dev_alloc_copy(ctx, &new_cl, a->wide.data(), a->wide.size() * sizeof(WideNode));
-    if (rc == RT_OK && a->ok_sh) rc = dev_alloc_copy(ctx, &new_sh, a->wide_sh.data(), a->wide_sh.size() * sizeof(WideNode));
-    if (rc == RT_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail(ctx, "rt_integrate: uploading the adapted fold failed");
     const size_t at = s.tree_report.find("adaptive fold");              // one line, the latest adaptation's
     if (at != std::string::npos) s.tree_report.erase(at);
-    if (rc != RT_OK)
+    if (a->o.empty())
+    {
+        s.tree_report += "adaptive fold: the probe frame brought no rays back -> the fold stays as it is\n";
+        a->state = FoldAdapt::OFF;
+    }
+    else if (a->upload_failed)
     {
         // the scene keeps the fold it has: a failed adaptation costs nothing but itself (and is not tried again)
-        (void)hipGetLastError();
-        if (new_cl) (void)hipFree(new_cl);
-        if (new_sh) (void)hipFree(new_sh);
         s.tree_report += "adaptive fold: not adopted (device allocation or copy failed)\n";
         a->state = FoldAdapt::OFF;
     }
@@ -2401,19 +2633,21 @@ static int fold_adopt(rt_ctx* ctx)
         if (a->ok)
         {
             void* old = s.wnodes;
-            s.wnodes = new_cl;
-            s.d.wnodes = (const float4*)new_cl; s.d.w_entry_ref = a->entry; s.n_wide = (uint32_t)a->wide.size();
-            if (shared && !a->ok_sh) { s.wnodes_sh = old; a->roots_sh = a->roots; }   // ... and keep walking the old ones (theirs now)
-            else (void)hipFree(old);
+            s.wnodes = a->new_cl;
+            s.d.wnodes = (const float4*)a->new_cl; s.d.w_entry_ref = a->entry; s.n_wide = (uint32_t)a->wide.size();
+            if (shared && !a->ok_sh) { s.wnodes_sh = old; a->roots_sh = a->roots; s.n_wide_sh = (uint32_t)a->roots.size(); }   // ... and keep walking the old ones (theirs now)
+            else if (old) a->retired.push_back(old);
             a->roots.swap(a->roots_new);
+            a->new_cl = nullptr;
         }
         if (a->ok_sh)
         {
-            if (s.wnodes_sh) (void)hipFree(s.wnodes_sh);
-            s.wnodes_sh = new_sh;
-            s.d.wnodes_sh = (const float4*)new_sh; s.d.w_sh_entry_ref = a->entry_sh; s.n_wide_sh = (uint32_t)a->wide_sh.size();
+            if (s.wnodes_sh) a->retired.push_back(s.wnodes_sh);
+            s.wnodes_sh = a->new_sh;
+            s.d.wnodes_sh = (const float4*)a->new_sh; s.d.w_sh_entry_ref = a->entry_sh; s.n_wide_sh = (uint32_t)a->wide_sh.size();
             a->roots_sh.swap(a->roots_sh_new);
             if (a->rotations != 0) a->bvh2_sh.swap(a->bvh2_sh_new);          // the shadow rays' binary tree from now on
+            a->new_sh = nullptr;
         }
         if (a->ok || a->ok_sh) ++a->adaptations;
         snprintf(line, sizeof(line), "adaptive fold (probe %u): %zu closest-hit and %zu shadow probe rays; box passes per probe ray at record roots: closest-hit %.2f -> %.2f (%s), "
@@ -2430,6 +2664,13 @@ static int fold_adopt(rt_ctx* ctx)
         {
             s.tree_report.pop_back();
             snprintf(line, sizeof(line), "; the shadow rays' binary tree rotated for the probe rays' crossings first (%u rotations)\n", a->rotations);
+            s.tree_report += line;
+        }
+        const uint64_t truncated = g_truncated_walks.exchange(0);
+        if (truncated != 0)
+        {
+            s.tree_report.pop_back();
+            snprintf(line, sizeof(line), "; %llu host walks met a subtree deeper than their 126-entry stack (weights only)\n", (unsigned long long)truncated);
             s.tree_report += line;
         }
     }
@@ -2460,12 +2701,21 @@ static int fold_adapt_hook(rt_frame* f)
     Scene& s = f->ctx->scene;
     FoldAdapt* a = s.adapt;
     if (!a || a->state == FoldAdapt::OFF) return RT_OK;
-    if (a->state == FoldAdapt::IDLE && !(f->denoiser || f->aov != 0 || f->n_local == 0) && fold_view_left(*a, f->camera)) a->state = FoldAdapt::ARMED;
+    if (a->probe == f) return RT_OK;                                       // (the probe frame goes through the stage API, never through here)
+    const bool eligible = !(f->denoiser || f->aov != 0 || f->n_local == 0);
+    if (a->state == FoldAdapt::IDLE && eligible && fold_view_left(*a, f->camera))
+    {
+        // an orbiting camera leaves the view again and again: at most one adaptation per min_interval_ms (bit 1 -- tests, bench.py -- waits
+        // for every one of them anyway)
+        const auto now = std::chrono::steady_clock::now();
+        if ((a->mode & 2u) || std::chrono::duration<double, std::milli>(now - a->last_armed).count() >= (double)a->min_interval_ms) a->state = FoldAdapt::ARMED;
+    }
     if (a->state == FoldAdapt::ARMED)
     {
-        if (f->denoiser || f->aov != 0 || f->n_local == 0) return RT_OK;     // another frame of this scene will do
+        if (!eligible) return RT_OK;                                       // another frame of this scene will do
         a->camera = f->camera;
-        if (fold_probe(f, *a) != RT_OK || a->o.empty())
+        a->last_armed = std::chrono::steady_clock::now();
+        if (fold_probe_enqueue(f, *a) != RT_OK)
         {
             a->state = FoldAdapt::OFF;
             const size_t at = s.tree_report.find("adaptive fold");
@@ -2473,8 +2723,20 @@ static int fold_adapt_hook(rt_frame* f)
             s.tree_report += "adaptive fold: the probe frame failed (" + f->ctx->error + ") -> the fold stays as it is\n";
             return RT_OK;
         }
+        a->state = FoldAdapt::PROBING;
+    }
+    if (a->state == FoldAdapt::PROBING)
+    {
+        if (a->mode & 2u) { if (hipEventSynchronize(a->probe_done) != hipSuccess) { (void)hipGetLastError(); a->state = FoldAdapt::OFF; return RT_OK; } }
+        else
+        {
+            const hipError_t e = hipEventQuery(a->probe_done);
+            if (e == hipErrorNotReady) return RT_OK;                       // the frame goes on with the fold it has
+            if (e != hipSuccess) { (void)hipGetLastError(); a->state = FoldAdapt::OFF; return RT_OK; }
+        }
         a->state = FoldAdapt::COMPUTING;
         a->ok = a->ok_sh = false;
+        a->upload_failed = false;
         a->cost[0][0] = a->cost[0][1] = a->cost[1][0] = a->cost[1][1] = 0.0;
         a->finished.store(false);
         a->worker = std::thread(fold_adapt_worker, a);
@@ -2486,6 +2748,11 @@ static int fold_adapt_hook(rt_frame* f)
 int rt_integrate(rt_frame* f, uint32_t n_samples)       // n x Integrator::Integrate(), integrator.cpp:27-59
 {
     FRAME_PROLOGUE(f, "rt_integrate");
+    if (f->stage_chunks > 1)
+    {
+        for (const PathPipe& q : f->ps) if (q.cur_slots != 0) return fail(ctx, "rt_integrate: a sample of the stage API is in flight (rt_advance_sample first)");
+        f->stage_chunks = 1;
+    }
     if (fold_adapt_hook(f) != RT_OK) return RT_ERROR;
     // `slots` samples travel through the wavefront together (more rays per launch ->
     // fuller machine, shorter relative tails); the radiance log keeps the sum exact.
@@ -2633,7 +2900,7 @@ int rt_frame_present(rt_frame* f, float* host_rgba)
         f->present_stream = st; f->resolved_b = second;
         f->ev_resolved[0] = ev[0]; f->ev_resolved[1] = ev[1]; f->ev_copied[0] = ev[2]; f->ev_copied[1] = ev[3];
     }
-    if (flush_log(f) != RT_OK) return RT_ERROR;
+    if (flush_stage(f) != RT_OK) return RT_ERROR;
     const uint32_t i = f->present_flip & 1u;
     float4* image = i ? f->resolved_b : f->resolved;
     HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, f->ev_copied[i], 0));      // the copy that last read this device image (two frames ago)
@@ -2662,7 +2929,7 @@ int rt_frame_resolve(rt_frame* f, float* host_rgba)     // ResolveRadiance, :677
     (void)hipSetDevice(ctx->device);
     if (f->n_local == 0) return RT_OK;
     if (rt_frame_present_wait(f) != RT_OK) return RT_ERROR;                // an image still travelling to (possibly) the same host buffer
-    if (flush_log(f) != RT_OK) return RT_ERROR;
+    if (flush_stage(f) != RT_OK) return RT_ERROR;
     uint32_t blocks = (f->n_local + 255u) / 256u;
     hipLaunchKernelGGL(k_resolve, dim3(blocks), dim3(256), 0, ctx->stream, (const float4*)f->radiance, f->aov_buf,
         f->resolved, f->n_local, f->sample_count, f->aov, f->denoiser);
@@ -2679,7 +2946,7 @@ int rt_frame_read_radiance(rt_frame* f, float* host_rgba)
     rt_ctx* ctx = f->ctx;
     (void)hipSetDevice(ctx->device);
     if (f->n_local == 0) return RT_OK;
-    if (flush_log_keep(f) != RT_OK) return RT_ERROR;
+    if (flush_stage(f, true) != RT_OK) return RT_ERROR;
     HIPCHK(ctx, hipMemcpyAsync(host_rgba, f->radiance, (size_t)f->n_local * sizeof(float4), hipMemcpyDeviceToHost,
         ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -2750,7 +3017,7 @@ int rt_frame_copy_radiance(rt_frame* f, void* device_dst)
     rt_ctx* ctx = f->ctx;
     (void)hipSetDevice(ctx->device);
     if (f->n_local == 0) return RT_OK;
-    if (flush_log_keep(f) != RT_OK) return RT_ERROR;
+    if (flush_stage(f, true) != RT_OK) return RT_ERROR;
     HIPCHK(ctx, hipMemcpyAsync(device_dst, f->radiance, (size_t)f->n_local * sizeof(float4), hipMemcpyDeviceToDevice,
         ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -2765,6 +3032,7 @@ int rt_frame_debug_read_queue(rt_frame* f, int which, uint32_t bounce, rt_ray* r
     rt_ctx* ctx = f->ctx;
     (void)hipSetDevice(ctx->device);
     if (bounce > RT_MAX_BOUNCES_LIMIT + 1) return fail(ctx, "rt_frame_debug_read_queue: bounce out of range");
+    if (f->stage_chunks > 1) return fail(ctx, "rt_frame_debug_read_queue: the sample in flight is spread over several pipes (set RT_OPT_STAGE_PIPES to 1 for the debug readers)");
     if (f->p->side) HIPCHK(ctx, hipStreamSynchronize(f->p->side));      // a shadow trace may be retracting log entries
     DCounters h;
     HIPCHK(ctx, hipMemcpyAsync(&h, f->p->counters, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
@@ -2820,6 +3088,7 @@ int rt_frame_debug_read_hits(rt_frame* f, rt_hit* hits, uint32_t count)
     rt_ctx* ctx = f->ctx;
     (void)hipSetDevice(ctx->device);
     if (count > f->log_stride) return fail(ctx, "rt_frame_debug_read_hits: count too large");
+    if (f->stage_chunks > 1) return fail(ctx, "rt_frame_debug_read_hits: the sample in flight is spread over several pipes (set RT_OPT_STAGE_PIPES to 1 for the debug readers)");
     std::vector<float4> h(count ? count : 1);
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     HIPCHK(ctx, hipMemcpy(h.data(), f->p->hits, (size_t)count * 16, hipMemcpyDeviceToHost));

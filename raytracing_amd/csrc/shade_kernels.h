@@ -654,13 +654,17 @@ __global__ __launch_bounds__(RT_SHADE_BLOCK) __attribute__((amdgpu_waves_per_eu(
         {
             const uint32_t lane = threadIdx.x & 63u;
             const uint32_t home = blockIdx.x * (RT_SHADE_BLOCK / 64u) + (threadIdx.x >> 6);
-            const uint32_t share = a.log.ovf_blocks / RT_LOG_SUBPOOLS;
+            // Fewer sub-pools for a small pool (at least 32 blocks each: a tile of a few hundred paths used to get shares of ONE block, a
+            // dry share at once and a fallback to the full layout for good -- ADVICE r04); the division's remainder belongs to the last share.
+            uint32_t n_pools = RT_LOG_SUBPOOLS;
+            while (n_pools > 1u && a.log.ovf_blocks / n_pools < 32u) n_pools >>= 1;
+            const uint32_t share = a.log.ovf_blocks / n_pools, last_share = a.log.ovf_blocks - share * (n_pools - 1u);
             uint32_t got = RT_EMPTY_REF;
             // the wave's own share first, then up to seven others (a share that is full does not end the batch while its
             // neighbours have room: small launches use few shares, late bounces use them unevenly)
-            for (uint32_t attempt = 0; attempt < 8u && wm != 0ull; ++attempt)
+            for (uint32_t attempt = 0; attempt < (n_pools < 8u ? n_pools : 8u) && wm != 0ull; ++attempt)
             {
-                const uint32_t pool = (home + attempt * 9u) & (RT_LOG_SUBPOOLS - 1u);
+                const uint32_t pool = (home + attempt * (n_pools > 8u ? 9u : 1u)) & (n_pools - 1u);
                 uint32_t base = 0;
                 const int first = __builtin_ctzll(wm);
                 if ((int)lane == first) base = atomicAdd(&a.counters->log_ovf_next[pool], (uint32_t)__popcll(wm));
@@ -668,7 +672,7 @@ __global__ __launch_bounds__(RT_SHADE_BLOCK) __attribute__((amdgpu_waves_per_eu(
                 if (want_block && got == RT_EMPTY_REF)
                 {
                     const uint32_t k = base + (uint32_t)__popcll(wm & ((1ull << lane) - 1ull));
-                    if (k < share) got = pool * share + k;
+                    if (k < (pool == n_pools - 1u ? last_share : share)) got = pool * share + k;
                 }
                 wm = __ballot(want_block && got == RT_EMPTY_REF);
             }

@@ -64,6 +64,9 @@ inline uint32_t rotate(const rt_bvh_node* nodes, uint32_t nn, const float* origi
     t.kid0.assign(nn, Tree::NONE); t.kid1.assign(nn, Tree::NONE); t.leaf_ref.assign(nn, Tree::NONE);
     t.mn.resize((size_t)nn * 3); t.mx.resize((size_t)nn * 3);
     t.rays.resize(nn);
+    // the caller may be an exported test hook (rt_debug_rotate_tree): every node but the root must be the child of exactly one interior
+    // node -- a shared child (a DAG) would be walked once per path to it and only fail the size check at the very end
+    std::vector<uint8_t> referenced(nn, 0);
     for (uint32_t i = 0; i < nn; ++i)
     {
         const rt_bvh_node& n = nodes[i];
@@ -73,6 +76,8 @@ inline uint32_t rotate(const rt_bvh_node* nodes, uint32_t nn, const float* origi
         else
         {
             if (i + 1 >= nn || n.offset >= nn || n.offset <= i + 1) return 0;
+            if (referenced[i + 1] || referenced[n.offset]) return 0;
+            referenced[i + 1] = referenced[n.offset] = 1;
             t.kid0[i] = i + 1; t.kid1[i] = n.offset;
         }
     }

@@ -132,7 +132,7 @@ def test_random_scene_matches_oracle_bit_for_bit(ctx, env_map, seed):
     ctx.set_shadow_tree((1, 2, 3, 2, 0)[seed % 5])
     # RT_CTX_OPT_ADAPTIVE_FOLD on every sixth seed (7 = on, wait for the new fold, small trees too): the first integrate() below then traces a
     # probe frame, both trees are folded again for its rays and the records replaced before the frame's own rays start -- same bits
-    ctx.set_adaptive_fold((7, 15)[(seed // 6) % 2] if seed % 6 == 5 else (0, capi.ADAPTIVE_FOLD_DEFAULT)[seed % 2])   # 15: + the shadow tree rotated first
+    ctx.set_adaptive_fold((7, 15, 31)[(seed // 6) % 3] if seed % 6 == 5 else (0, capi.ADAPTIVE_FOLD_DEFAULT)[seed % 2])   # 15: + the shadow tree rotated first, 31: + slots occluder first
     try:
         ctx.upload_scene(sc)
     finally:

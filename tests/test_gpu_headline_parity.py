@@ -257,6 +257,63 @@ def test_stage_api_after_a_chunked_batch_renders_the_whole_tile(golden_scenes):
     fr.close(); ctx.close()
 
 
+def test_stage_pipes_carry_one_sample_as_chunks_on_streams_of_their_own(golden_scenes):
+    """RT_OPT_STAGE_PIPES (round 5): ONE sample per pixel in flight -- the reference's frame-by-frame pattern through the stage API,
+    and rt_integrate(f, 1) -- travels as 2 .. 4 chunks of the tile, each on a pipe (stream + per-path buffers) of its own, so that the
+    chunks' launch tails overlap.  Same radiance and ray counters bit for bit as the one-chunk frame; larger batches afterwards (another
+    allocation), the stage API again, the presented image, and the debug readers' refusal."""
+    w, h, b = 640, 416, 3                                    # >= 512 x 512 pixels: smaller tiles stay in one chunk
+    sc = golden_scenes["coverage"]
+    cam = T.default_camera(w, h)
+    ctx = capi.Context(0)
+    ctx.upload_scene(sc)
+    one = capi.Frame(ctx, w, h)
+    one.set_camera(cam); one.set_max_bounces(b)
+    def stage_sample(fr):
+        fr.generate_rays()
+        for bounce in range(b + 1):
+            fr.intersect(bounce); fr.shade(bounce); fr.intersect_shadow(bounce)
+        fr.advance_sample()
+    for _ in range(3):
+        stage_sample(one)
+    want3, st3 = one.radiance()[..., :3].copy(), one.stats()
+    assert st3.pipelines == 1 and st3.chunk_pixels == w * h
+    orc = _oracle.Oracle(w, h, sc)
+    orc.set_camera(cam); orc.set_max_bounces(b); orc.integrate(3)
+    assert np.array_equal(want3, orc.radiance()[..., :3], equal_nan=True)
+    one.integrate(1); one.integrate(4)
+    stage_sample(one)
+    want9, st9 = one.radiance()[..., :3].copy(), one.stats()
+    for pipes in (2, 3, 4):
+        fr = capi.Frame(ctx, w, h)
+        fr.set_camera(cam); fr.set_max_bounces(b)
+        fr.set_option(capi.OPT_STAGE_PIPES, pipes)
+        for _ in range(3):
+            stage_sample(fr)
+        st = fr.stats()
+        assert st.pipelines == pipes and st.chunk_pixels < w * h and st.chunk_pixels * pipes >= w * h, (pipes, st.pipelines, st.chunk_pixels)
+        assert np.array_equal(fr.radiance()[..., :3], want3, equal_nan=True), pipes
+        assert (st.closest_rays, st.shadow_rays) == (st3.closest_rays, st3.shadow_rays), pipes
+        assert list(st.last_active[:b + 1]) == list(st3.last_active[:b + 1]) and list(st.last_shadow[:b + 1]) == list(st3.last_shadow[:b + 1]), pipes
+        fr.integrate(1)                                      # one sample through rt_integrate: the same chunks
+        assert fr.stats().pipelines == pipes
+        fr.integrate(4)                                      # a batch: one pipe, the whole tile, four samples in flight
+        assert fr.stats().chunk_pixels == w * h
+        fr.generate_rays()                                   # ... and back
+        with pytest.raises(capi.RtError, match="several pipes"):
+            fr.read_queue(0, 0)
+        for bounce in range(b + 1):
+            fr.intersect(bounce); fr.shade(bounce); fr.intersect_shadow(bounce)
+        fr.advance_sample()
+        st = fr.stats()
+        assert fr.sample_count() == 9 and st.pipelines == pipes
+        assert np.array_equal(fr.radiance()[..., :3], want9, equal_nan=True), pipes
+        assert (st.closest_rays, st.shadow_rays) == (st9.closest_rays, st9.shadow_rays), pipes
+        assert np.array_equal(fr.resolve()[..., :3], one.resolve()[..., :3], equal_nan=True), pipes
+        fr.close()
+    one.close(); ctx.close()
+
+
 def test_pipelined_chunks_on_several_streams_are_bit_identical(golden_scenes):
     """RT_OPT_PIPELINES: a large batch (>= 4 M paths) is cut into chunks that travel through the wavefront loop on
     separate pipes (per-path buffers + HIP stream each) so that launch tails overlap.  1, 2, 3 and 4 pipes, with and

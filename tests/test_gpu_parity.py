@@ -193,10 +193,9 @@ def test_mid_sample_reads_on_a_compact_log_allocation(ctx):
     fr.close()
 
 
-# (bit 4 -- shadow records' slots stored likeliest occluder first -- was built after round 4's last GPU second: its host half is covered on the CPU,
-# tests/test_adaptive_fold.py; its two device runs are enabled by RT_TEST_ADAPTIVE_BIT4=1 -- tools/gpu_calls/r05_call01_*.sh sets it -- and join the
-# default list once they have passed on a device)
-_ADAPTIVE_MODES = [(7, 1), (7, 0), (7, 2), (5, 1), (1, 1), (15, 1), (15, 0), (9, 2)] + ([(31, 1), (31, 0)] if os.environ.get("RT_TEST_ADAPTIVE_BIT4") else [])
+# (bit 4 -- shadow records' slots stored likeliest occluder first -- ran on a device for the first time in round 5, call 1: modes (31, 1) and
+# (31, 0) passed with the other eight and joined the list, profiles/r05_call01_pytest_adaptive_fold_all_modes.log; bits 0 + 3 + 4 are the library default)
+_ADAPTIVE_MODES = [(7, 1), (7, 0), (7, 2), (5, 1), (1, 1), (15, 1), (15, 0), (9, 2), (31, 1), (31, 0)]
 
 
 @pytest.mark.parametrize("mode,shadow_tree", _ADAPTIVE_MODES)

@@ -63,7 +63,10 @@ def series(scene_arrays, width, height, bounces, spps, cam, hip_image_at, thread
                         nan_positions_equal=bool(np.array_equal(np.isfinite(got).all(-1), np.isfinite(ref).all(-1))),
                         share_of_worst_pixel=round(float(top[0]) / tot, 4) if tot > 0 else 0.0,
                         share_of_worst_16_pixels=round(float(top[:16].sum()) / tot, 4) if tot > 0 else 0.0,
-                        largest_pixel_difference=float(np.sqrt(top[0])) if len(top) else 0.0, seconds=round(time.time() - t0, 1)))
+                        largest_pixel_difference=float(np.sqrt(top[0])) if len(top) else 0.0,
+                        # one firefly cannot move a median: |difference| / max(|reference|, 1e-6) per pixel, the middle pixel's
+                        median_pixel_rel_err=float(np.median(np.sqrt(d2) / np.maximum(np.linalg.norm(ref.astype(np.float64), axis=-1)[fin], 1e-6))) if fin.any() else None,
+                        seconds=round(time.time() - t0, 1)))
     return out
 
 
