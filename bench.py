@@ -365,12 +365,10 @@ def moving_camera_leg(args, render, lib, frame, capi, host, cam0, frames):
     """The reference's interactive pattern with a camera that MOVES (src/render.cpp:188-195: a changed camera requests a reset, every
     frame starts its accumulation again): the camera turns about the up axis by 0.66 degrees per frame, so it leaves the view the folds
     were adapted to (20 degrees) every ~30 frames.  The fold adaptation runs as the library ships it (asynchronous: probe enqueued behind
-    the frame, worker thread, pointer exchange; at most one per RT_CTX_OPT_ADAPT_MIN_INTERVAL_MS).  Beside it: the same frames with the
-    camera set again every frame but not moved (the reset alone), so that the difference is what moving costs."""
-    import numpy as np
+    the frame, worker thread, pointer exchange; at most one per RT_CTX_OPT_ADAPT_MIN_INTERVAL_MS).  Beside it: the SAME camera path with
+    re-adaptation rate-limited away, so that the difference is what re-adapting costs (or brings) an orbiting camera."""
+    import numpy as np, re
     ctx = host.load().rth_render_ctx_handle(render.handle)
-    mode = args.adaptive_fold
-    assert lib.rt_ctx_set_option(ctx, 4, mode & ~2) == 0              # bit 1 (wait) off from now on: takes effect at once
     def turned(deg):
         c = cam0.copy()
         a = np.float32(np.deg2rad(deg))
@@ -379,35 +377,35 @@ def moving_camera_leg(args, render, lib, frame, capi, host, cam0, frames):
             x, y = float(c[vec]["x"]), float(c[vec]["y"])
             c[vec]["x"], c[vec]["y"] = np.float32(ca * x - sa * y), np.float32(sa * x + ca * y)
         return c
-    def run(step_deg):
+    def probe_no():
+        m = re.search(r"adaptive fold \(probe (\d+)\)", render.tree_report())
+        return int(m.group(1)) if m else 0
+    def run(min_interval_ms):
+        assert lib.rt_ctx_set_option(ctx, 5, min_interval_ms) == 0
         assert lib.rt_reset(frame) == 0
         render.set_resolve_every_frame(True)
         for i in range(3):
             render.set_camera(turned(0.0)); render.render_frame()
         render.finish()
+        n0 = probe_no()
         t0 = time.perf_counter()
         for i in range(frames):
-            render.set_camera(turned(step_deg * (i + 1)))
+            render.set_camera(turned(0.66 * (i + 1)))
             render.render_frame()
         render.finish()
         dt = time.perf_counter() - t0
         render.set_resolve_every_frame(False)
-        return dt
-    report0 = render.tree_report()
-    t_static = run(0.0)
-    t_moving = run(0.66)
-    report1 = render.tree_report()
+        return dt, probe_no() - n0
+    assert lib.rt_ctx_set_option(ctx, 6, 0) == 0                       # RT_CTX_OPT_ADAPT_WAIT off: as the library ships
+    t_fixed, n_fixed = run(0xFFFFFFFF)                                 # the folds stay the ones made for the start view
+    t_moving, n_moving = run(500)                                      # the library's default
     render.set_camera(cam0)
-    assert lib.rt_ctx_set_option(ctx, 4, mode) == 0
-    def probe_no(rep):
-        import re
-        m = re.search(r"adaptive fold \(probe (\d+)\)", rep)
-        return int(m.group(1)) if m else 0
-    return dict(ms_per_frame=round(t_moving * 1e3 / frames, 4), ms_per_frame_camera_set_not_moved=round(t_static * 1e3 / frames, 4), frames=frames,
-                degrees_per_frame=0.66, moving_over_static=round(t_moving / t_static, 4),
-                adaptations_adopted_meanwhile=probe_no(report1) - probe_no(report0),
-                what="one Integrate() per frame through the hooks, camera changed (-> reset) every frame; fold adaptation asynchronous "
-                     "(library default); ResolveRadiance + Finish() every frame")
+    assert lib.rt_ctx_set_option(ctx, 6, 1 if args.adaptive_fold & 2 else 0) == 0
+    return dict(ms_per_frame=round(t_moving * 1e3 / frames, 4), ms_per_frame_without_re_adaptation=round(t_fixed * 1e3 / frames, 4), frames=frames,
+                degrees_per_frame=0.66, with_over_without=round(t_moving / t_fixed, 4),
+                adaptations_adopted=n_moving, adaptations_adopted_without=n_fixed,
+                what="one Integrate() per frame through the hooks, camera turned (-> reset) every frame, ResolveRadiance + Finish() every frame; "
+                     "fold adaptation asynchronous (library default, at most one per 500 ms) against the same camera path with the folds of the start view kept")
 
 
 def roofline_object(args, world, live_step, per_ray, isolated):
@@ -566,6 +564,7 @@ def main():
                     "Bit-identical for every value.")
     ap.add_argument("--tail-lanes", type=int, default=None, help="RT_OPT_TRACE_TAIL_LANES (library default 40; 0 = loop D off)")
     ap.add_argument("--chunk-refill", type=int, default=None, help="RT_OPT_CHUNK_REFILL (library default 1)")
+    ap.add_argument("--refill-quorum", type=int, default=None, help="RT_OPT_TRACE_REFILL_QUORUM (library default 1)")
     ap.add_argument("--tail-paths", type=int, default=None, help="RT_OPT_TRACE_TAIL_PATHS (library default 100000000)")
     ap.add_argument("--libm-series", default=None, help="sample counts (e.g. 1,2,4,8) of parity.rel_l2_vs_libm_build_series: the HIP path against the "
                     "reference's kernels over glibc libm on a 960x540 frame of the same scene (default: 1,2,4,8 for --config 5, off elsewhere; '' = off)")
@@ -574,7 +573,7 @@ def main():
                     "one Integrate() per frame); 0 = skip it")
     ap.add_argument("--stage-pipes", type=int, default=None, help="RT_OPT_STAGE_PIPES for the per_frame legs (library default 1: the frame's one sample per pixel "
                     "travels as one chunk; 2..4: as that many chunks on streams of their own, their launch tails overlapping)")
-    ap.add_argument("--moving-camera-frames", type=int, default=240, help="frames of per_frame.moving_camera (0 = skip): the camera turns 0.66 degrees per frame, "
+    ap.add_argument("--moving-camera-frames", type=int, default=720, help="frames of per_frame.moving_camera (0 = skip): the camera turns 0.66 degrees per frame, "
                     "so it leaves the adapted view every ~30 frames, with the library's default (asynchronous) fold adaptation")
     ap.add_argument("--surface-area-fold-steps", type=int, default=2, help="steps of the surface-area-fold figure printed beside value (0 = skip): the scene uploaded "
                     "again with RT_CTX_OPT_ADAPTIVE_FOLD = 0 after everything else, untimed by the driver")
@@ -735,6 +734,8 @@ def main():
         assert lib.rt_set_option(frame, capi.OPT_CHUNK_REFILL, args.chunk_refill) == 0
     if args.tail_paths is not None:
         assert lib.rt_set_option(frame, capi.OPT_TRACE_TAIL_PATHS, args.tail_paths) == 0
+    if args.refill_quorum is not None:
+        assert lib.rt_set_option(frame, capi.OPT_TRACE_REFILL_QUORUM, args.refill_quorum) == 0
     if args.per_frame_only:
         if args.stage_pipes:
             assert lib.rt_set_option(frame, capi.OPT_STAGE_PIPES, args.stage_pipes) == 0

@@ -92,7 +92,7 @@ enum rt_ctx_option
                                       device in round 5 (profiles/r05_call01_*): bits 3 + 4 take the shadow trace of the headline scene
                                       from 0.314 to 0.258 ms per sample (6711 -> 6917 Mrays/s), every config's frame bit-identical.
                                       0: off.
-                                      Takes effect at the next rt_scene_upload (bit 1 at once); rt_scene_tree_report carries the latest
+                                      Takes effect at the next rt_scene_upload; rt_scene_tree_report carries the latest
                                       adaptation's line.  Costs: a host copy of the binary tree(s), 48 bytes per node, for as long
                                       as the scene lives; per adaptation a probe frame's launches on the context's stream (nothing
                                       waits for them: the queues come back through pinned memory, the worker uploads the new
@@ -101,6 +101,9 @@ enum rt_ctx_option
     , RT_CTX_OPT_ADAPT_MIN_INTERVAL_MS = 5 /* default 500: a camera that keeps leaving the adapted view (an orbit) starts at most one
                                       fold adaptation per this many milliseconds (bit 1 of RT_CTX_OPT_ADAPTIVE_FOLD -- wait for every
                                       adaptation: tests, bench.py -- is not rate-limited).  Takes effect at once. */
+    , RT_CTX_OPT_ADAPT_WAIT = 6    /* 1 / 0: sets / clears bit 1 of RT_CTX_OPT_ADAPTIVE_FOLD (rt_integrate waits for an adaptation it has
+                                      started) for the scene IN PLACE, at once; the context's option, which the next upload reads, stays
+                                      (bench.py: the headline waits for its fold, the moving-camera leg runs as the library ships) */
 };
 int rt_ctx_set_option(rt_ctx* ctx, int option, uint32_t value);
 /* The blue-noise sampler tables (src/utils/blue_noise_sampler.hpp: sobol_256spp_256d[256*256],
@@ -260,6 +263,10 @@ enum rt_option
                                       pattern is its own tail (a launch lasts as long as its longest ray); side by side the chunks'
                                       tails overlap.  Same image bit for bit (chunks are independent; path ids are chunk-relative).
                                       Not with RT_OPT_AOV / RT_OPT_DENOISER (whole tile); the debug readers want 1. */
+    , RT_OPT_TRACE_REFILL_QUORUM = 25 /* k_trace_w4 in refill mode (large launches): phase A -- retire finished rays, hand out new ones, ~220
+                                      vector instructions per pass whatever it serves -- runs once this many lanes of the wave are idle
+                                      (default 1: as soon as one is; tools/lane_pool_model.py prices 16 at - 2.5 % instructions per
+                                      closest-hit ray, - 4.5 % with RT_OPT_TRACE_TUNE 40 : 12).  Results are identical for every value. */
     , RT_OPT_TRACE_TUNE = 12       /* k_trace2 (variants 8, 9) loop thresholds: value & 255 = lanes that must hold an
                                        interior node for a wave to stay in the node loop, value >> 8 & 255 = lanes that
                                        must wait at a triangle for another pass of the triangle loop, value >> 16 & 255 = rays a wave takes
