@@ -564,7 +564,7 @@ def main():
                     "Bit-identical for every value.")
     ap.add_argument("--tail-lanes", type=int, default=None, help="RT_OPT_TRACE_TAIL_LANES (library default 40; 0 = loop D off)")
     ap.add_argument("--chunk-refill", type=int, default=None, help="RT_OPT_CHUNK_REFILL (library default 1)")
-    ap.add_argument("--refill-quorum", type=int, default=None, help="RT_OPT_TRACE_REFILL_QUORUM (library default 1)")
+    ap.add_argument("--refill-quorum", type=int, default=None, help="RT_OPT_TRACE_REFILL_QUORUM (library default 16)")
     ap.add_argument("--tail-paths", type=int, default=None, help="RT_OPT_TRACE_TAIL_PATHS (library default 100000000)")
     ap.add_argument("--libm-series", default=None, help="sample counts (e.g. 1,2,4,8) of parity.rel_l2_vs_libm_build_series: the HIP path against the "
                     "reference's kernels over glibc libm on a 960x540 frame of the same scene (default: 1,2,4,8 for --config 5, off elsewhere; '' = off)")

@@ -167,7 +167,8 @@ struct rt_frame
     bool small_launch_set = false;              // ... set by the caller (otherwise the loop-D instance uses 8 M: launch_trace_w4)
     uint32_t trace_waves_per_cu = 0;   // RT_OPT_TRACE_WAVES_PER_CU (0 = LDS-limited residency)
     uint32_t chunk_refill = 1;                 // RT_OPT_CHUNK_REFILL: chunk mode refills idle lanes from the wave's own chunks
-    uint32_t refill_quorum = 1;                // RT_OPT_TRACE_REFILL_QUORUM: refill mode runs phase A once this many lanes are idle (trace_kernels.h)
+    uint32_t refill_quorum = 16;               // RT_OPT_TRACE_REFILL_QUORUM: refill mode runs phase A once this many lanes are idle (trace_kernels.h; 1 / 8 / 16 / 24:
+                                               // 6586 / 6682 / 6746 / 6720 Mrays/s on one box, same code object: profiles/r05_call03.log)
     uint64_t trace_tail_paths = 100000000ull; // RT_OPT_TRACE_TAIL_PATHS: batches of fewer paths launch the instance with loop D and refilled chunks (8 / 16 / 32 / 64 /
                                               // 128 samples of a 1080p frame in flight: +8 / +5 / +2.3 / -1.6 / -2.8 %, profiles/r04_call20_21.log, r04_call22.log)
     uint32_t trace_tail_lanes = 40;    // RT_OPT_TRACE_TAIL_LANES: k_trace_w4's loop D (0 = off); sweep: profiles/r04_call04_kernel_ab.log

@@ -702,6 +702,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TAIL ? 7 : 4
     // pixel, the late bounces of any batch) are all tail in refill mode; 2430 vs 849 Mrays/s at one 1080p sample in flight,
     // equal at ~8, 3340 vs 5940 at 64 (profiles/r03_call05_chunk_vs_refill_cfg4.log).
     const bool chunk_mode = (tune & 0x800000u) != 0u || count < chunk_below;
+    const uint32_t wait_q = (TAIL || chunk_mode) ? 1u : refill_q;        // idle lanes that make the node loop yield to phase A
     uint32_t grab = ((tune >> 16) & 0x7Fu) ? ((tune >> 16) & 0x7Fu) * 16u : 512u;
     if (chunk_mode) grab = 64u;
     {
@@ -838,8 +839,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TAIL ? 7 : 4
         // ---- A: retire finished rays, start new ones -------------------------------------
         const unsigned long long idle_m = __ballot(ref == RT_IDLE_REF);
         const uint32_t n_idle = (uint32_t)__popcll(idle_m);
-        if ((chunk_mode && !(TAIL && chunk_refill)) ? idle_m == ~0ull
-                                                    : (idle_m != 0ull && (TAIL || chunk_mode || n_idle >= refill_q || n_idle > 48u || pool.exhausted)))
+        if ((chunk_mode && !(TAIL && chunk_refill)) ? idle_m == ~0ull : (n_idle >= wait_q || n_idle > 48u || (idle_m != 0ull && pool.exhausted)))
         {
             if (ref == RT_IDLE_REF && ray_i != RT_INVALID_ID)
             {
@@ -996,15 +996,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TAIL ? 7 : 4
         }
 
         // ---- C: wide nodes, the hot loop ----------------------------------------------------
+#ifdef RT_W4_LOOP_ALIGN                  // experiment (tools/build_variants.py): where the hot loop's first instruction falls in a fetch line
+        asm volatile(".p2align " RT_W4_LOOP_ALIGN);
+#endif
         for (;;)
         {
             const unsigned long long node_m = __ballot((int)ref >= 0);
             if (node_m == 0ull) break;
             if ((uint32_t)__popcll(node_m) < node_q)
             {
+                // (two ballots in mask form, like the one they replace: written with a conditional the compiler turns the loop's exit into
+                // exec-mask bookkeeping on every pass -- 3 % of the closest-hit kernel, profiles/r05_call04.log)
                 const unsigned long long at_leaf = __ballot((int)ref < -1);
-                const uint32_t n_refillable = (!pool.exhausted && (!chunk_mode || (TAIL && chunk_refill))) ? (uint32_t)__popcll(__ballot(ref == RT_IDLE_REF)) : 0u;
-                if (at_leaf != 0ull || n_refillable >= ((TAIL || chunk_mode) ? 1u : refill_q)) break;
+                const unsigned long long refillable = __ballot(ref == RT_IDLE_REF && !pool.exhausted && (!chunk_mode || (TAIL && chunk_refill)));
+                if (at_leaf != 0ull || (uint32_t)__popcll(refillable) >= wait_q) break;
             }
             if ((int)ref >= 0)
             {
