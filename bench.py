@@ -41,7 +41,7 @@ Extra objects on the JSON line:
                Integrator::Integrate() through the fifteen stage hooks, one sample per pixel per call,
                ResolveRadiance + host sync every frame (src/render.cpp:197): mrays_per_s, ms_per_frame.
   roofline     the dominant kernel (closest-hit traversal).  bound "hbm": `achieved` = HBM GB/s from the
-               rocprofv3 --pmc passes of this workload (profiles/r03_trace_counters.json, made by
+               rocprofv3 --pmc passes of this workload (profiles/r05_trace_counters.json, made by
                tools/pmc_bench2.sh + tools/make_counters_json.py), `frac` = achieved / 8 TB/s, `traffic` =
                HBM bytes per launch, next to SURVEY 8d's algorithmic bytes; `units` = busy fractions of the
                vector ALU / scalar ALU / L1-texture-address path against calibrated ceilings;
@@ -73,7 +73,7 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 LIGHT = ((-0.6, -1.5, 3.5), (15.0, 10.0, 5.0))   # reference main.cpp:58
-COUNTERS_FILE = os.path.join(ROOT, "profiles", "r04_trace_counters.json")
+COUNTERS_FILE = os.path.join(ROOT, "profiles", "r05_trace_counters.json")
 VISIT_MICROBENCH_FILE = os.path.join(ROOT, "profiles", "r04_visit_microbench.json")
 
 
@@ -564,7 +564,6 @@ def main():
                     "Bit-identical for every value.")
     ap.add_argument("--tail-lanes", type=int, default=None, help="RT_OPT_TRACE_TAIL_LANES (library default 40; 0 = loop D off)")
     ap.add_argument("--chunk-refill", type=int, default=None, help="RT_OPT_CHUNK_REFILL (library default 1)")
-    ap.add_argument("--refill-quorum", type=int, default=None, help="RT_OPT_TRACE_REFILL_QUORUM (library default 16)")
     ap.add_argument("--tail-paths", type=int, default=None, help="RT_OPT_TRACE_TAIL_PATHS (library default 100000000)")
     ap.add_argument("--libm-series", default=None, help="sample counts (e.g. 1,2,4,8) of parity.rel_l2_vs_libm_build_series: the HIP path against the "
                     "reference's kernels over glibc libm on a 960x540 frame of the same scene (default: 1,2,4,8 for --config 5, off elsewhere; '' = off)")
@@ -734,8 +733,6 @@ def main():
         assert lib.rt_set_option(frame, capi.OPT_CHUNK_REFILL, args.chunk_refill) == 0
     if args.tail_paths is not None:
         assert lib.rt_set_option(frame, capi.OPT_TRACE_TAIL_PATHS, args.tail_paths) == 0
-    if args.refill_quorum is not None:
-        assert lib.rt_set_option(frame, capi.OPT_TRACE_REFILL_QUORUM, args.refill_quorum) == 0
     if args.per_frame_only:
         if args.stage_pipes:
             assert lib.rt_set_option(frame, capi.OPT_STAGE_PIPES, args.stage_pipes) == 0

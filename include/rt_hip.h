@@ -263,12 +263,6 @@ enum rt_option
                                       pattern is its own tail (a launch lasts as long as its longest ray); side by side the chunks'
                                       tails overlap.  Same image bit for bit (chunks are independent; path ids are chunk-relative).
                                       Not with RT_OPT_AOV / RT_OPT_DENOISER (whole tile); the debug readers want 1. */
-    , RT_OPT_TRACE_REFILL_QUORUM = 25 /* k_trace_w4 in refill mode (large launches): phase A -- retire finished rays, hand out new ones, ~220
-                                      vector instructions per pass whatever it serves -- runs once this many lanes of the wave are idle
-                                      (default 16; 1 = as soon as one is, the schedule of rounds 2 - 4: tools/lane_pool_model.py prices 16
-                                      at - 2.5 % vector instructions per closest-hit ray; measured 1 / 8 / 16 / 24: 6586 / 6682 / 6746 /
-                                      6720 Mrays/s on the headline, + 2.8 % on config 2, + 2 % on config 5, profiles/r05_call03.log).
-                                      Results are identical for every value. */
     , RT_OPT_TRACE_TUNE = 12       /* k_trace2 (variants 8, 9) loop thresholds: value & 255 = lanes that must hold an
                                        interior node for a wave to stay in the node loop, value >> 8 & 255 = lanes that
                                        must wait at a triangle for another pass of the triangle loop, value >> 16 & 255 = rays a wave takes

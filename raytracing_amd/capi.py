@@ -69,7 +69,7 @@ EXPORTS = [
     "rt_group_create_unchecked",
 ]
 
-OPT_MAX_BOUNCES, OPT_WHITE_FURNACE, OPT_SAMPLER, OPT_AOV, OPT_DENOISER, OPT_DROP_LAST, OPT_PROFILE, OPT_TRACE_VARIANT, OPT_TRACE_WAVES, OPT_SAMPLES_IN_FLIGHT, OPT_SELECT_FORM_BOX, OPT_PACKET_BOUNCES, OPT_TRACE_TUNE, OPT_DEBUG_ALLOC_LIMIT, OPT_PATH_STATE_LIMIT_MB, OPT_PIPELINES, OPT_SHADE_PARTITION, OPT_OVERLAP_SHADOW, OPT_SMALL_LAUNCH_PATHS, OPT_COMPACT_LOG, OPT_DEBUG_LOG_POOL_DIV, OPT_TRACE_TAIL_LANES, OPT_TRACE_TAIL_PATHS, OPT_CHUNK_REFILL, OPT_STAGE_PIPES, OPT_TRACE_REFILL_QUORUM = range(26)
+OPT_MAX_BOUNCES, OPT_WHITE_FURNACE, OPT_SAMPLER, OPT_AOV, OPT_DENOISER, OPT_DROP_LAST, OPT_PROFILE, OPT_TRACE_VARIANT, OPT_TRACE_WAVES, OPT_SAMPLES_IN_FLIGHT, OPT_SELECT_FORM_BOX, OPT_PACKET_BOUNCES, OPT_TRACE_TUNE, OPT_DEBUG_ALLOC_LIMIT, OPT_PATH_STATE_LIMIT_MB, OPT_PIPELINES, OPT_SHADE_PARTITION, OPT_OVERLAP_SHADOW, OPT_SMALL_LAUNCH_PATHS, OPT_COMPACT_LOG, OPT_DEBUG_LOG_POOL_DIV, OPT_TRACE_TAIL_LANES, OPT_TRACE_TAIL_PATHS, OPT_CHUNK_REFILL, OPT_STAGE_PIPES = range(25)
 
 
 def load():

@@ -167,8 +167,6 @@ struct rt_frame
     bool small_launch_set = false;              // ... set by the caller (otherwise the loop-D instance uses 8 M: launch_trace_w4)
     uint32_t trace_waves_per_cu = 0;   // RT_OPT_TRACE_WAVES_PER_CU (0 = LDS-limited residency)
     uint32_t chunk_refill = 1;                 // RT_OPT_CHUNK_REFILL: chunk mode refills idle lanes from the wave's own chunks
-    uint32_t refill_quorum = 16;               // RT_OPT_TRACE_REFILL_QUORUM: refill mode runs phase A once this many lanes are idle (trace_kernels.h; 1 / 8 / 16 / 24:
-                                               // 6586 / 6682 / 6746 / 6720 Mrays/s on one box, same code object: profiles/r05_call03.log)
     uint64_t trace_tail_paths = 100000000ull; // RT_OPT_TRACE_TAIL_PATHS: batches of fewer paths launch the instance with loop D and refilled chunks (8 / 16 / 32 / 64 /
                                               // 128 samples of a 1080p frame in flight: +8 / +5 / +2.3 / -1.6 / -2.8 %, profiles/r04_call20_21.log, r04_call22.log)
     uint32_t trace_tail_lanes = 40;    // RT_OPT_TRACE_TAIL_LANES: k_trace_w4's loop D (0 = off); sweep: profiles/r04_call04_kernel_ab.log
@@ -2100,7 +2098,6 @@ int rt_set_option(rt_frame* f, int option, uint32_t value)
     case RT_OPT_TRACE_TAIL_LANES: f->trace_tail_lanes = value > 64u ? 64u : value; return RT_OK;
     case RT_OPT_TRACE_TAIL_PATHS: f->trace_tail_paths = value; return RT_OK;
     case RT_OPT_CHUNK_REFILL: f->chunk_refill = value ? 1u : 0u; return RT_OK;
-    case RT_OPT_TRACE_REFILL_QUORUM: f->refill_quorum = value > 64u ? 64u : (value ? value : 1u); return RT_OK;
     case RT_OPT_COMPACT_LOG:
     case RT_OPT_DEBUG_LOG_POOL_DIV:
         if (option == RT_OPT_DEBUG_LOG_POOL_DIV && value == 0) return fail(f->ctx, "rt_set_option: RT_OPT_DEBUG_LOG_POOL_DIV must be >= 1");
@@ -2216,15 +2213,15 @@ void launch_trace_w4(rt_frame* f, const float4* o4, const float4* d4, const uint
         hipLaunchKernelGGL((k_trace_w4<false, 12, true, false>), dim3(blocks), dim3(64), 0, f->tl_stream, ctx->scene.d, o4, d4, aux, count,
             &f->p->counters->head[s][0], f->p->hits, dlog(f), f->tl_spill, tune, f->tl_slow_list,
             &f->p->counters->slow_count[s], &f->p->counters->stack_spills, &f->p->counters->tl_start[f->timeline_bounce & 63u],
-            f->timeline_bounce & 63u, chunk_below, 0u, f->chunk_refill | f->refill_quorum << 8);
+            f->timeline_bounce & 63u, chunk_below, 0u, f->chunk_refill);
     else if (tail)
         hipLaunchKernelGGL((k_trace_w4<SHADOW, 12, false, true>), dim3(blocks), dim3(64), 0, f->tl_stream, ctx->scene.d, o4, d4, aux, count,
             &f->p->counters->head[s][0], SHADOW ? (float4*)nullptr : f->p->hits, dlog(f),
-            f->tl_spill, tune, f->tl_slow_list, &f->p->counters->slow_count[s], &f->p->counters->stack_spills, no_timeline, 0u, chunk_below, f->trace_tail_lanes, f->chunk_refill | f->refill_quorum << 8);
+            f->tl_spill, tune, f->tl_slow_list, &f->p->counters->slow_count[s], &f->p->counters->stack_spills, no_timeline, 0u, chunk_below, f->trace_tail_lanes, f->chunk_refill);
     else
         hipLaunchKernelGGL((k_trace_w4<SHADOW, STACK, false, false>), dim3(blocks), dim3(64), 0, f->tl_stream, ctx->scene.d, o4, d4, aux, count,
             &f->p->counters->head[s][0], SHADOW ? (float4*)nullptr : f->p->hits, dlog(f),
-            f->tl_spill, tune, f->tl_slow_list, &f->p->counters->slow_count[s], &f->p->counters->stack_spills, no_timeline, 0u, chunk_below, 0u, f->chunk_refill | f->refill_quorum << 8);
+            f->tl_spill, tune, f->tl_slow_list, &f->p->counters->slow_count[s], &f->p->counters->stack_spills, no_timeline, 0u, chunk_below, 0u, f->chunk_refill);
     // The follow-up over the (normally empty) slow list: waves with a two-entry LDS stack (the rest of the stack
     // lives in the spill area) -- 1 KiB of LDS and a few registers, so it finds room beside the resident waves of the
     // OTHER stream's persistent launch (RT_OPT_OVERLAP_SHADOW) instead of waiting for that launch to end: with the

@@ -654,15 +654,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TAIL ? 7 : 4
     unsigned long long* __restrict__ timeline /* TIMELINE: DCounters::tl_start + timeline_slot (rt_frame_debug_timeline) */,
     uint32_t timeline_slot, uint32_t chunk_below /* launches of fewer rays run in chunk mode (below) */,
     uint32_t tail_q /* loop D: with this many or fewer lanes busy and nothing to refill the others with, one fused pass serves all */,
-    uint32_t chunk_refill_q /* bit 0: chunk mode: idle lanes take the next rays of the wave's OWN chunks at once (below); bits 8..15: refill
-                               quorum -- refill mode runs phase A only once this many lanes are idle (0 / 1: as soon as one is) */)
+    uint32_t chunk_refill /* chunk mode: idle lanes take the next rays of the wave's OWN chunks at once (below) */)
 {
-    const uint32_t chunk_refill = chunk_refill_q & 1u;
-    // Refill quorum (round 5; tools/lane_pool_model.py): phase A costs ~220 vector instructions per pass whether it serves one lane or
-    // sixty-four, and with "any idle lane" it serves 12 - 16.  Waiting for `refill_q` idle lanes (unless fewer than 16 lanes have work at all)
-    // trades fuller A passes for emptier C passes: the model prices it at - 2.5 % instructions per closest-hit ray at the shipped loop
-    // thresholds, - 4.5 % at 40 : 12.  A launch parameter, so that 1 IS the previous schedule in the same code object.
-    const uint32_t refill_q = ((chunk_refill_q >> 8) & 0xFFu) > 1u ? ((chunk_refill_q >> 8) & 0xFFu) : 1u;
     __shared__ uint2 stack[STACK][64];
     uint32_t* const stack32 = reinterpret_cast<uint32_t*>(&stack[0][0]);     // SHADOW: 2 * STACK entries of 4 bytes
     // spill area: plain (cached) stores; the loads go through spill_load*: written in C they are folded with the LDS side
@@ -702,7 +695,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TAIL ? 7 : 4
     // pixel, the late bounces of any batch) are all tail in refill mode; 2430 vs 849 Mrays/s at one 1080p sample in flight,
     // equal at ~8, 3340 vs 5940 at 64 (profiles/r03_call05_chunk_vs_refill_cfg4.log).
     const bool chunk_mode = (tune & 0x800000u) != 0u || count < chunk_below;
-    const uint32_t wait_q = (TAIL || chunk_mode) ? 1u : refill_q;        // idle lanes that make the node loop yield to phase A
     uint32_t grab = ((tune >> 16) & 0x7Fu) ? ((tune >> 16) & 0x7Fu) * 16u : 512u;
     if (chunk_mode) grab = 64u;
     {
@@ -838,8 +830,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TAIL ? 7 : 4
     {
         // ---- A: retire finished rays, start new ones -------------------------------------
         const unsigned long long idle_m = __ballot(ref == RT_IDLE_REF);
-        const uint32_t n_idle = (uint32_t)__popcll(idle_m);
-        if ((chunk_mode && !(TAIL && chunk_refill)) ? idle_m == ~0ull : (n_idle >= wait_q || n_idle > 48u || (idle_m != 0ull && pool.exhausted)))
+        if ((chunk_mode && !(TAIL && chunk_refill)) ? idle_m == ~0ull : idle_m != 0ull)
         {
             if (ref == RT_IDLE_REF && ray_i != RT_INVALID_ID)
             {
@@ -996,20 +987,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TAIL ? 7 : 4
         }
 
         // ---- C: wide nodes, the hot loop ----------------------------------------------------
-#ifdef RT_W4_LOOP_ALIGN                  // experiment (tools/build_variants.py): where the hot loop's first instruction falls in a fetch line
-        asm volatile(".p2align " RT_W4_LOOP_ALIGN);
-#endif
         for (;;)
         {
             const unsigned long long node_m = __ballot((int)ref >= 0);
             if (node_m == 0ull) break;
             if ((uint32_t)__popcll(node_m) < node_q)
             {
-                // (two ballots in mask form, like the one they replace: written with a conditional the compiler turns the loop's exit into
-                // exec-mask bookkeeping on every pass -- 3 % of the closest-hit kernel, profiles/r05_call04.log)
-                const unsigned long long at_leaf = __ballot((int)ref < -1);
-                const unsigned long long refillable = __ballot(ref == RT_IDLE_REF && !pool.exhausted && (!chunk_mode || (TAIL && chunk_refill)));
-                if (at_leaf != 0ull || (uint32_t)__popcll(refillable) >= wait_q) break;
+                const unsigned long long waiting = __ballot((int)ref < -1 || (ref == RT_IDLE_REF && !pool.exhausted && (!chunk_mode || (TAIL && chunk_refill))));
+                if (waiting != 0ull) break;
             }
             if ((int)ref >= 0)
             {

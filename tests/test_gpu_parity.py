@@ -435,8 +435,6 @@ def test_samples_in_flight_and_kernel_variants_are_bit_invariant(ctx, golden_sce
     # launches this small would all run in chunk mode (RT_OPT_SMALL_LAUNCH_PATHS, 3 M rays): keep the REFILLING form under test
     # for the explicit variants (610 / 710 force chunk mode through the tune word), the automatic choice (5) takes both
     fr.set_option(capi.OPT_SMALL_LAUNCH_PATHS, 3000000 if variant == 5 and slots != 3 else 0)
-    # k_trace_w4's refill quorum (round 5; library default 16): phase A once 1 / 16 / 40 / 64 lanes are idle -- a schedule, never a result
-    fr.set_option(capi.OPT_TRACE_REFILL_QUORUM, {2: 1, 3: 40, 8: 64}[slots] if variant in (10, 11) else 16)
     fr.set_option(capi.OPT_COMPACT_LOG, 1 if slots == 8 and variant in (5, 9, 10, 610) else 0)     # the compact log layout takes batches of 8
     fr.integrate(spp)
     assert fr.sample_count() == spp
