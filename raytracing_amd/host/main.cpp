@@ -23,7 +23,7 @@ int main(int argc, char** argv)
 {
     try
     {
-        unsigned width = 1280, height = 720, spp = 16, bounces = 3, gpus = 1;
+        unsigned width = 1280, height = 720, spp = 16, bounces = 3, gpus = 1, frames = 0;
         std::string scene_path = "assets/ShaderBalls.obj", out, save_cache;
         float scale = 1.0f, aperture = 0.0f, focus = 10.0f;
         bool flip_yz = false, furnace = false, tiled_path = false, shared_device = false, plan_only = false;
@@ -44,6 +44,7 @@ int main(int argc, char** argv)
             else if (!strcmp(argv[i], "--out")) out = next();
             else if (!strcmp(argv[i], "--save-cache")) save_cache = next();
             else if (!strcmp(argv[i], "--gpus")) gpus = (unsigned)atoi(next());
+            else if (!strcmp(argv[i], "--frames")) frames = (unsigned)atoi(next());      // the reference's interactive loop, headless: n x RenderFrame()
             else if (!strcmp(argv[i], "--tiled")) tiled_path = atoi(next()) != 0;      // take the TiledRender path even with one GPU
             else if (!strcmp(argv[i], "--shared_device")) shared_device = atoi(next()) != 0;   // all tiles on GPU 0 (device copies instead of RCCL)
             else if (!strcmp(argv[i], "--plan")) plan_only = atoi(next()) != 0;              // print the tiling and exit: no GPU, no scene
@@ -56,6 +57,8 @@ int main(int argc, char** argv)
                              "  --gpus n tiles the image over devices 0..n-1 (interleaved 8-row bands, one RCCL gather);\n"
                              "  --shared_device 1 puts all n tiles on GPU 0 (device copies instead of RCCL); --plan 1 prints the tiling and exits\n"
                              "  --scene also accepts a file written by --save-cache (parsed scene + BVH)\n"
+                             "  --frames n times the reference's own loop instead of a batch: n x Render::RenderFrame() = one Integrate() through\n"
+                             "  the fifteen hooks, one sample per pixel, ResolveRadiance + Finish() every frame (src/render.cpp:172-204)\n"
                              "  extensions (off = the reference's behaviour): --wide_texture_indices 1 loads scenes with more than 255\n"
                              "  textures; --emissive_nee 1 adds the emissive triangles to next-event estimation\n";
                 return 0;
@@ -120,6 +123,29 @@ int main(int argc, char** argv)
         render.SetCamera(cam);
         render.GetIntegrator().SetMaxBounces(bounces);
         render.GetIntegrator().EnableWhiteFurnace(furnace);
+        if (frames != 0)
+        {
+            // timing run: wait for the fold adaptation instead of adopting it whenever its worker is done (RT_CTX_OPT_ADAPTIVE_FOLD | 2, as bench.py does)
+            if (rt_ctx_set_option(render.GetContext().Get(), RT_CTX_OPT_ADAPTIVE_FOLD, 27u) != RT_OK) throw rt::HIPException("rt_ctx_set_option failed");
+            render.UploadGPUData();
+            // The reference's main loop without its window (src/main.cpp:62-72 -> Render::RenderFrame, src/render.cpp:172-204): every frame is one
+            // Integrate() through the hooks and ends with ResolveRadiance + Finish().  A warm-up batch first (the fold adaptation happens there),
+            // then `frames` timed frames.  No Python, no PyTorch in this process: the HIP runtime is the system's.
+            render.RenderSamples(8);
+            for (int i = 0; i < 8; ++i) render.RenderFrame();
+            render.GetContext().Finish();
+            rt_stats s0 = render.GetIntegrator().GetStats();
+            auto tf = std::chrono::steady_clock::now();
+            for (unsigned i = 0; i < frames; ++i) render.RenderFrame();
+            (void)render.GetIntegrator().GetResolvedImage();               // the last image has arrived
+            render.GetContext().Finish();
+            double df = std::chrono::duration<double>(std::chrono::steady_clock::now() - tf).count();
+            rt_stats s1 = render.GetIntegrator().GetStats();
+            double frays = (double)(s1.closest_rays - s0.closest_rays) + (double)(s1.shadow_rays - s0.shadow_rays);
+            std::cout << frames << " frames (one Integrate() each, resolve + Finish() every frame) in " << df << " s: " << df * 1e3 / frames
+                      << " ms per frame, " << frays / df / 1e6 << " Mrays/s" << std::endl;
+            return 0;
+        }
         auto t0 = std::chrono::steady_clock::now();
         render.RenderSamples(spp);
         render.GetContext().Finish();

@@ -301,6 +301,25 @@ def test_rays_that_pass_nothing_leave_the_fold_alone(golden_scenes):
         capi.adapt_fold(arrays["nodes"], o, d)
 
 
+def test_rotation_refuses_a_node_array_that_is_not_a_tree(golden_scenes):
+    """rt_debug_rotate_tree is an exported entry point and tree_rotate.h's rotate() used to check child indices only locally -- two
+    interior nodes sharing a child (a DAG) were walked once per path and caught only by the size check at the very end.  Now every node but the
+    root must be the child of exactly one interior node, checked before anything is walked."""
+    arrays = golden_scenes["coverage"]
+    nodes = arrays["nodes"].copy()
+    orc, q = queues_of(arrays, 24, 16, 2)
+    so = np.concatenate([as_probe(s)[0] for _, _, s, _ in q]); sdir = np.concatenate([as_probe(s)[1] for _, _, s, _ in q])
+    assert len(so) > 0
+    rot, crossings, made = capi.rotate_tree(nodes, so, sdir, 2)             # the tree as it is: accepted
+    assert len(rot) == len(nodes)
+    interior = [i for i in range(len(nodes)) if (int(nodes[i]["num_primitives_axis"]) >> 16) == 0]
+    a = next(i for i in interior if (int(nodes[i + 1]["num_primitives_axis"]) >> 16) == 0 and int(nodes[i + 1]["offset"]) > i + 2)
+    bad = nodes.copy()
+    bad[a]["offset"] = int(nodes[a + 1]["offset"])                         # a's second child is now also its first child's second child
+    with pytest.raises(capi.RtError, match="not a tree"):
+        capi.rotate_tree(bad, so, sdir, 2)
+
+
 def test_when_the_camera_has_left_the_view():
     """fold_view_left (rt_hip.hip): the thresholds that arm a new adaptation -- 3 % of the scene's diagonal, 20 degrees, a tenth of the field of view"""
     lib = capi.load()

@@ -793,6 +793,10 @@ def test_rt_render_cli(tmp_path):
                          "--out", str(out2)], cwd=ROOT, capture_output=True, text=True, timeout=300)
     assert r2.returncode == 0, r2.stderr
     assert open(out2, "rb").read() == raw
+    # --frames: the reference's own loop (n x Render::RenderFrame(), resolve + Finish() every frame) timed from C++
+    fr = subprocess.run([exe, "-w", "64", "-h", "48", "--scene", "assets/CornellBox.obj", "--bounces", "4", "--frames", "5"],
+                        cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert fr.returncode == 0 and "5 frames (one Integrate() each" in fr.stdout and "ms per frame" in fr.stdout, fr.stdout + fr.stderr
     # the multi-GPU path of the C++ host (TiledRender: device group + the one RCCL gather), on the GPUs there are
     out3 = tmp_path / "img3.pfm"
     r3 = subprocess.run([exe, "-w", "64", "-h", "48", "--scene", "assets/CornellBox.obj", "--spp", "4", "--bounces", "4",
