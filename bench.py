@@ -361,6 +361,17 @@ def median_pixel_rel_err(a, b):
     return float(np.median(d / n))
 
 
+def p99_pixel_rel_err(a, b):
+    """... and the 99th percentile of the same per-pixel quantity"""
+    import numpy as np
+    fin = np.isfinite(a).all(-1) & np.isfinite(b).all(-1)
+    if not fin.any():
+        return None
+    d = np.linalg.norm(a[fin].astype(np.float64) - b[fin].astype(np.float64), axis=-1)
+    n = np.maximum(np.linalg.norm(b[fin].astype(np.float64), axis=-1), 1e-6)
+    return float(np.percentile(d / n, 99.0))
+
+
 def moving_camera_leg(args, render, lib, frame, capi, host, cam0, frames):
     """The reference's interactive pattern with a camera that MOVES (src/render.cpp:188-195: a changed camera requests a reset, every
     frame starts its accumulation again): the camera turns about the up axis by 0.66 degrees per frame, so it leaves the view the folds
@@ -751,6 +762,7 @@ def main():
     render.render_samples(spp_warm) if spp_warm > 0 else None
     render.finish()
     t_warm = time.perf_counter() - t_warm0                # with bit 1 of --adaptive-fold: probe + worker + adoption are in here
+    trees_after_warmup = render.tree_report() if args.adaptive_fold else tree_report     # the folds the timed region runs on (later legs may adapt again)
     if args.warmup > 0:     # the gather path too (first use sets up the RCCL channels)
         if group is not None:
             try:
@@ -931,6 +943,7 @@ def main():
                 denr = np.linalg.norm(libm_img[finr].astype(np.float64).ravel())
                 parity["reference_self_rel_l2"] = float(numr / denr) if denr > 0 else 0.0
                 parity["reference_self_median_pixel_rel_err"] = median_pixel_rel_err(ref_img, libm_img)
+                parity["reference_self_p99_pixel_rel_err"] = p99_pixel_rel_err(ref_img, libm_img)
                 parity["reference_self"] = ("oracle/_ref/libref.so vs oracle/_ref/libref_libm.so (the reference's unmodified kernels over two conformant builtin "
                                             "libraries), the CPU leg's frame: a property of the reference, measured without the GPU")
                 parity["median_pixel_rel_err_vs_libm_build"] = median_pixel_rel_err(got, libm_img)
@@ -992,7 +1005,7 @@ def main():
         roofline = roofline_object(args, world, live_step, per_ray, isolated)
         if isolated is not None:
             roofline["live_isolated"] = isolated
-        trees_now = (render.tree_report() if args.adaptive_fold else tree_report).strip().split("\n")
+        trees_now = trees_after_warmup.strip().split("\n")
         # The headline runs on the fold ADAPTED to this view (RT_CTX_OPT_ADAPTIVE_FOLD, bit 1: the warm-up waits for it).  Beside it: what the
         # adaptation took, and the same job on the fold rt_scene_upload makes (surface area) -- the scene uploaded again with the option off, a
         # warm-up step and a few timed ones, after everything else.
@@ -1014,11 +1027,12 @@ def main():
                 assert lib.rt_reset(frame) == 0
                 sa0 = render.stats()
                 ta = time.perf_counter()
-                render.render_samples(args.surface_area_fold_steps * sps); render.finish()
+                sa_steps = max(args.surface_area_fold_steps, min(args.steps, int(round(0.4 / max(dt_max / max(args.steps, 1), 1e-6)))))   # >= 0.4 s of work
+                render.render_samples(sa_steps * sps); render.finish()
                 tb = time.perf_counter() - ta
                 sa1 = render.stats()
                 sa_rays = float((sa1.closest_rays - sa0.closest_rays) + (sa1.shadow_rays - sa0.shadow_rays))
-                surface_area_fold = dict(value=round(sa_rays / tb / 1e6, 2), unit="Mrays/s", steps=args.surface_area_fold_steps,
+                surface_area_fold = dict(value=round(sa_rays / tb / 1e6, 2), unit="Mrays/s", steps=sa_steps,
                                          what="the same job on the fold rt_scene_upload makes (RT_CTX_OPT_ADAPTIVE_FOLD = 0), same box, untimed by the driver")
             except Exception as e:                              # noqa: BLE001 -- reported, never fatal to the measurement
                 surface_area_fold = dict(error=repr(e))

@@ -285,6 +285,9 @@ RT_DEV f3 SampleSky(const DScene& sc, f3 dir)
 // (hit_surface.cl:138,173).  Same-address L2 atomics retire at ~10 ns each on
 // MI355X, so at ~20 M rays per launch even one atomic per wave (600 k of them) was
 // the shade kernel's bottleneck; per 512-thread block it is 8x fewer.
+#ifndef RT_SHADE_WAVES            // waves per SIMD k_shade is compiled for (78 VGPRs at 6; tools/build_variants.py: 7 / 8 tried in round 5)
+#define RT_SHADE_WAVES 6
+#endif
 #ifndef RT_SHADE_BLOCK            // 256 measured no different (profiles/r02_variants_ab_call41.log)
 #define RT_SHADE_BLOCK 512
 #endif
@@ -400,7 +403,7 @@ RT_DEV float SampleBlueNoise(const ShadeArgs& a, uint32_t px, uint32_t py, uint3
 // COMPACT: the radiance log is in its compact layout (DLog; RT_OPT_COMPACT_LOG): separate instances, so that the default ones
 // carry none of its code.
 template <bool FURNACE, bool BLUE, bool NEE = false, bool COMPACT = false>
-__global__ __launch_bounds__(RT_SHADE_BLOCK) __attribute__((amdgpu_waves_per_eu(NEE ? 5 : 6))) void k_shade(DScene sc, DTile tile, ShadeArgs a)
+__global__ __launch_bounds__(RT_SHADE_BLOCK) __attribute__((amdgpu_waves_per_eu(NEE ? 5 : RT_SHADE_WAVES))) void k_shade(DScene sc, DTile tile, ShadeArgs a)
 {
     const uint32_t count = a.counters->queue[a.bounce];
     // the closest-hit trace of this bounce has completed (stream order): rewind the
