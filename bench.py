@@ -583,6 +583,8 @@ def main():
                     "one Integrate() per frame); 0 = skip it")
     ap.add_argument("--stage-pipes", type=int, default=None, help="RT_OPT_STAGE_PIPES for the per_frame legs (library default 1: the frame's one sample per pixel "
                     "travels as one chunk; 2..4: as that many chunks on streams of their own, their launch tails overlapping)")
+    ap.add_argument("--frame-kernel", type=int, default=None, help="RT_OPT_FRAME_KERNEL for the per_frame legs (library default 0): 1 = every frame of the "
+                    "hooks' pattern is ONE launch of k_frame")
     ap.add_argument("--moving-camera-frames", type=int, default=720, help="frames of per_frame.moving_camera (0 = skip): the camera turns 0.66 degrees per frame, "
                     "so it leaves the adapted view every ~30 frames, with the library's default (asynchronous) fold adaptation")
     ap.add_argument("--surface-area-fold-steps", type=int, default=2, help="steps of the surface-area-fold figure printed beside value (0 = skip): the scene uploaded "
@@ -745,6 +747,8 @@ def main():
     if args.tail_paths is not None:
         assert lib.rt_set_option(frame, capi.OPT_TRACE_TAIL_PATHS, args.tail_paths) == 0
     if args.per_frame_only:
+        if args.frame_kernel is not None:
+            assert lib.rt_set_option(frame, capi.OPT_FRAME_KERNEL, args.frame_kernel) == 0
         if args.stage_pipes:
             assert lib.rt_set_option(frame, capi.OPT_STAGE_PIPES, args.stage_pipes) == 0
         pf = per_frame_leg(args, render, lib, frame, capi, max(args.per_frame_frames, 1))

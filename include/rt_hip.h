@@ -263,6 +263,14 @@ enum rt_option
                                       pattern is its own tail (a launch lasts as long as its longest ray); side by side the chunks'
                                       tails overlap.  Same image bit for bit (chunks are independent; path ids are chunk-relative).
                                       Not with RT_OPT_AOV / RT_OPT_DENOISER (whole tile); the debug readers want 1. */
+    , RT_OPT_FRAME_KERNEL = 25      /* 0 (default) / 1: ONE sample per pixel in flight through the stage API -- the reference's frame-by-frame pattern,
+                                      Integrator::Integrate through the fifteen hooks -- as ONE launch: the stage calls of a sample are recorded while
+                                      they come in the canonical order (rt_generate_rays; rt_intersect, rt_shade, rt_intersect_shadow for bounce 0 ..
+                                      max_bounces; rt_advance_sample) and rt_advance_sample launches k_frame, in which every wave carries its own
+                                      pixels through all the bounces (raytracing_amd/csrc/frame_kernels.h).  Any other order, a debug reader or the
+                                      radiance between two stages replays the recorded stages with the stage kernels first.  Same radiance and ray
+                                      counters bit for bit.  Not with AOVs / the denoiser, the compact log, RT_SCENE_EMISSIVE_NEE or profiling
+                                      (those samples take the stage kernels). */
     , RT_OPT_TRACE_TUNE = 12       /* k_trace2 (variants 8, 9) loop thresholds: value & 255 = lanes that must hold an
                                        interior node for a wave to stay in the node loop, value >> 8 & 255 = lanes that
                                        must wait at a triangle for another pass of the triangle loop, value >> 16 & 255 = rays a wave takes
@@ -343,6 +351,8 @@ typedef struct rt_stats
     uint32_t log_inline_entries;       /* != 0: the radiance log is in its compact layout with this many inline entries per path
                                           (RT_OPT_COMPACT_LOG); 0: the full layout, 2 (max_bounces + 1) entries per path */
     uint32_t log_fallbacks;            /* batches whose overflow pool ran dry and that were repeated in the full layout */
+    uint32_t frame_kernel_samples;     /* samples of the stage API that went through k_frame in one launch (RT_OPT_FRAME_KERNEL), since the frame was created */
+    uint32_t reserved_;
 } rt_stats;
 int rt_frame_get_stats(rt_frame* frame, rt_stats* out);
 

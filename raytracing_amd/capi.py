@@ -22,7 +22,7 @@ class rt_stats(C.Structure):
                 ("last_active", C.c_uint32 * 64), ("last_shadow", C.c_uint32 * 64),
                 ("samples_in_flight", C.c_uint32), ("samples_in_flight_limit", C.c_uint32), ("path_state_bytes", C.c_uint64),
                 ("stack_spills", C.c_uint32), ("slow_rays", C.c_uint32), ("chunk_pixels", C.c_uint32), ("pipelines", C.c_uint32),
-                ("log_inline_entries", C.c_uint32), ("log_fallbacks", C.c_uint32)]
+                ("log_inline_entries", C.c_uint32), ("log_fallbacks", C.c_uint32), ("frame_kernel_samples", C.c_uint32), ("reserved_", C.c_uint32)]
 
 
 class rt_profile(C.Structure):
@@ -69,7 +69,7 @@ EXPORTS = [
     "rt_group_create_unchecked",
 ]
 
-OPT_MAX_BOUNCES, OPT_WHITE_FURNACE, OPT_SAMPLER, OPT_AOV, OPT_DENOISER, OPT_DROP_LAST, OPT_PROFILE, OPT_TRACE_VARIANT, OPT_TRACE_WAVES, OPT_SAMPLES_IN_FLIGHT, OPT_SELECT_FORM_BOX, OPT_PACKET_BOUNCES, OPT_TRACE_TUNE, OPT_DEBUG_ALLOC_LIMIT, OPT_PATH_STATE_LIMIT_MB, OPT_PIPELINES, OPT_SHADE_PARTITION, OPT_OVERLAP_SHADOW, OPT_SMALL_LAUNCH_PATHS, OPT_COMPACT_LOG, OPT_DEBUG_LOG_POOL_DIV, OPT_TRACE_TAIL_LANES, OPT_TRACE_TAIL_PATHS, OPT_CHUNK_REFILL, OPT_STAGE_PIPES = range(25)
+OPT_MAX_BOUNCES, OPT_WHITE_FURNACE, OPT_SAMPLER, OPT_AOV, OPT_DENOISER, OPT_DROP_LAST, OPT_PROFILE, OPT_TRACE_VARIANT, OPT_TRACE_WAVES, OPT_SAMPLES_IN_FLIGHT, OPT_SELECT_FORM_BOX, OPT_PACKET_BOUNCES, OPT_TRACE_TUNE, OPT_DEBUG_ALLOC_LIMIT, OPT_PATH_STATE_LIMIT_MB, OPT_PIPELINES, OPT_SHADE_PARTITION, OPT_OVERLAP_SHADOW, OPT_SMALL_LAUNCH_PATHS, OPT_COMPACT_LOG, OPT_DEBUG_LOG_POOL_DIV, OPT_TRACE_TAIL_LANES, OPT_TRACE_TAIL_PATHS, OPT_CHUNK_REFILL, OPT_STAGE_PIPES, OPT_FRAME_KERNEL = range(26)
 
 
 def load():

@@ -4,5 +4,6 @@
 #include "raygen_kernels.h"
 #include "trace_kernels.h"
 #include "shade_kernels.h"
+#include "frame_kernels.h"
 #include "aov_kernels.h"
 #include "relayout_kernels.h"

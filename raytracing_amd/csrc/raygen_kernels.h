@@ -3,6 +3,48 @@
 #pragma once
 #include "kernels_common.h"
 
+// The primary ray of global pixel (pixel_x, pixel_y) for sample `sample_idx` (raygeneration.cl:92-133): origin on the lens, direction through the
+// focus plane.  Shared by k_raygen and k_frame (frame_kernels.h).
+RT_DEV void raygen_ray(const DTile& tile, const rt_camera& cam, float tan_half_fov, uint32_t pixel_x, uint32_t pixel_y, uint32_t sample_idx,
+    f3& new_pos, f3& d)
+{
+    uint32_t pixel_idx = pixel_y * tile.width + pixel_x;                 // GLOBAL pixel index
+    float inv_width = 1.0f / (float)tile.width;
+    float inv_height = 1.0f / (float)tile.height;
+    uint32_t seed = pixel_idx + (1103515245u * sample_idx + 12345u);     // :61,98
+
+    float x = ((float)pixel_x + GetRandomFloat(seed)) * inv_width;
+    float y = ((float)pixel_y + GetRandomFloat(seed)) * inv_height;
+
+    float angle = tan_half_fov;                                          // rt_tanf(0.5f * fov), host-evaluated
+    x = (x * 2.0f - 1.0f) * angle * cam.aspect_ratio;
+    y = (y * 2.0f - 1.0f) * angle;
+
+    f3 front = F3(cam.front.x, cam.front.y, cam.front.z);
+    f3 up = F3(cam.up.x, cam.up.y, cam.up.z);
+    f3 pos = F3(cam.position.x, cam.position.y, cam.position.z);
+    f3 right = cross3(front, up);
+    f3 dir = normalize3(right * x + up * y + front);
+
+    f3 point_aimed = pos + dir * cam.focus_distance;
+    // PointInHexagon :40-49 (index 3 = the reference's out-of-bounds read, defined as (0,0))
+    int hidx = (int)__builtin_floorf(GetRandomFloat(seed) * 3.0f);
+    int h1 = hidx > 3 ? 3 : hidx;
+    int h2 = (hidx + 1) % 3;
+    float hx1 = h1 == 0 ? -1.0f : (h1 == 3 ? 0.0f : 0.5f);
+    float hy1 = h1 == 1 ? 0.866f : (h1 == 2 ? -0.866f : 0.0f);
+    float hx2 = h2 == 0 ? -1.0f : 0.5f;
+    float hy2 = h2 == 1 ? 0.866f : (h2 == 2 ? -0.866f : 0.0f);
+    float p1 = GetRandomFloat(seed);
+    float p2 = GetRandomFloat(seed);
+    float dofx = p1 * hx1 + p2 * hx2;
+    float dofy = p1 * hy1 + p2 * hy2;
+    float r = cam.aperture;
+    new_pos = pos + right * (dofx * r) + up * (dofy * r);
+    d = normalize3(point_aimed - new_pos);
+
+}
+
 // ---------------------------------------------------------------------------
 // sample begin + ray generation (raygeneration.cl:65-139)
 // ---------------------------------------------------------------------------
@@ -53,42 +95,9 @@ __global__ __launch_bounds__(256) void k_raygen(DTile tile, rt_camera cam, uint3
     uint32_t ly = lp / tile.width;
     uint32_t pixel_x = lp - ly * tile.width;
     uint32_t pixel_y = tile_global_row(tile, ly);
-    uint32_t pixel_idx = pixel_y * tile.width + pixel_x;                 // GLOBAL pixel index
 
-    float inv_width = 1.0f / (float)tile.width;
-    float inv_height = 1.0f / (float)tile.height;
-    uint32_t seed = pixel_idx + (1103515245u * sample_idx + 12345u);     // :61,98
-
-    float x = ((float)pixel_x + GetRandomFloat(seed)) * inv_width;
-    float y = ((float)pixel_y + GetRandomFloat(seed)) * inv_height;
-
-    float angle = tan_half_fov;                                          // rt_tanf(0.5f * fov), host-evaluated
-    x = (x * 2.0f - 1.0f) * angle * cam.aspect_ratio;
-    y = (y * 2.0f - 1.0f) * angle;
-
-    f3 front = F3(cam.front.x, cam.front.y, cam.front.z);
-    f3 up = F3(cam.up.x, cam.up.y, cam.up.z);
-    f3 pos = F3(cam.position.x, cam.position.y, cam.position.z);
-    f3 right = cross3(front, up);
-    f3 dir = normalize3(right * x + up * y + front);
-
-    f3 point_aimed = pos + dir * cam.focus_distance;
-    // PointInHexagon :40-49 (index 3 = the reference's out-of-bounds read, defined as (0,0))
-    int hidx = (int)__builtin_floorf(GetRandomFloat(seed) * 3.0f);
-    int h1 = hidx > 3 ? 3 : hidx;
-    int h2 = (hidx + 1) % 3;
-    float hx1 = h1 == 0 ? -1.0f : (h1 == 3 ? 0.0f : 0.5f);
-    float hy1 = h1 == 1 ? 0.866f : (h1 == 2 ? -0.866f : 0.0f);
-    float hx2 = h2 == 0 ? -1.0f : 0.5f;
-    float hy2 = h2 == 1 ? 0.866f : (h2 == 2 ? -0.866f : 0.0f);
-    float p1 = GetRandomFloat(seed);
-    float p2 = GetRandomFloat(seed);
-    float dofx = p1 * hx1 + p2 * hx2;
-    float dofy = p1 * hy1 + p2 * hy2;
-    float r = cam.aperture;
-    f3 new_pos = pos + right * (dofx * r) + up * (dofy * r);
-    f3 d = normalize3(point_aimed - new_pos);
-
+    f3 new_pos, d;
+    raygen_ray(tile, cam, tan_half_fov, pixel_x, pixel_y, sample_idx, new_pos, d);
     o4[i] = make_float4(new_pos.x, new_pos.y, new_pos.z, RT_MAX_RENDER_DIST);
     d4[i] = make_float4(d.x, d.y, d.z, __uint_as_float(slot * chunk_stride + cp));   // path id
     thr[i] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);

@@ -141,6 +141,14 @@ struct rt_frame
                                    // pattern) is cut into this many chunks, each on a pipe (stream) of its own: every launch of that pattern is
                                    // its own tail, and the chunks' tails overlap
     uint32_t stage_chunks = 1;     // pipes holding a chunk of the stage API's sample in flight (set by rt_generate_rays)
+    // RT_OPT_FRAME_KERNEL: the stage API's sample as ONE launch (k_frame, frame_kernels.h).  The stage calls of a sample are only RECORDED
+    // while they come in the canonical order; rt_advance_sample launches the kernel.  Anything that needs the state between two stages
+    // (a debug reader, the radiance mid-sample, another order of calls) first replays the recorded stages with the stage kernels.
+    uint32_t frame_kernel = 0;
+    struct { bool active = false; uint32_t bounce = 0; int next = 0; } deferred;   // next: 0 = rt_intersect(bounce), 1 = rt_shade, 2 = rt_intersect_shadow
+    uint32_t* frame_counts = nullptr; uint32_t* frame_slow = nullptr;              // k_frame's per-wave rows and slow-ray lists
+    uint32_t frame_blocks = 0, frame_chunks_per_wave = 0;
+    uint64_t frame_launches = 0;                                                   // samples rendered by k_frame so far (rt_stats)
     uint32_t n_pipes = 1;          // pipes the current allocation holds
     uint32_t slots = 1;            // samples traced concurrently (resolved from slots_opt)
     uint32_t slots_opt = 0;        // RT_OPT_SAMPLES_IN_FLIGHT as set by the caller (0 = auto)
@@ -1845,6 +1853,8 @@ static int sync_frame_streams(rt_frame* f)
     return RT_OK;
 }
 
+extern "C" { static int deferred_materialize(rt_frame* f); }   // RT_OPT_FRAME_KERNEL (below, with the stage functions)
+
 namespace
 {
 // Mid-sample read (stage API / debugging): apply what has been logged so far but
@@ -1876,6 +1886,7 @@ int for_stage_pipes(rt_frame* f, F&& body)
 // ... their logs replayed into the radiance (keep: the sample stays open), and the context's stream made to see all of them
 int flush_stage(rt_frame* f, bool keep = false)
 {
+    if (f->deferred.active && deferred_materialize(f) != RT_OK) return RT_ERROR;    // RT_OPT_FRAME_KERNEL: the recorded stages run after all
     const uint32_t n = f->stage_chunks ? f->stage_chunks : 1u;
     if (for_stage_pipes(f, [&]() { return keep ? flush_log_keep(f) : flush_log(f); }) != RT_OK) return RT_ERROR;
     return n > 1 ? join_pipes(f) : RT_OK;
@@ -1971,6 +1982,8 @@ int rt_frame_destroy(rt_frame* f)
         if (i > 0 && q.stream) (void)hipStreamDestroy(q.stream);
     }
     if (f->present_stream) { (void)hipStreamSynchronize(f->present_stream); (void)hipStreamDestroy(f->present_stream); }
+    if (f->frame_counts) (void)hipFree(f->frame_counts);
+    if (f->frame_slow) (void)hipFree(f->frame_slow);
     for (hipEvent_t e : f->ev_resolved) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : f->ev_copied) if (e) (void)hipEventDestroy(e);
     if (f->resolved_b) (void)hipFree(f->resolved_b);
@@ -1992,6 +2005,7 @@ uint32_t rt_frame_global_row(rt_frame* f, uint32_t ly)
 int rt_set_option(rt_frame* f, int option, uint32_t value)
 {
     if (!f) return fail(nullptr, "rt_set_option: frame is NULL");
+    if (f->deferred.active && option != RT_OPT_FRAME_KERNEL && deferred_materialize(f) != RT_OK) return RT_ERROR;   // an option changed between two recorded stages
     switch (option)
     {
     case RT_OPT_MAX_BOUNCES:
@@ -2064,6 +2078,10 @@ int rt_set_option(rt_frame* f, int option, uint32_t value)
             f->pipelines = value;
             return alloc_path_buffers(f, f->slots);
         }
+        return RT_OK;
+    case RT_OPT_FRAME_KERNEL:
+        if (f->deferred.active) return fail(f->ctx, "rt_set_option: RT_OPT_FRAME_KERNEL cannot change while a sample is in flight (rt_advance_sample first)");
+        f->frame_kernel = value ? 1u : 0u;
         return RT_OK;
     case RT_OPT_STAGE_PIPES:
         if (value == 0 || value > RT_MAX_PIPES) return fail(f->ctx, "rt_set_option: stage pipes must be 1..RT_MAX_PIPES");
@@ -2292,6 +2310,7 @@ int rt_reset(rt_frame* f)                               // CLPathTraceIntegrator
     }
     f->p = &f->ps[0];
     f->stage_chunks = 1;
+    f->deferred.active = false;                             // a recorded sample that was never advanced: nothing has run
     for (uint32_t i = 0; i < RT_MAX_PIPES; ++i)
     {
         PathPipe& q = f->ps[i];
@@ -2342,6 +2361,112 @@ extern "C" {
 
 static int fold_adapt_hook(rt_frame* f);
 
+} // extern "C"
+
+namespace
+{
+// ---- RT_OPT_FRAME_KERNEL: the stage API's sample as one launch (k_frame) ---------------------------------------------------------
+// Can this frame's next sample go through k_frame?  One sample in flight over the whole tile in one chunk on one pipe, the full log layout,
+// the wide tree in place, no per-frame feature that reads between the stages, and none of the paths k_frame has no instance for.
+bool frame_kernel_eligible(const rt_frame* f)
+{
+    const rt_ctx* ctx = f->ctx;
+    const uint32_t n_local = f->n_local ? f->n_local : 1u;
+    return f->frame_kernel != 0u && f->n_local != 0u && !(f->denoiser || f->aov != 0) && ctx->scene.wide_ok && !ctx->scene.slow_shadow &&
+           ctx->scene.d.emissive_nee == 0u && f->log_ovf_blocks == 0u && f->n_pipes == 1u && f->chunk_pixels >= n_local && f->stage_chunks <= 1u &&
+           (f->trace_variant == 5u || f->trace_variant == 10u) && !f->profile && !f->timeline && f->select_form_box == 0u && f->max_bounces < 63u;
+}
+
+template <bool FURNACE, bool BLUE>
+int launch_frame_kernel_t(rt_frame* f)
+{
+    rt_ctx* ctx = f->ctx;
+    PathPipe& q = f->ps[0];
+    if (f->frame_blocks == 0u)
+    {
+        // as many one-wave blocks as the device keeps resident (the kernel's registers decide), every wave with the same number of chunks
+        int per_cu = 0;
+        HIPCHK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_frame<FURNACE, BLUE>, 64, 0));
+        if (per_cu < 1) return fail(ctx, "rt_advance_sample: k_frame does not fit the device");
+        const uint32_t n_chunks = (f->n_local + 63u) >> 6, cpx = (n_chunks + 7u) >> 3;
+        const uint32_t s_max = std::max(1u, (uint32_t)ctx->prop.multiProcessorCount * (uint32_t)per_cu / 8u);
+        const uint32_t cpw = (cpx + s_max - 1u) / s_max;                      // chunks per wave
+        const uint32_t s_waves = (cpx + cpw - 1u) / cpw;                      // waves per XCD region
+        f->frame_blocks = 8u * s_waves;
+        f->frame_chunks_per_wave = cpw;
+        if ((size_t)f->frame_blocks * 64u * (RT_W4_STACK_MAX - 12) > (size_t)ctx->prop.multiProcessorCount * 32 * 64 * (RT_W4_STACK_MAX - 8))
+            return fail(ctx, "rt_advance_sample: k_frame's grid exceeds the spill area");
+        HIPCHK(ctx, hipMalloc((void**)&f->frame_counts, (size_t)f->frame_blocks * RT_FRAME_COUNT_STRIDE * sizeof(uint32_t)));
+        HIPCHK(ctx, hipMalloc((void**)&f->frame_slow, (size_t)f->frame_blocks * cpw * 64u * sizeof(uint32_t)));
+    }
+    // the previous sample's per-bounce counters go to the totals first (k_raygen does this for the stage kernels)
+    hipLaunchKernelGGL(k_fold_counters, dim3(1), dim3(64), 0, q.stream, q.counters, q.prev_bounces, q.fold_accumulates);
+    q.fold_accumulates = 0;
+    q.prev_bounces = f->max_bounces;
+    FrameArgs fa;
+    memset(&fa, 0, sizeof(fa));
+    ShadeArgs& a = fa.shade;
+    a.log = dlog(f); a.counters = q.counters;
+    a.bn_sobol = ctx->blue_noise; a.bn_scramble = ctx->blue_noise ? ctx->blue_noise + 65536 : nullptr;
+    a.bn_rank = ctx->blue_noise ? ctx->blue_noise + 65536 + 131072 : nullptr;
+    a.sample_base = f->sample_count;
+    a.n_local = f->chunk_pixels ? f->chunk_pixels : 1;
+    a.pix_base = 0;
+    a.count_in_ray = 1u;
+    a.partition = 0;
+    for (int i = 0; i < 2; ++i) { fa.o4[i] = q.o4[i]; fa.d4[i] = q.d4[i]; fa.thr[i] = q.thr[i]; }
+    fa.hits = q.hits;
+    fa.sh_o4 = q.sh_o4[0]; fa.sh_d4 = q.sh_d4[0]; fa.sh_aux = q.sh_aux[0];
+    fa.radiance = f->radiance;
+    fa.spill = q.spill;
+    fa.slow_list = f->frame_slow;
+    fa.wave_counts = f->frame_counts;
+    fa.cam = f->camera;
+    fa.tan_half_fov = rt_tanf(0.5f * f->camera.fov);
+    fa.max_bounces = f->max_bounces;
+    fa.drop_last = f->drop_last;
+    const uint32_t t = f->trace_tune;
+    fa.tune = ((t & 0xFFu) ? (t & 0xFFu) : (RT_TRACE2_DEFAULT_TUNE & 0xFFu)) | ((((t >> 8) & 0xFFu) ? ((t >> 8) & 0xFFu) : ((RT_TRACE2_DEFAULT_TUNE >> 8) & 0xFFu)) << 8);
+    fa.tail_q = f->trace_tail_lanes;
+    fa.chunks_per_wave = f->frame_chunks_per_wave;
+    hipLaunchKernelGGL((k_frame<FURNACE, BLUE>), dim3(f->frame_blocks), dim3(64), 0, q.stream, ctx->scene.d, f->tile, fa);
+    hipLaunchKernelGGL(k_frame_sum, dim3(130), dim3(256), 0, q.stream, (const uint32_t*)f->frame_counts, f->frame_blocks, f->max_bounces, q.counters);
+    HIPCHK(ctx, hipGetLastError());
+    q.chunk_base = 0;
+    q.chunk_count = f->n_local;
+    ++f->frame_launches;
+    return RT_OK;
+}
+
+int launch_frame_kernel(rt_frame* f)
+{
+    const bool blue = f->sampler == 1;
+    if (f->white_furnace) return blue ? launch_frame_kernel_t<true, true>(f) : launch_frame_kernel_t<true, false>(f);
+    return blue ? launch_frame_kernel_t<false, true>(f) : launch_frame_kernel_t<false, false>(f);
+}
+
+} // namespace
+
+extern "C" {
+
+// The recorded stages of a deferred sample, run with the stage kernels after all (somebody wants the state between two stages).
+static int deferred_materialize(rt_frame* f)
+{
+    if (!f->deferred.active) return RT_OK;
+    const uint32_t done = f->deferred.bounce;
+    const int next = f->deferred.next;
+    f->deferred.active = false;
+    if (generate_rays(f, 1) != RT_OK) return RT_ERROR;
+    for (uint32_t b = 0; b <= done; ++b)
+    {
+        const int upto = b < done ? 3 : next;                            // stages of bounce b that were recorded
+        if (upto >= 1 && rt_intersect(f, b) != RT_OK) return RT_ERROR;
+        if (upto >= 2 && rt_shade(f, b) != RT_OK) return RT_ERROR;
+        if (upto >= 3 && rt_intersect_shadow(f, b) != RT_OK) return RT_ERROR;
+    }
+    return RT_OK;
+}
+
 int rt_generate_rays(rt_frame* f)                       // GenerateRays, :516-520
 {
     FRAME_PROLOGUE(f, "rt_generate_rays");
@@ -2354,10 +2479,18 @@ int rt_generate_rays(rt_frame* f)                       // GenerateRays, :516-52
     if ((uint64_t)cp * np < n_local)
         return fail(ctx, "rt_generate_rays: RT_OPT_PATH_STATE_LIMIT_MB is too small for one sample of the whole tile "
                          "(the stage API keeps every chunk on a pipe of its own; use rt_integrate)");
+    if (f->deferred.active) return fail(ctx, "rt_generate_rays: the previous sample was not advanced (rt_advance_sample)");
     if (np <= 1)
     {
         f->stage_chunks = 1;
         if (ensure_whole_tile(f) != RT_OK) return RT_ERROR;
+        if (frame_kernel_eligible(f))
+        {
+            // RT_OPT_FRAME_KERNEL: nothing is launched yet -- the stages are recorded, rt_advance_sample launches k_frame
+            if (f->p->cur_slots != 0) return fail(ctx, "rt_generate_rays: the previous sample was not advanced (rt_advance_sample)");
+            if (ensure_slots(f, 1) != RT_OK) return RT_ERROR;
+            if (frame_kernel_eligible(f)) { f->deferred.active = true; f->deferred.bounce = 0; f->deferred.next = 0; return RT_OK; }
+        }
         return generate_rays(f, 1);
     }
     // RT_OPT_STAGE_PIPES: the sample's chunks travel side by side, one per pipe; an allocation made for a larger batch (one pipe, the
@@ -2381,6 +2514,11 @@ int rt_intersect(rt_frame* f, uint32_t bounce)          // IntersectRays, :522-5
 {
     FRAME_PROLOGUE(f, "rt_intersect");
     if (bounce > RT_MAX_BOUNCES_LIMIT) return fail(ctx, "rt_intersect: bounce out of range");
+    if (f->deferred.active)
+    {
+        if (f->deferred.next == 0 && bounce == f->deferred.bounce) { f->deferred.next = 1; return RT_OK; }
+        if (deferred_materialize(f) != RT_OK) return RT_ERROR;
+    }
     uint32_t in = bounce & 1u;
     f->timeline_bounce = bounce;
     auto one = [&]() -> int
@@ -2404,6 +2542,11 @@ int rt_shade(rt_frame* f, uint32_t bounce)              // ShadeMissedRays + Sha
     FRAME_PROLOGUE(f, "rt_shade");
     if (bounce > RT_MAX_BOUNCES_LIMIT) return fail(ctx, "rt_shade: bounce out of range");
     if (2u * (bounce + 1u) > f->log_entries) return fail(ctx, "rt_shade: bounce beyond the configured max_bounces");
+    if (f->deferred.active)
+    {
+        if (f->deferred.next == 1 && bounce == f->deferred.bounce) { f->deferred.next = 2; return RT_OK; }
+        if (deferred_materialize(f) != RT_OK) return RT_ERROR;
+    }
     auto one = [&]() -> int
     {
     uint32_t in = bounce & 1u, out = (bounce + 1u) & 1u;
@@ -2456,6 +2599,11 @@ int rt_intersect_shadow(rt_frame* f, uint32_t bounce)   // IntersectShadowRays +
 {
     FRAME_PROLOGUE(f, "rt_intersect_shadow");
     if (bounce > RT_MAX_BOUNCES_LIMIT) return fail(ctx, "rt_intersect_shadow: bounce out of range");
+    if (f->deferred.active)
+    {
+        if (f->deferred.next == 2 && bounce == f->deferred.bounce) { f->deferred.next = 0; ++f->deferred.bounce; return RT_OK; }
+        if (deferred_materialize(f) != RT_OK) return RT_ERROR;
+    }
     const uint32_t q = bounce & 1u;
     auto one = [&]() -> int
     {
@@ -2521,6 +2669,18 @@ int rt_advance_sample(rt_frame* f)                      // AdvanceSampleCount, :
 {
     if (!f) return fail(nullptr, "rt_advance_sample: frame is NULL");
     (void)hipSetDevice(f->ctx->device);
+    if (f->deferred.active)
+    {
+        // the whole sample was recorded in the canonical order: ONE launch (k_frame replays its own pixels' log, too)
+        if (f->deferred.next == 0 && f->deferred.bounce == f->max_bounces + 1u && frame_kernel_eligible(f))
+        {
+            f->deferred.active = false;
+            if (launch_frame_kernel(f) != RT_OK) return RT_ERROR;
+            f->sample_count += 1;
+            return RT_OK;
+        }
+        if (deferred_materialize(f) != RT_OK) return RT_ERROR;
+    }
     uint32_t n = f->p->cur_slots ? f->p->cur_slots : 1u;
     if (flush_stage(f) != RT_OK) return RT_ERROR;        // radiance_buffer_ += this sample's contributions (of every chunk: RT_OPT_STAGE_PIPES)
     f->sample_count += n;
@@ -2748,6 +2908,7 @@ static int fold_adapt_hook(rt_frame* f)
 int rt_integrate(rt_frame* f, uint32_t n_samples)       // n x Integrator::Integrate(), integrator.cpp:27-59
 {
     FRAME_PROLOGUE(f, "rt_integrate");
+    if (f->deferred.active) return fail(ctx, "rt_integrate: a sample of the stage API is in flight (rt_advance_sample first)");
     if (f->stage_chunks > 1)
     {
         for (const PathPipe& q : f->ps) if (q.cur_slots != 0) return fail(ctx, "rt_integrate: a sample of the stage API is in flight (rt_advance_sample first)");
@@ -2961,6 +3122,7 @@ int rt_frame_get_stats(rt_frame* f, rt_stats* out)
     if (!f || !out) return fail(nullptr, "rt_frame_get_stats: NULL argument");
     rt_ctx* ctx = f->ctx;
     (void)hipSetDevice(ctx->device);
+    if (f->deferred.active && deferred_materialize(f) != RT_OK) return RT_ERROR;     // RT_OPT_FRAME_KERNEL: the counters of the stages recorded so far
     if (join_pipes(f) != RT_OK || sync_frame_streams(f) != RT_OK) return RT_ERROR;   // a shadow trace on a side stream still counts rays
     memset(out, 0, sizeof(*out));
     for (uint32_t i = 0; i < RT_MAX_PIPES; ++i)              // the pipes' counters add up
@@ -2985,6 +3147,7 @@ int rt_frame_get_stats(rt_frame* f, rt_stats* out)
     out->path_state_bytes = (uint64_t)f->log_stride * bytes_per_path(f, f->log_ovf_blocks ? f->slots : 1u) * f->n_pipes;
     out->log_inline_entries = f->log_ovf_blocks ? f->log_inline : 0u;
     out->log_fallbacks = f->log_fallbacks;
+    out->frame_kernel_samples = (uint32_t)f->frame_launches;
     out->chunk_pixels = f->chunk_pixels;
     out->pipelines = f->n_pipes;
     return RT_OK;
@@ -3033,6 +3196,7 @@ int rt_frame_debug_read_queue(rt_frame* f, int which, uint32_t bounce, rt_ray* r
     (void)hipSetDevice(ctx->device);
     if (bounce > RT_MAX_BOUNCES_LIMIT + 1) return fail(ctx, "rt_frame_debug_read_queue: bounce out of range");
     if (f->stage_chunks > 1) return fail(ctx, "rt_frame_debug_read_queue: the sample in flight is spread over several pipes (set RT_OPT_STAGE_PIPES to 1 for the debug readers)");
+    if (f->deferred.active && deferred_materialize(f) != RT_OK) return RT_ERROR;
     if (f->p->side) HIPCHK(ctx, hipStreamSynchronize(f->p->side));      // a shadow trace may be retracting log entries
     DCounters h;
     HIPCHK(ctx, hipMemcpyAsync(&h, f->p->counters, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
@@ -3089,6 +3253,7 @@ int rt_frame_debug_read_hits(rt_frame* f, rt_hit* hits, uint32_t count)
     (void)hipSetDevice(ctx->device);
     if (count > f->log_stride) return fail(ctx, "rt_frame_debug_read_hits: count too large");
     if (f->stage_chunks > 1) return fail(ctx, "rt_frame_debug_read_hits: the sample in flight is spread over several pipes (set RT_OPT_STAGE_PIPES to 1 for the debug readers)");
+    if (f->deferred.active && deferred_materialize(f) != RT_OK) return RT_ERROR;
     std::vector<float4> h(count ? count : 1);
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     HIPCHK(ctx, hipMemcpy(h.data(), f->p->hits, (size_t)count * 16, hipMemcpyDeviceToHost));

@@ -398,6 +398,197 @@ RT_DEV float SampleBlueNoise(const ShadeArgs& a, uint32_t px, uint32_t py, uint3
     return (0.5f + (float)value) / 256.0f;
 }
 
+// One queue entry of k_shade -- Miss (miss.cl:65-76) or HitSurface (hit_surface.cl:79-184) with the log entries, the deferred direct sample and the
+// BSDF sample -- as a function of its own: k_shade calls it per thread and compacts the outputs per block, k_frame (frame_kernels.h) per lane of a
+// wave that carries its own paths through the bounces.
+template <bool FURNACE, bool BLUE, bool NEE, bool COMPACT>
+RT_DEV void shade_entry(const DScene& sc, const DTile& tile, const ShadeArgs& a, const uint32_t i, bool& want_shadow, bool& want_next, bool& no_block,
+    uint32_t& next_flag, float4& sh_o, float4& sh_d, float4& nx_o, float4& nx_d, float4& nx_t, uint32_t& sh_entry)
+{
+    float4 hit = a.hits[i];
+    float4 rd = a.in_d4[i];
+    uint32_t prim = __float_as_uint(hit.z);
+    uint32_t id = __float_as_uint(rd.w);                               // slot * n_local + local pixel
+    uint32_t slot = id / a.n_local;
+    uint32_t pix = id - slot * a.n_local;
+    uint32_t sample_idx = a.sample_base + slot;
+    float4 thr4 = a.in_thr[i];
+    uint32_t nlog = a.count_in_ray ? (__float_as_uint(thr4.w) & 0x7FFFFFFFu) : a.log.cnt[id];   // contributions logged so far
+    // compact log: this bounce may write entries nlog and nlog + 1; those beyond the inline rows go to the path's overflow
+    // block, which the previous bounce allocated (below) whenever that could happen
+    uint32_t oblk = RT_EMPTY_REF;
+    if (COMPACT && nlog + 1u >= a.log.inline_entries) oblk = a.log.ovf_slot[id];
+    no_block = oblk == RT_EMPTY_REF;
+    // one entry of this path's log (the full layout: row nlog, column id)
+    auto put = [&](float x, float y, float z)
+    {
+        if (COMPACT) log_put(a.log, nlog, id, oblk, x, y, z);
+        else log_store(a.log.rlog, (size_t)nlog * a.log.stride + id, x, y, z);
+    };
+    // NEE: bit 31 of the same word = the path's last scattering event was a delta one (set by the previous bounce)
+    const bool prev_delta = NEE && (__float_as_uint(thr4.w) >> 31) != 0u;
+    f3 hit_throughput = F3(thr4.x, thr4.y, thr4.z);
+
+    if (prim == RT_INVALID_ID)
+    {
+        // Miss, miss.cl:65-76
+        f3 sky = FURNACE ? F3s(0.5f) : SampleSky(sc, F3(rd.x, rd.y, rd.z));
+        f3 add = sky * hit_throughput;
+        put(add.x, add.y, add.z);   // radiance[pix] += ...
+        ++nlog;
+    }
+    else
+    {
+        // HitSurface, hit_surface.cl:79-184
+        f3 incoming = F3(-rd.x, -rd.y, -rd.z);
+        uint32_t lp = a.pix_base + pix;                                  // local pixel of the tile
+        uint32_t ly = lp / tile.width;
+        uint32_t px = lp - ly * tile.width;
+        uint32_t py = tile_global_row(tile, ly);
+
+        const float4* tp = sc.tris_sh + (size_t)prim * 8;
+        float4 q0 = tp[0], q1 = tp[1], q2 = tp[2], q3 = tp[3], q4 = tp[4], q5 = tp[5], q6 = tp[6];
+        f3 p1 = xyz(q0), p2 = xyz(q1), p3 = xyz(q2);
+        f3 n1 = xyz(q3), n2 = xyz(q4), n3 = xyz(q5);
+        float bu = hit.x, bv = hit.y;
+        float w0 = 1.0f - bu - bv;
+        f3 position = p1 * w0 + p2 * bu + p3 * bv;
+        f3 geometry_normal = normalize3(cross3(p2 - p1, p3 - p1));
+        f2 texcoord;
+        texcoord.x = q0.w * w0 + q2.w * bu + q4.w * bv;                // uv1.x, uv2.x, uv3.x
+        texcoord.y = q1.w * w0 + q3.w * bu + q5.w * bv;                // uv1.y, uv2.y, uv3.y
+        f3 normal = normalize3(n1 * w0 + n2 * bu + n3 * bv);
+
+        Material material;
+        ApplyTextures(sc, __float_as_uint(q6.x), material, texcoord);
+
+        // NEE: light gathered from the emissive triangles by next-event estimation is not counted again when a
+        // scattered ray happens to hit one -- emission is added for camera rays and after delta events only
+        if (!FURNACE && (!NEE || a.bounce == 0u || prev_delta))
+        {
+            if (material.emission.x * 1.0f + material.emission.y * 1.0f + material.emission.z * 1.0f > 0.0f)
+            {
+                f3 e = hit_throughput * material.emission;
+                put(e.x, e.y, e.z);         // radiance[pix] += ...
+                ++nlog;
+            }
+        }
+
+        uint32_t sample_seed = BLUE ? 0u : SampleRandomSampleSeed(SampleRandomPixelSeed(px, py), sample_idx);
+        // SampleRandom(x, y, sample, bounce, type), sampling.h:64-82
+        auto draw = [&](uint32_t type) -> float
+        {
+            return BLUE ? SampleBlueNoise(a, px, py, sample_idx, a.bounce * 5u + type)
+                        : SampleRandomDim(sample_seed, a.bounce, type);
+        };
+
+        // Direct lighting :115-145 (Light_Sample light.h:30-65)
+        {
+            float s_light = draw(4);
+            const uint32_t n_lights = NEE ? sc.light_count + sc.emissive_count : sc.light_count;
+            int light_idx = cl_clampi((int)(s_light * (float)n_lights), 0, (int)n_lights - 1);
+            float pdf = 1.0f / (float)n_lights;
+            f3 light_radiance;
+            f3 outgoing;
+            if (!NEE || (uint32_t)light_idx < sc.light_count)
+            {
+                float4 lo = sc.lights[light_idx * 3 + 0], lr = sc.lights[light_idx * 3 + 1];
+                uint32_t ltype = __float_as_uint(sc.lights[light_idx * 3 + 2].x);
+                light_radiance = xyz(lr);
+                if (ltype == RT_LIGHT_TYPE_POINT)
+                {
+                    f3 to_light = xyz(lo) - position;
+                    float sq_length = dot3(to_light, to_light);
+                    light_radiance = light_radiance / sq_length;
+                    outgoing = to_light;
+                }
+                else
+                {
+                    outgoing = xyz(lo) * RT_MAX_RENDER_DIST;
+                }
+            }
+            else
+            {
+                // an emissive triangle, sampled uniformly by area: u1 = what the index left of s * n, u2 = the
+                // BSDF-layer sample of this bounce (oracle.c: Light_SampleWithEmissive, the same operations)
+                const uint32_t lt = sc.emissive[(uint32_t)light_idx - sc.light_count];
+                float u1 = s_light * (float)n_lights - (float)light_idx;
+                u1 = cl_min(cl_max(u1, 0.0f), 1.0f);
+                const float su = __builtin_sqrtf(u1);
+                const float b0 = 1.0f - su, b1 = draw(1) * su;
+                const float b2 = 1.0f - b0 - b1;
+                const float4* lq = sc.tris_sh + (size_t)lt * 8;
+                const float4 l0 = lq[0], l1 = lq[1], l2 = lq[2], l3 = lq[3], l4 = lq[4], l5 = lq[5], l6 = lq[6];
+                const f3 a1 = xyz(l0), a2 = xyz(l1), a3 = xyz(l2);
+                const f3 lp = a1 * b0 + a2 * b1 + a3 * b2;
+                f2 luv;
+                luv.x = l0.w * b0 + l2.w * b1 + l4.w * b2;
+                luv.y = l1.w * b0 + l3.w * b1 + l5.w * b2;
+                Material lm;
+                ApplyTextures(sc, __float_as_uint(l6.x), lm, luv);
+                const f3 nl = cross3(a2 - a1, a3 - a1);                  // length = 2 * area
+                const f3 to_light = lp - position;
+                const float d2 = dot3(to_light, to_light);
+                float g = 0.0f;
+                // front side only: the reference's ray-triangle test culls back faces (det = -dir . nl < 1e-8), so a
+                // triangle is visible, and its emission counted, only from the side its normal points to
+                const float dist = __builtin_sqrtf(d2);
+                const float nd = -dot3(nl, to_light);                    // 2 * area * d * cos_l
+                if (d2 > 0.0f && nd / dist >= 1e-8f) g = (nd * 0.5f) / (dist * d2);   // cos_l * area / d^2
+                // the shadow ray starts EPS along the normal but is aimed from `position`: it meets the emitter's plane
+                // up to EPS / |cos_l| early.  Stop short by twice that + 2^-10 d; drop what leaves nothing (oracle.c)
+                float keep = 1.0f - 0.0009765625f - (2.0f * RT_EPS) * __builtin_sqrtf(dot3(nl, nl)) / nd;
+                if (!(keep > 0.0f) || !(g > 0.0f)) { keep = 1.0f; g = 0.0f; }
+                outgoing = to_light * keep;
+                light_radiance = lm.emission * g;
+            }
+            float distance_to_light = length3(outgoing);
+            outgoing = normalize3(outgoing);
+            f3 brdf = EvaluateMaterial(material, normal, incoming, outgoing);
+            float m = cl_max(dot3(outgoing, normal), 0.0f);
+            f3 lsamp = ((light_radiance * hit_throughput) * brdf / pdf) * m;
+            want_shadow = (pdf > 0.0f) && (dot3(lsamp, lsamp) > 0.0f);
+            f3 so = position + normal * RT_EPS;
+            sh_o = make_float4(so.x, so.y, so.z, distance_to_light);
+            sh_d = make_float4(outgoing.x, outgoing.y, outgoing.z, __uint_as_float(id));
+            sh_entry = nlog;
+            if (want_shadow)
+            {
+                // deferred direct sample (direct_light_samples_buffer_): logged now, retracted
+                // by the shadow trace if the light turns out to be occluded
+                put(lsamp.x, lsamp.y, lsamp.z);
+                ++nlog;
+            }
+        }
+
+        // Indirect lighting :148-184.  On the last bounce the outgoing ray is never traced (and its throughput
+        // never read): the whole block is skipped, wave-uniformly.
+        if (a.emit_outgoing != 0)
+        {
+            f2 s;
+            s.x = draw(2);
+            s.y = draw(3);
+            float s1 = draw(1);
+            float pdf = 0.0f;
+            f3 outgoing;
+            float offset;
+            bool delta;
+            f3 bxdf = SampleBxdf<FURNACE>(s1, s, material, normal, incoming, outgoing, pdf, offset, delta);
+            if (NEE && delta) next_flag = 0x80000000u;
+            f3 throughput = F3s(0.0f);
+            if ((double)pdf > 0.0) throughput = bxdf / pdf;
+            f3 new_thr = hit_throughput * throughput;                 // throughputs[pixel] *= throughput
+            want_next = (double)pdf > 0.0;
+            f3 oo = position + geometry_normal * RT_EPS * offset;
+            nx_o = make_float4(oo.x, oo.y, oo.z, RT_MAX_RENDER_DIST);
+            nx_d = make_float4(outgoing.x, outgoing.y, outgoing.z, rd.w);
+            nx_t = make_float4(new_thr.x, new_thr.y, new_thr.z, 0.0f);
+        }
+    }
+    nx_t.w = __uint_as_float(nlog | next_flag);
+    if (!a.count_in_ray || ((!want_next || a.final_bounce) && nlog != 0u)) a.log.cnt[id] = nlog;   // the path's final count is what k_flush replays
+}
+
 // NEE: the scene asked for next-event estimation over the emissive triangles too (RT_SCENE_EMISSIVE_NEE, an opt-in
 // extension: DESIGN.md 7b); the other instances are the reference's estimator.
 // COMPACT: the radiance log is in its compact layout (DLog; RT_OPT_COMPACT_LOG): separate instances, so that the default ones
@@ -457,191 +648,7 @@ __global__ __launch_bounds__(RT_SHADE_BLOCK) __attribute__((amdgpu_waves_per_eu(
     float4 sh_o = make_float4(0, 0, 0, 0), sh_d = sh_o, nx_o = sh_o, nx_d = sh_o, nx_t = sh_o;
     uint32_t sh_entry = 0;
 
-    if (active)
-    {
-        float4 hit = a.hits[i];
-        float4 rd = a.in_d4[i];
-        uint32_t prim = __float_as_uint(hit.z);
-        uint32_t id = __float_as_uint(rd.w);                               // slot * n_local + local pixel
-        uint32_t slot = id / a.n_local;
-        uint32_t pix = id - slot * a.n_local;
-        uint32_t sample_idx = a.sample_base + slot;
-        float4 thr4 = a.in_thr[i];
-        uint32_t nlog = a.count_in_ray ? (__float_as_uint(thr4.w) & 0x7FFFFFFFu) : a.log.cnt[id];   // contributions logged so far
-        // compact log: this bounce may write entries nlog and nlog + 1; those beyond the inline rows go to the path's overflow
-        // block, which the previous bounce allocated (below) whenever that could happen
-        uint32_t oblk = RT_EMPTY_REF;
-        if (COMPACT && nlog + 1u >= a.log.inline_entries) oblk = a.log.ovf_slot[id];
-        no_block = oblk == RT_EMPTY_REF;
-        // one entry of this path's log (the full layout: row nlog, column id)
-        auto put = [&](float x, float y, float z)
-        {
-            if (COMPACT) log_put(a.log, nlog, id, oblk, x, y, z);
-            else log_store(a.log.rlog, (size_t)nlog * a.log.stride + id, x, y, z);
-        };
-        // NEE: bit 31 of the same word = the path's last scattering event was a delta one (set by the previous bounce)
-        const bool prev_delta = NEE && (__float_as_uint(thr4.w) >> 31) != 0u;
-        f3 hit_throughput = F3(thr4.x, thr4.y, thr4.z);
-
-        if (prim == RT_INVALID_ID)
-        {
-            // Miss, miss.cl:65-76
-            f3 sky = FURNACE ? F3s(0.5f) : SampleSky(sc, F3(rd.x, rd.y, rd.z));
-            f3 add = sky * hit_throughput;
-            put(add.x, add.y, add.z);   // radiance[pix] += ...
-            ++nlog;
-        }
-        else
-        {
-            // HitSurface, hit_surface.cl:79-184
-            f3 incoming = F3(-rd.x, -rd.y, -rd.z);
-            uint32_t lp = a.pix_base + pix;                                  // local pixel of the tile
-            uint32_t ly = lp / tile.width;
-            uint32_t px = lp - ly * tile.width;
-            uint32_t py = tile_global_row(tile, ly);
-
-            const float4* tp = sc.tris_sh + (size_t)prim * 8;
-            float4 q0 = tp[0], q1 = tp[1], q2 = tp[2], q3 = tp[3], q4 = tp[4], q5 = tp[5], q6 = tp[6];
-            f3 p1 = xyz(q0), p2 = xyz(q1), p3 = xyz(q2);
-            f3 n1 = xyz(q3), n2 = xyz(q4), n3 = xyz(q5);
-            float bu = hit.x, bv = hit.y;
-            float w0 = 1.0f - bu - bv;
-            f3 position = p1 * w0 + p2 * bu + p3 * bv;
-            f3 geometry_normal = normalize3(cross3(p2 - p1, p3 - p1));
-            f2 texcoord;
-            texcoord.x = q0.w * w0 + q2.w * bu + q4.w * bv;                // uv1.x, uv2.x, uv3.x
-            texcoord.y = q1.w * w0 + q3.w * bu + q5.w * bv;                // uv1.y, uv2.y, uv3.y
-            f3 normal = normalize3(n1 * w0 + n2 * bu + n3 * bv);
-
-            Material material;
-            ApplyTextures(sc, __float_as_uint(q6.x), material, texcoord);
-
-            // NEE: light gathered from the emissive triangles by next-event estimation is not counted again when a
-            // scattered ray happens to hit one -- emission is added for camera rays and after delta events only
-            if (!FURNACE && (!NEE || a.bounce == 0u || prev_delta))
-            {
-                if (material.emission.x * 1.0f + material.emission.y * 1.0f + material.emission.z * 1.0f > 0.0f)
-                {
-                    f3 e = hit_throughput * material.emission;
-                    put(e.x, e.y, e.z);         // radiance[pix] += ...
-                    ++nlog;
-                }
-            }
-
-            uint32_t sample_seed = BLUE ? 0u : SampleRandomSampleSeed(SampleRandomPixelSeed(px, py), sample_idx);
-            // SampleRandom(x, y, sample, bounce, type), sampling.h:64-82
-            auto draw = [&](uint32_t type) -> float
-            {
-                return BLUE ? SampleBlueNoise(a, px, py, sample_idx, a.bounce * 5u + type)
-                            : SampleRandomDim(sample_seed, a.bounce, type);
-            };
-
-            // Direct lighting :115-145 (Light_Sample light.h:30-65)
-            {
-                float s_light = draw(4);
-                const uint32_t n_lights = NEE ? sc.light_count + sc.emissive_count : sc.light_count;
-                int light_idx = cl_clampi((int)(s_light * (float)n_lights), 0, (int)n_lights - 1);
-                float pdf = 1.0f / (float)n_lights;
-                f3 light_radiance;
-                f3 outgoing;
-                if (!NEE || (uint32_t)light_idx < sc.light_count)
-                {
-                    float4 lo = sc.lights[light_idx * 3 + 0], lr = sc.lights[light_idx * 3 + 1];
-                    uint32_t ltype = __float_as_uint(sc.lights[light_idx * 3 + 2].x);
-                    light_radiance = xyz(lr);
-                    if (ltype == RT_LIGHT_TYPE_POINT)
-                    {
-                        f3 to_light = xyz(lo) - position;
-                        float sq_length = dot3(to_light, to_light);
-                        light_radiance = light_radiance / sq_length;
-                        outgoing = to_light;
-                    }
-                    else
-                    {
-                        outgoing = xyz(lo) * RT_MAX_RENDER_DIST;
-                    }
-                }
-                else
-                {
-                    // an emissive triangle, sampled uniformly by area: u1 = what the index left of s * n, u2 = the
-                    // BSDF-layer sample of this bounce (oracle.c: Light_SampleWithEmissive, the same operations)
-                    const uint32_t lt = sc.emissive[(uint32_t)light_idx - sc.light_count];
-                    float u1 = s_light * (float)n_lights - (float)light_idx;
-                    u1 = cl_min(cl_max(u1, 0.0f), 1.0f);
-                    const float su = __builtin_sqrtf(u1);
-                    const float b0 = 1.0f - su, b1 = draw(1) * su;
-                    const float b2 = 1.0f - b0 - b1;
-                    const float4* lq = sc.tris_sh + (size_t)lt * 8;
-                    const float4 l0 = lq[0], l1 = lq[1], l2 = lq[2], l3 = lq[3], l4 = lq[4], l5 = lq[5], l6 = lq[6];
-                    const f3 a1 = xyz(l0), a2 = xyz(l1), a3 = xyz(l2);
-                    const f3 lp = a1 * b0 + a2 * b1 + a3 * b2;
-                    f2 luv;
-                    luv.x = l0.w * b0 + l2.w * b1 + l4.w * b2;
-                    luv.y = l1.w * b0 + l3.w * b1 + l5.w * b2;
-                    Material lm;
-                    ApplyTextures(sc, __float_as_uint(l6.x), lm, luv);
-                    const f3 nl = cross3(a2 - a1, a3 - a1);                  // length = 2 * area
-                    const f3 to_light = lp - position;
-                    const float d2 = dot3(to_light, to_light);
-                    float g = 0.0f;
-                    // front side only: the reference's ray-triangle test culls back faces (det = -dir . nl < 1e-8), so a
-                    // triangle is visible, and its emission counted, only from the side its normal points to
-                    const float dist = __builtin_sqrtf(d2);
-                    const float nd = -dot3(nl, to_light);                    // 2 * area * d * cos_l
-                    if (d2 > 0.0f && nd / dist >= 1e-8f) g = (nd * 0.5f) / (dist * d2);   // cos_l * area / d^2
-                    // the shadow ray starts EPS along the normal but is aimed from `position`: it meets the emitter's plane
-                    // up to EPS / |cos_l| early.  Stop short by twice that + 2^-10 d; drop what leaves nothing (oracle.c)
-                    float keep = 1.0f - 0.0009765625f - (2.0f * RT_EPS) * __builtin_sqrtf(dot3(nl, nl)) / nd;
-                    if (!(keep > 0.0f) || !(g > 0.0f)) { keep = 1.0f; g = 0.0f; }
-                    outgoing = to_light * keep;
-                    light_radiance = lm.emission * g;
-                }
-                float distance_to_light = length3(outgoing);
-                outgoing = normalize3(outgoing);
-                f3 brdf = EvaluateMaterial(material, normal, incoming, outgoing);
-                float m = cl_max(dot3(outgoing, normal), 0.0f);
-                f3 lsamp = ((light_radiance * hit_throughput) * brdf / pdf) * m;
-                want_shadow = (pdf > 0.0f) && (dot3(lsamp, lsamp) > 0.0f);
-                f3 so = position + normal * RT_EPS;
-                sh_o = make_float4(so.x, so.y, so.z, distance_to_light);
-                sh_d = make_float4(outgoing.x, outgoing.y, outgoing.z, __uint_as_float(id));
-                sh_entry = nlog;
-                if (want_shadow)
-                {
-                    // deferred direct sample (direct_light_samples_buffer_): logged now, retracted
-                    // by the shadow trace if the light turns out to be occluded
-                    put(lsamp.x, lsamp.y, lsamp.z);
-                    ++nlog;
-                }
-            }
-
-            // Indirect lighting :148-184.  On the last bounce the outgoing ray is never traced (and its throughput
-            // never read): the whole block is skipped, wave-uniformly.
-            if (a.emit_outgoing != 0)
-            {
-                f2 s;
-                s.x = draw(2);
-                s.y = draw(3);
-                float s1 = draw(1);
-                float pdf = 0.0f;
-                f3 outgoing;
-                float offset;
-                bool delta;
-                f3 bxdf = SampleBxdf<FURNACE>(s1, s, material, normal, incoming, outgoing, pdf, offset, delta);
-                if (NEE && delta) next_flag = 0x80000000u;
-                f3 throughput = F3s(0.0f);
-                if ((double)pdf > 0.0) throughput = bxdf / pdf;
-                f3 new_thr = hit_throughput * throughput;                 // throughputs[pixel] *= throughput
-                want_next = (double)pdf > 0.0;
-                f3 oo = position + geometry_normal * RT_EPS * offset;
-                nx_o = make_float4(oo.x, oo.y, oo.z, RT_MAX_RENDER_DIST);
-                nx_d = make_float4(outgoing.x, outgoing.y, outgoing.z, rd.w);
-                nx_t = make_float4(new_thr.x, new_thr.y, new_thr.z, 0.0f);
-            }
-        }
-        nx_t.w = __uint_as_float(nlog | next_flag);
-        if (!a.count_in_ray || ((!want_next || a.final_bounce) && nlog != 0u)) a.log.cnt[id] = nlog;   // the path's final count is what k_flush replays
-    }
+    if (active) shade_entry<FURNACE, BLUE, NEE, COMPACT>(sc, tile, a, i, want_shadow, want_next, no_block, next_flag, sh_o, sh_d, nx_o, nx_d, nx_t, sh_entry);
     // Compact log: the next bounce writes entries nlog, nlog + 1 -- a path that goes on and could cross the inline rows gets its
     // overflow block now (nx_t.w = its entries so far, nx_d.w = its id).  Entries so far <= 2 (bounce + 1): before that reaches
     // inline_entries - 1 no path of the launch can want one.

@@ -76,6 +76,125 @@ RT_DEV void log_retract(const DLog& L, uint32_t entry, uint32_t id)
     log_put(L, entry, id, slot, 0.0f, 0.0f, 0.0f);
 }
 
+// One ray through the reference's loop (trace_bvh.cl:99-211) on the child-pair records: the per-ray walk of k_trace_v1, and the walk k_frame gives the
+// rays its wide-tree body does not take (RT_SIGN_SLOW).  `push(sp, e)` / `pop(sp)` are the caller's stack (LDS + spill area, or the spill area alone).
+// Returns occluded (SHADOW) / writes the closest hit.
+template <bool SHADOW, class Push, class Pop>
+RT_DEV bool v1_trace_ray(const DScene& sc, const float4 ro, const float4 rd, Push&& push, Pop&& pop, float4& hit_out)
+{
+    f3 org = F3(ro.x, ro.y, ro.z), dir = F3(rd.x, rd.y, rd.z);
+    const float t_min = 0.0f;                                        // origin.w is 0 for every ray the path emits
+    float t_max = ro.w;
+    f3 inv = F3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);           // trace_bvh.cl:125
+    uint32_t sign_bits = (inv.x < 0.0f ? 1u : 0u) | (inv.y < 0.0f ? 2u : 0u) | (inv.z < 0.0f ? 4u : 0u);
+
+    uint32_t hit_prim = RT_INVALID_ID;
+    float hit_u = 0.0f, hit_v = 0.0f, hit_t = 0.0f;
+    bool occluded = false;
+
+    int sp = 0;
+    uint32_t ref = sc.root_ref;
+    float entry;
+    bool alive = box_test(sc.root_min[0], sc.root_min[1], sc.root_min[2], sc.root_max[0], sc.root_max[1],
+        sc.root_max[2], org, inv, t_min, t_max, entry);
+
+    while (alive)
+    {
+        bool need_pop;
+        if (ref & RT_LEAF_BIT)
+        {
+            // leaf: test its triangles in array order (trace_bvh.cl:155-169)
+            uint32_t prim = ref & ~RT_LEAF_BIT;
+            bool last;
+            do
+            {
+                const float4* tp = sc.tris_rt + (size_t)prim * 4;
+                float4 a = tp[0], b = tp[1], cc = tp[2];
+                last = a.w != 0.0f;
+                f3 p1 = F3(a.x, a.y, a.z), e1 = F3(b.x, b.y, b.z), e2 = F3(cc.x, cc.y, cc.z);
+                // RayTriangle, trace_bvh.cl:28-73
+                f3 pvec = cross3(dir, e2);
+                float det = dot3(e1, pvec);
+                if (!(det < 1e-8f || -det > 1e-8f))
+                {
+                    float inv_det = 1.0f / det;
+                    f3 tvec = org - p1;
+                    float u = dot3(tvec, pvec) * inv_det;
+                    if (!(u < 0.0f || u > 1.0f))
+                    {
+                        f3 qvec = cross3(tvec, e1);
+                        float v = dot3(dir, qvec) * inv_det;
+                        if (!(v < 0.0f || u + v > 1.0f))
+                        {
+                            float t = dot3(e2, qvec) * inv_det;
+                            if (!(t < t_min || t > t_max))
+                            {
+                                hit_u = u; hit_v = v; hit_t = t; hit_prim = prim;
+                                t_max = t;                           // :162
+                                if (SHADOW) { occluded = true; }
+                            }
+                        }
+                    }
+                }
+                ++prim;
+            } while (!last && !(SHADOW && occluded));
+            if (SHADOW && occluded) break;                           // goto endtrace, :164-167
+            need_pop = true;
+        }
+        else
+        {
+            const float4* np = sc.nodes + (size_t)ref * 4;
+            float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+            uint32_t c0 = __float_as_uint(n3.x), c1 = __float_as_uint(n3.y), axis = __float_as_uint(n3.z);
+            float a0, a1;
+            bool h0 = box_test(RT_NODE_C0(n0, n1, n2), org, inv, t_min, t_max, a0);
+            bool h1 = box_test(RT_NODE_C1(n0, n1, n2), org, inv, t_min, t_max, a1);
+            h1 = h1 && (c1 != RT_EMPTY_REF);
+            // near child: first child unless the ray is negative along the split axis (:181-190)
+            bool swap = (sign_bits >> axis) & 1u;
+            uint32_t near_ref = swap ? c1 : c0, far_ref = swap ? c0 : c1;
+            bool near_hit = swap ? h1 : h0, far_hit = swap ? h0 : h1;
+            float far_entry = swap ? a0 : a1;
+            if (near_hit)
+            {
+                if (far_hit)
+                {
+                    push(sp, make_uint2(far_ref, __float_as_uint(far_entry)));
+                    ++sp;
+                }
+                ref = near_ref;
+                need_pop = false;
+            }
+            else if (far_hit)
+            {
+                ref = far_ref;
+                need_pop = false;
+            }
+            else
+            {
+                need_pop = true;
+            }
+        }
+        if (need_pop)
+        {
+            alive = false;
+            while (sp > 0)
+            {
+                --sp;
+                uint2 e = pop(sp);
+                if (t_max >= __uint_as_float(e.y))                   // box re-test at pop time
+                {
+                    ref = e.x;
+                    alive = true;
+                    break;
+                }
+            }
+        }
+    }
+    hit_out = make_float4(hit_u, hit_v, __uint_as_float(hit_prim), hit_t);
+    return occluded;
+}
+
 template <bool SHADOW>
 __global__ __launch_bounds__(64) void k_trace_v1(DScene sc, const float4* __restrict__ o4, const float4* __restrict__ d4,
     const uint32_t* __restrict__ aux /* shadow rays: log entry of the deferred direct sample */, const uint32_t* __restrict__ count_ptr,
@@ -92,6 +211,8 @@ __global__ __launch_bounds__(64) void k_trace_v1(DScene sc, const float4* __rest
     const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
     const uint32_t cpx = (nchunks + 7u) >> 3;
     uint2* my_spill = spill + (size_t)(blockIdx.x * 64u + lane) * (RT_TRACE_STACK_MAX - RT_TRACE_STACK_LDS);
+    auto push = [&](int sp, uint2 e) { if (sp < RT_TRACE_STACK_LDS) stack[sp][lane] = e; else my_spill[sp - RT_TRACE_STACK_LDS] = e; };
+    auto pop = [&](int sp) -> uint2 { return (sp < RT_TRACE_STACK_LDS) ? stack[sp][lane] : my_spill[sp - RT_TRACE_STACK_LDS]; };
 
     for (uint32_t c = slot; c < cpx; c += per_xcd)
     {
@@ -100,118 +221,8 @@ __global__ __launch_bounds__(64) void k_trace_v1(DScene sc, const float4* __rest
         if (i >= count) continue;
 
         float4 ro = o4[i], rd = d4[i];
-        f3 org = F3(ro.x, ro.y, ro.z), dir = F3(rd.x, rd.y, rd.z);
-        const float t_min = 0.0f;                                        // origin.w is 0 for every ray the path emits
-        float t_max = ro.w;
-        f3 inv = F3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);           // trace_bvh.cl:125
-        uint32_t sign_bits = (inv.x < 0.0f ? 1u : 0u) | (inv.y < 0.0f ? 2u : 0u) | (inv.z < 0.0f ? 4u : 0u);
-
-        uint32_t hit_prim = RT_INVALID_ID;
-        float hit_u = 0.0f, hit_v = 0.0f, hit_t = 0.0f;
-        bool occluded = false;
-
-        int sp = 0;
-        uint32_t ref = sc.root_ref;
-        float entry;
-        bool alive = box_test(sc.root_min[0], sc.root_min[1], sc.root_min[2], sc.root_max[0], sc.root_max[1],
-            sc.root_max[2], org, inv, t_min, t_max, entry);
-
-        while (alive)
-        {
-            bool need_pop;
-            if (ref & RT_LEAF_BIT)
-            {
-                // leaf: test its triangles in array order (trace_bvh.cl:155-169)
-                uint32_t prim = ref & ~RT_LEAF_BIT;
-                bool last;
-                do
-                {
-                    const float4* tp = sc.tris_rt + (size_t)prim * 4;
-                    float4 a = tp[0], b = tp[1], cc = tp[2];
-                    last = a.w != 0.0f;
-                    f3 p1 = F3(a.x, a.y, a.z), e1 = F3(b.x, b.y, b.z), e2 = F3(cc.x, cc.y, cc.z);
-                    // RayTriangle, trace_bvh.cl:28-73
-                    f3 pvec = cross3(dir, e2);
-                    float det = dot3(e1, pvec);
-                    if (!(det < 1e-8f || -det > 1e-8f))
-                    {
-                        float inv_det = 1.0f / det;
-                        f3 tvec = org - p1;
-                        float u = dot3(tvec, pvec) * inv_det;
-                        if (!(u < 0.0f || u > 1.0f))
-                        {
-                            f3 qvec = cross3(tvec, e1);
-                            float v = dot3(dir, qvec) * inv_det;
-                            if (!(v < 0.0f || u + v > 1.0f))
-                            {
-                                float t = dot3(e2, qvec) * inv_det;
-                                if (!(t < t_min || t > t_max))
-                                {
-                                    hit_u = u; hit_v = v; hit_t = t; hit_prim = prim;
-                                    t_max = t;                           // :162
-                                    if (SHADOW) { occluded = true; }
-                                }
-                            }
-                        }
-                    }
-                    ++prim;
-                } while (!last && !(SHADOW && occluded));
-                if (SHADOW && occluded) break;                           // goto endtrace, :164-167
-                need_pop = true;
-            }
-            else
-            {
-                const float4* np = sc.nodes + (size_t)ref * 4;
-                float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
-                uint32_t c0 = __float_as_uint(n3.x), c1 = __float_as_uint(n3.y), axis = __float_as_uint(n3.z);
-                float a0, a1;
-                bool h0 = box_test(RT_NODE_C0(n0, n1, n2), org, inv, t_min, t_max, a0);
-                bool h1 = box_test(RT_NODE_C1(n0, n1, n2), org, inv, t_min, t_max, a1);
-                h1 = h1 && (c1 != RT_EMPTY_REF);
-                // near child: first child unless the ray is negative along the split axis (:181-190)
-                bool swap = (sign_bits >> axis) & 1u;
-                uint32_t near_ref = swap ? c1 : c0, far_ref = swap ? c0 : c1;
-                bool near_hit = swap ? h1 : h0, far_hit = swap ? h0 : h1;
-                float far_entry = swap ? a0 : a1;
-                if (near_hit)
-                {
-                    if (far_hit)
-                    {
-                        uint2 e = make_uint2(far_ref, __float_as_uint(far_entry));
-                        if (sp < RT_TRACE_STACK_LDS) stack[sp][lane] = e;
-                        else my_spill[sp - RT_TRACE_STACK_LDS] = e;
-                        ++sp;
-                    }
-                    ref = near_ref;
-                    need_pop = false;
-                }
-                else if (far_hit)
-                {
-                    ref = far_ref;
-                    need_pop = false;
-                }
-                else
-                {
-                    need_pop = true;
-                }
-            }
-            if (need_pop)
-            {
-                alive = false;
-                while (sp > 0)
-                {
-                    --sp;
-                    uint2 e = (sp < RT_TRACE_STACK_LDS) ? stack[sp][lane] : my_spill[sp - RT_TRACE_STACK_LDS];
-                    if (t_max >= __uint_as_float(e.y))                   // box re-test at pop time
-                    {
-                        ref = e.x;
-                        alive = true;
-                        break;
-                    }
-                }
-            }
-        }
-
+        float4 hit;
+        const bool occluded = v1_trace_ray<SHADOW>(sc, ro, rd, push, pop, hit);
         if (SHADOW)
         {
             // AccumulateDirectSamples (accumulate_direct_samples.cl:46-52) fused: k_shade
@@ -223,7 +234,7 @@ __global__ __launch_bounds__(64) void k_trace_v1(DScene sc, const float4* __rest
         }
         else
         {
-            hits[i] = make_float4(hit_u, hit_v, __uint_as_float(hit_prim), hit_t);
+            hits[i] = hit;
         }
     }
 }
@@ -645,25 +656,29 @@ RT_DEV void w4_test_slots(const float4 q0, const float4 q1, const float4 q2, con
 // batch: every launch of the reference's one-sample-per-frame pattern).  It is an instance of its own because the extra loop
 // costs the three hot loops their register allocation: 75 VGPRs (6 waves per SIMD instead of 7), or 72 with five dwords of
 // phase A spilled -- either way ~2 % of a large launch (profiles/r04_call04_kernel_ab.log), which has no use for loop D.
-template <bool SHADOW, int STACK, bool TIMELINE = false, bool TAIL = false>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TAIL ? 7 : 4, 8))) void k_trace_w4(DScene sc, const float4* __restrict__ o4, const float4* __restrict__ d4,
-    const uint32_t* __restrict__ aux /* shadow rays: log entry of the deferred direct sample */, const uint32_t* __restrict__ count_ptr,
+// PRIVATE (round 5, k_frame below): the body as ONE WAVE's walk over a queue of its own -- rays 0 .. count - 1 of the wave live in ITS chunks of the
+// arrays (position p at chunk priv_first + (p >> 6) * priv_stride, slot p & 63), handed out to idle lanes in order, no atomics, nothing shared; a
+// ray the wide walk does not take (RT_SIGN_SLOW) comes back through `slow` for the caller to trace.  block_id / grid_blocks stand in for blockIdx.x /
+// gridDim.x (the kernel below passes them; a wave of k_frame passes what gives it its own spill area).
+template <bool SHADOW, int STACK, bool TIMELINE, bool TAIL, bool PRIVATE>
+RT_DEV void w4_trace_body(const DScene& sc, const float4* __restrict__ o4, const float4* __restrict__ d4,
+    const uint32_t* __restrict__ aux /* shadow rays: log entry of the deferred direct sample */, const uint32_t count,
     uint32_t* __restrict__ heads,
-    float4* __restrict__ hits, DLog log, uint2* __restrict__ spill, uint32_t tune,
+    float4* __restrict__ hits, const DLog& log, uint2* __restrict__ spill, uint32_t tune,
     uint32_t* __restrict__ slow_list, uint32_t* __restrict__ slow_count, uint32_t* __restrict__ stat_counts /* [0] spills, [1] slow rays */,
     unsigned long long* __restrict__ timeline /* TIMELINE: DCounters::tl_start + timeline_slot (rt_frame_debug_timeline) */,
     uint32_t timeline_slot, uint32_t chunk_below /* launches of fewer rays run in chunk mode (below) */,
     uint32_t tail_q /* loop D: with this many or fewer lanes busy and nothing to refill the others with, one fused pass serves all */,
-    uint32_t chunk_refill /* chunk mode: idle lanes take the next rays of the wave's OWN chunks at once (below) */)
+    uint32_t chunk_refill /* chunk mode: idle lanes take the next rays of the wave's OWN chunks at once (below) */,
+    uint2 (*stack)[64] /* LDS, STACK entries per lane */, const uint32_t block_id, const uint32_t grid_blocks,
+    const uint32_t priv_first, const uint32_t priv_stride)
 {
-    __shared__ uint2 stack[STACK][64];
     uint32_t* const stack32 = reinterpret_cast<uint32_t*>(&stack[0][0]);     // SHADOW: 2 * STACK entries of 4 bytes
     // spill area: plain (cached) stores; the loads go through spill_load*: written in C they are folded with the LDS side
     // of the pop into one flat_load on a selected generic address, and the common LDS pop loses its ds_read_b64
     uint2* const vspill = spill;
     uint32_t* const vspill32 = reinterpret_cast<uint32_t*>(spill);
     const uint32_t lane = threadIdx.x;
-    const uint32_t count = *count_ptr;
     if (count == 0) return;
     bool dry_noted = false;
     if (TIMELINE && lane == 0) atomicMin(&timeline[0], wall_clock64());
@@ -675,14 +690,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TAIL ? 7 : 4
     // without knowing `count`; with few rays (one sample per pixel in flight, late bounces) every lane of that grid gets a
     // handful of rays and the whole launch is its tail (DESIGN.md "Where a launch's time goes"): tune bits 24..31 = the
     // fewest rays per lane a wave is worth starting for, waves beyond that leave at once and the rest see a grid of n_blocks.
-    uint32_t n_blocks = gridDim.x;
-    if ((tune >> 24) != 0u)
+    uint32_t n_blocks = grid_blocks;
+    if (!PRIVATE && (tune >> 24) != 0u)
     {
         const uint32_t want = ((count / (64u * (tune >> 24)) + 7u) & ~7u);
         n_blocks = want < 8u ? 8u : (want < n_blocks ? want : n_blocks);
-        if (blockIdx.x >= n_blocks) return;
+        if (block_id >= n_blocks) return;
     }
-    const uint32_t xcd = blockIdx.x & 7u;
+    const uint32_t xcd = block_id & 7u;
     const uint32_t per = (((count + 7u) >> 3) + 63u) & ~63u;
     // rays a wave takes from the queue per hand-out: large, because every hand-out is one atomic on one of eight
     // addresses that 6000 waves share (128 -> 512 rays: +3 %, profiles/r02_handout_sweep.log), but never so large that a
@@ -694,7 +709,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TAIL ? 7 : 4
     // -- decided here, from the live queue counter (the host does not know it): small launches (a frame's single sample per
     // pixel, the late bounces of any batch) are all tail in refill mode; 2430 vs 849 Mrays/s at one 1080p sample in flight,
     // equal at ~8, 3340 vs 5940 at 64 (profiles/r03_call05_chunk_vs_refill_cfg4.log).
-    const bool chunk_mode = (tune & 0x800000u) != 0u || count < chunk_below;
+    const bool chunk_mode = PRIVATE || (tune & 0x800000u) != 0u || count < chunk_below;
     uint32_t grab = ((tune >> 16) & 0x7Fu) ? ((tune >> 16) & 0x7Fu) * 16u : 512u;
     if (chunk_mode) grab = 64u;
     {
@@ -704,13 +719,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TAIL ? 7 : 4
     // (Tapering the hand-outs towards the end of the region does not shorten the tail of a launch -- 0.75-0.95 ms
     // after the first wave finds the queue dry, tools/launch_timeline.py -- by more than 0.1 ms: the tail is single
     // long rays on nearly empty waves, not the size of the last hand-outs.  profiles/r02_taper_sweep.log)
-    const uint32_t spill_base = (blockIdx.x * 64u + lane) * (uint32_t)(RT_W4_STACK_MAX - STACK);
+    const uint32_t spill_base = (block_id * 64u + lane) * (uint32_t)(RT_W4_STACK_MAX - STACK);
     const char* const node_base = reinterpret_cast<const char*>(SHADOW ? sc.wnodes_sh : sc.wnodes);
     const char* const tri_base = reinterpret_cast<const char*>(sc.tris_rt);
     const uint32_t entry_ref = SHADOW ? sc.w_sh_entry_ref : sc.w_entry_ref;
 
     RayPool pool = {0u, 0u, 0u, false};
-    uint32_t chunk_next = blockIdx.x >> 3;         // chunk mode: this wave's next chunk of its XCD's region
+    uint32_t chunk_next = PRIVATE ? 0u : block_id >> 3;   // chunk mode: this wave's next chunk of its XCD's region (PRIVATE: its next position)
     uint32_t ref = RT_IDLE_REF;                    // wide node | RT_LEAF_BIT (| RT_LEAF_CONT_BIT) + triangle | idle
     uint32_t ray_i = RT_INVALID_ID;
     uint32_t sign_bits = 0, octant4 = 0, hit_prim = RT_INVALID_ID;          // octant4: shift of this ray's entry in a node's order table
@@ -851,7 +866,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TAIL ? 7 : 4
             }
             if (!pool.exhausted)
             {
-                if (TAIL && chunk_mode && chunk_refill)
+                if (PRIVATE)
+                {
+                    // the wave's own queue, in order: positions chunk_next .. count - 1 go to the idle lanes
+                    const unsigned long long need = __ballot(ref == RT_IDLE_REF && ray_i == RT_INVALID_ID);
+                    const uint32_t avail = count - chunk_next;
+                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
+                    const uint32_t n = (uint32_t)__popcll(need);
+                    if (ref == RT_IDLE_REF && ray_i == RT_INVALID_ID && rank < avail)
+                    {
+                        const uint32_t p = chunk_next + rank;
+                        ray_i = (priv_first + (p >> 6) * priv_stride) * 64u + (p & 63u);
+                    }
+                    chunk_next += n < avail ? n : avail;
+                    if (chunk_next >= count) pool.exhausted = true;
+                }
+                else if (TAIL && chunk_mode && chunk_refill)
                 {
                     // STATIC chunks, REFILLED lanes (round 4; in the TAIL instance only: in the plain one the extra hand-out path costs the hot
                     // loops 2 % through their register allocation, profiles/r04_call18.log): the wave's chunks -- slot, slot + waves per XCD, ... of its XCD's
@@ -920,8 +950,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TAIL ? 7 : 4
                 if (slow_m != 0ull)
                 {
                     uint32_t base = 0;
-                    if (lane == 0) { base = atomicAdd(slow_count, (uint32_t)__popcll(slow_m)); atomicAdd(&stat_counts[1], (uint32_t)__popcll(slow_m)); }
-                    base = __shfl(base, 0, 64);
+                    if (PRIVATE) { base = *slow_count; if (lane == 0) *slow_count = base + (uint32_t)__popcll(slow_m); }     // the wave's own counter: no atomics
+                    else
+                    {
+                        if (lane == 0) { base = atomicAdd(slow_count, (uint32_t)__popcll(slow_m)); atomicAdd(&stat_counts[1], (uint32_t)__popcll(slow_m)); }
+                        base = __shfl(base, 0, 64);
+                    }
                     if (slow)
                     {
                         uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(slow_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)slow_m, 0u));
@@ -1005,7 +1039,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TAIL ? 7 : 4
             n_spills += (uint32_t)__popcll(__ballot(sp > (SHADOW ? 2 * STACK : STACK)));
         }
     }
-    if (lane == 0 && n_spills != 0u) atomicAdd(&stat_counts[0], n_spills);
+    if (lane == 0 && n_spills != 0u) { if (PRIVATE) stat_counts[0] += n_spills; else atomicAdd(&stat_counts[0], n_spills); }
     if (TIMELINE)
     {
         if (lane == 0)
@@ -1019,4 +1053,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TAIL ? 7 : 4
         atomicMax(&timeline[192], (unsigned long long)tl_max_steps);
         atomicMax(&timeline[256], (tl_max_ticks << 24) | (tl_steps_of_slowest & 0xFFFFFFull));
     }
+}
+
+template <bool SHADOW, int STACK, bool TIMELINE = false, bool TAIL = false>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TAIL ? 7 : 4, 8))) void k_trace_w4(DScene sc, const float4* __restrict__ o4, const float4* __restrict__ d4,
+    const uint32_t* __restrict__ aux, const uint32_t* __restrict__ count_ptr, uint32_t* __restrict__ heads,
+    float4* __restrict__ hits, DLog log, uint2* __restrict__ spill, uint32_t tune,
+    uint32_t* __restrict__ slow_list, uint32_t* __restrict__ slow_count, uint32_t* __restrict__ stat_counts,
+    unsigned long long* __restrict__ timeline, uint32_t timeline_slot, uint32_t chunk_below, uint32_t tail_q, uint32_t chunk_refill)
+{
+    __shared__ uint2 stack[STACK][64];
+    w4_trace_body<SHADOW, STACK, TIMELINE, TAIL, false>(sc, o4, d4, aux, *count_ptr, heads, hits, log, spill, tune, slow_list, slow_count, stat_counts, timeline,
+        timeline_slot, chunk_below, tail_q, chunk_refill, stack, blockIdx.x, gridDim.x, 0u, 0u);
 }
