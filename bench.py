@@ -350,6 +350,42 @@ def per_frame_leg(args, render, lib, frame, capi, frames, resolve=True):
                              "resolves into a GL image and reads nothing back); the last image's arrival is inside the timed region")
 
 
+def frame_kernel_legs(args, render, lib, frame, capi):
+    """RT_OPT_FRAME_KERNEL (opt-in): the same frame-by-frame loop with every frame ONE launch of k_frame -- forced (1), and with the library's measured
+    choice (255: the first dozen frames of a scene time both ways).  The image after the same number of frames must equal the stage kernels' bit for bit."""
+    import numpy as np
+    frames = args.per_frame_frames
+    want = render.radiance().copy()                          # the stage kernels' leg has just run: 3 + frames frames since its reset
+    out = {}
+    try:
+        assert lib.rt_set_option(frame, capi.OPT_FRAME_KERNEL, 1) == 0
+        k0 = render.stats().frame_kernel_samples
+        forced = per_frame_leg(args, render, lib, frame, capi, frames)
+        got = render.radiance()
+        out["forced"] = dict(mrays_per_s=forced["mrays_per_s"], ms_per_frame=forced["ms_per_frame"], frames=frames,
+                             frames_through_k_frame=int(render.stats().frame_kernel_samples - k0),
+                             bit_identical_to_the_stage_kernels=bool(np.array_equal(got, want, equal_nan=True)))
+        assert lib.rt_set_option(frame, capi.OPT_FRAME_KERNEL, 255) == 0
+        assert lib.rt_reset(frame) == 0
+        render.set_resolve_every_frame(True)
+        for _ in range(16):                                  # 2 + 4 frames each way are timed, then the faster stays
+            render.render_frame()
+        render.finish()
+        k1 = render.stats().frame_kernel_samples
+        auto = per_frame_leg(args, render, lib, frame, capi, frames)
+        used = int(render.stats().frame_kernel_samples - k1)
+        out["measured_choice"] = dict(mrays_per_s=auto["mrays_per_s"], ms_per_frame=auto["ms_per_frame"], frames=frames,
+                                      chose="k_frame" if used >= frames else "the stage kernels", frames_through_k_frame=used,
+                                      bit_identical_to_the_stage_kernels=bool(np.array_equal(render.radiance(), want, equal_nan=True)))
+    except Exception as e:                                   # noqa: BLE001 -- reported, never fatal to the measurement
+        out["error"] = repr(e)
+    finally:
+        lib.rt_set_option(frame, capi.OPT_FRAME_KERNEL, 0)
+    out["what"] = ("RT_OPT_FRAME_KERNEL: every frame of the hooks' pattern as one launch in which each wave carries its own pixels through all the bounces "
+                   "(raytracing_amd/csrc/frame_kernels.h); opt-in -- per_frame above is the library's default, the stage kernels")
+    return out
+
+
 def median_pixel_rel_err(a, b):
     """median over the pixels of |a - b| / max(|b|, 1e-6) (L2 over the channels): one firefly sample cannot move it, unlike rel-L2"""
     import numpy as np
@@ -908,6 +944,8 @@ def main():
             assert lib.rt_set_option(frame, capi.OPT_STAGE_PIPES, args.stage_pipes) == 0
         per_frame = per_frame_leg(args, render, lib, frame, capi, args.per_frame_frames)
         per_frame["stage_pipes"] = args.stage_pipes or 1
+        if args.frame_kernel is None:
+            per_frame["frame_kernel"] = frame_kernel_legs(args, render, lib, frame, capi)
         if args.moving_camera_frames > 0:
             per_frame["moving_camera"] = moving_camera_leg(args, render, lib, frame, capi, host, cam, args.moving_camera_frames)
         if args.stage_pipes:

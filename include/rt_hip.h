@@ -263,7 +263,7 @@ enum rt_option
                                       pattern is its own tail (a launch lasts as long as its longest ray); side by side the chunks'
                                       tails overlap.  Same image bit for bit (chunks are independent; path ids are chunk-relative).
                                       Not with RT_OPT_AOV / RT_OPT_DENOISER (whole tile); the debug readers want 1. */
-    , RT_OPT_FRAME_KERNEL = 25      /* 0 (default) / 1: ONE sample per pixel in flight through the stage API -- the reference's frame-by-frame pattern,
+    , RT_OPT_FRAME_KERNEL = 25      /* 0 (default) / 1 / k >= 2 (k chunks of 64 pixels per wave: more blocks than are resident): ONE sample per pixel in flight through the stage API -- the reference's frame-by-frame pattern,
                                       Integrator::Integrate through the fifteen hooks -- as ONE launch: the stage calls of a sample are recorded while
                                       they come in the canonical order (rt_generate_rays; rt_intersect, rt_shade, rt_intersect_shadow for bounce 0 ..
                                       max_bounces; rt_advance_sample) and rt_advance_sample launches k_frame, in which every wave carries its own
@@ -355,6 +355,9 @@ typedef struct rt_stats
     uint32_t reserved_;
 } rt_stats;
 int rt_frame_get_stats(rt_frame* frame, rt_stats* out);
+/* RT_OPT_FRAME_KERNEL's per-wave rows of the latest k_frame launch (diagnostics: rays per bounce and 100 MHz ticks per phase of every wave;
+ * raytracing_amd/csrc/frame_kernels.h).  out may be NULL (size query). */
+int rt_frame_debug_frame_rows(rt_frame* frame, uint32_t* out, uint32_t capacity_rows, uint32_t* n_rows, uint32_t* row_words);
 
 /* ---- per-kernel timing (RT_OPT_PROFILE_KERNELS): HIP-event durations of the
  * launches since the option was switched on / since the last call, summed per

@@ -63,7 +63,7 @@ EXPORTS = [
     "rt_compute_aovs", "rt_denoise", "rt_copy_history",
     "rt_frame_resolve", "rt_frame_present", "rt_frame_present_wait", "rt_frame_read_radiance", "rt_frame_radiance_device_ptr", "rt_frame_sample_count",
     "rt_frame_get_stats", "rt_frame_get_profile", "rt_frame_copy_radiance", "rt_frame_debug_read_queue", "rt_frame_debug_read_hits", "rt_debug_eval",
-    "rt_debug_wide_bvh", "rt_frame_debug_timeline", "rt_debug_own_bvh", "rt_debug_wide_bvh_metric", "rt_scene_tree_report", "rt_debug_choose_tree", "rt_debug_adapt_fold", "rt_debug_fold_abandon", "rt_debug_adapt_shadow_side", "rt_debug_rotate_tree", "rt_debug_fold_view_left",
+    "rt_debug_wide_bvh", "rt_frame_debug_timeline", "rt_frame_debug_frame_rows", "rt_debug_own_bvh", "rt_debug_wide_bvh_metric", "rt_scene_tree_report", "rt_debug_choose_tree", "rt_debug_adapt_fold", "rt_debug_fold_abandon", "rt_debug_adapt_shadow_side", "rt_debug_rotate_tree", "rt_debug_fold_view_left",
     "rt_group_create", "rt_group_unique_id", "rt_group_join", "rt_group_size", "rt_group_local_count", "rt_group_local_rank", "rt_group_comm_count",
     "rt_group_gather_radiance", "rt_group_destroy", "rt_group_last_error", "rt_group_denoise", "rt_group_create_local",
     "rt_group_create_unchecked",
@@ -113,6 +113,7 @@ def load():
         "rt_debug_eval": (i32, [vp, i32, vp, vp, vp, u32]),
         "rt_debug_wide_bvh": (i32, [vp, u32, i32, vp, vp, u32, C.POINTER(u32), C.POINTER(u32)]),
         "rt_frame_debug_timeline": (i32, [vp, i32, vp]),
+        "rt_frame_debug_frame_rows": (i32, [vp, vp, u32, C.POINTER(u32), C.POINTER(u32)]),
         "rt_scene_tree_report": (C.c_char_p, [vp]),
         "rt_debug_choose_tree": (i32, [C.POINTER(rt_scene_desc), i32, u32, vp, u32, C.POINTER(u32), C.POINTER(u32), C.c_char_p, sz]),
         "rt_debug_own_bvh": (i32, [vp, u32, C.c_double, vp, u32, vp, u32, C.POINTER(u32)]),

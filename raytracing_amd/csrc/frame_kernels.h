@@ -14,7 +14,8 @@
 #include "trace_kernels.h"
 #include "shade_kernels.h"
 
-#define RT_FRAME_COUNT_STRIDE 132u       // per-wave row: [0..63] closest rays per bounce, [64..127] shadow rays per bounce, [128] spills, [129] slow rays, [130] scratch
+#define RT_FRAME_COUNT_STRIDE 136u       // per-wave row: [0..63] closest rays per bounce, [64..127] shadow rays per bounce, [128] spills, [129] slow rays, [130] scratch,
+                                         // [131..134] the wave's 100 MHz ticks in the closest walks / shading / shadow walks / in all (rt_frame_debug_frame_rows)
 
 struct FrameArgs
 {
@@ -31,19 +32,33 @@ struct FrameArgs
     uint32_t max_bounces, drop_last, tune, tail_q, chunks_per_wave;
 };
 
+#ifndef RT_FRAME_WAVES             // waves per SIMD k_frame is compiled for (tools/build_variants.py)
+#define RT_FRAME_WAVES 5          // 96 VGPRs + 27 dwords of scratch; at 4 (126 VGPRs, nothing spilled) 3 - 5 % slower on every config (profiles/r05_call13.log)
+#endif
+#ifndef RT_FRAME_XCD_REGIONS       // 1: a wave's chunks come from its XCD's eighth of the tile (the stage kernels' rule: one image region per L2);
+#define RT_FRAME_XCD_REGIONS 0     // 0: from the whole tile -- pixels are owned for the WHOLE frame here, and an XCD whose eighth is sky idles (below)
+#endif
 template <bool FURNACE, bool BLUE>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 6))) void k_frame(DScene sc, DTile tile, FrameArgs fa)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RT_FRAME_WAVES, 6))) void k_frame(DScene sc, DTile tile, FrameArgs fa)
 {
     __shared__ uint2 stack[12][64];
     const uint32_t lane = threadIdx.x, w = blockIdx.x, G = gridDim.x;
     const uint32_t n_local = fa.shade.n_local;
     const uint32_t n_chunks = (n_local + 63u) >> 6;
-    // this wave's chunks: slot, slot + S, slot + 2 S ... of its XCD's eighth of the tile's chunks (block b runs on XCD b % 8)
+    // This wave's chunks: w, w + G, w + 2 G ... of the tile's chunks -- a sample of the WHOLE image.  (With the stage kernels' rule -- slot, slot + S ...
+    // of the XCD's contiguous eighth of the queue -- the city block's frame took 4.36 ms against 3.37 with the stage kernels while the closed Cornell box
+    // took 2.50 against 3.99: a queue is compacted per launch, so its eighths are balanced, but pixels are owned for the whole frame here, and the XCDs
+    // whose eighth of the image is sky ran dry after the first bounce.  profiles/r05_call12.log)
+#if RT_FRAME_XCD_REGIONS
     const uint32_t xcd = w & 7u, slot = w >> 3, S = G >> 3;
     const uint32_t cpx = (n_chunks + 7u) >> 3;
     const uint32_t first = xcd * cpx + slot;
     uint32_t my_chunks = 0;
     while (slot + my_chunks * S < cpx && first + my_chunks * S < n_chunks) ++my_chunks;
+#else
+    const uint32_t first = w, S = G;
+    const uint32_t my_chunks = w < n_chunks ? (n_chunks - 1u - w) / G + 1u : 0u;
+#endif
     uint32_t* const row = fa.wave_counts + (size_t)w * RT_FRAME_COUNT_STRIDE;
     if (lane == 0) { row[128] = 0; row[129] = 0; }
     for (uint32_t k = lane; k < 128u; k += 64u) row[k] = 0;
@@ -68,20 +83,25 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 6))) void
         fa.d4[0][lp] = make_float4(d.x, d.y, d.z, __uint_as_float(lp));
         fa.thr[0][lp] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
     }
-    // what the wave's lanes wrote is read by OTHER lanes of the wave next, through an L1 that may still hold the lines as an earlier
-    // phase (or frame) left them: write back, then invalidate, at every phase boundary
-    __threadfence();
+    // What the wave's lanes wrote is read by OTHER lanes of the same wave next: a workgroup-scope fence (the stores have left the wave; the CU's L1
+    // is written through and serves its own CU's later loads).  NOT __threadfence(): at agent scope that is a write-back of the XCD's whole L2 and an
+    // invalidation of the L1 -- 36 of them per wave and frame made the first version of this kernel 2.5 x SLOWER than the stage kernels
+    // (8.57 against 3.37 ms per frame, profiles/r05_call12.log).
+    __threadfence_block();
 
     uint32_t n = n_pixels, cur = 0;
+    const unsigned long long t_begin = wall_clock64();
+    unsigned long long t_closest = 0, t_shade = 0, t_shadow = 0;
     for (uint32_t bounce = 0; bounce <= fa.max_bounces; ++bounce)
     {
+        const unsigned long long t0 = wall_clock64();
         if (lane == 0) row[bounce] = n;
         // ---- closest hits ----
         if (lane == 0) row[130] = 0;
         w4_trace_body<false, 12, false, true, true>(sc, fa.o4[cur], fa.d4[cur], (const uint32_t*)nullptr, n, (uint32_t*)nullptr, fa.hits, log, fa.spill,
             fa.tune, my_slow, row + 130, row + 128, (unsigned long long*)nullptr, 0u, 0u, fa.tail_q, 1u, stack, w, G, first, S);
         {
-            __threadfence();
+            __threadfence_block();
             const uint32_t n_slow = row[130];
             for (uint32_t k = lane; k < n_slow; k += 64u)                  // rays with a non-finite 1 / dir: the reference's loop on the exact BVH2
             {
@@ -91,8 +111,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 6))) void
                 fa.hits[i] = hit;
             }
             if (lane == 0 && n_slow != 0u) row[129] += n_slow;
-            __threadfence();
+            __threadfence_block();
         }
+        const unsigned long long t1 = wall_clock64();
+        t_closest += t1 - t0;
         // ---- Miss / HitSurface per entry; outgoing and shadow rays compacted into the wave's chunks of the next queues ----
         ShadeArgs a = fa.shade;
         a.in_o4 = fa.o4[cur]; a.in_d4 = fa.d4[cur]; a.in_thr = fa.thr[cur]; a.hits = fa.hits;
@@ -124,7 +146,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 6))) void
             n_shadow += (uint32_t)__popcll(ms);
             n_next += (uint32_t)__popcll(mn);
         }
-        __threadfence();
+        __threadfence_block();
+        const unsigned long long t2 = wall_clock64();
+        t_shade += t2 - t1;
         if (lane == 0) row[64u + bounce] = n_shadow;
         // ---- shadow rays: an occluded one retracts its path's tentative direct sample (AccumulateDirectSamples fused) ----
         if (n_shadow != 0u)
@@ -132,7 +156,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 6))) void
             if (lane == 0) row[130] = 0;
             w4_trace_body<true, 12, false, true, true>(sc, fa.sh_o4, fa.sh_d4, fa.sh_aux, n_shadow, (uint32_t*)nullptr, (float4*)nullptr, log, fa.spill,
                 fa.tune, my_slow, row + 130, row + 128, (unsigned long long*)nullptr, 0u, 0u, fa.tail_q, 1u, stack, w, G, first, S);
-            __threadfence();
+            __threadfence_block();
             const uint32_t n_slow = row[130];
             for (uint32_t k = lane; k < n_slow; k += 64u)
             {
@@ -142,11 +166,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 6))) void
                 if (v1_trace_ray<true>(sc, fa.sh_o4[i], rd, spill_push, spill_pop, hit)) log_retract(log, fa.sh_aux[i], __float_as_uint(rd.w));
             }
             if (lane == 0 && n_slow != 0u) row[129] += n_slow;
-            __threadfence();
+            __threadfence_block();
         }
+        t_shadow += wall_clock64() - t2;
         cur ^= 1u;
         n = n_next;
         if (n == 0u) break;
+    }
+    if (lane == 0)
+    {
+        row[131] = (uint32_t)t_closest; row[132] = (uint32_t)t_shade; row[133] = (uint32_t)t_shadow; row[134] = (uint32_t)(wall_clock64() - t_begin);
     }
     // ---- the radiance log of the wave's pixels, replayed in the order the reference adds (k_flush for one sample in flight) ----
     for (uint32_t p = lane; p < n_pixels; p += 64u)

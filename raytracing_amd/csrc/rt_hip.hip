@@ -73,6 +73,7 @@ struct rt_ctx
                                   // every shadow record are stored likeliest occluder first (measured on the device in round 5, profiles/r05_call01_*:
                                   // shadow trace 0.314 -> 0.258 ms per sample on the headline scene, bit-identical on all five configs)
     uint32_t adapt_min_interval_ms = 500;   // RT_CTX_OPT_ADAPT_MIN_INTERVAL_MS
+    uint64_t scene_uploads = 0;             // rt_scene_upload calls so far (what a frame's measured choices were made for)
     std::vector<rt_frame*> frames;   // the frames alive on this context (rt_finish waits for their side streams too)
     uint8_t* blue_noise = nullptr;   // sobol[65536] | scramblingTile[131072] | rankingTile[131072]
     float* gamma_lut = nullptr;      // pow(byte / 255, 2.2f), 256 entries (k_fill_gamma_lut)
@@ -147,8 +148,14 @@ struct rt_frame
     uint32_t frame_kernel = 0;
     struct { bool active = false; uint32_t bounce = 0; int next = 0; } deferred;   // next: 0 = rt_intersect(bounce), 1 = rt_shade, 2 = rt_intersect_shadow
     uint32_t* frame_counts = nullptr; uint32_t* frame_slow = nullptr;              // k_frame's per-wave rows and slow-ray lists
+    uint2* frame_spill = nullptr;                                                  // ... and its blocks' stack spill area
     uint32_t frame_blocks = 0, frame_chunks_per_wave = 0;
     uint64_t frame_launches = 0;                                                   // samples rendered by k_frame so far (rt_stats)
+    // RT_OPT_FRAME_KERNEL = 255: the choice is MEASURED -- k_frame wins by 1.4 - 1.8 x on scenes of up to ~1 M triangles and loses 7 - 10 % on the 2.8 M /
+    // 10 M ones (profiles/r05_call13.log), so the first frames of a scene time both: 2 + 4 frames with the stage kernels, 2 + 4 with k_frame (host
+    // clock between consecutive rt_generate_rays: the pattern ends every frame with Finish()), then the faster stays.
+    struct { int frames = 0; bool decided = false, use_kernel = false; double t_stage = 0.0, t_kernel = 0.0; uint64_t scene = 0;
+             std::chrono::steady_clock::time_point last{}; } fk_auto;
     uint32_t n_pipes = 1;          // pipes the current allocation holds
     uint32_t slots = 1;            // samples traced concurrently (resolved from slots_opt)
     uint32_t slots_opt = 0;        // RT_OPT_SAMPLES_IN_FLIGHT as set by the caller (0 = auto)
@@ -1271,6 +1278,7 @@ int rt_scene_upload(rt_ctx* ctx, const rt_scene_desc* sd)
     (void)hipSetDevice(ctx->device);
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     free_scene(ctx->scene);
+    ++ctx->scene_uploads;
     Scene& s = ctx->scene;
     const uint32_t nt = sd->num_triangles, nn = sd->num_nodes;
     // the trees of the backend's own (below, "Trees of the backend's own") are built on worker threads meanwhile
@@ -1984,6 +1992,7 @@ int rt_frame_destroy(rt_frame* f)
     if (f->present_stream) { (void)hipStreamSynchronize(f->present_stream); (void)hipStreamDestroy(f->present_stream); }
     if (f->frame_counts) (void)hipFree(f->frame_counts);
     if (f->frame_slow) (void)hipFree(f->frame_slow);
+    if (f->frame_spill) (void)hipFree(f->frame_spill);
     for (hipEvent_t e : f->ev_resolved) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : f->ev_copied) if (e) (void)hipEventDestroy(e);
     if (f->resolved_b) (void)hipFree(f->resolved_b);
@@ -2081,7 +2090,17 @@ int rt_set_option(rt_frame* f, int option, uint32_t value)
         return RT_OK;
     case RT_OPT_FRAME_KERNEL:
         if (f->deferred.active) return fail(f->ctx, "rt_set_option: RT_OPT_FRAME_KERNEL cannot change while a sample is in flight (rt_advance_sample first)");
-        f->frame_kernel = value ? 1u : 0u;
+        if (value != f->frame_kernel)
+        {
+            // (the grid and its buffers are sized by the value: the next launch makes them again)
+            HIPCHK(f->ctx, hipStreamSynchronize(f->ctx->stream));
+            if (f->frame_counts) (void)hipFree(f->frame_counts);
+            if (f->frame_slow) (void)hipFree(f->frame_slow);
+            if (f->frame_spill) (void)hipFree(f->frame_spill);
+            f->frame_counts = nullptr; f->frame_slow = nullptr; f->frame_spill = nullptr; f->frame_blocks = 0;
+            f->frame_kernel = value == 255u ? 255u : (value > 64u ? 64u : value);
+            f->fk_auto = {};
+        }
         return RT_OK;
     case RT_OPT_STAGE_PIPES:
         if (value == 0 || value > RT_MAX_PIPES) return fail(f->ctx, "rt_set_option: stage pipes must be 1..RT_MAX_PIPES");
@@ -2372,7 +2391,8 @@ bool frame_kernel_eligible(const rt_frame* f)
 {
     const rt_ctx* ctx = f->ctx;
     const uint32_t n_local = f->n_local ? f->n_local : 1u;
-    return f->frame_kernel != 0u && f->n_local != 0u && !(f->denoiser || f->aov != 0) && ctx->scene.wide_ok && !ctx->scene.slow_shadow &&
+    const bool wanted = f->frame_kernel == 255u ? (f->fk_auto.decided ? f->fk_auto.use_kernel : f->fk_auto.frames > 6) : f->frame_kernel != 0u;
+    return wanted && f->n_local != 0u && !(f->denoiser || f->aov != 0) && ctx->scene.wide_ok && !ctx->scene.slow_shadow &&
            ctx->scene.d.emissive_nee == 0u && f->log_ovf_blocks == 0u && f->n_pipes == 1u && f->chunk_pixels >= n_local && f->stage_chunks <= 1u &&
            (f->trace_variant == 5u || f->trace_variant == 10u) && !f->profile && !f->timeline && f->select_form_box == 0u && f->max_bounces < 63u;
 }
@@ -2384,20 +2404,20 @@ int launch_frame_kernel_t(rt_frame* f)
     PathPipe& q = f->ps[0];
     if (f->frame_blocks == 0u)
     {
-        // as many one-wave blocks as the device keeps resident (the kernel's registers decide), every wave with the same number of chunks
+        // RT_OPT_FRAME_KERNEL = 1: as many one-wave blocks as the device keeps resident (the kernel's registers decide), every wave with the same
+        // number of chunks; = k >= 2: k chunks per wave, i.e. MORE blocks than are resident -- the hardware starts the next block where one has
+        // finished, which is a dynamic schedule of the frame's chunks in units of k
         int per_cu = 0;
         HIPCHK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_frame<FURNACE, BLUE>, 64, 0));
         if (per_cu < 1) return fail(ctx, "rt_advance_sample: k_frame does not fit the device");
-        const uint32_t n_chunks = (f->n_local + 63u) >> 6, cpx = (n_chunks + 7u) >> 3;
-        const uint32_t s_max = std::max(1u, (uint32_t)ctx->prop.multiProcessorCount * (uint32_t)per_cu / 8u);
-        const uint32_t cpw = (cpx + s_max - 1u) / s_max;                      // chunks per wave
-        const uint32_t s_waves = (cpx + cpw - 1u) / cpw;                      // waves per XCD region
-        f->frame_blocks = 8u * s_waves;
+        const uint32_t n_chunks = (f->n_local + 63u) >> 6;
+        const uint32_t resident = std::max(8u, (uint32_t)ctx->prop.multiProcessorCount * (uint32_t)per_cu);
+        const uint32_t cpw = f->frame_kernel >= 2u && f->frame_kernel != 255u ? f->frame_kernel : (n_chunks + resident - 1u) / resident;     // chunks per wave
+        f->frame_blocks = (((n_chunks + cpw - 1u) / cpw) + 7u) & ~7u;
         f->frame_chunks_per_wave = cpw;
-        if ((size_t)f->frame_blocks * 64u * (RT_W4_STACK_MAX - 12) > (size_t)ctx->prop.multiProcessorCount * 32 * 64 * (RT_W4_STACK_MAX - 8))
-            return fail(ctx, "rt_advance_sample: k_frame's grid exceeds the spill area");
         HIPCHK(ctx, hipMalloc((void**)&f->frame_counts, (size_t)f->frame_blocks * RT_FRAME_COUNT_STRIDE * sizeof(uint32_t)));
         HIPCHK(ctx, hipMalloc((void**)&f->frame_slow, (size_t)f->frame_blocks * cpw * 64u * sizeof(uint32_t)));
+        HIPCHK(ctx, hipMalloc((void**)&f->frame_spill, (size_t)f->frame_blocks * 64u * (RT_W4_STACK_MAX - 12) * sizeof(uint2)));
     }
     // the previous sample's per-bounce counters go to the totals first (k_raygen does this for the stage kernels)
     hipLaunchKernelGGL(k_fold_counters, dim3(1), dim3(64), 0, q.stream, q.counters, q.prev_bounces, q.fold_accumulates);
@@ -2418,7 +2438,7 @@ int launch_frame_kernel_t(rt_frame* f)
     fa.hits = q.hits;
     fa.sh_o4 = q.sh_o4[0]; fa.sh_d4 = q.sh_d4[0]; fa.sh_aux = q.sh_aux[0];
     fa.radiance = f->radiance;
-    fa.spill = q.spill;
+    fa.spill = f->frame_spill;
     fa.slow_list = f->frame_slow;
     fa.wave_counts = f->frame_counts;
     fa.cam = f->camera;
@@ -2484,6 +2504,22 @@ int rt_generate_rays(rt_frame* f)                       // GenerateRays, :516-52
     {
         f->stage_chunks = 1;
         if (ensure_whole_tile(f) != RT_OK) return RT_ERROR;
+        if (f->frame_kernel == 255u)
+        {
+            // frames 0 - 1 warm up and 2 - 5 are timed with the stage kernels, 6 - 7 warm up and 8 - 11 are timed with k_frame; frame 12 knows
+            auto& m = f->fk_auto;
+            if (m.scene != ctx->scene_uploads) { m = {}; m.scene = ctx->scene_uploads; }
+            if (!m.decided)
+            {
+                const auto now = std::chrono::steady_clock::now();
+                const double dt = std::chrono::duration<double>(now - m.last).count();
+                if (m.frames >= 3 && m.frames <= 6) m.t_stage += dt;          // the interval that ends now belongs to the frame before
+                if (m.frames >= 9 && m.frames <= 12) m.t_kernel += dt;
+                if (m.frames == 12) { m.decided = true; m.use_kernel = m.t_kernel < m.t_stage; }
+                m.last = now;
+                ++m.frames;
+            }
+        }
         if (frame_kernel_eligible(f))
         {
             // RT_OPT_FRAME_KERNEL: nothing is launched yet -- the stages are recorded, rt_advance_sample launches k_frame
@@ -3271,6 +3307,20 @@ int rt_frame_debug_read_hits(rt_frame* f, rt_hit* hits, uint32_t count)
 // most recent bounce-b launch, in ticks of the 100 MHz wall clock (0 where nothing ran), then the most traversal steps
 // any ray took and the slowest ray's ticks from hand-out to retirement and its steps; after those 64 x 6 values, out[384 + i] =
 // waves (of all recorded launches) that left in the i-th 25 us after their launch's queue ran dry.
+// k_frame's per-wave rows of its latest launch (RT_FRAME_COUNT_STRIDE words each; frame_kernels.h): rays per bounce and the wave's ticks per phase
+int rt_frame_debug_frame_rows(rt_frame* f, uint32_t* out, uint32_t capacity_rows, uint32_t* n_rows, uint32_t* row_words)
+{
+    if (!f || !n_rows || !row_words) return fail(nullptr, "rt_frame_debug_frame_rows: NULL argument");
+    rt_ctx* ctx = f->ctx;
+    (void)hipSetDevice(ctx->device);
+    *n_rows = f->frame_blocks; *row_words = RT_FRAME_COUNT_STRIDE;
+    if (!out || f->frame_blocks == 0u || !f->frame_counts) return RT_OK;
+    if (capacity_rows < f->frame_blocks) return fail(ctx, "rt_frame_debug_frame_rows: the caller's array is too small");
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipMemcpy(out, f->frame_counts, (size_t)f->frame_blocks * RT_FRAME_COUNT_STRIDE * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
 int rt_frame_debug_timeline(rt_frame* f, int arm, unsigned long long* out /* [64][6] + [64] when reading */)
 {
     if (!f) return fail(nullptr, "rt_frame_debug_timeline: frame is NULL");

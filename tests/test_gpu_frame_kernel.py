@@ -12,6 +12,8 @@ from raytracing_amd import capi, host, scenes as S, types as T
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# RT_OPT_FRAME_KERNEL's value: 1 = every block resident, k >= 2 = k chunks of 64 pixels per wave (more blocks than are resident)
+KERNEL_VALUE = int(os.environ.get("RT_TEST_FRAME_KERNEL_VALUE", "1"))
 
 
 @pytest.fixture(scope="module")
@@ -34,7 +36,7 @@ def framed(ctx, w, h, cam, bounces, furnace=False, blue=False, kernel=True):
     fr.set_option(capi.OPT_WHITE_FURNACE, int(furnace))
     if blue:
         fr.set_option(capi.OPT_SAMPLER, 1)
-    fr.set_option(capi.OPT_FRAME_KERNEL, int(kernel))
+    fr.set_option(capi.OPT_FRAME_KERNEL, KERNEL_VALUE if kernel else 0)
     return fr
 
 
@@ -104,8 +106,9 @@ def test_recorded_stages_are_replayed_when_somebody_looks_between_them(ctx, gold
     for f in (plain, fr):
         f.generate_rays(); f.intersect(0); f.shade(0)
     qa, qb = plain.read_queue(0, 1), fr.read_queue(0, 1)
+    oa, ob = np.argsort(qa[1], kind="stable"), np.argsort(qb[1], kind="stable")      # (queue ORDER is the blocks' arrival order at an atomic: by pixel)
     for x, y in zip(qa, qb):
-        assert np.array_equal(x, y)
+        assert np.array_equal(x[oa], y[ob])
     for f in (plain, fr):
         f.intersect_shadow(0)
         for bounce in range(1, b + 1):
@@ -152,7 +155,7 @@ def test_frame_kernel_at_the_production_frame_through_the_hooks():
         r = host.Render(w, h, scene)
         r.set_camera(host.default_camera(w, h)); r.set_max_bounces(b)
         frame = host.load().rth_render_frame_handle(r.handle)
-        assert lib.rt_set_option(frame, capi.OPT_FRAME_KERNEL, kernel) == 0
+        assert lib.rt_set_option(frame, capi.OPT_FRAME_KERNEL, KERNEL_VALUE if kernel else 0) == 0
         r.set_resolve_every_frame(True)
         for _ in range(frames):
             r.render_frame()
@@ -163,3 +166,32 @@ def test_frame_kernel_at_the_production_frame_through_the_hooks():
     assert np.array_equal(images[0], images[1], equal_nan=True)
     assert (stats[0].closest_rays, stats[0].shadow_rays) == (stats[1].closest_rays, stats[1].shadow_rays)
     assert list(stats[0].last_active[: b + 1]) == list(stats[1].last_active[: b + 1])
+
+
+def test_the_measured_choice_times_both_ways_and_changes_no_bit(ctx, golden_scenes):
+    """RT_OPT_FRAME_KERNEL = 255: frames 0 - 5 of a scene go through the stage kernels, 6 - 11 through k_frame (2 warm-up + 4 timed frames each way, host
+    clock between consecutive rt_generate_rays), from frame 12 on the faster way stays -- whichever that is, the accumulated image is the stage kernels';
+    a new scene upload measures again."""
+    w, h, b, n = 96, 64, 3, 20
+    sc = golden_scenes["coverage"]
+    cam = T.default_camera(w, h)
+    ctx.upload_scene(sc)
+    plain = framed(ctx, w, h, cam, b, kernel=False)
+    fr = framed(ctx, w, h, cam, b, kernel=False)
+    fr.set_option(capi.OPT_FRAME_KERNEL, 255)
+    seen = []
+    for i in range(n):
+        stage_sample(plain, b); stage_sample(fr, b)
+        ctx.finish()
+        seen.append(fr.stats().frame_kernel_samples)
+    assert seen[5] == 0 and seen[11] == 6, seen                               # frames 6 .. 11 were k_frame's
+    assert seen[-1] in (6, 6 + n - 12), seen                                  # ... and from frame 12 on one way or the other
+    assert np.array_equal(fr.radiance(), plain.radiance(), equal_nan=True)
+    ctx.upload_scene(sc)                                                      # another upload: the choice is made again
+    fr.reset(); plain.reset()
+    base = fr.stats().frame_kernel_samples
+    for i in range(8):
+        stage_sample(plain, b); stage_sample(fr, b)
+    assert fr.stats().frame_kernel_samples == base + 2                        # frames 6 and 7 of the new measurement
+    assert np.array_equal(fr.radiance(), plain.radiance(), equal_nan=True)
+    fr.close(); plain.close()
