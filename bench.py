@@ -329,7 +329,7 @@ def per_frame_leg(args, render, lib, frame, capi, frames, resolve=True):
     host synchronisation (cl_pt_integrator.cpp:677-684).  Untimed by the headline; reported beside it."""
     assert lib.rt_reset(frame) == 0
     render.set_resolve_every_frame(resolve)
-    for _ in range(3):
+    for _ in range(16):                                   # (HIPPathTraceIntegrator's default times both ways over a scene's first 12 frames: RT_OPT_FRAME_KERNEL = 255)
         render.render_frame()
     render.finish()
     st0 = render.stats()
@@ -343,6 +343,7 @@ def per_frame_leg(args, render, lib, frame, capi, frames, resolve=True):
     rays = float((st1.closest_rays - st0.closest_rays) + (st1.shadow_rays - st0.shadow_rays))
     return dict(mrays_per_s=round(rays / dt / 1e6, 1), ms_per_frame=round(dt * 1e3 / frames, 4), frames=frames,
                 rays_per_frame=round(rays / frames, 1), samples_in_flight=1, resolve_every_frame=bool(resolve),
+                frames_through_k_frame=int(st1.frame_kernel_samples - st0.frame_kernel_samples),
                 call_pattern="K x Render::RenderFrame() -> Integrator::Integrate() through the 15 stage hooks of HIPPathTraceIntegrator, "
                              "1 sample per pixel per call, ResolveRadiance + Finish() (host sync on the frame's kernels) every frame "
                              "(src/render.cpp:197, src/integrator/integrator.cpp:27-59, cl_pt_integrator.cpp:677-684); the resolved image "
@@ -350,39 +351,27 @@ def per_frame_leg(args, render, lib, frame, capi, frames, resolve=True):
                              "resolves into a GL image and reads nothing back); the last image's arrival is inside the timed region")
 
 
-def frame_kernel_legs(args, render, lib, frame, capi):
-    """RT_OPT_FRAME_KERNEL (opt-in): the same frame-by-frame loop with every frame ONE launch of k_frame -- forced (1), and with the library's measured
-    choice (255: the first dozen frames of a scene time both ways).  The image after the same number of frames must equal the stage kernels' bit for bit."""
+def frame_kernel_legs(args, render, lib, frame, capi, default_leg):
+    """`per_frame` runs as HIPPathTraceIntegrator ships: RT_OPT_FRAME_KERNEL = 255, the backend's measured choice between its stage kernels and ONE
+    launch of k_frame per Integrate() (the first dozen frames of a scene time both).  Beside it: both ways forced, same frames -- and the image after
+    the same number of frames must be the same bit for bit whichever way they went."""
     import numpy as np
     frames = args.per_frame_frames
-    want = render.radiance().copy()                          # the stage kernels' leg has just run: 3 + frames frames since its reset
-    out = {}
+    want = render.radiance().copy()                          # the default leg has just run: 16 + frames frames since its reset
+    out = dict(default_went="through k_frame" if default_leg["frames_through_k_frame"] >= frames else "through the stage kernels")
     try:
-        assert lib.rt_set_option(frame, capi.OPT_FRAME_KERNEL, 1) == 0
-        k0 = render.stats().frame_kernel_samples
-        forced = per_frame_leg(args, render, lib, frame, capi, frames)
-        got = render.radiance()
-        out["forced"] = dict(mrays_per_s=forced["mrays_per_s"], ms_per_frame=forced["ms_per_frame"], frames=frames,
-                             frames_through_k_frame=int(render.stats().frame_kernel_samples - k0),
-                             bit_identical_to_the_stage_kernels=bool(np.array_equal(got, want, equal_nan=True)))
-        assert lib.rt_set_option(frame, capi.OPT_FRAME_KERNEL, 255) == 0
-        assert lib.rt_reset(frame) == 0
-        render.set_resolve_every_frame(True)
-        for _ in range(16):                                  # 2 + 4 frames each way are timed, then the faster stays
-            render.render_frame()
-        render.finish()
-        k1 = render.stats().frame_kernel_samples
-        auto = per_frame_leg(args, render, lib, frame, capi, frames)
-        used = int(render.stats().frame_kernel_samples - k1)
-        out["measured_choice"] = dict(mrays_per_s=auto["mrays_per_s"], ms_per_frame=auto["ms_per_frame"], frames=frames,
-                                      chose="k_frame" if used >= frames else "the stage kernels", frames_through_k_frame=used,
-                                      bit_identical_to_the_stage_kernels=bool(np.array_equal(render.radiance(), want, equal_nan=True)))
+        for name, mode in (("stage_kernels", 0), ("k_frame", 1)):
+            assert lib.rt_set_option(frame, capi.OPT_FRAME_KERNEL, mode) == 0
+            leg = per_frame_leg(args, render, lib, frame, capi, frames)
+            out[name] = dict(mrays_per_s=leg["mrays_per_s"], ms_per_frame=leg["ms_per_frame"], frames=frames,
+                             frames_through_k_frame=leg["frames_through_k_frame"],
+                             bit_identical_to_the_default_leg=bool(np.array_equal(render.radiance(), want, equal_nan=True)))
     except Exception as e:                                   # noqa: BLE001 -- reported, never fatal to the measurement
         out["error"] = repr(e)
     finally:
-        lib.rt_set_option(frame, capi.OPT_FRAME_KERNEL, 0)
+        lib.rt_set_option(frame, capi.OPT_FRAME_KERNEL, 255)
     out["what"] = ("RT_OPT_FRAME_KERNEL: every frame of the hooks' pattern as one launch in which each wave carries its own pixels through all the bounces "
-                   "(raytracing_amd/csrc/frame_kernels.h); opt-in -- per_frame above is the library's default, the stage kernels")
+                   "(raytracing_amd/csrc/frame_kernels.h), or the stage kernels (47 launches per frame); 255 = measured per scene")
     return out
 
 
@@ -945,7 +934,7 @@ def main():
         per_frame = per_frame_leg(args, render, lib, frame, capi, args.per_frame_frames)
         per_frame["stage_pipes"] = args.stage_pipes or 1
         if args.frame_kernel is None:
-            per_frame["frame_kernel"] = frame_kernel_legs(args, render, lib, frame, capi)
+            per_frame["frame_kernel"] = frame_kernel_legs(args, render, lib, frame, capi, per_frame)
         if args.moving_camera_frames > 0:
             per_frame["moving_camera"] = moving_camera_leg(args, render, lib, frame, capi, host, cam, args.moving_camera_frames)
         if args.stage_pipes:

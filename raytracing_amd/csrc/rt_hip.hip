@@ -152,10 +152,9 @@ struct rt_frame
     uint32_t frame_blocks = 0, frame_chunks_per_wave = 0;
     uint64_t frame_launches = 0;                                                   // samples rendered by k_frame so far (rt_stats)
     // RT_OPT_FRAME_KERNEL = 255: the choice is MEASURED -- k_frame wins by 1.4 - 1.8 x on scenes of up to ~1 M triangles and loses 7 - 10 % on the 2.8 M /
-    // 10 M ones (profiles/r05_call13.log), so the first frames of a scene time both: 2 + 4 frames with the stage kernels, 2 + 4 with k_frame (host
-    // clock between consecutive rt_generate_rays: the pattern ends every frame with Finish()), then the faster stays.
-    struct { int frames = 0; bool decided = false, use_kernel = false; double t_stage = 0.0, t_kernel = 0.0; uint64_t scene = 0;
-             std::chrono::steady_clock::time_point last{}; } fk_auto;
+    // 10 M ones (profiles/r05_call13.log), so the first frames of a scene time both: 2 + 4 frames with the stage kernels, 2 + 4 with k_frame (HIP events
+    // around each timed frame's launches on the frame's stream, read once the last has completed), then the faster stays.
+    struct { int frames = 0, timing = -1; bool decided = false, use_kernel = false; uint64_t scene = 0; hipEvent_t ev[8][2] = {}; float ms_stage = 0.0f, ms_kernel = 0.0f; } fk_auto;
     uint32_t n_pipes = 1;          // pipes the current allocation holds
     uint32_t slots = 1;            // samples traced concurrently (resolved from slots_opt)
     uint32_t slots_opt = 0;        // RT_OPT_SAMPLES_IN_FLIGHT as set by the caller (0 = auto)
@@ -1993,6 +1992,7 @@ int rt_frame_destroy(rt_frame* f)
     if (f->frame_counts) (void)hipFree(f->frame_counts);
     if (f->frame_slow) (void)hipFree(f->frame_slow);
     if (f->frame_spill) (void)hipFree(f->frame_spill);
+    for (auto& pair : f->fk_auto.ev) for (hipEvent_t e : pair) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : f->ev_resolved) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : f->ev_copied) if (e) (void)hipEventDestroy(e);
     if (f->resolved_b) (void)hipFree(f->resolved_b);
@@ -2099,7 +2099,7 @@ int rt_set_option(rt_frame* f, int option, uint32_t value)
             if (f->frame_spill) (void)hipFree(f->frame_spill);
             f->frame_counts = nullptr; f->frame_slow = nullptr; f->frame_spill = nullptr; f->frame_blocks = 0;
             f->frame_kernel = value == 255u ? 255u : (value > 64u ? 64u : value);
-            f->fk_auto = {};
+            f->fk_auto.frames = 0; f->fk_auto.timing = -1; f->fk_auto.decided = false; f->fk_auto.use_kernel = false;
         }
         return RT_OK;
     case RT_OPT_STAGE_PIPES:
@@ -2506,18 +2506,36 @@ int rt_generate_rays(rt_frame* f)                       // GenerateRays, :516-52
         if (ensure_whole_tile(f) != RT_OK) return RT_ERROR;
         if (f->frame_kernel == 255u)
         {
-            // frames 0 - 1 warm up and 2 - 5 are timed with the stage kernels, 6 - 7 warm up and 8 - 11 are timed with k_frame; frame 12 knows
+            // frames 0 - 1 warm up and 2 - 5 are timed with the stage kernels, 6 - 7 warm up and 8 - 11 are timed with k_frame; once the last timed
+            // frame's events have completed, the faster way stays (until the next scene upload)
             auto& m = f->fk_auto;
-            if (m.scene != ctx->scene_uploads) { m = {}; m.scene = ctx->scene_uploads; }
+            if (m.scene != ctx->scene_uploads) { m.frames = 0; m.timing = -1; m.decided = false; m.use_kernel = false; m.scene = ctx->scene_uploads; }
+            m.timing = -1;
             if (!m.decided)
             {
-                const auto now = std::chrono::steady_clock::now();
-                const double dt = std::chrono::duration<double>(now - m.last).count();
-                if (m.frames >= 3 && m.frames <= 6) m.t_stage += dt;          // the interval that ends now belongs to the frame before
-                if (m.frames >= 9 && m.frames <= 12) m.t_kernel += dt;
-                if (m.frames == 12) { m.decided = true; m.use_kernel = m.t_kernel < m.t_stage; }
-                m.last = now;
-                ++m.frames;
+                const int k = m.frames;
+                if (k >= 12 && hipEventQuery(m.ev[7][1]) == hipSuccess)
+                {
+                    m.ms_stage = m.ms_kernel = 0.0f;
+                    bool ok = true;
+                    for (int i = 0; i < 8 && ok; ++i)
+                    {
+                        float t = 0.0f;
+                        ok = hipEventElapsedTime(&t, m.ev[i][0], m.ev[i][1]) == hipSuccess;
+                        (i < 4 ? m.ms_stage : m.ms_kernel) += t;
+                    }
+                    if (!ok) (void)hipGetLastError();
+                    m.decided = true;
+                    m.use_kernel = ok && m.ms_kernel < m.ms_stage;
+                }
+                else if ((k >= 2 && k <= 5) || (k >= 8 && k <= 11))
+                {
+                    m.timing = k <= 5 ? k - 2 : k - 4;
+                    bool ok = true;
+                    for (hipEvent_t& e : m.ev[m.timing]) if (!e) ok = ok && hipEventCreate(&e) == hipSuccess;
+                    if (!ok || hipEventRecord(m.ev[m.timing][0], ctx->stream) != hipSuccess) { (void)hipGetLastError(); m.decided = true; m.use_kernel = false; m.timing = -1; }
+                }
+                if (!m.decided) ++m.frames;
             }
         }
         if (frame_kernel_eligible(f))
@@ -2713,6 +2731,7 @@ int rt_advance_sample(rt_frame* f)                      // AdvanceSampleCount, :
             f->deferred.active = false;
             if (launch_frame_kernel(f) != RT_OK) return RT_ERROR;
             f->sample_count += 1;
+            if (f->fk_auto.timing >= 0) { (void)hipEventRecord(f->fk_auto.ev[f->fk_auto.timing][1], f->ctx->stream); f->fk_auto.timing = -1; }
             return RT_OK;
         }
         if (deferred_materialize(f) != RT_OK) return RT_ERROR;
@@ -2720,6 +2739,7 @@ int rt_advance_sample(rt_frame* f)                      // AdvanceSampleCount, :
     uint32_t n = f->p->cur_slots ? f->p->cur_slots : 1u;
     if (flush_stage(f) != RT_OK) return RT_ERROR;        // radiance_buffer_ += this sample's contributions (of every chunk: RT_OPT_STAGE_PIPES)
     f->sample_count += n;
+    if (f->fk_auto.timing >= 0) { (void)hipEventRecord(f->fk_auto.ev[f->fk_auto.timing][1], f->ctx->stream); f->fk_auto.timing = -1; }   // RT_OPT_FRAME_KERNEL = 255
     return RT_OK;
 }
 

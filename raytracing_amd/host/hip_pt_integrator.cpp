@@ -78,6 +78,9 @@ HIPPathTraceIntegrator::HIPPathTraceIntegrator(std::uint32_t width, std::uint32_
     {
         resolved_.assign((size_t)rt_frame_local_rows(frame_) * width * 4, 0.0f);
         CreateKernels();
+        // Integrate() through the hooks is this class's whole purpose: let the backend MEASURE whether a frame is better served by its stage
+        // kernels or by one k_frame launch (RT_OPT_FRAME_KERNEL = 255; bit-identical either way; SetFrameKernel(0) keeps the stage kernels)
+        Check(rt_set_option(frame_, RT_OPT_FRAME_KERNEL, 255u));
     }
     catch (...)
     {
@@ -176,6 +179,7 @@ void HIPPathTraceIntegrator::SyncOptions()
     Check(rt_set_option(frame_, RT_OPT_WHITE_FURNACE, enable_white_furnace_ ? 1u : 0u));
 }
 
+void HIPPathTraceIntegrator::SetFrameKernel(std::uint32_t mode) { Check(rt_set_option(frame_, RT_OPT_FRAME_KERNEL, mode)); }
 void HIPPathTraceIntegrator::Reset() { SyncOptions(); Check(rt_reset(frame_)); }
 void HIPPathTraceIntegrator::AdvanceSampleCount() { Check(rt_advance_sample(frame_)); }
 void HIPPathTraceIntegrator::GenerateRays() { SyncOptions(); Check(rt_generate_rays(frame_)); }

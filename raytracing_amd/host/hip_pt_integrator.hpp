@@ -71,6 +71,8 @@ public:
     std::uint32_t GetGlobalRow(std::uint32_t local_row) const;
     rt_stats GetStats() const;
     void SetResolveEveryFrame(bool enable) { resolve_every_frame_ = enable; }
+    // RT_OPT_FRAME_KERNEL: 255 (this class's default) = measured choice between the stage kernels and one k_frame launch per Integrate(); 0 / 1 = forced
+    void SetFrameKernel(std::uint32_t mode);
     // packed uint8 tables, see tools/make_blue_noise_asset.py (default: relative to the CWD like the env map)
     void SetBlueNoiseTablePath(std::string path) { blue_noise_path_ = std::move(path); }
     rt_frame* GetFrame() const { return frame_; }

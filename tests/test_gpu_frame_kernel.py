@@ -195,3 +195,34 @@ def test_the_measured_choice_times_both_ways_and_changes_no_bit(ctx, golden_scen
     assert fr.stats().frame_kernel_samples == base + 2                        # frames 6 and 7 of the new measurement
     assert np.array_equal(fr.radiance(), plain.radiance(), equal_nan=True)
     fr.close(); plain.close()
+
+
+def test_frame_kernel_on_the_tiles_of_a_multi_gpu_split(ctx, golden_scenes):
+    """A tile of an N-way split (interleaved row bands: rt_frame_desc.tile_rank / tile_count / band_height) through k_frame: the assembled image is
+    the single frame's, bit for bit (the RNG is keyed by GLOBAL pixel coordinates, the path id by the tile's local pixel)."""
+    w, h, b, spp = 96, 72, 4, 2
+    sc = golden_scenes["coverage"]
+    cam = T.default_camera(w, h)
+    ctx.upload_scene(sc)
+    full = framed(ctx, w, h, cam, b, kernel=False)
+    for _ in range(spp):
+        stage_sample(full, b)
+    want = full.radiance()
+    for world, band in ((2, 8), (3, 4)):
+        img = np.zeros_like(want)
+        rays = 0
+        for r in range(world):
+            fr = capi.Frame(ctx, w, h, tile_rank=r, tile_count=world, band_height=band)
+            fr.set_camera(cam); fr.set_max_bounces(b)
+            fr.set_option(capi.OPT_FRAME_KERNEL, KERNEL_VALUE)
+            for _ in range(spp):
+                stage_sample(fr, b)
+            st = fr.stats()
+            assert st.frame_kernel_samples == spp
+            img[fr.global_rows()] = fr.radiance()
+            rays += st.closest_rays + st.shadow_rays
+            fr.close()
+        assert np.array_equal(img, want, equal_nan=True), (world, band)
+        fs = full.stats()
+        assert rays == fs.closest_rays + fs.shadow_rays
+    full.close()

@@ -158,7 +158,18 @@ def test_random_scene_matches_oracle_bit_for_bit(ctx, env_map, seed):
     fr.set_option(capi.OPT_TRACE_TAIL_LANES, (40, 1, 64, 16, 0)[(seed // 3) % 5])
     fr.set_option(capi.OPT_CHUNK_REFILL, 0 if seed % 4 == 2 else 1)    # chunk mode: round 3's form / lanes refilled from the wave's own chunks
     fr.set_option(capi.OPT_SMALL_LAUNCH_PATHS, int(rng.choice([3000000, 0, 4000000000, 700])))   # chunk mode below this many rays per launch: default, never, always, for the last bounces
-    fr.integrate(spp)
+    # k_frame (round 5): every fifth seed renders its samples through the stage API with RT_OPT_FRAME_KERNEL (1: every block resident, 2 / 3: that
+    # many chunks per wave) -- one launch per sample in which each wave carries its own pixels through all the bounces; where the frame is not
+    # eligible (compact log, a forced kernel variant) the same calls take the stage kernels
+    if seed % 5 == 2:
+        fr.set_option(capi.OPT_FRAME_KERNEL, (1, 2, 3)[(seed // 5) % 3])
+        for _ in range(spp):
+            fr.generate_rays()
+            for bounce in range(bounces + 1):
+                fr.intersect(bounce); fr.shade(bounce); fr.intersect_shadow(bounce)
+            fr.advance_sample()
+    else:
+        fr.integrate(spp)
     orc = _oracle.Oracle(w, h, sc, furnace=furnace)
     orc.set_camera(cam); orc.set_max_bounces(bounces)
     orc.set_blue_noise(blue, S.blue_noise_tables())
