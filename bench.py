@@ -329,7 +329,7 @@ def per_frame_leg(args, render, lib, frame, capi, frames, resolve=True):
     host synchronisation (cl_pt_integrator.cpp:677-684).  Untimed by the headline; reported beside it."""
     assert lib.rt_reset(frame) == 0
     render.set_resolve_every_frame(resolve)
-    for _ in range(16):                                   # (HIPPathTraceIntegrator's default times both ways over a scene's first 12 frames: RT_OPT_FRAME_KERNEL = 255)
+    for _ in range(24):                                   # (HIPPathTraceIntegrator's default times both ways over a scene's first 20 frames: RT_OPT_FRAME_KERNEL = 255)
         render.render_frame()
     render.finish()
     st0 = render.stats()
@@ -357,7 +357,7 @@ def frame_kernel_legs(args, render, lib, frame, capi, default_leg):
     the same number of frames must be the same bit for bit whichever way they went."""
     import numpy as np
     frames = args.per_frame_frames
-    want = render.radiance().copy()                          # the default leg has just run: 16 + frames frames since its reset
+    want = render.radiance().copy()                          # the default leg has just run: 24 + frames frames since its reset
     out = dict(default_went="through k_frame" if default_leg["frames_through_k_frame"] >= frames else "through the stage kernels")
     try:
         for name, mode in (("stage_kernels", 0), ("k_frame", 1)):

@@ -264,8 +264,8 @@ enum rt_option
                                       tails overlap.  Same image bit for bit (chunks are independent; path ids are chunk-relative).
                                       Not with RT_OPT_AOV / RT_OPT_DENOISER (whole tile); the debug readers want 1. */
     , RT_OPT_FRAME_KERNEL = 25      /* 0 (default) / 1 / k = 2 .. 64 (k chunks of 64 pixels per wave: more or fewer blocks than are resident; measured: never
-                                      better than 1) / 255 (the choice is MEASURED: frames 2 - 5 of a scene are timed with the stage kernels, 8 - 11 with
-                                      k_frame -- HIP events around each frame's launches -- and the faster way stays until the next rt_scene_upload:
+                                      better than 1) / 255 (the choice is MEASURED: after four warm-up frames, frames 4 - 19 of a scene alternate between the stage kernels
+                                      and k_frame, timed with HIP events around each frame's launches, and the faster way stays until the next rt_scene_upload:
                                       k_frame wins 1.4 - 1.8 x on scenes of up to ~1 M triangles and loses 7 - 10 % on 2.8 M / 10 M): ONE sample per pixel in flight through the stage API -- the reference's frame-by-frame pattern,
                                       Integrator::Integrate through the fifteen hooks -- as ONE launch: the stage calls of a sample are recorded while
                                       they come in the canonical order (rt_generate_rays; rt_intersect, rt_shade, rt_intersect_shadow for bounce 0 ..

@@ -152,9 +152,11 @@ struct rt_frame
     uint32_t frame_blocks = 0, frame_chunks_per_wave = 0;
     uint64_t frame_launches = 0;                                                   // samples rendered by k_frame so far (rt_stats)
     // RT_OPT_FRAME_KERNEL = 255: the choice is MEASURED -- k_frame wins by 1.4 - 1.8 x on scenes of up to ~1 M triangles and loses 7 - 10 % on the 2.8 M /
-    // 10 M ones (profiles/r05_call13.log), so the first frames of a scene time both: 2 + 4 frames with the stage kernels, 2 + 4 with k_frame (HIP events
-    // around each timed frame's launches on the frame's stream, read once the last has completed), then the faster stays.
-    struct { int frames = 0, timing = -1; bool decided = false, use_kernel = false; uint64_t scene = 0; hipEvent_t ev[8][2] = {}; float ms_stage = 0.0f, ms_kernel = 0.0f; } fk_auto;
+    // 10 M ones (profiles/r05_call13.log), so the first frames of a scene time both: frames 0 - 1 (stage kernels) and 2 - 3 (k_frame) warm up, frames 4 - 19
+    // ALTERNATE between the two (the device's clocks ramp over a process's first frames: timed in two blocks, whichever came second looked faster --
+    // rt_render --frames chose k_frame for the 2.8 M-triangle scene, profiles/r05_call18.log) with HIP events around each frame's launches on the frame's
+    // stream, read once the last has completed; then the faster way stays.
+    struct { int frames = 0, timing = -1; bool decided = false, use_kernel = false; uint64_t scene = 0; hipEvent_t ev[16][2] = {}; float ms_stage = 0.0f, ms_kernel = 0.0f; } fk_auto;
     uint32_t n_pipes = 1;          // pipes the current allocation holds
     uint32_t slots = 1;            // samples traced concurrently (resolved from slots_opt)
     uint32_t slots_opt = 0;        // RT_OPT_SAMPLES_IN_FLIGHT as set by the caller (0 = auto)
@@ -2391,7 +2393,9 @@ bool frame_kernel_eligible(const rt_frame* f)
 {
     const rt_ctx* ctx = f->ctx;
     const uint32_t n_local = f->n_local ? f->n_local : 1u;
-    const bool wanted = f->frame_kernel == 255u ? (f->fk_auto.decided ? f->fk_auto.use_kernel : f->fk_auto.frames > 6) : f->frame_kernel != 0u;
+    // (fk_auto.frames has been advanced past the frame being started: frame k = frames - 1)
+    const int fk = f->fk_auto.frames - 1;
+    const bool wanted = f->frame_kernel == 255u ? (f->fk_auto.decided ? f->fk_auto.use_kernel : (fk == 2 || fk == 3 || (fk >= 4 && (fk & 1)))) : f->frame_kernel != 0u;
     return wanted && f->n_local != 0u && !(f->denoiser || f->aov != 0) && ctx->scene.wide_ok && !ctx->scene.slow_shadow &&
            ctx->scene.d.emissive_nee == 0u && f->log_ovf_blocks == 0u && f->n_pipes == 1u && f->chunk_pixels >= n_local && f->stage_chunks <= 1u &&
            (f->trace_variant == 5u || f->trace_variant == 10u) && !f->profile && !f->timeline && f->select_form_box == 0u && f->max_bounces < 63u;
@@ -2506,37 +2510,38 @@ int rt_generate_rays(rt_frame* f)                       // GenerateRays, :516-52
         if (ensure_whole_tile(f) != RT_OK) return RT_ERROR;
         if (f->frame_kernel == 255u)
         {
-            // frames 0 - 1 warm up and 2 - 5 are timed with the stage kernels, 6 - 7 warm up and 8 - 11 are timed with k_frame; once the last timed
-            // frame's events have completed, the faster way stays (until the next scene upload)
+            // frames 0 - 3 warm up (two each way), frames 4 - 19 alternate stage kernels / k_frame and are timed; once the last timed frame's events
+            // have completed, the faster way stays (until the next scene upload)
             auto& m = f->fk_auto;
             if (m.scene != ctx->scene_uploads) { m.frames = 0; m.timing = -1; m.decided = false; m.use_kernel = false; m.scene = ctx->scene_uploads; }
             m.timing = -1;
             if (!m.decided)
             {
                 const int k = m.frames;
-                if (k >= 12 && hipEventQuery(m.ev[7][1]) == hipSuccess)
+                if (k >= 20 && hipEventQuery(m.ev[15][1]) == hipSuccess)
                 {
                     m.ms_stage = m.ms_kernel = 0.0f;
                     bool ok = true;
-                    for (int i = 0; i < 8 && ok; ++i)
+                    for (int i = 0; i < 16 && ok; ++i)
                     {
                         float t = 0.0f;
                         ok = hipEventElapsedTime(&t, m.ev[i][0], m.ev[i][1]) == hipSuccess;
-                        (i < 4 ? m.ms_stage : m.ms_kernel) += t;
+                        ((i & 1) ? m.ms_kernel : m.ms_stage) += t;
                     }
                     if (!ok) (void)hipGetLastError();
                     m.decided = true;
                     m.use_kernel = ok && m.ms_kernel < m.ms_stage;
                 }
-                else if ((k >= 2 && k <= 5) || (k >= 8 && k <= 11))
+                else if (k >= 4 && k < 20)
                 {
-                    m.timing = k <= 5 ? k - 2 : k - 4;
+                    m.timing = k - 4;
                     bool ok = true;
                     for (hipEvent_t& e : m.ev[m.timing]) if (!e) ok = ok && hipEventCreate(&e) == hipSuccess;
                     if (!ok || hipEventRecord(m.ev[m.timing][0], ctx->stream) != hipSuccess) { (void)hipGetLastError(); m.decided = true; m.use_kernel = false; m.timing = -1; }
                 }
                 if (!m.decided) ++m.frames;
             }
+            if (m.decided) m.frames = 1 << 20;          // (frame_kernel_eligible reads `decided`; keep frames - 1 out of the schedule's range)
         }
         if (frame_kernel_eligible(f))
         {
@@ -3079,7 +3084,7 @@ int rt_frame_present_wait(rt_frame* f)
     if (!f) return fail(nullptr, "rt_frame_present_wait: frame is NULL");
     if (!f->present_pending) return RT_OK;
     (void)hipSetDevice(f->ctx->device);
-    HIPCHK(f->ctx, hipStreamSynchronize(f->present_stream));
+    HIPCHK(f->ctx, hipEventSynchronize(f->ev_copied[(f->present_flip ^ 1u) & 1u]));      // the latest copy (its stream carries later frames' work too)
     f->present_pending = false;
     return RT_OK;
 }
@@ -3102,7 +3107,7 @@ int rt_frame_present(rt_frame* f, float* host_rgba)
         hipStream_t st = nullptr;
         hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
         float4* second = nullptr;
-        bool ok = hipStreamCreateWithPriority(&st, hipStreamNonBlocking, lo) == hipSuccess;
+        bool ok = hipStreamCreateWithPriority(&st, hipStreamNonBlocking, lo) == hipSuccess;           // (used only by a frame without a side stream)
         for (hipEvent_t& e : ev) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
         ok = ok && hipMalloc((void**)&second, (size_t)f->n_local * sizeof(float4)) == hipSuccess;
         ok = ok && hipEventRecord(ev[2], st) == hipSuccess && hipEventRecord(ev[3], st) == hipSuccess;
@@ -3126,13 +3131,20 @@ int rt_frame_present(rt_frame* f, float* host_rgba)
         image, f->n_local, f->sample_count, f->aov, f->denoiser);
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipEventRecord(f->ev_resolved[i], ctx->stream));
-    HIPCHK(ctx, hipStreamWaitEvent(f->present_stream, f->ev_resolved[i], 0));
+    // The copy goes to pipe 0's SIDE stream (where the shadow traces run), not to a stream of its own: which hardware queue a further stream lands
+    // on is the runtime's business, and when it was the side stream's the copy's completion barrier held the next frame's shadow traces back for
+    // the whole 0.6 ms -- in rt_render's process with a low-priority copy stream (3.87 instead of 3.33 ms per frame), in bench.py's (PyTorch has
+    // made streams before) with a normal-priority one (3.86 instead of 3.38): profiles/r05_call19.log.  On the side stream itself the order is
+    // explicit and harmless: the copy is enqueued at the end of frame N and runs while frame N + 1 generates, traces and shades its camera rays --
+    // longer than the copy takes -- before that frame's first shadow trace is enqueued behind it.  3.30 / 3.31 ms per frame in both processes.
+    hipStream_t const copy_stream = f->ps[0].side ? f->ps[0].side : f->present_stream;
+    HIPCHK(ctx, hipStreamWaitEvent(copy_stream, f->ev_resolved[i], 0));
     // (The runtime's copy of a page-locked destination is a blit kernel, 441 us for a 1080p image; a 64-block copy kernel of our
     // own that left the other CUs alone was tried and is SLOWER end to end -- it holds PCIe for milliseconds and every persistent
     // grid launched meanwhile finds part of its residency taken: 4.22 instead of 3.70 ms per frame, profiles/r04_call07_*.  The
     // stream's low priority is what keeps the blit's workgroups behind the next frame's first launches.)
-    HIPCHK(ctx, hipMemcpyAsync(host_rgba, image, (size_t)f->n_local * sizeof(float4), hipMemcpyDeviceToHost, f->present_stream));
-    HIPCHK(ctx, hipEventRecord(f->ev_copied[i], f->present_stream));
+    HIPCHK(ctx, hipMemcpyAsync(host_rgba, image, (size_t)f->n_local * sizeof(float4), hipMemcpyDeviceToHost, copy_stream));
+    HIPCHK(ctx, hipEventRecord(f->ev_copied[i], copy_stream));
     f->present_flip ^= 1u;
     f->present_pending = true;
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));      // Finish(), :682: every kernel of the frame has run

@@ -26,7 +26,7 @@ int main(int argc, char** argv)
         unsigned width = 1280, height = 720, spp = 16, bounces = 3, gpus = 1, frames = 0;
         std::string scene_path = "assets/ShaderBalls.obj", out, save_cache;
         float scale = 1.0f, aperture = 0.0f, focus = 10.0f;
-        bool flip_yz = false, furnace = false, tiled_path = false, shared_device = false, plan_only = false;
+        bool flip_yz = false, furnace = false, tiled_path = false, shared_device = false, plan_only = false, resolve = true;
         unsigned scene_options = 0;      // rt::Scene::Options (opt-in extensions)
         for (int i = 1; i < argc; ++i)
         {
@@ -44,6 +44,7 @@ int main(int argc, char** argv)
             else if (!strcmp(argv[i], "--out")) out = next();
             else if (!strcmp(argv[i], "--save-cache")) save_cache = next();
             else if (!strcmp(argv[i], "--gpus")) gpus = (unsigned)atoi(next());
+            else if (!strcmp(argv[i], "--resolve")) resolve = atoi(next()) != 0;          // with --frames: 0 = no ResolveRadiance / present per frame (diagnostic)
             else if (!strcmp(argv[i], "--frames")) frames = (unsigned)atoi(next());      // the reference's interactive loop, headless: n x RenderFrame()
             else if (!strcmp(argv[i], "--tiled")) tiled_path = atoi(next()) != 0;      // take the TiledRender path even with one GPU
             else if (!strcmp(argv[i], "--shared_device")) shared_device = atoi(next()) != 0;   // all tiles on GPU 0 (device copies instead of RCCL)
@@ -131,8 +132,9 @@ int main(int argc, char** argv)
             // The reference's main loop without its window (src/main.cpp:62-72 -> Render::RenderFrame, src/render.cpp:172-204): every frame is one
             // Integrate() through the hooks and ends with ResolveRadiance + Finish().  A warm-up batch first (the fold adaptation happens there),
             // then `frames` timed frames.  No Python, no PyTorch in this process: the HIP runtime is the system's.
+            render.GetIntegrator().SetResolveEveryFrame(resolve);
             render.RenderSamples(8);
-            for (int i = 0; i < 8; ++i) render.RenderFrame();
+            for (int i = 0; i < 24; ++i) render.RenderFrame();             // (the backend times its two ways over a scene's first 20 frames: RT_OPT_FRAME_KERNEL = 255)
             render.GetContext().Finish();
             rt_stats s0 = render.GetIntegrator().GetStats();
             auto tf = std::chrono::steady_clock::now();

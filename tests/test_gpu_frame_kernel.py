@@ -169,10 +169,10 @@ def test_frame_kernel_at_the_production_frame_through_the_hooks():
 
 
 def test_the_measured_choice_times_both_ways_and_changes_no_bit(ctx, golden_scenes):
-    """RT_OPT_FRAME_KERNEL = 255: frames 0 - 5 of a scene go through the stage kernels, 6 - 11 through k_frame (2 warm-up + 4 timed frames each way, host
-    clock between consecutive rt_generate_rays), from frame 12 on the faster way stays -- whichever that is, the accumulated image is the stage kernels';
-    a new scene upload measures again."""
-    w, h, b, n = 96, 64, 3, 20
+    """RT_OPT_FRAME_KERNEL = 255: frames 0 - 1 of a scene go through the stage kernels and 2 - 3 through k_frame (warm-up), frames 4 - 19 alternate and are
+    timed with HIP events, from frame 20 on the faster way stays -- whichever that is, the accumulated image is the stage kernels'; a new scene upload
+    measures again."""
+    w, h, b, n = 96, 64, 3, 26
     sc = golden_scenes["coverage"]
     cam = T.default_camera(w, h)
     ctx.upload_scene(sc)
@@ -184,15 +184,15 @@ def test_the_measured_choice_times_both_ways_and_changes_no_bit(ctx, golden_scen
         stage_sample(plain, b); stage_sample(fr, b)
         ctx.finish()
         seen.append(fr.stats().frame_kernel_samples)
-    assert seen[5] == 0 and seen[11] == 6, seen                               # frames 6 .. 11 were k_frame's
-    assert seen[-1] in (6, 6 + n - 12), seen                                  # ... and from frame 12 on one way or the other
+    assert seen[:4] == [0, 0, 1, 2] and seen[19] == 10, seen                  # frames 2, 3 and the odd ones of 4 .. 19 were k_frame's
+    assert seen[-1] in (10, 10 + n - 20), seen                                # ... and from frame 20 on one way or the other
     assert np.array_equal(fr.radiance(), plain.radiance(), equal_nan=True)
     ctx.upload_scene(sc)                                                      # another upload: the choice is made again
     fr.reset(); plain.reset()
     base = fr.stats().frame_kernel_samples
-    for i in range(8):
+    for i in range(6):
         stage_sample(plain, b); stage_sample(fr, b)
-    assert fr.stats().frame_kernel_samples == base + 2                        # frames 6 and 7 of the new measurement
+    assert fr.stats().frame_kernel_samples == base + 3                        # frames 2, 3 and 5 of the new measurement
     assert np.array_equal(fr.radiance(), plain.radiance(), equal_nan=True)
     fr.close(); plain.close()
 
