@@ -39,7 +39,15 @@ the gather then goes through gloo): plumbing check on a one-GPU box.
 Extra objects on the JSON line:
   per_frame    the reference's OWN call pattern beside the headline: K x Render::RenderFrame() =
                Integrator::Integrate() through the fifteen stage hooks, one sample per pixel per call,
-               ResolveRadiance + host sync every frame (src/render.cpp:197): mrays_per_s, ms_per_frame.
+               ResolveRadiance + host sync every frame (src/render.cpp:197): mrays_per_s, ms_per_frame --
+               as HIPPathTraceIntegrator ships (RT_OPT_FRAME_KERNEL = 255: the backend's measured choice
+               between its stage kernels and ONE k_frame launch per frame).  per_frame.frame_kernel: both ways
+               forced, each with bit_identical_to_the_default_leg; per_frame.moving_camera: the camera turned
+               every frame, with the library's asynchronous fold re-adaptation and with it switched off.
+  adaptation / surface_area_fold   the headline runs on the fold adapted to its view, the adaptation outside the
+               timer: what it took (seconds_to_adapted) and the same job on the fold rt_scene_upload makes.
+  scaling_estimate   "measured": false -- tools/tile_efficiency.py's one-GPU timing of every rank's tile of an
+               N-way split (profiles/r05_tile_efficiency.json); no node with more than one GPU was available.
   roofline     the dominant kernel (closest-hit traversal).  bound "hbm": `achieved` = HBM GB/s from the
                rocprofv3 --pmc passes of this workload (profiles/r05_trace_counters.json, made by
                tools/pmc_bench2.sh + tools/make_counters_json.py), `frac` = achieved / 8 TB/s, `traffic` =
@@ -53,7 +61,9 @@ Extra objects on the JSON line:
                kernels is rendered again on the GPU (same samples, outside the timed
                region) and compared: bit_identical, rel_l2, non-finite pixels on both sides;
                rel_l2_vs_libm_build: the same frame rendered by the reference kernels over glibc's libm
-               instead of the project's rt_detmath.h (an independent pin of the transcendentals).
+               instead of the project's rt_detmath.h (an independent pin of the transcendentals);
+               reference_self_rel_l2: those two builds of the REFERENCE against each other, no GPU involved
+               (what its result moves by when only its builtin library changes); median / p99 per-pixel errors.
   cpu_baseline the reference's own OpenCL kernels compiled for x86-64 (oracle/_ref, kind
                "reference") or the C restatement (kind "port"), timed on this box's host
                cores on a bounded sample.
