@@ -333,32 +333,67 @@ def plumbing_only(args, rank, world):
     return 0
 
 
-def per_frame_leg(args, render, lib, frame, capi, frames, resolve=True):
+def per_frame_leg(args, render, lib, frame, capi, frames, resolve=True, ahead=None):
     """The reference's own call pattern (src/render.cpp:172-204): K x Render::RenderFrame() = Integrator::Integrate()
     through the fifteen stage hooks, ONE sample per pixel per call, each frame ending with ResolveRadiance and its
-    host synchronisation (cl_pt_integrator.cpp:677-684).  Untimed by the headline; reported beside it."""
+    host synchronisation (cl_pt_integrator.cpp:677-684).  Untimed by the headline; reported beside it.
+    ahead: RT_OPT_SAMPLES_AHEAD for this leg (None = as the frame has it).  With the mode on, the banks count rays per batch and
+    run ahead of the sample count, so the rays of exactly the timed frames' samples are counted AFTERWARDS by tracing the same
+    sample indices again with rt_integrate (deterministic; untimed) -- which also says whether the two sums are the same bits."""
+    import numpy as np
+    if ahead is not None:
+        assert lib.rt_set_option(frame, capi.OPT_SAMPLES_AHEAD, ahead) == 0
     assert lib.rt_reset(frame) == 0
     render.set_resolve_every_frame(resolve)
-    for _ in range(24):                                   # (HIPPathTraceIntegrator's default times both ways over a scene's first 20 frames: RT_OPT_FRAME_KERNEL = 255)
+    warm = 24
+    for _ in range(warm):                                 # (HIPPathTraceIntegrator's default times both ways over a scene's first 20 frames: RT_OPT_FRAME_KERNEL = 255)
         render.render_frame()
     render.finish()
     st0 = render.stats()
+    times = []
     t0 = time.perf_counter()
     for _ in range(frames):
+        ta = time.perf_counter()
         render.render_frame()
+        times.append(time.perf_counter() - ta)
     render.finish()
     dt = time.perf_counter() - t0
     st1 = render.stats()
     render.set_resolve_every_frame(False)
     rays = float((st1.closest_rays - st0.closest_rays) + (st1.shadow_rays - st0.shadow_rays))
-    return dict(mrays_per_s=round(rays / dt / 1e6, 1), ms_per_frame=round(dt * 1e3 / frames, 4), frames=frames,
-                rays_per_frame=round(rays / frames, 1), samples_in_flight=1, resolve_every_frame=bool(resolve),
-                frames_through_k_frame=int(st1.frame_kernel_samples - st0.frame_kernel_samples),
-                call_pattern="K x Render::RenderFrame() -> Integrator::Integrate() through the 15 stage hooks of HIPPathTraceIntegrator, "
-                             "1 sample per pixel per call, ResolveRadiance + Finish() (host sync on the frame's kernels) every frame "
-                             "(src/render.cpp:197, src/integrator/integrator.cpp:27-59, cl_pt_integrator.cpp:677-684); the resolved image "
-                             "travels to the host on a copy stream while the next frame is traced (rt_frame_present: the reference "
-                             "resolves into a GL image and reads nothing back); the last image's arrival is inside the timed region")
+    banked = int(st1.samples_from_banks - st0.samples_from_banks)
+    out = dict(frames=frames, samples_in_flight=1, resolve_every_frame=bool(resolve),
+               frames_through_k_frame=int(st1.frame_kernel_samples - st0.frame_kernel_samples))
+    if banked or st1.samples_ahead:
+        got = render.radiance().copy()
+        assert lib.rt_set_option(frame, capi.OPT_SAMPLES_IN_FLIGHT, 8) == 0
+        assert lib.rt_reset(frame) == 0
+        render.render_samples(warm)
+        render.finish()
+        sa = render.stats()
+        render.render_samples(frames)
+        render.finish()
+        sb = render.stats()
+        rays = float((sb.closest_rays - sa.closest_rays) + (sb.shadow_rays - sa.shadow_rays))
+        t = np.sort(np.asarray(times)) * 1e3
+        out["samples_ahead"] = dict(frames_replayed_from_a_batch=banked, samples_ahead_at_the_end=int(st1.samples_ahead),
+                                    ms_per_call_median=round(float(t[len(t) // 2]), 4), ms_per_call_p99=round(float(t[min(len(t) - 1, int(0.99 * len(t)))]), 4),
+                                    ms_per_call_max=round(float(t[-1]), 4),
+                                    bit_identical_to_rt_integrate_of_the_same_samples=bool(np.array_equal(render.radiance(), got, equal_nan=True)),
+                                    rays="counted by an rt_integrate of the same %d sample indices after the timed frames (the banks count per batch and run ahead)" % frames,
+                                    what="RT_OPT_SAMPLES_AHEAD (HIPPathTraceIntegrator's default): while the camera stands still the next samples are traced ahead in "
+                                         "batches of 2, 4, .. k on streams beside the frame's, and an Integrate() whose sample is there replays that sample's log slot -- "
+                                         "the radiance after every call is the same bit for bit; calls come in bursts (a batch's samples one after the other, then a wait "
+                                         "for the next batch): median / p99 / max per call beside the mean")
+        assert lib.rt_set_option(frame, capi.OPT_SAMPLES_IN_FLIGHT, args.samples_in_flight) == 0
+        assert lib.rt_reset(frame) == 0
+    out.update(mrays_per_s=round(rays / dt / 1e6, 1), ms_per_frame=round(dt * 1e3 / frames, 4), rays_per_frame=round(rays / frames, 1),
+               call_pattern="K x Render::RenderFrame() -> Integrator::Integrate() through the 15 stage hooks of HIPPathTraceIntegrator, "
+                            "1 sample per pixel per call, ResolveRadiance + Finish() (host sync on the frame's kernels) every frame "
+                            "(src/render.cpp:197, src/integrator/integrator.cpp:27-59, cl_pt_integrator.cpp:677-684); the resolved image "
+                            "travels to the host on a copy stream while the next frame is traced (rt_frame_present: the reference "
+                            "resolves into a GL image and reads nothing back); the last image's arrival is inside the timed region")
+    return out
 
 
 def frame_kernel_legs(args, render, lib, frame, capi, default_leg):
@@ -367,12 +402,16 @@ def frame_kernel_legs(args, render, lib, frame, capi, default_leg):
     the same number of frames must be the same bit for bit whichever way they went."""
     import numpy as np
     frames = args.per_frame_frames
-    want = render.radiance().copy()                          # the default leg has just run: 24 + frames frames since its reset
-    out = dict(default_went="through k_frame" if default_leg["frames_through_k_frame"] >= frames else "through the stage kernels")
+    out = {}
     try:
+        # every Integrate() traces its own sample (RT_OPT_SAMPLES_AHEAD = 0: round 5's default): the measured choice, then both ways forced
+        one = per_frame_leg(args, render, lib, frame, capi, frames, ahead=0)
+        want = render.radiance().copy()                      # 24 + frames frames since its reset
+        out["one_sample_per_call"] = dict(mrays_per_s=one["mrays_per_s"], ms_per_frame=one["ms_per_frame"], frames=frames, frames_through_k_frame=one["frames_through_k_frame"])
+        out["default_went"] = "through k_frame" if one["frames_through_k_frame"] >= frames else "through the stage kernels"
         for name, mode in (("stage_kernels", 0), ("k_frame", 1)):
             assert lib.rt_set_option(frame, capi.OPT_FRAME_KERNEL, mode) == 0
-            leg = per_frame_leg(args, render, lib, frame, capi, frames)
+            leg = per_frame_leg(args, render, lib, frame, capi, frames, ahead=0)
             out[name] = dict(mrays_per_s=leg["mrays_per_s"], ms_per_frame=leg["ms_per_frame"], frames=frames,
                              frames_through_k_frame=leg["frames_through_k_frame"],
                              bit_identical_to_the_default_leg=bool(np.array_equal(render.radiance(), want, equal_nan=True)))
@@ -380,7 +419,8 @@ def frame_kernel_legs(args, render, lib, frame, capi, default_leg):
         out["error"] = repr(e)
     finally:
         lib.rt_set_option(frame, capi.OPT_FRAME_KERNEL, 255)
-    out["what"] = ("RT_OPT_FRAME_KERNEL: every frame of the hooks' pattern as one launch in which each wave carries its own pixels through all the bounces "
+        lib.rt_set_option(frame, capi.OPT_SAMPLES_AHEAD, 1 if args.samples_ahead is None else args.samples_ahead)
+    out["what"] = ("with RT_OPT_SAMPLES_AHEAD = 0 (every Integrate() traces its own sample).  RT_OPT_FRAME_KERNEL: every frame of the hooks' pattern as one launch in which each wave carries its own pixels through all the bounces "
                    "(raytracing_amd/csrc/frame_kernels.h), or the stage kernels (47 launches per frame); 255 = measured per scene")
     return out
 
@@ -620,10 +660,15 @@ def main():
                     "travels as one chunk; 2..4: as that many chunks on streams of their own, their launch tails overlapping)")
     ap.add_argument("--frame-kernel", type=int, default=None, help="RT_OPT_FRAME_KERNEL for the per_frame legs (library default 0): 1 = every frame of the "
                     "hooks' pattern is ONE launch of k_frame")
+    ap.add_argument("--wide-layout", type=int, default=None, help="RT_CTX_OPT_WIDE_LAYOUT (library default 0): 1 = the 4-wide records in (parent, likeliest child) pairs, one pair per 128-byte line")
+    ap.add_argument("--device-fold", type=int, default=None, help="RT_CTX_OPT_DEVICE_FOLD (library default 1): 0 = the folds on host threads")
+    ap.add_argument("--samples-ahead", type=int, default=None, help="RT_OPT_SAMPLES_AHEAD for the per_frame leg (HIPPathTraceIntegrator's default: 1 = automatic depth; "
+                    "0 = every Integrate() traces its own sample; k = 2..64 samples per batch; + 256 = one stream per bank)")
     ap.add_argument("--moving-camera-frames", type=int, default=720, help="frames of per_frame.moving_camera (0 = skip): the camera turns 0.66 degrees per frame, "
                     "so it leaves the adapted view every ~30 frames, with the library's default (asynchronous) fold adaptation")
     ap.add_argument("--surface-area-fold-steps", type=int, default=2, help="steps of the surface-area-fold figure printed beside value (0 = skip): the scene uploaded "
                     "again with RT_CTX_OPT_ADAPTIVE_FOLD = 0 after everything else, untimed by the driver")
+    ap.add_argument("--cold-job-spp", type=int, default=256, help="samples of the cold_job leg: BASELINE's job from rt_scene_upload to the gather on the library's defaults (0 = skip)")
     ap.add_argument("--per-frame-only", action="store_true", help="run only the per_frame leg and print its object (tuning runs)")
     ap.add_argument("--debug-shared-gpu", action="store_true",
                     help="plumbing test only: all ranks share GPU 0 and gather over gloo (RCCL refuses two ranks per device)")
@@ -707,9 +752,14 @@ def main():
     render = host.Render(args.width, args.height, scene, device=local_rank, tile_rank=rank, tile_count=world,
                          band_height=args.band_height)      # builds the BVH (or adopts the cached one), finalises, uploads
     t_setup = time.time() - t0
+    setup_breakdown = render.setup_seconds()                 # Render's constructor: BVH build / Finalize / frame / UploadGPUData (its stages: the `upload:` line of the tree report)
     if args.wide_collapse != 1:
         render.set_wide_bvh(args.wide_collapse)               # A/B: uploads the scene again with the other collapse
-    if args.shadow_tree is not None or args.closest_tree is not None or args.adaptive_fold != capi.ADAPTIVE_FOLD_DEFAULT:
+    if args.shadow_tree is not None or args.closest_tree is not None or args.adaptive_fold != capi.ADAPTIVE_FOLD_DEFAULT or args.wide_layout is not None or args.device_fold is not None:
+        if args.wide_layout is not None:
+            render.set_ctx_option(8, args.wide_layout, False)      # RT_CTX_OPT_WIDE_LAYOUT
+        if args.device_fold is not None:
+            render.set_ctx_option(7, args.device_fold, False)      # RT_CTX_OPT_DEVICE_FOLD
         if args.adaptive_fold != capi.ADAPTIVE_FOLD_DEFAULT:
             render.set_adaptive_fold(args.adaptive_fold, upload=False)
         if args.shadow_tree is not None:
@@ -786,7 +836,7 @@ def main():
             assert lib.rt_set_option(frame, capi.OPT_FRAME_KERNEL, args.frame_kernel) == 0
         if args.stage_pipes:
             assert lib.rt_set_option(frame, capi.OPT_STAGE_PIPES, args.stage_pipes) == 0
-        pf = per_frame_leg(args, render, lib, frame, capi, max(args.per_frame_frames, 1))
+        pf = per_frame_leg(args, render, lib, frame, capi, max(args.per_frame_frames, 1), ahead=args.samples_ahead)
         if args.moving_camera_frames > 0:
             pf["moving_camera"] = moving_camera_leg(args, render, lib, frame, capi, host, cam, args.moving_camera_frames)
         if rank == 0:
@@ -941,7 +991,7 @@ def main():
     if world == 1 and args.per_frame_frames > 0:
         if args.stage_pipes:
             assert lib.rt_set_option(frame, capi.OPT_STAGE_PIPES, args.stage_pipes) == 0
-        per_frame = per_frame_leg(args, render, lib, frame, capi, args.per_frame_frames)
+        per_frame = per_frame_leg(args, render, lib, frame, capi, args.per_frame_frames, ahead=args.samples_ahead)
         per_frame["stage_pipes"] = args.stage_pipes or 1
         if args.frame_kernel is None:
             per_frame["frame_kernel"] = frame_kernel_legs(args, render, lib, frame, capi, per_frame)
@@ -1077,6 +1127,35 @@ def main():
                                          what="the same job on the fold rt_scene_upload makes (RT_CTX_OPT_ADAPTIVE_FOLD = 0), same box, untimed by the driver")
             except Exception as e:                              # noqa: BLE001 -- reported, never fatal to the measurement
                 surface_area_fold = dict(error=repr(e))
+        # BASELINE's job as a user of rt_render gets it: 256 spp of this frame from rt_scene_upload to the last sample's gather, the LIBRARY's defaults
+        # (RT_CTX_OPT_ADAPTIVE_FOLD = 25: the probe, the worker and the adoption run beside the job, nothing waits for them), per-path buffers
+        # allocated inside the timer.  Beside the warm headline: what a cold job really sees of the adapted fold.
+        cold_job = None
+        if world == 1 and args.cold_job_spp > 0 and not args.per_frame_only:
+            try:
+                assert lib.rt_set_option(frame, capi.OPT_SAMPLES_IN_FLIGHT, 1) == 0      # gives the batch buffers back ...
+                assert lib.rt_set_option(frame, capi.OPT_SAMPLES_IN_FLIGHT, args.samples_in_flight) == 0
+                render.finish()
+                t_a = time.perf_counter()
+                render.set_adaptive_fold(capi.ADAPTIVE_FOLD_DEFAULT)                      # ... and uploads the scene again (rt_scene_upload)
+                t_b = time.perf_counter()
+                c0 = render.stats()
+                assert lib.rt_reset(frame) == 0
+                render.render_samples(args.cold_job_spp)
+                render.finish()
+                gather(True)
+                t_c = time.perf_counter()
+                c1 = render.stats()
+                c_rays = float((c1.closest_rays - c0.closest_rays) + (c1.shadow_rays - c0.shadow_rays))
+                cold_job = dict(spp=args.cold_job_spp, upload_s=round(t_b - t_a, 3), render_s=round(t_c - t_b, 3), wall_s=round(t_c - t_a, 3),
+                                mrays_per_s_render=round(c_rays / (t_c - t_b) / 1e6, 1), mrays_per_s_wall=round(c_rays / (t_c - t_a) / 1e6, 1),
+                                over_the_warm_headline=round(c_rays / (t_c - t_b) / 1e6 / value, 4) if value > 0 else None,
+                                trees=render.tree_report().strip().split("\n"),
+                                what="the config's whole job, cold: rt_scene_upload (re-layout, folds, own tree, tree choice) + %d spp + the gather, library defaults "
+                                     "(adaptive fold 25 = asynchronous: the job starts on the upload's fold and adopts the adapted one when its worker is done), per-path "
+                                     "buffers allocated inside the timer; scene generation / OBJ parsing and the reference-topology BVH build are in setup_s" % args.cold_job_spp)
+            except Exception as e:                              # noqa: BLE001 -- reported, never fatal to the measurement
+                cold_job = dict(error=repr(e))
         scaling_estimate = None
         est_path = os.path.join(ROOT, "profiles", "r05_tile_efficiency.json")
         if os.path.exists(est_path) and args.config == 4:
@@ -1114,6 +1193,7 @@ def main():
                                 log_inline_entries=int(st1.log_inline_entries), log_fallbacks=int(st1.log_fallbacks),   # 0 inline = the full log layout
                                 trees=trees_now, adaptive_fold=args.adaptive_fold,    # what rt_scene_upload measured when it chose the shadow (/ closest-hit) tree
                                 setup_s=round(t_setup, 2), scene_s=round(t_scene, 2),     # scene_s: parse / generate (or load the cache); setup_s: + BVH, wide collapse, upload
+                                setup_breakdown=setup_breakdown,
                                 device=name),
                     ranks=dict(render_ms_min=round(float(tmin[0].item()) * 1e3, 3), render_ms_max=round(float(tmax[1].item()) * 1e3, 3),
                                render_ms=[r["render_ms"] for r in per_rank], gather_ms=[r["gather_ms"] for r in per_rank],
@@ -1123,7 +1203,7 @@ def main():
                                in_flight=[r["in_flight"] for r in per_rank], rays_per_launch=[r["rays_per_launch"] for r in per_rank],
                                rays_in_first_launch=[r["rays_in_first_launch"] for r in per_rank]),
                     gather=gather_info, per_frame=per_frame, roofline=roofline, parity=parity, cpu_baseline=baseline,
-                    adaptation=adaptation, surface_area_fold=surface_area_fold, scaling_estimate=scaling_estimate)
+                    adaptation=adaptation, surface_area_fold=surface_area_fold, cold_job=cold_job, scaling_estimate=scaling_estimate)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -101,6 +101,16 @@ enum rt_ctx_option
     , RT_CTX_OPT_ADAPT_MIN_INTERVAL_MS = 5 /* default 500: a camera that keeps leaving the adapted view (an orbit) starts at most one
                                       fold adaptation per this many milliseconds (bit 1 of RT_CTX_OPT_ADAPTIVE_FOLD -- wait for every
                                       adaptation: tests, bench.py -- is not rate-limited).  Takes effect at once. */
+    , RT_CTX_OPT_DEVICE_FOLD = 7   /* 1 (default): the collapse of a binary tree into the 4-wide records of k_trace_w4 -- the dynamic programme over node x slots,
+                                      the record roots, the slots' placement, the quantised boxes -- runs on the DEVICE (raytracing_amd/csrc/fold_kernels.h:
+                                      five kernels; the reference's tree at rt_scene_upload, the shadow rays' own tree, and every re-fold of an
+                                      adaptation, whose crossing counts are a device kernel too); 0: on host threads (build_wide_bvh, the same algorithm:
+                                      the two are compared record for record in tests/test_gpu_device_fold.py, and the host's is the fallback when the device
+                                      path fails).  Results do not depend on it.  Takes effect at the next rt_scene_upload. */
+    , RT_CTX_OPT_WIDE_LAYOUT = 8   /* 0: the 4-wide records in the fold's own (depth-first) order; 1: in PAIRS -- every record with interior slots at an even index,
+                                      the child it hands most rays on to right behind it, i.e. in the same 128-byte line (the L2 of gfx950 fetches whole lines:
+                                      a 64-byte record that misses pays for its line-mate anyway).  A permutation of the records: no result depends on it.
+                                      Takes effect at the next rt_scene_upload. */
     , RT_CTX_OPT_ADAPT_WAIT = 6    /* 1 / 0: sets / clears bit 1 of RT_CTX_OPT_ADAPTIVE_FOLD (rt_integrate waits for an adaptation it has
                                       started) for the scene IN PLACE, at once; the context's option, which the next upload reads, stays
                                       (bench.py: the headline waits for its fold, the moving-camera leg runs as the library ships) */
@@ -274,6 +284,19 @@ enum rt_option
                                       radiance between two stages replays the recorded stages with the stage kernels first.  Same radiance and ray
                                       counters bit for bit.  Not with AOVs / the denoiser, the compact log, RT_SCENE_EMISSIVE_NEE or profiling
                                       (those samples take the stage kernels). */
+    , RT_OPT_SAMPLES_AHEAD = 26     /* 0 (default: off) / 1 (automatic depth: batches of ~16 M paths, i.e. 8 samples of a 1080p frame) / k = 2 .. 64 samples per batch;
+                                      + 256: the two banks launch on a stream each (their batches overlap) instead of one after the other on one stream.
+                                      The stage API -- the reference's frame-by-frame pattern, one Integrate() per frame at one sample per pixel,
+                                      src/render.cpp:197 -- traces the NEXT samples of a standing camera ahead: after three samples without rt_reset the frame
+                                      enqueues batches of 2, 4, .. k consecutive samples (rt_integrate's launches, its radiance log left unreplayed) into two
+                                      banks beside its own stream, and a later sample that sits in a bank costs its Integrate() one replay of that sample's log
+                                      slot -- the radiance after EVERY call is the reference's, bit for bit, sample by sample.  rt_reset, another camera or
+                                      option, rt_scene_upload, rt_integrate and anything that looks between two stages drop what was traced ahead (at most
+                                      2 k samples of device time, once; a camera that moves every frame never starts the mode).  The image of a frame is
+                                      what it always was; what changes is WHEN the work is done: a launch of one sample per pixel is its own tail (3.3 ms per
+                                      1080p frame of the 2.8 M-triangle scene where the rays are worth 1.6), a launch of k is not.  Costs: two more sets of
+                                      per-path buffers for k samples in flight (within 64 GiB, or RT_OPT_PATH_STATE_LIMIT_MB); rt_stats' ray totals run ahead of
+                                      its sample count by rt_stats.samples_ahead.  Not with AOVs / the denoiser / RT_OPT_STAGE_PIPES / profiling. */
     , RT_OPT_TRACE_TUNE = 12       /* k_trace2 (variants 8, 9) loop thresholds: value & 255 = lanes that must hold an
                                        interior node for a wave to stay in the node loop, value >> 8 & 255 = lanes that
                                        must wait at a triangle for another pass of the triangle loop, value >> 16 & 255 = rays a wave takes
@@ -355,7 +378,9 @@ typedef struct rt_stats
                                           (RT_OPT_COMPACT_LOG); 0: the full layout, 2 (max_bounces + 1) entries per path */
     uint32_t log_fallbacks;            /* batches whose overflow pool ran dry and that were repeated in the full layout */
     uint32_t frame_kernel_samples;     /* samples of the stage API that went through k_frame in one launch (RT_OPT_FRAME_KERNEL), since the frame was created */
-    uint32_t reserved_;
+    uint32_t samples_ahead;            /* RT_OPT_SAMPLES_AHEAD: samples traced (or being traced) ahead of `samples` at the moment; closest_rays / shadow_rays
+                                          INCLUDE their rays (the banks count per batch) */
+    uint64_t samples_from_banks;       /* RT_OPT_SAMPLES_AHEAD: samples of the stage API that were replayed out of a batch traced ahead, since the frame was created */
 } rt_stats;
 int rt_frame_get_stats(rt_frame* frame, rt_stats* out);
 /* RT_OPT_FRAME_KERNEL's per-wave rows of the latest k_frame launch (diagnostics: rays per bounce and 100 MHz ticks per phase of every wave;
@@ -460,6 +485,18 @@ int rt_debug_own_bvh(const rt_bvh_node* nodes, uint32_t num_nodes, double iso_we
  * the own trees) */
 int rt_debug_wide_bvh_metric(const rt_bvh_node* nodes, uint32_t num_nodes, double iso_weight, const float* dirs, uint32_t n_dirs,
     void* records, uint32_t capacity, uint32_t* num_records, uint32_t* entry_ref);
+
+/* fold_kernels.h on its own: the SAH collapse of `nodes` run on ctx's device (metric: iso_weight < 0 = plain surface area, else as rt_debug_wide_bvh_metric;
+ * weights: per node, or NULL) -- the records, the node each one tests, *seconds = what the device path took.  tests/test_gpu_device_fold.py compares it
+ * with rt_debug_wide_bvh / rt_debug_wide_bvh_metric / rt_debug_adapt_fold record for record. */
+int rt_debug_device_fold(rt_ctx* ctx, const rt_bvh_node* nodes, uint32_t num_nodes, double iso_weight, const float* dirs, uint32_t n_dirs, const double* weights,
+    void* records, uint32_t* roots, uint32_t capacity, uint32_t* num_records, uint32_t* entry_ref, double* seconds);
+/* RT_CTX_OPT_WIDE_LAYOUT = 1 on its own (host only): the records of a fold of `nodes` (and the node each one tests) permuted in place into (parent,
+ * likeliest child) pairs, by the area of the children's boxes. */
+int rt_debug_pair_layout(const rt_bvh_node* nodes, uint32_t num_nodes, void* records, uint32_t* roots, uint32_t num_records);
+/* ... and the host's fold for given per-node weights (what an adaptation folds with), for that comparison */
+int rt_debug_wide_bvh_weights(const rt_bvh_node* nodes, uint32_t num_nodes, const double* weights, void* records, uint32_t* roots, uint32_t capacity,
+    uint32_t* num_records, uint32_t* entry_ref);
 
 /* RT_CTX_OPT_ADAPTIVE_FOLD's host half on its own (no device): the fold of `nodes` adapted to n_rays rays (origins_tmax: x, y, z, t_max per
  * ray; directions: x, y, z, - per ray) -- its records (and, optional, the node each one tests), and cost2 = {the surface-area fold's, the adapted

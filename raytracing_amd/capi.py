@@ -22,7 +22,7 @@ class rt_stats(C.Structure):
                 ("last_active", C.c_uint32 * 64), ("last_shadow", C.c_uint32 * 64),
                 ("samples_in_flight", C.c_uint32), ("samples_in_flight_limit", C.c_uint32), ("path_state_bytes", C.c_uint64),
                 ("stack_spills", C.c_uint32), ("slow_rays", C.c_uint32), ("chunk_pixels", C.c_uint32), ("pipelines", C.c_uint32),
-                ("log_inline_entries", C.c_uint32), ("log_fallbacks", C.c_uint32), ("frame_kernel_samples", C.c_uint32), ("reserved_", C.c_uint32)]
+                ("log_inline_entries", C.c_uint32), ("log_fallbacks", C.c_uint32), ("frame_kernel_samples", C.c_uint32), ("samples_ahead", C.c_uint32), ("samples_from_banks", C.c_uint64)]
 
 
 class rt_profile(C.Structure):
@@ -63,13 +63,13 @@ EXPORTS = [
     "rt_compute_aovs", "rt_denoise", "rt_copy_history",
     "rt_frame_resolve", "rt_frame_present", "rt_frame_present_wait", "rt_frame_read_radiance", "rt_frame_radiance_device_ptr", "rt_frame_sample_count",
     "rt_frame_get_stats", "rt_frame_get_profile", "rt_frame_copy_radiance", "rt_frame_debug_read_queue", "rt_frame_debug_read_hits", "rt_debug_eval",
-    "rt_debug_wide_bvh", "rt_frame_debug_timeline", "rt_frame_debug_frame_rows", "rt_debug_own_bvh", "rt_debug_wide_bvh_metric", "rt_scene_tree_report", "rt_debug_choose_tree", "rt_debug_adapt_fold", "rt_debug_fold_abandon", "rt_debug_adapt_shadow_side", "rt_debug_rotate_tree", "rt_debug_fold_view_left",
+    "rt_debug_wide_bvh", "rt_frame_debug_timeline", "rt_frame_debug_frame_rows", "rt_debug_own_bvh", "rt_debug_wide_bvh_metric", "rt_scene_tree_report", "rt_debug_choose_tree", "rt_debug_adapt_fold", "rt_debug_fold_abandon", "rt_debug_adapt_shadow_side", "rt_debug_rotate_tree", "rt_debug_fold_view_left", "rt_debug_device_fold", "rt_debug_wide_bvh_weights", "rt_debug_pair_layout",
     "rt_group_create", "rt_group_unique_id", "rt_group_join", "rt_group_size", "rt_group_local_count", "rt_group_local_rank", "rt_group_comm_count",
     "rt_group_gather_radiance", "rt_group_destroy", "rt_group_last_error", "rt_group_denoise", "rt_group_create_local",
     "rt_group_create_unchecked",
 ]
 
-OPT_MAX_BOUNCES, OPT_WHITE_FURNACE, OPT_SAMPLER, OPT_AOV, OPT_DENOISER, OPT_DROP_LAST, OPT_PROFILE, OPT_TRACE_VARIANT, OPT_TRACE_WAVES, OPT_SAMPLES_IN_FLIGHT, OPT_SELECT_FORM_BOX, OPT_PACKET_BOUNCES, OPT_TRACE_TUNE, OPT_DEBUG_ALLOC_LIMIT, OPT_PATH_STATE_LIMIT_MB, OPT_PIPELINES, OPT_SHADE_PARTITION, OPT_OVERLAP_SHADOW, OPT_SMALL_LAUNCH_PATHS, OPT_COMPACT_LOG, OPT_DEBUG_LOG_POOL_DIV, OPT_TRACE_TAIL_LANES, OPT_TRACE_TAIL_PATHS, OPT_CHUNK_REFILL, OPT_STAGE_PIPES, OPT_FRAME_KERNEL = range(26)
+OPT_MAX_BOUNCES, OPT_WHITE_FURNACE, OPT_SAMPLER, OPT_AOV, OPT_DENOISER, OPT_DROP_LAST, OPT_PROFILE, OPT_TRACE_VARIANT, OPT_TRACE_WAVES, OPT_SAMPLES_IN_FLIGHT, OPT_SELECT_FORM_BOX, OPT_PACKET_BOUNCES, OPT_TRACE_TUNE, OPT_DEBUG_ALLOC_LIMIT, OPT_PATH_STATE_LIMIT_MB, OPT_PIPELINES, OPT_SHADE_PARTITION, OPT_OVERLAP_SHADOW, OPT_SMALL_LAUNCH_PATHS, OPT_COMPACT_LOG, OPT_DEBUG_LOG_POOL_DIV, OPT_TRACE_TAIL_LANES, OPT_TRACE_TAIL_PATHS, OPT_CHUNK_REFILL, OPT_STAGE_PIPES, OPT_FRAME_KERNEL, OPT_SAMPLES_AHEAD = range(27)
 
 
 def load():
@@ -119,6 +119,9 @@ def load():
         "rt_debug_own_bvh": (i32, [vp, u32, C.c_double, vp, u32, vp, u32, C.POINTER(u32)]),
         "rt_debug_wide_bvh_metric": (i32, [vp, u32, C.c_double, vp, u32, vp, u32, C.POINTER(u32), C.POINTER(u32)]),
         "rt_debug_fold_view_left": (i32, [vp, vp, C.c_double]),
+        "rt_debug_device_fold": (i32, [vp, vp, u32, C.c_double, vp, u32, vp, vp, vp, u32, C.POINTER(u32), C.POINTER(u32), C.POINTER(C.c_double)]),
+        "rt_debug_wide_bvh_weights": (i32, [vp, u32, vp, vp, vp, u32, C.POINTER(u32), C.POINTER(u32)]),
+        "rt_debug_pair_layout": (i32, [vp, u32, vp, vp, u32]),
         "rt_debug_rotate_tree": (i32, [vp, u32, vp, vp, u32, i32, vp, C.POINTER(C.c_double), C.POINTER(u32), i32, C.c_double]),
         "rt_debug_adapt_shadow_side": (i32, [vp, u32, vp, vp, u32, u32, vp, vp, u32, C.POINTER(u32), C.POINTER(u32), vp, C.POINTER(C.c_double), C.POINTER(u32), vp, u32, C.POINTER(u32)]),
         "rt_debug_fold_abandon": (C.c_double, [vp, u32, vp, vp, u32, u32, u32, C.POINTER(i32)]),
@@ -165,6 +168,36 @@ def choose_tree(scene, shadow=True, mode=1):
 
 
 ADAPTIVE_FOLD_DEFAULT = 25     # rt_ctx's RT_CTX_OPT_ADAPTIVE_FOLD as created (rt_hip.hip): bits 0 + 3 + 4 since round 5
+
+
+def device_fold(ctx, nodes, iso_weight=-1.0, dirs=None, weights=None):
+    """rt_debug_device_fold: the SAH collapse of the LinearBVHNode[] `nodes` on ctx's device (raytracing_amd/csrc/fold_kernels.h).
+    iso_weight < 0: the plain surface area; else the metric of rt_debug_wide_bvh_metric; weights: float64[n] per node or None.
+    Returns (records uint8[n, 64], entry_ref, roots uint32[n], seconds)."""
+    lib = load()
+    nodes = np.ascontiguousarray(nodes)
+    d = np.ascontiguousarray(dirs, np.float32) if dirs is not None else None
+    w = np.ascontiguousarray(weights, np.float64) if weights is not None else None
+    cap = len(nodes) // 2 + 2
+    out, roots = np.zeros((cap, 64), np.uint8), np.zeros(cap, np.uint32)
+    n, entry, sec = C.c_uint32(), C.c_uint32(), C.c_double()
+    if lib.rt_debug_device_fold(ctx.handle, nodes.ctypes.data, len(nodes), iso_weight, d.ctypes.data if d is not None else None, len(d) if d is not None else 0,
+                                w.ctypes.data if w is not None else None, out.ctypes.data, roots.ctypes.data, cap, C.byref(n), C.byref(entry), C.byref(sec)):
+        raise RtError(lib.rt_last_error(ctx.handle).decode())
+    return out[:n.value].copy(), entry.value, roots[:n.value].copy(), sec.value
+
+
+def wide_bvh_weights(nodes, weights):
+    """rt_debug_wide_bvh_weights (host only): build_wide_bvh's SAH collapse with per-node weights in place of the area.  Returns (records, entry_ref, roots)."""
+    lib = load()
+    nodes = np.ascontiguousarray(nodes)
+    w = np.ascontiguousarray(weights, np.float64)
+    cap = len(nodes) // 2 + 2
+    out, roots = np.zeros((cap, 64), np.uint8), np.zeros(cap, np.uint32)
+    n, entry = C.c_uint32(), C.c_uint32()
+    if lib.rt_debug_wide_bvh_weights(nodes.ctypes.data, len(nodes), w.ctypes.data, out.ctypes.data, roots.ctypes.data, cap, C.byref(n), C.byref(entry)):
+        raise RtError(lib.rt_last_error(None).decode())
+    return out[:n.value].copy(), entry.value, roots[:n.value].copy()
 
 
 def adapt_fold(nodes, origins_tmax, directions):

@@ -7,3 +7,4 @@
 #include "frame_kernels.h"
 #include "aov_kernels.h"
 #include "relayout_kernels.h"
+#include "fold_kernels.h"

@@ -20,6 +20,7 @@
 #include "tree_select.h"
 #include "tree_rotate.h"
 #include <chrono>
+#include "device_fold.h"
 
 namespace
 {
@@ -73,6 +74,8 @@ struct rt_ctx
                                   // every shadow record are stored likeliest occluder first (measured on the device in round 5, profiles/r05_call01_*:
                                   // shadow trace 0.314 -> 0.258 ms per sample on the headline scene, bit-identical on all five configs)
     uint32_t adapt_min_interval_ms = 500;   // RT_CTX_OPT_ADAPT_MIN_INTERVAL_MS
+    uint32_t wide_layout = 0;               // RT_CTX_OPT_WIDE_LAYOUT: 1 = the 4-wide records stored in (parent, likeliest child) pairs, one pair per 128-byte line (pair_layout)
+    uint32_t device_fold = 1;               // RT_CTX_OPT_DEVICE_FOLD: the SAH collapse into 4-wide records runs on the device (fold_kernels.h); 0 = on host threads
     uint64_t scene_uploads = 0;             // rt_scene_upload calls so far (what a frame's measured choices were made for)
     std::vector<rt_frame*> frames;   // the frames alive on this context (rt_finish waits for their side streams too)
     uint8_t* blue_noise = nullptr;   // sobol[65536] | scramblingTile[131072] | rankingTile[131072]
@@ -119,6 +122,28 @@ struct PathPipe
     bool shadow_pending = false;       // rt_shade issued, rt_intersect_shadow not yet
 };
 
+// RT_OPT_SAMPLES_AHEAD: samples of the stage API traced ahead of the caller's Integrate() calls (below, "samples ahead").  A BANK is a frame of its
+// own -- same tile, same options, its own per-path buffers -- that holds one batch; two banks, so that one computes while the other is consumed.
+struct AheadBank
+{
+    rt_frame* h = nullptr;
+    uint32_t base = 0, n = 0, next = 0;     // holds samples base .. base + n - 1; slots < next have reached the owner's radiance
+    hipEvent_t done = nullptr;              // the batch's last launch (the bank's stream, after its side stream has been joined)
+    hipEvent_t order = nullptr;             // what the bank's stream waits for before it starts another batch: the owner's last replay of the old one
+};
+struct Ahead
+{
+    AheadBank bank[2];
+    hipStream_t stream[2] = {nullptr, nullptr};
+    uint32_t quiet = 0;                     // samples advanced since the last reset / discard
+    uint32_t depth = 0, last_n = 0;         // the most samples a batch holds (resolved for this tile); the latest batch's size (the ramp: 2, 4, .. depth)
+    bool configured = false;
+    uint32_t mirrored[16] = {};             // the owner's options as the banks have them
+    rt_camera camera;                       // what the batches in flight were traced for
+    uint64_t scene = 0;
+    uint64_t launched = 0, consumed = 0, discarded = 0;   // samples
+};
+
 struct rt_frame
 {
     rt_ctx* ctx;
@@ -146,7 +171,11 @@ struct rt_frame
     // while they come in the canonical order; rt_advance_sample launches the kernel.  Anything that needs the state between two stages
     // (a debug reader, the radiance mid-sample, another order of calls) first replays the recorded stages with the stage kernels.
     uint32_t frame_kernel = 0;
-    struct { bool active = false; uint32_t bounce = 0; int next = 0; } deferred;   // next: 0 = rt_intersect(bounce), 1 = rt_shade, 2 = rt_intersect_shadow
+    struct { bool active = false; uint32_t bounce = 0; int next = 0; bool ahead = false; } deferred;   // next: 0 = rt_intersect(bounce), 1 = rt_shade, 2 = rt_intersect_shadow;
+                                                                                                      // ahead: the sample is in a bank (RT_OPT_SAMPLES_AHEAD)
+    uint32_t ahead_opt = 0;            // RT_OPT_SAMPLES_AHEAD
+    Ahead* ahead = nullptr;            // ... its banks (made when the first batch is launched)
+    rt_frame* ahead_owner = nullptr;   // this frame IS a bank of that frame
     uint32_t* frame_counts = nullptr; uint32_t* frame_slow = nullptr;              // k_frame's per-wave rows and slow-ray lists
     uint2* frame_spill = nullptr;                                                  // ... and its blocks' stack spill area
     uint32_t frame_blocks = 0, frame_chunks_per_wave = 0;
@@ -156,7 +185,7 @@ struct rt_frame
     // ALTERNATE between the two (the device's clocks ramp over a process's first frames: timed in two blocks, whichever came second looked faster --
     // rt_render --frames chose k_frame for the 2.8 M-triangle scene, profiles/r05_call18.log) with HIP events around each frame's launches on the frame's
     // stream, read once the last has completed; then the faster way stays.
-    struct { int frames = 0, timing = -1; bool decided = false, use_kernel = false; uint64_t scene = 0; hipEvent_t ev[16][2] = {}; float ms_stage = 0.0f, ms_kernel = 0.0f; } fk_auto;
+    struct { int frames = 0, timing = -1; bool decided = false, use_kernel = false, skip = false; uint64_t scene = 0; hipEvent_t ev[16][2] = {}; float ms_stage = 0.0f, ms_kernel = 0.0f; } fk_auto;
     uint32_t n_pipes = 1;          // pipes the current allocation holds
     uint32_t slots = 1;            // samples traced concurrently (resolved from slots_opt)
     uint32_t slots_opt = 0;        // RT_OPT_SAMPLES_IN_FLIGHT as set by the caller (0 = auto)
@@ -217,6 +246,10 @@ struct rt_frame
 };
 
 static int sync_frame_streams(rt_frame* f);
+static void ahead_discard(rt_frame* f);      // RT_OPT_SAMPLES_AHEAD: whatever was traced ahead is dropped (reset, another camera, another option, a peek)
+static void ahead_destroy(rt_frame* f);
+static bool ahead_wanted(const rt_frame* f);
+static int ahead_holds(const rt_frame* f, uint32_t sample);
 
 namespace
 {
@@ -307,8 +340,9 @@ int rt_finish(rt_ctx* ctx)
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     // ... and for whatever the frames put on streams of their own: chunks on other pipes, shadow traces on the side streams
     // (the stage API sends them there too since round 3) -- Finish() means everything (cl_context.cpp:115-118)
+    // (not for the banks of RT_OPT_SAMPLES_AHEAD: what they trace ahead is the library's own business until a later Integrate() consumes it)
     for (rt_frame* f : ctx->frames)
-        if (sync_frame_streams(f) != RT_OK) return RT_ERROR;
+        if (!f->ahead_owner && sync_frame_streams(f) != RT_OK) return RT_ERROR;
     return RT_OK;
 }
 
@@ -374,6 +408,8 @@ int rt_ctx_set_option(rt_ctx* ctx, int option, uint32_t value)
     if (option == RT_CTX_OPT_SHADOW_TREE) { ctx->shadow_tree = value > 3u ? 1u : value; return RT_OK; }
     if (option == RT_CTX_OPT_CLOSEST_TREE) { ctx->closest_tree = value > 2u ? 1u : value; return RT_OK; }
     if (option == RT_CTX_OPT_ADAPTIVE_FOLD) { ctx->adaptive_fold = value & 31u; return RT_OK; }
+    if (option == RT_CTX_OPT_DEVICE_FOLD) { ctx->device_fold = value ? 1u : 0u; return RT_OK; }
+    if (option == RT_CTX_OPT_WIDE_LAYOUT) { ctx->wide_layout = value ? 1u : 0u; return RT_OK; }
     if (option == RT_CTX_OPT_ADAPT_WAIT)
     {
         if (ctx->scene.adapt) fold_adapt_set_wait(ctx->scene.adapt, value != 0u);          // the scene in place only
@@ -475,8 +511,7 @@ namespace
 //                                          along axis a) four bits at 4 * o = the conditional exchanges of slots (0,1), (2,3),
 //                                          (0,2), (1,3), made in that order, that bring the occupied slots into the
 //                                          reference's visit order (see `arrange` in build_wide_bvh)
-struct WideNode { float ox, oy, oz; uint32_t meta; uint32_t lo[3]; uint32_t hi[3]; uint32_t ref[4]; uint32_t order; uint32_t pad; };
-static_assert(sizeof(WideNode) == 64, "wide node record");
+// (struct WideNode: fold_kernels.h -- the device builds the same records, device_fold.h)
 
 // Which BVH2 nodes become the four slots of a record (`collapse`):
 //  RT_WIDE_TWO_LEVELS  the grandchildren (a child that is a leaf fills one slot): round 2's rule;
@@ -761,6 +796,79 @@ bool build_wide_bvh(const rt_bvh_node* nodes, uint32_t nn, int collapse, std::ve
     return true;
 }
 
+// ---- RT_CTX_OPT_WIDE_LAYOUT = 1: the records in PAIRS (round 6) -------------------------------------------------------------------------
+// The L2 of gfx950 fetches 128-byte lines (every read request of the traversal kernels at the fabric is a 128-byte one: TCC_EA0_RDREQ_128B,
+// profiles/r06_fetch_size_calibration.json), so a 64-byte record that misses brings its line-mate along whether anybody wants it or not.  In the fold's
+// own order -- depth first -- the line-mate of a record at an even index is its first slot's record and that of one at an odd index is whatever came
+// before it.  Here the line-mate is CHOSEN: every record that has interior slots is stored at an even index with the child it hands most rays on to right
+// behind it (by the weight the fold was made for: the measured crossings of an adaptation, else the area of the child's box), so a visit of that child
+// never misses after the visit of its parent that must precede it.  A pure permutation of the records (refs are indices): no result depends on it.
+// weight(record) -> the visit weight of the record's root box.
+template <class W>
+void pair_layout(std::vector<WideNode>& wide, std::vector<uint32_t>* roots, W&& weight)
+{
+    const uint32_t n = (uint32_t)wide.size();
+    if (n < 3u) return;
+    auto interior = [](uint32_t ref) { return ref != RT_EMPTY_REF && !(ref & RT_LEAF_BIT); };
+    std::vector<uint32_t> order, singles, todo;
+    std::vector<uint8_t> placed(n, 0);
+    order.reserve(n);
+    todo.push_back(0u);
+    while (!todo.empty())
+    {
+        const uint32_t r = todo.back();
+        todo.pop_back();
+        if (r >= n || placed[r]) continue;
+        placed[r] = 1;
+        uint32_t best = RT_EMPTY_REF;
+        double best_w = -1.0;
+        for (uint32_t ref : wide[r].ref)
+            if (interior(ref) && ref < n && !placed[ref]) { const double w = weight(ref); if (best == RT_EMPTY_REF || w > best_w) { best = ref; best_w = w; } }
+        if (best == RT_EMPTY_REF) { singles.push_back(r); continue; }
+        placed[best] = 1;
+        order.push_back(r); order.push_back(best);
+        // what hangs below the two, depth first (the head's other children before the tail's: they are the nearer relatives)
+        for (int k = 3; k >= 0; --k) { const uint32_t ref = wide[best].ref[k]; if (interior(ref) && ref < n && !placed[ref]) todo.push_back(ref); }
+        for (int k = 3; k >= 0; --k) { const uint32_t ref = wide[r].ref[k]; if (interior(ref) && ref < n && !placed[ref]) todo.push_back(ref); }
+    }
+    order.insert(order.end(), singles.begin(), singles.end());
+    if (order.size() != n || order[0] != 0u) return;                       // (not a tree over all records: leave it as it is)
+    std::vector<uint32_t> at(n);
+    for (uint32_t i = 0; i < n; ++i) at[order[i]] = i;
+    std::vector<WideNode> out(n);
+    for (uint32_t i = 0; i < n; ++i)
+    {
+        WideNode r = wide[order[i]];
+        for (uint32_t& ref : r.ref) if (interior(ref) && ref < n) ref = at[ref];
+        out[i] = r;
+    }
+    wide.swap(out);
+    if (roots && roots->size() == n)
+    {
+        std::vector<uint32_t> rn(n);
+        for (uint32_t i = 0; i < n; ++i) rn[i] = (*roots)[order[i]];
+        roots->swap(rn);
+    }
+}
+
+// the static folds' weight: the area (the own trees': their metric) of the box a record tests
+template <class M>
+void pair_layout_by_area(std::vector<WideNode>& wide, std::vector<uint32_t>& roots, const rt_bvh_node* nodes, uint32_t nn, const M* metric)
+{
+    if (roots.size() != wide.size()) return;
+    const std::vector<uint32_t> r0 = roots;                                // (weights are asked for by OLD record index while `roots` is being permuted at the end only)
+    pair_layout(wide, &roots, [&](uint32_t rec) -> double
+    {
+        const uint32_t node = r0[rec];
+        if (node >= nn) return 0.0;
+        const rt_bvh_node& b = nodes[node];
+        const float mn[3] = {b.bounds_min.x, b.bounds_min.y, b.bounds_min.z}, mx[3] = {b.bounds_max.x, b.bounds_max.y, b.bounds_max.z};
+        if (metric) return metric->of(mn, mx);
+        const double dx = (double)mx[0] - mn[0], dy = (double)mx[1] - mn[1], dz = (double)mx[2] - mn[2];
+        return dx * dy + dy * dz + dz * dx;
+    });
+}
+
 // The ray population a shadow tree serves (own_bvh.h): shadow rays go to the analytic lights only (hit_surface.cl:114-146,
 // light.h:30-65), one uniformly chosen per hit -- towards a directional light they all share its direction, towards a point
 // light they come from everywhere.
@@ -788,6 +896,43 @@ struct OwnTree
 {
     std::vector<WideNode> wide; uint32_t entry = 0; bool ok = false; const char* name = ""; std::thread worker;
     std::vector<rt_bvh_node> bvh2; std::vector<uint32_t> roots;    // the binary tree the records fold, and the node each record tests (FoldAdapt)
+    WideNode* d_wide = nullptr;                                    // the records on the device already (RT_CTX_OPT_DEVICE_FOLD); whoever adopts them owns them
+    int device = -1;                                               // >= 0: fold on that device (a stream of the worker's own)
+    bool pairs = false;                                            // RT_CTX_OPT_WIDE_LAYOUT
+    double fold_seconds = 0.0, build_seconds = 0.0;
+    // the collapse of the finished binary tree: on the device (the tree goes up, the records stay there and come back for the choice by proxy rays), or by build_wide_bvh
+    bool fold_it(const ownbvh::Metric& m)
+    {
+        const auto t0 = std::chrono::steady_clock::now();
+        bool done = false;
+        if (device >= 0 && hipSetDevice(device) == hipSuccess)
+        {
+            hipStream_t st = nullptr;
+            void* d_nodes = nullptr;
+            if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess)
+            {
+                if (hipMalloc(&d_nodes, bvh2.size() * sizeof(rt_bvh_node)) == hipSuccess &&
+                    hipMemcpyAsync(d_nodes, bvh2.data(), bvh2.size() * sizeof(rt_bvh_node), hipMemcpyHostToDevice, st) == hipSuccess)
+                {
+                    uint32_t n = 0;
+                    done = devfold::fold(st, (const rt_bvh_node*)d_nodes, (uint32_t)bvh2.size(), bvh2[0], &m, nullptr, &d_wide, &n, &entry, &roots, &wide) && n != 0u;
+                }
+                (void)hipStreamSynchronize(st);
+                if (d_nodes) (void)hipFree(d_nodes);
+                (void)hipStreamDestroy(st);
+            }
+            (void)hipGetLastError();
+            if (!done && d_wide) { (void)hipFree(d_wide); d_wide = nullptr; }
+        }
+        if (!done) done = build_wide_bvh(bvh2.data(), (uint32_t)bvh2.size(), RT_WIDE_SAH, wide, entry, &roots, &m) && !wide.empty();
+        if (done && pairs)
+        {
+            pair_layout_by_area(wide, roots, bvh2.data(), (uint32_t)bvh2.size(), &m);
+            if (d_wide && hipMemcpy(d_wide, wide.data(), wide.size() * sizeof(WideNode), hipMemcpyHostToDevice) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(d_wide); d_wide = nullptr; }
+        }
+        fold_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        return done;
+    }
     void start(const rt_scene_desc* sd, bool shadow, uint32_t mode)
     {
         ownbvh::Metric m;
@@ -799,11 +944,14 @@ struct OwnTree
         }
         worker = std::thread([this, sd, m]()
         {
-            ok = ownbvh::build(sd->nodes, sd->num_nodes, m, bvh2) && build_wide_bvh(bvh2.data(), (uint32_t)bvh2.size(), RT_WIDE_SAH, wide, entry, &roots, &m) && !wide.empty();
+            const auto t0 = std::chrono::steady_clock::now();
+            ok = ownbvh::build(sd->nodes, sd->num_nodes, m, bvh2);
+            build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            ok = ok && fold_it(m);
         });
     }
     void join() { if (worker.joinable()) worker.join(); }
-    ~OwnTree() { join(); }
+    ~OwnTree() { join(); if (d_wide) (void)hipFree(d_wide); }
 };
 
 // true: walk the own tree; false: keep the reference topology
@@ -847,7 +995,7 @@ struct FoldAdapt
     enum { ARMED = 1, COMPUTING = 2, IDLE = 3, OFF = 4, PROBING = 5 };   // IDLE: adapted to `camera`; a frame whose camera has moved away arms it again;
                                                                          // PROBING: the probe frame's launches and copies are on the stream
     int state = ARMED;
-    uint32_t mode = 1;                                 // ctx->adaptive_fold at upload
+    std::atomic<uint32_t> mode{1};                     // ctx->adaptive_fold at upload (atomic: RT_CTX_OPT_ADAPT_WAIT changes bit 1 on the render thread while the worker reads bits 3 / 4)
     uint32_t adaptations = 0;                          // folds adopted so far
     rt_camera camera;                                  // the probe's camera
     double scene_diagonal = 0.0;
@@ -876,11 +1024,13 @@ struct FoldAdapt
     // earlier adoption replaced after a device synchronisation of ITS thread (every launch that could still read them was enqueued before
     // that adoption).  The render thread only exchanges pointers: no hipDeviceSynchronize, no hipMalloc / hipFree between two frames.
     int device = -1;                                                     // -1: host only (rt_debug_fold_abandon)
+    bool device_fold = false;                                            // RT_CTX_OPT_DEVICE_FOLD: crossing counts and re-folds on `device`
+    bool pairs = false;                                                  // RT_CTX_OPT_WIDE_LAYOUT
     void *new_cl = nullptr, *new_sh = nullptr;
     bool upload_failed = false;
     std::vector<void*> retired;
     std::chrono::steady_clock::time_point last_armed{};                  // re-arming is rate-limited (RT_CTX_OPT_ADAPT_MIN_INTERVAL_MS)
-    uint32_t min_interval_ms = 500;
+    std::atomic<uint32_t> min_interval_ms{500};
     size_t probe_block(uint32_t sample, uint32_t bounce, uint32_t which /* 0 o, 1 d, 2 hits, 3 shadow o, 4 shadow d */) const
     {
         return ((((size_t)sample * probe_bounces + bounce) * 5u + which) * probe_paths) * sizeof(float4);
@@ -890,7 +1040,7 @@ struct FoldAdapt
 };
 void drop_fold_adapt(FoldAdapt* a) { delete a; }
 void fold_adapt_set_interval(FoldAdapt* a, uint32_t ms) { a->min_interval_ms = ms; }
-void fold_adapt_set_wait(FoldAdapt* a, bool wait) { a->mode = wait ? (a->mode | 2u) : (a->mode & ~2u); }
+void fold_adapt_set_wait(FoldAdapt* a, bool wait) { if (wait) a->mode.fetch_or(2u); else a->mode.fetch_and(~2u); }
 
 // Host threads one side of an adaptation may use beside the render loop: the closest-hit and the shadow side run together, one process per
 // GPU runs one context each, so 16 + 16 threads x 8 ranks stays within a 256-core host (2 x 32 per context oversubscribed it).
@@ -945,13 +1095,35 @@ void count_box_passes(const rt_bvh_node* nodes, uint32_t nn, const float4* o, co
 }
 
 // One tree folded again for the rays that were counted on it.  cost[] = what the current and the new fold cost those rays.
+// fold_device >= 0 (RT_CTX_OPT_DEVICE_FOLD): the crossing counts and the collapse run on that device, on a stream of the calling (worker) thread's own -- the tree
+// goes up once per call (the shadow rays' tree changes with every rotation), the records come back for the host's bookkeeping; anything that fails there
+// is done here on host threads instead.
 bool refold_for_rays(const std::vector<rt_bvh_node>& tree, const std::vector<float4>& o, const std::vector<float4>& d, const std::vector<uint32_t>& roots_now,
-    std::vector<WideNode>& out, uint32_t& entry, double (&cost)[2], const std::atomic<bool>& cancel, std::vector<uint32_t>* roots_out = nullptr)
+    std::vector<WideNode>& out, uint32_t& entry, double (&cost)[2], const std::atomic<bool>& cancel, std::vector<uint32_t>* roots_out = nullptr, int fold_device = -1,
+    bool pairs = false /* RT_CTX_OPT_WIDE_LAYOUT: the new records in (parent, likeliest child) pairs, by the measured weights */)
 {
     if (tree.empty() || o.empty() || o.size() != d.size() || roots_now.empty()) return false;
     const uint32_t nn = (uint32_t)tree.size();
     std::vector<uint32_t> counts;
-    count_box_passes(tree.data(), nn, o.data(), d.data(), o.size(), counts, cancel);
+    struct DeviceTree
+    {
+        hipStream_t st = nullptr; void* nodes = nullptr;
+        ~DeviceTree() { if (st) (void)hipStreamSynchronize(st); if (nodes) (void)hipFree(nodes); if (st) (void)hipStreamDestroy(st); (void)hipGetLastError(); }
+    } dev;
+    bool on_device = false;
+    if (fold_device >= 0 && hipSetDevice(fold_device) == hipSuccess && hipStreamCreateWithFlags(&dev.st, hipStreamNonBlocking) == hipSuccess)
+    {
+        on_device = hipMalloc(&dev.nodes, (size_t)nn * sizeof(rt_bvh_node)) == hipSuccess &&
+                    hipMemcpyAsync(dev.nodes, tree.data(), (size_t)nn * sizeof(rt_bvh_node), hipMemcpyHostToDevice, dev.st) == hipSuccess;
+        if (on_device)
+        {
+            uint64_t truncated = 0;
+            on_device = devfold::count_box_passes(dev.st, (const rt_bvh_node*)dev.nodes, nn, o.data(), d.data(), o.size(), counts, &truncated);
+            if (truncated) g_truncated_walks.fetch_add(truncated, std::memory_order_relaxed);
+        }
+        if (!on_device) (void)hipGetLastError();
+    }
+    if (!on_device) count_box_passes(tree.data(), nn, o.data(), d.data(), o.size(), counts, cancel);
     if (cancel.load()) return false;
     // the measured passes, plus a twentieth of their sum spread by surface area: boxes no probe ray met still fold sensibly
     std::vector<double> w(nn);
@@ -973,9 +1145,24 @@ bool refold_for_rays(const std::vector<rt_bvh_node>& tree, const std::vector<flo
     for (uint32_t r : roots_now) if (r < nn) cost[0] += w[r];
     cost[0] /= (double)o.size();
     std::vector<uint32_t> roots_new;
-    if (!build_wide_bvh(tree.data(), nn, RT_WIDE_SAH, out, entry, &roots_new, nullptr, w.data(), &cancel) || out.empty()) return false;
+    bool folded = false;
+    if (on_device)
+    {
+        WideNode* d_recs = nullptr;
+        uint32_t n_recs = 0;
+        folded = devfold::fold(dev.st, (const rt_bvh_node*)dev.nodes, nn, tree[0], nullptr, w.data(), &d_recs, &n_recs, &entry, &roots_new, &out, &cancel) && !out.empty();
+        if (d_recs) (void)hipFree(d_recs);                                 // (the records travel with fold_upload, with the shadow side's slot order applied)
+        (void)hipGetLastError();
+        if (cancel.load()) return false;
+    }
+    if (!folded && (!build_wide_bvh(tree.data(), nn, RT_WIDE_SAH, out, entry, &roots_new, nullptr, w.data(), &cancel) || out.empty())) return false;
     for (uint32_t r : roots_new) cost[1] += w[r];
     cost[1] /= (double)o.size();
+    if (pairs && roots_new.size() == out.size())
+    {
+        const std::vector<uint32_t> r0 = roots_new;
+        pair_layout(out, &roots_new, [&](uint32_t rec) { return r0[rec] < nn ? w[r0[rec]] : 0.0; });
+    }
     if (roots_out) roots_out->swap(roots_new);
     return cost[1] < cost[0];
 }
@@ -1122,8 +1309,9 @@ bool adapt_shadow_candidate(FoldAdapt* a)
     const std::vector<uint32_t>& roots = a->roots_sh.empty() ? a->roots : a->roots_sh;
     a->rotations = 0;
     a->bvh2_sh_new.clear();
-    bool ok = refold_for_rays(tree, a->sh_o, a->sh_d, roots, a->wide_sh, a->entry_sh, a->cost[1], a->cancel, &a->roots_sh_new);
-    if (!(a->mode & 8u) || a->sh_o.empty() || a->cancel.load()) return ok;
+    const int fold_device = a->device_fold ? a->device : -1;
+    bool ok = refold_for_rays(tree, a->sh_o, a->sh_d, roots, a->wide_sh, a->entry_sh, a->cost[1], a->cancel, &a->roots_sh_new, fold_device, a->pairs);
+    if (!(a->mode.load() & 8u) || a->sh_o.empty() || a->cancel.load()) return ok;
     std::vector<rt_bvh_node> rotated;
     double crossings[2] = {0.0, 0.0};
     const uint32_t made = treerot::rotate(tree.data(), (uint32_t)tree.size(), (const float*)a->sh_o.data(), (const float*)a->sh_d.data(), a->sh_o.size(), 8, rotated, crossings, &a->cancel);
@@ -1133,7 +1321,7 @@ bool adapt_shadow_candidate(FoldAdapt* a)
     uint32_t entry = 0;
     double cost[2] = {0.0, 0.0};
     const std::vector<uint32_t> top{0u};                                   // (the rotated tree has no current fold: only cost[1] is read)
-    (void)refold_for_rays(rotated, a->sh_o, a->sh_d, top, wide, entry, cost, a->cancel, &roots_rot);
+    (void)refold_for_rays(rotated, a->sh_o, a->sh_d, top, wide, entry, cost, a->cancel, &roots_rot, fold_device, a->pairs);
     if (wide.empty() || roots_rot.empty() || a->cancel.load()) return ok;
     // the rotated tree's boxes differ, so its measured passes are compared as they are (both are box passes per probe ray at record roots);
     // without a known cost of the fold on the device nothing is adopted
@@ -1150,7 +1338,7 @@ bool adapt_shadow_side(FoldAdapt* a)
 {
     a->reordered = 0;
     const bool ok = adapt_shadow_candidate(a);
-    if (ok && (a->mode & 16u) && !a->tri9.empty() && !a->wide_sh.empty() && !a->cancel.load())
+    if (ok && (a->mode.load() & 16u) && !a->tri9.empty() && !a->wide_sh.empty() && !a->cancel.load())
     {
         // the candidate's slots, likeliest occluder first (mode bit 4)
         std::vector<uint32_t> prim;
@@ -1239,7 +1427,7 @@ void fold_adapt_worker(FoldAdapt* a)
     if (!a->o.empty())
     {
         std::thread shadow([a]() { a->ok_sh = adapt_shadow_side(a); });
-        a->ok = refold_for_rays(a->bvh2, a->o, a->d, a->roots, a->wide, a->entry, a->cost[0], a->cancel, &a->roots_new);
+        a->ok = refold_for_rays(a->bvh2, a->o, a->d, a->roots, a->wide, a->entry, a->cost[0], a->cancel, &a->roots_new, a->device_fold ? a->device : -1, a->pairs);
         shadow.join();
         fold_upload(a);
     }
@@ -1277,14 +1465,25 @@ int rt_scene_upload(rt_ctx* ctx, const rt_scene_desc* sd)
     if (!sd->env_rgba || sd->env_width == 0 || sd->env_height == 0)
         return fail(ctx, "rt_scene_upload: no environment image");
     (void)hipSetDevice(ctx->device);
+    // nothing may still read the scene that is about to be freed: batches traced ahead are dropped (RT_OPT_SAMPLES_AHEAD), and every
+    // stream a frame launches on -- side streams, pipes, banks -- has drained
+    for (rt_frame* f : ctx->frames) ahead_discard(f);
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    for (rt_frame* f : ctx->frames)
+        if (sync_frame_streams(f) != RT_OK) return RT_ERROR;
     free_scene(ctx->scene);
     ++ctx->scene_uploads;
     Scene& s = ctx->scene;
     const uint32_t nt = sd->num_triangles, nn = sd->num_nodes;
+    const auto t_upload = std::chrono::steady_clock::now();
+    auto lap = [](std::chrono::steady_clock::time_point& t) { const auto n = std::chrono::steady_clock::now(); const double d = std::chrono::duration<double>(n - t).count(); t = n; return d; };
+    auto t_lap = t_upload;
+    double t_layout = 0.0, t_device = 0.0, t_fold = 0.0, t_own_wait = 0.0, t_choose = 0.0;
     // the trees of the backend's own (below, "Trees of the backend's own") are built on worker threads meanwhile
     OwnTree own_sh, own_cl;
     const bool may_own = ctx->build_wide == 1u && (uint64_t)nt * 64 <= 0xFFFFFFFFull && (sd->nodes[0].num_primitives_axis >> 16) == 0;
+    if (ctx->device_fold && ctx->build_wide == 1u) { own_sh.device = ctx->device; own_cl.device = ctx->device; }
+    own_sh.pairs = own_cl.pairs = ctx->wide_layout != 0u;
     if (may_own && ctx->shadow_tree) own_sh.start(sd, true, ctx->shadow_tree);
     if (may_own && ctx->closest_tree) own_cl.start(sd, false, ctx->closest_tree);
 
@@ -1325,6 +1524,7 @@ int rt_scene_upload(rt_ctx* ctx, const rt_scene_desc* sd)
             for (size_t k = frontier.size(); k-- > 0;) roots.push_back(frontier[k]);   // first child's cluster next
         }
     }
+    t_layout = lap(t_lap);
     // the records themselves are written on the device (k_relayout_*), below
     std::vector<float4> super_root(4);
     const rt_bvh_node& root = sd->nodes[0];
@@ -1427,10 +1627,26 @@ int rt_scene_upload(rt_ctx* ctx, const rt_scene_desc* sd)
              hipMemcpyAsync(&relayout_err, d_err, sizeof(int), hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
              hipStreamSynchronize(ctx->stream) == hipSuccess;
     }
+    // RT_CTX_OPT_DEVICE_FOLD: the reference tree's collapse into 4-wide records, from the node array the re-layout kernels have just read (device_fold.h)
+    std::vector<WideNode> wide;
+    uint32_t w_entry = 0;
+    std::vector<uint32_t> wide_roots;
+    WideNode* d_wide = nullptr;
+    uint32_t n_wide_dev = 0;
+    bool folded_on_device = false;
+    double t_dev_fold = 0.0;
+    if (ok && relayout_err == RL_OK && ctx->device_fold && ctx->build_wide == 1u && (uint64_t)nt * 64 <= 0xFFFFFFFFull)
+    {
+        const bool want_host_copy = ctx->wide_layout != 0u || (may_own && (ctx->shadow_tree == 1u || ctx->closest_tree == 1u));   // the pair layout and the choice by proxy rays work on the host
+        folded_on_device = devfold::fold(ctx->stream, (const rt_bvh_node*)raw_nodes, nn, sd->nodes[0], nullptr, nullptr, &d_wide, &n_wide_dev, &w_entry, &wide_roots,
+                                         want_host_copy ? &wide : nullptr, nullptr, &t_dev_fold);
+        (void)hipGetLastError();
+    }
     free_temps();
-    if (!ok) { free_scene(s); return fail(ctx, "rt_scene_upload: device re-layout failed"); }
+    if (!ok) { if (d_wide) (void)hipFree(d_wide); free_scene(s); return fail(ctx, "rt_scene_upload: device re-layout failed"); }
     if (relayout_err != RL_OK)
     {
+        if (d_wide) (void)hipFree(d_wide);
         free_scene(s);
         switch (relayout_err)
         {
@@ -1448,40 +1664,56 @@ int rt_scene_upload(rt_ctx* ctx, const rt_scene_desc* sd)
     rc |= dev_alloc_copy(ctx, &s.emissive, sd->emissive_indices, (size_t)sd->num_emissive * 4);
     if (sd->material_texture_indices)
         rc |= dev_alloc_copy(ctx, &s.mat_tex16, sd->material_texture_indices, (size_t)sd->num_materials * 6 * sizeof(uint16_t));
+    t_device = lap(t_lap) - t_dev_fold;
     // the 4-wide quantized tree for k_trace_w4 (optional: trees that do not qualify keep the BVH2 kernels)
-    std::vector<WideNode> wide;
-    uint32_t w_entry = 0;
     // (a SAH collapse can be deeper than the kernel's stack bound allows where two levels at a time are not: try both)
-    std::vector<uint32_t> wide_roots;
-    const bool have_wide = ctx->build_wide && (uint64_t)nt * 64 <= 0xFFFFFFFFull &&
+    const bool have_wide = folded_on_device || (ctx->build_wide && (uint64_t)nt * 64 <= 0xFFFFFFFFull &&
         ((ctx->build_wide != 2u && build_wide_bvh(sd->nodes, nn, RT_WIDE_SAH, wide, w_entry, &wide_roots)) ||
-         build_wide_bvh(sd->nodes, nn, RT_WIDE_TWO_LEVELS, wide, w_entry, &wide_roots));
-    if (have_wide) rc |= dev_alloc_copy(ctx, &s.wnodes, wide.data(), wide.size() * sizeof(WideNode));
+         build_wide_bvh(sd->nodes, nn, RT_WIDE_TWO_LEVELS, wide, w_entry, &wide_roots)));
+    const uint32_t n_wide_ref = folded_on_device ? n_wide_dev : (uint32_t)wide.size();
+    if (have_wide && ctx->wide_layout && !wide.empty())
+    {
+        pair_layout_by_area(wide, wide_roots, sd->nodes, nn, (const ownbvh::Metric*)nullptr);
+        if (folded_on_device && hipMemcpyAsync(d_wide, wide.data(), wide.size() * sizeof(WideNode), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc |= fail(ctx, "rt_scene_upload: uploading the paired records failed");
+    }
+    if (folded_on_device) s.wnodes = d_wide;
+    else if (have_wide) rc |= dev_alloc_copy(ctx, &s.wnodes, wide.data(), wide.size() * sizeof(WideNode));
     // Trees of the backend's own over the reference's leaves (own_bvh.h): one for the shadow rays (exact: an any-hit verdict
     // does not depend on what sits above the leaves) and -- opt-in, tolerance mode -- one for the closest-hit rays.  Which
     // candidate a population walks is MEASURED with proxy rays (tree_select.h); the reference's own topology is a candidate,
     // so the choice is never worse than sharing on that measure.
     bool have_sh = false, have_cl = false;
     s.tree_report.clear();
+    t_fold = lap(t_lap) + t_dev_fold;
     own_sh.join(); own_cl.join();
-    if (have_wide && !wide.empty() && may_own && ctx->shadow_tree)
+    t_own_wait = lap(t_lap);
+    (void)hipSetDevice(ctx->device);
+    auto adopt_own = [&](OwnTree& own, void*& dst)
+    {
+        if (own.d_wide) { dst = own.d_wide; own.d_wide = nullptr; }                        // folded on the device: the records are there
+        else rc |= dev_alloc_copy(ctx, &dst, own.wide.data(), own.wide.size() * sizeof(WideNode));
+    };
+    if (have_wide && n_wide_ref != 0u && may_own && ctx->shadow_tree)
     {
         have_sh = choose_tree(sd, wide, w_entry, true, ctx->shadow_tree, own_sh, s.tree_report);
-        if (have_sh) rc |= dev_alloc_copy(ctx, &s.wnodes_sh, own_sh.wide.data(), own_sh.wide.size() * sizeof(WideNode));
+        if (have_sh) adopt_own(own_sh, s.wnodes_sh);
     }
-    if (have_wide && !wide.empty() && may_own && ctx->closest_tree)
+    if (have_wide && n_wide_ref != 0u && may_own && ctx->closest_tree)
     {
         have_cl = choose_tree(sd, wide, w_entry, false, ctx->closest_tree, own_cl, s.tree_report);
-        if (have_cl) rc |= dev_alloc_copy(ctx, &s.wnodes_cl, own_cl.wide.data(), own_cl.wide.size() * sizeof(WideNode));
+        if (have_cl) adopt_own(own_cl, s.wnodes_cl);
     }
     const uint32_t w_entry_sh = own_sh.entry, w_entry_cl = own_cl.entry;
+    t_choose = lap(t_lap);
     if (rc != RT_OK) { free_scene(s); return RT_ERROR; }
     // RT_CTX_OPT_ADAPTIVE_FOLD: what the first rt_integrate needs to fold these trees again for its own rays (FoldAdapt)
-    if ((ctx->adaptive_fold & 1u) && have_wide && !wide.empty() && !have_cl && (nn >= 8192u || (ctx->adaptive_fold & 4u)))
+    if ((ctx->adaptive_fold & 1u) && have_wide && n_wide_ref != 0u && !have_cl && (nn >= 8192u || (ctx->adaptive_fold & 4u)))
     {
         FoldAdapt* a = new FoldAdapt();
         a->mode = ctx->adaptive_fold;
         a->device = ctx->device;
+        a->device_fold = ctx->device_fold != 0u && ctx->build_wide == 1u;
+        a->pairs = ctx->wide_layout != 0u;
         a->min_interval_ms = ctx->adapt_min_interval_ms;
         memset(&a->camera, 0, sizeof(a->camera));
         {
@@ -1491,7 +1723,7 @@ int rt_scene_upload(rt_ctx* ctx, const rt_scene_desc* sd)
         a->bvh2.assign(sd->nodes, sd->nodes + nn);
         a->roots = std::move(wide_roots);
         if (have_sh) { a->bvh2_sh = std::move(own_sh.bvh2); a->roots_sh = std::move(own_sh.roots); }
-        if (a->mode & 16u)
+        if (a->mode.load() & 16u)
         {
             a->tri9.resize((size_t)nt * 9);
             for (uint32_t i = 0; i < nt; ++i)
@@ -1526,7 +1758,7 @@ int rt_scene_upload(rt_ctx* ctx, const rt_scene_desc* sd)
     s.d.wnodes_sh = have_sh ? (const float4*)s.wnodes_sh : s.d.wnodes;
     s.d.w_sh_entry_ref = have_sh ? w_entry_sh : w_entry;
     if (have_cl) { s.d.wnodes = (const float4*)s.wnodes_cl; s.d.w_entry_ref = w_entry_cl; }
-    s.n_wide = have_wide ? (uint32_t)wide.size() : 0u;
+    s.n_wide = have_wide ? n_wide_ref : 0u;
     s.n_wide_sh = have_sh ? (uint32_t)own_sh.wide.size() : 0u;
     s.n_wide_cl = have_cl ? (uint32_t)own_cl.wide.size() : 0u;
     s.wide_ok = have_wide;
@@ -1536,6 +1768,16 @@ int rt_scene_upload(rt_ctx* ctx, const rt_scene_desc* sd)
                         "address them with 32-bit byte offsets, so every launch takes the per-ray kernel k_trace_v1 -- correct, and several times slower\n",
             n_interior, nt);
     s.valid = true;
+    {
+        // where the upload's time went (rt_scene_tree_report; bench.py prints it as `setup`)
+        char line[400];
+        const double t_rest = lap(t_lap);
+        snprintf(line, sizeof(line), "upload: %.3f s = record order on the host %.3f + copies and re-layout kernels %.3f + fold of the reference's tree %.3f (%s) + waiting for the own tree(s) %.3f "
+            "(shadow tree: built in %.3f, folded in %.3f) + choosing by proxy rays and uploading %.3f + adaptation state %.3f (%u triangles, %u nodes, %u + %u wide records)\n",
+            std::chrono::duration<double>(std::chrono::steady_clock::now() - t_upload).count(), t_layout, t_device, t_fold, folded_on_device ? "on the device" : "on host threads", t_own_wait,
+            own_sh.build_seconds, own_sh.fold_seconds, t_choose, t_rest, nt, nn, s.n_wide, s.n_wide_sh);
+        s.tree_report += line;
+    }
     return RT_OK;
 }
 
@@ -1840,7 +2082,7 @@ int flush_log(rt_frame* f, bool keep_open)
     if (wait_shadow(f, 0) != RT_OK || wait_shadow(f, 1) != RT_OK) return RT_ERROR;   // their verdicts are in the log
     uint32_t blocks = (f->p->chunk_count + 255u) / 256u;
     hipLaunchKernelGGL(k_flush, dim3(blocks), dim3(256), 0, f->p->stream, f->radiance + f->p->chunk_base, dlog(f),
-        f->p->chunk_count, f->p->cur_slots, f->chunk_pixels, keep_open && f->log_ovf_blocks != 0u ? 1u : 0u);
+        f->p->chunk_count, f->p->cur_slots, f->chunk_pixels, keep_open && f->log_ovf_blocks != 0u ? 1u : 0u, 0u);
     if (hipGetLastError() != hipSuccess) return fail(ctx, "k_flush launch failed");
     f->p->cur_slots = 0;
     return RT_OK;
@@ -1904,7 +2146,12 @@ int flush_stage(rt_frame* f, bool keep = false)
 
 extern "C" {
 
-int rt_frame_create(rt_ctx* ctx, const rt_frame_desc* fd, rt_frame** out)
+static int create_frame(rt_ctx* ctx, const rt_frame_desc* fd, rt_frame** out, hipStream_t borrowed_main_stream);
+
+int rt_frame_create(rt_ctx* ctx, const rt_frame_desc* fd, rt_frame** out) { return create_frame(ctx, fd, out, nullptr); }
+
+// borrowed_main_stream != NULL: pipe 0 launches there instead of on the context's stream (a bank of RT_OPT_SAMPLES_AHEAD; the stream stays the lender's)
+static int create_frame(rt_ctx* ctx, const rt_frame_desc* fd, rt_frame** out, hipStream_t borrowed_main_stream)
 {
     if (!ctx || !fd || !out) return fail(ctx, "rt_frame_create: NULL argument");
     *out = nullptr;
@@ -1931,6 +2178,7 @@ int rt_frame_create(rt_ctx* ctx, const rt_frame_desc* fd, rt_frame** out)
     f->trace_blocks = (f->trace_blocks + 7u) & ~7u;
     f->radiance = nullptr;
     f->resolved = nullptr;
+    f->ps[0].stream = borrowed_main_stream;              // (NULL: ensure_pipe_resources gives pipe 0 the context's stream)
     bool ok = true;
     ok = ok && hipMalloc((void**)&f->radiance, n * sizeof(float4)) == hipSuccess;
     ok = ok && hipMalloc((void**)&f->resolved, n * sizeof(float4)) == hipSuccess;
@@ -1966,6 +2214,7 @@ int rt_frame_destroy(rt_frame* f)
 {
     if (!f) return RT_OK;
     (void)hipSetDevice(f->ctx->device);
+    ahead_destroy(f);                                     // its banks first (frames of their own)
     f->ctx->frames.erase(std::remove(f->ctx->frames.begin(), f->ctx->frames.end(), f), f->ctx->frames.end());
     for (PathPipe& q : f->ps)
     {
@@ -2017,12 +2266,21 @@ int rt_set_option(rt_frame* f, int option, uint32_t value)
 {
     if (!f) return fail(nullptr, "rt_set_option: frame is NULL");
     if (f->deferred.active && option != RT_OPT_FRAME_KERNEL && deferred_materialize(f) != RT_OK) return RT_ERROR;   // an option changed between two recorded stages
+    if (f->ahead && option != RT_OPT_PROFILE_KERNELS && !(option == RT_OPT_MAX_BOUNCES && value == f->max_bounces) && !(option == RT_OPT_WHITE_FURNACE && (value ? 1u : 0u) == f->white_furnace))
+        ahead_discard(f);                                 // (the two exceptions: HIPPathTraceIntegrator::SyncOptions sets them before every frame)
     switch (option)
     {
+    case RT_OPT_SAMPLES_AHEAD:
+        if ((value & 0xFFu) > 64u && (value & 0xFFu) != 255u) return fail(f->ctx, "rt_set_option: RT_OPT_SAMPLES_AHEAD is 0 (off), 1 (automatic depth) or 2..64 samples per batch (+ 256: one stream per bank)");
+        if (f->ahead_owner) return fail(f->ctx, "rt_set_option: RT_OPT_SAMPLES_AHEAD on a bank");
+        f->ahead_opt = value & 0x1FFu;
+        if (f->ahead) f->ahead->configured = false;
+        return RT_OK;
     case RT_OPT_MAX_BOUNCES:
         if (value > RT_MAX_BOUNCES_LIMIT) return fail(f->ctx, "rt_set_option: max_bounces above RT_MAX_BOUNCES_LIMIT");
         if (value != f->max_bounces)
         {
+            f->fk_auto.frames = 0; f->fk_auto.timing = -1; f->fk_auto.decided = false; f->fk_auto.use_kernel = false;   //  another workload: RT_OPT_FRAME_KERNEL = 255 measures again
             if (flush_log(f) != RT_OK) return RT_ERROR;
             HIPCHK(f->ctx, hipStreamSynchronize(f->ctx->stream));
             f->max_bounces = value;
@@ -2053,6 +2311,7 @@ int rt_set_option(rt_frame* f, int option, uint32_t value)
         if (value > 1) return fail(f->ctx, "rt_set_option: sampler must be 0 (kRandom) or 1 (kBlueNoise)");
         if (value == 1 && !f->ctx->blue_noise)
             return fail(f->ctx, "rt_set_option: SamplerType::kBlueNoise needs rt_upload_blue_noise_tables first");
+        if (value != f->sampler) { f->fk_auto.frames = 0; f->fk_auto.timing = -1; f->fk_auto.decided = false; f->fk_auto.use_kernel = false; }
         f->sampler = value;
         return RT_OK;
     case RT_OPT_AOV:
@@ -2069,7 +2328,10 @@ int rt_set_option(rt_frame* f, int option, uint32_t value)
                                 "on one GPU (tile_count == 1); on tiles use RT_OPT_DENOISER = 2 + rt_group_denoise");
         f->denoiser = value;
         return RT_OK;
-    case RT_OPT_TRACE_DROP_LAST_BOUNCE_RAYS: f->drop_last = value ? 1 : 0; return RT_OK;
+    case RT_OPT_TRACE_DROP_LAST_BOUNCE_RAYS:
+        if ((value ? 1u : 0u) != f->drop_last) { f->fk_auto.frames = 0; f->fk_auto.timing = -1; f->fk_auto.decided = false; f->fk_auto.use_kernel = false; }
+        f->drop_last = value ? 1 : 0;
+        return RT_OK;
     case RT_OPT_PROFILE_KERNELS: f->profile = value ? 1 : 0; return RT_OK;
     case RT_OPT_TRACE_WAVES_PER_CU: f->trace_waves_per_cu = value; return RT_OK;
     case RT_OPT_TRACE_PACKET_BOUNCES:
@@ -2158,6 +2420,10 @@ int rt_set_option(rt_frame* f, int option, uint32_t value)
 int rt_set_camera(rt_frame* f, const rt_camera* camera)
 {
     if (!f || !camera) return fail(nullptr, "rt_set_camera: NULL argument");
+    //  a camera set between rt_generate_rays and rt_advance_sample: the recorded stages belong to the OLD camera -- they run now, with it
+    if (f->deferred.active && memcmp(&f->camera, camera, sizeof(rt_camera)) != 0 && deferred_materialize(f) != RT_OK) return RT_ERROR;
+    if (f->ahead && memcmp(&f->camera, camera, sizeof(rt_camera)) != 0) ahead_discard(f);              // whatever was traced ahead (and the quiet count) belonged to another view
+                                                                                                       // (HIPPathTraceIntegrator sets the SAME camera before every frame: nothing happens)
     f->camera = *camera;
     f->prev_camera = f->camera_last;     // what GenerateAOV sees as prev_camera this frame
     f->camera_last = *camera;
@@ -2323,6 +2589,7 @@ int rt_reset(rt_frame* f)                               // CLPathTraceIntegrator
     rt_ctx* ctx = f->ctx;
     (void)hipSetDevice(ctx->device);
     if (join_pipes(f) != RT_OK) return RT_ERROR;
+    ahead_discard(f);                        // RT_OPT_SAMPLES_AHEAD: the samples traced ahead continued a sum that starts again
     if (!f->denoiser) f->sample_count = 0;   // Reset() keeps the frame index while denoising (:499-504)
     for (uint32_t i = 0; i < RT_MAX_PIPES; ++i)           // a shadow trace still running on a side stream writes the log
     {
@@ -2331,7 +2598,7 @@ int rt_reset(rt_frame* f)                               // CLPathTraceIntegrator
     }
     f->p = &f->ps[0];
     f->stage_chunks = 1;
-    f->deferred.active = false;                             // a recorded sample that was never advanced: nothing has run
+    f->deferred.active = false; f->deferred.ahead = false;  // a recorded sample that was never advanced: nothing has run
     for (uint32_t i = 0; i < RT_MAX_PIPES; ++i)
     {
         PathPipe& q = f->ps[i];
@@ -2395,7 +2662,7 @@ bool frame_kernel_eligible(const rt_frame* f)
     const uint32_t n_local = f->n_local ? f->n_local : 1u;
     // (fk_auto.frames has been advanced past the frame being started: frame k = frames - 1)
     const int fk = f->fk_auto.frames - 1;
-    const bool wanted = f->frame_kernel == 255u ? (f->fk_auto.decided ? f->fk_auto.use_kernel : (fk == 2 || fk == 3 || (fk >= 4 && (fk & 1)))) : f->frame_kernel != 0u;
+    const bool wanted = f->frame_kernel == 255u ? (f->fk_auto.decided ? f->fk_auto.use_kernel : (!f->fk_auto.skip && (fk == 2 || fk == 3 || (fk >= 4 && (fk & 1))))) : f->frame_kernel != 0u;
     return wanted && f->n_local != 0u && !(f->denoiser || f->aov != 0) && ctx->scene.wide_ok && !ctx->scene.slow_shadow &&
            ctx->scene.d.emissive_nee == 0u && f->log_ovf_blocks == 0u && f->n_pipes == 1u && f->chunk_pixels >= n_local && f->stage_chunks <= 1u &&
            (f->trace_variant == 5u || f->trace_variant == 10u) && !f->profile && !f->timeline && f->select_form_box == 0u && f->max_bounces < 63u;
@@ -2417,11 +2684,23 @@ int launch_frame_kernel_t(rt_frame* f)
         const uint32_t n_chunks = (f->n_local + 63u) >> 6;
         const uint32_t resident = std::max(8u, (uint32_t)ctx->prop.multiProcessorCount * (uint32_t)per_cu);
         const uint32_t cpw = f->frame_kernel >= 2u && f->frame_kernel != 255u ? f->frame_kernel : (n_chunks + resident - 1u) / resident;     // chunks per wave
-        f->frame_blocks = (((n_chunks + cpw - 1u) / cpw) + 7u) & ~7u;
+        //  all three or none: the grid's size is committed only with its buffers, so a failed allocation cannot leave a later
+        // launch with frame_blocks != 0 and a NULL buffer
+        const uint32_t n_blocks = (((n_chunks + cpw - 1u) / cpw) + 7u) & ~7u;
+        uint32_t *counts = nullptr, *slow = nullptr; uint2* spill = nullptr;
+        const bool ok = f->debug_alloc_limit != 0xFFFFFFFFu &&                       // (RT_OPT_DEBUG_ALLOC_LIMIT = 0xFFFFFFFF: the test hook for this path)
+                        hipMalloc((void**)&counts, (size_t)n_blocks * RT_FRAME_COUNT_STRIDE * sizeof(uint32_t)) == hipSuccess &&
+                        hipMalloc((void**)&slow, (size_t)n_blocks * cpw * 64u * sizeof(uint32_t)) == hipSuccess &&
+                        hipMalloc((void**)&spill, (size_t)n_blocks * 64u * (RT_W4_STACK_MAX - 12) * sizeof(uint2)) == hipSuccess;
+        if (!ok)
+        {
+            (void)hipGetLastError();
+            for (void* p : {(void*)counts, (void*)slow, (void*)spill}) if (p) (void)hipFree(p);
+            return fail(ctx, "rt_advance_sample: out of device memory for k_frame's per-wave buffers");
+        }
+        f->frame_counts = counts; f->frame_slow = slow; f->frame_spill = spill;
+        f->frame_blocks = n_blocks;
         f->frame_chunks_per_wave = cpw;
-        HIPCHK(ctx, hipMalloc((void**)&f->frame_counts, (size_t)f->frame_blocks * RT_FRAME_COUNT_STRIDE * sizeof(uint32_t)));
-        HIPCHK(ctx, hipMalloc((void**)&f->frame_slow, (size_t)f->frame_blocks * cpw * 64u * sizeof(uint32_t)));
-        HIPCHK(ctx, hipMalloc((void**)&f->frame_spill, (size_t)f->frame_blocks * 64u * (RT_W4_STACK_MAX - 12) * sizeof(uint2)));
     }
     // the previous sample's per-bounce counters go to the totals first (k_raygen does this for the stage kernels)
     hipLaunchKernelGGL(k_fold_counters, dim3(1), dim3(64), 0, q.stream, q.counters, q.prev_bounces, q.fold_accumulates);
@@ -2480,6 +2759,9 @@ static int deferred_materialize(rt_frame* f)
     const uint32_t done = f->deferred.bounce;
     const int next = f->deferred.next;
     f->deferred.active = false;
+    // RT_OPT_SAMPLES_AHEAD: somebody looks between the stages of a sample that sits in a bank -- the frame traces it itself after all, and what
+    // was traced ahead (that sample's slot first of all) is dropped
+    if (f->deferred.ahead) { f->deferred.ahead = false; ahead_discard(f); }
     if (generate_rays(f, 1) != RT_OK) return RT_ERROR;
     for (uint32_t b = 0; b <= done; ++b)
     {
@@ -2508,6 +2790,13 @@ int rt_generate_rays(rt_frame* f)                       // GenerateRays, :516-52
     {
         f->stage_chunks = 1;
         if (ensure_whole_tile(f) != RT_OK) return RT_ERROR;
+        if (f->ahead && ahead_wanted(f) && ahead_holds(f, f->sample_count) >= 0)
+        {
+            // RT_OPT_SAMPLES_AHEAD: this sample has been traced ahead -- nothing is launched, the stages are recorded, rt_advance_sample replays its log
+            if (f->p->cur_slots != 0) return fail(ctx, "rt_generate_rays: the previous sample was not advanced (rt_advance_sample)");
+            f->deferred.active = true; f->deferred.bounce = 0; f->deferred.next = 0; f->deferred.ahead = true;
+            return RT_OK;
+        }
         if (f->frame_kernel == 255u)
         {
             // frames 0 - 3 warm up (two each way), frames 4 - 19 alternate stage kernels / k_frame and are timed; once the last timed frame's events
@@ -2515,6 +2804,7 @@ int rt_generate_rays(rt_frame* f)                       // GenerateRays, :516-52
             auto& m = f->fk_auto;
             if (m.scene != ctx->scene_uploads) { m.frames = 0; m.timing = -1; m.decided = false; m.use_kernel = false; m.scene = ctx->scene_uploads; }
             m.timing = -1;
+            m.skip = false;
             if (!m.decided)
             {
                 const int k = m.frames;
@@ -2532,6 +2822,12 @@ int rt_generate_rays(rt_frame* f)                       // GenerateRays, :516-52
                     m.decided = true;
                     m.use_kernel = ok && m.ms_kernel < m.ms_stage;
                 }
+                else if (k >= 4 && k < 20 && ctx->scene.adapt && (ctx->scene.adapt->state == FoldAdapt::ARMED || ctx->scene.adapt->state == FoldAdapt::PROBING || ctx->scene.adapt->state == FoldAdapt::COMPUTING))
+                {
+                    //  a fold adaptation is under way -- probe launches on this stream, a fold swapped mid-window: such a frame is not one
+                    // of the sixteen that are compared (it runs through the stage kernels, untimed; the schedule goes on once the folds have settled)
+                    m.skip = true;
+                }
                 else if (k >= 4 && k < 20)
                 {
                     m.timing = k - 4;
@@ -2539,7 +2835,7 @@ int rt_generate_rays(rt_frame* f)                       // GenerateRays, :516-52
                     for (hipEvent_t& e : m.ev[m.timing]) if (!e) ok = ok && hipEventCreate(&e) == hipSuccess;
                     if (!ok || hipEventRecord(m.ev[m.timing][0], ctx->stream) != hipSuccess) { (void)hipGetLastError(); m.decided = true; m.use_kernel = false; m.timing = -1; }
                 }
-                if (!m.decided) ++m.frames;
+                if (!m.decided && !m.skip) ++m.frames;
             }
             if (m.decided) m.frames = 1 << 20;          // (frame_kernel_eligible reads `decided`; keep frames - 1 out of the schedule's range)
         }
@@ -2548,7 +2844,7 @@ int rt_generate_rays(rt_frame* f)                       // GenerateRays, :516-52
             // RT_OPT_FRAME_KERNEL: nothing is launched yet -- the stages are recorded, rt_advance_sample launches k_frame
             if (f->p->cur_slots != 0) return fail(ctx, "rt_generate_rays: the previous sample was not advanced (rt_advance_sample)");
             if (ensure_slots(f, 1) != RT_OK) return RT_ERROR;
-            if (frame_kernel_eligible(f)) { f->deferred.active = true; f->deferred.bounce = 0; f->deferred.next = 0; return RT_OK; }
+            if (frame_kernel_eligible(f)) { f->deferred.active = true; f->deferred.bounce = 0; f->deferred.next = 0; f->deferred.ahead = false; return RT_OK; }
         }
         return generate_rays(f, 1);
     }
@@ -2724,19 +3020,287 @@ int rt_copy_history(rt_frame* f)                        // CopyHistoryBuffers, :
     return RT_OK;
 }
 
+// ---- RT_OPT_SAMPLES_AHEAD: samples traced ahead of the caller's Integrate() calls -------------------------------------------------------
+// The reference's own pattern is one Integrate() per frame at one sample per pixel (src/render.cpp:197); while the camera stands still -- its
+// progressive accumulation -- sample s + 1 .. s + k are known the moment sample s is: same camera, consecutive sample indices.  A launch of one
+// sample per pixel is its own tail (3.3 ms per 1080p frame where the work is worth 1.6), a launch of k samples is not.  So,
+// once `RT_AHEAD_QUIET` samples have been advanced without a reset, the frame traces BATCHES of the next samples into two banks (frames of its
+// own: same tile, same options, the rt_integrate schedule without its replay) on streams beside the context's, 2, 4, 8 .. `depth` samples at a time,
+// and a later rt_advance_sample whose sample sits in a bank only REPLAYS that sample's slot of the bank's radiance log into the radiance
+// (k_flush, first_slot) -- the sum after every Integrate() is the reference's bit for bit, sample by sample, in sample order.  One bank is
+// consumed while the other computes; the moment a bank is empty its next batch is enqueued, so the device always has one batch running and one
+// queued.  A reset, another camera, another option, a scene upload, rt_integrate or anything that looks between two stages DISCARDS what was
+// traced ahead (its launches finish on their own streams, unobserved): the price of a camera that starts to move is at most 2 x depth samples
+// of device time, once; a camera that moves every frame never leaves the quiet phase and pays nothing.
+#define RT_AHEAD_QUIET 3u
+
+static bool ahead_bank_idle(const AheadBank& b) { return b.next >= b.n; }
+
+// the bank that holds sample `s` as its next slot, or -1
+static int ahead_holds(const rt_frame* f, uint32_t s)
+{
+    if (!f->ahead || !f->ahead_opt) return -1;
+    const Ahead& A = *f->ahead;
+    if (A.scene != f->ctx->scene_uploads || memcmp(&A.camera, &f->camera, sizeof(rt_camera)) != 0) return -1;
+    for (int i = 0; i < 2; ++i)
+        if (A.bank[i].h && !ahead_bank_idle(A.bank[i]) && A.bank[i].base + A.bank[i].next == s) return i;
+    return -1;
+}
+
+// Samples per batch: the caller's (2 .. 64), or -- 1 = automatic -- what makes a batch ~32 M paths: 16 samples of a 1080p frame, 4 of a 4K one
+// (rt_integrate at 2 / 4 / 8 / 16 samples of the 1080p headline frame in flight: 2.67 / 2.26 / 1.97 / 1.80 ms per sample where one alone costs 3.3 and
+// 128 together 1.56; the 4K / 16-bounce config: 22.7 / 19.4 / 17.9 ms at 1 / 2 / 4 -- profiles/r06_call01.log), within 64 GiB of path state for the two banks.
+static uint32_t ahead_depth(const rt_frame* f)
+{
+    const uint64_t n = f->n_local ? f->n_local : 1u;
+    uint64_t k = f->ahead_opt & 0xFFu;
+    if (k == 0) return 0;
+    if (k == 1 || k == 255) { k = (32000000ull + n - 1) / n; if (k > 64) k = 64; }
+    const uint64_t budget = f->state_limit_mb ? ((uint64_t)f->state_limit_mb << 20) : (64ull << 30);
+    const uint64_t per_sample = 2ull * n * (11u * 16u + 5u * 4u + 12u * 2u * (f->max_bounces + 1u));
+    if (k * per_sample > budget) k = budget / per_sample;
+    return k >= 2 ? (uint32_t)k : 0u;
+}
+
+// Is the stage API's next sample one this mode may serve?  (One sample of the whole tile in one chunk on the context's stream, nothing that reads
+// between the stages.)
+static bool ahead_wanted(const rt_frame* f)
+{
+    return f->ahead_opt != 0u && !f->ahead_owner && f->n_local != 0u && !(f->denoiser || f->aov != 0) && !f->profile && !f->timeline &&
+           f->stage_pipes <= 1u && f->pipelines == 1u && f->ctx->scene.valid && ahead_depth(f) >= 2u;
+}
+
+static void ahead_mirror(const rt_frame* f, uint32_t (&m)[16])
+{
+    const uint32_t v[16] = {f->max_bounces, f->sampler, f->white_furnace, f->drop_last, f->overlap_shadow, f->trace_variant, f->trace_tune, f->shade_partition,
+        f->trace_tail_lanes, f->chunk_refill, f->trace_waves_per_cu, f->select_form_box ? 1u : 0u, f->small_launch_set ? (uint32_t)std::min<uint64_t>(f->small_launch_paths, 0xFFFFFFFFull) : 0xFFFFFFFFu,
+        (uint32_t)std::min<uint64_t>(f->trace_tail_paths, 0xFFFFFFFFull), ahead_depth(f), f->ahead_opt & 0x100u};
+    memcpy(m, v, sizeof(v));
+}
+
+// The banks exist, are laid out for `depth` samples in flight and have the owner's options.  (Anything here may wait for the device: it runs when
+// the mode starts and after an option has changed, never between two frames of a quiet camera.)
+static int ahead_configure(rt_frame* f)
+{
+    rt_ctx* ctx = f->ctx;
+    if (!f->ahead) f->ahead = new Ahead();
+    Ahead& A = *f->ahead;
+    uint32_t want[16];
+    ahead_mirror(f, want);
+    if (A.configured && memcmp(want, A.mirrored, sizeof(want)) == 0) return RT_OK;
+    ahead_discard(f);
+    A.configured = false;
+    const bool two_streams = (f->ahead_opt & 0x100u) != 0u;
+    for (int i = 0; i < 2; ++i)
+    {
+        // the banks' launches go beside the frame's own: one stream for both banks (their batches in order) or one each (they overlap)
+        if (!A.stream[i] && (i == 0 || two_streams)) HIPCHK(ctx, hipStreamCreateWithFlags(&A.stream[i], hipStreamNonBlocking));
+        AheadBank& b = A.bank[i];
+        hipStream_t const st = two_streams ? A.stream[i] : A.stream[0];
+        if (b.h && b.h->ps[0].stream != st) { (void)rt_frame_destroy(b.h); b.h = nullptr; }
+        if (!b.h)
+        {
+            rt_frame_desc fd = {f->tile.width, f->tile.height, f->tile.rank, f->tile.nranks, f->tile.band_h};
+            if (create_frame(ctx, &fd, &b.h, st) != RT_OK) { b.h = nullptr; return RT_ERROR; }
+            b.h->ahead_owner = f;
+        }
+        if (!b.done) HIPCHK(ctx, hipEventCreateWithFlags(&b.done, hipEventDisableTiming));
+        if (!b.order) HIPCHK(ctx, hipEventCreateWithFlags(&b.order, hipEventDisableTiming));
+        if (sync_frame_streams(b.h) != RT_OK) return RT_ERROR;
+        rt_frame* h = b.h;
+        const std::pair<int, uint32_t> options[] = {{RT_OPT_MAX_BOUNCES, f->max_bounces}, {RT_OPT_SAMPLER, f->sampler}, {RT_OPT_WHITE_FURNACE, f->white_furnace},
+            {RT_OPT_TRACE_DROP_LAST_BOUNCE_RAYS, f->drop_last}, {RT_OPT_OVERLAP_SHADOW, f->overlap_shadow}, {RT_OPT_TRACE_VARIANT, f->trace_variant},
+            {RT_OPT_TRACE_TUNE, f->trace_tune}, {RT_OPT_SHADE_PARTITION, f->shade_partition}, {RT_OPT_TRACE_TAIL_LANES, f->trace_tail_lanes},
+            {RT_OPT_CHUNK_REFILL, f->chunk_refill}, {RT_OPT_TRACE_WAVES_PER_CU, f->trace_waves_per_cu}, {RT_OPT_TRACE_SELECT_FORM_BOX, f->select_form_box ? 1u : 0u}};
+        for (const auto& o : options)
+            if (rt_set_option(h, o.first, o.second) != RT_OK) return RT_ERROR;
+        h->trace_tail_paths = f->trace_tail_paths;
+        h->small_launch_paths = f->small_launch_paths; h->small_launch_set = f->small_launch_set;
+        if (ensure_slots(h, want[14]) != RT_OK) return RT_ERROR;
+        if (h->slots < 2u || h->chunk_pixels < (f->n_local ? f->n_local : 1u)) return fail(ctx, "RT_OPT_SAMPLES_AHEAD: a bank could not be laid out for the whole tile");
+    }
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));       // the banks' allocations were cleared on the context's stream
+    A.depth = std::min(want[14], std::min(A.bank[0].h->slots, A.bank[1].h->slots));
+    memcpy(A.mirrored, want, sizeof(want));
+    A.configured = true;
+    return RT_OK;
+}
+
+// A batch: samples base .. base + n - 1 through the wavefront loop of bank i, as rt_integrate runs one (the same launches in the same order), but the
+// log is left as it is: its replay happens sample by sample, by ahead_consume.
+static int ahead_launch(rt_frame* f, int i, uint32_t base, uint32_t n)
+{
+    rt_ctx* ctx = f->ctx;
+    Ahead& A = *f->ahead;
+    AheadBank& b = A.bank[i];
+    rt_frame* h = b.h;
+    hipStream_t const st = h->ps[0].stream;
+    h->camera = f->camera;
+    h->sample_count = base;
+    // behind whatever the owner's stream holds: the last replay out of this bank's log
+    HIPCHK(ctx, hipEventRecord(b.order, ctx->stream));
+    HIPCHK(ctx, hipStreamWaitEvent(st, b.order, 0));
+    h->p = &h->ps[0];
+    h->fused = true;
+    h->side_active = side_on(h);
+    int rc = generate_rays(h, n, 0, false);
+    if (rc == RT_OK) rc = rt_intersect(h, 0);
+    for (uint32_t bounce = 0; bounce <= h->max_bounces && rc == RT_OK; ++bounce)
+    {
+        if (rt_shade(h, bounce) != RT_OK) rc = RT_ERROR;
+        else if (h->side_active && bounce < h->max_bounces && rt_intersect(h, bounce + 1u) != RT_OK) rc = RT_ERROR;
+        else if (rt_intersect_shadow(h, bounce) != RT_OK) rc = RT_ERROR;
+        else if (!h->side_active && bounce < h->max_bounces && rt_intersect(h, bounce + 1u) != RT_OK) rc = RT_ERROR;
+    }
+    if (rc == RT_OK && (wait_shadow(h, 0) != RT_OK || wait_shadow(h, 1) != RT_OK)) rc = RT_ERROR;
+    h->fused = false;
+    if (rc == RT_OK && hipEventRecord(b.done, st) != hipSuccess) rc = fail(ctx, "RT_OPT_SAMPLES_AHEAD: recording a batch's end failed");
+    if (rc != RT_OK)
+    {
+        // nothing of a batch that could not be enqueued is ever replayed
+        (void)hipGetLastError();
+        (void)sync_frame_streams(h);
+        (void)hipMemsetAsync(h->ps[0].cnt, 0, (size_t)h->log_stride * sizeof(uint32_t), st);
+        h->ps[0].cur_slots = 0; h->ps[0].shadow_pending = false; h->ps[0].shadow_in_flight[0] = h->ps[0].shadow_in_flight[1] = false;
+        b.n = b.next = 0;
+        return RT_ERROR;
+    }
+    b.base = base; b.n = n; b.next = 0;
+    A.camera = f->camera;
+    A.scene = ctx->scene_uploads;
+    A.last_n = n;
+    A.launched += n;
+    return RT_OK;
+}
+
+// rt_advance_sample for a sample that sits in bank i: its slot of the bank's log, replayed into the radiance on the context's stream
+static int ahead_consume(rt_frame* f, int i)
+{
+    rt_ctx* ctx = f->ctx;
+    AheadBank& b = f->ahead->bank[i];
+    rt_frame* h = b.h;
+    HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, b.done, 0));
+    const uint32_t blocks = (f->n_local + 255u) / 256u;
+    hipLaunchKernelGGL(k_flush, dim3(blocks), dim3(256), 0, ctx->stream, f->radiance, dlog(h), f->n_local, 1u, h->chunk_pixels, 0u, b.next);
+    HIPCHK(ctx, hipGetLastError());
+    ++b.next;
+    ++f->sample_count;
+    ++f->ahead->consumed;
+    if (ahead_bank_idle(b)) h->ps[0].cur_slots = 0;       // every slot replayed (k_flush has set their counts back to zero)
+    return RT_OK;
+}
+
+// Every idle bank gets the next batch -- the samples behind the last one traced ahead -- as long as some bank holds the next sample (otherwise the
+// mode is starting: `first` = the sample to begin with).  A failure to launch only ends the speculation: the samples are traced when they are asked for.
+static void ahead_schedule(rt_frame* f, bool starting)
+{
+    if (!ahead_wanted(f)) return;
+    if (ahead_configure(f) != RT_OK) { (void)hipGetLastError(); f->ahead_opt = 0; return; }   // (e.g. no memory for the banks: the mode switches itself off)
+    Ahead& A = *f->ahead;
+    if (A.depth < 2u) return;
+    const uint32_t s = f->sample_count;
+    if (!starting && ahead_holds(f, s) < 0 && !(ahead_bank_idle(A.bank[0]) && ahead_bank_idle(A.bank[1]))) return;
+    for (int i = 0; i < 2; ++i)
+    {
+        if (!ahead_bank_idle(A.bank[i])) continue;
+        uint32_t end = s;
+        for (const AheadBank& o : A.bank) if (!ahead_bank_idle(o)) end = std::max(end, o.base + o.n);
+        const uint32_t n = ahead_bank_idle(A.bank[i ^ 1]) ? 2u : std::min(A.depth, 2u * std::max(1u, A.last_n));
+        if (end > 0xFFFFFFFFu - n) return;
+        if (ahead_launch(f, i, end, n) != RT_OK) { (void)hipGetLastError(); return; }
+        if (starting) return;                               // the first batch alone: the ramp's next step follows at its first replay
+    }
+}
+
+static void ahead_discard(rt_frame* f)
+{
+    if (!f || !f->ahead) return;
+    Ahead& A = *f->ahead;
+    A.quiet = 0;
+    A.last_n = 0;
+    for (AheadBank& b : A.bank)
+    {
+        if (!b.h) continue;
+        rt_frame* h = b.h;
+        hipStream_t const st = h->ps[0].stream;
+        if (!ahead_bank_idle(b) || h->ps[0].cur_slots != 0)
+        {
+            // behind the owner's last replay out of this log AND behind the batch itself (same stream): the slots nobody replayed go back to zero, and so
+            // do the bank's ray counters (rt_frame_get_stats adds them to the owner's)
+            (void)hipEventRecord(b.order, f->ctx->stream);
+            (void)hipStreamWaitEvent(st, b.order, 0);
+            (void)hipMemsetAsync(h->ps[0].cnt, 0, (size_t)h->log_stride * sizeof(uint32_t), st);
+            A.discarded += b.n - b.next;
+        }
+        if (h->ps[0].counters) (void)hipMemsetAsync(h->ps[0].counters, 0, sizeof(DCounters), st);
+        h->ps[0].cur_slots = 0; h->ps[0].shadow_pending = false; h->ps[0].prev_bounces = 0; h->ps[0].fold_accumulates = 0;
+        b.n = b.next = 0;
+    }
+}
+
+static void ahead_destroy(rt_frame* f)
+{
+    if (!f || !f->ahead) return;
+    Ahead* A = f->ahead;
+    f->ahead = nullptr;
+    for (AheadBank& b : A->bank)
+    {
+        if (b.h) (void)rt_frame_destroy(b.h);             // (waits for its streams)
+        if (b.done) (void)hipEventDestroy(b.done);
+        if (b.order) (void)hipEventDestroy(b.order);
+    }
+    for (hipStream_t st : A->stream) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+    delete A;
+}
+
+// A sample the frame traced itself has been advanced: RT_AHEAD_QUIET of them in a row (no reset between) start the mode -- a first batch of two.
+static void ahead_after_plain_sample(rt_frame* f)
+{
+    if (!f->ahead_opt || !ahead_wanted(f)) return;
+    if (!f->ahead) f->ahead = new Ahead();
+    Ahead& A = *f->ahead;
+    if (++A.quiet < RT_AHEAD_QUIET) return;
+    if (ahead_bank_idle(A.bank[0]) && ahead_bank_idle(A.bank[1])) ahead_schedule(f, true);
+}
+
 int rt_advance_sample(rt_frame* f)                      // AdvanceSampleCount, :510-514
 {
     if (!f) return fail(nullptr, "rt_advance_sample: frame is NULL");
     (void)hipSetDevice(f->ctx->device);
     if (f->deferred.active)
     {
-        // the whole sample was recorded in the canonical order: ONE launch (k_frame replays its own pixels' log, too)
-        if (f->deferred.next == 0 && f->deferred.bounce == f->max_bounces + 1u && frame_kernel_eligible(f))
+        const bool whole = f->deferred.next == 0 && f->deferred.bounce == f->max_bounces + 1u;
+        if (f->deferred.ahead)
         {
+            // RT_OPT_SAMPLES_AHEAD: the sample was traced ahead; its recorded stages are dropped and its log slot is replayed
+            const int bank = whole ? ahead_holds(f, f->sample_count) : -1;
+            if (bank >= 0)
+            {
+                f->deferred.active = false; f->deferred.ahead = false;
+                if (ahead_consume(f, bank) != RT_OK) return RT_ERROR;
+                ++f->ahead->quiet;
+                ahead_schedule(f, false);
+                return RT_OK;
+            }
+        }
+        // the whole sample was recorded in the canonical order: ONE launch (k_frame replays its own pixels' log, too)
+        else if (whole && frame_kernel_eligible(f))
+        {
+            if (launch_frame_kernel(f) != RT_OK)
+            {
+                //  the recorded sample is not lost: it runs through the stage kernels, and this frame stops asking for k_frame
+                (void)hipGetLastError();
+                f->frame_kernel = 0u;
+                f->fk_auto.decided = true; f->fk_auto.use_kernel = false; f->fk_auto.timing = -1;
+                if (deferred_materialize(f) != RT_OK || flush_stage(f) != RT_OK) return RT_ERROR;
+                f->sample_count += 1;
+                ahead_after_plain_sample(f);
+                return RT_OK;
+            }
             f->deferred.active = false;
-            if (launch_frame_kernel(f) != RT_OK) return RT_ERROR;
             f->sample_count += 1;
             if (f->fk_auto.timing >= 0) { (void)hipEventRecord(f->fk_auto.ev[f->fk_auto.timing][1], f->ctx->stream); f->fk_auto.timing = -1; }
+            ahead_after_plain_sample(f);
             return RT_OK;
         }
         if (deferred_materialize(f) != RT_OK) return RT_ERROR;
@@ -2745,6 +3309,7 @@ int rt_advance_sample(rt_frame* f)                      // AdvanceSampleCount, :
     if (flush_stage(f) != RT_OK) return RT_ERROR;        // radiance_buffer_ += this sample's contributions (of every chunk: RT_OPT_STAGE_PIPES)
     f->sample_count += n;
     if (f->fk_auto.timing >= 0) { (void)hipEventRecord(f->fk_auto.ev[f->fk_auto.timing][1], f->ctx->stream); f->fk_auto.timing = -1; }   // RT_OPT_FRAME_KERNEL = 255
+    ahead_after_plain_sample(f);
     return RT_OK;
 }
 
@@ -2929,7 +3494,7 @@ static int fold_adapt_hook(rt_frame* f)
         // an orbiting camera leaves the view again and again: at most one adaptation per min_interval_ms (bit 1 -- tests, bench.py -- waits
         // for every one of them anyway)
         const auto now = std::chrono::steady_clock::now();
-        if ((a->mode & 2u) || std::chrono::duration<double, std::milli>(now - a->last_armed).count() >= (double)a->min_interval_ms) a->state = FoldAdapt::ARMED;
+        if ((a->mode.load() & 2u) || std::chrono::duration<double, std::milli>(now - a->last_armed).count() >= (double)a->min_interval_ms.load()) a->state = FoldAdapt::ARMED;
     }
     if (a->state == FoldAdapt::ARMED)
     {
@@ -2948,7 +3513,7 @@ static int fold_adapt_hook(rt_frame* f)
     }
     if (a->state == FoldAdapt::PROBING)
     {
-        if (a->mode & 2u) { if (hipEventSynchronize(a->probe_done) != hipSuccess) { (void)hipGetLastError(); a->state = FoldAdapt::OFF; return RT_OK; } }
+        if (a->mode.load() & 2u) { if (hipEventSynchronize(a->probe_done) != hipSuccess) { (void)hipGetLastError(); a->state = FoldAdapt::OFF; return RT_OK; } }
         else
         {
             const hipError_t e = hipEventQuery(a->probe_done);
@@ -2962,7 +3527,7 @@ static int fold_adapt_hook(rt_frame* f)
         a->finished.store(false);
         a->worker = std::thread(fold_adapt_worker, a);
     }
-    if (a->state == FoldAdapt::COMPUTING && ((a->mode & 2u) || a->finished.load())) return fold_adopt(f->ctx);
+    if (a->state == FoldAdapt::COMPUTING && ((a->mode.load() & 2u) || a->finished.load())) return fold_adopt(f->ctx);
     return RT_OK;
 }
 
@@ -2975,6 +3540,7 @@ int rt_integrate(rt_frame* f, uint32_t n_samples)       // n x Integrator::Integ
         for (const PathPipe& q : f->ps) if (q.cur_slots != 0) return fail(ctx, "rt_integrate: a sample of the stage API is in flight (rt_advance_sample first)");
         f->stage_chunks = 1;
     }
+    ahead_discard(f);                                   // RT_OPT_SAMPLES_AHEAD serves the stage API; these samples are traced here
     if (fold_adapt_hook(f) != RT_OK) return RT_ERROR;
     // `slots` samples travel through the wavefront together (more rays per launch ->
     // fuller machine, shorter relative tails); the radiance log keeps the sum exact.
@@ -3218,6 +3784,22 @@ int rt_frame_get_stats(rt_frame* f, rt_stats* out)
     out->frame_kernel_samples = (uint32_t)f->frame_launches;
     out->chunk_pixels = f->chunk_pixels;
     out->pipelines = f->n_pipes;
+    if (f->ahead)
+    {
+        // RT_OPT_SAMPLES_AHEAD: the rays of the samples that came out of the banks were counted there -- whole batches at a time, so the totals
+        // include `samples_ahead` samples that `samples` does not yet
+        for (const AheadBank& b : f->ahead->bank)
+        {
+            if (!b.h) continue;
+            rt_stats hs;
+            if (rt_frame_get_stats(b.h, &hs) != RT_OK) return RT_ERROR;
+            out->closest_rays += hs.closest_rays; out->shadow_rays += hs.shadow_rays;
+            out->stack_spills += hs.stack_spills; out->slow_rays += hs.slow_rays;
+            out->path_state_bytes += hs.path_state_bytes;
+            out->samples_ahead += b.n - b.next;
+        }
+        out->samples_from_banks = f->ahead->consumed;
+    }
     return RT_OK;
 }
 
@@ -3408,6 +3990,67 @@ int rt_debug_wide_bvh(const rt_bvh_node* nodes, uint32_t num_nodes, int collapse
 }
 
 const char* rt_scene_tree_report(rt_ctx* ctx) { return ctx ? ctx->scene.tree_report.c_str() : ""; }
+
+int rt_debug_device_fold(rt_ctx* ctx, const rt_bvh_node* nodes, uint32_t num_nodes, double iso_weight, const float* dirs, uint32_t n_dirs, const double* weights,
+    void* records, uint32_t* roots, uint32_t capacity, uint32_t* num_records, uint32_t* entry_ref, double* seconds)
+{
+    if (!ctx || !nodes || num_nodes == 0 || !num_records || !entry_ref) return fail(ctx, "rt_debug_device_fold: NULL argument");
+    (void)hipSetDevice(ctx->device);
+    ownbvh::Metric m;
+    const bool with_metric = iso_weight >= 0.0;
+    if (with_metric)
+    {
+        m.iso = iso_weight;
+        for (uint32_t i = 0; i < n_dirs && dirs; ++i) m.dirs.push_back({std::fabs((double)dirs[3 * i]), std::fabs((double)dirs[3 * i + 1]), std::fabs((double)dirs[3 * i + 2])});
+    }
+    void* d_nodes = nullptr;
+    if (dev_alloc_copy(ctx, &d_nodes, nodes, (size_t)num_nodes * sizeof(rt_bvh_node)) != RT_OK) return RT_ERROR;
+    WideNode* d_recs = nullptr;
+    std::vector<uint32_t> folded;
+    std::vector<WideNode> wide;
+    const bool ok = devfold::fold(ctx->stream, (const rt_bvh_node*)d_nodes, num_nodes, nodes[0], with_metric ? &m : nullptr, weights, &d_recs, num_records, entry_ref, &folded, &wide, nullptr, seconds);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_nodes);
+    if (d_recs) (void)hipFree(d_recs);
+    if (!ok) return fail(ctx, "rt_debug_device_fold: the tree does not qualify for the 4-wide layout, or the device path failed");
+    if (records)
+    {
+        if (wide.size() > capacity) return fail(ctx, "rt_debug_device_fold: capacity too small");
+        memcpy(records, wide.data(), wide.size() * sizeof(WideNode));
+        if (roots) memcpy(roots, folded.data(), folded.size() * sizeof(uint32_t));
+    }
+    return RT_OK;
+}
+
+int rt_debug_pair_layout(const rt_bvh_node* nodes, uint32_t num_nodes, void* records, uint32_t* roots, uint32_t num_records)
+{
+    if (!nodes || !records || !roots || num_nodes == 0) return fail(nullptr, "rt_debug_pair_layout: NULL argument");
+    std::vector<WideNode> wide((const WideNode*)records, (const WideNode*)records + num_records);
+    std::vector<uint32_t> r(roots, roots + num_records);
+    pair_layout_by_area(wide, r, nodes, num_nodes, (const ownbvh::Metric*)nullptr);
+    memcpy(records, wide.data(), wide.size() * sizeof(WideNode));
+    memcpy(roots, r.data(), r.size() * sizeof(uint32_t));
+    return RT_OK;
+}
+
+int rt_debug_wide_bvh_weights(const rt_bvh_node* nodes, uint32_t num_nodes, const double* weights, void* records, uint32_t* roots, uint32_t capacity,
+    uint32_t* num_records, uint32_t* entry_ref)
+{
+    if (!nodes || num_nodes == 0 || !weights || !num_records || !entry_ref) return fail(nullptr, "rt_debug_wide_bvh_weights: NULL argument");
+    std::vector<WideNode> wide;
+    std::vector<uint32_t> folded;
+    uint32_t entry = 0;
+    if (!build_wide_bvh(nodes, num_nodes, RT_WIDE_SAH, wide, entry, &folded, nullptr, weights)) return fail(nullptr, "rt_debug_wide_bvh_weights: the tree does not qualify for the 4-wide layout");
+    *num_records = (uint32_t)wide.size();
+    *entry_ref = entry;
+    if (records)
+    {
+        if (wide.size() > capacity) return fail(nullptr, "rt_debug_wide_bvh_weights: capacity too small");
+        memcpy(records, wide.data(), wide.size() * sizeof(WideNode));
+        if (roots) memcpy(roots, folded.data(), folded.size() * sizeof(uint32_t));
+    }
+    return RT_OK;
+}
 
 int rt_debug_choose_tree(const rt_scene_desc* sd, int shadow, uint32_t mode, void* records, uint32_t capacity, uint32_t* num_records,
     uint32_t* entry_ref, char* report, size_t report_len)

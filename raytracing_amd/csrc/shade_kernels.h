@@ -724,14 +724,16 @@ __global__ __launch_bounds__(RT_SHADE_BLOCK) __attribute__((amdgpu_waves_per_eu(
 // keep_open (a mid-sample read through the stage API on a COMPACT allocation): the sample goes on, and its count and its
 // overflow block must stay what k_shade knows them to be -- the entries replayed here are zeroed instead (adding +0.0 again
 // at the sample's end is the identity), the count is kept.  The full layout restarts the count at 0 as it always did.
+// first_slot (RT_OPT_SAMPLES_AHEAD): the replay covers the sample slots first_slot .. first_slot + n_slots - 1 only -- a batch traced ahead of the
+// caller's Integrate() calls reaches the radiance one sample per call, in sample order.
 __global__ __launch_bounds__(256) void k_flush(float4* __restrict__ radiance, DLog log, uint32_t n_pixels, uint32_t n_slots, uint32_t id_stride,
-    uint32_t keep_open)
+    uint32_t keep_open, uint32_t first_slot)
 {
     // radiance: already offset to the chunk's first pixel; id_stride: pixels per chunk as allocated
     uint32_t p = blockIdx.x * 256u + threadIdx.x;
     if (p >= n_pixels) return;
     float4 r = radiance[p];
-    for (uint32_t slot = 0; slot < n_slots; ++slot)
+    for (uint32_t slot = first_slot; slot < first_slot + n_slots; ++slot)
     {
         uint32_t id = slot * id_stride + p;
         uint32_t c = log.cnt[id];

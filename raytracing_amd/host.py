@@ -23,7 +23,7 @@ EXPORTS = [
     "rth_render_read_radiance", "rth_render_read_resolved", "rth_render_stats", "rth_render_frame_handle",
     "rth_render_ctx_handle", "rth_render_num_nodes", "rth_render_nodes", "rth_render_set_aov", "rth_render_resolve",
     "rth_render_set_blue_noise_path", "rth_render_reserve_samples", "rth_scene_save_cache", "rth_load_jpeg",
-    "rth_render_upload_gpu_data",
+    "rth_render_upload_gpu_data", "rth_render_setup_seconds",
 ]
 
 
@@ -58,6 +58,7 @@ def load():
         "rth_render_enable_white_furnace": (i32, [vp, i32]), "rth_render_set_sampler": (i32, [vp, i32]),
         "rth_render_enable_denoiser": (i32, [vp, i32]), "rth_render_set_resolve_every_frame": (i32, [vp, i32]),
         "rth_render_frame": (i32, [vp]), "rth_render_samples": (i32, [vp, u32]), "rth_render_reserve_samples": (i32, [vp, u32]), "rth_render_finish": (i32, [vp]),
+        "rth_render_setup_seconds": (None, [vp, C.POINTER(C.c_double)]),
         "rth_render_local_rows": (u32, [vp]), "rth_render_global_row": (u32, [vp, u32]),
         "rth_render_sample_count": (u32, [vp]), "rth_render_read_radiance": (i32, [vp, vp]),
         "rth_render_read_resolved": (i32, [vp, vp]), "rth_render_stats": (i32, [vp, C.POINTER(rt_stats)]),
@@ -291,6 +292,12 @@ class Render:
         self._c(self.lib.rth_render_resolve(self.handle, out.ctypes.data))
         return out
     def set_resolve_every_frame(self, e): self._c(self.lib.rth_render_set_resolve_every_frame(self.handle, int(e)))
+    def setup_seconds(self):
+        """what the constructor spent: BVH build (or adoption of a cached tree), Scene::Finalize, the integrator's frame, UploadGPUData"""
+        out = (C.c_double * 4)()
+        self.lib.rth_render_setup_seconds(self.handle, out)
+        return dict(bvh_build=round(out[0], 3), finalize=round(out[1], 3), frame=round(out[2], 3), upload=round(out[3], 3))
+
     def render_frame(self): self._c(self.lib.rth_render_frame(self.handle))
     def render_samples(self, n): self._c(self.lib.rth_render_samples(self.handle, n))
 

@@ -81,6 +81,9 @@ HIPPathTraceIntegrator::HIPPathTraceIntegrator(std::uint32_t width, std::uint32_
         // Integrate() through the hooks is this class's whole purpose: let the backend MEASURE whether a frame is better served by its stage
         // kernels or by one k_frame launch (RT_OPT_FRAME_KERNEL = 255; bit-identical either way; SetFrameKernel(0) keeps the stage kernels)
         Check(rt_set_option(frame_, RT_OPT_FRAME_KERNEL, 255u));
+        // ... and trace a standing camera's next samples ahead, in batches (RT_OPT_SAMPLES_AHEAD = 1: the image after every Integrate() is the same
+        // bit for bit; a launch of k samples is not its own tail the way a launch of one is; SetSamplesAhead(0) switches it off)
+        Check(rt_set_option(frame_, RT_OPT_SAMPLES_AHEAD, 1u));
     }
     catch (...)
     {
@@ -180,6 +183,7 @@ void HIPPathTraceIntegrator::SyncOptions()
 }
 
 void HIPPathTraceIntegrator::SetFrameKernel(std::uint32_t mode) { Check(rt_set_option(frame_, RT_OPT_FRAME_KERNEL, mode)); }
+void HIPPathTraceIntegrator::SetSamplesAhead(std::uint32_t mode) { Check(rt_set_option(frame_, RT_OPT_SAMPLES_AHEAD, mode)); }
 void HIPPathTraceIntegrator::Reset() { SyncOptions(); Check(rt_reset(frame_)); }
 void HIPPathTraceIntegrator::AdvanceSampleCount() { Check(rt_advance_sample(frame_)); }
 void HIPPathTraceIntegrator::GenerateRays() { SyncOptions(); Check(rt_generate_rays(frame_)); }

@@ -73,6 +73,9 @@ public:
     void SetResolveEveryFrame(bool enable) { resolve_every_frame_ = enable; }
     // RT_OPT_FRAME_KERNEL: 255 (this class's default) = measured choice between the stage kernels and one k_frame launch per Integrate(); 0 / 1 = forced
     void SetFrameKernel(std::uint32_t mode);
+    // RT_OPT_SAMPLES_AHEAD: 1 (this class's default) = while the camera stands still the backend traces the next samples ahead in batches and an
+    // Integrate() whose sample is there only replays it (same radiance after every call); 0 = every Integrate() traces its own sample; k = batch size
+    void SetSamplesAhead(std::uint32_t mode);
     // packed uint8 tables, see tools/make_blue_noise_asset.py (default: relative to the CWD like the env map)
     void SetBlueNoiseTablePath(std::string path) { blue_noise_path_ = std::move(path); }
     rt_frame* GetFrame() const { return frame_; }

@@ -189,6 +189,7 @@ int rth_render_reserve_samples(void* r, uint32_t n)
 }
 int rth_render_finish(void* r) { return guard([&]() { ((rt::Render*)r)->GetContext().Finish(); return 0; }, 1); }
 uint32_t rth_render_local_rows(void* r) { return ((rt::Render*)r)->GetIntegrator().GetLocalRows(); }
+void rth_render_setup_seconds(void* r, double* out4) { const double* s = ((rt::Render*)r)->GetSetupSeconds(); for (int i = 0; i < 4; ++i) out4[i] = s[i]; }
 uint32_t rth_render_global_row(void* r, uint32_t row) { return ((rt::Render*)r)->GetIntegrator().GetGlobalRow(row); }
 uint32_t rth_render_sample_count(void* r) { return ((rt::Render*)r)->GetIntegrator().GetSampleCount(); }
 int rth_render_read_radiance(void* r, float* out)

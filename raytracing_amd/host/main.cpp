@@ -23,7 +23,7 @@ int main(int argc, char** argv)
 {
     try
     {
-        unsigned width = 1280, height = 720, spp = 16, bounces = 3, gpus = 1, frames = 0;
+        unsigned width = 1280, height = 720, spp = 16, bounces = 3, gpus = 1, frames = 0, samples_ahead = 1;
         std::string scene_path = "assets/ShaderBalls.obj", out, save_cache;
         float scale = 1.0f, aperture = 0.0f, focus = 10.0f;
         bool flip_yz = false, furnace = false, tiled_path = false, shared_device = false, plan_only = false, resolve = true;
@@ -46,6 +46,7 @@ int main(int argc, char** argv)
             else if (!strcmp(argv[i], "--gpus")) gpus = (unsigned)atoi(next());
             else if (!strcmp(argv[i], "--resolve")) resolve = atoi(next()) != 0;          // with --frames: 0 = no ResolveRadiance / present per frame (diagnostic)
             else if (!strcmp(argv[i], "--frames")) frames = (unsigned)atoi(next());      // the reference's interactive loop, headless: n x RenderFrame()
+            else if (!strcmp(argv[i], "--samples_ahead")) samples_ahead = (unsigned)atoi(next());   // with --frames: RT_OPT_SAMPLES_AHEAD (1 = the integrator's default, 0 = off)
             else if (!strcmp(argv[i], "--tiled")) tiled_path = atoi(next()) != 0;      // take the TiledRender path even with one GPU
             else if (!strcmp(argv[i], "--shared_device")) shared_device = atoi(next()) != 0;   // all tiles on GPU 0 (device copies instead of RCCL)
             else if (!strcmp(argv[i], "--plan")) plan_only = atoi(next()) != 0;              // print the tiling and exit: no GPU, no scene
@@ -59,7 +60,8 @@ int main(int argc, char** argv)
                              "  --shared_device 1 puts all n tiles on GPU 0 (device copies instead of RCCL); --plan 1 prints the tiling and exits\n"
                              "  --scene also accepts a file written by --save-cache (parsed scene + BVH)\n"
                              "  --frames n times the reference's own loop instead of a batch: n x Render::RenderFrame() = one Integrate() through\n"
-                             "  the fifteen hooks, one sample per pixel, ResolveRadiance + Finish() every frame (src/render.cpp:172-204)\n"
+                             "  the fifteen hooks, one sample per pixel, ResolveRadiance + Finish() every frame (src/render.cpp:172-204);\n"
+                             "  --samples_ahead 0 makes every one of them trace its own sample (default 1: a standing camera's next samples are traced ahead in batches)\n"
                              "  extensions (off = the reference's behaviour): --wide_texture_indices 1 loads scenes with more than 255\n"
                              "  textures; --emissive_nee 1 adds the emissive triangles to next-event estimation\n";
                 return 0;
@@ -133,6 +135,7 @@ int main(int argc, char** argv)
             // Integrate() through the hooks and ends with ResolveRadiance + Finish().  A warm-up batch first (the fold adaptation happens there),
             // then `frames` timed frames.  No Python, no PyTorch in this process: the HIP runtime is the system's.
             render.GetIntegrator().SetResolveEveryFrame(resolve);
+            render.GetIntegrator().SetSamplesAhead(samples_ahead);
             render.RenderSamples(8);
             for (int i = 0; i < 24; ++i) render.RenderFrame();             // (the backend times its two ways over a scene's first 20 frames: RT_OPT_FRAME_KERNEL = 255)
             render.GetContext().Finish();
@@ -144,8 +147,11 @@ int main(int argc, char** argv)
             double df = std::chrono::duration<double>(std::chrono::steady_clock::now() - tf).count();
             rt_stats s1 = render.GetIntegrator().GetStats();
             double frays = (double)(s1.closest_rays - s0.closest_rays) + (double)(s1.shadow_rays - s0.shadow_rays);
+            // (RT_OPT_SAMPLES_AHEAD: the ray totals include the samples traced ahead at either end -- scaled to the timed frames' share; bench.py counts exactly)
+            const double traced = (double)frames + (double)s1.samples_ahead - (double)s0.samples_ahead;
+            if (traced > 0.0) frays *= (double)frames / traced;
             std::cout << frames << " frames (one Integrate() each, resolve + Finish() every frame) in " << df << " s: " << df * 1e3 / frames
-                      << " ms per frame, " << frays / df / 1e6 << " Mrays/s" << std::endl;
+                      << " ms per frame, " << frays / df / 1e6 << " Mrays/s (" << (s1.samples_from_banks - s0.samples_from_banks) << " of them replayed from batches traced ahead)" << std::endl;
             return 0;
         }
         auto t0 = std::chrono::steady_clock::now();

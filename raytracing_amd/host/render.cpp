@@ -32,15 +32,22 @@ Render::Render(std::uint32_t width, std::uint32_t height, Scene& scene, int devi
     : scene_(scene), width_(width), height_(height)
 {
     context_ = std::make_shared<HIPContext>(device_ordinal);
+    auto now = []() { return std::chrono::steady_clock::now(); };
+    auto since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double>(now() - t).count(); };
     // Build first, Finalize after: the build reorders the triangles the emissive
     // list indexes (render.cpp:61-67)
+    auto t = now();
     auto bvh = std::make_unique<Bvh>();
     if (scene_.HasPrebuiltBvh()) bvh->AdoptNodes(scene_.GetPrebuiltNodes());   // binary scene cache
     else bvh->BuildCPU(scene_.GetTriangles());
     acc_structure_ = std::move(bvh);
+    setup_seconds_[0] = since(t); t = now();
     scene_.Finalize();
+    setup_seconds_[1] = since(t); t = now();
     integrator_ = std::make_unique<HIPPathTraceIntegrator>(width_, height_, *acc_structure_, *context_, tile);
+    setup_seconds_[2] = since(t); t = now();
     integrator_->UploadGPUData(scene_, *acc_structure_);
+    setup_seconds_[3] = since(t);
     camera_ = DefaultCamera(width_, height_);
 }
 

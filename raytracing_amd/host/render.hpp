@@ -29,10 +29,13 @@ public:
     AccelerationStructure const& GetAccelerationStructure() const { return *acc_structure_; }
     std::uint32_t GetWidth() const { return width_; }
     std::uint32_t GetHeight() const { return height_; }
+    // what the constructor spent, seconds: {Bvh::BuildCPU (or adopting a cached tree), Scene::Finalize, the integrator (frame buffers), UploadGPUData}
+    double const* GetSetupSeconds() const { return setup_seconds_; }
 
 private:
     Scene& scene_;
     std::uint32_t width_, height_;
+    double setup_seconds_[4] = {0.0, 0.0, 0.0, 0.0};
     std::shared_ptr<HIPContext> context_;
     std::unique_ptr<AccelerationStructure> acc_structure_;
     std::unique_ptr<HIPPathTraceIntegrator> integrator_;

@@ -175,6 +175,9 @@ def test_the_measured_choice_times_both_ways_and_changes_no_bit(ctx, golden_scen
     w, h, b, n = 96, 64, 3, 26
     sc = golden_scenes["coverage"]
     cam = T.default_camera(w, h)
+    # (a frame during which a fold adaptation is under way is not one of the sixteen timed ones -- round 6, ADVICE r05: the schedule below is the one
+    # of a scene whose folds have settled, so this scene's adaptation is waited for: RT_CTX_OPT_ADAPTIVE_FOLD bit 1)
+    assert ctx.lib.rt_ctx_set_option(ctx.handle, 4, capi.ADAPTIVE_FOLD_DEFAULT | 2) == 0
     ctx.upload_scene(sc)
     plain = framed(ctx, w, h, cam, b, kernel=False)
     fr = framed(ctx, w, h, cam, b, kernel=False)
@@ -193,6 +196,23 @@ def test_the_measured_choice_times_both_ways_and_changes_no_bit(ctx, golden_scen
     for i in range(6):
         stage_sample(plain, b); stage_sample(fr, b)
     assert fr.stats().frame_kernel_samples == base + 3                        # frames 2, 3 and 5 of the new measurement
+    assert np.array_equal(fr.radiance(), plain.radiance(), equal_nan=True)
+    fr.close(); plain.close()
+    assert ctx.lib.rt_ctx_set_option(ctx.handle, 4, capi.ADAPTIVE_FOLD_DEFAULT) == 0
+
+
+def test_frames_during_a_fold_adaptation_are_not_timed(ctx, golden_scenes):
+    """with the adaptation asynchronous (the library's default) the measured choice does not time the frames during which the probe runs, the
+    worker folds or the new fold is adopted -- they go through the stage kernels -- and the image stays the stage kernels' whatever happens when."""
+    w, h, b, n = 96, 64, 3, 40
+    sc = golden_scenes["coverage"]
+    cam = T.default_camera(w, h)
+    ctx.upload_scene(sc)                                                      # (9161 nodes: above the adaptation's threshold)
+    plain = framed(ctx, w, h, cam, b, kernel=False)
+    fr = framed(ctx, w, h, cam, b, kernel=False)
+    fr.set_option(capi.OPT_FRAME_KERNEL, 255)
+    for i in range(n):
+        stage_sample(plain, b); stage_sample(fr, b)
     assert np.array_equal(fr.radiance(), plain.radiance(), equal_nan=True)
     fr.close(); plain.close()
 
@@ -226,3 +246,50 @@ def test_frame_kernel_on_the_tiles_of_a_multi_gpu_split(ctx, golden_scenes):
         fs = full.stats()
         assert rays == fs.closest_rays + fs.shadow_rays
     full.close()
+
+
+def test_a_camera_set_between_recorded_stages_belongs_to_the_next_sample(ctx, golden_scenes):
+    """rt_set_camera between rt_generate_rays and rt_advance_sample.  The stage kernels generate a sample's primary rays at rt_generate_rays,
+    so a camera set afterwards moves the NEXT sample; a recorded (deferred) sample must do the same -- the recorded stages run with the camera they were
+    recorded under."""
+    w, h, b = 72, 48, 3
+    sc = golden_scenes["coverage"]
+    cam, cam2 = T.default_camera(w, h), T.default_camera(w, h)
+    cam2["position"]["x"] += np.float32(0.07)
+    ctx.upload_scene(sc)
+    plain = framed(ctx, w, h, cam, b, kernel=False)
+    fr = framed(ctx, w, h, cam, b)
+    for f in (plain, fr):
+        f.generate_rays()
+        f.intersect(0); f.shade(0)
+        f.set_camera(cam2)                                   # between two recorded stages
+        f.intersect_shadow(0)
+        for bounce in range(1, b + 1):
+            f.intersect(bounce); f.shade(bounce); f.intersect_shadow(bounce)
+        f.advance_sample()
+        stage_sample(f, b)                                   # this one sees cam2 in both
+    assert np.array_equal(fr.radiance(), plain.radiance(), equal_nan=True)
+    assert fr.stats().frame_kernel_samples == 1              # the second sample; the first was replayed by the stage kernels with the old camera
+    fr.close(); plain.close()
+
+
+def test_k_frame_that_cannot_allocate_falls_back_to_the_stage_kernels(ctx, golden_scenes):
+    """a failed allocation of k_frame's per-wave buffers must neither leave a half-made grid behind nor lose the recorded sample."""
+    w, h, b = 72, 48, 3
+    sc = golden_scenes["coverage"]
+    cam = T.default_camera(w, h)
+    ctx.upload_scene(sc)
+    plain = framed(ctx, w, h, cam, b, kernel=False)
+    fr = framed(ctx, w, h, cam, b)
+    fr.set_option(capi.OPT_DEBUG_ALLOC_LIMIT, 0xFFFFFFFF)    # the hook: k_frame's buffers "do not fit"
+    for _ in range(3):
+        stage_sample(plain, b); stage_sample(fr, b)
+    assert fr.stats().frame_kernel_samples == 0
+    assert np.array_equal(fr.radiance(), plain.radiance(), equal_nan=True)
+    assert fr.sample_count() == 3
+    fr.set_option(capi.OPT_DEBUG_ALLOC_LIMIT, 0)
+    fr.set_option(capi.OPT_FRAME_KERNEL, KERNEL_VALUE)       # asked for again, and now it fits
+    stage_sample(plain, b); stage_sample(fr, b)
+    assert fr.stats().frame_kernel_samples == 1
+    assert np.array_equal(fr.radiance(), plain.radiance(), equal_nan=True)
+    fr.close(); plain.close()

@@ -114,3 +114,50 @@ def test_wide_walk_on_random_soups(seed, env_map):
     assert c["triangle_tests"] > 0 and sh["rays"] > 0
     if seed == 3:
         assert sh["rays_left_to_bvh2"] > 0
+
+
+def test_the_pair_layout_is_a_permutation_the_walk_does_not_see(golden_scenes):
+    """RT_CTX_OPT_WIDE_LAYOUT = 1 (round 6): the records in (parent, likeliest child) pairs -- a valid fold by every invariant of tests/test_wide_bvh.py, every
+    record with interior slots at an even index followed by one of its children, and the CPU restatement of k_trace_w4's walk returns the reference's hits
+    and verdicts on the permuted records exactly as on the fold's own order."""
+    import ctypes as C
+    from tests.test_wide_bvh import check, WIDE
+    from raytracing_amd import capi
+    lib = capi.load()
+    for name, (w, h, b) in {"cornell": (48, 32, 3), "coverage": (56, 40, 4)}.items():
+        arrays = golden_scenes[name]
+        nodes = np.ascontiguousarray(arrays["nodes"])
+        wide, entry, roots = wide_of(nodes, 1, with_roots=True)
+        paired, proots = wide.copy(), roots.copy()
+        assert lib.rt_debug_pair_layout(nodes.ctypes.data, len(nodes), paired.ctypes.data, proots.ctypes.data, len(paired)) == 0
+        assert sorted(proots.tolist()) == sorted(roots.tolist()) and proots[0] == 0
+        check(nodes, fold=(paired, entry, proots))
+        interior = lambda ref: ref != 0xFFFFFFFF and not (ref & 0x80000000)
+        heads = 0
+        for i in range(0, len(paired) - 1, 2):
+            kids = [int(r) for r in paired["ref"][i] if interior(int(r))]
+            if kids:
+                assert i + 1 in kids, (name, i)
+                heads += 1
+        with_kids = sum(1 for i in range(len(paired)) if any(interior(int(r)) for r in paired["ref"][i]))
+        assert heads > 0.2 * len(paired) and heads >= 0.5 * with_kids, (heads, with_kids, len(paired))    # (most records of a 4-wide tree hold leaves only: nothing to pair them with)
+        # the walk on both
+        orc = _oracle.Oracle(w, h, arrays)
+        orc.set_camera(T.default_camera(w, h)); orc.set_max_bounces(b)
+        n = w * h
+        orc.stage("reset"); orc.stage("generate_rays")
+        for bounce in range(b + 1):
+            k = int(orc.buffer("ray_counter%d" % (bounce & 1), np.uint32, 1)[0])
+            rays = orc.buffer("rays%d" % (bounce & 1), T.ray, n)[:k]
+            orc.stage("intersect", bounce)
+            want = orc.buffer("hits", T.hit, n)[:k]
+            hit = want["primitive_id"] != 0xFFFFFFFF
+            got = orc.wide_trace(paired, entry, rays, False, None)
+            assert np.array_equal(got["primitive_id"], want["primitive_id"]) and np.array_equal(got[hit].tobytes(), want[hit].tobytes())
+            for st, args in (("shade_miss", (bounce,)), ("clear_counters", (bounce,)), ("shade_hits", (bounce,))):
+                orc.stage(st, *args)
+            ks = int(orc.buffer("shadow_ray_counter", np.uint32, 1)[0])
+            srays = orc.buffer("shadow_rays", T.ray, n)[:ks]
+            orc.stage("intersect_shadow")
+            assert np.array_equal(orc.wide_trace(paired, entry, srays, True, None), orc.buffer("shadow_hits", np.uint32, n)[:ks])
+            orc.stage("accumulate")

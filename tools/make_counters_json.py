@@ -9,8 +9,10 @@ tools/issue_microbench.hip on the same counters, plus HBM traffic.  bench.py rea
          ceiling is 4 / (f * 4 / 1.72 + (1 - f) * 4 / 0.96).
   SALU   SALUBusy saturates at 0.96 per CU x 4 (one scalar issue per SIMD per 4 cycles): reported against 1.0.
   L1/TA  TA_TA_BUSY_sum / TAs / cycles: 0.99 for saturating divergent dwordx4 loads.
-  HBM    (FETCH_SIZE x 0.99 + WRITE_SIZE) KiB per launch / duration against 8 TB/s (FETCH_SIZE calibration:
-         profiles/r01_final_fetch_size_calibration.txt).
+  HBM    read bytes = 32 x TCC_EA0_RDREQ_32B + 64 x TCC_EA0_RDREQ_64B + 128 x TCC_EA0_RDREQ_128B (pass `rdreq`; round 6: checked against known byte
+         counts per access pattern, profiles/r06_fetch_size_calibration.json -- this rocprofv3's FETCH_SIZE tallies every request at 64 bytes, i.e. HALF
+         of a coalesced 16 B / lane stream or of a 128-byte record gather, and is right only for 64-byte records), + WRITE_SIZE KiB (exact for 16- and
+         12-byte-per-lane streams), per launch / duration against 8 TB/s.  Without the `rdreq` pass: FETCH_SIZE x 0.99 (rounds 1 - 5; `hbm_read_how` says which).
   The fraction f of a TRACE kernel is its DYNAMIC mix: per-loop static opcode counts weighted by how often each loop's body runs
   (tools/isa_mix.py --loops, pass counts from tools/wave_schedule_model.py); k_shade has no loops worth weighting (static mix).
   The file records the SHA-256 of the code object the counters were collected from (raytracing_amd/codeobj.py):
@@ -71,13 +73,20 @@ for key, match in KERNELS.items():
     salu_raw = mean("busy", "SQ_ACTIVE_INST_SCA", match) * 4.0 / SIMDS / (mean("busy", "GRBM_GUI_ACTIVE", match) / 8.0)
     ta = mean("ta", "TA_TA_BUSY_sum", match) / CUS / (mean("ta", "GRBM_GUI_ACTIVE", match) / 8.0)
     fetch, write = mean("fetch", "FETCH_SIZE", match), mean("write", "WRITE_SIZE", match)
-    hbm_bytes = (fetch * 0.99 + write) * 1024.0
+    sized = [mean("rdreq", "TCC_EA0_RDREQ_%s_sum" % n, match) for n in ("32B", "64B", "128B")]
+    if all(v is not None for v in sized):
+        read_bytes, read_how = 32.0 * sized[0] + 64.0 * sized[1] + 128.0 * sized[2], "32 / 64 / 128-byte read requests counted separately (pass rdreq)"
+    else:
+        read_bytes, read_how = fetch * 0.99 * 1024.0, "FETCH_SIZE x 0.99 (every request tallied at 64 bytes: a lower bound where 128-byte requests occur)"
+    hbm_bytes = read_bytes + write * 1024.0
     acc = mean("tcp", "TCP_TOTAL_CACHE_ACCESSES_sum", match)
     l2req = mean("tcp", "TCP_TCC_READ_REQ_sum", match)
     entry[key] = {
         "kernel": match + "...>", "launches_profiled": calls, "avg_launch_ms": avg_ms, "cycles_per_launch": cyc,
         "valu_busy_raw": valu_raw, "valu_fast_opcode_fraction": f2, "valu_ceiling_raw": valu_ceiling, "valu_busy": valu_raw / valu_ceiling,
         "salu_busy": salu_raw / 0.96, "l1_ta_busy": ta / 0.99,
+        "hbm_read_bytes_per_launch": read_bytes, "hbm_write_bytes_per_launch": write * 1024.0, "hbm_read_how": read_how,
+        "fetch_size_KiB_per_launch": fetch, "read_requests_per_launch": dict(zip(("32B", "64B", "128B"), sized)) if all(v is not None for v in sized) else None,
         "hbm_bytes_per_launch": hbm_bytes, "hbm_GBs": hbm_bytes / (avg_ms * 1e-3) / 1e9, "hbm_frac": hbm_bytes / (avg_ms * 1e-3) / 8e12,
         "per_launch": {"valu_instructions": mean("sq", "SQ_INSTS_VALU", match), "salu_instructions": mean("sq", "SQ_INSTS_SALU", match),
                        "vmem_instructions": mean("sq", "SQ_INSTS_VMEM", match), "lds_instructions": mean("sq", "SQ_INSTS_LDS", match),
