@@ -41,12 +41,38 @@ def hipcc():
     raise RuntimeError("hipcc not found")
 
 
-def build_hip(force=False):
-    out = os.path.join(HERE, "librt_hip.so")
-    srcs = [os.path.join(CSRC, "rt_hip.hip")] + sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h"))
-    srcs += [os.path.join(ROOT, "include", f) for f in ("rt_hip.h", "rt_types.h")]
-    if force or _newer(out, srcs):
-        _run([hipcc()] + HIP_FLAGS + INC + [srcs[0], "-o", out])
+# librt_hip.so = three translation units (round 6; rt_hip.hip alone was 3 600 lines): the C-ABI with the hot path's kernels, the tree work on the device
+# (a code object of its own: the hot path's is not rebuilt or re-hashed when the builder changes), and the host side of the tree work.
+HIP_UNITS = [
+    ("rt_hip", "rt_hip.hip", True),            # C-ABI, frames, launch logic + kernels.h (the hot path)
+    ("device_fold", "device_fold.hip", True),  # fold_kernels.h + its host driver
+    ("wide_bvh", "wide_bvh.cpp", False),       # build_wide_bvh, pair layout, the adaptation's host walks (no device code)
+]
+
+
+def _unit_sources(src):
+    """what a unit is rebuilt for: its source and every header of csrc/ + include/ (coarse, like the single-unit build was)"""
+    srcs = [os.path.join(CSRC, src)] + sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h"))
+    return srcs + [os.path.join(ROOT, "include", f) for f in ("rt_hip.h", "rt_types.h")]
+
+
+def build_hip(force=False, extra_flags=(), out=None, obj_dir=None):
+    out = out or os.path.join(HERE, "librt_hip.so")
+    obj_dir = obj_dir or os.path.join(HERE, "build")
+    os.makedirs(obj_dir, exist_ok=True)
+    compile_flags = [f for f in HIP_FLAGS if f not in ("-shared", "-ldl")] + ["-c"] + list(extra_flags)
+    objs, procs = [], []
+    for name, src, device in HIP_UNITS:
+        obj = os.path.join(obj_dir, name + ".o")
+        objs.append(obj)
+        if force or _newer(obj, _unit_sources(src)):
+            flags = compile_flags if device else [f for f in compile_flags if not f.startswith("--offload-arch") and not f.startswith("-fhip")]
+            procs.append(subprocess.Popen([hipcc()] + flags + INC + [os.path.join(CSRC, src), "-o", obj], cwd=ROOT))
+    failed = [p.args for p in procs if p.wait() != 0]
+    if failed:
+        raise subprocess.CalledProcessError(1, failed[0])
+    if force or _newer(out, objs):
+        _run([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-ldl", "-o", out])
     return out
 
 

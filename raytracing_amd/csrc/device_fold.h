@@ -1,145 +1,22 @@
-// device_fold.h -- the host side of fold_kernels.h: build_wide_bvh's SAH collapse of a binary tree (reference layout) run on the device.
-// Included by rt_hip.hip; every function leaves the HIP error state clean and reports failure by its return value (the callers fall back to
-// the host's build_wide_bvh, which is also the tests' oracle for this path).
+// device_fold.h -- the interface of device_fold.hip: build_wide_bvh's SAH collapse and the adaptation's crossing counts run on the device.
 #pragma once
-#include <hip/hip_runtime.h>
+#include <hip/hip_runtime_api.h>
+#include <hip/hip_vector_types.h>
+#include <stdint.h>
 #include <atomic>
 #include <vector>
-#include "fold_kernels.h"
+#include "rt_types.h"
+#include "wide_node.h"
 #include "own_bvh.h"
 
 namespace devfold
 {
-struct Buffers
-{
-    std::vector<void*> all;
-    ~Buffers() { for (void* p : all) if (p) (void)hipFree(p); }
-    template <class T> bool get(T*& out, size_t count)
-    {
-        void* p = nullptr;
-        if (hipMalloc(&p, count * sizeof(T) + 16) != hipSuccess) { (void)hipGetLastError(); out = nullptr; return false; }
-        all.push_back(p);
-        out = (T*)p;
-        return true;
-    }
-    void release(void* p) { for (void*& q : all) if (q == p) q = nullptr; }     // ownership goes to the caller
-};
-
-inline FoldMetric metric_of(const ownbvh::Metric* m)
-{
-    FoldMetric f;
-    memset(&f, 0, sizeof(f));
-    f.n_dirs = -1;
-    if (!m) return f;
-    f.iso = m->iso;
-    f.n_dirs = (int)std::min<size_t>(m->dirs.size(), 8);
-    for (int i = 0; i < f.n_dirs; ++i) for (int a = 0; a < 3; ++a) f.dirs[i][a] = m->dirs[(size_t)i][a];
-    return f;
-}
-
-// The fold of d_nodes[nn] (device, reference layout) on `stream`.  On success: *d_records = a device array of *n_records WideNode (the caller
-// frees it), entry_ref, and -- when asked for -- the records and the BVH2 node each one tests on the host.  false: the tree does not qualify
+// The fold of d_nodes[nn] (device, reference layout: src/bvh.cpp:223-245) on `stream`.  On success: *d_records = a device array of *n_records WideNode (hipMalloc'ed:
+// the caller frees it), entry_ref, and -- when asked for -- the records and the BVH2 node each one tests on the host.  false: the tree does not qualify
 // (exactly build_wide_bvh's conditions), the metric has more than 8 directions, a device allocation failed or `cancel` was raised.
-inline bool fold(hipStream_t stream, const rt_bvh_node* d_nodes, uint32_t nn, const rt_bvh_node& root_node, const ownbvh::Metric* metric, const double* host_weights,
+bool fold(hipStream_t stream, const rt_bvh_node* d_nodes, uint32_t nn, const rt_bvh_node& root_node, const ownbvh::Metric* metric, const double* host_weights,
     WideNode** d_records, uint32_t* n_records, uint32_t* entry_ref, std::vector<uint32_t>* roots_out, std::vector<WideNode>* records_out,
-    const std::atomic<bool>* cancel = nullptr, double* seconds = nullptr)
-{
-    const auto t0 = std::chrono::steady_clock::now();
-    *d_records = nullptr; *n_records = 0; *entry_ref = 0;
-    if (roots_out) roots_out->clear();
-    if (records_out) records_out->clear();
-    if ((root_node.num_primitives_axis >> 16) != 0u) { *entry_ref = RT_LEAF_BIT | root_node.offset; return true; }     // a leaf root: no records
-    if (metric && metric->dirs.size() > 8u) return false;
-    if (nn < 3u) return false;
-    auto cancelled = [&]() { return cancel && cancel->load(std::memory_order_relaxed); };
-    Buffers buf;
-    FoldState s;
-    memset(&s, 0, sizeof(s));
-    s.nodes = d_nodes; s.nn = nn;
-    s.metric = metric_of(metric);
-    double* d_weights = nullptr;
-    uint32_t *frontier[2] = {nullptr, nullptr}, *d_counts = nullptr, *block_sums = nullptr, *d_roots = nullptr;
-    const uint32_t scan_blocks = (nn + FOLD_SCAN_BLOCK - 1u) / FOLD_SCAN_BLOCK;
-    const uint32_t max_records = nn / 2u + 1u;
-    bool ok = buf.get(s.parent, nn) && buf.get(s.arrived, nn) && buf.get(s.T, nn) && buf.get(s.F, (size_t)nn * 3u) && buf.get(s.split, (size_t)nn * 3u) &&
-              buf.get(s.open, nn) && buf.get(s.is_root, nn) && buf.get(s.depth, nn) && buf.get(s.error, 1) && buf.get(frontier[0], max_records) &&
-              buf.get(frontier[1], max_records) && buf.get(d_counts, 4) && buf.get(block_sums, scan_blocks + 1u) && buf.get(d_roots, max_records);
-    if (ok && host_weights) ok = buf.get(d_weights, nn) && hipMemcpyAsync(d_weights, host_weights, (size_t)nn * sizeof(double), hipMemcpyHostToDevice, stream) == hipSuccess;
-    if (!ok) { (void)hipGetLastError(); return false; }
-    s.weights = d_weights;
-    const uint32_t node_blocks = (nn + 255u) / 256u;
-    ok = hipMemsetAsync(s.error, 0, sizeof(int), stream) == hipSuccess && hipMemsetAsync(s.open, 0, nn, stream) == hipSuccess &&
-         hipMemsetAsync(s.split, 0, (size_t)nn * 3u, stream) == hipSuccess;
-    if (!ok) { (void)hipGetLastError(); return false; }
-    hipLaunchKernelGGL(k_fold_prepare, dim3(node_blocks), dim3(256), 0, stream, s);
-    hipLaunchKernelGGL(k_fold_dp, dim3(node_blocks), dim3(256), 0, stream, s);
-    // top-down: the record roots, level by level (<= 33 levels: three pending slots per level must fit the kernel's stack)
-    const uint32_t zero = 0;
-    uint32_t n_front = 1;
-    ok = hipMemcpyAsync(frontier[0], &zero, sizeof(uint32_t), hipMemcpyHostToDevice, stream) == hipSuccess;
-    int err = FOLD_OK;
-    for (uint32_t level = 1; ok && n_front != 0u; ++level)
-    {
-        if (level > 33u) { err = FOLD_TOO_DEEP; break; }
-        if (cancelled()) { ok = false; break; }
-        uint32_t* cur = frontier[(level - 1u) & 1u]; uint32_t* nxt = frontier[level & 1u];
-        ok = hipMemsetAsync(d_counts, 0, sizeof(uint32_t), stream) == hipSuccess;
-        if (!ok) break;
-        hipLaunchKernelGGL(k_fold_roots, dim3((n_front + 255u) / 256u), dim3(256), 0, stream, s, (const uint32_t*)cur, n_front, nxt, d_counts, level);
-        uint32_t got[2] = {0, 0};
-        ok = hipMemcpyAsync(&got[0], d_counts, sizeof(uint32_t), hipMemcpyDeviceToHost, stream) == hipSuccess &&
-             hipMemcpyAsync(&err, s.error, sizeof(int), hipMemcpyDeviceToHost, stream) == hipSuccess && hipStreamSynchronize(stream) == hipSuccess;
-        if (!ok || err != FOLD_OK) break;
-        if (got[0] > max_records) { err = FOLD_NOT_A_TREE; break; }
-        n_front = got[0];
-    }
-    if (!ok || err != FOLD_OK) { (void)hipGetLastError(); return false; }
-    // record index = rank among the record roots in node order
-    uint32_t total = 0;
-    hipLaunchKernelGGL(k_fold_scan_sums, dim3(scan_blocks), dim3(256), 0, stream, (const uint32_t*)s.is_root, nn, block_sums);
-    hipLaunchKernelGGL(k_fold_scan_blocks, dim3(1), dim3(1024), 0, stream, block_sums, scan_blocks, d_counts + 1);
-    hipLaunchKernelGGL(k_fold_scan_apply, dim3(scan_blocks), dim3(256), 0, stream, s.is_root, nn, (const uint32_t*)block_sums, d_roots);
-    ok = hipMemcpyAsync(&total, d_counts + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, stream) == hipSuccess && hipStreamSynchronize(stream) == hipSuccess;
-    if (!ok || total == 0u || total > max_records || total >= (1u << 26)) { (void)hipGetLastError(); return false; }      // 32-bit byte offsets in the kernel
-    WideNode* recs = nullptr;
-    if (!buf.get(recs, total)) return false;
-    hipLaunchKernelGGL(k_fold_emit, dim3((total + 63u) / 64u), dim3(64), 0, stream, s, (const uint32_t*)d_roots, total, recs);
-    ok = hipMemcpyAsync(&err, s.error, sizeof(int), hipMemcpyDeviceToHost, stream) == hipSuccess;
-    if (ok && roots_out) { roots_out->resize(total); ok = hipMemcpyAsync(roots_out->data(), d_roots, (size_t)total * sizeof(uint32_t), hipMemcpyDeviceToHost, stream) == hipSuccess; }
-    if (ok && records_out) { records_out->resize(total); ok = hipMemcpyAsync(records_out->data(), recs, (size_t)total * sizeof(WideNode), hipMemcpyDeviceToHost, stream) == hipSuccess; }
-    ok = ok && hipStreamSynchronize(stream) == hipSuccess;
-    if (!ok || err != FOLD_OK || cancelled())
-    {
-        (void)hipGetLastError();
-        if (roots_out) roots_out->clear();
-        if (records_out) records_out->clear();
-        return false;
-    }
-    buf.release(recs);
-    *d_records = recs; *n_records = total; *entry_ref = 0;
-    if (seconds) *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    return true;
-}
-
-// count_box_passes on the device: counts[n] = probe rays whose slab test of node n passes (FoldAdapt).  The tree is uploaded here (the adaptation's
-// trees live on the host: the shadow rays' one changes with every rotation).
-inline bool count_box_passes(hipStream_t stream, const rt_bvh_node* d_nodes, uint32_t nn, const float4* o, const float4* d, size_t n_rays, std::vector<uint32_t>& counts, uint64_t* truncated)
-{
-    counts.assign(nn, 0u);
-    if (n_rays == 0 || n_rays > 0x7FFFFFFFull) return n_rays == 0;
-    Buffers buf;
-    float4 *d_o = nullptr, *d_d = nullptr; uint32_t *d_counts = nullptr, *d_trunc = nullptr;
-    bool ok = buf.get(d_o, n_rays) && buf.get(d_d, n_rays) && buf.get(d_counts, nn) && buf.get(d_trunc, 1);
-    ok = ok && hipMemcpyAsync(d_o, o, n_rays * sizeof(float4), hipMemcpyHostToDevice, stream) == hipSuccess &&
-         hipMemcpyAsync(d_d, d, n_rays * sizeof(float4), hipMemcpyHostToDevice, stream) == hipSuccess &&
-         hipMemsetAsync(d_counts, 0, (size_t)nn * sizeof(uint32_t), stream) == hipSuccess && hipMemsetAsync(d_trunc, 0, sizeof(uint32_t), stream) == hipSuccess;
-    if (!ok) { (void)hipGetLastError(); return false; }
-    hipLaunchKernelGGL(k_count_box_passes, dim3((uint32_t)((n_rays + 63u) / 64u)), dim3(64), 0, stream, d_nodes, nn, (const float4*)d_o, (const float4*)d_d, (uint32_t)n_rays, d_counts, d_trunc);
-    uint32_t trunc = 0;
-    ok = hipMemcpyAsync(counts.data(), d_counts, (size_t)nn * sizeof(uint32_t), hipMemcpyDeviceToHost, stream) == hipSuccess &&
-         hipMemcpyAsync(&trunc, d_trunc, sizeof(uint32_t), hipMemcpyDeviceToHost, stream) == hipSuccess && hipStreamSynchronize(stream) == hipSuccess;
-    if (!ok) { (void)hipGetLastError(); return false; }
-    if (truncated) *truncated += trunc;
-    return true;
-}
+    const std::atomic<bool>* cancel = nullptr, double* seconds = nullptr);
+// counts[n] = probe rays whose slab test of node n passes (FoldAdapt; the host form: rtw::count_box_passes); *truncated += walks that met a subtree deeper than the stack
+bool count_box_passes(hipStream_t stream, const rt_bvh_node* d_nodes, uint32_t nn, const float4* o, const float4* d, size_t n_rays, std::vector<uint32_t>& counts, uint64_t* truncated);
 } // namespace devfold

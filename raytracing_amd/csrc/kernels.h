@@ -7,4 +7,3 @@
 #include "frame_kernels.h"
 #include "aov_kernels.h"
 #include "relayout_kernels.h"
-#include "fold_kernels.h"

@@ -20,7 +20,9 @@
 #include "tree_select.h"
 #include "tree_rotate.h"
 #include <chrono>
-#include "device_fold.h"
+#include "wide_bvh.h"        // the host-side fold, the pair layout, the adaptation's host walks (wide_bvh.cpp)
+#include "device_fold.h"     // ... and the fold + crossing counts on the device (device_fold.hip)
+using namespace rtw;
 
 namespace
 {
@@ -485,972 +487,8 @@ size_t rt_buffer_size(rt_buffer* buf) { return buf ? buf->bytes : 0; }
 
 namespace
 {
-// ---- 4-wide quantized BVH (k_trace_w4) --------------------------------------
-// A connected piece of the reference BVH2 (LinearBVHNode[], bvh.cpp:223-245) -- a node and up to two more interior
-// nodes below it -- is folded into one 64-byte record: up to four "slots" = the frontier of that piece (which
-// frontier: `collapse`, below).  Slot boxes are stored as 8-bit grid coordinates relative to a per-node frame
-// (origin, power-of-two cell size per axis), rounded OUTWARD.
-//
-// Why results stay bit-identical to the reference ("wide traversal"):
-//  * the frame is chosen so that origin + q * cell is exactly representable in binary32 for every
-//    q in 0..255 (origin is a multiple of the cell, |origin| / cell < 2^23), so the kernel
-//    dequantises WITHOUT rounding and evaluates the reference's own expression
-//    fl(fl(b - o) * inv) on a box that contains the true one; that expression is monotone in b,
-//    hence "true box passes  =>  stored box passes": interior culling only ever visits MORE;
-//  * every leaf is box-tested again with its exact fp32 bounds and the ray's current t_max when it
-//    is reached (the bounds travel in the leaf's first triangle record), and leaves are reached in
-//    the reference's depth-first near/far order (the slots are brought into that order per direction octant by
-//    tabulated exchanges, see `arrange`).  Node bounds are exact unions of their children's
-//    (bvh.hpp:73, checked below), so a leaf's box passing implies that all its ancestors' boxes
-//    pass: the reference tests the triangles of a leaf iff that leaf's own box test passes at that
-//    point of the traversal -- which is exactly what the kernel evaluates.
-// Record: q0 = (origin.xyz, meta)   meta = ex | ey << 8 | ez << 16 | occupied slots << 24 (biased exponents of the cell sizes)
-//         q1 = (lo.x, lo.y, lo.z, hi.x)    one byte per slot in every dword
-//         q2 = (hi.y, hi.z, ref0, ref1)    ref = wide node index | RT_LEAF_BIT + first triangle | RT_EMPTY_REF
-//         q3 = (ref2, ref3, order, -)       order: for each of the 8 direction-sign octants o (bit a set = direction negative
-//                                          along axis a) four bits at 4 * o = the conditional exchanges of slots (0,1), (2,3),
-//                                          (0,2), (1,3), made in that order, that bring the occupied slots into the
-//                                          reference's visit order (see `arrange` in build_wide_bvh)
-// (struct WideNode: fold_kernels.h -- the device builds the same records, device_fold.h)
+#include "fold_adapt_impl.h"
 
-// Which BVH2 nodes become the four slots of a record (`collapse`):
-//  RT_WIDE_TWO_LEVELS  the grandchildren (a child that is a leaf fills one slot): round 2's rule;
-//  RT_WIDE_SAH         the frontier that minimises the expected number of wide-node visits: a record rooted at BVH2 node n
-//                      is visited when a ray passes n's slot box (probability ~ area(n)), the interior nodes between n and
-//                      its slots are never tested at all, leaves are what they are -- so the cost of a collapse is the sum of
-//                      area(root) over its records, minimised exactly by a small dynamic programme over (node, slots to
-//                      spend) (Ylitie, Karras, Laine 2017, section 4.1, for 4 slots and with the reference's leaves kept).
-//                      The frontier of a record is then any of the five binary-tree shapes with four leaves (or fewer slots).
-// The visit order of the slots stays the reference's for every shape: depth-first over the folded BVH2 nodes, the second
-// child first where the ray is negative along that node's split axis (trace_bvh.cl:181-190).
-enum { RT_WIDE_TWO_LEVELS = 0, RT_WIDE_SAH = 1 };
-
-// false: the tree does not qualify (non-finite or non-nested bounds, child order): k_trace2 is used
-bool build_wide_bvh(const rt_bvh_node* nodes, uint32_t nn, int collapse, std::vector<WideNode>& out, uint32_t& entry_ref,
-    std::vector<uint32_t>* roots = nullptr /* the BVH2 node each record folds (tests) */,
-    const ownbvh::Metric* metric = nullptr /* what "area" means for the SAH collapse (own_bvh.h); nullptr = surface area */,
-    const double* weights = nullptr /* per BVH2 node: replaces the area altogether (a MEASURED visit frequency: FoldAdapt) */,
-    const std::atomic<bool>* cancel = nullptr /* set by another thread: give up (false) at the next check -- a scene uploaded again does not wait */)
-{
-    auto cancelled = [&]() { return cancel && cancel->load(std::memory_order_relaxed); };
-    auto is_leaf = [&](uint32_t i) { return (nodes[i].num_primitives_axis >> 16) != 0; };
-    out.clear();
-    if (is_leaf(0)) { entry_ref = RT_LEAF_BIT | nodes[0].offset; return true; }
-    auto finite3 = [](const rt_float3& v) { return std::isfinite(v.x) && std::isfinite(v.y) && std::isfinite(v.z); };
-    // pass 0: bounds finite and exactly nested (child inside parent), children after their parent
-    for (uint32_t i = 0; i < nn; ++i)
-    {
-        const rt_bvh_node& n = nodes[i];
-        if (!finite3(n.bounds_min) || !finite3(n.bounds_max)) return false;
-        if (is_leaf(i)) continue;
-        if (i + 1 >= nn || n.offset >= nn || n.offset <= i + 1 || (n.num_primitives_axis & 0xFFFFu) > 2u) return false;
-        for (uint32_t c : {i + 1, n.offset})
-        {
-            const rt_bvh_node& k = nodes[c];
-            if (k.bounds_min.x < n.bounds_min.x || k.bounds_min.y < n.bounds_min.y || k.bounds_min.z < n.bounds_min.z ||
-                k.bounds_max.x > n.bounds_max.x || k.bounds_max.y > n.bounds_max.y || k.bounds_max.z > n.bounds_max.z)
-                return false;
-        }
-    }
-    // the collapse: split[n][k] = slots given to n's first child when n is folded with k slots to spend (k = 2..4, the second
-    // child gets the rest); a child with i >= 2 slots is folded too iff open[c] has bit i set, otherwise it is one slot
-    std::vector<uint8_t> split((size_t)nn * 5u, 0), open(nn, 0);
-    if (collapse == RT_WIDE_SAH)
-    {
-        // T[n] = cost of the best collapse of n's subtree with a record rooted at n; F[n][k] = the same without the root's own
-        // visit, n's subtree covered by k slots.  Children have larger indices than their parent (pass 0): one backward sweep.
-        std::vector<double> T(nn, 0.0), F((size_t)nn * 5u, 0.0);
-        auto G = [&](uint32_t c, uint32_t i) { return is_leaf(c) ? 0.0 : (i >= 2u ? std::min(T[c], F[(size_t)c * 5u + i]) : T[c]); };
-        for (uint32_t n = nn; n-- > 0;)
-        {
-            if ((n & 0xFFFFu) == 0u && cancelled()) return false;
-            if (is_leaf(n)) continue;
-            const uint32_t l = n + 1, r = nodes[n].offset;
-            for (uint32_t k = 2; k <= 4; ++k)
-            {
-                double best = 0.0; uint32_t at = 0;
-                for (uint32_t i = 1; i < k; ++i)
-                {
-                    const double c = G(l, i) + G(r, k - i);
-                    if (at == 0 || c < best) { best = c; at = i; }
-                }
-                F[(size_t)n * 5u + k] = best;
-                split[(size_t)n * 5u + k] = (uint8_t)at;
-            }
-            const rt_bvh_node& b = nodes[n];
-            const double dx = (double)b.bounds_max.x - b.bounds_min.x, dy = (double)b.bounds_max.y - b.bounds_min.y,
-                         dz = (double)b.bounds_max.z - b.bounds_min.z;
-            const float bmn[3] = {b.bounds_min.x, b.bounds_min.y, b.bounds_min.z}, bmx[3] = {b.bounds_max.x, b.bounds_max.y, b.bounds_max.z};
-            T[n] = (weights ? weights[n] : metric ? metric->of(bmn, bmx) : dx * dy + dy * dz + dz * dx) + F[(size_t)n * 5u + 4u];
-            for (uint32_t i = 2; i <= 4; ++i)
-                if (F[(size_t)n * 5u + i] < T[n]) open[n] |= (uint8_t)(1u << i);
-        }
-    }
-    else
-    {
-        for (uint32_t n = 0; n < nn; ++n)
-        {
-            if (is_leaf(n)) continue;
-            split[(size_t)n * 5u + 4u] = 2; split[(size_t)n * 5u + 3u] = 2; split[(size_t)n * 5u + 2u] = 1;
-            open[n] = 1u << 2;                                              // a child with two slots to spend shows its children
-        }
-    }
-    // One record: its slots in the BVH2's depth-first order and, per direction-sign octant, the positions in visit order.
-    struct Fold { uint32_t slot[4]; uint32_t n_slots; uint8_t visit[8][4]; };
-    struct Local
-    {
-        const rt_bvh_node* nodes; const std::vector<uint8_t>& split; const std::vector<uint8_t>& open;
-        bool leaf(uint32_t i) const { return (nodes[i].num_primitives_axis >> 16) != 0; }
-        // n folded with k slots to spend: appends n's slots to `f` and returns, per octant, their positions in visit order
-        void fold(uint32_t n, uint32_t k, Fold& f, uint8_t (&visit)[8][4], uint32_t& count) const
-        {
-            const uint32_t c[2] = {n + 1, nodes[n].offset};
-            const uint32_t give[2] = {split[(size_t)n * 5u + k], k - split[(size_t)n * 5u + k]};
-            uint8_t part[2][8][4];
-            uint32_t len[2] = {0, 0};
-            for (int i = 0; i < 2; ++i)
-            {
-                if (!leaf(c[i]) && give[i] >= 2u && ((open[c[i]] >> give[i]) & 1u)) fold(c[i], give[i], f, part[i], len[i]);
-                else
-                {
-                    for (int o = 0; o < 8; ++o) part[i][o][0] = (uint8_t)f.n_slots;
-                    f.slot[f.n_slots++] = c[i];
-                    len[i] = 1;
-                }
-            }
-            const uint32_t axis = nodes[n].num_primitives_axis & 0xFFFFu;
-            for (uint32_t o = 0; o < 8; ++o)
-            {
-                // trace_bvh.cl:181-190: the near child is the second one when the ray is negative along the split axis
-                const int first = (int)((o >> axis) & 1u);
-                uint32_t at = 0;
-                for (uint32_t j = 0; j < len[first]; ++j) visit[o][at++] = part[first][o][j];
-                for (uint32_t j = 0; j < len[first ^ 1]; ++j) visit[o][at++] = part[first ^ 1][o][j];
-            }
-            count = len[0] + len[1];
-        }
-    } local{nodes, split, open};
-    auto fold_of = [&](uint32_t n, Fold& f)
-    {
-        f.n_slots = 0;
-        for (int k = 0; k < 4; ++k) f.slot[k] = RT_EMPTY_REF;
-        uint32_t count = 0;
-        local.fold(n, 4u, f, f.visit, count);
-    };
-    // Where the slots of a record are stored.  The kernel brings them into visit order with FOUR conditional exchanges --
-    // (0,1), (2,3), (0,2), (1,3), one table bit each per direction octant: two instructions more than the three decisions
-    // round 2 tabulated for the one shape it folded -- and that network does not realise every permutation; but for each of
-    // the five shapes (and their smaller relatives) there is a placement of the slots for which it realises all the orders
-    // the shape can ask for (exhaustive search: tests/test_wide_bvh.py).  Found here by trying the 24 placements, once per
-    // distinct (slot count, eight visit orders); depth-first order is tried first, which is what the balanced shape keeps.
-    struct Arrangement { uint8_t place[4]; uint32_t order; };
-    typedef std::map<std::array<uint8_t, 33>, Arrangement> ArrangementCache;
-    auto arrange = [&](const Fold& f, ArrangementCache& arrangements) -> const Arrangement*
-    {
-        std::array<uint8_t, 33> key{};
-        key[0] = (uint8_t)f.n_slots;
-        for (int o = 0; o < 8; ++o)
-            for (uint32_t j = 0; j < f.n_slots; ++j) key[1 + 4 * o + j] = f.visit[o][j];
-        auto it = arrangements.find(key);
-        if (it != arrangements.end()) return &it->second;
-        uint8_t place[4] = {0, 1, 2, 3};                                   // place[j] = slot position of the j-th node in depth-first order
-        do
-        {
-            uint8_t node_at[4] = {255, 255, 255, 255};
-            for (uint32_t j = 0; j < f.n_slots; ++j) node_at[place[j]] = (uint8_t)j;
-            Arrangement a{};
-            bool all = true;
-            for (uint32_t o = 0; o < 8 && all; ++o)
-            {
-                bool found = false;
-                for (uint32_t bits = 0; bits < 16u && !found; ++bits)
-                {
-                    uint8_t pos[4] = {0, 1, 2, 3};
-                    static const int ex[4][2] = {{0, 1}, {2, 3}, {0, 2}, {1, 3}};
-                    for (int c = 0; c < 4; ++c)
-                        if ((bits >> c) & 1u) std::swap(pos[ex[c][0]], pos[ex[c][1]]);
-                    // the occupied slots, in the order the kernel will look at them, must be the reference's visit order
-                    uint32_t at = 0;
-                    bool same = true;
-                    for (int k = 0; k < 4 && same; ++k)
-                        if (node_at[pos[k]] != 255) same = node_at[pos[k]] == f.visit[o][at++];
-                    if (same) { a.order |= bits << (4u * o); found = true; }
-                }
-                all = found;
-            }
-            if (all)
-            {
-                memcpy(a.place, place, 4);
-                return &arrangements.emplace(key, a).first->second;
-            }
-        } while (std::next_permutation(place, place + 4));
-        return nullptr;
-    };
-    // pass 1: wide nodes in depth-first order (slot 0's subtree first), like the reference's flattening
-    std::vector<uint32_t> wide_of(nn, RT_EMPTY_REF), todo, order, depth_of;
-    todo.push_back(0);
-    depth_of.push_back(1);
-    while (!todo.empty())
-    {
-        uint32_t n = todo.back(), depth = depth_of.back();
-        todo.pop_back();
-        depth_of.pop_back();
-        if ((order.size() & 0xFFFFu) == 0u && cancelled()) return false;
-        if (depth > 33u) return false;                                     // <= 3 pending slots per level must fit RT_W4_STACK_MAX
-        // a node reached twice (several parents share a child) is not a tree: the walk below would append once per PATH
-        if (wide_of[n] != RT_EMPTY_REF || order.size() >= nn) return false;
-        wide_of[n] = (uint32_t)order.size();
-        order.push_back(n);
-        Fold f;
-        fold_of(n, f);
-        for (int k = 3; k >= 0; --k)
-            if (f.slot[k] != RT_EMPTY_REF && !is_leaf(f.slot[k])) { todo.push_back(f.slot[k]); depth_of.push_back(depth + 1u); }
-    }
-    if (order.size() >= (1u << 26)) return false;                          // 32-bit byte offsets in the kernel
-    // pass 2: records (independent of each other: host threads, each with its own cache of arrangements)
-    out.resize(order.size());
-    auto make_record = [&](size_t w, ArrangementCache& cache) -> bool
-    {
-        const uint32_t n = order[w];
-        Fold f;
-        fold_of(n, f);
-        const Arrangement* arr = arrange(f, cache);
-        if (!arr) return false;                                            // cannot happen (every shape has an arrangement: tests/test_wide_bvh.py)
-        uint32_t slot[4] = {RT_EMPTY_REF, RT_EMPTY_REF, RT_EMPTY_REF, RT_EMPTY_REF};
-        for (uint32_t j = 0; j < f.n_slots; ++j) slot[arr->place[j]] = f.slot[j];
-        WideNode& r = out[w];
-        memset(&r, 0, sizeof(r));
-        const float nmin[3] = {nodes[n].bounds_min.x, nodes[n].bounds_min.y, nodes[n].bounds_min.z};
-        const float nmax[3] = {nodes[n].bounds_max.x, nodes[n].bounds_max.y, nodes[n].bounds_max.z};
-        float origin[3];
-        int exps[3];
-        for (int a = 0; a < 3; ++a)
-        {
-            // cell = 2^e: 254 cells span the node (one spare for the floor of the origin), and the grid
-            // stays exactly representable: |origin| / cell < 2^23 leaves room for + 255 below 2^24
-            const double extent = (double)nmax[a] - (double)nmin[a];
-            const double amax = std::max(std::fabs((double)nmin[a]), std::fabs((double)nmax[a]));
-            int e = -126;
-            if (extent > 0.0) e = std::max(e, (int)std::ceil(std::log2(extent / 254.0)));
-            while (std::ldexp(254.0, e) < extent) ++e;
-            while (amax > 0.0 && amax / std::ldexp(1.0, e) >= 8388608.0 - 256.0) ++e;
-            // k_trace_w4 evaluates slab distances as q * (cell * inv) + (origin - org) * inv: bounded operands keep that
-            // finite for every ray it accepts (trace_kernels.h, loop C)
-            if (e > 20 || amax >= 268435456.0) return false;
-            const double cell = std::ldexp(1.0, e);
-            const double o = std::floor((double)nmin[a] / cell) * cell;
-            origin[a] = (float)o;
-            if ((double)origin[a] != o) return false;                     // cannot happen by construction
-            exps[a] = e;
-        }
-        r.ox = origin[0]; r.oy = origin[1]; r.oz = origin[2];
-        r.meta = (uint32_t)(exps[0] + 127) | (uint32_t)(exps[1] + 127) << 8 | (uint32_t)(exps[2] + 127) << 16 | f.n_slots << 24;
-        r.order = arr->order;
-        for (int k = 0; k < 4; ++k)
-        {
-            if (slot[k] == RT_EMPTY_REF)
-            {
-                r.ref[k] = RT_EMPTY_REF;
-                for (int a = 0; a < 3; ++a) { r.lo[a] |= 255u << (8 * k); }   // lo 255 > hi 0: never hit
-                continue;
-            }
-            const rt_bvh_node& c = nodes[slot[k]];
-            r.ref[k] = is_leaf(slot[k]) ? (RT_LEAF_BIT | c.offset) : wide_of[slot[k]];
-            const float cmin[3] = {c.bounds_min.x, c.bounds_min.y, c.bounds_min.z};
-            const float cmax[3] = {c.bounds_max.x, c.bounds_max.y, c.bounds_max.z};
-            for (int a = 0; a < 3; ++a)
-            {
-                const double cell = std::ldexp(1.0, exps[a]);
-                double lo = std::floor(((double)cmin[a] - (double)origin[a]) / cell);
-                double hi = std::ceil(((double)cmax[a] - (double)origin[a]) / cell);
-                // the difference above is rounded (a bound of 1e-17 beside an origin of -0.2 vanishes in it): settle the
-                // containment on the grid points themselves, which are exact in binary32 and binary64 alike
-                while ((double)origin[a] + lo * cell > (double)cmin[a]) lo -= 1.0;
-                while ((double)origin[a] + hi * cell < (double)cmax[a]) hi += 1.0;
-                if (lo < 0.0 || hi > 255.0 || lo > hi) return false;      // cannot happen: the child is inside the node
-                r.lo[a] |= (uint32_t)lo << (8 * k);
-                r.hi[a] |= (uint32_t)hi << (8 * k);
-            }
-        }
-        return true;
-    };
-    {
-        const size_t n_records = order.size();
-        // (a fold with measured weights is an adaptation's, made beside the render loop: 16 threads, adapt_threads below)
-        const unsigned n_threads = (unsigned)std::min<size_t>(std::max(1u, std::min(std::thread::hardware_concurrency(), weights ? 16u : 32u)), n_records / 4096 + 1);
-        std::atomic<bool> ok{true};
-        auto run = [&](size_t w0, size_t w1)
-        {
-            ArrangementCache cache;
-            for (size_t w = w0; w < w1 && ok.load(std::memory_order_relaxed); ++w)
-                if (((w & 0x3FFFu) == 0u && cancelled()) || !make_record(w, cache)) ok.store(false);
-        };
-        std::vector<std::thread> pool;
-        for (unsigned t = 1; t < n_threads; ++t) pool.emplace_back(run, n_records * t / n_threads, n_records * (t + 1) / n_threads);
-        run(0, n_records / n_threads);
-        for (auto& th : pool) th.join();
-        if (!ok) return false;
-    }
-    entry_ref = 0;
-    if (roots) *roots = order;
-    return true;
-}
-
-// ---- RT_CTX_OPT_WIDE_LAYOUT = 1: the records in PAIRS (round 6) -------------------------------------------------------------------------
-// The L2 of gfx950 fetches 128-byte lines (every read request of the traversal kernels at the fabric is a 128-byte one: TCC_EA0_RDREQ_128B,
-// profiles/r06_fetch_size_calibration.json), so a 64-byte record that misses brings its line-mate along whether anybody wants it or not.  In the fold's
-// own order -- depth first -- the line-mate of a record at an even index is its first slot's record and that of one at an odd index is whatever came
-// before it.  Here the line-mate is CHOSEN: every record that has interior slots is stored at an even index with the child it hands most rays on to right
-// behind it (by the weight the fold was made for: the measured crossings of an adaptation, else the area of the child's box), so a visit of that child
-// never misses after the visit of its parent that must precede it.  A pure permutation of the records (refs are indices): no result depends on it.
-// weight(record) -> the visit weight of the record's root box.
-template <class W>
-void pair_layout(std::vector<WideNode>& wide, std::vector<uint32_t>* roots, W&& weight)
-{
-    const uint32_t n = (uint32_t)wide.size();
-    if (n < 3u) return;
-    auto interior = [](uint32_t ref) { return ref != RT_EMPTY_REF && !(ref & RT_LEAF_BIT); };
-    std::vector<uint32_t> order, singles, todo;
-    std::vector<uint8_t> placed(n, 0);
-    order.reserve(n);
-    todo.push_back(0u);
-    while (!todo.empty())
-    {
-        const uint32_t r = todo.back();
-        todo.pop_back();
-        if (r >= n || placed[r]) continue;
-        placed[r] = 1;
-        uint32_t best = RT_EMPTY_REF;
-        double best_w = -1.0;
-        for (uint32_t ref : wide[r].ref)
-            if (interior(ref) && ref < n && !placed[ref]) { const double w = weight(ref); if (best == RT_EMPTY_REF || w > best_w) { best = ref; best_w = w; } }
-        if (best == RT_EMPTY_REF) { singles.push_back(r); continue; }
-        placed[best] = 1;
-        order.push_back(r); order.push_back(best);
-        // what hangs below the two, depth first (the head's other children before the tail's: they are the nearer relatives)
-        for (int k = 3; k >= 0; --k) { const uint32_t ref = wide[best].ref[k]; if (interior(ref) && ref < n && !placed[ref]) todo.push_back(ref); }
-        for (int k = 3; k >= 0; --k) { const uint32_t ref = wide[r].ref[k]; if (interior(ref) && ref < n && !placed[ref]) todo.push_back(ref); }
-    }
-    order.insert(order.end(), singles.begin(), singles.end());
-    if (order.size() != n || order[0] != 0u) return;                       // (not a tree over all records: leave it as it is)
-    std::vector<uint32_t> at(n);
-    for (uint32_t i = 0; i < n; ++i) at[order[i]] = i;
-    std::vector<WideNode> out(n);
-    for (uint32_t i = 0; i < n; ++i)
-    {
-        WideNode r = wide[order[i]];
-        for (uint32_t& ref : r.ref) if (interior(ref) && ref < n) ref = at[ref];
-        out[i] = r;
-    }
-    wide.swap(out);
-    if (roots && roots->size() == n)
-    {
-        std::vector<uint32_t> rn(n);
-        for (uint32_t i = 0; i < n; ++i) rn[i] = (*roots)[order[i]];
-        roots->swap(rn);
-    }
-}
-
-// the static folds' weight: the area (the own trees': their metric) of the box a record tests
-template <class M>
-void pair_layout_by_area(std::vector<WideNode>& wide, std::vector<uint32_t>& roots, const rt_bvh_node* nodes, uint32_t nn, const M* metric)
-{
-    if (roots.size() != wide.size()) return;
-    const std::vector<uint32_t> r0 = roots;                                // (weights are asked for by OLD record index while `roots` is being permuted at the end only)
-    pair_layout(wide, &roots, [&](uint32_t rec) -> double
-    {
-        const uint32_t node = r0[rec];
-        if (node >= nn) return 0.0;
-        const rt_bvh_node& b = nodes[node];
-        const float mn[3] = {b.bounds_min.x, b.bounds_min.y, b.bounds_min.z}, mx[3] = {b.bounds_max.x, b.bounds_max.y, b.bounds_max.z};
-        if (metric) return metric->of(mn, mx);
-        const double dx = (double)mx[0] - mn[0], dy = (double)mx[1] - mn[1], dz = (double)mx[2] - mn[2];
-        return dx * dy + dy * dz + dz * dx;
-    });
-}
-
-// The ray population a shadow tree serves (own_bvh.h): shadow rays go to the analytic lights only (hit_surface.cl:114-146,
-// light.h:30-65), one uniformly chosen per hit -- towards a directional light they all share its direction, towards a point
-// light they come from everywhere.
-ownbvh::Metric shadow_metric(const rt_light* lights, uint32_t n, double iso_share)
-{
-    ownbvh::Metric m;
-    m.iso = 0.0;
-    for (uint32_t i = 0; i < n; ++i)
-    {
-        const rt_light& l = lights[i];
-        const double len = std::sqrt((double)l.origin.x * l.origin.x + (double)l.origin.y * l.origin.y + (double)l.origin.z * l.origin.z);
-        if (l.type == RT_LIGHT_TYPE_POINT || !(len > 0.0) || !std::isfinite(len)) { m.iso += 1.0; continue; }
-        m.dirs.push_back({std::fabs(l.origin.x / len), std::fabs(l.origin.y / len), std::fabs(l.origin.z / len)});
-    }
-    if (m.dirs.empty()) m.iso = 1.0;
-    else m.iso += iso_share * (double)m.dirs.size();   // some isotropy keeps boxes that are thin along d from growing without bound
-    return m;
-}
-
-// Which tree a ray population walks: the candidate of own_bvh.h against the reference's own topology (`ref_wide`), both
-// walked by proxy rays of that population (tree_select.h).  mode 1: own only if it saves more than 10 % of the steps (the proxy rays are not the
-// camera's: a tree that promised 6 % fewer steps on the ShaderBalls-class scene made its shadow trace 10 % slower, profiles/r04_call01_*);
-// mode 2: own whatever it costs (A/B runs); mode 3 (shadow): own with the plain surface-area metric, unconditionally (A/B).
-struct OwnTree
-{
-    std::vector<WideNode> wide; uint32_t entry = 0; bool ok = false; const char* name = ""; std::thread worker;
-    std::vector<rt_bvh_node> bvh2; std::vector<uint32_t> roots;    // the binary tree the records fold, and the node each record tests (FoldAdapt)
-    WideNode* d_wide = nullptr;                                    // the records on the device already (RT_CTX_OPT_DEVICE_FOLD); whoever adopts them owns them
-    int device = -1;                                               // >= 0: fold on that device (a stream of the worker's own)
-    bool pairs = false;                                            // RT_CTX_OPT_WIDE_LAYOUT
-    double fold_seconds = 0.0, build_seconds = 0.0;
-    // the collapse of the finished binary tree: on the device (the tree goes up, the records stay there and come back for the choice by proxy rays), or by build_wide_bvh
-    bool fold_it(const ownbvh::Metric& m)
-    {
-        const auto t0 = std::chrono::steady_clock::now();
-        bool done = false;
-        if (device >= 0 && hipSetDevice(device) == hipSuccess)
-        {
-            hipStream_t st = nullptr;
-            void* d_nodes = nullptr;
-            if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess)
-            {
-                if (hipMalloc(&d_nodes, bvh2.size() * sizeof(rt_bvh_node)) == hipSuccess &&
-                    hipMemcpyAsync(d_nodes, bvh2.data(), bvh2.size() * sizeof(rt_bvh_node), hipMemcpyHostToDevice, st) == hipSuccess)
-                {
-                    uint32_t n = 0;
-                    done = devfold::fold(st, (const rt_bvh_node*)d_nodes, (uint32_t)bvh2.size(), bvh2[0], &m, nullptr, &d_wide, &n, &entry, &roots, &wide) && n != 0u;
-                }
-                (void)hipStreamSynchronize(st);
-                if (d_nodes) (void)hipFree(d_nodes);
-                (void)hipStreamDestroy(st);
-            }
-            (void)hipGetLastError();
-            if (!done && d_wide) { (void)hipFree(d_wide); d_wide = nullptr; }
-        }
-        if (!done) done = build_wide_bvh(bvh2.data(), (uint32_t)bvh2.size(), RT_WIDE_SAH, wide, entry, &roots, &m) && !wide.empty();
-        if (done && pairs)
-        {
-            pair_layout_by_area(wide, roots, bvh2.data(), (uint32_t)bvh2.size(), &m);
-            if (d_wide && hipMemcpy(d_wide, wide.data(), wide.size() * sizeof(WideNode), hipMemcpyHostToDevice) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(d_wide); d_wide = nullptr; }
-        }
-        fold_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-        return done;
-    }
-    void start(const rt_scene_desc* sd, bool shadow, uint32_t mode)
-    {
-        ownbvh::Metric m;
-        name = "own: surface area";
-        if (shadow && mode != 3u)
-        {
-            ownbvh::Metric d = shadow_metric(sd->lights, sd->num_lights, 0.5);
-            if (!d.dirs.empty()) { m = d; name = "own: projected area along the directional lights + 50 % isotropic"; }
-        }
-        worker = std::thread([this, sd, m]()
-        {
-            const auto t0 = std::chrono::steady_clock::now();
-            ok = ownbvh::build(sd->nodes, sd->num_nodes, m, bvh2);
-            build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-            ok = ok && fold_it(m);
-        });
-    }
-    void join() { if (worker.joinable()) worker.join(); }
-    ~OwnTree() { join(); if (d_wide) (void)hipFree(d_wide); }
-};
-
-// true: walk the own tree; false: keep the reference topology
-bool choose_tree(const rt_scene_desc* sd, const std::vector<WideNode>& ref_wide, uint32_t ref_entry, bool shadow, uint32_t mode,
-    OwnTree& own, std::string& report)
-{
-    own.join();
-    char line[320];
-    if (!own.ok) { report += shadow ? "shadow tree: the own tree does not qualify -> reference topology\n" : "closest-hit tree: the own tree does not qualify -> reference topology\n"; return false; }
-    if (mode >= 2u)
-    {
-        snprintf(line, sizeof(line), "%s tree: %s, forced (not measured)\n", shadow ? "shadow" : "closest-hit", own.name);
-        report += line;
-        return true;
-    }
-    const uint32_t nt = sd->num_triangles, nn = sd->num_nodes;
-    std::vector<uint32_t> leaf_of_first(nt, 0u);
-    for (uint32_t i = 0; i < nn; ++i)
-        if ((sd->nodes[i].num_primitives_axis >> 16) != 0 && sd->nodes[i].offset < nt) leaf_of_first[sd->nodes[i].offset] = i;
-    const std::vector<treesel::ProxyRay> rays = treesel::proxy_rays(sd->triangles, nt, sd->lights, sd->num_lights, 8192u, shadow);
-    if (rays.empty()) { report += shadow ? "shadow tree: no lights, nothing to measure -> reference topology\n" : "closest-hit tree: nothing to measure -> reference topology\n"; return false; }
-    const double c_ref = treesel::walk_cost((const treesel::Record*)ref_wide.data(), (uint32_t)ref_wide.size(), ref_entry, sd->nodes, leaf_of_first.data(), sd->triangles, rays, shadow);
-    const double c_own = treesel::walk_cost((const treesel::Record*)own.wide.data(), (uint32_t)own.wide.size(), own.entry, sd->nodes, leaf_of_first.data(), sd->triangles, rays, shadow);
-    const bool pick = c_own < 0.90 * c_ref;
-    snprintf(line, sizeof(line), "%s tree: reference topology %.2f steps per proxy ray, %s %.2f -> %s\n", shadow ? "shadow" : "closest-hit", c_ref, own.name, c_own,
-        pick ? "own" : "reference topology");
-    report += line;
-    return pick;
-}
-
-// ---- Fold adaptation (RT_CTX_OPT_ADAPTIVE_FOLD) ---------------------------------------------------------------------------------
-// build_wide_bvh's dynamic programme is optimal for whatever visit probability it is given, and the surface area is only the
-// probability of a ray population nobody traces: uniformly distributed lines.  The rays of a frame are not that (they start at
-// the camera or on surfaces and stop at the first hit), and what they do can be measured: the first rt_integrate of a scene
-// traces a small probe frame, the host counts how often its rays pass each box of the binary tree (closest-hit rays clipped at
-// their hit), and the trees are folded again for those frequencies -- tools/fold_weight_study.py: - 8 % closest-hit and - 10 %
-// shadow record visits on the benchmark scene, out of sample, and 14 000 probe rays are as good as 220 000.
-// Exact by construction: every fold of the same binary tree tests the same leaves in the same order (build_wide_bvh).
-struct FoldAdapt
-{
-    enum { ARMED = 1, COMPUTING = 2, IDLE = 3, OFF = 4, PROBING = 5 };   // IDLE: adapted to `camera`; a frame whose camera has moved away arms it again;
-                                                                         // PROBING: the probe frame's launches and copies are on the stream
-    int state = ARMED;
-    std::atomic<uint32_t> mode{1};                     // ctx->adaptive_fold at upload (atomic: RT_CTX_OPT_ADAPT_WAIT changes bit 1 on the render thread while the worker reads bits 3 / 4)
-    uint32_t adaptations = 0;                          // folds adopted so far
-    rt_camera camera;                                  // the probe's camera
-    double scene_diagonal = 0.0;
-    std::vector<rt_bvh_node> bvh2, bvh2_sh;            // the reference's tree; the shadow rays' own binary tree (empty: they walk the reference's)
-    std::vector<uint32_t> roots, roots_sh;             // the binary-tree node each record of the CURRENT folds tests
-    std::vector<uint32_t> roots_new, roots_sh_new;     // ... of the adapted folds
-    std::vector<float> tri9;                           // mode bit 4: the triangles' corner positions (9 floats each), for the host's occluder search
-    uint32_t reordered = 0;                            // ... shadow records whose slots changed places (0: placed as build_wide_bvh places them)
-    std::vector<rt_bvh_node> bvh2_sh_new;              // mode bit 3: the shadow rays' binary tree after tree_rotate.h's rotations (when that is what was folded)
-    uint32_t rotations = 0;                            // ... how many (0: the fold is of the tree as it was)
-    std::vector<float4> o, d, sh_o, sh_d;              // the probe's rays (o.w = t_max: the hit distance where there was one)
-    std::vector<WideNode> wide, wide_sh;               // the adapted folds
-    uint32_t entry = 0, entry_sh = 0;
-    bool ok = false, ok_sh = false;                    // ... exist and are cheaper for the probe rays
-    double cost[2][2] = {{0.0, 0.0}, {0.0, 0.0}};      // [closest, shadow][current, adapted]: record visits per probe ray (an upper bound: box passes)
-    double seconds = 0.0;
-    std::atomic<bool> finished{false}, cancel{false};
-    std::thread worker;
-    // The probe (round 5: nothing on the render thread waits for it): a frame of its own, kept for the scene's life; its queues come back through
-    // pinned memory with asynchronous copies behind each stage, `probe_done` marks the last one; the worker unpacks them (probe_unpack).
-    rt_frame* probe = nullptr;
-    uint32_t probe_paths = 0, probe_samples = 0, probe_bounces = 0;      // capacity of a queue, samples traced, bounces + 1
-    char* staging = nullptr; size_t staging_bytes = 0;                   // pinned; layout: probe_block / probe_counters below
-    hipEvent_t probe_done = nullptr;
-    // The device side of an adoption is the WORKER's too: it uploads the adapted records on a stream of its own, and frees the ones an
-    // earlier adoption replaced after a device synchronisation of ITS thread (every launch that could still read them was enqueued before
-    // that adoption).  The render thread only exchanges pointers: no hipDeviceSynchronize, no hipMalloc / hipFree between two frames.
-    int device = -1;                                                     // -1: host only (rt_debug_fold_abandon)
-    bool device_fold = false;                                            // RT_CTX_OPT_DEVICE_FOLD: crossing counts and re-folds on `device`
-    bool pairs = false;                                                  // RT_CTX_OPT_WIDE_LAYOUT
-    void *new_cl = nullptr, *new_sh = nullptr;
-    bool upload_failed = false;
-    std::vector<void*> retired;
-    std::chrono::steady_clock::time_point last_armed{};                  // re-arming is rate-limited (RT_CTX_OPT_ADAPT_MIN_INTERVAL_MS)
-    std::atomic<uint32_t> min_interval_ms{500};
-    size_t probe_block(uint32_t sample, uint32_t bounce, uint32_t which /* 0 o, 1 d, 2 hits, 3 shadow o, 4 shadow d */) const
-    {
-        return ((((size_t)sample * probe_bounces + bounce) * 5u + which) * probe_paths) * sizeof(float4);
-    }
-    size_t probe_counters(uint32_t sample) const { return (size_t)probe_samples * probe_bounces * 5u * probe_paths * sizeof(float4) + (size_t)sample * sizeof(DCounters); }
-    ~FoldAdapt();
-};
-void drop_fold_adapt(FoldAdapt* a) { delete a; }
-void fold_adapt_set_interval(FoldAdapt* a, uint32_t ms) { a->min_interval_ms = ms; }
-void fold_adapt_set_wait(FoldAdapt* a, bool wait) { if (wait) a->mode.fetch_or(2u); else a->mode.fetch_and(~2u); }
-
-// Host threads one side of an adaptation may use beside the render loop: the closest-hit and the shadow side run together, one process per
-// GPU runs one context each, so 16 + 16 threads x 8 ranks stays within a 256-core host (2 x 32 per context oversubscribed it).
-static unsigned adapt_threads(size_t work_items, size_t per_thread)
-{
-    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-    return (unsigned)std::min<size_t>(std::min(hw, 16u), work_items / per_thread + 1);
-}
-static std::atomic<uint64_t> g_truncated_walks{0};   // host walks (weights only) that met a binary tree deeper than their 126-entry stack
-
-// counts[n] = rays whose slab test of binary-tree node n passes within [0, o.w] (plain binary32 arithmetic: a weight, not a result)
-void count_box_passes(const rt_bvh_node* nodes, uint32_t nn, const float4* o, const float4* d, size_t n_rays, std::vector<uint32_t>& counts,
-    const std::atomic<bool>& cancel)
-{
-    counts.assign(nn, 0u);
-    auto run = [&](size_t r0, size_t r1)
-    {
-        uint32_t stack[128];
-        for (size_t r = r0; r < r1 && !cancel.load(std::memory_order_relaxed); ++r)
-        {
-            const float org[3] = {o[r].x, o[r].y, o[r].z}, inv[3] = {1.0f / d[r].x, 1.0f / d[r].y, 1.0f / d[r].z};
-            const float t_max = o[r].w;
-            int sp = 0;
-            stack[sp++] = 0;
-            while (sp > 0)
-            {
-                const uint32_t n = stack[--sp];
-                const rt_bvh_node& b = nodes[n];
-                const float mn[3] = {b.bounds_min.x, b.bounds_min.y, b.bounds_min.z}, mx[3] = {b.bounds_max.x, b.bounds_max.y, b.bounds_max.z};
-                float t0 = 0.0f, t1 = t_max;
-                for (int a = 0; a < 3; ++a)
-                {
-                    const float ta = (mn[a] - org[a]) * inv[a], tb = (mx[a] - org[a]) * inv[a];
-                    t0 = std::fmax(t0, std::fmin(ta, tb));         // fmin / fmax drop a NaN (0 * inf): conservative, like the kernels
-                    t1 = std::fmin(t1, std::fmax(ta, tb));
-                }
-                if (!(t0 <= t1)) continue;
-                __atomic_fetch_add(&counts[n], 1u, __ATOMIC_RELAXED);
-                if ((b.num_primitives_axis >> 16) != 0) continue;
-                if (sp > 125) { g_truncated_walks.fetch_add(1, std::memory_order_relaxed); continue; }
-                if (b.offset >= nn || n + 1u >= nn) continue;
-                stack[sp++] = b.offset;
-                stack[sp++] = n + 1u;
-            }
-        }
-    };
-    const unsigned n_threads = adapt_threads(n_rays, 2048);
-    std::vector<std::thread> pool;
-    for (unsigned t = 1; t < n_threads; ++t) pool.emplace_back(run, n_rays * t / n_threads, n_rays * (t + 1) / n_threads);
-    run(0, n_rays / n_threads);
-    for (auto& th : pool) th.join();
-}
-
-// One tree folded again for the rays that were counted on it.  cost[] = what the current and the new fold cost those rays.
-// fold_device >= 0 (RT_CTX_OPT_DEVICE_FOLD): the crossing counts and the collapse run on that device, on a stream of the calling (worker) thread's own -- the tree
-// goes up once per call (the shadow rays' tree changes with every rotation), the records come back for the host's bookkeeping; anything that fails there
-// is done here on host threads instead.
-bool refold_for_rays(const std::vector<rt_bvh_node>& tree, const std::vector<float4>& o, const std::vector<float4>& d, const std::vector<uint32_t>& roots_now,
-    std::vector<WideNode>& out, uint32_t& entry, double (&cost)[2], const std::atomic<bool>& cancel, std::vector<uint32_t>* roots_out = nullptr, int fold_device = -1,
-    bool pairs = false /* RT_CTX_OPT_WIDE_LAYOUT: the new records in (parent, likeliest child) pairs, by the measured weights */)
-{
-    if (tree.empty() || o.empty() || o.size() != d.size() || roots_now.empty()) return false;
-    const uint32_t nn = (uint32_t)tree.size();
-    std::vector<uint32_t> counts;
-    struct DeviceTree
-    {
-        hipStream_t st = nullptr; void* nodes = nullptr;
-        ~DeviceTree() { if (st) (void)hipStreamSynchronize(st); if (nodes) (void)hipFree(nodes); if (st) (void)hipStreamDestroy(st); (void)hipGetLastError(); }
-    } dev;
-    bool on_device = false;
-    if (fold_device >= 0 && hipSetDevice(fold_device) == hipSuccess && hipStreamCreateWithFlags(&dev.st, hipStreamNonBlocking) == hipSuccess)
-    {
-        on_device = hipMalloc(&dev.nodes, (size_t)nn * sizeof(rt_bvh_node)) == hipSuccess &&
-                    hipMemcpyAsync(dev.nodes, tree.data(), (size_t)nn * sizeof(rt_bvh_node), hipMemcpyHostToDevice, dev.st) == hipSuccess;
-        if (on_device)
-        {
-            uint64_t truncated = 0;
-            on_device = devfold::count_box_passes(dev.st, (const rt_bvh_node*)dev.nodes, nn, o.data(), d.data(), o.size(), counts, &truncated);
-            if (truncated) g_truncated_walks.fetch_add(truncated, std::memory_order_relaxed);
-        }
-        if (!on_device) (void)hipGetLastError();
-    }
-    if (!on_device) count_box_passes(tree.data(), nn, o.data(), d.data(), o.size(), counts, cancel);
-    if (cancel.load()) return false;
-    // the measured passes, plus a twentieth of their sum spread by surface area: boxes no probe ray met still fold sensibly
-    std::vector<double> w(nn);
-    double total = 0.0, area_sum = 0.0;
-    for (uint32_t n = 0; n < nn; ++n)
-    {
-        const rt_bvh_node& b = tree[n];
-        const double dx = (double)b.bounds_max.x - b.bounds_min.x, dy = (double)b.bounds_max.y - b.bounds_min.y, dz = (double)b.bounds_max.z - b.bounds_min.z;
-        w[n] = dx * dy + dy * dz + dz * dx;
-        area_sum += w[n];
-        total += (double)counts[n];
-    }
-    if (!(total > 0.0) || !(area_sum > 0.0) || !std::isfinite(area_sum)) return false;
-    const double prior = 0.05 * total / area_sum;
-    for (uint32_t n = 0; n < nn; ++n) w[n] = (double)counts[n] + prior * w[n];
-    // what the fold on the device costs these rays: known before, and whether or not, a new fold can be built (a failed build
-    // used to leave it 0, and a rotated candidate was then adopted without ever having been compared with it)
-    cost[0] = cost[1] = 0.0;
-    for (uint32_t r : roots_now) if (r < nn) cost[0] += w[r];
-    cost[0] /= (double)o.size();
-    std::vector<uint32_t> roots_new;
-    bool folded = false;
-    if (on_device)
-    {
-        WideNode* d_recs = nullptr;
-        uint32_t n_recs = 0;
-        folded = devfold::fold(dev.st, (const rt_bvh_node*)dev.nodes, nn, tree[0], nullptr, w.data(), &d_recs, &n_recs, &entry, &roots_new, &out, &cancel) && !out.empty();
-        if (d_recs) (void)hipFree(d_recs);                                 // (the records travel with fold_upload, with the shadow side's slot order applied)
-        (void)hipGetLastError();
-        if (cancel.load()) return false;
-    }
-    if (!folded && (!build_wide_bvh(tree.data(), nn, RT_WIDE_SAH, out, entry, &roots_new, nullptr, w.data(), &cancel) || out.empty())) return false;
-    for (uint32_t r : roots_new) cost[1] += w[r];
-    cost[1] /= (double)o.size();
-    if (pairs && roots_new.size() == out.size())
-    {
-        const std::vector<uint32_t> r0 = roots_new;
-        pair_layout(out, &roots_new, [&](uint32_t rec) { return r0[rec] < nn ? w[r0[rec]] : 0.0; });
-    }
-    if (roots_out) roots_out->swap(roots_new);
-    return cost[1] < cost[0];
-}
-
-// Mode bit 4: the ORDER in which a shadow ray looks at the slots of a record is free -- its verdict is an OR over the leaves it reaches -- and
-// k_trace_w4<shadow> takes them as they are stored (the exchange network is the closest-hit rays': trace_kernels.h, w4_test_slots).  An occluded
-// ray stops at its first hit, so each record's slots are stored likeliest occluder first: by how many probe shadow rays had their NEAREST occluder
-// in the slot's subtree.  (tools/fold_weight_study.py --order: - 12 % steps per shadow ray on the headline scene with a quarter of them
-// occluded, - 25 % for the occluded ones.)  The nearest occluder of a probe ray is found here, on the host: a plain closest-hit walk of the
-// reference's binary tree with Moeller-Trumbore in binary32 -- a statistic, not a result.
-void nearest_occluders(const std::vector<rt_bvh_node>& tree, const std::vector<float>& tri9, const std::vector<float4>& o, const std::vector<float4>& d,
-    std::vector<uint32_t>& prim, const std::atomic<bool>& cancel)
-{
-    const size_t n_rays = o.size();
-    const uint32_t nn = (uint32_t)tree.size(), nt = (uint32_t)(tri9.size() / 9);
-    prim.assign(n_rays, RT_INVALID_ID);
-    auto run = [&](size_t r0, size_t r1)
-    {
-        uint32_t stack[128];
-        for (size_t r = r0; r < r1 && !cancel.load(std::memory_order_relaxed); ++r)
-        {
-            const float org[3] = {o[r].x, o[r].y, o[r].z}, dir[3] = {d[r].x, d[r].y, d[r].z}, inv[3] = {1.0f / d[r].x, 1.0f / d[r].y, 1.0f / d[r].z};
-            float t_max = o[r].w;
-            int sp = 0;
-            stack[sp++] = 0;
-            while (sp > 0)
-            {
-                const uint32_t n = stack[--sp];
-                const rt_bvh_node& b = tree[n];
-                const float mn[3] = {b.bounds_min.x, b.bounds_min.y, b.bounds_min.z}, mx[3] = {b.bounds_max.x, b.bounds_max.y, b.bounds_max.z};
-                float t0 = 0.0f, t1 = t_max;
-                for (int a = 0; a < 3; ++a)
-                {
-                    const float ta = (mn[a] - org[a]) * inv[a], tb = (mx[a] - org[a]) * inv[a];
-                    t0 = std::fmax(t0, std::fmin(ta, tb));
-                    t1 = std::fmin(t1, std::fmax(ta, tb));
-                }
-                if (!(t0 <= t1)) continue;
-                const uint32_t count = b.num_primitives_axis >> 16;
-                if (count != 0)
-                {
-                    for (uint32_t k = 0; k < count && b.offset + k < nt; ++k)
-                    {
-                        const float* p = &tri9[(size_t)(b.offset + k) * 9];
-                        const float e1[3] = {p[3] - p[0], p[4] - p[1], p[5] - p[2]}, e2[3] = {p[6] - p[0], p[7] - p[1], p[8] - p[2]};
-                        const float pv[3] = {dir[1] * e2[2] - dir[2] * e2[1], dir[2] * e2[0] - dir[0] * e2[2], dir[0] * e2[1] - dir[1] * e2[0]};
-                        const float det = e1[0] * pv[0] + e1[1] * pv[1] + e1[2] * pv[2];
-                        if (!(std::fabs(det) > 1e-8f)) continue;
-                        const float id = 1.0f / det;
-                        const float tv[3] = {org[0] - p[0], org[1] - p[1], org[2] - p[2]};
-                        const float u = (tv[0] * pv[0] + tv[1] * pv[1] + tv[2] * pv[2]) * id;
-                        if (!(u >= 0.0f && u <= 1.0f)) continue;
-                        const float qv[3] = {tv[1] * e1[2] - tv[2] * e1[1], tv[2] * e1[0] - tv[0] * e1[2], tv[0] * e1[1] - tv[1] * e1[0]};
-                        const float v = (dir[0] * qv[0] + dir[1] * qv[1] + dir[2] * qv[2]) * id;
-                        if (!(v >= 0.0f && u + v <= 1.0f)) continue;
-                        const float t = (e2[0] * qv[0] + e2[1] * qv[1] + e2[2] * qv[2]) * id;
-                        if (t > 0.0f && t < t_max) { t_max = t; prim[r] = b.offset + k; }
-                    }
-                    continue;
-                }
-                if (sp > 125) { g_truncated_walks.fetch_add(1, std::memory_order_relaxed); continue; }
-                if (b.offset >= nn || n + 1u >= nn) continue;
-                stack[sp++] = b.offset;
-                stack[sp++] = n + 1u;
-            }
-        }
-    };
-    const unsigned n_threads = adapt_threads(n_rays, 2048);
-    std::vector<std::thread> pool;
-    for (unsigned t = 1; t < n_threads; ++t) pool.emplace_back(run, n_rays * t / n_threads, n_rays * (t + 1) / n_threads);
-    run(0, n_rays / n_threads);
-    for (auto& th : pool) th.join();
-}
-
-// The slots of every record of `wide` (a fold of `tree`, record w testing node roots[w]) stored by descending count of probe rays whose nearest
-// occluder (prim[]) lies in the slot's subtree; equal counts keep their places.  A pure permutation within each record.  Returns the records changed.
-uint32_t occluder_first(std::vector<WideNode>& wide, const std::vector<uint32_t>& roots, const std::vector<rt_bvh_node>& tree, const std::vector<uint32_t>& prim)
-{
-    const uint32_t nn = (uint32_t)tree.size();
-    if (wide.empty() || roots.size() != wide.size() || nn == 0) return 0;
-    std::vector<uint32_t> parent(nn, RT_EMPTY_REF), hit(nn, 0u);
-    uint32_t max_prim = 0;
-    for (uint32_t i = 0; i < nn; ++i)
-    {
-        const uint32_t count = tree[i].num_primitives_axis >> 16;
-        if (count != 0) { max_prim = std::max(max_prim, tree[i].offset + count); continue; }
-        if (i + 1u < nn) parent[i + 1u] = i;
-        if (tree[i].offset < nn) parent[tree[i].offset] = i;
-    }
-    std::vector<uint32_t> leaf_of(max_prim, RT_EMPTY_REF);                 // primitive -> the leaf node of `tree` that holds it
-    for (uint32_t i = 0; i < nn; ++i)
-    {
-        const uint32_t count = tree[i].num_primitives_axis >> 16;
-        for (uint32_t k = 0; k < count; ++k) leaf_of[tree[i].offset + k] = i;
-    }
-    for (uint32_t p : prim)
-    {
-        if (p >= max_prim) continue;
-        uint32_t guard = 0;
-        for (uint32_t n = leaf_of[p]; n != RT_EMPTY_REF && guard < 256u; n = parent[n], ++guard) ++hit[n];
-    }
-    uint32_t changed = 0;
-    for (size_t w = 0; w < wide.size(); ++w)
-    {
-        WideNode& r = wide[w];
-        uint32_t score[4]; int idx[4] = {0, 1, 2, 3};
-        bool any = false;
-        for (int k = 0; k < 4; ++k)
-        {
-            const uint32_t ref = r.ref[k];
-            uint32_t node = RT_EMPTY_REF;
-            if (ref == RT_EMPTY_REF) { score[k] = 0; continue; }
-            if (ref & RT_LEAF_BIT) { const uint32_t first = ref & ~RT_LEAF_BIT; node = first < max_prim ? leaf_of[first] : RT_EMPTY_REF; }
-            else if (ref < roots.size()) node = roots[ref];
-            score[k] = node < nn ? hit[node] + 1u : 1u;                    // occupied slots before empty ones
-            any = true;
-        }
-        if (!any) continue;
-        std::stable_sort(idx, idx + 4, [&](int x, int y) { return score[x] > score[y]; });
-        if (idx[0] == 0 && idx[1] == 1 && idx[2] == 2 && idx[3] == 3) continue;
-        WideNode q = r;
-        for (int a = 0; a < 3; ++a) { q.lo[a] = 0; q.hi[a] = 0; }
-        for (int k = 0; k < 4; ++k)
-        {
-            q.ref[k] = r.ref[idx[k]];
-            for (int a = 0; a < 3; ++a)
-            {
-                q.lo[a] |= ((r.lo[a] >> (8 * idx[k])) & 0xFFu) << (8 * k);
-                q.hi[a] |= ((r.hi[a] >> (8 * idx[k])) & 0xFFu) << (8 * k);
-            }
-        }
-        r = q;
-        ++changed;
-    }
-    return changed;
-}
-
-// The shadow rays' side of an adaptation.  Their verdict does not depend on the tree above the reference's leaves (own_bvh.h), so with mode bit 3
-// the binary tree itself is first rotated for the probe rays' measured crossings (tree_rotate.h) and then folded; whichever of the two folds --
-// of the tree as it was, of the rotated tree -- costs the probe rays less is the candidate.
-bool adapt_shadow_candidate(FoldAdapt* a)
-{
-    const std::vector<rt_bvh_node>& tree = a->bvh2_sh.empty() ? a->bvh2 : a->bvh2_sh;
-    const std::vector<uint32_t>& roots = a->roots_sh.empty() ? a->roots : a->roots_sh;
-    a->rotations = 0;
-    a->bvh2_sh_new.clear();
-    const int fold_device = a->device_fold ? a->device : -1;
-    bool ok = refold_for_rays(tree, a->sh_o, a->sh_d, roots, a->wide_sh, a->entry_sh, a->cost[1], a->cancel, &a->roots_sh_new, fold_device, a->pairs);
-    if (!(a->mode.load() & 8u) || a->sh_o.empty() || a->cancel.load()) return ok;
-    std::vector<rt_bvh_node> rotated;
-    double crossings[2] = {0.0, 0.0};
-    const uint32_t made = treerot::rotate(tree.data(), (uint32_t)tree.size(), (const float*)a->sh_o.data(), (const float*)a->sh_d.data(), a->sh_o.size(), 8, rotated, crossings, &a->cancel);
-    if (made == 0 || rotated.size() != tree.size() || a->cancel.load()) return ok;
-    std::vector<WideNode> wide;
-    std::vector<uint32_t> roots_rot;
-    uint32_t entry = 0;
-    double cost[2] = {0.0, 0.0};
-    const std::vector<uint32_t> top{0u};                                   // (the rotated tree has no current fold: only cost[1] is read)
-    (void)refold_for_rays(rotated, a->sh_o, a->sh_d, top, wide, entry, cost, a->cancel, &roots_rot, fold_device, a->pairs);
-    if (wide.empty() || roots_rot.empty() || a->cancel.load()) return ok;
-    // the rotated tree's boxes differ, so its measured passes are compared as they are (both are box passes per probe ray at record roots);
-    // without a known cost of the fold on the device nothing is adopted
-    if (!(a->cost[1][0] > 0.0)) return ok;
-    const double current = a->cost[1][0], plain = ok ? a->cost[1][1] : current;
-    if (!(cost[1] < plain)) return ok;
-    a->wide_sh.swap(wide); a->entry_sh = entry; a->roots_sh_new.swap(roots_rot); a->bvh2_sh_new.swap(rotated);
-    a->cost[1][1] = cost[1];
-    a->rotations = made;
-    return cost[1] < current;
-}
-
-bool adapt_shadow_side(FoldAdapt* a)
-{
-    a->reordered = 0;
-    const bool ok = adapt_shadow_candidate(a);
-    if (ok && (a->mode.load() & 16u) && !a->tri9.empty() && !a->wide_sh.empty() && !a->cancel.load())
-    {
-        // the candidate's slots, likeliest occluder first (mode bit 4)
-        std::vector<uint32_t> prim;
-        nearest_occluders(a->bvh2, a->tri9, a->sh_o, a->sh_d, prim, a->cancel);
-        const std::vector<rt_bvh_node>& tree = a->rotations != 0 ? a->bvh2_sh_new : (a->bvh2_sh.empty() ? a->bvh2 : a->bvh2_sh);
-        if (!a->cancel.load()) a->reordered = occluder_first(a->wide_sh, a->roots_sh_new, tree, prim);
-    }
-    return ok;
-}
-
-// The probe's queues, as the asynchronous copies left them in the pinned staging area, become the rays the folds are made for
-// (closest-hit rays clipped at their hit: a ray that hit something never visits what lies behind the hit).
-void probe_unpack(FoldAdapt* a)
-{
-    if (!a->staging || a->probe_paths == 0) return;                    // rays given directly (rt_debug_fold_abandon)
-    a->o.clear(); a->d.clear(); a->sh_o.clear(); a->sh_d.clear();
-    for (uint32_t sample = 0; sample < a->probe_samples; ++sample)
-    {
-        DCounters h;
-        memcpy(&h, a->staging + a->probe_counters(sample), sizeof(h));
-        for (uint32_t bounce = 0; bounce < a->probe_bounces; ++bounce)
-        {
-            const uint32_t n = h.queue[bounce], ns = h.shadow[bounce];
-            if (n > a->probe_paths || ns > a->probe_paths) { a->o.clear(); a->d.clear(); a->sh_o.clear(); a->sh_d.clear(); return; }
-            if (n == 0) break;
-            const float4* o = (const float4*)(a->staging + a->probe_block(sample, bounce, 0));
-            const float4* d = (const float4*)(a->staging + a->probe_block(sample, bounce, 1));
-            const float4* hits = (const float4*)(a->staging + a->probe_block(sample, bounce, 2));
-            const size_t at = a->o.size();
-            a->o.insert(a->o.end(), o, o + n);
-            a->d.insert(a->d.end(), d, d + n);
-            for (uint32_t i = 0; i < n; ++i)
-            {
-                uint32_t prim;
-                memcpy(&prim, &hits[i].z, 4);
-                if (prim != RT_INVALID_ID && hits[i].w > 0.0f && hits[i].w * 1.0001f < a->o[at + i].w) a->o[at + i].w = hits[i].w * 1.0001f;
-            }
-            if (ns != 0)
-            {
-                const float4* so = (const float4*)(a->staging + a->probe_block(sample, bounce, 3));
-                const float4* sd = (const float4*)(a->staging + a->probe_block(sample, bounce, 4));
-                a->sh_o.insert(a->sh_o.end(), so, so + ns);
-                a->sh_d.insert(a->sh_d.end(), sd, sd + ns);
-            }
-        }
-    }
-}
-
-// The adapted records go to the device from HERE, on a stream of the worker's own; what earlier adoptions replaced is freed here too, after
-// a device synchronisation that only this thread waits for.
-void fold_upload(FoldAdapt* a)
-{
-    if (a->device < 0 || a->cancel.load() || !(a->ok || a->ok_sh)) return;
-    a->upload_failed = true;
-    if (hipSetDevice(a->device) != hipSuccess) return;
-    if (!a->retired.empty())
-    {
-        if (hipDeviceSynchronize() != hipSuccess) { (void)hipGetLastError(); return; }
-        for (void* p : a->retired) (void)hipFree(p);
-        a->retired.clear();
-    }
-    hipStream_t st = nullptr;
-    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); return; }
-    bool ok = true;
-    if (a->ok) ok = hipMalloc(&a->new_cl, a->wide.size() * sizeof(WideNode)) == hipSuccess &&
-                    hipMemcpyAsync(a->new_cl, a->wide.data(), a->wide.size() * sizeof(WideNode), hipMemcpyHostToDevice, st) == hipSuccess;
-    if (ok && a->ok_sh) ok = hipMalloc(&a->new_sh, a->wide_sh.size() * sizeof(WideNode)) == hipSuccess &&
-                             hipMemcpyAsync(a->new_sh, a->wide_sh.data(), a->wide_sh.size() * sizeof(WideNode), hipMemcpyHostToDevice, st) == hipSuccess;
-    ok = hipStreamSynchronize(st) == hipSuccess && ok;
-    (void)hipStreamDestroy(st);
-    if (!ok)
-    {
-        (void)hipGetLastError();
-        if (a->new_cl) (void)hipFree(a->new_cl);
-        if (a->new_sh) (void)hipFree(a->new_sh);
-        a->new_cl = a->new_sh = nullptr;
-        return;
-    }
-    a->upload_failed = false;
-}
-
-void fold_adapt_worker(FoldAdapt* a)
-{
-    const auto t0 = std::chrono::steady_clock::now();
-    probe_unpack(a);
-    if (!a->o.empty())
-    {
-        std::thread shadow([a]() { a->ok_sh = adapt_shadow_side(a); });
-        a->ok = refold_for_rays(a->bvh2, a->o, a->d, a->roots, a->wide, a->entry, a->cost[0], a->cancel, &a->roots_new, a->device_fold ? a->device : -1, a->pairs);
-        shadow.join();
-        fold_upload(a);
-    }
-    a->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    a->finished.store(true);
-}
-
-FoldAdapt::~FoldAdapt()
-{
-    cancel.store(true);
-    if (worker.joinable()) worker.join();
-    if (device >= 0)
-    {
-        // (the callers -- rt_scene_upload, rt_ctx_destroy -- free the scene's own records the same way: after their stream synchronisation)
-        (void)hipSetDevice(device);
-        if (probe_done) { (void)hipEventSynchronize(probe_done); (void)hipEventDestroy(probe_done); }
-        if (probe) (void)rt_frame_destroy(probe);
-        if (staging) (void)hipHostFree(staging);
-        for (void* p : {new_cl, new_sh}) if (p) (void)hipFree(p);
-        if (!retired.empty()) (void)hipDeviceSynchronize();
-        for (void* p : retired) (void)hipFree(p);
-    }
-}
 } // namespace
 
 extern "C" {
@@ -3020,248 +2058,7 @@ int rt_copy_history(rt_frame* f)                        // CopyHistoryBuffers, :
     return RT_OK;
 }
 
-// ---- RT_OPT_SAMPLES_AHEAD: samples traced ahead of the caller's Integrate() calls -------------------------------------------------------
-// The reference's own pattern is one Integrate() per frame at one sample per pixel (src/render.cpp:197); while the camera stands still -- its
-// progressive accumulation -- sample s + 1 .. s + k are known the moment sample s is: same camera, consecutive sample indices.  A launch of one
-// sample per pixel is its own tail (3.3 ms per 1080p frame where the work is worth 1.6), a launch of k samples is not.  So,
-// once `RT_AHEAD_QUIET` samples have been advanced without a reset, the frame traces BATCHES of the next samples into two banks (frames of its
-// own: same tile, same options, the rt_integrate schedule without its replay) on streams beside the context's, 2, 4, 8 .. `depth` samples at a time,
-// and a later rt_advance_sample whose sample sits in a bank only REPLAYS that sample's slot of the bank's radiance log into the radiance
-// (k_flush, first_slot) -- the sum after every Integrate() is the reference's bit for bit, sample by sample, in sample order.  One bank is
-// consumed while the other computes; the moment a bank is empty its next batch is enqueued, so the device always has one batch running and one
-// queued.  A reset, another camera, another option, a scene upload, rt_integrate or anything that looks between two stages DISCARDS what was
-// traced ahead (its launches finish on their own streams, unobserved): the price of a camera that starts to move is at most 2 x depth samples
-// of device time, once; a camera that moves every frame never leaves the quiet phase and pays nothing.
-#define RT_AHEAD_QUIET 3u
-
-static bool ahead_bank_idle(const AheadBank& b) { return b.next >= b.n; }
-
-// the bank that holds sample `s` as its next slot, or -1
-static int ahead_holds(const rt_frame* f, uint32_t s)
-{
-    if (!f->ahead || !f->ahead_opt) return -1;
-    const Ahead& A = *f->ahead;
-    if (A.scene != f->ctx->scene_uploads || memcmp(&A.camera, &f->camera, sizeof(rt_camera)) != 0) return -1;
-    for (int i = 0; i < 2; ++i)
-        if (A.bank[i].h && !ahead_bank_idle(A.bank[i]) && A.bank[i].base + A.bank[i].next == s) return i;
-    return -1;
-}
-
-// Samples per batch: the caller's (2 .. 64), or -- 1 = automatic -- what makes a batch ~32 M paths: 16 samples of a 1080p frame, 4 of a 4K one
-// (rt_integrate at 2 / 4 / 8 / 16 samples of the 1080p headline frame in flight: 2.67 / 2.26 / 1.97 / 1.80 ms per sample where one alone costs 3.3 and
-// 128 together 1.56; the 4K / 16-bounce config: 22.7 / 19.4 / 17.9 ms at 1 / 2 / 4 -- profiles/r06_call01.log), within 64 GiB of path state for the two banks.
-static uint32_t ahead_depth(const rt_frame* f)
-{
-    const uint64_t n = f->n_local ? f->n_local : 1u;
-    uint64_t k = f->ahead_opt & 0xFFu;
-    if (k == 0) return 0;
-    if (k == 1 || k == 255) { k = (32000000ull + n - 1) / n; if (k > 64) k = 64; }
-    const uint64_t budget = f->state_limit_mb ? ((uint64_t)f->state_limit_mb << 20) : (64ull << 30);
-    const uint64_t per_sample = 2ull * n * (11u * 16u + 5u * 4u + 12u * 2u * (f->max_bounces + 1u));
-    if (k * per_sample > budget) k = budget / per_sample;
-    return k >= 2 ? (uint32_t)k : 0u;
-}
-
-// Is the stage API's next sample one this mode may serve?  (One sample of the whole tile in one chunk on the context's stream, nothing that reads
-// between the stages.)
-static bool ahead_wanted(const rt_frame* f)
-{
-    return f->ahead_opt != 0u && !f->ahead_owner && f->n_local != 0u && !(f->denoiser || f->aov != 0) && !f->profile && !f->timeline &&
-           f->stage_pipes <= 1u && f->pipelines == 1u && f->ctx->scene.valid && ahead_depth(f) >= 2u;
-}
-
-static void ahead_mirror(const rt_frame* f, uint32_t (&m)[16])
-{
-    const uint32_t v[16] = {f->max_bounces, f->sampler, f->white_furnace, f->drop_last, f->overlap_shadow, f->trace_variant, f->trace_tune, f->shade_partition,
-        f->trace_tail_lanes, f->chunk_refill, f->trace_waves_per_cu, f->select_form_box ? 1u : 0u, f->small_launch_set ? (uint32_t)std::min<uint64_t>(f->small_launch_paths, 0xFFFFFFFFull) : 0xFFFFFFFFu,
-        (uint32_t)std::min<uint64_t>(f->trace_tail_paths, 0xFFFFFFFFull), ahead_depth(f), f->ahead_opt & 0x100u};
-    memcpy(m, v, sizeof(v));
-}
-
-// The banks exist, are laid out for `depth` samples in flight and have the owner's options.  (Anything here may wait for the device: it runs when
-// the mode starts and after an option has changed, never between two frames of a quiet camera.)
-static int ahead_configure(rt_frame* f)
-{
-    rt_ctx* ctx = f->ctx;
-    if (!f->ahead) f->ahead = new Ahead();
-    Ahead& A = *f->ahead;
-    uint32_t want[16];
-    ahead_mirror(f, want);
-    if (A.configured && memcmp(want, A.mirrored, sizeof(want)) == 0) return RT_OK;
-    ahead_discard(f);
-    A.configured = false;
-    const bool two_streams = (f->ahead_opt & 0x100u) != 0u;
-    for (int i = 0; i < 2; ++i)
-    {
-        // the banks' launches go beside the frame's own: one stream for both banks (their batches in order) or one each (they overlap)
-        if (!A.stream[i] && (i == 0 || two_streams)) HIPCHK(ctx, hipStreamCreateWithFlags(&A.stream[i], hipStreamNonBlocking));
-        AheadBank& b = A.bank[i];
-        hipStream_t const st = two_streams ? A.stream[i] : A.stream[0];
-        if (b.h && b.h->ps[0].stream != st) { (void)rt_frame_destroy(b.h); b.h = nullptr; }
-        if (!b.h)
-        {
-            rt_frame_desc fd = {f->tile.width, f->tile.height, f->tile.rank, f->tile.nranks, f->tile.band_h};
-            if (create_frame(ctx, &fd, &b.h, st) != RT_OK) { b.h = nullptr; return RT_ERROR; }
-            b.h->ahead_owner = f;
-        }
-        if (!b.done) HIPCHK(ctx, hipEventCreateWithFlags(&b.done, hipEventDisableTiming));
-        if (!b.order) HIPCHK(ctx, hipEventCreateWithFlags(&b.order, hipEventDisableTiming));
-        if (sync_frame_streams(b.h) != RT_OK) return RT_ERROR;
-        rt_frame* h = b.h;
-        const std::pair<int, uint32_t> options[] = {{RT_OPT_MAX_BOUNCES, f->max_bounces}, {RT_OPT_SAMPLER, f->sampler}, {RT_OPT_WHITE_FURNACE, f->white_furnace},
-            {RT_OPT_TRACE_DROP_LAST_BOUNCE_RAYS, f->drop_last}, {RT_OPT_OVERLAP_SHADOW, f->overlap_shadow}, {RT_OPT_TRACE_VARIANT, f->trace_variant},
-            {RT_OPT_TRACE_TUNE, f->trace_tune}, {RT_OPT_SHADE_PARTITION, f->shade_partition}, {RT_OPT_TRACE_TAIL_LANES, f->trace_tail_lanes},
-            {RT_OPT_CHUNK_REFILL, f->chunk_refill}, {RT_OPT_TRACE_WAVES_PER_CU, f->trace_waves_per_cu}, {RT_OPT_TRACE_SELECT_FORM_BOX, f->select_form_box ? 1u : 0u}};
-        for (const auto& o : options)
-            if (rt_set_option(h, o.first, o.second) != RT_OK) return RT_ERROR;
-        h->trace_tail_paths = f->trace_tail_paths;
-        h->small_launch_paths = f->small_launch_paths; h->small_launch_set = f->small_launch_set;
-        if (ensure_slots(h, want[14]) != RT_OK) return RT_ERROR;
-        if (h->slots < 2u || h->chunk_pixels < (f->n_local ? f->n_local : 1u)) return fail(ctx, "RT_OPT_SAMPLES_AHEAD: a bank could not be laid out for the whole tile");
-    }
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));       // the banks' allocations were cleared on the context's stream
-    A.depth = std::min(want[14], std::min(A.bank[0].h->slots, A.bank[1].h->slots));
-    memcpy(A.mirrored, want, sizeof(want));
-    A.configured = true;
-    return RT_OK;
-}
-
-// A batch: samples base .. base + n - 1 through the wavefront loop of bank i, as rt_integrate runs one (the same launches in the same order), but the
-// log is left as it is: its replay happens sample by sample, by ahead_consume.
-static int ahead_launch(rt_frame* f, int i, uint32_t base, uint32_t n)
-{
-    rt_ctx* ctx = f->ctx;
-    Ahead& A = *f->ahead;
-    AheadBank& b = A.bank[i];
-    rt_frame* h = b.h;
-    hipStream_t const st = h->ps[0].stream;
-    h->camera = f->camera;
-    h->sample_count = base;
-    // behind whatever the owner's stream holds: the last replay out of this bank's log
-    HIPCHK(ctx, hipEventRecord(b.order, ctx->stream));
-    HIPCHK(ctx, hipStreamWaitEvent(st, b.order, 0));
-    h->p = &h->ps[0];
-    h->fused = true;
-    h->side_active = side_on(h);
-    int rc = generate_rays(h, n, 0, false);
-    if (rc == RT_OK) rc = rt_intersect(h, 0);
-    for (uint32_t bounce = 0; bounce <= h->max_bounces && rc == RT_OK; ++bounce)
-    {
-        if (rt_shade(h, bounce) != RT_OK) rc = RT_ERROR;
-        else if (h->side_active && bounce < h->max_bounces && rt_intersect(h, bounce + 1u) != RT_OK) rc = RT_ERROR;
-        else if (rt_intersect_shadow(h, bounce) != RT_OK) rc = RT_ERROR;
-        else if (!h->side_active && bounce < h->max_bounces && rt_intersect(h, bounce + 1u) != RT_OK) rc = RT_ERROR;
-    }
-    if (rc == RT_OK && (wait_shadow(h, 0) != RT_OK || wait_shadow(h, 1) != RT_OK)) rc = RT_ERROR;
-    h->fused = false;
-    if (rc == RT_OK && hipEventRecord(b.done, st) != hipSuccess) rc = fail(ctx, "RT_OPT_SAMPLES_AHEAD: recording a batch's end failed");
-    if (rc != RT_OK)
-    {
-        // nothing of a batch that could not be enqueued is ever replayed
-        (void)hipGetLastError();
-        (void)sync_frame_streams(h);
-        (void)hipMemsetAsync(h->ps[0].cnt, 0, (size_t)h->log_stride * sizeof(uint32_t), st);
-        h->ps[0].cur_slots = 0; h->ps[0].shadow_pending = false; h->ps[0].shadow_in_flight[0] = h->ps[0].shadow_in_flight[1] = false;
-        b.n = b.next = 0;
-        return RT_ERROR;
-    }
-    b.base = base; b.n = n; b.next = 0;
-    A.camera = f->camera;
-    A.scene = ctx->scene_uploads;
-    A.last_n = n;
-    A.launched += n;
-    return RT_OK;
-}
-
-// rt_advance_sample for a sample that sits in bank i: its slot of the bank's log, replayed into the radiance on the context's stream
-static int ahead_consume(rt_frame* f, int i)
-{
-    rt_ctx* ctx = f->ctx;
-    AheadBank& b = f->ahead->bank[i];
-    rt_frame* h = b.h;
-    HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, b.done, 0));
-    const uint32_t blocks = (f->n_local + 255u) / 256u;
-    hipLaunchKernelGGL(k_flush, dim3(blocks), dim3(256), 0, ctx->stream, f->radiance, dlog(h), f->n_local, 1u, h->chunk_pixels, 0u, b.next);
-    HIPCHK(ctx, hipGetLastError());
-    ++b.next;
-    ++f->sample_count;
-    ++f->ahead->consumed;
-    if (ahead_bank_idle(b)) h->ps[0].cur_slots = 0;       // every slot replayed (k_flush has set their counts back to zero)
-    return RT_OK;
-}
-
-// Every idle bank gets the next batch -- the samples behind the last one traced ahead -- as long as some bank holds the next sample (otherwise the
-// mode is starting: `first` = the sample to begin with).  A failure to launch only ends the speculation: the samples are traced when they are asked for.
-static void ahead_schedule(rt_frame* f, bool starting)
-{
-    if (!ahead_wanted(f)) return;
-    if (ahead_configure(f) != RT_OK) { (void)hipGetLastError(); f->ahead_opt = 0; return; }   // (e.g. no memory for the banks: the mode switches itself off)
-    Ahead& A = *f->ahead;
-    if (A.depth < 2u) return;
-    const uint32_t s = f->sample_count;
-    if (!starting && ahead_holds(f, s) < 0 && !(ahead_bank_idle(A.bank[0]) && ahead_bank_idle(A.bank[1]))) return;
-    for (int i = 0; i < 2; ++i)
-    {
-        if (!ahead_bank_idle(A.bank[i])) continue;
-        uint32_t end = s;
-        for (const AheadBank& o : A.bank) if (!ahead_bank_idle(o)) end = std::max(end, o.base + o.n);
-        const uint32_t n = ahead_bank_idle(A.bank[i ^ 1]) ? 2u : std::min(A.depth, 2u * std::max(1u, A.last_n));
-        if (end > 0xFFFFFFFFu - n) return;
-        if (ahead_launch(f, i, end, n) != RT_OK) { (void)hipGetLastError(); return; }
-        if (starting) return;                               // the first batch alone: the ramp's next step follows at its first replay
-    }
-}
-
-static void ahead_discard(rt_frame* f)
-{
-    if (!f || !f->ahead) return;
-    Ahead& A = *f->ahead;
-    A.quiet = 0;
-    A.last_n = 0;
-    for (AheadBank& b : A.bank)
-    {
-        if (!b.h) continue;
-        rt_frame* h = b.h;
-        hipStream_t const st = h->ps[0].stream;
-        if (!ahead_bank_idle(b) || h->ps[0].cur_slots != 0)
-        {
-            // behind the owner's last replay out of this log AND behind the batch itself (same stream): the slots nobody replayed go back to zero, and so
-            // do the bank's ray counters (rt_frame_get_stats adds them to the owner's)
-            (void)hipEventRecord(b.order, f->ctx->stream);
-            (void)hipStreamWaitEvent(st, b.order, 0);
-            (void)hipMemsetAsync(h->ps[0].cnt, 0, (size_t)h->log_stride * sizeof(uint32_t), st);
-            A.discarded += b.n - b.next;
-        }
-        if (h->ps[0].counters) (void)hipMemsetAsync(h->ps[0].counters, 0, sizeof(DCounters), st);
-        h->ps[0].cur_slots = 0; h->ps[0].shadow_pending = false; h->ps[0].prev_bounces = 0; h->ps[0].fold_accumulates = 0;
-        b.n = b.next = 0;
-    }
-}
-
-static void ahead_destroy(rt_frame* f)
-{
-    if (!f || !f->ahead) return;
-    Ahead* A = f->ahead;
-    f->ahead = nullptr;
-    for (AheadBank& b : A->bank)
-    {
-        if (b.h) (void)rt_frame_destroy(b.h);             // (waits for its streams)
-        if (b.done) (void)hipEventDestroy(b.done);
-        if (b.order) (void)hipEventDestroy(b.order);
-    }
-    for (hipStream_t st : A->stream) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
-    delete A;
-}
-
-// A sample the frame traced itself has been advanced: RT_AHEAD_QUIET of them in a row (no reset between) start the mode -- a first batch of two.
-static void ahead_after_plain_sample(rt_frame* f)
-{
-    if (!f->ahead_opt || !ahead_wanted(f)) return;
-    if (!f->ahead) f->ahead = new Ahead();
-    Ahead& A = *f->ahead;
-    if (++A.quiet < RT_AHEAD_QUIET) return;
-    if (ahead_bank_idle(A.bank[0]) && ahead_bank_idle(A.bank[1])) ahead_schedule(f, true);
-}
+#include "samples_ahead_impl.h"
 
 int rt_advance_sample(rt_frame* f)                      // AdvanceSampleCount, :510-514
 {
@@ -3321,215 +2118,7 @@ int rt_frame_reserve_samples(rt_frame* f, uint32_t n_samples, uint32_t* reserved
     return RT_OK;
 }
 
-// ---- RT_CTX_OPT_ADAPTIVE_FOLD: probe, worker hand-over, adoption (FoldAdapt) -------------------------------------------------
-// The probe: a frame of the same camera at 1/k of the resolution (about 32 K paths), one sample (several for tiny images), taken
-// through the stage API.  Round 5: nothing here waits for the device -- every queue travels to pinned host memory with an asynchronous copy
-// enqueued right behind the stage that filled it (whole capacity: the counters that say how much of it is rays come back last), an event
-// marks the end, and the frame, the staging area and the event are kept for the scene's life (round 4: three blocking copies per bounce,
-// frame created and destroyed per probe -- what an orbiting camera paid at every re-adaptation, VERDICT r04 / ADVICE r04).
-static int fold_probe_enqueue(rt_frame* f, FoldAdapt& a)
-{
-    rt_ctx* ctx = f->ctx;
-    const uint64_t pixels = (uint64_t)f->tile.width * f->tile.height;
-    uint32_t k = 1;
-    while (pixels / ((uint64_t)k * k) > 32768u) ++k;
-    rt_frame_desc desc;
-    desc.width = std::max(1u, f->tile.width / k); desc.height = std::max(1u, f->tile.height / k);
-    desc.tile_rank = 0; desc.tile_count = 1; desc.band_height = desc.height;
-    const uint32_t paths = desc.width * desc.height;
-    const uint32_t n_samples = std::min(16u, std::max(1u, 32768u / std::max(1u, paths)));
-    const uint32_t n_bounces = f->max_bounces + 1u;
-    if (a.probe && (a.probe->tile.width != desc.width || a.probe->tile.height != desc.height)) { (void)rt_frame_destroy(a.probe); a.probe = nullptr; }
-    if (!a.probe && rt_frame_create(ctx, &desc, &a.probe) != RT_OK) { a.probe = nullptr; return RT_ERROR; }
-    rt_frame* p = a.probe;
-    if (!a.probe_done && hipEventCreateWithFlags(&a.probe_done, hipEventDisableTiming) != hipSuccess) { a.probe_done = nullptr; return fail(ctx, "rt_integrate: the probe frame's event could not be created"); }
-    a.probe_paths = paths; a.probe_samples = n_samples; a.probe_bounces = n_bounces;
-    const size_t need = a.probe_counters(n_samples);
-    if (need > a.staging_bytes)
-    {
-        if (a.staging) (void)hipHostFree(a.staging);
-        a.staging = nullptr; a.staging_bytes = 0;
-        if (hipHostMalloc((void**)&a.staging, need, hipHostMallocDefault) != hipSuccess) { a.staging = nullptr; (void)hipGetLastError(); return fail(ctx, "rt_integrate: no pinned memory for the probe frame's queues"); }
-        a.staging_bytes = need;
-    }
-    int rc = rt_reset(p);                                                // sample 0 again, like the fresh frame of round 4's probe
-    const std::pair<int, uint32_t> options[] = {{RT_OPT_MAX_BOUNCES, f->max_bounces}, {RT_OPT_SAMPLER, f->sampler}, {RT_OPT_WHITE_FURNACE, f->white_furnace},
-        {RT_OPT_TRACE_DROP_LAST_BOUNCE_RAYS, f->drop_last}, {RT_OPT_OVERLAP_SHADOW, 0u}};
-    for (const auto& o : options)
-        if (rc == RT_OK && rt_set_option(p, o.first, o.second) != RT_OK) rc = RT_ERROR;
-    if (rc == RT_OK && rt_set_camera(p, &f->camera) != RT_OK) rc = RT_ERROR;
-    if (rc == RT_OK && (p->log_stride < paths || p->chunk_pixels < paths)) rc = fail(ctx, "rt_integrate: the probe frame's queues are smaller than its image");
-    auto back = [&](size_t at, const void* src, size_t bytes) -> bool
-    {
-        return hipMemcpyAsync(a.staging + at, src, bytes, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess;
-    };
-    const size_t q = (size_t)paths * sizeof(float4);
-    for (uint32_t sample = 0; sample < n_samples && rc == RT_OK; ++sample)
-    {
-        if (rt_generate_rays(p) != RT_OK) { rc = RT_ERROR; break; }
-        for (uint32_t bounce = 0; bounce < n_bounces && rc == RT_OK; ++bounce)
-        {
-            const uint32_t in = bounce & 1u;
-            if (rt_intersect(p, bounce) != RT_OK) { rc = RT_ERROR; break; }
-            if (!back(a.probe_block(sample, bounce, 0), p->p->o4[in], q) || !back(a.probe_block(sample, bounce, 1), p->p->d4[in], q) ||
-                !back(a.probe_block(sample, bounce, 2), p->p->hits, q)) { rc = RT_ERROR; break; }
-            if (rt_shade(p, bounce) != RT_OK) { rc = RT_ERROR; break; }
-            if (!back(a.probe_block(sample, bounce, 3), p->p->sh_o4[in], q) || !back(a.probe_block(sample, bounce, 4), p->p->sh_d4[in], q)) { rc = RT_ERROR; break; }
-            if (rt_intersect_shadow(p, bounce) != RT_OK) rc = RT_ERROR;
-        }
-        // the sample's counters: queue[b] and shadow[b] of every bounce are still there (k_raygen resets them for the NEXT sequence)
-        if (rc == RT_OK && !back(a.probe_counters(sample), p->p->counters, sizeof(DCounters))) rc = RT_ERROR;
-        if (rc == RT_OK && rt_advance_sample(p) != RT_OK) rc = RT_ERROR;
-    }
-    if (rc == RT_OK && hipEventRecord(a.probe_done, ctx->stream) != hipSuccess) rc = RT_ERROR;
-    if (rc != RT_OK)
-    {
-        (void)hipGetLastError();
-        (void)hipStreamSynchronize(ctx->stream);                         // whatever was enqueued writes the staging area: let it finish
-    }
-    return rc;
-}
-
-// The adapted folds replace the records the kernels are given from now on: an exchange of pointers (the worker has uploaded the new records;
-// launches already enqueued keep reading the old ones, which the NEXT worker frees after a device synchronisation of its own thread).
-static int fold_adopt(rt_ctx* ctx)
-{
-    Scene& s = ctx->scene;
-    FoldAdapt* a = s.adapt;
-    if (a->worker.joinable()) a->worker.join();
-    a->state = FoldAdapt::IDLE;
-    a->finished.store(false);
-    char line[400];
-    const size_t at = s.tree_report.find("adaptive fold");              // one line, the latest adaptation's
-    if (at != std::string::npos) s.tree_report.erase(at);
-    if (a->o.empty())
-    {
-        s.tree_report += "adaptive fold: the probe frame brought no rays back -> the fold stays as it is\n";
-        a->state = FoldAdapt::OFF;
-    }
-    else if (a->upload_failed)
-    {
-        // the scene keeps the fold it has: a failed adaptation costs nothing but itself (and is not tried again)
-        s.tree_report += "adaptive fold: not adopted (device allocation or copy failed)\n";
-        a->state = FoldAdapt::OFF;
-    }
-    else
-    {
-        const bool shared = s.d.wnodes_sh == s.d.wnodes;               // the shadow rays walk the closest-hit records
-        if (a->ok)
-        {
-            void* old = s.wnodes;
-            s.wnodes = a->new_cl;
-            s.d.wnodes = (const float4*)a->new_cl; s.d.w_entry_ref = a->entry; s.n_wide = (uint32_t)a->wide.size();
-            if (shared && !a->ok_sh) { s.wnodes_sh = old; a->roots_sh = a->roots; s.n_wide_sh = (uint32_t)a->roots.size(); }   // ... and keep walking the old ones (theirs now)
-            else if (old) a->retired.push_back(old);
-            a->roots.swap(a->roots_new);
-            a->new_cl = nullptr;
-        }
-        if (a->ok_sh)
-        {
-            if (s.wnodes_sh) a->retired.push_back(s.wnodes_sh);
-            s.wnodes_sh = a->new_sh;
-            s.d.wnodes_sh = (const float4*)a->new_sh; s.d.w_sh_entry_ref = a->entry_sh; s.n_wide_sh = (uint32_t)a->wide_sh.size();
-            a->roots_sh.swap(a->roots_sh_new);
-            if (a->rotations != 0) a->bvh2_sh.swap(a->bvh2_sh_new);          // the shadow rays' binary tree from now on
-            a->new_sh = nullptr;
-        }
-        if (a->ok || a->ok_sh) ++a->adaptations;
-        snprintf(line, sizeof(line), "adaptive fold (probe %u): %zu closest-hit and %zu shadow probe rays; box passes per probe ray at record roots: closest-hit %.2f -> %.2f (%s), "
-            "shadow %.2f -> %.2f (%s); %.2f s on a worker thread\n", a->adaptations, a->o.size(), a->sh_o.size(), a->cost[0][0], a->cost[0][1], a->ok ? "adopted" : "kept",
-            a->cost[1][0], a->cost[1][1], a->ok_sh ? "adopted" : "kept", a->seconds);
-        s.tree_report += line;
-        if (a->ok_sh && a->reordered != 0)
-        {
-            s.tree_report.pop_back();
-            snprintf(line, sizeof(line), "; %u shadow records' slots stored likeliest occluder first\n", a->reordered);
-            s.tree_report += line;
-        }
-        if (a->ok_sh && a->rotations != 0)
-        {
-            s.tree_report.pop_back();
-            snprintf(line, sizeof(line), "; the shadow rays' binary tree rotated for the probe rays' crossings first (%u rotations)\n", a->rotations);
-            s.tree_report += line;
-        }
-        const uint64_t truncated = g_truncated_walks.exchange(0);
-        if (truncated != 0)
-        {
-            s.tree_report.pop_back();
-            snprintf(line, sizeof(line), "; %llu host walks met a subtree deeper than their 126-entry stack (weights only)\n", (unsigned long long)truncated);
-            s.tree_report += line;
-        }
-    }
-    // the rays and the records have served; the binary trees stay for the next camera
-    for (auto* v : {&a->o, &a->d, &a->sh_o, &a->sh_d}) std::vector<float4>().swap(*v);
-    for (auto* v : {&a->wide, &a->wide_sh}) std::vector<WideNode>().swap(*v);
-    for (auto* v : {&a->roots_new, &a->roots_sh_new}) std::vector<uint32_t>().swap(*v);
-    std::vector<rt_bvh_node>().swap(a->bvh2_sh_new);
-    return RT_OK;
-}
-
-// Has the camera left the view the folds were adapted to?  (tools/fold_weight_study.py --views: a fold adapted to one view costs another view
-// 0 .. + 2 % against the surface-area fold as a rule and up to + 11 % -- street level seen with a fold made from above -- while its own view
-// gains 2 .. 14 %.)  Position by 3 % of the scene's diagonal, direction by 20 degrees, field of view by a tenth.
-static bool fold_view_left(const FoldAdapt& a, const rt_camera& c)
-{
-    const double dx = (double)c.position.x - a.camera.position.x, dy = (double)c.position.y - a.camera.position.y, dz = (double)c.position.z - a.camera.position.z;
-    if (std::sqrt(dx * dx + dy * dy + dz * dz) > 0.03 * a.scene_diagonal) return true;
-    const double la = std::sqrt((double)a.camera.front.x * a.camera.front.x + (double)a.camera.front.y * a.camera.front.y + (double)a.camera.front.z * a.camera.front.z);
-    const double lc = std::sqrt((double)c.front.x * c.front.x + (double)c.front.y * c.front.y + (double)c.front.z * c.front.z);
-    const double dot = (double)c.front.x * a.camera.front.x + (double)c.front.y * a.camera.front.y + (double)c.front.z * a.camera.front.z;
-    if (la > 0.0 && lc > 0.0 && !(dot >= 0.9396926 * la * lc)) return true;
-    return std::fabs((double)c.fov - a.camera.fov) > 0.1 * std::fabs((double)a.camera.fov);
-}
-
-static int fold_adapt_hook(rt_frame* f)
-{
-    Scene& s = f->ctx->scene;
-    FoldAdapt* a = s.adapt;
-    if (!a || a->state == FoldAdapt::OFF) return RT_OK;
-    if (a->probe == f) return RT_OK;                                       // (the probe frame goes through the stage API, never through here)
-    const bool eligible = !(f->denoiser || f->aov != 0 || f->n_local == 0);
-    if (a->state == FoldAdapt::IDLE && eligible && fold_view_left(*a, f->camera))
-    {
-        // an orbiting camera leaves the view again and again: at most one adaptation per min_interval_ms (bit 1 -- tests, bench.py -- waits
-        // for every one of them anyway)
-        const auto now = std::chrono::steady_clock::now();
-        if ((a->mode.load() & 2u) || std::chrono::duration<double, std::milli>(now - a->last_armed).count() >= (double)a->min_interval_ms.load()) a->state = FoldAdapt::ARMED;
-    }
-    if (a->state == FoldAdapt::ARMED)
-    {
-        if (!eligible) return RT_OK;                                       // another frame of this scene will do
-        a->camera = f->camera;
-        a->last_armed = std::chrono::steady_clock::now();
-        if (fold_probe_enqueue(f, *a) != RT_OK)
-        {
-            a->state = FoldAdapt::OFF;
-            const size_t at = s.tree_report.find("adaptive fold");
-            if (at != std::string::npos) s.tree_report.erase(at);
-            s.tree_report += "adaptive fold: the probe frame failed (" + f->ctx->error + ") -> the fold stays as it is\n";
-            return RT_OK;
-        }
-        a->state = FoldAdapt::PROBING;
-    }
-    if (a->state == FoldAdapt::PROBING)
-    {
-        if (a->mode.load() & 2u) { if (hipEventSynchronize(a->probe_done) != hipSuccess) { (void)hipGetLastError(); a->state = FoldAdapt::OFF; return RT_OK; } }
-        else
-        {
-            const hipError_t e = hipEventQuery(a->probe_done);
-            if (e == hipErrorNotReady) return RT_OK;                       // the frame goes on with the fold it has
-            if (e != hipSuccess) { (void)hipGetLastError(); a->state = FoldAdapt::OFF; return RT_OK; }
-        }
-        a->state = FoldAdapt::COMPUTING;
-        a->ok = a->ok_sh = false;
-        a->upload_failed = false;
-        a->cost[0][0] = a->cost[0][1] = a->cost[1][0] = a->cost[1][1] = 0.0;
-        a->finished.store(false);
-        a->worker = std::thread(fold_adapt_worker, a);
-    }
-    if (a->state == FoldAdapt::COMPUTING && ((a->mode.load() & 2u) || a->finished.load())) return fold_adopt(f->ctx);
-    return RT_OK;
-}
+#include "fold_hooks_impl.h"
 
 int rt_integrate(rt_frame* f, uint32_t n_samples)       // n x Integrator::Integrate(), integrator.cpp:27-59
 {
@@ -3969,286 +2558,7 @@ int rt_frame_debug_timeline(rt_frame* f, int arm, unsigned long long* out /* [64
     return RT_OK;
 }
 
-int rt_debug_wide_bvh(const rt_bvh_node* nodes, uint32_t num_nodes, int collapse, void* records, uint32_t* roots, uint32_t capacity,
-    uint32_t* num_records, uint32_t* entry_ref)
-{
-    if (!nodes || num_nodes == 0 || !num_records || !entry_ref) return fail(nullptr, "rt_debug_wide_bvh: NULL argument");
-    std::vector<WideNode> wide;
-    uint32_t entry = 0;
-    std::vector<uint32_t> folded;
-    if (!build_wide_bvh(nodes, num_nodes, collapse == 2 ? RT_WIDE_TWO_LEVELS : RT_WIDE_SAH, wide, entry, &folded))
-        return fail(nullptr, "rt_debug_wide_bvh: the tree does not qualify for the 4-wide layout (bounds not finite / not nested, or too deep)");
-    *num_records = (uint32_t)wide.size();
-    *entry_ref = entry;
-    if (records)
-    {
-        if (wide.size() > capacity) return fail(nullptr, "rt_debug_wide_bvh: capacity too small");
-        memcpy(records, wide.data(), wide.size() * sizeof(WideNode));
-        if (roots) memcpy(roots, folded.data(), folded.size() * sizeof(uint32_t));
-    }
-    return RT_OK;
-}
-
-const char* rt_scene_tree_report(rt_ctx* ctx) { return ctx ? ctx->scene.tree_report.c_str() : ""; }
-
-int rt_debug_device_fold(rt_ctx* ctx, const rt_bvh_node* nodes, uint32_t num_nodes, double iso_weight, const float* dirs, uint32_t n_dirs, const double* weights,
-    void* records, uint32_t* roots, uint32_t capacity, uint32_t* num_records, uint32_t* entry_ref, double* seconds)
-{
-    if (!ctx || !nodes || num_nodes == 0 || !num_records || !entry_ref) return fail(ctx, "rt_debug_device_fold: NULL argument");
-    (void)hipSetDevice(ctx->device);
-    ownbvh::Metric m;
-    const bool with_metric = iso_weight >= 0.0;
-    if (with_metric)
-    {
-        m.iso = iso_weight;
-        for (uint32_t i = 0; i < n_dirs && dirs; ++i) m.dirs.push_back({std::fabs((double)dirs[3 * i]), std::fabs((double)dirs[3 * i + 1]), std::fabs((double)dirs[3 * i + 2])});
-    }
-    void* d_nodes = nullptr;
-    if (dev_alloc_copy(ctx, &d_nodes, nodes, (size_t)num_nodes * sizeof(rt_bvh_node)) != RT_OK) return RT_ERROR;
-    WideNode* d_recs = nullptr;
-    std::vector<uint32_t> folded;
-    std::vector<WideNode> wide;
-    const bool ok = devfold::fold(ctx->stream, (const rt_bvh_node*)d_nodes, num_nodes, nodes[0], with_metric ? &m : nullptr, weights, &d_recs, num_records, entry_ref, &folded, &wide, nullptr, seconds);
-    (void)hipStreamSynchronize(ctx->stream);
-    (void)hipFree(d_nodes);
-    if (d_recs) (void)hipFree(d_recs);
-    if (!ok) return fail(ctx, "rt_debug_device_fold: the tree does not qualify for the 4-wide layout, or the device path failed");
-    if (records)
-    {
-        if (wide.size() > capacity) return fail(ctx, "rt_debug_device_fold: capacity too small");
-        memcpy(records, wide.data(), wide.size() * sizeof(WideNode));
-        if (roots) memcpy(roots, folded.data(), folded.size() * sizeof(uint32_t));
-    }
-    return RT_OK;
-}
-
-int rt_debug_pair_layout(const rt_bvh_node* nodes, uint32_t num_nodes, void* records, uint32_t* roots, uint32_t num_records)
-{
-    if (!nodes || !records || !roots || num_nodes == 0) return fail(nullptr, "rt_debug_pair_layout: NULL argument");
-    std::vector<WideNode> wide((const WideNode*)records, (const WideNode*)records + num_records);
-    std::vector<uint32_t> r(roots, roots + num_records);
-    pair_layout_by_area(wide, r, nodes, num_nodes, (const ownbvh::Metric*)nullptr);
-    memcpy(records, wide.data(), wide.size() * sizeof(WideNode));
-    memcpy(roots, r.data(), r.size() * sizeof(uint32_t));
-    return RT_OK;
-}
-
-int rt_debug_wide_bvh_weights(const rt_bvh_node* nodes, uint32_t num_nodes, const double* weights, void* records, uint32_t* roots, uint32_t capacity,
-    uint32_t* num_records, uint32_t* entry_ref)
-{
-    if (!nodes || num_nodes == 0 || !weights || !num_records || !entry_ref) return fail(nullptr, "rt_debug_wide_bvh_weights: NULL argument");
-    std::vector<WideNode> wide;
-    std::vector<uint32_t> folded;
-    uint32_t entry = 0;
-    if (!build_wide_bvh(nodes, num_nodes, RT_WIDE_SAH, wide, entry, &folded, nullptr, weights)) return fail(nullptr, "rt_debug_wide_bvh_weights: the tree does not qualify for the 4-wide layout");
-    *num_records = (uint32_t)wide.size();
-    *entry_ref = entry;
-    if (records)
-    {
-        if (wide.size() > capacity) return fail(nullptr, "rt_debug_wide_bvh_weights: capacity too small");
-        memcpy(records, wide.data(), wide.size() * sizeof(WideNode));
-        if (roots) memcpy(roots, folded.data(), folded.size() * sizeof(uint32_t));
-    }
-    return RT_OK;
-}
-
-int rt_debug_choose_tree(const rt_scene_desc* sd, int shadow, uint32_t mode, void* records, uint32_t capacity, uint32_t* num_records,
-    uint32_t* entry_ref, char* report, size_t report_len)
-{
-    if (!sd || !sd->nodes || !sd->triangles || !num_records || !entry_ref) return fail(nullptr, "rt_debug_choose_tree: NULL argument");
-    std::vector<WideNode> ref_wide;
-    uint32_t ref_entry = 0;
-    if (!build_wide_bvh(sd->nodes, sd->num_nodes, RT_WIDE_SAH, ref_wide, ref_entry) || ref_wide.empty())
-        return fail(nullptr, "rt_debug_choose_tree: the tree does not qualify for the 4-wide layout");
-    std::string rep;
-    OwnTree own;
-    own.start(sd, shadow != 0, mode);
-    const bool picked = choose_tree(sd, ref_wide, ref_entry, shadow != 0, mode, own, rep);
-    const std::vector<WideNode>& w = picked ? own.wide : ref_wide;
-    *num_records = (uint32_t)w.size();
-    *entry_ref = picked ? own.entry : ref_entry;
-    if (report && report_len) snprintf(report, report_len, "%s", rep.c_str());
-    if (records)
-    {
-        if (w.size() > capacity) return fail(nullptr, "rt_debug_choose_tree: capacity too small");
-        memcpy(records, w.data(), w.size() * sizeof(WideNode));
-    }
-    return RT_OK;
-}
-
-int rt_debug_own_bvh(const rt_bvh_node* nodes, uint32_t num_nodes, double iso_weight, const float* dirs, uint32_t n_dirs,
-    rt_bvh_node* out_nodes, uint32_t capacity, uint32_t* num_out)
-{
-    if (!nodes || num_nodes == 0 || !num_out) return fail(nullptr, "rt_debug_own_bvh: NULL argument");
-    ownbvh::Metric m;
-    m.iso = iso_weight;
-    for (uint32_t i = 0; i < n_dirs && dirs; ++i) m.dirs.push_back({std::fabs((double)dirs[3 * i]), std::fabs((double)dirs[3 * i + 1]), std::fabs((double)dirs[3 * i + 2])});
-    std::vector<rt_bvh_node> own;
-    if (!ownbvh::build(nodes, num_nodes, m, own)) return fail(nullptr, "rt_debug_own_bvh: nothing to build (leaf root) or the node array is not a tree");
-    *num_out = (uint32_t)own.size();
-    if (out_nodes)
-    {
-        if (own.size() > capacity) return fail(nullptr, "rt_debug_own_bvh: capacity too small");
-        memcpy(out_nodes, own.data(), own.size() * sizeof(rt_bvh_node));
-    }
-    return RT_OK;
-}
-
-int rt_debug_wide_bvh_metric(const rt_bvh_node* nodes, uint32_t num_nodes, double iso_weight, const float* dirs, uint32_t n_dirs,
-    void* records, uint32_t capacity, uint32_t* num_records, uint32_t* entry_ref)
-{
-    if (!nodes || num_nodes == 0 || !num_records || !entry_ref) return fail(nullptr, "rt_debug_wide_bvh_metric: NULL argument");
-    ownbvh::Metric m;
-    m.iso = iso_weight;
-    for (uint32_t i = 0; i < n_dirs && dirs; ++i) m.dirs.push_back({std::fabs((double)dirs[3 * i]), std::fabs((double)dirs[3 * i + 1]), std::fabs((double)dirs[3 * i + 2])});
-    std::vector<WideNode> wide;
-    uint32_t entry = 0;
-    if (!build_wide_bvh(nodes, num_nodes, RT_WIDE_SAH, wide, entry, nullptr, &m))
-        return fail(nullptr, "rt_debug_wide_bvh_metric: the tree does not qualify for the 4-wide layout");
-    *num_records = (uint32_t)wide.size();
-    *entry_ref = entry;
-    if (records)
-    {
-        if (wide.size() > capacity) return fail(nullptr, "rt_debug_wide_bvh_metric: capacity too small");
-        memcpy(records, wide.data(), wide.size() * sizeof(WideNode));
-    }
-    return RT_OK;
-}
-
-// RT_CTX_OPT_ADAPTIVE_FOLD's host half on its own (no device): the surface-area fold of `nodes`, then the fold adapted to `n_rays` rays
-// (origin.xyz + t_max in .w, direction.xyz) -- the records of the latter, and what both cost those rays (box passes at record roots).
-int rt_debug_adapt_fold(const rt_bvh_node* nodes, uint32_t num_nodes, const float* origins_tmax, const float* directions, uint32_t n_rays,
-    void* records, uint32_t* roots, uint32_t capacity, uint32_t* num_records, uint32_t* entry_ref, double* cost2, int* cheaper)
-{
-    if (!nodes || num_nodes == 0 || !origins_tmax || !directions || !num_records || !entry_ref) return fail(nullptr, "rt_debug_adapt_fold: NULL argument");
-    std::vector<rt_bvh_node> tree(nodes, nodes + num_nodes);
-    std::vector<WideNode> wide, adapted;
-    std::vector<uint32_t> wide_roots;
-    uint32_t entry = 0;
-    if (!build_wide_bvh(nodes, num_nodes, RT_WIDE_SAH, wide, entry, &wide_roots) || wide.empty())
-        return fail(nullptr, "rt_debug_adapt_fold: the tree does not qualify for the 4-wide layout");
-    std::vector<float4> o(n_rays), d(n_rays);
-    for (uint32_t i = 0; i < n_rays; ++i)
-    {
-        o[i] = make_float4(origins_tmax[4 * i], origins_tmax[4 * i + 1], origins_tmax[4 * i + 2], origins_tmax[4 * i + 3]);
-        d[i] = make_float4(directions[4 * i], directions[4 * i + 1], directions[4 * i + 2], 0.0f);
-    }
-    double cost[2] = {0.0, 0.0};
-    std::atomic<bool> cancel{false};
-    std::vector<uint32_t> adapted_roots;
-    const bool better = refold_for_rays(tree, o, d, wide_roots, adapted, entry, cost, cancel, &adapted_roots);
-    if (adapted.empty()) return fail(nullptr, "rt_debug_adapt_fold: no adapted fold (no ray passed the root box, or the weighted fold is too deep)");
-    if (cost2) { cost2[0] = cost[0]; cost2[1] = cost[1]; }
-    if (cheaper) *cheaper = better ? 1 : 0;
-    *num_records = (uint32_t)adapted.size();
-    *entry_ref = entry;
-    if (records)
-    {
-        if (adapted.size() > capacity) return fail(nullptr, "rt_debug_adapt_fold: capacity too small");
-        memcpy(records, adapted.data(), adapted.size() * sizeof(WideNode));
-        if (roots) memcpy(roots, adapted_roots.data(), adapted_roots.size() * sizeof(uint32_t));
-    }
-    return RT_OK;
-}
-
-// RT_CTX_OPT_ADAPTIVE_FOLD's trigger on its own: has camera `now` left the view the folds were adapted to (`adapted`), in a scene of this diagonal?
-int rt_debug_fold_view_left(const rt_camera* adapted, const rt_camera* now, double scene_diagonal)
-{
-    if (!adapted || !now) return -1;
-    FoldAdapt a;
-    a.camera = *adapted;
-    a.scene_diagonal = scene_diagonal;
-    return fold_view_left(a, *now) ? 1 : 0;
-}
-
-// FoldAdapt's shadow side exactly as the worker runs it (adapt_shadow_side; host only): `nodes` is the shadow rays' current binary tree under its surface-area
-// fold, `mode` RT_CTX_OPT_ADAPTIVE_FOLD's value (bit 3 = rotate first).  Out: the candidate's records, the tree they fold (out_tree[num_nodes]; `nodes`
-// again when nothing was rotated), cost2 = {current, candidate}, *rotations, return value 1 = would be adopted, 0 = kept, < 0 = error.
-int rt_debug_adapt_shadow_side(const rt_bvh_node* nodes, uint32_t num_nodes, const float* origins_tmax, const float* directions, uint32_t n_rays, uint32_t mode,
-    void* records, uint32_t* roots, uint32_t capacity, uint32_t* num_records, uint32_t* entry_ref, rt_bvh_node* out_tree, double* cost2, uint32_t* rotations,
-    const rt_triangle* triangles, uint32_t num_triangles, uint32_t* reordered)
-{
-    if (!nodes || num_nodes == 0 || !origins_tmax || !directions || !num_records || !entry_ref) { fail(nullptr, "rt_debug_adapt_shadow_side: NULL argument"); return -1; }
-    FoldAdapt a;
-    a.mode = mode;
-    if (triangles && (mode & 16u))
-    {
-        a.tri9.resize((size_t)num_triangles * 9);
-        for (uint32_t i = 0; i < num_triangles; ++i)
-        {
-            const rt_float3 v[3] = {triangles[i].v1.position, triangles[i].v2.position, triangles[i].v3.position};
-            for (int k = 0; k < 3; ++k) { a.tri9[(size_t)i * 9 + 3 * k] = v[k].x; a.tri9[(size_t)i * 9 + 3 * k + 1] = v[k].y; a.tri9[(size_t)i * 9 + 3 * k + 2] = v[k].z; }
-        }
-    }
-    a.bvh2.assign(nodes, nodes + num_nodes);
-    std::vector<WideNode> wide;
-    uint32_t entry = 0;
-    if (!build_wide_bvh(nodes, num_nodes, RT_WIDE_SAH, wide, entry, &a.roots) || wide.empty()) { fail(nullptr, "rt_debug_adapt_shadow_side: the tree does not qualify for the 4-wide layout"); return -1; }
-    a.sh_o.resize(n_rays); a.sh_d.resize(n_rays);
-    for (uint32_t i = 0; i < n_rays; ++i)
-    {
-        a.sh_o[i] = make_float4(origins_tmax[4 * i], origins_tmax[4 * i + 1], origins_tmax[4 * i + 2], origins_tmax[4 * i + 3]);
-        a.sh_d[i] = make_float4(directions[4 * i], directions[4 * i + 1], directions[4 * i + 2], 0.0f);
-    }
-    const bool adopted = adapt_shadow_side(&a);
-    if (a.wide_sh.empty()) { fail(nullptr, "rt_debug_adapt_shadow_side: no candidate (no ray passed the root box, or the folds are too deep)"); return -1; }
-    *num_records = (uint32_t)a.wide_sh.size();
-    *entry_ref = a.entry_sh;
-    if (cost2) { cost2[0] = a.cost[1][0]; cost2[1] = a.cost[1][1]; }
-    if (rotations) *rotations = a.rotations;
-    if (reordered) *reordered = a.reordered;
-    if (records)
-    {
-        if (a.wide_sh.size() > capacity) { fail(nullptr, "rt_debug_adapt_shadow_side: capacity too small"); return -1; }
-        memcpy(records, a.wide_sh.data(), a.wide_sh.size() * sizeof(WideNode));
-        if (roots) memcpy(roots, a.roots_sh_new.data(), a.roots_sh_new.size() * sizeof(uint32_t));
-    }
-    if (out_tree) memcpy(out_tree, a.rotations != 0 ? a.bvh2_sh_new.data() : nodes, (size_t)num_nodes * sizeof(rt_bvh_node));
-    return adopted ? 1 : 0;
-}
-
-// What rt_scene_upload / rt_ctx_destroy do to an adaptation in flight (host only): a FoldAdapt whose worker has just started on `nodes` and the rays
-// given is dropped after delay_ms; returns the milliseconds the drop took (the worker gives up at its next check), -1 on an argument error.
-double rt_debug_fold_abandon(const rt_bvh_node* nodes, uint32_t num_nodes, const float* origins_tmax, const float* directions, uint32_t n_rays, uint32_t mode,
-    uint32_t delay_ms, int* had_finished)
-{
-    if (!nodes || num_nodes == 0 || !origins_tmax || !directions) { fail(nullptr, "rt_debug_fold_abandon: NULL argument"); return -1.0; }
-    FoldAdapt* a = new FoldAdapt();
-    a->mode = mode;
-    a->bvh2.assign(nodes, nodes + num_nodes);
-    std::vector<WideNode> wide;
-    uint32_t entry = 0;
-    if (!build_wide_bvh(nodes, num_nodes, RT_WIDE_SAH, wide, entry, &a->roots) || wide.empty()) { delete a; fail(nullptr, "rt_debug_fold_abandon: the tree does not qualify"); return -1.0; }
-    a->o.resize(n_rays); a->d.resize(n_rays);
-    for (uint32_t i = 0; i < n_rays; ++i)
-    {
-        a->o[i] = make_float4(origins_tmax[4 * i], origins_tmax[4 * i + 1], origins_tmax[4 * i + 2], origins_tmax[4 * i + 3]);
-        a->d[i] = make_float4(directions[4 * i], directions[4 * i + 1], directions[4 * i + 2], 0.0f);
-    }
-    a->sh_o = a->o; a->sh_d = a->d;
-    a->state = FoldAdapt::COMPUTING;
-    a->worker = std::thread(fold_adapt_worker, a);
-    std::this_thread::sleep_for(std::chrono::milliseconds(delay_ms));
-    if (had_finished) *had_finished = a->finished.load() ? 1 : 0;
-    const auto t0 = std::chrono::steady_clock::now();
-    drop_fold_adapt(a);
-    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-}
-
-// tree_rotate.h on its own (host only): the binary tree `nodes` rotated for the rays given (as rt_debug_adapt_fold takes them); out_nodes[num_nodes]
-int rt_debug_rotate_tree(const rt_bvh_node* nodes, uint32_t num_nodes, const float* origins_tmax, const float* directions, uint32_t n_rays, int max_passes,
-    rt_bvh_node* out_nodes, double* cost2, uint32_t* rotations, int moves, double min_gain)
-{
-    if (!nodes || num_nodes == 0 || !origins_tmax || !directions || !out_nodes) return fail(nullptr, "rt_debug_rotate_tree: NULL argument");
-    std::vector<rt_bvh_node> out;
-    double cost[2] = {0.0, 0.0};
-    const uint32_t made = treerot::rotate(nodes, num_nodes, origins_tmax, directions, n_rays, max_passes, out, cost, nullptr, moves, min_gain);
-    if (out.size() != num_nodes) return fail(nullptr, "rt_debug_rotate_tree: the node array is not a tree");
-    memcpy(out_nodes, out.data(), out.size() * sizeof(rt_bvh_node));
-    if (cost2) { cost2[0] = cost[0]; cost2[1] = cost[1]; }
-    if (rotations) *rotations = made;
-    return RT_OK;
-}
+#include "debug_exports_impl.h"
 
 int rt_debug_eval(rt_ctx* ctx, int fn, const float* a, const float* b, float* out, uint32_t n)
 {

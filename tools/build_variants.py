@@ -9,12 +9,12 @@ import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from raytracing_amd import _build
-procs = []
 for spec in sys.argv[1:]:
     name, macros = spec.split("=", 1)
     d = os.path.join(ROOT, "raytracing_amd", "variants", name)
     os.makedirs(d, exist_ok=True)
-    cmd = [_build.hipcc()] + _build.HIP_FLAGS + _build.INC + macros.split(",") + [os.path.join(_build.CSRC, "rt_hip.hip"), "-o", os.path.join(d, "librt_hip.so")]
-    procs.append((name, subprocess.Popen(cmd, cwd=ROOT, stderr=subprocess.DEVNULL)))
-for name, p in procs:
-    print(name, "ok" if p.wait() == 0 else "FAILED")
+    try:
+        _build.build_hip(force=True, extra_flags=macros.split(","), out=os.path.join(d, "librt_hip.so"), obj_dir=os.path.join(d, "build"))
+        print(name, "ok")
+    except Exception as e:      # noqa: BLE001
+        print(name, "FAILED", e)
