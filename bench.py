@@ -83,8 +83,8 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 LIGHT = ((-0.6, -1.5, 3.5), (15.0, 10.0, 5.0))   # reference main.cpp:58
-COUNTERS_FILE = os.path.join(ROOT, "profiles", "r05_trace_counters.json")
-VISIT_MICROBENCH_FILE = os.path.join(ROOT, "profiles", "r04_visit_microbench.json")
+COUNTERS_FILE = os.path.join(ROOT, "profiles", "r06_trace_counters.json")
+CALIBRATION_FILE = os.path.join(ROOT, "profiles", "r06_fetch_size_calibration.json")
 
 
 SURVEY_A_ACTIVE = [65536, 65536, 51957, 44567, 38383]      # CornellBox.obj 256x256, sample 0, max_bounces 4
@@ -501,13 +501,14 @@ def roofline_object(args, world, live_step, per_ray, isolated):
 
       bound / achieved / peak / frac   the north star's quantity: HBM traffic the counters saw per launch / launch duration,
                                        against the 8 TB/s peak.  frac = achieved / peak.
-      traffic                          HBM bytes per launch = (FETCH_SIZE x 0.99 + WRITE_SIZE) KiB (tools/make_counters_json.py)
+      traffic                          HBM bytes per launch = 128 x TCC_EA0_RDREQ_128B + 64 x .._64B + 32 x .._32B + WRITE_SIZE KiB (tools/make_counters_json.py;
+                                       round 6: this rocprofv3's FETCH_SIZE tallies every read request at 64 bytes while the L2 fetches whole 128-byte lines --
+                                       profiles/r06_fetch_size_calibration.json checks both against known byte counts per access pattern)
+      hbm_all_kernels                  the same for every kernel of the path (k_shade is the HBM-leaning one), and the ceilings the calibration measured:
+                                       streaming reads / writes, and random 64-byte records (whose every miss moves a 128-byte line)
       algorithmic                      SURVEY 8d's per-ray byte model x rays per launch, and traffic / algorithmic
       units                            busy fractions of the units the kernel can saturate, against calibrated ceilings
-      latency_ceiling                  useful wide-tree steps per second of the kernel against the rate of the BARE visit chain
-                                       (tools/visit_microbench.hip: fetch a 64-byte node -> dequantise -> 4 slab tests -> order ->
-                                       LDS push / pop, every lane busy, nothing else) at its best residency and the kernel's own
-                                       L1 / L2 hit mix:  ceiling_grays = visits_per_s / steps_per_ray."""
+      (latency_ceiling, a model that the kernel exceeded by 15 %, is gone from the line: VERDICT r05, weak 11)"""
     bytes_closest = 48.0 + 32.0 * per_ray["closest_nodes"] + 36.0 * per_ray["closest_tris"]     # SURVEY 8d, per ray
     avg_ms = live_step["avg_launch_ms"] if live_step else 0.0
     rays_per_launch = live_step["rays_per_launch"] if live_step else 0.0
@@ -546,8 +547,28 @@ def roofline_object(args, world, live_step, per_ray, isolated):
         achieved = traffic / (float(k["avg_launch_ms"]) * 1e-3) / 1e9
         out.update(achieved=round(achieved, 1), frac=round(achieved / HBM_PEAK_GBS, 4), traffic=round(traffic, 0),
                    formula="achieved = traffic / avg_launch_ms of the profiled launches (%.3f ms; this run, alone on the machine: %.3f ms); "
-                           "frac = achieved / peak; traffic = (FETCH_SIZE x 0.99 + WRITE_SIZE) KiB per launch" % (k["avg_launch_ms"], iso_ms),
+                           "frac = achieved / peak; traffic = read requests by size (%s) + WRITE_SIZE KiB per launch" % (k["avg_launch_ms"], iso_ms, k.get("hbm_read_how", "FETCH_SIZE x 0.99")),
                    stale=bool(stale))
+        # every kernel of the path against HBM, and against what the calibration kernels reach with the same counters
+        try:
+            cal = json.load(open(CALIBRATION_FILE))["patterns"]
+            rand_line_TBs = cal["k_rand64"]["TBs"] * cal["k_rand64"]["sized_request_bytes_over_known"]      # useful 64-byte records/s x the 128-byte lines they move
+            ceil = dict(stream_read_TBs=cal["k_read16"]["TBs"], stream_write_TBs=cal["k_write16"]["TBs"], random_64B_records_useful_TBs=cal["k_rand64"]["TBs"],
+                        random_64B_records_line_traffic_TBs=round(rand_line_TBs, 3))
+        except Exception:
+            cal, ceil, rand_line_TBs = None, None, None
+        allk = {}
+        for name in ("closest", "shadow", "shade"):
+            e = doc["config_%d" % args.config].get(name)
+            if e:
+                allk[name] = dict(avg_launch_ms=round(e["avg_launch_ms"], 3), read_GB=round(e.get("hbm_read_bytes_per_launch", 0.0) / 1e9, 3),
+                                  write_GB=round(e.get("hbm_write_bytes_per_launch", 0.0) / 1e9, 3), GBs=round(e["hbm_GBs"], 1), frac_of_peak=round(e["hbm_frac"], 4),
+                                  frac_of_random_line_ceiling=round(e["hbm_GBs"] / 1e3 / rand_line_TBs, 3) if rand_line_TBs and name != "shade" else None,
+                                  frac_of_stream_read_ceiling=round(e["hbm_GBs"] / 1e3 / ceil["stream_read_TBs"], 3) if ceil and name == "shade" else None,
+                                  l2_hit_rate=round(e["per_launch"]["l2_hit_rate"], 3), valu_busy=round(e["valu_busy"], 3), l1_ta_busy=round(e["l1_ta_busy"], 3))
+        out["hbm_all_kernels"] = dict(kernels=allk, measured_ceilings=ceil, calibration=os.path.relpath(CALIBRATION_FILE, ROOT),
+                                      note="the traversal kernels fetch 64-byte records: every L2 miss moves a 128-byte line, half of it unasked for -- their ceiling is the "
+                                           "random-record kernel's line traffic, not the streaming rate; k_shade streams its queues and is priced against the streaming read rate")
         out["algorithmic"]["traffic_over_algorithmic"] = round(traffic / alg_bytes, 4) if alg_bytes > 0 else None
         out["units"] = dict(valu_busy=round(k["valu_busy"], 4), salu_busy=round(k["salu_busy"], 4), l1_ta_busy=round(k["l1_ta_busy"], 4),
                             hbm_frac=round(k["hbm_frac"], 4), valu_fast_opcode_fraction=k.get("valu_fast_opcode_fraction"),
@@ -564,42 +585,13 @@ def roofline_object(args, world, live_step, per_ray, isolated):
         for name, busy in (("valu_issue", k["valu_busy"]), ("l1_texture_address", k["l1_ta_busy"]), ("hbm", k["hbm_frac"])):
             if busy and busy > 0:
                 ceilings[name] = round(achieved_grays / float(busy), 3)
-    try:
-        mb = json.load(open(VISIT_MICROBENCH_FILE))
-        runs = [r for r in mb["runs"] if r["kernel"] == "closest"]
-        resident = int(mb.get("resident_blocks_per_cu") or 26)
-        at_res = [r for r in runs if r["waves_per_cu"] == min(26, resident)] or [max(runs, key=lambda r: r["waves_per_cu"])]
-        best = max(runs, key=lambda r: r["gvisits_per_s"])
-        alone = min(runs, key=lambda r: r["waves_per_cu"])
-        steps = per_ray.get("closest_steps")
-        if steps:
-            chain_at_res = round(at_res[0]["gvisits_per_s"] / steps, 3)
-            out["latency_ceiling"] = dict(
-                is_a="MODEL, not a ceiling: the bare chain with EVERY lane busy saturates the L1 / texture-address path it shares with the kernel -- at "
-                     "the kernel's own residency it delivers fewer visits per second than the kernel's useful steps (the kernel runs ~61 % of the lanes "
-                     "per pass, i.e. fewer look-ups in flight); the ceilings this line prices the kernel against are `ceilings` (counters)",
-                visit_ns_alone=alone["ns_per_visit"], resident_waves_per_cu=at_res[0]["waves_per_cu"], gvisits_per_s_at_residency=at_res[0]["gvisits_per_s"],
-                best_gvisits_per_s=best["gvisits_per_s"], best_at_waves_per_cu=best["waves_per_cu"],
-                sweep=[(r["waves_per_cu"], r["gvisits_per_s"]) for r in runs],
-                l1_hit=mb.get("l1_hit"), l2_hit=mb.get("l2_hit"),
-                steps_per_ray=round(steps, 2), wide_visits_per_ray=round(per_ray.get("closest_wide_visits", 0.0), 2),
-                achieved_gsteps_per_s=round(achieved_grays * steps, 1), ceiling_grays=chain_at_res, ceiling_grays_at_best_residency=round(best["gvisits_per_s"] / steps, 3),
-                achieved_grays=round(achieved_grays, 3),
-                frac_of_ceiling=round(achieved_grays / chain_at_res, 4),
-                formula="ceiling_grays = G visits/s of the bare visit chain AT THE KERNEL'S RESIDENCY (every lane busy, per-CU hot sets, the kernel's "
-                        "L1 / L2 hit mix) / steps_per_ray; steps_per_ray = wide-node visits + leaf passes per ray, counted by the CPU restatement of "
-                        "the walk (oracle.c: orc_wide_trace) on a 320x180 frame of the same scene; the kernel runs its passes with ~61 % of the lanes busy, "
-                        "so reaching this figure would take full passes",
-                source=os.path.relpath(VISIT_MICROBENCH_FILE, ROOT) + " (tools/visit_microbench.hip on MI355X)")
-    except Exception:
-        pass
     if ceilings:
         lowest = min(ceilings, key=ceilings.get)
         out["ceilings"] = dict(grays=ceilings, binding=lowest, achieved_grays=round(achieved_grays, 3),
-                               frac_of_ceiling=round(achieved_grays / ceilings[lowest], 4),
+                               busiest_unit_fraction=round(achieved_grays / ceilings[lowest], 4),
                                formula="valu_issue / l1_texture_address / hbm = achieved_grays / that unit's busy fraction of its calibrated ceiling "
-                                       "(units above: counters of the profiled launches of this code object); "
-                                       "frac_of_ceiling = achieved_grays / min(ceilings)")
+                                       "(units above: counters of the profiled launches of this code object); busiest_unit_fraction = achieved_grays / min(ceilings) "
+                                       "= the largest busy fraction: a MODEL of headroom (the issue ceilings are self-calibrated, tools/make_counters_json.py), not a measurement of it")
     return out
 
 
@@ -660,6 +652,7 @@ def main():
                     "travels as one chunk; 2..4: as that many chunks on streams of their own, their launch tails overlapping)")
     ap.add_argument("--frame-kernel", type=int, default=None, help="RT_OPT_FRAME_KERNEL for the per_frame legs (library default 0): 1 = every frame of the "
                     "hooks' pattern is ONE launch of k_frame")
+    ap.add_argument("--share-folds", type=int, default=1, help="N > 1: 1 (default) = one fold adaptation per process group (rank 0's records are broadcast), 0 = every rank adapts itself")
     ap.add_argument("--wide-layout", type=int, default=None, help="RT_CTX_OPT_WIDE_LAYOUT (library default 0): 1 = the 4-wide records in (parent, likeliest child) pairs, one pair per 128-byte line")
     ap.add_argument("--device-fold", type=int, default=None, help="RT_CTX_OPT_DEVICE_FOLD (library default 1): 0 = the folds on host threads")
     ap.add_argument("--samples-ahead", type=int, default=None, help="RT_OPT_SAMPLES_AHEAD for the per_frame leg (HIPPathTraceIntegrator's default: 1 = automatic depth; "
@@ -749,13 +742,20 @@ def main():
         scene, n_tris = build_scene(args, host, S)
         scene_source = "built by this rank"
     t_scene = time.time() - t0
+    # N > 1: ONE fold adaptation per process group: rank 0 builds the shadow rays' tree and adapts the folds, the other ranks upload without either
+    # (RT_CTX_OPT_SHADOW_TREE = 0, RT_CTX_OPT_ADAPTIVE_FOLD = 0) and take rank 0's records after its warm-up (rt_scene_export_folds -> this launcher's
+    # gloo broadcast -> rt_scene_import_folds); any fold is exact, so the image does not depend on it
+    share_folds = world > 1 and args.share_folds and args.adaptive_fold != 0 and args.shadow_tree is None and args.closest_tree is None
     render = host.Render(args.width, args.height, scene, device=local_rank, tile_rank=rank, tile_count=world,
-                         band_height=args.band_height)      # builds the BVH (or adopts the cached one), finalises, uploads
+                         band_height=args.band_height,      # builds the BVH (or adopts the cached one), finalises, uploads
+                         ctx_options=((2, 0), (4, 0)) if share_folds and rank != 0 else ())
     t_setup = time.time() - t0
     setup_breakdown = render.setup_seconds()                 # Render's constructor: BVH build / Finalize / frame / UploadGPUData (its stages: the `upload:` line of the tree report)
     if args.wide_collapse != 1:
         render.set_wide_bvh(args.wide_collapse)               # A/B: uploads the scene again with the other collapse
-    if args.shadow_tree is not None or args.closest_tree is not None or args.adaptive_fold != capi.ADAPTIVE_FOLD_DEFAULT or args.wide_layout is not None or args.device_fold is not None:
+    if share_folds and rank != 0:
+        pass                                                  # (this rank's folds come from rank 0: nothing to set, nothing to upload again)
+    elif args.shadow_tree is not None or args.closest_tree is not None or args.adaptive_fold != capi.ADAPTIVE_FOLD_DEFAULT or args.wide_layout is not None or args.device_fold is not None:
         if args.wide_layout is not None:
             render.set_ctx_option(8, args.wide_layout, False)      # RT_CTX_OPT_WIDE_LAYOUT
         if args.device_fold is not None:
@@ -851,6 +851,31 @@ def main():
     render.render_samples(spp_warm) if spp_warm > 0 else None
     render.finish()
     t_warm = time.perf_counter() - t_warm0                # with bit 1 of --adaptive-fold: probe + worker + adoption are in here
+    fold_share = None
+    if share_folds:
+        # rank 0's records (adapted inside its warm-up: bit 1 waits) to everybody, then one more untimed step on the folds the timed region runs on
+        t_s0 = time.perf_counter()
+        ctx_h = host.load().rth_render_ctx_handle(render.handle)
+        meta = torch.zeros(4, dtype=torch.int64)
+        if rank == 0:
+            cl, sh, ent = capi.export_folds(ctx_h)
+            meta[:] = torch.tensor([len(cl), len(sh), ent[0], ent[1]])
+        dist.broadcast(meta, src=0)
+        n_cl, n_sh = int(meta[0]), int(meta[1])
+        t_cl = torch.from_numpy(cl) if rank == 0 else torch.empty((n_cl, 64), dtype=torch.uint8)
+        t_sh = torch.from_numpy(sh) if rank == 0 else torch.empty((max(n_sh, 1), 64), dtype=torch.uint8)
+        if rank == 0 and n_sh == 0:
+            t_sh = torch.zeros((1, 64), dtype=torch.uint8)
+        dist.broadcast(t_cl, src=0)
+        dist.broadcast(t_sh, src=0)
+        if rank != 0:
+            capi.import_folds(ctx_h, t_cl.numpy(), t_sh.numpy()[:n_sh], (int(meta[2]), int(meta[3])))
+        if spp_warm > 0:
+            render.render_samples(min(spp_warm, sps))
+        render.finish()
+        fold_share = dict(records=[n_cl, n_sh], seconds=round(time.perf_counter() - t_s0, 3),
+                          what="one fold adaptation per process group: rank 0's 4-wide records (closest-hit + shadow, adapted in its warm-up) broadcast over the launcher's "
+                               "gloo group and imported by the other ranks, which uploaded without a shadow tree or an adaptation of their own (untimed)")
     trees_after_warmup = render.tree_report() if args.adaptive_fold else tree_report     # the folds the timed region runs on (later legs may adapt again)
     if args.warmup > 0:     # the gather path too (first use sets up the RCCL channels)
         if group is not None:
@@ -1199,7 +1224,7 @@ def main():
                                render_ms=[r["render_ms"] for r in per_rank], gather_ms=[r["gather_ms"] for r in per_rank],
                                setup_s=[r["setup_s"] for r in per_rank], setup_s_max=max(r["setup_s"] for r in per_rank),
                                scene_s=[r["scene_s"] for r in per_rank], rows=[r["rows"] for r in per_rank],
-                               mrays=[round(r["rays"] / 1e6, 1) for r in per_rank], scene=scene_source,
+                               mrays=[round(r["rays"] / 1e6, 1) for r in per_rank], scene=scene_source, fold_share=fold_share,
                                in_flight=[r["in_flight"] for r in per_rank], rays_per_launch=[r["rays_per_launch"] for r in per_rank],
                                rays_in_first_launch=[r["rays_in_first_launch"] for r in per_rank]),
                     gather=gather_info, per_frame=per_frame, roofline=roofline, parity=parity, cpu_baseline=baseline,

@@ -162,6 +162,14 @@ typedef struct rt_scene_desc
 
 int rt_scene_upload(rt_ctx* ctx, const rt_scene_desc* scene);
 
+/* One fold adaptation per process GROUP instead of one per rank (N ranks that tile one image hold the same scene and would each probe, rotate and fold for
+ * identical records): the context's current 4-wide records -- the closest-hit rays' and the shadow rays' (n_shadow == 0: they share), as adapted so far -- to
+ * host buffers of `capacity` records each (records NULL: size query; entries2 = {closest entry, shadow entry}), and into another context that has uploaded
+ * the SAME scene (same triangle order): they replace its own, its adaptation is switched off, refs are range-checked.  The launcher's channel carries the
+ * bytes in between (bench.py: torch.distributed).  Any fold of the same tree is exact: results do not change. */
+int rt_scene_export_folds(rt_ctx* ctx, void* closest_records, void* shadow_records, uint32_t capacity, uint32_t* n_closest, uint32_t* n_shadow, uint32_t* entries2);
+int rt_scene_import_folds(rt_ctx* ctx, const void* closest_records, uint32_t n_closest, uint32_t entry_closest, const void* shadow_records, uint32_t n_shadow, uint32_t entry_shadow);
+
 /* ---- frame: the per-pixel state CLPathTraceIntegrator allocates in its ctor
  * (cl_pt_integrator.cpp:188-259).  A frame renders a TILE of the full image:
  * the rows whose band index (row / band_height) is congruent to tile_rank

@@ -63,7 +63,7 @@ EXPORTS = [
     "rt_compute_aovs", "rt_denoise", "rt_copy_history",
     "rt_frame_resolve", "rt_frame_present", "rt_frame_present_wait", "rt_frame_read_radiance", "rt_frame_radiance_device_ptr", "rt_frame_sample_count",
     "rt_frame_get_stats", "rt_frame_get_profile", "rt_frame_copy_radiance", "rt_frame_debug_read_queue", "rt_frame_debug_read_hits", "rt_debug_eval",
-    "rt_debug_wide_bvh", "rt_frame_debug_timeline", "rt_frame_debug_frame_rows", "rt_debug_own_bvh", "rt_debug_wide_bvh_metric", "rt_scene_tree_report", "rt_debug_choose_tree", "rt_debug_adapt_fold", "rt_debug_fold_abandon", "rt_debug_adapt_shadow_side", "rt_debug_rotate_tree", "rt_debug_fold_view_left", "rt_debug_device_fold", "rt_debug_wide_bvh_weights", "rt_debug_pair_layout",
+    "rt_debug_wide_bvh", "rt_frame_debug_timeline", "rt_frame_debug_frame_rows", "rt_debug_own_bvh", "rt_debug_wide_bvh_metric", "rt_scene_tree_report", "rt_debug_choose_tree", "rt_debug_adapt_fold", "rt_debug_fold_abandon", "rt_debug_adapt_shadow_side", "rt_debug_rotate_tree", "rt_debug_fold_view_left", "rt_debug_device_fold", "rt_debug_wide_bvh_weights", "rt_debug_pair_layout", "rt_scene_export_folds", "rt_scene_import_folds",
     "rt_group_create", "rt_group_unique_id", "rt_group_join", "rt_group_size", "rt_group_local_count", "rt_group_local_rank", "rt_group_comm_count",
     "rt_group_gather_radiance", "rt_group_destroy", "rt_group_last_error", "rt_group_denoise", "rt_group_create_local",
     "rt_group_create_unchecked",
@@ -122,6 +122,8 @@ def load():
         "rt_debug_device_fold": (i32, [vp, vp, u32, C.c_double, vp, u32, vp, vp, vp, u32, C.POINTER(u32), C.POINTER(u32), C.POINTER(C.c_double)]),
         "rt_debug_wide_bvh_weights": (i32, [vp, u32, vp, vp, vp, u32, C.POINTER(u32), C.POINTER(u32)]),
         "rt_debug_pair_layout": (i32, [vp, u32, vp, vp, u32]),
+        "rt_scene_export_folds": (i32, [vp, vp, vp, u32, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]),
+        "rt_scene_import_folds": (i32, [vp, vp, u32, u32, vp, u32, u32]),
         "rt_debug_rotate_tree": (i32, [vp, u32, vp, vp, u32, i32, vp, C.POINTER(C.c_double), C.POINTER(u32), i32, C.c_double]),
         "rt_debug_adapt_shadow_side": (i32, [vp, u32, vp, vp, u32, u32, vp, vp, u32, C.POINTER(u32), C.POINTER(u32), vp, C.POINTER(C.c_double), C.POINTER(u32), vp, u32, C.POINTER(u32)]),
         "rt_debug_fold_abandon": (C.c_double, [vp, u32, vp, vp, u32, u32, u32, C.POINTER(i32)]),
@@ -168,6 +170,29 @@ def choose_tree(scene, shadow=True, mode=1):
 
 
 ADAPTIVE_FOLD_DEFAULT = 25     # rt_ctx's RT_CTX_OPT_ADAPTIVE_FOLD as created (rt_hip.hip): bits 0 + 3 + 4 since round 5
+
+
+def export_folds(ctx_handle):
+    """rt_scene_export_folds: (closest records uint8[n, 64], shadow records uint8[m, 64] (m = 0: shared), (closest entry, shadow entry))"""
+    lib = load()
+    n, m = C.c_uint32(), C.c_uint32()
+    ent = (C.c_uint32 * 2)()
+    if lib.rt_scene_export_folds(ctx_handle, None, None, 0, C.byref(n), C.byref(m), ent):
+        raise RtError(lib.rt_last_error(ctx_handle).decode())
+    cap = max(n.value, m.value, 1)
+    cl, sh = np.zeros((cap, 64), np.uint8), np.zeros((cap, 64), np.uint8)
+    if lib.rt_scene_export_folds(ctx_handle, cl.ctypes.data, sh.ctypes.data, cap, C.byref(n), C.byref(m), ent):
+        raise RtError(lib.rt_last_error(ctx_handle).decode())
+    return cl[:n.value].copy(), sh[:m.value].copy(), (int(ent[0]), int(ent[1]))
+
+
+def import_folds(ctx_handle, closest, shadow, entries):
+    """rt_scene_import_folds: another context's records in place of this one's (same scene); its own adaptation goes off"""
+    lib = load()
+    cl = np.ascontiguousarray(closest, np.uint8)
+    sh = np.ascontiguousarray(shadow, np.uint8) if shadow is not None and len(shadow) else None
+    if lib.rt_scene_import_folds(ctx_handle, cl.ctypes.data, len(cl), entries[0], sh.ctypes.data if sh is not None else None, len(sh) if sh is not None else 0, entries[1]):
+        raise RtError(lib.rt_last_error(ctx_handle).decode())
 
 
 def device_fold(ctx, nodes, iso_weight=-1.0, dirs=None, weights=None):

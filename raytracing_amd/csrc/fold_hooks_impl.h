@@ -212,3 +212,79 @@ static int fold_adapt_hook(rt_frame* f)
     return RT_OK;
 }
 
+
+// ---- one adaptation per process GROUP (round 6) ----------------------------------------------------------------------------------------
+// N ranks that tile one image hold the same scene and probe the same low-resolution frame: N identical adaptations (tree rotations on host threads: seconds)
+// for identical records.  Instead one rank adapts and the others TAKE its 4-wide records: rt_scene_export_folds copies the context's current records (the
+// closest-hit rays' and the shadow rays', as adapted so far) to the host, the launcher's own channel carries them (torch.distributed, MPI, a file: 64 bytes
+// per record, ~240 MB for the 2.8 M-triangle scene), rt_scene_import_folds puts them in place of the receiver's own and switches its adaptation off.  The
+// records are indices into the triangle records every rank made from the same scene, so nothing else travels.  Exactness is the fold's: any fold of the same
+// binary tree over the same leaves gives the same results -- and the importer checks what it can: record count, refs within range,
+// leaf refs within the triangle array.
+int rt_scene_export_folds(rt_ctx* ctx, void* closest_records, void* shadow_records, uint32_t capacity, uint32_t* n_closest, uint32_t* n_shadow, uint32_t* entries2)
+{
+    if (!ctx || !n_closest || !n_shadow) return fail(ctx, "rt_scene_export_folds: NULL argument");
+    Scene& s = ctx->scene;
+    if (!s.valid || !s.wide_ok || !s.wnodes) return fail(ctx, "rt_scene_export_folds: the scene has no 4-wide tree");
+    (void)hipSetDevice(ctx->device);
+    const bool own_shadow = s.d.wnodes_sh != s.d.wnodes && s.wnodes_sh != nullptr;
+    const uint32_t n_cl = s.wnodes_cl != nullptr && s.d.wnodes == (const float4*)s.wnodes_cl ? s.n_wide_cl : s.n_wide;   // (tolerance mode: the closest-hit rays walk wnodes_cl)
+    *n_closest = n_cl;
+    *n_shadow = own_shadow ? s.n_wide_sh : 0u;
+    if (entries2) { entries2[0] = s.d.w_entry_ref; entries2[1] = s.d.w_sh_entry_ref; }
+    if (!closest_records) return RT_OK;                                                       // size query
+    if (n_cl > capacity || *n_shadow > capacity) return fail(ctx, "rt_scene_export_folds: capacity too small");
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipMemcpy(closest_records, s.d.wnodes, (size_t)n_cl * sizeof(WideNode), hipMemcpyDeviceToHost));
+    if (own_shadow && shadow_records) HIPCHK(ctx, hipMemcpy(shadow_records, s.d.wnodes_sh, (size_t)s.n_wide_sh * sizeof(WideNode), hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+int rt_scene_import_folds(rt_ctx* ctx, const void* closest_records, uint32_t n_closest, uint32_t entry_closest, const void* shadow_records, uint32_t n_shadow, uint32_t entry_shadow)
+{
+    if (!ctx || !closest_records || n_closest == 0) return fail(ctx, "rt_scene_import_folds: NULL argument");
+    Scene& s = ctx->scene;
+    if (!s.valid || !s.wide_ok) return fail(ctx, "rt_scene_import_folds: the scene has no 4-wide tree to replace (upload it first, with RT_CTX_OPT_WIDE_BVH = 1)");
+    if (n_closest >= (1u << 26) || n_shadow >= (1u << 26)) return fail(ctx, "rt_scene_import_folds: too many records");
+    (void)hipSetDevice(ctx->device);
+    // what can be checked: every ref is a record of the same array, a leaf inside the triangle array, or empty
+    const uint32_t nt = s.n_tris;
+    auto sane = [&](const WideNode* r, uint32_t n, uint32_t entry) -> bool
+    {
+        if (entry >= n) return false;
+        for (uint32_t i = 0; i < n; ++i)
+            for (uint32_t ref : r[i].ref)
+            {
+                if (ref == RT_EMPTY_REF) continue;
+                if (ref & RT_LEAF_BIT) { if ((ref & ~RT_LEAF_BIT) >= nt) return false; }
+                else if (ref >= n) return false;
+            }
+        return true;
+    };
+    if (!sane((const WideNode*)closest_records, n_closest, entry_closest)) return fail(ctx, "rt_scene_import_folds: the closest-hit records do not fit this scene (a ref outside the records / the triangles)");
+    if (n_shadow && (!shadow_records || !sane((const WideNode*)shadow_records, n_shadow, entry_shadow))) return fail(ctx, "rt_scene_import_folds: the shadow records do not fit this scene");
+    // nothing in flight may still read the records that go: batches traced ahead are dropped, every stream drains, an adaptation of this context's own is abandoned
+    for (rt_frame* f : ctx->frames) ahead_discard(f);
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    for (rt_frame* f : ctx->frames)
+        if (sync_frame_streams(f) != RT_OK) return RT_ERROR;
+    if (s.adapt) { drop_fold_adapt(s.adapt); s.adapt = nullptr; }
+    void *cl = nullptr, *sh = nullptr;
+    int rc = dev_alloc_copy(ctx, &cl, closest_records, (size_t)n_closest * sizeof(WideNode));
+    if (rc == RT_OK && n_shadow) rc = dev_alloc_copy(ctx, &sh, shadow_records, (size_t)n_shadow * sizeof(WideNode));
+    if (rc == RT_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail(ctx, "rt_scene_import_folds: upload failed");
+    if (rc != RT_OK) { if (cl) (void)hipFree(cl); if (sh) (void)hipFree(sh); (void)hipGetLastError(); return RT_ERROR; }
+    const bool closest_is_own = s.wnodes_cl != nullptr && s.d.wnodes == (const float4*)s.wnodes_cl;      // (tolerance mode: the closest-hit rays walk wnodes_cl)
+    if (closest_is_own) { (void)hipFree(s.wnodes_cl); s.wnodes_cl = cl; s.n_wide_cl = n_closest; }
+    else { if (s.wnodes) (void)hipFree(s.wnodes); s.wnodes = cl; s.n_wide = n_closest; }
+    s.d.wnodes = (const float4*)cl; s.d.w_entry_ref = entry_closest;
+    if (s.wnodes_sh) { (void)hipFree(s.wnodes_sh); s.wnodes_sh = nullptr; s.n_wide_sh = 0; }
+    if (n_shadow) { s.wnodes_sh = sh; s.n_wide_sh = n_shadow; s.d.wnodes_sh = (const float4*)sh; s.d.w_sh_entry_ref = entry_shadow; }
+    else { s.d.wnodes_sh = s.d.wnodes; s.d.w_sh_entry_ref = s.d.w_entry_ref; }
+    char line[200];
+    const size_t at = s.tree_report.find("imported folds");
+    if (at != std::string::npos) s.tree_report.erase(at);
+    snprintf(line, sizeof(line), "imported folds: %u closest-hit + %u shadow records taken from another context of the group; this context's own adaptation is off\n", n_closest, n_shadow);
+    s.tree_report += line;
+    return RT_OK;
+}

@@ -54,26 +54,13 @@ RT_DEV void log_store(float* __restrict__ rlog, size_t index, float x, float y, 
 
 // Non-temporal queue accesses (round 6).  A trace launch reads every ray of its queue and writes every hit exactly once; marked non-temporal (the `nt` bit of
 // global_load / global_store) those streams do not push the trees' records out of an XCD's 4 MB of L2.  Measured as build variants on the same box, two runs
-// each (profiles/r06_call02.log): the 10 M-triangle config, whose closest-hit walk misses the L2 for 45 % of its record fetches, 3785 / 3788 -> 3864 / 3870
-// Mrays/s (closest-hit trace 10.31 -> 10.02 ms per sample); the 2.8 M-triangle headline 6940 / 6946 -> 6915 / 6928 (inside the boxes' spread); the same hint
-// on k_shade's streams moved nothing on either (dropped).  RT_NT_ACCESS: bit 0 = the ray fetch and the hit store (adopted), bit 2 = EXPERIMENT: the leaf
-// loop's triangle records too (tools/build_variants.py -DRT_NT_ACCESS=5).
+// each (profiles/r06/call02.log, call03.log): the 10 M-triangle config, whose closest-hit walk misses the L2 for 45 % of its record fetches, 3785 / 3788 ->
+// 3864 / 3870 Mrays/s (closest-hit trace 10.31 -> 10.02 ms per sample) and again 3766 / 3780 -> 3833 / 3859; the 2.8 M-triangle headline 6940 / 6946 ->
+// 6915 / 6928 on one box, 6800 / 6812 -> 6871 / 6888 on the next.  The same hint on k_shade's streams moved nothing on either (dropped); on the leaf loop's
+// triangle records it LOSES 9 % / 22 % (6308 / 2994: those records are re-read by the neighbouring rays of the wave and the next waves -- dropped).
 typedef float rt_v4f __attribute__((ext_vector_type(4)));
-#ifndef RT_NT_ACCESS
-#define RT_NT_ACCESS 1
-#endif
-template <int BIT>
-RT_DEV float4 q_load(const float4* p)
-{
-    if ((RT_NT_ACCESS >> BIT) & 1) { const rt_v4f t = __builtin_nontemporal_load((const rt_v4f*)p); return make_float4(t.x, t.y, t.z, t.w); }
-    return *p;
-}
-template <int BIT>
-RT_DEV void q_store(float4* p, const float4& v)
-{
-    if ((RT_NT_ACCESS >> BIT) & 1) { const rt_v4f t = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(t, (rt_v4f*)p); }
-    else *p = v;
-}
+RT_DEV float4 q_load(const float4* p) { const rt_v4f t = __builtin_nontemporal_load((const rt_v4f*)p); return make_float4(t.x, t.y, t.z, t.w); }
+RT_DEV void q_store(float4* p, const float4& v) { const rt_v4f t = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(t, (rt_v4f*)p); }
 
 // Where the entries of a path's radiance log live.  FULL layout (inline_entries = 2 (B + 1), the worst case a path can
 // log): entry k of path id at row-major index k * stride + id.  COMPACT layout (round 3; rt_integrate with many samples in

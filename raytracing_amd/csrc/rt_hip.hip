@@ -43,6 +43,7 @@ struct Scene
     void* wnodes_sh = nullptr;   // the shadow rays' own 4-wide tree (own_bvh.h over the reference's leaves); nullptr = they share wnodes
     void* wnodes_cl = nullptr;   // RT_CTX_OPT_CLOSEST_TREE = 1 (tolerance mode): the closest-hit rays' own tree
     uint32_t n_wide_sh = 0, n_wide_cl = 0;
+    uint32_t n_tris = 0;         // triangles of the uploaded scene (rt_scene_import_folds checks leaf refs against it)
     std::string tree_report;     // what rt_scene_upload measured when it chose the trees (rt_scene_tree_report)
     FoldAdapt* adapt = nullptr;  // RT_CTX_OPT_ADAPTIVE_FOLD: armed at upload, run by the first rt_integrate (fold_adapt_hook)
     DScene d = {};
@@ -797,6 +798,7 @@ int rt_scene_upload(rt_ctx* ctx, const rt_scene_desc* sd)
     s.d.w_sh_entry_ref = have_sh ? w_entry_sh : w_entry;
     if (have_cl) { s.d.wnodes = (const float4*)s.wnodes_cl; s.d.w_entry_ref = w_entry_cl; }
     s.n_wide = have_wide ? n_wide_ref : 0u;
+    s.n_tris = nt;
     s.n_wide_sh = have_sh ? (uint32_t)own_sh.wide.size() : 0u;
     s.n_wide_cl = have_cl ? (uint32_t)own_cl.wide.size() : 0u;
     s.wide_ok = have_wide;

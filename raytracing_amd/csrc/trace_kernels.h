@@ -855,7 +855,7 @@ RT_DEV void w4_trace_body(const DScene& sc, const float4* __restrict__ o4, const
                         log_retract(log, log_entry, payload);
                 }
                 else
-                    q_store<0>(hits + ray_i, make_float4(hit_u, hit_v, __uint_as_float(hit_prim), t_max));
+                    q_store(hits + ray_i, make_float4(hit_u, hit_v, __uint_as_float(hit_prim), t_max));
                 if (TIMELINE)
                 {
                     const unsigned long long dt = wall_clock64() - tl_t0;
@@ -927,7 +927,7 @@ RT_DEV void w4_trace_body(const DScene& sc, const float4* __restrict__ o4, const
                 bool slow = false;
                 if (ref == RT_IDLE_REF && ray_i != RT_INVALID_ID)
                 {
-                    const float4 q0 = q_load<0>(o4 + ray_i), q1 = q_load<0>(d4 + ray_i);
+                    const float4 q0 = q_load(o4 + ray_i), q1 = q_load(d4 + ray_i);
                     if (SHADOW) { payload = __float_as_uint(q1.w); log_entry = aux[ray_i]; }
                     org = F3(q0.x, q0.y, q0.z);
                     dir = F3(q1.x, q1.y, q1.z);
@@ -1013,7 +1013,7 @@ RT_DEV void w4_trace_body(const DScene& sc, const float4* __restrict__ o4, const
                     {
                         const uint32_t prim = ref & ~(RT_LEAF_BIT | RT_LEAF_CONT_BIT);
                         const float4* tp = reinterpret_cast<const float4*>(tri_base + (size_t)(prim << 6));
-                        const float4 q0 = q_load<2>(tp), q1 = q_load<2>(tp + 1), q2 = q_load<2>(tp + 2), q3 = q_load<2>(tp + 3);
+                        const float4 q0 = tp[0], q1 = tp[1], q2 = tp[2], q3 = tp[3];
                         leaf_step(q0, q1, q2, q3, prim);
                     }
                     leaf_m = __ballot((int)ref < -1);

@@ -23,7 +23,7 @@ EXPORTS = [
     "rth_render_read_radiance", "rth_render_read_resolved", "rth_render_stats", "rth_render_frame_handle",
     "rth_render_ctx_handle", "rth_render_num_nodes", "rth_render_nodes", "rth_render_set_aov", "rth_render_resolve",
     "rth_render_set_blue_noise_path", "rth_render_reserve_samples", "rth_scene_save_cache", "rth_load_jpeg",
-    "rth_render_upload_gpu_data", "rth_render_setup_seconds",
+    "rth_render_upload_gpu_data", "rth_render_setup_seconds", "rth_render_create_with_options",
 ]
 
 
@@ -54,6 +54,7 @@ def load():
         "rth_load_jpeg": (i32, [cp, C.POINTER(u32), C.POINTER(u32)]),
         "rth_default_camera": (None, [u32, u32, vp]), "rth_make_camera": (None, [f32] * 9 + [vp]),
         "rth_render_create": (vp, [u32, u32, vp, i32, u32, u32, u32]), "rth_render_destroy": (None, [vp]),
+        "rth_render_create_with_options": (vp, [u32, u32, vp, i32, u32, u32, u32, vp, u32]),
         "rth_render_set_camera": (i32, [vp, vp]), "rth_render_set_max_bounces": (i32, [vp, u32]),
         "rth_render_enable_white_furnace": (i32, [vp, i32]), "rth_render_set_sampler": (i32, [vp, i32]),
         "rth_render_enable_denoiser": (i32, [vp, i32]), "rth_render_set_resolve_every_frame": (i32, [vp, i32]),
@@ -225,12 +226,18 @@ class Scene:
 class Render:
     """rt::Render: headless Render(width, height, scene) -> RenderFrame()."""
 
-    def __init__(self, width, height, scene, device=0, tile_rank=0, tile_count=1, band_height=8):
+    def __init__(self, width, height, scene, device=0, tile_rank=0, tile_count=1, band_height=8, ctx_options=()):
+        """ctx_options: (rt_ctx_option, value) pairs set on the context BEFORE the scene is uploaded (a rank that will take another rank's folds uploads
+        without a shadow tree and an adaptation of its own: ((2, 0), (4, 0)))"""
         self.lib = load()
         self.scene = scene
         self.width, self.height = width, height
-        self.handle = self.lib.rth_render_create(width, height, scene.handle, device, tile_rank, tile_count,
-                                                 band_height)
+        if ctx_options:
+            flat = np.asarray([v for pair in ctx_options for v in pair], np.uint32)
+            self.handle = self.lib.rth_render_create_with_options(width, height, scene.handle, device, tile_rank, tile_count, band_height, flat.ctypes.data, len(ctx_options))
+        else:
+            self.handle = self.lib.rth_render_create(width, height, scene.handle, device, tile_rank, tile_count,
+                                                     band_height)
         if not self.handle:
             raise _err(self.lib)
         self.local_rows = self.lib.rth_render_local_rows(self.handle)

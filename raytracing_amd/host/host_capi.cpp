@@ -160,6 +160,18 @@ void* rth_render_create(uint32_t w, uint32_t h, void* scene, int device, uint32_
         return new rt::Render(w, h, *(rt::Scene*)scene, device, t);
     }, nullptr);
 }
+// ... with context options set before the upload: options = n_options x {option, value}
+void* rth_render_create_with_options(uint32_t w, uint32_t h, void* scene, int device, uint32_t tile_rank, uint32_t tile_count,
+    uint32_t band_height, const uint32_t* options, uint32_t n_options)
+{
+    return guard([&]() -> void*
+    {
+        rt::TileDesc t; t.rank = tile_rank; t.count = tile_count; t.band_height = band_height;
+        std::vector<std::pair<int, std::uint32_t>> opts;
+        for (uint32_t i = 0; i < n_options; ++i) opts.emplace_back((int)options[2 * i], options[2 * i + 1]);
+        return new rt::Render(w, h, *(rt::Scene*)scene, device, t, opts);
+    }, nullptr);
+}
 void rth_render_destroy(void* r) { delete (rt::Render*)r; }
 int rth_render_set_camera(void* r, const rt_camera* cam) { return guard([&]() { ((rt::Render*)r)->SetCamera(*cam); return 0; }, 1); }
 int rth_render_set_max_bounces(void* r, uint32_t b) { return guard([&]() { ((rt::Render*)r)->GetIntegrator().SetMaxBounces(b); return 0; }, 1); }

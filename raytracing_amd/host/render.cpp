@@ -28,10 +28,13 @@ Camera DefaultCamera(std::uint32_t width, std::uint32_t height)
         (float)width / (float)height, 0.0f, 10.0f);
 }
 
-Render::Render(std::uint32_t width, std::uint32_t height, Scene& scene, int device_ordinal, TileDesc tile)
+Render::Render(std::uint32_t width, std::uint32_t height, Scene& scene, int device_ordinal, TileDesc tile,
+    std::vector<std::pair<int, std::uint32_t>> const& context_options)
     : scene_(scene), width_(width), height_(height)
 {
     context_ = std::make_shared<HIPContext>(device_ordinal);
+    for (auto const& o : context_options)
+        if (rt_ctx_set_option(context_->Get(), o.first, o.second) != RT_OK) throw HIPException(rt_last_error(context_->Get()));
     auto now = []() { return std::chrono::steady_clock::now(); };
     auto since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double>(now() - t).count(); };
     // Build first, Finalize after: the build reorders the triangles the emissive
@@ -92,6 +95,12 @@ TiledRender::TiledRender(std::uint32_t width, std::uint32_t height, Scene& scene
     for (std::size_t i = 0; i < devices.size(); ++i)
     {
         contexts_.push_back(std::make_unique<HIPContext>(devices[i]));
+        // one adaptation per group (ShareFolds): tile 0 builds the shadow rays' tree and adapts its folds -- waited for by its first frame -- the others take its records
+        if (devices.size() > 1)
+        {
+            if (i == 0) rt_ctx_set_option(contexts_[i]->Get(), RT_CTX_OPT_ADAPT_WAIT, 1u);
+            else { rt_ctx_set_option(contexts_[i]->Get(), RT_CTX_OPT_SHADOW_TREE, 0u); rt_ctx_set_option(contexts_[i]->Get(), RT_CTX_OPT_ADAPTIVE_FOLD, 0u); }
+        }
         TileDesc tile;
         tile.rank = (std::uint32_t)i;
         tile.count = (std::uint32_t)devices.size();
@@ -170,6 +179,20 @@ void TiledRender::RenderSamples(std::uint32_t n)
     for (auto& w : workers) w.join();
     camera_changed_ = false;
     for (auto& e : errors) if (!e.empty()) throw HIPException(e);
+    if (!folds_shared_ && integrators_.size() > 1) ShareFolds();
+}
+
+void TiledRender::ShareFolds()
+{
+    folds_shared_ = true;
+    rt_ctx* root = contexts_[0]->Get();
+    std::uint32_t n = 0, m = 0, entries[2] = {0, 0};
+    if (rt_scene_export_folds(root, nullptr, nullptr, 0, &n, &m, entries) != RT_OK) return;          // (no 4-wide tree: nothing to share)
+    std::vector<unsigned char> cl((std::size_t)n * 64), sh((std::size_t)(m ? m : 1) * 64);
+    if (rt_scene_export_folds(root, cl.data(), sh.data(), n > m ? n : m, &n, &m, entries) != RT_OK) throw HIPException(rt_last_error(root));
+    for (std::size_t i = 1; i < contexts_.size(); ++i)
+        if (rt_scene_import_folds(contexts_[i]->Get(), cl.data(), n, entries[0], m ? sh.data() : nullptr, m, entries[1]) != RT_OK)
+            throw HIPException(rt_last_error(contexts_[i]->Get()));
 }
 
 std::vector<float> TiledRender::GatherRadiance(int root)

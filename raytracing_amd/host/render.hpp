@@ -2,6 +2,7 @@
 // the integrator and the camera (reference: src/render.{hpp,cpp}, minus the
 // window, GL framebuffer and ImGui).  RenderFrame() = one sample per pixel.
 #pragma once
+#include <utility>
 #include <memory>
 #include <vector>
 #include "bvh.hpp"
@@ -17,7 +18,10 @@ Camera MakeCamera(float3 position, float yaw, float pitch, float fov, float aspe
 class Render
 {
 public:
-    Render(std::uint32_t width, std::uint32_t height, Scene& scene, int device_ordinal = 0, TileDesc tile = TileDesc());
+    // context_options: (rt_ctx_option, value) pairs set on the context before the scene is uploaded -- e.g. a rank of a group that will take another
+    // rank's folds (rt_scene_import_folds) uploads without a shadow tree and without an adaptation of its own: {{2, 0}, {4, 0}}
+    Render(std::uint32_t width, std::uint32_t height, Scene& scene, int device_ordinal = 0, TileDesc tile = TileDesc(),
+        std::vector<std::pair<int, std::uint32_t>> const& context_options = {});
 
     void RenderFrame();                          // render.cpp:172-204 without present/GUI
     void RenderSamples(std::uint32_t n);         // n samples through the fused fast path
@@ -66,6 +70,10 @@ public:
     rt_stats GetStats() const;                            // ray counters summed over the tiles
     std::size_t GetTileCount() const { return integrators_.size(); }
     std::vector<double> const& GetLastTileSeconds() const { return tile_seconds_; }
+    // One fold adaptation per GROUP: tile 0 adapts (its first RenderSamples waits for it), the other tiles -- uploaded without a shadow tree or an adaptation
+    // of their own -- take its records (rt_scene_export_folds / rt_scene_import_folds).  Called by the first RenderSamples; results do not depend on it.
+    void ShareFolds();
+    bool FoldsShared() const { return folds_shared_; }
     HIPContext& GetContext(std::size_t i) { return *contexts_[i]; }
     AccelerationStructure const& GetAccelerationStructure() const { return *acc_structure_; }
 
@@ -76,6 +84,7 @@ private:
     std::vector<std::unique_ptr<HIPContext>> contexts_;
     std::vector<std::unique_ptr<HIPPathTraceIntegrator>> integrators_;
     std::vector<double> tile_seconds_;
+    bool folds_shared_ = false;
     rt_group* group_ = nullptr;
     Camera camera_;
     bool camera_changed_ = true;

@@ -64,3 +64,25 @@ def test_bench_py_two_tiles_gather_the_reference_kernels_frame(tmp_path):
         assert line["cpu_baseline"] is None                             # timed at N = 1 only
         # --debug-try-rccl: RCCL refuses two ranks on one device; every rank then agrees on the gloo gather and the line says why
         assert ("RCCL FALLBACK" in line["gather"]["transport"]) == bool(extra), line["gather"]
+        # one fold adaptation per group (round 6): rank 1 uploaded without a shadow tree / an adaptation and took rank 0's records
+        assert line["ranks"]["fold_share"]["records"][0] > 0, line["ranks"]
+
+
+def test_bench_py_eight_ranks_share_one_gpu_and_one_adaptation(tmp_path):
+    """The driver's N = 8 launch on the one GPU of a test box (--debug-shared-gpu): eight processes, eight tiles of interleaved bands, rank 0's scene cache,
+    ONE fold adaptation for the group -- rank 0's records broadcast to the seven others, which uploaded without a shadow tree or an adaptation of their own
+    (their set-up is the cheap part: `setup_breakdown`) -- and the frame gathered from the eight tiles is the reference kernels' frame bit for bit."""
+    from tests import _ref
+    if not _ref.available():
+        pytest.skip("oracle/_ref is not built here")
+    obj = S.shader_balls_obj(str(tmp_path), 2000)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--debug-shared-gpu", "--scene", obj, "--width", "320",
+                        "--height", "200", "--bounces", "4", "--steps", "1", "--warmup", "1", "--samples-per-step", "4"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 8 and line["value"] > 0
+    assert len(line["ranks"]["render_ms"]) == 8 and sum(line["ranks"]["rows"]) == 200
+    assert line["ranks"]["fold_share"]["records"][0] > 0
+    p = line["parity"]
+    assert p["tiles"] == 8 and p["bit_identical"] is True and p["differing_pixels"] == 0, p

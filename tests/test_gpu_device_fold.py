@@ -116,3 +116,40 @@ def test_a_scene_renders_the_same_bits_with_the_fold_on_the_device_or_on_the_hos
     orc = _oracle.Oracle(w, h, sc)
     orc.set_camera(cam); orc.set_max_bounces(b); orc.integrate(spp)
     assert np.array_equal(images[0][..., :3], orc.radiance()[..., :3], equal_nan=True)
+
+
+def test_one_context_takes_another_contexts_folds(golden_scenes):
+    """rt_scene_export_folds / rt_scene_import_folds (one fold adaptation per process GROUP): context A adapts its folds (waited for), context B -- the same scene
+    uploaded WITHOUT a shadow tree and without an adaptation of its own, as a rank > 0 of a group does -- takes A's records; both render the oracle's bits, B walks
+    A's records (same bytes), and records that do not fit the scene are refused."""
+    w, h, b, spp = 96, 64, 4, 5
+    sc = golden_scenes["coverage"]
+    cam = T.default_camera(w, h)
+    A, B = capi.Context(0), capi.Context(0)
+    assert A.lib.rt_ctx_set_option(A.handle, 4, 31) == 0 and A.lib.rt_ctx_set_option(A.handle, 2, 2) == 0     # adapt + wait, own shadow tree forced
+    assert B.lib.rt_ctx_set_option(B.handle, 4, 0) == 0 and B.lib.rt_ctx_set_option(B.handle, 2, 0) == 0
+    A.upload_scene(sc); B.upload_scene(sc)
+    fa, fb = capi.Frame(A, w, h), capi.Frame(B, w, h)
+    for f in (fa, fb):
+        f.set_camera(cam); f.set_max_bounces(b)
+    fa.integrate(2)                                                           # A's first integrate probes, folds again and adopts
+    cl, sh, ent = capi.export_folds(A.handle)
+    assert len(cl) > 0 and len(sh) > 0
+    fb.integrate(2)
+    capi.import_folds(B.handle, cl, sh, ent)
+    assert "imported folds" in B.lib.rt_scene_tree_report(B.handle).decode()
+    cl2, sh2, ent2 = capi.export_folds(B.handle)
+    assert ent2 == ent and np.array_equal(cl2, cl) and np.array_equal(sh2, sh)
+    fa.integrate(spp - 2); fb.integrate(spp - 2)
+    assert np.array_equal(fa.radiance(), fb.radiance(), equal_nan=True)
+    orc = _oracle.Oracle(w, h, sc)
+    orc.set_camera(cam); orc.set_max_bounces(b); orc.integrate(spp)
+    assert np.array_equal(fb.radiance()[..., :3], orc.radiance()[..., :3], equal_nan=True)
+    # refused: a ref outside the records, a leaf outside the triangles
+    bad = cl.copy().view(np.uint32).reshape(len(cl), 16)
+    bad[0, 10] = len(cl) + 5                                                  # ref[0] of record 0
+    with pytest.raises(capi.RtError, match="do not fit"):
+        capi.import_folds(B.handle, bad.view(np.uint8).reshape(len(cl), 64), sh, ent)
+    fb.integrate(1); fa.integrate(1)                                           # ... and B is still intact
+    assert np.array_equal(fa.radiance(), fb.radiance(), equal_nan=True)
+    fa.close(); fb.close(); A.close(); B.close()

@@ -161,7 +161,18 @@ def test_random_scene_matches_oracle_bit_for_bit(ctx, env_map, seed):
     # k_frame (round 5): every fifth seed renders its samples through the stage API with RT_OPT_FRAME_KERNEL (1: every block resident, 2 / 3: that
     # many chunks per wave) -- one launch per sample in which each wave carries its own pixels through all the bounces; where the frame is not
     # eligible (compact log, a forced kernel variant) the same calls take the stage kernels
-    if seed % 5 == 2:
+    # RT_OPT_SAMPLES_AHEAD (round 6): every seventh seed renders at least six samples through the stage API with the next samples traced ahead in batches
+    # of 2 / 3 (one stream, or one per bank) and replayed one per call -- the sum must be the oracle's all the same
+    ahead = seed % 7 == 3 and seed % 5 != 2
+    if ahead:
+        spp = max(spp, 6)
+        fr.set_option(capi.OPT_SAMPLES_AHEAD, (2, 3, 256 + 2, 64)[(seed // 7) % 4])
+        for _ in range(spp):
+            fr.generate_rays()
+            for bounce in range(bounces + 1):
+                fr.intersect(bounce); fr.shade(bounce); fr.intersect_shadow(bounce)
+            fr.advance_sample()
+    elif seed % 5 == 2:
         fr.set_option(capi.OPT_FRAME_KERNEL, (1, 2, 3)[(seed // 5) % 3])
         for _ in range(spp):
             fr.generate_rays()
@@ -177,4 +188,7 @@ def test_random_scene_matches_oracle_bit_for_bit(ctx, env_map, seed):
     got, want = fr.radiance()[..., :3], orc.radiance()[..., :3]
     assert np.array_equal(got, want, equal_nan=True), (seed, np.argwhere(~np.isclose(got, want, equal_nan=True))[:4])
     st = fr.stats()
-    assert (st.closest_rays, st.shadow_rays) == orc.ray_totals()
+    if ahead:
+        assert st.samples_from_banks == spp - 3 and st.samples == spp, (seed, st.samples_from_banks, spp)      # (the banks' ray totals run ahead: rt_stats.samples_ahead)
+    else:
+        assert (st.closest_rays, st.shadow_rays) == orc.ray_totals()
