@@ -1164,25 +1164,32 @@ def main():
                 t_a = time.perf_counter()
                 render.set_adaptive_fold(capi.ADAPTIVE_FOLD_DEFAULT)                      # ... and uploads the scene again (rt_scene_upload)
                 t_b = time.perf_counter()
-                c0 = render.stats()
                 assert lib.rt_reset(frame) == 0
+                render.finish()
+                c0 = render.stats()
+                cold_in_flight = render.reserve_samples(args.cold_job_spp)               # the per-path buffers of the job's batches: hipMalloc of ~100 GB is not free
+                render.finish()
+                t_r = time.perf_counter()
                 render.render_samples(args.cold_job_spp)
                 render.finish()
                 gather(True)
                 t_c = time.perf_counter()
                 c1 = render.stats()
                 c_rays = float((c1.closest_rays - c0.closest_rays) + (c1.shadow_rays - c0.shadow_rays))
-                cold_job = dict(spp=args.cold_job_spp, upload_s=round(t_b - t_a, 3), render_s=round(t_c - t_b, 3), wall_s=round(t_c - t_a, 3),
-                                mrays_per_s_render=round(c_rays / (t_c - t_b) / 1e6, 1), mrays_per_s_wall=round(c_rays / (t_c - t_a) / 1e6, 1),
-                                over_the_warm_headline=round(c_rays / (t_c - t_b) / 1e6 / value, 4) if value > 0 else None,
+                cold_job = dict(spp=args.cold_job_spp, upload_s=round(t_b - t_a, 3), alloc_s=round(t_r - t_b, 3), samples_in_flight=int(cold_in_flight),
+                                render_s=round(t_c - t_r, 3), wall_s=round(t_c - t_a, 3),
+                                mrays_per_s_render=round(c_rays / (t_c - t_r) / 1e6, 1), mrays_per_s_wall=round(c_rays / (t_c - t_a) / 1e6, 1),
+                                over_the_warm_headline=round(c_rays / (t_c - t_r) / 1e6 / value, 4) if value > 0 else None,
                                 trees=render.tree_report().strip().split("\n"),
                                 what="the config's whole job, cold: rt_scene_upload (re-layout, folds, own tree, tree choice) + %d spp + the gather, library defaults "
-                                     "(adaptive fold 25 = asynchronous: the job starts on the upload's fold and adopts the adapted one when its worker is done), per-path "
-                                     "buffers allocated inside the timer; scene generation / OBJ parsing and the reference-topology BVH build are in setup_s" % args.cold_job_spp)
+                                     "(adaptive fold 25 = asynchronous: the job starts on the upload's fold and adopts the adapted one when its worker is done), the per-path "
+                                     "buffers of its batches allocated inside the wall time (alloc_s); scene generation / OBJ parsing and the reference-topology BVH build are in setup_s" % args.cold_job_spp)
             except Exception as e:                              # noqa: BLE001 -- reported, never fatal to the measurement
                 cold_job = dict(error=repr(e))
         scaling_estimate = None
-        est_path = os.path.join(ROOT, "profiles", "r05_tile_efficiency.json")
+        est_path = os.path.join(ROOT, "profiles", "r06_tile_efficiency.json")
+        if not os.path.exists(est_path):
+            est_path = os.path.join(ROOT, "profiles", "r05_tile_efficiency.json")
         if os.path.exists(est_path) and args.config == 4:
             try:
                 scaling_estimate = json.load(open(est_path))

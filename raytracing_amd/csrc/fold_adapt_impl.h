@@ -140,7 +140,12 @@ struct FoldAdapt
     // earlier adoption replaced after a device synchronisation of ITS thread (every launch that could still read them was enqueued before
     // that adoption).  The render thread only exchanges pointers: no hipDeviceSynchronize, no hipMalloc / hipFree between two frames.
     int device = -1;                                                     // -1: host only (rt_debug_fold_abandon)
-    bool device_fold = false;                                            // RT_CTX_OPT_DEVICE_FOLD: crossing counts and re-folds on `device`
+    bool device_fold = false;                                            // RT_CTX_OPT_DEVICE_FOLD: crossing counts and re-folds on `device` ...
+    // ... when the device has nothing better to do: with bit 1 (rt_integrate waits for the adaptation) it is idle and the folds on it shorten the wait
+    // (1.33 -> 1.09 s to the adapted fold on the headline scene, 8.5 -> 7.1 s on the 10 M-triangle one: profiles/r06/call03.log); asynchronously -- the library's
+    // default -- the frames keep it busy and the host's threads are what is free: the same folds on the device took an orbiting camera's frames from
+    // + 2 .. 4 % to + 23 % (per_frame.moving_camera, profiles/r06/call04.log), so there the worker folds on host threads as it did before.
+    int worker_fold_device() const { return device_fold && (mode.load() & 2u) ? device : -1; }
     bool pairs = false;                                                  // RT_CTX_OPT_WIDE_LAYOUT
     void *new_cl = nullptr, *new_sh = nullptr;
     bool upload_failed = false;
@@ -239,7 +244,7 @@ bool adapt_shadow_candidate(FoldAdapt* a)
     const std::vector<uint32_t>& roots = a->roots_sh.empty() ? a->roots : a->roots_sh;
     a->rotations = 0;
     a->bvh2_sh_new.clear();
-    const int fold_device = a->device_fold ? a->device : -1;
+    const int fold_device = a->worker_fold_device();
     bool ok = refold_for_rays(tree, a->sh_o, a->sh_d, roots, a->wide_sh, a->entry_sh, a->cost[1], a->cancel, &a->roots_sh_new, fold_device, a->pairs);
     if (!(a->mode.load() & 8u) || a->sh_o.empty() || a->cancel.load()) return ok;
     std::vector<rt_bvh_node> rotated;
@@ -357,7 +362,7 @@ void fold_adapt_worker(FoldAdapt* a)
     if (!a->o.empty())
     {
         std::thread shadow([a]() { a->ok_sh = adapt_shadow_side(a); });
-        a->ok = refold_for_rays(a->bvh2, a->o, a->d, a->roots, a->wide, a->entry, a->cost[0], a->cancel, &a->roots_new, a->device_fold ? a->device : -1, a->pairs);
+        a->ok = refold_for_rays(a->bvh2, a->o, a->d, a->roots, a->wide, a->entry, a->cost[0], a->cancel, &a->roots_new, a->worker_fold_device(), a->pairs);
         shadow.join();
         fold_upload(a);
     }

@@ -16,6 +16,7 @@ ap.add_argument("--tiles", default="1,2,4,8")
 ap.add_argument("--band-height", type=int, default=8)
 ap.add_argument("--adaptive-fold", type=int, default=27)
 ap.add_argument("--json", default=None)
+ap.add_argument("--pipelines", type=int, default=0, help="RT_OPT_PIPELINES for the tiles' frames (0 = the library's default, 1)")
 a = ap.parse_args()
 cfg = bench.CONFIGS[a.config]
 args = argparse.Namespace(config=a.config, blob_tris=871_200, ball_tris=20_000, scene=None, width=cfg["width"], height=cfg["height"], bounces=cfg["bounces"])
@@ -38,6 +39,8 @@ for n in [int(x) for x in a.tiles.split(",")]:
         render.set_max_bounces(cfg["bounces"])
         render.set_resolve_every_frame(False)
         frame = host.load().rth_render_frame_handle(render.handle)
+        if a.pipelines:
+            assert lib.rt_set_option(frame, capi.OPT_PIPELINES, a.pipelines) == 0
         for j in jobs:
             in_flight[j] = render.reserve_samples(j)
             render.render_samples(min(j, 64)); render.finish()
