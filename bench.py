@@ -654,6 +654,7 @@ def main():
                     "hooks' pattern is ONE launch of k_frame")
     ap.add_argument("--share-folds", type=int, default=1, help="N > 1: 1 (default) = one fold adaptation per process group (rank 0's records are broadcast), 0 = every rank adapts itself")
     ap.add_argument("--wide-layout", type=int, default=None, help="RT_CTX_OPT_WIDE_LAYOUT (library default 0): 1 = the 4-wide records in (parent, likeliest child) pairs, one pair per 128-byte line")
+    ap.add_argument("--tree-builder", type=int, default=None, help="RT_CTX_OPT_TREE_BUILDER (library default 0): 1 = the shadow rays' own binary tree built on the device (PLOC)")
     ap.add_argument("--device-fold", type=int, default=None, help="RT_CTX_OPT_DEVICE_FOLD (library default 1): 0 = the folds on host threads")
     ap.add_argument("--samples-ahead", type=int, default=None, help="RT_OPT_SAMPLES_AHEAD for the per_frame leg (HIPPathTraceIntegrator's default: 1 = automatic depth; "
                     "0 = every Integrate() traces its own sample; k = 2..64 samples per batch; + 256 = one stream per bank)")
@@ -755,7 +756,9 @@ def main():
         render.set_wide_bvh(args.wide_collapse)               # A/B: uploads the scene again with the other collapse
     if share_folds and rank != 0:
         pass                                                  # (this rank's folds come from rank 0: nothing to set, nothing to upload again)
-    elif args.shadow_tree is not None or args.closest_tree is not None or args.adaptive_fold != capi.ADAPTIVE_FOLD_DEFAULT or args.wide_layout is not None or args.device_fold is not None:
+    elif args.shadow_tree is not None or args.closest_tree is not None or args.adaptive_fold != capi.ADAPTIVE_FOLD_DEFAULT or args.wide_layout is not None or args.device_fold is not None or args.tree_builder is not None:
+        if args.tree_builder is not None:
+            render.set_ctx_option(9, args.tree_builder, False)     # RT_CTX_OPT_TREE_BUILDER
         if args.wide_layout is not None:
             render.set_ctx_option(8, args.wide_layout, False)      # RT_CTX_OPT_WIDE_LAYOUT
         if args.device_fold is not None:

@@ -107,6 +107,11 @@ enum rt_ctx_option
                                       adaptation, whose crossing counts are a device kernel too); 0: on host threads (build_wide_bvh, the same algorithm:
                                       the two are compared record for record in tests/test_gpu_device_fold.py, and the host's is the fallback when the device
                                       path fails).  Results do not depend on it.  Takes effect at the next rt_scene_upload. */
+    , RT_CTX_OPT_TREE_BUILDER = 9  /* 0: the shadow rays' own binary tree (RT_CTX_OPT_SHADOW_TREE) is built by own_bvh.h's full-sweep SAH on host threads; 1: on the DEVICE --
+                                      PLOC (parallel locally-ordered clustering, Meister & Bittner 2017) over the reference's leaves in Morton order, the tree's own metric (projected
+                                      area along the directional lights + an isotropic share) as the merge cost, then the same fold (raytracing_amd/csrc/ploc_kernels.h).  Any binary tree
+                                      over the reference's leaves gives an any-hit query the reference's verdict; which candidate the shadow rays walk is still measured with proxy rays
+                                      (rt_scene_tree_report).  Takes effect at the next rt_scene_upload. */
     , RT_CTX_OPT_WIDE_LAYOUT = 8   /* 0: the 4-wide records in the fold's own (depth-first) order; 1: in PAIRS -- every record with interior slots at an even index,
                                       the child it hands most rays on to right behind it, i.e. in the same 128-byte line (the L2 of gfx950 fetches whole lines:
                                       a 64-byte record that misses pays for its line-mate anyway).  A permutation of the records: no result depends on it.
@@ -502,6 +507,10 @@ int rt_debug_device_fold(rt_ctx* ctx, const rt_bvh_node* nodes, uint32_t num_nod
 /* RT_CTX_OPT_WIDE_LAYOUT = 1 on its own (host only): the records of a fold of `nodes` (and the node each one tests) permuted in place into (parent,
  * likeliest child) pairs, by the area of the children's boxes. */
 int rt_debug_pair_layout(const rt_bvh_node* nodes, uint32_t num_nodes, void* records, uint32_t* roots, uint32_t num_records);
+/* ploc_kernels.h on its own: a binary tree over the leaves of `nodes` built on ctx's device with the metric of rt_debug_own_bvh (the same layout comes back: out_nodes[2 leaves - 1];
+ * NULL = count query); *seconds = the device path's time, *rounds = clustering rounds. */
+int rt_debug_device_tree(rt_ctx* ctx, const rt_bvh_node* nodes, uint32_t num_nodes, double iso_weight, const float* dirs, uint32_t n_dirs, rt_bvh_node* out_nodes, uint32_t capacity,
+    uint32_t* num_out, double* seconds, uint32_t* rounds);
 /* ... and the host's fold for given per-node weights (what an adaptation folds with), for that comparison */
 int rt_debug_wide_bvh_weights(const rt_bvh_node* nodes, uint32_t num_nodes, const double* weights, void* records, uint32_t* roots, uint32_t capacity,
     uint32_t* num_records, uint32_t* entry_ref);

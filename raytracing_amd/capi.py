@@ -63,7 +63,7 @@ EXPORTS = [
     "rt_compute_aovs", "rt_denoise", "rt_copy_history",
     "rt_frame_resolve", "rt_frame_present", "rt_frame_present_wait", "rt_frame_read_radiance", "rt_frame_radiance_device_ptr", "rt_frame_sample_count",
     "rt_frame_get_stats", "rt_frame_get_profile", "rt_frame_copy_radiance", "rt_frame_debug_read_queue", "rt_frame_debug_read_hits", "rt_debug_eval",
-    "rt_debug_wide_bvh", "rt_frame_debug_timeline", "rt_frame_debug_frame_rows", "rt_debug_own_bvh", "rt_debug_wide_bvh_metric", "rt_scene_tree_report", "rt_debug_choose_tree", "rt_debug_adapt_fold", "rt_debug_fold_abandon", "rt_debug_adapt_shadow_side", "rt_debug_rotate_tree", "rt_debug_fold_view_left", "rt_debug_device_fold", "rt_debug_wide_bvh_weights", "rt_debug_pair_layout", "rt_scene_export_folds", "rt_scene_import_folds",
+    "rt_debug_wide_bvh", "rt_frame_debug_timeline", "rt_frame_debug_frame_rows", "rt_debug_own_bvh", "rt_debug_wide_bvh_metric", "rt_scene_tree_report", "rt_debug_choose_tree", "rt_debug_adapt_fold", "rt_debug_fold_abandon", "rt_debug_adapt_shadow_side", "rt_debug_rotate_tree", "rt_debug_fold_view_left", "rt_debug_device_fold", "rt_debug_wide_bvh_weights", "rt_debug_pair_layout", "rt_debug_device_tree", "rt_scene_export_folds", "rt_scene_import_folds",
     "rt_group_create", "rt_group_unique_id", "rt_group_join", "rt_group_size", "rt_group_local_count", "rt_group_local_rank", "rt_group_comm_count",
     "rt_group_gather_radiance", "rt_group_destroy", "rt_group_last_error", "rt_group_denoise", "rt_group_create_local",
     "rt_group_create_unchecked",
@@ -122,6 +122,7 @@ def load():
         "rt_debug_device_fold": (i32, [vp, vp, u32, C.c_double, vp, u32, vp, vp, vp, u32, C.POINTER(u32), C.POINTER(u32), C.POINTER(C.c_double)]),
         "rt_debug_wide_bvh_weights": (i32, [vp, u32, vp, vp, vp, u32, C.POINTER(u32), C.POINTER(u32)]),
         "rt_debug_pair_layout": (i32, [vp, u32, vp, vp, u32]),
+        "rt_debug_device_tree": (i32, [vp, vp, u32, C.c_double, vp, u32, vp, u32, C.POINTER(u32), C.POINTER(C.c_double), C.POINTER(u32)]),
         "rt_scene_export_folds": (i32, [vp, vp, vp, u32, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]),
         "rt_scene_import_folds": (i32, [vp, vp, u32, u32, vp, u32, u32]),
         "rt_debug_rotate_tree": (i32, [vp, u32, vp, vp, u32, i32, vp, C.POINTER(C.c_double), C.POINTER(u32), i32, C.c_double]),
@@ -210,6 +211,19 @@ def device_fold(ctx, nodes, iso_weight=-1.0, dirs=None, weights=None):
                                 w.ctypes.data if w is not None else None, out.ctypes.data, roots.ctypes.data, cap, C.byref(n), C.byref(entry), C.byref(sec)):
         raise RtError(lib.rt_last_error(ctx.handle).decode())
     return out[:n.value].copy(), entry.value, roots[:n.value].copy(), sec.value
+
+
+def device_tree(ctx, nodes, iso_weight=1.0, dirs=None):
+    """rt_debug_device_tree: a binary tree over the leaves of `nodes` built on ctx's device (PLOC, raytracing_amd/csrc/ploc_kernels.h).  Returns (nodes, seconds, rounds)."""
+    lib = load()
+    nodes = np.ascontiguousarray(nodes)
+    d = np.ascontiguousarray(np.asarray(dirs, np.float32).reshape(-1, 3)) if dirs is not None else None
+    out = np.zeros(len(nodes), nodes.dtype)
+    n, sec, rounds = C.c_uint32(), C.c_double(), C.c_uint32()
+    if lib.rt_debug_device_tree(ctx.handle, nodes.ctypes.data, len(nodes), iso_weight, d.ctypes.data if d is not None and len(d) else None, len(d) if d is not None else 0,
+                                out.ctypes.data, len(out), C.byref(n), C.byref(sec), C.byref(rounds)):
+        raise RtError(lib.rt_last_error(ctx.handle).decode())
+    return out[:n.value].copy(), sec.value, rounds.value
 
 
 def wide_bvh_weights(nodes, weights):

@@ -55,6 +55,33 @@ int rt_debug_device_fold(rt_ctx* ctx, const rt_bvh_node* nodes, uint32_t num_nod
     return RT_OK;
 }
 
+int rt_debug_device_tree(rt_ctx* ctx, const rt_bvh_node* nodes, uint32_t num_nodes, double iso_weight, const float* dirs, uint32_t n_dirs, rt_bvh_node* out_nodes, uint32_t capacity,
+    uint32_t* num_out, double* seconds, uint32_t* rounds)
+{
+    if (!ctx || !nodes || num_nodes == 0 || !num_out) return fail(ctx, "rt_debug_device_tree: NULL argument");
+    (void)hipSetDevice(ctx->device);
+    ownbvh::Metric m;
+    m.iso = iso_weight;
+    for (uint32_t i = 0; i < n_dirs && dirs; ++i) m.dirs.push_back({std::fabs((double)dirs[3 * i]), std::fabs((double)dirs[3 * i + 1]), std::fabs((double)dirs[3 * i + 2])});
+    void* d_nodes = nullptr;
+    if (dev_alloc_copy(ctx, &d_nodes, nodes, (size_t)num_nodes * sizeof(rt_bvh_node)) != RT_OK) return RT_ERROR;
+    rt_bvh_node* d_tree = nullptr;
+    uint32_t n = 0;
+    std::vector<rt_bvh_node> tree;
+    const bool ok = devfold::build_tree(ctx->stream, (const rt_bvh_node*)d_nodes, num_nodes, nodes[0], &m, &d_tree, &n, &tree, nullptr, seconds, rounds);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_nodes);
+    if (d_tree) (void)hipFree(d_tree);
+    if (!ok) return fail(ctx, "rt_debug_device_tree: nothing to build (leaf root), or the device path failed");
+    *num_out = n;
+    if (out_nodes)
+    {
+        if (n > capacity) return fail(ctx, "rt_debug_device_tree: capacity too small");
+        memcpy(out_nodes, tree.data(), tree.size() * sizeof(rt_bvh_node));
+    }
+    return RT_OK;
+}
+
 int rt_debug_pair_layout(const rt_bvh_node* nodes, uint32_t num_nodes, void* records, uint32_t* roots, uint32_t num_records)
 {
     if (!nodes || !records || !roots || num_nodes == 0) return fail(nullptr, "rt_debug_pair_layout: NULL argument");

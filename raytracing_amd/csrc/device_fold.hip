@@ -9,6 +9,8 @@
 #include <chrono>
 #include "device_fold.h"
 #include "fold_kernels.h"
+#include "ploc_kernels.h"
+#include <hipcub/hipcub.hpp>
 
 namespace devfold
 {
@@ -119,6 +121,100 @@ bool fold(hipStream_t stream, const rt_bvh_node* d_nodes, uint32_t nn, const rt_
     }
     buf.release(recs);
     *d_records = recs; *n_records = total; *entry_ref = 0;
+    if (seconds) *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return true;
+}
+
+// ---- a binary tree over the reference's leaves, built on the device (ploc_kernels.h) ----
+// exclusive prefix sum of 0 / 1 flags over n elements with fold_kernels.h's three scan kernels: flags[i] becomes its rank (RT_EMPTY_REF where the flag was 0), list[rank] = i
+static bool scan_flags(hipStream_t stream, uint32_t* flags, uint32_t n, uint32_t* block_sums, uint32_t* d_total, uint32_t* list, uint32_t* total)
+{
+    const uint32_t blocks = (n + FOLD_SCAN_BLOCK - 1u) / FOLD_SCAN_BLOCK;
+    hipLaunchKernelGGL(k_fold_scan_sums, dim3(blocks), dim3(256), 0, stream, (const uint32_t*)flags, n, block_sums);
+    hipLaunchKernelGGL(k_fold_scan_blocks, dim3(1), dim3(1024), 0, stream, block_sums, blocks, d_total);
+    hipLaunchKernelGGL(k_fold_scan_apply, dim3(blocks), dim3(256), 0, stream, flags, n, (const uint32_t*)block_sums, list);
+    return hipMemcpyAsync(total, d_total, sizeof(uint32_t), hipMemcpyDeviceToHost, stream) == hipSuccess && hipStreamSynchronize(stream) == hipSuccess;
+}
+
+bool build_tree(hipStream_t stream, const rt_bvh_node* d_ref_nodes, uint32_t nn, const rt_bvh_node& root_node, const ownbvh::Metric* metric, rt_bvh_node** d_tree, uint32_t* n_tree,
+    std::vector<rt_bvh_node>* tree_out, const std::atomic<bool>* cancel, double* seconds, uint32_t* rounds_out)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    *d_tree = nullptr; *n_tree = 0;
+    if (tree_out) tree_out->clear();
+    if ((root_node.num_primitives_axis >> 16) != 0u || nn < 3u) return false;                  // a leaf root: nothing to build
+    if (metric && metric->dirs.size() > 8u) return false;
+    auto cancelled = [&]() { return cancel && cancel->load(std::memory_order_relaxed); };
+    const FoldMetric fm = metric_of(metric);
+    Buffers buf;
+    uint32_t *flags = nullptr, *leaf_nodes = nullptr, *block_sums = nullptr, *d_counts = nullptr, *values = nullptr, *values_sorted = nullptr;
+    unsigned long long *keys = nullptr, *keys_sorted = nullptr;
+    int* d_err = nullptr;
+    const uint32_t scan_blocks = (nn + FOLD_SCAN_BLOCK - 1u) / FOLD_SCAN_BLOCK;
+    bool ok = buf.get(flags, nn) && buf.get(leaf_nodes, nn) && buf.get(block_sums, scan_blocks + 1u) && buf.get(d_counts, 4) && buf.get(d_err, 1);
+    if (!ok) return false;
+    ok = hipMemsetAsync(d_err, 0, sizeof(int), stream) == hipSuccess;
+    hipLaunchKernelGGL(k_ploc_flag_leaves, dim3((nn + 255u) / 256u), dim3(256), 0, stream, d_ref_nodes, nn, flags);
+    uint32_t n_leaves = 0;
+    ok = ok && scan_flags(stream, flags, nn, block_sums, d_counts, leaf_nodes, &n_leaves);
+    if (!ok || n_leaves < 2u || 2ull * n_leaves - 1u > 0x7FFFFFFFull) { (void)hipGetLastError(); return false; }
+    const uint32_t n_nodes = 2u * n_leaves - 1u;
+    // Morton order of the leaves
+    ok = buf.get(keys, n_leaves) && buf.get(keys_sorted, n_leaves) && buf.get(values, n_leaves) && buf.get(values_sorted, n_leaves);
+    if (!ok) return false;
+    const uint32_t leaf_blocks = (n_leaves + 255u) / 256u;
+    hipLaunchKernelGGL(k_ploc_keys, dim3(leaf_blocks), dim3(256), 0, stream, d_ref_nodes, (const uint32_t*)leaf_nodes, n_leaves, keys, values);
+    size_t temp_bytes = 0;
+    void* temp = nullptr;
+    if (hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, keys, keys_sorted, values, values_sorted, (int)n_leaves, 0, 63, stream) != hipSuccess) { (void)hipGetLastError(); return false; }
+    { char* t = nullptr; if (!buf.get(t, temp_bytes + 256u)) return false; temp = t; }
+    if (hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys, keys_sorted, values, values_sorted, (int)n_leaves, 0, 63, stream) != hipSuccess) { (void)hipGetLastError(); return false; }
+    // the pool of nodes (leaves first, in Morton order) and the cluster lists
+    PlocNode* pool = nullptr;
+    uint32_t *parent = nullptr, *cluster[2] = {nullptr, nullptr}, *nearest = nullptr, *keep = nullptr, *merge = nullptr, *keep_list = nullptr, *merge_list = nullptr, *block_sums2 = nullptr;
+    ok = buf.get(pool, n_nodes) && buf.get(parent, n_nodes) && buf.get(cluster[0], n_leaves) && buf.get(cluster[1], n_leaves) && buf.get(nearest, n_leaves) && buf.get(keep, n_leaves) &&
+         buf.get(merge, n_leaves) && buf.get(keep_list, n_leaves) && buf.get(merge_list, n_leaves) && buf.get(block_sums2, (n_leaves + FOLD_SCAN_BLOCK - 1u) / FOLD_SCAN_BLOCK + 1u);
+    if (!ok) return false;
+    hipLaunchKernelGGL(k_ploc_init, dim3(leaf_blocks), dim3(256), 0, stream, d_ref_nodes, (const uint32_t*)leaf_nodes, (const uint32_t*)values_sorted, n_leaves, pool, parent, cluster[0]);
+    uint32_t n = n_leaves, next_id = n_leaves, rounds = 0;
+    int cur = 0;
+    while (n > 1u)
+    {
+        if (++rounds > 400u || cancelled()) { (void)hipGetLastError(); return false; }       // (every round merges at least the globally cheapest pair; typical: ~30 rounds)
+        const uint32_t blocks = (n + 255u) / 256u;
+        hipLaunchKernelGGL(k_ploc_nearest, dim3(blocks), dim3(256), 0, stream, (const PlocNode*)pool, (const uint32_t*)cluster[cur], n, fm, nearest);
+        hipLaunchKernelGGL(k_ploc_decide, dim3(blocks), dim3(256), 0, stream, (const uint32_t*)nearest, n, keep, merge);
+        // positions of the survivors and ids of the new nodes, both in position order (the scan turns a flag into its rank: the flags themselves are needed again, so copies are scanned)
+        uint32_t n_keep = 0, n_merge = 0;
+        ok = hipMemcpyAsync(keep_list, keep, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream) == hipSuccess &&
+             hipMemcpyAsync(merge_list, merge, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream) == hipSuccess;
+        // (scan_flags writes rank-or-EMPTY back into its flag array and the flagged indices into `list`: here the list is scratch -- nearest is still needed, so flags is reused)
+        ok = ok && scan_flags(stream, keep_list, n, block_sums2, d_counts, flags, &n_keep) && scan_flags(stream, merge_list, n, block_sums2, d_counts + 1, flags, &n_merge);
+        if (!ok || n_merge == 0u || n_keep + n_merge != n || next_id + n_merge > n_nodes) { (void)hipGetLastError(); return false; }
+        hipLaunchKernelGGL(k_ploc_apply, dim3(blocks), dim3(256), 0, stream, pool, parent, (const uint32_t*)cluster[cur], (const uint32_t*)nearest, (const uint32_t*)keep, (const uint32_t*)merge,
+            (const uint32_t*)keep_list, (const uint32_t*)merge_list, n, next_id, cluster[cur ^ 1]);
+        next_id += n_merge;
+        n = n_keep;
+        cur ^= 1;
+    }
+    if (next_id != n_nodes) { (void)hipGetLastError(); return false; }
+    const uint32_t root = n_nodes - 1u;                                     // the last node made
+    // sizes, then the reference's linear layout
+    uint32_t *arrived = nullptr, *size = nullptr, *index_of = nullptr;
+    rt_bvh_node* out = nullptr;
+    ok = buf.get(arrived, n_nodes) && buf.get(size, n_nodes) && buf.get(index_of, n_nodes) && buf.get(out, n_nodes);
+    ok = ok && hipMemsetAsync(arrived, 0, (size_t)n_nodes * sizeof(uint32_t), stream) == hipSuccess;
+    if (!ok) { (void)hipGetLastError(); return false; }
+    hipLaunchKernelGGL(k_ploc_sizes, dim3(leaf_blocks), dim3(256), 0, stream, (const PlocNode*)pool, (const uint32_t*)parent, n_leaves, n_nodes, arrived, size, d_err);
+    hipLaunchKernelGGL(k_ploc_emit, dim3((n_nodes + 255u) / 256u), dim3(256), 0, stream, d_ref_nodes, (const PlocNode*)pool, (const uint32_t*)parent, (const uint32_t*)size, n_nodes, root, out, index_of, d_err);
+    int err = 0;
+    ok = hipMemcpyAsync(&err, d_err, sizeof(int), hipMemcpyDeviceToHost, stream) == hipSuccess;
+    if (ok && tree_out) { tree_out->resize(n_nodes); ok = hipMemcpyAsync(tree_out->data(), out, (size_t)n_nodes * sizeof(rt_bvh_node), hipMemcpyDeviceToHost, stream) == hipSuccess; }
+    ok = ok && hipStreamSynchronize(stream) == hipSuccess;
+    if (!ok || err != FOLD_OK || cancelled()) { (void)hipGetLastError(); if (tree_out) tree_out->clear(); return false; }
+    buf.release(out);
+    *d_tree = out; *n_tree = n_nodes;
+    if (rounds_out) *rounds_out = rounds;
     if (seconds) *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     return true;
 }

@@ -15,6 +15,40 @@ struct OwnTree
     WideNode* d_wide = nullptr;                                    // the records on the device already (RT_CTX_OPT_DEVICE_FOLD); whoever adopts them owns them
     int device = -1;                                               // >= 0: fold on that device (a stream of the worker's own)
     bool pairs = false;                                            // RT_CTX_OPT_WIDE_LAYOUT
+    bool device_builder = false;                                   // RT_CTX_OPT_TREE_BUILDER = 1: the binary tree itself is built on the device (PLOC, ploc_kernels.h)
+    bool built_on_device = false; uint32_t ploc_rounds = 0;
+    // RT_CTX_OPT_TREE_BUILDER = 1: tree AND fold on the device -- the reference's nodes go up once, the tree is clustered there (devfold::build_tree), folded there
+    // (devfold::fold takes the device array as it is) and comes back once for the adaptation's host side; false = something failed: the host path takes over
+    bool build_and_fold_on_device(const rt_scene_desc* sd, const ownbvh::Metric& m)
+    {
+        if (device < 0 || hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); return false; }
+        hipStream_t st = nullptr;
+        if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); return false; }
+        void* d_ref = nullptr;
+        rt_bvh_node* d_tree = nullptr;
+        uint32_t n_tree = 0, n = 0;
+        bool done = hipMalloc(&d_ref, (size_t)sd->num_nodes * sizeof(rt_bvh_node)) == hipSuccess &&
+                    hipMemcpyAsync(d_ref, sd->nodes, (size_t)sd->num_nodes * sizeof(rt_bvh_node), hipMemcpyHostToDevice, st) == hipSuccess;
+        const auto t0 = std::chrono::steady_clock::now();
+        done = done && devfold::build_tree(st, (const rt_bvh_node*)d_ref, sd->num_nodes, sd->nodes[0], &m, &d_tree, &n_tree, &bvh2, nullptr, nullptr, &ploc_rounds);
+        build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        const auto t1 = std::chrono::steady_clock::now();
+        done = done && devfold::fold(st, d_tree, n_tree, bvh2[0], &m, nullptr, &d_wide, &n, &entry, &roots, &wide) && n != 0u;
+        (void)hipStreamSynchronize(st);
+        if (d_ref) (void)hipFree(d_ref);
+        if (d_tree) (void)hipFree(d_tree);
+        (void)hipStreamDestroy(st);
+        (void)hipGetLastError();
+        if (!done) { if (d_wide) { (void)hipFree(d_wide); d_wide = nullptr; } bvh2.clear(); wide.clear(); roots.clear(); return false; }
+        if (pairs)
+        {
+            pair_layout_by_area(wide, roots, bvh2.data(), (uint32_t)bvh2.size(), &m);
+            if (hipMemcpy(d_wide, wide.data(), wide.size() * sizeof(WideNode), hipMemcpyHostToDevice) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(d_wide); d_wide = nullptr; return false; }
+        }
+        fold_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
+        built_on_device = true;
+        return true;
+    }
     double fold_seconds = 0.0, build_seconds = 0.0;
     // the collapse of the finished binary tree: on the device (the tree goes up, the records stay there and come back for the choice by proxy rays), or by build_wide_bvh
     bool fold_it(const ownbvh::Metric& m)
@@ -60,6 +94,7 @@ struct OwnTree
         }
         worker = std::thread([this, sd, m]()
         {
+            if (device_builder && build_and_fold_on_device(sd, m)) { ok = true; return; }
             const auto t0 = std::chrono::steady_clock::now();
             ok = ownbvh::build(sd->nodes, sd->num_nodes, m, bvh2);
             build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

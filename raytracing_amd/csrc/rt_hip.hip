@@ -78,6 +78,7 @@ struct rt_ctx
                                   // shadow trace 0.314 -> 0.258 ms per sample on the headline scene, bit-identical on all five configs)
     uint32_t adapt_min_interval_ms = 500;   // RT_CTX_OPT_ADAPT_MIN_INTERVAL_MS
     uint32_t wide_layout = 0;               // RT_CTX_OPT_WIDE_LAYOUT: 1 = the 4-wide records stored in (parent, likeliest child) pairs, one pair per 128-byte line (pair_layout)
+    uint32_t tree_builder = 0;              // RT_CTX_OPT_TREE_BUILDER: 1 = the shadow rays' own binary tree is built on the device (PLOC: ploc_kernels.h) instead of by own_bvh.h's host sweep
     uint32_t device_fold = 1;               // RT_CTX_OPT_DEVICE_FOLD: the SAH collapse into 4-wide records runs on the device (fold_kernels.h); 0 = on host threads
     uint64_t scene_uploads = 0;             // rt_scene_upload calls so far (what a frame's measured choices were made for)
     std::vector<rt_frame*> frames;   // the frames alive on this context (rt_finish waits for their side streams too)
@@ -413,6 +414,7 @@ int rt_ctx_set_option(rt_ctx* ctx, int option, uint32_t value)
     if (option == RT_CTX_OPT_ADAPTIVE_FOLD) { ctx->adaptive_fold = value & 31u; return RT_OK; }
     if (option == RT_CTX_OPT_DEVICE_FOLD) { ctx->device_fold = value ? 1u : 0u; return RT_OK; }
     if (option == RT_CTX_OPT_WIDE_LAYOUT) { ctx->wide_layout = value ? 1u : 0u; return RT_OK; }
+    if (option == RT_CTX_OPT_TREE_BUILDER) { ctx->tree_builder = value ? 1u : 0u; return RT_OK; }
     if (option == RT_CTX_OPT_ADAPT_WAIT)
     {
         if (ctx->scene.adapt) fold_adapt_set_wait(ctx->scene.adapt, value != 0u);          // the scene in place only
@@ -523,6 +525,7 @@ int rt_scene_upload(rt_ctx* ctx, const rt_scene_desc* sd)
     const bool may_own = ctx->build_wide == 1u && (uint64_t)nt * 64 <= 0xFFFFFFFFull && (sd->nodes[0].num_primitives_axis >> 16) == 0;
     if (ctx->device_fold && ctx->build_wide == 1u) { own_sh.device = ctx->device; own_cl.device = ctx->device; }
     own_sh.pairs = own_cl.pairs = ctx->wide_layout != 0u;
+    own_sh.device_builder = ctx->tree_builder != 0u && ctx->device_fold != 0u && ctx->build_wide == 1u;      // (the shadow rays' tree only: the closest-hit rays' own tree is the tolerance mode's, host-built)
     if (may_own && ctx->shadow_tree) own_sh.start(sd, true, ctx->shadow_tree);
     if (may_own && ctx->closest_tree) own_cl.start(sd, false, ctx->closest_tree);
 
@@ -813,9 +816,9 @@ int rt_scene_upload(rt_ctx* ctx, const rt_scene_desc* sd)
         char line[400];
         const double t_rest = lap(t_lap);
         snprintf(line, sizeof(line), "upload: %.3f s = record order on the host %.3f + copies and re-layout kernels %.3f + fold of the reference's tree %.3f (%s) + waiting for the own tree(s) %.3f "
-            "(shadow tree: built in %.3f, folded in %.3f) + choosing by proxy rays and uploading %.3f + adaptation state %.3f (%u triangles, %u nodes, %u + %u wide records)\n",
+            "(shadow tree: built %s in %.3f, folded in %.3f) + choosing by proxy rays and uploading %.3f + adaptation state %.3f (%u triangles, %u nodes, %u + %u wide records)\n",
             std::chrono::duration<double>(std::chrono::steady_clock::now() - t_upload).count(), t_layout, t_device, t_fold, folded_on_device ? "on the device" : "on host threads", t_own_wait,
-            own_sh.build_seconds, own_sh.fold_seconds, t_choose, t_rest, nt, nn, s.n_wide, s.n_wide_sh);
+            own_sh.built_on_device ? "on the device (PLOC)" : "on host threads", own_sh.build_seconds, own_sh.fold_seconds, t_choose, t_rest, nt, nn, s.n_wide, s.n_wide_sh);
         s.tree_report += line;
     }
     return RT_OK;

@@ -153,3 +153,64 @@ def test_one_context_takes_another_contexts_folds(golden_scenes):
     fb.integrate(1); fa.integrate(1)                                           # ... and B is still intact
     assert np.array_equal(fa.radiance(), fb.radiance(), equal_nan=True)
     fa.close(); fb.close(); A.close(); B.close()
+
+
+def test_the_tree_built_on_the_device_is_a_tree_over_the_references_leaves(ctx, trees, golden_scenes):
+    """RT_CTX_OPT_TREE_BUILDER = 1 (ploc_kernels.h): PLOC on the device over the reference's leaves.  Structure by the CPU suite's own checker (tests/test_own_tree.py:
+    exactly the reference's leaves -- first triangle, count, exact box -- in the reference's linear layout, interior boxes exact unions), the same tree every run, and
+    the CPU restatement of k_trace_w4's walk over its fold returns the reference's shadow verdicts."""
+    from tests.test_own_tree import check_own_structure, shadow_and_closest_on
+    d = light_dir()
+    for name in ("cornell", "coverage", "city 40 K", "city 300 K"):
+        nodes = trees[name]
+        own, sec, rounds = capi.device_tree(ctx, nodes, 0.5, [d])
+        check_own_structure(nodes, own)
+        again, _, _ = capi.device_tree(ctx, nodes, 0.5, [d])
+        assert np.array_equal(own.view(np.uint8), again.view(np.uint8)), name      # no choice depends on which thread arrives first
+        assert rounds < 200, (name, rounds)
+        recs, entry, roots, _ = capi.device_fold(ctx, own, 0.5, [np.abs(d)])
+        h, he = wide_metric(own, 0.5, [d])
+        assert entry == he and np.array_equal(np.ascontiguousarray(recs).view(np.uint8).reshape(-1), np.ascontiguousarray(h).view(np.uint8).reshape(-1))
+    for name, (w, h, b) in {"cornell": (48, 32, 3), "coverage": (56, 40, 4)}.items():
+        arrays = golden_scenes[name]
+        own, _, _ = capi.device_tree(ctx, arrays["nodes"], 0.5, [d])
+        shadow_and_closest_on(arrays, {"device": wide_metric(own, 0.5, [d])}, w, h, b)    # asserts equal shadow verdicts at every bounce
+
+
+def test_the_device_built_tree_is_about_as_good_as_the_host_built_one(ctx, trees):
+    """quality, by the library's own yardstick: the metric summed over the interior boxes (what both builders minimise greedily)"""
+    d = light_dir()
+    for name in ("city 40 K", "city 300 K"):
+        nodes = trees[name]
+        host_tree = own_tree(nodes, 0.5, [d])
+        dev_tree, sec, rounds = capi.device_tree(ctx, nodes, 0.5, [d])
+        def cost(t):
+            inner = (t["num_primitives_axis"] >> 16) == 0
+            e = np.stack([t["bounds_max"][c].astype(np.float64) - t["bounds_min"][c].astype(np.float64) for c in "xyz"], 1)[inner]
+            iso = 0.5 * 0.5 * (e[:, 0] * e[:, 1] + e[:, 1] * e[:, 2] + e[:, 2] * e[:, 0])
+            proj = abs(d[0]) * e[:, 1] * e[:, 2] + abs(d[1]) * e[:, 2] * e[:, 0] + abs(d[2]) * e[:, 0] * e[:, 1]
+            return float((iso + proj).sum())
+        ratio = cost(dev_tree) / cost(host_tree)
+        print("%s: device-built / host-built interior cost %.3f, %d rounds, %.3f s" % (name, ratio, rounds, sec))
+        assert ratio < 1.35, (name, ratio)
+
+
+def test_a_scene_with_its_shadow_tree_built_on_the_device_renders_the_references_bits(golden_scenes):
+    w, h, b, spp = 96, 64, 4, 4
+    sc = golden_scenes["coverage"]
+    cam = T.default_camera(w, h)
+    c = capi.Context(0)
+    assert c.lib.rt_ctx_set_option(c.handle, 9, 1) == 0 and c.lib.rt_ctx_set_option(c.handle, 2, 2) == 0      # device builder, own shadow tree forced
+    assert c.lib.rt_ctx_set_option(c.handle, 4, 31) == 0                                                     # ... and adapted (rotated, re-folded) before the frame's rays
+    c.upload_scene(sc)
+    rep = c.lib.rt_scene_tree_report(c.handle).decode()
+    assert "on the device (PLOC)" in rep, rep
+    fr = capi.Frame(c, w, h)
+    fr.set_camera(cam); fr.set_max_bounces(b)
+    fr.integrate(spp)
+    orc = _oracle.Oracle(w, h, sc)
+    orc.set_camera(cam); orc.set_max_bounces(b); orc.integrate(spp)
+    assert np.array_equal(fr.radiance()[..., :3], orc.radiance()[..., :3], equal_nan=True)
+    st = fr.stats()
+    assert (st.closest_rays, st.shadow_rays) == orc.ray_totals()
+    fr.close(); c.close()
