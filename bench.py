@@ -847,7 +847,10 @@ def main():
                                                             trace_tune=args.trace_tune, small_launch_paths=args.small_launch_paths,
                                                             trace_variant=args.trace_variant, overlap_shadow=args.overlap_shadow))), flush=True)
         return 0
+    t_alloc0 = time.perf_counter()
     in_flight = render.reserve_samples(max(spp_timed, spp_warm))
+    render.finish()
+    t_first_alloc = time.perf_counter() - t_alloc0          # the process's first allocation of the batch's per-path buffers (hipMalloc of up to ~100 GB)
 
     # ---- warm-up ------------------------------------------------------------
     t_warm0 = time.perf_counter()
@@ -1228,7 +1231,7 @@ def main():
                                 log_inline_entries=int(st1.log_inline_entries), log_fallbacks=int(st1.log_fallbacks),   # 0 inline = the full log layout
                                 trees=trees_now, adaptive_fold=args.adaptive_fold,    # what rt_scene_upload measured when it chose the shadow (/ closest-hit) tree
                                 setup_s=round(t_setup, 2), scene_s=round(t_scene, 2),     # scene_s: parse / generate (or load the cache); setup_s: + BVH, wide collapse, upload
-                                setup_breakdown=setup_breakdown,
+                                setup_breakdown=setup_breakdown, path_state_alloc_s=round(t_first_alloc, 3),
                                 device=name),
                     ranks=dict(render_ms_min=round(float(tmin[0].item()) * 1e3, 3), render_ms_max=round(float(tmax[1].item()) * 1e3, 3),
                                render_ms=[r["render_ms"] for r in per_rank], gather_ms=[r["gather_ms"] for r in per_rank],
