@@ -1200,6 +1200,12 @@ def main():
             try:
                 scaling_estimate = json.load(open(est_path))
                 scaling_estimate["measured"] = False
+                # what the tile timing leaves out: the one gather.  Every rank sends its tile (16 B per pixel) over its OWN xGMI link to the root
+                # (point-to-point links, ~153 GB/s each: /opt/skills/guides/MI355X_MICROARCH.md), so the transfers run side by side
+                per_rank_mb = args.width * args.height * 16 / 8 / 1e6
+                scaling_estimate["gather_model_ms"] = dict(n8=round(per_rank_mb / 153e3 * 1e3 + 0.03, 3),
+                                                           formula="N = 8: %.2f MB per rank / 153 GB/s per xGMI link, seven links into the root in parallel, + ~0.03 ms launch and "
+                                                                   "synchronisation = a model (no multi-GPU node has been available); against 56 ms of rendering per rank at 256 spp" % per_rank_mb)
             except Exception as e:                              # noqa: BLE001
                 scaling_estimate = dict(error=repr(e), measured=False)
         name, cus, mem = render_ctx_info(capi, host, render)

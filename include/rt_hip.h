@@ -510,7 +510,7 @@ int rt_debug_pair_layout(const rt_bvh_node* nodes, uint32_t num_nodes, void* rec
 /* ploc_kernels.h on its own: a binary tree over the leaves of `nodes` built on ctx's device with the metric of rt_debug_own_bvh (the same layout comes back: out_nodes[2 leaves - 1];
  * NULL = count query); *seconds = the device path's time, *rounds = clustering rounds. */
 int rt_debug_device_tree(rt_ctx* ctx, const rt_bvh_node* nodes, uint32_t num_nodes, double iso_weight, const float* dirs, uint32_t n_dirs, rt_bvh_node* out_nodes, uint32_t capacity,
-    uint32_t* num_out, double* seconds, uint32_t* rounds);
+    uint32_t* num_out, double* seconds, uint32_t* rounds, uint32_t radius /* 0 = the library's */, const float* frame_dir /* NULL = world axes */, double stretch);
 /* ... and the host's fold for given per-node weights (what an adaptation folds with), for that comparison */
 int rt_debug_wide_bvh_weights(const rt_bvh_node* nodes, uint32_t num_nodes, const double* weights, void* records, uint32_t* roots, uint32_t capacity,
     uint32_t* num_records, uint32_t* entry_ref);

@@ -122,7 +122,7 @@ def load():
         "rt_debug_device_fold": (i32, [vp, vp, u32, C.c_double, vp, u32, vp, vp, vp, u32, C.POINTER(u32), C.POINTER(u32), C.POINTER(C.c_double)]),
         "rt_debug_wide_bvh_weights": (i32, [vp, u32, vp, vp, vp, u32, C.POINTER(u32), C.POINTER(u32)]),
         "rt_debug_pair_layout": (i32, [vp, u32, vp, vp, u32]),
-        "rt_debug_device_tree": (i32, [vp, vp, u32, C.c_double, vp, u32, vp, u32, C.POINTER(u32), C.POINTER(C.c_double), C.POINTER(u32)]),
+        "rt_debug_device_tree": (i32, [vp, vp, u32, C.c_double, vp, u32, vp, u32, C.POINTER(u32), C.POINTER(C.c_double), C.POINTER(u32), u32, vp, C.c_double]),
         "rt_scene_export_folds": (i32, [vp, vp, vp, u32, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]),
         "rt_scene_import_folds": (i32, [vp, vp, u32, u32, vp, u32, u32]),
         "rt_debug_rotate_tree": (i32, [vp, u32, vp, vp, u32, i32, vp, C.POINTER(C.c_double), C.POINTER(u32), i32, C.c_double]),
@@ -213,7 +213,7 @@ def device_fold(ctx, nodes, iso_weight=-1.0, dirs=None, weights=None):
     return out[:n.value].copy(), entry.value, roots[:n.value].copy(), sec.value
 
 
-def device_tree(ctx, nodes, iso_weight=1.0, dirs=None):
+def device_tree(ctx, nodes, iso_weight=1.0, dirs=None, radius=0, frame_dir=None, stretch=1.0):
     """rt_debug_device_tree: a binary tree over the leaves of `nodes` built on ctx's device (PLOC, raytracing_amd/csrc/ploc_kernels.h).  Returns (nodes, seconds, rounds)."""
     lib = load()
     nodes = np.ascontiguousarray(nodes)
@@ -221,7 +221,8 @@ def device_tree(ctx, nodes, iso_weight=1.0, dirs=None):
     out = np.zeros(len(nodes), nodes.dtype)
     n, sec, rounds = C.c_uint32(), C.c_double(), C.c_uint32()
     if lib.rt_debug_device_tree(ctx.handle, nodes.ctypes.data, len(nodes), iso_weight, d.ctypes.data if d is not None and len(d) else None, len(d) if d is not None else 0,
-                                out.ctypes.data, len(out), C.byref(n), C.byref(sec), C.byref(rounds)):
+                                out.ctypes.data, len(out), C.byref(n), C.byref(sec), C.byref(rounds), radius,
+                                np.ascontiguousarray(frame_dir, np.float32).ctypes.data if frame_dir is not None else None, stretch):
         raise RtError(lib.rt_last_error(ctx.handle).decode())
     return out[:n.value].copy(), sec.value, rounds.value
 

@@ -56,7 +56,7 @@ int rt_debug_device_fold(rt_ctx* ctx, const rt_bvh_node* nodes, uint32_t num_nod
 }
 
 int rt_debug_device_tree(rt_ctx* ctx, const rt_bvh_node* nodes, uint32_t num_nodes, double iso_weight, const float* dirs, uint32_t n_dirs, rt_bvh_node* out_nodes, uint32_t capacity,
-    uint32_t* num_out, double* seconds, uint32_t* rounds)
+    uint32_t* num_out, double* seconds, uint32_t* rounds, uint32_t radius, const float* frame_dir, double stretch)
 {
     if (!ctx || !nodes || num_nodes == 0 || !num_out) return fail(ctx, "rt_debug_device_tree: NULL argument");
     (void)hipSetDevice(ctx->device);
@@ -68,7 +68,7 @@ int rt_debug_device_tree(rt_ctx* ctx, const rt_bvh_node* nodes, uint32_t num_nod
     rt_bvh_node* d_tree = nullptr;
     uint32_t n = 0;
     std::vector<rt_bvh_node> tree;
-    const bool ok = devfold::build_tree(ctx->stream, (const rt_bvh_node*)d_nodes, num_nodes, nodes[0], &m, &d_tree, &n, &tree, nullptr, seconds, rounds);
+    const bool ok = devfold::build_tree(ctx->stream, (const rt_bvh_node*)d_nodes, num_nodes, nodes[0], &m, &d_tree, &n, &tree, nullptr, seconds, rounds, frame_dir, radius, stretch);
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipFree(d_nodes);
     if (d_tree) (void)hipFree(d_tree);

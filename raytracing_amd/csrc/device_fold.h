@@ -21,7 +21,8 @@ bool fold(hipStream_t stream, const rt_bvh_node* d_nodes, uint32_t nn, const rt_
 // *d_tree = the tree in the reference's linear layout on the device (hipMalloc'ed: the caller frees it; fold() takes it as it is), *n_tree = 2 leaves - 1, and -- when asked
 // for -- its host copy.  false: a leaf root, a metric of more than 8 directions, an allocation that failed, `cancel`, or the clustering did not finish within its round limit.
 bool build_tree(hipStream_t stream, const rt_bvh_node* d_ref_nodes, uint32_t nn, const rt_bvh_node& root_node, const ownbvh::Metric* metric, rt_bvh_node** d_tree, uint32_t* n_tree,
-    std::vector<rt_bvh_node>* tree_out, const std::atomic<bool>* cancel = nullptr, double* seconds = nullptr, uint32_t* rounds_out = nullptr);
+    std::vector<rt_bvh_node>* tree_out, const std::atomic<bool>* cancel = nullptr, double* seconds = nullptr, uint32_t* rounds_out = nullptr,
+    const float* light_dir = nullptr /* the Morton order's frame: (u, v, this direction); NULL = the world axes */, uint32_t radius = 0 /* 0 = PLOC_RADIUS */, double stretch = 1.0);
 // counts[n] = probe rays whose slab test of node n passes (FoldAdapt; the host form: rtw::count_box_passes); *truncated += walks that met a subtree deeper than the stack
 bool count_box_passes(hipStream_t stream, const rt_bvh_node* d_nodes, uint32_t nn, const float4* o, const float4* d, size_t n_rays, std::vector<uint32_t>& counts, uint64_t* truncated);
 } // namespace devfold

@@ -7,6 +7,7 @@
 #include <string.h>
 #include <algorithm>
 #include <chrono>
+#include <cmath>
 #include "device_fold.h"
 #include "fold_kernels.h"
 #include "ploc_kernels.h"
@@ -136,9 +137,58 @@ static bool scan_flags(hipStream_t stream, uint32_t* flags, uint32_t n, uint32_t
     return hipMemcpyAsync(total, d_total, sizeof(uint32_t), hipMemcpyDeviceToHost, stream) == hipSuccess && hipStreamSynchronize(stream) == hipSuccess;
 }
 
-bool build_tree(hipStream_t stream, const rt_bvh_node* d_ref_nodes, uint32_t nn, const rt_bvh_node& root_node, const ownbvh::Metric* metric, rt_bvh_node** d_tree, uint32_t* n_tree,
-    std::vector<rt_bvh_node>* tree_out, const std::atomic<bool>* cancel, double* seconds, uint32_t* rounds_out)
+// the frame of the Morton order (ploc_kernels.h): world axes, or (u, v, light) with the light's axis stretched
+static PlocFrame ploc_frame(const rt_bvh_node& root, const float* light_dir, double stretch)
 {
+    PlocFrame f;
+    memset(&f, 0, sizeof(f));
+    double ax[3][3] = {{1.0, 0.0, 0.0}, {0.0, 1.0, 0.0}, {0.0, 0.0, 1.0}};
+    if (light_dir)
+    {
+        const double d[3] = {light_dir[0], light_dir[1], light_dir[2]};
+        const double len = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+        if (len > 0.0 && std::isfinite(len))
+        {
+            const double w[3] = {d[0] / len, d[1] / len, d[2] / len};
+            // u: perpendicular to w, from the world axis w is least aligned with; v = w x u
+            int m = std::fabs(w[0]) <= std::fabs(w[1]) ? (std::fabs(w[0]) <= std::fabs(w[2]) ? 0 : 2) : (std::fabs(w[1]) <= std::fabs(w[2]) ? 1 : 2);
+            double e[3] = {0.0, 0.0, 0.0}; e[m] = 1.0;
+            const double dot = e[0] * w[0] + e[1] * w[1] + e[2] * w[2];
+            double u[3] = {e[0] - dot * w[0], e[1] - dot * w[1], e[2] - dot * w[2]};
+            const double ul = std::sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+            for (double& x : u) x /= ul;
+            const double v[3] = {w[1] * u[2] - w[2] * u[1], w[2] * u[0] - w[0] * u[2], w[0] * u[1] - w[1] * u[0]};
+            for (int k = 0; k < 3; ++k) { ax[0][k] = u[k]; ax[1][k] = v[k]; ax[2][k] = w[k]; }
+        }
+    }
+    const double corner[2][3] = {{root.bounds_min.x, root.bounds_min.y, root.bounds_min.z}, {root.bounds_max.x, root.bounds_max.y, root.bounds_max.z}};
+    for (int a = 0; a < 3; ++a)
+    {
+        double lo = INFINITY, hi = -INFINITY;
+        for (int c = 0; c < 8; ++c)
+        {
+            const double p = ax[a][0] * corner[c & 1][0] + ax[a][1] * corner[(c >> 1) & 1][1] + ax[a][2] * corner[(c >> 2) & 1][2];
+            lo = std::min(lo, p); hi = std::max(hi, p);
+        }
+        for (int k = 0; k < 3; ++k) f.axis[a][k] = ax[a][k];
+        f.lo[a] = lo; f.hi[a] = hi;
+    }
+    // cells of the same length along every axis (the scene's longest extent sets it), the light's axis `stretch` times longer: its interval is widened accordingly
+    double longest = 0.0;
+    for (int a = 0; a < 3; ++a) longest = std::max(longest, f.hi[a] - f.lo[a]);
+    for (int a = 0; a < 3; ++a)
+    {
+        const double want = longest * (a == 2 && light_dir ? stretch : 1.0);
+        f.hi[a] = f.lo[a] + (want > 0.0 ? want : 1.0);
+    }
+    return f;
+}
+
+bool build_tree(hipStream_t stream, const rt_bvh_node* d_ref_nodes, uint32_t nn, const rt_bvh_node& root_node, const ownbvh::Metric* metric, rt_bvh_node** d_tree, uint32_t* n_tree,
+    std::vector<rt_bvh_node>* tree_out, const std::atomic<bool>* cancel, double* seconds, uint32_t* rounds_out, const float* light_dir, uint32_t radius, double stretch)
+{
+    if (radius == 0u) radius = PLOC_RADIUS;
+    if (radius > 256u) radius = 256u;
     const auto t0 = std::chrono::steady_clock::now();
     *d_tree = nullptr; *n_tree = 0;
     if (tree_out) tree_out->clear();
@@ -163,7 +213,7 @@ bool build_tree(hipStream_t stream, const rt_bvh_node* d_ref_nodes, uint32_t nn,
     ok = buf.get(keys, n_leaves) && buf.get(keys_sorted, n_leaves) && buf.get(values, n_leaves) && buf.get(values_sorted, n_leaves);
     if (!ok) return false;
     const uint32_t leaf_blocks = (n_leaves + 255u) / 256u;
-    hipLaunchKernelGGL(k_ploc_keys, dim3(leaf_blocks), dim3(256), 0, stream, d_ref_nodes, (const uint32_t*)leaf_nodes, n_leaves, keys, values);
+    hipLaunchKernelGGL(k_ploc_keys, dim3(leaf_blocks), dim3(256), 0, stream, d_ref_nodes, (const uint32_t*)leaf_nodes, n_leaves, ploc_frame(root_node, light_dir, stretch > 0.0 ? stretch : 1.0), keys, values);
     size_t temp_bytes = 0;
     void* temp = nullptr;
     if (hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, keys, keys_sorted, values, values_sorted, (int)n_leaves, 0, 63, stream) != hipSuccess) { (void)hipGetLastError(); return false; }
@@ -182,7 +232,7 @@ bool build_tree(hipStream_t stream, const rt_bvh_node* d_ref_nodes, uint32_t nn,
     {
         if (++rounds > 400u || cancelled()) { (void)hipGetLastError(); return false; }       // (every round merges at least the globally cheapest pair; typical: ~30 rounds)
         const uint32_t blocks = (n + 255u) / 256u;
-        hipLaunchKernelGGL(k_ploc_nearest, dim3(blocks), dim3(256), 0, stream, (const PlocNode*)pool, (const uint32_t*)cluster[cur], n, fm, nearest);
+        hipLaunchKernelGGL(k_ploc_nearest, dim3(blocks), dim3(256), 0, stream, (const PlocNode*)pool, (const uint32_t*)cluster[cur], n, fm, radius, nearest);
         hipLaunchKernelGGL(k_ploc_decide, dim3(blocks), dim3(256), 0, stream, (const uint32_t*)nearest, n, keep, merge);
         // positions of the survivors and ids of the new nodes, both in position order (the scan turns a flag into its rank: the flags themselves are needed again, so copies are scanned)
         uint32_t n_keep = 0, n_merge = 0;

@@ -19,7 +19,7 @@
 #pragma once
 #include "fold_kernels.h"
 
-#define PLOC_RADIUS 16
+#define PLOC_RADIUS 32
 
 struct PlocNode { float mn[3]; uint32_t left; float mx[3]; uint32_t right; };     // interior: children (pool ids); leaf: left = reference node | 0x80000000, right = unused
 
@@ -52,20 +52,24 @@ RT_DEV unsigned long long ploc_spread21(uint32_t v)       // 21 bits -> every th
 }
 
 // leaf_nodes[k] = the k-th leaf of the reference's array; key = Morton code of its box's centre in the root's box; the leaf becomes pool node k' after the sort
-__global__ __launch_bounds__(256) void k_ploc_keys(const rt_bvh_node* __restrict__ nodes, const uint32_t* __restrict__ leaf_nodes, uint32_t n_leaves,
+// The order the clustering starts from: Morton codes of the leaf boxes' centres in a FRAME (rows of `frame`: three directions, each with the interval [lo, hi] the
+// scene's corners span along it).  The world axes for an isotropic metric; for shadow rays towards a directional light a frame with the light's direction as its
+// third axis, that axis' cells `stretch` times as long as the others' -- boxes that are long along the light are what that metric prices cheaply, and leaves that
+// follow each other along the light should be neighbours in the order (measured: DESIGN.md section 7).
+struct PlocFrame { double axis[3][3]; double lo[3], hi[3]; };
+__global__ __launch_bounds__(256) void k_ploc_keys(const rt_bvh_node* __restrict__ nodes, const uint32_t* __restrict__ leaf_nodes, uint32_t n_leaves, PlocFrame frame,
     unsigned long long* __restrict__ keys, uint32_t* __restrict__ values)
 {
     const uint32_t k = blockIdx.x * 256u + threadIdx.x;
     if (k >= n_leaves) return;
-    const rt_bvh_node root = nodes[0];
     const rt_bvh_node b = nodes[leaf_nodes[k]];
-    const float c[3] = {0.5f * (b.bounds_min.x + b.bounds_max.x), 0.5f * (b.bounds_min.y + b.bounds_max.y), 0.5f * (b.bounds_min.z + b.bounds_max.z)};
-    const float lo[3] = {root.bounds_min.x, root.bounds_min.y, root.bounds_min.z}, hi[3] = {root.bounds_max.x, root.bounds_max.y, root.bounds_max.z};
+    const double w[3] = {0.5 * ((double)b.bounds_min.x + (double)b.bounds_max.x), 0.5 * ((double)b.bounds_min.y + (double)b.bounds_max.y), 0.5 * ((double)b.bounds_min.z + (double)b.bounds_max.z)};
     uint32_t q[3];
     for (int a = 0; a < 3; ++a)
     {
-        const double e = (double)hi[a] - (double)lo[a];
-        double t = e > 0.0 ? ((double)c[a] - (double)lo[a]) / e : 0.0;
+        const double c = frame.axis[a][0] * w[0] + frame.axis[a][1] * w[1] + frame.axis[a][2] * w[2];
+        const double e = frame.hi[a] - frame.lo[a];
+        double t = e > 0.0 ? (c - frame.lo[a]) / e : 0.0;
         t = t < 0.0 ? 0.0 : (t > 1.0 ? 1.0 : t);
         const double s = t * 2097151.0;
         q[a] = (uint32_t)s;
@@ -91,12 +95,12 @@ __global__ __launch_bounds__(256) void k_ploc_init(const rt_bvh_node* __restrict
     cluster[k] = k;
 }
 
-__global__ __launch_bounds__(256) void k_ploc_nearest(const PlocNode* __restrict__ pool, const uint32_t* __restrict__ cluster, uint32_t n, FoldMetric metric, uint32_t* __restrict__ nearest)
+__global__ __launch_bounds__(256) void k_ploc_nearest(const PlocNode* __restrict__ pool, const uint32_t* __restrict__ cluster, uint32_t n, FoldMetric metric, uint32_t radius, uint32_t* __restrict__ nearest)
 {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
     const PlocNode a = pool[cluster[i]];
-    const uint32_t lo = i > PLOC_RADIUS ? i - PLOC_RADIUS : 0u, hi = i + PLOC_RADIUS < n - 1u ? i + PLOC_RADIUS : n - 1u;
+    const uint32_t lo = i > radius ? i - radius : 0u, hi = i + radius < n - 1u ? i + radius : n - 1u;
     double best = 0.0; uint32_t at = RT_EMPTY_REF;
     for (uint32_t j = lo; j <= hi; ++j)
     {

@@ -1,8 +1,8 @@
 #!/bin/bash
-# Round 6, call 6: RT_CTX_OPT_TREE_BUILDER = 1 -- the shadow rays' own tree built on the device (PLOC) -- its tests, and against the host-built tree on configs 4, 2, 5:
+# Round 6, calls 6 and 8 (8: after the Morton cells became cubes and the radius 32): RT_CTX_OPT_TREE_BUILDER = 1 -- the shadow rays' own tree built on the device (PLOC) -- its tests, and against the host-built tree on configs 4, 2, 5:
 # upload stages, steps per proxy ray (the tree report), shadow trace alone, the job.
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r06_call06
+O=$R/gpurun_out/r06_call08
 mkdir -p $O
 cd $R
 T0=$(date +%s)
@@ -16,7 +16,7 @@ run() { # name, config, extra args
 import json; d=json.loads(open('$O/$1_cfg$2.json').read().strip().splitlines()[-1]); k=d['roofline']['live_isolated']['kernel_ms_per_spp']; c=d['config']
 print(d['value'], k, 'sa-fold', (d.get('surface_area_fold') or {}).get('value'), 'cold', {x: v for x, v in (d.get('cold_job') or {}).items() if x not in ('what', 'trees')}, c.get('setup_breakdown'), [t for t in c.get('trees', []) if t.startswith('upload') or t.startswith('shadow')], d['adaptation'].get('seconds_to_adapted'))" 2>&1 | tail -1)
 }
-for cfg in 4 2 5; do
+for cfg in 4 2 5 3; do
   run host_1 $cfg "--tree-builder 0"; run device_1 $cfg "--tree-builder 1"
   run host_2 $cfg "--tree-builder 0"; run device_2 $cfg "--tree-builder 1"
 done
