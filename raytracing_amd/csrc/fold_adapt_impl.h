@@ -15,7 +15,9 @@ struct OwnTree
     WideNode* d_wide = nullptr;                                    // the records on the device already (RT_CTX_OPT_DEVICE_FOLD); whoever adopts them owns them
     int device = -1;                                               // >= 0: fold on that device (a stream of the worker's own)
     bool pairs = false;                                            // RT_CTX_OPT_WIDE_LAYOUT
-    bool device_builder = false;                                   // RT_CTX_OPT_TREE_BUILDER = 1: the binary tree itself is built on the device (PLOC, ploc_kernels.h)
+    bool device_builder = false;                                   // RT_CTX_OPT_TREE_BUILDER: the binary tree itself is built on the device (PLOC, ploc_kernels.h) ...
+    bool device_only = false;                                      // ... and if that fails this candidate is simply not there (another OwnTree is the host-built candidate)
+    std::atomic<bool> cancel_build{false};                         // the host build gives up: another candidate has won
     bool built_on_device = false; uint32_t ploc_rounds = 0;
     // RT_CTX_OPT_TREE_BUILDER = 1: tree AND fold on the device -- the reference's nodes go up once, the tree is clustered there (devfold::build_tree), folded there
     // (devfold::fold takes the device array as it is) and comes back once for the adaptation's host side; false = something failed: the host path takes over
@@ -47,8 +49,10 @@ struct OwnTree
         }
         fold_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
         built_on_device = true;
+        name = name_device.c_str();
         return true;
     }
+    std::string name_device;
     double fold_seconds = 0.0, build_seconds = 0.0;
     // the collapse of the finished binary tree: on the device (the tree goes up, the records stay there and come back for the choice by proxy rays), or by build_wide_bvh
     bool fold_it(const ownbvh::Metric& m)
@@ -92,11 +96,13 @@ struct OwnTree
             ownbvh::Metric d = shadow_metric(sd->lights, sd->num_lights, 0.5);
             if (!d.dirs.empty()) { m = d; name = "own: projected area along the directional lights + 50 % isotropic"; }
         }
+        name_device = std::string(name) + ", built on the device (PLOC)";
         worker = std::thread([this, sd, m]()
         {
             if (device_builder && build_and_fold_on_device(sd, m)) { ok = true; return; }
+            if (device_only) { ok = false; return; }
             const auto t0 = std::chrono::steady_clock::now();
-            ok = ownbvh::build(sd->nodes, sd->num_nodes, m, bvh2);
+            ok = ownbvh::build(sd->nodes, sd->num_nodes, m, bvh2, &cancel_build);
             build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             ok = ok && fold_it(m);
         });

@@ -64,6 +64,8 @@ struct Builder
     struct Task { uint32_t b, e, pos; };
     std::vector<Task> tasks;
     uint32_t grain = 16384;
+    const std::atomic<bool>* cancel = nullptr;
+    bool cancelled() const { return cancel && cancel->load(std::memory_order_relaxed); }
 
     static void grow(float mn[3], float mx[3], const Prim& p)
     {
@@ -188,6 +190,7 @@ struct Builder
         for (;;)
         {
             const uint32_t n = e - b;
+            if (n > 4096u && cancelled()) return;                           // (the result is dropped by build())
             if (n == 1) { write_leaf(pos, prims[b]); return; }
             if (collect && n <= grain) { tasks.push_back({b, e, pos}); return; }
             float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
@@ -206,13 +209,15 @@ struct Builder
 
 // nodes[nn]: the reference's LinearBVHNode[] (validated by the caller: build_wide_bvh's pass 0 has the same requirements).
 // false: nothing to do (leaf root) or the array is not a tree.
-inline bool build(const rt_bvh_node* nodes, uint32_t nn, const Metric& metric, std::vector<rt_bvh_node>& out)
+// cancel (optional): raised by another thread -- the build gives up at its next check and returns false (rt_scene_upload: a candidate built on the device won already)
+inline bool build(const rt_bvh_node* nodes, uint32_t nn, const Metric& metric, std::vector<rt_bvh_node>& out, const std::atomic<bool>* cancel = nullptr)
 {
     out.clear();
     if (nn == 0 || (nodes[0].num_primitives_axis >> 16) != 0) return false;
     Builder B;
     B.ref = nodes;
     B.metric = metric;
+    B.cancel = cancel;
     {
         std::vector<uint32_t> todo{0u};
         size_t seen = 0;
@@ -256,13 +261,14 @@ inline bool build(const rt_bvh_node* nodes, uint32_t nn, const Metric& metric, s
         {
             std::vector<double> s;
             std::vector<uint32_t> o;
-            for (size_t t; (t = next.fetch_add(1)) < B.tasks.size();) B.build(B.tasks[t].b, B.tasks[t].e, B.tasks[t].pos, false, s, o);
+            for (size_t t; (t = next.fetch_add(1)) < B.tasks.size() && !B.cancelled();) B.build(B.tasks[t].b, B.tasks[t].e, B.tasks[t].pos, false, s, o);
         };
         std::vector<std::thread> pool;
         for (unsigned t = 1; t < n_threads; ++t) pool.emplace_back(run);
         run();
         for (auto& th : pool) th.join();
     }
+    if (B.cancelled()) return false;
     out.swap(B.out);
     return true;
 }

@@ -78,7 +78,8 @@ struct rt_ctx
                                   // shadow trace 0.314 -> 0.258 ms per sample on the headline scene, bit-identical on all five configs)
     uint32_t adapt_min_interval_ms = 500;   // RT_CTX_OPT_ADAPT_MIN_INTERVAL_MS
     uint32_t wide_layout = 0;               // RT_CTX_OPT_WIDE_LAYOUT: 1 = the 4-wide records stored in (parent, likeliest child) pairs, one pair per 128-byte line (pair_layout)
-    uint32_t tree_builder = 0;              // RT_CTX_OPT_TREE_BUILDER: 1 = the shadow rays' own binary tree is built on the device (PLOC: ploc_kernels.h) instead of by own_bvh.h's host sweep
+    uint32_t tree_builder = 2;              // RT_CTX_OPT_TREE_BUILDER: the shadow rays' own binary tree -- 0 = own_bvh.h's full-sweep SAH on host threads, 1 = PLOC on the device (ploc_kernels.h),
+                                            // 2 (default) = both start, the device's is measured first and the host's build is abandoned if it wins its measurement
     uint32_t device_fold = 1;               // RT_CTX_OPT_DEVICE_FOLD: the SAH collapse into 4-wide records runs on the device (fold_kernels.h); 0 = on host threads
     uint64_t scene_uploads = 0;             // rt_scene_upload calls so far (what a frame's measured choices were made for)
     std::vector<rt_frame*> frames;   // the frames alive on this context (rt_finish waits for their side streams too)
@@ -414,7 +415,7 @@ int rt_ctx_set_option(rt_ctx* ctx, int option, uint32_t value)
     if (option == RT_CTX_OPT_ADAPTIVE_FOLD) { ctx->adaptive_fold = value & 31u; return RT_OK; }
     if (option == RT_CTX_OPT_DEVICE_FOLD) { ctx->device_fold = value ? 1u : 0u; return RT_OK; }
     if (option == RT_CTX_OPT_WIDE_LAYOUT) { ctx->wide_layout = value ? 1u : 0u; return RT_OK; }
-    if (option == RT_CTX_OPT_TREE_BUILDER) { ctx->tree_builder = value ? 1u : 0u; return RT_OK; }
+    if (option == RT_CTX_OPT_TREE_BUILDER) { ctx->tree_builder = value > 2u ? 2u : value; return RT_OK; }
     if (option == RT_CTX_OPT_ADAPT_WAIT)
     {
         if (ctx->scene.adapt) fold_adapt_set_wait(ctx->scene.adapt, value != 0u);          // the scene in place only
@@ -521,12 +522,18 @@ int rt_scene_upload(rt_ctx* ctx, const rt_scene_desc* sd)
     auto t_lap = t_upload;
     double t_layout = 0.0, t_device = 0.0, t_fold = 0.0, t_own_wait = 0.0, t_choose = 0.0;
     // the trees of the backend's own (below, "Trees of the backend's own") are built on worker threads meanwhile
-    OwnTree own_sh, own_cl;
+    OwnTree own_sh, own_cl, own_sh_dev;      // own_sh_dev: the shadow rays' candidate built on the device (RT_CTX_OPT_TREE_BUILDER != 0)
     const bool may_own = ctx->build_wide == 1u && (uint64_t)nt * 64 <= 0xFFFFFFFFull && (sd->nodes[0].num_primitives_axis >> 16) == 0;
     if (ctx->device_fold && ctx->build_wide == 1u) { own_sh.device = ctx->device; own_cl.device = ctx->device; }
     own_sh.pairs = own_cl.pairs = ctx->wide_layout != 0u;
-    own_sh.device_builder = ctx->tree_builder != 0u && ctx->device_fold != 0u && ctx->build_wide == 1u;      // (the shadow rays' tree only: the closest-hit rays' own tree is the tolerance mode's, host-built)
-    if (may_own && ctx->shadow_tree) own_sh.start(sd, true, ctx->shadow_tree);
+    // (the shadow rays' tree only: the closest-hit rays' own tree is the tolerance mode's, host-built)
+    const bool try_device_tree = may_own && ctx->shadow_tree && ctx->tree_builder != 0u && ctx->device_fold != 0u && ctx->build_wide == 1u;
+    if (try_device_tree)
+    {
+        own_sh_dev.device = ctx->device; own_sh_dev.pairs = own_sh.pairs; own_sh_dev.device_builder = true; own_sh_dev.device_only = true;
+        own_sh_dev.start(sd, true, ctx->shadow_tree);
+    }
+    if (may_own && ctx->shadow_tree && !(try_device_tree && ctx->tree_builder == 1u)) own_sh.start(sd, true, ctx->shadow_tree);
     if (may_own && ctx->closest_tree) own_cl.start(sd, false, ctx->closest_tree);
 
     // --- BVH re-layout: LinearBVHNode[] (bvh.cpp:223-245) -> child-pair records
@@ -727,6 +734,18 @@ int rt_scene_upload(rt_ctx* ctx, const rt_scene_desc* sd)
     bool have_sh = false, have_cl = false;
     s.tree_report.clear();
     t_fold = lap(t_lap) + t_dev_fold;
+    // the shadow rays' candidates: the one built on the device is ready first and is measured first; if it wins, the host's build is abandoned
+    OwnTree* sh = &own_sh;
+    if (try_device_tree)
+    {
+        own_sh_dev.join();
+        (void)hipSetDevice(ctx->device);
+        if (own_sh_dev.ok && have_wide && n_wide_ref != 0u && choose_tree(sd, wide, w_entry, true, ctx->shadow_tree, own_sh_dev, s.tree_report))
+        {
+            sh = &own_sh_dev;
+            own_sh.cancel_build.store(true);
+        }
+    }
     own_sh.join(); own_cl.join();
     t_own_wait = lap(t_lap);
     (void)hipSetDevice(ctx->device);
@@ -737,15 +756,15 @@ int rt_scene_upload(rt_ctx* ctx, const rt_scene_desc* sd)
     };
     if (have_wide && n_wide_ref != 0u && may_own && ctx->shadow_tree)
     {
-        have_sh = choose_tree(sd, wide, w_entry, true, ctx->shadow_tree, own_sh, s.tree_report);
-        if (have_sh) adopt_own(own_sh, s.wnodes_sh);
+        have_sh = sh == &own_sh_dev || choose_tree(sd, wide, w_entry, true, ctx->shadow_tree, own_sh, s.tree_report);
+        if (have_sh) adopt_own(*sh, s.wnodes_sh);
     }
     if (have_wide && n_wide_ref != 0u && may_own && ctx->closest_tree)
     {
         have_cl = choose_tree(sd, wide, w_entry, false, ctx->closest_tree, own_cl, s.tree_report);
         if (have_cl) adopt_own(own_cl, s.wnodes_cl);
     }
-    const uint32_t w_entry_sh = own_sh.entry, w_entry_cl = own_cl.entry;
+    const uint32_t w_entry_sh = sh->entry, w_entry_cl = own_cl.entry;
     t_choose = lap(t_lap);
     if (rc != RT_OK) { free_scene(s); return RT_ERROR; }
     // RT_CTX_OPT_ADAPTIVE_FOLD: what the first rt_integrate needs to fold these trees again for its own rays (FoldAdapt)
@@ -764,7 +783,7 @@ int rt_scene_upload(rt_ctx* ctx, const rt_scene_desc* sd)
         }
         a->bvh2.assign(sd->nodes, sd->nodes + nn);
         a->roots = std::move(wide_roots);
-        if (have_sh) { a->bvh2_sh = std::move(own_sh.bvh2); a->roots_sh = std::move(own_sh.roots); }
+        if (have_sh) { a->bvh2_sh = std::move(sh->bvh2); a->roots_sh = std::move(sh->roots); }
         if (a->mode.load() & 16u)
         {
             a->tri9.resize((size_t)nt * 9);
@@ -802,7 +821,7 @@ int rt_scene_upload(rt_ctx* ctx, const rt_scene_desc* sd)
     if (have_cl) { s.d.wnodes = (const float4*)s.wnodes_cl; s.d.w_entry_ref = w_entry_cl; }
     s.n_wide = have_wide ? n_wide_ref : 0u;
     s.n_tris = nt;
-    s.n_wide_sh = have_sh ? (uint32_t)own_sh.wide.size() : 0u;
+    s.n_wide_sh = have_sh ? (uint32_t)sh->wide.size() : 0u;
     s.n_wide_cl = have_cl ? (uint32_t)own_cl.wide.size() : 0u;
     s.wide_ok = have_wide;
     s.offsets32 = (uint64_t)(n_interior + 1) * 64 <= 0xFFFFFFFFull && (uint64_t)nt * 64 <= 0xFFFFFFFFull;
@@ -818,7 +837,8 @@ int rt_scene_upload(rt_ctx* ctx, const rt_scene_desc* sd)
         snprintf(line, sizeof(line), "upload: %.3f s = record order on the host %.3f + copies and re-layout kernels %.3f + fold of the reference's tree %.3f (%s) + waiting for the own tree(s) %.3f "
             "(shadow tree: built %s in %.3f, folded in %.3f) + choosing by proxy rays and uploading %.3f + adaptation state %.3f (%u triangles, %u nodes, %u + %u wide records)\n",
             std::chrono::duration<double>(std::chrono::steady_clock::now() - t_upload).count(), t_layout, t_device, t_fold, folded_on_device ? "on the device" : "on host threads", t_own_wait,
-            own_sh.built_on_device ? "on the device (PLOC)" : "on host threads", own_sh.build_seconds, own_sh.fold_seconds, t_choose, t_rest, nt, nn, s.n_wide, s.n_wide_sh);
+            sh->built_on_device ? "on the device (PLOC)" : (try_device_tree ? "on host threads (the device-built candidate did not win its measurement)" : "on host threads"),
+            sh->build_seconds, sh->fold_seconds, t_choose, t_rest, nt, nn, s.n_wide, s.n_wide_sh);
         s.tree_report += line;
     }
     return RT_OK;
