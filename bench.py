@@ -1144,12 +1144,14 @@ def main():
         if args.adaptive_fold and world == 1 and args.surface_area_fold_steps > 0 and not args.per_frame_only:
             try:
                 render.set_adaptive_fold(0)                      # ... and uploads again
-                render.reserve_samples(sps)
+                sa_steps = max(args.surface_area_fold_steps, min(args.steps, int(round(0.4 / max(dt_max / max(args.steps, 1), 1e-6)))))   # >= 0.4 s of work
+                # (the buffers of the WHOLE job's batches before the timer, as the headline has them: the per-frame legs have shrunk them meanwhile, and a
+                # hipMalloc of ~100 GB takes seconds -- round 6's first lines timed it here for configs 2 and 5, whose step is smaller than their batch)
+                render.reserve_samples(max(sa_steps * sps, spp_timed))
                 render.render_samples(sps); render.finish()
                 assert lib.rt_reset(frame) == 0
                 sa0 = render.stats()
                 ta = time.perf_counter()
-                sa_steps = max(args.surface_area_fold_steps, min(args.steps, int(round(0.4 / max(dt_max / max(args.steps, 1), 1e-6)))))   # >= 0.4 s of work
                 render.render_samples(sa_steps * sps); render.finish()
                 tb = time.perf_counter() - ta
                 sa1 = render.stats()

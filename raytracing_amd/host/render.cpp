@@ -98,7 +98,7 @@ TiledRender::TiledRender(std::uint32_t width, std::uint32_t height, Scene& scene
         // one adaptation per group (ShareFolds): tile 0 builds the shadow rays' tree and adapts its folds -- waited for by its first frame -- the others take its records
         if (devices.size() > 1)
         {
-            if (i == 0) rt_ctx_set_option(contexts_[i]->Get(), RT_CTX_OPT_ADAPT_WAIT, 1u);
+            if (i == 0) rt_ctx_set_option(contexts_[i]->Get(), RT_CTX_OPT_ADAPTIVE_FOLD, 25u | 2u);     // (the library's default + bit 1: its first frame waits for the adapted fold)
             else { rt_ctx_set_option(contexts_[i]->Get(), RT_CTX_OPT_SHADOW_TREE, 0u); rt_ctx_set_option(contexts_[i]->Get(), RT_CTX_OPT_ADAPTIVE_FOLD, 0u); }
         }
         TileDesc tile;
