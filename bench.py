@@ -1175,23 +1175,30 @@ def main():
                 assert lib.rt_reset(frame) == 0
                 render.finish()
                 c0 = render.stats()
-                cold_in_flight = render.reserve_samples(args.cold_job_spp)               # the per-path buffers of the job's batches: hipMalloc of ~100 GB is not free
-                render.finish()
                 t_r = time.perf_counter()
+                # (no reservation: the library sizes the job's buffers itself -- lean growth, rt_integrate -- and maps them inside render_s; beside it, afterwards and
+                # untimed by the job: what mapping the FULL batch's buffers costs on this box, the figure that made the growth lean)
                 render.render_samples(args.cold_job_spp)
                 render.finish()
                 gather(True)
                 t_c = time.perf_counter()
                 c1 = render.stats()
+                cold_in_flight = int(c1.samples_in_flight)
+                t_f0 = time.perf_counter()
+                full_in_flight = render.reserve_samples(args.cold_job_spp)
+                render.finish()
+                t_full = time.perf_counter() - t_f0
                 c_rays = float((c1.closest_rays - c0.closest_rays) + (c1.shadow_rays - c0.shadow_rays))
-                cold_job = dict(spp=args.cold_job_spp, upload_s=round(t_b - t_a, 3), alloc_s=round(t_r - t_b, 3), samples_in_flight=int(cold_in_flight),
+                cold_job = dict(spp=args.cold_job_spp, upload_s=round(t_b - t_a, 3), samples_in_flight=cold_in_flight, path_state_GB=round(c1.path_state_bytes / 2.0**30, 2),
                                 render_s=round(t_c - t_r, 3), wall_s=round(t_c - t_a, 3),
+                                full_batch=dict(samples_in_flight=int(full_in_flight), alloc_s=round(t_full, 3),
+                                                what="growing the buffers from the job's to the full batch's afterwards (hipMalloc + hipFree): what a job that reserves the full batch pays before its first ray"),
                                 mrays_per_s_render=round(c_rays / (t_c - t_r) / 1e6, 1), mrays_per_s_wall=round(c_rays / (t_c - t_a) / 1e6, 1),
                                 over_the_warm_headline=round(c_rays / (t_c - t_r) / 1e6 / value, 4) if value > 0 else None,
                                 trees=render.tree_report().strip().split("\n"),
                                 what="the config's whole job, cold: rt_scene_upload (re-layout, folds, own tree, tree choice) + %d spp + the gather, library defaults "
-                                     "(adaptive fold 25 = asynchronous: the job starts on the upload's fold and adopts the adapted one when its worker is done), the per-path "
-                                     "buffers of its batches allocated inside the wall time (alloc_s); scene generation / OBJ parsing and the reference-topology BVH build are in setup_s" % args.cold_job_spp)
+                                     "(adaptive fold 25 = asynchronous: the job starts on the upload's fold and adopts the adapted one when its worker is done; no reservation: the buffers grow "
+                                     "lean, an eighth of the samples asked for), everything inside the wall time; scene generation / OBJ parsing and the reference-topology BVH build are in setup_s" % args.cold_job_spp)
             except Exception as e:                              # noqa: BLE001 -- reported, never fatal to the measurement
                 cold_job = dict(error=repr(e))
         scaling_estimate = None

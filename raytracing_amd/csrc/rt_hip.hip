@@ -195,6 +195,8 @@ struct rt_frame
     uint32_t slots = 1;            // samples traced concurrently (resolved from slots_opt)
     uint32_t slots_opt = 0;        // RT_OPT_SAMPLES_IN_FLIGHT as set by the caller (0 = auto)
     uint32_t slots_limit = 0;      // != 0: a larger batch did not fit into device memory
+    bool reserved_explicitly = false;  // rt_frame_reserve_samples has been called: rt_integrate does not second-guess the buffers' size
+    uint64_t samples_asked = 0;        // samples rt_integrate has been asked for since the frame was made (lean growth of the buffers)
     uint32_t log_stride = 0;       // elements per log entry row = slots * chunk_pixels
     // Chunks also bound memory: RT_OPT_PATH_STATE_LIMIT_MB caps the per-path buffers of all pipes together
     // (path ids are chunk-relative, the radiance log is replayed per chunk).
@@ -1360,6 +1362,7 @@ int rt_set_option(rt_frame* f, int option, uint32_t value)
             HIPCHK(f->ctx, hipStreamSynchronize(f->ctx->stream));
             uint32_t old = f->slots_opt, old_slots = f->slots;
             f->slots_opt = value;
+            f->reserved_explicitly = false; f->samples_asked = 0;      // (the caller decides anew how the buffers are sized: lean growth starts over)
             // an explicit count is allocated now; auto (0) grows with the batches requested
             if (alloc_path_buffers(f, value ? value : 1u) != RT_OK)
             {
@@ -2138,6 +2141,7 @@ int rt_advance_sample(rt_frame* f)                      // AdvanceSampleCount, :
 int rt_frame_reserve_samples(rt_frame* f, uint32_t n_samples, uint32_t* reserved)
 {
     FRAME_PROLOGUE(f, "rt_frame_reserve_samples");
+    f->reserved_explicitly = true;                       // (rt_integrate then takes the buffers as they are: no lean growth)
     if (ensure_slots(f, n_samples ? n_samples : 1u) != RT_OK) return RT_ERROR;
     if (reserved) *reserved = f->slots;
     return RT_OK;
@@ -2161,7 +2165,21 @@ int rt_integrate(rt_frame* f, uint32_t n_samples)       // n x Integrator::Integ
     uint32_t done = 0;
     const bool per_frame = f->denoiser || f->aov != 0;  // interactive features: one sample per Integrate()
     uint32_t cap = per_frame ? 1u : slot_cap(f);
-    if (ensure_slots(f, n_samples < cap ? n_samples : cap) != RT_OK) return RT_ERROR;
+    uint32_t want = n_samples < cap ? n_samples : cap;
+    // Lean growth (round 6).  Mapping the per-path buffers is not free: a hipMalloc of the 102 GB that 128 samples of a 1080p frame in flight take costs 2.4 - 3.5 s on
+    // an MI355X box (bench.py: config.path_state_alloc_s, cold_job.alloc_s) -- six times what BASELINE's whole 256-spp job renders in.  So a job that has to GROW the buffers,
+    // was not told how many samples to keep in flight (RT_OPT_SAMPLES_IN_FLIGHT = 0) and did not reserve them (rt_frame_reserve_samples) grows them with what it has been asked
+    // for so far: an eighth of the samples requested since the frame was made (at least 16), never below what 8 GiB hold -- 256 spp at 1080p: 32 in flight, 27 GB, ~5 % below the
+    // full batch's rate; a job that keeps asking reaches the full batch by doubling.
+    f->samples_asked += n_samples;
+    if (!per_frame && f->slots_opt == 0u && !f->reserved_explicitly && want > f->slots)
+    {
+        const uint64_t per_slot = (uint64_t)bytes_per_path(f, want) * (f->n_local ? f->n_local : 1u);
+        const uint64_t lean = std::max<uint64_t>(16u, (f->samples_asked + 7u) / 8u), floor_slots = (8ull << 30) / (per_slot ? per_slot : 1u);
+        const uint64_t grown = std::max<uint64_t>(std::max(lean, floor_slots), f->slots);
+        if (grown < want) want = (uint32_t)grown;
+    }
+    if (ensure_slots(f, want) != RT_OK) return RT_ERROR;
     // ensure_slots may have halved the batch to fit the device (slots_limit): never ask for more than it got
     if (!per_frame) cap = slot_cap(f) < f->slots ? slot_cap(f) : f->slots;
     if (cap == 0) cap = 1;

@@ -114,3 +114,23 @@ def test_headline_frame_128_samples_in_flight_equals_8_in_flight_bit_for_bit(env
     assert not diff.any(), "%d of %d pixels differ, first at %s" % (diff.sum(), diff.size, np.argwhere(diff)[:3].tolist())
     assert (st_small.closest_rays, st_small.shadow_rays) == (st_big.closest_rays, st_big.shadow_rays)     # rt_reset rewinds the counters
     r.close()
+
+
+def test_a_job_that_does_not_reserve_grows_its_buffers_lean(blob_scene):
+    """Round 6: mapping the per-path buffers costs seconds per 100 GB, so rt_integrate grows them with the samples it has been asked for (an eighth of them, at least
+    16, never below what 8 GiB hold) unless the caller reserved (rt_frame_reserve_samples) or fixed the count (RT_OPT_SAMPLES_IN_FLIGHT) -- same bits either way."""
+    w, h, b = 960, 540, 4
+    ctx = capi.Context(0)
+    ctx.upload_scene(blob_scene)
+    cam = T.default_camera(w, h)
+    lean, full = capi.Frame(ctx, w, h), capi.Frame(ctx, w, h)
+    for f in (lean, full):
+        f.set_camera(cam); f.set_max_bounces(b)
+    assert full.reserve_samples(256) >= 128
+    lean.integrate(256); full.integrate(256)
+    sl, sf = lean.stats(), full.stats()
+    assert sl.samples_in_flight < sf.samples_in_flight and sl.path_state_bytes <= 9 * 2**30, (sl.samples_in_flight, sl.path_state_bytes)
+    assert np.array_equal(lean.radiance(), full.radiance(), equal_nan=True)
+    lean.integrate(2048 - 256)                           # a job that keeps asking reaches the full batch
+    assert lean.stats().samples_in_flight >= min(sf.samples_in_flight, 256)
+    lean.close(); full.close(); ctx.close()
