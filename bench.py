@@ -425,6 +425,42 @@ def frame_kernel_legs(args, render, lib, frame, capi, default_leg):
     return out
 
 
+def cold_job_leg(args, render, host, capi, lib, torch, setup_breakdown):
+    """BASELINE's job as a user of rt_render gets it, and the FIRST thing this process does with the device: the scene upload Render's constructor has just made
+    (library defaults: RT_CTX_OPT_ADAPTIVE_FOLD = 25, the probe, the worker and the adoption run beside the job and nothing waits for them) + `--cold-job-spp` samples
+    + the copy of the frame to the host, no reservation (rt_integrate sizes the job's buffers itself -- lean growth -- and maps them inside render_s).
+    First, because a process that has just given large buffers back waits for the driver's wipe of them in its next hipMalloc (tools/alloc_microbench.hip,
+    profiles/r06/call13_alloc_sequences.log: 0 - 6 s for 100 GiB, by what was released when) -- which is this bench's history, not a cold job's."""
+    frame = host.load().rth_render_frame_handle(render.handle)
+    tile = torch.zeros((max(render.local_rows, 1), args.width, 4), dtype=torch.float32, device="cuda")      # (torch's own start-up: not the job's)
+    torch.cuda.synchronize()
+    t_r = time.perf_counter()
+    render.set_camera(host.default_camera(args.width, args.height))
+    render.set_max_bounces(args.bounces)
+    render.set_resolve_every_frame(False)
+    c0 = render.stats()
+    render.render_samples(args.cold_job_spp)
+    render.finish()
+    lib.rt_frame_copy_radiance(frame, tile.data_ptr())
+    img = tile[:render.local_rows].cpu()
+    t_c = time.perf_counter()
+    c1 = render.stats()
+    rays = float((c1.closest_rays - c0.closest_rays) + (c1.shadow_rays - c0.shadow_rays))
+    upload_s = float(setup_breakdown.get("upload", 0.0))
+    out = dict(spp=args.cold_job_spp, upload_s=round(upload_s, 3), samples_in_flight=int(c1.samples_in_flight), path_state_GB=round(c1.path_state_bytes / 2.0**30, 2),
+               render_s=round(t_c - t_r, 3), wall_s=round(upload_s + (t_c - t_r), 3), rays=rays, finite=bool(torch.isfinite(img).all().item()),
+               mrays_per_s_render=round(rays / (t_c - t_r) / 1e6, 1), mrays_per_s_wall=round(rays / (upload_s + (t_c - t_r)) / 1e6, 1),
+               trees=render.tree_report().strip().split("\n"),
+               what="the config's whole job, cold, the first use of the device by this process: Render's own UploadGPUData (rt_scene_upload: re-layout, folds, own tree, tree choice) "
+                    "+ %d spp + the frame's copy to the host, library defaults (adaptive fold 25 = asynchronous: the job starts on the upload's fold and adopts the adapted one when "
+                    "its worker is done; no reservation: the buffers grow lean, an eighth of the samples asked for, mapped inside render_s); scene generation / OBJ parsing and the "
+                    "reference-topology BVH build are in setup_s" % args.cold_job_spp)
+    assert lib.rt_reset(frame) == 0
+    render.finish()
+    del tile
+    return out
+
+
 def median_pixel_rel_err(a, b):
     """median over the pixels of |a - b| / max(|b|, 1e-6) (L2 over the channels): one firefly sample cannot move it, unlike rel-L2"""
     import numpy as np
@@ -752,6 +788,15 @@ def main():
                          ctx_options=((2, 0), (4, 0)) if share_folds and rank != 0 else ())
     t_setup = time.time() - t0
     setup_breakdown = render.setup_seconds()                 # Render's constructor: BVH build / Finalize / frame / UploadGPUData (its stages: the `upload:` line of the tree report)
+    cold_job = None
+    if world == 1 and args.cold_job_spp > 0 and not args.per_frame_only:
+        try:
+            cold_job = cold_job_leg(args, render, host, capi, capi.load(), torch, setup_breakdown)
+        except Exception as e:                                # noqa: BLE001 -- reported, never fatal to the measurement
+            cold_job = dict(error=repr(e))
+        if not (args.shadow_tree is not None or args.closest_tree is not None or args.adaptive_fold != capi.ADAPTIVE_FOLD_DEFAULT or args.wide_layout is not None
+                or args.device_fold is not None or args.tree_builder is not None or args.wide_collapse != 1):
+            render.set_wide_bvh(args.wide_collapse)           # the measured job starts from a fresh upload as well (no other branch below makes one)
     if args.wide_collapse != 1:
         render.set_wide_bvh(args.wide_collapse)               # A/B: uploads the scene again with the other collapse
     if share_folds and rank != 0:
@@ -1160,47 +1205,11 @@ def main():
                                          what="the same job on the fold rt_scene_upload makes (RT_CTX_OPT_ADAPTIVE_FOLD = 0), same box, untimed by the driver")
             except Exception as e:                              # noqa: BLE001 -- reported, never fatal to the measurement
                 surface_area_fold = dict(error=repr(e))
-        # BASELINE's job as a user of rt_render gets it: 256 spp of this frame from rt_scene_upload to the last sample's gather, the LIBRARY's defaults
-        # (RT_CTX_OPT_ADAPTIVE_FOLD = 25: the probe, the worker and the adoption run beside the job, nothing waits for them), per-path buffers
-        # allocated inside the timer.  Beside the warm headline: what a cold job really sees of the adapted fold.
-        cold_job = None
-        if world == 1 and args.cold_job_spp > 0 and not args.per_frame_only:
-            try:
-                assert lib.rt_set_option(frame, capi.OPT_SAMPLES_IN_FLIGHT, 1) == 0      # gives the batch buffers back ...
-                assert lib.rt_set_option(frame, capi.OPT_SAMPLES_IN_FLIGHT, args.samples_in_flight) == 0
-                render.finish()
-                t_a = time.perf_counter()
-                render.set_adaptive_fold(capi.ADAPTIVE_FOLD_DEFAULT)                      # ... and uploads the scene again (rt_scene_upload)
-                t_b = time.perf_counter()
-                assert lib.rt_reset(frame) == 0
-                render.finish()
-                c0 = render.stats()
-                t_r = time.perf_counter()
-                # (no reservation: the library sizes the job's buffers itself -- lean growth, rt_integrate -- and maps them inside render_s; beside it, afterwards and
-                # untimed by the job: what mapping the FULL batch's buffers costs on this box, the figure that made the growth lean)
-                render.render_samples(args.cold_job_spp)
-                render.finish()
-                gather(True)
-                t_c = time.perf_counter()
-                c1 = render.stats()
-                cold_in_flight = int(c1.samples_in_flight)
-                t_f0 = time.perf_counter()
-                full_in_flight = render.reserve_samples(args.cold_job_spp)
-                render.finish()
-                t_full = time.perf_counter() - t_f0
-                c_rays = float((c1.closest_rays - c0.closest_rays) + (c1.shadow_rays - c0.shadow_rays))
-                cold_job = dict(spp=args.cold_job_spp, upload_s=round(t_b - t_a, 3), samples_in_flight=cold_in_flight, path_state_GB=round(c1.path_state_bytes / 2.0**30, 2),
-                                render_s=round(t_c - t_r, 3), wall_s=round(t_c - t_a, 3),
-                                full_batch=dict(samples_in_flight=int(full_in_flight), alloc_s=round(t_full, 3),
-                                                what="growing the buffers from the job's to the full batch's afterwards (hipMalloc + hipFree): what a job that reserves the full batch pays before its first ray"),
-                                mrays_per_s_render=round(c_rays / (t_c - t_r) / 1e6, 1), mrays_per_s_wall=round(c_rays / (t_c - t_a) / 1e6, 1),
-                                over_the_warm_headline=round(c_rays / (t_c - t_r) / 1e6 / value, 4) if value > 0 else None,
-                                trees=render.tree_report().strip().split("\n"),
-                                what="the config's whole job, cold: rt_scene_upload (re-layout, folds, own tree, tree choice) + %d spp + the gather, library defaults "
-                                     "(adaptive fold 25 = asynchronous: the job starts on the upload's fold and adopts the adapted one when its worker is done; no reservation: the buffers grow "
-                                     "lean, an eighth of the samples asked for), everything inside the wall time; scene generation / OBJ parsing and the reference-topology BVH build are in setup_s" % args.cold_job_spp)
-            except Exception as e:                              # noqa: BLE001 -- reported, never fatal to the measurement
-                cold_job = dict(error=repr(e))
+        if cold_job and "rays" in cold_job:
+            # (the growth from the cold job's buffers to the measured job's full batch is path_state_alloc_s: what a job that reserves the full batch pays before its first ray)
+            cold_job["full_batch"] = dict(samples_in_flight=int(in_flight), alloc_s=round(t_first_alloc, 3),
+                                          what="growing the buffers from the cold job's to the measured job's full batch afterwards (hipFree + hipMalloc), untimed by either")
+            cold_job["over_the_warm_headline"] = round(cold_job["mrays_per_s_render"] / value, 4) if value > 0 else None
         scaling_estimate = None
         est_path = os.path.join(ROOT, "profiles", "r06_tile_efficiency.json")
         if not os.path.exists(est_path):

@@ -34,6 +34,8 @@
 #include <algorithm>
 #include <array>
 #include <atomic>
+#include <condition_variable>
+#include <mutex>
 #include <thread>
 #include <vector>
 #include "rt_types.h"
@@ -62,8 +64,8 @@ struct Builder
     std::vector<Prim> prims;
     std::vector<rt_bvh_node> out;
     struct Task { uint32_t b, e, pos; };
-    std::vector<Task> tasks;
-    uint32_t grain = 16384;
+    uint32_t grain = 16384;                 // a range of at most this many leaves is one task: its whole subtree, built by one thread
+    unsigned n_threads = 1;
     const std::atomic<bool>* cancel = nullptr;
     bool cancelled() const { return cancel && cancel->load(std::memory_order_relaxed); }
 
@@ -88,15 +90,41 @@ struct Builder
         out[pos] = n;
     }
 
+    // fn(slice, first, last) over K equal slices of [b, e), slice 0 on the calling thread.  Everything the slices reduce here (min / max of floats, counts) is
+    // exact and order-free, so a result never depends on K.
+    template <class F> static void slices(uint32_t b, uint32_t e, unsigned K, F fn)
+    {
+        const uint32_t n = e - b;
+        if (K <= 1u || n < 2u * K) { fn(0u, b, e); return; }
+        std::vector<std::thread> pool;
+        for (unsigned k = 1; k < K; ++k) pool.emplace_back(fn, k, b + (uint32_t)((uint64_t)n * k / K), b + (uint32_t)((uint64_t)n * (k + 1) / K));
+        fn(0u, b, b + (uint32_t)((uint64_t)n / K));
+        for (auto& th : pool) th.join();
+    }
+
     // Splits prims[b, e) (n >= 2) in place; returns the first index of the upper part and the axis.  Cost of a candidate:
     // metric(lower box) * leaves below it + metric(upper box) * leaves above it (the greedy top-down SAH; interior boxes
     // are all that is paid for here -- every leaf is one reference leaf whichever tree it hangs in).
-    uint32_t split(uint32_t b, uint32_t e, uint32_t& axis_out, std::vector<double>& scratch, std::vector<uint32_t>& order)
+    // K: the threads this range may use for its passes (the top of a large tree: Builder::run); the split is the same for every K.
+    uint32_t split(uint32_t b, uint32_t e, uint32_t& axis_out, std::vector<double>& scratch, std::vector<uint32_t>& order, unsigned K = 1)
     {
         const uint32_t n = e - b;
         float cmn[3] = {INFINITY, INFINITY, INFINITY}, cmx[3] = {-INFINITY, -INFINITY, -INFINITY};
-        for (uint32_t i = b; i < e; ++i)
-            for (int a = 0; a < 3; ++a) { cmn[a] = std::min(cmn[a], prims[i].c[a]); cmx[a] = std::max(cmx[a], prims[i].c[a]); }
+        if (K > 1u)
+        {
+            std::vector<std::array<float, 6>> part(K, std::array<float, 6>{INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY});
+            slices(b, e, K, [&](unsigned k, uint32_t sb, uint32_t se)
+            {
+                std::array<float, 6> r = part[k];
+                for (uint32_t i = sb; i < se; ++i)
+                    for (int a = 0; a < 3; ++a) { r[a] = std::min(r[a], prims[i].c[a]); r[3 + a] = std::max(r[3 + a], prims[i].c[a]); }
+                part[k] = r;
+            });
+            for (const auto& r : part) for (int a = 0; a < 3; ++a) { cmn[a] = std::min(cmn[a], r[a]); cmx[a] = std::max(cmx[a], r[3 + a]); }
+        }
+        else
+            for (uint32_t i = b; i < e; ++i)
+                for (int a = 0; a < 3; ++a) { cmn[a] = std::min(cmn[a], prims[i].c[a]); cmx[a] = std::max(cmx[a], prims[i].c[a]); }
         double best = INFINITY; int best_axis = -1; uint32_t best_at = 0;
         const float NINF = -INFINITY;
         if (n > 768u)
@@ -111,7 +139,28 @@ struct Builder
                 for (int j = 0; j < NB; ++j) { Bin& bn = bins[j]; for (int k = 0; k < 3; ++k) { bn.mn[k] = INFINITY; bn.mx[k] = NINF; } bn.count = 0; }
                 const double scale = NB / ((double)cmx[a] - cmn[a]);
                 auto bin_of = [&](const Prim& p) { int k = (int)(((double)p.c[a] - cmn[a]) * scale); return k < 0 ? 0 : (k >= NB ? NB - 1 : k); };
-                for (uint32_t i = b; i < e; ++i) { Bin& bn = bins[bin_of(prims[i])]; grow(bn.mn, bn.mx, prims[i]); ++bn.count; }
+                if (K > 1u)
+                {
+                    // every slice bins into bins of its own; merged in slice order (min / max / sums of counts: the same bins whatever K is)
+                    std::vector<Bin> part((size_t)K * NB);
+                    slices(b, e, K, [&](unsigned k, uint32_t sb, uint32_t se)
+                    {
+                        Bin* mine = &part[(size_t)k * NB];
+                        for (int j = 0; j < NB; ++j) { for (int q = 0; q < 3; ++q) { mine[j].mn[q] = INFINITY; mine[j].mx[q] = NINF; } mine[j].count = 0; }
+                        for (uint32_t i = sb; i < se; ++i) { Bin& bn = mine[bin_of(prims[i])]; grow(bn.mn, bn.mx, prims[i]); ++bn.count; }
+                    });
+                    for (unsigned k = 0; k < K; ++k)
+                        for (int j = 0; j < NB; ++j)
+                        {
+                            const Bin& src = part[(size_t)k * NB + j];
+                            if (!src.count) continue;
+                            Bin& bn = bins[j];
+                            for (int q = 0; q < 3; ++q) { bn.mn[q] = std::min(bn.mn[q], src.mn[q]); bn.mx[q] = std::max(bn.mx[q], src.mx[q]); }
+                            bn.count += src.count;
+                        }
+                }
+                else
+                    for (uint32_t i = b; i < e; ++i) { Bin& bn = bins[bin_of(prims[i])]; grow(bn.mn, bn.mx, prims[i]); ++bn.count; }
                 scratch.assign(NB, 0.0);
                 float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {NINF, NINF, NINF};
                 uint32_t cnt = 0;
@@ -184,33 +233,109 @@ struct Builder
         return b + n / 2;
     }
 
+    // One node: the box of prims[b, e) (n >= 2), its split, its record at pos.  Returns the first index of the upper part.
     // a subtree over n leaves takes 2 n - 1 records: first child at pos + 1, second at pos + 2 * (leaves of the first)
-    void build(uint32_t b, uint32_t e, uint32_t pos, bool collect, std::vector<double>& scratch, std::vector<uint32_t>& order)
+    uint32_t step(uint32_t b, uint32_t e, uint32_t pos, std::vector<double>& scratch, std::vector<uint32_t>& order, unsigned K = 1)
+    {
+        float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+        if (K > 1u)
+        {
+            std::vector<std::array<float, 6>> part(K, std::array<float, 6>{INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY});
+            slices(b, e, K, [&](unsigned k, uint32_t sb, uint32_t se)
+            {
+                float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+                for (uint32_t i = sb; i < se; ++i) grow(lo, hi, prims[i]);
+                part[k] = {lo[0], lo[1], lo[2], hi[0], hi[1], hi[2]};
+            });
+            for (const auto& r : part) for (int a = 0; a < 3; ++a) { mn[a] = std::min(mn[a], r[a]); mx[a] = std::max(mx[a], r[3 + a]); }
+        }
+        else
+            for (uint32_t i = b; i < e; ++i) grow(mn, mx, prims[i]);
+        uint32_t axis = 0;
+        const uint32_t mid = split(b, e, axis, scratch, order, K);
+        write_interior(pos, mn, mx, axis, pos + 2u * (mid - b));
+        return mid;
+    }
+
+    // the whole subtree over prims[b, e) at pos, on the calling thread
+    void build(uint32_t b, uint32_t e, uint32_t pos, std::vector<double>& scratch, std::vector<uint32_t>& order)
     {
         for (;;)
         {
             const uint32_t n = e - b;
             if (n > 4096u && cancelled()) return;                           // (the result is dropped by build())
             if (n == 1) { write_leaf(pos, prims[b]); return; }
-            if (collect && n <= grain) { tasks.push_back({b, e, pos}); return; }
-            float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-            for (uint32_t i = b; i < e; ++i) grow(mn, mx, prims[i]);
-            uint32_t axis = 0;
-            const uint32_t mid = split(b, e, axis, scratch, order);
+            const uint32_t mid = step(b, e, pos, scratch, order);
             const uint32_t nl = mid - b;
-            write_interior(pos, mn, mx, axis, pos + 2u * nl);
             // recurse into the SMALLER part, iterate on the larger: the positions of both are known (pos + 1 and pos + 2 nl), so the
             // order does not matter and the recursion is at most log2(n) deep however lopsided the splits are
-            if (nl <= n - nl) { build(b, mid, pos + 1u, collect, scratch, order); b = mid; pos = pos + 2u * nl; }
-            else { build(mid, e, pos + 2u * nl, collect, scratch, order); e = mid; pos = pos + 1u; }
+            if (nl <= n - nl) { build(b, mid, pos + 1u, scratch, order); b = mid; pos = pos + 2u * nl; }
+            else { build(mid, e, pos + 2u * nl, scratch, order); e = mid; pos = pos + 1u; }
         }
+    }
+
+    // The tree, on n_threads threads.  A queue of ranges, the largest taken first: a range above the grain is split ONCE (its passes over the leaves on as many
+    // threads as its share of all leaves is of the pool: the root's on all of them, its children's on half each ...) and hands its two parts back to the queue; a
+    // range within the grain is built to the bottom by the thread that took it.  Which thread does what changes nothing in the result: a split depends on the SET
+    // of leaves in its range only (bins are min / max / counts, the sweep sorts by a total order), and every record's position follows from the counts.
+    // (Round 6: the top of the tree -- nine levels for 8.7 M leaves -- used to be built by one thread before the pool started: 1.8 s of which 1.5 were that.)
+    void run()
+    {
+        const uint32_t np = (uint32_t)prims.size();
+        std::mutex mu;
+        std::condition_variable cv;
+        std::vector<Task> queue{Task{0u, np, 0u}};
+        unsigned active = 0;
+        auto worker = [&]()
+        {
+            std::vector<double> scratch;
+            std::vector<uint32_t> order;
+            for (;;)
+            {
+                Task t;
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return !queue.empty() || active == 0u || cancelled(); });
+                    if (cancelled() || queue.empty()) { cv.notify_all(); return; }      // (empty and nobody active: done)
+                    size_t at = 0;
+                    for (size_t i = 1; i < queue.size(); ++i) if (queue[i].e - queue[i].b > queue[at].e - queue[at].b) at = i;
+                    t = queue[at];
+                    queue[at] = queue.back();
+                    queue.pop_back();
+                    ++active;
+                }
+                const uint32_t n = t.e - t.b;
+                Task kids[2];
+                unsigned n_kids = 0;
+                if (n <= grain || n < 2u) build(t.b, t.e, t.pos, scratch, order);
+                else
+                {
+                    const unsigned K = (unsigned)std::max<uint64_t>(1u, std::min<uint64_t>(n_threads, ((uint64_t)n_threads * n + np / 2u) / np));
+                    const uint32_t mid = step(t.b, t.e, t.pos, scratch, order, n >= 65536u ? K : 1u);
+                    kids[0] = Task{t.b, mid, t.pos + 1u};
+                    kids[1] = Task{mid, t.e, t.pos + 2u * (mid - t.b)};
+                    n_kids = 2;
+                }
+                {
+                    std::lock_guard<std::mutex> lk(mu);
+                    for (unsigned k = 0; k < n_kids; ++k) queue.push_back(kids[k]);
+                    --active;
+                }
+                cv.notify_all();
+            }
+        };
+        std::vector<std::thread> pool;
+        for (unsigned t = 1; t < n_threads; ++t) pool.emplace_back(worker);
+        worker();
+        for (auto& th : pool) th.join();
     }
 };
 
 // nodes[nn]: the reference's LinearBVHNode[] (validated by the caller: build_wide_bvh's pass 0 has the same requirements).
 // false: nothing to do (leaf root) or the array is not a tree.
 // cancel (optional): raised by another thread -- the build gives up at its next check and returns false (rt_scene_upload: a candidate built on the device won already)
-inline bool build(const rt_bvh_node* nodes, uint32_t nn, const Metric& metric, std::vector<rt_bvh_node>& out, const std::atomic<bool>* cancel = nullptr)
+// threads: 0 = the host's (at most 32); the tree does not depend on it
+inline bool build(const rt_bvh_node* nodes, uint32_t nn, const Metric& metric, std::vector<rt_bvh_node>& out, const std::atomic<bool>* cancel = nullptr, unsigned threads = 0)
 {
     out.clear();
     if (nn == 0 || (nodes[0].num_primitives_axis >> 16) != 0) return false;
@@ -249,25 +374,8 @@ inline bool build(const rt_bvh_node* nodes, uint32_t nn, const Metric& metric, s
     const uint32_t np = (uint32_t)B.prims.size();
     if (np < 2) return false;
     B.out.resize((size_t)2 * np - 1);
-    std::vector<double> scratch;
-    std::vector<uint32_t> order;
-    B.build(0, np, 0, true, scratch, order);                              // the top of the tree; subtrees of <= grain leaves become tasks
-    {
-        const unsigned n_threads = (unsigned)std::min<size_t>(std::max(1u, std::min(std::thread::hardware_concurrency(), 32u)), B.tasks.size());
-        std::atomic<size_t> next{0};
-        // largest first: the pool drains evenly
-        std::sort(B.tasks.begin(), B.tasks.end(), [](const Builder::Task& x, const Builder::Task& y) { return x.e - x.b > y.e - y.b; });
-        auto run = [&]()
-        {
-            std::vector<double> s;
-            std::vector<uint32_t> o;
-            for (size_t t; (t = next.fetch_add(1)) < B.tasks.size() && !B.cancelled();) B.build(B.tasks[t].b, B.tasks[t].e, B.tasks[t].pos, false, s, o);
-        };
-        std::vector<std::thread> pool;
-        for (unsigned t = 1; t < n_threads; ++t) pool.emplace_back(run);
-        run();
-        for (auto& th : pool) th.join();
-    }
+    B.n_threads = threads ? threads : std::max(1u, std::min(std::thread::hardware_concurrency(), 32u));
+    B.run();
     if (B.cancelled()) return false;
     out.swap(B.out);
     return true;

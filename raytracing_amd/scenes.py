@@ -346,13 +346,13 @@ def _instances(unit, centers, scales, rng, mtl_ids):
 
 
 def _triangles_with_ids(P, N, U, mt):
+    """(n, 3, 3) positions and normals, (n, 3, 2) texture coordinates and n material ids as rt_types' 160-byte triangle records: per vertex 12 floats
+    (position xyz_, texcoord xy__, normal xyz_), written as three block copies through a float view of the record array."""
     tris = np.zeros(len(P), dtype=T.triangle)
-    for vi, vn in enumerate(("v1", "v2", "v3")):
-        for ci, c in enumerate("xyz"):
-            tris[vn]["position"][c] = P[:, vi, ci]
-            tris[vn]["normal"][c] = N[:, vi, ci]
-        tris[vn]["texcoord"]["x"] = U[:, vi, 0]
-        tris[vn]["texcoord"]["y"] = U[:, vi, 1]
+    v = tris.view(np.float32).reshape(len(P), 40)[:, :36].reshape(len(P), 3, 12)
+    v[:, :, 0:3] = P
+    v[:, :, 4:6] = U
+    v[:, :, 8:11] = N
     tris["mtl_index"] = mt
     return tris
 
