@@ -34,6 +34,7 @@
 #include <algorithm>
 #include <array>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <mutex>
 #include <thread>
@@ -335,15 +336,23 @@ struct Builder
 // false: nothing to do (leaf root) or the array is not a tree.
 // cancel (optional): raised by another thread -- the build gives up at its next check and returns false (rt_scene_upload: a candidate built on the device won already)
 // threads: 0 = the host's (at most 32); the tree does not depend on it
-inline bool build(const rt_bvh_node* nodes, uint32_t nn, const Metric& metric, std::vector<rt_bvh_node>& out, const std::atomic<bool>* cancel = nullptr, unsigned threads = 0)
+// phases (optional, tools/own_bvh_bench.cpp): seconds of { collecting the leaves, allocating the output, the pool }
+inline bool build(const rt_bvh_node* nodes, uint32_t nn, const Metric& metric, std::vector<rt_bvh_node>& out, const std::atomic<bool>* cancel = nullptr, unsigned threads = 0,
+    double* phases = nullptr)
 {
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto since = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count(); };
     out.clear();
     if (nn == 0 || (nodes[0].num_primitives_axis >> 16) != 0) return false;
     Builder B;
     B.ref = nodes;
     B.metric = metric;
     B.cancel = cancel;
+    B.n_threads = threads ? threads : std::max(1u, std::min(std::thread::hardware_concurrency(), 32u));
     {
+        // the walk only lists the leaves (and is what says "not a tree"); their boxes are read by the pool's threads afterwards
+        std::vector<uint32_t> leaves;
+        leaves.reserve((size_t)nn / 2u + 1u);
         std::vector<uint32_t> todo{0u};
         size_t seen = 0;
         while (!todo.empty())
@@ -352,30 +361,39 @@ inline bool build(const rt_bvh_node* nodes, uint32_t nn, const Metric& metric, s
             todo.pop_back();
             if (++seen > nn) return false;
             const rt_bvh_node& n = nodes[i];
-            if ((n.num_primitives_axis >> 16) != 0)
+            if ((n.num_primitives_axis >> 16) != 0) { leaves.push_back(i); continue; }
+            if (i + 1 >= nn || n.offset >= nn || n.offset <= i + 1) return false;
+            todo.push_back(n.offset);
+            todo.push_back(i + 1);
+        }
+        B.prims.resize(leaves.size());
+        std::atomic<bool> finite{true};
+        Builder::slices(0u, (uint32_t)leaves.size(), leaves.size() >= 65536u ? B.n_threads : 1u, [&](unsigned, uint32_t sb, uint32_t se)
+        {
+            for (uint32_t k = sb; k < se; ++k)
             {
+                const rt_bvh_node& n = nodes[leaves[k]];
                 Prim p;
                 p.mn[0] = n.bounds_min.x; p.mn[1] = n.bounds_min.y; p.mn[2] = n.bounds_min.z;
                 p.mx[0] = n.bounds_max.x; p.mx[1] = n.bounds_max.y; p.mx[2] = n.bounds_max.z;
                 for (int a = 0; a < 3; ++a)
                 {
-                    if (!std::isfinite(p.mn[a]) || !std::isfinite(p.mx[a])) return false;
+                    if (!std::isfinite(p.mn[a]) || !std::isfinite(p.mx[a])) finite.store(false, std::memory_order_relaxed);
                     p.c[a] = 0.5f * p.mn[a] + 0.5f * p.mx[a];
                 }
-                p.leaf = i;
-                B.prims.push_back(p);
-                continue;
+                p.leaf = leaves[k];
+                B.prims[k] = p;
             }
-            if (i + 1 >= nn || n.offset >= nn || n.offset <= i + 1) return false;
-            todo.push_back(n.offset);
-            todo.push_back(i + 1);
-        }
+        });
+        if (!finite.load()) return false;
     }
     const uint32_t np = (uint32_t)B.prims.size();
     if (np < 2) return false;
+    const double t_collected = since();
     B.out.resize((size_t)2 * np - 1);
-    B.n_threads = threads ? threads : std::max(1u, std::min(std::thread::hardware_concurrency(), 32u));
+    const double t_allocated = since();
     B.run();
+    if (phases) { phases[0] = t_collected; phases[1] = t_allocated - t_collected; phases[2] = since() - t_allocated; }
     if (B.cancelled()) return false;
     out.swap(B.out);
     return true;
