@@ -169,6 +169,8 @@ struct FoldAdapt
     bool ok = false, ok_sh = false;                    // ... exist and are cheaper for the probe rays
     double cost[2][2] = {{0.0, 0.0}, {0.0, 0.0}};      // [closest, shadow][current, adapted]: record visits per probe ray (an upper bound: box passes)
     double seconds = 0.0;
+    double rotate_s[4] = {0, 0, 0, 0};                     // ... and tree_rotate.h's phases
+    double stage_s[7] = {0, 0, 0, 0, 0, 0, 0};             // the worker's stages: unpacking the probe, closest-hit re-fold, shadow: plain re-fold, rotations, rotated re-fold, occluder order; upload
     std::atomic<bool> finished{false}, cancel{false};
     std::thread worker;
     // The probe (round 5: nothing on the render thread waits for it): a frame of its own, kept for the scene's life; its queues come back through
@@ -286,11 +288,15 @@ bool adapt_shadow_candidate(FoldAdapt* a)
     a->rotations = 0;
     a->bvh2_sh_new.clear();
     const int fold_device = a->worker_fold_device();
+    auto t_stage = std::chrono::steady_clock::now();
+    auto stage = [&](int k) { const auto t = std::chrono::steady_clock::now(); a->stage_s[k] = std::chrono::duration<double>(t - t_stage).count(); t_stage = t; };
     bool ok = refold_for_rays(tree, a->sh_o, a->sh_d, roots, a->wide_sh, a->entry_sh, a->cost[1], a->cancel, &a->roots_sh_new, fold_device, a->pairs);
+    stage(2);
     if (!(a->mode.load() & 8u) || a->sh_o.empty() || a->cancel.load()) return ok;
     std::vector<rt_bvh_node> rotated;
     double crossings[2] = {0.0, 0.0};
-    const uint32_t made = treerot::rotate(tree.data(), (uint32_t)tree.size(), (const float*)a->sh_o.data(), (const float*)a->sh_d.data(), a->sh_o.size(), 8, rotated, crossings, &a->cancel);
+    const uint32_t made = treerot::rotate(tree.data(), (uint32_t)tree.size(), (const float*)a->sh_o.data(), (const float*)a->sh_d.data(), a->sh_o.size(), 8, rotated, crossings, &a->cancel, 3, 0.03, a->rotate_s);
+    stage(3);
     if (made == 0 || rotated.size() != tree.size() || a->cancel.load()) return ok;
     std::vector<WideNode> wide;
     std::vector<uint32_t> roots_rot;
@@ -298,6 +304,7 @@ bool adapt_shadow_candidate(FoldAdapt* a)
     double cost[2] = {0.0, 0.0};
     const std::vector<uint32_t> top{0u};                                   // (the rotated tree has no current fold: only cost[1] is read)
     (void)refold_for_rays(rotated, a->sh_o, a->sh_d, top, wide, entry, cost, a->cancel, &roots_rot, fold_device, a->pairs);
+    stage(4);
     if (wide.empty() || roots_rot.empty() || a->cancel.load()) return ok;
     // the rotated tree's boxes differ, so its measured passes are compared as they are (both are box passes per probe ray at record roots);
     // without a known cost of the fold on the device nothing is adopted
@@ -317,10 +324,12 @@ bool adapt_shadow_side(FoldAdapt* a)
     if (ok && (a->mode.load() & 16u) && !a->tri9.empty() && !a->wide_sh.empty() && !a->cancel.load())
     {
         // the candidate's slots, likeliest occluder first (mode bit 4)
+        const auto t_occ = std::chrono::steady_clock::now();
         std::vector<uint32_t> prim;
         nearest_occluders(a->bvh2, a->tri9, a->sh_o, a->sh_d, prim, a->cancel);
         const std::vector<rt_bvh_node>& tree = a->rotations != 0 ? a->bvh2_sh_new : (a->bvh2_sh.empty() ? a->bvh2 : a->bvh2_sh);
         if (!a->cancel.load()) a->reordered = occluder_first(a->wide_sh, a->roots_sh_new, tree, prim);
+        a->stage_s[5] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_occ).count();
     }
     return ok;
 }
@@ -399,13 +408,19 @@ void fold_upload(FoldAdapt* a)
 void fold_adapt_worker(FoldAdapt* a)
 {
     const auto t0 = std::chrono::steady_clock::now();
+    auto since = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
+    for (double& t : a->stage_s) t = 0.0;
     probe_unpack(a);
+    a->stage_s[0] = since();
     if (!a->o.empty())
     {
         std::thread shadow([a]() { a->ok_sh = adapt_shadow_side(a); });
         a->ok = refold_for_rays(a->bvh2, a->o, a->d, a->roots, a->wide, a->entry, a->cost[0], a->cancel, &a->roots_new, a->worker_fold_device(), a->pairs);
+        a->stage_s[1] = since() - a->stage_s[0];
         shadow.join();
+        const double t_up = since();
         fold_upload(a);
+        a->stage_s[6] = since() - t_up;
     }
     a->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     a->finished.store(true);

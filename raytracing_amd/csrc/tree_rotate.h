@@ -16,6 +16,10 @@
 #include <math.h>
 #include <algorithm>
 #include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include <vector>
 #include "rt_types.h"
 
@@ -55,8 +59,12 @@ inline uint32_t rotate(const rt_bvh_node* nodes, uint32_t nn, const float* origi
     double min_gain = 0.03 /* a move must save more than this share of the crossings of the node it is made at: a search that takes every small gain
                               locks itself in (a probe twice as large changes nothing, so it is the greed, not the sample) -- 0 / 0.03 / 0.1: 5.01 /
                               4.60 / 4.64 steps per unseen shadow ray on a 300 K-triangle scene with both move kinds; 11.43 at 0.03 against 11.98 with
-                              the first kind alone on the 2.8 M one (tools/fold_weight_study.py --tree) */)
+                              the first kind alone on the 2.8 M one (tools/fold_weight_study.py --tree) */,
+    double* phases = nullptr /* seconds of { pointer form, the rays' lists, the passes, back to the linear layout } */,
+    unsigned threads = 0 /* 0 = the host's, at most 16; the rotated tree does not depend on it */, size_t grain = 2048 /* a child with a list this long is another thread's */)
 {
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto lap = [&, last = 0.0](int k) mutable { const double t = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count(); if (phases) phases[k] = t - last; last = t; };
     out.clear();
     cost[0] = cost[1] = 0.0;
     if (nn == 0 || n_rays == 0) return 0;
@@ -81,6 +89,7 @@ inline uint32_t rotate(const rt_bvh_node* nodes, uint32_t nn, const float* origi
             t.kid0[i] = i + 1; t.kid1[i] = n.offset;
         }
     }
+    lap(0);
     std::vector<Ray> rays(n_rays);
     for (size_t r = 0; r < n_rays; ++r)
     {
@@ -88,126 +97,198 @@ inline uint32_t rotate(const rt_bvh_node* nodes, uint32_t nn, const float* origi
         for (int a = 0; a < 3; ++a) { q.o[a] = origins_tmax[4 * r + a]; q.inv[a] = 1.0f / directions[4 * r + a]; }
         q.t_max = origins_tmax[4 * r + 3];
     }
-    // the lists: every ray walks the tree once
+    // the lists: every ray walks the tree once -- the rays in equal slices on the pool's threads, each noting (node, ray) as it goes; the notes become the
+    // lists slice after slice, so every list is in ascending ray order whatever the number of threads
+    const unsigned n_threads = threads ? threads : std::max(1u, std::min(std::thread::hardware_concurrency(), 16u));
+    auto is_cancelled = [&]() { return cancel && cancel->load(std::memory_order_relaxed); };
     {
-        std::vector<uint32_t> stack;
-        for (size_t r = 0; r < n_rays; ++r)
+        const unsigned K = (unsigned)std::min<size_t>(n_threads, n_rays / 1024u + 1u);
+        std::vector<std::vector<std::pair<uint32_t, uint32_t>>> notes(K);
+        auto walk = [&](unsigned k)
         {
-            stack.assign(1, 0u);
-            while (!stack.empty())
+            std::vector<uint32_t> stack;
+            auto& mine = notes[k];
+            for (size_t r = n_rays * k / K, r1 = n_rays * (k + 1) / K; r < r1; ++r)
             {
-                const uint32_t i = stack.back();
-                stack.pop_back();
-                if (!crosses(rays[r], &t.mn[3 * (size_t)i], &t.mx[3 * (size_t)i])) continue;
-                if (t.leaf(i)) continue;
-                t.rays[i].push_back((uint32_t)r);
-                stack.push_back(t.kid1[i]);
-                stack.push_back(t.kid0[i]);
+                stack.assign(1, 0u);
+                while (!stack.empty())
+                {
+                    const uint32_t i = stack.back();
+                    stack.pop_back();
+                    if (!crosses(rays[r], &t.mn[3 * (size_t)i], &t.mx[3 * (size_t)i])) continue;
+                    if (t.leaf(i)) continue;
+                    mine.emplace_back(i, (uint32_t)r);
+                    stack.push_back(t.kid1[i]);
+                    stack.push_back(t.kid0[i]);
+                }
+                if ((r & 1023u) == 0u && is_cancelled()) return;
             }
-            if ((r & 1023u) == 0u && cancel && cancel->load(std::memory_order_relaxed)) return 0;
-        }
+        };
+        std::vector<std::thread> pool;
+        for (unsigned k = 1; k < K; ++k) pool.emplace_back(walk, k);
+        walk(0u);
+        for (auto& th : pool) th.join();
+        if (is_cancelled()) return 0;
+        std::vector<uint32_t> count(nn, 0u);
+        for (const auto& part : notes) for (const auto& nr : part) ++count[nr.first];
+        for (uint32_t i = 0; i < nn; ++i) if (count[i]) t.rays[i].reserve(count[i]);
+        for (const auto& part : notes) for (const auto& nr : part) t.rays[nr.first].push_back(nr.second);
     }
     auto total = [&]() { double s = 0.0; for (uint32_t i = 0; i < nn; ++i) s += (double)t.rays[i].size(); return s / (double)n_rays; };
     cost[0] = total();
-    // rotations, top-down over the nodes rays reach (a node without rays has nothing to gain), repeated until a pass changes little
-    uint32_t rotations = 0;
-    std::vector<uint32_t> order, keep;
-    for (int pass = 0; pass < max_passes; ++pass)
+    lap(1);
+    // rotations, top-down over the nodes rays reach (a node without rays has nothing to gain), repeated until a pass changes little.
+    // What a visit of node n reads and writes lies in n's subtree (its children's and grandchildren's links, its children's boxes and lists), and it must come
+    // after the visits of n's ancestors in the same pass -- nothing else orders two visits, so disjoint subtrees are visited by different threads: a visited node
+    // hands each child whose list is at least `grain` rays long to a shared queue and walks the smaller ones itself, breadth first.  The result is the serial
+    // pass's whatever the threads do (round 6: the passes were 0.7 of an adaptation's 1.2 s on the headline scene, on one thread).
+    struct Scratch { std::vector<uint32_t> keep, keep2, best_list, best_list2, order; };
+    auto visit = [&](uint32_t n, Scratch& sc) -> uint32_t
     {
-        uint32_t made = 0;
-        order.assign(1, t.root);
-        for (size_t head = 0; head < order.size(); ++head)
+        std::vector<uint32_t>&keep = sc.keep, &keep2 = sc.keep2, &best_list = sc.best_list, &best_list2 = sc.best_list2;
+        // candidates: (a) exchange one child of n with one grandchild under the OTHER child -- one box changes; (b) exchange a grandchild
+        // under one child with a grandchild under the other -- both children's boxes change
+        long best_gain = (long)(min_gain * (double)t.rays[n].size()); int best_kind = -1, best_side = -1, best_g = -1, best_h = -1;
+        for (int side = 0; side < 2 && (moves & 1); ++side)
         {
-            const uint32_t n = order[head];
-            if (t.leaf(n) || t.rays[n].empty()) continue;
-            if ((head & 4095u) == 0u && cancel && cancel->load(std::memory_order_relaxed)) return 0;
-            // candidates: (a) exchange one child of n with one grandchild under the OTHER child -- one box changes; (b) exchange a grandchild
-            // under one child with a grandchild under the other -- both children's boxes change
-            long best_gain = (long)(min_gain * (double)t.rays[n].size()); int best_kind = -1, best_side = -1, best_g = -1, best_h = -1;
-            std::vector<uint32_t> best_list, best_list2, keep2;
-            for (int side = 0; side < 2 && (moves & 1); ++side)
+            const uint32_t c = side ? t.kid1[n] : t.kid0[n];             // the child that is opened
+            const uint32_t other = side ? t.kid0[n] : t.kid1[n];          // the child that moves down
+            if (t.leaf(c)) continue;
+            for (int g = 0; g < 2; ++g)
             {
-                const uint32_t c = side ? t.kid1[n] : t.kid0[n];             // the child that is opened
-                const uint32_t other = side ? t.kid0[n] : t.kid1[n];          // the child that moves down
-                if (t.leaf(c)) continue;
-                for (int g = 0; g < 2; ++g)
+                const uint32_t stay = g ? t.kid0[c] : t.kid1[c];          // (the grandchild that moves up is the other one)
+                float bmn[3], bmx[3];
+                for (int a = 0; a < 3; ++a)
                 {
-                    const uint32_t stay = g ? t.kid0[c] : t.kid1[c];          // (the grandchild that moves up is the other one)
-                    float bmn[3], bmx[3];
+                    bmn[a] = std::min(t.mn[3 * (size_t)other + a], t.mn[3 * (size_t)stay + a]);
+                    bmx[a] = std::max(t.mx[3 * (size_t)other + a], t.mx[3 * (size_t)stay + a]);
+                }
+                keep.clear();
+                for (uint32_t r : t.rays[n]) if (crosses(rays[r], bmn, bmx)) keep.push_back(r);
+                const long gain = (long)t.rays[c].size() - (long)keep.size();   // c's box becomes (other + stay)'s
+                if (gain > best_gain) { best_gain = gain; best_kind = 0; best_side = side; best_g = g; best_list = keep; }
+            }
+        }
+        const uint32_t L = t.kid0[n], R = t.kid1[n];
+        if ((moves & 2) && !t.leaf(L) && !t.leaf(R))
+            for (int g = 0; g < 2; ++g)
+                for (int h = 0; h < 2; ++h)
+                {
+                    // L = (lg, lo), R = (rh, ro)  ->  L = (rh, lo), R = (lg, ro); (g, h) and (1 - g, 1 - h) give the same pair of sets: h <= g suffices
+                    if (h > g) continue;
+                    const uint32_t lg = g ? t.kid1[L] : t.kid0[L], lo = g ? t.kid0[L] : t.kid1[L];
+                    const uint32_t rh = h ? t.kid1[R] : t.kid0[R], ro = h ? t.kid0[R] : t.kid1[R];
+                    float amn[3], amx[3], bmn[3], bmx[3];
                     for (int a = 0; a < 3; ++a)
                     {
-                        bmn[a] = std::min(t.mn[3 * (size_t)other + a], t.mn[3 * (size_t)stay + a]);
-                        bmx[a] = std::max(t.mx[3 * (size_t)other + a], t.mx[3 * (size_t)stay + a]);
+                        amn[a] = std::min(t.mn[3 * (size_t)rh + a], t.mn[3 * (size_t)lo + a]); amx[a] = std::max(t.mx[3 * (size_t)rh + a], t.mx[3 * (size_t)lo + a]);
+                        bmn[a] = std::min(t.mn[3 * (size_t)lg + a], t.mn[3 * (size_t)ro + a]); bmx[a] = std::max(t.mx[3 * (size_t)lg + a], t.mx[3 * (size_t)ro + a]);
                     }
-                    keep.clear();
-                    for (uint32_t r : t.rays[n]) if (crosses(rays[r], bmn, bmx)) keep.push_back(r);
-                    const long gain = (long)t.rays[c].size() - (long)keep.size();   // c's box becomes (other + stay)'s
-                    if (gain > best_gain) { best_gain = gain; best_kind = 0; best_side = side; best_g = g; best_list = keep; }
-                }
-            }
-            const uint32_t L = t.kid0[n], R = t.kid1[n];
-            if ((moves & 2) && !t.leaf(L) && !t.leaf(R))
-                for (int g = 0; g < 2; ++g)
-                    for (int h = 0; h < 2; ++h)
+                    keep.clear(); keep2.clear();
+                    for (uint32_t r : t.rays[n])
                     {
-                        // L = (lg, lo), R = (rh, ro)  ->  L = (rh, lo), R = (lg, ro); (g, h) and (1 - g, 1 - h) give the same pair of sets: h <= g suffices
-                        if (h > g) continue;
-                        const uint32_t lg = g ? t.kid1[L] : t.kid0[L], lo = g ? t.kid0[L] : t.kid1[L];
-                        const uint32_t rh = h ? t.kid1[R] : t.kid0[R], ro = h ? t.kid0[R] : t.kid1[R];
-                        float amn[3], amx[3], bmn[3], bmx[3];
-                        for (int a = 0; a < 3; ++a)
-                        {
-                            amn[a] = std::min(t.mn[3 * (size_t)rh + a], t.mn[3 * (size_t)lo + a]); amx[a] = std::max(t.mx[3 * (size_t)rh + a], t.mx[3 * (size_t)lo + a]);
-                            bmn[a] = std::min(t.mn[3 * (size_t)lg + a], t.mn[3 * (size_t)ro + a]); bmx[a] = std::max(t.mx[3 * (size_t)lg + a], t.mx[3 * (size_t)ro + a]);
-                        }
-                        keep.clear(); keep2.clear();
-                        for (uint32_t r : t.rays[n])
-                        {
-                            if (crosses(rays[r], amn, amx)) keep.push_back(r);
-                            if (crosses(rays[r], bmn, bmx)) keep2.push_back(r);
-                        }
-                        const long gain = (long)t.rays[L].size() + (long)t.rays[R].size() - (long)keep.size() - (long)keep2.size();
-                        if (gain > best_gain) { best_gain = gain; best_kind = 1; best_g = g; best_h = h; best_list = keep; best_list2 = keep2; }
+                        if (crosses(rays[r], amn, amx)) keep.push_back(r);
+                        if (crosses(rays[r], bmn, bmx)) keep2.push_back(r);
                     }
-            if (best_kind == 0)
-            {
-                const uint32_t c = best_side ? t.kid1[n] : t.kid0[n];
-                const uint32_t other = best_side ? t.kid0[n] : t.kid1[n];
-                const uint32_t up = best_g ? t.kid1[c] : t.kid0[c];
-                const uint32_t stay = best_g ? t.kid0[c] : t.kid1[c];
-                // n = (c, other), c = (up, stay)  ->  n = (c, up), c = (other, stay)
-                (best_side ? t.kid0[n] : t.kid1[n]) = up;
-                t.kid0[c] = other; t.kid1[c] = stay;
-                for (int a = 0; a < 3; ++a)
-                {
-                    t.mn[3 * (size_t)c + a] = std::min(t.mn[3 * (size_t)other + a], t.mn[3 * (size_t)stay + a]);
-                    t.mx[3 * (size_t)c + a] = std::max(t.mx[3 * (size_t)other + a], t.mx[3 * (size_t)stay + a]);
+                    const long gain = (long)t.rays[L].size() + (long)t.rays[R].size() - (long)keep.size() - (long)keep2.size();
+                    if (gain > best_gain) { best_gain = gain; best_kind = 1; best_g = g; best_h = h; best_list = keep; best_list2 = keep2; }
                 }
-                t.rays[c].swap(best_list);
-                ++made;
-            }
-            else if (best_kind == 1)
+        if (best_kind == 0)
+        {
+            const uint32_t c = best_side ? t.kid1[n] : t.kid0[n];
+            const uint32_t other = best_side ? t.kid0[n] : t.kid1[n];
+            const uint32_t up = best_g ? t.kid1[c] : t.kid0[c];
+            const uint32_t stay = best_g ? t.kid0[c] : t.kid1[c];
+            // n = (c, other), c = (up, stay)  ->  n = (c, up), c = (other, stay)
+            (best_side ? t.kid0[n] : t.kid1[n]) = up;
+            t.kid0[c] = other; t.kid1[c] = stay;
+            for (int a = 0; a < 3; ++a)
             {
-                const uint32_t lg = best_g ? t.kid1[L] : t.kid0[L], lo = best_g ? t.kid0[L] : t.kid1[L];
-                const uint32_t rh = best_h ? t.kid1[R] : t.kid0[R], ro = best_h ? t.kid0[R] : t.kid1[R];
-                t.kid0[L] = rh; t.kid1[L] = lo;
-                t.kid0[R] = lg; t.kid1[R] = ro;
-                for (int a = 0; a < 3; ++a)
-                {
-                    t.mn[3 * (size_t)L + a] = std::min(t.mn[3 * (size_t)rh + a], t.mn[3 * (size_t)lo + a]); t.mx[3 * (size_t)L + a] = std::max(t.mx[3 * (size_t)rh + a], t.mx[3 * (size_t)lo + a]);
-                    t.mn[3 * (size_t)R + a] = std::min(t.mn[3 * (size_t)lg + a], t.mn[3 * (size_t)ro + a]); t.mx[3 * (size_t)R + a] = std::max(t.mx[3 * (size_t)lg + a], t.mx[3 * (size_t)ro + a]);
-                }
-                t.rays[L].swap(best_list);
-                t.rays[R].swap(best_list2);
-                ++made;
+                t.mn[3 * (size_t)c + a] = std::min(t.mn[3 * (size_t)other + a], t.mn[3 * (size_t)stay + a]);
+                t.mx[3 * (size_t)c + a] = std::max(t.mx[3 * (size_t)other + a], t.mx[3 * (size_t)stay + a]);
             }
-            order.push_back(t.kid0[n]);
-            order.push_back(t.kid1[n]);
+            t.rays[c].swap(best_list);
+            return 1u;
         }
-        rotations += made;
-        if (made == 0) break;
+        if (best_kind == 1)
+        {
+            const uint32_t lg = best_g ? t.kid1[L] : t.kid0[L], lo = best_g ? t.kid0[L] : t.kid1[L];
+            const uint32_t rh = best_h ? t.kid1[R] : t.kid0[R], ro = best_h ? t.kid0[R] : t.kid1[R];
+            t.kid0[L] = rh; t.kid1[L] = lo;
+            t.kid0[R] = lg; t.kid1[R] = ro;
+            for (int a = 0; a < 3; ++a)
+            {
+                t.mn[3 * (size_t)L + a] = std::min(t.mn[3 * (size_t)rh + a], t.mn[3 * (size_t)lo + a]); t.mx[3 * (size_t)L + a] = std::max(t.mx[3 * (size_t)rh + a], t.mx[3 * (size_t)lo + a]);
+                t.mn[3 * (size_t)R + a] = std::min(t.mn[3 * (size_t)lg + a], t.mn[3 * (size_t)ro + a]); t.mx[3 * (size_t)R + a] = std::max(t.mx[3 * (size_t)lg + a], t.mx[3 * (size_t)ro + a]);
+            }
+            t.rays[L].swap(best_list);
+            t.rays[R].swap(best_list2);
+            return 1u;
+        }
+        return 0u;
+    };
+    uint32_t rotations = 0;
+    for (int pass = 0; pass < max_passes; ++pass)
+    {
+        std::atomic<uint32_t> made{0};
+        std::mutex mu;
+        std::condition_variable cv;
+        std::vector<uint32_t> queue{t.root};                                   // subtree roots whose ancestors have been visited in this pass
+        unsigned active = 0;
+        auto worker = [&]()
+        {
+            Scratch sc;
+            std::vector<uint32_t> hand_over;
+            for (;;)
+            {
+                uint32_t top;
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return !queue.empty() || active == 0u || is_cancelled(); });
+                    if (is_cancelled() || queue.empty()) { cv.notify_all(); return; }
+                    size_t at = 0;
+                    for (size_t i = 1; i < queue.size(); ++i) if (t.rays[queue[i]].size() > t.rays[queue[at]].size()) at = i;      // the longest list first
+                    top = queue[at];
+                    queue[at] = queue.back();
+                    queue.pop_back();
+                    ++active;
+                }
+                uint32_t made_here = 0;
+                hand_over.clear();
+                sc.order.assign(1, top);
+                for (size_t head = 0; head < sc.order.size(); ++head)
+                {
+                    const uint32_t n = sc.order[head];
+                    if (t.leaf(n) || t.rays[n].empty()) continue;
+                    if ((head & 1023u) == 0u && is_cancelled()) break;
+                    made_here += visit(n, sc);
+                    for (uint32_t c : {t.kid0[n], t.kid1[n]})
+                    {
+                        if (t.leaf(c) || t.rays[c].empty()) continue;
+                        if (n_threads > 1u && t.rays[c].size() >= grain) hand_over.push_back(c); else sc.order.push_back(c);
+                    }
+                    if (!hand_over.empty())
+                    {
+                        { std::lock_guard<std::mutex> lk(mu); queue.insert(queue.end(), hand_over.begin(), hand_over.end()); }
+                        cv.notify_all();
+                        hand_over.clear();
+                    }
+                }
+                made.fetch_add(made_here);
+                { std::lock_guard<std::mutex> lk(mu); --active; }
+                cv.notify_all();
+            }
+        };
+        std::vector<std::thread> pool;
+        for (unsigned k = 1; k < n_threads; ++k) pool.emplace_back(worker);
+        worker();
+        for (auto& th : pool) th.join();
+        if (is_cancelled()) return 0;
+        rotations += made.load();
+        if (made.load() == 0) break;
     }
     cost[1] = total();
+    lap(2);
     // back to the linear layout: depth first, first child at i + 1
     out.resize(nn);
     struct Item { uint32_t node, pos; };
@@ -251,6 +332,7 @@ inline uint32_t rotate(const rt_bvh_node* nodes, uint32_t nn, const float* origi
         st.push_back({b, it.pos + 1u + size[a]});
         st.push_back({a, it.pos + 1u});
     }
+    lap(3);
     return rotations;
 }
 } // namespace treerot

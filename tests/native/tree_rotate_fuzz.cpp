@@ -1,6 +1,7 @@
 // ASAN / UBSAN harness for tree_rotate.h: random binary trees over random leaf boxes, random rays; invariants after rotation.
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <random>
 #include <vector>
 #include <algorithm>
@@ -46,7 +47,19 @@ int main()
         std::vector<rt_bvh_node> out;
         double cost[2];
         const int moves = 1 + (int)(rng() % 3);
-        const uint32_t made = treerot::rotate(nodes.data(), (uint32_t)nodes.size(), o.data(), d.data(), n_rays, 1 + (int)(rng() % 8), out, cost, nullptr, moves, (iter % 2) ? 0.0 : 0.03);
+        const int passes = 1 + (int)(rng() % 8);
+        const double min_gain = (iter % 2) ? 0.0 : 0.03;
+        const uint32_t made = treerot::rotate(nodes.data(), (uint32_t)nodes.size(), o.data(), d.data(), n_rays, passes, out, cost, nullptr, moves, min_gain, nullptr, 1);
+        {
+            // the passes on several threads (subtrees with a list of `grain` rays or more go to the shared queue): the same rotations, the same tree
+            std::vector<rt_bvh_node> out_mt;
+            double cost_mt[2];
+            const unsigned threads = 2 + (unsigned)(rng() % 7);
+            const size_t grain = 1 + (size_t)(rng() % 40);
+            const uint32_t made_mt = treerot::rotate(nodes.data(), (uint32_t)nodes.size(), o.data(), d.data(), n_rays, passes, out_mt, cost_mt, nullptr, moves, min_gain, nullptr, threads, grain);
+            if (made_mt != made || out_mt.size() != out.size() || (!out.empty() && memcmp(out_mt.data(), out.data(), out.size() * sizeof(rt_bvh_node)) != 0) || cost_mt[1] != cost[1])
+            { printf("FAIL: %u threads (grain %zu) rotate differently: %u / %u rotations, iter %d\n", threads, grain, made_mt, made, iter); return 1; }
+        }
         if (n_rays == 0) { if (!out.empty() || made) { printf("FAIL: no rays\n"); return 1; } continue; }
         if (out.size() != nodes.size()) { printf("FAIL size %zu %zu iter %d\n", out.size(), nodes.size(), iter); return 1; }
         if (cost[1] > cost[0] + 1e-9) { printf("FAIL cost went up\n"); return 1; }
