@@ -18,7 +18,9 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <memory>
 #include <mutex>
+#include <queue>
 #include <thread>
 #include <vector>
 #include "rt_types.h"
@@ -61,7 +63,7 @@ inline uint32_t rotate(const rt_bvh_node* nodes, uint32_t nn, const float* origi
                               4.60 / 4.64 steps per unseen shadow ray on a 300 K-triangle scene with both move kinds; 11.43 at 0.03 against 11.98 with
                               the first kind alone on the 2.8 M one (tools/fold_weight_study.py --tree) */,
     double* phases = nullptr /* seconds of { pointer form, the rays' lists, the passes, back to the linear layout } */,
-    unsigned threads = 0 /* 0 = the host's, at most 16; the rotated tree does not depend on it */, size_t grain = 2048 /* a child with a list this long is another thread's */)
+    unsigned threads = 0 /* 0 = the host's, at most 16; the rotated tree does not depend on it */, size_t grain = 256 /* a child with a list this long is another thread's */)
 {
     const auto t_begin = std::chrono::steady_clock::now();
     auto lap = [&, last = 0.0](int k) mutable { const double t = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count(); if (phases) phases[k] = t - last; last = t; };
@@ -74,20 +76,38 @@ inline uint32_t rotate(const rt_bvh_node* nodes, uint32_t nn, const float* origi
     t.rays.resize(nn);
     // the caller may be an exported test hook (rt_debug_rotate_tree): every node but the root must be the child of exactly one interior
     // node -- a shared child (a DAG) would be walked once per path to it and only fail the size check at the very end
-    std::vector<uint8_t> referenced(nn, 0);
-    for (uint32_t i = 0; i < nn; ++i)
+    const unsigned n_threads = threads ? threads : std::max(1u, std::min(std::thread::hardware_concurrency(), 16u));
+    auto is_cancelled = [&]() { return cancel && cancel->load(std::memory_order_relaxed); };
+    // fn(k) for k = 0 .. K - 1, k = 0 on the calling thread
+    auto on_threads = [&](unsigned K, auto fn)
     {
-        const rt_bvh_node& n = nodes[i];
-        t.mn[3 * (size_t)i] = n.bounds_min.x; t.mn[3 * (size_t)i + 1] = n.bounds_min.y; t.mn[3 * (size_t)i + 2] = n.bounds_min.z;
-        t.mx[3 * (size_t)i] = n.bounds_max.x; t.mx[3 * (size_t)i + 1] = n.bounds_max.y; t.mx[3 * (size_t)i + 2] = n.bounds_max.z;
-        if ((n.num_primitives_axis >> 16) != 0) t.leaf_ref[i] = i;
-        else
+        std::vector<std::thread> pool;
+        for (unsigned k = 1; k < K; ++k) pool.emplace_back(fn, k);
+        fn(0u);
+        for (auto& th : pool) th.join();
+    };
+    {
+        std::unique_ptr<std::atomic<uint8_t>[]> referenced(new std::atomic<uint8_t>[nn]);
+        std::atomic<bool> bad{false};
+        const unsigned K = nn >= 65536u ? n_threads : 1u;
+        on_threads(K, [&](unsigned k) { for (uint32_t i = (uint32_t)((uint64_t)nn * k / K), e = (uint32_t)((uint64_t)nn * (k + 1) / K); i < e; ++i) referenced[i].store(0, std::memory_order_relaxed); });
+        on_threads(K, [&](unsigned k)
         {
-            if (i + 1 >= nn || n.offset >= nn || n.offset <= i + 1) return 0;
-            if (referenced[i + 1] || referenced[n.offset]) return 0;
-            referenced[i + 1] = referenced[n.offset] = 1;
-            t.kid0[i] = i + 1; t.kid1[i] = n.offset;
-        }
+            for (uint32_t i = (uint32_t)((uint64_t)nn * k / K), e = (uint32_t)((uint64_t)nn * (k + 1) / K); i < e; ++i)
+            {
+                const rt_bvh_node& n = nodes[i];
+                t.mn[3 * (size_t)i] = n.bounds_min.x; t.mn[3 * (size_t)i + 1] = n.bounds_min.y; t.mn[3 * (size_t)i + 2] = n.bounds_min.z;
+                t.mx[3 * (size_t)i] = n.bounds_max.x; t.mx[3 * (size_t)i + 1] = n.bounds_max.y; t.mx[3 * (size_t)i + 2] = n.bounds_max.z;
+                if ((n.num_primitives_axis >> 16) != 0) t.leaf_ref[i] = i;
+                else
+                {
+                    if (i + 1 >= nn || n.offset >= nn || n.offset <= i + 1) { bad.store(true); return; }
+                    if (referenced[i + 1].fetch_add(1, std::memory_order_relaxed) != 0 || referenced[n.offset].fetch_add(1, std::memory_order_relaxed) != 0) { bad.store(true); return; }
+                    t.kid0[i] = i + 1; t.kid1[i] = n.offset;
+                }
+            }
+        });
+        if (bad.load()) return 0;
     }
     lap(0);
     std::vector<Ray> rays(n_rays);
@@ -99,8 +119,6 @@ inline uint32_t rotate(const rt_bvh_node* nodes, uint32_t nn, const float* origi
     }
     // the lists: every ray walks the tree once -- the rays in equal slices on the pool's threads, each noting (node, ray) as it goes; the notes become the
     // lists slice after slice, so every list is in ascending ray order whatever the number of threads
-    const unsigned n_threads = threads ? threads : std::max(1u, std::min(std::thread::hardware_concurrency(), 16u));
-    auto is_cancelled = [&]() { return cancel && cancel->load(std::memory_order_relaxed); };
     {
         const unsigned K = (unsigned)std::min<size_t>(n_threads, n_rays / 1024u + 1u);
         std::vector<std::vector<std::pair<uint32_t, uint32_t>>> notes(K);
@@ -233,7 +251,9 @@ inline uint32_t rotate(const rt_bvh_node* nodes, uint32_t nn, const float* origi
         std::atomic<uint32_t> made{0};
         std::mutex mu;
         std::condition_variable cv;
-        std::vector<uint32_t> queue{t.root};                                   // subtree roots whose ancestors have been visited in this pass
+        typedef std::pair<size_t, uint32_t> Job;                               // (rays in the list when it was handed over, subtree root): the longest list first
+        std::priority_queue<Job> queue;                                        // subtree roots whose ancestors have been visited in this pass
+        queue.push(Job(t.rays[t.root].size(), t.root));
         unsigned active = 0;
         auto worker = [&]()
         {
@@ -246,11 +266,8 @@ inline uint32_t rotate(const rt_bvh_node* nodes, uint32_t nn, const float* origi
                     std::unique_lock<std::mutex> lk(mu);
                     cv.wait(lk, [&] { return !queue.empty() || active == 0u || is_cancelled(); });
                     if (is_cancelled() || queue.empty()) { cv.notify_all(); return; }
-                    size_t at = 0;
-                    for (size_t i = 1; i < queue.size(); ++i) if (t.rays[queue[i]].size() > t.rays[queue[at]].size()) at = i;      // the longest list first
-                    top = queue[at];
-                    queue[at] = queue.back();
-                    queue.pop_back();
+                    top = queue.top().second;
+                    queue.pop();
                     ++active;
                 }
                 uint32_t made_here = 0;
@@ -269,7 +286,7 @@ inline uint32_t rotate(const rt_bvh_node* nodes, uint32_t nn, const float* origi
                     }
                     if (!hand_over.empty())
                     {
-                        { std::lock_guard<std::mutex> lk(mu); queue.insert(queue.end(), hand_over.begin(), hand_over.end()); }
+                        { std::lock_guard<std::mutex> lk(mu); for (uint32_t c : hand_over) queue.push(Job(t.rays[c].size(), c)); }
                         cv.notify_all();
                         hand_over.clear();
                     }
@@ -289,33 +306,55 @@ inline uint32_t rotate(const rt_bvh_node* nodes, uint32_t nn, const float* origi
     }
     cost[1] = total();
     lap(2);
-    // back to the linear layout: depth first, first child at i + 1
+    // back to the linear layout: depth first, first child at i + 1.  The top of the tree (to depth 10) on this thread, the subtrees below it on the pool: sizes
+    // bottom-up first, then every node's position follows from its parent's and its sibling's size
     out.resize(nn);
-    struct Item { uint32_t node, pos; };
     std::vector<uint32_t> size(nn, 1u);
+    struct Item { uint32_t node, pos; };
+    std::vector<uint32_t> tops;                                            // interior nodes above the cut, parents before children
+    std::vector<Item> cuts;                                                // the subtrees' roots (pos: filled in below)
     {
-        // subtree sizes, children before parents: an explicit post-order
-        std::vector<std::pair<uint32_t, int>> st{{t.root, 0}};
-        while (!st.empty())
+        std::vector<std::pair<uint32_t, uint32_t>> level{{t.root, 0u}};
+        for (size_t head = 0; head < level.size(); ++head)
         {
-            auto& top = st.back();
-            const uint32_t i = top.first;
-            if (t.leaf(i)) { st.pop_back(); continue; }
-            if (top.second == 0) { top.second = 1; st.push_back({t.kid0[i], 0}); }
-            else if (top.second == 1) { top.second = 2; st.push_back({t.kid1[i], 0}); }
-            else { size[i] = 1u + size[t.kid0[i]] + size[t.kid1[i]]; st.pop_back(); }
+            const uint32_t i = level[head].first, depth = level[head].second;
+            if (level.size() > (size_t)nn) { out.clear(); return 0; }      // (a cycle among the top nodes)
+            if (t.leaf(i) || depth >= 10u) { cuts.push_back({i, 0u}); continue; }
+            tops.push_back(i);
+            level.push_back({t.kid0[i], depth + 1u});
+            level.push_back({t.kid1[i], depth + 1u});
         }
     }
-    if (size[t.root] != nn) { out.clear(); return 0; }
-    std::vector<Item> st{{t.root, 0u}};
-    while (!st.empty())
+    std::atomic<bool> broken{false};
+    std::atomic<size_t> next_cut{0};
+    const unsigned K_layout = nn >= 65536u ? n_threads : 1u;
+    on_threads(K_layout, [&](unsigned)
     {
-        const Item it = st.back();
-        st.pop_back();
-        const uint32_t i = it.node;
+        // subtree sizes, children before parents: an explicit post-order
+        std::vector<std::pair<uint32_t, int>> st;
+        for (size_t c; (c = next_cut.fetch_add(1)) < cuts.size();)
+        {
+            st.assign(1, {cuts[c].node, 0});
+            size_t steps = 0;
+            while (!st.empty())
+            {
+                if (++steps > 3u * (size_t)nn + 3u) { broken.store(true); return; }
+                auto& top = st.back();
+                const uint32_t i = top.first;
+                if (t.leaf(i)) { st.pop_back(); continue; }
+                if (top.second == 0) { top.second = 1; st.push_back({t.kid0[i], 0}); }
+                else if (top.second == 1) { top.second = 2; st.push_back({t.kid1[i], 0}); }
+                else { size[i] = 1u + size[t.kid0[i]] + size[t.kid1[i]]; st.pop_back(); }
+            }
+        }
+    });
+    if (broken.load()) { out.clear(); return 0; }
+    for (size_t k = tops.size(); k-- > 0;) size[tops[k]] = 1u + size[t.kid0[tops[k]]] + size[t.kid1[tops[k]]];
+    if (size[t.root] != nn) { out.clear(); return 0; }
+    auto emit = [&](uint32_t i, uint32_t pos)                              // one interior node's record; returns its second child's position
+    {
         rt_bvh_node n;
         memset(&n, 0, sizeof(n));
-        if (t.leaf(i)) { n = nodes[t.leaf_ref[i]]; n.num_primitives_axis &= 0xFFFF0000u; out[it.pos] = n; continue; }
         n.bounds_min.x = t.mn[3 * (size_t)i]; n.bounds_min.y = t.mn[3 * (size_t)i + 1]; n.bounds_min.z = t.mn[3 * (size_t)i + 2];
         n.bounds_max.x = t.mx[3 * (size_t)i]; n.bounds_max.y = t.mx[3 * (size_t)i + 1]; n.bounds_max.z = t.mx[3 * (size_t)i + 2];
         const uint32_t a = t.kid0[i], b = t.kid1[i];
@@ -326,12 +365,46 @@ inline uint32_t rotate(const rt_bvh_node* nodes, uint32_t nn, const float* origi
             const float d = fabsf(ca - cb);
             if (d > far) { far = d; axis = k; }
         }
-        n.offset = it.pos + 1u + size[a];
+        n.offset = pos + 1u + size[a];
         n.num_primitives_axis = (uint32_t)axis;
-        out[it.pos] = n;
-        st.push_back({b, it.pos + 1u + size[a]});
-        st.push_back({a, it.pos + 1u});
+        out[pos] = n;
+        return n.offset;
+    };
+    {
+        // positions of the top nodes and of the cuts, in the order they were found (a parent's is known before its children's)
+        std::vector<uint32_t> pos_of_level{0u};
+        size_t k_top = 0, k_cut = 0;
+        std::vector<std::pair<uint32_t, uint32_t>> level{{t.root, 0u}};
+        for (size_t head = 0; head < level.size(); ++head)
+        {
+            const uint32_t i = level[head].first, depth = level[head].second, pos = pos_of_level[head];
+            if (t.leaf(i) || depth >= 10u) { cuts[k_cut++].pos = pos; continue; }
+            ++k_top;
+            const uint32_t second = emit(i, pos);
+            level.push_back({t.kid0[i], depth + 1u}); pos_of_level.push_back(pos + 1u);
+            level.push_back({t.kid1[i], depth + 1u}); pos_of_level.push_back(second);
+        }
+        (void)k_top;
     }
+    next_cut.store(0);
+    on_threads(K_layout, [&](unsigned)
+    {
+        std::vector<Item> st;
+        for (size_t c; (c = next_cut.fetch_add(1)) < cuts.size();)
+        {
+            st.assign(1, cuts[c]);
+            while (!st.empty())
+            {
+                const Item it = st.back();
+                st.pop_back();
+                const uint32_t i = it.node;
+                if (t.leaf(i)) { rt_bvh_node n = nodes[t.leaf_ref[i]]; n.num_primitives_axis &= 0xFFFF0000u; out[it.pos] = n; continue; }
+                const uint32_t second = emit(i, it.pos);
+                st.push_back({t.kid1[i], second});
+                st.push_back({t.kid0[i], it.pos + 1u});
+            }
+        }
+    });
     lap(3);
     return rotations;
 }
