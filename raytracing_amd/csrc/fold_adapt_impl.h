@@ -351,17 +351,31 @@ bool adapt_shadow_candidate(FoldAdapt* a)
 bool adapt_shadow_side(FoldAdapt* a)
 {
     a->reordered = 0;
-    const bool ok = adapt_shadow_candidate(a);
-    if (ok && (a->mode.load() & 16u) && !a->tri9.empty() && !a->wide_sh.empty() && !a->cancel.load())
+    // mode bit 4 needs every probe shadow ray's nearest occluder: a walk of the reference's tree that depends on neither the rotations nor the folds, so -- when the
+    // folds are the device's and the host's threads are this worker's (bit 1) -- it runs beside them
+    const bool want_order = (a->mode.load() & 16u) && !a->tri9.empty() && !a->sh_o.empty();
+    std::vector<uint32_t> prim;
+    double t_occ = 0.0;
+    auto find_occluders = [&]()
     {
-        // the candidate's slots, likeliest occluder first (mode bit 4)
-        const auto t_occ = std::chrono::steady_clock::now();
-        std::vector<uint32_t> prim;
+        const auto t0 = std::chrono::steady_clock::now();
         nearest_occluders(a->bvh2, a->tri9, a->sh_o, a->sh_d, prim, a->cancel);
+        t_occ = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    };
+    std::thread beside;
+    if (want_order && a->worker_fold_device() >= 0) beside = std::thread(find_occluders);
+    const bool ok = adapt_shadow_candidate(a);
+    if (beside.joinable()) beside.join();
+    if (ok && want_order && !a->wide_sh.empty() && !a->cancel.load())
+    {
+        // the candidate's slots, likeliest occluder first
+        const auto t0 = std::chrono::steady_clock::now();
+        if (prim.size() != a->sh_o.size()) find_occluders();
         const std::vector<rt_bvh_node>& tree = a->rotations != 0 ? a->bvh2_sh_new : (a->bvh2_sh.empty() ? a->bvh2 : a->bvh2_sh);
         if (!a->cancel.load()) a->reordered = occluder_first(a->wide_sh, a->roots_sh_new, tree, prim);
-        a->stage_s[5] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_occ).count();
+        a->stage_s[5] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     }
+    (void)t_occ;
     return ok;
 }
 

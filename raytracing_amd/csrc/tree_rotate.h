@@ -31,9 +31,9 @@ struct Ray { float o[3], inv[3], t_max; };
 
 struct Tree
 {
-    // pointer form: node i has children kid[i][0..1] (RT_NONE for a leaf), box mn/mx, and for a leaf the reference node it copies
+    // pointer form: node i has children kid0[i], kid1[i] (NONE for a leaf) and box mn / mx
     static constexpr uint32_t NONE = 0xFFFFFFFFu;
-    std::vector<uint32_t> kid0, kid1, leaf_ref;
+    std::vector<uint32_t> kid0, kid1;                           // (node ids are the input's: a leaf i is nodes[i])
     std::vector<float> mn, mx;                                  // 3 floats per node
     std::vector<std::vector<uint32_t>> rays;                    // the probe rays crossing each interior node's box (empty for leaves)
     uint32_t root = 0;
@@ -71,7 +71,7 @@ inline uint32_t rotate(const rt_bvh_node* nodes, uint32_t nn, const float* origi
     cost[0] = cost[1] = 0.0;
     if (nn == 0 || n_rays == 0) return 0;
     Tree t;
-    t.kid0.assign(nn, Tree::NONE); t.kid1.assign(nn, Tree::NONE); t.leaf_ref.assign(nn, Tree::NONE);
+    t.kid0.assign(nn, Tree::NONE); t.kid1.assign(nn, Tree::NONE);
     t.mn.resize((size_t)nn * 3); t.mx.resize((size_t)nn * 3);
     t.rays.resize(nn);
     // the caller may be an exported test hook (rt_debug_rotate_tree): every node but the root must be the child of exactly one interior
@@ -98,8 +98,7 @@ inline uint32_t rotate(const rt_bvh_node* nodes, uint32_t nn, const float* origi
                 const rt_bvh_node& n = nodes[i];
                 t.mn[3 * (size_t)i] = n.bounds_min.x; t.mn[3 * (size_t)i + 1] = n.bounds_min.y; t.mn[3 * (size_t)i + 2] = n.bounds_min.z;
                 t.mx[3 * (size_t)i] = n.bounds_max.x; t.mx[3 * (size_t)i + 1] = n.bounds_max.y; t.mx[3 * (size_t)i + 2] = n.bounds_max.z;
-                if ((n.num_primitives_axis >> 16) != 0) t.leaf_ref[i] = i;
-                else
+                if ((n.num_primitives_axis >> 16) == 0)
                 {
                     if (i + 1 >= nn || n.offset >= nn || n.offset <= i + 1) { bad.store(true); return; }
                     if (referenced[i + 1].fetch_add(1, std::memory_order_relaxed) != 0 || referenced[n.offset].fetch_add(1, std::memory_order_relaxed) != 0) { bad.store(true); return; }
@@ -398,7 +397,7 @@ inline uint32_t rotate(const rt_bvh_node* nodes, uint32_t nn, const float* origi
                 const Item it = st.back();
                 st.pop_back();
                 const uint32_t i = it.node;
-                if (t.leaf(i)) { rt_bvh_node n = nodes[t.leaf_ref[i]]; n.num_primitives_axis &= 0xFFFF0000u; out[it.pos] = n; continue; }
+                if (t.leaf(i)) { rt_bvh_node n = nodes[i]; n.num_primitives_axis &= 0xFFFF0000u; out[it.pos] = n; continue; }
                 const uint32_t second = emit(i, it.pos);
                 st.push_back({t.kid1[i], second});
                 st.push_back({t.kid0[i], it.pos + 1u});
