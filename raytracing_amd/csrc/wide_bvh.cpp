@@ -548,59 +548,85 @@ uint32_t occluder_first(std::vector<WideNode>& wide, const std::vector<uint32_t>
     const uint32_t nn = (uint32_t)tree.size();
     if (wide.empty() || roots.size() != wide.size() || nn == 0) return 0;
     std::vector<uint32_t> parent(nn, RT_EMPTY_REF), hit(nn, 0u);
+    // (the passes over the nodes and over the records in slices on host threads: every write goes to an element only one slice owns)
+    const unsigned T = nn >= 262144u ? adapt_threads(nn, 131072) : 1u;
+    auto in_slices = [&](size_t n, auto fn)
+    {
+        std::vector<std::thread> pool;
+        for (unsigned t = 1; t < T; ++t) pool.emplace_back(fn, t, n * t / T, n * (t + 1) / T);
+        fn(0u, (size_t)0, n / T);
+        for (auto& th : pool) th.join();
+    };
+    std::vector<uint32_t> max_prim_of(T, 0u);
+    in_slices(nn, [&](unsigned t, size_t b, size_t e)
+    {
+        uint32_t mp = 0;
+        for (size_t i = b; i < e; ++i)
+        {
+            const uint32_t count = tree[i].num_primitives_axis >> 16;
+            if (count != 0) { mp = std::max(mp, tree[i].offset + count); continue; }
+            if (i + 1u < nn) parent[i + 1u] = (uint32_t)i;
+            if (tree[i].offset < nn) parent[tree[i].offset] = (uint32_t)i;
+        }
+        max_prim_of[t] = mp;
+    });
     uint32_t max_prim = 0;
-    for (uint32_t i = 0; i < nn; ++i)
-    {
-        const uint32_t count = tree[i].num_primitives_axis >> 16;
-        if (count != 0) { max_prim = std::max(max_prim, tree[i].offset + count); continue; }
-        if (i + 1u < nn) parent[i + 1u] = i;
-        if (tree[i].offset < nn) parent[tree[i].offset] = i;
-    }
+    for (uint32_t mp : max_prim_of) max_prim = std::max(max_prim, mp);
     std::vector<uint32_t> leaf_of(max_prim, RT_EMPTY_REF);                 // primitive -> the leaf node of `tree` that holds it
-    for (uint32_t i = 0; i < nn; ++i)
+    in_slices(nn, [&](unsigned, size_t b, size_t e)
     {
-        const uint32_t count = tree[i].num_primitives_axis >> 16;
-        for (uint32_t k = 0; k < count; ++k) leaf_of[tree[i].offset + k] = i;
-    }
+        for (size_t i = b; i < e; ++i)
+        {
+            const uint32_t count = tree[i].num_primitives_axis >> 16;
+            for (uint32_t k = 0; k < count; ++k) leaf_of[tree[i].offset + k] = (uint32_t)i;
+        }
+    });
     for (uint32_t p : prim)
     {
         if (p >= max_prim) continue;
         uint32_t guard = 0;
         for (uint32_t n = leaf_of[p]; n != RT_EMPTY_REF && guard < 256u; n = parent[n], ++guard) ++hit[n];
     }
-    uint32_t changed = 0;
-    for (size_t w = 0; w < wide.size(); ++w)
+    std::vector<uint32_t> changed_of(T, 0u);
+    in_slices(wide.size(), [&](unsigned t, size_t wb, size_t we)
     {
-        WideNode& r = wide[w];
-        uint32_t score[4]; int idx[4] = {0, 1, 2, 3};
-        bool any = false;
-        for (int k = 0; k < 4; ++k)
+        uint32_t changed = 0;
+        for (size_t w = wb; w < we; ++w)
         {
-            const uint32_t ref = r.ref[k];
-            uint32_t node = RT_EMPTY_REF;
-            if (ref == RT_EMPTY_REF) { score[k] = 0; continue; }
-            if (ref & RT_LEAF_BIT) { const uint32_t first = ref & ~RT_LEAF_BIT; node = first < max_prim ? leaf_of[first] : RT_EMPTY_REF; }
-            else if (ref < roots.size()) node = roots[ref];
-            score[k] = node < nn ? hit[node] + 1u : 1u;                    // occupied slots before empty ones
-            any = true;
-        }
-        if (!any) continue;
-        std::stable_sort(idx, idx + 4, [&](int x, int y) { return score[x] > score[y]; });
-        if (idx[0] == 0 && idx[1] == 1 && idx[2] == 2 && idx[3] == 3) continue;
-        WideNode q = r;
-        for (int a = 0; a < 3; ++a) { q.lo[a] = 0; q.hi[a] = 0; }
-        for (int k = 0; k < 4; ++k)
-        {
-            q.ref[k] = r.ref[idx[k]];
-            for (int a = 0; a < 3; ++a)
+            WideNode& r = wide[w];
+            uint32_t score[4]; int idx[4] = {0, 1, 2, 3};
+            bool any = false;
+            for (int k = 0; k < 4; ++k)
             {
-                q.lo[a] |= ((r.lo[a] >> (8 * idx[k])) & 0xFFu) << (8 * k);
-                q.hi[a] |= ((r.hi[a] >> (8 * idx[k])) & 0xFFu) << (8 * k);
+                const uint32_t ref = r.ref[k];
+                uint32_t node = RT_EMPTY_REF;
+                if (ref == RT_EMPTY_REF) { score[k] = 0; continue; }
+                if (ref & RT_LEAF_BIT) { const uint32_t first = ref & ~RT_LEAF_BIT; node = first < max_prim ? leaf_of[first] : RT_EMPTY_REF; }
+                else if (ref < roots.size()) node = roots[ref];
+                score[k] = node < nn ? hit[node] + 1u : 1u;                    // occupied slots before empty ones
+                any = true;
             }
+            if (!any) continue;
+            std::stable_sort(idx, idx + 4, [&](int x, int y) { return score[x] > score[y]; });
+            if (idx[0] == 0 && idx[1] == 1 && idx[2] == 2 && idx[3] == 3) continue;
+            WideNode q = r;
+            for (int a = 0; a < 3; ++a) { q.lo[a] = 0; q.hi[a] = 0; }
+            for (int k = 0; k < 4; ++k)
+            {
+                q.ref[k] = r.ref[idx[k]];
+                for (int a = 0; a < 3; ++a)
+                {
+                    q.lo[a] |= ((r.lo[a] >> (8 * idx[k])) & 0xFFu) << (8 * k);
+                    q.hi[a] |= ((r.hi[a] >> (8 * idx[k])) & 0xFFu) << (8 * k);
+                }
+            }
+            r = q;
+            ++changed;
         }
-        r = q;
-        ++changed;
-    }
+        changed_of[t] = changed;
+    });
+    uint32_t changed = 0;
+    for (uint32_t c : changed_of) changed += c;
     return changed;
 }
 
