@@ -119,7 +119,7 @@ static int fold_adopt(rt_ctx* ctx)
         if (a->ok || a->ok_sh) ++a->adaptations;
         snprintf(line, sizeof(line), "adaptive fold (probe %u): %zu closest-hit and %zu shadow probe rays; box passes per probe ray at record roots: closest-hit %.2f -> %.2f (%s), "
             "shadow %.2f -> %.2f (%s); %.2f s on a worker thread (probe unpacked %.2f; closest-hit re-fold %.2f beside the shadow side's: plain re-fold %.2f, rotations %.2f = pointer form %.2f + ray lists %.2f + passes %.2f + linear layout %.2f, "
-            "rotated re-fold %.2f, occluder order %.2f; upload %.2f)\n", a->adaptations, a->o.size(), a->sh_o.size(), a->cost[0][0], a->cost[0][1], a->ok ? "adopted" : "kept",
+            "re-fold after them %.2f, occluder order %.2f; upload %.2f)\n", a->adaptations, a->o.size(), a->sh_o.size(), a->cost[0][0], a->cost[0][1], a->ok ? "adopted" : "kept",
             a->cost[1][0], a->cost[1][1], a->ok_sh ? "adopted" : "kept", a->seconds, a->stage_s[0], a->stage_s[1], a->stage_s[2], a->stage_s[3], a->rotate_s[0], a->rotate_s[1], a->rotate_s[2], a->rotate_s[3], a->stage_s[4], a->stage_s[5], a->stage_s[6]);
         s.tree_report += line;
         if (a->ok_sh && a->reordered != 0)
