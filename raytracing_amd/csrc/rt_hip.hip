@@ -537,6 +537,26 @@ int rt_scene_upload(rt_ctx* ctx, const rt_scene_desc* sd)
     }
     if (may_own && ctx->shadow_tree && !(try_device_tree && ctx->tree_builder == 1u)) own_sh.start(sd, true, ctx->shadow_tree);
     if (may_own && ctx->closest_tree) own_cl.start(sd, false, ctx->closest_tree);
+    // what an adaptation keeps of the caller's arrays (FoldAdapt, below: the binary tree, the triangles' corners -- 157 + 100 MB for 2.8 M triangles) is copied beside
+    // everything else instead of after it
+    struct AdaptCopies
+    {
+        std::vector<rt_bvh_node> bvh2; std::vector<float> tri9; std::thread worker;
+        ~AdaptCopies() { if (worker.joinable()) worker.join(); }
+    } adapt_copies;
+    if ((ctx->adaptive_fold & 1u) && ctx->build_wide == 1u && !ctx->closest_tree && (nn >= 8192u || (ctx->adaptive_fold & 4u)))
+        adapt_copies.worker = std::thread([&adapt_copies, sd, nn, nt, corners = (ctx->adaptive_fold & 16u) != 0u]()
+        {
+            adapt_copies.bvh2.assign(sd->nodes, sd->nodes + nn);
+            if (!corners) return;
+            adapt_copies.tri9.resize((size_t)nt * 9);
+            for (uint32_t i = 0; i < nt; ++i)
+            {
+                const rt_triangle& t = sd->triangles[i];
+                const rt_float3 v[3] = {t.v1.position, t.v2.position, t.v3.position};
+                for (int k = 0; k < 3; ++k) { adapt_copies.tri9[(size_t)i * 9 + 3 * k] = v[k].x; adapt_copies.tri9[(size_t)i * 9 + 3 * k + 1] = v[k].y; adapt_copies.tri9[(size_t)i * 9 + 3 * k + 2] = v[k].z; }
+            }
+        });
 
     // --- BVH re-layout: LinearBVHNode[] (bvh.cpp:223-245) -> child-pair records
     // Record order = cache-friendly "treelet" layout: a breadth-first cluster of up to
@@ -783,17 +803,22 @@ int rt_scene_upload(rt_ctx* ctx, const rt_scene_desc* sd)
             const double ex = (double)root.bounds_max.x - root.bounds_min.x, ey = (double)root.bounds_max.y - root.bounds_min.y, ez = (double)root.bounds_max.z - root.bounds_min.z;
             a->scene_diagonal = std::sqrt(ex * ex + ey * ey + ez * ez);
         }
-        a->bvh2.assign(sd->nodes, sd->nodes + nn);
+        if (adapt_copies.worker.joinable()) adapt_copies.worker.join();
+        if (adapt_copies.bvh2.size() == nn) a->bvh2.swap(adapt_copies.bvh2); else a->bvh2.assign(sd->nodes, sd->nodes + nn);
         a->roots = std::move(wide_roots);
         if (have_sh) { a->bvh2_sh = std::move(sh->bvh2); a->roots_sh = std::move(sh->roots); }
         if (a->mode.load() & 16u)
         {
-            a->tri9.resize((size_t)nt * 9);
-            for (uint32_t i = 0; i < nt; ++i)
+            if (adapt_copies.tri9.size() == (size_t)nt * 9) a->tri9.swap(adapt_copies.tri9);
+            else
             {
-                const rt_triangle& t = sd->triangles[i];
-                const rt_float3 v[3] = {t.v1.position, t.v2.position, t.v3.position};
-                for (int k = 0; k < 3; ++k) { a->tri9[(size_t)i * 9 + 3 * k] = v[k].x; a->tri9[(size_t)i * 9 + 3 * k + 1] = v[k].y; a->tri9[(size_t)i * 9 + 3 * k + 2] = v[k].z; }
+                a->tri9.resize((size_t)nt * 9);
+                for (uint32_t i = 0; i < nt; ++i)
+                {
+                    const rt_triangle& t = sd->triangles[i];
+                    const rt_float3 v[3] = {t.v1.position, t.v2.position, t.v3.position};
+                    for (int k = 0; k < 3; ++k) { a->tri9[(size_t)i * 9 + 3 * k] = v[k].x; a->tri9[(size_t)i * 9 + 3 * k + 1] = v[k].y; a->tri9[(size_t)i * 9 + 3 * k + 2] = v[k].z; }
+                }
             }
         }
         s.adapt = a;
