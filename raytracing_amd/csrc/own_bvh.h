@@ -348,7 +348,7 @@ inline bool build(const rt_bvh_node* nodes, uint32_t nn, const Metric& metric, s
     B.ref = nodes;
     B.metric = metric;
     B.cancel = cancel;
-    B.n_threads = threads ? threads : std::max(1u, std::min(std::thread::hardware_concurrency(), 32u));
+    B.n_threads = threads ? threads : (unsigned)std::min<size_t>(std::max(1u, std::min(std::thread::hardware_concurrency(), 32u)), (size_t)nn / 8192u + 1u);   // (a small tree: few threads)
     {
         // the walk only lists the leaves (and is what says "not a tree"); their boxes are read by the pool's threads afterwards
         std::vector<uint32_t> leaves;

@@ -76,7 +76,7 @@ inline uint32_t rotate(const rt_bvh_node* nodes, uint32_t nn, const float* origi
     t.rays.resize(nn);
     // the caller may be an exported test hook (rt_debug_rotate_tree): every node but the root must be the child of exactly one interior
     // node -- a shared child (a DAG) would be walked once per path to it and only fail the size check at the very end
-    const unsigned n_threads = threads ? threads : std::max(1u, std::min(std::thread::hardware_concurrency(), 16u));
+    const unsigned n_threads = threads ? threads : (unsigned)std::min<size_t>(std::max(1u, std::min(std::thread::hardware_concurrency(), 16u)), n_rays / 512u + 1u);   // (a small probe: few threads)
     auto is_cancelled = [&]() { return cancel && cancel->load(std::memory_order_relaxed); };
     // fn(k) for k = 0 .. K - 1, k = 0 on the calling thread
     auto on_threads = [&](unsigned K, auto fn)
