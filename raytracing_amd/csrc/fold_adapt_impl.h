@@ -188,6 +188,8 @@ struct FoldAdapt
     // (1.33 -> 1.09 s to the adapted fold on the headline scene, 8.5 -> 7.1 s on the 10 M-triangle one: profiles/r06/call03.log); asynchronously -- the library's
     // default -- the frames keep it busy and the host's threads are what is free: the same folds on the device took an orbiting camera's frames from
     // + 2 .. 4 % to + 23 % (per_frame.moving_camera, profiles/r06/call04.log), so there the worker folds on host threads as it did before.
+    // Measured again in round 6's call 24, with the worker's other stages short: the folds on the device beside an orbiting camera's frames take 0.36 - 0.60 s instead of the
+    // host's 0.22 - 0.25 (their kernels queue behind the frames') and the frames 3.6 - 3.8 ms instead of 2.68 (+ 40 %): the policy stands.
     int worker_fold_device() const { return device_fold && (mode.load() & 2u) ? device : -1; }
     bool pairs = false;                                                  // RT_CTX_OPT_WIDE_LAYOUT
     void *new_cl = nullptr, *new_sh = nullptr;
