@@ -6,6 +6,7 @@
 #include <array>
 #include <cmath>
 #include <map>
+#include <memory>
 #include <thread>
 #include "rt_hip.h"
 
@@ -52,27 +53,47 @@ namespace rtw
 
 // false: the tree does not qualify (non-finite or non-nested bounds, child order): k_trace2 is used
 bool build_wide_bvh(const rt_bvh_node* nodes, uint32_t nn, int collapse, std::vector<WideNode>& out, uint32_t& entry_ref,
-    std::vector<uint32_t>* roots, const ownbvh::Metric* metric, const double* weights, const std::atomic<bool>* cancel)
+    std::vector<uint32_t>* roots, const ownbvh::Metric* metric, const double* weights, const std::atomic<bool>* cancel, unsigned threads)
 {
     auto cancelled = [&]() { return cancel && cancel->load(std::memory_order_relaxed); };
     auto is_leaf = [&](uint32_t i) { return (nodes[i].num_primitives_axis >> 16) != 0; };
     out.clear();
     if (is_leaf(0)) { entry_ref = RT_LEAF_BIT | nodes[0].offset; return true; }
     auto finite3 = [](const rt_float3& v) { return std::isfinite(v.x) && std::isfinite(v.y) && std::isfinite(v.z); };
-    // pass 0: bounds finite and exactly nested (child inside parent), children after their parent
-    for (uint32_t i = 0; i < nn; ++i)
+    // (the host's threads: an adaptation's fold -- measured weights -- is made beside the render loop on at most 16 of them)
+    const unsigned T_host = threads ? threads : nn >= 262144u ? std::max(1u, std::min(std::thread::hardware_concurrency(), weights ? 16u : 32u)) : 1u;
+    // fn(index) for index = 0 .. count - 1, taken by T_host threads from a shared counter
+    auto on_pool = [&](size_t count, auto fn)
     {
-        const rt_bvh_node& n = nodes[i];
-        if (!finite3(n.bounds_min) || !finite3(n.bounds_max)) return false;
-        if (is_leaf(i)) continue;
-        if (i + 1 >= nn || n.offset >= nn || n.offset <= i + 1 || (n.num_primitives_axis & 0xFFFFu) > 2u) return false;
-        for (uint32_t c : {i + 1, n.offset})
+        std::atomic<size_t> next{0};
+        auto run = [&]() { for (size_t k; (k = next.fetch_add(1)) < count;) fn(k); };
+        std::vector<std::thread> pool;
+        for (unsigned t = 1; t < T_host && t < count; ++t) pool.emplace_back(run);
+        run();
+        for (auto& th : pool) th.join();
+    };
+    // pass 0: bounds finite and exactly nested (child inside parent), children after their parent
+    {
+        std::atomic<bool> bad{false};
+        const size_t n_slices = T_host > 1u ? 4u * T_host : 1u;
+        on_pool(n_slices, [&](size_t k)
         {
-            const rt_bvh_node& k = nodes[c];
-            if (k.bounds_min.x < n.bounds_min.x || k.bounds_min.y < n.bounds_min.y || k.bounds_min.z < n.bounds_min.z ||
-                k.bounds_max.x > n.bounds_max.x || k.bounds_max.y > n.bounds_max.y || k.bounds_max.z > n.bounds_max.z)
-                return false;
-        }
+            for (uint32_t i = (uint32_t)((uint64_t)nn * k / n_slices), e = (uint32_t)((uint64_t)nn * (k + 1) / n_slices); i < e; ++i)
+            {
+                const rt_bvh_node& n = nodes[i];
+                if (!finite3(n.bounds_min) || !finite3(n.bounds_max)) { bad.store(true); return; }
+                if (is_leaf(i)) continue;
+                if (i + 1 >= nn || n.offset >= nn || n.offset <= i + 1 || (n.num_primitives_axis & 0xFFFFu) > 2u) { bad.store(true); return; }
+                for (uint32_t c : {i + 1, n.offset})
+                {
+                    const rt_bvh_node& kk = nodes[c];
+                    if (kk.bounds_min.x < n.bounds_min.x || kk.bounds_min.y < n.bounds_min.y || kk.bounds_min.z < n.bounds_min.z ||
+                        kk.bounds_max.x > n.bounds_max.x || kk.bounds_max.y > n.bounds_max.y || kk.bounds_max.z > n.bounds_max.z)
+                    { bad.store(true); return; }
+                }
+            }
+        });
+        if (bad.load()) return false;
     }
     // the collapse: split[n][k] = slots given to n's first child when n is folded with k slots to spend (k = 2..4, the second
     // child gets the rest); a child with i >= 2 slots is folded too iff open[c] has bit i set, otherwise it is one slot
@@ -81,12 +102,14 @@ bool build_wide_bvh(const rt_bvh_node* nodes, uint32_t nn, int collapse, std::ve
     {
         // T[n] = cost of the best collapse of n's subtree with a record rooted at n; F[n][k] = the same without the root's own
         // visit, n's subtree covered by k slots.  Children have larger indices than their parent (pass 0): one backward sweep.
-        std::vector<double> T(nn, 0.0), F((size_t)nn * 5u, 0.0);
+        // (not value-initialised: every element that is read -- an interior node's -- is written first, by the thread that sweeps its range, which is then also
+        // the thread that touches its pages)
+        const std::unique_ptr<double[]> T_store(new double[nn]), F_store(new double[(size_t)nn * 5u]);
+        double* const T = T_store.get();
+        double* const F = F_store.get();
         auto G = [&](uint32_t c, uint32_t i) { return is_leaf(c) ? 0.0 : (i >= 2u ? std::min(T[c], F[(size_t)c * 5u + i]) : T[c]); };
-        for (uint32_t n = nn; n-- > 0;)
+        auto dp_node = [&](uint32_t n)
         {
-            if ((n & 0xFFFFu) == 0u && cancelled()) return false;
-            if (is_leaf(n)) continue;
             const uint32_t l = n + 1, r = nodes[n].offset;
             for (uint32_t k = 2; k <= 4; ++k)
             {
@@ -106,7 +129,62 @@ bool build_wide_bvh(const rt_bvh_node* nodes, uint32_t nn, int collapse, std::ve
             T[n] = (weights ? weights[n] : metric ? metric->of(bmn, bmx) : dx * dy + dy * dz + dz * dx) + F[(size_t)n * 5u + 4u];
             for (uint32_t i = 2; i <= 4; ++i)
                 if (F[(size_t)n * 5u + i] < T[n]) open[n] |= (uint8_t)(1u << i);
+        };
+        // The sweep is backward over the array (children have larger indices).  On several threads: the array is cut into the index ranges [n, e) below
+        // nodes near the root -- in the reference's depth-first layout the range of a node is its subtree, [n + 1, offset) and [offset, e) its children's --
+        // every range is swept backward by one thread, then the nodes above the cut by this one.  A node whose second child lies outside its range (an array
+        // that is a tree but not in that layout) makes the whole sweep start again on one thread: the ranges always partition the array, so nothing is lost.
+        bool swept = false;
+        if (T_host > 1u)
+        {
+            struct Range { uint32_t n, e; };
+            std::vector<Range> ranges{{0u, nn}};
+            std::vector<uint32_t> above;                                    // the nodes above the cut, parents before children
+            bool layout_ok = true;
+            while (ranges.size() < 16u * (size_t)T_host)
+            {
+                // open the largest range
+                size_t at = 0;
+                for (size_t i = 1; i < ranges.size(); ++i) if (ranges[i].e - ranges[i].n > ranges[at].e - ranges[at].n) at = i;
+                const Range r = ranges[at];
+                if (r.e - r.n < 65536u || is_leaf(r.n)) break;
+                const uint32_t second = nodes[r.n].offset;
+                if (second <= r.n + 1u || second >= r.e) { layout_ok = false; break; }
+                above.push_back(r.n);
+                ranges[at] = Range{r.n + 1u, second};
+                ranges.push_back(Range{second, r.e});
+            }
+            if (layout_ok)
+            {
+                std::atomic<bool> outside{false};
+                on_pool(ranges.size(), [&](size_t k)
+                {
+                    const Range r = ranges[k];
+                    for (uint32_t n = r.e; n-- > r.n;)
+                    {
+                        if ((n & 0xFFFFu) == 0u && (cancelled() || outside.load(std::memory_order_relaxed))) return;
+                        if (is_leaf(n)) continue;
+                        if (nodes[n].offset >= r.e) { outside.store(true); return; }
+                        dp_node(n);
+                    }
+                });
+                if (cancelled()) return false;
+                if (!outside.load())
+                {
+                    // (an opened range's node is above both of its parts: the reverse of the order of opening has children first)
+                    for (size_t k = above.size(); k-- > 0;) dp_node(above[k]);
+                    swept = true;
+                }
+                else std::fill(open.begin(), open.end(), (uint8_t)0);
+            }
         }
+        if (!swept)
+            for (uint32_t n = nn; n-- > 0;)
+            {
+                if ((n & 0xFFFFu) == 0u && cancelled()) return false;
+                if (is_leaf(n)) continue;
+                dp_node(n);
+            }
     }
     else
     {
@@ -150,6 +228,17 @@ bool build_wide_bvh(const rt_bvh_node* nodes, uint32_t nn, int collapse, std::ve
                 for (uint32_t j = 0; j < len[first ^ 1]; ++j) visit[o][at++] = part[first ^ 1][o][j];
             }
             count = len[0] + len[1];
+        }
+        // the slots alone (pass 1 needs no visit orders)
+        void slots(uint32_t n, uint32_t k, uint32_t (&slot)[4], uint32_t& count) const
+        {
+            const uint32_t c[2] = {n + 1, nodes[n].offset};
+            const uint32_t give[2] = {split[(size_t)n * 5u + k], k - split[(size_t)n * 5u + k]};
+            for (int i = 0; i < 2; ++i)
+            {
+                if (!leaf(c[i]) && give[i] >= 2u && ((open[c[i]] >> give[i]) & 1u)) slots(c[i], give[i], slot, count);
+                else if (count < 4u) slot[count++] = c[i];
+            }
         }
     } local{nodes, split, open};
     auto fold_of = [&](uint32_t n, Fold& f)
@@ -208,25 +297,64 @@ bool build_wide_bvh(const rt_bvh_node* nodes, uint32_t nn, int collapse, std::ve
         } while (std::next_permutation(place, place + 4));
         return nullptr;
     };
-    // pass 1: wide nodes in depth-first order (slot 0's subtree first), like the reference's flattening
-    std::vector<uint32_t> wide_of(nn, RT_EMPTY_REF), todo, order, depth_of;
-    todo.push_back(0);
-    depth_of.push_back(1);
-    while (!todo.empty())
+    // pass 1: wide nodes in depth-first order (slot 0's subtree first), like the reference's flattening.  On several threads: this one walks the records
+    // down to depth 7 and notes, in the order it meets them, the records there as roots of subtrees; the pool walks those (each the same depth-first walk,
+    // into a list of its own); the lists, spliced in where their roots were met, are the one-thread order.
+    std::vector<uint32_t> wide_of(nn, RT_EMPTY_REF), order;
     {
-        uint32_t n = todo.back(), depth = depth_of.back();
-        todo.pop_back();
-        depth_of.pop_back();
-        if ((order.size() & 0xFFFFu) == 0u && cancelled()) return false;
-        if (depth > 33u) return false;                                     // <= 3 pending slots per level must fit RT_W4_STACK_MAX
-        // a node reached twice (several parents share a child) is not a tree: the walk below would append once per PATH
-        if (wide_of[n] != RT_EMPTY_REF || order.size() >= nn) return false;
-        wide_of[n] = (uint32_t)order.size();
-        order.push_back(n);
-        Fold f;
-        fold_of(n, f);
-        for (int k = 3; k >= 0; --k)
-            if (f.slot[k] != RT_EMPTY_REF && !is_leaf(f.slot[k])) { todo.push_back(f.slot[k]); depth_of.push_back(depth + 1u); }
+        const uint32_t MARK = 0xFFFFFFFEu;                                  // reached, not numbered yet
+        // a node reached twice (several parents share a child) is not a tree: the walk would append once per PATH
+        auto reach = [&](uint32_t n) { return __atomic_exchange_n(&wide_of[n], MARK, __ATOMIC_RELAXED) == RT_EMPTY_REF; };
+        struct Sub { uint32_t root, depth; std::vector<uint32_t> list; };
+        struct Met { uint32_t what; bool sub; };
+        std::vector<Sub> subs;
+        std::vector<Met> met;
+        std::atomic<bool> bad{false};
+        // the walk from `root` (at `depth`): records to `list`; at cut_depth (0 = never) a record becomes a Sub instead of being walked
+        auto walk = [&](uint32_t root, uint32_t depth0, uint32_t cut_depth, std::vector<uint32_t>* list) -> bool
+        {
+            std::vector<uint32_t> todo{root}, depth_of{depth0};
+            size_t mine = 0;
+            while (!todo.empty())
+            {
+                const uint32_t n = todo.back(), depth = depth_of.back();
+                todo.pop_back();
+                depth_of.pop_back();
+                if ((mine & 0xFFFFu) == 0u && (cancelled() || bad.load(std::memory_order_relaxed))) return false;
+                if (depth > 33u) return false;                                 // <= 3 pending slots per level must fit RT_W4_STACK_MAX
+                if (cut_depth != 0u && depth == cut_depth) { met.push_back(Met{(uint32_t)subs.size(), true}); subs.push_back(Sub{n, depth, {}}); continue; }
+                if (!reach(n) || ++mine > nn) return false;
+                if (list) list->push_back(n); else met.push_back(Met{n, false});
+                uint32_t slot[4] = {RT_EMPTY_REF, RT_EMPTY_REF, RT_EMPTY_REF, RT_EMPTY_REF}, count = 0;
+                local.slots(n, 4u, slot, count);
+                for (int k = 3; k >= 0; --k)
+                    if (slot[k] != RT_EMPTY_REF && !is_leaf(slot[k])) { todo.push_back(slot[k]); depth_of.push_back(depth + 1u); }
+            }
+            return true;
+        };
+        if (T_host > 1u)
+        {
+            if (!walk(0u, 1u, 7u, nullptr)) return false;
+            on_pool(subs.size(), [&](size_t k) { if (!walk(subs[k].root, subs[k].depth, 0u, &subs[k].list)) bad.store(true); });
+            if (bad.load() || cancelled()) return false;
+            size_t total = 0;
+            for (const Met& m : met) total += m.sub ? subs[m.what].list.size() : 1u;
+            if (total > nn) return false;
+            order.reserve(total);
+            std::vector<size_t> first_of(subs.size(), 0);
+            for (const Met& m : met)
+            {
+                if (!m.sub) { wide_of[m.what] = (uint32_t)order.size(); order.push_back(m.what); continue; }
+                first_of[m.what] = order.size();
+                order.insert(order.end(), subs[m.what].list.begin(), subs[m.what].list.end());
+            }
+            on_pool(subs.size(), [&](size_t k) { for (size_t j = 0; j < subs[k].list.size(); ++j) wide_of[subs[k].list[j]] = (uint32_t)(first_of[k] + j); });
+        }
+        else
+        {
+            if (!walk(0u, 1u, 0u, &order)) return false;
+            for (size_t w = 0; w < order.size(); ++w) wide_of[order[w]] = (uint32_t)w;
+        }
     }
     if (order.size() >= (1u << 26)) return false;                          // 32-bit byte offsets in the kernel
     // pass 2: records (independent of each other: host threads, each with its own cache of arrangements)
@@ -299,7 +427,7 @@ bool build_wide_bvh(const rt_bvh_node* nodes, uint32_t nn, int collapse, std::ve
     {
         const size_t n_records = order.size();
         // (a fold with measured weights is an adaptation's, made beside the render loop: 16 threads, adapt_threads below)
-        const unsigned n_threads = (unsigned)std::min<size_t>(std::max(1u, std::min(std::thread::hardware_concurrency(), weights ? 16u : 32u)), n_records / 4096 + 1);
+        const unsigned n_threads = (unsigned)std::min<size_t>(threads ? threads : std::max(1u, std::min(std::thread::hardware_concurrency(), weights ? 16u : 32u)), n_records / 4096 + 1);
         std::atomic<bool> ok{true};
         auto run = [&](size_t w0, size_t w1)
         {

@@ -20,7 +20,8 @@ bool build_wide_bvh(const rt_bvh_node* nodes, uint32_t nn, int collapse, std::ve
     std::vector<uint32_t>* roots = nullptr /* the BVH2 node each record folds (tests) */,
     const ownbvh::Metric* metric = nullptr /* what "area" means for the SAH collapse (own_bvh.h); nullptr = surface area */,
     const double* weights = nullptr /* per BVH2 node: replaces the area altogether (a MEASURED visit frequency: FoldAdapt) */,
-    const std::atomic<bool>* cancel = nullptr /* set by another thread: give up (false) at the next check -- a scene uploaded again does not wait */);
+    const std::atomic<bool>* cancel = nullptr /* set by another thread: give up (false) at the next check -- a scene uploaded again does not wait */,
+    unsigned threads = 0 /* 0 = the host's (at most 32; 16 with weights); the records do not depend on it */);
 
 // RT_CTX_OPT_WIDE_LAYOUT = 1: the records permuted into (parent, likeliest child) pairs, one pair per 128-byte line; weight[record] = the visit weight of
 // the box the record tests (by OLD record index); roots (optional) is permuted along

@@ -24,3 +24,23 @@ def test_the_tree_does_not_depend_on_the_thread_count(tmp_path, sanitizer, leave
     if run.returncode != 0 and "FATAL: ThreadSanitizer: unexpected memory mapping" in run.stderr:
         pytest.skip("ThreadSanitizer cannot map its shadow in this container")
     assert run.returncode == 0 and "ok: 14 trees identical" in run.stdout, (run.stdout[-500:], run.stderr[-3000:])
+
+
+@pytest.mark.skipif(shutil.which("g++") is None or not os.path.exists("/opt/rocm/include/hip/hip_vector_types.h"), reason="no g++ or no HIP headers")
+@pytest.mark.parametrize("sanitizer", ["thread", "address,undefined"])
+def test_the_host_fold_does_not_depend_on_the_thread_count(tmp_path, sanitizer):
+    """build_wide_bvh (wide_bvh.cpp; round 6: validation in slices, the dynamic programme over index ranges, record numbering by subtrees): with measured weights,
+    the surface area, a metric and the two-level collapse, 2 / 5 / 16 threads give the one-thread records, order and roots; an array that is a tree but not in
+    depth-first layout makes the range sweep fall back (tests/native/wide_bvh_threads.cpp)."""
+    exe = str(tmp_path / "wide_bvh_threads")
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-pthread", "-D__HIP_PLATFORM_AMD__", "-fsanitize=" + sanitizer, "-fno-sanitize-recover=all", "-I", "/opt/rocm/include",
+           "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "raytracing_amd", "csrc"), os.path.join(ROOT, "tests", "native", "wide_bvh_threads.cpp"),
+           os.path.join(ROOT, "raytracing_amd", "csrc", "wide_bvh.cpp"), "-o", exe]
+    build = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    if build.returncode != 0 and "sanitize" in build.stderr:
+        pytest.skip("this g++ has no %s sanitizer runtime: %s" % (sanitizer, build.stderr[-200:]))
+    assert build.returncode == 0, build.stderr[-2000:]
+    run = subprocess.run([exe, "140000"], capture_output=True, text=True, timeout=900, env=dict(os.environ, TSAN_OPTIONS="halt_on_error=1"))
+    if run.returncode != 0 and "ThreadSanitizer: unexpected memory mapping" in run.stderr:
+        pytest.skip("ThreadSanitizer cannot map its shadow in this container")
+    assert run.returncode == 0 and "ok: 13 folds identical" in run.stdout, (run.stdout[-500:], run.stderr[-3000:])
