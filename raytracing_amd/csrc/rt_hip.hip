@@ -1870,6 +1870,18 @@ int rt_generate_rays(rt_frame* f)                       // GenerateRays, :516-52
     // the reference's own pattern (one Integrate() per frame through the hooks) adapts its folds too: probe, worker and adoption ride on
     // the frames' first stage (rt_integrate calls the same hook)
     if (fold_adapt_hook(f) != RT_OK) return RT_ERROR;
+    // The stages run on the FULL log layout.  A compact log's pool can run dry (k_shade raises DCounters::log_ovf_flag); rt_integrate then repeats the batch in the
+    // full layout, but here the caller drives the stages and there is nothing to repeat -- the sample's later entries would simply be missing from the sum (fuzz seed
+    // 5652 of a 10 000-seed campaign, round 6: RT_OPT_COMPACT_LOG + a test-sized pool + the stage API, 20 pixels short).  One reallocation, the first time a frame
+    // whose buffers are compact is driven through the stages.
+    if (f->log_ovf_blocks != 0u)
+    {
+        if (f->p->cur_slots != 0 || f->deferred.active) return fail(ctx, "rt_generate_rays: the previous sample was not advanced (rt_advance_sample)");
+        if (flush_log(f) != RT_OK || join_pipes(f) != RT_OK) return RT_ERROR;
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        f->log_full_forced = true;
+        if (alloc_path_buffers(f, f->slots ? f->slots : 1u) != RT_OK) return RT_ERROR;
+    }
     const uint32_t n_local = f->n_local ? f->n_local : 1u;
     uint32_t np = 1, cp = 0;
     chunk_plan(f, 1, np, cp);
