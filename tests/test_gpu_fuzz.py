@@ -107,7 +107,7 @@ def ctx():
     c.close()
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("RT_FUZZ_SEEDS", "24"))))   # RT_FUZZ_SEEDS=2000 for a campaign
+@pytest.mark.parametrize("seed", range(int(os.environ.get("RT_FUZZ_FIRST", "0")), int(os.environ.get("RT_FUZZ_SEEDS", "24"))))   # RT_FUZZ_SEEDS=2000 for a campaign (RT_FUZZ_FIRST: seeds below it are skipped)
 def test_random_scene_matches_oracle_bit_for_bit(ctx, env_map, seed):
     rng = np.random.default_rng(1000 + seed)
     sc = random_scene(rng, env_map)
