@@ -266,7 +266,9 @@ enum rt_option
                                        lit room) is discarded and repeated in the full layout, which the frame then keeps
                                        (rt_stats.log_fallbacks).  0: always the full layout.  2 (default): compact exactly when the
                                        caller bounds the path state (RT_OPT_PATH_STATE_LIMIT_MB != 0: larger chunks, +2.9 % at
-                                       32 GiB), full otherwise.  Results are bit-identical for every value. */
+                                       32 GiB), full otherwise.  The stage calls (rt_generate_rays ... rt_advance_sample) always run
+                                       on the full layout -- they have no batch to repeat -- and re-allocate a compact frame once.
+                                       Results are bit-identical for every value. */
     , RT_OPT_DEBUG_LOG_POOL_DIV = 20 /* test hook: the overflow pool holds paths / value blocks (default 8) */
     , RT_OPT_TRACE_TAIL_LANES = 21  /* k_trace_w4's loop D, in the instance that launches known to be small take (a batch of fewer
                                        than RT_OPT_SMALL_LAUNCH_PATHS paths: the reference's one-sample-per-frame pattern): when
