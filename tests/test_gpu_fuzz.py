@@ -153,10 +153,6 @@ def test_random_scene_matches_oracle_bit_for_bit(ctx, env_map, seed):
         fr.set_option(capi.OPT_DEBUG_LOG_POOL_DIV, 8 if seed % 2 else 64)
         if seed % 9 == 0:
             fr.set_option(capi.OPT_SAMPLES_IN_FLIGHT, 8)
-    # RT_OPT_PATH_STATE_LIMIT_MB on every eleventh seed (round 6; keyed by the seed): 1 MB of path state -- a tile of more than 4096 pixels is then rendered in chunks
-    # (rt_integrate: one after the other; the stage calls: every chunk on a pipe of its own), and batches of 8 samples in flight take the compact log on their own
-    if seed % 11 == 7:
-        fr.set_option(capi.OPT_PATH_STATE_LIMIT_MB, 1)
     # k_trace_w4's loop D (round 4): the instance that has it for every launch / none, and when it takes over a wave's last lanes
     fr.set_option(capi.OPT_TRACE_TAIL_PATHS, (4000000000, 0, 50000000)[seed % 3])
     fr.set_option(capi.OPT_TRACE_TAIL_LANES, (40, 1, 64, 16, 0)[(seed // 3) % 5])
@@ -184,6 +180,10 @@ def test_random_scene_matches_oracle_bit_for_bit(ctx, env_map, seed):
                 fr.intersect(bounce); fr.shade(bounce); fr.intersect_shadow(bounce)
             fr.advance_sample()
     else:
+        # RT_OPT_PATH_STATE_LIMIT_MB on every eleventh of these seeds (round 6): 1 MB of path state -- a tile of more than 4096 pixels is then rendered in chunks, one
+        # after the other, and batches of 8 samples in flight take the compact log on their own (the stage calls refuse a limit below one sample of the whole tile)
+        if seed % 11 == 7:
+            fr.set_option(capi.OPT_PATH_STATE_LIMIT_MB, 1)
         fr.integrate(spp)
     orc = _oracle.Oracle(w, h, sc, furnace=furnace)
     orc.set_camera(cam); orc.set_max_bounces(bounces)
