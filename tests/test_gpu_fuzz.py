@@ -141,23 +141,27 @@ def test_random_scene_matches_oracle_bit_for_bit(ctx, env_map, seed):
         ctx.set_adaptive_fold(capi.ADAPTIVE_FOLD_DEFAULT)
     fr = capi.Frame(ctx, w, h)
     fr.set_camera(cam); fr.set_max_bounces(bounces)
-    fr.set_option(capi.OPT_WHITE_FURNACE, int(furnace))
-    fr.set_option(capi.OPT_SAMPLER, int(blue))
-    fr.set_option(capi.OPT_SAMPLES_IN_FLIGHT, int(rng.integers(0, 5)))
+    applied = []                                                       # (the frame's options, for the tiles of the seeds that render in tiles)
+    def opt(o, v):
+        applied.append((o, v))
+        fr.set_option(o, v)
+    opt(capi.OPT_WHITE_FURNACE, int(furnace))
+    opt(capi.OPT_SAMPLER, int(blue))
+    opt(capi.OPT_SAMPLES_IN_FLIGHT, int(rng.integers(0, 5)))
     variant = int(rng.choice([0, 8, 5, 9, 8, 9, 10, 10, 10, 11]))
-    fr.set_option(capi.OPT_TRACE_VARIANT, int(os.environ.get("RT_FUZZ_VARIANT", variant)))   # a campaign on one kernel
-    fr.set_option(capi.OPT_TRACE_TUNE, int(rng.choice([0, (2 << 24) | (1 << 23), 24 | (4 << 8), 56 | (32 << 8) | (7 << 24), 64 | (1 << 8) | (1 << 23)])))
-    fr.set_option(capi.OPT_SHADE_PARTITION, int(seed & 3))            # bit 0: hits first, bit 1: outputs grouped by octant
+    opt(capi.OPT_TRACE_VARIANT, int(os.environ.get("RT_FUZZ_VARIANT", variant)))   # a campaign on one kernel
+    opt(capi.OPT_TRACE_TUNE, int(rng.choice([0, (2 << 24) | (1 << 23), 24 | (4 << 8), 56 | (32 << 8) | (7 << 24), 64 | (1 << 8) | (1 << 23)])))
+    opt(capi.OPT_SHADE_PARTITION, int(seed & 3))            # bit 0: hits first, bit 1: outputs grouped by octant
     if seed % 3 == 0:                                                  # the compact radiance log, with a pool small enough to run dry now and then
-        fr.set_option(capi.OPT_COMPACT_LOG, 1)
-        fr.set_option(capi.OPT_DEBUG_LOG_POOL_DIV, 8 if seed % 2 else 64)
+        opt(capi.OPT_COMPACT_LOG, 1)
+        opt(capi.OPT_DEBUG_LOG_POOL_DIV, 8 if seed % 2 else 64)
         if seed % 9 == 0:
-            fr.set_option(capi.OPT_SAMPLES_IN_FLIGHT, 8)
+            opt(capi.OPT_SAMPLES_IN_FLIGHT, 8)
     # k_trace_w4's loop D (round 4): the instance that has it for every launch / none, and when it takes over a wave's last lanes
-    fr.set_option(capi.OPT_TRACE_TAIL_PATHS, (4000000000, 0, 50000000)[seed % 3])
-    fr.set_option(capi.OPT_TRACE_TAIL_LANES, (40, 1, 64, 16, 0)[(seed // 3) % 5])
-    fr.set_option(capi.OPT_CHUNK_REFILL, 0 if seed % 4 == 2 else 1)    # chunk mode: round 3's form / lanes refilled from the wave's own chunks
-    fr.set_option(capi.OPT_SMALL_LAUNCH_PATHS, int(rng.choice([3000000, 0, 4000000000, 700])))   # chunk mode below this many rays per launch: default, never, always, for the last bounces
+    opt(capi.OPT_TRACE_TAIL_PATHS, (4000000000, 0, 50000000)[seed % 3])
+    opt(capi.OPT_TRACE_TAIL_LANES, (40, 1, 64, 16, 0)[(seed // 3) % 5])
+    opt(capi.OPT_CHUNK_REFILL, 0 if seed % 4 == 2 else 1)    # chunk mode: round 3's form / lanes refilled from the wave's own chunks
+    opt(capi.OPT_SMALL_LAUNCH_PATHS, int(rng.choice([3000000, 0, 4000000000, 700])))   # chunk mode below this many rays per launch: default, never, always, for the last bounces
     # k_frame (round 5): every fifth seed renders its samples through the stage API with RT_OPT_FRAME_KERNEL (1: every block resident, 2 / 3: that
     # many chunks per wave) -- one launch per sample in which each wave carries its own pixels through all the bounces; where the frame is not
     # eligible (compact log, a forced kernel variant) the same calls take the stage kernels
@@ -183,7 +187,25 @@ def test_random_scene_matches_oracle_bit_for_bit(ctx, env_map, seed):
         # RT_OPT_PATH_STATE_LIMIT_MB on every eleventh of these seeds (round 6): 1 MB of path state -- a tile of more than 4096 pixels is then rendered in chunks, one
         # after the other, and batches of 8 samples in flight take the compact log on their own (the stage calls refuse a limit below one sample of the whole tile)
         if seed % 11 == 7:
-            fr.set_option(capi.OPT_PATH_STATE_LIMIT_MB, 1)
+            opt(capi.OPT_PATH_STATE_LIMIT_MB, 1)
+        # every thirteenth of these seeds renders the frame as 2 - 4 TILES (interleaved bands of 1 / 2 / 4 / 8 rows: rt_frame_desc, the multi-GPU path's
+        # decomposition) with the same options, one frame per tile on this device; the assembled rows and the summed ray counts must be the whole frame's
+        if seed % 13 == 5:
+            tiles, band = 2 + (seed // 13) % 3, (1, 2, 4, 8)[(seed // 39) % 4]
+            tiled = np.zeros((h, w, 3), np.float32)
+            tiled_rays = [0, 0]
+            for rank in range(tiles):
+                t = capi.Frame(ctx, w, h, tile_rank=rank, tile_count=tiles, band_height=band)
+                t.set_camera(cam); t.set_max_bounces(bounces)
+                for o, v in applied:
+                    t.set_option(o, v)
+                t.integrate(spp)
+                rows = t.global_rows()
+                if len(rows):
+                    tiled[rows] = t.radiance()[..., :3]
+                ts = t.stats()
+                tiled_rays[0] += ts.closest_rays; tiled_rays[1] += ts.shadow_rays
+                t.close()
         fr.integrate(spp)
     orc = _oracle.Oracle(w, h, sc, furnace=furnace)
     orc.set_camera(cam); orc.set_max_bounces(bounces)
@@ -196,3 +218,6 @@ def test_random_scene_matches_oracle_bit_for_bit(ctx, env_map, seed):
         assert st.samples_from_banks == spp - 3 and st.samples == spp, (seed, st.samples_from_banks, spp)      # (the banks' ray totals run ahead: rt_stats.samples_ahead)
     else:
         assert (st.closest_rays, st.shadow_rays) == orc.ray_totals()
+    if not ahead and seed % 5 != 2 and seed % 13 == 5:
+        assert np.array_equal(tiled, want, equal_nan=True), (seed, "tiles", np.argwhere(~np.isclose(tiled, want, equal_nan=True))[:4])
+        assert tuple(tiled_rays) == orc.ray_totals(), (seed, "tiles")
