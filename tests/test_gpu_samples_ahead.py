@@ -243,3 +243,100 @@ def test_a_tile_of_an_image(ctx, golden_scenes):
     assert np.array_equal(tiles[0].radiance(), tiles[1].radiance(), equal_nan=True)
     for fr in tiles:
         fr.close()
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("RT_SEQ_FIRST", "0")), int(os.environ.get("RT_SEQ_SEEDS", "16"))))   # RT_SEQ_SEEDS=2000 for a campaign
+def test_random_sequences_of_calls_equal_the_plain_frame(ctx, golden_scenes, seed):
+    """A random walk through the API on two frames at once -- one with batches traced ahead (a random depth, one stream or two), one without: stage samples,
+    rt_integrate of a few samples in between, resets, the same camera set again, another camera with and without a reset, another bounce limit, the other sampler,
+    another depth of the mode, the radiance read after every call and sometimes between a sample's stages.  After EVERY call both frames hold the same image and the
+    same sample count, bit for bit; at the end both are the oracle's for a sequence that ends on a run of plain samples."""
+    rng = np.random.default_rng(77000 + seed)
+    key = ("cornell", "coverage")[seed % 2]
+    sc = golden_scenes[key]
+    w, h = int(rng.integers(16, 72)), int(rng.integers(12, 48))
+    bounces = int(rng.integers(1, 6))
+    cams = [T.default_camera(w, h)]
+    for _ in range(2):
+        c = cams[0].copy()
+        c["position"]["x"] += np.float32(rng.uniform(-0.3, 0.3)); c["position"]["z"] += np.float32(rng.uniform(-0.2, 0.2))
+        cams.append(c)
+    depths = (2, 3, 4, 8, 1, 256 + 2, 256 + 5, 64)
+    ctx.upload_scene(sc)
+    plain = framed(ctx, w, h, cams[0], bounces, 0)
+    fr = framed(ctx, w, h, cams[0], bounces, int(depths[rng.integers(0, len(depths))]))
+    both = (plain, fr)
+    since_reset = []                                                   # what the oracle has to repeat at the end: (camera index, bounces, blue, samples) runs since the last reset
+    cam_i, blue = 0, False
+
+    def same(what):
+        assert fr.sample_count() == plain.sample_count(), (seed, what)
+        assert np.array_equal(fr.radiance(), plain.radiance(), equal_nan=True), (seed, what)
+
+    def note(n):
+        if since_reset and since_reset[-1][:3] == (cam_i, bounces, blue):
+            since_reset[-1] = (cam_i, bounces, blue, since_reset[-1][3] + n)
+        else:
+            since_reset.append((cam_i, bounces, blue, n))
+
+    for step in range(int(rng.integers(12, 40))):
+        op = int(rng.choice([0, 0, 0, 0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 8]))
+        if op == 0:                                                    # one frame the reference's way
+            peek = rng.random() < 0.15
+            for f in both:
+                f.generate_rays()
+                for b in range(bounces + 1):
+                    f.intersect(b); f.shade(b); f.intersect_shadow(b)
+                    if peek and b == bounces // 2:
+                        f.radiance()                                   # a read between two bounces (after the shadow stage: allowed)
+                f.advance_sample()
+            note(1)
+        elif op == 1:                                                  # a few samples in one call
+            k = int(rng.integers(1, 5))
+            for f in both:
+                f.integrate(k)
+            note(k)
+        elif op == 2:
+            for f in both:
+                f.reset()
+            since_reset.clear()
+        elif op == 3:                                                  # the integrator sets the camera before every frame: the same one changes nothing
+            for f in both:
+                f.set_camera(cams[cam_i])
+        elif op == 4:                                                  # another camera, the reference's way (a reset follows)
+            cam_i = int(rng.integers(0, len(cams)))
+            for f in both:
+                f.set_camera(cams[cam_i]); f.reset()
+            since_reset.clear()
+        elif op == 5:                                                  # ... and without a reset: the sum goes on with the new camera's samples
+            cam_i = int(rng.integers(0, len(cams)))
+            for f in both:
+                f.set_camera(cams[cam_i])
+        elif op == 6:
+            bounces = int(rng.integers(1, 6))
+            for f in both:
+                f.set_max_bounces(bounces); f.reset()
+            since_reset.clear()
+        elif op == 7:
+            blue = not blue
+            if blue:
+                ctx.upload_blue_noise_tables(*S.blue_noise_tables())
+            for f in both:
+                f.set_option(capi.OPT_SAMPLER, int(blue)); f.reset()
+            since_reset.clear()
+        else:
+            fr.set_option(capi.OPT_SAMPLES_AHEAD, int(depths[rng.integers(0, len(depths))]))
+        same("step %d op %d" % (step, op))
+    for _ in range(int(rng.integers(0, 7))):                           # a quiet tail: the mode is (or gets) going when the comparison with the oracle is made
+        for f in both:
+            stage_sample(f, bounces)
+        note(1)
+        same("tail")
+    if since_reset and fr.sample_count() <= 48:
+        orc = _oracle.Oracle(w, h, sc)
+        for ci, bb, bl, n in since_reset:
+            orc.set_camera(cams[ci]); orc.set_max_bounces(bb); orc.set_blue_noise(bl, S.blue_noise_tables())
+            orc.integrate(n)
+        assert orc.sample_count() == fr.sample_count(), seed
+        assert np.array_equal(fr.radiance()[..., :3], orc.radiance()[..., :3], equal_nan=True), seed
+    fr.close(); plain.close()
