@@ -250,7 +250,7 @@ def test_random_sequences_of_calls_equal_the_plain_frame(ctx, golden_scenes, see
     """A random walk through the API on two frames at once -- one with batches traced ahead (a random depth, one stream or two), one without: stage samples,
     rt_integrate of a few samples in between, resets, the same camera set again, another camera with and without a reset, another bounce limit, the other sampler,
     another depth of the mode, the radiance read after every call and sometimes between a sample's stages.  After EVERY call both frames hold the same image and the
-    same sample count, bit for bit; at the end both are the oracle's for a sequence that ends on a run of plain samples."""
+    same sample count, bit for bit; where one camera has been in place since the last reset, both are the oracle's at the end."""
     rng = np.random.default_rng(77000 + seed)
     key = ("cornell", "coverage")[seed % 2]
     sc = golden_scenes[key]
@@ -332,11 +332,11 @@ def test_random_sequences_of_calls_equal_the_plain_frame(ctx, golden_scenes, see
             stage_sample(f, bounces)
         note(1)
         same("tail")
-    if since_reset and fr.sample_count() <= 48:
+    if len(since_reset) == 1 and fr.sample_count() <= 48:             # (one camera since the last reset: the oracle's set_camera starts its sum again, like the reference's)
         orc = _oracle.Oracle(w, h, sc)
-        for ci, bb, bl, n in since_reset:
-            orc.set_camera(cams[ci]); orc.set_max_bounces(bb); orc.set_blue_noise(bl, S.blue_noise_tables())
-            orc.integrate(n)
+        ci, bb, bl, n = since_reset[0]
+        orc.set_camera(cams[ci]); orc.set_max_bounces(bb); orc.set_blue_noise(bl, S.blue_noise_tables())
+        orc.integrate(n)
         assert orc.sample_count() == fr.sample_count(), seed
         assert np.array_equal(fr.radiance()[..., :3], orc.radiance()[..., :3], equal_nan=True), seed
     fr.close(); plain.close()
