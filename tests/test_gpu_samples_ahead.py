@@ -247,9 +247,10 @@ def test_a_tile_of_an_image(ctx, golden_scenes):
 
 @pytest.mark.parametrize("seed", range(int(os.environ.get("RT_SEQ_FIRST", "0")), int(os.environ.get("RT_SEQ_SEEDS", "16"))))   # RT_SEQ_SEEDS=2000 for a campaign
 def test_random_sequences_of_calls_equal_the_plain_frame(ctx, golden_scenes, seed):
-    """A random walk through the API on two frames at once -- one with batches traced ahead (a random depth, one stream or two), one without: stage samples,
+    """A random walk through the API on three frames at once -- one with batches traced ahead (a random depth, one stream or two), one whose stage samples go through
+    the one-launch frame kernel (RT_OPT_FRAME_KERNEL 1 / 2 / 3 / the measured choice), one plain: stage samples,
     rt_integrate of a few samples in between, resets, the same camera set again, another camera with and without a reset, another bounce limit, the other sampler,
-    another depth of the mode, the radiance read after every call and sometimes between a sample's stages.  After EVERY call both frames hold the same image and the
+    another depth of the mode, the radiance read after every call and sometimes between a sample's stages.  After EVERY call all three hold the same image and the
     same sample count, bit for bit; where one camera has been in place since the last reset, both are the oracle's at the end."""
     rng = np.random.default_rng(77000 + seed)
     key = ("cornell", "coverage")[seed % 2]
@@ -265,13 +266,17 @@ def test_random_sequences_of_calls_equal_the_plain_frame(ctx, golden_scenes, see
     ctx.upload_scene(sc)
     plain = framed(ctx, w, h, cams[0], bounces, 0)
     fr = framed(ctx, w, h, cams[0], bounces, int(depths[rng.integers(0, len(depths))]))
-    both = (plain, fr)
+    fk = framed(ctx, w, h, cams[0], bounces, 0)                        # a third frame: no samples ahead, its stage samples through the one-launch frame kernel where eligible
+    fk.set_option(capi.OPT_FRAME_KERNEL, int(rng.choice([1, 2, 3, 255])))
+    both = (plain, fr, fk)
     since_reset = []                                                   # what the oracle has to repeat at the end: (camera index, bounces, blue, samples) runs since the last reset
     cam_i, blue = 0, False
 
     def same(what):
-        assert fr.sample_count() == plain.sample_count(), (seed, what)
-        assert np.array_equal(fr.radiance(), plain.radiance(), equal_nan=True), (seed, what)
+        want = plain.radiance()
+        for name, f in (("samples ahead", fr), ("frame kernel", fk)):
+            assert f.sample_count() == plain.sample_count(), (seed, what, name)
+            assert np.array_equal(f.radiance(), want, equal_nan=True), (seed, what, name)
 
     def note(n):
         if since_reset and since_reset[-1][:3] == (cam_i, bounces, blue):
@@ -339,4 +344,4 @@ def test_random_sequences_of_calls_equal_the_plain_frame(ctx, golden_scenes, see
         orc.integrate(n)
         assert orc.sample_count() == fr.sample_count(), seed
         assert np.array_equal(fr.radiance()[..., :3], orc.radiance()[..., :3], equal_nan=True), seed
-    fr.close(); plain.close()
+    fr.close(); plain.close(); fk.close()
