@@ -262,8 +262,26 @@ def test_random_sequences_of_calls_equal_the_plain_frame(ctx, golden_scenes, see
         c = cams[0].copy()
         c["position"]["x"] += np.float32(rng.uniform(-0.3, 0.3)); c["position"]["z"] += np.float32(rng.uniform(-0.2, 0.2))
         cams.append(c)
+    if seed % 3 == 1:                                                  # ... and a camera far enough away to leave the view the folds were adapted to
+        c = cams[0].copy()
+        a = np.float32(0.7)
+        for vec in ("front", "up"):
+            x, y = float(c[vec]["x"]), float(c[vec]["y"])
+            c[vec]["x"], c[vec]["y"] = np.float32(np.cos(a) * x - np.sin(a) * y), np.float32(np.sin(a) * x + np.cos(a) * y)
+        cams.append(c)
     depths = (2, 3, 4, 8, 1, 256 + 2, 256 + 5, 64)
-    ctx.upload_scene(sc)
+    # every third seed: the fold adaptation as the library ships it (asynchronous: probe behind a frame, worker thread, pointer exchange between two calls), on these
+    # small trees too (bit 2), rotations and occluder order included, re-armed without a rate limit -- folds change under all three frames while the walk goes on
+    adaptive = seed % 3 == 1
+    if adaptive:
+        ctx.set_adaptive_fold(1 | 4 | 8 | 16)
+        assert capi.load().rt_ctx_set_option(ctx.handle, 5, 0) == 0      # RT_CTX_OPT_ADAPT_MIN_INTERVAL_MS
+    try:
+        ctx.upload_scene(sc)
+    finally:
+        if adaptive:
+            ctx.set_adaptive_fold(capi.ADAPTIVE_FOLD_DEFAULT)
+            assert capi.load().rt_ctx_set_option(ctx.handle, 5, 500) == 0
     plain = framed(ctx, w, h, cams[0], bounces, 0)
     fr = framed(ctx, w, h, cams[0], bounces, int(depths[rng.integers(0, len(depths))]))
     fk = framed(ctx, w, h, cams[0], bounces, 0)                        # a third frame: no samples ahead, its stage samples through the one-launch frame kernel where eligible
