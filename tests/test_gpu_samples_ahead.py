@@ -28,8 +28,8 @@ def stage_sample(fr, bounces):
     fr.advance_sample()
 
 
-def framed(ctx, w, h, cam, bounces, ahead, furnace=False, blue=False):
-    fr = capi.Frame(ctx, w, h)
+def framed(ctx, w, h, cam, bounces, ahead, furnace=False, blue=False, tile=None):
+    fr = capi.Frame(ctx, w, h) if tile is None else capi.Frame(ctx, w, h, tile_rank=tile[0], tile_count=tile[1], band_height=tile[2])
     fr.set_camera(cam); fr.set_max_bounces(bounces)
     fr.set_option(capi.OPT_WHITE_FURNACE, int(furnace))
     if blue:
@@ -282,19 +282,25 @@ def test_random_sequences_of_calls_equal_the_plain_frame(ctx, golden_scenes, see
         if adaptive:
             ctx.set_adaptive_fold(capi.ADAPTIVE_FOLD_DEFAULT)
             assert capi.load().rt_ctx_set_option(ctx.handle, 5, 500) == 0
-    plain = framed(ctx, w, h, cams[0], bounces, 0)
-    fr = framed(ctx, w, h, cams[0], bounces, int(depths[rng.integers(0, len(depths))]))
-    fk = framed(ctx, w, h, cams[0], bounces, 0)                        # a third frame: no samples ahead, its stage samples through the one-launch frame kernel where eligible
+    # every fourth seed: the three frames are one TILE of the image (rank r of 2 - 4, bands of 1 - 8 rows), the multi-GPU path's decomposition
+    tile = (int(rng.integers(0, 4)) % (2 + seed % 3), 2 + seed % 3, int(rng.choice([1, 2, 4, 8]))) if seed % 4 == 2 else None
+    plain = framed(ctx, w, h, cams[0], bounces, 0, tile=tile)
+    fr = framed(ctx, w, h, cams[0], bounces, int(depths[rng.integers(0, len(depths))]), tile=tile)
+    fk = framed(ctx, w, h, cams[0], bounces, 0, tile=tile)             # a third frame: no samples ahead, its stage samples through the one-launch frame kernel where eligible
     fk.set_option(capi.OPT_FRAME_KERNEL, int(rng.choice([1, 2, 3, 255])))
     both = (plain, fr, fk)
+    denoiser, aov = 0, 0
     since_reset = []                                                   # what the oracle has to repeat at the end: (camera index, bounces, blue, samples) runs since the last reset
     cam_i, blue = 0, False
 
     def same(what):
         want = plain.radiance()
+        shown = plain.resolve() if plain.sample_count() and (tile is None or denoiser == 0) else None
         for name, f in (("samples ahead", fr), ("frame kernel", fk)):
             assert f.sample_count() == plain.sample_count(), (seed, what, name)
             assert np.array_equal(f.radiance(), want, equal_nan=True), (seed, what, name)
+            if shown is not None:                                      # what the reference would show: ResolveRadiance (and the AOV / denoiser when switched on)
+                assert np.array_equal(f.resolve(), shown, equal_nan=True), (seed, what, name, "resolved")
 
     def note(n):
         if since_reset and since_reset[-1][:3] == (cam_i, bounces, blue):
@@ -303,7 +309,7 @@ def test_random_sequences_of_calls_equal_the_plain_frame(ctx, golden_scenes, see
             since_reset.append((cam_i, bounces, blue, n))
 
     for step in range(int(rng.integers(12, 40))):
-        op = int(rng.choice([0, 0, 0, 0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 8]))
+        op = int(rng.choice([0, 0, 0, 0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10]))
         if op == 0:                                                    # one frame the reference's way
             peek = rng.random() < 0.15
             for f in both:
@@ -347,8 +353,18 @@ def test_random_sequences_of_calls_equal_the_plain_frame(ctx, golden_scenes, see
             for f in both:
                 f.set_option(capi.OPT_SAMPLER, int(blue)); f.reset()
             since_reset.clear()
-        else:
+        elif op == 8:
             fr.set_option(capi.OPT_SAMPLES_AHEAD, int(depths[rng.integers(0, len(depths))]))
+        elif op == 9:                                                  # the temporal denoiser on / off (EnableDenoiser -> RequestReset); a tile only collects its inputs (mode 2)
+            denoiser = 0 if denoiser else (1 if tile is None else 2)
+            for f in both:
+                f.set_option(capi.OPT_DENOISER, denoiser); f.reset()
+            since_reset.clear()
+        else:                                                          # another AOV (SetAOV -> RequestReset)
+            aov = int(rng.integers(0, 5))
+            for f in both:
+                f.set_option(capi.OPT_AOV, aov); f.reset()
+            since_reset.clear()
         same("step %d op %d" % (step, op))
     for _ in range(int(rng.integers(0, 7))):                           # a quiet tail: the mode is (or gets) going when the comparison with the oracle is made
         for f in both:
@@ -361,5 +377,6 @@ def test_random_sequences_of_calls_equal_the_plain_frame(ctx, golden_scenes, see
         orc.set_camera(cams[ci]); orc.set_max_bounces(bb); orc.set_blue_noise(bl, S.blue_noise_tables())
         orc.integrate(n)
         assert orc.sample_count() == fr.sample_count(), seed
-        assert np.array_equal(fr.radiance()[..., :3], orc.radiance()[..., :3], equal_nan=True), seed
+        rows = fr.global_rows() if tile is not None else slice(None)
+        assert np.array_equal(fr.radiance()[..., :3], orc.radiance()[..., :3][rows], equal_nan=True), seed
     fr.close(); plain.close(); fk.close()
