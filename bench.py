@@ -448,7 +448,8 @@ def cold_job_leg(args, render, host, capi, lib, torch, setup_breakdown):
     rays = float((c1.closest_rays - c0.closest_rays) + (c1.shadow_rays - c0.shadow_rays))
     upload_s = float(setup_breakdown.get("upload", 0.0))
     out = dict(spp=args.cold_job_spp, upload_s=round(upload_s, 3), samples_in_flight=int(c1.samples_in_flight), path_state_GB=round(c1.path_state_bytes / 2.0**30, 2),
-               render_s=round(t_c - t_r, 3), wall_s=round(upload_s + (t_c - t_r), 3), rays=rays, finite=bool(torch.isfinite(img).all().item()),
+               render_s=round(t_c - t_r, 3), wall_s=round(upload_s + (t_c - t_r), 3), rays=rays,
+               non_finite_pixels=int((~torch.isfinite(img[..., :3]).all(-1)).sum().item()),      # (the reference's own: material.h:79-81 inf * 0 -- config.non_finite_pixels)
                mrays_per_s_render=round(rays / (t_c - t_r) / 1e6, 1), mrays_per_s_wall=round(rays / (upload_s + (t_c - t_r)) / 1e6, 1),
                trees=render.tree_report().strip().split("\n"),
                what="the config's whole job, cold, the first use of the device by this process: Render's own UploadGPUData (rt_scene_upload: re-layout, folds, own tree, tree choice) "
