@@ -387,3 +387,51 @@ def test_random_sequences_of_calls_equal_the_plain_frame(ctx, golden_scenes, see
         rows = fr.global_rows() if tile is not None else slice(None)
         assert np.array_equal(fr.radiance()[..., :3], orc.radiance()[..., :3][rows], equal_nan=True), seed
     fr.close(); plain.close(); fk.close()
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("RT_HOST_SEQ_FIRST", "0")), int(os.environ.get("RT_HOST_SEQ_SEEDS", "6"))))   # RT_HOST_SEQ_SEEDS=300 for a campaign
+def test_random_sequences_through_the_integrator_equal_the_plain_integrator(seed):
+    """The same walk one level up, where the reference's own code would call: two host.Render objects -- the C++ Integrator with HIPPathTraceIntegrator behind its fifteen
+    hooks -- on the same scene, one on the integrator's defaults (samples ahead: automatic; the frame kernel: measured choice), one with both switched off on its frame:
+    RenderFrame(), RenderSamples(k), SetCameraData (the same camera and another: RequestReset), SetMaxBounces, EnableWhiteFurnace, EnableDenoiser, SetAOV in a random
+    order; after every call the same radiance, the same resolved image and the same sample count."""
+    rng = np.random.default_rng(91000 + seed)
+    w, h = int(rng.integers(24, 96)), int(rng.integers(16, 64))
+    renders = []
+    for _ in range(2):
+        scene = host.Scene(os.path.join(ROOT, "assets", "CornellBox.obj"))
+        scene.add_directional_light((-0.6, -1.5, 3.5), (15.0, 10.0, 5.0))
+        renders.append(host.Render(w, h, scene))
+    a, r = renders
+    frame_r = host.load().rth_render_frame_handle(r.handle)
+    lib = capi.load()
+    assert lib.rt_set_option(frame_r, capi.OPT_SAMPLES_AHEAD, 0) == 0 and lib.rt_set_option(frame_r, capi.OPT_FRAME_KERNEL, 0) == 0
+    cams = [host.default_camera(w, h)]
+    for _ in range(2):
+        c = cams[0].copy()
+        c["position"]["x"] += np.float32(rng.uniform(-0.2, 0.2)); c["position"]["z"] += np.float32(rng.uniform(-0.2, 0.2))
+        cams.append(c)
+    bounces = int(rng.integers(1, 6))
+    for x in renders:
+        x.set_camera(cams[0]); x.set_max_bounces(bounces)
+    denoiser, furnace = False, False
+    for step in range(int(rng.integers(10, 36))):
+        op = int(rng.choice([0, 0, 0, 0, 0, 0, 0, 1, 2, 3, 4, 5, 6, 7]))
+        for x in renders:
+            if op == 0: x.render_frame()
+            elif op == 1: x.render_samples(1 + step % 3)
+            elif op == 2: x.set_camera(cams[0])
+            elif op == 3: x.set_camera(cams[1 + step % 2])
+            elif op == 4: x.set_max_bounces(1 + (bounces + step) % 5)
+            elif op == 5: x.enable_white_furnace(not furnace)
+            elif op == 6: x.enable_denoiser(not denoiser)
+            else: x.set_aov(step % 5)
+        if op == 5: furnace = not furnace
+        if op == 6: denoiser = not denoiser
+        for x in renders:
+            x.finish()
+        assert a.sample_count() == r.sample_count(), (seed, step, op)
+        assert np.array_equal(a.radiance(), r.radiance(), equal_nan=True), (seed, step, op)
+        if a.sample_count():
+            assert np.array_equal(a.resolved(), r.resolved(), equal_nan=True), (seed, step, op, "resolved")
+    a.close(); r.close()
