@@ -188,6 +188,9 @@ def test_random_scene_matches_oracle_bit_for_bit(ctx, env_map, seed):
         # after the other, and batches of 8 samples in flight take the compact log on their own (the stage calls refuse a limit below one sample of the whole tile)
         if seed % 11 == 7:
             opt(capi.OPT_PATH_STATE_LIMIT_MB, 1)
+            opt(capi.OPT_PIPELINES, 1 + (seed // 11) % 3)               # ... the chunks on 1 - 3 pipes (streams of their own; more than one: the full log layout)
+        if seed % 11 in (3, 7):
+            opt(capi.OPT_OVERLAP_SHADOW, (seed // 11) % 2)             # the shadow trace of bounce b beside the next bounce (the default) or in line
         # every thirteenth of these seeds renders the frame as 2 - 4 TILES (interleaved bands of 1 / 2 / 4 / 8 rows: rt_frame_desc, the multi-GPU path's
         # decomposition) with the same options, one frame per tile on this device; the assembled rows and the summed ray counts must be the whole frame's
         if seed % 13 == 5:
