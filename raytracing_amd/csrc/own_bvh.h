@@ -36,6 +36,7 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -258,6 +259,82 @@ struct Builder
         return mid;
     }
 
+    // A subtree of at most 768 leaves -- where split() sweeps every border on all three axes -- built from orders sorted ONCE: split() sorts the range three times at
+    // every node, this keeps the three orders of the subtree's leaves (by centroid, then reference leaf: the total order split() sorts by) and partitions them
+    // stably into the two parts at every node, so each node's sweeps see exactly the sequences split() would have sorted.  The same candidates in the same order
+    // with the same arithmetic: the same tree (tools/own_bvh_bench.cpp compares; 55 % of a build's one-thread time were those sorts).  prims[] is not permuted:
+    // which leaf ends where follows from set membership alone.
+    struct Small
+    {
+        uint16_t ord[3][768];              // the subtree's leaves (indices relative to b) in each axis' order; a node owns the same segment [s, s + m) of all three
+        uint16_t tmp[768];
+        uint8_t lower[768];
+        double suffix[768];
+    };
+    void small_node(Small& S, uint32_t b, uint32_t s, uint32_t m, uint32_t pos)
+    {
+        if (m == 1) { write_leaf(pos, prims[b + S.ord[0][s]]); return; }
+        float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (uint32_t i = 0; i < m; ++i) grow(mn, mx, prims[b + S.ord[0][s + i]]);
+        const float NINF = -INFINITY;
+        double best = INFINITY; int best_axis = -1; uint32_t best_at = 0;
+        float cmn[3], cmx[3];
+        for (int a = 0; a < 3; ++a) { cmn[a] = prims[b + S.ord[a][s]].c[a]; cmx[a] = prims[b + S.ord[a][s + m - 1u]].c[a]; }
+        for (int a = 0; a < 3; ++a)
+        {
+            if (!(cmx[a] > cmn[a])) continue;
+            const uint16_t* o = &S.ord[a][s];
+            float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {NINF, NINF, NINF};
+            for (uint32_t i = m; i-- > 1;) { grow(lo, hi, prims[b + o[i]]); S.suffix[i] = metric.of(lo, hi) * (m - i); }
+            for (int q = 0; q < 3; ++q) { lo[q] = INFINITY; hi[q] = NINF; }
+            for (uint32_t i = 1; i < m; ++i)
+            {
+                grow(lo, hi, prims[b + o[i - 1]]);
+                const double c = metric.of(lo, hi) * i + S.suffix[i];
+                if (c < best) { best = c; best_axis = a; best_at = i; }
+            }
+        }
+        uint32_t nl, axis;
+        if (best_axis >= 0)
+        {
+            nl = best_at; axis = (uint32_t)best_axis;
+            for (uint32_t i = 0; i < m; ++i) S.lower[S.ord[best_axis][s + i]] = i < nl ? 1 : 0;
+        }
+        else
+        {
+            // all centroids coincide: halve by reference order (split()'s last resort)
+            for (uint32_t i = 0; i < m; ++i) S.tmp[i] = S.ord[0][s + i];
+            std::sort(S.tmp, S.tmp + m, [&](uint16_t x, uint16_t y) { return prims[b + x].leaf < prims[b + y].leaf; });
+            nl = m / 2u;
+            for (uint32_t i = 0; i < m; ++i) S.lower[S.tmp[i]] = i < nl ? 1 : 0;
+            int a = 0;
+            for (int q = 1; q < 3; ++q) if (cmx[q] - cmn[q] > cmx[a] - cmn[a]) a = q;
+            axis = (uint32_t)a;
+        }
+        for (int a = 0; a < 3; ++a)
+        {
+            uint16_t* o = &S.ord[a][s];
+            uint32_t at = 0, up = 0;
+            for (uint32_t i = 0; i < m; ++i) { if (S.lower[o[i]]) o[at++] = o[i]; else S.tmp[up++] = o[i]; }      // (at <= i: nothing unread is overwritten)
+            for (uint32_t i = 0; i < up; ++i) o[at + i] = S.tmp[i];
+        }
+        write_interior(pos, mn, mx, axis, pos + 2u * nl);
+        small_node(S, b, s, nl, pos + 1u);
+        small_node(S, b, s + nl, m - nl, pos + 2u * nl);
+    }
+    void build_small(uint32_t b, uint32_t e, uint32_t pos)
+    {
+        const uint32_t n = e - b;
+        std::unique_ptr<Small> S(new Small);
+        for (int a = 0; a < 3; ++a)
+        {
+            for (uint32_t i = 0; i < n; ++i) S->ord[a][i] = (uint16_t)i;
+            std::sort(S->ord[a], S->ord[a] + n, [&](uint16_t x, uint16_t y)
+                { const Prim &p = prims[b + x], &q = prims[b + y]; return p.c[a] < q.c[a] || (p.c[a] == q.c[a] && p.leaf < q.leaf); });
+        }
+        small_node(*S, b, 0u, n, pos);
+    }
+
     // the whole subtree over prims[b, e) at pos, on the calling thread
     void build(uint32_t b, uint32_t e, uint32_t pos, std::vector<double>& scratch, std::vector<uint32_t>& order)
     {
@@ -266,6 +343,7 @@ struct Builder
             const uint32_t n = e - b;
             if (n > 4096u && cancelled()) return;                           // (the result is dropped by build())
             if (n == 1) { write_leaf(pos, prims[b]); return; }
+            if (n <= 768u) { build_small(b, e, pos); return; }             // (split() would take its sweep branch for this node and every node below it)
             const uint32_t mid = step(b, e, pos, scratch, order);
             const uint32_t nl = mid - b;
             // recurse into the SMALLER part, iterate on the larger: the positions of both are known (pos + 1 and pos + 2 nl), so the
