@@ -111,9 +111,19 @@ struct OwnTree
     ~OwnTree() { join(); if (d_wide) (void)hipFree(d_wide); }
 };
 
+// What every candidate of one ray population is measured against and with: the proxy rays (an area-weighted pass over all triangles), the leaf of every first
+// triangle, the reference fold's cost -- made by the first choose_tree call and kept for the next (the device-built candidate, then the host-built one).
+struct ChoiceInputs
+{
+    bool valid = false;
+    std::vector<uint32_t> leaf_of_first;
+    std::vector<treesel::ProxyRay> rays;
+    double c_ref = 0.0;
+};
+
 // true: walk the own tree; false: keep the reference topology
 bool choose_tree(const rt_scene_desc* sd, const std::vector<WideNode>& ref_wide, uint32_t ref_entry, bool shadow, uint32_t mode,
-    OwnTree& own, std::string& report)
+    OwnTree& own, std::string& report, ChoiceInputs* kept = nullptr)
 {
     own.join();
     char line[320];
@@ -125,12 +135,22 @@ bool choose_tree(const rt_scene_desc* sd, const std::vector<WideNode>& ref_wide,
         return true;
     }
     const uint32_t nt = sd->num_triangles, nn = sd->num_nodes;
-    std::vector<uint32_t> leaf_of_first(nt, 0u);
-    for (uint32_t i = 0; i < nn; ++i)
-        if ((sd->nodes[i].num_primitives_axis >> 16) != 0 && sd->nodes[i].offset < nt) leaf_of_first[sd->nodes[i].offset] = i;
-    const std::vector<treesel::ProxyRay> rays = treesel::proxy_rays(sd->triangles, nt, sd->lights, sd->num_lights, 8192u, shadow);
+    ChoiceInputs mine;
+    ChoiceInputs& in = kept ? *kept : mine;
+    if (!in.valid)
+    {
+        in.leaf_of_first.assign(nt, 0u);
+        for (uint32_t i = 0; i < nn; ++i)
+            if ((sd->nodes[i].num_primitives_axis >> 16) != 0 && sd->nodes[i].offset < nt) in.leaf_of_first[sd->nodes[i].offset] = i;
+        in.rays = treesel::proxy_rays(sd->triangles, nt, sd->lights, sd->num_lights, 8192u, shadow);
+        if (!in.rays.empty())
+            in.c_ref = treesel::walk_cost((const treesel::Record*)ref_wide.data(), (uint32_t)ref_wide.size(), ref_entry, sd->nodes, in.leaf_of_first.data(), sd->triangles, in.rays, shadow);
+        in.valid = true;
+    }
+    const std::vector<uint32_t>& leaf_of_first = in.leaf_of_first;
+    const std::vector<treesel::ProxyRay>& rays = in.rays;
     if (rays.empty()) { report += shadow ? "shadow tree: no lights, nothing to measure -> reference topology\n" : "closest-hit tree: nothing to measure -> reference topology\n"; return false; }
-    const double c_ref = treesel::walk_cost((const treesel::Record*)ref_wide.data(), (uint32_t)ref_wide.size(), ref_entry, sd->nodes, leaf_of_first.data(), sd->triangles, rays, shadow);
+    const double c_ref = in.c_ref;
     const double c_own = treesel::walk_cost((const treesel::Record*)own.wide.data(), (uint32_t)own.wide.size(), own.entry, sd->nodes, leaf_of_first.data(), sd->triangles, rays, shadow);
     const bool pick = c_own < 0.90 * c_ref;
     snprintf(line, sizeof(line), "%s tree: reference topology %.2f steps per proxy ray, %s %.2f -> %s\n", shadow ? "shadow" : "closest-hit", c_ref, own.name, c_own,

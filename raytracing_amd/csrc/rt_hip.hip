@@ -17,6 +17,7 @@
 #include "rt_hip.h"
 #include "kernels.h"
 #include "own_bvh.h"
+#include "treelet_order.h"
 #include "tree_select.h"
 #include "tree_rotate.h"
 #include <chrono>
@@ -558,42 +559,13 @@ int rt_scene_upload(rt_ctx* ctx, const rt_scene_desc* sd)
             }
         });
 
-    // --- BVH re-layout: LinearBVHNode[] (bvh.cpp:223-245) -> child-pair records
-    // Record order = cache-friendly "treelet" layout: a breadth-first cluster of up to
-    // RT_TREELET_NODES interior nodes is stored contiguously (7 records = 448 B, i.e. the
-    // next three levels below a node share a few cache lines), then the clusters hanging
-    // off it, depth first.  This is a pure permutation of records: traversal decisions and
-    // results do not depend on it.  (RT_TREELET_NODES = 1 gives the reference's DFS order.)
-    std::vector<uint32_t> interior_index(nn, RT_EMPTY_REF);
+    // --- BVH re-layout: LinearBVHNode[] (bvh.cpp:223-245) -> child-pair records, in treelet order (treelet_order.h: a pure permutation of records)
+    std::vector<uint32_t> interior_index;
     uint32_t n_interior = 0;
     {
-        auto is_interior = [&](uint32_t i) { return (sd->nodes[i].num_primitives_axis >> 16) == 0; };
-        const uint32_t kTreelet = ctx->treelet_nodes ? ctx->treelet_nodes : 1u;
-        std::vector<uint32_t> roots, cluster, frontier;
-        if (is_interior(0)) roots.push_back(0);
-        while (!roots.empty())
-        {
-            uint32_t r = roots.back();
-            roots.pop_back();
-            cluster.clear();
-            frontier.clear();
-            cluster.push_back(r);
-            if (n_interior + cluster.size() > nn) return fail(ctx, "rt_scene_upload: the node array is not a tree (cycle)");
-            for (size_t head = 0; head < cluster.size(); ++head)       // BFS inside the treelet
-            {
-                uint32_t n = cluster[head];
-                uint32_t kids[2] = {n + 1, sd->nodes[n].offset};
-                for (uint32_t c : kids)
-                {
-                    if (c >= nn || c <= n) return fail(ctx, "rt_scene_upload: child index outside the node array");
-                    if (!is_interior(c)) continue;
-                    if (cluster.size() < kTreelet) cluster.push_back(c);
-                    else frontier.push_back(c);
-                }
-            }
-            for (uint32_t n : cluster) interior_index[n] = n_interior++;
-            for (size_t k = frontier.size(); k-- > 0;) roots.push_back(frontier[k]);   // first child's cluster next
-        }
+        const int bad = treelet::order(sd->nodes, nn, ctx->treelet_nodes, interior_index, n_interior);
+        if (bad == 1) return fail(ctx, "rt_scene_upload: child index outside the node array");
+        if (bad != 0) return fail(ctx, "rt_scene_upload: the node array is not a tree (cycle)");
     }
     t_layout = lap(t_lap);
     // the records themselves are written on the device (k_relayout_*), below
@@ -758,11 +730,12 @@ int rt_scene_upload(rt_ctx* ctx, const rt_scene_desc* sd)
     t_fold = lap(t_lap) + t_dev_fold;
     // the shadow rays' candidates: the one built on the device is ready first and is measured first; if it wins, the host's build is abandoned
     OwnTree* sh = &own_sh;
+    ChoiceInputs shadow_choice;              // (the proxy rays and the reference fold's cost: measured once for both candidates)
     if (try_device_tree)
     {
         own_sh_dev.join();
         (void)hipSetDevice(ctx->device);
-        if (own_sh_dev.ok && have_wide && n_wide_ref != 0u && choose_tree(sd, wide, w_entry, true, ctx->shadow_tree, own_sh_dev, s.tree_report))
+        if (own_sh_dev.ok && have_wide && n_wide_ref != 0u && choose_tree(sd, wide, w_entry, true, ctx->shadow_tree, own_sh_dev, s.tree_report, &shadow_choice))
         {
             sh = &own_sh_dev;
             own_sh.cancel_build.store(true);
@@ -778,7 +751,7 @@ int rt_scene_upload(rt_ctx* ctx, const rt_scene_desc* sd)
     };
     if (have_wide && n_wide_ref != 0u && may_own && ctx->shadow_tree)
     {
-        have_sh = sh == &own_sh_dev || choose_tree(sd, wide, w_entry, true, ctx->shadow_tree, own_sh, s.tree_report);
+        have_sh = sh == &own_sh_dev || choose_tree(sd, wide, w_entry, true, ctx->shadow_tree, own_sh, s.tree_report, &shadow_choice);
         if (have_sh) adopt_own(*sh, s.wnodes_sh);
     }
     if (have_wide && n_wide_ref != 0u && may_own && ctx->closest_tree)

@@ -44,3 +44,22 @@ def test_the_host_fold_does_not_depend_on_the_thread_count(tmp_path, sanitizer):
     if run.returncode != 0 and "ThreadSanitizer: unexpected memory mapping" in run.stderr:
         pytest.skip("ThreadSanitizer cannot map its shadow in this container")
     assert run.returncode == 0 and "ok: 13 folds identical" in run.stdout, (run.stdout[-500:], run.stderr[-3000:])
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="no g++")
+@pytest.mark.parametrize("sanitizer", ["thread", "address,undefined"])
+def test_the_record_order_does_not_depend_on_the_thread_count(tmp_path, sanitizer):
+    """treelet_order.h (rt_scene_upload's record order of the exact BVH2; round 6: the clusters below depth 4 ordered by a pool): treelet sizes 1 / 3 / 7 / 15 on
+    2 / 5 / 16 threads give the one-thread order; a shared interior child and a child index behind the array are refused on every thread count
+    (tests/native/treelet_order_threads.cpp)."""
+    exe = str(tmp_path / "treelet_order_threads")
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-pthread", "-fsanitize=" + sanitizer, "-fno-sanitize-recover=all", "-I", os.path.join(ROOT, "include"),
+           "-I", os.path.join(ROOT, "raytracing_amd", "csrc"), os.path.join(ROOT, "tests", "native", "treelet_order_threads.cpp"), "-o", exe]
+    build = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    if build.returncode != 0 and "sanitize" in build.stderr:
+        pytest.skip("this g++ has no %s sanitizer runtime: %s" % (sanitizer, build.stderr[-200:]))
+    assert build.returncode == 0, build.stderr[-2000:]
+    run = subprocess.run([exe, "150000"], capture_output=True, text=True, timeout=900, env=dict(os.environ, TSAN_OPTIONS="halt_on_error=1"))
+    if run.returncode != 0 and "ThreadSanitizer: unexpected memory mapping" in run.stderr:
+        pytest.skip("ThreadSanitizer cannot map its shadow in this container")
+    assert run.returncode == 0 and "ok: 14 orders identical" in run.stdout, (run.stdout[-500:], run.stderr[-3000:])
