@@ -26,7 +26,9 @@ inline int order(const rt_bvh_node* nodes, uint32_t nn, uint32_t treelet, std::v
     if (nn == 0) return 0;
     auto is_interior = [&](uint32_t i) { return (nodes[i].num_primitives_axis >> 16) == 0; };
     const uint32_t kTreelet = treelet ? treelet : 1u;
-    const unsigned T = threads ? threads : (nn >= 262144u ? std::max(1u, std::min(std::thread::hardware_concurrency(), 16u)) : 1u);
+    // (a pool from 8 M nodes up: below, the one-thread walk is 0.03 s and the upload's other threads -- the own tree's builders start at the same moment -- are
+    // better served by the cores: 0.050 instead of 0.030 s on the 4.9 M-node headline scene, 0.047 instead of 0.119 s on the 17.5 M-node one, profiles/r06/call50*.log)
+    const unsigned T = threads ? threads : (nn >= 8000000u ? std::max(1u, std::min(std::thread::hardware_concurrency(), 16u)) : 1u);
     struct Met { uint32_t what; bool sub; };
     // the walk from `root`: interior nodes in record order to `list`; with cut != 0, a cluster root at cluster depth `cut` is noted as a subtree instead of being walked
     auto walk = [&](uint32_t root, uint32_t cut, std::vector<uint32_t>* list, std::vector<Met>* met, std::vector<uint32_t>* subs, size_t limit) -> int
