@@ -444,6 +444,9 @@ inline bool build(const rt_bvh_node* nodes, uint32_t nn, const Metric& metric, s
             todo.push_back(n.offset);
             todo.push_back(i + 1);
         }
+        // (the output array -- 2 n - 1 records, value-initialised by one thread whatever is done about it -- is allocated beside the leaves' array and its filling)
+        struct Beside { std::thread th; ~Beside() { if (th.joinable()) th.join(); } } beside;
+        if (leaves.size() >= 65536u) beside.th = std::thread([&B, n = leaves.size()]() { B.out.resize(2u * n - 1u); });
         B.prims.resize(leaves.size());
         std::atomic<bool> finite{true};
         Builder::slices(0u, (uint32_t)leaves.size(), leaves.size() >= 65536u ? B.n_threads : 1u, [&](unsigned, uint32_t sb, uint32_t se)
@@ -468,7 +471,7 @@ inline bool build(const rt_bvh_node* nodes, uint32_t nn, const Metric& metric, s
     const uint32_t np = (uint32_t)B.prims.size();
     if (np < 2) return false;
     const double t_collected = since();
-    B.out.resize((size_t)2 * np - 1);
+    if (B.out.size() != (size_t)2 * np - 1) B.out.resize((size_t)2 * np - 1);
     const double t_allocated = since();
     B.run();
     if (phases) { phases[0] = t_collected; phases[1] = t_allocated - t_collected; phases[2] = since() - t_allocated; }
