@@ -193,7 +193,8 @@ struct Builder
         }
         else
         {
-            // full sweep: every border between two consecutive centroids, all three axes
+            // full sweep: every border between two consecutive centroids, all three axes.  (Since build_small() takes every range of <= 768 leaves this branch is
+            // its specification rather than its code path: build_small() visits the same candidates in the same order from orders sorted once.)
             typedef std::pair<float, uint32_t> Key;                        // (centroid, reference leaf): a total order
             std::vector<Key> keys(n), best_keys;
             std::vector<uint32_t> at(n);                                   // position in prims[] of the k-th key
